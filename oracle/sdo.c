@@ -1,0 +1,966 @@
+/*
+ * oracle/sdo.c -- CPU ORACLE (test infrastructure only; see sdo.h header comment).
+ * "parity unpinned" vs upstream sigutils/suscan; [REF-PINNED] parts follow /root/reference.
+ *
+ * Build: gcc -O2 -std=c11 -ffp-contract=off -mfma -fPIC -shared  (see Makefile)
+ */
+#include "sdo.h"
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+#include <assert.h>
+
+#define SDO_PI 3.14159265358979323846
+
+/* ===================================================================================== */
+/* D. deterministic math primitives (SPEC.md section D)                                  */
+/* ===================================================================================== */
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float    u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* D1: phase (2^32 per turn) -> (cos, sin).  Quadrant reduction to |x| <= pi/4, then the
+ * Cephes sinf/cosf minimax kernels; every operation is listed, all in binary32. */
+void sdo_phasor_u32(uint32_t p, float *c, float *s)
+{
+  uint32_t q = (p + 0x20000000u) >> 30;                 /* nearest quadrant 0..3 */
+  int32_t  r = (int32_t)(p - (q << 30));                /* residual in [-2^29, 2^29) */
+  float x  = (float)r * 1.46291807926715968e-9f;        /* * 2 pi / 2^32 */
+  float z  = x * x;
+  float sp = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  sp = fmaf(sp, z, -1.6666654611e-1f);
+  float sn = fmaf(sp * z, x, x);
+  float cp = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  cp = fmaf(cp, z, 4.166664568298827e-2f);
+  float cs = fmaf(cp * z, z, fmaf(z, -0.5f, 1.0f));
+  switch (q) {
+    case 0:  *c =  cs; *s =  sn; break;
+    case 1:  *c = -sn; *s =  cs; break;
+    case 2:  *c = -cs; *s = -sn; break;
+    default: *c =  sn; *s = -cs; break;
+  }
+}
+
+/* D2: atan2 in radians, Cephes atanf kernel on t = min/max in [0,1]. */
+float sdo_atan2f(float y, float x)
+{
+  float ax = fabsf(x), ay = fabsf(y);
+  float mx = ax > ay ? ax : ay;
+  float mn = ax > ay ? ay : ax;
+  float a;
+  if (mx == 0.0f)
+    return 0.0f;
+  float t  = mn / mx;
+  float y0 = 0.0f;
+  if (t > 0.4142135623730950f) {                        /* tan(pi/8) */
+    y0 = 0.78539816339744830962f;
+    t  = (t - 1.0f) / (t + 1.0f);
+  }
+  float z = t * t;
+  float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+  p = fmaf(p, z, 1.99777106478e-1f);
+  p = fmaf(p, z, -3.33329491539e-1f);
+  a = fmaf(p * z, t, t) + y0;
+  if (ay > ax)  a = 1.57079632679489661923f - a;
+  if (x < 0.0f) a = 3.14159265358979323846f - a;
+  if (y < 0.0f) a = -a;
+  return a;
+}
+
+/* D3: log2 for normal positive x (Cephes logf kernel). */
+float sdo_log2f(float x)
+{
+  uint32_t bits = f2u(x);
+  int32_t  e = (int32_t)(bits >> 23) - 127;
+  float    m = u2f((bits & 0x007FFFFFu) | 0x3F800000u);  /* [1,2) */
+  if (m > 1.41421356237309504880f) { m = m * 0.5f; e = e + 1; }
+  float f = m - 1.0f;
+  float z = f * f;
+  float y = 7.0376836292e-2f;
+  y = fmaf(y, f, -1.1514610310e-1f);
+  y = fmaf(y, f,  1.1676998740e-1f);
+  y = fmaf(y, f, -1.2420140846e-1f);
+  y = fmaf(y, f,  1.4249322787e-1f);
+  y = fmaf(y, f, -1.6668057665e-1f);
+  y = fmaf(y, f,  2.0000714765e-1f);
+  y = fmaf(y, f, -2.4999993993e-1f);
+  y = fmaf(y, f,  3.3333331174e-1f);
+  y = (y * f) * z;
+  y = fmaf(-0.5f, z, y);
+  float ln = f + y;
+  return fmaf(ln, 1.44269504088896341f, (float)e);
+}
+
+/* D4: 2^x, x clamped to [-126, 126] (Cephes expf kernel). */
+float sdo_exp2f(float x)
+{
+  if (x >  126.0f) x =  126.0f;
+  if (x < -126.0f) x = -126.0f;
+  float fl = floorf(x + 0.5f);
+  int32_t n = (int32_t)fl;
+  float t = (x - fl) * 0.693147180559945309417f;
+  float z = t * t;
+  float y = 1.9875691500e-4f;
+  y = fmaf(y, t, 1.3981999507e-3f);
+  y = fmaf(y, t, 8.3334519073e-3f);
+  y = fmaf(y, t, 4.1665795894e-2f);
+  y = fmaf(y, t, 1.6666665459e-1f);
+  y = fmaf(y, t, 5.0000001201e-1f);
+  y = fmaf(y, z, t) + 1.0f;
+  return y * u2f((uint32_t)(n + 127) << 23);
+}
+
+uint32_t sdo_fnor_to_dphase(double fnor)
+{
+  /* normalised frequency fnor = 2 f / fs  ->  turns/sample = fnor / 2 */
+  long long v = llrint(fnor * 2147483648.0);
+  return (uint32_t)(v & 0xFFFFFFFFll);
+}
+
+/* radians -> signed phase step, |d| clamped below pi; truncation toward zero */
+static inline int32_t rad_to_dphase(float d)
+{
+  if (d >  3.1415925f) d =  3.1415925f;
+  if (d < -3.1415925f) d = -3.1415925f;
+  return (int32_t)(d * 683565275.57643158978f);         /* 2^32 / 2 pi */
+}
+
+static inline float phase_to_rad(uint32_t p)
+{
+  return (float)(int32_t)p * 1.46291807926715968e-9f;   /* [-pi, pi) */
+}
+
+/* ===================================================================================== */
+/* A3/A4/A9: reference-owned PSD post-processing  [REF-PINNED]                            */
+/* ===================================================================================== */
+
+/* SU_POWER_DB(p) = 10*log10(p + SUFLOAT_MIN_REF_MAG), SUFLOAT_MIN_REF_MAG = 1e-8
+ * (upstream recollection; SU_LOG is log10 per Suscan/Library.cpp:115-119) */
+static inline float su_power_db(float p)     { return 10.0f * log10f(p + 1e-8f); }
+static inline float su_power_db_raw(float p) { return 10.0f * log10f(p); }
+
+/* Suscan/Messages/PSDMessage.cpp:29-38 */
+void sdo_psd_shift_db(float *psd, size_t n)
+{
+  size_t half = n / 2, i;
+  for (i = 0; i < half; ++i) {
+    float tmp = psd[i + half];
+    psd[i + half] = su_power_db(psd[i]);
+    psd[i] = su_power_db(tmp);
+  }
+}
+
+/* Misc/Averager.cpp:25-50 */
+int sdo_averager_feed(float *last, size_t *bufsiz, const float *x, size_t n, float alpha)
+{
+  int blend = alpha < 1.f;
+  size_t i;
+  if (*bufsiz != n) { *bufsiz = n; blend = 0; }
+  if (blend) {
+    for (i = 0; i < n; ++i)
+      last[i] += alpha * (x[i] - last[i]);
+    return 0;
+  }
+  memcpy(last, x, n * sizeof(float));
+  return 1;
+}
+
+/* Default/GenericInspector/GenericInspector.cpp:231-247 */
+void sdo_inspector_spectrum_db_shift(float *data, size_t len)
+{
+  size_t p = len / 2, i;
+  for (i = 0; i < len; ++i)
+    data[i] = su_power_db_raw(data[i] + 1e-20f);
+  for (i = 0; i < len / 2; ++i) {
+    float x = data[i];
+    data[i] = data[p];
+    data[p] = x;
+    if (++p == len)
+      p = 0;
+  }
+}
+
+/* ===================================================================================== */
+/* A2: windowed FFT power spectrum  [SPEC]                                                */
+/* ===================================================================================== */
+
+void sdo_window(int type, float *w, size_t n)
+{
+  size_t i;
+  double d = (double)(n - 1);
+  for (i = 0; i < n; ++i) {
+    double t = 2.0 * SDO_PI * (double)i / d, v = 1.0;
+    switch (type) {
+      case SDO_WIN_HAMMING: v = 0.54 - 0.46 * cos(t); break;
+      case SDO_WIN_HANN:    v = 0.5 - 0.5 * cos(t); break;
+      case SDO_WIN_FLAT_TOP:
+        v = 0.21557895 - 0.41663158 * cos(t) + 0.277263158 * cos(2 * t)
+          - 0.083578947 * cos(3 * t) + 0.006947368 * cos(4 * t);
+        break;
+      case SDO_WIN_BLACKMANN_HARRIS:
+        v = 0.35875 - 0.48829 * cos(t) + 0.14128 * cos(2 * t) - 0.01168 * cos(3 * t);
+        break;
+      default: v = 1.0;
+    }
+    w[i] = (float)v;
+  }
+}
+
+void sdo_fft_f64(double *re, double *im, size_t n)
+{
+  size_t i, j, len;
+  for (i = 1, j = 0; i < n; ++i) {                      /* bit reversal */
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) {
+      double t = re[i]; re[i] = re[j]; re[j] = t;
+      t = im[i]; im[i] = im[j]; im[j] = t;
+    }
+  }
+  for (len = 2; len <= n; len <<= 1) {
+    size_t half = len >> 1, k;
+    for (i = 0; i < n; i += len) {
+      for (k = 0; k < half; ++k) {
+        double ang = -2.0 * SDO_PI * (double)k / (double)len;
+        double wr = cos(ang), wi = sin(ang);
+        double ur = re[i + k], ui = im[i + k];
+        double vr = re[i + k + half] * wr - im[i + k + half] * wi;
+        double vi = re[i + k + half] * wi + im[i + k + half] * wr;
+        re[i + k] = ur + vr; im[i + k] = ui + vi;
+        re[i + k + half] = ur - vr; im[i + k + half] = ui - vi;
+      }
+    }
+  }
+}
+
+void sdo_psd_frames(const sdo_c32 *x, size_t nframes, size_t n, size_t hop,
+                    const float *window, size_t navg, float scale, float *out)
+{
+  double *re = malloc(sizeof(double) * n), *im = malloc(sizeof(double) * n);
+  double *acc = malloc(sizeof(double) * n);
+  size_t nout = nframes / navg, o, f, i;
+  for (o = 0; o < nout; ++o) {
+    for (i = 0; i < n; ++i) acc[i] = 0;
+    for (f = 0; f < navg; ++f) {
+      const sdo_c32 *fr = x + (o * navg + f) * hop;
+      for (i = 0; i < n; ++i) {
+        /* the window multiply is a binary32 product, as on the device */
+        re[i] = (double)(fr[i].re * window[i]);
+        im[i] = (double)(fr[i].im * window[i]);
+      }
+      sdo_fft_f64(re, im, n);
+      for (i = 0; i < n; ++i) acc[i] += re[i] * re[i] + im[i] * im[i];
+    }
+    for (i = 0; i < n; ++i)
+      out[o * n + i] = (float)(acc[i] * (double)scale / (double)navg);
+  }
+  free(re); free(im); free(acc);
+}
+
+/* ===================================================================================== */
+/* T1/K4: NCO translate  [SPEC]  (sign conventions: Tasks/CarrierXlator.cpp:36-37,57-60)  */
+/* ===================================================================================== */
+
+static inline sdo_c32 cmul_spec(sdo_c32 a, float c, float s)
+{
+  /* (a.re + j a.im)(c + j s): re = a.re*c - a.im*s ; im = a.im*c + a.re*s */
+  sdo_c32 r;
+  r.re = fmaf(-a.im, s, a.re * c);
+  r.im = fmaf( a.im, c, a.re * s);
+  return r;
+}
+
+void sdo_xlate_bulk(const sdo_c32 *x, sdo_c32 *y, size_t len, uint32_t p0, uint32_t dp, uint64_t n0)
+{
+  size_t i;
+  for (i = 0; i < len; ++i) {
+    uint32_t p = p0 + (uint32_t)((n0 + i) * (uint64_t)dp);
+    float c, s;
+    sdo_phasor_u32(p, &c, &s);
+    y[i] = cmul_spec(x[i], c, s);
+  }
+}
+
+/* ===================================================================================== */
+/* K4+K5: translate + decimating low-pass as a complex band-pass polyphase FIR  [SPEC]    */
+/* ===================================================================================== */
+
+void sdo_lpf_design(float *h, size_t ntaps, double fc)
+{
+  /* brick-wall low-pass (cut-off fc, 1 = Nyquist), Hamming window, unit DC gain */
+  double *d = malloc(sizeof(double) * ntaps), sum = 0;
+  size_t i;
+  for (i = 0; i < ntaps; ++i) {
+    double t = (double)i - 0.5 * (double)(ntaps - 1);
+    double a = SDO_PI * fc * t;
+    double sinc = fabs(a) < 1e-12 ? 1.0 : sin(a) / a;
+    double w = ntaps > 1 ? 0.54 - 0.46 * cos(2.0 * SDO_PI * (double)i / (double)(ntaps - 1)) : 1.0;
+    d[i] = fc * sinc * w;
+    sum += d[i];
+  }
+  for (i = 0; i < ntaps; ++i) h[i] = (float)(d[i] / sum);
+  free(d);
+}
+
+void sdo_chan_modulate_taps(const float *h, size_t ntaps, uint32_t dp, sdo_c32 *g)
+{
+  size_t k;
+  for (k = 0; k < ntaps; ++k) {
+    float c, s;
+    sdo_phasor_u32((uint32_t)0 - (uint32_t)k * dp, &c, &s);
+    g[k].re = h[k] * c;
+    g[k].im = h[k] * s;
+  }
+}
+
+size_t sdo_chan_feed(const sdo_c32 *hist, const sdo_c32 *x, size_t len, uint64_t n0,
+                     const sdo_c32 *g, size_t ntaps, uint32_t D, uint32_t p0, uint32_t dp,
+                     sdo_c32 *y)
+{
+  size_t i, k, nout = 0;
+  for (i = 0; i < len; ++i) {
+    uint64_t n = n0 + i;
+    if (n % D) continue;
+    float ar = 0.0f, ai = 0.0f;
+    for (k = 0; k < ntaps; ++k) {
+      /* sample n-k: index i-k into x, or into hist (hist[ntaps-2] is sample n0-1) */
+      sdo_c32 v = (k <= i) ? x[i - k] : hist[(ntaps - 1) - (k - i)];
+      ar = fmaf( g[k].re, v.re, ar);
+      ar = fmaf(-g[k].im, v.im, ar);
+      ai = fmaf( g[k].re, v.im, ai);
+      ai = fmaf( g[k].im, v.re, ai);
+    }
+    float c, s;
+    sdo_phasor_u32(p0 + (uint32_t)(n * (uint64_t)dp), &c, &s);
+    sdo_c32 a = { ar, ai };
+    y[nout++] = cmul_spec(a, c, s);
+  }
+  return nout;
+}
+
+/* ===================================================================================== */
+/* T5/T7/T11 element-wise demodulators                                                    */
+/* ===================================================================================== */
+
+static inline sdo_c32 cmul_conj(sdo_c32 a, sdo_c32 b)    /* a * conj(b) */
+{
+  sdo_c32 r;
+  r.re = fmaf(a.im, b.im, a.re * b.re);
+  r.im = fmaf(a.im, b.re, -(a.re * b.im));
+  return r;
+}
+
+/* Tasks/QuadDemodTask.cpp:44-60: dest[p] = SU_I * (1/pi) * arg(x * conj(prev)) */
+void sdo_quad_demod(const sdo_c32 *x, sdo_c32 *y, size_t len, sdo_c32 prev, int first)
+{
+  const float k = (float)(1. / SDO_PI);
+  size_t p;
+  for (p = 0; p < len; ++p) {
+    if (p < 1 && first) {
+      y[p].re = 0; y[p].im = 0;
+    } else {
+      sdo_c32 d = cmul_conj(x[p], prev);
+      y[p].re = 0.0f;
+      y[p].im = k * sdo_atan2f(d.im, d.re);
+    }
+    prev = x[p];
+  }
+}
+
+/* Tasks/DelayedConjTask.cpp:70-84: the circular delay line holds x[p-delay] */
+void sdo_delayed_conj(const sdo_c32 *x, sdo_c32 *y, size_t len, size_t delay)
+{
+  size_t p;
+  for (p = 0; p < len; ++p) {
+    if (p < delay) {
+      y[p].re = 0; y[p].im = 0;
+    } else {
+      sdo_c32 prev = x[p - delay];
+      float mag  = sqrtf(fmaf(prev.re, prev.re, prev.im * prev.im));
+      float kinv = 1.0f / (mag + 1e-3f);
+      sdo_c32 d = cmul_conj(x[p], prev);
+      y[p].re = kinv * d.re;
+      y[p].im = kinv * d.im;
+    }
+  }
+}
+
+/* Tasks/HistogramFeeder.cpp:45-66 */
+size_t sdo_histogram_feed(const sdo_c32 *x, size_t len, int space, float *out)
+{
+  size_t p, q = 0;
+  switch (space) {
+    case 0:
+      for (p = 0; p < len; ++p)
+        out[q++] = sqrtf(fmaf(x[p].re, x[p].re, x[p].im * x[p].im));
+      break;
+    case 1:
+      for (p = 0; p < len; ++p)
+        out[q++] = sdo_atan2f(x[p].im, x[p].re);
+      break;
+    default:
+      for (p = 0; p < len; ++p)
+        if (p > 0) {
+          sdo_c32 d = cmul_conj(x[p], x[p - 1]);
+          out[q++] = sdo_atan2f(d.im, d.re);
+        }
+  }
+  return q;
+}
+
+/* ===================================================================================== */
+/* IIR helper + Butterworth design                                                        */
+/* ===================================================================================== */
+
+void sdo_butter_lp(int order, double fc, float *b, float *a)
+{
+  /* analog Butterworth prototype, pre-warped, bilinear transform (T = 2).
+   * poles p_i = wc * exp(j pi (2i + n + 1) / (2n)); digital pole z_i = (1 + p_i)/(1 - p_i) */
+  double wc = tan(0.5 * SDO_PI * fc);
+  double ar[SDO_IIR_MAX_ORDER + 1] = { 1 }, ai[SDO_IIR_MAX_ORDER + 1] = { 0 };
+  int i, k, n = order;
+  assert(order >= 0 && order <= SDO_IIR_MAX_ORDER);
+  for (i = 0; i < n; ++i) {
+    double th = SDO_PI * (2.0 * i + n + 1.0) / (2.0 * n);
+    double pr = wc * cos(th), pi = wc * sin(th);
+    /* z = (1 + p) / (1 - p) */
+    double dr = 1.0 - pr, di = -pi, nr = 1.0 + pr, ni = pi;
+    double den = dr * dr + di * di;
+    double zr = (nr * dr + ni * di) / den, zi = (ni * dr - nr * di) / den;
+    /* poly *= (1 - z q) with q = z^-1 */
+    for (k = i + 1; k >= 1; --k) {
+      double tr = ar[k] - (zr * ar[k - 1] - zi * ai[k - 1]);
+      double ti = ai[k] - (zr * ai[k - 1] + zi * ar[k - 1]);
+      ar[k] = tr; ai[k] = ti;
+    }
+  }
+  /* numerator (1 + q)^n scaled to unit DC gain */
+  double bn[SDO_IIR_MAX_ORDER + 1] = { 1 }, sa = 0, sb = 0;
+  for (i = 0; i < n; ++i)
+    for (k = i + 1; k >= 1; --k)
+      bn[k] += bn[k - 1];
+  for (k = 0; k <= n; ++k) { sa += ar[k]; sb += bn[k]; }
+  for (k = 0; k <= SDO_IIR_MAX_ORDER; ++k) { b[k] = 0; a[k] = 0; }
+  for (k = 0; k <= n; ++k) {
+    b[k] = (float)(bn[k] * sa / sb);
+    a[k] = (float)ar[k];
+  }
+}
+
+static inline sdo_c32 iir_feed(sdo_iir *f, sdo_c32 x)
+{
+  /* direct form I; the history part is summed first so that the new sample enters last */
+  float tr = 0.0f, ti = 0.0f;
+  int i;
+  sdo_c32 y;
+  for (i = f->order; i >= 1; --i) {
+    tr = fmaf(f->b[i], f->xh[i].re, tr);
+    ti = fmaf(f->b[i], f->xh[i].im, ti);
+  }
+  for (i = f->order; i >= 1; --i) {
+    tr = fmaf(-f->a[i], f->yh[i].re, tr);
+    ti = fmaf(-f->a[i], f->yh[i].im, ti);
+  }
+  y.re = fmaf(f->b[0], x.re, tr);
+  y.im = fmaf(f->b[0], x.im, ti);
+  for (i = f->order; i >= 2; --i) { f->xh[i] = f->xh[i - 1]; f->yh[i] = f->yh[i - 1]; }
+  if (f->order >= 1) { f->xh[1] = x; f->yh[1] = y; }
+  return y;
+}
+
+/* ===================================================================================== */
+/* K6: Costas loop [SPEC] (init: Tasks/CostasRecoveryTask.cpp:36-41; feed: :58-61)         */
+/* ===================================================================================== */
+
+int sdo_costas_init(sdo_costas *c, int kind, float fhint, float arm_bw, unsigned arm_order, float loop_bw)
+{
+  memset(c, 0, sizeof *c);
+  if (kind < SDO_COSTAS_BPSK || kind > SDO_COSTAS_8PSK) return 0;
+  if (arm_order == 0) arm_order = 1;
+  if (arm_order - 1 > SDO_IIR_MAX_ORDER) return 0;
+  c->kind  = kind;
+  c->a     = (float)(SDO_PI * (double)loop_bw);          /* SU_NORM2ANG_FREQ(loop_bw) */
+  c->b     = 0.5f * c->a * c->a;
+  c->gain  = 1.0f;
+  c->omega = (float)(SDO_PI * (double)fhint);
+  c->phase = 0;
+  c->af.order = (int)arm_order - 1;
+  sdo_butter_lp(c->af.order, (double)arm_bw, c->af.b, c->af.a);
+  return 1;
+}
+
+static inline float sgnf(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+sdo_c32 sdo_costas_feed(sdo_costas *c, sdo_c32 x)
+{
+  float cs, sn, e;
+  sdo_c32 m, z;
+  sdo_phasor_u32(c->phase, &cs, &sn);
+  /* mix: x * conj(ref) */
+  m.re = fmaf(x.im, sn, x.re * cs);
+  m.im = fmaf(x.im, cs, -(x.re * sn));
+  z = iir_feed(&c->af, m);
+  z.re = c->gain * z.re;
+  z.im = c->gain * z.im;
+  switch (c->kind) {
+    case SDO_COSTAS_BPSK:
+      e = z.re * z.im;
+      break;
+    case SDO_COSTAS_QPSK:
+      e = sgnf(z.re) * z.im - sgnf(z.im) * z.re;
+      break;
+    default: /* 8PSK */
+      if (fabsf(z.re) >= fabsf(z.im))
+        e = sgnf(z.re) * z.im - (sgnf(z.im) * z.re) * 0.41421356237309504880f;
+      else
+        e = (sgnf(z.re) * z.im) * 0.41421356237309504880f - sgnf(z.im) * z.re;
+  }
+  /* phi[n+1] = phi[n] + omega[n] + a e ;  omega[n+1] = omega[n] + b e */
+  float dphi = fmaf(c->a, e, c->omega);
+  c->omega   = fmaf(c->b, e, c->omega);
+  c->phase  += (uint32_t)rad_to_dphase(dphi);
+  return z;
+}
+
+void sdo_costas_feed_bulk(sdo_costas *c, const sdo_c32 *x, sdo_c32 *y, size_t len)
+{
+  size_t i;
+  for (i = 0; i < len; ++i) y[i] = sdo_costas_feed(c, x[i]);
+}
+
+/* ===================================================================================== */
+/* K7: PLL [SPEC] (init: Tasks/PLLSyncTask.cpp:36; track: :53-56)                          */
+/* ===================================================================================== */
+
+int sdo_pll_init(sdo_pll *p, float fhint, float fc)
+{
+  double w = SDO_PI * (double)fc;
+  double dinv = 1.0 / (1.0 + 2.0 * 0.707 * w + w * w);
+  memset(p, 0, sizeof *p);
+  p->alpha = (float)(4.0 * w * w * dinv);
+  p->beta  = (float)(4.0 * 0.707 * w * dinv);
+  p->omega = (float)(SDO_PI * (double)fhint);
+  return 1;
+}
+
+sdo_c32 sdo_pll_track(sdo_pll *p, sdo_c32 x)
+{
+  float cs, sn;
+  sdo_c32 m;
+  sdo_phasor_u32(p->phase, &cs, &sn);
+  m.re = fmaf(x.im, sn, x.re * cs);
+  m.im = fmaf(x.im, cs, -(x.re * sn));
+  float err = sdo_atan2f(x.im, x.re) - phase_to_rad(p->phase);
+  if (err >  3.14159265358979323846f) err -= 6.28318530717958647692f;
+  if (err < -3.14159265358979323846f) err += 6.28318530717958647692f;
+  float dphi = fmaf(p->beta, err, p->omega);
+  p->omega   = fmaf(p->alpha, err, p->omega);
+  p->phase  += (uint32_t)rad_to_dphase(dphi);
+  return m;
+}
+
+void sdo_pll_track_bulk(sdo_pll *p, const sdo_c32 *x, sdo_c32 *y, size_t len)
+{
+  size_t i;
+  for (i = 0; i < len; ++i) y[i] = sdo_pll_track(p, x[i]);
+}
+
+/* ===================================================================================== */
+/* K8: Gardner clock recovery [SPEC] (Tasks/WaveSampler.cpp:60-65, :177-213)               */
+/* ===================================================================================== */
+
+int sdo_clock_init(sdo_clock *cd, float loop_gain, float bhint)
+{
+  memset(cd, 0, sizeof *cd);
+  if (!(bhint > 0.0f)) return -1;
+  cd->alpha = 2e-1f;                                     /* SU_PREFERED_CLOCK_ALPHA */
+  cd->beta  = 1.2e-4f;                                   /* SU_PREFERED_CLOCK_BETA  */
+  cd->gain  = loop_gain;
+  cd->phi   = 0.25f;
+  cd->bnor  = bhint;
+  cd->bmin  = 0.5f * bhint;
+  cd->bmax  = bhint > 0.5f ? 1.0f : 2.0f * bhint;
+  return 0;
+}
+
+size_t sdo_clock_feed_bulk(sdo_clock *cd, const sdo_c32 *x, size_t len, sdo_c32 *out)
+{
+  size_t i, n = 0;
+  for (i = 0; i < len; ++i) {
+    sdo_c32 v = x[i];
+    cd->phi = cd->phi + cd->bnor;
+    if (cd->phi >= 0.5f) {
+      /* the half-symbol instant fell mu samples before v, 0 <= mu < 1 */
+      float mu = (cd->phi - 0.5f) / cd->bnor;
+      sdo_c32 p;
+      p.re = fmaf(mu, cd->prev.re - v.re, v.re);
+      p.im = fmaf(mu, cd->prev.im - v.im, v.im);
+      cd->phi = cd->phi - 0.5f;
+      cd->halfcycle = !cd->halfcycle;
+      if (!cd->halfcycle) {
+        cd->x2 = cd->x0;
+        cd->x0 = p;
+        float dr = cd->x0.re - cd->x2.re, di = cd->x0.im - cd->x2.im;
+        float e  = cd->gain * fmaf(cd->x1.im, di, cd->x1.re * dr);
+        cd->phi  = fmaf(cd->alpha, e, cd->phi);
+        float b  = fmaf(cd->beta, e, cd->bnor);
+        if (b < cd->bmin) b = cd->bmin;
+        if (b > cd->bmax) b = cd->bmax;
+        cd->bnor = b;
+        out[n++] = p;
+      } else {
+        cd->x1 = p;
+      }
+    }
+    cd->prev = v;
+  }
+  return n;
+}
+
+/* ===================================================================================== */
+/* K9: AGC [SPEC] (Tasks/AGCTask.cpp:22-28,41-53,70-73)                                    */
+/* ===================================================================================== */
+
+const sdo_agc_params sdo_agc_params_default = { -100.f, 6.f, 100, 20, 20, 2.f, 4.f, 20.f, 40.f };
+
+void sdo_agc_params_from_tau(sdo_agc_params *p, float tau)
+{
+  /* Tasks/AGCTask.cpp:22-28,43-47: DELAY_LINE_FRAC / MAG_HISTORY_FRAC are defined but
+   * never applied, so the INITIALIZER's delay-line and history sizes stay */
+  const double rise = 2 * 3.9062e-1;
+  *p = sdo_agc_params_default;
+  p->fast_rise_t = (float)(tau * rise);
+  p->fast_fall_t = (float)(tau * 2 * rise);
+  p->slow_rise_t = (float)(tau * 10 * rise);
+  p->slow_fall_t = (float)(tau * 10 * 2 * rise);
+  p->hang_max    = (unsigned)(tau * rise * 5);
+}
+
+int sdo_agc_init(sdo_agc *agc, const sdo_agc_params *p)
+{
+  memset(agc, 0, sizeof *agc);
+  if (p->delay_line_size == 0 || p->delay_line_size > SDO_AGC_MAX_HIST) return 0;
+  if (p->mag_history_size == 0 || p->mag_history_size > SDO_AGC_MAX_HIST) return 0;
+  agc->knee        = p->threshold;
+  agc->gain_slope  = p->slope_factor * 1e-2f;
+  agc->fixed_gain  = 0;
+  agc->hang_max    = p->hang_max;
+  agc->delay_line_size  = p->delay_line_size;
+  agc->mag_history_size = p->mag_history_size;
+  agc->fast_alpha_rise = (float)(1.0 - exp(-1.0 / (double)p->fast_rise_t));
+  agc->fast_alpha_fall = (float)(1.0 - exp(-1.0 / (double)p->fast_fall_t));
+  agc->slow_alpha_rise = (float)(1.0 - exp(-1.0 / (double)p->slow_rise_t));
+  agc->slow_alpha_fall = (float)(1.0 - exp(-1.0 / (double)p->slow_fall_t));
+  return 1;
+}
+
+sdo_c32 sdo_agc_feed(sdo_agc *agc, sdo_c32 x)
+{
+  unsigned i;
+  sdo_c32 xd = agc->delay_line[agc->delay_ptr];
+  agc->delay_line[agc->delay_ptr] = x;
+  if (++agc->delay_ptr == agc->delay_line_size) agc->delay_ptr = 0;
+
+  /* magnitude in dB: 10 log10(|x|^2 + 1e-8) */
+  float pw   = fmaf(x.re, x.re, x.im * x.im) + 1e-8f;
+  float x_db = 3.01029995663981195f * sdo_log2f(pw);
+  float x_db_old = agc->mag_history[agc->hist_ptr];
+  agc->mag_history[agc->hist_ptr] = x_db;
+  if (++agc->hist_ptr == agc->mag_history_size) agc->hist_ptr = 0;
+
+  if (agc->peak < x_db) {
+    agc->peak = x_db;
+  } else if (agc->peak == x_db_old) {
+    float pk = -160.0f;                                  /* SUFLOAT_MIN_REF_DB */
+    for (i = 0; i < agc->mag_history_size; ++i)
+      if (pk < agc->mag_history[i]) pk = agc->mag_history[i];
+    agc->peak = pk;
+  }
+
+  float d = agc->peak - agc->fast_level;
+  agc->fast_level = fmaf(d > 0.0f ? agc->fast_alpha_rise : agc->fast_alpha_fall, d, agc->fast_level);
+
+  d = agc->peak - agc->slow_level;
+  if (d > 0.0f) {
+    agc->slow_level = fmaf(agc->slow_alpha_rise, d, agc->slow_level);
+    agc->hang_n = 0;
+  } else if (agc->hang_n >= agc->hang_max) {
+    agc->slow_level = fmaf(agc->slow_alpha_fall, d, agc->slow_level);
+  } else {
+    ++agc->hang_n;
+  }
+
+  float lvl  = agc->fast_level > agc->slow_level ? agc->fast_level : agc->slow_level;
+  if (lvl < agc->knee) lvl = agc->knee;
+  float g_db = lvl * (agc->gain_slope - 1.0f);
+  float g    = sdo_exp2f(g_db * 0.166096404744368117f) * 0.7f;   /* 10^(g_db/20) * SU_AGC_RESCALE */
+  sdo_c32 y = { xd.re * g, xd.im * g };
+  return y;
+}
+
+void sdo_agc_feed_bulk(sdo_agc *agc, const sdo_c32 *x, sdo_c32 *y, size_t len)
+{
+  size_t i;
+  for (i = 0; i < len; ++i) y[i] = sdo_agc_feed(agc, x[i]);
+}
+
+/* ===================================================================================== */
+/* T8: WaveSampler manual mode [REF-PINNED]  Tasks/WaveSampler.cpp:45-51, :96-175          */
+/* ===================================================================================== */
+
+void sdo_sample_manual(const sdo_c32 *data, size_t length, double symbol_count,
+                       double symbol_sync, int space, sdo_c32 *out, size_t nout)
+{
+  double delta = (double)length / symbol_count;          /* :45 */
+  double sampOffset = symbol_sync / delta;               /* :46 */
+  float deltaInv = 1.f / (float)delta;                   /* :106 */
+  sdo_c32 prev = { 0, 0 }, x = { 0, 0 };
+  long p;
+  for (p = 0; p < (long)nout; ++p) {
+    double start = ((double)p - sampOffset) * delta + symbol_sync;   /* :115 */
+    double end = start + delta;
+    float ar = 0, ai = 0;
+    long long iStart = (long long)floor(start);
+    long long iEnd   = (long long)ceil(end);
+    float tStart = (float)(1 - (start - (double)iStart));
+    float tEnd   = (float)(1 - ((double)iEnd - end));
+    long long i;
+    for (i = iStart; i <= iEnd; ++i) {
+      if (i >= 0 && i < (long long)length) {
+        if (i == iStart)      { x.re = tStart * data[i].re; x.im = tStart * data[i].im; }
+        else if (i == iEnd)   { x.re = tEnd * data[i].re;   x.im = tEnd * data[i].im; }
+        else                  x = data[i];
+      } else {
+        x.re = 0; x.im = 0;
+      }
+      if (space == 0) {                                  /* AMPLITUDE: avg += x conj(x) */
+        ar = ar + fmaf(x.im, x.im, x.re * x.re);
+      } else {                                           /* PHASE / FREQUENCY: x conj(prev) */
+        sdo_c32 d = cmul_conj(x, prev);
+        ar = ar + d.re; ai = ai + d.im;
+      }
+      prev = x;
+    }
+    if (space == 0) { out[p].re = sqrtf(deltaInv * ar); out[p].im = 0; }
+    else            { out[p].re = deltaInv * ar; out[p].im = deltaInv * ai; }
+  }
+}
+
+/* ===================================================================================== */
+/* T9: carrier centroid [REF-PINNED structure] Tasks/CarrierDetector.cpp:80-143            */
+/* ===================================================================================== */
+
+void sdo_blackmann_harris_complex(sdo_c32 *h, size_t n)
+{
+  size_t i;
+  for (i = 0; i < n; ++i) {
+    double t = 2.0 * SDO_PI * (double)i / (double)(n - 1);
+    float w = (float)(0.35875 - 0.48829 * cos(t) + 0.14128 * cos(2 * t) - 0.01168 * cos(3 * t));
+    h[i].re *= w; h[i].im *= w;
+  }
+}
+
+float sdo_carrier_detect(const sdo_c32 *data, size_t len, float avgRelBw, float dcNotchRelBw)
+{
+  size_t alloc = 1, k;
+  while (alloc < len) alloc <<= 1;
+  sdo_c32 *buf = calloc(alloc, sizeof *buf);
+  double *re = malloc(sizeof(double) * alloc), *im = malloc(sizeof(double) * alloc);
+  memcpy(buf, data, len * sizeof *buf);
+  sdo_blackmann_harris_complex(buf, len);
+  for (k = 0; k < alloc; ++k) { re[k] = buf[k].re; im[k] = buf[k].im; }
+  sdo_fft_f64(re, im, alloc);
+  for (k = 0; k < alloc; ++k) { buf[k].re = (float)re[k]; buf[k].im = (float)im[k]; }
+
+  int i, maxNdx = 0;
+  int bins = (int)((double)alloc * (double)avgRelBw) + 1;
+  int delta = (bins - 1) / 2, start;
+  int skipLen = (int)(.5 * (double)dcNotchRelBw * (double)alloc);
+  float maxVal = 0, psd;
+  double accr = 0, acci = 0;
+  for (i = skipLen; i < (int)alloc - skipLen; ++i) {
+    buf[i].re = fmaf(buf[i].re, buf[i].re, buf[i].im * buf[i].im);
+    buf[i].im = 0;
+    psd = buf[i].re;
+    if (psd > maxVal) { maxVal = psd; maxNdx = i; }
+  }
+  start = maxNdx - delta;
+  for (i = 0; i < bins; ++i) {
+    int j = i + start;
+    if (j < 0) j += (int)alloc;
+    j %= (int)alloc;
+    psd = buf[j].re;
+    float nFreq = 2.f * (float)j / (float)alloc;
+    double ang = (double)((float)SDO_PI * nFreq);
+    accr += (double)psd * cos(ang);
+    acci += (double)psd * sin(ang);
+  }
+  float peak = (float)atan2(acci, accr);
+  free(buf); free(re); free(im);
+  return peak;
+}
+
+/* ===================================================================================== */
+/* P2/P3: SpectrumView [REF-PINNED] Panoramic/Scanner.cpp:27-293                           */
+/* ===================================================================================== */
+
+#define SCN_DEFAULT_BIN_VALUE -200.0f
+#define SCN_FREQ_RESOLUTION   1000.0
+#define SCN_COUNT_MAX         5.0f
+#define SCN_COUNT_RESET       1.0f
+
+static unsigned next_pow2(unsigned n) { unsigned i = 1; while (i < n) i <<= 1; return i; }
+
+static void specview_reset(sdo_specview *v)
+{
+  memset(v->psd, 0, SDO_SCANNER_SPECTRUM_SIZE * sizeof(float));
+  memset(v->psdAccum, 0, SDO_SCANNER_SPECTRUM_SIZE * sizeof(float));
+  memset(v->psdCount, 0, SDO_SCANNER_SPECTRUM_SIZE * sizeof(float));
+}
+
+void sdo_specview_init(sdo_specview *v, float *psd, float *accum, float *count)
+{
+  memset(v, 0, sizeof *v);
+  v->spectrumSize = SDO_SCANNER_SPECTRUM_SIZE;
+  v->fftRelBw = .5f;
+  v->psd = psd; v->psdAccum = accum; v->psdCount = count;
+  specview_reset(v);
+}
+
+void sdo_specview_set_range(sdo_specview *v, double fmin, double fmax)
+{
+  v->freqMin = fmin; v->freqMax = fmax; v->freqRange = fmax - fmin;
+  v->spectrumSize = next_pow2((unsigned)(v->freqRange / SCN_FREQ_RESOLUTION));
+  if (v->spectrumSize > SDO_SCANNER_SPECTRUM_SIZE)
+    v->spectrumSize = SDO_SCANNER_SPECTRUM_SIZE;
+  specview_reset(v);
+}
+
+void sdo_specview_interpolate(sdo_specview *v)
+{
+  unsigned i, j, count = 1, zero_pos = 0;
+  float t = 0, left = SCN_DEFAULT_BIN_VALUE, right = SCN_DEFAULT_BIN_VALUE;
+  int first = 1, inGap = 0;
+  for (i = 0; i < v->spectrumSize; ++i) {
+    if (!inGap) {
+      if (v->psdCount[i] <= .5f) {
+        inGap = 1; zero_pos = i; count = 1;
+        first = i == 0;
+        if (!first) left = v->psd[i - 1];
+      } else {
+        v->psd[i] = v->psdAccum[i] / v->psdCount[i];
+        if (v->psdCount[i] > SCN_COUNT_MAX) {
+          v->psdCount[i] = SCN_COUNT_RESET;
+          v->psdAccum[i] = v->psd[i] * SCN_COUNT_RESET;
+        }
+      }
+    } else {
+      if (v->psdCount[i] <= .5f) {
+        ++count;
+      } else {
+        inGap = 0;
+        right = v->psd[i] = v->psdAccum[i] / v->psdCount[i];
+        if (first) {
+          for (j = 0; j < count; ++j) v->psd[j + zero_pos] = right;
+        } else {
+          for (j = 0; j < count; ++j) {
+            t = (float)(j + .5f) / count;
+            v->psd[j + zero_pos] = (1 - t) * left + t * right;
+          }
+        }
+      }
+    }
+  }
+  if (inGap)
+    for (j = 0; j < count; ++j) v->psd[j + zero_pos] = left;
+}
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static void specview_feed_linear(sdo_specview *v, const float *psdData, const float *countData,
+                                 size_t psdSize, double freqMin, double freqMax, int adjustSides)
+{
+  double inpBw, bw, freqSkip, fftCount, bins, pos, delta, srcBinW, dstBinW;
+  int skip, j, k;
+  inpBw = freqMax - freqMin;
+  skip = adjustSides ? (int)(.5f * (1 - v->fftRelBw) * psdSize) : 0;
+  freqSkip = (double)skip / psdSize * inpBw;
+  bw = inpBw - 2 * freqSkip;
+  fftCount = v->freqRange / bw;
+  bins = v->spectrumSize / fftCount;
+  srcBinW = inpBw / psdSize;
+  dstBinW = v->freqRange / v->spectrumSize;
+  delta = dstBinW / srcBinW;
+  pos = (freqSkip + freqMin - v->freqMin) / v->freqRange;
+  pos *= v->spectrumSize;
+  j = pos > 0 ? (int)pos : 0;
+  k = pos + bins < v->spectrumSize ? (int)(pos + bins) : (int)v->spectrumSize;
+  while (j < k) {
+    double freqJ = v->freqMin + dstBinW * j;
+    double srcBin = (freqJ - freqMin) / srcBinW;
+    int startBin = (int)srcBin, endBin = (int)(srcBin + delta), i;
+    float psdAccum = 0, psdCount = 0;
+    startBin = clampi(startBin, 0, (int)(psdSize - 1));
+    endBin = clampi(endBin, startBin + 1, (int)psdSize);
+    for (i = startBin; i < endBin; i++) {
+      psdAccum += psdData[i];
+      psdCount += countData != NULL ? countData[i] : 1;
+    }
+    if (psdCount > 0) {
+      v->psdAccum[j] += psdAccum / psdCount;
+      v->psdCount[j] += 1;
+    }
+    j++;
+  }
+}
+
+static void specview_feed_histogram(sdo_specview *v, const float *psdData, size_t psdSize,
+                                    double freqMin, double freqMax)
+{
+  double relBw = (freqMax - freqMin) / v->freqRange;
+  double fStart = (freqMin - v->freqMin) / v->freqRange;
+  double fEnd = (freqMax - v->freqMin) / v->freqRange;
+  float t, inv = (float)(1. / psdSize), accum = 0;
+  unsigned i, j;
+  fStart *= v->spectrumSize; fEnd *= v->spectrumSize; relBw *= v->spectrumSize;
+  j = (unsigned)fStart;
+  if (j > v->spectrumSize - 1) j = v->spectrumSize - 1;
+  for (i = 0; i < psdSize; ++i) accum += psdData[i];
+  accum *= inv;
+  if (floor(fStart) != floor(fEnd)) {
+    t = (float)((fStart - floor(fStart)) / relBw);
+    v->psdCount[j] += 1 - t;
+    v->psdAccum[j] += (1 - t) * accum;
+    if (j + 1 < v->spectrumSize) {
+      v->psdCount[j + 1] += t;
+      v->psdAccum[j + 1] += t * accum;
+    }
+  } else {
+    v->psdCount[j] += 1;
+    v->psdAccum[j] += accum;
+  }
+}
+
+void sdo_specview_feed(sdo_specview *v, const float *psd, const float *count, size_t psdSize,
+                       double freqMin, double freqMax, int adjustSides)
+{
+  double fftCount = (freqMax - freqMin) / v->freqRange;
+  if (fftCount * v->spectrumSize >= 2)
+    specview_feed_linear(v, psd, count, psdSize, freqMin, freqMax, adjustSides);
+  else
+    specview_feed_histogram(v, psd, psdSize, freqMin, freqMax);
+  sdo_specview_interpolate(v);
+}
+
+/* ===================================================================================== */
+/* bulk helpers for the test-suite (vectorised access to the D primitives)                */
+/* ===================================================================================== */
+void sdo_phasor_u32_bulk(const uint32_t *p, sdo_c32 *out, size_t n)
+{ size_t i; for (i = 0; i < n; ++i) sdo_phasor_u32(p[i], &out[i].re, &out[i].im); }
+void sdo_atan2f_bulk(const float *y, const float *x, float *out, size_t n)
+{ size_t i; for (i = 0; i < n; ++i) out[i] = sdo_atan2f(y[i], x[i]); }
+void sdo_log2f_bulk(const float *x, float *out, size_t n)
+{ size_t i; for (i = 0; i < n; ++i) out[i] = sdo_log2f(x[i]); }
+void sdo_exp2f_bulk(const float *x, float *out, size_t n)
+{ size_t i; for (i = 0; i < n; ++i) out[i] = sdo_exp2f(x[i]); }

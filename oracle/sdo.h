@@ -1,0 +1,182 @@
+/*
+ * oracle/sdo.h -- CPU ORACLE for the SigDigger DSP hot path.   *** TEST INFRASTRUCTURE ONLY ***
+ *
+ * This is a plain-C restatement of the algorithms on the north-star path.  It is
+ * used ONLY as the checker by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg.  Nothing under sigdigger_amd/ may include, link or call it.
+ *
+ * PARITY STATUS: "parity unpinned" versus upstream sigutils/suscan.  The reference
+ * tree (/root/reference = SigDigger GUI) contains no golden vectors and the DSP
+ * libraries (sigutils, suscan, FFTW3f; unpinned master, Scripts/dist-common.sh:331-333)
+ * are absent.  Functions marked [REF-PINNED] restate
+ * arithmetic that IS present in /root/reference, line by line; functions marked
+ * [SPEC] follow the semantics frozen in SPEC.md (seeded from SURVEY.md Appendix C)
+ * and are validated from first principles in tests/ (numpy.fft, scipy.signal,
+ * libm, lock/convergence tests).
+ *
+ * Deterministic arithmetic: every [SPEC] function of the inspector chain is a
+ * fixed sequence of IEEE-754 binary32 operations (add, mul, fma, div, compare,
+ * int<->float conversion).  Build with -ffp-contract=off (see Makefile) so that
+ * only the fmaf() calls written below fuse.  The HIP kernels implement the same
+ * sequences, hence bit-exact comparison is possible for that part of the path.
+ */
+#ifndef SDO_H
+#define SDO_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float re, im; } sdo_c32;       /* == SUCOMPLEX (interleaved f32) */
+
+/* ---- D: deterministic math primitives (SPEC.md section D) ------------------------- */
+void  sdo_phasor_u32(uint32_t phase, float *c, float *s);   /* e^{j 2 pi phase / 2^32} */
+float sdo_atan2f(float y, float x);
+float sdo_log2f(float x);                                   /* x > 0 */
+float sdo_exp2f(float x);
+uint32_t sdo_fnor_to_dphase(double fnor);                   /* round(fnor * 2^31) mod 2^32 */
+
+/* ---- A3/A4/A9: reference-owned PSD post-processing [REF-PINNED] ------------------- */
+void sdo_psd_shift_db(float *psd, size_t n);                /* Suscan/Messages/PSDMessage.cpp:26-39 */
+/* Misc/Averager.cpp:25-50.  last/bufsiz are the caller-held state. Returns 1 if it
+ * (re)initialised (copy) instead of blending. */
+int  sdo_averager_feed(float *last, size_t *bufsiz, const float *x, size_t n, float alpha);
+void sdo_inspector_spectrum_db_shift(float *data, size_t len); /* GenericInspector.cpp:231-254 */
+
+/* ---- A2: windowed FFT power spectrum [SPEC] --------------------------------------- */
+enum { SDO_WIN_NONE = 0, SDO_WIN_HAMMING, SDO_WIN_HANN, SDO_WIN_FLAT_TOP, SDO_WIN_BLACKMANN_HARRIS };
+void sdo_window(int type, float *w, size_t n);
+/* double-precision radix-2 FFT, in place, n power of two */
+void sdo_fft_f64(double *re, double *im, size_t n);
+/* out[o][i] = (1/navg) * sum_{f<navg} |FFT(w .* x[(o*navg+f)*hop ...])[i]|^2 * scale,
+ * natural FFT order (DC at index 0); nout = nframes / navg outputs */
+void sdo_psd_frames(const sdo_c32 *x, size_t nframes, size_t n, size_t hop,
+                    const float *window, size_t navg, float scale, float *out);
+
+/* ---- T1/K4: NCO translate [SPEC] -------------------------------------------------- */
+/* y[i] = x[i] * e^{j 2 pi (p0 + (n0+i) dp) / 2^32}; Tasks/CarrierXlator.cpp:36-37,57-60 */
+void sdo_xlate_bulk(const sdo_c32 *x, sdo_c32 *y, size_t len, uint32_t p0, uint32_t dp, uint64_t n0);
+
+/* ---- K4+K5: batched translate + decimating low-pass [SPEC] ------------------------ */
+void sdo_lpf_design(float *h, size_t ntaps, double fc_nor);  /* hamming-windowed sinc, unit DC gain */
+/* g[k] = h[k] * phasor(-(k*dp)) for k<ntaps, zero for ntaps<=k<ntaps_padded */
+void sdo_chan_modulate_taps(const float *h, size_t ntaps, uint32_t dp, sdo_c32 *g);
+/* One channel. hist = the ntaps-1 input samples preceding x[0] (oldest first).
+ * Produces outputs for every absolute input index n = n0+i with n % D == 0:
+ *   acc = sum_{k=0}^{ntaps-1} g[k] * xx[n-k]   (k ascending, 4 fmaf per tap)
+ *   y   = acc * phasor(p0 + n*dp)
+ * returns number of outputs written. */
+size_t sdo_chan_feed(const sdo_c32 *hist, const sdo_c32 *x, size_t len, uint64_t n0,
+                     const sdo_c32 *g, size_t ntaps, uint32_t D, uint32_t p0, uint32_t dp,
+                     sdo_c32 *y);
+
+/* ---- T5/T7/T11: element-wise demodulators [REF-PINNED structure, SPEC arg()] -------- */
+/* Tasks/QuadDemodTask.cpp:44-60.  prev = sample before x[0]; first!=0 => dest[0]=0 */
+void sdo_quad_demod(const sdo_c32 *x, sdo_c32 *y, size_t len, sdo_c32 prev, int first);
+/* Tasks/DelayedConjTask.cpp:70-84 (delay line expressed as direct indexing) */
+void sdo_delayed_conj(const sdo_c32 *x, sdo_c32 *y, size_t len, size_t delay);
+/* Tasks/HistogramFeeder.cpp:45-66; space: 0 amplitude, 1 phase, 2 frequency. returns count */
+size_t sdo_histogram_feed(const sdo_c32 *x, size_t len, int space, float *out);
+
+/* ---- K6/K7: carrier recovery loops [SPEC] ------------------------------------------ */
+#define SDO_IIR_MAX_ORDER 4
+typedef struct {
+  int   order;                              /* number of poles (arm_order - 1)        */
+  float b[SDO_IIR_MAX_ORDER + 1];
+  float a[SDO_IIR_MAX_ORDER + 1];           /* a[0] = 1                                */
+  sdo_c32 xh[SDO_IIR_MAX_ORDER + 1];        /* xh[i] = x[n-i], i>=1                    */
+  sdo_c32 yh[SDO_IIR_MAX_ORDER + 1];
+} sdo_iir;
+void sdo_butter_lp(int order, double fc_nor, float *b, float *a);   /* bilinear Butterworth */
+
+enum { SDO_COSTAS_NONE = 0, SDO_COSTAS_BPSK, SDO_COSTAS_QPSK, SDO_COSTAS_8PSK };
+typedef struct {
+  int      kind;
+  uint32_t phase;                           /* NCO phase, 2^32 per turn               */
+  float    omega;                           /* NCO frequency, rad/sample              */
+  float    a, b;                            /* loop gains                             */
+  float    gain;
+  sdo_iir  af;                              /* arm filter                             */
+} sdo_costas;
+/* su_costas_init(c, kind, fhint, arm_bw, arm_order, loop_bw): Tasks/CostasRecoveryTask.cpp:41 */
+int  sdo_costas_init(sdo_costas *c, int kind, float fhint, float arm_bw, unsigned arm_order, float loop_bw);
+sdo_c32 sdo_costas_feed(sdo_costas *c, sdo_c32 x);       /* Tasks/CostasRecoveryTask.cpp:58-61 */
+void sdo_costas_feed_bulk(sdo_costas *c, const sdo_c32 *x, sdo_c32 *y, size_t len);
+
+typedef struct {
+  uint32_t phase;
+  float    omega;
+  float    alpha, beta;
+} sdo_pll;
+int  sdo_pll_init(sdo_pll *p, float fhint, float fc);     /* Tasks/PLLSyncTask.cpp:36 */
+sdo_c32 sdo_pll_track(sdo_pll *p, sdo_c32 x);             /* Tasks/PLLSyncTask.cpp:53-56 */
+void sdo_pll_track_bulk(sdo_pll *p, const sdo_c32 *x, sdo_c32 *y, size_t len);
+
+/* ---- K8: Gardner clock recovery [SPEC] --------------------------------------------- */
+typedef struct {
+  float alpha, beta, gain;
+  float phi, bnor, bmin, bmax;
+  int   halfcycle;
+  sdo_c32 prev, x0, x1, x2;
+} sdo_clock;
+/* su_clock_detector_init(cd, loop_gain, bhint, bufsiz): Tasks/WaveSampler.cpp:60-65 */
+int    sdo_clock_init(sdo_clock *cd, float loop_gain, float bhint);
+/* feeds len samples, appends recovered symbols to out; returns number appended */
+size_t sdo_clock_feed_bulk(sdo_clock *cd, const sdo_c32 *x, size_t len, sdo_c32 *out);
+
+/* ---- K9: AGC [SPEC] ------------------------------------------------------------------ */
+#define SDO_AGC_MAX_HIST 64
+typedef struct {
+  float threshold, slope_factor;
+  unsigned hang_max, delay_line_size, mag_history_size;
+  float fast_rise_t, fast_fall_t, slow_rise_t, slow_fall_t;
+} sdo_agc_params;
+extern const sdo_agc_params sdo_agc_params_default;       /* su_agc_params_INITIALIZER */
+typedef struct {
+  float knee, gain_slope, fixed_gain;
+  float fast_alpha_rise, fast_alpha_fall, slow_alpha_rise, slow_alpha_fall;
+  unsigned hang_max, hang_n, delay_line_size, mag_history_size;
+  unsigned delay_ptr, hist_ptr;
+  float peak, fast_level, slow_level;
+  sdo_c32 delay_line[SDO_AGC_MAX_HIST];
+  float   mag_history[SDO_AGC_MAX_HIST];
+} sdo_agc;
+int  sdo_agc_init(sdo_agc *agc, const sdo_agc_params *p);  /* Tasks/AGCTask.cpp:41-53 */
+sdo_c32 sdo_agc_feed(sdo_agc *agc, sdo_c32 x);            /* Tasks/AGCTask.cpp:70-73 */
+void sdo_agc_feed_bulk(sdo_agc *agc, const sdo_c32 *x, sdo_c32 *y, size_t len);
+/* AGCTask's time constants from tau: Tasks/AGCTask.cpp:22-28,43-47 */
+void sdo_agc_params_from_tau(sdo_agc_params *p, float tau);
+
+/* ---- T8: WaveSampler manual / zero-crossing [REF-PINNED] ---------------------------- */
+/* Tasks/WaveSampler.cpp:96-175. space: 0 amplitude, 1 phase, 2 frequency.
+ * Computes symbols [0, symbol_count). */
+void sdo_sample_manual(const sdo_c32 *data, size_t length, double symbol_count,
+                       double symbol_sync, int space, sdo_c32 *out, size_t nout);
+
+/* ---- T9: carrier centroid [REF-PINNED structure] ------------------------------------ */
+/* Tasks/CarrierDetector.cpp:80-143. returns peak in rad/sample */
+float sdo_carrier_detect(const sdo_c32 *data, size_t len, float avg_rel_bw, float dc_notch_rel_bw);
+void  sdo_blackmann_harris_complex(sdo_c32 *h, size_t n);
+
+/* ---- P2/P3: SpectrumView [REF-PINNED] ----------------------------------------------- */
+#define SDO_SCANNER_SPECTRUM_SIZE 65536
+typedef struct {
+  double freqMin, freqMax, freqRange;
+  unsigned spectrumSize;
+  double fftBandwidth;
+  float  fftRelBw;
+  float *psd, *psdAccum, *psdCount;          /* SDO_SCANNER_SPECTRUM_SIZE each */
+} sdo_specview;
+void sdo_specview_init(sdo_specview *v, float *psd, float *accum, float *count);
+void sdo_specview_set_range(sdo_specview *v, double fmin, double fmax);  /* Scanner.cpp:41-54 */
+void sdo_specview_feed(sdo_specview *v, const float *psd, const float *count, size_t psdSize,
+                       double freqMin, double freqMax, int adjustSides);  /* Scanner.cpp:239-256 */
+void sdo_specview_interpolate(sdo_specview *v);                          /* Scanner.cpp:56-116 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDO_H */

@@ -1,0 +1,361 @@
+"""ctypes binding of the CPU oracle (oracle/libsdo.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under sigdigger_amd/ imports this module.
+"parity unpinned" vs upstream sigutils/suscan (see oracle/sdo.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c32 = np.complex64
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libsdo.so")
+    src = [os.path.join(_HERE, f) for f in ("sdo.c", "sdo.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libsdo.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+class C32(C.Structure):
+    _fields_ = [("re", C.c_float), ("im", C.c_float)]
+
+
+class IIR(C.Structure):
+    _fields_ = [("order", C.c_int), ("b", C.c_float * 5), ("a", C.c_float * 5),
+                ("xh", C.c_float * 10), ("yh", C.c_float * 10)]
+
+
+class Costas(C.Structure):
+    _fields_ = [("kind", C.c_int), ("phase", C.c_uint32), ("omega", C.c_float),
+                ("a", C.c_float), ("b", C.c_float), ("gain", C.c_float), ("af", IIR)]
+
+
+class PLL(C.Structure):
+    _fields_ = [("phase", C.c_uint32), ("omega", C.c_float), ("alpha", C.c_float), ("beta", C.c_float)]
+
+
+class Clock(C.Structure):
+    _fields_ = [("alpha", C.c_float), ("beta", C.c_float), ("gain", C.c_float),
+                ("phi", C.c_float), ("bnor", C.c_float), ("bmin", C.c_float), ("bmax", C.c_float),
+                ("halfcycle", C.c_int), ("prev", C.c_float * 2), ("x0", C.c_float * 2),
+                ("x1", C.c_float * 2), ("x2", C.c_float * 2)]
+
+
+class AGCParams(C.Structure):
+    _fields_ = [("threshold", C.c_float), ("slope_factor", C.c_float), ("hang_max", C.c_uint),
+                ("delay_line_size", C.c_uint), ("mag_history_size", C.c_uint),
+                ("fast_rise_t", C.c_float), ("fast_fall_t", C.c_float),
+                ("slow_rise_t", C.c_float), ("slow_fall_t", C.c_float)]
+
+
+class AGC(C.Structure):
+    _fields_ = [("knee", C.c_float), ("gain_slope", C.c_float), ("fixed_gain", C.c_float),
+                ("fast_alpha_rise", C.c_float), ("fast_alpha_fall", C.c_float),
+                ("slow_alpha_rise", C.c_float), ("slow_alpha_fall", C.c_float),
+                ("hang_max", C.c_uint), ("hang_n", C.c_uint), ("delay_line_size", C.c_uint),
+                ("mag_history_size", C.c_uint), ("delay_ptr", C.c_uint), ("hist_ptr", C.c_uint),
+                ("peak", C.c_float), ("fast_level", C.c_float), ("slow_level", C.c_float),
+                ("delay_line", C.c_float * 128), ("mag_history", C.c_float * 64)]
+
+
+class SpecView(C.Structure):
+    _fields_ = [("freqMin", C.c_double), ("freqMax", C.c_double), ("freqRange", C.c_double),
+                ("spectrumSize", C.c_uint), ("fftBandwidth", C.c_double), ("fftRelBw", C.c_float),
+                ("psd", C.c_void_p), ("psdAccum", C.c_void_p), ("psdCount", C.c_void_p)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.sdo_atan2f.restype = C.c_float
+        L.sdo_atan2f.argtypes = [C.c_float, C.c_float]
+        L.sdo_log2f.restype = C.c_float
+        L.sdo_log2f.argtypes = [C.c_float]
+        L.sdo_exp2f.restype = C.c_float
+        L.sdo_exp2f.argtypes = [C.c_float]
+        L.sdo_fnor_to_dphase.restype = C.c_uint32
+        L.sdo_fnor_to_dphase.argtypes = [C.c_double]
+        L.sdo_chan_feed.restype = C.c_size_t
+        L.sdo_histogram_feed.restype = C.c_size_t
+        L.sdo_clock_feed_bulk.restype = C.c_size_t
+        L.sdo_carrier_detect.restype = C.c_float
+        L.sdo_averager_feed.restype = C.c_int
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c(x):
+    return np.ascontiguousarray(x, dtype=c32)
+
+
+def _f(x):
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+# ---- D ----------------------------------------------------------------------------------
+def phasor_u32(p):
+    p = np.ascontiguousarray(p, dtype=np.uint32)
+    out = np.empty(p.shape, dtype=c32)
+    lib().sdo_phasor_u32_bulk(_p(p), _p(out), C.c_size_t(p.size))
+    return out
+
+
+def atan2f(y, x):
+    y, x = _f(y), _f(x)
+    out = np.empty(y.shape, dtype=np.float32)
+    lib().sdo_atan2f_bulk(_p(y), _p(x), _p(out), C.c_size_t(y.size))
+    return out
+
+
+def log2f(x):
+    x = _f(x)
+    out = np.empty(x.shape, dtype=np.float32)
+    lib().sdo_log2f_bulk(_p(x), _p(out), C.c_size_t(x.size))
+    return out
+
+
+def exp2f(x):
+    x = _f(x)
+    out = np.empty(x.shape, dtype=np.float32)
+    lib().sdo_exp2f_bulk(_p(x), _p(out), C.c_size_t(x.size))
+    return out
+
+
+def fnor_to_dphase(fnor):
+    return int(lib().sdo_fnor_to_dphase(float(fnor)))
+
+
+# ---- PSD --------------------------------------------------------------------------------
+def psd_shift_db(psd):
+    out = _f(psd).copy()
+    lib().sdo_psd_shift_db(_p(out), C.c_size_t(out.size))
+    return out
+
+
+class Averager:
+    """Misc/Averager.cpp state holder."""
+
+    def __init__(self, alpha=1.0):
+        self.alpha = alpha
+        self.last = None
+        self.bufsiz = C.c_size_t(0)
+
+    def feed(self, x):
+        x = _f(x)
+        if self.last is None or self.last.size != x.size:
+            self.last = np.zeros(x.size, dtype=np.float32)
+        lib().sdo_averager_feed(_p(self.last), C.byref(self.bufsiz), _p(x), C.c_size_t(x.size),
+                                C.c_float(self.alpha))
+        return self.last
+
+
+def inspector_spectrum_db_shift(data):
+    out = _f(data).copy()
+    lib().sdo_inspector_spectrum_db_shift(_p(out), C.c_size_t(out.size))
+    return out
+
+
+def window(kind, n):
+    w = np.empty(n, dtype=np.float32)
+    lib().sdo_window(C.c_int(kind), _p(w), C.c_size_t(n))
+    return w
+
+
+def fft_f64(x):
+    re = np.ascontiguousarray(np.real(x), dtype=np.float64).copy()
+    im = np.ascontiguousarray(np.imag(x), dtype=np.float64).copy()
+    lib().sdo_fft_f64(_p(re), _p(im), C.c_size_t(re.size))
+    return re + 1j * im
+
+
+def psd_frames(x, nframes, n, hop, win, navg=1, scale=1.0):
+    x = _c(x)
+    win = _f(win)
+    assert x.size >= (nframes - 1) * hop + n
+    out = np.empty((nframes // navg, n), dtype=np.float32)
+    lib().sdo_psd_frames(_p(x), C.c_size_t(nframes), C.c_size_t(n), C.c_size_t(hop), _p(win),
+                         C.c_size_t(navg), C.c_float(scale), _p(out))
+    return out
+
+
+# ---- NCO / channelizer ------------------------------------------------------------------
+def xlate_bulk(x, p0, dp, n0=0):
+    x = _c(x)
+    y = np.empty_like(x)
+    lib().sdo_xlate_bulk(_p(x), _p(y), C.c_size_t(x.size), C.c_uint32(p0), C.c_uint32(dp), C.c_uint64(n0))
+    return y
+
+
+def lpf_design(ntaps, fc):
+    h = np.empty(ntaps, dtype=np.float32)
+    lib().sdo_lpf_design(_p(h), C.c_size_t(ntaps), C.c_double(fc))
+    return h
+
+
+def chan_modulate_taps(h, dp):
+    h = _f(h)
+    g = np.empty(h.size, dtype=c32)
+    lib().sdo_chan_modulate_taps(_p(h), C.c_size_t(h.size), C.c_uint32(dp), _p(g))
+    return g
+
+
+def chan_feed(hist, x, n0, g, D, p0, dp):
+    x = _c(x)
+    g = _c(g)
+    hist = _c(hist)
+    assert hist.size == g.size - 1
+    y = np.empty(x.size // D + 2, dtype=c32)
+    n = lib().sdo_chan_feed(_p(hist), _p(x), C.c_size_t(x.size), C.c_uint64(n0), _p(g),
+                            C.c_size_t(g.size), C.c_uint32(D), C.c_uint32(p0), C.c_uint32(dp), _p(y))
+    return y[:n].copy()
+
+
+# ---- element-wise -----------------------------------------------------------------------
+def quad_demod(x, prev=0j, first=True):
+    x = _c(x)
+    y = np.empty_like(x)
+    pv = C32(float(np.real(prev)), float(np.imag(prev)))
+    lib().sdo_quad_demod.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C32, C.c_int]
+    lib().sdo_quad_demod(_p(x), _p(y), x.size, pv, int(first))
+    return y
+
+
+def delayed_conj(x, delay):
+    x = _c(x)
+    y = np.empty_like(x)
+    lib().sdo_delayed_conj(_p(x), _p(y), C.c_size_t(x.size), C.c_size_t(delay))
+    return y
+
+
+def histogram_feed(x, space):
+    x = _c(x)
+    out = np.empty(x.size, dtype=np.float32)
+    n = lib().sdo_histogram_feed(_p(x), C.c_size_t(x.size), C.c_int(space), _p(out))
+    return out[:n].copy()
+
+
+# ---- loops ------------------------------------------------------------------------------
+def butter_lp(order, fc):
+    b = np.zeros(5, dtype=np.float32)
+    a = np.zeros(5, dtype=np.float32)
+    lib().sdo_butter_lp(C.c_int(order), C.c_double(fc), _p(b), _p(a))
+    return b, a
+
+
+def costas_new(kind, fhint, arm_bw, arm_order, loop_bw):
+    c = Costas()
+    ok = lib().sdo_costas_init(C.byref(c), C.c_int(kind), C.c_float(fhint), C.c_float(arm_bw),
+                               C.c_uint(arm_order), C.c_float(loop_bw))
+    assert ok
+    return c
+
+
+def costas_feed_bulk(c, x):
+    x = _c(x)
+    y = np.empty_like(x)
+    lib().sdo_costas_feed_bulk(C.byref(c), _p(x), _p(y), C.c_size_t(x.size))
+    return y
+
+
+def pll_new(fhint, fc):
+    p = PLL()
+    lib().sdo_pll_init(C.byref(p), C.c_float(fhint), C.c_float(fc))
+    return p
+
+
+def pll_track_bulk(p, x):
+    x = _c(x)
+    y = np.empty_like(x)
+    lib().sdo_pll_track_bulk(C.byref(p), _p(x), _p(y), C.c_size_t(x.size))
+    return y
+
+
+def clock_new(loop_gain, bhint):
+    cd = Clock()
+    r = lib().sdo_clock_init(C.byref(cd), C.c_float(loop_gain), C.c_float(bhint))
+    assert r != -1
+    return cd
+
+
+def clock_feed_bulk(cd, x):
+    x = _c(x)
+    out = np.empty(x.size + 1, dtype=c32)
+    n = lib().sdo_clock_feed_bulk(C.byref(cd), _p(x), C.c_size_t(x.size), _p(out))
+    return out[:n].copy()
+
+
+def agc_params_default():
+    return AGCParams.in_dll(lib(), "sdo_agc_params_default")
+
+
+def agc_params_from_tau(tau):
+    p = AGCParams()
+    lib().sdo_agc_params_from_tau(C.byref(p), C.c_float(tau))
+    return p
+
+
+def agc_new(params=None):
+    a = AGC()
+    if params is None:
+        params = agc_params_default()
+    ok = lib().sdo_agc_init(C.byref(a), C.byref(params))
+    assert ok
+    return a
+
+
+def agc_feed_bulk(a, x):
+    x = _c(x)
+    y = np.empty_like(x)
+    lib().sdo_agc_feed_bulk(C.byref(a), _p(x), _p(y), C.c_size_t(x.size))
+    return y
+
+
+# ---- Tasks ------------------------------------------------------------------------------
+def sample_manual(data, symbol_count, symbol_sync, space, nout=None):
+    data = _c(data)
+    if nout is None:
+        nout = int(symbol_count)
+    out = np.empty(nout, dtype=c32)
+    lib().sdo_sample_manual(_p(data), C.c_size_t(data.size), C.c_double(symbol_count),
+                            C.c_double(symbol_sync), C.c_int(space), _p(out), C.c_size_t(nout))
+    return out
+
+
+def carrier_detect(data, avg_rel_bw, dc_notch_rel_bw):
+    data = _c(data)
+    return float(lib().sdo_carrier_detect(_p(data), C.c_size_t(data.size), C.c_float(avg_rel_bw),
+                                          C.c_float(dc_notch_rel_bw)))
+
+
+class SpectrumView:
+    """Panoramic/Scanner.cpp SpectrumView."""
+    SIZE = 65536
+
+    def __init__(self):
+        self.psd = np.zeros(self.SIZE, dtype=np.float32)
+        self.accum = np.zeros(self.SIZE, dtype=np.float32)
+        self.count = np.zeros(self.SIZE, dtype=np.float32)
+        self.v = SpecView()
+        lib().sdo_specview_init(C.byref(self.v), _p(self.psd), _p(self.accum), _p(self.count))
+
+    def set_range(self, fmin, fmax):
+        lib().sdo_specview_set_range(C.byref(self.v), C.c_double(fmin), C.c_double(fmax))
+
+    def feed(self, psd, fmin, fmax, adjust_sides=True, count=None):
+        psd = _f(psd)
+        cp = _p(_f(count)) if count is not None else None
+        lib().sdo_specview_feed(C.byref(self.v), _p(psd), cp, C.c_size_t(psd.size),
+                                C.c_double(fmin), C.c_double(fmax), C.c_int(int(adjust_sides)))
