@@ -1,0 +1,199 @@
+/*
+ * include/sigdigger_amd.h -- C ABI of libsigdigger_amd.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the SigDigger DSP hot path: every entry point
+ * below replaces one block-at-a-time loop (or one libsigutils/libsuscan call) that the
+ * reference makes, and cites it.  Signatures are plain C: pointers, sizes, scalars.
+ *
+ *   d_*    : DEVICE pointers (HBM).  Complex data is SUCOMPLEX = interleaved float32 I/Q,
+ *            exactly the layout the reference passes around (include/Suscan/Messages/SamplesMessage.h:33-58).
+ *   stream : a hipStream_t passed as void* (NULL = the null stream).  All work is enqueued
+ *            asynchronously on it; nothing here synchronises unless stated.
+ *   return : SUBOOL (SU_TRUE / SU_FALSE) or a pointer (NULL on failure), the reference's own
+ *            convention (include/Suscan/Compat.h:28-36 wraps every call in SU_ATTEMPT).
+ *            suamd_last_error() returns the reason (thread-local).
+ *
+ * There is NO CPU fallback: without a usable gfx950 device every constructor fails.
+ */
+#ifndef SIGDIGGER_AMD_H
+#define SIGDIGGER_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUAMD_API __attribute__((visibility("default")))
+
+typedef float    SUFLOAT;
+typedef double   SUFREQ;
+typedef uint64_t SUSCOUNT;
+typedef int      SUBOOL;
+typedef struct { SUFLOAT re, im; } suamd_complex;   /* layout-identical to SUCOMPLEX */
+#ifndef SU_TRUE
+#  define SU_TRUE  1
+#  define SU_FALSE 0
+#endif
+
+typedef struct suamd_ctx         suamd_ctx_t;
+typedef struct suamd_psd         suamd_psd_t;
+typedef struct suamd_chanbank    suamd_chanbank_t;
+typedef struct suamd_costas_bank suamd_costas_bank_t;
+typedef struct suamd_pll_bank    suamd_pll_bank_t;
+typedef struct suamd_clock_bank  suamd_clock_bank_t;
+typedef struct suamd_agc_bank    suamd_agc_bank_t;
+
+/* ------------------------------------------------------------------------------------ */
+/* library / context                                                                    */
+/* ------------------------------------------------------------------------------------ */
+SUAMD_API const char *suamd_last_error(void);
+SUAMD_API const char *suamd_version(void);
+/* Replaces suscan_sigutils_init + su_lib_gen_wisdom for this path (Suscan/Library.cpp:97,
+ * App/Loader.cpp:46): binds a GPU and builds the shared tables. */
+SUAMD_API suamd_ctx_t *suamd_ctx_new(int device_ordinal);
+SUAMD_API void         suamd_ctx_destroy(suamd_ctx_t *ctx);
+SUAMD_API int          suamd_ctx_device(const suamd_ctx_t *ctx);
+
+/* ------------------------------------------------------------------------------------ */
+/* A2-A4, A9: main-spectrum PSD                                                          */
+/* ------------------------------------------------------------------------------------ */
+/* enum sigutils_channel_detector_window (include/Suscan/AnalyzerParams.h:37-43) */
+enum suamd_window {
+  SUAMD_WINDOW_NONE = 0, SUAMD_WINDOW_HAMMING, SUAMD_WINDOW_HANN,
+  SUAMD_WINDOW_FLAT_TOP, SUAMD_WINDOW_BLACKMANN_HARRIS
+};
+enum suamd_psd_mode {
+  SUAMD_PSD_LINEAR    = 0,  /* what struct suscan_analyzer_psd_msg::psd_data carries: linear
+                               power, natural FFT order (Suscan/Messages/PSDMessage.cpp:29-38
+                               proves it by shifting + taking dB itself)                   */
+  SUAMD_PSD_DB_SHIFTED = 1  /* PSDMessage ctor fused in: fftshift + SU_POWER_DB             */
+};
+/* Plan for detector_params.window_size / .window (Suscan/AnalyzerParams.cpp:53-71).
+ * window_size: power of two, 512..16384 in this round. */
+SUAMD_API suamd_psd_t *suamd_psd_new(suamd_ctx_t *ctx, unsigned window_size, int window_type);
+SUAMD_API void         suamd_psd_destroy(suamd_psd_t *psd);
+/* For o < nframes/navg:
+ *   d_out[o*N + i] = scale/navg * sum_{f<navg} |FFT_N(window .* d_x[(o*navg+f)*hop ...])[i]|^2
+ * (mode LINEAR), or its fftshift + 10*log10(. + 1e-8) (mode DB_SHIFTED). */
+SUAMD_API SUBOOL suamd_psd_feed(suamd_psd_t *psd, const suamd_complex *d_x, SUSCOUNT nframes,
+                                SUSCOUNT hop, unsigned navg, SUFLOAT scale, int mode,
+                                SUFLOAT *d_out, void *stream);
+/* PSDMessage::PSDMessage loop (Suscan/Messages/PSDMessage.cpp:29-38), nframes frames of n floats in place */
+SUAMD_API SUBOOL suamd_psd_shift_db(suamd_ctx_t *ctx, SUFLOAT *d_psd, SUSCOUNT n, SUSCOUNT nframes, void *stream);
+/* Averager::feed blend branch (Misc/Averager.cpp:44-47): last[i] += alpha*(x[i]-last[i]);
+ * blend == SU_FALSE is the memcpy branch (:48). */
+SUAMD_API SUBOOL suamd_averager_feed(suamd_ctx_t *ctx, SUFLOAT *d_last, const SUFLOAT *d_x, SUSCOUNT n,
+                                     SUFLOAT alpha, SUBOOL blend, void *stream);
+/* GenericInspector::inspectorMessage SPECTRUM case (Default/GenericInspector/GenericInspector.cpp:231-247) */
+SUAMD_API SUBOOL suamd_inspector_spectrum_db_shift(suamd_ctx_t *ctx, SUFLOAT *d_data, SUSCOUNT len,
+                                                   SUSCOUNT nspectra, void *stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* T1 / K4: NCO carrier translate                                                        */
+/* ------------------------------------------------------------------------------------ */
+/* su_ncqo_init(-relFreq) + su_ncqo_set_phase(-phase) + per-sample su_ncqo_read loop
+ * (Tasks/CarrierXlator.cpp:36-37,57-60).  Phase is a 32-bit accumulator (2^32 per turn):
+ *   y[i] = x[i] * exp(j 2 pi (phase0 + (n0+i)*dphase) / 2^32)
+ * suamd_fnor_to_dphase(fnor) converts a normalised frequency (2f/fs) to dphase. */
+SUAMD_API uint32_t suamd_fnor_to_dphase(double fnor);
+SUAMD_API SUBOOL suamd_xlate_bulk(suamd_ctx_t *ctx, const suamd_complex *d_x, suamd_complex *d_y,
+                                  SUSCOUNT len, uint32_t phase0, uint32_t dphase, SUSCOUNT n0, void *stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* K4+K5: bank of inspector channels: translate + low-pass + decimate                    */
+/* ------------------------------------------------------------------------------------ */
+/* One bank = the set of channels opened with suscan_analyzer_open_ex_async
+ * (Suscan/Analyzer.cpp:459-484) that share a decimation; replaces the su_specttuner
+ * channel path (Tasks/LPFTask.cpp:52-69,83-87) with the 255-tap polyphase FIR the north
+ * star prescribes.  fnor[c] = channel centre (2 fc / fs); taps = real low-pass prototype. */
+SUAMD_API void   suamd_lpf_design(SUFLOAT *taps, unsigned ntaps, double fc_nor);
+SUAMD_API suamd_chanbank_t *suamd_chanbank_new(suamd_ctx_t *ctx, unsigned nchan, const double *fnor,
+                                               unsigned decimation, const SUFLOAT *taps, unsigned ntaps);
+SUAMD_API void   suamd_chanbank_destroy(suamd_chanbank_t *bank);
+/* Number of outputs per channel the next feed of len samples will produce. */
+SUAMD_API SUSCOUNT suamd_chanbank_output_count(const suamd_chanbank_t *bank, SUSCOUNT len);
+/* Feeds len input samples (shared by all channels); writes
+ * d_y[c*y_stride + m], m < *n_out, channel-major.  State (history, sample clock) carries
+ * to the next call, so a stream may be fed block by block. */
+SUAMD_API SUBOOL suamd_chanbank_feed(suamd_chanbank_t *bank, const suamd_complex *d_x, SUSCOUNT len,
+                                     suamd_complex *d_y, SUSCOUNT y_stride, SUSCOUNT *n_out, void *stream);
+SUAMD_API SUBOOL suamd_chanbank_reset(suamd_chanbank_t *bank, void *stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* T5 / T7 / T11: element-wise demodulators (batched: nchan rows of len samples)         */
+/* ------------------------------------------------------------------------------------ */
+/* QuadDemodTask::work loop (Tasks/QuadDemodTask.cpp:44-60).  d_prev[c] (may be NULL when
+ * first) = sample preceding row c; first => dest[0] = 0.  If d_prev_out != NULL the last
+ * sample of each row is stored there for the next block. */
+SUAMD_API SUBOOL suamd_quad_demod_batch(suamd_ctx_t *ctx, const suamd_complex *d_x, SUSCOUNT x_stride,
+                                        suamd_complex *d_y, SUSCOUNT y_stride, unsigned nchan, SUSCOUNT len,
+                                        const suamd_complex *d_prev, SUBOOL first,
+                                        suamd_complex *d_prev_out, void *stream);
+/* DelayedConjTask::work loop (Tasks/DelayedConjTask.cpp:70-84), whole capture at once */
+SUAMD_API SUBOOL suamd_delayed_conj_bulk(suamd_ctx_t *ctx, const suamd_complex *d_x, suamd_complex *d_y,
+                                         SUSCOUNT len, SUSCOUNT delay, void *stream);
+/* HistogramFeeder::work loops (Tasks/HistogramFeeder.cpp:45-66); space 0 amplitude,
+ * 1 phase, 2 frequency (len-1 outputs) */
+SUAMD_API SUBOOL suamd_histogram_feed_bulk(suamd_ctx_t *ctx, const suamd_complex *d_x, SUSCOUNT len,
+                                           int space, SUFLOAT *d_out, void *stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* K6-K9: per-channel recurrences, one lane per channel                                  */
+/* ------------------------------------------------------------------------------------ */
+/* enum sigutils_costas_kind (Components/TimeWindow.cpp:1948-1960) */
+enum suamd_costas_kind { SUAMD_COSTAS_NONE = 0, SUAMD_COSTAS_BPSK, SUAMD_COSTAS_QPSK, SUAMD_COSTAS_8PSK };
+
+/* su_costas_init(&c, kind, fhint, arm_bw, arm_order, loop_bw) for nchan identical loops
+ * (Tasks/CostasRecoveryTask.cpp:41) */
+SUAMD_API suamd_costas_bank_t *suamd_costas_bank_new(suamd_ctx_t *ctx, unsigned nchan, int kind, SUFLOAT fhint,
+                                                     SUFLOAT arm_bw, unsigned arm_order, SUFLOAT loop_bw);
+SUAMD_API void   suamd_costas_bank_destroy(suamd_costas_bank_t *b);
+/* the `while (amount--) dest[p] = su_costas_feed(&costas, origin[p])` loop
+ * (Tasks/CostasRecoveryTask.cpp:58-61) for every row c */
+SUAMD_API SUBOOL suamd_costas_bank_feed(suamd_costas_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride,
+                                        suamd_complex *d_y, SUSCOUNT y_stride, SUSCOUNT len, void *stream);
+/* copies omega[c] (rad/sample) and phase[c] (2^32/turn) to host; synchronises the stream */
+SUAMD_API SUBOOL suamd_costas_bank_get_state(suamd_costas_bank_t *b, SUFLOAT *omega, uint32_t *phase, void *stream);
+
+/* su_pll_init(&pll, fhint, fc) / su_pll_track loop (Tasks/PLLSyncTask.cpp:36,53-56) */
+SUAMD_API suamd_pll_bank_t *suamd_pll_bank_new(suamd_ctx_t *ctx, unsigned nchan, SUFLOAT fhint, SUFLOAT fc);
+SUAMD_API void   suamd_pll_bank_destroy(suamd_pll_bank_t *b);
+SUAMD_API SUBOOL suamd_pll_bank_feed(suamd_pll_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride,
+                                     suamd_complex *d_y, SUSCOUNT y_stride, SUSCOUNT len, void *stream);
+SUAMD_API SUBOOL suamd_pll_bank_get_state(suamd_pll_bank_t *b, SUFLOAT *omega, uint32_t *phase, void *stream);
+
+/* su_clock_detector_init(&cd, loop_gain, bhint, bufsiz) + feed/read loops
+ * (Tasks/WaveSampler.cpp:60-65,177-213).  Symbols of row c are appended at
+ * d_sym[c*sym_stride + d_count[c]++]; d_count (uint32 per channel) is zeroed by the caller
+ * (or carried over to keep appending). */
+SUAMD_API suamd_clock_bank_t *suamd_clock_bank_new(suamd_ctx_t *ctx, unsigned nchan, SUFLOAT loop_gain, SUFLOAT bhint);
+SUAMD_API void   suamd_clock_bank_destroy(suamd_clock_bank_t *b);
+SUAMD_API SUBOOL suamd_clock_bank_feed(suamd_clock_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride,
+                                       SUSCOUNT len, suamd_complex *d_sym, SUSCOUNT sym_stride,
+                                       uint32_t *d_count, void *stream);
+SUAMD_API SUBOOL suamd_clock_bank_get_state(suamd_clock_bank_t *b, SUFLOAT *bnor, SUFLOAT *phi, void *stream);
+
+/* struct su_agc_params (Tasks/AGCTask.cpp:41-47) + su_agc_params_INITIALIZER defaults */
+struct suamd_agc_params {
+  SUFLOAT  threshold;
+  SUFLOAT  slope_factor;
+  unsigned hang_max;
+  unsigned delay_line_size;
+  unsigned mag_history_size;
+  SUFLOAT  fast_rise_t, fast_fall_t, slow_rise_t, slow_fall_t;
+};
+#define suamd_agc_params_INITIALIZER { -100.f, 6.f, 100, 20, 20, 2.f, 4.f, 20.f, 40.f }
+/* AGCTask ctor time constants (Tasks/AGCTask.cpp:22-28,43-47) */
+SUAMD_API void   suamd_agc_params_from_tau(struct suamd_agc_params *p, SUFLOAT tau);
+SUAMD_API suamd_agc_bank_t *suamd_agc_bank_new(suamd_ctx_t *ctx, unsigned nchan, const struct suamd_agc_params *p);
+SUAMD_API void   suamd_agc_bank_destroy(suamd_agc_bank_t *b);
+/* `dest[p] = su_agc_feed(&agc, origin[p])` loop (Tasks/AGCTask.cpp:70-73) */
+SUAMD_API SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride,
+                                     suamd_complex *d_y, SUSCOUNT y_stride, SUSCOUNT len, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGDIGGER_AMD_H */

@@ -1,0 +1,676 @@
+// capi.hip -- the C ABI of libsigdigger_amd.so (include/sigdigger_amd.h): contexts, plans,
+// per-bank device state, parameter design (host, double precision) and kernel dispatch.
+// There is deliberately no CPU implementation of any hot-path operation in this file: if no
+// gfx950 device is usable every constructor fails and says why.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/sigdigger_amd.h"
+#include "kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+void set_err(const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+#define HIP_TRY(expr, ret)                                                          \
+  do {                                                                              \
+    hipError_t e__ = (expr);                                                        \
+    if (e__ != hipSuccess) {                                                        \
+      set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return ret;                                                                   \
+    }                                                                               \
+  } while (0)
+
+constexpr double kPi = 3.14159265358979323846;
+
+template <typename T> T *dev_alloc(size_t n)
+{
+  void *p = nullptr;
+  if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+  return static_cast<T *>(p);
+}
+
+template <typename T> bool dev_upload(T *dst, const T *src, size_t n)
+{
+  return hipMemcpy(dst, src, n * sizeof(T), hipMemcpyHostToDevice) == hipSuccess;
+}
+
+template <typename T> T *dev_from_host(const std::vector<T> &v)
+{
+  T *p = dev_alloc<T>(v.size());
+  if (p && !v.empty() && !dev_upload(p, v.data(), v.size())) { hipFree(p); return nullptr; }
+  return p;
+}
+
+template <typename T> T *dev_zeros(size_t n)
+{
+  T *p = dev_alloc<T>(n);
+  if (p && hipMemset(p, 0, (n ? n : 1) * sizeof(T)) != hipSuccess) { hipFree(p); return nullptr; }
+  return p;
+}
+
+inline hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
+
+// ---- parameter design (host, double precision; not on the hot path) ----------------------
+
+// bilinear-transform Butterworth low-pass, order <= 4, cut-off fc (1 = Nyquist)
+void butter_lp(int order, double fc, float *b, float *a)
+{
+  const double wc = std::tan(0.5 * kPi * fc);
+  double ar[5] = {1, 0, 0, 0, 0}, ai[5] = {0, 0, 0, 0, 0};
+  const int n = order;
+  for (int i = 0; i < n; ++i) {
+    const double th = kPi * (2.0 * i + n + 1.0) / (2.0 * n);
+    const double pr = wc * std::cos(th), pi = wc * std::sin(th);
+    const double dr = 1.0 - pr, di = -pi, nr = 1.0 + pr, ni = pi;
+    const double den = dr * dr + di * di;
+    const double zr = (nr * dr + ni * di) / den, zi = (ni * dr - nr * di) / den;
+    for (int k = i + 1; k >= 1; --k) {
+      const double tr = ar[k] - (zr * ar[k - 1] - zi * ai[k - 1]);
+      const double ti = ai[k] - (zr * ai[k - 1] + zi * ar[k - 1]);
+      ar[k] = tr; ai[k] = ti;
+    }
+  }
+  double bn[5] = {1, 0, 0, 0, 0}, sa = 0, sb = 0;
+  for (int i = 0; i < n; ++i)
+    for (int k = i + 1; k >= 1; --k) bn[k] += bn[k - 1];
+  for (int k = 0; k <= n; ++k) { sa += ar[k]; sb += bn[k]; }
+  for (int k = 0; k <= 4; ++k) { b[k] = 0; a[k] = 0; }
+  for (int k = 0; k <= n; ++k) { b[k] = (float)(bn[k] * sa / sb); a[k] = (float)ar[k]; }
+}
+
+void make_window(int type, std::vector<float> &w)
+{
+  const size_t n = w.size();
+  const double d = (double)(n - 1);
+  for (size_t i = 0; i < n; ++i) {
+    const double t = 2.0 * kPi * (double)i / d;
+    double v = 1.0;
+    switch (type) {
+      case SUAMD_WINDOW_HAMMING: v = 0.54 - 0.46 * std::cos(t); break;
+      case SUAMD_WINDOW_HANN:    v = 0.5 - 0.5 * std::cos(t); break;
+      case SUAMD_WINDOW_FLAT_TOP:
+        v = 0.21557895 - 0.41663158 * std::cos(t) + 0.277263158 * std::cos(2 * t)
+          - 0.083578947 * std::cos(3 * t) + 0.006947368 * std::cos(4 * t);
+        break;
+      case SUAMD_WINDOW_BLACKMANN_HARRIS:
+        v = 0.35875 - 0.48829 * std::cos(t) + 0.14128 * std::cos(2 * t) - 0.01168 * std::cos(3 * t);
+        break;
+      default: v = 1.0;
+    }
+    w[i] = (float)v;
+  }
+}
+
+}  // namespace
+
+// ==========================================================================================
+struct suamd_ctx {
+  int device;
+};
+
+struct suamd_psd {
+  suamd_ctx *ctx;
+  unsigned n, log2n;
+  float *d_window;
+  void  *d_twiddle;      // float2[n]
+};
+
+struct suamd_chanbank {
+  suamd_ctx *ctx;
+  unsigned nchan, D, ntaps;
+  uint64_t n_total;      // samples consumed so far (absolute index of the next x[0])
+  float    *d_taps;      // real prototype [ntaps]
+  void     *d_g;         // float2 [nchan][ntaps]
+  uint32_t *d_dphase, *d_phase0;
+  void     *d_hist;      // float2 [ntaps-1]
+};
+
+struct suamd_costas_bank {
+  suamd_ctx *ctx;
+  unsigned nchan;
+  sdk::CostasParams p;
+  sdk::CostasState  s;
+};
+
+struct suamd_pll_bank {
+  suamd_ctx *ctx;
+  unsigned nchan;
+  float alpha, beta;
+  sdk::PllState s;
+};
+
+struct suamd_clock_bank {
+  suamd_ctx *ctx;
+  unsigned nchan;
+  sdk::ClockParams p;
+  sdk::ClockState  s;
+};
+
+struct suamd_agc_bank {
+  suamd_ctx *ctx;
+  unsigned nchan;
+  sdk::AgcParams p;
+  sdk::AgcState  s;
+};
+
+extern "C" {
+
+const char *suamd_last_error(void) { return g_err.c_str(); }
+const char *suamd_version(void) { return "sigdigger_amd 0.1 (gfx950)"; }
+
+suamd_ctx_t *suamd_ctx_new(int device_ordinal)
+{
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    set_err("no HIP device available (%s); libsigdigger_amd has no CPU fallback",
+            e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return nullptr;
+  }
+  if (device_ordinal < 0 || device_ordinal >= count) {
+    set_err("device ordinal %d out of range (0..%d)", device_ordinal, count - 1);
+    return nullptr;
+  }
+  HIP_TRY(hipSetDevice(device_ordinal), nullptr);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal), nullptr);
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_err("device %d is %s; this library only carries gfx950 code objects", device_ordinal, prop.gcnArchName);
+    return nullptr;
+  }
+  suamd_ctx *ctx = new (std::nothrow) suamd_ctx;
+  if (!ctx) { set_err("out of memory"); return nullptr; }
+  ctx->device = device_ordinal;
+  return ctx;
+}
+
+void suamd_ctx_destroy(suamd_ctx_t *ctx) { delete ctx; }
+int  suamd_ctx_device(const suamd_ctx_t *ctx) { return ctx ? ctx->device : -1; }
+
+// ---- PSD -----------------------------------------------------------------------------------
+suamd_psd_t *suamd_psd_new(suamd_ctx_t *ctx, unsigned n, int window_type)
+{
+  if (!ctx) { set_err("null context"); return nullptr; }
+  unsigned log2n = 0;
+  while ((1u << log2n) < n) ++log2n;
+  if ((1u << log2n) != n || log2n < 9 || log2n > 14) {
+    set_err("window_size %u unsupported (power of two, 512..16384)", n);
+    return nullptr;
+  }
+  if (window_type < SUAMD_WINDOW_NONE || window_type > SUAMD_WINDOW_BLACKMANN_HARRIS) {
+    set_err("unknown window type %d", window_type);
+    return nullptr;
+  }
+  HIP_TRY(hipSetDevice(ctx->device), nullptr);
+  std::vector<float> w(n);
+  make_window(window_type, w);
+  std::vector<float> tw(2 * (size_t)n);
+  for (unsigned i = 0; i < n; ++i) {
+    const double ang = -2.0 * kPi * (double)i / (double)n;
+    tw[2 * i] = (float)std::cos(ang);
+    tw[2 * i + 1] = (float)std::sin(ang);
+  }
+  suamd_psd *p = new (std::nothrow) suamd_psd;
+  if (!p) { set_err("out of memory"); return nullptr; }
+  p->ctx = ctx; p->n = n; p->log2n = log2n;
+  p->d_window = dev_from_host(w);
+  p->d_twiddle = dev_from_host(tw);
+  if (!p->d_window || !p->d_twiddle) {
+    set_err("device allocation failed");
+    suamd_psd_destroy(p);
+    return nullptr;
+  }
+  return p;
+}
+
+void suamd_psd_destroy(suamd_psd_t *p)
+{
+  if (!p) return;
+  if (p->d_window) hipFree(p->d_window);
+  if (p->d_twiddle) hipFree(p->d_twiddle);
+  delete p;
+}
+
+SUBOOL suamd_psd_feed(suamd_psd_t *p, const suamd_complex *d_x, SUSCOUNT nframes, SUSCOUNT hop, unsigned navg,
+                      SUFLOAT scale, int mode, SUFLOAT *d_out, void *stream)
+{
+  if (!p || !d_x || !d_out) { set_err("null argument"); return SU_FALSE; }
+  if (navg == 0) { set_err("navg must be >= 1"); return SU_FALSE; }
+  if (mode != SUAMD_PSD_LINEAR && mode != SUAMD_PSD_DB_SHIFTED) { set_err("bad mode %d", mode); return SU_FALSE; }
+  const long long nout = (long long)(nframes / navg);
+  HIP_TRY(sdk::psd_frames((int)p->log2n, d_x, (long long)hop, (int)navg, p->d_window, p->d_twiddle, scale, mode,
+                          d_out, nout, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUBOOL suamd_psd_shift_db(suamd_ctx_t *ctx, SUFLOAT *d_psd, SUSCOUNT n, SUSCOUNT nframes, void *stream)
+{
+  if (!ctx || !d_psd) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(sdk::psd_shift_db(d_psd, (long long)n, (long long)nframes, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUBOOL suamd_averager_feed(suamd_ctx_t *ctx, SUFLOAT *d_last, const SUFLOAT *d_x, SUSCOUNT n, SUFLOAT alpha,
+                           SUBOOL blend, void *stream)
+{
+  if (!ctx || !d_last || !d_x) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(sdk::averager_feed(d_last, d_x, (long long)n, alpha, blend ? 1 : 0, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUBOOL suamd_inspector_spectrum_db_shift(suamd_ctx_t *ctx, SUFLOAT *d_data, SUSCOUNT len, SUSCOUNT nspectra, void *stream)
+{
+  if (!ctx || !d_data) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(sdk::insp_spectrum_db_shift(d_data, (long long)len, (long long)nspectra, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+// ---- NCO -----------------------------------------------------------------------------------
+uint32_t suamd_fnor_to_dphase(double fnor)
+{
+  const long long v = std::llrint(fnor * 2147483648.0);
+  return (uint32_t)(v & 0xFFFFFFFFll);
+}
+
+SUBOOL suamd_xlate_bulk(suamd_ctx_t *ctx, const suamd_complex *d_x, suamd_complex *d_y, SUSCOUNT len,
+                        uint32_t phase0, uint32_t dphase, SUSCOUNT n0, void *stream)
+{
+  if (!ctx || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(sdk::xlate_bulk(d_x, d_y, (long long)len, phase0, dphase, n0, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+// ---- channel bank ----------------------------------------------------------------------------
+void suamd_lpf_design(SUFLOAT *taps, unsigned ntaps, double fc)
+{
+  std::vector<double> d(ntaps);
+  double sum = 0;
+  for (unsigned i = 0; i < ntaps; ++i) {
+    const double t = (double)i - 0.5 * (double)(ntaps - 1);
+    const double a = kPi * fc * t;
+    const double sinc = std::fabs(a) < 1e-12 ? 1.0 : std::sin(a) / a;
+    const double w = ntaps > 1 ? 0.54 - 0.46 * std::cos(2.0 * kPi * (double)i / (double)(ntaps - 1)) : 1.0;
+    d[i] = fc * sinc * w;
+    sum += d[i];
+  }
+  for (unsigned i = 0; i < ntaps; ++i) taps[i] = (float)(d[i] / sum);
+}
+
+suamd_chanbank_t *suamd_chanbank_new(suamd_ctx_t *ctx, unsigned nchan, const double *fnor, unsigned decimation,
+                                     const SUFLOAT *taps, unsigned ntaps)
+{
+  if (!ctx || !fnor || !taps) { set_err("null argument"); return nullptr; }
+  if (nchan == 0 || decimation == 0 || ntaps == 0) { set_err("nchan, decimation and ntaps must be > 0"); return nullptr; }
+  HIP_TRY(hipSetDevice(ctx->device), nullptr);
+  suamd_chanbank *b = new (std::nothrow) suamd_chanbank;
+  if (!b) { set_err("out of memory"); return nullptr; }
+  std::memset(b, 0, sizeof *b);
+  b->ctx = ctx; b->nchan = nchan; b->D = decimation; b->ntaps = ntaps; b->n_total = 0;
+  std::vector<uint32_t> dp(nchan), p0(nchan, 0u);
+  // translate by -fc: Tasks/CarrierXlator.cpp:36 initialises the NCO with -relFreq
+  for (unsigned c = 0; c < nchan; ++c) dp[c] = suamd_fnor_to_dphase(-fnor[c]);
+  b->d_taps   = dev_alloc<float>(ntaps);
+  b->d_g      = dev_alloc<float>(2 * (size_t)nchan * ntaps);
+  b->d_dphase = dev_from_host(dp);
+  b->d_phase0 = dev_from_host(p0);
+  b->d_hist   = dev_zeros<float>(2 * (size_t)(ntaps > 1 ? ntaps - 1 : 1));
+  if (!b->d_taps || !b->d_g || !b->d_dphase || !b->d_phase0 || !b->d_hist ||
+      !dev_upload(b->d_taps, taps, ntaps)) {
+    set_err("device allocation failed");
+    suamd_chanbank_destroy(b);
+    return nullptr;
+  }
+  hipError_t e = sdk::chan_modulate_taps(b->d_taps, (int)ntaps, b->d_dphase, (int)nchan, b->d_g, nullptr);
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  if (e != hipSuccess) {
+    set_err("tap modulation kernel failed: %s", hipGetErrorString(e));
+    suamd_chanbank_destroy(b);
+    return nullptr;
+  }
+  return b;
+}
+
+void suamd_chanbank_destroy(suamd_chanbank_t *b)
+{
+  if (!b) return;
+  if (b->d_taps) hipFree(b->d_taps);
+  if (b->d_g) hipFree(b->d_g);
+  if (b->d_dphase) hipFree(b->d_dphase);
+  if (b->d_phase0) hipFree(b->d_phase0);
+  if (b->d_hist) hipFree(b->d_hist);
+  delete b;
+}
+
+static void chan_out_range(const suamd_chanbank *b, SUSCOUNT len, uint64_t *m_first, SUSCOUNT *n_out)
+{
+  const uint64_t n0 = b->n_total, D = b->D;
+  const uint64_t mf = (n0 + D - 1) / D;
+  *m_first = mf;
+  if (len == 0 || mf * D >= n0 + len) { *n_out = 0; return; }
+  const uint64_t ml = (n0 + len - 1) / D;
+  *n_out = ml - mf + 1;
+}
+
+SUSCOUNT suamd_chanbank_output_count(const suamd_chanbank_t *b, SUSCOUNT len)
+{
+  if (!b) return 0;
+  uint64_t mf; SUSCOUNT n;
+  chan_out_range(b, len, &mf, &n);
+  return n;
+}
+
+SUBOOL suamd_chanbank_feed(suamd_chanbank_t *b, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_y,
+                           SUSCOUNT y_stride, SUSCOUNT *n_out, void *stream)
+{
+  if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  uint64_t mf; SUSCOUNT no;
+  chan_out_range(b, len, &mf, &no);
+  if (no > y_stride) { set_err("y_stride %llu smaller than output count %llu", (unsigned long long)y_stride, (unsigned long long)no); return SU_FALSE; }
+  sdk::ChanFeedArgs a;
+  a.x = d_x; a.hist = b->d_hist; a.len = (long long)len; a.n0 = b->n_total;
+  a.g = b->d_g; a.dphase = b->d_dphase; a.phase0 = b->d_phase0;
+  a.ntaps = (int)b->ntaps; a.nchan = (int)b->nchan; a.D = b->D;
+  a.m_first = mf; a.n_out = (long long)no; a.y = d_y; a.y_stride = (long long)y_stride;
+  HIP_TRY(sdk::chan_feed(a, as_stream(stream)), SU_FALSE);
+  HIP_TRY(sdk::chan_update_hist(b->d_hist, d_x, (long long)len, (int)b->ntaps, as_stream(stream)), SU_FALSE);
+  b->n_total += len;
+  if (n_out) *n_out = no;
+  return SU_TRUE;
+}
+
+SUBOOL suamd_chanbank_reset(suamd_chanbank_t *b, void *stream)
+{
+  if (!b) { set_err("null argument"); return SU_FALSE; }
+  b->n_total = 0;
+  if (b->ntaps > 1)
+    HIP_TRY(hipMemsetAsync(b->d_hist, 0, 2 * sizeof(float) * (b->ntaps - 1), as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+// ---- element-wise ------------------------------------------------------------------------------
+SUBOOL suamd_quad_demod_batch(suamd_ctx_t *ctx, const suamd_complex *d_x, SUSCOUNT x_stride, suamd_complex *d_y,
+                              SUSCOUNT y_stride, unsigned nchan, SUSCOUNT len, const suamd_complex *d_prev,
+                              SUBOOL first, suamd_complex *d_prev_out, void *stream)
+{
+  if (!ctx || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  if (!first && !d_prev) { set_err("d_prev required when first == SU_FALSE"); return SU_FALSE; }
+  HIP_TRY(sdk::quad_demod_batch(d_x, (long long)x_stride, d_y, (long long)y_stride, (int)nchan, (long long)len,
+                                d_prev, first ? 1 : 0, d_prev_out, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUBOOL suamd_delayed_conj_bulk(suamd_ctx_t *ctx, const suamd_complex *d_x, suamd_complex *d_y, SUSCOUNT len,
+                               SUSCOUNT delay, void *stream)
+{
+  if (!ctx || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  if (d_x == d_y) { set_err("delayed_conj cannot run in place"); return SU_FALSE; }
+  HIP_TRY(sdk::delayed_conj_bulk(d_x, d_y, (long long)len, (long long)delay, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUBOOL suamd_histogram_feed_bulk(suamd_ctx_t *ctx, const suamd_complex *d_x, SUSCOUNT len, int space,
+                                 SUFLOAT *d_out, void *stream)
+{
+  if (!ctx || !d_x || !d_out) { set_err("null argument"); return SU_FALSE; }
+  if (space < 0 || space > 2) { set_err("bad space %d", space); return SU_FALSE; }
+  HIP_TRY(sdk::histogram_feed_bulk(d_x, (long long)len, space, d_out, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+// ---- Costas --------------------------------------------------------------------------------------
+suamd_costas_bank_t *suamd_costas_bank_new(suamd_ctx_t *ctx, unsigned nchan, int kind, SUFLOAT fhint, SUFLOAT arm_bw,
+                                           unsigned arm_order, SUFLOAT loop_bw)
+{
+  if (!ctx || nchan == 0) { set_err("bad argument"); return nullptr; }
+  if (kind < SUAMD_COSTAS_BPSK || kind > SUAMD_COSTAS_8PSK) { set_err("unsupported Costas kind %d", kind); return nullptr; }
+  if (arm_order == 0) arm_order = 1;
+  if (arm_order - 1 > 4) { set_err("arm_order %u unsupported (<= 5)", arm_order); return nullptr; }
+  HIP_TRY(hipSetDevice(ctx->device), nullptr);
+  suamd_costas_bank *b = new (std::nothrow) suamd_costas_bank;
+  if (!b) { set_err("out of memory"); return nullptr; }
+  std::memset(b, 0, sizeof *b);
+  b->ctx = ctx; b->nchan = nchan;
+  b->p.kind = kind; b->p.order = (int)arm_order - 1;
+  b->p.a = (float)(kPi * (double)loop_bw);
+  b->p.b = 0.5f * b->p.a * b->p.a;
+  b->p.gain = 1.0f;
+  butter_lp(b->p.order, (double)arm_bw, b->p.fb, b->p.fa);
+  std::vector<float> om(nchan, (float)(kPi * (double)fhint));
+  b->s.phase = dev_zeros<uint32_t>(nchan);
+  b->s.omega = dev_from_host(om);
+  b->s.xh = dev_zeros<float>(8 * (size_t)nchan);
+  b->s.yh = dev_zeros<float>(8 * (size_t)nchan);
+  if (!b->s.phase || !b->s.omega || !b->s.xh || !b->s.yh) {
+    set_err("device allocation failed");
+    suamd_costas_bank_destroy(b);
+    return nullptr;
+  }
+  return b;
+}
+
+void suamd_costas_bank_destroy(suamd_costas_bank_t *b)
+{
+  if (!b) return;
+  if (b->s.phase) hipFree(b->s.phase);
+  if (b->s.omega) hipFree(b->s.omega);
+  if (b->s.xh) hipFree(b->s.xh);
+  if (b->s.yh) hipFree(b->s.yh);
+  delete b;
+}
+
+SUBOOL suamd_costas_bank_feed(suamd_costas_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride, suamd_complex *d_y,
+                              SUSCOUNT y_stride, SUSCOUNT len, void *stream)
+{
+  if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(sdk::costas_feed(b->p, b->s, (int)b->nchan, d_x, (long long)x_stride, d_y, (long long)y_stride,
+                           (long long)len, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUBOOL suamd_costas_bank_get_state(suamd_costas_bank_t *b, SUFLOAT *omega, uint32_t *phase, void *stream)
+{
+  if (!b) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(hipStreamSynchronize(as_stream(stream)), SU_FALSE);
+  if (omega) HIP_TRY(hipMemcpy(omega, b->s.omega, sizeof(float) * b->nchan, hipMemcpyDeviceToHost), SU_FALSE);
+  if (phase) HIP_TRY(hipMemcpy(phase, b->s.phase, sizeof(uint32_t) * b->nchan, hipMemcpyDeviceToHost), SU_FALSE);
+  return SU_TRUE;
+}
+
+// ---- PLL -----------------------------------------------------------------------------------------
+suamd_pll_bank_t *suamd_pll_bank_new(suamd_ctx_t *ctx, unsigned nchan, SUFLOAT fhint, SUFLOAT fc)
+{
+  if (!ctx || nchan == 0) { set_err("bad argument"); return nullptr; }
+  HIP_TRY(hipSetDevice(ctx->device), nullptr);
+  suamd_pll_bank *b = new (std::nothrow) suamd_pll_bank;
+  if (!b) { set_err("out of memory"); return nullptr; }
+  std::memset(b, 0, sizeof *b);
+  b->ctx = ctx; b->nchan = nchan;
+  const double w = kPi * (double)fc;
+  const double dinv = 1.0 / (1.0 + 2.0 * 0.707 * w + w * w);
+  b->alpha = (float)(4.0 * w * w * dinv);
+  b->beta  = (float)(4.0 * 0.707 * w * dinv);
+  std::vector<float> om(nchan, (float)(kPi * (double)fhint));
+  b->s.phase = dev_zeros<uint32_t>(nchan);
+  b->s.omega = dev_from_host(om);
+  if (!b->s.phase || !b->s.omega) { set_err("device allocation failed"); suamd_pll_bank_destroy(b); return nullptr; }
+  return b;
+}
+
+void suamd_pll_bank_destroy(suamd_pll_bank_t *b)
+{
+  if (!b) return;
+  if (b->s.phase) hipFree(b->s.phase);
+  if (b->s.omega) hipFree(b->s.omega);
+  delete b;
+}
+
+SUBOOL suamd_pll_bank_feed(suamd_pll_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride, suamd_complex *d_y,
+                           SUSCOUNT y_stride, SUSCOUNT len, void *stream)
+{
+  if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(sdk::pll_feed(b->alpha, b->beta, b->s, (int)b->nchan, d_x, (long long)x_stride, d_y, (long long)y_stride,
+                        (long long)len, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUBOOL suamd_pll_bank_get_state(suamd_pll_bank_t *b, SUFLOAT *omega, uint32_t *phase, void *stream)
+{
+  if (!b) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(hipStreamSynchronize(as_stream(stream)), SU_FALSE);
+  if (omega) HIP_TRY(hipMemcpy(omega, b->s.omega, sizeof(float) * b->nchan, hipMemcpyDeviceToHost), SU_FALSE);
+  if (phase) HIP_TRY(hipMemcpy(phase, b->s.phase, sizeof(uint32_t) * b->nchan, hipMemcpyDeviceToHost), SU_FALSE);
+  return SU_TRUE;
+}
+
+// ---- clock recovery --------------------------------------------------------------------------------
+suamd_clock_bank_t *suamd_clock_bank_new(suamd_ctx_t *ctx, unsigned nchan, SUFLOAT loop_gain, SUFLOAT bhint)
+{
+  if (!ctx || nchan == 0) { set_err("bad argument"); return nullptr; }
+  if (!(bhint > 0.0f)) { set_err("bhint must be > 0"); return nullptr; }
+  HIP_TRY(hipSetDevice(ctx->device), nullptr);
+  suamd_clock_bank *b = new (std::nothrow) suamd_clock_bank;
+  if (!b) { set_err("out of memory"); return nullptr; }
+  std::memset(b, 0, sizeof *b);
+  b->ctx = ctx; b->nchan = nchan;
+  b->p.alpha = 2e-1f; b->p.beta = 1.2e-4f; b->p.gain = loop_gain;
+  b->p.bmin = 0.5f * bhint;
+  b->p.bmax = bhint > 0.5f ? 1.0f : 2.0f * bhint;
+  std::vector<float> phi(nchan, 0.25f), bn(nchan, bhint);
+  b->s.phi = dev_from_host(phi);
+  b->s.bnor = dev_from_host(bn);
+  b->s.halfcycle = dev_zeros<int>(nchan);
+  b->s.prev = dev_zeros<float>(2 * (size_t)nchan);
+  b->s.x0 = dev_zeros<float>(2 * (size_t)nchan);
+  b->s.x1 = dev_zeros<float>(2 * (size_t)nchan);
+  b->s.x2 = dev_zeros<float>(2 * (size_t)nchan);
+  if (!b->s.phi || !b->s.bnor || !b->s.halfcycle || !b->s.prev || !b->s.x0 || !b->s.x1 || !b->s.x2) {
+    set_err("device allocation failed");
+    suamd_clock_bank_destroy(b);
+    return nullptr;
+  }
+  return b;
+}
+
+void suamd_clock_bank_destroy(suamd_clock_bank_t *b)
+{
+  if (!b) return;
+  if (b->s.phi) hipFree(b->s.phi);
+  if (b->s.bnor) hipFree(b->s.bnor);
+  if (b->s.halfcycle) hipFree(b->s.halfcycle);
+  if (b->s.prev) hipFree(b->s.prev);
+  if (b->s.x0) hipFree(b->s.x0);
+  if (b->s.x1) hipFree(b->s.x1);
+  if (b->s.x2) hipFree(b->s.x2);
+  delete b;
+}
+
+SUBOOL suamd_clock_bank_feed(suamd_clock_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride, SUSCOUNT len,
+                             suamd_complex *d_sym, SUSCOUNT sym_stride, uint32_t *d_count, void *stream)
+{
+  if (!b || !d_x || !d_sym || !d_count) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(sdk::clock_feed(b->p, b->s, (int)b->nchan, d_x, (long long)x_stride, (long long)len, d_sym,
+                          (long long)sym_stride, d_count, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUBOOL suamd_clock_bank_get_state(suamd_clock_bank_t *b, SUFLOAT *bnor, SUFLOAT *phi, void *stream)
+{
+  if (!b) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(hipStreamSynchronize(as_stream(stream)), SU_FALSE);
+  if (bnor) HIP_TRY(hipMemcpy(bnor, b->s.bnor, sizeof(float) * b->nchan, hipMemcpyDeviceToHost), SU_FALSE);
+  if (phi)  HIP_TRY(hipMemcpy(phi, b->s.phi, sizeof(float) * b->nchan, hipMemcpyDeviceToHost), SU_FALSE);
+  return SU_TRUE;
+}
+
+// ---- AGC -------------------------------------------------------------------------------------------
+void suamd_agc_params_from_tau(struct suamd_agc_params *p, SUFLOAT tau)
+{
+  const struct suamd_agc_params def = suamd_agc_params_INITIALIZER;
+  const double rise = 2 * 3.9062e-1;
+  *p = def;
+  p->fast_rise_t = (float)(tau * rise);
+  p->fast_fall_t = (float)(tau * 2 * rise);
+  p->slow_rise_t = (float)(tau * 10 * rise);
+  p->slow_fall_t = (float)(tau * 10 * 2 * rise);
+  p->hang_max    = (unsigned)(tau * rise * 5);
+}
+
+suamd_agc_bank_t *suamd_agc_bank_new(suamd_ctx_t *ctx, unsigned nchan, const struct suamd_agc_params *pp)
+{
+  if (!ctx || nchan == 0 || !pp) { set_err("bad argument"); return nullptr; }
+  if (pp->delay_line_size == 0 || pp->delay_line_size > 64 || pp->mag_history_size == 0 || pp->mag_history_size > 64) {
+    set_err("delay_line_size / mag_history_size must be in 1..64");
+    return nullptr;
+  }
+  HIP_TRY(hipSetDevice(ctx->device), nullptr);
+  suamd_agc_bank *b = new (std::nothrow) suamd_agc_bank;
+  if (!b) { set_err("out of memory"); return nullptr; }
+  std::memset(b, 0, sizeof *b);
+  b->ctx = ctx; b->nchan = nchan;
+  b->p.knee = pp->threshold;
+  b->p.gain_slope = pp->slope_factor * 1e-2f;
+  b->p.hang_max = pp->hang_max;
+  b->p.delay_line_size = pp->delay_line_size;
+  b->p.mag_history_size = pp->mag_history_size;
+  b->p.fast_alpha_rise = (float)(1.0 - std::exp(-1.0 / (double)pp->fast_rise_t));
+  b->p.fast_alpha_fall = (float)(1.0 - std::exp(-1.0 / (double)pp->fast_fall_t));
+  b->p.slow_alpha_rise = (float)(1.0 - std::exp(-1.0 / (double)pp->slow_rise_t));
+  b->p.slow_alpha_fall = (float)(1.0 - std::exp(-1.0 / (double)pp->slow_fall_t));
+  b->s.delay_line = dev_zeros<float>(64 * 2 * (size_t)nchan);
+  b->s.mag_history = dev_zeros<float>(64 * (size_t)nchan);
+  b->s.delay_ptr = dev_zeros<unsigned>(nchan);
+  b->s.hist_ptr = dev_zeros<unsigned>(nchan);
+  b->s.hang_n = dev_zeros<unsigned>(nchan);
+  b->s.peak = dev_zeros<float>(nchan);
+  b->s.fast_level = dev_zeros<float>(nchan);
+  b->s.slow_level = dev_zeros<float>(nchan);
+  if (!b->s.delay_line || !b->s.mag_history || !b->s.delay_ptr || !b->s.hist_ptr || !b->s.hang_n || !b->s.peak ||
+      !b->s.fast_level || !b->s.slow_level) {
+    set_err("device allocation failed");
+    suamd_agc_bank_destroy(b);
+    return nullptr;
+  }
+  return b;
+}
+
+void suamd_agc_bank_destroy(suamd_agc_bank_t *b)
+{
+  if (!b) return;
+  if (b->s.delay_line) hipFree(b->s.delay_line);
+  if (b->s.mag_history) hipFree(b->s.mag_history);
+  if (b->s.delay_ptr) hipFree(b->s.delay_ptr);
+  if (b->s.hist_ptr) hipFree(b->s.hist_ptr);
+  if (b->s.hang_n) hipFree(b->s.hang_n);
+  if (b->s.peak) hipFree(b->s.peak);
+  if (b->s.fast_level) hipFree(b->s.fast_level);
+  if (b->s.slow_level) hipFree(b->s.slow_level);
+  delete b;
+}
+
+SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride, suamd_complex *d_y,
+                           SUSCOUNT y_stride, SUSCOUNT len, void *stream)
+{
+  if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(sdk::agc_feed(b->p, b->s, (int)b->nchan, d_x, (long long)x_stride, d_y, (long long)y_stride,
+                        (long long)len, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// kernels.hpp -- internal launch interface between the C-ABI layer (capi.hip) and the
+// gfx950 kernels.  Not installed; the public boundary is include/sigdigger_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sdk {
+
+// ---- psd.hip ----
+hipError_t psd_frames(int log2n, const void *x, long long hop, int navg, const float *window,
+                      const void *tw, float scale, int mode, float *out, long long nout, hipStream_t st);
+hipError_t psd_shift_db(float *psd, long long n, long long nframes, hipStream_t st);
+hipError_t averager_feed(float *last, const float *x, long long n, float alpha, int blend, hipStream_t st);
+hipError_t insp_spectrum_db_shift(float *data, long long len, long long nspec, hipStream_t st);
+
+// ---- chan.hip ----
+hipError_t xlate_bulk(const void *x, void *y, long long len, uint32_t p0, uint32_t dp, uint64_t n0, hipStream_t st);
+hipError_t chan_modulate_taps(const float *h, int ntaps, const uint32_t *dphase, int nchan, void *g, hipStream_t st);
+struct ChanFeedArgs {
+  const void *x;        // input block (device), len samples
+  const void *hist;     // ntaps-1 samples preceding x[0] (device)
+  long long   len;
+  uint64_t    n0;       // absolute index of x[0]
+  const void *g;        // [nchan][ntaps] modulated taps
+  const uint32_t *dphase;   // [nchan]
+  const uint32_t *phase0;   // [nchan]
+  int         ntaps, nchan;
+  uint32_t    D;
+  uint64_t    m_first;  // first output index (n = m*D)
+  long long   n_out;
+  void       *y;        // [nchan][y_stride]
+  long long   y_stride;
+};
+hipError_t chan_feed(const ChanFeedArgs &a, hipStream_t st);
+hipError_t chan_update_hist(void *hist, const void *x, long long len, int ntaps, hipStream_t st);
+
+// ---- loops.hip ----
+hipError_t quad_demod_batch(const void *x, long long xs, void *y, long long ys, int nchan, long long len,
+                            const void *prev, int first, void *prev_out, hipStream_t st);
+hipError_t delayed_conj_bulk(const void *x, void *y, long long len, long long delay, hipStream_t st);
+hipError_t histogram_feed_bulk(const void *x, long long len, int space, float *out, hipStream_t st);
+
+struct CostasState {            // SoA over channels, all device pointers
+  uint32_t *phase; float *omega;
+  float *xh; float *yh;         // [4][2][nchan] : history index, re/im, channel
+};
+struct CostasParams { int kind; int order; float a, b, gain; float fb[5]; float fa[5]; };
+hipError_t costas_feed(const CostasParams &p, const CostasState &s, int nchan, const void *x, long long xs,
+                       void *y, long long ys, long long len, hipStream_t st);
+
+struct PllState { uint32_t *phase; float *omega; };
+hipError_t pll_feed(float alpha, float beta, const PllState &s, int nchan, const void *x, long long xs,
+                    void *y, long long ys, long long len, hipStream_t st);
+
+struct ClockState {             // all [nchan]
+  float *phi, *bnor; int *halfcycle; float *prev, *x0, *x1, *x2;   // complex ones: [2][nchan]
+};
+struct ClockParams { float alpha, beta, gain, bmin, bmax; };
+hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, const void *x, long long xs,
+                      long long len, void *sym, long long sym_stride, uint32_t *count, hipStream_t st);
+
+struct AgcParams {
+  float knee, gain_slope;
+  float fast_alpha_rise, fast_alpha_fall, slow_alpha_rise, slow_alpha_fall;
+  unsigned hang_max, delay_line_size, mag_history_size;
+};
+struct AgcState {               // device
+  float *delay_line;            // [64][2][nchan]
+  float *mag_history;           // [64][nchan]
+  unsigned *delay_ptr, *hist_ptr, *hang_n;
+  float *peak, *fast_level, *slow_level;
+};
+hipError_t agc_feed(const AgcParams &p, const AgcState &s, int nchan, const void *x, long long xs,
+                    void *y, long long ys, long long len, hipStream_t st);
+
+}  // namespace sdk

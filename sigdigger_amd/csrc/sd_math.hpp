@@ -1,0 +1,136 @@
+// sd_math.hpp -- deterministic binary32 primitives for gfx950 device code (SPEC.md section D).
+//
+// Every function is a fixed sequence of IEEE-754 binary32 operations; the translation unit
+// MUST be compiled with -ffp-contract=off so that only the __builtin_fmaf calls below fuse.
+// hipcc's default float division / sqrt are correctly rounded
+// (-fhip-fp32-correctly-rounded-divide-sqrt), which the SPEC relies on.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sd {
+
+struct c32 { float re, im; };
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// D1: 32-bit phase (2^32 per turn) -> cos/sin. Quadrant reduction + Cephes minimax kernels.
+__device__ __forceinline__ void phasor_u32(uint32_t p, float &c, float &s)
+{
+  const uint32_t q = (p + 0x20000000u) >> 30;
+  const int32_t  r = (int32_t)(p - (q << 30));
+  const float x  = (float)r * 1.46291807926715968e-9f;
+  const float z  = x * x;
+  float sp = fma_(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  sp = fma_(sp, z, -1.6666654611e-1f);
+  const float sn = fma_(sp * z, x, x);
+  float cp = fma_(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  cp = fma_(cp, z, 4.166664568298827e-2f);
+  const float cs = fma_(cp * z, z, fma_(z, -0.5f, 1.0f));
+  // rotate by q quarter turns
+  const float a = (q & 1u) ? sn : cs;       // |cos| source
+  const float b = (q & 1u) ? cs : sn;       // |sin| source
+  c = (q == 1u || q == 2u) ? -a : a;
+  s = (q >= 2u) ? -b : b;
+}
+
+// D2: atan2 (radians), Cephes atanf kernel on min/max.
+__device__ __forceinline__ float atan2_(float y, float x)
+{
+  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+  const float mx = ax > ay ? ax : ay;
+  const float mn = ax > ay ? ay : ax;
+  if (mx == 0.0f) return 0.0f;
+  float t  = mn / mx;
+  float y0 = 0.0f;
+  if (t > 0.4142135623730950f) {
+    y0 = 0.78539816339744830962f;
+    t  = (t - 1.0f) / (t + 1.0f);
+  }
+  const float z = t * t;
+  float p = fma_(8.05374449538e-2f, z, -1.38776856032e-1f);
+  p = fma_(p, z, 1.99777106478e-1f);
+  p = fma_(p, z, -3.33329491539e-1f);
+  float a = fma_(p * z, t, t) + y0;
+  if (ay > ax)  a = 1.57079632679489661923f - a;
+  if (x < 0.0f) a = 3.14159265358979323846f - a;
+  if (y < 0.0f) a = -a;
+  return a;
+}
+
+// D3: log2 of a normal positive float.
+__device__ __forceinline__ float log2_(float x)
+{
+  const uint32_t bits = __float_as_uint(x);
+  int32_t e = (int32_t)(bits >> 23) - 127;
+  float   m = __uint_as_float((bits & 0x007FFFFFu) | 0x3F800000u);
+  if (m > 1.41421356237309504880f) { m = m * 0.5f; e = e + 1; }
+  const float f = m - 1.0f;
+  const float z = f * f;
+  float y = 7.0376836292e-2f;
+  y = fma_(y, f, -1.1514610310e-1f);
+  y = fma_(y, f,  1.1676998740e-1f);
+  y = fma_(y, f, -1.2420140846e-1f);
+  y = fma_(y, f,  1.4249322787e-1f);
+  y = fma_(y, f, -1.6668057665e-1f);
+  y = fma_(y, f,  2.0000714765e-1f);
+  y = fma_(y, f, -2.4999993993e-1f);
+  y = fma_(y, f,  3.3333331174e-1f);
+  y = (y * f) * z;
+  y = fma_(-0.5f, z, y);
+  const float ln = f + y;
+  return fma_(ln, 1.44269504088896341f, (float)e);
+}
+
+// D4: 2^x, x clamped to [-126, 126].
+__device__ __forceinline__ float exp2_(float x)
+{
+  if (x >  126.0f) x =  126.0f;
+  if (x < -126.0f) x = -126.0f;
+  const float fl = __builtin_floorf(x + 0.5f);
+  const int32_t n = (int32_t)fl;
+  const float t = (x - fl) * 0.693147180559945309417f;
+  const float z = t * t;
+  float y = 1.9875691500e-4f;
+  y = fma_(y, t, 1.3981999507e-3f);
+  y = fma_(y, t, 8.3334519073e-3f);
+  y = fma_(y, t, 4.1665795894e-2f);
+  y = fma_(y, t, 1.6666665459e-1f);
+  y = fma_(y, t, 5.0000001201e-1f);
+  y = fma_(y, z, t) + 1.0f;
+  return y * __uint_as_float((uint32_t)(n + 127) << 23);
+}
+
+__device__ __forceinline__ int32_t rad_to_dphase(float d)
+{
+  if (d >  3.1415925f) d =  3.1415925f;
+  if (d < -3.1415925f) d = -3.1415925f;
+  return (int32_t)(d * 683565275.57643158978f);
+}
+
+__device__ __forceinline__ float phase_to_rad(uint32_t p)
+{
+  return (float)(int32_t)p * 1.46291807926715968e-9f;
+}
+
+// (a.re + j a.im)(c + j s)
+__device__ __forceinline__ c32 cmul_cs(c32 a, float c, float s)
+{
+  c32 r;
+  r.re = fma_(-a.im, s, a.re * c);
+  r.im = fma_( a.im, c, a.re * s);
+  return r;
+}
+
+// a * conj(b)
+__device__ __forceinline__ c32 cmul_conj(c32 a, c32 b)
+{
+  c32 r;
+  r.re = fma_(a.im, b.im, a.re * b.re);
+  r.im = fma_(a.im, b.re, -(a.re * b.im));
+  return r;
+}
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+}  // namespace sd

@@ -1,0 +1,329 @@
+"""Host-side plumbing over the C ABI (include/sigdigger_amd.h) for Python callers.
+
+PyTorch is used only as the owner of device memory and streams (and torch.distributed for
+the multi-GPU IQ broadcast in pipeline.py); every computation happens inside
+libsigdigger_amd.so.  Tensors are torch.complex64 / float32 CUDA tensors, whose memory layout
+is exactly SUCOMPLEX / SUFLOAT.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as _l
+from .lib import SigDiggerAmdError, check
+
+WINDOW_NONE, WINDOW_HAMMING, WINDOW_HANN, WINDOW_FLAT_TOP, WINDOW_BLACKMANN_HARRIS = range(5)
+PSD_LINEAR, PSD_DB_SHIFTED = 0, 1
+COSTAS_BPSK, COSTAS_QPSK, COSTAS_8PSK = 1, 2, 3
+
+
+def _stream(stream=None):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _chk_c64(t, name):
+    if not (t.is_cuda and t.dtype == torch.complex64 and t.is_contiguous()):
+        raise SigDiggerAmdError(f"{name} must be a contiguous CUDA complex64 tensor")
+
+
+def _chk_rows(t, name):
+    if not (t.is_cuda and t.dtype == torch.complex64 and t.dim() == 2 and t.stride(1) == 1):
+        raise SigDiggerAmdError(f"{name} must be a CUDA complex64 [channels, time] tensor with unit time stride")
+
+
+class Context:
+    """suamd_ctx_t: binds one GPU (replaces suscan_sigutils_init for this path)."""
+
+    def __init__(self, device=0):
+        self.lib = _l.load()
+        self.device = int(device)
+        self.h = self.lib.suamd_ctx_new(self.device)
+        if not self.h:
+            raise SigDiggerAmdError("suamd_ctx_new: " + _l.last_error())
+
+    def close(self):
+        if self.h:
+            self.lib.suamd_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- element-wise entry points -------------------------------------------------------
+    def psd_shift_db(self, psd, stream=None):
+        """PSDMessage ctor loop, in place on [frames, n] (or [n])."""
+        n = psd.shape[-1]
+        nfr = psd.numel() // n
+        check(self.lib.suamd_psd_shift_db(self.h, _ptr(psd), n, nfr, _stream(stream)), "suamd_psd_shift_db")
+        return psd
+
+    def averager_feed(self, last, x, alpha, blend=True, stream=None):
+        check(self.lib.suamd_averager_feed(self.h, _ptr(last), _ptr(x), x.numel(), float(alpha), int(blend),
+                                           _stream(stream)), "suamd_averager_feed")
+        return last
+
+    def inspector_spectrum_db_shift(self, data, stream=None):
+        n = data.shape[-1]
+        check(self.lib.suamd_inspector_spectrum_db_shift(self.h, _ptr(data), n, data.numel() // n,
+                                                         _stream(stream)), "suamd_inspector_spectrum_db_shift")
+        return data
+
+    def fnor_to_dphase(self, fnor):
+        return int(self.lib.suamd_fnor_to_dphase(float(fnor)))
+
+    def xlate(self, x, phase0, dphase, n0=0, out=None, stream=None):
+        _chk_c64(x, "x")
+        if out is None:
+            out = torch.empty_like(x)
+        check(self.lib.suamd_xlate_bulk(self.h, _ptr(x), _ptr(out), x.numel(), phase0 & 0xFFFFFFFF,
+                                        dphase & 0xFFFFFFFF, int(n0), _stream(stream)), "suamd_xlate_bulk")
+        return out
+
+    def quad_demod(self, x, prev=None, first=True, out=None, prev_out=None, stream=None):
+        """x: [channels, len] (or [len]).  Tasks/QuadDemodTask.cpp loop per row."""
+        x2 = x if x.dim() == 2 else x.unsqueeze(0)
+        _chk_rows(x2, "x")
+        if out is None:
+            out = torch.empty_like(x2)
+        o2 = out if out.dim() == 2 else out.unsqueeze(0)
+        check(self.lib.suamd_quad_demod_batch(
+            self.h, _ptr(x2), x2.stride(0), _ptr(o2), o2.stride(0), x2.shape[0], x2.shape[1],
+            _ptr(prev) if prev is not None else None, int(first),
+            _ptr(prev_out) if prev_out is not None else None, _stream(stream)), "suamd_quad_demod_batch")
+        return out if x.dim() == 2 else o2[0]
+
+    def delayed_conj(self, x, delay, out=None, stream=None):
+        _chk_c64(x, "x")
+        if out is None:
+            out = torch.empty_like(x)
+        check(self.lib.suamd_delayed_conj_bulk(self.h, _ptr(x), _ptr(out), x.numel(), int(delay),
+                                               _stream(stream)), "suamd_delayed_conj_bulk")
+        return out
+
+    def histogram_feed(self, x, space, stream=None):
+        _chk_c64(x, "x")
+        n = x.numel() - (1 if space == 2 else 0)
+        out = torch.empty(max(n, 0), dtype=torch.float32, device=x.device)
+        check(self.lib.suamd_histogram_feed_bulk(self.h, _ptr(x), x.numel(), int(space), _ptr(out),
+                                                 _stream(stream)), "suamd_histogram_feed_bulk")
+        return out
+
+    def lpf_design(self, ntaps, fc):
+        h = np.empty(ntaps, dtype=np.float32)
+        self.lib.suamd_lpf_design(h.ctypes.data_as(C.c_void_p), ntaps, float(fc))
+        return h
+
+
+class PSD:
+    """suamd_psd_t: plan for detector_params.window_size / .window."""
+
+    def __init__(self, ctx, window_size, window=WINDOW_BLACKMANN_HARRIS):
+        self.ctx = ctx
+        self.n = int(window_size)
+        self.h = ctx.lib.suamd_psd_new(ctx.h, self.n, int(window))
+        if not self.h:
+            raise SigDiggerAmdError("suamd_psd_new: " + _l.last_error())
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.suamd_psd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def feed(self, x, nframes=None, hop=None, navg=1, scale=1.0, mode=PSD_LINEAR, out=None, stream=None):
+        _chk_c64(x, "x")
+        hop = self.n if hop is None else int(hop)
+        if nframes is None:
+            nframes = (x.numel() - self.n) // hop + 1 if x.numel() >= self.n else 0
+        if nframes and (nframes - 1) * hop + self.n > x.numel():
+            raise SigDiggerAmdError("x too short for nframes")
+        nout = nframes // navg
+        if out is None:
+            out = torch.empty((nout, self.n), dtype=torch.float32, device=x.device)
+        check(self.ctx.lib.suamd_psd_feed(self.h, _ptr(x), nframes, hop, navg, float(scale), int(mode),
+                                          _ptr(out), _stream(stream)), "suamd_psd_feed")
+        return out
+
+
+class ChannelBank:
+    """suamd_chanbank_t: translate + low-pass + decimate for a bank of inspector channels."""
+
+    def __init__(self, ctx, fnor, decimation, taps):
+        self.ctx = ctx
+        fn = np.ascontiguousarray(fnor, dtype=np.float64)
+        tp = np.ascontiguousarray(taps, dtype=np.float32)
+        self.nchan, self.D, self.ntaps = fn.size, int(decimation), tp.size
+        self.h = ctx.lib.suamd_chanbank_new(ctx.h, fn.size, fn.ctypes.data_as(C.c_void_p), self.D,
+                                            tp.ctypes.data_as(C.c_void_p), tp.size)
+        if not self.h:
+            raise SigDiggerAmdError("suamd_chanbank_new: " + _l.last_error())
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.suamd_chanbank_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def output_count(self, length):
+        return int(self.ctx.lib.suamd_chanbank_output_count(self.h, int(length)))
+
+    def feed(self, x, out=None, stream=None):
+        """x: [len] complex64.  Returns out[:, :n_out] (channel-major)."""
+        _chk_c64(x, "x")
+        n = self.output_count(x.numel())
+        if out is None:
+            out = torch.empty((self.nchan, max(n, 1)), dtype=torch.complex64, device=x.device)
+        _chk_rows(out, "out")
+        nout = C.c_uint64(0)
+        check(self.ctx.lib.suamd_chanbank_feed(self.h, _ptr(x), x.numel(), _ptr(out), out.stride(0),
+                                               C.byref(nout), _stream(stream)), "suamd_chanbank_feed")
+        return out[:, :nout.value]
+
+    def reset(self, stream=None):
+        check(self.ctx.lib.suamd_chanbank_reset(self.h, _stream(stream)), "suamd_chanbank_reset")
+
+
+class _LoopBank:
+    _destroy = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            getattr(self.ctx.lib, self._destroy)(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _rows(self, x, out):
+        _chk_rows(x, "x")
+        if x.shape[0] != self.nchan:
+            raise SigDiggerAmdError(f"expected {self.nchan} rows, got {x.shape[0]}")
+        if out is None:
+            out = torch.empty_like(x)
+        _chk_rows(out, "out")
+        return out
+
+
+class CostasBank(_LoopBank):
+    """nchan x su_costas_t (Tasks/CostasRecoveryTask.cpp)."""
+    _destroy = "suamd_costas_bank_destroy"
+
+    def __init__(self, ctx, nchan, kind, fhint, arm_bw, arm_order, loop_bw):
+        self.ctx, self.nchan = ctx, int(nchan)
+        self.h = ctx.lib.suamd_costas_bank_new(ctx.h, self.nchan, int(kind), float(fhint), float(arm_bw),
+                                               int(arm_order), float(loop_bw))
+        if not self.h:
+            raise SigDiggerAmdError("suamd_costas_bank_new: " + _l.last_error())
+
+    def feed(self, x, out=None, stream=None):
+        out = self._rows(x, out)
+        check(self.ctx.lib.suamd_costas_bank_feed(self.h, _ptr(x), x.stride(0), _ptr(out), out.stride(0),
+                                                  x.shape[1], _stream(stream)), "suamd_costas_bank_feed")
+        return out
+
+    def state(self, stream=None):
+        om = np.empty(self.nchan, dtype=np.float32)
+        ph = np.empty(self.nchan, dtype=np.uint32)
+        check(self.ctx.lib.suamd_costas_bank_get_state(self.h, om.ctypes.data_as(C.c_void_p),
+                                                       ph.ctypes.data_as(C.c_void_p), _stream(stream)),
+              "suamd_costas_bank_get_state")
+        return om, ph
+
+
+class PLLBank(_LoopBank):
+    """nchan x su_pll_t (Tasks/PLLSyncTask.cpp)."""
+    _destroy = "suamd_pll_bank_destroy"
+
+    def __init__(self, ctx, nchan, fhint, fc):
+        self.ctx, self.nchan = ctx, int(nchan)
+        self.h = ctx.lib.suamd_pll_bank_new(ctx.h, self.nchan, float(fhint), float(fc))
+        if not self.h:
+            raise SigDiggerAmdError("suamd_pll_bank_new: " + _l.last_error())
+
+    def feed(self, x, out=None, stream=None):
+        out = self._rows(x, out)
+        check(self.ctx.lib.suamd_pll_bank_feed(self.h, _ptr(x), x.stride(0), _ptr(out), out.stride(0),
+                                               x.shape[1], _stream(stream)), "suamd_pll_bank_feed")
+        return out
+
+    def state(self, stream=None):
+        om = np.empty(self.nchan, dtype=np.float32)
+        ph = np.empty(self.nchan, dtype=np.uint32)
+        check(self.ctx.lib.suamd_pll_bank_get_state(self.h, om.ctypes.data_as(C.c_void_p),
+                                                    ph.ctypes.data_as(C.c_void_p), _stream(stream)),
+              "suamd_pll_bank_get_state")
+        return om, ph
+
+
+class ClockBank(_LoopBank):
+    """nchan x su_clock_detector_t, Gardner (Tasks/WaveSampler.cpp:177-213)."""
+    _destroy = "suamd_clock_bank_destroy"
+
+    def __init__(self, ctx, nchan, loop_gain, bhint):
+        self.ctx, self.nchan = ctx, int(nchan)
+        self.h = ctx.lib.suamd_clock_bank_new(ctx.h, self.nchan, float(loop_gain), float(bhint))
+        if not self.h:
+            raise SigDiggerAmdError("suamd_clock_bank_new: " + _l.last_error())
+
+    def feed(self, x, sym, count, stream=None):
+        """Appends recovered symbols of row c at sym[c, count[c]...]; count is uint32-as-int32 [nchan]."""
+        _chk_rows(x, "x")
+        _chk_rows(sym, "sym")
+        check(self.ctx.lib.suamd_clock_bank_feed(self.h, _ptr(x), x.stride(0), x.shape[1], _ptr(sym),
+                                                 sym.stride(0), _ptr(count), _stream(stream)),
+              "suamd_clock_bank_feed")
+        return sym, count
+
+    def state(self, stream=None):
+        bn = np.empty(self.nchan, dtype=np.float32)
+        ph = np.empty(self.nchan, dtype=np.float32)
+        check(self.ctx.lib.suamd_clock_bank_get_state(self.h, bn.ctypes.data_as(C.c_void_p),
+                                                      ph.ctypes.data_as(C.c_void_p), _stream(stream)),
+              "suamd_clock_bank_get_state")
+        return bn, ph
+
+
+class AGCBank(_LoopBank):
+    """nchan x su_agc_t (Tasks/AGCTask.cpp)."""
+    _destroy = "suamd_agc_bank_destroy"
+
+    def __init__(self, ctx, nchan, params=None, tau=None):
+        self.ctx, self.nchan = ctx, int(nchan)
+        p = _l.AgcParams(-100.0, 6.0, 100, 20, 20, 2.0, 4.0, 20.0, 40.0)
+        if tau is not None:
+            ctx.lib.suamd_agc_params_from_tau(C.byref(p), float(tau))
+        if params is not None:
+            p = params
+        self.params = p
+        self.h = ctx.lib.suamd_agc_bank_new(ctx.h, self.nchan, C.byref(p))
+        if not self.h:
+            raise SigDiggerAmdError("suamd_agc_bank_new: " + _l.last_error())
+
+    def feed(self, x, out=None, stream=None):
+        out = self._rows(x, out)
+        check(self.ctx.lib.suamd_agc_bank_feed(self.h, _ptr(x), x.stride(0), _ptr(out), out.stride(0),
+                                               x.shape[1], _stream(stream)), "suamd_agc_bank_feed")
+        return out

@@ -1,0 +1,102 @@
+"""ctypes loader for libsigdigger_amd.so -- the C ABI declared in include/sigdigger_amd.h.
+
+The library is the product; this module only declares prototypes.  There is no Python or
+CPU implementation of any operation behind it: if the .so is missing, loading fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libsigdigger_amd.so")
+
+_lib = None
+
+VP = C.c_void_p
+U32 = C.c_uint32
+U64 = C.c_uint64
+F32 = C.c_float
+F64 = C.c_double
+INT = C.c_int
+UINT = C.c_uint
+
+
+class AgcParams(C.Structure):
+    """struct suamd_agc_params"""
+    _fields_ = [("threshold", F32), ("slope_factor", F32), ("hang_max", UINT),
+                ("delay_line_size", UINT), ("mag_history_size", UINT),
+                ("fast_rise_t", F32), ("fast_fall_t", F32), ("slow_rise_t", F32), ("slow_fall_t", F32)]
+
+
+# name -> (restype, argtypes); mirrors include/sigdigger_amd.h one to one
+PROTOTYPES = {
+    "suamd_last_error": (C.c_char_p, []),
+    "suamd_version": (C.c_char_p, []),
+    "suamd_ctx_new": (VP, [INT]),
+    "suamd_ctx_destroy": (None, [VP]),
+    "suamd_ctx_device": (INT, [VP]),
+    "suamd_psd_new": (VP, [VP, UINT, INT]),
+    "suamd_psd_destroy": (None, [VP]),
+    "suamd_psd_feed": (INT, [VP, VP, U64, U64, UINT, F32, INT, VP, VP]),
+    "suamd_psd_shift_db": (INT, [VP, VP, U64, U64, VP]),
+    "suamd_averager_feed": (INT, [VP, VP, VP, U64, F32, INT, VP]),
+    "suamd_inspector_spectrum_db_shift": (INT, [VP, VP, U64, U64, VP]),
+    "suamd_fnor_to_dphase": (U32, [F64]),
+    "suamd_xlate_bulk": (INT, [VP, VP, VP, U64, U32, U32, U64, VP]),
+    "suamd_lpf_design": (None, [VP, UINT, F64]),
+    "suamd_chanbank_new": (VP, [VP, UINT, VP, UINT, VP, UINT]),
+    "suamd_chanbank_destroy": (None, [VP]),
+    "suamd_chanbank_output_count": (U64, [VP, U64]),
+    "suamd_chanbank_feed": (INT, [VP, VP, U64, VP, U64, C.POINTER(U64), VP]),
+    "suamd_chanbank_reset": (INT, [VP, VP]),
+    "suamd_quad_demod_batch": (INT, [VP, VP, U64, VP, U64, UINT, U64, VP, INT, VP, VP]),
+    "suamd_delayed_conj_bulk": (INT, [VP, VP, VP, U64, U64, VP]),
+    "suamd_histogram_feed_bulk": (INT, [VP, VP, U64, INT, VP, VP]),
+    "suamd_costas_bank_new": (VP, [VP, UINT, INT, F32, F32, UINT, F32]),
+    "suamd_costas_bank_destroy": (None, [VP]),
+    "suamd_costas_bank_feed": (INT, [VP, VP, U64, VP, U64, U64, VP]),
+    "suamd_costas_bank_get_state": (INT, [VP, VP, VP, VP]),
+    "suamd_pll_bank_new": (VP, [VP, UINT, F32, F32]),
+    "suamd_pll_bank_destroy": (None, [VP]),
+    "suamd_pll_bank_feed": (INT, [VP, VP, U64, VP, U64, U64, VP]),
+    "suamd_pll_bank_get_state": (INT, [VP, VP, VP, VP]),
+    "suamd_clock_bank_new": (VP, [VP, UINT, F32, F32]),
+    "suamd_clock_bank_destroy": (None, [VP]),
+    "suamd_clock_bank_feed": (INT, [VP, VP, U64, U64, VP, U64, VP, VP]),
+    "suamd_clock_bank_get_state": (INT, [VP, VP, VP, VP]),
+    "suamd_agc_params_from_tau": (None, [C.POINTER(AgcParams), F32]),
+    "suamd_agc_bank_new": (VP, [VP, UINT, C.POINTER(AgcParams)]),
+    "suamd_agc_bank_destroy": (None, [VP]),
+    "suamd_agc_bank_feed": (INT, [VP, VP, U64, VP, U64, U64, VP]),
+}
+
+
+class SigDiggerAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library (once) and installs the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise SigDiggerAmdError(
+            f"{SO_PATH} is missing: build it with `python -m sigdigger_amd.build` "
+            "(there is no CPU fallback for the SigDigger hot path)")
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)            # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().suamd_last_error().decode("utf-8", "replace")
+
+
+def check(ok, what):
+    if not ok:
+        raise SigDiggerAmdError(f"{what}: {last_error()}")
+    return ok

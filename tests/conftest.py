@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def sdo():
+    """The CPU oracle (test infrastructure)."""
+    from oracle import sdo as _sdo
+    _sdo.lib()
+    return _sdo
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """A libsigdigger_amd context on cuda:0 (GPU tests only)."""
+    import torch
+    assert torch.cuda.is_available(), "GPU test selected but no GPU visible"
+    from sigdigger_amd import engine
+    c = engine.Context(0)
+    yield c
+    c.close()

@@ -1,0 +1,340 @@
+"""GPU parity: libsigdigger_amd.so (through its C ABI) vs the CPU oracle on the same inputs.
+
+Bars: integer / index work bit-exact; the inspector chain is specified as a
+fixed binary32 operation sequence (SPEC.md section D) so it is compared BIT-EXACT too; the FFT PSD
+(different summation order from the float64 oracle) within 1e-5 of the frame's peak bin.
+"""
+import numpy as np
+import pytest
+import torch
+
+from sigdigger_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+PSD_TOL = 1e-5          # relative to the strongest bin of the frame (norm-wise relative error)
+DB_TOL = 2e-3           # dB, where a shifted-dB frame is compared
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def assert_bits(a, b, what=""):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    av = a.view(np.uint32) if a.dtype in (np.float32, np.complex64) else a
+    bv = b.view(np.uint32) if b.dtype in (np.float32, np.complex64) else b
+    if not np.array_equal(av, bv):
+        # -0.0 == +0.0 is accepted; anything else is a failure
+        ok = np.array_equal(a, b)
+        nbad = int(np.sum(a != b))
+        assert ok, f"{what}: {nbad} of {a.size} values differ (max abs {np.max(np.abs(a - b))})"
+
+
+# ------------------------------------------------------------------------------------------
+# A2-A4, A9: PSD
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192, 16384])
+def test_psd_linear_all_sizes(ctx, sdo, n):
+    nframes = 6
+    x = synth.tone_noise(n * nframes, f_rel=0.1003, sigma2=1e-3, seed=n)
+    win = sdo.window(4, n)                        # Blackmann-Harris
+    ref = sdo.psd_frames(x, nframes, n, n, win, navg=1, scale=1.0 / n)
+    psd = engine.PSD(ctx, n, engine.WINDOW_BLACKMANN_HARRIS)
+    out = host(psd.feed(dev(x), nframes=nframes, scale=1.0 / n))
+    assert out.shape == ref.shape
+    for f in range(nframes):
+        err = np.max(np.abs(out[f] - ref[f])) / np.max(ref[f])
+        assert err < PSD_TOL, f"frame {f}: rel err {err}"
+    # bin indexing is exact: the peak lands in the same bin
+    assert np.array_equal(np.argmax(out, axis=1), np.argmax(ref, axis=1))
+
+
+@pytest.mark.parametrize("window", [0, 1, 2, 3, 4])
+def test_psd_windows_and_averaging(ctx, sdo, window):
+    n, nframes, navg = 8192, 8, 4
+    x = synth.psk_carriers(n * nframes, [0.25, -0.4], sps=16, seed=7)
+    win = sdo.window(window, n)
+    ref = sdo.psd_frames(x, nframes, n, n, win, navg=navg, scale=1.0)
+    psd = engine.PSD(ctx, n, window)
+    out = host(psd.feed(dev(x), nframes=nframes, navg=navg, scale=1.0))
+    assert out.shape == (nframes // navg, n)
+    err = np.max(np.abs(out - ref), axis=1) / np.max(ref, axis=1)
+    assert np.all(err < PSD_TOL), err
+
+
+def test_psd_overlapped_hop(ctx, sdo):
+    n, hop, nframes = 4096, 1024, 13
+    x = synth.tone_noise((nframes - 1) * hop + n, f_rel=-0.2, seed=3)
+    win = sdo.window(2, n)
+    ref = sdo.psd_frames(x, nframes, n, hop, win)
+    out = host(engine.PSD(ctx, n, engine.WINDOW_HANN).feed(dev(x), nframes=nframes, hop=hop))
+    err = np.max(np.abs(out - ref), axis=1) / np.max(ref, axis=1)
+    assert np.all(err < PSD_TOL), err
+
+
+def test_psd_db_shifted_matches_psdmessage(ctx, sdo):
+    """mode DB_SHIFTED == PSDMessage ctor applied to the linear frame (Suscan/Messages/PSDMessage.cpp:26-39)."""
+    n, nframes = 8192, 4
+    x = synth.tone_noise(n * nframes, f_rel=0.05, sigma2=1e-2, seed=11)
+    win = sdo.window(4, n)
+    lin = sdo.psd_frames(x, nframes, n, n, win, scale=1.0 / n)
+    ref = np.stack([sdo.psd_shift_db(f) for f in lin])
+    psd = engine.PSD(ctx, n, engine.WINDOW_BLACKMANN_HARRIS)
+    out = host(psd.feed(dev(x), nframes=nframes, scale=1.0 / n, mode=engine.PSD_DB_SHIFTED))
+    assert np.max(np.abs(out - ref)) < DB_TOL
+    # index mapping is integer-exact: DC bin (natural index 0) lands at n/2
+    assert np.array_equal(np.argmax(out, axis=1), np.argmax(ref, axis=1))
+
+
+def test_psd_shift_db_inplace_and_averager(ctx, sdo):
+    rng = np.random.default_rng(5)
+    frames = (rng.random((5, 4096)).astype(np.float32) ** 4) * 10.0
+    frames[0, :7] = 0.0                                   # SU_POWER_DB epsilon path
+    ref = np.stack([sdo.psd_shift_db(f) for f in frames])
+    d = dev(frames)
+    ctx.psd_shift_db(d)
+    got = host(d)
+    assert np.max(np.abs(got - ref)) < 1e-4               # log10f implementations differ by ulps
+    # the shift itself is exact: a frame of distinct integers-as-power keeps its permutation
+    perm = np.argsort(np.argsort(ref[1]))
+    assert np.array_equal(np.argsort(np.argsort(got[1])), perm)
+    # Averager::feed: first frame copies, later frames blend in place (Misc/Averager.cpp:25-50)
+    avg = sdo.Averager(alpha=0.25)
+    last = torch.empty(4096, dtype=torch.float32, device="cuda")
+    for i, f in enumerate(ref):
+        avg.feed(f)
+        ctx.averager_feed(last, dev(f), 0.25, blend=(i > 0))
+        assert_bits(host(last), avg.last, f"averager frame {i}")
+
+
+@pytest.mark.parametrize("length", [1024, 1000, 777])
+def test_inspector_spectrum_db_shift(ctx, sdo, length):
+    rng = np.random.default_rng(length)
+    spec = (rng.random((3, length)).astype(np.float32) ** 3)
+    ref = np.stack([sdo.inspector_spectrum_db_shift(s) for s in spec])
+    d = dev(spec)
+    ctx.inspector_spectrum_db_shift(d)
+    assert np.max(np.abs(host(d) - ref)) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------
+# T1/K4: NCO translate -- bit exact
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,n0", [(1, 0), (2, 5), (4097, 0), (100001, 123456789012)])
+def test_xlate_bit_exact(ctx, sdo, n, n0):
+    x = synth.tone_noise(n, f_rel=0.01, seed=n)
+    dp = sdo.fnor_to_dphase(-0.123456)
+    assert dp == ctx.fnor_to_dphase(-0.123456)
+    p0 = 0x12345678
+    ref = sdo.xlate_bulk(x, p0, dp, n0)
+    got = host(ctx.xlate(dev(x), p0, dp, n0))
+    assert_bits(got, ref, "xlate")
+
+
+def test_xlate_streaming_equals_one_shot(ctx, sdo):
+    x = synth.tone_noise(30000, seed=9)
+    dp = sdo.fnor_to_dphase(0.3)
+    whole = host(ctx.xlate(dev(x), 0, dp, 0))
+    parts = [host(ctx.xlate(dev(x[a:b]), 0, dp, a)) for a, b in ((0, 4096), (4096, 4097), (4097, 30000))]
+    assert_bits(np.concatenate(parts), whole, "xlate streaming")
+
+
+# ------------------------------------------------------------------------------------------
+# K4+K5: channel bank -- bit exact, block-size invariant
+# ------------------------------------------------------------------------------------------
+def _oracle_bank(sdo, x, fnors, D, taps, blocks):
+    outs = [[] for _ in fnors]
+    T = len(taps)
+    for c, f in enumerate(fnors):
+        dp = sdo.fnor_to_dphase(-f)
+        g = sdo.chan_modulate_taps(taps, dp)
+        hist = np.zeros(T - 1, dtype=np.complex64)
+        n0 = 0
+        for a, b in blocks:
+            blk = x[a:b]
+            outs[c].append(sdo.chan_feed(hist, blk, n0, g, D, 0, dp))
+            cat = np.concatenate([hist, blk])
+            hist = cat[len(cat) - (T - 1):]
+            n0 += len(blk)
+    return [np.concatenate(o) for o in outs]
+
+
+@pytest.mark.parametrize("nchan,D,T", [(1, 16, 255), (3, 64, 255), (8, 64, 255), (5, 1, 31), (2, 7, 64),
+                                       (64, 64, 255), (4, 256, 255)])
+def test_chanbank_bit_exact(ctx, sdo, nchan, D, T):
+    n = 40000 if nchan < 64 else 24000
+    fn = synth.raster(nchan, 1.6 / max(nchan, 2))
+    x = synth.psk_carriers(n, fn[: min(nchan, 4)], sps=max(2 * D // 4, 4), seed=21)
+    taps = sdo.lpf_design(T, 0.8 / D)
+    assert_bits(ctx.lpf_design(T, 0.8 / D), taps, "lpf design")
+    blocks = [(0, 10000), (10000, 10001), (10001, 10001 + 3 * D + 5), (10001 + 3 * D + 5, n)]
+    ref = _oracle_bank(sdo, x, fn, D, taps, blocks)
+    bank = engine.ChannelBank(ctx, fn, D, taps)
+    got = []
+    for a, b in blocks:
+        y = bank.feed(dev(x[a:b]))
+        got.append(host(y))
+    got = np.concatenate(got, axis=1)
+    assert got.shape[1] == len(ref[0]) == (n + D - 1) // D
+    for c in range(nchan):
+        assert_bits(got[c], ref[c], f"chanbank channel {c}")
+
+
+def test_chanbank_block_size_invariance_large(ctx, sdo):
+    """size-independent property at a BASELINE-size block: feeding 1 Mi samples at once equals
+    feeding them in ragged pieces, bit for bit (state carry of history + sample clock)."""
+    n, D, T, nchan = 1 << 20, 64, 255, 64
+    fn = synth.raster(nchan, 1.0 / 40)
+    x = dev(synth.tone_noise(n, f_rel=0.0131, sigma2=0.1, seed=4))
+    taps = sdo.lpf_design(T, 0.8 / D)
+    one = host(engine.ChannelBank(ctx, fn, D, taps).feed(x))
+    bank = engine.ChannelBank(ctx, fn, D, taps)
+    cuts = [0, 1, 4097, 300000, 300001, 777777, n]
+    parts = [host(bank.feed(x[a:b])) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert_bits(np.concatenate(parts, axis=1), one, "block-size invariance")
+    # and the oracle agrees on a channel subset over the first 64k samples
+    ref = _oracle_bank(sdo, host(x[:65536]), fn[[0, 31, 63]], D, taps, [(0, 65536)])
+    for i, c in enumerate((0, 31, 63)):
+        assert_bits(one[c, :1024], ref[i], f"channel {c} vs oracle")
+
+
+# ------------------------------------------------------------------------------------------
+# T5/T7/T11: element-wise demodulators -- bit exact
+# ------------------------------------------------------------------------------------------
+def test_quad_demod_bit_exact(ctx, sdo):
+    x = synth.fsk_carriers(20000, [0.0], sps=10, seed=2)
+    ref = sdo.quad_demod(x)
+    got = host(ctx.quad_demod(dev(x)))
+    assert_bits(got, ref, "quad demod")
+    assert got[0] == 0 and np.all(got.real == 0)
+    # streaming with prev carry, batched rows
+    rows = np.stack([x[:8000], x[8000:16000]])
+    prev = dev(np.array([x[7], x[7999]], dtype=np.complex64))
+    gotb = host(ctx.quad_demod(dev(rows[:, 8:]), prev=prev, first=False))
+    assert_bits(gotb[0], sdo.quad_demod(rows[0, 8:], prev=x[7], first=False), "row 0")
+    assert_bits(gotb[1], sdo.quad_demod(rows[1, 8:], prev=x[7999], first=False), "row 1")
+
+
+@pytest.mark.parametrize("delay", [1, 37, 5000])
+def test_delayed_conj_bit_exact(ctx, sdo, delay):
+    x = synth.psk_carriers(12000, [0.01], sps=8, seed=5)
+    assert_bits(host(ctx.delayed_conj(dev(x), delay)), sdo.delayed_conj(x, delay), "delayed conj")
+
+
+@pytest.mark.parametrize("space", [0, 1, 2])
+def test_histogram_feed_bit_exact(ctx, sdo, space):
+    x = synth.psk_carriers(9999, [0.02], sps=8, seed=6)
+    assert_bits(host(ctx.histogram_feed(dev(x), space)), sdo.histogram_feed(x, space), "histogram")
+
+
+# ------------------------------------------------------------------------------------------
+# K6-K9: recurrences -- bit exact, state carried across blocks
+# ------------------------------------------------------------------------------------------
+def _rows(nchan, n, order=4, sps=8, seed=30):
+    return np.stack([synth.psk_carriers(n, [0.004 * (c % 5 - 2)], sps=sps, order=order, seed=seed + c,
+                                        snr_db=15 + c % 7) for c in range(nchan)])
+
+
+@pytest.mark.parametrize("kind,order,arm_order", [(1, 2, 3), (2, 4, 3), (3, 8, 3), (2, 4, 1), (2, 4, 5)])
+def test_costas_bank_bit_exact(ctx, sdo, kind, order, arm_order):
+    nchan, n = 70, 6000                                   # > 64: two wavefronts, ragged last one
+    x = _rows(nchan, n, order=order)
+    bank = engine.CostasBank(ctx, nchan, kind, 0.0, 2.0 / 8, arm_order, 0.01)
+    dx = dev(x)
+    got = np.concatenate([host(bank.feed(dx[:, a:b].contiguous())) for a, b in ((0, 1), (1, 2500), (2500, n))],
+                         axis=1)
+    om, ph = bank.state()
+    for c in range(nchan):
+        st = sdo.costas_new(kind, 0.0, 2.0 / 8, arm_order, 0.01)
+        ref = sdo.costas_feed_bulk(st, x[c])
+        assert_bits(got[c], ref, f"costas ch {c}")
+        assert np.float32(st.omega).view(np.uint32) == om[c].view(np.uint32) and st.phase == ph[c]
+
+
+def test_pll_bank_bit_exact(ctx, sdo):
+    nchan, n = 9, 5000
+    t = np.arange(n)
+    x = np.stack([(np.exp(1j * (np.pi * 0.003 * (c + 1) * t + c)) +
+                   0.05 * synth.tone_noise(n, seed=c)).astype(np.complex64) for c in range(nchan)])
+    bank = engine.PLLBank(ctx, nchan, 0.0, 0.02)
+    dx = dev(x)
+    got = np.concatenate([host(bank.feed(dx[:, :1234].contiguous())), host(bank.feed(dx[:, 1234:].contiguous()))],
+                         axis=1)
+    om, ph = bank.state()
+    for c in range(nchan):
+        st = sdo.pll_new(0.0, 0.02)
+        assert_bits(got[c], sdo.pll_track_bulk(st, x[c]), f"pll ch {c}")
+        assert st.phase == ph[c]
+
+
+def test_clock_bank_bit_exact_symbol_counts(ctx, sdo):
+    nchan, n, sps = 66, 8000, 8
+    x = _rows(nchan, n, order=2, sps=sps)
+    bank = engine.ClockBank(ctx, nchan, 1.0, 1.0 / sps * 1.01)
+    sym = torch.zeros((nchan, n // 4), dtype=torch.complex64, device="cuda")
+    cnt = torch.zeros(nchan, dtype=torch.int32, device="cuda")
+    dx = dev(x)
+    for a, b in ((0, 3), (3, 4000), (4000, n)):
+        bank.feed(dx[:, a:b].contiguous(), sym, cnt)
+    counts = host(cnt)
+    syms = host(sym)
+    for c in range(nchan):
+        st = sdo.clock_new(1.0, 1.0 / sps * 1.01)
+        ref = sdo.clock_feed_bulk(st, x[c])
+        assert counts[c] == len(ref), f"symbol count ch {c}: {counts[c]} vs {len(ref)}"
+        assert_bits(syms[c, :counts[c]], ref, f"clock ch {c}")
+
+
+def test_agc_bank_bit_exact(ctx, sdo):
+    nchan, n = 65, 6000
+    x = _rows(nchan, n)
+    env = np.repeat(np.array([0.01, 1.0, 0.1, 5.0], dtype=np.float32), n // 4)
+    x = (x * env[None, :]).astype(np.complex64)
+    bank = engine.AGCBank(ctx, nchan, tau=16.0)
+    dx = dev(x)
+    got = np.concatenate([host(bank.feed(dx[:, :777].contiguous())), host(bank.feed(dx[:, 777:].contiguous()))],
+                         axis=1)
+    for c in range(nchan):
+        st = sdo.agc_new(sdo.agc_params_from_tau(16.0))
+        assert_bits(got[c], sdo.agc_feed_bulk(st, x[c]), f"agc ch {c}")
+
+
+def test_psk_inspector_chain_end_to_end(ctx, sdo):
+    """bank -> AGC -> Costas -> Gardner for 8 QPSK carriers: every stage bit-exact vs the oracle
+    chain, symbol counts identical, and the recovered symbols sit on the QPSK constellation."""
+    nchan, D, T, sps_in = 8, 16, 255, 128                 # 8 samples/symbol after decimation
+    n = 1 << 17
+    fn = synth.raster(nchan, 1.0 / 12)
+    x = synth.psk_carriers(n, fn, sps=sps_in, order=4, seed=77, snr_db=25)
+    taps = sdo.lpf_design(T, 0.75 / D)
+    bank = engine.ChannelBank(ctx, fn, D, taps)
+    agc = engine.AGCBank(ctx, nchan, tau=float(sps_in // D))
+    cos = engine.CostasBank(ctx, nchan, 2, 0.0, 2.0 / (sps_in // D), 3, 0.005)
+    clk = engine.ClockBank(ctx, nchan, 0.2, float(D) / sps_in)
+    y = bank.feed(dev(x)).contiguous()
+    a = agc.feed(y)
+    z = cos.feed(a)
+    sym = torch.zeros((nchan, y.shape[1]), dtype=torch.complex64, device="cuda")
+    cnt = torch.zeros(nchan, dtype=torch.int32, device="cuda")
+    clk.feed(z, sym, cnt)
+    yh, ah, zh, sh, ch = host(y), host(a), host(z), host(sym), host(cnt)
+    ry = _oracle_bank(sdo, x, fn, D, taps, [(0, n)])
+    for c in range(nchan):
+        assert_bits(yh[c], ry[c], f"bank ch {c}")
+        ra = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(float(sps_in // D))), ry[c])
+        assert_bits(ah[c], ra, f"agc ch {c}")
+        rz = sdo.costas_feed_bulk(sdo.costas_new(2, 0.0, 2.0 / (sps_in // D), 3, 0.005), ra)
+        assert_bits(zh[c], rz, f"costas ch {c}")
+        rs = sdo.clock_feed_bulk(sdo.clock_new(0.2, float(D) / sps_in), rz)
+        assert ch[c] == len(rs)
+        assert_bits(sh[c, :ch[c]], rs, f"symbols ch {c}")
+        tail = sh[c, ch[c] // 2: ch[c]]
+        m4 = np.mean((tail / np.abs(tail)) ** 4)
+        assert np.abs(m4) > 0.8, f"ch {c}: constellation not locked ({abs(m4):.3f})"
