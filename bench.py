@@ -1,0 +1,277 @@
+#!/usr/bin/env python
+"""bench.py -- MS/s of complex IQ sustained through (PSD + N inspectors) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c4|c2|c3] [--block LOG2]
+
+A "step" is one pass of the hot path over one resident block of synthetic IQ: 8192-pt windowed FFT
+PSD over every window of the block + the bank of inspector chains (translate + 255-tap polyphase
+decimating low-pass -> AGC -> Costas -> Gardner).  With N>1 GPUs (one process per GPU, RCCL)
+the inspector channels are sharded 64 per GPU, rank 0's IQ block is broadcast every step
+(double-buffered, overlapped with compute), and there is no other collective.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus "roofline" and "cpu_baseline".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from sigdigger_amd import engine, pipeline, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290
+FP32_PEAK_TFLOPS = 157.3     # vector FP32 spec peak
+
+WORKLOADS = {
+    # C4 / north-star target line: 50 MS/s-class IQ, 8192-pt PSD + 64 QPSK inspectors per GPU
+    "c4": dict(desc="C4 slice / north-star target: 8192-pt PSD + 64 QPSK inspectors per GPU "
+                    "(AGC+Costas+Gardner), 255-tap LPF, D=64, 50 kBd @ 50 MS/s (15.6 sps)",
+               psd=8192, per_gpu=64, D=64, T=255, sps_in=1000, kind="psk", spacing=2 * 90e3 / 50e6),
+    # C2: 20 MS/s, 8192-pt PSD + 1 PSK inspector
+    "c2": dict(desc="C2: 8192-pt PSD + 1 QPSK inspector (AGC+Costas+Gardner), 255-tap LPF, D=16, "
+                    "250 kBd @ 20 MS/s (5 sps)",
+               psd=8192, per_gpu=1, D=16, T=255, sps_in=80, kind="psk", spacing=0.25),
+    # C3: 50 MS/s, 16384-pt PSD + 64 FSK inspectors (quad-demod path)
+    "c3": dict(desc="C3: 16384-pt PSD + 64 2-FSK inspectors (quad demod + Gardner), 255-tap LPF, D=64, "
+                    "100 kBd @ 50 MS/s (7.8 sps)",
+               psd=16384, per_gpu=64, D=64, T=255, sps_in=500, kind="fsk", spacing=2 * 700e3 / 50e6),
+}
+
+
+def make_block(n, fnor, sps_in, kind, device, seed=1234):
+    """Synthetic IQ block generated on the device: sum of rect-pulse QPSK / 2-FSK carriers + noise."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    t = torch.arange(n, device=device, dtype=torch.float64)
+    x = torch.zeros(n, dtype=torch.complex64, device=device)
+    nsym = n // sps_in + 2
+    idx = (torch.arange(n, device=device) // sps_in)
+    for c, f in enumerate(fnor):
+        if kind == "psk":
+            sym = torch.randint(0, 4, (nsym,), generator=g, device=device)
+            ph = (np.pi / 2) * sym[idx].to(torch.float64) + np.pi / 4
+        else:
+            bits = torch.randint(0, 2, (nsym,), generator=g, device=device).to(torch.float64) * 2 - 1
+            ph = torch.cumsum(bits[idx] * (np.pi / sps_in), 0)
+        ph = ph + (np.pi * float(f)) * t + 0.37 * c
+        x += torch.polar(torch.ones_like(ph), ph).to(torch.complex64)
+    noise = torch.randn(n, 2, generator=g, device=device, dtype=torch.float32) * 0.05
+    x += torch.view_as_complex(noise)
+    x *= 1.0 / max(len(fnor), 1) ** 0.5
+    return x
+
+
+def cpu_baseline(cfg, nsamples, fnor_rank, ncores):
+    """Times the CPU oracle (oracle/sdo.c, a restatement -- NOT upstream sigutils) on a bounded
+    sample of the same workload on this box's host cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import sdo
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal(nsamples) + 1j * rng.standard_normal(nsamples)).astype(np.complex64) * 0.3
+    N, D, T = cfg["psd"], cfg["D"], cfg["T"]
+    sps = cfg["sps_in"] / D
+    taps = sdo.lpf_design(T, 0.75 / D)
+    win = sdo.window(4, N)
+
+    def chain(f):
+        dp = sdo.fnor_to_dphase(-f)
+        y = sdo.chan_feed(np.zeros(T - 1, np.complex64), x, 0, sdo.chan_modulate_taps(taps, dp), D, 0, dp)
+        if cfg["kind"] == "psk":
+            a = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(sps)), y)
+            z = sdo.costas_feed_bulk(sdo.costas_new(2, 0.0, 2.0 / sps, 3, 0.005), a)
+        else:
+            z = sdo.quad_demod(y)
+        return len(sdo.clock_feed_bulk(sdo.clock_new(0.2, 1.0 / sps), z))
+
+    def run(threads):
+        t0 = time.perf_counter()
+        sdo.psd_frames(x, nsamples // N, N, N, win, navg=nsamples // N, scale=1.0 / N)
+        if threads == 1:
+            for f in fnor_rank:
+                chain(f)
+        else:
+            with ThreadPoolExecutor(threads) as ex:
+                list(ex.map(chain, fnor_rank))
+        return time.perf_counter() - t0
+
+    t1 = run(1)
+    tn = run(ncores) if ncores > 1 and len(fnor_rank) > 1 else t1
+    cores = ncores if (ncores > 1 and len(fnor_rank) > 1) else 1
+    return {
+        "value": round(nsamples / tn / 1e6, 4), "unit": "MS/s", "cores": cores, "kind": "port",
+        "value_1thread": round(nsamples / t1 / 1e6, 4),
+        "sample": f"{nsamples} complex samples of the same workload (PSD {N}-pt + {len(fnor_rank)} "
+                  f"inspector chains) through oracle/sdo.c, {cores} thread(s), channels partitioned "
+                  f"across threads; oracle is a restatement, not upstream sigutils",
+        "cpu_model": _cpu_model(),
+    }
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def run_workload(name, args, rank, world, dev, ctx, dist):
+    cfg = WORKLOADS[name]
+    L = 1 << args.block
+    nch_total = cfg["per_gpu"] * world
+    fn_all = synth.raster(nch_total, cfg["spacing"])
+    fn_rank = pipeline.shard_channels(fn_all, rank, world)
+    bank = pipeline.InspectorBankConfig(kind=cfg["kind"], fnor=fn_rank, decimation=cfg["D"], ntaps=cfg["T"],
+                                        sps=cfg["sps_in"] / cfg["D"])
+    # PSD runs on rank 0 only; frames averaged to ~25 fps at 50 MS/s
+    navg = min(256, L // cfg["psd"])
+    pipe = pipeline.AnalyzerPipeline(ctx, L, psd_size=cfg["psd"], psd_navg=navg, bank=bank, do_psd=(rank == 0))
+
+    bufs = [make_block(L, fn_all, cfg["sps_in"], cfg["kind"], dev, seed=1234),
+            torch.empty(L, dtype=torch.complex64, device=dev)]
+    bufs[1].copy_(bufs[0])
+    torch.cuda.synchronize(dev)
+
+    def one_step(k, timed):
+        cur = bufs[k & 1]
+        work = None
+        if world > 1:
+            # rank 0's next block -> every GPU over xGMI, overlapped with this step's compute
+            work = dist.broadcast(bufs[(k + 1) & 1], src=0, async_op=True)
+        pipe.step(cur, timed=timed)
+        if work is not None:
+            work.wait()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    if world > 1:
+        dist.broadcast(bufs[0], src=0)
+    for k in range(args.warmup):
+        one_step(k, False)
+    fence()
+    pipe.reset_events()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(k, True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    stages = pipe.stage_times_ms()
+    return cfg, L, dt, stages, fn_rank, pipe
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--block", type=int, default=22, help="log2 of the IQ block length (samples)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (c2, c3)")
+    ap.add_argument("--cpu-samples", type=int, default=1 << 23)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ctx = engine.Context(local_rank)
+
+    cfg, L, dt, stages, fn_rank, pipe = run_workload(args.workload, args, rank, world, dev, ctx, dist)
+
+    if rank == 0:
+        K = args.steps
+        # units all ranks processed: every rank pushes the same L-sample block through its own
+        # 64-inspector bank each step
+        total_samples = float(L) * K * world
+        value = total_samples / dt / 1e6
+        C, D, T = len(fn_rank), cfg["D"], cfg["T"]
+        m_out = L // D
+        # dominant memory/compute-streaming kernel of the north star: the FIR channel bank.
+        # algorithmic (compulsory) bytes per launch: shared input + per-channel decimated output
+        fir_bytes = 8.0 * L + 8.0 * C * m_out
+        fir_flops = float(C) * m_out * T * 8.0 + 14.0 * C * m_out      # 4 fma/tap + de-rotation
+        fir_ms = stages.get("fir")
+        psd_ms = stages.get("psd")
+        psd_bytes = 8.0 * L + 4.0 * cfg["psd"] * (L // cfg["psd"] // pipe.navg)
+        roof = {
+            "kernel": "chan_fir_kernel (translate + 255-tap polyphase decimating FIR bank)",
+            "bound": "hbm", "achieved": round(fir_bytes / (fir_ms * 1e-3) / 1e9, 2) if fir_ms else None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(fir_bytes / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if fir_ms else None,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": fir_bytes,
+            "kernel_ms": round(fir_ms, 4) if fir_ms else None,
+            "fp32_vector": {"achieved_tflops": round(fir_flops / (fir_ms * 1e-3) / 1e12, 3) if fir_ms else None,
+                            "peak_tflops": FP32_PEAK_TFLOPS,
+                            "frac": round(fir_flops / (fir_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4) if fir_ms else None},
+            "psd_kernel": {"achieved": round(psd_bytes / (psd_ms * 1e-3) / 1e9, 2) if psd_ms else None,
+                           "frac": round(psd_bytes / (psd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if psd_ms else None,
+                           "kernel_ms": round(psd_ms, 4) if psd_ms else None,
+                           "algorithmic_bytes_per_launch": psd_bytes},
+            "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+            "note": "recurrence stages (AGC/Costas/Gardner) are one-lane-per-channel and latency-bound; "
+                    "they are reported in stage_ms, not against a roofline (SURVEY.md section 8d)",
+        }
+        out = {
+            "metric": "MS/s complex IQ sustained (PSD + N inspectors)", "value": round(value, 3), "unit": "MS/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["desc"], "block_samples": L, "psd_size": cfg["psd"],
+                       "inspectors_per_gpu": cfg["per_gpu"], "inspectors_total": cfg["per_gpu"] * world,
+                       "decimation": D, "taps": T,
+                       "parallelism": f"channel-sharded x{world}, RCCL broadcast of the IQ block" if world > 1
+                       else "single GPU",
+                       "value_definition": "sum over ranks of IQ samples pushed through that rank's PSD+inspector "
+                                           "bank per second; every rank consumes the same broadcast stream, so "
+                                           "stream rate = value / n_gpus"},
+            "stream_rate_MSps": round(value / world, 3),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_extra:
+            extra = {}
+            for w in ("c2", "c3"):
+                if w == args.workload:
+                    continue
+                a2 = argparse.Namespace(**vars(args))
+                a2.steps, a2.warmup = max(5, args.steps // 4), 2
+                c2, L2, dt2, st2, _, _ = run_workload(w, a2, 0, 1, dev, ctx, None)
+                extra[w] = {"workload": c2["desc"], "value_MSps": round(L2 * a2.steps / dt2 / 1e6, 3),
+                            "ms_per_step": round(dt2 / a2.steps * 1e3, 4),
+                            "stage_ms": {k: round(v, 4) for k, v in st2.items()}}
+            out["other_workloads"] = extra
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_samples, fn_rank, os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

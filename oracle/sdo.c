@@ -208,7 +208,20 @@ void sdo_window(int type, float *w, size_t n)
 
 void sdo_fft_f64(double *re, double *im, size_t n)
 {
+  /* iterative radix-2 DIT; twiddles for the last size used are cached (single-threaded use) */
+  static size_t tw_n = 0;
+  static double *twr = NULL, *twi = NULL;
   size_t i, j, len;
+  if (tw_n != n) {
+    free(twr); free(twi);
+    twr = malloc(sizeof(double) * (n / 2 + 1));
+    twi = malloc(sizeof(double) * (n / 2 + 1));
+    for (i = 0; i < n / 2; ++i) {
+      double ang = -2.0 * SDO_PI * (double)i / (double)n;
+      twr[i] = cos(ang); twi[i] = sin(ang);
+    }
+    tw_n = n;
+  }
   for (i = 1, j = 0; i < n; ++i) {                      /* bit reversal */
     size_t bit = n >> 1;
     for (; j & bit; bit >>= 1) j ^= bit;
@@ -219,11 +232,10 @@ void sdo_fft_f64(double *re, double *im, size_t n)
     }
   }
   for (len = 2; len <= n; len <<= 1) {
-    size_t half = len >> 1, k;
+    size_t half = len >> 1, k, step = n / len;
     for (i = 0; i < n; i += len) {
       for (k = 0; k < half; ++k) {
-        double ang = -2.0 * SDO_PI * (double)k / (double)len;
-        double wr = cos(ang), wi = sin(ang);
+        double wr = twr[k * step], wi = twi[k * step];
         double ur = re[i + k], ui = im[i + k];
         double vr = re[i + k + half] * wr - im[i + k + half] * wi;
         double vi = re[i + k + half] * wi + im[i + k + half] * wr;
