@@ -17,8 +17,11 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# one HIP hardware queue per pipeline stream (default is 4; the analyzer uses 4 + RCCL's)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -143,10 +146,8 @@ def run_workload(name, args, rank, world, dev, ctx, dist):
 
     def one_step(k, timed):
         cur = bufs[k & 1]
-        work = None
-        if world > 1:
-            # rank 0's next block -> every GPU over xGMI, overlapped with this step's compute
-            work = dist.broadcast(bufs[(k + 1) & 1], src=0, async_op=True)
+        # rank 0's next block -> every GPU over xGMI, overlapped with this step's compute
+        work = pipeline.broadcast_block(bufs[(k + 1) & 1], dist) if world > 1 else None
         pipe.step(cur, timed=timed)
         if work is not None:
             work.wait()

@@ -37,6 +37,14 @@ typedef struct { SUFLOAT re, im; } suamd_complex;   /* layout-identical to SUCOM
 #  define SU_FALSE 0
 #endif
 
+/* A batch of `nchan` sample rows: element (channel c, time m) lives at
+ * base[c*chan_stride + m*time_stride], strides in complex samples.
+ *   channel-major [c][m]: { row_pitch, 1 }  -- the layout of per-inspector sample batches
+ *                                               (struct suscan_analyzer_sample_batch_msg)
+ *   time-major    [m][c]: { 1, nchan_pitch } -- the layout the one-lane-per-channel loops stream
+ *                                               at full speed (a wavefront reads 512 contiguous bytes) */
+typedef struct { SUSCOUNT chan_stride, time_stride; } suamd_view;
+
 typedef struct suamd_ctx         suamd_ctx_t;
 typedef struct suamd_psd         suamd_psd_t;
 typedef struct suamd_chanbank    suamd_chanbank_t;
@@ -114,11 +122,11 @@ SUAMD_API suamd_chanbank_t *suamd_chanbank_new(suamd_ctx_t *ctx, unsigned nchan,
 SUAMD_API void   suamd_chanbank_destroy(suamd_chanbank_t *bank);
 /* Number of outputs per channel the next feed of len samples will produce. */
 SUAMD_API SUSCOUNT suamd_chanbank_output_count(const suamd_chanbank_t *bank, SUSCOUNT len);
-/* Feeds len input samples (shared by all channels); writes
- * d_y[c*y_stride + m], m < *n_out, channel-major.  State (history, sample clock) carries
- * to the next call, so a stream may be fed block by block. */
+/* Feeds len input samples (shared by all channels); writes output m < *n_out of channel c at
+ * d_y[c*yv.chan_stride + m*yv.time_stride].  State (history, sample clock) carries to the next
+ * call, so a stream may be fed block by block. */
 SUAMD_API SUBOOL suamd_chanbank_feed(suamd_chanbank_t *bank, const suamd_complex *d_x, SUSCOUNT len,
-                                     suamd_complex *d_y, SUSCOUNT y_stride, SUSCOUNT *n_out, void *stream);
+                                     suamd_complex *d_y, suamd_view yv, SUSCOUNT *n_out, void *stream);
 SUAMD_API SUBOOL suamd_chanbank_reset(suamd_chanbank_t *bank, void *stream);
 
 /* ------------------------------------------------------------------------------------ */
@@ -127,8 +135,8 @@ SUAMD_API SUBOOL suamd_chanbank_reset(suamd_chanbank_t *bank, void *stream);
 /* QuadDemodTask::work loop (Tasks/QuadDemodTask.cpp:44-60).  d_prev[c] (may be NULL when
  * first) = sample preceding row c; first => dest[0] = 0.  If d_prev_out != NULL the last
  * sample of each row is stored there for the next block. */
-SUAMD_API SUBOOL suamd_quad_demod_batch(suamd_ctx_t *ctx, const suamd_complex *d_x, SUSCOUNT x_stride,
-                                        suamd_complex *d_y, SUSCOUNT y_stride, unsigned nchan, SUSCOUNT len,
+SUAMD_API SUBOOL suamd_quad_demod_batch(suamd_ctx_t *ctx, const suamd_complex *d_x, suamd_view xv,
+                                        suamd_complex *d_y, suamd_view yv, unsigned nchan, SUSCOUNT len,
                                         const suamd_complex *d_prev, SUBOOL first,
                                         suamd_complex *d_prev_out, void *stream);
 /* DelayedConjTask::work loop (Tasks/DelayedConjTask.cpp:70-84), whole capture at once */
@@ -152,16 +160,16 @@ SUAMD_API suamd_costas_bank_t *suamd_costas_bank_new(suamd_ctx_t *ctx, unsigned 
 SUAMD_API void   suamd_costas_bank_destroy(suamd_costas_bank_t *b);
 /* the `while (amount--) dest[p] = su_costas_feed(&costas, origin[p])` loop
  * (Tasks/CostasRecoveryTask.cpp:58-61) for every row c */
-SUAMD_API SUBOOL suamd_costas_bank_feed(suamd_costas_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride,
-                                        suamd_complex *d_y, SUSCOUNT y_stride, SUSCOUNT len, void *stream);
+SUAMD_API SUBOOL suamd_costas_bank_feed(suamd_costas_bank_t *b, const suamd_complex *d_x, suamd_view xv,
+                                        suamd_complex *d_y, suamd_view yv, SUSCOUNT len, void *stream);
 /* copies omega[c] (rad/sample) and phase[c] (2^32/turn) to host; synchronises the stream */
 SUAMD_API SUBOOL suamd_costas_bank_get_state(suamd_costas_bank_t *b, SUFLOAT *omega, uint32_t *phase, void *stream);
 
 /* su_pll_init(&pll, fhint, fc) / su_pll_track loop (Tasks/PLLSyncTask.cpp:36,53-56) */
 SUAMD_API suamd_pll_bank_t *suamd_pll_bank_new(suamd_ctx_t *ctx, unsigned nchan, SUFLOAT fhint, SUFLOAT fc);
 SUAMD_API void   suamd_pll_bank_destroy(suamd_pll_bank_t *b);
-SUAMD_API SUBOOL suamd_pll_bank_feed(suamd_pll_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride,
-                                     suamd_complex *d_y, SUSCOUNT y_stride, SUSCOUNT len, void *stream);
+SUAMD_API SUBOOL suamd_pll_bank_feed(suamd_pll_bank_t *b, const suamd_complex *d_x, suamd_view xv,
+                                     suamd_complex *d_y, suamd_view yv, SUSCOUNT len, void *stream);
 SUAMD_API SUBOOL suamd_pll_bank_get_state(suamd_pll_bank_t *b, SUFLOAT *omega, uint32_t *phase, void *stream);
 
 /* su_clock_detector_init(&cd, loop_gain, bhint, bufsiz) + feed/read loops
@@ -170,7 +178,7 @@ SUAMD_API SUBOOL suamd_pll_bank_get_state(suamd_pll_bank_t *b, SUFLOAT *omega, u
  * (or carried over to keep appending). */
 SUAMD_API suamd_clock_bank_t *suamd_clock_bank_new(suamd_ctx_t *ctx, unsigned nchan, SUFLOAT loop_gain, SUFLOAT bhint);
 SUAMD_API void   suamd_clock_bank_destroy(suamd_clock_bank_t *b);
-SUAMD_API SUBOOL suamd_clock_bank_feed(suamd_clock_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride,
+SUAMD_API SUBOOL suamd_clock_bank_feed(suamd_clock_bank_t *b, const suamd_complex *d_x, suamd_view xv,
                                        SUSCOUNT len, suamd_complex *d_sym, SUSCOUNT sym_stride,
                                        uint32_t *d_count, void *stream);
 SUAMD_API SUBOOL suamd_clock_bank_get_state(suamd_clock_bank_t *b, SUFLOAT *bnor, SUFLOAT *phi, void *stream);
@@ -190,8 +198,8 @@ SUAMD_API void   suamd_agc_params_from_tau(struct suamd_agc_params *p, SUFLOAT t
 SUAMD_API suamd_agc_bank_t *suamd_agc_bank_new(suamd_ctx_t *ctx, unsigned nchan, const struct suamd_agc_params *p);
 SUAMD_API void   suamd_agc_bank_destroy(suamd_agc_bank_t *b);
 /* `dest[p] = su_agc_feed(&agc, origin[p])` loop (Tasks/AGCTask.cpp:70-73) */
-SUAMD_API SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride,
-                                     suamd_complex *d_y, SUSCOUNT y_stride, SUSCOUNT len, void *stream);
+SUAMD_API SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d_x, suamd_view xv,
+                                     suamd_complex *d_y, suamd_view yv, SUSCOUNT len, void *stream);
 
 #ifdef __cplusplus
 }

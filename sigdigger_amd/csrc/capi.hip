@@ -66,6 +66,22 @@ template <typename T> T *dev_zeros(size_t n)
 }
 
 inline hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
+inline sdk::View as_view(suamd_view v) { return sdk::View{(long long)v.chan_stride, (long long)v.time_stride}; }
+
+// grow-only device scratch owned by a plan / bank
+struct Scratch {
+  void *p = nullptr;
+  size_t bytes = 0;
+  bool reserve(size_t need)
+  {
+    if (need <= bytes) return true;
+    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    if (hipMalloc(&p, need) != hipSuccess) return false;
+    bytes = need;
+    return true;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
 
 // ---- parameter design (host, double precision; not on the hot path) ----------------------
 
@@ -130,6 +146,7 @@ struct suamd_psd {
   unsigned n, log2n;
   float *d_window;
   void  *d_twiddle;      // float2[n]
+  Scratch partial;       // split-frame partial sums
 };
 
 struct suamd_chanbank {
@@ -166,8 +183,10 @@ struct suamd_clock_bank {
 struct suamd_agc_bank {
   suamd_ctx *ctx;
   unsigned nchan;
+  uint64_t n_fed;        // samples fed so far (history ring position = n_fed mod mag_history_size)
   sdk::AgcParams p;
   sdk::AgcState  s;
+  Scratch scratch;       // 2 x [len][nchan] floats: magnitudes in dB; their sliding maximum, then levels
 };
 
 extern "C" {
@@ -227,7 +246,7 @@ suamd_psd_t *suamd_psd_new(suamd_ctx_t *ctx, unsigned n, int window_type)
     tw[2 * i] = (float)std::cos(ang);
     tw[2 * i + 1] = (float)std::sin(ang);
   }
-  suamd_psd *p = new (std::nothrow) suamd_psd;
+  suamd_psd *p = new (std::nothrow) suamd_psd();
   if (!p) { set_err("out of memory"); return nullptr; }
   p->ctx = ctx; p->n = n; p->log2n = log2n;
   p->d_window = dev_from_host(w);
@@ -245,6 +264,7 @@ void suamd_psd_destroy(suamd_psd_t *p)
   if (!p) return;
   if (p->d_window) hipFree(p->d_window);
   if (p->d_twiddle) hipFree(p->d_twiddle);
+  p->partial.release();
   delete p;
 }
 
@@ -255,8 +275,16 @@ SUBOOL suamd_psd_feed(suamd_psd_t *p, const suamd_complex *d_x, SUSCOUNT nframes
   if (navg == 0) { set_err("navg must be >= 1"); return SU_FALSE; }
   if (mode != SUAMD_PSD_LINEAR && mode != SUAMD_PSD_DB_SHIFTED) { set_err("bad mode %d", mode); return SU_FALSE; }
   const long long nout = (long long)(nframes / navg);
+  const int S = sdk::psd_split(nout, (int)navg);
+  float *partial = nullptr;
+  if (S > 1) {
+    // NOTE: growing the scratch frees the old one; callers that enqueue on several streams must
+    // size the plan with the largest request first
+    if (!p->partial.reserve(sizeof(float) * (size_t)nout * S * p->n)) { set_err("scratch allocation failed"); return SU_FALSE; }
+    partial = static_cast<float *>(p->partial.p);
+  }
   HIP_TRY(sdk::psd_frames((int)p->log2n, d_x, (long long)hop, (int)navg, p->d_window, p->d_twiddle, scale, mode,
-                          d_out, nout, as_stream(stream)), SU_FALSE);
+                          d_out, nout, partial, as_stream(stream)), SU_FALSE);
   return SU_TRUE;
 }
 
@@ -377,17 +405,20 @@ SUSCOUNT suamd_chanbank_output_count(const suamd_chanbank_t *b, SUSCOUNT len)
 }
 
 SUBOOL suamd_chanbank_feed(suamd_chanbank_t *b, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_y,
-                           SUSCOUNT y_stride, SUSCOUNT *n_out, void *stream)
+                           suamd_view yv, SUSCOUNT *n_out, void *stream)
 {
   if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
   uint64_t mf; SUSCOUNT no;
   chan_out_range(b, len, &mf, &no);
-  if (no > y_stride) { set_err("y_stride %llu smaller than output count %llu", (unsigned long long)y_stride, (unsigned long long)no); return SU_FALSE; }
+  if (yv.time_stride == 1 && b->nchan > 1 && no > yv.chan_stride) {
+    set_err("chan_stride %llu smaller than output count %llu", (unsigned long long)yv.chan_stride, (unsigned long long)no);
+    return SU_FALSE;
+  }
   sdk::ChanFeedArgs a;
   a.x = d_x; a.hist = b->d_hist; a.len = (long long)len; a.n0 = b->n_total;
   a.g = b->d_g; a.dphase = b->d_dphase; a.phase0 = b->d_phase0;
   a.ntaps = (int)b->ntaps; a.nchan = (int)b->nchan; a.D = b->D;
-  a.m_first = mf; a.n_out = (long long)no; a.y = d_y; a.y_stride = (long long)y_stride;
+  a.m_first = mf; a.n_out = (long long)no; a.y = d_y; a.yv = as_view(yv);
   HIP_TRY(sdk::chan_feed(a, as_stream(stream)), SU_FALSE);
   HIP_TRY(sdk::chan_update_hist(b->d_hist, d_x, (long long)len, (int)b->ntaps, as_stream(stream)), SU_FALSE);
   b->n_total += len;
@@ -405,13 +436,13 @@ SUBOOL suamd_chanbank_reset(suamd_chanbank_t *b, void *stream)
 }
 
 // ---- element-wise ------------------------------------------------------------------------------
-SUBOOL suamd_quad_demod_batch(suamd_ctx_t *ctx, const suamd_complex *d_x, SUSCOUNT x_stride, suamd_complex *d_y,
-                              SUSCOUNT y_stride, unsigned nchan, SUSCOUNT len, const suamd_complex *d_prev,
+SUBOOL suamd_quad_demod_batch(suamd_ctx_t *ctx, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y,
+                              suamd_view yv, unsigned nchan, SUSCOUNT len, const suamd_complex *d_prev,
                               SUBOOL first, suamd_complex *d_prev_out, void *stream)
 {
   if (!ctx || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
   if (!first && !d_prev) { set_err("d_prev required when first == SU_FALSE"); return SU_FALSE; }
-  HIP_TRY(sdk::quad_demod_batch(d_x, (long long)x_stride, d_y, (long long)y_stride, (int)nchan, (long long)len,
+  HIP_TRY(sdk::quad_demod_batch(d_x, as_view(xv), d_y, as_view(yv), (int)nchan, (long long)len,
                                 d_prev, first ? 1 : 0, d_prev_out, as_stream(stream)), SU_FALSE);
   return SU_TRUE;
 }
@@ -475,11 +506,11 @@ void suamd_costas_bank_destroy(suamd_costas_bank_t *b)
   delete b;
 }
 
-SUBOOL suamd_costas_bank_feed(suamd_costas_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride, suamd_complex *d_y,
-                              SUSCOUNT y_stride, SUSCOUNT len, void *stream)
+SUBOOL suamd_costas_bank_feed(suamd_costas_bank_t *b, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y,
+                              suamd_view yv, SUSCOUNT len, void *stream)
 {
   if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
-  HIP_TRY(sdk::costas_feed(b->p, b->s, (int)b->nchan, d_x, (long long)x_stride, d_y, (long long)y_stride,
+  HIP_TRY(sdk::costas_feed(b->p, b->s, (int)b->nchan, d_x, as_view(xv), d_y, as_view(yv),
                            (long long)len, as_stream(stream)), SU_FALSE);
   return SU_TRUE;
 }
@@ -521,11 +552,11 @@ void suamd_pll_bank_destroy(suamd_pll_bank_t *b)
   delete b;
 }
 
-SUBOOL suamd_pll_bank_feed(suamd_pll_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride, suamd_complex *d_y,
-                           SUSCOUNT y_stride, SUSCOUNT len, void *stream)
+SUBOOL suamd_pll_bank_feed(suamd_pll_bank_t *b, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y,
+                           suamd_view yv, SUSCOUNT len, void *stream)
 {
   if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
-  HIP_TRY(sdk::pll_feed(b->alpha, b->beta, b->s, (int)b->nchan, d_x, (long long)x_stride, d_y, (long long)y_stride,
+  HIP_TRY(sdk::pll_feed(b->alpha, b->beta, b->s, (int)b->nchan, d_x, as_view(xv), d_y, as_view(yv),
                         (long long)len, as_stream(stream)), SU_FALSE);
   return SU_TRUE;
 }
@@ -581,11 +612,11 @@ void suamd_clock_bank_destroy(suamd_clock_bank_t *b)
   delete b;
 }
 
-SUBOOL suamd_clock_bank_feed(suamd_clock_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride, SUSCOUNT len,
+SUBOOL suamd_clock_bank_feed(suamd_clock_bank_t *b, const suamd_complex *d_x, suamd_view xv, SUSCOUNT len,
                              suamd_complex *d_sym, SUSCOUNT sym_stride, uint32_t *d_count, void *stream)
 {
   if (!b || !d_x || !d_sym || !d_count) { set_err("null argument"); return SU_FALSE; }
-  HIP_TRY(sdk::clock_feed(b->p, b->s, (int)b->nchan, d_x, (long long)x_stride, (long long)len, d_sym,
+  HIP_TRY(sdk::clock_feed(b->p, b->s, (int)b->nchan, d_x, as_view(xv), (long long)len, d_sym,
                           (long long)sym_stride, d_count, as_stream(stream)), SU_FALSE);
   return SU_TRUE;
 }
@@ -620,10 +651,9 @@ suamd_agc_bank_t *suamd_agc_bank_new(suamd_ctx_t *ctx, unsigned nchan, const str
     return nullptr;
   }
   HIP_TRY(hipSetDevice(ctx->device), nullptr);
-  suamd_agc_bank *b = new (std::nothrow) suamd_agc_bank;
+  suamd_agc_bank *b = new (std::nothrow) suamd_agc_bank();
   if (!b) { set_err("out of memory"); return nullptr; }
-  std::memset(b, 0, sizeof *b);
-  b->ctx = ctx; b->nchan = nchan;
+  b->ctx = ctx; b->nchan = nchan; b->n_fed = 0;
   b->p.knee = pp->threshold;
   b->p.gain_slope = pp->slope_factor * 1e-2f;
   b->p.hang_max = pp->hang_max;
@@ -635,14 +665,10 @@ suamd_agc_bank_t *suamd_agc_bank_new(suamd_ctx_t *ctx, unsigned nchan, const str
   b->p.slow_alpha_fall = (float)(1.0 - std::exp(-1.0 / (double)pp->slow_fall_t));
   b->s.delay_line = dev_zeros<float>(64 * 2 * (size_t)nchan);
   b->s.mag_history = dev_zeros<float>(64 * (size_t)nchan);
-  b->s.delay_ptr = dev_zeros<unsigned>(nchan);
-  b->s.hist_ptr = dev_zeros<unsigned>(nchan);
   b->s.hang_n = dev_zeros<unsigned>(nchan);
-  b->s.peak = dev_zeros<float>(nchan);
   b->s.fast_level = dev_zeros<float>(nchan);
   b->s.slow_level = dev_zeros<float>(nchan);
-  if (!b->s.delay_line || !b->s.mag_history || !b->s.delay_ptr || !b->s.hist_ptr || !b->s.hang_n || !b->s.peak ||
-      !b->s.fast_level || !b->s.slow_level) {
+  if (!b->s.delay_line || !b->s.mag_history || !b->s.hang_n || !b->s.fast_level || !b->s.slow_level) {
     set_err("device allocation failed");
     suamd_agc_bank_destroy(b);
     return nullptr;
@@ -655,21 +681,23 @@ void suamd_agc_bank_destroy(suamd_agc_bank_t *b)
   if (!b) return;
   if (b->s.delay_line) hipFree(b->s.delay_line);
   if (b->s.mag_history) hipFree(b->s.mag_history);
-  if (b->s.delay_ptr) hipFree(b->s.delay_ptr);
-  if (b->s.hist_ptr) hipFree(b->s.hist_ptr);
   if (b->s.hang_n) hipFree(b->s.hang_n);
-  if (b->s.peak) hipFree(b->s.peak);
   if (b->s.fast_level) hipFree(b->s.fast_level);
   if (b->s.slow_level) hipFree(b->s.slow_level);
+  b->scratch.release();
   delete b;
 }
 
-SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride, suamd_complex *d_y,
-                           SUSCOUNT y_stride, SUSCOUNT len, void *stream)
+SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y,
+                           suamd_view yv, SUSCOUNT len, void *stream)
 {
   if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
-  HIP_TRY(sdk::agc_feed(b->p, b->s, (int)b->nchan, d_x, (long long)x_stride, d_y, (long long)y_stride,
-                        (long long)len, as_stream(stream)), SU_FALSE);
+  if (d_x == d_y) { set_err("the AGC bank cannot run in place (the output is the input delayed)"); return SU_FALSE; }
+  if (len == 0) return SU_TRUE;
+  if (!b->scratch.reserve(2 * sizeof(float) * (size_t)len * b->nchan)) { set_err("scratch allocation failed"); return SU_FALSE; }
+  HIP_TRY(sdk::agc_feed(b->p, b->s, (int)b->nchan, d_x, as_view(xv), d_y, as_view(yv), (long long)len,
+                        static_cast<float *>(b->scratch.p), as_stream(stream)), SU_FALSE);
+  b->n_fed += len;
   return SU_TRUE;
 }
 

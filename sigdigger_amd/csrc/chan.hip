@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void chan_fir_kernel(const float2 *__restrict_
                                                        const uint32_t *__restrict__ dphase,
                                                        const uint32_t *__restrict__ phase0, FirGeom ge,
                                                        uint64_t m_first, long long n_out,
-                                                       float2 *__restrict__ y, long long y_stride)
+                                                       float2 *__restrict__ y, sdk::View yv)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2 *win = reinterpret_cast<float2 *>(smem);
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void chan_fir_kernel(const float2 *__restrict_
     int k = 0;
     for (int colofs = kd_cols; colofs >= 0 && k < T; --colofs) {
       const int row_hi = (colofs == kd_cols) ? 0 : D - 1;             // irel = KD is row 0 of column kd_cols
-      const float2 *wp = win + colofs + ml;
+      const float2 *wp = win + colofs + (ml < ge.MT ? ml : ge.MT - 1);
       for (int row = row_hi; row >= 0 && k < T; --row, ++k) {
         const float2 v = wp[row * ge.LDW];
 #pragma unroll
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void chan_fir_kernel(const float2 *__restrict_
           float cs, sn;
           sd::phasor_u32(phase0[c] + (uint32_t)(n * (uint64_t)dphase[c]), cs, sn);
           const c32 r = sd::cmul_cs(c32{ar[j], ai[j]}, cs, sn);
-          y[(long long)c * y_stride + m_rel] = float2{r.re, r.im};
+          y[(long long)c * yv.cs + m_rel * yv.ms] = float2{r.re, r.im};
         }
       }
     }
@@ -199,7 +199,7 @@ hipError_t launch_fir(const sdk::ChanFeedArgs &a, const FirGeom &ge, size_t lds,
   hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds, st,
                      reinterpret_cast<const float2 *>(a.x), reinterpret_cast<const float2 *>(a.hist), a.len, a.n0,
                      reinterpret_cast<const float2 *>(a.g), a.dphase, a.phase0, ge, a.m_first, a.n_out,
-                     reinterpret_cast<float2 *>(a.y), a.y_stride);
+                     reinterpret_cast<float2 *>(a.y), a.yv);
   return hipGetLastError();
 }
 

@@ -6,9 +6,19 @@
 
 namespace sdk {
 
+// A batch of nchan sample rows: element (c, m) lives at base[c*cs + m*ms] (units: complex samples).
+//   channel-major  [c][m]: cs = row pitch, ms = 1   (what consumers of sample batches want)
+//   time-major     [m][c]: cs = 1, ms = nchan pitch (what one-lane-per-channel kernels want:
+//                                                    a wavefront's access is one contiguous 512 B)
+struct View { long long cs, ms; };
+
 // ---- psd.hip ----
+// partial: scratch for split-frame accumulation, >= nout * psd_split(nout, navg) * N floats (may be
+// nullptr when psd_split() == 1)
+int        psd_split(long long nout, int navg);
 hipError_t psd_frames(int log2n, const void *x, long long hop, int navg, const float *window,
-                      const void *tw, float scale, int mode, float *out, long long nout, hipStream_t st);
+                      const void *tw, float scale, int mode, float *out, long long nout, float *partial,
+                      hipStream_t st);
 hipError_t psd_shift_db(float *psd, long long n, long long nframes, hipStream_t st);
 hipError_t averager_feed(float *last, const float *x, long long n, float alpha, int blend, hipStream_t st);
 hipError_t insp_spectrum_db_shift(float *data, long long len, long long nspec, hipStream_t st);
@@ -28,14 +38,14 @@ struct ChanFeedArgs {
   uint32_t    D;
   uint64_t    m_first;  // first output index (n = m*D)
   long long   n_out;
-  void       *y;        // [nchan][y_stride]
-  long long   y_stride;
+  void       *y;        // element (c, m) at y[c*yv.cs + m*yv.ms]
+  View        yv;
 };
 hipError_t chan_feed(const ChanFeedArgs &a, hipStream_t st);
 hipError_t chan_update_hist(void *hist, const void *x, long long len, int ntaps, hipStream_t st);
 
 // ---- loops.hip ----
-hipError_t quad_demod_batch(const void *x, long long xs, void *y, long long ys, int nchan, long long len,
+hipError_t quad_demod_batch(const void *x, View xv, void *y, View yv, int nchan, long long len,
                             const void *prev, int first, void *prev_out, hipStream_t st);
 hipError_t delayed_conj_bulk(const void *x, void *y, long long len, long long delay, hipStream_t st);
 hipError_t histogram_feed_bulk(const void *x, long long len, int space, float *out, hipStream_t st);
@@ -45,18 +55,18 @@ struct CostasState {            // SoA over channels, all device pointers
   float *xh; float *yh;         // [4][2][nchan] : history index, re/im, channel
 };
 struct CostasParams { int kind; int order; float a, b, gain; float fb[5]; float fa[5]; };
-hipError_t costas_feed(const CostasParams &p, const CostasState &s, int nchan, const void *x, long long xs,
-                       void *y, long long ys, long long len, hipStream_t st);
+hipError_t costas_feed(const CostasParams &p, const CostasState &s, int nchan, const void *x, View xv,
+                       void *y, View yv, long long len, hipStream_t st);
 
 struct PllState { uint32_t *phase; float *omega; };
-hipError_t pll_feed(float alpha, float beta, const PllState &s, int nchan, const void *x, long long xs,
-                    void *y, long long ys, long long len, hipStream_t st);
+hipError_t pll_feed(float alpha, float beta, const PllState &s, int nchan, const void *x, View xv,
+                    void *y, View yv, long long len, hipStream_t st);
 
 struct ClockState {             // all [nchan]
   float *phi, *bnor; int *halfcycle; float *prev, *x0, *x1, *x2;   // complex ones: [2][nchan]
 };
 struct ClockParams { float alpha, beta, gain, bmin, bmax; };
-hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, const void *x, long long xs,
+hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, const void *x, View xv,
                       long long len, void *sym, long long sym_stride, uint32_t *count, hipStream_t st);
 
 struct AgcParams {
@@ -65,12 +75,14 @@ struct AgcParams {
   unsigned hang_max, delay_line_size, mag_history_size;
 };
 struct AgcState {               // device
-  float *delay_line;            // [64][2][nchan]
-  float *mag_history;           // [64][nchan]
-  unsigned *delay_ptr, *hist_ptr, *hang_n;
-  float *peak, *fast_level, *slow_level;
+  float *delay_line;            // [delay_line_size][2][nchan]: the last inputs, oldest first
+  float *mag_history;           // [mag_history_size-1][nchan]: the last magnitudes (dB), oldest first
+  unsigned *hang_n;             // [nchan]
+  float *fast_level, *slow_level;
 };
-hipError_t agc_feed(const AgcParams &p, const AgcState &s, int nchan, const void *x, long long xs,
-                    void *y, long long ys, long long len, hipStream_t st);
+// |x|^2 -> dB and its sliding maximum (parallel), level tracking (one lane per channel), gain
+// (parallel), state carry.  scratch: >= 2 * len * nchan floats.
+hipError_t agc_feed(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv,
+                    void *y, View yv, long long len, float *scratch, hipStream_t st);
 
 }  // namespace sdk

@@ -3,8 +3,10 @@
 //
 // The recurrences are serial in time and non-linear (sign(), wrap, data-dependent strobes),
 // so the only exact parallel axis is the channel: ONE LANE PER CHANNEL, 64 channels per
-// wavefront, state in registers for the whole block, samples streamed from the channel-major
-// [channel][time] layout in 64-byte per-lane chunks that are prefetched one chunk ahead.
+// wavefront, state in registers for the whole block.  Rows are addressed through a two-stride
+// view (kernels.hpp: View); with the time-major layout [time][channel] a wavefront's access
+// to one time step is a single contiguous 512-byte transaction, and CHUNK steps are
+// prefetched one chunk ahead of the serial arithmetic.
 // Compiled with -ffp-contract=off: the arithmetic is the SPEC's fixed binary32 sequence and
 // matches the CPU oracle bit for bit.
 #include <hip/hip_runtime.h>
@@ -15,36 +17,73 @@
 namespace {
 
 using sd::c32;
-constexpr int CHUNK = 8;     // samples per lane per prefetch (64 bytes)
+constexpr int CHUNK = 16;    // time steps prefetched per lane (one chunk ahead of the arithmetic)
 
-__device__ __forceinline__ void load_chunk(const float2 *__restrict__ row, long long i, long long len, float2 *buf)
+// Element (c, m) of a view = base[c*cs + m*ms]: the m*ms part is wave-uniform (scalar base
+// address), the c*cs part is a 32-bit per-lane byte offset -> "saddr + voffset" addressing, no
+// 64-bit vector address arithmetic per access.
+template <typename T>
+__device__ __forceinline__ T ld_elem(const T *__restrict__ base, long long uniform_elem, uint32_t lane_off)
 {
+  const char *b = reinterpret_cast<const char *>(base + uniform_elem);
+  return *reinterpret_cast<const T *>(b + lane_off);
+}
+template <typename T>
+__device__ __forceinline__ void st_elem(T *__restrict__ base, long long uniform_elem, uint32_t lane_off, T v)
+{
+  char *b = reinterpret_cast<char *>(base + uniform_elem);
+  *reinterpret_cast<T *>(b + lane_off) = v;
+}
+
+// Streams `len` time steps of one lane's row through step(m, value): chunks of CHUNK steps are
+// prefetched one chunk ahead; the steady-state loop has no bounds checks (a single wavefront
+// issues ~one instruction per 4-5 cycles, so per-sample instruction count is the cost).
+template <typename T, typename F>
+__device__ __forceinline__ void stream_row(const T *__restrict__ x, long long ms, uint32_t lane_off, long long len,
+                                           F step)
+{
+  long long i = 0;
+  if (len >= 2 * CHUNK) {
+    T cur[CHUNK], nxt[CHUNK];
 #pragma unroll
-  for (int j = 0; j < CHUNK; ++j) buf[j] = (i + j < len) ? row[i + j] : float2{0.0f, 0.0f};
+    for (int j = 0; j < CHUNK; ++j) cur[j] = ld_elem(x, (long long)j * ms, lane_off);
+    for (; i + 2 * CHUNK <= len; i += CHUNK) {
+#pragma unroll
+      for (int j = 0; j < CHUNK; ++j) nxt[j] = ld_elem(x, (i + CHUNK + j) * ms, lane_off);
+#pragma unroll
+      for (int j = 0; j < CHUNK; ++j) step(i + j, cur[j]);
+#pragma unroll
+      for (int j = 0; j < CHUNK; ++j) cur[j] = nxt[j];
+    }
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) step(i + j, cur[j]);
+    i += CHUNK;
+  }
+  for (; i < len; ++i) step(i, ld_elem(x, i * ms, lane_off));
 }
 
 // ---------------------------------------------------------------------------------------
 // T5: QuadDemodTask::work  dest[p] = j/pi * arg(x[p] conj(x[p-1]))
-__global__ void quad_demod_kernel(const float2 *__restrict__ x, long long xs, float2 *__restrict__ y, long long ys,
+__global__ void quad_demod_kernel(const float2 *__restrict__ x, sdk::View xv, float2 *__restrict__ y, sdk::View yv,
                                   long long len, const float2 *__restrict__ prev, int first,
                                   float2 *__restrict__ prev_out)
 {
   const int c = blockIdx.y;
-  const float2 *xr = x + (long long)c * xs;
-  float2 *yr = y + (long long)c * ys;
+  const float2 *xr = x + (long long)c * xv.cs;
+  float2 *yr = y + (long long)c * yv.cs;
   const float k = 0.318309886183790671538f;
   for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < len;
        p += (long long)gridDim.x * blockDim.x) {
-    const float2 v = xr[p];
+    const float2 v = xr[p * xv.ms];
     float2 out;
     if (p == 0 && first) {
       out = float2{0.0f, 0.0f};
     } else {
-      const float2 pv = (p == 0) ? prev[c] : xr[p - 1];
+      const float2 pv = (p == 0) ? prev[c] : xr[(p - 1) * xv.ms];
       const c32 d = sd::cmul_conj(c32{v.x, v.y}, c32{pv.x, pv.y});
       out = float2{0.0f, k * sd::atan2_(d.im, d.re)};
     }
-    yr[p] = out;
+    yr[p * yv.ms] = out;
     if (prev_out != nullptr && p == len - 1) prev_out[c] = v;
   }
 }
@@ -95,7 +134,7 @@ template <int ORDER> struct CostasRegs {
   c32 xh[ORDER + 1], yh[ORDER + 1];
 };
 
-template <int ORDER>
+template <int KIND, int ORDER>
 __device__ __forceinline__ float2 costas_step(const sdk::CostasParams &p, CostasRegs<ORDER> &r, float2 v)
 {
   // history part of the arm filter first: it does not depend on the new sample
@@ -115,12 +154,12 @@ __device__ __forceinline__ float2 costas_step(const sdk::CostasParams &p, Costas
 #pragma unroll
   for (int q = ORDER; q >= 2; --q) { r.xh[q] = r.xh[q - 1]; r.yh[q] = r.yh[q - 1]; }
   if (ORDER >= 1) { r.xh[1] = m; r.yh[1] = z; }
-  z.re = p.gain * z.re;
+  z.re = p.gain * z.re;                                       // gain is 1 upstream; x*1 is exact
   z.im = p.gain * z.im;
   float e;
-  if (p.kind == 1) {
+  if (KIND == 1) {
     e = z.re * z.im;
-  } else if (p.kind == 2) {
+  } else if (KIND == 2) {
     e = sd::sgn(z.re) * z.im - sd::sgn(z.im) * z.re;
   } else {
     if (__builtin_fabsf(z.re) >= __builtin_fabsf(z.im))
@@ -134,10 +173,14 @@ __device__ __forceinline__ float2 costas_step(const sdk::CostasParams &p, Costas
   return float2{z.re, z.im};
 }
 
-template <int ORDER>
+// A single wavefront issues roughly one instruction every 4-5 cycles, so the cost of a serial
+// recurrence is its dynamic instruction count per sample: the loop kind is a template
+// parameter (no per-sample scalar branching), full chunks run without bounds checks and only
+// the last partial chunk is guarded.
+template <int KIND, int ORDER>
 __global__ __launch_bounds__(64) void costas_kernel(sdk::CostasParams p, sdk::CostasState s, int nchan,
-                                                    const float2 *__restrict__ x, long long xs,
-                                                    float2 *__restrict__ y, long long ys, long long len)
+                                                    const float2 *__restrict__ x, sdk::View xv,
+                                                    float2 *__restrict__ y, sdk::View yv, long long len)
 {
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= nchan) return;
@@ -149,202 +192,244 @@ __global__ __launch_bounds__(64) void costas_kernel(sdk::CostasParams p, sdk::Co
     r.xh[i] = c32{s.xh[((i - 1) * 2 + 0) * nchan + c], s.xh[((i - 1) * 2 + 1) * nchan + c]};
     r.yh[i] = c32{s.yh[((i - 1) * 2 + 0) * nchan + c], s.yh[((i - 1) * 2 + 1) * nchan + c]};
   }
-  const float2 *xr = x + (long long)c * xs;
-  float2 *yr = y + (long long)c * ys;
-  float2 cur[CHUNK], nxt[CHUNK];
-  load_chunk(xr, 0, len, cur);
-  for (long long i = 0; i < len; i += CHUNK) {
-    load_chunk(xr, i + CHUNK, len, nxt);
-#pragma unroll
-    for (int j = 0; j < CHUNK; ++j)
-      if (i + j < len) yr[i + j] = costas_step<ORDER>(p, r, cur[j]);     // len is wave-uniform
-#pragma unroll
-    for (int j = 0; j < CHUNK; ++j) cur[j] = nxt[j];
-  }
+  const uint32_t xo = (uint32_t)((long long)c * xv.cs * 8), yo = (uint32_t)((long long)c * yv.cs * 8);
+  const long long yms = yv.ms;
+  stream_row(x, xv.ms, xo, len, [&](long long m, float2 v) {
+    st_elem(y, m * yms, yo, costas_step<KIND, ORDER>(p, r, v));
+  });
   s.phase[c] = r.phase;
   s.omega[c] = r.omega;
 #pragma unroll
-  for (int i = 1; i <= ORDER; ++i) {
-    s.xh[((i - 1) * 2 + 0) * nchan + c] = r.xh[i].re; s.xh[((i - 1) * 2 + 1) * nchan + c] = r.xh[i].im;
-    s.yh[((i - 1) * 2 + 0) * nchan + c] = r.yh[i].re; s.yh[((i - 1) * 2 + 1) * nchan + c] = r.yh[i].im;
+  for (int i2 = 1; i2 <= ORDER; ++i2) {
+    s.xh[((i2 - 1) * 2 + 0) * nchan + c] = r.xh[i2].re; s.xh[((i2 - 1) * 2 + 1) * nchan + c] = r.xh[i2].im;
+    s.yh[((i2 - 1) * 2 + 0) * nchan + c] = r.yh[i2].re; s.yh[((i2 - 1) * 2 + 1) * nchan + c] = r.yh[i2].im;
   }
 }
 
 // ---------------------------------------------------------------------------------------
 // K7: PLL
+__device__ __forceinline__ float2 pll_step(float alpha, float beta, uint32_t &phase, float &omega, float2 v)
+{
+  float cs, sn;
+  sd::phasor_u32(phase, cs, sn);
+  float2 m;
+  m.x = sd::fma_(v.y, sn, v.x * cs);
+  m.y = sd::fma_(v.y, cs, -(v.x * sn));
+  float err = sd::atan2_(v.y, v.x) - sd::phase_to_rad(phase);
+  if (err >  3.14159265358979323846f) err -= 6.28318530717958647692f;
+  if (err < -3.14159265358979323846f) err += 6.28318530717958647692f;
+  const float dphi = sd::fma_(beta, err, omega);
+  omega = sd::fma_(alpha, err, omega);
+  phase += (uint32_t)sd::rad_to_dphase(dphi);
+  return m;
+}
+
 __global__ __launch_bounds__(64) void pll_kernel(float alpha, float beta, sdk::PllState s, int nchan,
-                                                 const float2 *__restrict__ x, long long xs,
-                                                 float2 *__restrict__ y, long long ys, long long len)
+                                                 const float2 *__restrict__ x, sdk::View xv,
+                                                 float2 *__restrict__ y, sdk::View yv, long long len)
 {
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= nchan) return;
   uint32_t phase = s.phase[c];
   float omega = s.omega[c];
-  const float2 *xr = x + (long long)c * xs;
-  float2 *yr = y + (long long)c * ys;
-  float2 cur[CHUNK], nxt[CHUNK];
-  load_chunk(xr, 0, len, cur);
-  for (long long i = 0; i < len; i += CHUNK) {
-    load_chunk(xr, i + CHUNK, len, nxt);
-#pragma unroll
-    for (int j = 0; j < CHUNK; ++j) {
-      if (i + j < len) {
-        const float2 v = cur[j];
-        float cs, sn;
-        sd::phasor_u32(phase, cs, sn);
-        float2 m;
-        m.x = sd::fma_(v.y, sn, v.x * cs);
-        m.y = sd::fma_(v.y, cs, -(v.x * sn));
-        float err = sd::atan2_(v.y, v.x) - sd::phase_to_rad(phase);
-        if (err >  3.14159265358979323846f) err -= 6.28318530717958647692f;
-        if (err < -3.14159265358979323846f) err += 6.28318530717958647692f;
-        const float dphi = sd::fma_(beta, err, omega);
-        omega = sd::fma_(alpha, err, omega);
-        phase += (uint32_t)sd::rad_to_dphase(dphi);
-        yr[i + j] = m;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < CHUNK; ++j) cur[j] = nxt[j];
-  }
+  const uint32_t xo = (uint32_t)((long long)c * xv.cs * 8), yo = (uint32_t)((long long)c * yv.cs * 8);
+  const long long yms = yv.ms;
+  stream_row(x, xv.ms, xo, len, [&](long long m, float2 v) {
+    st_elem(y, m * yms, yo, pll_step(alpha, beta, phase, omega, v));
+  });
   s.phase[c] = phase;
   s.omega[c] = omega;
 }
 
 // ---------------------------------------------------------------------------------------
 // K8: Gardner clock recovery; variable-rate output, per-lane append
+struct ClockRegs {
+  float phi, bnor;
+  int halfcycle;
+  float2 prev, x0, x1, x2;
+  uint32_t n;
+};
+
+__device__ __forceinline__ void clock_step(const sdk::ClockParams &p, ClockRegs &r, float2 v, float2 *__restrict__ out)
+{
+  r.phi = r.phi + r.bnor;
+  if (r.phi >= 0.5f) {
+    const float mu = (r.phi - 0.5f) / r.bnor;
+    float2 q;
+    q.x = sd::fma_(mu, r.prev.x - v.x, v.x);
+    q.y = sd::fma_(mu, r.prev.y - v.y, v.y);
+    r.phi = r.phi - 0.5f;
+    r.halfcycle = !r.halfcycle;
+    if (!r.halfcycle) {
+      r.x2 = r.x0;
+      r.x0 = q;
+      const float dr = r.x0.x - r.x2.x, di = r.x0.y - r.x2.y;
+      const float e = p.gain * sd::fma_(r.x1.y, di, r.x1.x * dr);
+      r.phi = sd::fma_(p.alpha, e, r.phi);
+      float b = sd::fma_(p.beta, e, r.bnor);
+      if (b < p.bmin) b = p.bmin;
+      if (b > p.bmax) b = p.bmax;
+      r.bnor = b;
+      out[r.n++] = q;
+    } else {
+      r.x1 = q;
+    }
+  }
+  r.prev = v;
+}
+
 __global__ __launch_bounds__(64) void clock_kernel(sdk::ClockParams p, sdk::ClockState s, int nchan,
-                                                   const float2 *__restrict__ x, long long xs, long long len,
+                                                   const float2 *__restrict__ x, sdk::View xv, long long len,
                                                    float2 *__restrict__ sym, long long sym_stride,
                                                    uint32_t *__restrict__ count)
 {
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= nchan) return;
-  float phi = s.phi[c], bnor = s.bnor[c];
-  int halfcycle = s.halfcycle[c];
-  float2 prev = float2{s.prev[c], s.prev[nchan + c]};
-  float2 x0 = float2{s.x0[c], s.x0[nchan + c]};
-  float2 x1 = float2{s.x1[c], s.x1[nchan + c]};
-  float2 x2 = float2{s.x2[c], s.x2[nchan + c]};
-  uint32_t n = count[c];
-  const float2 *xr = x + (long long)c * xs;
+  ClockRegs r;
+  r.phi = s.phi[c]; r.bnor = s.bnor[c];
+  r.halfcycle = s.halfcycle[c];
+  r.prev = float2{s.prev[c], s.prev[nchan + c]};
+  r.x0 = float2{s.x0[c], s.x0[nchan + c]};
+  r.x1 = float2{s.x1[c], s.x1[nchan + c]};
+  r.x2 = float2{s.x2[c], s.x2[nchan + c]};
+  r.n = count[c];
+  const uint32_t xo = (uint32_t)((long long)c * xv.cs * 8);
   float2 *out = sym + (long long)c * sym_stride;
-  float2 cur[CHUNK], nxt[CHUNK];
-  load_chunk(xr, 0, len, cur);
-  for (long long i = 0; i < len; i += CHUNK) {
-    load_chunk(xr, i + CHUNK, len, nxt);
-#pragma unroll
-    for (int j = 0; j < CHUNK; ++j) {
-      if (i + j < len) {
-        const float2 v = cur[j];
-        phi = phi + bnor;
-        if (phi >= 0.5f) {
-          const float mu = (phi - 0.5f) / bnor;
-          float2 q;
-          q.x = sd::fma_(mu, prev.x - v.x, v.x);
-          q.y = sd::fma_(mu, prev.y - v.y, v.y);
-          phi = phi - 0.5f;
-          halfcycle = !halfcycle;
-          if (!halfcycle) {
-            x2 = x0;
-            x0 = q;
-            const float dr = x0.x - x2.x, di = x0.y - x2.y;
-            const float e = p.gain * sd::fma_(x1.y, di, x1.x * dr);
-            phi = sd::fma_(p.alpha, e, phi);
-            float b = sd::fma_(p.beta, e, bnor);
-            if (b < p.bmin) b = p.bmin;
-            if (b > p.bmax) b = p.bmax;
-            bnor = b;
-            out[n++] = q;
-          } else {
-            x1 = q;
-          }
-        }
-        prev = v;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < CHUNK; ++j) cur[j] = nxt[j];
-  }
-  s.phi[c] = phi; s.bnor[c] = bnor; s.halfcycle[c] = halfcycle;
-  s.prev[c] = prev.x; s.prev[nchan + c] = prev.y;
-  s.x0[c] = x0.x; s.x0[nchan + c] = x0.y;
-  s.x1[c] = x1.x; s.x1[nchan + c] = x1.y;
-  s.x2[c] = x2.x; s.x2[nchan + c] = x2.y;
-  count[c] = n;
+  stream_row(x, xv.ms, xo, len, [&](long long, float2 v) { clock_step(p, r, v, out); });
+  s.phi[c] = r.phi; s.bnor[c] = r.bnor; s.halfcycle[c] = r.halfcycle;
+  s.prev[c] = r.prev.x; s.prev[nchan + c] = r.prev.y;
+  s.x0[c] = r.x0.x; s.x0[nchan + c] = r.x0.y;
+  s.x1[c] = r.x1.x; s.x1[nchan + c] = r.x1.y;
+  s.x2[c] = r.x2.x; s.x2[nchan + c] = r.x2.y;
+  count[c] = r.n;
 }
 
 // ---------------------------------------------------------------------------------------
-// K9: AGC.  Delay line and magnitude history (<= 64 entries each) live in LDS, laid out
-// [entry][lane] so that the common case (all lanes at the same ring position) is conflict-free.
-__global__ __launch_bounds__(64) void agc_kernel(sdk::AgcParams p, sdk::AgcState s, int nchan,
-                                                 const float2 *__restrict__ x, long long xs,
-                                                 float2 *__restrict__ y, long long ys, long long len)
+// K9: AGC (SPEC.md section H).  Only the fast / slow level trackers are a recurrence.  The dB
+// conversion, the sliding maximum over the magnitude history (a pure function of the last H
+// magnitudes: the oracle's "peak", which it maintains by rescanning whenever the old peak
+// leaves the history, is always exactly that maximum) and the gain applied to the delayed
+// sample are feed-forward, so the bank runs as
+//   (1) agc_mag_kernel   : db[m][c]   = 10 log10(|x|^2 + 1e-8)                       parallel
+//   (2) agc_peak_kernel  : peak[m][c] = max(db[m-H+1 .. m][c])  (history for m < H-1)  parallel
+//   (3) agc_level_kernel : fast / slow levels + hang counter -> lvl[m][c] in place     1 lane/channel
+//   (4) agc_apply_kernel : y = x[m - delay] * 10^(lvl*(slope-1)/20) * 0.7              parallel
+//   (5) agc_state_kernel : carries the last H-1 magnitudes and `delay` inputs to the next block
+__global__ void agc_mag_kernel(const float2 *__restrict__ x, sdk::View xv, int nchan, long long len,
+                               float *__restrict__ db)
 {
-  __shared__ float dl_re[64][64], dl_im[64][64], mh[64][64];
-  const int lane = threadIdx.x;
-  const int c = blockIdx.x * 64 + lane;
-  if (c >= nchan) return;
-  for (unsigned i = 0; i < p.delay_line_size; ++i) {
-    dl_re[i][lane] = s.delay_line[(i * 2 + 0) * nchan + c];
-    dl_im[i][lane] = s.delay_line[(i * 2 + 1) * nchan + c];
+  const long long total = len * nchan;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long m = t / nchan;
+    const int c = (int)(t - m * nchan);
+    const float2 v = x[(long long)c * xv.cs + m * xv.ms];
+    const float pw = sd::fma_(v.x, v.x, v.y * v.y) + 1e-8f;
+    db[t] = 3.01029995663981195f * sd::log2_(pw);
   }
-  for (unsigned i = 0; i < p.mag_history_size; ++i) mh[i][lane] = s.mag_history[i * nchan + c];
-  unsigned dptr = s.delay_ptr[c], hptr = s.hist_ptr[c], hang_n = s.hang_n[c];
-  float peak = s.peak[c], fast = s.fast_level[c], slow = s.slow_level[c];
-  const float2 *xr = x + (long long)c * xs;
-  float2 *yr = y + (long long)c * ys;
-  float2 cur[CHUNK], nxt[CHUNK];
-  load_chunk(xr, 0, len, cur);
-  for (long long i = 0; i < len; i += CHUNK) {
-    load_chunk(xr, i + CHUNK, len, nxt);
-#pragma unroll
-    for (int j = 0; j < CHUNK; ++j) {
-      if (i + j < len) {
-        const float2 v = cur[j];
-        const float2 xd = float2{dl_re[dptr][lane], dl_im[dptr][lane]};
-        dl_re[dptr][lane] = v.x; dl_im[dptr][lane] = v.y;
-        if (++dptr == p.delay_line_size) dptr = 0;
-        const float pw = sd::fma_(v.x, v.x, v.y * v.y) + 1e-8f;
-        const float x_db = 3.01029995663981195f * sd::log2_(pw);
-        const float x_db_old = mh[hptr][lane];
-        mh[hptr][lane] = x_db;
-        if (++hptr == p.mag_history_size) hptr = 0;
-        if (peak < x_db) {
-          peak = x_db;
-        } else if (peak == x_db_old) {
-          float pk = -160.0f;
-          for (unsigned q = 0; q < p.mag_history_size; ++q) { const float h = mh[q][lane]; if (pk < h) pk = h; }
-          peak = pk;
-        }
-        float d = peak - fast;
-        fast = sd::fma_(d > 0.0f ? p.fast_alpha_rise : p.fast_alpha_fall, d, fast);
-        d = peak - slow;
-        if (d > 0.0f) {
-          slow = sd::fma_(p.slow_alpha_rise, d, slow);
-          hang_n = 0;
-        } else if (hang_n >= p.hang_max) {
-          slow = sd::fma_(p.slow_alpha_fall, d, slow);
-        } else {
-          ++hang_n;
-        }
-        float lvl = fast > slow ? fast : slow;
-        if (lvl < p.knee) lvl = p.knee;
-        const float g_db = lvl * (p.gain_slope - 1.0f);
-        const float g = sd::exp2_(g_db * 0.166096404744368117f) * 0.7f;
-        yr[i + j] = float2{xd.x * g, xd.y * g};
-      }
+}
+
+__global__ void agc_peak_kernel(const float *__restrict__ db, const float *__restrict__ hist, int nchan,
+                                long long len, int H, float *__restrict__ peak)
+{
+  const long long total = len * nchan;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long m = t / nchan;
+    const int c = (int)(t - m * nchan);
+    float pk = db[t];
+    for (int i = 1; i < H; ++i) {
+      const long long idx = m - i;
+      const float v = idx >= 0 ? db[idx * nchan + c] : hist[(idx + (H - 1)) * nchan + c];
+      pk = pk > v ? pk : v;
     }
-#pragma unroll
-    for (int j = 0; j < CHUNK; ++j) cur[j] = nxt[j];
+    peak[t] = pk;
   }
-  for (unsigned i = 0; i < p.delay_line_size; ++i) {
-    s.delay_line[(i * 2 + 0) * nchan + c] = dl_re[i][lane];
-    s.delay_line[(i * 2 + 1) * nchan + c] = dl_im[i][lane];
+}
+
+__global__ __launch_bounds__(64) void agc_level_kernel(sdk::AgcParams p, sdk::AgcState s, int nchan,
+                                                       long long len, float *__restrict__ peak)
+{
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= nchan) return;
+  unsigned hang_n = s.hang_n[c];
+  float fast = s.fast_level[c], slow = s.slow_level[c];
+  const uint32_t lo = (uint32_t)c * 4u;
+  // parameters into registers: selecting between two fields of the by-value kernel argument
+  // otherwise compiles to an address select + a kernarg load + s_waitcnt vmcnt(0) PER SAMPLE
+  const float far = p.fast_alpha_rise, faf = p.fast_alpha_fall, sar = p.slow_alpha_rise, saf = p.slow_alpha_fall;
+  const float knee = p.knee;
+  const unsigned hang_max = p.hang_max;
+  stream_row(peak, (long long)nchan, lo, len, [&](long long m, float pk) {
+    float d = pk - fast;
+    const float fa = d > 0.0f ? far : faf;
+    fast = sd::fma_(fa, d, fast);
+    d = pk - slow;
+    // hang logic, branch-free: a rise resets the counter, a fall only after hang_max quiet samples
+    const bool rise = d > 0.0f;
+    const bool fall = !rise && hang_n >= hang_max;
+    const float sa = rise ? sar : saf;
+    const float upd = sd::fma_(sa, d, slow);
+    slow = (rise || fall) ? upd : slow;
+    hang_n = rise ? 0u : (fall ? hang_n : hang_n + 1u);
+    float lvl = fast > slow ? fast : slow;
+    if (lvl < knee) lvl = knee;
+    st_elem(peak, m * (long long)nchan, lo, lvl);
+  });
+  s.hang_n[c] = hang_n; s.fast_level[c] = fast; s.slow_level[c] = slow;
+}
+
+__global__ void agc_apply_kernel(sdk::AgcParams p, const float *__restrict__ delay_line, int nchan,
+                                 const float2 *__restrict__ x, sdk::View xv, float2 *__restrict__ y, sdk::View yv,
+                                 long long len, const float *__restrict__ lvl)
+{
+  const long long total = len * nchan;
+  const long long delay = p.delay_line_size;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long m = t / nchan;
+    const int c = (int)(t - m * nchan);
+    float2 xd;
+    if (m >= delay) {
+      xd = x[(long long)c * xv.cs + (m - delay) * xv.ms];
+    } else {
+      xd = float2{delay_line[(m * 2 + 0) * nchan + c], delay_line[(m * 2 + 1) * nchan + c]};
+    }
+    const float g_db = lvl[t] * (p.gain_slope - 1.0f);
+    const float g = sd::exp2_(g_db * 0.166096404744368117f) * 0.7f;
+    y[(long long)c * yv.cs + m * yv.ms] = float2{xd.x * g, xd.y * g};
   }
-  for (unsigned i = 0; i < p.mag_history_size; ++i) s.mag_history[i * nchan + c] = mh[i][lane];
-  s.delay_ptr[c] = dptr; s.hist_ptr[c] = hptr; s.hang_n[c] = hang_n;
-  s.peak[c] = peak; s.fast_level[c] = fast; s.slow_level[c] = slow;
+}
+
+// delay line <- last `delay` samples of [delay line ; x];  magnitude history <- last H-1 values of
+// [history ; db]   (one lane per channel; both are tiny)
+__global__ __launch_bounds__(64) void agc_state_kernel(float *delay_line, float *hist, int nchan, int delay, int H,
+                                                       const float2 *__restrict__ x, sdk::View xv,
+                                                       const float *__restrict__ db, long long len)
+{
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= nchan) return;
+  float2 tmp[64];
+#pragma unroll 1
+  for (int i = 0; i < delay; ++i) {
+    const long long src = (long long)i + len;             // index into [delay line ; x]
+    tmp[i] = src < delay ? float2{delay_line[(src * 2 + 0) * nchan + c], delay_line[(src * 2 + 1) * nchan + c]}
+                         : x[(long long)c * xv.cs + (src - delay) * xv.ms];
+  }
+#pragma unroll 1
+  for (int i = 0; i < delay; ++i) {
+    delay_line[(i * 2 + 0) * nchan + c] = tmp[i].x;
+    delay_line[(i * 2 + 1) * nchan + c] = tmp[i].y;
+  }
+  const int hl = H - 1;
+  float th[64];
+#pragma unroll 1
+  for (int i = 0; i < hl; ++i) {
+    const long long src = (long long)i + len;             // index into [history ; db]
+    th[i] = src < hl ? hist[src * nchan + c] : db[(src - hl) * nchan + c];
+  }
+#pragma unroll 1
+  for (int i = 0; i < hl; ++i) hist[(long long)i * nchan + c] = th[i];
 }
 
 inline unsigned grid_for(long long n, int block) {
@@ -358,7 +443,7 @@ inline unsigned grid_for(long long n, int block) {
 
 namespace sdk {
 
-hipError_t quad_demod_batch(const void *x, long long xs, void *y, long long ys, int nchan, long long len,
+hipError_t quad_demod_batch(const void *x, View xs, void *y, View ys, int nchan, long long len,
                             const void *prev, int first, void *prev_out, hipStream_t st)
 {
   if (len <= 0 || nchan <= 0) return hipSuccess;
@@ -386,26 +471,28 @@ hipError_t histogram_feed_bulk(const void *x, long long len, int space, float *o
   return hipGetLastError();
 }
 
-hipError_t costas_feed(const CostasParams &p, const CostasState &s, int nchan, const void *x, long long xs,
-                       void *y, long long ys, long long len, hipStream_t st)
+hipError_t costas_feed(const CostasParams &p, const CostasState &s, int nchan, const void *x, View xs,
+                       void *y, View ys, long long len, hipStream_t st)
 {
   if (len <= 0 || nchan <= 0) return hipSuccess;
   const dim3 grid((nchan + 63) / 64), block(64);
   const float2 *xx = reinterpret_cast<const float2 *>(x);
   float2 *yy = reinterpret_cast<float2 *>(y);
-  switch (p.order) {
-    case 0: hipLaunchKernelGGL(costas_kernel<0>, grid, block, 0, st, p, s, nchan, xx, xs, yy, ys, len); break;
-    case 1: hipLaunchKernelGGL(costas_kernel<1>, grid, block, 0, st, p, s, nchan, xx, xs, yy, ys, len); break;
-    case 2: hipLaunchKernelGGL(costas_kernel<2>, grid, block, 0, st, p, s, nchan, xx, xs, yy, ys, len); break;
-    case 3: hipLaunchKernelGGL(costas_kernel<3>, grid, block, 0, st, p, s, nchan, xx, xs, yy, ys, len); break;
-    case 4: hipLaunchKernelGGL(costas_kernel<4>, grid, block, 0, st, p, s, nchan, xx, xs, yy, ys, len); break;
+#define SD_COSTAS_CASE(K, O) \
+  case (K) * 8 + (O): hipLaunchKernelGGL((costas_kernel<K, O>), grid, block, 0, st, p, s, nchan, xx, xs, yy, ys, len); break;
+  if (p.order < 0 || p.order > 4 || p.kind < 1 || p.kind > 3) return hipErrorInvalidValue;
+  switch (p.kind * 8 + p.order) {
+    SD_COSTAS_CASE(1, 0) SD_COSTAS_CASE(1, 1) SD_COSTAS_CASE(1, 2) SD_COSTAS_CASE(1, 3) SD_COSTAS_CASE(1, 4)
+    SD_COSTAS_CASE(2, 0) SD_COSTAS_CASE(2, 1) SD_COSTAS_CASE(2, 2) SD_COSTAS_CASE(2, 3) SD_COSTAS_CASE(2, 4)
+    SD_COSTAS_CASE(3, 0) SD_COSTAS_CASE(3, 1) SD_COSTAS_CASE(3, 2) SD_COSTAS_CASE(3, 3) SD_COSTAS_CASE(3, 4)
     default: return hipErrorInvalidValue;
   }
+#undef SD_COSTAS_CASE
   return hipGetLastError();
 }
 
-hipError_t pll_feed(float alpha, float beta, const PllState &s, int nchan, const void *x, long long xs,
-                    void *y, long long ys, long long len, hipStream_t st)
+hipError_t pll_feed(float alpha, float beta, const PllState &s, int nchan, const void *x, View xs,
+                    void *y, View ys, long long len, hipStream_t st)
 {
   if (len <= 0 || nchan <= 0) return hipSuccess;
   hipLaunchKernelGGL(pll_kernel, dim3((nchan + 63) / 64), dim3(64), 0, st, alpha, beta, s, nchan,
@@ -413,7 +500,7 @@ hipError_t pll_feed(float alpha, float beta, const PllState &s, int nchan, const
   return hipGetLastError();
 }
 
-hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, const void *x, long long xs,
+hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, const void *x, View xs,
                       long long len, void *sym, long long sym_stride, uint32_t *count, hipStream_t st)
 {
   if (len <= 0 || nchan <= 0) return hipSuccess;
@@ -422,12 +509,22 @@ hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, cons
   return hipGetLastError();
 }
 
-hipError_t agc_feed(const AgcParams &p, const AgcState &s, int nchan, const void *x, long long xs,
-                    void *y, long long ys, long long len, hipStream_t st)
+hipError_t agc_feed(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv,
+                    void *y, View yv, long long len, float *scratch, hipStream_t st)
 {
   if (len <= 0 || nchan <= 0) return hipSuccess;
-  hipLaunchKernelGGL(agc_kernel, dim3((nchan + 63) / 64), dim3(64), 0, st, p, s, nchan,
-                     reinterpret_cast<const float2 *>(x), xs, reinterpret_cast<float2 *>(y), ys, len);
+  const float2 *xx = reinterpret_cast<const float2 *>(x);
+  float2 *yy = reinterpret_cast<float2 *>(y);
+  const long long total = len * nchan;
+  float *db = scratch, *peak = scratch + total;
+  const int H = (int)p.mag_history_size;
+  hipLaunchKernelGGL(agc_mag_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, xx, xv, nchan, len, db);
+  hipLaunchKernelGGL(agc_peak_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, db, s.mag_history, nchan, len, H, peak);
+  hipLaunchKernelGGL(agc_level_kernel, dim3((nchan + 63) / 64), dim3(64), 0, st, p, s, nchan, len, peak);
+  hipLaunchKernelGGL(agc_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, p, s.delay_line, nchan, xx, xv,
+                     yy, yv, len, peak);
+  hipLaunchKernelGGL(agc_state_kernel, dim3((nchan + 63) / 64), dim3(64), 0, st, s.delay_line, s.mag_history, nchan,
+                     (int)p.delay_line_size, H, xx, xv, db, len);
   return hipGetLastError();
 }
 

@@ -159,12 +159,14 @@ struct PassRunner {
   }
 };
 
-// grid.x = number of output frames
+// grid.x = number of output frames, grid.y = S (split of the navg frames of one output over S
+// workgroups; S > 1 writes unscaled partial sums to `partial`, reduced by psd_reduce_kernel in a
+// fixed order so the result is deterministic)
 template <int LOG2N, int THREADS>
 __global__ __launch_bounds__(THREADS) void psd_kernel(const cf *__restrict__ x, long long hop, int navg,
                                                       const float *__restrict__ window,
                                                       const cf *__restrict__ tw, float scale, int mode,
-                                                      float *__restrict__ out)
+                                                      float *__restrict__ out, float *__restrict__ partial)
 {
   using PL = Plan<LOG2N>;
   constexpr int N  = 1 << LOG2N;
@@ -181,7 +183,11 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(const cf *__restrict__ x, 
 #pragma unroll
   for (int i = 0; i < E; ++i) pw[i] = 0.0f;
 
-  for (int f = 0; f < navg; ++f) {
+  const int S = gridDim.y;
+  const int fps = (navg + S - 1) / S;
+  const int f_begin = blockIdx.y * fps;
+  const int f_end = (f_begin + fps < navg) ? f_begin + fps : navg;
+  for (int f = f_begin; f < f_end; ++f) {
     // Make the lane id opaque per frame: otherwise LICM hoists every twiddle (and its derived
     // powers) and every LDS address of all passes out of the frame loop and the kernel needs
     // >256 VGPRs.  Re-deriving them per frame costs a few integer ops and L1-resident loads.
@@ -206,8 +212,9 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(const cf *__restrict__ x, 
   }
 
   // epilogue: thread holds power of bins j + q*N/RL (last-pass geometry)
-  const float sc = scale / (float)navg;
-  float *dst = out + o * N;
+  const float sc = (S > 1) ? 1.0f : scale / (float)navg;
+  if (S > 1) mode = 0;
+  float *dst = (S > 1) ? partial + (o * S + blockIdx.y) * N : out + o * N;
   constexpr int NBL = E / RL;
 #pragma unroll
   for (int b = 0; b < NBL; ++b) {
@@ -226,9 +233,23 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(const cf *__restrict__ x, 
   }
 }
 
+// out[o][.] = (scale/navg) * sum_s partial[o][s][.]   (s ascending), optional shift + dB
+__global__ void psd_reduce_kernel(const float *__restrict__ partial, int S, int n, float sc, int mode,
+                                  float *__restrict__ out)
+{
+  const long long o = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float acc = 0.0f;
+    for (int s2 = 0; s2 < S; ++s2) acc += partial[(o * S + s2) * n + i];
+    const float p = acc * sc;
+    if (mode == 0) out[o * n + i] = p;
+    else out[o * n + ((i + n / 2) & (n - 1))] = 10.0f * log10f(p + 1e-8f);
+  }
+}
+
 template <int LOG2N, int THREADS>
 hipError_t launch_psd(const void *x, long long hop, int navg, const float *window, const void *tw,
-                      float scale, int mode, float *out, long long nout, hipStream_t st)
+                      float scale, int mode, float *out, long long nout, float *partial, int S, hipStream_t st)
 {
   constexpr int N = 1 << LOG2N;
   const size_t lds = sizeof(cf) * (size_t)(N + (N >> 4) + 1);
@@ -240,9 +261,13 @@ hipError_t launch_psd(const void *x, long long hop, int navg, const float *windo
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nout), dim3(THREADS), lds, st,
+  hipLaunchKernelGGL(kern, dim3((unsigned)nout, (unsigned)S), dim3(THREADS), lds, st,
                      reinterpret_cast<const cf *>(x), hop, navg, window, reinterpret_cast<const cf *>(tw),
-                     scale, mode, out);
+                     scale, mode, out, partial);
+  if (S > 1) {
+    hipLaunchKernelGGL(psd_reduce_kernel, dim3((N + 255) / 256, (unsigned)nout), dim3(256), 0, st,
+                       partial, S, N, scale / (float)navg, mode, out);
+  }
   return hipGetLastError();
 }
 
@@ -306,18 +331,31 @@ inline unsigned grid_for(long long n, int block) {
 
 namespace sdk {
 
+// how many workgroups share the navg frames of one output: enough to put >= ~1024 workgroups
+// on the chip, at least 2 frames each
+int psd_split(long long nout, int navg)
+{
+  if (nout <= 0 || navg < 4 || nout >= 1024) return 1;
+  long long s = (1024 + nout - 1) / nout;
+  if (s > navg / 2) s = navg / 2;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
 hipError_t psd_frames(int log2n, const void *x, long long hop, int navg, const float *window,
-                      const void *tw, float scale, int mode, float *out, long long nout, hipStream_t st)
+                      const void *tw, float scale, int mode, float *out, long long nout, float *partial,
+                      hipStream_t st)
 {
   if (nout <= 0) return hipSuccess;
+  const int S = partial ? psd_split(nout, navg) : 1;
   switch (log2n) {
     // 16 points per thread (8 for N = 512): one radix-16 or two radix-8 butterflies per pass
-    case 9:  return launch_psd<9, 64>(x, hop, navg, window, tw, scale, mode, out, nout, st);
-    case 10: return launch_psd<10, 64>(x, hop, navg, window, tw, scale, mode, out, nout, st);
-    case 11: return launch_psd<11, 128>(x, hop, navg, window, tw, scale, mode, out, nout, st);
-    case 12: return launch_psd<12, 256>(x, hop, navg, window, tw, scale, mode, out, nout, st);
-    case 13: return launch_psd<13, 512>(x, hop, navg, window, tw, scale, mode, out, nout, st);
-    case 14: return launch_psd<14, 1024>(x, hop, navg, window, tw, scale, mode, out, nout, st);
+    case 9:  return launch_psd<9, 64>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
+    case 10: return launch_psd<10, 64>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
+    case 11: return launch_psd<11, 128>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
+    case 12: return launch_psd<12, 256>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
+    case 13: return launch_psd<13, 512>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
+    case 14: return launch_psd<14, 1024>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
     default: return hipErrorInvalidValue;
   }
 }

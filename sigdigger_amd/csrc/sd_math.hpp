@@ -27,11 +27,16 @@ __device__ __forceinline__ void phasor_u32(uint32_t p, float &c, float &s)
   float cp = fma_(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
   cp = fma_(cp, z, 4.166664568298827e-2f);
   const float cs = fma_(cp * z, z, fma_(z, -0.5f, 1.0f));
-  // rotate by q quarter turns
-  const float a = (q & 1u) ? sn : cs;       // |cos| source
-  const float b = (q & 1u) ? cs : sn;       // |sin| source
-  c = (q == 1u || q == 2u) ? -a : a;
-  s = (q >= 2u) ? -b : b;
+  // rotate by q quarter turns -- q=0:(cs,sn) 1:(-sn,cs) 2:(-cs,-sn) 3:(sn,-cs) -- with integer
+  // bit operations only (a compare + v_cndmask pair costs ~4x a bit-op on gfx950 because of the
+  // VCC write->read hazard); the values are exactly the selected / negated polynomials.
+  const uint32_t t    = p + 0x20000000u;                       // bits 31:30 = q
+  const uint32_t swap = (uint32_t)((int32_t)(t << 1) >> 31);   // all ones when q is odd
+  const uint32_t ics = __float_as_uint(cs), isn = __float_as_uint(sn);
+  const uint32_t a = (isn & swap) | (ics & ~swap);             // q odd ? sn : cs
+  const uint32_t b = (ics & swap) | (isn & ~swap);             // q odd ? cs : sn
+  c = __uint_as_float(a ^ ((t ^ (t << 1)) & 0x80000000u));     // negate for q = 1, 2
+  s = __uint_as_float(b ^ (t & 0x80000000u));                  // negate for q = 2, 3
 }
 
 // D2: atan2 (radians), Cephes atanf kernel on min/max.
@@ -103,8 +108,8 @@ __device__ __forceinline__ float exp2_(float x)
 
 __device__ __forceinline__ int32_t rad_to_dphase(float d)
 {
-  if (d >  3.1415925f) d =  3.1415925f;
-  if (d < -3.1415925f) d = -3.1415925f;
+  // clamp to (-pi, pi): one v_med3_f32 (identical to the two compares of the SPEC for non-NaN d)
+  d = __builtin_amdgcn_fmed3f(d, -3.1415925f, 3.1415925f);
   return (int32_t)(d * 683565275.57643158978f);
 }
 

@@ -34,8 +34,20 @@ def _chk_c64(t, name):
 
 
 def _chk_rows(t, name):
-    if not (t.is_cuda and t.dtype == torch.complex64 and t.dim() == 2 and t.stride(1) == 1):
-        raise SigDiggerAmdError(f"{name} must be a CUDA complex64 [channels, time] tensor with unit time stride")
+    if not (t.is_cuda and t.dtype == torch.complex64 and t.dim() == 2):
+        raise SigDiggerAmdError(f"{name} must be a CUDA complex64 [channels, time] tensor")
+
+
+def _view(t):
+    """suamd_view of a [channels, time] tensor: any strides (channel-major, or the transpose of a
+    [time, channels] buffer = time-major)."""
+    return _l.View(t.stride(0), t.stride(1))
+
+
+def time_major(nchan, length, device, dtype=torch.complex64):
+    """[channels, time] tensor stored time-major ([time][channel] in memory): the layout the
+    one-lane-per-channel kernels stream with one contiguous access per wavefront."""
+    return torch.empty((length, nchan), dtype=dtype, device=device).t()
 
 
 class Context:
@@ -97,7 +109,7 @@ class Context:
             out = torch.empty_like(x2)
         o2 = out if out.dim() == 2 else out.unsqueeze(0)
         check(self.lib.suamd_quad_demod_batch(
-            self.h, _ptr(x2), x2.stride(0), _ptr(o2), o2.stride(0), x2.shape[0], x2.shape[1],
+            self.h, _ptr(x2), _view(x2), _ptr(o2), _view(o2), x2.shape[0], x2.shape[1],
             _ptr(prev) if prev is not None else None, int(first),
             _ptr(prev_out) if prev_out is not None else None, _stream(stream)), "suamd_quad_demod_batch")
         return out if x.dim() == 2 else o2[0]
@@ -195,7 +207,9 @@ class ChannelBank:
             out = torch.empty((self.nchan, max(n, 1)), dtype=torch.complex64, device=x.device)
         _chk_rows(out, "out")
         nout = C.c_uint64(0)
-        check(self.ctx.lib.suamd_chanbank_feed(self.h, _ptr(x), x.numel(), _ptr(out), out.stride(0),
+        if out.shape[0] != self.nchan or out.shape[1] < n:
+            raise SigDiggerAmdError(f"out must be [{self.nchan}, >= {n}]")
+        check(self.ctx.lib.suamd_chanbank_feed(self.h, _ptr(x), x.numel(), _ptr(out), _view(out),
                                                C.byref(nout), _stream(stream)), "suamd_chanbank_feed")
         return out[:, :nout.value]
 
@@ -240,7 +254,7 @@ class CostasBank(_LoopBank):
 
     def feed(self, x, out=None, stream=None):
         out = self._rows(x, out)
-        check(self.ctx.lib.suamd_costas_bank_feed(self.h, _ptr(x), x.stride(0), _ptr(out), out.stride(0),
+        check(self.ctx.lib.suamd_costas_bank_feed(self.h, _ptr(x), _view(x), _ptr(out), _view(out),
                                                   x.shape[1], _stream(stream)), "suamd_costas_bank_feed")
         return out
 
@@ -265,7 +279,7 @@ class PLLBank(_LoopBank):
 
     def feed(self, x, out=None, stream=None):
         out = self._rows(x, out)
-        check(self.ctx.lib.suamd_pll_bank_feed(self.h, _ptr(x), x.stride(0), _ptr(out), out.stride(0),
+        check(self.ctx.lib.suamd_pll_bank_feed(self.h, _ptr(x), _view(x), _ptr(out), _view(out),
                                                x.shape[1], _stream(stream)), "suamd_pll_bank_feed")
         return out
 
@@ -292,7 +306,9 @@ class ClockBank(_LoopBank):
         """Appends recovered symbols of row c at sym[c, count[c]...]; count is uint32-as-int32 [nchan]."""
         _chk_rows(x, "x")
         _chk_rows(sym, "sym")
-        check(self.ctx.lib.suamd_clock_bank_feed(self.h, _ptr(x), x.stride(0), x.shape[1], _ptr(sym),
+        if sym.stride(1) != 1:
+            raise SigDiggerAmdError("sym must be channel-major (unit time stride)")
+        check(self.ctx.lib.suamd_clock_bank_feed(self.h, _ptr(x), _view(x), x.shape[1], _ptr(sym),
                                                  sym.stride(0), _ptr(count), _stream(stream)),
               "suamd_clock_bank_feed")
         return sym, count
@@ -324,6 +340,6 @@ class AGCBank(_LoopBank):
 
     def feed(self, x, out=None, stream=None):
         out = self._rows(x, out)
-        check(self.ctx.lib.suamd_agc_bank_feed(self.h, _ptr(x), x.stride(0), _ptr(out), out.stride(0),
+        check(self.ctx.lib.suamd_agc_bank_feed(self.h, _ptr(x), _view(x), _ptr(out), _view(out),
                                                x.shape[1], _stream(stream)), "suamd_agc_bank_feed")
         return out

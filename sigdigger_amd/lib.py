@@ -20,6 +20,11 @@ INT = C.c_int
 UINT = C.c_uint
 
 
+class View(C.Structure):
+    """suamd_view: element (c, m) at base[c*chan_stride + m*time_stride]"""
+    _fields_ = [("chan_stride", U64), ("time_stride", U64)]
+
+
 class AgcParams(C.Structure):
     """struct suamd_agc_params"""
     _fields_ = [("threshold", F32), ("slope_factor", F32), ("hang_max", UINT),
@@ -46,27 +51,27 @@ PROTOTYPES = {
     "suamd_chanbank_new": (VP, [VP, UINT, VP, UINT, VP, UINT]),
     "suamd_chanbank_destroy": (None, [VP]),
     "suamd_chanbank_output_count": (U64, [VP, U64]),
-    "suamd_chanbank_feed": (INT, [VP, VP, U64, VP, U64, C.POINTER(U64), VP]),
+    "suamd_chanbank_feed": (INT, [VP, VP, U64, VP, View, C.POINTER(U64), VP]),
     "suamd_chanbank_reset": (INT, [VP, VP]),
-    "suamd_quad_demod_batch": (INT, [VP, VP, U64, VP, U64, UINT, U64, VP, INT, VP, VP]),
+    "suamd_quad_demod_batch": (INT, [VP, VP, View, VP, View, UINT, U64, VP, INT, VP, VP]),
     "suamd_delayed_conj_bulk": (INT, [VP, VP, VP, U64, U64, VP]),
     "suamd_histogram_feed_bulk": (INT, [VP, VP, U64, INT, VP, VP]),
     "suamd_costas_bank_new": (VP, [VP, UINT, INT, F32, F32, UINT, F32]),
     "suamd_costas_bank_destroy": (None, [VP]),
-    "suamd_costas_bank_feed": (INT, [VP, VP, U64, VP, U64, U64, VP]),
+    "suamd_costas_bank_feed": (INT, [VP, VP, View, VP, View, U64, VP]),
     "suamd_costas_bank_get_state": (INT, [VP, VP, VP, VP]),
     "suamd_pll_bank_new": (VP, [VP, UINT, F32, F32]),
     "suamd_pll_bank_destroy": (None, [VP]),
-    "suamd_pll_bank_feed": (INT, [VP, VP, U64, VP, U64, U64, VP]),
+    "suamd_pll_bank_feed": (INT, [VP, VP, View, VP, View, U64, VP]),
     "suamd_pll_bank_get_state": (INT, [VP, VP, VP, VP]),
     "suamd_clock_bank_new": (VP, [VP, UINT, F32, F32]),
     "suamd_clock_bank_destroy": (None, [VP]),
-    "suamd_clock_bank_feed": (INT, [VP, VP, U64, U64, VP, U64, VP, VP]),
+    "suamd_clock_bank_feed": (INT, [VP, VP, View, U64, VP, U64, VP, VP]),
     "suamd_clock_bank_get_state": (INT, [VP, VP, VP, VP]),
     "suamd_agc_params_from_tau": (None, [C.POINTER(AgcParams), F32]),
     "suamd_agc_bank_new": (VP, [VP, UINT, C.POINTER(AgcParams)]),
     "suamd_agc_bank_destroy": (None, [VP]),
-    "suamd_agc_bank_feed": (INT, [VP, VP, U64, VP, U64, U64, VP]),
+    "suamd_agc_bank_feed": (INT, [VP, VP, View, VP, View, U64, VP]),
 }
 
 

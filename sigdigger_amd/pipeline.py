@@ -30,15 +30,27 @@ class InspectorBankConfig:
 
 
 class AnalyzerPipeline:
-    """PSD + inspector bank on one device, block at a time, state carried between blocks."""
+    """PSD + inspector bank on one device, block at a time, state carried between blocks.
+
+    The inspector chain has three serial (one-lane-per-channel) stages -- AGC level tracking,
+    Costas, Gardner -- each a single wavefront per 64 channels.  With overlap=True every stage
+    runs on its own HIP stream and block k's stage s only waits for block k's stage s-1 (and,
+    for buffer reuse, for the consumer of the buffer it overwrites), so consecutive blocks flow
+    through the stages like a pipeline: steady-state cost per block = the slowest stage, not the
+    sum.  The rest of the chip stays free for the PSD and FIR kernels of the next blocks.
+    """
+
+    NBUF = 3                                   # ring depth of every inter-stage buffer
 
     def __init__(self, ctx, block_len, psd_size=8192, psd_window=engine.WINDOW_BLACKMANN_HARRIS,
-                 psd_navg=None, bank=None, do_psd=True):
+                 psd_navg=None, bank=None, do_psd=True, overlap=True):
         self.ctx = ctx
         self.block_len = int(block_len)
         self.dev = torch.device("cuda", ctx.device)
         self.do_psd = do_psd
         self.psd_size = int(psd_size)
+        self.overlap = overlap
+        self.k = 0                             # blocks fed so far
         if do_psd:
             assert self.block_len % self.psd_size == 0
             self.nframes = self.block_len // self.psd_size
@@ -54,23 +66,35 @@ class AnalyzerPipeline:
             taps = ctx.lpf_design(bank.ntaps, bank.bw_rel / D)
             self.chan = engine.ChannelBank(ctx, bank.fnor, D, taps)
             self.m_max = self.block_len // D + 2
-            stride = (self.m_max + 7) // 8 * 8
-            self.y = torch.empty((self.nchan, stride), dtype=torch.complex64, device=self.dev)
-            self.a = torch.empty_like(self.y)
-            self.z = torch.empty_like(self.y)
-            self.sym = torch.empty_like(self.y)
-            self.count = torch.zeros(self.nchan, dtype=torch.int32, device=self.dev)
+            nb = self.NBUF if overlap else 1
+            # intermediates between stages are time-major ([time][channel] in memory): each
+            # time step of the 64-lane recurrences is one contiguous 512-byte access
+            self.y = [engine.time_major(self.nchan, self.m_max, self.dev) for _ in range(nb)]
+            self.a = [engine.time_major(self.nchan, self.m_max, self.dev) for _ in range(nb)]
+            self.z = [engine.time_major(self.nchan, self.m_max, self.dev) for _ in range(nb)]
+            # recovered symbols leave the device per inspector: channel-major rows
+            self.sym = [torch.empty((self.nchan, self.m_max), dtype=torch.complex64, device=self.dev)
+                        for _ in range(nb)]
+            self.count = [torch.zeros(self.nchan, dtype=torch.int32, device=self.dev) for _ in range(nb)]
+            self.agc = None
             if bank.kind == "psk":
                 self.agc = engine.AGCBank(ctx, self.nchan, tau=bank.sps) if bank.agc else None
                 self.costas = engine.CostasBank(ctx, self.nchan, bank.costas_kind, 0.0, 2.0 / bank.sps, 3,
                                                 bank.loop_bw)
             else:
-                self.qprev = torch.zeros(self.nchan, dtype=torch.complex64, device=self.dev)
+                # last sample of the previous block per channel; ping-pong so that a launch never
+                # reads and writes the same buffer
+                self.qprev = [torch.zeros(self.nchan, dtype=torch.complex64, device=self.dev) for _ in range(2)]
                 self.first = True
             self.clock = engine.ClockBank(ctx, self.nchan, bank.clock_gain, 1.0 / bank.sps)
-        # per-stage HIP events (recorded on the stream the kernels are launched on)
-        self.ev = {}
+        if overlap:
+            self.s_agc = torch.cuda.Stream(self.dev)
+            self.s_dem = torch.cuda.Stream(self.dev)      # Costas / quad demod
+            self.s_clk = torch.cuda.Stream(self.dev)
+        self.done = {}                         # (stage, block index) -> event
+        self.ev = {}                           # per-stage timing events
 
+    # ---- helpers ---------------------------------------------------------------------------
     def _mark(self, name, stream, timed):
         if not timed:
             return
@@ -78,9 +102,77 @@ class AnalyzerPipeline:
         e.record(stream)
         self.ev.setdefault(name, []).append(e)
 
+    def _signal(self, stage, k, stream):
+        e = torch.cuda.Event()
+        e.record(stream)
+        self.done[(stage, k)] = e
+        self.done.pop((stage, k - 2 * self.NBUF), None)
+
+    def _wait(self, stream, stage, k):
+        e = self.done.get((stage, k))
+        if e is not None:
+            stream.wait_event(e)
+
     def step(self, x, timed=False, stream=None):
         """One pass of the hot path over one resident IQ block x (complex64 [block_len])."""
         st = stream or torch.cuda.current_stream(self.dev)
+        k = self.k
+        self.k += 1
+        if not self.overlap:
+            return self._step_serial(x, timed, st)
+        nb = self.NBUF
+        i = k % nb
+        # ---- main spectrum on its own stream (reads x only) ----
+        # (on the caller's stream: four streams = the four HIP hardware queues, so the three
+        #  serial stages never share a queue and really run concurrently)
+        if self.do_psd:
+            self._mark("psd0", st, timed)
+            self.psd.feed(x, nframes=self.nframes, navg=self.navg, scale=1.0 / self.psd_size,
+                          out=self.psd_out, stream=st)
+            self._mark("psd1", st, timed)
+        if not self.nchan:
+            return self.psd_out if self.do_psd else None
+        cfg = self.bank_cfg
+        psk = cfg.kind == "psk"
+        # ---- channel bank: many workgroups, on the caller's stream ----
+        self._wait(st, "agc" if (psk and self.agc is not None) else "dem", k - nb)   # y[i] free again
+        self._mark("fir0", st, timed)
+        y = self.chan.feed(x, out=self.y[i], stream=st)
+        self._mark("fir1", st, timed)
+        self._signal("fir", k, st)
+        m = y.shape[1]
+        src = y
+        # ---- AGC ----
+        if psk and self.agc is not None:
+            self._wait(self.s_agc, "fir", k)
+            self._wait(self.s_agc, "dem", k - nb)                                    # a[i] free again
+            self._mark("agc0", self.s_agc, timed)
+            src = self.agc.feed(y, out=self.a[i][:, :m], stream=self.s_agc)
+            self._mark("agc1", self.s_agc, timed)
+            self._signal("agc", k, self.s_agc)
+        # ---- carrier recovery / quadrature demod ----
+        self._wait(self.s_dem, "agc" if (psk and self.agc is not None) else "fir", k)
+        self._wait(self.s_dem, "clk", k - nb)                                        # z[i] free again
+        self._mark("dem0", self.s_dem, timed)
+        if psk:
+            z = self.costas.feed(src, out=self.z[i][:, :m], stream=self.s_dem)
+        else:
+            z = self.ctx.quad_demod(y, prev=self.qprev[k & 1], first=self.first, out=self.z[i][:, :m],
+                                    prev_out=self.qprev[(k + 1) & 1], stream=self.s_dem)
+            self.first = False
+        self._mark("dem1", self.s_dem, timed)
+        self._signal("dem", k, self.s_dem)
+        # ---- clock recovery ----
+        self._wait(self.s_clk, "dem", k)
+        with torch.cuda.stream(self.s_clk):
+            self.count[i].zero_()
+        self._mark("clk0", self.s_clk, timed)
+        self.clock.feed(z, self.sym[i], self.count[i], stream=self.s_clk)
+        self._mark("clk1", self.s_clk, timed)
+        self._signal("clk", k, self.s_clk)
+        return self.psd_out if self.do_psd else None
+
+    def _step_serial(self, x, timed, st):
         if self.do_psd:
             self._mark("psd0", st, timed)
             self.psd.feed(x, nframes=self.nframes, navg=self.navg, scale=1.0 / self.psd_size,
@@ -89,47 +181,54 @@ class AnalyzerPipeline:
         if self.nchan:
             cfg = self.bank_cfg
             self._mark("fir0", st, timed)
-            y = self.chan.feed(x, out=self.y, stream=st)
+            y = self.chan.feed(x, out=self.y[0], stream=st)
             self._mark("fir1", st, timed)
             m = y.shape[1]
-            self.count.zero_()
+            with torch.cuda.stream(st):
+                self.count[0].zero_()
+            src = y
             if cfg.kind == "psk":
-                src = y
                 if self.agc is not None:
-                    src = self.agc.feed(y, out=self.a[:, :m], stream=st)
+                    self._mark("agc0", st, timed)
+                    src = self.agc.feed(y, out=self.a[0][:, :m], stream=st)
                     self._mark("agc1", st, timed)
-                z = self.costas.feed(src, out=self.z[:, :m], stream=st)
-                self._mark("costas1", st, timed)
+                self._mark("dem0", st, timed)
+                z = self.costas.feed(src, out=self.z[0][:, :m], stream=st)
+                self._mark("dem1", st, timed)
             else:
-                z = self.ctx.quad_demod(y, prev=self.qprev, first=self.first, out=self.z[:, :m],
-                                        prev_out=self.qprev, stream=st)
+                self._mark("dem0", st, timed)
+                kk = self.k - 1
+                z = self.ctx.quad_demod(y, prev=self.qprev[kk & 1], first=self.first, out=self.z[0][:, :m],
+                                        prev_out=self.qprev[(kk + 1) & 1], stream=st)
                 self.first = False
-                self._mark("quad1", st, timed)
-            self.clock.feed(z, self.sym, self.count, stream=st)
-            self._mark("clock1", st, timed)
+                self._mark("dem1", st, timed)
+            self._mark("clk0", st, timed)
+            self.clock.feed(z, self.sym[0], self.count[0], stream=st)
+            self._mark("clk1", st, timed)
         return self.psd_out if self.do_psd else None
 
+    def latest_symbols(self):
+        """(sym, count) of the most recently fed block (synchronises the clock stage)."""
+        i = (self.k - 1) % (self.NBUF if self.overlap else 1)
+        if self.overlap:
+            self.s_clk.synchronize()
+        return self.sym[i], self.count[i]
+
+    def sync(self):
+        torch.cuda.synchronize(self.dev)
+
     def stage_times_ms(self):
-        """Average duration of each stage over the timed steps (HIP events; call after a sync)."""
-        out = {}
+        """Average kernel time of each stage over the timed steps (HIP events recorded on the
+        stream each stage runs on; call after a device sync)."""
         ev = self.ev
 
         def avg(a, b):
             if a in ev and b in ev:
                 return float(np.mean([s.elapsed_time(e) for s, e in zip(ev[a], ev[b])]))
             return None
-        out["psd"] = avg("psd0", "psd1")
-        out["fir"] = avg("fir0", "fir1")
-        if "agc1" in ev:
-            out["agc"] = avg("fir1", "agc1")
-            out["costas"] = avg("agc1", "costas1")
-        elif "costas1" in ev:
-            out["costas"] = avg("fir1", "costas1")
-        if "quad1" in ev:
-            out["quad"] = avg("fir1", "quad1")
-            out["clock"] = avg("quad1", "clock1")
-        elif "costas1" in ev:
-            out["clock"] = avg("costas1", "clock1")
+        demod = "costas" if (self.bank_cfg is not None and self.bank_cfg.kind == "psk") else "quad"
+        out = {"psd": avg("psd0", "psd1"), "fir": avg("fir0", "fir1"), "agc": avg("agc0", "agc1"),
+               demod: avg("dem0", "dem1"), "clock": avg("clk0", "clk1")}
         return {k: v for k, v in out.items() if v is not None}
 
     def reset_events(self):
@@ -140,3 +239,17 @@ def shard_channels(fnor, rank, world):
     """channel c -> rank c mod G: independent chains, no data-path collective."""
     fnor = np.asarray(fnor, dtype=np.float64)
     return fnor[rank::world]
+
+
+def channel_owner(c, world):
+    """rank that owns inspector channel c, and its index inside that rank's bank"""
+    return c % world, c // world
+
+
+def broadcast_block(buf, dist, src=0, async_op=True):
+    """The one exchange step of the multi-GPU path: rank `src` holds the IQ block, every rank
+    needs it (RCCL broadcast over xGMI on GPUs; gloo in the CPU tests).  Returns the work handle
+    (None when not distributed)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    return dist.broadcast(buf, src=src, async_op=async_op)

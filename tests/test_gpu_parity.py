@@ -24,6 +24,19 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
+def dev_rows(a, layout):
+    """[channels, time] device tensor, stored channel-major ("cm") or time-major ("tm")."""
+    if layout == "cm":
+        return dev(a)
+    return dev(np.ascontiguousarray(a.T)).t()
+
+
+def empty_rows(nchan, n, layout):
+    if layout == "cm":
+        return torch.empty((nchan, n), dtype=torch.complex64, device="cuda")
+    return engine.time_major(nchan, n, "cuda")
+
+
 def assert_bits(a, b, what=""):
     a = np.ascontiguousarray(a)
     b = np.ascontiguousarray(b)
@@ -67,6 +80,25 @@ def test_psd_windows_and_averaging(ctx, sdo, window):
     assert out.shape == (nframes // navg, n)
     err = np.max(np.abs(out - ref), axis=1) / np.max(ref, axis=1)
     assert np.all(err < PSD_TOL), err
+
+
+def test_psd_split_frame_accumulation(ctx, sdo):
+    """many frames averaged into few outputs: the frames of one output are split over several
+    workgroups and reduced in a fixed order (deterministic, run-to-run identical)."""
+    n, nframes, navg = 2048, 192, 64
+    x = synth.psk_carriers(n * nframes, [0.1, -0.3, 0.6], sps=8, seed=17)
+    win = sdo.window(4, n)
+    ref = sdo.psd_frames(x, nframes, n, n, win, navg=navg, scale=1.0 / n)
+    psd = engine.PSD(ctx, n, engine.WINDOW_BLACKMANN_HARRIS)
+    dx = dev(x)
+    out = host(psd.feed(dx, nframes=nframes, navg=navg, scale=1.0 / n))
+    assert out.shape == (3, n)
+    err = np.max(np.abs(out - ref), axis=1) / np.max(ref, axis=1)
+    assert np.all(err < PSD_TOL), err
+    again = host(psd.feed(dx, nframes=nframes, navg=navg, scale=1.0 / n))
+    assert_bits(again, out, "split-frame PSD is deterministic")
+    db = host(psd.feed(dx, nframes=nframes, navg=navg, scale=1.0 / n, mode=engine.PSD_DB_SHIFTED))
+    assert np.max(np.abs(db - np.stack([sdo.psd_shift_db(f) for f in ref]))) < DB_TOL
 
 
 def test_psd_overlapped_hop(ctx, sdo):
@@ -176,15 +208,17 @@ def test_chanbank_bit_exact(ctx, sdo, nchan, D, T):
     assert_bits(ctx.lpf_design(T, 0.8 / D), taps, "lpf design")
     blocks = [(0, 10000), (10000, 10001), (10001, 10001 + 3 * D + 5), (10001 + 3 * D + 5, n)]
     ref = _oracle_bank(sdo, x, fn, D, taps, blocks)
-    bank = engine.ChannelBank(ctx, fn, D, taps)
-    got = []
-    for a, b in blocks:
-        y = bank.feed(dev(x[a:b]))
-        got.append(host(y))
-    got = np.concatenate(got, axis=1)
-    assert got.shape[1] == len(ref[0]) == (n + D - 1) // D
-    for c in range(nchan):
-        assert_bits(got[c], ref[c], f"chanbank channel {c}")
+    for layout in ("cm", "tm"):
+        bank = engine.ChannelBank(ctx, fn, D, taps)
+        got = []
+        for a, b in blocks:
+            out = empty_rows(nchan, bank.output_count(b - a) + 3, layout)
+            y = bank.feed(dev(x[a:b]), out=out)
+            got.append(host(y))
+        got = np.concatenate(got, axis=1)
+        assert got.shape[1] == len(ref[0]) == (n + D - 1) // D
+        for c in range(nchan):
+            assert_bits(got[c], ref[c], f"chanbank channel {c} ({layout})")
 
 
 def test_chanbank_block_size_invariance_large(ctx, sdo):
@@ -242,14 +276,15 @@ def _rows(nchan, n, order=4, sps=8, seed=30):
                                         snr_db=15 + c % 7) for c in range(nchan)])
 
 
+@pytest.mark.parametrize("layout", ["cm", "tm"])
 @pytest.mark.parametrize("kind,order,arm_order", [(1, 2, 3), (2, 4, 3), (3, 8, 3), (2, 4, 1), (2, 4, 5)])
-def test_costas_bank_bit_exact(ctx, sdo, kind, order, arm_order):
+def test_costas_bank_bit_exact(ctx, sdo, kind, order, arm_order, layout):
     nchan, n = 70, 6000                                   # > 64: two wavefronts, ragged last one
     x = _rows(nchan, n, order=order)
     bank = engine.CostasBank(ctx, nchan, kind, 0.0, 2.0 / 8, arm_order, 0.01)
-    dx = dev(x)
-    got = np.concatenate([host(bank.feed(dx[:, a:b].contiguous())) for a, b in ((0, 1), (1, 2500), (2500, n))],
-                         axis=1)
+    dx = dev_rows(x, layout)
+    got = np.concatenate([host(bank.feed(dx[:, a:b], out=empty_rows(nchan, b - a, layout)))
+                          for a, b in ((0, 1), (1, 2500), (2500, n))], axis=1)
     om, ph = bank.state()
     for c in range(nchan):
         st = sdo.costas_new(kind, 0.0, 2.0 / 8, arm_order, 0.01)
@@ -258,15 +293,15 @@ def test_costas_bank_bit_exact(ctx, sdo, kind, order, arm_order):
         assert np.float32(st.omega).view(np.uint32) == om[c].view(np.uint32) and st.phase == ph[c]
 
 
-def test_pll_bank_bit_exact(ctx, sdo):
+@pytest.mark.parametrize("layout", ["cm", "tm"])
+def test_pll_bank_bit_exact(ctx, sdo, layout):
     nchan, n = 9, 5000
     t = np.arange(n)
     x = np.stack([(np.exp(1j * (np.pi * 0.003 * (c + 1) * t + c)) +
                    0.05 * synth.tone_noise(n, seed=c)).astype(np.complex64) for c in range(nchan)])
     bank = engine.PLLBank(ctx, nchan, 0.0, 0.02)
-    dx = dev(x)
-    got = np.concatenate([host(bank.feed(dx[:, :1234].contiguous())), host(bank.feed(dx[:, 1234:].contiguous()))],
-                         axis=1)
+    dx = dev_rows(x, layout)
+    got = np.concatenate([host(bank.feed(dx[:, :1234])), host(bank.feed(dx[:, 1234:]))], axis=1)
     om, ph = bank.state()
     for c in range(nchan):
         st = sdo.pll_new(0.0, 0.02)
@@ -274,15 +309,16 @@ def test_pll_bank_bit_exact(ctx, sdo):
         assert st.phase == ph[c]
 
 
-def test_clock_bank_bit_exact_symbol_counts(ctx, sdo):
+@pytest.mark.parametrize("layout", ["cm", "tm"])
+def test_clock_bank_bit_exact_symbol_counts(ctx, sdo, layout):
     nchan, n, sps = 66, 8000, 8
     x = _rows(nchan, n, order=2, sps=sps)
     bank = engine.ClockBank(ctx, nchan, 1.0, 1.0 / sps * 1.01)
     sym = torch.zeros((nchan, n // 4), dtype=torch.complex64, device="cuda")
     cnt = torch.zeros(nchan, dtype=torch.int32, device="cuda")
-    dx = dev(x)
+    dx = dev_rows(x, layout)
     for a, b in ((0, 3), (3, 4000), (4000, n)):
-        bank.feed(dx[:, a:b].contiguous(), sym, cnt)
+        bank.feed(dx[:, a:b], sym, cnt)
     counts = host(cnt)
     syms = host(sym)
     for c in range(nchan):
@@ -292,15 +328,17 @@ def test_clock_bank_bit_exact_symbol_counts(ctx, sdo):
         assert_bits(syms[c, :counts[c]], ref, f"clock ch {c}")
 
 
-def test_agc_bank_bit_exact(ctx, sdo):
+@pytest.mark.parametrize("layout", ["cm", "tm"])
+def test_agc_bank_bit_exact(ctx, sdo, layout):
     nchan, n = 65, 6000
     x = _rows(nchan, n)
     env = np.repeat(np.array([0.01, 1.0, 0.1, 5.0], dtype=np.float32), n // 4)
     x = (x * env[None, :]).astype(np.complex64)
     bank = engine.AGCBank(ctx, nchan, tau=16.0)
-    dx = dev(x)
-    got = np.concatenate([host(bank.feed(dx[:, :777].contiguous())), host(bank.feed(dx[:, 777:].contiguous()))],
-                         axis=1)
+    dx = dev_rows(x, layout)
+    cuts = (0, 1, 8, 27, 777, 800, n)                      # pieces shorter than the 20-sample history too
+    got = np.concatenate([host(bank.feed(dx[:, a:b], out=empty_rows(nchan, b - a, layout)))
+                          for a, b in zip(cuts[:-1], cuts[1:])], axis=1)
     for c in range(nchan):
         st = sdo.agc_new(sdo.agc_params_from_tau(16.0))
         assert_bits(got[c], sdo.agc_feed_bulk(st, x[c]), f"agc ch {c}")
@@ -318,9 +356,10 @@ def test_psk_inspector_chain_end_to_end(ctx, sdo):
     agc = engine.AGCBank(ctx, nchan, tau=float(sps_in // D))
     cos = engine.CostasBank(ctx, nchan, 2, 0.0, 2.0 / (sps_in // D), 3, 0.005)
     clk = engine.ClockBank(ctx, nchan, 0.2, float(D) / sps_in)
-    y = bank.feed(dev(x)).contiguous()
-    a = agc.feed(y)
-    z = cos.feed(a)
+    m = bank.output_count(n)
+    y = bank.feed(dev(x), out=engine.time_major(nchan, m, "cuda"))     # time-major between stages
+    a = agc.feed(y, out=engine.time_major(nchan, m, "cuda"))
+    z = cos.feed(a, out=engine.time_major(nchan, m, "cuda"))
     sym = torch.zeros((nchan, y.shape[1]), dtype=torch.complex64, device="cuda")
     cnt = torch.zeros(nchan, dtype=torch.int32, device="cuda")
     clk.feed(z, sym, cnt)
@@ -338,3 +377,48 @@ def test_psk_inspector_chain_end_to_end(ctx, sdo):
         tail = sh[c, ch[c] // 2: ch[c]]
         m4 = np.mean((tail / np.abs(tail)) ** 4)
         assert np.abs(m4) > 0.8, f"ch {c}: constellation not locked ({abs(m4):.3f})"
+
+
+# ------------------------------------------------------------------------------------------
+# analyzer step: stream-pipelined == serial, block after block
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["psk", "fsk"])
+def test_pipeline_overlap_equals_serial_and_oracle(ctx, sdo, kind):
+    from sigdigger_amd import pipeline
+    L, D, nchan, nblocks = 1 << 15, 16, 6, 5
+    fn = synth.raster(nchan, 0.11)
+    sps_in = 128
+    xs = (synth.psk_carriers(L * nblocks, fn, sps=sps_in, order=4, seed=91, snr_db=22) if kind == "psk"
+          else synth.fsk_carriers(L * nblocks, fn, sps=sps_in, seed=92))
+    def run(overlap):
+        bank = pipeline.InspectorBankConfig(kind=kind, fnor=fn, decimation=D, ntaps=255, sps=sps_in / D)
+        pipe = pipeline.AnalyzerPipeline(ctx, L, psd_size=4096, psd_navg=4, bank=bank, overlap=overlap)
+        syms, psds = [[] for _ in range(nchan)], []
+        for b in range(nblocks):
+            out = pipe.step(dev(xs[b * L:(b + 1) * L]))
+            sym, cnt = pipe.latest_symbols()
+            pipe.sync()
+            psds.append(host(out).copy())
+            c = host(cnt)
+            s = host(sym)
+            for ch in range(nchan):
+                syms[ch].append(s[ch, :c[ch]].copy())
+        return [np.concatenate(v) for v in syms], np.concatenate(psds)
+    s_ov, p_ov = run(True)
+    s_se, p_se = run(False)
+    assert_bits(p_ov, p_se, "psd overlap vs serial")
+    for ch in range(nchan):
+        assert_bits(s_ov[ch], s_se[ch], f"symbols ch {ch} overlap vs serial")
+    # oracle for two channels, whole stream in one go (block-size invariance + parity)
+    taps = sdo.lpf_design(255, 0.75 / D)
+    sps = sps_in / D
+    for ch in (0, nchan - 1):
+        dp = sdo.fnor_to_dphase(-fn[ch])
+        y = sdo.chan_feed(np.zeros(254, np.complex64), xs, 0, sdo.chan_modulate_taps(taps, dp), D, 0, dp)
+        if kind == "psk":
+            a = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(sps)), y)
+            z = sdo.costas_feed_bulk(sdo.costas_new(2, 0.0, 2.0 / sps, 3, 0.005), a)
+        else:
+            z = sdo.quad_demod(y)
+        ref = sdo.clock_feed_bulk(sdo.clock_new(0.2, 1.0 / sps), z)
+        assert_bits(s_ov[ch], ref, f"symbols ch {ch} vs oracle")
