@@ -60,11 +60,17 @@ def test_host_side_helpers_do_not_need_a_device(sdo):
 
 
 def test_product_never_imports_the_oracle():
+    """nothing under sigdigger_amd/ imports, includes, links or dlopens anything of oracle/"""
     pkg = os.path.join(ROOT, "sigdigger_amd")
+    bad = re.compile(r"(from|import)\s+oracle|oracle/|oracle\.sdo|libsdo|sdo\.h|\bsdo_\w+|\bsdo\.")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
-                assert "oracle" not in txt.replace("the CPU oracle", "").replace("CPU oracle", ""), \
-                    f"{f} references oracle/"
-                assert "sdo" not in re.findall(r"\bsdo\b", txt), f"{f} references the oracle module"
+                m = bad.search(txt)
+                assert m is None, f"{f} references the oracle: {m.group(0)!r}"
+    # and the shared library does not depend on it
+    import subprocess
+    from sigdigger_amd import lib
+    needed = subprocess.run(["readelf", "-d", lib.SO_PATH], capture_output=True, text=True).stdout
+    assert "sdo" not in needed
