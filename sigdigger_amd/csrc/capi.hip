@@ -154,7 +154,7 @@ struct suamd_chanbank {
   unsigned nchan, D, ntaps;
   uint64_t n_total;      // samples consumed so far (absolute index of the next x[0])
   float    *d_taps;      // real prototype [ntaps]
-  void     *d_g;         // float2 [nchan][ntaps]
+  void     *d_g;         // float4 [nchan][ntaps]: modulated taps as (re, re, -im, im)
   uint32_t *d_dphase, *d_phase0;
   void     *d_hist;      // float2 [ntaps-1]
 };
@@ -355,7 +355,7 @@ suamd_chanbank_t *suamd_chanbank_new(suamd_ctx_t *ctx, unsigned nchan, const dou
   // translate by -fc: Tasks/CarrierXlator.cpp:36 initialises the NCO with -relFreq
   for (unsigned c = 0; c < nchan; ++c) dp[c] = suamd_fnor_to_dphase(-fnor[c]);
   b->d_taps   = dev_alloc<float>(ntaps);
-  b->d_g      = dev_alloc<float>(2 * (size_t)nchan * ntaps);
+  b->d_g      = dev_alloc<float>(4 * (size_t)nchan * ntaps);
   b->d_dphase = dev_from_host(dp);
   b->d_phase0 = dev_from_host(p0);
   b->d_hist   = dev_zeros<float>(2 * (size_t)(ntaps > 1 ? ntaps - 1 : 1));

@@ -23,6 +23,19 @@
 namespace {
 
 using sd::c32;
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// acc += g * x for one tap, as the two packed fmas of SPEC.md section C:
+//   (acc.re, acc.im) = fma((g.re, g.re), (x.re, x.im), acc);  then fma((-g.im, g.im), (x.im, x.re), acc)
+// per component: acc.re = fma(g.re, x.re, acc.re); acc.re = fma(-g.im, x.im, acc.re);
+//                acc.im = fma(g.re, x.im, acc.im); acc.im = fma( g.im, x.re, acc.im)   (exact fmas)
+__device__ __forceinline__ v2f tap_mac(v2f acc, float4 t, v2f x)
+{
+  const v2f t0 = {t.x, t.y}, t1 = {t.z, t.w};
+  acc = __builtin_elementwise_fma(t0, x, acc);
+  acc = __builtin_elementwise_fma(t1, x.yx, acc);
+  return acc;
+}
 
 // ---------------------------------------------------------------------------------------
 // T1/K4: y[i] = x[i] * phasor(p0 + (n0+i)*dp)      (Tasks/CarrierXlator.cpp:57-60)
@@ -53,16 +66,19 @@ __global__ void xlate_kernel(const float4 *__restrict__ x, float4 *__restrict__ 
   }
 }
 
-// g[c][k] = h[k] * phasor(-(k*dp_c))
+// g[c][k] = h[k] * phasor(-(k*dp_c)), stored as (re, re, -im, im): the operand pairs of the two
+// packed fmas that accumulate (acc.re, acc.im) -- the SGPR pairs come straight out of s_load,
+// no scalar ALU work per tap.
 __global__ void modulate_taps_kernel(const float *__restrict__ h, int ntaps, const uint32_t *__restrict__ dphase,
-                                     int nchan, float2 *__restrict__ g)
+                                     int nchan, float4 *__restrict__ g)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ntaps * nchan) return;
   const int c = t / ntaps, k = t - c * ntaps;
   float cs, sn;
   sd::phasor_u32(0u - (uint32_t)k * dphase[c], cs, sn);
-  g[t] = float2{h[k] * cs, h[k] * sn};
+  const float re = h[k] * cs, im = h[k] * sn;
+  g[t] = float4{re, re, -im, im};
 }
 
 // ---------------------------------------------------------------------------------------
@@ -74,10 +90,12 @@ struct FirGeom {
   int LDW;           // LDS row pitch in samples (odd)
 };
 
+constexpr int FIR_THREADS = 512;   // 8 waves share one staged window: 4 workgroups x 8 = 32 waves per CU
+
 template <int NCH>
-__global__ __launch_bounds__(256) void chan_fir_kernel(const float2 *__restrict__ x, const float2 *__restrict__ hist,
+__global__ __launch_bounds__(FIR_THREADS) void chan_fir_kernel(const float2 *__restrict__ x, const float2 *__restrict__ hist,
                                                        long long len, uint64_t n0,
-                                                       const float2 *__restrict__ g,
+                                                       const float4 *__restrict__ g,
                                                        const uint32_t *__restrict__ dphase,
                                                        const uint32_t *__restrict__ phase0, FirGeom ge,
                                                        uint64_t m_first, long long n_out,
@@ -94,7 +112,7 @@ __global__ __launch_bounds__(256) void chan_fir_kernel(const float2 *__restrict_
   const long long hist0 = (long long)n0 - (T - 1);                    // absolute index of hist[0]
 
   // ---- stage the window: coalesced HBM reads, transposed LDS writes ----
-  for (int i = tid; i < span; i += 256) {
+  for (int i = tid; i < span; i += FIR_THREADS) {
     const long long n = nbase + i;
     float2 v = float2{0.0f, 0.0f};
     if (n >= (long long)n0) {
@@ -115,36 +133,62 @@ __global__ __launch_bounds__(256) void chan_fir_kernel(const float2 *__restrict_
   const int nunits = nsub * ngrp;
   const int kd_cols = ge.KD / D;
 
-  for (int u = wave; u < nunits; u += 4) {
+  for (int u = wave; u < nunits; u += FIR_THREADS / 64) {
     const int sub = u / ngrp;
     const int c0  = (u - sub * ngrp) * NCH;
     const int ml  = sub * 64 + lane;                                  // output within the tile
-    float ar[NCH], ai[NCH];
+    v2f acc[NCH];
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) { ar[j] = 0.0f; ai[j] = 0.0f; }
-    const float2 *gp[NCH];
+    for (int j = 0; j < NCH; ++j) acc[j] = v2f{0.0f, 0.0f};
+    const float4 *gp[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int c = (c0 + j < ge.nchan) ? c0 + j : ge.nchan - 1;      // clamp: duplicates are not stored
       gp[j] = g + (long long)c * T;
     }
-    // window index of tap k for output ml: i = ml*D + KD - k  -> row (KD-k) mod D, col ml + (KD-k)/D
-    // walk irel = KD - k downwards from KD (k = 0) to KD - T + 1
-    int k = 0;
-    for (int colofs = kd_cols; colofs >= 0 && k < T; --colofs) {
-      const int row_hi = (colofs == kd_cols) ? 0 : D - 1;             // irel = KD is row 0 of column kd_cols
-      const float2 *wp = win + colofs + (ml < ge.MT ? ml : ge.MT - 1);
-      for (int row = row_hi; row >= 0 && k < T; --row, ++k) {
-        const float2 v = wp[row * ge.LDW];
+    // window index of tap k for output ml: i = ml*D + KD - k  -> row (KD-k) mod D, col ml + (KD-k)/D.
+    // k = 0 sits at (row 0, column kd_cols); each following tap is one row up (address - LDW)
+    // until the row wraps to D-1 of the previous column.  Taps are consumed in runs that end at
+    // a wrap, 4 at a time inside a run so that the wave-uniform taps arrive as one
+    // s_load_dwordx16 per channel and feed v_pk_fma_f32 directly (the CU's single scalar unit
+    // is otherwise the bottleneck: 3 SALU per VALU were measured with the tap-at-a-time form).
+    const int mlc = ml < ge.MT ? ml : ge.MT - 1;
+    const int ldw = ge.LDW;
+    int row = 0, colofs = kd_cols;
+    for (int k = 0; k < T;) {
+      const int run = (row + 1 < T - k) ? row + 1 : T - k;
+      const float2 *wp = win + row * ldw + colofs + mlc;
+      int r = 0;
+      for (; r + 4 <= run; r += 4) {
+        v2f v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float2 w = wp[-(r + q) * ldw]; v[q] = v2f{w.x, w.y}; }
+        // all NCH x 4 taps first (one s_load_dwordx16 per channel, all in flight together),
+        // then the fmas tap-major so consecutive instructions hit different accumulators
+        float4 t[NCH][4];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-          const float2 gk = gp[j][k];
-          ar[j] = sd::fma_( gk.x, v.x, ar[j]);
-          ar[j] = sd::fma_(-gk.y, v.y, ar[j]);
-          ai[j] = sd::fma_( gk.x, v.y, ai[j]);
-          ai[j] = sd::fma_( gk.y, v.x, ai[j]);
+          const float4 *gk = gp[j] + (k + r);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t[j][q] = gk[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int j = 0; j < NCH; ++j) acc[j] = __builtin_elementwise_fma(v2f{t[j][q].x, t[j][q].y}, v[q], acc[j]);
+#pragma unroll
+          for (int j = 0; j < NCH; ++j) acc[j] = __builtin_elementwise_fma(v2f{t[j][q].z, t[j][q].w}, v[q].yx, acc[j]);
         }
       }
+      for (; r < run; ++r) {
+        const float2 w = wp[-r * ldw];
+        const v2f v = {w.x, w.y};
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) acc[j] = tap_mac(acc[j], gp[j][k + r], v);
+      }
+      k += run;
+      row = D - 1;
+      colofs -= 1;
     }
     // ---- de-rotate to baseband and store (coalesced over m) ----
     const long long m_rel = tile_m0 + ml;
@@ -156,7 +200,7 @@ __global__ __launch_bounds__(256) void chan_fir_kernel(const float2 *__restrict_
         if (c < ge.nchan) {
           float cs, sn;
           sd::phasor_u32(phase0[c] + (uint32_t)(n * (uint64_t)dphase[c]), cs, sn);
-          const c32 r = sd::cmul_cs(c32{ar[j], ai[j]}, cs, sn);
+          const c32 r = sd::cmul_cs(c32{acc[j].x, acc[j].y}, cs, sn);
           y[(long long)c * yv.cs + m_rel * yv.ms] = float2{r.re, r.im};
         }
       }
@@ -196,9 +240,9 @@ hipError_t launch_fir(const sdk::ChanFeedArgs &a, const FirGeom &ge, size_t lds,
     if (e != hipSuccess) return e;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds, st,
+  hipLaunchKernelGGL(kern, dim3(ntiles), dim3(FIR_THREADS), lds, st,
                      reinterpret_cast<const float2 *>(a.x), reinterpret_cast<const float2 *>(a.hist), a.len, a.n0,
-                     reinterpret_cast<const float2 *>(a.g), a.dphase, a.phase0, ge, a.m_first, a.n_out,
+                     reinterpret_cast<const float4 *>(a.g), a.dphase, a.phase0, ge, a.m_first, a.n_out,
                      reinterpret_cast<float2 *>(a.y), a.yv);
   return hipGetLastError();
 }
@@ -220,7 +264,7 @@ hipError_t chan_modulate_taps(const float *h, int ntaps, const uint32_t *dphase,
 {
   const int total = ntaps * nchan;
   hipLaunchKernelGGL(modulate_taps_kernel, dim3((total + 255) / 256), dim3(256), 0, st, h, ntaps, dphase, nchan,
-                     reinterpret_cast<float2 *>(g));
+                     reinterpret_cast<float4 *>(g));
   return hipGetLastError();
 }
 

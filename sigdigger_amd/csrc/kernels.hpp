@@ -31,7 +31,7 @@ struct ChanFeedArgs {
   const void *hist;     // ntaps-1 samples preceding x[0] (device)
   long long   len;
   uint64_t    n0;       // absolute index of x[0]
-  const void *g;        // [nchan][ntaps] modulated taps
+  const void *g;        // float4 [nchan][ntaps] modulated taps (re, re, -im, im)
   const uint32_t *dphase;   // [nchan]
   const uint32_t *phase0;   // [nchan]
   int         ntaps, nchan;
