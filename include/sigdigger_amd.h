@@ -201,6 +201,31 @@ SUAMD_API void   suamd_agc_bank_destroy(suamd_agc_bank_t *b);
 SUAMD_API SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d_x, suamd_view xv,
                                      suamd_complex *d_y, suamd_view yv, SUSCOUNT len, void *stream);
 
+/* ------------------------------------------------------------------------------------ */
+/* P2 / P3: panoramic scanner SpectrumView                                               */
+/* ------------------------------------------------------------------------------------ */
+/* struct SpectrumView (include/Scanner.h:63-110): psd / psdAccum / psdCount of up to 65536 bins
+ * resident on the GPU.  set_range = SpectrumView::setRange (Panoramic/Scanner.cpp:41-54), feed =
+ * SpectrumView::feed (:239-256: feedLinearMode :118-185 or feedHistogramMode :187-237, then
+ * interpolate :56-116).  d_psd: one PSD frame as delivered by PSDMessage (shifted, dB). */
+typedef struct suamd_specview suamd_specview_t;
+#define SUAMD_SCANNER_SPECTRUM_SIZE 65536
+SUAMD_API suamd_specview_t *suamd_specview_new(suamd_ctx_t *ctx);
+SUAMD_API void     suamd_specview_destroy(suamd_specview_t *v);
+SUAMD_API SUBOOL   suamd_specview_set_range(suamd_specview_t *v, SUFREQ freq_min, SUFREQ freq_max, void *stream);
+SUAMD_API void     suamd_specview_set_fft(suamd_specview_t *v, SUFREQ fft_bandwidth, SUFLOAT fft_rel_bw);
+SUAMD_API unsigned suamd_specview_spectrum_size(const suamd_specview_t *v);
+/* d_count may be NULL (every source bin counts 1); adjust_sides crops (1 - fftRelBw)/2 per side */
+SUAMD_API SUBOOL   suamd_specview_feed(suamd_specview_t *v, const SUFLOAT *d_psd, const SUFLOAT *d_count,
+                                       SUSCOUNT psd_size, SUFREQ freq_min, SUFREQ freq_max, SUBOOL adjust_sides,
+                                       void *stream);
+/* nframes consecutive frames d_psd[f*psd_size ...] centred on center[f] (host array), each spanning
+ * fft_bandwidth: Scanner::onPSDMessage (Panoramic/Scanner.cpp:503-523) for a whole sweep */
+SUAMD_API SUBOOL   suamd_specview_feed_sweep(suamd_specview_t *v, const SUFLOAT *d_psd, SUSCOUNT psd_size,
+                                             SUSCOUNT nframes, const SUFREQ *center, SUBOOL adjust_sides, void *stream);
+/* device pointers to the view's arrays (valid until destroy): 0 psd, 1 psdAccum, 2 psdCount */
+SUAMD_API SUFLOAT *suamd_specview_array(suamd_specview_t *v, int which);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,7 @@ SOURCES = {
     "psd.hip":   ["-ffp-contract=fast"],
     "chan.hip":  ["-ffp-contract=off"],
     "loops.hip": ["-ffp-contract=off"],
+    "specview.hip": ["-ffp-contract=off"],
     "capi.hip":  ["-ffp-contract=off"],
 }
 HEADERS = ["kernels.hpp", "sd_math.hpp", os.path.join("..", "..", "include", "sigdigger_amd.h")]

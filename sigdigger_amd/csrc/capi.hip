@@ -701,4 +701,134 @@ SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d_x, suamd_
   return SU_TRUE;
 }
 
+// ---- SpectrumView ----------------------------------------------------------------------------------
+struct suamd_specview {
+  suamd_ctx *ctx;
+  double freqMin, freqMax, freqRange, fftBandwidth;
+  float fftRelBw;
+  unsigned spectrumSize;
+  float *d_psd, *d_accum, *d_count;
+};
+
+static unsigned next_pow2_u(unsigned n) { unsigned i = 1; while (i < n) i <<= 1; return i; }
+
+static SUBOOL specview_reset(suamd_specview *v, hipStream_t st)
+{
+  const size_t bytes = sizeof(float) * SUAMD_SCANNER_SPECTRUM_SIZE;
+  HIP_TRY(hipMemsetAsync(v->d_psd, 0, bytes, st), SU_FALSE);
+  HIP_TRY(hipMemsetAsync(v->d_accum, 0, bytes, st), SU_FALSE);
+  HIP_TRY(hipMemsetAsync(v->d_count, 0, bytes, st), SU_FALSE);
+  return SU_TRUE;
+}
+
+suamd_specview_t *suamd_specview_new(suamd_ctx_t *ctx)
+{
+  if (!ctx) { set_err("null context"); return nullptr; }
+  HIP_TRY(hipSetDevice(ctx->device), nullptr);
+  suamd_specview *v = new (std::nothrow) suamd_specview();
+  if (!v) { set_err("out of memory"); return nullptr; }
+  v->ctx = ctx;
+  v->spectrumSize = SUAMD_SCANNER_SPECTRUM_SIZE;
+  v->fftRelBw = .5f;
+  v->d_psd = dev_zeros<float>(SUAMD_SCANNER_SPECTRUM_SIZE);
+  v->d_accum = dev_zeros<float>(SUAMD_SCANNER_SPECTRUM_SIZE);
+  v->d_count = dev_zeros<float>(SUAMD_SCANNER_SPECTRUM_SIZE);
+  if (!v->d_psd || !v->d_accum || !v->d_count) { set_err("device allocation failed"); suamd_specview_destroy(v); return nullptr; }
+  return v;
+}
+
+void suamd_specview_destroy(suamd_specview_t *v)
+{
+  if (!v) return;
+  if (v->d_psd) hipFree(v->d_psd);
+  if (v->d_accum) hipFree(v->d_accum);
+  if (v->d_count) hipFree(v->d_count);
+  delete v;
+}
+
+SUBOOL suamd_specview_set_range(suamd_specview_t *v, SUFREQ fmin, SUFREQ fmax, void *stream)
+{
+  if (!v) { set_err("null argument"); return SU_FALSE; }
+  // Panoramic/Scanner.cpp:41-54
+  v->freqMin = fmin; v->freqMax = fmax; v->freqRange = fmax - fmin;
+  v->spectrumSize = next_pow2_u((unsigned)(v->freqRange / 1000.0));
+  if (v->spectrumSize > SUAMD_SCANNER_SPECTRUM_SIZE) v->spectrumSize = SUAMD_SCANNER_SPECTRUM_SIZE;
+  return specview_reset(v, as_stream(stream));
+}
+
+void suamd_specview_set_fft(suamd_specview_t *v, SUFREQ bw, SUFLOAT rel)
+{
+  if (!v) return;
+  v->fftBandwidth = bw;
+  v->fftRelBw = rel;
+}
+
+unsigned suamd_specview_spectrum_size(const suamd_specview_t *v) { return v ? v->spectrumSize : 0; }
+
+SUFLOAT *suamd_specview_array(suamd_specview_t *v, int which)
+{
+  if (!v) return nullptr;
+  return which == 0 ? v->d_psd : (which == 1 ? v->d_accum : (which == 2 ? v->d_count : nullptr));
+}
+
+SUBOOL suamd_specview_feed(suamd_specview_t *v, const SUFLOAT *d_psd, const SUFLOAT *d_count, SUSCOUNT psdSize,
+                           SUFREQ freqMin, SUFREQ freqMax, SUBOOL adjustSides, void *stream)
+{
+  if (!v || !d_psd) { set_err("null argument"); return SU_FALSE; }
+  if (psdSize == 0 || psdSize > 0x7fffffff || !(v->freqRange > 0)) { set_err("bad frame size / range not set"); return SU_FALSE; }
+  hipStream_t st = as_stream(stream);
+  const double fftCount0 = (freqMax - freqMin) / v->freqRange;          // Scanner.cpp:247
+  if (fftCount0 * v->spectrumSize >= 2) {
+    // feedLinearMode, Scanner.cpp:126-151 (host side: the per-frame geometry)
+    double inpBw, bw, freqSkip, fftCount, bins, pos;
+    int skip;
+    sdk::SpecViewLinear g;
+    inpBw = freqMax - freqMin;
+    skip = adjustSides ? static_cast<int>(.5f * (1 - v->fftRelBw) * psdSize) : 0;
+    freqSkip = static_cast<double>(skip) / psdSize * inpBw;
+    bw = inpBw - 2 * freqSkip;
+    fftCount = static_cast<double>(v->freqRange / bw);
+    bins = v->spectrumSize / fftCount;
+    g.srcBinW = static_cast<double>(inpBw) / psdSize;
+    g.dstBinW = static_cast<double>(v->freqRange) / v->spectrumSize;
+    g.delta = g.dstBinW / g.srcBinW;
+    pos = static_cast<double>(freqSkip + freqMin - v->freqMin) / (v->freqRange);
+    pos *= v->spectrumSize;
+    g.j0 = pos > 0 ? static_cast<int>(pos) : 0;
+    g.k = pos + bins < v->spectrumSize ? static_cast<int>(pos + bins) : (int)v->spectrumSize;
+    g.viewFreqMin = v->freqMin; g.freqMin = freqMin; g.psdSize = (int)psdSize;
+    HIP_TRY(sdk::specview_feed_linear(g, d_psd, d_count, v->d_accum, v->d_count, st), SU_FALSE);
+  } else {
+    // feedHistogramMode, Scanner.cpp:194-236
+    double relBw = (freqMax - freqMin) / v->freqRange;
+    double fStart = (freqMin - v->freqMin) / v->freqRange;
+    double fEnd = (freqMax - v->freqMin) / v->freqRange;
+    sdk::SpecViewHist g;
+    fStart *= v->spectrumSize; fEnd *= v->spectrumSize; relBw *= v->spectrumSize;
+    unsigned j = static_cast<unsigned>(fStart);
+    if (j > v->spectrumSize - 1) j = v->spectrumSize - 1;
+    g.psdSize = (int)psdSize;
+    g.inv = (float)(1. / psdSize);
+    g.j = j; g.spectrumSize = v->spectrumSize;
+    g.split = std::floor(fStart) != std::floor(fEnd);
+    g.t = g.split ? static_cast<float>((fStart - std::floor(fStart)) / relBw) : 0.0f;
+    HIP_TRY(sdk::specview_feed_hist(g, d_psd, v->d_accum, v->d_count, st), SU_FALSE);
+  }
+  HIP_TRY(sdk::specview_interpolate(v->d_psd, v->d_accum, v->d_count, (int)v->spectrumSize, st), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUBOOL suamd_specview_feed_sweep(suamd_specview_t *v, const SUFLOAT *d_psd, SUSCOUNT psdSize, SUSCOUNT nframes,
+                                 const SUFREQ *center, SUBOOL adjustSides, void *stream)
+{
+  if (!v || !d_psd || !center) { set_err("null argument"); return SU_FALSE; }
+  for (SUSCOUNT f = 0; f < nframes; ++f) {
+    // SpectrumView::feed(psd, count, size, center, adjust), Scanner.cpp:258-273
+    if (!suamd_specview_feed(v, d_psd + f * psdSize, nullptr, psdSize, center[f] - v->fftBandwidth / 2,
+                             center[f] + v->fftBandwidth / 2, adjustSides, stream))
+      return SU_FALSE;
+  }
+  return SU_TRUE;
+}
+
 }  // extern "C"

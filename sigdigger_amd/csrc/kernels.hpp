@@ -85,4 +85,15 @@ struct AgcState {               // device
 hipError_t agc_feed(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv,
                     void *y, View yv, long long len, float *scratch, hipStream_t st);
 
+// ---- specview.hip ----
+struct SpecViewLinear {          // geometry of one frame, computed on the host in double precision
+  double viewFreqMin, dstBinW, freqMin, srcBinW, delta;
+  int j0, k, psdSize;
+};
+struct SpecViewHist { int psdSize; float inv, t; unsigned j, spectrumSize; int split; };
+hipError_t specview_feed_linear(const SpecViewLinear &g, const float *psd, const float *count, float *accum,
+                                float *cnt, hipStream_t st);
+hipError_t specview_feed_hist(const SpecViewHist &g, const float *psd, float *accum, float *cnt, hipStream_t st);
+hipError_t specview_interpolate(float *psd, float *accum, float *cnt, int n, hipStream_t st);
+
 }  // namespace sdk

@@ -343,3 +343,69 @@ class AGCBank(_LoopBank):
         check(self.ctx.lib.suamd_agc_bank_feed(self.h, _ptr(x), _view(x), _ptr(out), _view(out),
                                                x.shape[1], _stream(stream)), "suamd_agc_bank_feed")
         return out
+
+
+class SpectrumView:
+    """suamd_specview_t: the panoramic scanner's SpectrumView (Panoramic/Scanner.cpp) on the GPU."""
+    SIZE = 65536
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.h = ctx.lib.suamd_specview_new(ctx.h)
+        if not self.h:
+            raise SigDiggerAmdError("suamd_specview_new: " + _l.last_error())
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.suamd_specview_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_range(self, fmin, fmax, stream=None):
+        check(self.ctx.lib.suamd_specview_set_range(self.h, float(fmin), float(fmax), _stream(stream)),
+              "suamd_specview_set_range")
+
+    def set_fft(self, bandwidth, rel_bw=0.5):
+        self.ctx.lib.suamd_specview_set_fft(self.h, float(bandwidth), float(rel_bw))
+
+    @property
+    def spectrum_size(self):
+        return int(self.ctx.lib.suamd_specview_spectrum_size(self.h))
+
+    def feed(self, psd, fmin, fmax, adjust_sides=True, count=None, stream=None):
+        check(self.ctx.lib.suamd_specview_feed(self.h, _ptr(psd), _ptr(count) if count is not None else None,
+                                               psd.numel(), float(fmin), float(fmax), int(adjust_sides),
+                                               _stream(stream)), "suamd_specview_feed")
+
+    def feed_sweep(self, frames, centers, adjust_sides=True, stream=None):
+        """frames: [F, N] float32 (shifted dB PSD frames); centers: F centre frequencies (Hz)."""
+        cen = np.ascontiguousarray(centers, dtype=np.float64)
+        check(self.ctx.lib.suamd_specview_feed_sweep(self.h, _ptr(frames), frames.shape[1], frames.shape[0],
+                                                     cen.ctypes.data_as(C.c_void_p), int(adjust_sides),
+                                                     _stream(stream)), "suamd_specview_feed_sweep")
+
+    def arrays(self):
+        """(psd, accum, count) as host numpy arrays (synchronises)."""
+        torch.cuda.synchronize()
+        out = []
+        for which in range(3):
+            p = self.ctx.lib.suamd_specview_array(self.h, which)
+            t = torch.empty(self.SIZE, dtype=torch.float32, device="cuda")
+            _memcpy_d2d(t, p, self.SIZE * 4)
+            out.append(t.cpu().numpy())
+        return out
+
+
+def _memcpy_d2d(dst_tensor, src_ptr, nbytes):
+    """hipMemcpy DtoD from a raw device pointer into a tensor (uses the HIP runtime torch loaded)."""
+    hip = C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL)
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    rc = hip.hipMemcpy(C.c_void_p(dst_tensor.data_ptr()), C.c_void_p(src_ptr), nbytes, 3)   # hipMemcpyDeviceToDevice
+    if rc != 0:
+        raise SigDiggerAmdError(f"hipMemcpy failed: {rc}")

@@ -72,6 +72,14 @@ PROTOTYPES = {
     "suamd_agc_bank_new": (VP, [VP, UINT, C.POINTER(AgcParams)]),
     "suamd_agc_bank_destroy": (None, [VP]),
     "suamd_agc_bank_feed": (INT, [VP, VP, View, VP, View, U64, VP]),
+    "suamd_specview_new": (VP, [VP]),
+    "suamd_specview_destroy": (None, [VP]),
+    "suamd_specview_set_range": (INT, [VP, F64, F64, VP]),
+    "suamd_specview_set_fft": (None, [VP, F64, F32]),
+    "suamd_specview_spectrum_size": (UINT, [VP]),
+    "suamd_specview_feed": (INT, [VP, VP, VP, U64, F64, F64, INT, VP]),
+    "suamd_specview_feed_sweep": (INT, [VP, VP, U64, U64, VP, INT, VP]),
+    "suamd_specview_array": (VP, [VP, INT]),
 }
 
 

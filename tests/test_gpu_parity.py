@@ -422,3 +422,66 @@ def test_pipeline_overlap_equals_serial_and_oracle(ctx, sdo, kind):
             z = sdo.quad_demod(y)
         ref = sdo.clock_feed_bulk(sdo.clock_new(0.2, 1.0 / sps), z)
         assert_bits(s_ov[ch], ref, f"symbols ch {ch} vs oracle")
+
+
+# ------------------------------------------------------------------------------------------
+# P2/P3: panoramic SpectrumView (config C5 shape) -- bit exact
+# ------------------------------------------------------------------------------------------
+def _sweep_frames(sdo, ctx, nframes, n, seed):
+    x = synth.tone_noise(n * nframes, f_rel=0.07, sigma2=0.05, seed=seed)
+    psd = engine.PSD(ctx, n, engine.WINDOW_BLACKMANN_HARRIS)
+    return psd.feed(dev(x), nframes=nframes, scale=1.0 / n, mode=engine.PSD_DB_SHIFTED)
+
+
+@pytest.mark.parametrize("span,fs,nframes", [(100e6, 20e6, 24), (30e6, 2.4e6, 40), (1000e6, 20e6, 30)])
+def test_specview_sweep_bit_exact(ctx, sdo, span, fs, nframes):
+    n = 8192
+    frames = _sweep_frames(sdo, ctx, nframes, n, seed=int(span / 1e6))
+    fh = host(frames)
+    f0 = 400e6
+    rng = np.random.default_rng(3)
+    # hop across the range like the scanner does, revisiting some centres (count cap / reset path)
+    centers = f0 + fs / 2 + (rng.integers(0, max(int((span - fs) / (fs / 4)), 1), nframes) * (fs / 4))
+    centers[5] = centers[2]
+    for k in range(7, 15):
+        centers[k] = centers[6]                           # > SCANNER_COUNT_MAX hits on the same bins
+    ref = sdo.SpectrumView()
+    ref.set_range(f0, f0 + span)
+    ref.v.fftBandwidth = fs
+    view = engine.SpectrumView(ctx)
+    view.set_range(f0, f0 + span)
+    view.set_fft(fs, 0.5)
+    assert view.spectrum_size == ref.v.spectrumSize
+    for f in range(nframes):
+        ref.feed(fh[f], centers[f] - fs / 2, centers[f] + fs / 2, True)
+    view.feed_sweep(frames, centers, True)
+    psd, accum, count = view.arrays()
+    sz = view.spectrum_size
+    assert_bits(count[:sz], ref.count[:sz], "psdCount")
+    assert_bits(accum[:sz], ref.accum[:sz], "psdAccum")
+    assert_bits(psd[:sz], ref.psd[:sz], "psd (interpolated)")
+
+
+def test_specview_histogram_mode_and_detail_counts(ctx, sdo):
+    """frames narrower than two view bins take the histogram path (Scanner.cpp:187-237); a feed with a
+    count array is the SpectrumView::feed(SpectrumView const &) merge (Scanner.cpp:275-285)."""
+    n = 1024
+    frames = _sweep_frames(sdo, ctx, 12, n, seed=9)
+    fh = host(frames)
+    ref = sdo.SpectrumView()
+    view = engine.SpectrumView(ctx)
+    ref.set_range(0.0, 1e9)
+    view.set_range(0.0, 1e9)
+    for f in range(12):
+        lo = 500e6 + f * 3.7e3
+        ref.feed(fh[f], lo, lo + 10e3, False)
+        view.feed(frames[f], lo, lo + 10e3, False)
+    rng = np.random.default_rng(1)
+    cnt = (rng.integers(0, 4, n)).astype(np.float32)
+    ref.feed(fh[0], 100e6, 160e6, False, count=cnt)
+    view.feed(frames[0], 100e6, 160e6, False, count=dev(cnt))
+    psd, accum, count = view.arrays()
+    sz = view.spectrum_size
+    assert_bits(count[:sz], ref.count[:sz], "psdCount")
+    assert_bits(accum[:sz], ref.accum[:sz], "psdAccum")
+    assert_bits(psd[:sz], ref.psd[:sz], "psd")
