@@ -147,6 +147,14 @@ SUAMD_API SUBOOL suamd_delayed_conj_bulk(suamd_ctx_t *ctx, const suamd_complex *
 SUAMD_API SUBOOL suamd_histogram_feed_bulk(suamd_ctx_t *ctx, const suamd_complex *d_x, SUSCOUNT len,
                                            int space, SUFLOAT *d_out, void *stream);
 
+/* WaveSampler::sampleManual (Tasks/WaveSampler.cpp:96-175; delta / sampOffset of its ctor :45-46):
+ * fractional-boundary boxcar per symbol over the whole capture.  space: 0 AMPLITUDE (rms),
+ * 1 PHASE, 2 FREQUENCY (sum of x conj(prev)); symbols [0, nout) are written (complex, as
+ * WaveSampleSet::block) */
+SUAMD_API SUBOOL suamd_sample_manual_bulk(suamd_ctx_t *ctx, const suamd_complex *d_data, SUSCOUNT length,
+                                          double symbol_count, SUSCOUNT symbol_sync, int space,
+                                          suamd_complex *d_out, SUSCOUNT nout, void *stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* K6-K9: per-channel recurrences, one lane per channel                                  */
 /* ------------------------------------------------------------------------------------ */

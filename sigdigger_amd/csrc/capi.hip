@@ -465,6 +465,16 @@ SUBOOL suamd_histogram_feed_bulk(suamd_ctx_t *ctx, const suamd_complex *d_x, SUS
   return SU_TRUE;
 }
 
+SUBOOL suamd_sample_manual_bulk(suamd_ctx_t *ctx, const suamd_complex *d_data, SUSCOUNT length, double symbol_count,
+                                SUSCOUNT symbol_sync, int space, suamd_complex *d_out, SUSCOUNT nout, void *stream)
+{
+  if (!ctx || !d_data || !d_out) { set_err("null argument"); return SU_FALSE; }
+  if (!(symbol_count > 0) || space < 0 || space > 2) { set_err("bad symbol_count / space"); return SU_FALSE; }
+  HIP_TRY(sdk::sample_manual_bulk(d_data, (long long)length, symbol_count, (double)symbol_sync, space, d_out,
+                                  (long long)nout, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
 // ---- Costas --------------------------------------------------------------------------------------
 suamd_costas_bank_t *suamd_costas_bank_new(suamd_ctx_t *ctx, unsigned nchan, int kind, SUFLOAT fhint, SUFLOAT arm_bw,
                                            unsigned arm_order, SUFLOAT loop_bw)

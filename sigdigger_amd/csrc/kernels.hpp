@@ -49,6 +49,8 @@ hipError_t quad_demod_batch(const void *x, View xv, void *y, View yv, int nchan,
                             const void *prev, int first, void *prev_out, hipStream_t st);
 hipError_t delayed_conj_bulk(const void *x, void *y, long long len, long long delay, hipStream_t st);
 hipError_t histogram_feed_bulk(const void *x, long long len, int space, float *out, hipStream_t st);
+hipError_t sample_manual_bulk(const void *data, long long length, double symbol_count, double symbol_sync, int space,
+                              void *out, long long nout, hipStream_t st);
 
 struct CostasState {            // SoA over channels, all device pointers
   uint32_t *phase; float *omega;

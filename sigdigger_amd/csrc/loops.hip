@@ -128,6 +128,57 @@ __global__ void histogram_kernel(const float2 *__restrict__ x, long long len, in
 }
 
 // ---------------------------------------------------------------------------------------
+// T8: WaveSampler::sampleManual (Tasks/WaveSampler.cpp:96-175): fractional-boundary boxcar per
+// symbol.  Symbols are independent except for `prev`, the last (weighted) sample of the previous
+// symbol, which each thread recomputes from the reference's own expressions -> one thread per
+// symbol, same double-precision index arithmetic, same binary32 accumulation order.
+__device__ __forceinline__ float2 manual_fetch(const float2 *__restrict__ data, long long length, long long i,
+                                               long long iStart, long long iEnd, float tStart, float tEnd)
+{
+  if (i >= 0 && i < length) {
+    const float2 d = data[i];
+    if (i == iStart) return float2{tStart * d.x, tStart * d.y};
+    if (i == iEnd) return float2{tEnd * d.x, tEnd * d.y};
+    return d;
+  }
+  return float2{0.0f, 0.0f};
+}
+
+__global__ void sample_manual_kernel(const float2 *__restrict__ data, long long length, double delta,
+                                     double sampOffset, double symbolSync, int space, float2 *__restrict__ out,
+                                     long long nout)
+{
+  const float deltaInv = 1.f / (float)delta;
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < nout;
+       p += (long long)gridDim.x * blockDim.x) {
+    float2 prev = float2{0.0f, 0.0f};
+    if (p > 0) {                                            // last sample of symbol p-1
+      const double s0 = ((double)(p - 1) - sampOffset) * delta + symbolSync;
+      const double e0 = s0 + delta;
+      const long long is0 = (long long)floor(s0), ie0 = (long long)ceil(e0);
+      const float ts0 = (float)(1 - (s0 - (double)is0)), te0 = (float)(1 - ((double)ie0 - e0));
+      prev = manual_fetch(data, length, ie0, is0, ie0, ts0, te0);
+    }
+    const double start = ((double)p - sampOffset) * delta + symbolSync;
+    const double end = start + delta;
+    const long long iStart = (long long)floor(start), iEnd = (long long)ceil(end);
+    const float tStart = (float)(1 - (start - (double)iStart)), tEnd = (float)(1 - ((double)iEnd - end));
+    float ar = 0, ai = 0;
+    for (long long i = iStart; i <= iEnd; ++i) {
+      const float2 x = manual_fetch(data, length, i, iStart, iEnd, tStart, tEnd);
+      if (space == 0) {
+        ar = ar + sd::fma_(x.y, x.y, x.x * x.x);
+      } else {
+        const c32 d = sd::cmul_conj(c32{x.x, x.y}, c32{prev.x, prev.y});
+        ar = ar + d.re; ai = ai + d.im;
+      }
+      prev = x;
+    }
+    out[p] = space == 0 ? float2{__builtin_sqrtf(deltaInv * ar), 0.0f} : float2{deltaInv * ar, deltaInv * ai};
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // K6: Costas loop
 template <int ORDER> struct CostasRegs {
   uint32_t phase; float omega;
@@ -468,6 +519,18 @@ hipError_t histogram_feed_bulk(const void *x, long long len, int space, float *o
   if (len <= 0) return hipSuccess;
   hipLaunchKernelGGL(histogram_kernel, dim3(grid_for(len, 256)), dim3(256), 0, st,
                      reinterpret_cast<const float2 *>(x), len, space, out);
+  return hipGetLastError();
+}
+
+hipError_t sample_manual_bulk(const void *data, long long length, double symbol_count, double symbol_sync, int space,
+                              void *out, long long nout, hipStream_t st)
+{
+  if (nout <= 0) return hipSuccess;
+  const double delta = (double)length / symbol_count;       // Tasks/WaveSampler.cpp:45-46
+  const double sampOffset = symbol_sync / delta;
+  hipLaunchKernelGGL(sample_manual_kernel, dim3(grid_for(nout, 128)), dim3(128), 0, st,
+                     reinterpret_cast<const float2 *>(data), length, delta, sampOffset, symbol_sync, space,
+                     reinterpret_cast<float2 *>(out), nout);
   return hipGetLastError();
 }
 

@@ -130,6 +130,17 @@ class Context:
                                                  _stream(stream)), "suamd_histogram_feed_bulk")
         return out
 
+    def sample_manual(self, data, symbol_count, symbol_sync, space, nout=None, stream=None):
+        """WaveSampler::sampleManual over a whole capture (Tasks/WaveSampler.cpp:96-175)."""
+        _chk_c64(data, "data")
+        if nout is None:
+            nout = int(symbol_count)
+        out = torch.empty(nout, dtype=torch.complex64, device=data.device)
+        check(self.lib.suamd_sample_manual_bulk(self.h, _ptr(data), data.numel(), float(symbol_count),
+                                                int(symbol_sync), int(space), _ptr(out), nout, _stream(stream)),
+              "suamd_sample_manual_bulk")
+        return out
+
     def lpf_design(self, ntaps, fc):
         h = np.empty(ntaps, dtype=np.float32)
         self.lib.suamd_lpf_design(h.ctypes.data_as(C.c_void_p), ntaps, float(fc))

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "suamd_quad_demod_batch": (INT, [VP, VP, View, VP, View, UINT, U64, VP, INT, VP, VP]),
     "suamd_delayed_conj_bulk": (INT, [VP, VP, VP, U64, U64, VP]),
     "suamd_histogram_feed_bulk": (INT, [VP, VP, U64, INT, VP, VP]),
+    "suamd_sample_manual_bulk": (INT, [VP, VP, U64, F64, U64, INT, VP, U64, VP]),
     "suamd_costas_bank_new": (VP, [VP, UINT, INT, F32, F32, UINT, F32]),
     "suamd_costas_bank_destroy": (None, [VP]),
     "suamd_costas_bank_feed": (INT, [VP, VP, View, VP, View, U64, VP]),

@@ -485,3 +485,15 @@ def test_specview_histogram_mode_and_detail_counts(ctx, sdo):
     assert_bits(count[:sz], ref.count[:sz], "psdCount")
     assert_bits(accum[:sz], ref.accum[:sz], "psdAccum")
     assert_bits(psd[:sz], ref.psd[:sz], "psd")
+
+
+# ------------------------------------------------------------------------------------------
+# T8: manual sampler -- bit exact
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("space", [0, 1, 2])
+@pytest.mark.parametrize("nsym,sync", [(1000.0, 0), (777.5, 13), (20000.0, 3)])
+def test_sample_manual_bit_exact(ctx, sdo, space, nsym, sync):
+    x = synth.psk_carriers(50000, [0.003], sps=8, order=4, seed=31)
+    ref = sdo.sample_manual(x, nsym, sync, space)
+    got = host(ctx.sample_manual(dev(x), nsym, sync, space))
+    assert_bits(got, ref, f"manual sampler space {space}")
