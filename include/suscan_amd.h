@@ -1,0 +1,199 @@
+/*
+ * include/suscan_amd.h -- live-path C ABI: the subset of libsuscan that SigDigger's
+ * Suscan::Analyzer wrapper calls (Suscan/Analyzer.cpp:63-639, Suscan/MQ.cpp:24-44), served by
+ * libsigdigger_amd.so with the PSD and the inspector chains running on the MI355X.
+ *
+ * Function names, argument order and the message / ownership protocol are the reference's
+ * (SURVEY.md section 8b, Appendix A/B); struct LAYOUTS cannot be checked against upstream headers
+ * (absent from /root/reference), so compatibility is source level: recompile the wrapper against
+ * this header.  Every message returned by suscan_analyzer_read() is an ordinary malloc'd host
+ * object owned by the caller (consumers mutate payloads in place: PSDMessage.cpp:34-38) and must
+ * be released with exactly one suscan_analyzer_dispose_message().
+ */
+#ifndef SUSCAN_AMD_H
+#define SUSCAN_AMD_H
+
+#include <stdint.h>
+#include <sys/time.h>
+#include "sigdigger_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t SUHANDLE;
+
+/* ---- message queue (Suscan/MQ.cpp:28-43) --------------------------------------------------- */
+struct suscan_mq { void *impl; };
+SUAMD_API SUBOOL suscan_mq_init(struct suscan_mq *mq);
+SUAMD_API void   suscan_mq_finalize(struct suscan_mq *mq);
+SUAMD_API void  *suscan_mq_read(struct suscan_mq *mq, uint32_t *type);          /* blocks */
+SUAMD_API SUBOOL suscan_mq_poll(struct suscan_mq *mq, uint32_t *type, void **msg);
+SUAMD_API SUBOOL suscan_mq_write(struct suscan_mq *mq, uint32_t type, void *msg);
+
+/* ---- message types switched on in Suscan/Analyzer.cpp:75-98, :330-375 ----------------------- */
+#define SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INFO 0x0
+#define SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INIT 0x1
+#define SUSCAN_ANALYZER_MESSAGE_TYPE_CHANNEL     0x2
+#define SUSCAN_ANALYZER_MESSAGE_TYPE_EOS         0x3
+#define SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR  0x4
+#define SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL    0x5
+#define SUSCAN_ANALYZER_MESSAGE_TYPE_SAMPLES_LOST 0x6
+#define SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR   0x7
+#define SUSCAN_ANALYZER_MESSAGE_TYPE_PSD         0x8
+#define SUSCAN_ANALYZER_MESSAGE_TYPE_SAMPLES     0x9
+#define SUSCAN_ANALYZER_MESSAGE_TYPE_THROTTLE    0xa
+#define SUSCAN_ANALYZER_MESSAGE_TYPE_PARAMS      0xb
+#define SUSCAN_WORKER_MSG_TYPE_HALT              0xffffffffu
+
+#define SUSCAN_ANALYZER_INIT_SUCCESS  0
+#define SUSCAN_ANALYZER_INIT_PROGRESS 1
+#define SUSCAN_ANALYZER_INIT_FAILURE  -1
+
+/* ---- analyzer parameters (Suscan/AnalyzerParams.cpp:27-71) ----------------------------------- */
+enum suscan_analyzer_mode { SUSCAN_ANALYZER_MODE_CHANNEL = 0, SUSCAN_ANALYZER_MODE_WIDE_SPECTRUM = 1 };
+struct sigutils_channel_detector_params {
+  SUFLOAT alpha, beta, gamma, snr;
+  SUSCOUNT window_size;
+  int window;                                /* enum suamd_window == sigutils_channel_detector_window */
+};
+struct suscan_analyzer_params {
+  enum suscan_analyzer_mode mode;
+  struct sigutils_channel_detector_params detector_params;
+  SUFLOAT channel_update_int;
+  SUFLOAT psd_update_int;
+  SUFREQ  min_freq, max_freq;
+};
+#define suscan_analyzer_params_INITIALIZER \
+  { SUSCAN_ANALYZER_MODE_CHANNEL, { 1e-2f, 1e-3f, .5f, 2.f, 4096, SUAMD_WINDOW_BLACKMANN_HARRIS }, .1f, .04f, -1, -1 }
+
+/* struct sigutils_channel (Suscan/Analyzer.cpp:417-424) */
+struct sigutils_channel { SUFREQ fc, f_lo, f_hi; SUFLOAT bw, snr, S0, N0; SUFREQ ft; uint32_t age, present; };
+#define sigutils_channel_INITIALIZER { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }
+
+/* ---- source configuration: the subset needed to stand up a file / tone-generator source ------ */
+typedef struct suscan_source_config suscan_source_config_t;
+enum suscan_source_format { SUSCAN_SOURCE_FORMAT_AUTO = 0, SUSCAN_SOURCE_FORMAT_RAW_FLOAT32 = 1 };
+SUAMD_API suscan_source_config_t *suscan_source_config_new(const char *type, enum suscan_source_format fmt);
+SUAMD_API void   suscan_source_config_destroy(suscan_source_config_t *cfg);
+SUAMD_API void   suscan_source_config_set_samp_rate(suscan_source_config_t *cfg, unsigned int rate);
+SUAMD_API void   suscan_source_config_set_freq(suscan_source_config_t *cfg, SUFREQ freq);
+SUAMD_API SUBOOL suscan_source_config_set_path(suscan_source_config_t *cfg, const char *path);
+SUAMD_API void   suscan_source_config_set_loop(suscan_source_config_t *cfg, SUBOOL loop);
+SUAMD_API SUBOOL suscan_source_config_set_param(suscan_source_config_t *cfg, const char *key, const char *val);
+
+struct suscan_source_info {
+  uint64_t permissions;
+  SUSCOUNT source_samp_rate, effective_samp_rate;
+  SUFLOAT  measured_samp_rate;
+  SUFREQ   frequency, freq_min, freq_max, lnb;
+  SUFLOAT  bandwidth, ppm;
+  SUBOOL   dc_remove, iq_reverse, agc, seekable;
+  struct timeval source_start, source_end;
+};
+
+/* ---- inspector configuration (Suscan/Config.cpp; key vocabulary: Default/GenericInspector/InspectorCtl) */
+enum suscan_field_type { SUSCAN_FIELD_TYPE_STRING, SUSCAN_FIELD_TYPE_INTEGER, SUSCAN_FIELD_TYPE_FLOAT,
+                         SUSCAN_FIELD_TYPE_FILE, SUSCAN_FIELD_TYPE_BOOLEAN };
+struct suscan_field { enum suscan_field_type type; SUBOOL optional; char *name; char *desc; };
+struct suscan_field_value {
+  SUBOOL set;
+  const struct suscan_field *field;
+  union { uint64_t as_int; SUFLOAT as_float; SUBOOL as_bool; };
+  char *as_string;
+};
+typedef struct suscan_config_desc { char *global_name; struct suscan_field **field_list; unsigned field_count; }
+  suscan_config_desc_t;
+typedef struct suscan_config { const suscan_config_desc_t *desc; struct suscan_field_value **values; }
+  suscan_config_t;
+SUAMD_API const suscan_config_desc_t *suscan_inspector_config_desc(const char *class_name);  /* "psk", "fsk", "raw" */
+SUAMD_API suscan_config_t *suscan_config_new(const suscan_config_desc_t *desc);
+SUAMD_API suscan_config_t *suscan_config_dup(const suscan_config_t *cfg);
+SUAMD_API void   suscan_config_destroy(suscan_config_t *cfg);
+SUAMD_API struct suscan_field_value *suscan_config_get_value(const suscan_config_t *cfg, const char *name);
+SUAMD_API SUBOOL suscan_config_set_integer(suscan_config_t *cfg, const char *name, uint64_t v);
+SUAMD_API SUBOOL suscan_config_set_float(suscan_config_t *cfg, const char *name, SUFLOAT v);
+SUAMD_API SUBOOL suscan_config_set_bool(suscan_config_t *cfg, const char *name, SUBOOL v);
+
+/* ---- messages (fields SigDigger dereferences: SURVEY.md Appendix B) --------------------------- */
+struct suscan_analyzer_psd_msg {
+  int64_t  fc;
+  uint32_t inspector_id;
+  struct timeval timestamp, rt_time;
+  SUBOOL   looped;
+  SUSCOUNT history_size;
+  SUFLOAT  samp_rate, measured_samp_rate, N0;
+  SUSCOUNT psd_size;
+  SUFLOAT *psd_data;                          /* linear power, natural FFT order (DC at 0) */
+};
+struct suscan_analyzer_sample_batch_msg {
+  uint32_t inspector_id;
+  suamd_complex *samples;                     /* SUCOMPLEX */
+  SUSCOUNT sample_count;
+};
+enum suscan_analyzer_inspector_msgkind {
+  SUSCAN_ANALYZER_INSPECTOR_MSGKIND_OPEN, SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SET_ID,
+  SUSCAN_ANALYZER_INSPECTOR_MSGKIND_GET_CONFIG, SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SET_CONFIG,
+  SUSCAN_ANALYZER_INSPECTOR_MSGKIND_ESTIMATOR, SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SPECTRUM,
+  SUSCAN_ANALYZER_INSPECTOR_MSGKIND_RESET_EQUALIZER, SUSCAN_ANALYZER_INSPECTOR_MSGKIND_CLOSE,
+  SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SET_FREQ, SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SET_BANDWIDTH,
+  SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SET_WATERMARK, SUSCAN_ANALYZER_INSPECTOR_MSGKIND_WRONG_HANDLE,
+  SUSCAN_ANALYZER_INSPECTOR_MSGKIND_WRONG_OBJECT, SUSCAN_ANALYZER_INSPECTOR_MSGKIND_INVALID_ARGUMENT,
+  SUSCAN_ANALYZER_INSPECTOR_MSGKIND_WRONG_KIND, SUSCAN_ANALYZER_INSPECTOR_MSGKIND_INVALID_CHANNEL,
+  SUSCAN_ANALYZER_INSPECTOR_MSGKIND_ORBIT_REPORT, SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SET_TLE
+};
+struct suscan_analyzer_inspector_msg {
+  enum suscan_analyzer_inspector_msgkind kind;
+  uint32_t inspector_id;
+  uint32_t req_id;
+  SUHANDLE handle;
+  int      status;
+  char    *class_name;
+  struct sigutils_channel channel;
+  suscan_config_t *config;                    /* borrowed by readers: they suscan_config_dup it */
+  SUBOOL   precise;
+  uint32_t fs;
+  SUFLOAT  equiv_fs, bandwidth, lo;
+  unsigned spectsrc_count; char **spectsrc_list;
+  unsigned estimator_count; char **estimator_list;
+  uint32_t spectsrc_id, estimator_id;
+  SUFLOAT *spectrum_data; SUSCOUNT spectrum_size; SUSCOUNT samp_rate;
+  SUSCOUNT watermark;
+};
+struct suscan_analyzer_status_msg { int code; char *err_msg; };
+
+/* ---- analyzer (Suscan/Analyzer.cpp:111-639) --------------------------------------------------- */
+typedef struct suscan_analyzer suscan_analyzer_t;
+SUAMD_API suscan_analyzer_t *suscan_analyzer_new(const struct suscan_analyzer_params *params,
+                                                 suscan_source_config_t *config, struct suscan_mq *mq);
+SUAMD_API void   suscan_analyzer_destroy(suscan_analyzer_t *analyzer);
+SUAMD_API void  *suscan_analyzer_read(suscan_analyzer_t *analyzer, uint32_t *type);
+SUAMD_API void   suscan_analyzer_dispose_message(uint32_t type, void *ptr);
+SUAMD_API void   suscan_analyzer_req_halt(suscan_analyzer_t *analyzer);
+SUAMD_API SUBOOL suscan_analyzer_set_params_async(suscan_analyzer_t *analyzer,
+                                                  const struct suscan_analyzer_params *params, uint32_t req_id);
+SUAMD_API SUBOOL suscan_analyzer_set_throttle_async(suscan_analyzer_t *analyzer, SUSCOUNT samp_rate, uint32_t req_id);
+SUAMD_API unsigned int suscan_analyzer_get_samp_rate(const suscan_analyzer_t *analyzer);
+SUAMD_API SUFLOAT suscan_analyzer_get_measured_samp_rate(const suscan_analyzer_t *analyzer);
+SUAMD_API struct suscan_source_info *suscan_analyzer_get_source_info(const suscan_analyzer_t *analyzer);  /* loaned */
+SUAMD_API SUBOOL suscan_analyzer_open_async(suscan_analyzer_t *analyzer, const char *class_name,
+                                            const struct sigutils_channel *channel, uint32_t req_id);
+SUAMD_API SUBOOL suscan_analyzer_open_ex_async(suscan_analyzer_t *analyzer, const char *class_name,
+                                               const struct sigutils_channel *channel, SUBOOL precise,
+                                               SUHANDLE parent, uint32_t req_id);
+SUAMD_API SUBOOL suscan_analyzer_close_async(suscan_analyzer_t *analyzer, SUHANDLE handle, uint32_t req_id);
+SUAMD_API SUBOOL suscan_analyzer_set_inspector_id_async(suscan_analyzer_t *analyzer, SUHANDLE handle,
+                                                        uint32_t inspector_id, uint32_t req_id);
+SUAMD_API SUBOOL suscan_analyzer_set_inspector_config_async(suscan_analyzer_t *analyzer, SUHANDLE handle,
+                                                            const suscan_config_t *config, uint32_t req_id);
+SUAMD_API SUBOOL suscan_analyzer_set_inspector_watermark_async(suscan_analyzer_t *analyzer, SUHANDLE handle,
+                                                               SUSCOUNT watermark, uint32_t req_id);
+SUAMD_API SUBOOL suscan_analyzer_set_inspector_freq_overridable(suscan_analyzer_t *analyzer, SUHANDLE handle,
+                                                                SUFREQ freq);
+SUAMD_API SUBOOL suscan_analyzer_set_inspector_bandwidth_overridable(suscan_analyzer_t *analyzer, SUHANDLE handle,
+                                                                     SUFREQ bw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUSCAN_AMD_H */

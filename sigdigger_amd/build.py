@@ -24,8 +24,10 @@ SOURCES = {
     "loops.hip": ["-ffp-contract=off"],
     "specview.hip": ["-ffp-contract=off"],
     "capi.hip":  ["-ffp-contract=off"],
+    "analyzer.cpp": ["-ffp-contract=off"],
 }
-HEADERS = ["kernels.hpp", "sd_math.hpp", os.path.join("..", "..", "include", "sigdigger_amd.h")]
+HEADERS = ["kernels.hpp", "sd_math.hpp", os.path.join("..", "..", "include", "sigdigger_amd.h"),
+           os.path.join("..", "..", "include", "suscan_amd.h")]
 
 
 def _stale(target, deps):
@@ -40,7 +42,7 @@ def build(force=False, verbose=False):
     objs, jobs = [], []
     for src, flags in SOURCES.items():
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
             jobs.append([HIPCC] + COMMON + flags + ["-c", s, "-o", o])
@@ -55,7 +57,7 @@ def build(force=False, verbose=False):
             list(ex.map(run, jobs))
     if force or jobs or _stale(OUT, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs +
-            ["-Wl,-rpath,/opt/rocm/lib"])
+            ["-Wl,-rpath,/opt/rocm/lib", "-lpthread"])
     return OUT
 
 

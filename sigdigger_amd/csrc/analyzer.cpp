@@ -1,0 +1,917 @@
+// analyzer.cpp -- live path behind the suscan_analyzer_* C ABI (include/suscan_amd.h): message
+// queue, source reader, analyzer worker thread and per-inspector chains.  All arithmetic is
+// delegated to the GPU entry points of include/sigdigger_amd.h; this file only moves blocks
+// (source -> pinned host -> HBM), sequences the calls and packages results as malloc'd messages
+// with the reference's ownership protocol.
+//
+// Worker loop per block (what libsuscan's source worker does):
+//   pending requests -> read L samples -> PSD (every window, Welch average -> one psd_msg per
+//   psd_update_int) -> every open inspector: channel bank -> [AGC] -> [Costas | quad demod] ->
+//   [Gardner] -> sample_batch_msg.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/suscan_amd.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// message queue
+struct MQImpl {
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<std::pair<uint32_t, void *>> q;
+};
+MQImpl *impl(struct suscan_mq *mq) { return static_cast<MQImpl *>(mq->impl); }
+
+// ------------------------------------------------------------------------------------------
+// inspector config descriptors: key vocabulary of Default/GenericInspector/InspectorCtl/*.cpp
+struct FieldDef { const char *name; suscan_field_type type; double def; };
+const FieldDef kPskFields[] = {
+  {"agc.enabled", SUSCAN_FIELD_TYPE_BOOLEAN, 1}, {"agc.gain", SUSCAN_FIELD_TYPE_FLOAT, 1},
+  {"afc.costas-order", SUSCAN_FIELD_TYPE_INTEGER, 0}, {"afc.bits-per-symbol", SUSCAN_FIELD_TYPE_INTEGER, 1},
+  {"afc.offset", SUSCAN_FIELD_TYPE_FLOAT, 0}, {"afc.loop-bw", SUSCAN_FIELD_TYPE_FLOAT, 100},
+  {"mf.type", SUSCAN_FIELD_TYPE_INTEGER, 0}, {"mf.roll-off", SUSCAN_FIELD_TYPE_FLOAT, .35},
+  {"clock.type", SUSCAN_FIELD_TYPE_INTEGER, 0}, {"clock.baud", SUSCAN_FIELD_TYPE_FLOAT, 0},
+  {"clock.gain", SUSCAN_FIELD_TYPE_FLOAT, .2}, {"clock.phase", SUSCAN_FIELD_TYPE_FLOAT, 0},
+  {"clock.running", SUSCAN_FIELD_TYPE_BOOLEAN, 1},
+  {"equalizer.type", SUSCAN_FIELD_TYPE_INTEGER, 0}, {"equalizer.rate", SUSCAN_FIELD_TYPE_FLOAT, 1e-3},
+  {"equalizer.locked", SUSCAN_FIELD_TYPE_BOOLEAN, 0},
+};
+const FieldDef kFskFields[] = {
+  {"agc.enabled", SUSCAN_FIELD_TYPE_BOOLEAN, 1}, {"agc.gain", SUSCAN_FIELD_TYPE_FLOAT, 1},
+  {"mf.type", SUSCAN_FIELD_TYPE_INTEGER, 0}, {"mf.roll-off", SUSCAN_FIELD_TYPE_FLOAT, .35},
+  {"clock.type", SUSCAN_FIELD_TYPE_INTEGER, 0}, {"clock.baud", SUSCAN_FIELD_TYPE_FLOAT, 0},
+  {"clock.gain", SUSCAN_FIELD_TYPE_FLOAT, .2}, {"clock.phase", SUSCAN_FIELD_TYPE_FLOAT, 0},
+  {"clock.running", SUSCAN_FIELD_TYPE_BOOLEAN, 1},
+  {"fsk.bits-per-symbol", SUSCAN_FIELD_TYPE_INTEGER, 1}, {"fsk.phase", SUSCAN_FIELD_TYPE_FLOAT, 0},
+  {"fsk.quad-demod", SUSCAN_FIELD_TYPE_BOOLEAN, 1},
+};
+
+struct DescHolder {
+  suscan_config_desc_t desc{};
+  std::vector<suscan_field> fields;
+  std::vector<suscan_field *> ptrs;
+  std::vector<double> defaults;
+  DescHolder(const char *name, const FieldDef *defs, size_t n)
+  {
+    fields.resize(n); ptrs.resize(n); defaults.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      fields[i].type = defs[i].type; fields[i].optional = SU_TRUE;
+      fields[i].name = const_cast<char *>(defs[i].name); fields[i].desc = const_cast<char *>("");
+      ptrs[i] = &fields[i]; defaults[i] = defs[i].def;
+    }
+    desc.global_name = const_cast<char *>(name);
+    desc.field_list = n ? ptrs.data() : nullptr;
+    desc.field_count = (unsigned)n;
+  }
+};
+DescHolder &psk_desc() { static DescHolder d("psk", kPskFields, sizeof kPskFields / sizeof kPskFields[0]); return d; }
+DescHolder &fsk_desc() { static DescHolder d("fsk", kFskFields, sizeof kFskFields / sizeof kFskFields[0]); return d; }
+DescHolder &raw_desc() { static DescHolder d("raw", nullptr, 0); return d; }
+DescHolder *holder_for(const char *cls)
+{
+  if (!cls) return nullptr;
+  if (!std::strcmp(cls, "psk")) return &psk_desc();
+  if (!std::strcmp(cls, "fsk")) return &fsk_desc();
+  if (!std::strcmp(cls, "raw")) return &raw_desc();
+  return nullptr;
+}
+
+double cfg_get(const suscan_config_t *cfg, const char *name, double dflt)
+{
+  if (!cfg) return dflt;
+  struct suscan_field_value *v = suscan_config_get_value(cfg, name);
+  if (!v) return dflt;
+  switch (v->field->type) {
+    case SUSCAN_FIELD_TYPE_INTEGER: return (double)v->as_int;
+    case SUSCAN_FIELD_TYPE_BOOLEAN: return v->as_bool ? 1.0 : 0.0;
+    case SUSCAN_FIELD_TYPE_FLOAT:   return (double)v->as_float;
+    default: return dflt;
+  }
+}
+
+char *dupstr(const char *s) { return s ? strdup(s) : nullptr; }
+
+}  // namespace
+
+// ==========================================================================================
+struct suscan_source_config {
+  std::string type;
+  enum suscan_source_format format;
+  unsigned samp_rate = 1000000;
+  double freq = 0;
+  std::string path;
+  bool loop = false;
+  std::map<std::string, std::string> params;
+};
+
+namespace {
+
+// source reader: raw float32 IQ file, or a tone generator ("tonegen": params signal / noise in dB,
+// Default/SourceConfig/ToneGenSourcePage.cpp:81-90,125-126)
+struct Source {
+  suscan_source_config cfg;
+  FILE *fp = nullptr;
+  uint64_t n = 0;
+  uint32_t lcg = 12345u;
+  bool open(std::string &err)
+  {
+    if (cfg.type == "file") {
+      fp = std::fopen(cfg.path.c_str(), "rb");
+      if (!fp) { err = "cannot open " + cfg.path; return false; }
+      return true;
+    }
+    if (cfg.type == "tonegen") return true;
+    err = "unsupported source type '" + cfg.type + "' (file, tonegen)";
+    return false;
+  }
+  // returns samples read (< want only at end of stream)
+  size_t read(suamd_complex *dst, size_t want, bool *looped)
+  {
+    if (cfg.type == "tonegen") {
+      const double sig = std::pow(10.0, std::atof(cfg.params.count("signal") ? cfg.params["signal"].c_str() : "0") / 20);
+      const double noi = std::pow(10.0, std::atof(cfg.params.count("noise") ? cfg.params["noise"].c_str() : "-40") / 20);
+      const double w = 2 * M_PI * 0.05;
+      for (size_t i = 0; i < want; ++i, ++n) {
+        lcg = lcg * 1664525u + 1013904223u; const float a = ((lcg >> 8) & 0xffff) / 32768.0f - 1.0f;
+        lcg = lcg * 1664525u + 1013904223u; const float b = ((lcg >> 8) & 0xffff) / 32768.0f - 1.0f;
+        dst[i].re = (float)(sig * std::cos(w * (double)n) + noi * a);
+        dst[i].im = (float)(sig * std::sin(w * (double)n) + noi * b);
+      }
+      return want;
+    }
+    size_t got = 0;
+    while (got < want) {
+      const size_t r = std::fread(dst + got, sizeof(suamd_complex), want - got, fp);
+      got += r;
+      if (got < want) {
+        if (cfg.loop && std::ftell(fp) > 0) { std::rewind(fp); if (looped) *looped = true; continue; }
+        break;
+      }
+    }
+    n += got;
+    return got;
+  }
+  ~Source() { if (fp) std::fclose(fp); }
+};
+
+struct Inspector {
+  SUHANDLE handle;
+  uint32_t inspector_id = 0;
+  std::string cls;
+  struct sigutils_channel channel;
+  suscan_config_t *config = nullptr;
+  unsigned D = 1;
+  double equiv_fs = 0, fnor = 0;
+  SUSCOUNT watermark = 0;
+  bool dirty = true;                          // chain must be (re)built
+  suamd_chanbank_t *bank = nullptr;
+  suamd_agc_bank_t *agc = nullptr;
+  suamd_costas_bank_t *costas = nullptr;
+  suamd_clock_bank_t *clock = nullptr;
+  bool quad = false, first = true;
+  suamd_complex *d_y = nullptr, *d_a = nullptr, *d_z = nullptr, *d_sym = nullptr, *d_prev = nullptr;
+  uint32_t *d_count = nullptr;
+  size_t cap = 0;
+  void free_chain()
+  {
+    if (bank) suamd_chanbank_destroy(bank);
+    if (agc) suamd_agc_bank_destroy(agc);
+    if (costas) suamd_costas_bank_destroy(costas);
+    if (clock) suamd_clock_bank_destroy(clock);
+    bank = nullptr; agc = nullptr; costas = nullptr; clock = nullptr;
+  }
+  void free_all()
+  {
+    free_chain();
+    for (void *p : {(void *)d_y, (void *)d_a, (void *)d_z, (void *)d_sym, (void *)d_prev, (void *)d_count})
+      if (p) (void)hipFree(p);
+    d_y = d_a = d_z = d_sym = d_prev = nullptr; d_count = nullptr;
+    if (config) suscan_config_destroy(config);
+    config = nullptr;
+  }
+};
+
+struct Request {
+  enum Kind { OPEN, CLOSE, SET_ID, SET_CONFIG, SET_WATERMARK, SET_FREQ, SET_BW, SET_PARAMS, SET_THROTTLE } kind;
+  uint32_t req_id = 0;
+  SUHANDLE handle = -1;
+  std::string cls;
+  struct sigutils_channel channel{};
+  uint32_t inspector_id = 0;
+  suscan_config_t *config = nullptr;
+  SUSCOUNT value = 0;
+  double fvalue = 0;
+  struct suscan_analyzer_params params{};
+};
+
+}  // namespace
+
+struct suscan_analyzer {
+  struct suscan_analyzer_params params;
+  suscan_source_config source_cfg;
+  struct suscan_mq *mq;
+  std::thread worker;
+  std::mutex req_m;
+  std::deque<Request> requests;
+  std::atomic<bool> halt{false};
+  std::atomic<float> measured_rate{0.f};
+  std::atomic<uint64_t> throttle{0};
+  struct suscan_source_info info{};
+  SUHANDLE next_handle = 0;
+  // worker-owned
+  suamd_ctx_t *ctx = nullptr;
+  suamd_psd_t *psd = nullptr;
+  std::map<SUHANDLE, std::unique_ptr<Inspector>> inspectors;
+  hipStream_t stream = nullptr;
+  suamd_complex *h_x = nullptr, *d_x = nullptr;
+  float *d_psd = nullptr;
+  size_t block = 0;
+  unsigned navg = 1;
+};
+
+namespace {
+
+void push(suscan_analyzer *a, uint32_t type, void *msg) { suscan_mq_write(a->mq, type, msg); }
+
+void push_status(suscan_analyzer *a, uint32_t type, int code, const std::string &text)
+{
+  auto *m = static_cast<suscan_analyzer_status_msg *>(std::calloc(1, sizeof(suscan_analyzer_status_msg)));
+  m->code = code;
+  m->err_msg = text.empty() ? nullptr : dupstr(text.c_str());
+  push(a, type, m);
+}
+
+suscan_analyzer_inspector_msg *new_insp_msg(suscan_analyzer_inspector_msgkind kind, uint32_t req_id)
+{
+  auto *m = static_cast<suscan_analyzer_inspector_msg *>(std::calloc(1, sizeof(suscan_analyzer_inspector_msg)));
+  m->kind = kind;
+  m->req_id = req_id;
+  m->handle = -1;
+  return m;
+}
+
+unsigned pow2floor(double v) { unsigned d = 1; while ((double)(d * 2) <= v && d < 4096) d *= 2; return d; }
+
+// (re)builds the GPU chain of one inspector from its channel + config
+bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
+{
+  in.free_chain();
+  const double fs = a->source_cfg.samp_rate;
+  const double bw = in.channel.bw > 0 ? in.channel.bw : fs / 4;
+  in.D = pow2floor(fs / (2.0 * bw));
+  in.equiv_fs = fs / in.D;
+  in.fnor = 2.0 * in.channel.fc / fs;                    // channel centre relative to the tuner
+  float taps[255];
+  suamd_lpf_design(taps, 255, bw / fs);                  // cut-off bw/2 in Hz = (bw/fs) of Nyquist
+  const double fn = in.fnor;
+  in.bank = suamd_chanbank_new(a->ctx, 1, &fn, in.D, taps, 255);
+  if (!in.bank) { err = suamd_last_error(); return false; }
+  const size_t need = a->block / in.D + 8;
+  if (need > in.cap) {
+    for (void *p : {(void *)in.d_y, (void *)in.d_a, (void *)in.d_z, (void *)in.d_sym, (void *)in.d_prev, (void *)in.d_count})
+      if (p) (void)hipFree(p);
+    bool ok = hipMalloc((void **)&in.d_y, need * 8) == hipSuccess && hipMalloc((void **)&in.d_a, need * 8) == hipSuccess &&
+              hipMalloc((void **)&in.d_z, need * 8) == hipSuccess && hipMalloc((void **)&in.d_sym, need * 8) == hipSuccess &&
+              hipMalloc((void **)&in.d_prev, 8) == hipSuccess && hipMalloc((void **)&in.d_count, 4) == hipSuccess;
+    if (!ok) { err = "device allocation failed"; return false; }
+    in.cap = need;
+  }
+  (void)hipMemsetAsync(in.d_prev, 0, 8, a->stream);
+  in.first = true;
+  in.quad = false;
+  if (in.cls == "raw") return true;
+  const double baud = cfg_get(in.config, "clock.baud", 0);
+  const double sps = baud > 0 ? in.equiv_fs / baud : 8.0;
+  if (cfg_get(in.config, "agc.enabled", 1) != 0) {
+    struct suamd_agc_params prm;
+    suamd_agc_params_from_tau(&prm, (float)sps);
+    in.agc = suamd_agc_bank_new(a->ctx, 1, &prm);
+    if (!in.agc) { err = suamd_last_error(); return false; }
+  }
+  if (in.cls == "psk") {
+    const int order = (int)cfg_get(in.config, "afc.costas-order", 0);
+    if (order >= 1 && order <= 3) {
+      const double loop_bw = cfg_get(in.config, "afc.loop-bw", 100);
+      in.costas = suamd_costas_bank_new(a->ctx, 1, order, 0.0f, (float)std::fmin(2.0 / sps, 0.95), 3,
+                                        (float)(2.0 * loop_bw / in.equiv_fs));
+      if (!in.costas) { err = suamd_last_error(); return false; }
+    }
+  } else {                                                // fsk
+    in.quad = cfg_get(in.config, "fsk.quad-demod", 1) != 0;
+  }
+  if ((int)cfg_get(in.config, "clock.type", 0) == 1 && baud > 0) {
+    in.clock = suamd_clock_bank_new(a->ctx, 1, (float)cfg_get(in.config, "clock.gain", .2), (float)(baud / in.equiv_fs));
+    if (!in.clock) { err = suamd_last_error(); return false; }
+  }
+  return true;
+}
+
+void emit_samples(suscan_analyzer *a, const Inspector &in, const suamd_complex *d_src, size_t count)
+{
+  if (count == 0) return;
+  auto *m = static_cast<suscan_analyzer_sample_batch_msg *>(std::calloc(1, sizeof(suscan_analyzer_sample_batch_msg)));
+  m->inspector_id = in.inspector_id;
+  m->sample_count = count;
+  m->samples = static_cast<suamd_complex *>(std::malloc(count * sizeof(suamd_complex)));
+  (void)hipMemcpyAsync(m->samples, d_src, count * sizeof(suamd_complex), hipMemcpyDeviceToHost, a->stream);
+  (void)hipStreamSynchronize(a->stream);
+  push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_SAMPLES, m);
+}
+
+void run_inspector(suscan_analyzer *a, Inspector &in, size_t len)
+{
+  if (in.dirty) {
+    std::string err;
+    if (!build_chain(a, in, err)) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, err); return; }
+    in.dirty = false;
+  }
+  const suamd_view row = {(SUSCOUNT)in.cap, 1};
+  SUSCOUNT m = 0;
+  if (!suamd_chanbank_feed(in.bank, a->d_x, len, in.d_y, row, &m, a->stream)) return;
+  const suamd_complex *cur = in.d_y;
+  if (in.agc) { suamd_agc_bank_feed(in.agc, cur, row, in.d_a, row, m, a->stream); cur = in.d_a; }
+  if (in.costas) {
+    suamd_costas_bank_feed(in.costas, cur, row, in.d_z, row, m, a->stream);
+    cur = in.d_z;
+  } else if (in.quad) {
+    suamd_quad_demod_batch(a->ctx, cur, row, in.d_z, row, 1, m, in.d_prev, in.first ? SU_TRUE : SU_FALSE, in.d_sym /*tmp*/,
+                           a->stream);
+    (void)hipMemcpyAsync(in.d_prev, in.d_sym, 8, hipMemcpyDeviceToDevice, a->stream);
+    in.first = false;
+    cur = in.d_z;
+  }
+  if (in.clock) {
+    (void)hipMemsetAsync(in.d_count, 0, 4, a->stream);
+    suamd_clock_bank_feed(in.clock, cur, row, m, in.d_sym, (SUSCOUNT)in.cap, in.d_count, a->stream);
+    uint32_t n = 0;
+    (void)hipMemcpyAsync(&n, in.d_count, 4, hipMemcpyDeviceToHost, a->stream);
+    (void)hipStreamSynchronize(a->stream);
+    emit_samples(a, in, in.d_sym, n);
+  } else {
+    emit_samples(a, in, cur, m);
+  }
+}
+
+void handle_request(suscan_analyzer *a, Request &r)
+{
+  switch (r.kind) {
+    case Request::OPEN: {
+      DescHolder *h = holder_for(r.cls.c_str());
+      if (!h) {
+        auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_WRONG_KIND, r.req_id);
+        push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
+        return;
+      }
+      const double fs = a->source_cfg.samp_rate;
+      if (!(r.channel.bw > 0) || std::fabs(r.channel.fc) > fs / 2 || r.channel.bw > fs) {
+        auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_INVALID_CHANNEL, r.req_id);
+        push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
+        return;
+      }
+      auto in = std::make_unique<Inspector>();
+      in->handle = a->next_handle++;
+      in->cls = r.cls;
+      in->channel = r.channel;
+      in->config = suscan_config_new(&h->desc);
+      std::string err;
+      if (!build_chain(a, *in, err)) {
+        push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, err);
+        in->free_all();
+        return;
+      }
+      in->dirty = false;
+      auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_OPEN, r.req_id);
+      m->handle = in->handle;
+      m->class_name = dupstr(r.cls.c_str());
+      m->channel = r.channel;
+      m->config = suscan_config_dup(in->config);
+      m->fs = (uint32_t)fs;
+      m->equiv_fs = (SUFLOAT)in->equiv_fs;
+      m->bandwidth = (SUFLOAT)r.channel.bw;
+      m->lo = (SUFLOAT)in->fnor;
+      a->inspectors[in->handle] = std::move(in);
+      push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
+      return;
+    }
+    default: break;
+  }
+  auto it = a->inspectors.find(r.handle);
+  if (r.kind != Request::SET_PARAMS && r.kind != Request::SET_THROTTLE && it == a->inspectors.end()) {
+    auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_WRONG_HANDLE, r.req_id);
+    m->handle = r.handle;
+    push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
+    if (r.config) suscan_config_destroy(r.config);
+    return;
+  }
+  switch (r.kind) {
+    case Request::CLOSE: {
+      auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_CLOSE, r.req_id);
+      m->handle = r.handle;
+      m->inspector_id = it->second->inspector_id;
+      it->second->free_all();
+      a->inspectors.erase(it);
+      push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
+      break;
+    }
+    case Request::SET_ID: {
+      it->second->inspector_id = r.inspector_id;
+      auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SET_ID, r.req_id);
+      m->handle = r.handle;
+      m->inspector_id = r.inspector_id;
+      push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
+      break;
+    }
+    case Request::SET_CONFIG: {
+      Inspector &in = *it->second;
+      // copy the values of every field the inspector knows
+      for (unsigned i = 0; r.config && i < r.config->desc->field_count; ++i) {
+        const suscan_field_value *v = r.config->values[i];
+        suscan_field_value *dst = suscan_config_get_value(in.config, v->field->name);
+        if (dst && dst->field->type == v->field->type) { dst->as_int = v->as_int; dst->set = SU_TRUE; }
+      }
+      in.dirty = true;
+      auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SET_CONFIG, r.req_id);
+      m->handle = r.handle;
+      m->inspector_id = in.inspector_id;
+      m->config = suscan_config_dup(in.config);
+      push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
+      if (r.config) suscan_config_destroy(r.config);
+      break;
+    }
+    case Request::SET_WATERMARK: {
+      it->second->watermark = r.value;
+      auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SET_WATERMARK, r.req_id);
+      m->handle = r.handle;
+      m->watermark = r.value;
+      push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
+      break;
+    }
+    case Request::SET_FREQ: it->second->channel.fc = r.fvalue; it->second->dirty = true; break;
+    case Request::SET_BW:   it->second->channel.bw = (SUFLOAT)r.fvalue; it->second->dirty = true; break;
+    case Request::SET_PARAMS: {
+      // only the PSD parameters matter on this path; applied at the next block boundary by the worker
+      a->params = r.params;
+      auto *m = static_cast<suscan_analyzer_params *>(std::malloc(sizeof(suscan_analyzer_params)));
+      *m = a->params;
+      push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_PARAMS, m);
+      break;
+    }
+    case Request::SET_THROTTLE: a->throttle = r.value; break;
+    default: break;
+  }
+}
+
+bool setup_psd(suscan_analyzer *a, std::string &err)
+{
+  if (a->psd) { suamd_psd_destroy(a->psd); a->psd = nullptr; }
+  const unsigned n = (unsigned)a->params.detector_params.window_size;
+  a->psd = suamd_psd_new(a->ctx, n, a->params.detector_params.window);
+  if (!a->psd) { err = suamd_last_error(); return false; }
+  const double per = a->params.psd_update_int > 0 ? a->params.psd_update_int : 0.04;
+  double frames = std::floor(a->source_cfg.samp_rate * per / n + 0.5);
+  if (frames < 1) frames = 1;
+  if (frames > 4096) frames = 4096;
+  a->navg = (unsigned)frames;
+  const size_t block = (size_t)n * a->navg;
+  if (block != a->block) {
+    if (a->h_x) (void)hipHostFree(a->h_x);
+    if (a->d_x) (void)hipFree(a->d_x);
+    if (a->d_psd) (void)hipFree(a->d_psd);
+    a->h_x = nullptr; a->d_x = nullptr; a->d_psd = nullptr;
+    if (hipHostMalloc((void **)&a->h_x, block * sizeof(suamd_complex), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&a->d_x, block * sizeof(suamd_complex)) != hipSuccess ||
+        hipMalloc((void **)&a->d_psd, n * sizeof(float)) != hipSuccess) {
+      err = "allocation of the block buffers failed";
+      return false;
+    }
+    a->block = block;
+    for (auto &kv : a->inspectors) kv.second->dirty = true;      // buffer capacities depend on the block
+  }
+  return true;
+}
+
+void worker_main(suscan_analyzer *a)
+{
+  std::string err;
+  Source src;
+  src.cfg = a->source_cfg;
+  a->ctx = suamd_ctx_new(0);
+  bool ok = a->ctx != nullptr;
+  if (!ok) err = suamd_last_error();
+  if (ok && hipStreamCreate(&a->stream) != hipSuccess) { ok = false; err = "hipStreamCreate failed"; }
+  if (ok) ok = src.open(err);
+  if (ok) ok = setup_psd(a, err);
+  if (!ok) {
+    push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INIT, SUSCAN_ANALYZER_INIT_FAILURE, err);
+    push(a, SUSCAN_WORKER_MSG_TYPE_HALT, nullptr);
+    return;
+  }
+  push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INIT, SUSCAN_ANALYZER_INIT_SUCCESS, "");
+  {
+    auto *si = static_cast<suscan_source_info *>(std::malloc(sizeof(suscan_source_info)));
+    *si = a->info;
+    push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INFO, si);
+  }
+  auto t_prev = std::chrono::steady_clock::now();
+  const auto t_start = t_prev;
+  uint64_t consumed = 0;
+  while (!a->halt) {
+    // ---- requests posted by the GUI thread ----
+    for (;;) {
+      Request r;
+      {
+        std::lock_guard<std::mutex> lk(a->req_m);
+        if (a->requests.empty()) break;
+        r = std::move(a->requests.front());
+        a->requests.pop_front();
+      }
+      const unsigned old_n = (unsigned)a->params.detector_params.window_size;
+      const int old_w = a->params.detector_params.window;
+      const float old_i = a->params.psd_update_int;
+      handle_request(a, r);
+      if (r.kind == Request::SET_PARAMS && (old_n != a->params.detector_params.window_size ||
+                                           old_w != a->params.detector_params.window ||
+                                           old_i != a->params.psd_update_int)) {
+        if (!setup_psd(a, err)) {
+          push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, err);
+          a->halt = true;
+        }
+      }
+    }
+    if (a->halt) break;
+    // ---- one block ----
+    bool looped = false;
+    const size_t got = src.read(a->h_x, a->block, &looped);
+    if (got < a->block) {                                  // a partial last block is dropped, as a
+      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_EOS, 0, "end of stream");   // whole PSD frame set is needed
+      break;
+    }
+    (void)hipMemcpyAsync(a->d_x, a->h_x, a->block * sizeof(suamd_complex), hipMemcpyHostToDevice, a->stream);
+    const unsigned n = (unsigned)a->params.detector_params.window_size;
+    if (!suamd_psd_feed(a->psd, a->d_x, a->navg, n, a->navg, 1.0f / (float)n, SUAMD_PSD_LINEAR, a->d_psd, a->stream)) {
+      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, suamd_last_error());
+      break;
+    }
+    {
+      auto *m = static_cast<suscan_analyzer_psd_msg *>(std::calloc(1, sizeof(suscan_analyzer_psd_msg)));
+      m->psd_size = n;
+      m->psd_data = static_cast<SUFLOAT *>(std::malloc(n * sizeof(SUFLOAT)));
+      (void)hipMemcpyAsync(m->psd_data, a->d_psd, n * sizeof(float), hipMemcpyDeviceToHost, a->stream);
+      (void)hipStreamSynchronize(a->stream);
+      m->fc = (int64_t)a->source_cfg.freq;
+      m->samp_rate = (SUFLOAT)a->source_cfg.samp_rate;
+      m->measured_samp_rate = a->measured_rate;
+      m->looped = looped ? SU_TRUE : SU_FALSE;
+      gettimeofday(&m->rt_time, nullptr);
+      const double ts = (double)consumed / a->source_cfg.samp_rate;
+      m->timestamp.tv_sec = (time_t)ts;
+      m->timestamp.tv_usec = (suseconds_t)((ts - std::floor(ts)) * 1e6);
+      push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_PSD, m);
+    }
+    for (auto &kv : a->inspectors) run_inspector(a, *kv.second, a->block);
+    consumed += a->block;
+    // ---- rate bookkeeping / throttle ----
+    auto now = std::chrono::steady_clock::now();
+    const uint64_t thr = a->throttle;
+    if (thr > 0) {
+      const double due = (double)consumed / (double)thr;
+      const double el = std::chrono::duration<double>(now - t_start).count();
+      if (due > el) std::this_thread::sleep_for(std::chrono::duration<double>(due - el));
+      now = std::chrono::steady_clock::now();
+    }
+    const double dt = std::chrono::duration<double>(now - t_prev).count();
+    t_prev = now;
+    if (dt > 0) {
+      const float inst = (float)((double)a->block / dt);
+      const float prev = a->measured_rate;
+      a->measured_rate = prev == 0.f ? inst : prev + 0.2f * (inst - prev);
+    }
+  }
+  for (auto &kv : a->inspectors) kv.second->free_all();
+  a->inspectors.clear();
+  if (a->psd) suamd_psd_destroy(a->psd);
+  if (a->h_x) (void)hipHostFree(a->h_x);
+  if (a->d_x) (void)hipFree(a->d_x);
+  if (a->d_psd) (void)hipFree(a->d_psd);
+  if (a->stream) (void)hipStreamDestroy(a->stream);
+  if (a->ctx) suamd_ctx_destroy(a->ctx);
+  a->psd = nullptr; a->h_x = nullptr; a->d_x = nullptr; a->d_psd = nullptr; a->stream = nullptr; a->ctx = nullptr;
+  push(a, SUSCAN_WORKER_MSG_TYPE_HALT, nullptr);
+}
+
+SUBOOL post(suscan_analyzer *a, Request &&r)
+{
+  if (!a) return SU_FALSE;
+  std::lock_guard<std::mutex> lk(a->req_m);
+  a->requests.push_back(std::move(r));
+  return SU_TRUE;
+}
+
+}  // namespace
+
+// ==========================================================================================
+extern "C" {
+
+SUBOOL suscan_mq_init(struct suscan_mq *mq)
+{
+  if (!mq) return SU_FALSE;
+  mq->impl = new (std::nothrow) MQImpl;
+  return mq->impl ? SU_TRUE : SU_FALSE;
+}
+
+void suscan_mq_finalize(struct suscan_mq *mq)
+{
+  if (!mq || !mq->impl) return;
+  MQImpl *q = impl(mq);
+  for (auto &e : q->q) suscan_analyzer_dispose_message(e.first, e.second);
+  delete q;
+  mq->impl = nullptr;
+}
+
+void *suscan_mq_read(struct suscan_mq *mq, uint32_t *type)
+{
+  MQImpl *q = impl(mq);
+  std::unique_lock<std::mutex> lk(q->m);
+  q->cv.wait(lk, [&] { return !q->q.empty(); });
+  auto e = q->q.front();
+  q->q.pop_front();
+  if (type) *type = e.first;
+  return e.second;
+}
+
+SUBOOL suscan_mq_poll(struct suscan_mq *mq, uint32_t *type, void **msg)
+{
+  MQImpl *q = impl(mq);
+  std::lock_guard<std::mutex> lk(q->m);
+  if (q->q.empty()) return SU_FALSE;
+  auto e = q->q.front();
+  q->q.pop_front();
+  if (type) *type = e.first;
+  if (msg) *msg = e.second;
+  return SU_TRUE;
+}
+
+SUBOOL suscan_mq_write(struct suscan_mq *mq, uint32_t type, void *msg)
+{
+  MQImpl *q = impl(mq);
+  {
+    std::lock_guard<std::mutex> lk(q->m);
+    q->q.emplace_back(type, msg);
+  }
+  q->cv.notify_one();
+  return SU_TRUE;
+}
+
+// ---- source config ----
+suscan_source_config_t *suscan_source_config_new(const char *type, enum suscan_source_format fmt)
+{
+  auto *c = new (std::nothrow) suscan_source_config;
+  if (!c) return nullptr;
+  c->type = type ? type : "file";
+  c->format = fmt;
+  return c;
+}
+void suscan_source_config_destroy(suscan_source_config_t *c) { delete c; }
+void suscan_source_config_set_samp_rate(suscan_source_config_t *c, unsigned int r) { if (c) c->samp_rate = r; }
+void suscan_source_config_set_freq(suscan_source_config_t *c, SUFREQ f) { if (c) c->freq = f; }
+SUBOOL suscan_source_config_set_path(suscan_source_config_t *c, const char *p)
+{
+  if (!c || !p) return SU_FALSE;
+  c->path = p;
+  return SU_TRUE;
+}
+void suscan_source_config_set_loop(suscan_source_config_t *c, SUBOOL l) { if (c) c->loop = l != 0; }
+SUBOOL suscan_source_config_set_param(suscan_source_config_t *c, const char *k, const char *v)
+{
+  if (!c || !k || !v) return SU_FALSE;
+  c->params[k] = v;
+  return SU_TRUE;
+}
+
+// ---- config ----
+const suscan_config_desc_t *suscan_inspector_config_desc(const char *cls)
+{
+  DescHolder *h = holder_for(cls);
+  return h ? &h->desc : nullptr;
+}
+
+suscan_config_t *suscan_config_new(const suscan_config_desc_t *desc)
+{
+  if (!desc) return nullptr;
+  auto *c = static_cast<suscan_config_t *>(std::calloc(1, sizeof(suscan_config_t)));
+  c->desc = desc;
+  c->values = static_cast<suscan_field_value **>(std::calloc(desc->field_count ? desc->field_count : 1, sizeof(void *)));
+  DescHolder *h = holder_for(desc->global_name);
+  for (unsigned i = 0; i < desc->field_count; ++i) {
+    auto *v = static_cast<suscan_field_value *>(std::calloc(1, sizeof(suscan_field_value)));
+    v->field = desc->field_list[i];
+    const double d = h ? h->defaults[i] : 0;
+    switch (v->field->type) {
+      case SUSCAN_FIELD_TYPE_INTEGER: v->as_int = (uint64_t)d; break;
+      case SUSCAN_FIELD_TYPE_BOOLEAN: v->as_bool = d != 0; break;
+      case SUSCAN_FIELD_TYPE_FLOAT:   v->as_float = (SUFLOAT)d; break;
+      default: break;
+    }
+    c->values[i] = v;
+  }
+  return c;
+}
+
+suscan_config_t *suscan_config_dup(const suscan_config_t *cfg)
+{
+  if (!cfg) return nullptr;
+  suscan_config_t *c = suscan_config_new(cfg->desc);
+  for (unsigned i = 0; c && i < cfg->desc->field_count; ++i) {
+    c->values[i]->set = cfg->values[i]->set;
+    c->values[i]->as_int = cfg->values[i]->as_int;
+  }
+  return c;
+}
+
+void suscan_config_destroy(suscan_config_t *cfg)
+{
+  if (!cfg) return;
+  for (unsigned i = 0; i < cfg->desc->field_count; ++i) {
+    if (cfg->values[i]) { std::free(cfg->values[i]->as_string); std::free(cfg->values[i]); }
+  }
+  std::free(cfg->values);
+  std::free(cfg);
+}
+
+struct suscan_field_value *suscan_config_get_value(const suscan_config_t *cfg, const char *name)
+{
+  if (!cfg || !name) return nullptr;
+  for (unsigned i = 0; i < cfg->desc->field_count; ++i)
+    if (!std::strcmp(cfg->desc->field_list[i]->name, name)) return cfg->values[i];
+  return nullptr;
+}
+
+SUBOOL suscan_config_set_integer(suscan_config_t *cfg, const char *name, uint64_t v)
+{
+  auto *f = suscan_config_get_value(cfg, name);
+  if (!f || f->field->type != SUSCAN_FIELD_TYPE_INTEGER) return SU_FALSE;
+  f->as_int = v; f->set = SU_TRUE;
+  return SU_TRUE;
+}
+SUBOOL suscan_config_set_float(suscan_config_t *cfg, const char *name, SUFLOAT v)
+{
+  auto *f = suscan_config_get_value(cfg, name);
+  if (!f || f->field->type != SUSCAN_FIELD_TYPE_FLOAT) return SU_FALSE;
+  f->as_int = 0; f->as_float = v; f->set = SU_TRUE;
+  return SU_TRUE;
+}
+SUBOOL suscan_config_set_bool(suscan_config_t *cfg, const char *name, SUBOOL v)
+{
+  auto *f = suscan_config_get_value(cfg, name);
+  if (!f || f->field->type != SUSCAN_FIELD_TYPE_BOOLEAN) return SU_FALSE;
+  f->as_int = 0; f->as_bool = v ? SU_TRUE : SU_FALSE; f->set = SU_TRUE;
+  return SU_TRUE;
+}
+
+// ---- analyzer ----
+suscan_analyzer_t *suscan_analyzer_new(const struct suscan_analyzer_params *params, suscan_source_config_t *config,
+                                       struct suscan_mq *mq)
+{
+  if (!params || !config || !mq || !mq->impl) return nullptr;
+  auto *a = new (std::nothrow) suscan_analyzer;
+  if (!a) return nullptr;
+  a->params = *params;
+  a->source_cfg = *config;
+  a->mq = mq;
+  a->info.source_samp_rate = a->info.effective_samp_rate = config->samp_rate;
+  a->info.frequency = config->freq;
+  a->info.freq_min = -3e11; a->info.freq_max = 3e11;
+  a->info.bandwidth = (SUFLOAT)config->samp_rate;
+  a->info.seekable = config->type == "file" ? SU_TRUE : SU_FALSE;
+  a->worker = std::thread(worker_main, a);
+  return a;
+}
+
+void suscan_analyzer_destroy(suscan_analyzer_t *a)
+{
+  if (!a) return;
+  a->halt = true;
+  if (a->worker.joinable()) a->worker.join();
+  for (auto &r : a->requests) if (r.config) suscan_config_destroy(r.config);
+  delete a;
+}
+
+void *suscan_analyzer_read(suscan_analyzer_t *a, uint32_t *type) { return a ? suscan_mq_read(a->mq, type) : nullptr; }
+
+void suscan_analyzer_dispose_message(uint32_t type, void *ptr)
+{
+  if (!ptr) return;
+  switch (type) {
+    case SUSCAN_ANALYZER_MESSAGE_TYPE_PSD:
+      std::free(static_cast<suscan_analyzer_psd_msg *>(ptr)->psd_data);
+      break;
+    case SUSCAN_ANALYZER_MESSAGE_TYPE_SAMPLES:
+      std::free(static_cast<suscan_analyzer_sample_batch_msg *>(ptr)->samples);
+      break;
+    case SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR: {
+      auto *m = static_cast<suscan_analyzer_inspector_msg *>(ptr);
+      std::free(m->class_name);
+      if (m->config) suscan_config_destroy(m->config);
+      std::free(m->spectrum_data);
+      break;
+    }
+    case SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INIT:
+    case SUSCAN_ANALYZER_MESSAGE_TYPE_EOS:
+    case SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR:
+    case SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL:
+      std::free(static_cast<suscan_analyzer_status_msg *>(ptr)->err_msg);
+      break;
+    default: break;
+  }
+  std::free(ptr);
+}
+
+void suscan_analyzer_req_halt(suscan_analyzer_t *a) { if (a) a->halt = true; }
+
+SUBOOL suscan_analyzer_set_params_async(suscan_analyzer_t *a, const struct suscan_analyzer_params *p, uint32_t req)
+{
+  if (!p) return SU_FALSE;
+  Request r; r.kind = Request::SET_PARAMS; r.req_id = req; r.params = *p;
+  return post(a, std::move(r));
+}
+
+SUBOOL suscan_analyzer_set_throttle_async(suscan_analyzer_t *a, SUSCOUNT rate, uint32_t req)
+{
+  Request r; r.kind = Request::SET_THROTTLE; r.req_id = req; r.value = rate;
+  return post(a, std::move(r));
+}
+
+unsigned int suscan_analyzer_get_samp_rate(const suscan_analyzer_t *a) { return a ? a->source_cfg.samp_rate : 0; }
+SUFLOAT suscan_analyzer_get_measured_samp_rate(const suscan_analyzer_t *a) { return a ? (SUFLOAT)a->measured_rate : 0; }
+struct suscan_source_info *suscan_analyzer_get_source_info(const suscan_analyzer_t *a)
+{
+  return a ? const_cast<suscan_source_info *>(&a->info) : nullptr;
+}
+
+SUBOOL suscan_analyzer_open_ex_async(suscan_analyzer_t *a, const char *cls, const struct sigutils_channel *ch,
+                                     SUBOOL, SUHANDLE, uint32_t req)
+{
+  if (!cls || !ch) return SU_FALSE;
+  Request r; r.kind = Request::OPEN; r.req_id = req; r.cls = cls; r.channel = *ch;
+  return post(a, std::move(r));
+}
+
+SUBOOL suscan_analyzer_open_async(suscan_analyzer_t *a, const char *cls, const struct sigutils_channel *ch, uint32_t req)
+{
+  return suscan_analyzer_open_ex_async(a, cls, ch, SU_FALSE, -1, req);
+}
+
+SUBOOL suscan_analyzer_close_async(suscan_analyzer_t *a, SUHANDLE h, uint32_t req)
+{
+  Request r; r.kind = Request::CLOSE; r.req_id = req; r.handle = h;
+  return post(a, std::move(r));
+}
+
+SUBOOL suscan_analyzer_set_inspector_id_async(suscan_analyzer_t *a, SUHANDLE h, uint32_t id, uint32_t req)
+{
+  Request r; r.kind = Request::SET_ID; r.req_id = req; r.handle = h; r.inspector_id = id;
+  return post(a, std::move(r));
+}
+
+SUBOOL suscan_analyzer_set_inspector_config_async(suscan_analyzer_t *a, SUHANDLE h, const suscan_config_t *cfg, uint32_t req)
+{
+  if (!cfg) return SU_FALSE;
+  Request r; r.kind = Request::SET_CONFIG; r.req_id = req; r.handle = h; r.config = suscan_config_dup(cfg);
+  return post(a, std::move(r));
+}
+
+SUBOOL suscan_analyzer_set_inspector_watermark_async(suscan_analyzer_t *a, SUHANDLE h, SUSCOUNT wm, uint32_t req)
+{
+  Request r; r.kind = Request::SET_WATERMARK; r.req_id = req; r.handle = h; r.value = wm;
+  return post(a, std::move(r));
+}
+
+SUBOOL suscan_analyzer_set_inspector_freq_overridable(suscan_analyzer_t *a, SUHANDLE h, SUFREQ f)
+{
+  Request r; r.kind = Request::SET_FREQ; r.handle = h; r.fvalue = f;
+  return post(a, std::move(r));
+}
+
+SUBOOL suscan_analyzer_set_inspector_bandwidth_overridable(suscan_analyzer_t *a, SUHANDLE h, SUFREQ bw)
+{
+  Request r; r.kind = Request::SET_BW; r.handle = h; r.fvalue = bw;
+  return post(a, std::move(r));
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+"""ctypes binding of the live-path ABI (include/suscan_amd.h): what SigDigger's Suscan::Analyzer
+wrapper (Suscan/Analyzer.cpp) does, for Python callers and the tests.  Plumbing only."""
+import ctypes as C
+
+from . import lib as _l
+
+MSG_SOURCE_INFO, MSG_SOURCE_INIT, MSG_CHANNEL, MSG_EOS, MSG_READ_ERROR, MSG_INTERNAL = 0, 1, 2, 3, 4, 5
+MSG_INSPECTOR, MSG_PSD, MSG_SAMPLES, MSG_PARAMS = 7, 8, 9, 0xB
+MSG_HALT = 0xFFFFFFFF
+KIND_OPEN, KIND_SET_ID, KIND_GET_CONFIG, KIND_SET_CONFIG = 0, 1, 2, 3
+KIND_CLOSE, KIND_SET_WATERMARK, KIND_WRONG_HANDLE, KIND_WRONG_KIND, KIND_INVALID_CHANNEL = 7, 10, 11, 14, 15
+
+
+class Timeval(C.Structure):
+    _fields_ = [("tv_sec", C.c_long), ("tv_usec", C.c_long)]
+
+
+class MQ(C.Structure):
+    _fields_ = [("impl", C.c_void_p)]
+
+
+class DetectorParams(C.Structure):
+    _fields_ = [("alpha", C.c_float), ("beta", C.c_float), ("gamma", C.c_float), ("snr", C.c_float),
+                ("window_size", C.c_uint64), ("window", C.c_int)]
+
+
+class AnalyzerParams(C.Structure):
+    _fields_ = [("mode", C.c_int), ("detector_params", DetectorParams), ("channel_update_int", C.c_float),
+                ("psd_update_int", C.c_float), ("min_freq", C.c_double), ("max_freq", C.c_double)]
+
+    @classmethod
+    def default(cls):
+        return cls(0, DetectorParams(1e-2, 1e-3, .5, 2., 4096, 4), .1, .04, -1, -1)
+
+
+class Channel(C.Structure):
+    """struct sigutils_channel"""
+    _fields_ = [("fc", C.c_double), ("f_lo", C.c_double), ("f_hi", C.c_double), ("bw", C.c_float),
+                ("snr", C.c_float), ("S0", C.c_float), ("N0", C.c_float), ("ft", C.c_double),
+                ("age", C.c_uint32), ("present", C.c_uint32)]
+
+
+class PSDMsg(C.Structure):
+    _fields_ = [("fc", C.c_int64), ("inspector_id", C.c_uint32), ("timestamp", Timeval), ("rt_time", Timeval),
+                ("looped", C.c_int), ("history_size", C.c_uint64), ("samp_rate", C.c_float),
+                ("measured_samp_rate", C.c_float), ("N0", C.c_float), ("psd_size", C.c_uint64),
+                ("psd_data", C.POINTER(C.c_float))]
+
+
+class SampleBatchMsg(C.Structure):
+    _fields_ = [("inspector_id", C.c_uint32), ("samples", C.POINTER(C.c_float)), ("sample_count", C.c_uint64)]
+
+
+class InspectorMsg(C.Structure):
+    _fields_ = [("kind", C.c_int), ("inspector_id", C.c_uint32), ("req_id", C.c_uint32), ("handle", C.c_int32),
+                ("status", C.c_int), ("class_name", C.c_char_p), ("channel", Channel), ("config", C.c_void_p),
+                ("precise", C.c_int), ("fs", C.c_uint32), ("equiv_fs", C.c_float), ("bandwidth", C.c_float),
+                ("lo", C.c_float), ("spectsrc_count", C.c_uint), ("spectsrc_list", C.c_void_p),
+                ("estimator_count", C.c_uint), ("estimator_list", C.c_void_p), ("spectsrc_id", C.c_uint32),
+                ("estimator_id", C.c_uint32), ("spectrum_data", C.c_void_p), ("spectrum_size", C.c_uint64),
+                ("samp_rate", C.c_uint64), ("watermark", C.c_uint64)]
+
+
+class StatusMsg(C.Structure):
+    _fields_ = [("code", C.c_int), ("err_msg", C.c_char_p)]
+
+
+VP, U32, U64, INT = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+PROTOTYPES = {
+    "suscan_mq_init": (INT, [C.POINTER(MQ)]),
+    "suscan_mq_finalize": (None, [C.POINTER(MQ)]),
+    "suscan_mq_read": (VP, [C.POINTER(MQ), C.POINTER(U32)]),
+    "suscan_mq_poll": (INT, [C.POINTER(MQ), C.POINTER(U32), C.POINTER(VP)]),
+    "suscan_mq_write": (INT, [C.POINTER(MQ), U32, VP]),
+    "suscan_source_config_new": (VP, [C.c_char_p, INT]),
+    "suscan_source_config_destroy": (None, [VP]),
+    "suscan_source_config_set_samp_rate": (None, [VP, C.c_uint]),
+    "suscan_source_config_set_freq": (None, [VP, C.c_double]),
+    "suscan_source_config_set_path": (INT, [VP, C.c_char_p]),
+    "suscan_source_config_set_loop": (None, [VP, INT]),
+    "suscan_source_config_set_param": (INT, [VP, C.c_char_p, C.c_char_p]),
+    "suscan_inspector_config_desc": (VP, [C.c_char_p]),
+    "suscan_config_new": (VP, [VP]),
+    "suscan_config_dup": (VP, [VP]),
+    "suscan_config_destroy": (None, [VP]),
+    "suscan_config_get_value": (VP, [VP, C.c_char_p]),
+    "suscan_config_set_integer": (INT, [VP, C.c_char_p, U64]),
+    "suscan_config_set_float": (INT, [VP, C.c_char_p, C.c_float]),
+    "suscan_config_set_bool": (INT, [VP, C.c_char_p, INT]),
+    "suscan_analyzer_new": (VP, [C.POINTER(AnalyzerParams), VP, C.POINTER(MQ)]),
+    "suscan_analyzer_destroy": (None, [VP]),
+    "suscan_analyzer_read": (VP, [VP, C.POINTER(U32)]),
+    "suscan_analyzer_dispose_message": (None, [U32, VP]),
+    "suscan_analyzer_req_halt": (None, [VP]),
+    "suscan_analyzer_set_params_async": (INT, [VP, C.POINTER(AnalyzerParams), U32]),
+    "suscan_analyzer_set_throttle_async": (INT, [VP, U64, U32]),
+    "suscan_analyzer_get_samp_rate": (C.c_uint, [VP]),
+    "suscan_analyzer_get_measured_samp_rate": (C.c_float, [VP]),
+    "suscan_analyzer_get_source_info": (VP, [VP]),
+    "suscan_analyzer_open_async": (INT, [VP, C.c_char_p, C.POINTER(Channel), U32]),
+    "suscan_analyzer_open_ex_async": (INT, [VP, C.c_char_p, C.POINTER(Channel), INT, C.c_int32, U32]),
+    "suscan_analyzer_close_async": (INT, [VP, C.c_int32, U32]),
+    "suscan_analyzer_set_inspector_id_async": (INT, [VP, C.c_int32, U32, U32]),
+    "suscan_analyzer_set_inspector_config_async": (INT, [VP, C.c_int32, VP, U32]),
+    "suscan_analyzer_set_inspector_watermark_async": (INT, [VP, C.c_int32, U64, U32]),
+    "suscan_analyzer_set_inspector_freq_overridable": (INT, [VP, C.c_int32, C.c_double]),
+    "suscan_analyzer_set_inspector_bandwidth_overridable": (INT, [VP, C.c_int32, C.c_double]),
+}
+
+_bound = None
+
+
+def load():
+    global _bound
+    if _bound is None:
+        L = _l.load()
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _bound = L
+    return _bound

@@ -9,12 +9,13 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "sigdigger_amd.h")
+SUSCAN_HEADER = os.path.join(ROOT, "include", "suscan_amd.h")
 
 
-def declared_symbols():
-    src = open(HEADER).read()
+def declared_symbols(header=HEADER, prefix="suamd_"):
+    src = open(header).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"SUAMD_API[^;(]*?\b(suamd_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"SUAMD_API[^;(]*?\b(" + prefix + r"\w+)\s*\(", src)))
 
 
 def test_header_declares_the_expected_surface():
@@ -34,6 +35,56 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     # the ctypes prototype table covers the header one to one
     assert sorted(lib.PROTOTYPES) == declared_symbols()
     lib.load()
+
+
+def test_live_path_abi_exports_and_headers_are_valid_c(tmp_path):
+    """include/suscan_amd.h: every declared suscan_* symbol is exported, the ctypes table mirrors it,
+    and both headers compile as plain C (the reference binds them from C/C++)."""
+    import subprocess
+    from sigdigger_amd import build, lib, suscan
+    build.build()
+    so = ctypes.CDLL(lib.SO_PATH)
+    syms = declared_symbols(SUSCAN_HEADER, "suscan_")
+    assert len(syms) >= 35
+    missing = [s for s in syms if not hasattr(so, s)]
+    assert not missing, f"declared in suscan_amd.h but not exported: {missing}"
+    assert sorted(suscan.PROTOTYPES) == syms
+    src = tmp_path / "t.c"
+    src.write_text('#include "suscan_amd.h"\n'
+                   'int main(void) { struct suscan_analyzer_params p = suscan_analyzer_params_INITIALIZER;\n'
+                   '  struct sigutils_channel c = sigutils_channel_INITIALIZER; struct suamd_agc_params a = '
+                   'suamd_agc_params_INITIALIZER;\n  return (int)p.detector_params.window_size + (int)c.bw + '
+                   '(int)a.hang_max == 0; }\n')
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                        str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_message_queue_and_config_without_a_gpu():
+    """the queue and the inspector config vocabulary are host code (Suscan/MQ.cpp, Suscan/Config.cpp)"""
+    from sigdigger_amd import suscan
+    L = suscan.load()
+    mq = suscan.MQ()
+    assert L.suscan_mq_init(ctypes.byref(mq))
+    t = ctypes.c_uint32(0)
+    p = ctypes.c_void_p(0)
+    assert not L.suscan_mq_poll(ctypes.byref(mq), ctypes.byref(t), ctypes.byref(p))
+    L.suscan_mq_write(ctypes.byref(mq), suscan.MSG_HALT, None)
+    assert L.suscan_mq_poll(ctypes.byref(mq), ctypes.byref(t), ctypes.byref(p)) and t.value == suscan.MSG_HALT
+    L.suscan_mq_finalize(ctypes.byref(mq))
+    desc = L.suscan_inspector_config_desc(b"psk")
+    assert desc and L.suscan_inspector_config_desc(b"fsk") and not L.suscan_inspector_config_desc(b"audio")
+    cfg = L.suscan_config_new(desc)
+    # key vocabulary of Default/GenericInspector/InspectorCtl/{Afc,Clock,Gain}Control.cpp
+    assert L.suscan_config_set_integer(cfg, b"afc.costas-order", 2)
+    assert L.suscan_config_set_float(cfg, b"clock.baud", 250e3)
+    assert L.suscan_config_set_bool(cfg, b"agc.enabled", 1)
+    assert not L.suscan_config_set_float(cfg, b"afc.costas-order", 1.0)      # wrong type
+    assert not L.suscan_config_set_integer(cfg, b"no.such.key", 1)
+    dup = L.suscan_config_dup(cfg)
+    assert L.suscan_config_get_value(dup, b"clock.baud")
+    L.suscan_config_destroy(dup)
+    L.suscan_config_destroy(cfg)
 
 
 def test_no_cpu_fallback_without_a_gpu():

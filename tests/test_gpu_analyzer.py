@@ -1,0 +1,190 @@
+"""Live path through the suscan_analyzer_* C ABI (include/suscan_amd.h), driven the way
+Suscan::Analyzer::AsyncThread::run does (Suscan/Analyzer.cpp:63-103): new -> read loop ->
+dispose; inspector open / set-id / set-config protocol of AnalyzerRequestTracker
+(Suscan/AnalyzerRequestTracker.cpp:70-183).  PSD frames and recovered symbols are checked
+against the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from sigdigger_amd import suscan, synth
+
+pytestmark = pytest.mark.gpu
+
+FS = 1_000_000
+N = 4096
+NAVG = 16                       # psd_update_int = N*NAVG/FS
+L = N * NAVG
+
+
+def _start(path, L_, loop=False, params=None):
+    Lb = suscan.load()
+    mq = suscan.MQ()
+    assert Lb.suscan_mq_init(C.byref(mq))
+    cfg = Lb.suscan_source_config_new(b"file", 1)
+    Lb.suscan_source_config_set_samp_rate(cfg, FS)
+    Lb.suscan_source_config_set_freq(cfg, 433.92e6)
+    assert Lb.suscan_source_config_set_path(cfg, str(path).encode())
+    Lb.suscan_source_config_set_loop(cfg, int(loop))
+    p = params or suscan.AnalyzerParams.default()
+    p.detector_params.window_size = N
+    p.detector_params.window = 4
+    p.psd_update_int = L_ / FS
+    an = Lb.suscan_analyzer_new(C.byref(p), cfg, C.byref(mq))
+    assert an
+    Lb.suscan_source_config_destroy(cfg)          # the analyzer keeps its own copy
+    return Lb, mq, an
+
+
+def _pump(Lb, an, on_msg, limit=10000):
+    """AsyncThread::run: read until HALT / EOS; every message disposed exactly once."""
+    seen = []
+    for _ in range(limit):
+        t = C.c_uint32(0)
+        ptr = Lb.suscan_analyzer_read(an, C.byref(t))
+        seen.append(t.value)
+        if t.value == suscan.MSG_HALT:
+            break
+        on_msg(t.value, ptr)
+        Lb.suscan_analyzer_dispose_message(t.value, ptr)
+    return seen
+
+
+def test_psd_stream_matches_oracle_and_eos(tmp_path, sdo):
+    nblocks = 5
+    x = synth.psk_carriers(L * nblocks + 1000, [0.2, -0.31], sps=16, seed=3)     # ragged tail is dropped
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    Lb, mq, an = _start(path, L)
+    frames, info = [], {}
+
+    def on_msg(t, ptr):
+        if t == suscan.MSG_SOURCE_INIT:
+            info["init"] = C.cast(ptr, C.POINTER(suscan.StatusMsg)).contents.code
+        elif t == suscan.MSG_PSD:
+            m = C.cast(ptr, C.POINTER(suscan.PSDMsg)).contents
+            assert m.psd_size == N and m.samp_rate == FS and m.fc == 433920000
+            frames.append(np.ctypeslib.as_array(m.psd_data, shape=(N,)).copy())
+            info.setdefault("ts", []).append(m.timestamp.tv_sec + 1e-6 * m.timestamp.tv_usec)
+        elif t == suscan.MSG_EOS:
+            info["eos"] = True
+
+    seen = _pump(Lb, an, on_msg)
+    assert info["init"] == 0 and info.get("eos") and seen[-1] == suscan.MSG_HALT
+    assert seen.count(suscan.MSG_PSD) == nblocks
+    assert Lb.suscan_analyzer_get_samp_rate(an) == FS
+    win = sdo.window(4, N)
+    ref = sdo.psd_frames(x, nblocks * NAVG, N, N, win, navg=NAVG, scale=1.0 / N)
+    got = np.stack(frames)
+    err = np.max(np.abs(got - ref), axis=1) / np.max(ref, axis=1)
+    assert np.all(err < 1e-5), err
+    assert np.allclose(info["ts"], np.arange(nblocks) * L / FS, atol=1e-5)          # signal time stamps
+    # what the consumer does next (PSDMessage ctor, in place on the message buffer)
+    assert np.argmax(sdo.psd_shift_db(got[0])) == np.argmax(sdo.psd_shift_db(ref[0]))
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+
+
+def test_psk_inspector_protocol_and_symbols(tmp_path, sdo):
+    nblocks = 12
+    fc, baud, bw = 125e3, 15625.0, 40e3
+    x = synth.psk_carriers(L * nblocks, [2 * fc / FS], sps=int(FS / baud), order=4, seed=8, snr_db=25)
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    Lb, mq, an = _start(path, L)
+    Lb.suscan_analyzer_set_throttle_async(an, 4 * FS, 0)     # leave time for the requests to land early
+    ch = suscan.Channel(fc=fc, f_lo=fc - bw / 2, f_hi=fc + bw / 2, bw=bw, ft=433.92e6)
+    assert Lb.suscan_analyzer_open_ex_async(an, b"psk", C.byref(ch), 1, -1, 77)
+    assert Lb.suscan_analyzer_open_async(an, b"audio", C.byref(ch), 78)          # unsupported class
+    bad = suscan.Channel(fc=0.0, bw=0.0)
+    assert Lb.suscan_analyzer_open_async(an, b"psk", C.byref(bad), 79)
+    assert Lb.suscan_analyzer_close_async(an, 1234, 80)                          # unknown handle
+    st = {"psd": 0, "samples": [], "kinds": {}, "cfg_at": None}
+
+    def on_msg(t, ptr):
+        if t == suscan.MSG_PSD:
+            st["psd"] += 1
+        elif t == suscan.MSG_INSPECTOR:
+            m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
+            st["kinds"][m.req_id] = m.kind
+            if m.kind == suscan.KIND_OPEN:
+                assert m.class_name == b"psk" and m.fs == FS and m.config
+                st["handle"], st["equiv_fs"] = m.handle, m.equiv_fs
+                # AnalyzerRequestTracker: OPEN -> set id (:150) ; then the tab pushes its config
+                assert Lb.suscan_analyzer_set_inspector_id_async(an, m.handle, 4242, 81)
+                cfg = Lb.suscan_config_dup(m.config)
+                Lb.suscan_config_set_integer(cfg, b"afc.costas-order", 2)
+                Lb.suscan_config_set_float(cfg, b"afc.loop-bw", 40.0)
+                Lb.suscan_config_set_integer(cfg, b"clock.type", 1)
+                Lb.suscan_config_set_float(cfg, b"clock.baud", baud)
+                Lb.suscan_config_set_float(cfg, b"clock.gain", 0.2)
+                assert Lb.suscan_analyzer_set_inspector_config_async(an, m.handle, cfg, 82)
+                Lb.suscan_config_destroy(cfg)
+            elif m.kind == suscan.KIND_SET_CONFIG:
+                st["cfg_at"] = st["psd"]                    # blocks fully processed before the new chain
+                st["samples"] = []
+        elif t == suscan.MSG_SAMPLES:
+            m = C.cast(ptr, C.POINTER(suscan.SampleBatchMsg)).contents
+            if st["cfg_at"] is not None:
+                assert m.inspector_id == 4242
+                a = np.ctypeslib.as_array(m.samples, shape=(m.sample_count * 2,)).copy()
+                st["samples"].append(a.view(np.complex64))
+
+    _pump(Lb, an, on_msg)
+    k = st["kinds"]
+    assert k[77] == suscan.KIND_OPEN and k[78] == suscan.KIND_WRONG_KIND
+    assert k[79] == suscan.KIND_INVALID_CHANNEL and k[80] == suscan.KIND_WRONG_HANDLE
+    assert k[81] == suscan.KIND_SET_ID and k[82] == suscan.KIND_SET_CONFIG
+    b0 = st["cfg_at"]
+    assert b0 is not None and b0 < nblocks - 4, "the configuration landed too late to test anything"
+    # oracle: the rebuilt chain starts fresh at block b0
+    D = 8                                               # pow2floor(fs / (2 bw)) = pow2floor(12.5)
+    assert abs(st["equiv_fs"] - FS / D) < 1e-3
+    taps = sdo.lpf_design(255, bw / FS)
+    dp = sdo.fnor_to_dphase(-2 * fc / FS)
+    xs = x[b0 * L:]
+    y = sdo.chan_feed(np.zeros(254, np.complex64), xs, 0, sdo.chan_modulate_taps(taps, dp), D, 0, dp)
+    sps = (FS / D) / baud
+    a = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(sps)), y)
+    z = sdo.costas_feed_bulk(sdo.costas_new(2, 0.0, min(2.0 / sps, 0.95), 3, 2 * 40.0 / (FS / D)), a)
+    ref = sdo.clock_feed_bulk(sdo.clock_new(0.2, baud / (FS / D)), z)
+    got = np.concatenate(st["samples"])
+    assert len(got) == len(ref), "symbol count"
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "symbols differ from the oracle"
+    tail = got[len(got) // 2:]
+    assert abs(np.mean((tail / np.abs(tail)) ** 4)) > 0.7          # a locked QPSK constellation
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+
+
+def test_halt_wakes_the_reader_and_bad_source_reports_failure(tmp_path):
+    x = synth.tone_noise(L * 2, seed=1)
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    Lb, mq, an = _start(path, L, loop=True)                  # endless source
+    n = {"psd": 0}
+
+    def on_msg(t, ptr):
+        if t == suscan.MSG_PSD:
+            n["psd"] += 1
+            if n["psd"] == 3:
+                Lb.suscan_analyzer_req_halt(an)              # Analyzer::halt (Suscan/Analyzer.cpp:318-322)
+
+    seen = _pump(Lb, an, on_msg)
+    assert seen[-1] == suscan.MSG_HALT and n["psd"] >= 3
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+    # missing file: SOURCE_INIT failure with a message, then HALT (App/Application.cpp:526-538)
+    Lb, mq, an = _start(tmp_path / "nope.raw", L)
+    got = {}
+
+    def on_msg2(t, ptr):
+        if t == suscan.MSG_SOURCE_INIT:
+            m = C.cast(ptr, C.POINTER(suscan.StatusMsg)).contents
+            got["code"], got["msg"] = m.code, m.err_msg
+
+    seen = _pump(Lb, an, on_msg2)
+    assert got["code"] == -1 and b"nope.raw" in got["msg"] and seen[-1] == suscan.MSG_HALT
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
