@@ -147,18 +147,18 @@ def run_workload(name, args, rank, world, dev, ctx, dist):
     def one_step(k, timed):
         cur = bufs[k & 1]
         # rank 0's next block -> every GPU over xGMI, overlapped with this step's compute
-        work = pipeline.broadcast_block(bufs[(k + 1) & 1], dist) if world > 1 else None
+        work = pipeline.broadcast_block(bufs[(k + 1) & 1], dist)
         pipe.step(cur, timed=timed)
         if work is not None:
             work.wait()
 
     def fence():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if world > 1:
-        dist.broadcast(bufs[0], src=0)
+    if dist is not None:
+        pipeline.broadcast_block(bufs[0], dist, async_op=False)
     for k in range(args.warmup):
         one_step(k, False)
     fence()
@@ -168,7 +168,7 @@ def run_workload(name, args, rank, world, dev, ctx, dist):
         one_step(k, True)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -188,6 +188,7 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=1 << 23)
     args = ap.parse_args()
 
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ       # under torch.distributed.run
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -196,10 +197,11 @@ def main():
     dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
     ctx = engine.Context(local_rank)
 
     cfg, L, dt, stages, fn_rank, pipe = run_workload(args.workload, args, rank, world, dev, ctx, dist)
@@ -269,7 +271,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_samples, fn_rank, os.cpu_count() or 1)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

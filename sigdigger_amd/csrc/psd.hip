@@ -12,16 +12,23 @@
 // stores of the first passes at <=2-way bank conflicts.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.hpp"
 
 namespace {
 
-struct cf { float x, y; };
+// complex = one aligned VGPR pair; arithmetic written so that it maps 1:1 onto v_pk_add_f32 /
+// v_pk_mul_f32 / v_pk_fma_f32 with op_sel / neg modifiers (no register shuffling)
+typedef float cf __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ cf cadd(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cf csub(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ cf mul_mj(cf a) { return {a.y, -a.x}; }          // a * (-j)
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+__device__ __forceinline__ cf mul_mj(cf a) { return cf{a.y, -a.x}; }          // a * (-j)
+__device__ __forceinline__ cf cmul(cf a, cf b)
+{
+  // (a.x b.x - a.y b.y, a.x b.y + a.y b.x) = a.xx * b + a.yy * (-b.y, b.x)
+  return __builtin_elementwise_fma(a.yy, cf{-b.y, b.x}, a.xx * b);
+}
 
 // forward DFTs on registers, natural order in, natural order out (DIT, even/odd split)
 __device__ __forceinline__ void dft2(cf &a, cf &b) { cf t = a; a = cadd(t, b); b = csub(t, b); }
@@ -32,16 +39,18 @@ __device__ __forceinline__ void dft4(cf &a0, cf &a1, cf &a2, cf &a3)
   a0 = cadd(t0, t2); a1 = cadd(t1, t3); a2 = csub(t0, t2); a3 = csub(t1, t3);
 }
 
+__device__ __forceinline__ cf mul_w8_1(cf a) { return (a + mul_mj(a)) * 0.70710678118654752440f; }   // * (1 - j)/sqrt2
+__device__ __forceinline__ cf mul_w8_3(cf a) { return (mul_mj(a) - a) * 0.70710678118654752440f; }   // * (-1 - j)/sqrt2
+
 __device__ __forceinline__ void dft8(cf *v)
 {
   cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
   cf o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
   dft4(e0, e1, e2, e3);
   dft4(o0, o1, o2, o3);
-  const float h = 0.70710678118654752440f;
-  o1 = cf{(o1.x + o1.y) * h, (o1.y - o1.x) * h};               // * (1 - j)/sqrt2
+  o1 = mul_w8_1(o1);
   o2 = mul_mj(o2);
-  o3 = cf{(o3.y - o3.x) * h, -(o3.x + o3.y) * h};              // * (-1 - j)/sqrt2
+  o3 = mul_w8_3(o3);
   v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
   v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
   v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
@@ -56,13 +65,12 @@ __device__ __forceinline__ void dft16(cf *v)
   dft8(e);
   dft8(o);
   const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;
-  const float h  = 0.70710678118654752440f;
   o[1] = cmul(o[1], cf{ c1, -s1});
-  o[2] = cf{(o[2].x + o[2].y) * h, (o[2].y - o[2].x) * h};
+  o[2] = mul_w8_1(o[2]);
   o[3] = cmul(o[3], cf{ s1, -c1});
   o[4] = mul_mj(o[4]);
   o[5] = cmul(o[5], cf{-s1, -c1});
-  o[6] = cf{(o[6].y - o[6].x) * h, -(o[6].x + o[6].y) * h};
+  o[6] = mul_w8_3(o[6]);
   o[7] = cmul(o[7], cf{-c1, -s1});
 #pragma unroll
   for (int i = 0; i < 8; ++i) { v[i] = cadd(e[i], o[i]); v[i + 8] = csub(e[i], o[i]); }
@@ -105,8 +113,62 @@ __device__ __forceinline__ void apply_twiddles(cf *v, const cf *__restrict__ tw,
   for (int q = 1; q < R; ++q) v[q] = cmul(v[q], w[q]);
 }
 
+// Base twiddles of one thread: W^(k), W^(2k), W^(4k), W^(8k) for each of its butterflies in each
+// pass.  They depend on the lane id only, so they are loaded ONCE per workgroup (before the frame
+// loop) and stay in registers; the other powers are re-derived per frame (one complex product each).
+constexpr int MAXP = 4, MAXNB = 2;
+struct TwBase { cf w[MAXP][MAXNB][4]; };
+
 template <int LOG2N, int THREADS, int PASS>
-__device__ __forceinline__ void fft_pass(cf *v /*[E]*/, cf *lds, const cf *__restrict__ tw, int tid,
+__device__ __forceinline__ void load_tw_base(TwBase &tb, const cf *__restrict__ tw, int tid)
+{
+  using PL = Plan<LOG2N>;
+  constexpr int N = 1 << LOG2N, E = N / THREADS;
+  if constexpr (PASS < PL::P) {
+    constexpr int RB = PL::bits(PASS), R = 1 << RB, NB = E / R, NSL = PL::ns_log2(PASS), NS = 1 << NSL;
+    static_assert(PL::P <= MAXP && NB <= MAXNB, "TwBase too small");
+    if constexpr (PASS > 0) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int j = tid + b * THREADS;
+        const int idx = (j & (NS - 1)) << (LOG2N - NSL - RB);
+        tb.w[PASS][b][0] = tw[idx & (N - 1)];
+        if (R > 2) tb.w[PASS][b][1] = tw[(2 * idx) & (N - 1)];
+        if (R > 4) tb.w[PASS][b][2] = tw[(4 * idx) & (N - 1)];
+        if (R > 8) tb.w[PASS][b][3] = tw[(8 * idx) & (N - 1)];
+      }
+    }
+    load_tw_base<LOG2N, THREADS, PASS + 1>(tb, tw, tid);
+  }
+}
+
+__device__ __forceinline__ cf opaque(cf a)
+{
+  // keeps LICM from hoisting the derived twiddle powers of every pass out of the frame loop
+  asm volatile("" : "+v"(a));
+  return a;
+}
+
+template <int R>
+__device__ __forceinline__ void apply_twiddles_base(cf *v, const cf *base)
+{
+  cf w[R];
+  w[1] = opaque(base[0]);
+  if (R > 2) w[2] = opaque(base[1]);
+  if (R > 4) w[4] = opaque(base[2]);
+  if (R > 8) w[8] = opaque(base[3]);
+  if (R > 2) w[3] = cmul(w[1], w[2]);
+  if (R > 4) { w[5] = cmul(w[1], w[4]); w[6] = cmul(w[2], w[4]); w[7] = cmul(w[3], w[4]); }
+  if (R > 8) {
+#pragma unroll
+    for (int q = 9; q < 16; ++q) w[q] = cmul(w[q - 8], w[8]);
+  }
+#pragma unroll
+  for (int q = 1; q < R; ++q) v[q] = cmul(v[q], w[q]);
+}
+
+template <int LOG2N, int THREADS, int PASS>
+__device__ __forceinline__ void fft_pass(cf *v /*[E]*/, cf *lds, const TwBase &tb, int tid,
                                          float *pw /*[E]*/)
 {
   using PL = Plan<LOG2N>;
@@ -135,7 +197,7 @@ __device__ __forceinline__ void fft_pass(cf *v /*[E]*/, cf *lds, const cf *__res
     const int j = tid + b * THREADS;
     const int k = j & (NS - 1);
     cf *vb = v + b * R;
-    if (PASS > 0) apply_twiddles<R>(vb, tw, k << (LOG2N - NSL - RB), N - 1);
+    if (PASS > 0) apply_twiddles_base<R>(vb, tb.w[PASS][b]);
     dftR<R>(vb);
     const int j0 = ((j - k) << RB) + k;
     if (!LAST) {
@@ -152,10 +214,10 @@ __device__ __forceinline__ void fft_pass(cf *v /*[E]*/, cf *lds, const cf *__res
 
 template <int LOG2N, int THREADS, int PASS>
 struct PassRunner {
-  static __device__ __forceinline__ void run(cf *v, cf *lds, const cf *__restrict__ tw, int tid, float *pw)
+  static __device__ __forceinline__ void run(cf *v, cf *lds, const TwBase &tb, int tid, float *pw)
   {
-    fft_pass<LOG2N, THREADS, PASS>(v, lds, tw, tid, pw);
-    if constexpr (PASS + 1 < Plan<LOG2N>::P) PassRunner<LOG2N, THREADS, PASS + 1>::run(v, lds, tw, tid, pw);
+    fft_pass<LOG2N, THREADS, PASS>(v, lds, tb, tid, pw);
+    if constexpr (PASS + 1 < Plan<LOG2N>::P) PassRunner<LOG2N, THREADS, PASS + 1>::run(v, lds, tb, tid, pw);
   }
 };
 
@@ -163,7 +225,8 @@ struct PassRunner {
 // workgroups; S > 1 writes unscaled partial sums to `partial`, reduced by psd_reduce_kernel in a
 // fixed order so the result is deterministic)
 template <int LOG2N, int THREADS>
-__global__ __launch_bounds__(THREADS) void psd_kernel(const cf *__restrict__ x, long long hop, int navg,
+// second launch bound: two workgroups per CU must fit the register file (N = 16384 is LDS-limited to one)
+__global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : (THREADS >= 128 ? THREADS / 128 : 1))) void psd_kernel(const cf *__restrict__ x, long long hop, int navg,
                                                       const float *__restrict__ window,
                                                       const cf *__restrict__ tw, float scale, int mode,
                                                       float *__restrict__ out, float *__restrict__ partial)
@@ -182,6 +245,8 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(const cf *__restrict__ x, 
   float pw[E];
 #pragma unroll
   for (int i = 0; i < E; ++i) pw[i] = 0.0f;
+  TwBase tb;
+  load_tw_base<LOG2N, THREADS, 0>(tb, tw, tid0);
 
   const int S = gridDim.y;
   const int fps = (navg + S - 1) / S;
@@ -202,13 +267,11 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(const cf *__restrict__ x, 
 #pragma unroll
       for (int q = 0; q < R0; ++q) {
         const int i = j + q * (N / R0);
-        const cf s = fr[i];
-        const float w = window[i];
-        v[b * R0 + q] = cf{s.x * w, s.y * w};
+        v[b * R0 + q] = fr[i] * window[i];
       }
     }
     // (the barrier after the previous frame's last gather already ordered LDS reuse)
-    PassRunner<LOG2N, THREADS, 0>::run(v, lds, tw, tid, pw);
+    PassRunner<LOG2N, THREADS, 0>::run(v, lds, tb, tid, pw);
   }
 
   // epilogue: thread holds power of bins j + q*N/RL (last-pass geometry)
@@ -233,17 +296,36 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(const cf *__restrict__ x, 
   }
 }
 
-// out[o][.] = (scale/navg) * sum_s partial[o][s][.]   (s ascending), optional shift + dB
-__global__ void psd_reduce_kernel(const float *__restrict__ partial, int S, int n, float sc, int mode,
-                                  float *__restrict__ out)
+// out[o][.] = (scale/navg) * sum_s partial[o][s][.], optional shift + dB.  A block handles 64 bins;
+// its 4 waves each sum a quarter of the S partials (ascending s), the quarters are combined as
+// (q0 + q1) + (q2 + q3): a fixed order, so the result is deterministic.
+__global__ __launch_bounds__(256) void psd_reduce_kernel(const float *__restrict__ partial, int S, int n, float sc,
+                                                         int mode, float *__restrict__ out)
 {
+  __shared__ float part[4][64];
   const long long o = blockIdx.y;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float acc = 0.0f;
-    for (int s2 = 0; s2 < S; ++s2) acc += partial[(o * S + s2) * n + i];
-    const float p = acc * sc;
-    if (mode == 0) out[o * n + i] = p;
-    else out[o * n + ((i + n / 2) & (n - 1))] = 10.0f * log10f(p + 1e-8f);
+  const int ix = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + ix;
+  const int s0 = (int)((long long)S * g / 4), s1 = (int)((long long)S * (g + 1) / 4);
+  float acc = 0.0f;
+  if (i < n) {
+    const float *p = partial + (o * S) * n + i;
+    int s2 = s0;
+    for (; s2 + 8 <= s1; s2 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(long long)(s2 + u) * n];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; s2 < s1; ++s2) acc += p[(long long)s2 * n];
+  }
+  part[g][ix] = acc;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    const float pw = ((part[0][ix] + part[1][ix]) + (part[2][ix] + part[3][ix])) * sc;
+    if (mode == 0) out[o * n + i] = pw;
+    else out[o * n + ((i + n / 2) & (n - 1))] = 10.0f * log10f(pw + 1e-8f);
   }
 }
 
@@ -265,7 +347,7 @@ hipError_t launch_psd(const void *x, long long hop, int navg, const float *windo
                      reinterpret_cast<const cf *>(x), hop, navg, window, reinterpret_cast<const cf *>(tw),
                      scale, mode, out, partial);
   if (S > 1) {
-    hipLaunchKernelGGL(psd_reduce_kernel, dim3((N + 255) / 256, (unsigned)nout), dim3(256), 0, st,
+    hipLaunchKernelGGL(psd_reduce_kernel, dim3((N + 63) / 64, (unsigned)nout), dim3(256), 0, st,
                        partial, S, N, scale / (float)navg, mode, out);
   }
   return hipGetLastError();
@@ -335,9 +417,20 @@ namespace sdk {
 // on the chip, at least 2 frames each
 int psd_split(long long nout, int navg)
 {
-  if (nout <= 0 || navg < 4 || nout >= 1024) return 1;
-  long long s = (1024 + nout - 1) / nout;
-  if (s > navg / 2) s = navg / 2;
+  // two resident workgroups per CU (512 on the chip), at least `minf` frames per workgroup so the
+  // register-resident twiddles are reused
+  static int target = 0, minf = 0;
+  if (target == 0) {
+    const char *e = getenv("SUAMD_PSD_SPLIT_TARGET");
+    target = e ? atoi(e) : 512;
+    e = getenv("SUAMD_PSD_MIN_FRAMES");
+    minf = e ? atoi(e) : 1;
+    if (target < 1) target = 1;
+    if (minf < 1) minf = 1;
+  }
+  if (nout <= 0 || navg < 2 * minf || nout >= target) return 1;
+  long long s = (target + nout - 1) / nout;
+  if (s > navg / minf) s = navg / minf;
   if (s < 1) s = 1;
   return (int)s;
 }

@@ -250,6 +250,8 @@ def broadcast_block(buf, dist, src=0, async_op=True):
     """The one exchange step of the multi-GPU path: rank `src` holds the IQ block, every rank
     needs it (RCCL broadcast over xGMI on GPUs; gloo in the CPU tests).  Returns the work handle
     (None when not distributed)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return None
+    if buf.is_complex():
+        buf = torch.view_as_real(buf)          # same memory; the collective only needs the bytes
     return dist.broadcast(buf, src=src, async_op=async_op)
