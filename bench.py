@@ -117,6 +117,23 @@ def cpu_baseline(cfg, nsamples, fnor_rank, ncores):
     }
 
 
+def pmc_traffic(kernel, workload, block):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json:
+    2*FETCH_SIZE + WRITE_SIZE, the gfx950 half-count correction calibrated there); None when the
+    profile was taken on a different workload / block size."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        w = d.get("workload", {})
+        if w.get("name") == workload and w.get("block_samples") == block and kernel in d.get("kernels", {}):
+            best = d["kernels"][kernel].get("hbm_bytes_per_launch")
+    return best
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -226,7 +243,7 @@ def main():
             "bound": "hbm", "achieved": round(fir_bytes / (fir_ms * 1e-3) / 1e9, 2) if fir_ms else None,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(fir_bytes / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if fir_ms else None,
-            "traffic": None,
+            "traffic": pmc_traffic("chan_fir_kernel", args.workload, L),
             "algorithmic_bytes_per_launch": fir_bytes,
             "kernel_ms": round(fir_ms, 4) if fir_ms else None,
             "fp32_vector": {"achieved_tflops": round(fir_flops / (fir_ms * 1e-3) / 1e12, 3) if fir_ms else None,
