@@ -185,7 +185,7 @@ template <int ORDER> struct CostasRegs {
   c32 xh[ORDER + 1], yh[ORDER + 1];
 };
 
-template <int KIND, int ORDER>
+template <int KIND, int ORDER, bool GAIN1>
 __device__ __forceinline__ float2 costas_step(const sdk::CostasParams &p, CostasRegs<ORDER> &r, float2 v)
 {
   // history part of the arm filter first: it does not depend on the new sample
@@ -205,8 +205,10 @@ __device__ __forceinline__ float2 costas_step(const sdk::CostasParams &p, Costas
 #pragma unroll
   for (int q = ORDER; q >= 2; --q) { r.xh[q] = r.xh[q - 1]; r.yh[q] = r.yh[q - 1]; }
   if (ORDER >= 1) { r.xh[1] = m; r.yh[1] = z; }
-  z.re = p.gain * z.re;                                       // gain is 1 upstream; x*1 is exact
-  z.im = p.gain * z.im;
+  if (!GAIN1) {                                               // gain is 1 upstream; x*1.0f is exact,
+    z.re = p.gain * z.re;                                     // so skipping the multiply keeps the bits
+    z.im = p.gain * z.im;
+  }
   float e;
   if (KIND == 1) {
     e = z.re * z.im;
@@ -228,7 +230,7 @@ __device__ __forceinline__ float2 costas_step(const sdk::CostasParams &p, Costas
 // recurrence is its dynamic instruction count per sample: the loop kind is a template
 // parameter (no per-sample scalar branching), full chunks run without bounds checks and only
 // the last partial chunk is guarded.
-template <int KIND, int ORDER>
+template <int KIND, int ORDER, bool GAIN1>
 __global__ __launch_bounds__(64) void costas_kernel(sdk::CostasParams p, sdk::CostasState s, int nchan,
                                                     const float2 *__restrict__ x, sdk::View xv,
                                                     float2 *__restrict__ y, sdk::View yv, long long len)
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(64) void costas_kernel(sdk::CostasParams p, sdk::Co
   const uint32_t xo = (uint32_t)((long long)c * xv.cs * 8), yo = (uint32_t)((long long)c * yv.cs * 8);
   const long long yms = yv.ms;
   stream_row(x, xv.ms, xo, len, [&](long long m, float2 v) {
-    st_elem(y, m * yms, yo, costas_step<KIND, ORDER>(p, r, v));
+    st_elem(y, m * yms, yo, costas_step<KIND, ORDER, GAIN1>(p, r, v));
   });
   s.phase[c] = r.phase;
   s.omega[c] = r.omega;
@@ -542,7 +544,10 @@ hipError_t costas_feed(const CostasParams &p, const CostasState &s, int nchan, c
   const float2 *xx = reinterpret_cast<const float2 *>(x);
   float2 *yy = reinterpret_cast<float2 *>(y);
 #define SD_COSTAS_CASE(K, O) \
-  case (K) * 8 + (O): hipLaunchKernelGGL((costas_kernel<K, O>), grid, block, 0, st, p, s, nchan, xx, xs, yy, ys, len); break;
+  case (K) * 8 + (O): \
+    if (p.gain == 1.0f) hipLaunchKernelGGL((costas_kernel<K, O, true>), grid, block, 0, st, p, s, nchan, xx, xs, yy, ys, len); \
+    else hipLaunchKernelGGL((costas_kernel<K, O, false>), grid, block, 0, st, p, s, nchan, xx, xs, yy, ys, len); \
+    break;
   if (p.order < 0 || p.order > 4 || p.kind < 1 || p.kind > 3) return hipErrorInvalidValue;
   switch (p.kind * 8 + p.order) {
     SD_COSTAS_CASE(1, 0) SD_COSTAS_CASE(1, 1) SD_COSTAS_CASE(1, 2) SD_COSTAS_CASE(1, 3) SD_COSTAS_CASE(1, 4)
