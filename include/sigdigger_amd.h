@@ -210,6 +210,27 @@ SUAMD_API SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d
                                      suamd_complex *d_y, suamd_view yv, SUSCOUNT len, void *stream);
 
 /* ------------------------------------------------------------------------------------ */
+/* T9 / T10: whole-capture FFT tasks                                                     */
+/* ------------------------------------------------------------------------------------ */
+/* Forward FFT of n = 2^log2n complex points (16 <= n <= 2^24), out of place: the
+ * SU_FFTW(_plan_dft_1d)(n, buf, buf, FFTW_FORWARD, ...) + _execute pair of
+ * Tasks/CarrierDetector.cpp:58-75,94.  d_work: scratch of n complex values. */
+SUAMD_API SUBOOL suamd_fft_forward_bulk(suamd_ctx_t *ctx, const suamd_complex *d_in, suamd_complex *d_out,
+                                        suamd_complex *d_work, unsigned log2n, void *stream);
+/* CarrierDetector::work, all states (Tasks/CarrierDetector.cpp:49-147): zero-pad to a power of two,
+ * Blackman-Harris over len, FFT, |X|^2 arg-max outside the DC notch, circular centroid over
+ * alloc*avg_rel_bw + 1 bins.  *peak = carrier in rad/sample.  Synchronises the stream. */
+SUAMD_API SUBOOL suamd_carrier_detect(suamd_ctx_t *ctx, const suamd_complex *d_data, SUSCOUNT len,
+                                      SUFLOAT avg_rel_bw, SUFLOAT dc_notch_rel_bw, SUFLOAT *peak, void *stream);
+/* DopplerCalculator::work (Tasks/DopplerCalculator.cpp:52-182): same front end; mirrored power
+ * spectrum into d_spectrum (may be NULL; *alloc floats), velocity centroid *peak (m/s), its
+ * spread *sigma (Hz-domain std dev as the reference computes it) and the spectrum maximum. */
+SUAMD_API SUSCOUNT suamd_doppler_alloc_size(SUSCOUNT len);
+SUAMD_API SUBOOL suamd_doppler_calc(suamd_ctx_t *ctx, const suamd_complex *d_data, SUSCOUNT len, SUFLOAT fs,
+                                    SUFREQ f0, SUFLOAT *d_spectrum, SUFLOAT *peak, SUFLOAT *sigma, SUFLOAT *max,
+                                    void *stream);
+
+/* ------------------------------------------------------------------------------------ */
 /* P2 / P3: panoramic scanner SpectrumView                                               */
 /* ------------------------------------------------------------------------------------ */
 /* struct SpectrumView (include/Scanner.h:63-110): psd / psdAccum / psdCount of up to 65536 bins

@@ -976,3 +976,58 @@ void sdo_log2f_bulk(const float *x, float *out, size_t n)
 { size_t i; for (i = 0; i < n; ++i) out[i] = sdo_log2f(x[i]); }
 void sdo_exp2f_bulk(const float *x, float *out, size_t n)
 { size_t i; for (i = 0; i < n; ++i) out[i] = sdo_exp2f(x[i]); }
+
+/* ===================================================================================== */
+/* T10: Doppler centroid [REF-PINNED structure] Tasks/DopplerCalculator.cpp:85-175        */
+/* ===================================================================================== */
+/* spectrum: alloc floats (mirrored PSD, :128); res[0] = peak velocity, res[1] = sigma, res[2] = max */
+void sdo_doppler_calc(const sdo_c32 *data, size_t len, float fs, double f0, float *spectrum, float *res)
+{
+  size_t alloc = 1, k;
+  while (alloc < len) alloc <<= 1;
+  if (alloc < 16) alloc = 16;
+  sdo_c32 *buf = calloc(alloc, sizeof *buf);
+  double *re = malloc(sizeof(double) * alloc), *im = malloc(sizeof(double) * alloc);
+  memcpy(buf, data, len * sizeof *buf);
+  sdo_blackmann_harris_complex(buf, len);
+  for (k = 0; k < alloc; ++k) { re[k] = buf[k].re; im[k] = buf[k].im; }
+  sdo_fft_f64(re, im, alloc);
+  for (k = 0; k < alloc; ++k) { buf[k].re = (float)re[k]; buf[k].im = (float)im[k]; }
+
+  int i, maxNdx = 0, bins = (int)alloc, delta = bins / 2, start;
+  float maxVal = 0, psd, peak, lambda = (float)(299792458. / f0);
+  double accr = 0, acci = 0;
+  float dispAcc = 0, totalEnergy = 0, err = 0, t, y;
+  for (i = 0; i < bins; ++i) {
+    buf[i].re = fmaf(buf[i].re, buf[i].re, buf[i].im * buf[i].im);
+    buf[i].im = 0;
+    psd = buf[i].re;
+    if (psd > maxVal) { maxVal = psd; maxNdx = i; }
+    if (spectrum) spectrum[((size_t)(bins - i) + (size_t)delta) % (size_t)bins] = psd;
+    y = psd - err;                                       /* Kahan, :131-134 */
+    t = totalEnergy + y;
+    err = (t - totalEnergy) - y;
+    totalEnergy = t;
+  }
+  start = maxNdx - delta;
+  for (i = 0; i < bins; ++i) {
+    long long j = i + start;
+    if (j < 0) j += (long long)alloc;
+    j %= (long long)alloc;
+    psd = buf[j].re;
+    float nFreq = 2.f * (float)j / (float)alloc;
+    double ang = (double)((float)SDO_PI * nFreq);
+    accr += (double)psd * cos(ang);
+    acci += (double)psd * sin(ang);
+    j = i;
+    if (j >= delta) j -= bins;
+    dispAcc += ((float)j * (float)j * psd / totalEnergy) / ((float)delta * (float)delta);
+  }
+  peak = (float)atan2(acci, accr);
+  if (peak > (float)SDO_PI) peak -= (float)(2 * SDO_PI);
+  peak = fs * (peak / (float)SDO_PI) * .5f;
+  res[0] = -lambda * peak;
+  res[1] = fs * sqrtf(dispAcc) * .5f;
+  res[2] = maxVal;
+  free(buf); free(re); free(im);
+}

@@ -160,6 +160,8 @@ void sdo_sample_manual(const sdo_c32 *data, size_t length, double symbol_count,
 /* Tasks/CarrierDetector.cpp:80-143. returns peak in rad/sample */
 float sdo_carrier_detect(const sdo_c32 *data, size_t len, float avg_rel_bw, float dc_notch_rel_bw);
 void  sdo_blackmann_harris_complex(sdo_c32 *h, size_t n);
+/* ---- T10: Doppler centroid [REF-PINNED structure] Tasks/DopplerCalculator.cpp:85-175 --- */
+void  sdo_doppler_calc(const sdo_c32 *data, size_t len, float fs, double f0, float *spectrum, float *res);
 
 /* ---- P2/P3: SpectrumView [REF-PINNED] ----------------------------------------------- */
 #define SDO_SCANNER_SPECTRUM_SIZE 65536

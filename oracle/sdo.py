@@ -340,6 +340,18 @@ def carrier_detect(data, avg_rel_bw, dc_notch_rel_bw):
                                           C.c_float(dc_notch_rel_bw)))
 
 
+def doppler_calc(data, fs, f0):
+    """DopplerCalculator::work: (peak velocity, sigma, max, mirrored spectrum)"""
+    data = _c(data)
+    alloc = 16
+    while alloc < data.size:
+        alloc <<= 1
+    spec = np.empty(alloc, dtype=np.float32)
+    res = np.empty(3, dtype=np.float32)
+    lib().sdo_doppler_calc(_p(data), C.c_size_t(data.size), C.c_float(fs), C.c_double(f0), _p(spec), _p(res))
+    return float(res[0]), float(res[1]), float(res[2]), spec
+
+
 class SpectrumView:
     """Panoramic/Scanner.cpp SpectrumView."""
     SIZE = 65536

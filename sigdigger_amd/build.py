@@ -23,6 +23,7 @@ SOURCES = {
     "chan.hip":  ["-ffp-contract=off"],
     "loops.hip": ["-ffp-contract=off"],
     "specview.hip": ["-ffp-contract=off"],
+    "fft.hip": ["-ffp-contract=fast"],
     "capi.hip":  ["-ffp-contract=off"],
     "analyzer.cpp": ["-ffp-contract=off"],
 }

@@ -711,6 +711,108 @@ SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d_x, suamd_
   return SU_TRUE;
 }
 
+// ---- whole-capture FFT tasks ------------------------------------------------------------------------
+SUBOOL suamd_fft_forward_bulk(suamd_ctx_t *ctx, const suamd_complex *d_in, suamd_complex *d_out, suamd_complex *d_work,
+                              unsigned log2n, void *stream)
+{
+  if (!ctx || !d_in || !d_out || !d_work) { set_err("null argument"); return SU_FALSE; }
+  if (log2n < 4 || log2n > 24) { set_err("log2n %u unsupported (4..24)", log2n); return SU_FALSE; }
+  hipStream_t st = as_stream(stream);
+  const size_t bytes = sizeof(suamd_complex) << log2n;
+  // arrange the ping-pong so that the last pass lands in d_out
+  const int npass = ((int)log2n + 3) / 4;
+  void *a = (npass & 1) ? (void *)d_work : (void *)d_out;
+  void *b = (npass & 1) ? (void *)d_out : (void *)d_work;
+  HIP_TRY(hipMemcpyAsync(a, d_in, bytes, hipMemcpyDeviceToDevice, st), SU_FALSE);
+  void *res = nullptr;
+  HIP_TRY(sdk::fft_forward(a, b, (int)log2n, &res, st), SU_FALSE);
+  if (res != (void *)d_out) HIP_TRY(hipMemcpyAsync(d_out, res, bytes, hipMemcpyDeviceToDevice, st), SU_FALSE);
+  return SU_TRUE;
+}
+
+namespace {
+struct CaptureFft {                      // scratch of one whole-capture task
+  void *a = nullptr, *b = nullptr, *res = nullptr;
+  float *blk_max = nullptr; long long *blk_idx = nullptr; double *blk_sum = nullptr, *d_res = nullptr;
+  long long alloc = 1; int log2n = 0;
+  static constexpr int NBLK = 512;
+  bool init(SUSCOUNT len)
+  {
+    while ((SUSCOUNT)alloc < len) { alloc <<= 1; ++log2n; }
+    if (log2n < 4) { alloc = 16; log2n = 4; }
+    const size_t bytes = sizeof(suamd_complex) * (size_t)alloc;
+    return hipMalloc(&a, bytes) == hipSuccess && hipMalloc(&b, bytes) == hipSuccess &&
+           hipMalloc((void **)&blk_max, NBLK * sizeof(float)) == hipSuccess &&
+           hipMalloc((void **)&blk_idx, NBLK * sizeof(long long)) == hipSuccess &&
+           hipMalloc((void **)&blk_sum, NBLK * sizeof(double)) == hipSuccess &&
+           hipMalloc((void **)&d_res, 8 * sizeof(double)) == hipSuccess;
+  }
+  ~CaptureFft()
+  {
+    for (void *p : {a, b, (void *)blk_max, (void *)blk_idx, (void *)blk_sum, (void *)d_res}) if (p) (void)hipFree(p);
+  }
+};
+}  // namespace
+
+SUBOOL suamd_carrier_detect(suamd_ctx_t *ctx, const suamd_complex *d_data, SUSCOUNT len, SUFLOAT avgRelBw,
+                            SUFLOAT dcNotchRelBw, SUFLOAT *peak, void *stream)
+{
+  if (!ctx || !d_data || !peak || len < 2) { set_err("bad argument"); return SU_FALSE; }
+  if (len > (1ull << 24)) { set_err("capture longer than 2^24 samples"); return SU_FALSE; }
+  hipStream_t st = as_stream(stream);
+  CaptureFft w;
+  if (!w.init(len)) { set_err("device allocation failed"); return SU_FALSE; }
+  HIP_TRY(sdk::window_pad(d_data, (long long)len, w.alloc, w.a, st), SU_FALSE);
+  HIP_TRY(sdk::fft_forward(w.a, w.b, w.log2n, &w.res, st), SU_FALSE);
+  // Tasks/CarrierDetector.cpp:99-104
+  const int bins = static_cast<int>((double)w.alloc * (double)avgRelBw) + 1;
+  const int delta = (bins - 1) / 2;
+  const int skipLen = static_cast<int>(.5 * (double)dcNotchRelBw * (double)w.alloc);
+  HIP_TRY(sdk::spectrum_centroid(w.res, w.alloc, skipLen, w.alloc - skipLen, nullptr, bins, delta, 0, w.blk_max,
+                                 w.blk_idx, w.blk_sum, CaptureFft::NBLK, w.d_res, st), SU_FALSE);
+  double res[5];
+  HIP_TRY(hipMemcpyAsync(res, w.d_res, sizeof res, hipMemcpyDeviceToHost, st), SU_FALSE);
+  HIP_TRY(hipStreamSynchronize(st), SU_FALSE);
+  float p = (float)std::atan2(res[1], res[0]);
+  if (p > (float)M_PI) p -= (float)(2 * M_PI);
+  *peak = p;
+  return SU_TRUE;
+}
+
+SUSCOUNT suamd_doppler_alloc_size(SUSCOUNT len)
+{
+  SUSCOUNT a = 1;
+  while (a < len) a <<= 1;
+  return a < 16 ? 16 : a;
+}
+
+SUBOOL suamd_doppler_calc(suamd_ctx_t *ctx, const suamd_complex *d_data, SUSCOUNT len, SUFLOAT fs, SUFREQ f0,
+                          SUFLOAT *d_spectrum, SUFLOAT *peak, SUFLOAT *sigma, SUFLOAT *max, void *stream)
+{
+  if (!ctx || !d_data || len < 2) { set_err("bad argument"); return SU_FALSE; }
+  if (len > (1ull << 24)) { set_err("capture longer than 2^24 samples"); return SU_FALSE; }
+  hipStream_t st = as_stream(stream);
+  CaptureFft w;
+  if (!w.init(len)) { set_err("device allocation failed"); return SU_FALSE; }
+  HIP_TRY(sdk::window_pad(d_data, (long long)len, w.alloc, w.a, st), SU_FALSE);
+  HIP_TRY(sdk::fft_forward(w.a, w.b, w.log2n, &w.res, st), SU_FALSE);
+  const long long bins = w.alloc, delta = bins / 2;                   // DopplerCalculator.cpp:107-108
+  HIP_TRY(sdk::spectrum_centroid(w.res, w.alloc, 0, w.alloc, d_spectrum, bins, delta, 1, w.blk_max, w.blk_idx,
+                                 w.blk_sum, CaptureFft::NBLK, w.d_res, st), SU_FALSE);
+  double res[5];
+  HIP_TRY(hipMemcpyAsync(res, w.d_res, sizeof res, hipMemcpyDeviceToHost, st), SU_FALSE);
+  HIP_TRY(hipStreamSynchronize(st), SU_FALSE);
+  // DopplerCalculator.cpp:158-173
+  const float lambda = static_cast<float>(299792458.0 / f0);
+  float pk = (float)std::atan2(res[1], res[0]);
+  if (pk > (float)M_PI) pk -= (float)(2 * M_PI);
+  pk = fs * (pk / (float)M_PI) * .5f;                                  // SU_NORM2ABS_FREQ(fs, SU_ANG2NORM_FREQ(pk))
+  if (peak) *peak = -lambda * pk;
+  if (sigma) *sigma = fs * (float)std::sqrt(res[2]) * .5f;
+  if (max) *max = (float)res[3];
+  return SU_TRUE;
+}
+
 // ---- SpectrumView ----------------------------------------------------------------------------------
 struct suamd_specview {
   suamd_ctx *ctx;

@@ -1,0 +1,250 @@
+// fft.hip -- large one-shot FFTs for the offline Tasks (T9 CarrierDetector, T10 DopplerCalculator:
+// Blackman-Harris window, zero-pad to a power of two, one forward FFT of the whole capture,
+// |X|^2, arg-max, circular centroid -- Tasks/CarrierDetector.cpp:80-143,
+// Tasks/DopplerCalculator.cpp:85-175).
+//
+// The transform is a Stockham autosort FFT run pass by pass through HBM (radix 16, a radix
+// 2/4/8 pass for the remainder, ping-pong buffers).  Every pass reads N*8 and writes N*8 bytes
+// with coalesced accesses (reads always; writes in runs of Ns elements), so a 4 Mi-point
+// transform moves ~0.4 GB: it is HBM-bound and runs once per Task, unlike the per-block PSD
+// (psd.hip) which keeps the whole frame in LDS.  Twiddles are evaluated with sincospif on the
+// exact dyadic argument (no table).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.hpp"
+
+namespace {
+
+typedef float cf __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ cf cmul(cf a, cf b) { return __builtin_elementwise_fma(a.yy, cf{-b.y, b.x}, a.xx * b); }
+__device__ __forceinline__ cf mul_mj(cf a) { return cf{a.y, -a.x}; }
+
+template <int R> __device__ __forceinline__ void dft(cf *v);
+template <> __device__ __forceinline__ void dft<2>(cf *v) { cf t = v[0]; v[0] = t + v[1]; v[1] = t - v[1]; }
+template <> __device__ __forceinline__ void dft<4>(cf *v)
+{
+  cf t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], t3 = mul_mj(v[1] - v[3]);
+  v[0] = t0 + t2; v[1] = t1 + t3; v[2] = t0 - t2; v[3] = t1 - t3;
+}
+template <> __device__ __forceinline__ void dft<8>(cf *v)
+{
+  cf e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+  dft<4>(e); dft<4>(o);
+  const float h = 0.70710678118654752440f;
+  o[1] = (o[1] + mul_mj(o[1])) * h;
+  o[2] = mul_mj(o[2]);
+  o[3] = (mul_mj(o[3]) - o[3]) * h;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = e[i] + o[i]; v[i + 4] = e[i] - o[i]; }
+}
+template <> __device__ __forceinline__ void dft<16>(cf *v)
+{
+  cf e[8], o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+  dft<8>(e); dft<8>(o);
+  const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+  o[1] = cmul(o[1], cf{ c1, -s1});
+  o[2] = (o[2] + mul_mj(o[2])) * h;
+  o[3] = cmul(o[3], cf{ s1, -c1});
+  o[4] = mul_mj(o[4]);
+  o[5] = cmul(o[5], cf{-s1, -c1});
+  o[6] = (mul_mj(o[6]) - o[6]) * h;
+  o[7] = cmul(o[7], cf{-c1, -s1});
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[i] = e[i] + o[i]; v[i + 8] = e[i] - o[i]; }
+}
+
+// one Stockham pass: butterfly j reads in[j + q*N/R], multiplies by W_(Ns*R)^(q*k), k = j mod Ns,
+// writes out[(j - k)*R + k + q*Ns]
+template <int R>
+__global__ void fft_pass_kernel(const cf *__restrict__ in, cf *__restrict__ out, long long n, long long ns)
+{
+  const long long nb = n / R;
+  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < nb;
+       j += (long long)gridDim.x * blockDim.x) {
+    const long long k = j & (ns - 1);
+    cf v[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = in[j + q * nb];
+    if (ns > 1) {
+      // angle(q) = -2 pi q k / (ns R): q k / (ns R) is a dyadic rational, exact in binary32 for n <= 2^24
+      const float base = -2.0f * (float)k / (float)(ns * R);
+#pragma unroll
+      for (int q = 1; q < R; ++q) {
+        float sn, cs;
+        sincospif(base * (float)q, &sn, &cs);
+        v[q] = cmul(v[q], cf{cs, sn});
+      }
+    }
+    dft<R>(v);
+    const long long j0 = (j - k) * R + k;
+#pragma unroll
+    for (int q = 0; q < R; ++q) out[j0 + q * ns] = v[q];
+  }
+}
+
+// Tasks/CarrierDetector.cpp:80-89: copy, zero-pad, Blackman-Harris over the first len samples
+__global__ void window_pad_kernel(const float2 *__restrict__ data, long long len, long long alloc, float2 *__restrict__ buf)
+{
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < alloc;
+       i += (long long)gridDim.x * blockDim.x) {
+    float2 v = float2{0.0f, 0.0f};
+    if (i < len) {
+      const double t = 2.0 * 3.14159265358979323846 * (double)i / (double)(len - 1);
+      const float w = (float)(0.35875 - 0.48829 * cos(t) + 0.14128 * cos(2 * t) - 0.01168 * cos(3 * t));
+      const float2 d = data[i];
+      v = float2{d.x * w, d.y * w};
+    }
+    buf[i] = v;
+  }
+}
+
+// |X|^2 of bins [lo, hi) (others keep Re(X), as the reference's loop leaves them), block-wise
+// arg-max (first maximum wins, like the sequential scan) and total energy (double)
+__global__ __launch_bounds__(256) void power_argmax_kernel(float2 *__restrict__ buf, long long alloc, long long lo,
+                                                           long long hi, float *__restrict__ mirror,
+                                                           float *__restrict__ blk_max, long long *__restrict__ blk_idx,
+                                                           double *__restrict__ blk_sum)
+{
+  __shared__ float smax[256];
+  __shared__ long long sidx[256];
+  __shared__ double ssum[256];
+  float best = 0.0f;
+  long long bi = 0;
+  double sum = 0.0;
+  for (long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < hi;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float2 x = buf[i];
+    const float p = __builtin_fmaf(x.x, x.x, x.y * x.y);
+    buf[i] = float2{p, 0.0f};
+    if (mirror != nullptr) mirror[(alloc - i + alloc / 2) % alloc] = p;      // DopplerCalculator.cpp:128
+    sum += (double)p;
+    if (p > best || (p == best && p > 0.0f && i < bi)) { best = p; bi = i; }
+  }
+  smax[threadIdx.x] = best; sidx[threadIdx.x] = bi; ssum[threadIdx.x] = sum;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float om = smax[threadIdx.x + s];
+      const long long oi = sidx[threadIdx.x + s];
+      if (om > smax[threadIdx.x] || (om == smax[threadIdx.x] && om > 0.0f && oi < sidx[threadIdx.x])) {
+        smax[threadIdx.x] = om; sidx[threadIdx.x] = oi;
+      }
+      ssum[threadIdx.x] += ssum[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { blk_max[blockIdx.x] = smax[0]; blk_idx[blockIdx.x] = sidx[0]; blk_sum[blockIdx.x] = ssum[0]; }
+}
+
+// final arg-max over the block results + circular centroid (and dispersion) around it
+// res[0] = acc.re, res[1] = acc.im, res[2] = dispersion accumulator, res[3] = max value, res[4] = total energy
+__global__ __launch_bounds__(256) void centroid_kernel(const float2 *__restrict__ buf, long long alloc, int nblk,
+                                                       const float *__restrict__ blk_max,
+                                                       const long long *__restrict__ blk_idx,
+                                                       const double *__restrict__ blk_sum, long long bins,
+                                                       long long delta, int with_dispersion, double *__restrict__ res)
+{
+  __shared__ double sre[256], sim[256], sdisp[256];
+  __shared__ long long smaxidx;
+  __shared__ float smaxval;
+  __shared__ double stotal;
+  if (threadIdx.x == 0) {
+    float best = 0.0f; long long bi = 0; double tot = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      if (blk_max[b] > best || (blk_max[b] == best && best > 0.0f && blk_idx[b] < bi)) { best = blk_max[b]; bi = blk_idx[b]; }
+      tot += blk_sum[b];
+    }
+    smaxidx = bi; smaxval = best; stotal = tot;
+  }
+  __syncthreads();
+  const long long start = smaxidx - delta;
+  const double total = stotal;
+  double are = 0, aim = 0, disp = 0;
+  for (long long i = threadIdx.x; i < bins; i += blockDim.x) {
+    long long j = i + start;
+    if (j < 0) j += alloc;
+    j %= alloc;
+    const float psd = buf[j].x;
+    const float nFreq = 2.f * (float)j / (float)alloc;
+    float sn, cs;
+    sincosf(3.14159265358979323846f * nFreq, &sn, &cs);
+    are += (double)(psd * cs);
+    aim += (double)(psd * sn);
+    if (with_dispersion) {
+      long long jj = i;
+      if (jj >= delta) jj -= bins;
+      disp += ((double)jj * (double)jj * (double)psd / total) / ((double)delta * (double)delta);
+    }
+  }
+  sre[threadIdx.x] = are; sim[threadIdx.x] = aim; sdisp[threadIdx.x] = disp;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      sre[threadIdx.x] += sre[threadIdx.x + s];
+      sim[threadIdx.x] += sim[threadIdx.x + s];
+      sdisp[threadIdx.x] += sdisp[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { res[0] = sre[0]; res[1] = sim[0]; res[2] = sdisp[0]; res[3] = (double)smaxval; res[4] = total; }
+}
+
+inline unsigned grid_for(long long n, int block) {
+  long long g = (n + block - 1) / block;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+namespace sdk {
+
+// forward FFT of n = 2^log2n points; a and b are ping-pong buffers (input in a); returns the
+// buffer holding the result through *result
+hipError_t fft_forward(void *a, void *b, int log2n, void **result, hipStream_t st)
+{
+  const long long n = 1ll << log2n;
+  cf *src = reinterpret_cast<cf *>(a), *dst = reinterpret_cast<cf *>(b);
+  long long ns = 1;
+  int bits = log2n;
+  while (bits > 0) {
+    const int rb = bits >= 4 ? 4 : bits;
+    const long long nb = n >> rb;
+    const dim3 grid(grid_for(nb, 256)), block(256);
+    switch (rb) {
+      case 4: hipLaunchKernelGGL(fft_pass_kernel<16>, grid, block, 0, st, src, dst, n, ns); break;
+      case 3: hipLaunchKernelGGL(fft_pass_kernel<8>, grid, block, 0, st, src, dst, n, ns); break;
+      case 2: hipLaunchKernelGGL(fft_pass_kernel<4>, grid, block, 0, st, src, dst, n, ns); break;
+      default: hipLaunchKernelGGL(fft_pass_kernel<2>, grid, block, 0, st, src, dst, n, ns); break;
+    }
+    ns <<= rb;
+    bits -= rb;
+    cf *t = src; src = dst; dst = t;
+  }
+  *result = src;
+  return hipGetLastError();
+}
+
+hipError_t window_pad(const void *data, long long len, long long alloc, void *buf, hipStream_t st)
+{
+  hipLaunchKernelGGL(window_pad_kernel, dim3(grid_for(alloc, 256)), dim3(256), 0, st,
+                     reinterpret_cast<const float2 *>(data), len, alloc, reinterpret_cast<float2 *>(buf));
+  return hipGetLastError();
+}
+
+hipError_t spectrum_centroid(void *buf, long long alloc, long long lo, long long hi, float *mirror, long long bins,
+                             long long delta, int with_dispersion, float *blk_max, long long *blk_idx, double *blk_sum,
+                             int nblk, double *res, hipStream_t st)
+{
+  hipLaunchKernelGGL(power_argmax_kernel, dim3(nblk), dim3(256), 0, st, reinterpret_cast<float2 *>(buf), alloc, lo, hi,
+                     mirror, blk_max, blk_idx, blk_sum);
+  hipLaunchKernelGGL(centroid_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const float2 *>(buf), alloc, nblk,
+                     blk_max, blk_idx, blk_sum, bins, delta, with_dispersion, res);
+  return hipGetLastError();
+}
+
+}  // namespace sdk

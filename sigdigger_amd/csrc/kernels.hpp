@@ -98,4 +98,11 @@ hipError_t specview_feed_linear(const SpecViewLinear &g, const float *psd, const
 hipError_t specview_feed_hist(const SpecViewHist &g, const float *psd, float *accum, float *cnt, hipStream_t st);
 hipError_t specview_interpolate(float *psd, float *accum, float *cnt, int n, hipStream_t st);
 
+// ---- fft.hip ----
+hipError_t fft_forward(void *a, void *b, int log2n, void **result, hipStream_t st);
+hipError_t window_pad(const void *data, long long len, long long alloc, void *buf, hipStream_t st);
+hipError_t spectrum_centroid(void *buf, long long alloc, long long lo, long long hi, float *mirror, long long bins,
+                             long long delta, int with_dispersion, float *blk_max, long long *blk_idx, double *blk_sum,
+                             int nblk, double *res, hipStream_t st);
+
 }  // namespace sdk

@@ -141,6 +141,38 @@ class Context:
               "suamd_sample_manual_bulk")
         return out
 
+    def fft_forward(self, x, stream=None):
+        """forward FFT of a power-of-two length capture (16..2^24 points)"""
+        _chk_c64(x, "x")
+        n = x.numel()
+        log2n = n.bit_length() - 1
+        if (1 << log2n) != n:
+            raise SigDiggerAmdError("length must be a power of two")
+        out, work = torch.empty_like(x), torch.empty_like(x)
+        check(self.lib.suamd_fft_forward_bulk(self.h, _ptr(x), _ptr(out), _ptr(work), log2n, _stream(stream)),
+              "suamd_fft_forward_bulk")
+        return out
+
+    def carrier_detect(self, data, avg_rel_bw, dc_notch_rel_bw, stream=None):
+        """CarrierDetector::work (Tasks/CarrierDetector.cpp): carrier in rad/sample."""
+        _chk_c64(data, "data")
+        pk = C.c_float(0)
+        check(self.lib.suamd_carrier_detect(self.h, _ptr(data), data.numel(), float(avg_rel_bw),
+                                            float(dc_notch_rel_bw), C.byref(pk), _stream(stream)),
+              "suamd_carrier_detect")
+        return pk.value
+
+    def doppler_calc(self, data, fs, f0, want_spectrum=True, stream=None):
+        """DopplerCalculator::work: (peak velocity m/s, sigma, max, mirrored spectrum or None)."""
+        _chk_c64(data, "data")
+        alloc = int(self.lib.suamd_doppler_alloc_size(data.numel()))
+        spec = torch.empty(alloc, dtype=torch.float32, device=data.device) if want_spectrum else None
+        pk, sg, mx = C.c_float(0), C.c_float(0), C.c_float(0)
+        check(self.lib.suamd_doppler_calc(self.h, _ptr(data), data.numel(), float(fs), float(f0),
+                                          _ptr(spec) if spec is not None else None, C.byref(pk), C.byref(sg),
+                                          C.byref(mx), _stream(stream)), "suamd_doppler_calc")
+        return pk.value, sg.value, mx.value, spec
+
     def lpf_design(self, ntaps, fc):
         h = np.empty(ntaps, dtype=np.float32)
         self.lib.suamd_lpf_design(h.ctypes.data_as(C.c_void_p), ntaps, float(fc))

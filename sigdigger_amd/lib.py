@@ -73,6 +73,10 @@ PROTOTYPES = {
     "suamd_agc_bank_new": (VP, [VP, UINT, C.POINTER(AgcParams)]),
     "suamd_agc_bank_destroy": (None, [VP]),
     "suamd_agc_bank_feed": (INT, [VP, VP, View, VP, View, U64, VP]),
+    "suamd_fft_forward_bulk": (INT, [VP, VP, VP, VP, UINT, VP]),
+    "suamd_carrier_detect": (INT, [VP, VP, U64, F32, F32, C.POINTER(F32), VP]),
+    "suamd_doppler_alloc_size": (U64, [U64]),
+    "suamd_doppler_calc": (INT, [VP, VP, U64, F32, F64, VP, C.POINTER(F32), C.POINTER(F32), C.POINTER(F32), VP]),
     "suamd_specview_new": (VP, [VP]),
     "suamd_specview_destroy": (None, [VP]),
     "suamd_specview_set_range": (INT, [VP, F64, F64, VP]),

@@ -497,3 +497,47 @@ def test_sample_manual_bit_exact(ctx, sdo, space, nsym, sync):
     ref = sdo.sample_manual(x, nsym, sync, space)
     got = host(ctx.sample_manual(dev(x), nsym, sync, space))
     assert_bits(got, ref, f"manual sampler space {space}")
+
+
+# ------------------------------------------------------------------------------------------
+# T9 / T10: whole-capture FFT tasks
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("log2n", [4, 7, 12, 15, 18, 22])
+def test_fft_forward_bulk(ctx, log2n):
+    n = 1 << log2n
+    rng = np.random.default_rng(log2n)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    got = host(ctx.fft_forward(dev(x)))
+    ref = np.fft.fft(x.astype(np.complex128))
+    err = np.max(np.abs(got - ref)) / np.max(np.abs(ref))
+    assert err < 2e-6, err
+    # linearity + a pure tone lands in exactly one bin (index exact)
+    k = n // 3
+    tone = np.exp(2j * np.pi * k * np.arange(n) / n).astype(np.complex64)
+    spec = np.abs(host(ctx.fft_forward(dev(tone))))
+    assert int(np.argmax(spec)) == k and spec[k] > 0.999 * n
+
+
+@pytest.mark.parametrize("n,f", [(5000, 0.11), (100000, -0.3), (1 << 20, 0.0123), (3000001, 0.4)])
+def test_carrier_detect_matches_oracle(ctx, sdo, n, f):
+    x = synth.tone_noise(n, f_rel=f / 2, sigma2=1e-2, seed=n % 97)      # carrier at pi*f rad/sample
+    ref = sdo.carrier_detect(x, 0.01, 0.005)
+    got = ctx.carrier_detect(dev(x), 0.01, 0.005)
+    assert abs(got - ref) < 1e-5 * np.pi, (got, ref)
+    assert abs(got - np.pi * f) < 2e-3
+
+
+def test_doppler_calc_matches_oracle(ctx, sdo):
+    n, fs, f0 = 300000, 250e3, 437e6
+    x = synth.tone_noise(n, f_rel=0.02, sigma2=1e-3, seed=4)
+    rp, rs, rm, rspec = sdo.doppler_calc(x, fs, f0)
+    gp, gs, gm, gspec = ctx.doppler_calc(dev(x), fs, f0)
+    gspec = host(gspec)
+    assert gspec.shape == rspec.shape
+    assert abs(gm - rm) <= 1e-5 * rm
+    assert np.argmax(gspec) == np.argmax(rspec)                          # mirrored index mapping exact
+    assert np.max(np.abs(gspec - rspec)) <= 1e-5 * rm
+    assert abs(gp - rp) <= 1e-4 * abs(rp) + 1e-3                         # m/s
+    assert abs(gs - rs) <= 2e-3 * abs(rs) + 1e-3                         # Kahan f32 vs pairwise f64 energy
+    # first principles: +0.02 cycles/sample at 250 kS/s = +5 kHz  ->  v = -lambda * f
+    assert abs(gp - (-(299792458.0 / f0) * 5e3)) < 0.5
