@@ -156,7 +156,8 @@ struct suamd_chanbank {
   float    *d_taps;      // real prototype [ntaps]
   void     *d_g;         // float4 [nchan][ntaps]: modulated taps as (re, re, -im, im)
   uint32_t *d_dphase, *d_phase0;
-  void     *d_hist;      // float2 [ntaps-1]
+  void     *d_hist[2];   // float2 [ntaps-1], ping-pong: d_hist[hist_cur] precedes the next block
+  int       hist_cur;
 };
 
 struct suamd_costas_bank {
@@ -358,8 +359,10 @@ suamd_chanbank_t *suamd_chanbank_new(suamd_ctx_t *ctx, unsigned nchan, const dou
   b->d_g      = dev_alloc<float>(4 * (size_t)nchan * ntaps);
   b->d_dphase = dev_from_host(dp);
   b->d_phase0 = dev_from_host(p0);
-  b->d_hist   = dev_zeros<float>(2 * (size_t)(ntaps > 1 ? ntaps - 1 : 1));
-  if (!b->d_taps || !b->d_g || !b->d_dphase || !b->d_phase0 || !b->d_hist ||
+  b->d_hist[0] = dev_zeros<float>(2 * (size_t)(ntaps > 1 ? ntaps - 1 : 1));
+  b->d_hist[1] = dev_zeros<float>(2 * (size_t)(ntaps > 1 ? ntaps - 1 : 1));
+  b->hist_cur = 0;
+  if (!b->d_taps || !b->d_g || !b->d_dphase || !b->d_phase0 || !b->d_hist[0] || !b->d_hist[1] ||
       !dev_upload(b->d_taps, taps, ntaps)) {
     set_err("device allocation failed");
     suamd_chanbank_destroy(b);
@@ -382,7 +385,8 @@ void suamd_chanbank_destroy(suamd_chanbank_t *b)
   if (b->d_g) hipFree(b->d_g);
   if (b->d_dphase) hipFree(b->d_dphase);
   if (b->d_phase0) hipFree(b->d_phase0);
-  if (b->d_hist) hipFree(b->d_hist);
+  if (b->d_hist[0]) hipFree(b->d_hist[0]);
+  if (b->d_hist[1]) hipFree(b->d_hist[1]);
   delete b;
 }
 
@@ -415,12 +419,13 @@ SUBOOL suamd_chanbank_feed(suamd_chanbank_t *b, const suamd_complex *d_x, SUSCOU
     return SU_FALSE;
   }
   sdk::ChanFeedArgs a;
-  a.x = d_x; a.hist = b->d_hist; a.len = (long long)len; a.n0 = b->n_total;
+  a.x = d_x; a.hist = b->d_hist[b->hist_cur]; a.hist_next = b->d_hist[b->hist_cur ^ 1];
+  a.len = (long long)len; a.n0 = b->n_total;
   a.g = b->d_g; a.dphase = b->d_dphase; a.phase0 = b->d_phase0;
   a.ntaps = (int)b->ntaps; a.nchan = (int)b->nchan; a.D = b->D;
   a.m_first = mf; a.n_out = (long long)no; a.y = d_y; a.yv = as_view(yv);
   HIP_TRY(sdk::chan_feed(a, as_stream(stream)), SU_FALSE);
-  HIP_TRY(sdk::chan_update_hist(b->d_hist, d_x, (long long)len, (int)b->ntaps, as_stream(stream)), SU_FALSE);
+  b->hist_cur ^= 1;
   b->n_total += len;
   if (n_out) *n_out = no;
   return SU_TRUE;
@@ -431,7 +436,7 @@ SUBOOL suamd_chanbank_reset(suamd_chanbank_t *b, void *stream)
   if (!b) { set_err("null argument"); return SU_FALSE; }
   b->n_total = 0;
   if (b->ntaps > 1)
-    HIP_TRY(hipMemsetAsync(b->d_hist, 0, 2 * sizeof(float) * (b->ntaps - 1), as_stream(stream)), SU_FALSE);
+    HIP_TRY(hipMemsetAsync(b->d_hist[b->hist_cur], 0, 2 * sizeof(float) * (b->ntaps - 1), as_stream(stream)), SU_FALSE);
   return SU_TRUE;
 }
 

@@ -17,6 +17,7 @@
 //     scalar loads and used as SGPR operands of v_fma_f32; each LDS read feeds 4*NCH fmas.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.hpp"
 #include "sd_math.hpp"
 
@@ -84,16 +85,75 @@ __global__ void modulate_taps_kernel(const float *__restrict__ h, int ntaps, con
 // ---------------------------------------------------------------------------------------
 struct FirGeom {
   int D, ntaps, nchan;
-  int MT;            // outputs per workgroup tile (multiple of 64 unless D is huge)
+  int MT;            // outputs per workgroup tile (multiple of 64)
   int KD;            // ceil((ntaps-1)/D)*D : window starts KD samples before the tile's first output
-  int COLS;          // columns of the transposed window  (= MT + KD/D)
-  int LDW;           // LDS row pitch in samples (odd)
+  int span;          // samples staged = MT*D + KD   (window index i <-> absolute n = nbase + i)
+  int PAD;           // LDS index of window sample i = i + (i / D) * PAD, with D + PAD odd
+  int lds_samples;   // padded window size in samples
 };
 
-constexpr int FIR_THREADS = 512;   // 8 waves share one staged window: 4 workgroups x 8 = 32 waves per CU
+constexpr int FIR_THREADS = 512;   // 8 waves share one staged window
 
-template <int NCH>
+// One chunk of TC consecutive taps for NCH channels and NOUT outputs per lane: the window samples
+// (one ds_read_b64 each, immediate offsets off one base address) and the taps (LDS broadcast reads,
+// or scalar loads).  A tap fetched once feeds NOUT*2 packed fmas per lane.
+template <int NCH, int NOUT, int TC> struct FirChunk {
+  v2f x[NOUT][TC];
+  float4 t[NCH][TC];
+};
+
+template <int NCH, int NOUT, int TC>
+__device__ __forceinline__ void fir_load(FirChunk<NCH, NOUT, TC> &c, const float2 *__restrict__ xlo, int ostride,
+                                         const float4 *const (&gp)[NCH], int k)
+{
+  // taps k .. k+TC-1 read window samples at DEcreasing addresses: xlo points at the sample of tap
+  // k+TC-1 of the lane's first output; its other outputs are ostride samples further on
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) {
+#pragma unroll
+    for (int q = 0; q < TC; ++q) { const float2 w = xlo[o * ostride + TC - 1 - q]; c.x[o][q] = v2f{w.x, w.y}; }
+  }
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+#pragma unroll
+    for (int q = 0; q < TC; ++q) c.t[j][q] = gp[j][k + q];
+  }
+}
+
+template <int NCH, int NOUT, int TC>
+__device__ __forceinline__ void fir_mac(v2f (&acc)[NCH][NOUT], const FirChunk<NCH, NOUT, TC> &c)
+{
+  // tap-major: consecutive packed fmas hit different accumulators; per accumulator the order is
+  // the SPEC's (k ascending; (re,re)*x then (-im,im)*x.yx)
+#pragma unroll
+  for (int q = 0; q < TC; ++q) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o)
+        acc[j][o] = __builtin_elementwise_fma(v2f{c.t[j][q].x, c.t[j][q].y}, c.x[o][q], acc[j][o]);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o)
+        acc[j][o] = __builtin_elementwise_fma(v2f{c.t[j][q].z, c.t[j][q].w}, c.x[o][q].yx, acc[j][o]);
+  }
+}
+
+// LDS_TAPS: few channels (C*T*16 B fits beside the window): the modulated taps are staged in LDS
+// and read with broadcast ds_read_b128 instead of scalar loads.
+//
+// Window layout in LDS: row-major with PAD samples of padding after every D samples
+// (index(i) = i + (i/D)*PAD, D + PAD odd).  Lanes hold consecutive outputs m, i.e. window
+// positions D apart -> lane stride D+PAD (odd) -> conflict-free ds_read_b64; consecutive taps of
+// one output sit at consecutive addresses, so a chunk of TC taps is TC reads with immediate
+// offsets off one base address.  Chunks are double-buffered: the loads of chunk c+1 are issued
+// before the fmas of chunk c.
+// NOUT: outputs per lane (64 apart); DB: double-buffer the chunks (not when the taps of two chunks
+// would not fit the SGPR file).
+template <int NCH, int NOUT, int TC, bool LDS_TAPS, bool DB>
 __global__ __launch_bounds__(FIR_THREADS) void chan_fir_kernel(const float2 *__restrict__ x, const float2 *__restrict__ hist,
+                                                       float2 *__restrict__ hist_next,
                                                        long long len, uint64_t n0,
                                                        const float4 *__restrict__ g,
                                                        const uint32_t *__restrict__ dphase,
@@ -104,122 +164,163 @@ __global__ __launch_bounds__(FIR_THREADS) void chan_fir_kernel(const float2 *__r
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2 *win = reinterpret_cast<float2 *>(smem);
   const int tid = threadIdx.x;
-  const int D = ge.D, T = ge.ntaps;
+  const int D = ge.D, T = ge.ntaps, PAD = ge.PAD;
   const long long tile_m0 = (long long)blockIdx.x * ge.MT;           // relative to m_first
-  // absolute index of window sample i = 0
-  const long long nbase = (long long)(m_first + (uint64_t)tile_m0) * D - ge.KD;
-  const int span = ge.COLS * D;                                       // samples staged
+  const long long nbase = (long long)(m_first + (uint64_t)tile_m0) * D - ge.KD;   // absolute index of window sample 0
+  const int span = ge.span;
   const long long hist0 = (long long)n0 - (T - 1);                    // absolute index of hist[0]
 
-  // ---- stage the window: coalesced HBM reads, transposed LDS writes ----
-  for (int i = tid; i < span; i += FIR_THREADS) {
-    const long long n = nbase + i;
-    float2 v = float2{0.0f, 0.0f};
-    if (n >= (long long)n0) {
-      if (n < (long long)n0 + len) v = x[n - (long long)n0];
-    } else if (n >= hist0) {
-      v = hist[n - hist0];
+  // ---- carry: history for the next block = last T-1 samples of [hist ; x] (ping-pong buffer) ----
+  if (blockIdx.x == gridDim.x - 1) {
+    const int hl = T - 1;
+    for (int i = tid; i < hl; i += FIR_THREADS) {
+      const long long src = (long long)i + len;                       // index into [hist ; x]
+      hist_next[i] = src < hl ? hist[src] : x[src - hl];
     }
-    const int row = i % D, col = i / D;
-    win[row * ge.LDW + col] = v;
+  }
+
+  float4 *ltaps = reinterpret_cast<float4 *>(win + (((size_t)ge.lds_samples + 1) & ~(size_t)1));   // 16-B aligned
+  if (LDS_TAPS) {
+    for (int i = tid; i < ge.nchan * T; i += FIR_THREADS) ltaps[i] = g[i];
+  }
+  // ---- stage the window: coalesced HBM reads, (nearly) linear LDS writes, 8 loads in flight ----
+  const bool interior = nbase >= (long long)n0 && nbase + span <= (long long)n0 + len;   // wave-uniform
+  const int dsh = (D & (D - 1)) == 0 ? __builtin_ctz((unsigned)D) : -1;
+  const float2 *xin = x + (nbase - (long long)n0);
+  for (int i0 = tid; i0 < span; i0 += 8 * FIR_THREADS) {
+    float2 v[8];
+    if (interior) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * FIR_THREADS;
+        v[u] = xin[i < span ? i : span - 1];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * FIR_THREADS;
+        const long long n = nbase + i;
+        float2 w = float2{0.0f, 0.0f};
+        if (i < span) {
+          if (n >= (long long)n0) {
+            if (n < (long long)n0 + len) w = x[n - (long long)n0];
+          } else if (n >= hist0) {
+            w = hist[n - hist0];
+          }
+        }
+        v[u] = w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * FIR_THREADS;
+      if (i < span) {
+        const int blk = dsh >= 0 ? (i >> dsh) : (int)((unsigned)i / (unsigned)D);
+        win[i + blk * PAD] = v[u];
+      }
+    }
   }
   __syncthreads();
 
-  // ---- units of work: (64-output sub-tile, group of NCH channels) round-robin over waves ----
+  // ---- units of work: (64*NOUT-output sub-tile, group of NCH channels) round-robin over the waves ----
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int nsub = ge.MT >> 6 ? ge.MT >> 6 : 1;
+  const int nsub = ge.MT / (64 * NOUT);
   const int ngrp = (ge.nchan + NCH - 1) / NCH;
   const int nunits = nsub * ngrp;
-  const int kd_cols = ge.KD / D;
+  const int S = D + PAD;                                              // lane stride in the window
+  const int kd_blk = ge.KD / D;
 
   for (int u = wave; u < nunits; u += FIR_THREADS / 64) {
     const int sub = u / ngrp;
     const int c0  = (u - sub * ngrp) * NCH;
-    const int ml  = sub * 64 + lane;                                  // output within the tile
-    v2f acc[NCH];
+    const int ml  = sub * 64 * NOUT + lane;                           // first output of this lane within the tile
+    v2f acc[NCH][NOUT];
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) acc[j] = v2f{0.0f, 0.0f};
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) acc[j][o] = v2f{0.0f, 0.0f};
     const float4 *gp[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int c = (c0 + j < ge.nchan) ? c0 + j : ge.nchan - 1;      // clamp: duplicates are not stored
-      gp[j] = g + (long long)c * T;
+      gp[j] = (LDS_TAPS ? (const float4 *)ltaps : g) + (long long)c * T;
     }
-    // window index of tap k for output ml: i = ml*D + KD - k  -> row (KD-k) mod D, col ml + (KD-k)/D.
-    // k = 0 sits at (row 0, column kd_cols); each following tap is one row up (address - LDW)
-    // until the row wraps to D-1 of the previous column.  Taps are consumed in runs that end at
-    // a wrap, 4 at a time inside a run so that the wave-uniform taps arrive as one
-    // s_load_dwordx16 per channel and feed v_pk_fma_f32 directly (the CU's single scalar unit
-    // is otherwise the bottleneck: 3 SALU per VALU were measured with the tap-at-a-time form).
-    const int mlc = ml < ge.MT ? ml : ge.MT - 1;
-    const int ldw = ge.LDW;
-    int row = 0, colofs = kd_cols;
-    for (int k = 0; k < T;) {
-      const int run = (row + 1 < T - k) ? row + 1 : T - k;
-      const float2 *wp = win + row * ldw + colofs + mlc;
+    // tap k of output ml reads window sample e = ml*D + KD - k, stored at ml*S + (KD-k) + ((KD-k)/D)*PAD.
+    // k = 0 is alone in its D-block (KD is a multiple of D); afterwards every D-block is a run of
+    // D taps at consecutive, decreasing addresses.  Output ml + 64*o sits 64*S samples further on.
+    const float2 *lbase = win + ml * S;
+    const int ostride = 64 * S;
+    int k = 0;
+    int blk = kd_blk;                                                  // (KD - k) / D of the current run
+    int e = ge.KD;                                                     // KD - k
+    while (k < T) {
+      const int run_full = e - blk * D + 1;                            // taps left in this D-block
+      const int run = run_full < T - k ? run_full : T - k;
+      const float2 *xr = lbase + e + blk * PAD;                        // sample of tap k+r: xr[-r]
       int r = 0;
-      for (; r + 4 <= run; r += 4) {
-        v2f v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const float2 w = wp[-(r + q) * ldw]; v[q] = v2f{w.x, w.y}; }
-        // all NCH x 4 taps first (one s_load_dwordx16 per channel, all in flight together),
-        // then the fmas tap-major so consecutive instructions hit different accumulators
-        float4 t[NCH][4];
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-          const float4 *gk = gp[j] + (k + r);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) t[j][q] = gk[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-          for (int j = 0; j < NCH; ++j) acc[j] = __builtin_elementwise_fma(v2f{t[j][q].x, t[j][q].y}, v[q], acc[j]);
-#pragma unroll
-          for (int j = 0; j < NCH; ++j) acc[j] = __builtin_elementwise_fma(v2f{t[j][q].z, t[j][q].w}, v[q].yx, acc[j]);
+      if (run >= TC) {
+        FirChunk<NCH, NOUT, TC> ca;
+        if (DB) {
+          FirChunk<NCH, NOUT, TC> cb;
+          fir_load<NCH, NOUT, TC>(ca, xr - (TC - 1), ostride, gp, k);
+          for (; r + 2 * TC <= run; r += TC) {
+            fir_load<NCH, NOUT, TC>(cb, xr - (r + 2 * TC - 1), ostride, gp, k + r + TC);
+            fir_mac<NCH, NOUT, TC>(acc, ca);
+            ca = cb;
+          }
+          fir_mac<NCH, NOUT, TC>(acc, ca);
+          r += TC;
+        } else {
+          for (; r + TC <= run; r += TC) {
+            fir_load<NCH, NOUT, TC>(ca, xr - (r + TC - 1), ostride, gp, k + r);
+            fir_mac<NCH, NOUT, TC>(acc, ca);
+          }
         }
       }
       for (; r < run; ++r) {
-        const float2 w = wp[-r * ldw];
-        const v2f v = {w.x, w.y};
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) acc[j] = tap_mac(acc[j], gp[j][k + r], v);
+        for (int o = 0; o < NOUT; ++o) {
+          const float2 w = xr[o * ostride - r];
+          const v2f v = {w.x, w.y};
+#pragma unroll
+          for (int j = 0; j < NCH; ++j) acc[j][o] = tap_mac(acc[j][o], gp[j][k + r], v);
+        }
       }
       k += run;
-      row = D - 1;
-      colofs -= 1;
+      e -= run;
+      blk -= 1;
     }
     // ---- de-rotate to baseband and store (coalesced over m) ----
-    const long long m_rel = tile_m0 + ml;
-    if (ml < ge.MT && m_rel < n_out) {
-      const uint64_t n = (m_first + (uint64_t)m_rel) * (uint64_t)D;
 #pragma unroll
-      for (int j = 0; j < NCH; ++j) {
-        const int c = c0 + j;
-        if (c < ge.nchan) {
-          float cs, sn;
-          sd::phasor_u32(phase0[c] + (uint32_t)(n * (uint64_t)dphase[c]), cs, sn);
-          const c32 r = sd::cmul_cs(c32{acc[j].x, acc[j].y}, cs, sn);
-          y[(long long)c * yv.cs + m_rel * yv.ms] = float2{r.re, r.im};
+    for (int o = 0; o < NOUT; ++o) {
+      const long long m_rel = tile_m0 + ml + 64 * o;
+      if (m_rel < n_out) {
+        const uint64_t n = (m_first + (uint64_t)m_rel) * (uint64_t)D;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+          const int c = c0 + j;
+          if (c < ge.nchan) {
+            float cs, sn;
+            sd::phasor_u32(phase0[c] + (uint32_t)(n * (uint64_t)dphase[c]), cs, sn);
+            const c32 r2 = sd::cmul_cs(c32{acc[j][o].x, acc[j][o].y}, cs, sn);
+            y[(long long)c * yv.cs + m_rel * yv.ms] = float2{r2.re, r2.im};
+          }
         }
       }
     }
   }
 }
 
-// new history = last (ntaps-1) samples of [old hist ; x]
-__global__ void update_hist_kernel(float2 *hist, const float2 *__restrict__ x, long long len, int hl)
+// new history = last (ntaps-1) samples of [old hist ; x]   (only used when a feed produces no output;
+// otherwise the last FIR workgroup writes it)
+__global__ void update_hist_kernel(float2 *__restrict__ hist_next, const float2 *__restrict__ hist,
+                                   const float2 *__restrict__ x, long long len, int hl)
 {
-  // single workgroup; two phases so that in-place shifting is safe
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float2 *tmp = reinterpret_cast<float2 *>(smem);
   for (int i = threadIdx.x; i < hl; i += blockDim.x) {
     const long long src = (long long)i + len;          // index into [hist ; x]
-    tmp[i] = src < hl ? hist[src] : x[src - hl];
+    hist_next[i] = src < hl ? hist[src] : x[src - hl];
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < hl; i += blockDim.x) hist[i] = tmp[i];
 }
 
 inline unsigned grid_for(long long n, int block) {
@@ -229,10 +330,10 @@ inline unsigned grid_for(long long n, int block) {
   return (unsigned)g;
 }
 
-template <int NCH>
+template <int NCH, int NOUT, int TC, bool LDS_TAPS, bool DB>
 hipError_t launch_fir(const sdk::ChanFeedArgs &a, const FirGeom &ge, size_t lds, unsigned ntiles, hipStream_t st)
 {
-  auto kern = chan_fir_kernel<NCH>;
+  auto kern = chan_fir_kernel<NCH, NOUT, TC, LDS_TAPS, DB>;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -241,7 +342,8 @@ hipError_t launch_fir(const sdk::ChanFeedArgs &a, const FirGeom &ge, size_t lds,
     attr_lds = lds;
   }
   hipLaunchKernelGGL(kern, dim3(ntiles), dim3(FIR_THREADS), lds, st,
-                     reinterpret_cast<const float2 *>(a.x), reinterpret_cast<const float2 *>(a.hist), a.len, a.n0,
+                     reinterpret_cast<const float2 *>(a.x), reinterpret_cast<const float2 *>(a.hist),
+                     reinterpret_cast<float2 *>(a.hist_next), a.len, a.n0,
                      reinterpret_cast<const float4 *>(a.g), a.dphase, a.phase0, ge, a.m_first, a.n_out,
                      reinterpret_cast<float2 *>(a.y), a.yv);
   return hipGetLastError();
@@ -270,34 +372,55 @@ hipError_t chan_modulate_taps(const float *h, int ntaps, const uint32_t *dphase,
 
 hipError_t chan_feed(const ChanFeedArgs &a, hipStream_t st)
 {
-  if (a.n_out <= 0) return hipSuccess;
+  if (a.n_out <= 0) return chan_update_hist(a.hist_next, a.hist, a.x, a.len, a.ntaps, st);
   FirGeom ge;
   ge.D = (int)a.D; ge.ntaps = a.ntaps; ge.nchan = a.nchan;
   ge.KD = ((a.ntaps - 1 + ge.D - 1) / ge.D) * ge.D;
-  // tile: as many 64-output sub-tiles as fit a ~48 KiB window (keeps >=3 workgroups per CU)
+  ge.PAD = (ge.D & 1) ? 0 : 1;                                      // D + PAD odd
+  static const int force_smem = getenv("SUAMD_FIR_SMEM_TAPS") ? atoi(getenv("SUAMD_FIR_SMEM_TAPS")) : 0;   // tuning knobs
+  static const int force_nout = getenv("SUAMD_FIR_NOUT") ? atoi(getenv("SUAMD_FIR_NOUT")) : 0;
+  const bool lds_taps = !force_smem && (size_t)a.nchan * a.ntaps * sizeof(float4) <= 16 * 1024;
+  const int nch = a.nchan >= 4 ? 4 : (a.nchan >= 2 ? 2 : 1);
+  const int ngrp = (a.nchan + nch - 1) / nch;
+  // outputs per lane: taps fetched once are reused for NOUT outputs (halves the scalar-cache tap
+  // traffic per fma: 40 -> 48 % of FP32 peak at C = D = 64) when there are plenty of channel groups
+  // to keep the waves busy and the window of 128 outputs stays small
+  int nout = force_nout ? force_nout : ((ngrp >= 8 && (size_t)(128 * ge.D + ge.KD) * sizeof(float2) <= 72 * 1024) ? 2 : 1);
+  if (nout != 1 && nout != 2) nout = 1;
+  const int gran = 64 * nout;
+  // tile: as many sub-tiles as fit a ~48 KiB window (keeps >= 3 workgroups per CU), but at least
+  // enough (sub-tile, channel-group) units to occupy the workgroup's 8 waves
   const int budget = 6144;                                         // samples
-  int mt = ((budget - ge.KD) / ge.D) / 64 * 64;
-  if (mt < 64) mt = 64;
+  int mt = ((budget - ge.KD) / ge.D) / gran * gran;
+  const int want = gran * ((FIR_THREADS / 64 + ngrp - 1) / ngrp);
+  if (mt < want && ((size_t)want * ge.D + ge.KD) * sizeof(float2) <= 72 * 1024) mt = want;
+  if (mt < gran) mt = gran;
   if (mt > 1024) mt = 1024;
-  // don't over-tile tiny problems
-  while (mt > 64 && (long long)(mt - 64) >= a.n_out) mt -= 64;
+  while (mt > gran && (long long)(mt - gran) >= a.n_out) mt -= gran;     // don't over-tile tiny problems
   ge.MT = mt;
-  ge.COLS = ge.MT + ge.KD / ge.D;
-  ge.LDW = ge.COLS | 1;                                            // odd pitch: conflict-free transposed writes
-  const size_t lds = (size_t)ge.D * ge.LDW * sizeof(float2);
+  ge.span = ge.MT * ge.D + ge.KD;
+  ge.lds_samples = ge.span + (ge.span / ge.D + 1) * ge.PAD;
+  size_t lds = (((size_t)ge.lds_samples + 1) & ~(size_t)1) * sizeof(float2);
+  if (lds_taps) lds += (size_t)a.nchan * a.ntaps * sizeof(float4);
   if (lds > 160 * 1024) return hipErrorInvalidValue;               // decimation too large for one tile
   const unsigned ntiles = (unsigned)((a.n_out + ge.MT - 1) / ge.MT);
-  if (a.nchan >= 4) return launch_fir<4>(a, ge, lds, ntiles, st);
-  if (a.nchan >= 2) return launch_fir<2>(a, ge, lds, ntiles, st);
-  return launch_fir<1>(a, ge, lds, ntiles, st);
+#define SD_FIR(NCH_, NOUT_, TC_, LT_, DB_) return launch_fir<NCH_, NOUT_, TC_, LT_, DB_>(a, ge, lds, ntiles, st)
+  if (lds_taps) {                                                   // taps from LDS: chunks double-buffered
+    if (nout == 2) { if (nch == 4) SD_FIR(4, 2, 2, true, true); if (nch == 2) SD_FIR(2, 2, 4, true, true); SD_FIR(1, 2, 8, true, true); }
+    if (nch == 4) SD_FIR(4, 1, 2, true, true); if (nch == 2) SD_FIR(2, 1, 4, true, true); SD_FIR(1, 1, 8, true, true);
+  }
+  // taps from scalar loads: 4 channels x 4 taps = 64 SGPRs per chunk, so no second chunk in flight
+  if (nout == 2) { if (nch == 4) SD_FIR(4, 2, 4, false, false); if (nch == 2) SD_FIR(2, 2, 4, false, true); SD_FIR(1, 2, 8, false, true); }
+  if (nch == 4) SD_FIR(4, 1, 4, false, false); if (nch == 2) SD_FIR(2, 1, 4, false, true); SD_FIR(1, 1, 8, false, true);
+#undef SD_FIR
 }
 
-hipError_t chan_update_hist(void *hist, const void *x, long long len, int ntaps, hipStream_t st)
+hipError_t chan_update_hist(void *hist_next, const void *hist, const void *x, long long len, int ntaps, hipStream_t st)
 {
   const int hl = ntaps - 1;
-  if (hl <= 0 || len <= 0) return hipSuccess;
-  hipLaunchKernelGGL(update_hist_kernel, dim3(1), dim3(256), (size_t)hl * sizeof(float2), st,
-                     reinterpret_cast<float2 *>(hist), reinterpret_cast<const float2 *>(x), len, hl);
+  if (hl <= 0) return hipSuccess;
+  hipLaunchKernelGGL(update_hist_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<float2 *>(hist_next),
+                     reinterpret_cast<const float2 *>(hist), reinterpret_cast<const float2 *>(x), len, hl);
   return hipGetLastError();
 }
 

@@ -29,6 +29,7 @@ hipError_t chan_modulate_taps(const float *h, int ntaps, const uint32_t *dphase,
 struct ChanFeedArgs {
   const void *x;        // input block (device), len samples
   const void *hist;     // ntaps-1 samples preceding x[0] (device)
+  void       *hist_next; // receives the history for the next block (ping-pong with hist)
   long long   len;
   uint64_t    n0;       // absolute index of x[0]
   const void *g;        // float4 [nchan][ntaps] modulated taps (re, re, -im, im)
@@ -42,7 +43,7 @@ struct ChanFeedArgs {
   View        yv;
 };
 hipError_t chan_feed(const ChanFeedArgs &a, hipStream_t st);
-hipError_t chan_update_hist(void *hist, const void *x, long long len, int ntaps, hipStream_t st);
+hipError_t chan_update_hist(void *hist_next, const void *hist, const void *x, long long len, int ntaps, hipStream_t st);
 
 // ---- loops.hip ----
 hipError_t quad_demod_batch(const void *x, View xv, void *y, View yv, int nchan, long long len,

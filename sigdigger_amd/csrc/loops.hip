@@ -65,15 +65,18 @@ __device__ __forceinline__ void stream_row(const T *__restrict__ x, long long ms
 // ---------------------------------------------------------------------------------------
 // T5: QuadDemodTask::work  dest[p] = j/pi * arg(x[p] conj(x[p-1]))
 __global__ void quad_demod_kernel(const float2 *__restrict__ x, sdk::View xv, float2 *__restrict__ y, sdk::View yv,
-                                  long long len, const float2 *__restrict__ prev, int first,
+                                  int nchan, long long len, const float2 *__restrict__ prev, int first,
                                   float2 *__restrict__ prev_out)
 {
-  const int c = blockIdx.y;
-  const float2 *xr = x + (long long)c * xv.cs;
-  float2 *yr = y + (long long)c * yv.cs;
   const float k = 0.318309886183790671538f;
-  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < len;
-       p += (long long)gridDim.x * blockDim.x) {
+  const long long total = len * nchan;
+  const bool time_major = xv.cs < xv.ms;                 // consecutive threads follow the unit stride
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    long long p; int c;
+    if (time_major) { p = t / nchan; c = (int)(t - p * nchan); }
+    else            { c = (int)(t / len); p = t - (long long)c * len; }
+    const float2 *xr = x + (long long)c * xv.cs;
     const float2 v = xr[p * xv.ms];
     float2 out;
     if (p == 0 && first) {
@@ -83,7 +86,7 @@ __global__ void quad_demod_kernel(const float2 *__restrict__ x, sdk::View xv, fl
       const c32 d = sd::cmul_conj(c32{v.x, v.y}, c32{pv.x, pv.y});
       out = float2{0.0f, k * sd::atan2_(d.im, d.re)};
     }
-    yr[p * yv.ms] = out;
+    y[(long long)c * yv.cs + p * yv.ms] = out;
     if (prev_out != nullptr && p == len - 1) prev_out[c] = v;
   }
 }
@@ -500,10 +503,8 @@ hipError_t quad_demod_batch(const void *x, View xs, void *y, View ys, int nchan,
                             const void *prev, int first, void *prev_out, hipStream_t st)
 {
   if (len <= 0 || nchan <= 0) return hipSuccess;
-  unsigned gx = grid_for(len, 256);
-  if ((long long)gx * nchan > 8192) gx = (unsigned)((8192 + nchan - 1) / nchan);
-  hipLaunchKernelGGL(quad_demod_kernel, dim3(gx, (unsigned)nchan), dim3(256), 0, st,
-                     reinterpret_cast<const float2 *>(x), xs, reinterpret_cast<float2 *>(y), ys, len,
+  hipLaunchKernelGGL(quad_demod_kernel, dim3(grid_for(len * nchan, 256)), dim3(256), 0, st,
+                     reinterpret_cast<const float2 *>(x), xs, reinterpret_cast<float2 *>(y), ys, nchan, len,
                      reinterpret_cast<const float2 *>(prev), first, reinterpret_cast<float2 *>(prev_out));
   return hipGetLastError();
 }
