@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (c2, c3)")
     ap.add_argument("--cpu-samples", type=int, default=1 << 23)
+    ap.add_argument("--isolated", action="store_true",
+                    help="after the timed region also time the FIR and PSD kernels alone on an idle GPU")
     args = ap.parse_args()
 
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ       # under torch.distributed.run
@@ -272,6 +274,31 @@ def main():
             "stream_rate_MSps": round(value / world, 3),
             "roofline": roof,
         }
+        if args.isolated:
+            # the same launches on an otherwise idle chip (in the pipeline they share the GPU with the
+            # AGC / Costas / Gardner kernels of neighbouring blocks)
+            iso = {}
+            x = torch.randn(L, dtype=torch.complex64, device=dev)
+            for name, fn in (("fir", lambda: pipe.chan.feed(x, out=pipe.y[0])),
+                             ("psd", (lambda: pipe.psd.feed(x, nframes=pipe.nframes, navg=pipe.navg,
+                                                            scale=1.0 / pipe.psd_size, out=pipe.psd_out))
+                              if pipe.do_psd else None)):
+                if fn is None:
+                    continue
+                fn()
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                iso[name + "_ms"] = round(e0.elapsed_time(e1) / 10, 4)
+            iso["fir_hbm_frac"] = round(fir_bytes / (iso["fir_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            iso["fir_fp32_frac"] = round(fir_flops / (iso["fir_ms"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
+            if "psd_ms" in iso:
+                iso["psd_hbm_frac"] = round(psd_bytes / (iso["psd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            roof["isolated"] = iso
         if world == 1 and not args.no_extra:
             extra = {}
             for w in ("c2", "c3"):

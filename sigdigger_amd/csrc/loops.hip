@@ -385,21 +385,33 @@ __global__ void agc_mag_kernel(const float2 *__restrict__ x, sdk::View xv, int n
   }
 }
 
-__global__ void agc_peak_kernel(const float *__restrict__ db, const float *__restrict__ hist, int nchan,
-                                long long len, int H, float *__restrict__ peak)
+// tile = 64 channels x TM time steps; the TM + H - 1 magnitudes each channel needs are staged once
+// in LDS (coalesced rows of 64 floats), then every output takes its maximum over H LDS reads
+// (instead of H global loads per output).  max() is exact and order-independent.
+constexpr int PEAK_TM = 128;
+__global__ __launch_bounds__(256) void agc_peak_kernel(const float *__restrict__ db, const float *__restrict__ hist,
+                                                       int nchan, long long len, int H, float *__restrict__ peak)
 {
-  const long long total = len * nchan;
-  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
-       t += (long long)gridDim.x * blockDim.x) {
-    const long long m = t / nchan;
-    const int c = (int)(t - m * nchan);
-    float pk = db[t];
-    for (int i = 1; i < H; ++i) {
-      const long long idx = m - i;
-      const float v = idx >= 0 ? db[idx * nchan + c] : hist[(idx + (H - 1)) * nchan + c];
-      pk = pk > v ? pk : v;
-    }
-    peak[t] = pk;
+  __shared__ float tile[PEAK_TM + 63][64];
+  const long long m0 = (long long)blockIdx.x * PEAK_TM;
+  const int c0 = blockIdx.y * 64;
+  const int lane = threadIdx.x & 63, rowt = threadIdx.x >> 6;          // 4 rows of 64 channels per pass
+  const int c = c0 + lane;
+  const int rows = PEAK_TM + H - 1;                                    // tile row r <-> time m0 - (H-1) + r
+  for (int r = rowt; r < rows; r += 4) {
+    const long long m = m0 - (H - 1) + r;
+    float v = -__builtin_inff();
+    if (c < nchan && m < len) v = m >= 0 ? db[m * nchan + c] : hist[(m + (H - 1)) * nchan + c];
+    tile[r][lane] = v;
+  }
+  __syncthreads();
+  if (c >= nchan) return;
+  for (int t = rowt; t < PEAK_TM; t += 4) {
+    const long long m = m0 + t;
+    if (m >= len) break;
+    float pk = tile[t + H - 1][lane];
+    for (int i = 1; i < H; ++i) { const float v = tile[t + H - 1 - i][lane]; pk = pk > v ? pk : v; }
+    peak[m * nchan + c] = pk;
   }
 }
 
@@ -588,7 +600,8 @@ hipError_t agc_feed(const AgcParams &p, const AgcState &s, int nchan, const void
   float *db = scratch, *peak = scratch + total;
   const int H = (int)p.mag_history_size;
   hipLaunchKernelGGL(agc_mag_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, xx, xv, nchan, len, db);
-  hipLaunchKernelGGL(agc_peak_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, db, s.mag_history, nchan, len, H, peak);
+  hipLaunchKernelGGL(agc_peak_kernel, dim3((unsigned)((len + PEAK_TM - 1) / PEAK_TM), (unsigned)((nchan + 63) / 64)), dim3(256), 0, st,
+                     db, s.mag_history, nchan, len, H, peak);
   hipLaunchKernelGGL(agc_level_kernel, dim3((nchan + 63) / 64), dim3(64), 0, st, p, s, nchan, len, peak);
   hipLaunchKernelGGL(agc_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, p, s.delay_line, nchan, xx, xv,
                      yy, yv, len, peak);
