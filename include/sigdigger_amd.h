@@ -79,7 +79,8 @@ enum suamd_psd_mode {
   SUAMD_PSD_DB_SHIFTED = 1  /* PSDMessage ctor fused in: fftshift + SU_POWER_DB             */
 };
 /* Plan for detector_params.window_size / .window (Suscan/AnalyzerParams.cpp:53-71).
- * window_size: power of two, 512..16384 in this round. */
+ * window_size: power of two, 512..1048576 (FFTWidget's 2^9..2^20, Default/FFT/FFTWidget.cpp:350-351);
+ * up to 16384 the frame stays in LDS, larger frames go pass by pass through HBM. */
 SUAMD_API suamd_psd_t *suamd_psd_new(suamd_ctx_t *ctx, unsigned window_size, int window_type);
 SUAMD_API void         suamd_psd_destroy(suamd_psd_t *psd);
 /* For o < nframes/navg:

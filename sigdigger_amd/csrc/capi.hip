@@ -230,8 +230,8 @@ suamd_psd_t *suamd_psd_new(suamd_ctx_t *ctx, unsigned n, int window_type)
   if (!ctx) { set_err("null context"); return nullptr; }
   unsigned log2n = 0;
   while ((1u << log2n) < n) ++log2n;
-  if ((1u << log2n) != n || log2n < 9 || log2n > 14) {
-    set_err("window_size %u unsupported (power of two, 512..16384)", n);
+  if ((1u << log2n) != n || log2n < 9 || log2n > 20) {
+    set_err("window_size %u unsupported (power of two, 512..1048576)", n);
     return nullptr;
   }
   if (window_type < SUAMD_WINDOW_NONE || window_type > SUAMD_WINDOW_BLACKMANN_HARRIS) {
@@ -241,8 +241,9 @@ suamd_psd_t *suamd_psd_new(suamd_ctx_t *ctx, unsigned n, int window_type)
   HIP_TRY(hipSetDevice(ctx->device), nullptr);
   std::vector<float> w(n);
   make_window(window_type, w);
-  std::vector<float> tw(2 * (size_t)n);
-  for (unsigned i = 0; i < n; ++i) {
+  const unsigned ntw = log2n <= 14 ? n : 1;          // the in-LDS kernels use an N-entry twiddle table
+  std::vector<float> tw(2 * (size_t)ntw);
+  for (unsigned i = 0; i < ntw; ++i) {
     const double ang = -2.0 * kPi * (double)i / (double)n;
     tw[2 * i] = (float)std::cos(ang);
     tw[2 * i + 1] = (float)std::sin(ang);
@@ -276,6 +277,16 @@ SUBOOL suamd_psd_feed(suamd_psd_t *p, const suamd_complex *d_x, SUSCOUNT nframes
   if (navg == 0) { set_err("navg must be >= 1"); return SU_FALSE; }
   if (mode != SUAMD_PSD_LINEAR && mode != SUAMD_PSD_DB_SHIFTED) { set_err("bad mode %d", mode); return SU_FALSE; }
   const long long nout = (long long)(nframes / navg);
+  if (p->log2n > 14) {
+    // FFTWidget offers 2^9..2^20 (Default/FFT/FFTWidget.cpp:350-351) and the scanner uses
+    // nextPow2(fs / 1 kHz) (Panoramic/Scanner.cpp:323): frames beyond the LDS go pass by pass through HBM
+    const size_t cb = sizeof(suamd_complex) * (size_t)p->n;
+    if (!p->partial.reserve(2 * cb + sizeof(float) * (size_t)p->n)) { set_err("scratch allocation failed"); return SU_FALSE; }
+    char *base = static_cast<char *>(p->partial.p);
+    HIP_TRY(sdk::psd_frames_large((int)p->log2n, d_x, (long long)hop, (int)navg, p->d_window, scale, mode, d_out, nout,
+                                  base, base + cb, reinterpret_cast<float *>(base + 2 * cb), as_stream(stream)), SU_FALSE);
+    return SU_TRUE;
+  }
   const int S = sdk::psd_split(nout, (int)navg);
   float *partial = nullptr;
   if (S > 1) {

@@ -192,6 +192,32 @@ __global__ __launch_bounds__(256) void centroid_kernel(const float2 *__restrict_
   if (threadIdx.x == 0) { res[0] = sre[0]; res[1] = sim[0]; res[2] = sdisp[0]; res[3] = (double)smaxval; res[4] = total; }
 }
 
+// large PSD frames (N > 16384): buf = window .* frame
+__global__ void frame_window_kernel(const float2 *__restrict__ x, const float *__restrict__ window, long long n,
+                                    float2 *__restrict__ buf)
+{
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float2 v = x[i];
+    const float w = window[i];
+    buf[i] = float2{v.x * w, v.y * w};
+  }
+}
+
+// acc[i] (+)= |X[i]|^2 ; on the last frame of an output: scale, optional fftshift + dB
+__global__ void frame_power_kernel(const float2 *__restrict__ X, long long n, float *__restrict__ acc, int first,
+                                   int last, float sc, int mode, float *__restrict__ out)
+{
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float2 v = X[i];
+    float p = v.x * v.x + v.y * v.y;
+    if (!first) p += acc[i];
+    if (!last) { acc[i] = p; continue; }
+    p *= sc;
+    if (mode == 0) out[i] = p;
+    else out[(i + n / 2) & (n - 1)] = 10.0f * log10f(p + 1e-8f);
+  }
+}
+
 inline unsigned grid_for(long long n, int block) {
   long long g = (n + block - 1) / block;
   if (g > 4096) g = 4096;
@@ -226,6 +252,28 @@ hipError_t fft_forward(void *a, void *b, int log2n, void **result, hipStream_t s
     cf *t = src; src = dst; dst = t;
   }
   *result = src;
+  return hipGetLastError();
+}
+
+// PSD of frames too large for the in-LDS kernel: window -> Stockham passes through HBM -> power,
+// navg frames accumulated per output.  a, b: ping-pong buffers of n complex; acc: n floats.
+hipError_t psd_frames_large(int log2n, const void *x, long long hop, int navg, const float *window, float scale,
+                            int mode, float *out, long long nout, void *a, void *b, float *acc, hipStream_t st)
+{
+  const long long n = 1ll << log2n;
+  const float2 *xx = reinterpret_cast<const float2 *>(x);
+  for (long long o = 0; o < nout; ++o) {
+    for (int f = 0; f < navg; ++f) {
+      hipLaunchKernelGGL(frame_window_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, xx + (o * navg + f) * hop,
+                         window, n, reinterpret_cast<float2 *>(a));
+      void *res = nullptr;
+      hipError_t e = fft_forward(a, b, log2n, &res, st);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(frame_power_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st,
+                         reinterpret_cast<const float2 *>(res), n, acc, f == 0, f == navg - 1,
+                         scale / (float)navg, mode, out + o * n);
+    }
+  }
   return hipGetLastError();
 }
 

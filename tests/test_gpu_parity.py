@@ -82,6 +82,23 @@ def test_psd_windows_and_averaging(ctx, sdo, window):
     assert np.all(err < PSD_TOL), err
 
 
+@pytest.mark.parametrize("n,nframes,navg", [(32768, 4, 2), (1 << 17, 3, 1), (1 << 20, 2, 2)])
+def test_psd_large_frames(ctx, sdo, n, nframes, navg):
+    """FFT sizes beyond the LDS (scanner: nextPow2(fs/1 kHz); FFTWidget: up to 2^20)"""
+    x = synth.tone_noise(n * nframes, f_rel=0.2501, sigma2=1e-2, seed=n % 1000)
+    win = sdo.window(4, n)
+    ref = sdo.psd_frames(x, nframes, n, n, win, navg=navg, scale=1.0 / n)
+    psd = engine.PSD(ctx, n, engine.WINDOW_BLACKMANN_HARRIS)
+    out = host(psd.feed(dev(x), nframes=nframes, navg=navg, scale=1.0 / n))
+    assert out.shape == ref.shape
+    err = np.max(np.abs(out - ref), axis=1) / np.max(ref, axis=1)
+    assert np.all(err < PSD_TOL), err
+    assert np.array_equal(np.argmax(out, axis=1), np.argmax(ref, axis=1))
+    db = host(psd.feed(dev(x), nframes=nframes, navg=navg, scale=1.0 / n, mode=engine.PSD_DB_SHIFTED))
+    # dB of the weakest bins amplifies the binary32 FFT error floor (1e-5 of the peak is ~40 dB above it)
+    assert np.max(np.abs(db - np.stack([sdo.psd_shift_db(f) for f in ref]))) < 5 * DB_TOL
+
+
 def test_psd_split_frame_accumulation(ctx, sdo):
     """many frames averaged into few outputs: the frames of one output are split over several
     workgroups and reduced in a fixed order (deterministic, run-to-run identical)."""
