@@ -163,6 +163,12 @@ __global__ __launch_bounds__(FIR_THREADS) void chan_fir_kernel(const float2 *__r
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2 *win = reinterpret_cast<float2 *>(smem);
+  // The recurrence kernels (Costas / AGC / Gardner) keep one wavefront resident for milliseconds on
+  // other streams.  That wave is the oldest on its SIMD and wins issue arbitration, so the two
+  // workgroups of this grid that share its CU ran 3.5x longer and, the grid being a single resident
+  // round, so did the whole kernel (125 -> 370 us, tools/corun3.py).  Raising the issue priority of
+  // these waves puts the straggler behind the throughput kernel instead.
+  __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x;
   const int D = ge.D, T = ge.ntaps, PAD = ge.PAD;
   const long long tile_m0 = (long long)blockIdx.x * ge.MT;           // relative to m_first

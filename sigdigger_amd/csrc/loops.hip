@@ -68,6 +68,7 @@ __global__ void quad_demod_kernel(const float2 *__restrict__ x, sdk::View xv, fl
                                   int nchan, long long len, const float2 *__restrict__ prev, int first,
                                   float2 *__restrict__ prev_out)
 {
+  __builtin_amdgcn_s_setprio(3);   // ahead of the resident recurrence wavefronts (see chan_fir_kernel)
   const float k = 0.318309886183790671538f;
   const long long total = len * nchan;
   const bool time_major = xv.cs < xv.ms;                 // consecutive threads follow the unit stride
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(64) void clock_kernel(sdk::ClockParams p, sdk::Cloc
 __global__ void agc_mag_kernel(const float2 *__restrict__ x, sdk::View xv, int nchan, long long len,
                                float *__restrict__ db)
 {
+  __builtin_amdgcn_s_setprio(3);   // ahead of the resident recurrence wavefronts (see chan_fir_kernel)
   const long long total = len * nchan;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
@@ -392,6 +394,7 @@ constexpr int PEAK_TM = 128;
 __global__ __launch_bounds__(256) void agc_peak_kernel(const float *__restrict__ db, const float *__restrict__ hist,
                                                        int nchan, long long len, int H, float *__restrict__ peak)
 {
+  __builtin_amdgcn_s_setprio(3);   // ahead of the resident recurrence wavefronts (see chan_fir_kernel)
   __shared__ float tile[PEAK_TM + 63][64];
   const long long m0 = (long long)blockIdx.x * PEAK_TM;
   const int c0 = blockIdx.y * 64;
@@ -451,6 +454,7 @@ __global__ void agc_apply_kernel(sdk::AgcParams p, const float *__restrict__ del
                                  const float2 *__restrict__ x, sdk::View xv, float2 *__restrict__ y, sdk::View yv,
                                  long long len, const float *__restrict__ lvl)
 {
+  __builtin_amdgcn_s_setprio(3);   // ahead of the resident recurrence wavefronts (see chan_fir_kernel)
   const long long total = len * nchan;
   const long long delay = p.delay_line_size;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;

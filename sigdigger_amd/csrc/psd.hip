@@ -231,6 +231,7 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : (THREADS >= 128 ? T
                                                       const cf *__restrict__ tw, float scale, int mode,
                                                       float *__restrict__ out, float *__restrict__ partial)
 {
+  __builtin_amdgcn_s_setprio(3);   // ahead of the resident recurrence wavefronts (see chan_fir_kernel)
   using PL = Plan<LOG2N>;
   constexpr int N  = 1 << LOG2N;
   constexpr int E  = N / THREADS;
