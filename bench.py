@@ -193,6 +193,57 @@ def run_workload(name, args, rank, world, dev, ctx, dist):
     return cfg, L, dt, stages, fn_rank, pipe
 
 
+def run_c5(args, dev, ctx, log2_file=30, N=8192, tile=256):
+    """C5: panoramic-scanner sweep over a captured file resident in HBM -- every dwell is `tile` frames of
+    N points averaged into one shifted-dB PSD message (PSDMessage.cpp:26-39 fused), fed to the SpectrumView
+    at the dwell's centre frequency (Panoramic/Scanner.cpp:239-293).  One step = one pass over the file."""
+    total = 1 << log2_file
+    x = torch.empty(total, dtype=torch.complex64, device=dev)
+    xr = torch.view_as_real(x)
+    chunk = 1 << 26
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    for o in range(0, total, chunk):
+        xr[o:o + chunk].normal_(generator=g)
+    dwells = total // (N * tile)
+    psd = engine.PSD(ctx, N)                     # Blackman-Harris (the analyzer default)
+    frames = torch.empty((dwells, N), dtype=torch.float32, device=dev)
+    fs, rel = 20e6, 0.5
+    view = engine.SpectrumView(ctx)
+    f0 = 100e6
+    view.set_range(f0, f0 + dwells * fs * rel)
+    view.set_fft(fs, rel)
+    centers = f0 + (np.arange(dwells) + 0.5) * fs * rel
+
+    def step(ev=None):
+        if ev: ev[0].record()
+        psd.feed(x, nframes=dwells * tile, hop=N, navg=tile, scale=1.0 / N, mode=engine.PSD_DB_SHIFTED, out=frames)
+        if ev: ev[1].record()
+        view.feed_sweep(frames, centers)
+        if ev: ev[2].record()
+
+    steps, warm = max(3, args.steps // 4), 1
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize(dev)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(evs[k])
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    psd_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
+    view_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / steps
+    psd_bytes = 8.0 * total + 4.0 * N * dwells
+    del x
+    return {"workload": f"C5: panoramic sweep over a {total / 1e9:.2f} GS capture in HBM, {dwells} dwells x {tile} x "
+                        f"{N}-pt frames (Blackman-Harris, averaged, shift+dB fused) -> SpectrumView",
+            "value_MSps": round(total * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+            "stage_ms": {"psd": round(psd_ms, 4), "specview": round(view_ms, 4)},
+            "psd_roofline": {"bound": "hbm", "achieved": round(psd_bytes / (psd_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(psd_bytes / (psd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "algorithmic_bytes_per_launch": psd_bytes}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,7 +252,7 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--block", type=int, default=22, help="log2 of the IQ block length (samples)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (c2, c3)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (c2, c3, c5)")
     ap.add_argument("--cpu-samples", type=int, default=1 << 23)
     ap.add_argument("--isolated", action="store_true",
                     help="after the timed region also time the FIR and PSD kernels alone on an idle GPU")
@@ -310,6 +361,7 @@ def main():
                 extra[w] = {"workload": c2["desc"], "value_MSps": round(L2 * a2.steps / dt2 / 1e6, 3),
                             "ms_per_step": round(dt2 / a2.steps * 1e3, 4),
                             "stage_ms": {k: round(v, 4) for k, v in st2.items()}}
+            extra["c5"] = run_c5(args, dev, ctx)
             out["other_workloads"] = extra
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_samples, fn_rank, os.cpu_count() or 1)

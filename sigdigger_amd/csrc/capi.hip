@@ -836,6 +836,8 @@ struct suamd_specview {
   float fftRelBw;
   unsigned spectrumSize;
   float *d_psd, *d_accum, *d_count;
+  sdk::SpecViewLinear *d_geom = nullptr;      // per-frame geometry of a batched sweep
+  size_t geom_cap = 0;
 };
 
 static unsigned next_pow2_u(unsigned n) { unsigned i = 1; while (i < n) i <<= 1; return i; }
@@ -871,6 +873,7 @@ void suamd_specview_destroy(suamd_specview_t *v)
   if (v->d_psd) hipFree(v->d_psd);
   if (v->d_accum) hipFree(v->d_accum);
   if (v->d_count) hipFree(v->d_count);
+  if (v->d_geom) hipFree(v->d_geom);
   delete v;
 }
 
@@ -899,32 +902,44 @@ SUFLOAT *suamd_specview_array(suamd_specview_t *v, int which)
   return which == 0 ? v->d_psd : (which == 1 ? v->d_accum : (which == 2 ? v->d_count : nullptr));
 }
 
+static bool specview_is_linear(const suamd_specview *v, double freqMin, double freqMax)
+{
+  const double fftCount = (freqMax - freqMin) / v->freqRange;          // Scanner.cpp:247
+  return fftCount * v->spectrumSize >= 2;
+}
+
+// feedLinearMode, Scanner.cpp:126-151 (host side: the per-frame geometry)
+static sdk::SpecViewLinear specview_linear_geom(const suamd_specview *v, SUSCOUNT psdSize, double freqMin, double freqMax,
+                                                SUBOOL adjustSides)
+{
+  double inpBw, bw, freqSkip, fftCount, bins, pos;
+  int skip;
+  sdk::SpecViewLinear g;
+  inpBw = freqMax - freqMin;
+  skip = adjustSides ? static_cast<int>(.5f * (1 - v->fftRelBw) * psdSize) : 0;
+  freqSkip = static_cast<double>(skip) / psdSize * inpBw;
+  bw = inpBw - 2 * freqSkip;
+  fftCount = static_cast<double>(v->freqRange / bw);
+  bins = v->spectrumSize / fftCount;
+  g.srcBinW = static_cast<double>(inpBw) / psdSize;
+  g.dstBinW = static_cast<double>(v->freqRange) / v->spectrumSize;
+  g.delta = g.dstBinW / g.srcBinW;
+  pos = static_cast<double>(freqSkip + freqMin - v->freqMin) / (v->freqRange);
+  pos *= v->spectrumSize;
+  g.j0 = pos > 0 ? static_cast<int>(pos) : 0;
+  g.k = pos + bins < v->spectrumSize ? static_cast<int>(pos + bins) : (int)v->spectrumSize;
+  g.viewFreqMin = v->freqMin; g.freqMin = freqMin; g.psdSize = (int)psdSize;
+  return g;
+}
+
 SUBOOL suamd_specview_feed(suamd_specview_t *v, const SUFLOAT *d_psd, const SUFLOAT *d_count, SUSCOUNT psdSize,
                            SUFREQ freqMin, SUFREQ freqMax, SUBOOL adjustSides, void *stream)
 {
   if (!v || !d_psd) { set_err("null argument"); return SU_FALSE; }
   if (psdSize == 0 || psdSize > 0x7fffffff || !(v->freqRange > 0)) { set_err("bad frame size / range not set"); return SU_FALSE; }
   hipStream_t st = as_stream(stream);
-  const double fftCount0 = (freqMax - freqMin) / v->freqRange;          // Scanner.cpp:247
-  if (fftCount0 * v->spectrumSize >= 2) {
-    // feedLinearMode, Scanner.cpp:126-151 (host side: the per-frame geometry)
-    double inpBw, bw, freqSkip, fftCount, bins, pos;
-    int skip;
-    sdk::SpecViewLinear g;
-    inpBw = freqMax - freqMin;
-    skip = adjustSides ? static_cast<int>(.5f * (1 - v->fftRelBw) * psdSize) : 0;
-    freqSkip = static_cast<double>(skip) / psdSize * inpBw;
-    bw = inpBw - 2 * freqSkip;
-    fftCount = static_cast<double>(v->freqRange / bw);
-    bins = v->spectrumSize / fftCount;
-    g.srcBinW = static_cast<double>(inpBw) / psdSize;
-    g.dstBinW = static_cast<double>(v->freqRange) / v->spectrumSize;
-    g.delta = g.dstBinW / g.srcBinW;
-    pos = static_cast<double>(freqSkip + freqMin - v->freqMin) / (v->freqRange);
-    pos *= v->spectrumSize;
-    g.j0 = pos > 0 ? static_cast<int>(pos) : 0;
-    g.k = pos + bins < v->spectrumSize ? static_cast<int>(pos + bins) : (int)v->spectrumSize;
-    g.viewFreqMin = v->freqMin; g.freqMin = freqMin; g.psdSize = (int)psdSize;
+  if (specview_is_linear(v, freqMin, freqMax)) {
+    const sdk::SpecViewLinear g = specview_linear_geom(v, psdSize, freqMin, freqMax, adjustSides);
     HIP_TRY(sdk::specview_feed_linear(g, d_psd, d_count, v->d_accum, v->d_count, st), SU_FALSE);
   } else {
     // feedHistogramMode, Scanner.cpp:194-236
@@ -950,12 +965,41 @@ SUBOOL suamd_specview_feed_sweep(suamd_specview_t *v, const SUFLOAT *d_psd, SUSC
                                  const SUFREQ *center, SUBOOL adjustSides, void *stream)
 {
   if (!v || !d_psd || !center) { set_err("null argument"); return SU_FALSE; }
-  for (SUSCOUNT f = 0; f < nframes; ++f) {
-    // SpectrumView::feed(psd, count, size, center, adjust), Scanner.cpp:258-273
-    if (!suamd_specview_feed(v, d_psd + f * psdSize, nullptr, psdSize, center[f] - v->fftBandwidth / 2,
-                             center[f] + v->fftBandwidth / 2, adjustSides, stream))
-      return SU_FALSE;
+  if (nframes == 0) return SU_TRUE;
+  if (psdSize == 0 || psdSize > 0x7fffffff || nframes > 0x7fffffff || !(v->freqRange > 0)) {
+    set_err("bad frame size / range not set"); return SU_FALSE;
   }
+  // SpectrumView::feed(psd, count, size, center, adjust), Scanner.cpp:258-273, once per frame
+  bool all_linear = true;
+  for (SUSCOUNT f = 0; f < nframes && all_linear; ++f)
+    all_linear = specview_is_linear(v, center[f] - v->fftBandwidth / 2, center[f] + v->fftBandwidth / 2);
+  if (!all_linear) {
+    for (SUSCOUNT f = 0; f < nframes; ++f) {
+      if (!suamd_specview_feed(v, d_psd + f * psdSize, nullptr, psdSize, center[f] - v->fftBandwidth / 2,
+                               center[f] + v->fftBandwidth / 2, adjustSides, stream))
+        return SU_FALSE;
+    }
+    return SU_TRUE;
+  }
+  // all frames are linear-mode feeds: one launch replays feed + count-cap for every frame in order,
+  // then interpolate() once (its output after the earlier frames would have been overwritten anyway)
+  hipStream_t st = as_stream(stream);
+  HIP_TRY(hipSetDevice(v->ctx->device), SU_FALSE);
+  std::vector<sdk::SpecViewLinear> geom(nframes);
+  for (SUSCOUNT f = 0; f < nframes; ++f)
+    geom[f] = specview_linear_geom(v, psdSize, center[f] - v->fftBandwidth / 2, center[f] + v->fftBandwidth / 2, adjustSides);
+  if (v->geom_cap < nframes) {
+    if (v->d_geom) { HIP_TRY(hipStreamSynchronize(st), SU_FALSE); hipFree(v->d_geom); v->d_geom = nullptr; v->geom_cap = 0; }
+    HIP_TRY(hipMalloc(&v->d_geom, nframes * sizeof(sdk::SpecViewLinear)), SU_FALSE);
+    v->geom_cap = nframes;
+  }
+  HIP_TRY(hipMemcpyAsync(v->d_geom, geom.data(), nframes * sizeof(sdk::SpecViewLinear), hipMemcpyHostToDevice, st), SU_FALSE);
+  HIP_TRY(hipStreamSynchronize(st), SU_FALSE);       // geom is a stack-lifetime host buffer
+  // d_psd doubles as the snapshot of the counts before the sweep (neighbour validity)
+  HIP_TRY(hipMemcpyAsync(v->d_psd, v->d_count, sizeof(float) * v->spectrumSize, hipMemcpyDeviceToDevice, st), SU_FALSE);
+  HIP_TRY(sdk::specview_sweep_linear(v->d_geom, (int)nframes, d_psd, (long long)psdSize, v->d_psd, v->d_accum, v->d_count,
+                                     (int)v->spectrumSize, st), SU_FALSE);
+  HIP_TRY(sdk::specview_interpolate(v->d_psd, v->d_accum, v->d_count, (int)v->spectrumSize, st), SU_FALSE);
   return SU_TRUE;
 }
 

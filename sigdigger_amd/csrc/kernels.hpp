@@ -98,6 +98,9 @@ hipError_t specview_feed_linear(const SpecViewLinear &g, const float *psd, const
                                 float *cnt, hipStream_t st);
 hipError_t specview_feed_hist(const SpecViewHist &g, const float *psd, float *accum, float *cnt, hipStream_t st);
 hipError_t specview_interpolate(float *psd, float *accum, float *cnt, int n, hipStream_t st);
+// nframes linear-mode feeds (each followed by the count-cap reset of interpolate()) in one launch
+hipError_t specview_sweep_linear(const SpecViewLinear *d_geom, int nframes, const float *frames, long long frame_stride,
+                                 const float *cnt_before, float *accum, float *cnt, int n, hipStream_t st);
 
 // ---- fft.hip ----
 hipError_t fft_forward(void *a, void *b, int log2n, void **result, hipStream_t st);

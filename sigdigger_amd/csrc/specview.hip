@@ -45,6 +45,47 @@ __global__ void feed_linear_kernel(sdk::SpecViewLinear g, const float *__restric
   }
 }
 
+// A whole sweep of linear-mode feeds, one destination bin per thread.  The reference processes the
+// frames one after the other -- feedLinearMode then interpolate() -- and the only state interpolate()
+// changes is the count cap (count > 5 -> accum = mean, count = 1) of bins that do not end a gap, i.e.
+// whose left neighbour is valid.  A linear feed adds exactly 1 to the count of every bin it covers,
+// so "left neighbour valid" = it was valid before the sweep or one of the frames so far covered it:
+// every bin can replay the sweep on its own, in frame order, with the same binary32 operations.
+__global__ __launch_bounds__(256) void sweep_linear_kernel(const sdk::SpecViewLinear *__restrict__ geom, int nframes,
+                                                          const float *__restrict__ frames, long long frame_stride,
+                                                          const float *__restrict__ cntBefore,
+                                                          float *__restrict__ psdAccum, float *__restrict__ psdCount, int n)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float acc = psdAccum[j], cnt = psdCount[j];
+  bool left_valid = j > 0 ? cntBefore[j - 1] > .5f : true;       // snapshot: psdCount[j-1] is being rewritten
+  for (int f = 0; f < nframes; ++f) {
+    const sdk::SpecViewLinear g = geom[f];                      // wave-uniform: scalar loads
+    if (j - 1 >= g.j0 && j - 1 < g.k) left_valid = true;
+    if (j >= g.j0 && j < g.k) {
+      const float *__restrict__ psdData = frames + (long long)f * frame_stride;
+      const double freqJ = g.viewFreqMin + g.dstBinW * j;
+      const double srcBin = (freqJ - g.freqMin) / g.srcBinW;
+      int startBin = (int)srcBin;
+      int endBin = (int)(srcBin + g.delta);
+      const int psdSize = g.psdSize;
+      startBin = startBin < 0 ? 0 : (startBin > psdSize - 1 ? psdSize - 1 : startBin);
+      endBin = endBin < startBin + 1 ? startBin + 1 : (endBin > psdSize ? psdSize : endBin);
+      float a = 0, c = 0;
+      for (int i = startBin; i < endBin; i++) { a += psdData[i]; c += 1.0f; }
+      if (c > 0) { acc += a / c; cnt += 1; }
+    }
+    if (cnt > kCountMax && left_valid) {                        // interpolate(), Scanner.cpp:87-90
+      const float v = acc / cnt;
+      cnt = kCountReset;
+      acc = v * kCountReset;
+    }
+  }
+  psdAccum[j] = acc;
+  psdCount[j] = cnt;
+}
+
 __global__ void feed_hist_kernel(sdk::SpecViewHist g, const float *__restrict__ psdData,
                                  float *__restrict__ psdAccum, float *__restrict__ psdCount)
 {
@@ -154,6 +195,15 @@ hipError_t specview_feed_linear(const SpecViewLinear &g, const float *psd, const
   const int nb = g.k - g.j0;
   if (nb <= 0) return hipSuccess;
   hipLaunchKernelGGL(feed_linear_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, g, psd, count, accum, cnt);
+  return hipGetLastError();
+}
+
+hipError_t specview_sweep_linear(const SpecViewLinear *d_geom, int nframes, const float *frames, long long frame_stride,
+                                 const float *cnt_before, float *accum, float *cnt, int n, hipStream_t st)
+{
+  if (n <= 0 || nframes <= 0) return hipSuccess;
+  hipLaunchKernelGGL(sweep_linear_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_geom, nframes, frames, frame_stride,
+                     cnt_before, accum, cnt, n);
   return hipGetLastError();
 }
 

@@ -479,6 +479,33 @@ def test_specview_sweep_bit_exact(ctx, sdo, span, fs, nframes):
     assert_bits(psd[:sz], ref.psd[:sz], "psd (interpolated)")
 
 
+def test_specview_sweep_in_pieces_and_frame_by_frame(ctx, sdo):
+    """The one-launch sweep (feed + count cap of every frame replayed per bin) must equal the reference's
+    frame-by-frame feed/interpolate sequence also when the view already holds state: two half sweeps,
+    one GPU view fed frame by frame, and the oracle all agree bit for bit."""
+    n, nframes, fs, span, f0 = 4096, 64, 10e6, 60e6, 1e9
+    frames = _sweep_frames(sdo, ctx, nframes, n, seed=77)
+    fh = host(frames)
+    rng = np.random.default_rng(8)
+    centers = f0 + fs / 2 + rng.integers(0, 24, nframes) * (fs / 4)      # heavy revisiting: many cap resets
+    centers[40:52] = centers[39]
+    ref = sdo.SpectrumView(); ref.set_range(f0, f0 + span); ref.v.fftBandwidth = fs
+    a = engine.SpectrumView(ctx); a.set_range(f0, f0 + span); a.set_fft(fs, 0.5)
+    b = engine.SpectrumView(ctx); b.set_range(f0, f0 + span); b.set_fft(fs, 0.5)
+    for f in range(nframes):
+        ref.feed(fh[f], centers[f] - fs / 2, centers[f] + fs / 2, True)
+        b.feed(frames[f], centers[f] - fs / 2, centers[f] + fs / 2, True)
+    a.feed_sweep(frames[:29], centers[:29], True)
+    a.feed_sweep(frames[29:], centers[29:], True)
+    sz = a.spectrum_size
+    for name, view in (("pieces", a), ("frame by frame", b)):
+        psd, accum, count = view.arrays()
+        assert_bits(count[:sz], ref.count[:sz], f"psdCount ({name})")
+        assert_bits(accum[:sz], ref.accum[:sz], f"psdAccum ({name})")
+        assert_bits(psd[:sz], ref.psd[:sz], f"psd ({name})")
+    assert (ref.count[:sz] > 5).sum() >= 0 and (np.abs(ref.count[:sz] - 1.0) < 1e-6).any()
+
+
 def test_specview_histogram_mode_and_detail_counts(ctx, sdo):
     """frames narrower than two view bins take the histogram path (Scanner.cpp:187-237); a feed with a
     count array is the SpectrumView::feed(SpectrumView const &) merge (Scanner.cpp:275-285)."""
