@@ -23,11 +23,28 @@ typedef float cf __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
 __device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
-__device__ __forceinline__ cf mul_mj(cf a) { return cf{a.y, -a.x}; }          // a * (-j)
+// The rotations by -j / +j and the complex product are single VOP3P instructions once the operand
+// halves are picked with op_sel / op_sel_hi and negated with neg_lo / neg_hi; the compiler builds
+// the swapped / negated pair with v_mov + v_xor instead (a quarter of the loop's VALU work).
+__device__ __forceinline__ cf add_mj(cf t, cf d)          // t + (-j) d = (t.x + d.y, t.y - d.x)
+{
+  cf r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(t), "v"(d));
+  return r;
+}
+__device__ __forceinline__ cf sub_mj(cf t, cf d)          // t - (-j) d = (t.x - d.y, t.y + d.x)
+{
+  cf r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(t), "v"(d));
+  return r;
+}
 __device__ __forceinline__ cf cmul(cf a, cf b)
 {
-  // (a.x b.x - a.y b.y, a.x b.y + a.y b.x) = a.xx * b + a.yy * (-b.y, b.x)
-  return __builtin_elementwise_fma(a.yy, cf{-b.y, b.x}, a.xx * b);
+  // (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+  cf t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  return r;
 }
 
 // forward DFTs on registers, natural order in, natural order out (DIT, even/odd split)
@@ -35,12 +52,12 @@ __device__ __forceinline__ void dft2(cf &a, cf &b) { cf t = a; a = cadd(t, b); b
 
 __device__ __forceinline__ void dft4(cf &a0, cf &a1, cf &a2, cf &a3)
 {
-  cf t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mj(csub(a1, a3));
-  a0 = cadd(t0, t2); a1 = cadd(t1, t3); a2 = csub(t0, t2); a3 = csub(t1, t3);
+  cf t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), d = csub(a1, a3);
+  a0 = cadd(t0, t2); a1 = add_mj(t1, d); a2 = csub(t0, t2); a3 = sub_mj(t1, d);
 }
 
-__device__ __forceinline__ cf mul_w8_1(cf a) { return (a + mul_mj(a)) * 0.70710678118654752440f; }   // * (1 - j)/sqrt2
-__device__ __forceinline__ cf mul_w8_3(cf a) { return (mul_mj(a) - a) * 0.70710678118654752440f; }   // * (-1 - j)/sqrt2
+__device__ __forceinline__ cf mul_w8_1(cf a) { return add_mj(a, a) * 0.70710678118654752440f; }            // * (1 - j)/sqrt2
+__device__ __forceinline__ cf mul_w8_3(cf a) { return add_mj(-a, a) * 0.70710678118654752440f; }           // * (-1 - j)/sqrt2
 
 __device__ __forceinline__ void dft8(cf *v)
 {
@@ -49,11 +66,10 @@ __device__ __forceinline__ void dft8(cf *v)
   dft4(e0, e1, e2, e3);
   dft4(o0, o1, o2, o3);
   o1 = mul_w8_1(o1);
-  o2 = mul_mj(o2);
   o3 = mul_w8_3(o3);
   v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
   v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
-  v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+  v[2] = add_mj(e2, o2); v[6] = sub_mj(e2, o2);          // o2 * (-j) folded into the butterfly
   v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
 }
 
@@ -68,12 +84,14 @@ __device__ __forceinline__ void dft16(cf *v)
   o[1] = cmul(o[1], cf{ c1, -s1});
   o[2] = mul_w8_1(o[2]);
   o[3] = cmul(o[3], cf{ s1, -c1});
-  o[4] = mul_mj(o[4]);
   o[5] = cmul(o[5], cf{-s1, -c1});
   o[6] = mul_w8_3(o[6]);
   o[7] = cmul(o[7], cf{-c1, -s1});
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { v[i] = cadd(e[i], o[i]); v[i + 8] = csub(e[i], o[i]); }
+  for (int i = 0; i < 8; ++i) {
+    if (i == 4) { v[4] = add_mj(e[4], o[4]); v[12] = sub_mj(e[4], o[4]); }
+    else { v[i] = cadd(e[i], o[i]); v[i + 8] = csub(e[i], o[i]); }
+  }
 }
 
 template <int R> __device__ __forceinline__ void dftR(cf *v);
@@ -116,8 +134,10 @@ __device__ __forceinline__ void apply_twiddles(cf *v, const cf *__restrict__ tw,
 // Base twiddles of one thread: W^(k), W^(2k), W^(4k), W^(8k) for each of its butterflies in each
 // pass.  They depend on the lane id only, so they are loaded ONCE per workgroup (before the frame
 // loop) and stay in registers; the other powers are re-derived per frame (one complex product each).
+// (W^(4k), W^(8k) are squared from W^(2k) per frame: two instructions each, and 12 VGPRs fewer
+// than keeping them -- the kernel sits exactly at the 128-VGPR budget of two workgroups per CU)
 constexpr int MAXP = 4, MAXNB = 2;
-struct TwBase { cf w[MAXP][MAXNB][4]; };
+struct TwBase { cf w[MAXP][MAXNB][2]; };
 
 template <int LOG2N, int THREADS, int PASS>
 __device__ __forceinline__ void load_tw_base(TwBase &tb, const cf *__restrict__ tw, int tid)
@@ -134,8 +154,6 @@ __device__ __forceinline__ void load_tw_base(TwBase &tb, const cf *__restrict__ 
         const int idx = (j & (NS - 1)) << (LOG2N - NSL - RB);
         tb.w[PASS][b][0] = tw[idx & (N - 1)];
         if (R > 2) tb.w[PASS][b][1] = tw[(2 * idx) & (N - 1)];
-        if (R > 4) tb.w[PASS][b][2] = tw[(4 * idx) & (N - 1)];
-        if (R > 8) tb.w[PASS][b][3] = tw[(8 * idx) & (N - 1)];
       }
     }
     load_tw_base<LOG2N, THREADS, PASS + 1>(tb, tw, tid);
@@ -155,8 +173,8 @@ __device__ __forceinline__ void apply_twiddles_base(cf *v, const cf *base)
   cf w[R];
   w[1] = opaque(base[0]);
   if (R > 2) w[2] = opaque(base[1]);
-  if (R > 4) w[4] = opaque(base[2]);
-  if (R > 8) w[8] = opaque(base[3]);
+  if (R > 4) w[4] = cmul(w[2], w[2]);
+  if (R > 8) w[8] = cmul(w[4], w[4]);
   if (R > 2) w[3] = cmul(w[1], w[2]);
   if (R > 4) { w[5] = cmul(w[1], w[4]); w[6] = cmul(w[2], w[4]); w[7] = cmul(w[3], w[4]); }
   if (R > 8) {
@@ -184,11 +202,14 @@ __device__ __forceinline__ void fft_pass(cf *v /*[E]*/, cf *lds, const TwBase &t
 
   if (PASS > 0) {
     // gather this pass's operands: element q of butterfly j sits at j + q*N/R
+    // (N/R is a multiple of 16, so lpad(j + q*N/R) = lpad(j) + q*lpad(N/R): one base address and
+    // immediate offsets)
+    static_assert((N / R) % 16 == 0, "gather offsets are compile-time constants only for N/R % 16 == 0");
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const int j = tid + b * THREADS;
+      const cf *gp = lds + lpad(tid + b * THREADS);
 #pragma unroll
-      for (int q = 0; q < R; ++q) v[b * R + q] = lds[lpad(j + q * (N / R))];
+      for (int q = 0; q < R; ++q) v[b * R + q] = gp[q * ((N / R) + (N / R) / 16)];
     }
     __syncthreads();                              // everyone has read: LDS may be overwritten
   }
@@ -201,8 +222,18 @@ __device__ __forceinline__ void fft_pass(cf *v /*[E]*/, cf *lds, const TwBase &t
     dftR<R>(vb);
     const int j0 = ((j - k) << RB) + k;
     if (!LAST) {
+      if constexpr (NS % 16 == 0) {               // lpad(j0 + q*NS) = lpad(j0) + q*lpad(NS)
+        cf *sp = lds + lpad(j0);
 #pragma unroll
-      for (int q = 0; q < R; ++q) lds[lpad(j0 + q * NS)] = vb[q];
+        for (int q = 0; q < R; ++q) sp[q * (NS + NS / 16)] = vb[q];
+      } else if constexpr (PASS == 0 && R <= 16) {   // j0 = j*R, q < R <= 16: no carry into the pad term
+        cf *sp = lds + lpad(j0);
+#pragma unroll
+        for (int q = 0; q < R; ++q) sp[q] = vb[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < R; ++q) lds[lpad(j0 + q * NS)] = vb[q];
+      }
     } else {
       // last pass: NS == N/R, j0 == j, output index j + q*N/R; accumulate power
 #pragma unroll
@@ -253,26 +284,46 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : (THREADS >= 128 ? T
   const int fps = (navg + S - 1) / S;
   const int f_begin = blockIdx.y * fps;
   const int f_end = (f_begin + fps < navg) ? f_begin + fps : navg;
+  // Software pipeline over the frames of this workgroup: the raw samples of frame f+1 are requested
+  // right after pass 0 of frame f has moved its operands to LDS, so the HBM latency hides behind
+  // passes 1..P-1 (with two workgroups per CU there is not enough other work to hide it otherwise:
+  // one-frame workgroups reached 51 % of the HBM peak where the in-loop version stayed at 38 %).
+  // (measured: pays for N = 4096 / 8192; N = 2048 loses a wave of occupancy to the 32 extra VGPRs,
+  // N = 16384 spills, smaller frames have enough workgroups per CU anyway)
+  constexpr bool PREFETCH = (LOG2N == 12 || LOG2N == 13);
+  cf nxt[E];
+  auto request = [&](int f) {
+    const cf *fr = x + (o * navg + f) * hop;
+#pragma unroll
+    for (int b = 0; b < NB0; ++b) {
+      const int j = tid0 + b * THREADS;
+#pragma unroll
+      for (int q = 0; q < R0; ++q) nxt[b * R0 + q] = fr[j + q * (N / R0)];
+    }
+  };
+  if (PREFETCH && f_begin < f_end) request(f_begin);
   for (int f = f_begin; f < f_end; ++f) {
+    if (!PREFETCH) request(f);
     // Make the lane id opaque per frame: otherwise LICM hoists every twiddle (and its derived
     // powers) and every LDS address of all passes out of the frame loop and the kernel needs
     // >256 VGPRs.  Re-deriving them per frame costs a few integer ops and L1-resident loads.
     int tid = tid0;
     asm volatile("" : "+v"(tid));
-    const cf *fr = x + (o * navg + f) * hop;
     cf v[E];
-    // pass 0 operands straight from HBM, window applied on the fly
+    // pass 0 operands: the prefetched samples, window applied on the fly
 #pragma unroll
     for (int b = 0; b < NB0; ++b) {
       const int j = tid + b * THREADS;
 #pragma unroll
       for (int q = 0; q < R0; ++q) {
         const int i = j + q * (N / R0);
-        v[b * R0 + q] = fr[i] * window[i];
+        v[b * R0 + q] = nxt[b * R0 + q] * window[i];
       }
     }
     // (the barrier after the previous frame's last gather already ordered LDS reuse)
-    PassRunner<LOG2N, THREADS, 0>::run(v, lds, tb, tid, pw);
+    fft_pass<LOG2N, THREADS, 0>(v, lds, tb, tid, pw);
+    if (PREFETCH && f + 1 < f_end) request(f + 1);
+    PassRunner<LOG2N, THREADS, 1>::run(v, lds, tb, tid, pw);
   }
 
   // epilogue: thread holds power of bins j + q*N/RL (last-pass geometry)
@@ -419,14 +470,16 @@ namespace sdk {
 int psd_split(long long nout, int navg)
 {
   // two resident workgroups per CU (512 on the chip), at least `minf` frames per workgroup: the
-  // register-resident twiddles are reused and the partial sums stay a small fraction of the input
-  // (PMC showed 2.1x the algorithmic HBM traffic with one frame per workgroup)
+  // register-resident twiddles are reused and the partial sums stay a fraction of the input (PMC
+  // showed 2.1x the algorithmic HBM traffic with one frame per workgroup).  Only matters for the
+  // small analyzer blocks (4 Mi samples: 8192-pt 25.6 us at minf = 2, 30.6 us at 4; 16384-pt 28.8
+  // vs 44.8 us); a capture-sized input has nout >= target and never splits.
   static int target = 0, minf = 0;
   if (target == 0) {
     const char *e = getenv("SUAMD_PSD_SPLIT_TARGET");
     target = e ? atoi(e) : 512;
     e = getenv("SUAMD_PSD_MIN_FRAMES");
-    minf = e ? atoi(e) : 4;
+    minf = e ? atoi(e) : 2;
     if (target < 1) target = 1;
     if (minf < 1) minf = 1;
   }
