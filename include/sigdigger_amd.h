@@ -30,6 +30,7 @@ extern "C" {
 typedef float    SUFLOAT;
 typedef double   SUFREQ;
 typedef uint64_t SUSCOUNT;
+typedef int64_t  SUSDIFF;
 typedef int      SUBOOL;
 typedef struct { SUFLOAT re, im; } suamd_complex;   /* layout-identical to SUCOMPLEX */
 #ifndef SU_TRUE
@@ -155,6 +156,22 @@ SUAMD_API SUBOOL suamd_histogram_feed_bulk(suamd_ctx_t *ctx, const suamd_complex
 SUAMD_API SUBOOL suamd_sample_manual_bulk(suamd_ctx_t *ctx, const suamd_complex *d_data, SUSCOUNT length,
                                           double symbol_count, SUSCOUNT symbol_sync, int space,
                                           suamd_complex *d_out, SUSCOUNT nout, void *stream);
+
+/* WaveSampler::sampleZeroCrossing (Tasks/WaveSampler.cpp:215-292), all work() calls of one capture:
+ * run lengths between sign changes of `var` -> round(samples * bnor) symbols of value (var > 0).
+ * var: space 0 AMPLITUDE = Re(x conj x) - Re(thr conj thr) if `amplitude`, else Re(x angle) - Re(thr angle);
+ * 1 PHASE = arg(x angle); 2 FREQUENCY = arg(j x conj(prev)).  The reference's block structure is kept
+ * (4096-sample blocks restarting from prevVar = -1 / prevSample = 0, `last` for the final block,
+ * <= 4096 symbols per block).  d_symbols (bytes, WaveSampleSet::symbols) must hold
+ * 4096 * ceil(length / 4096) entries; returns the number written, -1 on error.  Synchronises. */
+SUAMD_API SUSDIFF suamd_sample_zero_crossing_bulk(suamd_ctx_t *ctx, const suamd_complex *d_data, SUSCOUNT length,
+                                                  SUFLOAT bnor, int space, SUBOOL amplitude, SUFLOAT thr_re,
+                                                  SUFLOAT thr_im, SUFLOAT ang_re, SUFLOAT ang_im,
+                                                  unsigned char *d_symbols, SUSCOUNT capacity, void *stream);
+/* WaveSampler::sampleGardner in FREQUENCY space (Tasks/WaveSampler.cpp:188-196): d_y[p] = d_x[p] conj(d_x[p-1]),
+ * d_x[-1] = prev (this->prevSample); the result is what su_clock_detector_feed sees -> suamd_clock_bank_feed */
+SUAMD_API SUBOOL suamd_conj_prev_bulk(suamd_ctx_t *ctx, const suamd_complex *d_x, suamd_complex *d_y, SUSCOUNT len,
+                                      SUFLOAT prev_re, SUFLOAT prev_im, void *stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* K6-K9: per-channel recurrences, one lane per channel                                  */

@@ -759,6 +759,69 @@ void sdo_sample_manual(const sdo_c32 *data, size_t length, double symbol_count,
   }
 }
 
+#define SDO_WS_BLOCK 4096   /* SIGDIGGER_WAVESAMPLER_FEEDER_BLOCK_LENGTH, include/WaveSampler.h:28 */
+
+/* var of sample p (Tasks/WaveSampler.cpp:240-267); products as in SPEC "element-wise" */
+static float zc_var(const sdo_c32 *data, size_t p, int space, int amplitude, sdo_c32 thr, sdo_c32 ang, sdo_c32 prev)
+{
+  sdo_c32 x = data[p];
+  if (space == 0) {
+    float v, t;
+    if (amplitude) { v = fmaf(x.im, x.im, x.re * x.re);   t = fmaf(thr.im, thr.im, thr.re * thr.re); }
+    else           { v = fmaf(-x.im, ang.im, x.re * ang.re); t = fmaf(-thr.im, ang.im, thr.re * ang.re); }
+    return v - t;
+  } else if (space == 1) {
+    float re = fmaf(-x.im, ang.im, x.re * ang.re), im = fmaf(x.im, ang.re, x.re * ang.im);
+    return sdo_atan2f(im, re);
+  } else {
+    sdo_c32 u = { -x.im, x.re };                         /* SU_I * x */
+    sdo_c32 d = cmul_conj(u, prev);
+    return sdo_atan2f(d.im, d.re);
+  }
+}
+
+size_t sdo_sample_zero_crossing(const sdo_c32 *data, size_t length, float bnor, int space, int amplitude,
+                                sdo_c32 threshold, sdo_c32 zc_angle, unsigned char *out_sym, size_t nout)
+{
+  long p = 0, lastZc = 0;
+  size_t total = 0;
+  while (p < (long)length) {                               /* one work() call per iteration */
+    long amount = (long)length - p;
+    long i = 0;
+    int last;
+    sdo_c32 prev = { 0, 0 };                               /* this->prevSample, never written back */
+    float prevVar = -1.0f;                                 /* this->prevVar, never written back */
+    if (amount > SDO_WS_BLOCK) amount = SDO_WS_BLOCK;
+    last = p + amount >= (long)length;
+    while (amount--) {
+      float var = zc_var(data, (size_t)p, space, amplitude, threshold, zc_angle, prev);
+      if (space == 2) prev = data[p];
+      if ((var > 0 || var < 0) || last) {
+        if (var * prevVar < 0 || last) {
+          long samples = p - lastZc;
+          long symbols = (long)roundf((float)samples * bnor);
+          while (symbols-- > 0 && i < SDO_WS_BLOCK) {
+            if (total + (size_t)i < nout) out_sym[total + (size_t)i] = var > 0;
+            ++i;
+          }
+          lastZc = p;
+          prevVar = var;
+        }
+      }
+      ++p;
+    }
+    total += (size_t)i;
+  }
+  return total;
+}
+
+void sdo_conj_prev(const sdo_c32 *x, size_t n, sdo_c32 prev0, sdo_c32 *y)
+{
+  size_t p;
+  sdo_c32 prev = prev0;
+  for (p = 0; p < n; ++p) { sdo_c32 cur = x[p]; y[p] = cmul_conj(cur, prev); prev = cur; }
+}
+
 /* ===================================================================================== */
 /* T9: carrier centroid [REF-PINNED structure] Tasks/CarrierDetector.cpp:80-143            */
 /* ===================================================================================== */

@@ -156,6 +156,17 @@ void sdo_agc_params_from_tau(sdo_agc_params *p, float tau);
 void sdo_sample_manual(const sdo_c32 *data, size_t length, double symbol_count,
                        double symbol_sync, int space, sdo_c32 *out, size_t nout);
 
+/* Tasks/WaveSampler.cpp:215-292 (ZERO_CROSSING), all work() calls of one capture concatenated.
+ * The reference's block structure is part of the result and is kept literally: blocks of 4096
+ * input samples; prevVar (= -1) and prevSample (= 0) are members that sampleZeroCrossing() never
+ * writes back, so every block restarts from them; `last` holds for every sample of the final block;
+ * at most 4096 symbols per block; lastZc persists.  space as above; out_sym[i] = (var > 0).
+ * Returns the number of symbols (<= capacity `nout`, which must be >= 4096 * ceil(length/4096)). */
+size_t sdo_sample_zero_crossing(const sdo_c32 *data, size_t length, float bnor, int space, int amplitude,
+                                sdo_c32 threshold, sdo_c32 zc_angle, unsigned char *out_sym, size_t nout);
+/* Tasks/WaveSampler.cpp:188-196 (GARDNER, FREQUENCY space): y[p] = x[p] conj(x[p-1]), x[-1] = prev0 */
+void sdo_conj_prev(const sdo_c32 *x, size_t n, sdo_c32 prev0, sdo_c32 *y);
+
 /* ---- T9: carrier centroid [REF-PINNED structure] ------------------------------------ */
 /* Tasks/CarrierDetector.cpp:80-143. returns peak in rad/sample */
 float sdo_carrier_detect(const sdo_c32 *data, size_t len, float avg_rel_bw, float dc_notch_rel_bw);

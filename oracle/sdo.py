@@ -89,6 +89,10 @@ def lib():
         L.sdo_histogram_feed.restype = C.c_size_t
         L.sdo_clock_feed_bulk.restype = C.c_size_t
         L.sdo_carrier_detect.restype = C.c_float
+        L.sdo_sample_zero_crossing.restype = C.c_size_t
+        L.sdo_sample_zero_crossing.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_int, C32, C32,
+                                               C.c_void_p, C.c_size_t]
+        L.sdo_conj_prev.argtypes = [C.c_void_p, C.c_size_t, C32, C.c_void_p]
         L.sdo_averager_feed.restype = C.c_int
     return _LIB
 
@@ -332,6 +336,25 @@ def sample_manual(data, symbol_count, symbol_sync, space, nout=None):
     lib().sdo_sample_manual(_p(data), C.c_size_t(data.size), C.c_double(symbol_count),
                             C.c_double(symbol_sync), C.c_int(space), _p(out), C.c_size_t(nout))
     return out
+
+
+def sample_zero_crossing(data, bnor, space, amplitude=False, threshold=0j, zc_angle=1 + 0j):
+    """Symbols (uint8, var > 0) of WaveSampler's ZERO_CROSSING mode over a whole capture."""
+    data = _c(data)
+    cap = 4096 * ((data.size + 4095) // 4096)
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = lib().sdo_sample_zero_crossing(_p(data), data.size, float(bnor), int(space), int(bool(amplitude)),
+                                       C32(float(np.real(threshold)), float(np.imag(threshold))),
+                                       C32(float(np.real(zc_angle)), float(np.imag(zc_angle))),
+                                       out.ctypes.data_as(C.c_void_p), out.size)
+    return out[:n].copy()
+
+
+def conj_prev(x, prev0=0j):
+    x = _c(x)
+    y = np.empty(x.size, dtype=c32)
+    lib().sdo_conj_prev(_p(x), x.size, C32(float(np.real(prev0)), float(np.imag(prev0))), _p(y))
+    return y
 
 
 def carrier_detect(data, avg_rel_bw, dc_notch_rel_bw):

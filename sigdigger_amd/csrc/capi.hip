@@ -491,6 +491,57 @@ SUBOOL suamd_sample_manual_bulk(suamd_ctx_t *ctx, const suamd_complex *d_data, S
   return SU_TRUE;
 }
 
+SUBOOL suamd_conj_prev_bulk(suamd_ctx_t *ctx, const suamd_complex *d_x, suamd_complex *d_y, SUSCOUNT len,
+                            SUFLOAT prev_re, SUFLOAT prev_im, void *stream)
+{
+  if (!ctx || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(sdk::conj_prev_bulk(d_x, d_y, (long long)len, prev_re, prev_im, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUSDIFF suamd_sample_zero_crossing_bulk(suamd_ctx_t *ctx, const suamd_complex *d_data, SUSCOUNT length, SUFLOAT bnor,
+                                        int space, SUBOOL amplitude, SUFLOAT thr_re, SUFLOAT thr_im, SUFLOAT ang_re,
+                                        SUFLOAT ang_im, unsigned char *d_symbols, SUSCOUNT capacity, void *stream)
+{
+  if (!ctx || !d_data || !d_symbols) { set_err("null argument"); return -1; }
+  if (space < 0 || space > 2) { set_err("bad space %d", space); return -1; }
+  if (length == 0) return 0;
+  const long long nblocks = (long long)((length + 4095) / 4096);
+  if (capacity < (SUSCOUNT)nblocks * 4096) { set_err("d_symbols must hold 4096 * ceil(length / 4096) symbols"); return -1; }
+  hipStream_t st = as_stream(stream);
+  HIP_TRY(hipSetDevice(ctx->device), -1);
+  // scratch: var[length] | last_pos[nblocks] | offset[nblocks] | count[nblocks] | seg[nblocks * 4096]
+  const size_t o_var = 0, o_last = o_var + ((sizeof(float) * length + 15) & ~(size_t)15);
+  const size_t o_off = o_last + sizeof(long long) * nblocks, o_cnt = o_off + sizeof(unsigned long long) * nblocks;
+  const size_t o_seg = (o_cnt + sizeof(unsigned) * nblocks + 15) & ~(size_t)15;
+  char *d = nullptr;
+  HIP_TRY(hipMalloc(&d, o_seg + (size_t)nblocks * 4096), -1);
+  float *d_var = reinterpret_cast<float *>(d + o_var);
+  long long *d_last = reinterpret_cast<long long *>(d + o_last);
+  unsigned long long *d_off = reinterpret_cast<unsigned long long *>(d + o_off);
+  unsigned *d_cnt = reinterpret_cast<unsigned *>(d + o_cnt);
+  unsigned char *d_seg = reinterpret_cast<unsigned char *>(d + o_seg);
+  SUSDIFF total = -1;
+  std::vector<unsigned> cnt((size_t)nblocks);
+  std::vector<unsigned long long> off((size_t)nblocks);
+  hipError_t e = sdk::zc_var(d_data, (long long)length, space, amplitude ? 1 : 0, thr_re, thr_im, ang_re, ang_im, d_var, st);
+  if (e == hipSuccess) e = sdk::zc_scan(d_var, (long long)length, nblocks, d_last, st);
+  if (e == hipSuccess) e = sdk::zc_emit(d_var, (long long)length, nblocks, bnor, d_last, d_seg, d_cnt, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_cnt, sizeof(unsigned) * nblocks, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess) {
+    unsigned long long acc = 0;
+    for (long long b = 0; b < nblocks; ++b) { off[(size_t)b] = acc; acc += cnt[(size_t)b]; }
+    total = (SUSDIFF)acc;
+    e = hipMemcpyAsync(d_off, off.data(), sizeof(unsigned long long) * nblocks, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = sdk::zc_compact(d_seg, d_cnt, d_off, d_symbols, nblocks, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  (void)hipFree(d);
+  if (e != hipSuccess) { set_err("zero-crossing sampler: %s", hipGetErrorString(e)); return -1; }
+  return total;
+}
+
 // ---- Costas --------------------------------------------------------------------------------------
 suamd_costas_bank_t *suamd_costas_bank_new(suamd_ctx_t *ctx, unsigned nchan, int kind, SUFLOAT fhint, SUFLOAT arm_bw,
                                            unsigned arm_order, SUFLOAT loop_bw)

@@ -52,6 +52,15 @@ hipError_t delayed_conj_bulk(const void *x, void *y, long long len, long long de
 hipError_t histogram_feed_bulk(const void *x, long long len, int space, float *out, hipStream_t st);
 hipError_t sample_manual_bulk(const void *data, long long length, double symbol_count, double symbol_sync, int space,
                               void *out, long long nout, hipStream_t st);
+hipError_t conj_prev_bulk(const void *x, void *y, long long len, float prev_re, float prev_im, hipStream_t st);
+// WaveSampler ZERO_CROSSING stages (blocks of 4096 input samples)
+hipError_t zc_var(const void *data, long long length, int space, int amplitude, float thr_re, float thr_im,
+                  float ang_re, float ang_im, float *var, hipStream_t st);
+hipError_t zc_scan(const float *var, long long length, long long nblocks, long long *last_pos, hipStream_t st);
+hipError_t zc_emit(const float *var, long long length, long long nblocks, float bnor, const long long *last_pos,
+                   unsigned char *seg, unsigned *count, hipStream_t st);
+hipError_t zc_compact(const unsigned char *seg, const unsigned *count, const unsigned long long *offset,
+                      unsigned char *out, long long nblocks, hipStream_t st);
 
 struct CostasState {            // SoA over channels, all device pointers
   uint32_t *phase; float *omega;

@@ -183,6 +183,112 @@ __global__ void sample_manual_kernel(const float2 *__restrict__ data, long long 
 }
 
 // ---------------------------------------------------------------------------------------
+// T8: WaveSampler ZERO_CROSSING (Tasks/WaveSampler.cpp:215-292) over a whole capture.
+// The reference works in blocks of 4096 input samples and -- because sampleZeroCrossing() never
+// writes prevVar / prevSample back -- every block restarts from prevVar = -1, prevSample = 0; only
+// lastZc carries over.  So blocks are independent up to "where was the last crossing before me":
+//   zc_var_kernel    var[p] of every sample (parallel),
+//   zc_scan_kernel   one thread per block: position of its last crossing,
+//   zc_emit_kernel   one thread per block: lastZc from the blocks before it, run lengths ->
+//                    round(samples * bnor) symbols into the block's own 4096-slot segment,
+//   zc_compact_kernel  segments -> contiguous output (offsets = prefix sum of the counts).
+constexpr int ZC_BLOCK = 4096;   // SIGDIGGER_WAVESAMPLER_FEEDER_BLOCK_LENGTH
+
+__global__ void zc_var_kernel(const float2 *__restrict__ data, long long length, int space, int amplitude,
+                              float2 thr, float2 ang, float *__restrict__ var)
+{
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < length;
+       p += (long long)gridDim.x * blockDim.x) {
+    const float2 x = data[p];
+    float v;
+    if (space == 0) {
+      float t;
+      if (amplitude) { v = sd::fma_(x.y, x.y, x.x * x.x);      t = sd::fma_(thr.y, thr.y, thr.x * thr.x); }
+      else           { v = sd::fma_(-x.y, ang.y, x.x * ang.x); t = sd::fma_(-thr.y, ang.y, thr.x * ang.x); }
+      v = v - t;
+    } else if (space == 1) {
+      const float re = sd::fma_(-x.y, ang.y, x.x * ang.x), im = sd::fma_(x.y, ang.x, x.x * ang.y);
+      v = sd::atan2_(im, re);
+    } else {
+      const float2 pv = (p % ZC_BLOCK) == 0 ? float2{0.0f, 0.0f} : data[p - 1];
+      const c32 d = sd::cmul_conj(c32{-x.y, x.x}, c32{pv.x, pv.y});      // (SU_I * x) * conj(prev)
+      v = sd::atan2_(d.im, d.re);
+    }
+    var[p] = v;
+  }
+}
+
+// crossing test of one sample; prevVar is updated by the caller on a hit
+__device__ __forceinline__ bool zc_hit(float var, float prevVar, bool last)
+{
+  return ((var > 0 || var < 0) || last) && (var * prevVar < 0 || last);
+}
+
+__global__ void zc_scan_kernel(const float *__restrict__ var, long long length, long long nblocks,
+                               long long *__restrict__ last_pos)
+{
+  const long long b = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  const long long p0 = b * ZC_BLOCK, p1 = (p0 + ZC_BLOCK < length) ? p0 + ZC_BLOCK : length;
+  const bool last = (b == nblocks - 1);
+  float prevVar = -1.0f;
+  long long lp = -1;
+  for (long long p = p0; p < p1; ++p) {
+    const float v = var[p];
+    if (zc_hit(v, prevVar, last)) { lp = p; prevVar = v; }
+  }
+  last_pos[b] = lp;
+}
+
+__global__ void zc_emit_kernel(const float *__restrict__ var, long long length, long long nblocks, float bnor,
+                               const long long *__restrict__ last_pos, unsigned char *__restrict__ seg,
+                               unsigned *__restrict__ count)
+{
+  const long long b = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  const long long p0 = b * ZC_BLOCK, p1 = (p0 + ZC_BLOCK < length) ? p0 + ZC_BLOCK : length;
+  const bool last = (b == nblocks - 1);
+  long long lastZc = 0;
+  for (long long q = b - 1; q >= 0; --q) if (last_pos[q] >= 0) { lastZc = last_pos[q]; break; }
+  unsigned char *out = seg + b * ZC_BLOCK;
+  float prevVar = -1.0f;
+  int i = 0;
+  for (long long p = p0; p < p1; ++p) {
+    const float v = var[p];
+    if (zc_hit(v, prevVar, last)) {
+      const long long samples = p - lastZc;
+      long long symbols = (long long)roundf((float)samples * bnor);
+      const unsigned char s = v > 0;
+      while (symbols-- > 0 && i < ZC_BLOCK) out[i++] = s;
+      lastZc = p;
+      prevVar = v;
+    }
+  }
+  count[b] = (unsigned)i;
+}
+
+__global__ void zc_compact_kernel(const unsigned char *__restrict__ seg, const unsigned *__restrict__ count,
+                                  const unsigned long long *__restrict__ offset, unsigned char *__restrict__ out)
+{
+  const long long b = blockIdx.x;
+  const unsigned n = count[b];
+  const unsigned char *src = seg + b * ZC_BLOCK;
+  unsigned char *dst = out + offset[b];
+  for (unsigned i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+// WaveSampler::sampleGardner, FREQUENCY space (Tasks/WaveSampler.cpp:188-196): x[p] conj(x[p-1])
+__global__ void conj_prev_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, long long len, float2 prev0)
+{
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < len;
+       p += (long long)gridDim.x * blockDim.x) {
+    const float2 a = x[p], b = p > 0 ? x[p - 1] : prev0;
+    const c32 d = sd::cmul_conj(c32{a.x, a.y}, c32{b.x, b.y});
+    y[p] = float2{d.re, d.im};
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // K6: Costas loop
 template <int ORDER> struct CostasRegs {
   uint32_t phase; float omega;
@@ -538,6 +644,43 @@ hipError_t histogram_feed_bulk(const void *x, long long len, int space, float *o
   if (len <= 0) return hipSuccess;
   hipLaunchKernelGGL(histogram_kernel, dim3(grid_for(len, 256)), dim3(256), 0, st,
                      reinterpret_cast<const float2 *>(x), len, space, out);
+  return hipGetLastError();
+}
+
+hipError_t conj_prev_bulk(const void *x, void *y, long long len, float prev_re, float prev_im, hipStream_t st)
+{
+  if (len <= 0) return hipSuccess;
+  hipLaunchKernelGGL(conj_prev_kernel, dim3(grid_for(len, 256)), dim3(256), 0, st, reinterpret_cast<const float2 *>(x),
+                     reinterpret_cast<float2 *>(y), len, float2{prev_re, prev_im});
+  return hipGetLastError();
+}
+
+hipError_t zc_var(const void *data, long long length, int space, int amplitude, float thr_re, float thr_im,
+                  float ang_re, float ang_im, float *var, hipStream_t st)
+{
+  hipLaunchKernelGGL(zc_var_kernel, dim3(grid_for(length, 256)), dim3(256), 0, st, reinterpret_cast<const float2 *>(data),
+                     length, space, amplitude, float2{thr_re, thr_im}, float2{ang_re, ang_im}, var);
+  return hipGetLastError();
+}
+
+hipError_t zc_scan(const float *var, long long length, long long nblocks, long long *last_pos, hipStream_t st)
+{
+  hipLaunchKernelGGL(zc_scan_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, st, var, length, nblocks, last_pos);
+  return hipGetLastError();
+}
+
+hipError_t zc_emit(const float *var, long long length, long long nblocks, float bnor, const long long *last_pos,
+                   unsigned char *seg, unsigned *count, hipStream_t st)
+{
+  hipLaunchKernelGGL(zc_emit_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, st, var, length, nblocks, bnor,
+                     last_pos, seg, count);
+  return hipGetLastError();
+}
+
+hipError_t zc_compact(const unsigned char *seg, const unsigned *count, const unsigned long long *offset,
+                      unsigned char *out, long long nblocks, hipStream_t st)
+{
+  hipLaunchKernelGGL(zc_compact_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, seg, count, offset, out);
   return hipGetLastError();
 }
 

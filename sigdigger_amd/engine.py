@@ -141,6 +141,28 @@ class Context:
               "suamd_sample_manual_bulk")
         return out
 
+    def sample_zero_crossing(self, data, bnor, space, amplitude=False, threshold=0j, zc_angle=1 + 0j, stream=None):
+        """WaveSampler::sampleZeroCrossing over a whole capture (Tasks/WaveSampler.cpp:215-292) -> uint8 symbols."""
+        _chk_c64(data, "data")
+        cap = 4096 * ((data.numel() + 4095) // 4096)
+        out = torch.empty(max(cap, 1), dtype=torch.uint8, device=data.device)
+        n = self.lib.suamd_sample_zero_crossing_bulk(self.h, _ptr(data), data.numel(), float(bnor), int(space),
+                                                     int(bool(amplitude)), float(threshold.real), float(threshold.imag),
+                                                     float(zc_angle.real), float(zc_angle.imag), _ptr(out), out.numel(),
+                                                     _stream(stream))
+        if n < 0:
+            raise SigDiggerAmdError("suamd_sample_zero_crossing_bulk: " + _l.last_error())
+        return out[:n]
+
+    def conj_prev(self, x, prev0=0j, out=None, stream=None):
+        """x[p] * conj(x[p-1]) (Gardner sampler in FREQUENCY space, Tasks/WaveSampler.cpp:188-196)."""
+        _chk_c64(x, "x")
+        if out is None:
+            out = torch.empty_like(x)
+        check(self.lib.suamd_conj_prev_bulk(self.h, _ptr(x), _ptr(out), x.numel(), float(prev0.real), float(prev0.imag),
+                                            _stream(stream)), "suamd_conj_prev_bulk")
+        return out
+
     def fft_forward(self, x, stream=None):
         """forward FFT of a power-of-two length capture (16..2^24 points)"""
         _chk_c64(x, "x")

@@ -543,6 +543,50 @@ def test_sample_manual_bit_exact(ctx, sdo, space, nsym, sync):
     assert_bits(got, ref, f"manual sampler space {space}")
 
 
+@pytest.mark.parametrize("space,amplitude,thr,ang", [(0, False, 0.1 + 0.05j, 1 + 0j), (0, True, 0.7 + 0.2j, 1 + 0j),
+                                                     (0, False, 0j, -1j), (1, False, 0j, 1 + 0j), (1, False, 0j, -1j),
+                                                     (2, False, 0j, 1 + 0j)])
+@pytest.mark.parametrize("length,sps", [(4096 * 5 + 1234, 8.0), (3000, 4.0), (4096 * 3, 23.7), (200000, 2.2)])
+def test_sample_zero_crossing_bit_exact(ctx, sdo, space, amplitude, thr, ang, length, sps):
+    """ZERO_CROSSING sampler incl. the reference's block quirks (restart every 4096 samples, `last` block,
+    4096-symbol cap): symbol count and every symbol identical to the oracle."""
+    isps = max(2, int(round(sps)))                        # the sampler's baud need not match the signal's exactly
+    if space == 2:
+        x = synth.fsk_carriers(length, [0.0], sps=isps, seed=int(sps * 10))
+    elif space == 1:
+        x = (synth.psk_carriers(length, [0.0], sps=isps, order=2, seed=int(sps * 10)) * np.exp(0.3j)).astype(np.complex64)
+    else:
+        x = synth.psk_carriers(length, [0.0], sps=isps, order=2, seed=int(sps * 10))
+        if amplitude:                                     # on-off keyed envelope around the threshold
+            x = (x * (0.2 + (np.real(x) > 0))).astype(np.complex64)
+    x = np.ascontiguousarray(x[:length])
+    ref = sdo.sample_zero_crossing(x, 1.0 / sps, space, amplitude, thr, ang)
+    got = host(ctx.sample_zero_crossing(dev(x), 1.0 / sps, space, amplitude, thr, ang))
+    assert got.shape == ref.shape, f"symbol count {got.shape} vs {ref.shape}"
+    assert np.array_equal(got, ref)
+    if length > 3 * 4096:                                 # (a capture shorter than one block is all `last`: no symbols)
+        assert ref.size > 0.3 * length / sps
+
+
+def test_conj_prev_and_gardner_frequency_space(ctx, sdo):
+    """Gardner sampler in FREQUENCY space = conj-product with the previous sample (carried across calls),
+    then the clock detector (Tasks/WaveSampler.cpp:177-213)."""
+    x = synth.fsk_carriers(60000, [0.0], sps=10, seed=4)
+    ref = sdo.conj_prev(x)
+    a = ctx.conj_prev(dev(x[:25000]))
+    b = ctx.conj_prev(dev(x[25000:]), prev0=complex(x[24999]))
+    got = np.concatenate([host(a), host(b)])
+    assert_bits(got, ref, "x conj(prev)")
+    clk = engine.ClockBank(ctx, 1, 0.25, 0.1)
+    sym = torch.zeros((1, 60000), dtype=torch.complex64, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    clk.feed(dev(got).reshape(1, -1), sym, cnt)
+    n = int(cnt.cpu()[0])
+    refs = sdo.clock_feed_bulk(sdo.clock_new(0.25, 0.1), ref)
+    assert n == refs.size
+    assert_bits(host(sym[0, :n]), refs, "Gardner symbols (frequency space)")
+
+
 # ------------------------------------------------------------------------------------------
 # T9 / T10: whole-capture FFT tasks
 # ------------------------------------------------------------------------------------------
