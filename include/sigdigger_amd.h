@@ -157,6 +157,18 @@ SUAMD_API SUBOOL suamd_sample_manual_bulk(suamd_ctx_t *ctx, const suamd_complex 
                                           double symbol_count, SUSCOUNT symbol_sync, int space,
                                           suamd_complex *d_out, SUSCOUNT nout, void *stream);
 
+/* Sample formats of the file source (Default/SourceConfig/FileSourcePage.cpp:80-104, same order as
+ * enum suscan_source_format there; WAV / SigMF are containers around one of the raw payloads).
+ * d_out[i] = (I, Q) of interleaved raw sample i: u8 (v-128)/128, s8 v/128, s16 v/32768, f32 as is.
+ * d_raw 16-byte aligned.  This is the ingest step in front of the path:
+ * the host ships 2-4 B/sample over PCIe, the GPU expands to SUCOMPLEX. */
+enum suamd_sample_format {
+  SUAMD_FORMAT_RAW_FLOAT32 = 1, SUAMD_FORMAT_RAW_UNSIGNED8 = 2, SUAMD_FORMAT_RAW_SIGNED8 = 3, SUAMD_FORMAT_RAW_SIGNED16 = 4
+};
+SUAMD_API SUBOOL   suamd_ingest_iq(suamd_ctx_t *ctx, int format, const void *d_raw, SUSCOUNT nsamples,
+                                   suamd_complex *d_out, void *stream);
+SUAMD_API unsigned suamd_format_bytes_per_sample(int format);   /* per complex sample; 0 = unknown */
+
 /* WaveSampler::sampleZeroCrossing (Tasks/WaveSampler.cpp:215-292), all work() calls of one capture:
  * run lengths between sign changes of `var` -> round(samples * bnor) symbols of value (var > 0).
  * var: space 0 AMPLITUDE = Re(x conj x) - Re(thr conj thr) if `amplitude`, else Re(x angle) - Re(thr angle);

@@ -73,7 +73,13 @@ struct sigutils_channel { SUFREQ fc, f_lo, f_hi; SUFLOAT bw, snr, S0, N0; SUFREQ
 
 /* ---- source configuration: the subset needed to stand up a file / tone-generator source ------ */
 typedef struct suscan_source_config suscan_source_config_t;
-enum suscan_source_format { SUSCAN_SOURCE_FORMAT_AUTO = 0, SUSCAN_SOURCE_FORMAT_RAW_FLOAT32 = 1 };
+/* Default/SourceConfig/FileSourcePage.cpp:80-104; AUTO resolves by file extension.  Compact
+ * formats cross PCIe as they are and are expanded on the GPU (suamd_ingest_iq) */
+enum suscan_source_format {
+  SUSCAN_SOURCE_FORMAT_AUTO = 0, SUSCAN_SOURCE_FORMAT_RAW_FLOAT32 = 1, SUSCAN_SOURCE_FORMAT_RAW_UNSIGNED8 = 2,
+  SUSCAN_SOURCE_FORMAT_RAW_SIGNED8 = 3, SUSCAN_SOURCE_FORMAT_RAW_SIGNED16 = 4, SUSCAN_SOURCE_FORMAT_WAV = 5,
+  SUSCAN_SOURCE_FORMAT_SIGMF = 6
+};
 SUAMD_API suscan_source_config_t *suscan_source_config_new(const char *type, enum suscan_source_format fmt);
 SUAMD_API void   suscan_source_config_destroy(suscan_source_config_t *cfg);
 SUAMD_API void   suscan_source_config_set_samp_rate(suscan_source_config_t *cfg, unsigned int rate);

@@ -759,6 +759,21 @@ void sdo_sample_manual(const sdo_c32 *data, size_t length, double symbol_count,
   }
 }
 
+void sdo_ingest_iq(int format, const void *raw, size_t n, sdo_c32 *out)
+{
+  size_t i;
+  switch (format) {
+    case 1: memcpy(out, raw, n * sizeof *out); break;
+    case 2: { const unsigned char *r = raw;
+      for (i = 0; i < n; ++i) { out[i].re = (float)((int)r[2 * i] - 128) * 0.0078125f; out[i].im = (float)((int)r[2 * i + 1] - 128) * 0.0078125f; } break; }
+    case 3: { const signed char *r = raw;
+      for (i = 0; i < n; ++i) { out[i].re = (float)r[2 * i] * 0.0078125f; out[i].im = (float)r[2 * i + 1] * 0.0078125f; } break; }
+    case 4: { const short *r = raw;
+      for (i = 0; i < n; ++i) { out[i].re = (float)r[2 * i] * 3.0517578125e-05f; out[i].im = (float)r[2 * i + 1] * 3.0517578125e-05f; } break; }
+    default: break;
+  }
+}
+
 #define SDO_WS_BLOCK 4096   /* SIGDIGGER_WAVESAMPLER_FEEDER_BLOCK_LENGTH, include/WaveSampler.h:28 */
 
 /* var of sample p (Tasks/WaveSampler.cpp:240-267); products as in SPEC "element-wise" */

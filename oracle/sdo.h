@@ -167,6 +167,10 @@ size_t sdo_sample_zero_crossing(const sdo_c32 *data, size_t length, float bnor, 
 /* Tasks/WaveSampler.cpp:188-196 (GARDNER, FREQUENCY space): y[p] = x[p] conj(x[p-1]), x[-1] = prev0 */
 void sdo_conj_prev(const sdo_c32 *x, size_t n, sdo_c32 prev0, sdo_c32 *y);
 
+/* ---- ingest (section 8f #1): file-source sample formats -> SUCOMPLEX ------------------------------ */
+/* format 1 f32, 2 u8 (v-128)/128, 3 s8 v/128, 4 s16 v/32768 [UPSTREAM-RECOLLECTION: libsndfile norm] */
+void sdo_ingest_iq(int format, const void *raw, size_t nsamples, sdo_c32 *out);
+
 /* ---- T9: carrier centroid [REF-PINNED structure] ------------------------------------ */
 /* Tasks/CarrierDetector.cpp:80-143. returns peak in rad/sample */
 float sdo_carrier_detect(const sdo_c32 *data, size_t len, float avg_rel_bw, float dc_notch_rel_bw);

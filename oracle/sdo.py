@@ -350,6 +350,14 @@ def sample_zero_crossing(data, bnor, space, amplitude=False, threshold=0j, zc_an
     return out[:n].copy()
 
 
+def ingest_iq(fmt, raw):
+    raw = np.ascontiguousarray(raw)
+    n = raw.nbytes // {1: 8, 2: 2, 3: 2, 4: 4}[int(fmt)]
+    out = np.empty(n, dtype=c32)
+    lib().sdo_ingest_iq(C.c_int(int(fmt)), raw.ctypes.data_as(C.c_void_p), C.c_size_t(n), _p(out))
+    return out
+
+
 def conj_prev(x, prev0=0j):
     x = _c(x)
     y = np.empty(x.size, dtype=c32)

@@ -24,6 +24,7 @@ SOURCES = {
     "loops.hip": ["-ffp-contract=off"],
     "specview.hip": ["-ffp-contract=off"],
     "fft.hip": ["-ffp-contract=fast"],
+    "ingest.hip": ["-ffp-contract=off"],
     "capi.hip":  ["-ffp-contract=off"],
     "analyzer.cpp": ["-ffp-contract=off"],
 }

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <strings.h>
 #include <deque>
 #include <map>
 #include <memory>
@@ -122,45 +123,153 @@ struct suscan_source_config {
 
 namespace {
 
-// source reader: raw float32 IQ file, or a tone generator ("tonegen": params signal / noise in dB,
-// Default/SourceConfig/ToneGenSourcePage.cpp:81-90,125-126)
+// source reader: IQ file (raw float32 / u8 / s8 / s16, or a WAV / SigMF container around one of
+// them -- Default/SourceConfig/FileSourcePage.cpp:80-104), or a tone generator ("tonegen": params
+// signal / noise in dB, Default/SourceConfig/ToneGenSourcePage.cpp:81-90,125-126).  Compact formats
+// stay compact across PCIe: read() returns raw bytes, the worker expands them with suamd_ingest_iq.
 struct Source {
   suscan_source_config cfg;
   FILE *fp = nullptr;
   uint64_t n = 0;
   uint32_t lcg = 12345u;
+  int raw_format = SUAMD_FORMAT_RAW_FLOAT32;   // payload format after container / AUTO resolution
+  long data_start = 0;                         // payload offset (WAV header)
+  long data_bytes = -1;                        // payload length, -1 = to end of file
+
+  static bool ends_with(const std::string &s, const char *suf)
+  {
+    const size_t l = std::strlen(suf);
+    return s.size() >= l && strcasecmp(s.c_str() + s.size() - l, suf) == 0;
+  }
+  static uint32_t le32(const unsigned char *b) { return b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24); }
+
+  bool open_wav(std::string &err)
+  {
+    unsigned char h[12];
+    if (std::fread(h, 1, 12, fp) != 12 || std::memcmp(h, "RIFF", 4) || std::memcmp(h + 8, "WAVE", 4)) { err = "not a RIFF/WAVE file"; return false; }
+    bool have_fmt = false;
+    for (;;) {
+      unsigned char c[8];
+      if (std::fread(c, 1, 8, fp) != 8) { err = "WAV: no data chunk"; return false; }
+      const uint32_t len = le32(c + 4);
+      if (!std::memcmp(c, "fmt ", 4)) {
+        unsigned char f[16];
+        if (len < 16 || std::fread(f, 1, 16, fp) != 16) { err = "WAV: short fmt chunk"; return false; }
+        const unsigned tag = f[0] | (f[1] << 8), ch = f[2] | (f[3] << 8), bits = f[14] | (f[15] << 8);
+        const uint32_t rate = le32(f + 4);
+        if (ch != 2) { err = "WAV: need 2 channels (I/Q)"; return false; }
+        if (tag == 1 && bits == 8) raw_format = SUAMD_FORMAT_RAW_UNSIGNED8;
+        else if (tag == 1 && bits == 16) raw_format = SUAMD_FORMAT_RAW_SIGNED16;
+        else if (tag == 3 && bits == 32) raw_format = SUAMD_FORMAT_RAW_FLOAT32;
+        else { err = "WAV: unsupported sample type"; return false; }
+        if (rate) cfg.samp_rate = rate;
+        have_fmt = true;
+        std::fseek(fp, (long)(len - 16 + (len & 1)), SEEK_CUR);
+      } else if (!std::memcmp(c, "data", 4)) {
+        if (!have_fmt) { err = "WAV: data before fmt"; return false; }
+        data_start = std::ftell(fp);
+        data_bytes = len == 0xffffffffu ? -1 : (long)len;
+        return true;
+      } else {
+        std::fseek(fp, (long)(len + (len & 1)), SEEK_CUR);
+      }
+    }
+  }
+
+  // SigMF: datatype (and sample rate) from the .sigmf-meta next to the .sigmf-data
+  bool open_sigmf(std::string &err)
+  {
+    std::string base = cfg.path;
+    const size_t dot = base.rfind('.');
+    if (dot != std::string::npos) base.resize(dot);
+    const std::string meta = base + ".sigmf-meta", data = base + ".sigmf-data";
+    FILE *m = std::fopen(meta.c_str(), "rb");
+    if (!m) { err = "cannot open " + meta; return false; }
+    std::string js;
+    char buf[4096]; size_t r;
+    while ((r = std::fread(buf, 1, sizeof buf, m)) > 0) js.append(buf, r);
+    std::fclose(m);
+    auto value_of = [&](const char *key) -> std::string {
+      size_t k = js.find(key);
+      if (k == std::string::npos) return "";
+      k = js.find(':', k + std::strlen(key));
+      if (k == std::string::npos) return "";
+      size_t b = js.find_first_not_of(" \t\r\n\"", k + 1);
+      size_t e = js.find_first_of(",\"}\r\n", b);
+      return js.substr(b, e - b);
+    };
+    const std::string dt = value_of("\"core:datatype\"");
+    if (dt == "cf32_le" || dt == "cf32") raw_format = SUAMD_FORMAT_RAW_FLOAT32;
+    else if (dt == "ci16_le" || dt == "ci16") raw_format = SUAMD_FORMAT_RAW_SIGNED16;
+    else if (dt == "ci8") raw_format = SUAMD_FORMAT_RAW_SIGNED8;
+    else if (dt == "cu8") raw_format = SUAMD_FORMAT_RAW_UNSIGNED8;
+    else { err = "SigMF: unsupported core:datatype '" + dt + "'"; return false; }
+    const std::string sr = value_of("\"core:sample_rate\"");
+    if (!sr.empty() && std::atof(sr.c_str()) >= 1) cfg.samp_rate = (unsigned)std::atof(sr.c_str());
+    if (fp) std::fclose(fp);
+    fp = std::fopen(data.c_str(), "rb");
+    if (!fp) { err = "cannot open " + data; return false; }
+    return true;
+  }
+
   bool open(std::string &err)
   {
-    if (cfg.type == "file") {
-      fp = std::fopen(cfg.path.c_str(), "rb");
-      if (!fp) { err = "cannot open " + cfg.path; return false; }
-      return true;
-    }
     if (cfg.type == "tonegen") return true;
-    err = "unsupported source type '" + cfg.type + "' (file, tonegen)";
-    return false;
+    if (cfg.type != "file") { err = "unsupported source type '" + cfg.type + "' (file, tonegen)"; return false; }
+    fp = std::fopen(cfg.path.c_str(), "rb");
+    if (!fp) { err = "cannot open " + cfg.path; return false; }
+    int f = cfg.format;
+    if (f == SUSCAN_SOURCE_FORMAT_AUTO) {                  // by extension, as the file dialog filters do
+      const std::string &p = cfg.path;
+      if (ends_with(p, ".wav")) f = SUSCAN_SOURCE_FORMAT_WAV;
+      else if (ends_with(p, ".sigmf-data") || ends_with(p, ".sigmf-meta")) f = SUSCAN_SOURCE_FORMAT_SIGMF;
+      else if (ends_with(p, ".u8") || ends_with(p, ".cu8")) f = SUSCAN_SOURCE_FORMAT_RAW_UNSIGNED8;
+      else if (ends_with(p, ".s8") || ends_with(p, ".cs8")) f = SUSCAN_SOURCE_FORMAT_RAW_SIGNED8;
+      else if (ends_with(p, ".s16") || ends_with(p, ".cs16")) f = SUSCAN_SOURCE_FORMAT_RAW_SIGNED16;
+      else f = SUSCAN_SOURCE_FORMAT_RAW_FLOAT32;
+    }
+    switch (f) {
+      case SUSCAN_SOURCE_FORMAT_RAW_FLOAT32:   raw_format = SUAMD_FORMAT_RAW_FLOAT32; return true;
+      case SUSCAN_SOURCE_FORMAT_RAW_UNSIGNED8: raw_format = SUAMD_FORMAT_RAW_UNSIGNED8; return true;
+      case SUSCAN_SOURCE_FORMAT_RAW_SIGNED8:   raw_format = SUAMD_FORMAT_RAW_SIGNED8; return true;
+      case SUSCAN_SOURCE_FORMAT_RAW_SIGNED16:  raw_format = SUAMD_FORMAT_RAW_SIGNED16; return true;
+      case SUSCAN_SOURCE_FORMAT_WAV:           return open_wav(err);
+      case SUSCAN_SOURCE_FORMAT_SIGMF:         return open_sigmf(err);
+      default: err = "unsupported sample format"; return false;
+    }
   }
-  // returns samples read (< want only at end of stream)
-  size_t read(suamd_complex *dst, size_t want, bool *looped)
+  size_t bytes_per_sample() const { return cfg.type == "tonegen" ? 8 : suamd_format_bytes_per_sample(raw_format); }
+
+  // fills dst with `want` samples in the payload format (bytes_per_sample() each); returns the
+  // samples read (< want only at end of stream)
+  size_t read(void *dst, size_t want, bool *looped)
   {
     if (cfg.type == "tonegen") {
+      suamd_complex *o = static_cast<suamd_complex *>(dst);
       const double sig = std::pow(10.0, std::atof(cfg.params.count("signal") ? cfg.params["signal"].c_str() : "0") / 20);
       const double noi = std::pow(10.0, std::atof(cfg.params.count("noise") ? cfg.params["noise"].c_str() : "-40") / 20);
       const double w = 2 * M_PI * 0.05;
       for (size_t i = 0; i < want; ++i, ++n) {
         lcg = lcg * 1664525u + 1013904223u; const float a = ((lcg >> 8) & 0xffff) / 32768.0f - 1.0f;
         lcg = lcg * 1664525u + 1013904223u; const float b = ((lcg >> 8) & 0xffff) / 32768.0f - 1.0f;
-        dst[i].re = (float)(sig * std::cos(w * (double)n) + noi * a);
-        dst[i].im = (float)(sig * std::sin(w * (double)n) + noi * b);
+        o[i].re = (float)(sig * std::cos(w * (double)n) + noi * a);
+        o[i].im = (float)(sig * std::sin(w * (double)n) + noi * b);
       }
       return want;
     }
+    const size_t bps = bytes_per_sample();
+    unsigned char *o = static_cast<unsigned char *>(dst);
     size_t got = 0;
     while (got < want) {
-      const size_t r = std::fread(dst + got, sizeof(suamd_complex), want - got, fp);
+      size_t ask = want - got;
+      if (data_bytes >= 0) {
+        const long left = data_start + data_bytes - std::ftell(fp);
+        if ((long)(ask * bps) > left) ask = left > 0 ? (size_t)left / bps : 0;
+      }
+      const size_t r = ask ? std::fread(o + got * bps, bps, ask, fp) : 0;
       got += r;
       if (got < want) {
-        if (cfg.loop && std::ftell(fp) > 0) { std::rewind(fp); if (looped) *looped = true; continue; }
+        if (cfg.loop && std::ftell(fp) > data_start) { std::fseek(fp, data_start, SEEK_SET); if (looped) *looped = true; continue; }
         break;
       }
     }
@@ -240,6 +349,7 @@ struct suscan_analyzer {
   std::map<SUHANDLE, std::unique_ptr<Inspector>> inspectors;
   hipStream_t stream = nullptr;
   suamd_complex *h_x = nullptr, *d_x = nullptr;
+  void *d_raw = nullptr;                       // compact-format payload before suamd_ingest_iq
   float *d_psd = nullptr;
   size_t block = 0;
   unsigned navg = 1;
@@ -492,10 +602,12 @@ bool setup_psd(suscan_analyzer *a, std::string &err)
   if (block != a->block) {
     if (a->h_x) (void)hipHostFree(a->h_x);
     if (a->d_x) (void)hipFree(a->d_x);
+    if (a->d_raw) (void)hipFree(a->d_raw);
     if (a->d_psd) (void)hipFree(a->d_psd);
-    a->h_x = nullptr; a->d_x = nullptr; a->d_psd = nullptr;
+    a->h_x = nullptr; a->d_x = nullptr; a->d_raw = nullptr; a->d_psd = nullptr;
     if (hipHostMalloc((void **)&a->h_x, block * sizeof(suamd_complex), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&a->d_x, block * sizeof(suamd_complex)) != hipSuccess ||
+        hipMalloc(&a->d_raw, block * 4) != hipSuccess ||
         hipMalloc((void **)&a->d_psd, n * sizeof(float)) != hipSuccess) {
       err = "allocation of the block buffers failed";
       return false;
@@ -516,6 +628,11 @@ void worker_main(suscan_analyzer *a)
   if (!ok) err = suamd_last_error();
   if (ok && hipStreamCreate(&a->stream) != hipSuccess) { ok = false; err = "hipStreamCreate failed"; }
   if (ok) ok = src.open(err);
+  if (ok && src.cfg.samp_rate != a->source_cfg.samp_rate) {       // a WAV / SigMF header carries its own rate
+    a->source_cfg.samp_rate = src.cfg.samp_rate;
+    a->info.source_samp_rate = a->info.effective_samp_rate = src.cfg.samp_rate;
+    a->info.bandwidth = (SUFLOAT)src.cfg.samp_rate;
+  }
   if (ok) ok = setup_psd(a, err);
   if (!ok) {
     push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INIT, SUSCAN_ANALYZER_INIT_FAILURE, err);
@@ -562,7 +679,15 @@ void worker_main(suscan_analyzer *a)
       push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_EOS, 0, "end of stream");   // whole PSD frame set is needed
       break;
     }
-    (void)hipMemcpyAsync(a->d_x, a->h_x, a->block * sizeof(suamd_complex), hipMemcpyHostToDevice, a->stream);
+    if (src.bytes_per_sample() == sizeof(suamd_complex)) {
+      (void)hipMemcpyAsync(a->d_x, a->h_x, a->block * sizeof(suamd_complex), hipMemcpyHostToDevice, a->stream);
+    } else {                                               // 2-4 B/sample over PCIe, expanded on the GPU
+      (void)hipMemcpyAsync(a->d_raw, a->h_x, a->block * src.bytes_per_sample(), hipMemcpyHostToDevice, a->stream);
+      if (!suamd_ingest_iq(a->ctx, src.raw_format, a->d_raw, a->block, a->d_x, a->stream)) {
+        push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, suamd_last_error());
+        break;
+      }
+    }
     const unsigned n = (unsigned)a->params.detector_params.window_size;
     if (!suamd_psd_feed(a->psd, a->d_x, a->navg, n, a->navg, 1.0f / (float)n, SUAMD_PSD_LINEAR, a->d_psd, a->stream)) {
       push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, suamd_last_error());
@@ -608,10 +733,11 @@ void worker_main(suscan_analyzer *a)
   if (a->psd) suamd_psd_destroy(a->psd);
   if (a->h_x) (void)hipHostFree(a->h_x);
   if (a->d_x) (void)hipFree(a->d_x);
+  if (a->d_raw) (void)hipFree(a->d_raw);
   if (a->d_psd) (void)hipFree(a->d_psd);
   if (a->stream) (void)hipStreamDestroy(a->stream);
   if (a->ctx) suamd_ctx_destroy(a->ctx);
-  a->psd = nullptr; a->h_x = nullptr; a->d_x = nullptr; a->d_psd = nullptr; a->stream = nullptr; a->ctx = nullptr;
+  a->psd = nullptr; a->h_x = nullptr; a->d_x = nullptr; a->d_raw = nullptr; a->d_psd = nullptr; a->stream = nullptr; a->ctx = nullptr;
   push(a, SUSCAN_WORKER_MSG_TYPE_HALT, nullptr);
 }
 

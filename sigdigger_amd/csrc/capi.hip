@@ -491,6 +491,28 @@ SUBOOL suamd_sample_manual_bulk(suamd_ctx_t *ctx, const suamd_complex *d_data, S
   return SU_TRUE;
 }
 
+SUBOOL suamd_ingest_iq(suamd_ctx_t *ctx, int format, const void *d_raw, SUSCOUNT nsamples, suamd_complex *d_out, void *stream)
+{
+  if (!ctx) { set_err("null context"); return SU_FALSE; }
+  if (nsamples == 0) return SU_TRUE;
+  if (!d_raw || !d_out) { set_err("null argument"); return SU_FALSE; }
+  if (format < SUAMD_FORMAT_RAW_FLOAT32 || format > SUAMD_FORMAT_RAW_SIGNED16) { set_err("unsupported sample format %d", format); return SU_FALSE; }
+  if ((format == SUAMD_FORMAT_RAW_UNSIGNED8 || format == SUAMD_FORMAT_RAW_SIGNED8 || format == SUAMD_FORMAT_RAW_SIGNED16) &&
+      (reinterpret_cast<uintptr_t>(d_raw) & 15)) { set_err("d_raw must be 16-byte aligned"); return SU_FALSE; }
+  HIP_TRY(sdk::ingest_iq(format, d_raw, (long long)nsamples, d_out, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+unsigned suamd_format_bytes_per_sample(int format)
+{
+  switch (format) {
+    case SUAMD_FORMAT_RAW_FLOAT32: return 8;
+    case SUAMD_FORMAT_RAW_UNSIGNED8: case SUAMD_FORMAT_RAW_SIGNED8: return 2;
+    case SUAMD_FORMAT_RAW_SIGNED16: return 4;
+    default: return 0;
+  }
+}
+
 SUBOOL suamd_conj_prev_bulk(suamd_ctx_t *ctx, const suamd_complex *d_x, suamd_complex *d_y, SUSCOUNT len,
                             SUFLOAT prev_re, SUFLOAT prev_im, void *stream)
 {

@@ -111,6 +111,10 @@ hipError_t specview_interpolate(float *psd, float *accum, float *cnt, int n, hip
 hipError_t specview_sweep_linear(const SpecViewLinear *d_geom, int nframes, const float *frames, long long frame_stride,
                                  const float *cnt_before, float *accum, float *cnt, int n, hipStream_t st);
 
+// ---- ingest.hip ----
+// format: 1 float32, 2 unsigned 8, 3 signed 8, 4 signed 16 (interleaved I/Q) -> SUCOMPLEX
+hipError_t ingest_iq(int format, const void *raw, long long nsamp, void *out, hipStream_t st);
+
 // ---- fft.hip ----
 hipError_t fft_forward(void *a, void *b, int log2n, void **result, hipStream_t st);
 hipError_t psd_frames_large(int log2n, const void *x, long long hop, int navg, const float *window, float scale,

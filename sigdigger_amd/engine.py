@@ -15,6 +15,7 @@ from .lib import SigDiggerAmdError, check
 
 WINDOW_NONE, WINDOW_HAMMING, WINDOW_HANN, WINDOW_FLAT_TOP, WINDOW_BLACKMANN_HARRIS = range(5)
 PSD_LINEAR, PSD_DB_SHIFTED = 0, 1
+FORMAT_F32, FORMAT_U8, FORMAT_S8, FORMAT_S16 = 1, 2, 3, 4
 COSTAS_BPSK, COSTAS_QPSK, COSTAS_8PSK = 1, 2, 3
 
 
@@ -139,6 +140,17 @@ class Context:
         check(self.lib.suamd_sample_manual_bulk(self.h, _ptr(data), data.numel(), float(symbol_count),
                                                 int(symbol_sync), int(space), _ptr(out), nout, _stream(stream)),
               "suamd_sample_manual_bulk")
+        return out
+
+    def ingest(self, raw, fmt, out=None, stream=None):
+        """raw interleaved I/Q (torch uint8 / int8 / int16 / float32 tensor on the GPU) -> complex64."""
+        bps = int(self.lib.suamd_format_bytes_per_sample(int(fmt)))
+        if bps == 0:
+            raise SigDiggerAmdError(f"unknown sample format {fmt}")
+        n = raw.numel() * raw.element_size() // bps
+        if out is None:
+            out = torch.empty(n, dtype=torch.complex64, device=raw.device)
+        check(self.lib.suamd_ingest_iq(self.h, int(fmt), _ptr(raw), n, _ptr(out), _stream(stream)), "suamd_ingest_iq")
         return out
 
     def sample_zero_crossing(self, data, bnor, space, amplitude=False, threshold=0j, zc_angle=1 + 0j, stream=None):

@@ -59,6 +59,8 @@ PROTOTYPES = {
     "suamd_sample_manual_bulk": (INT, [VP, VP, U64, F64, U64, INT, VP, U64, VP]),
     "suamd_sample_zero_crossing_bulk": (C.c_int64, [VP, VP, U64, F32, INT, INT, F32, F32, F32, F32, VP, U64, VP]),
     "suamd_conj_prev_bulk": (INT, [VP, VP, VP, U64, F32, F32, VP]),
+    "suamd_ingest_iq": (INT, [VP, INT, VP, U64, VP, VP]),
+    "suamd_format_bytes_per_sample": (UINT, [INT]),
     "suamd_costas_bank_new": (VP, [VP, UINT, INT, F32, F32, UINT, F32]),
     "suamd_costas_bank_destroy": (None, [VP]),
     "suamd_costas_bank_feed": (INT, [VP, VP, View, VP, View, U64, VP]),

@@ -18,12 +18,12 @@ NAVG = 16                       # psd_update_int = N*NAVG/FS
 L = N * NAVG
 
 
-def _start(path, L_, loop=False, params=None):
+def _start(path, L_, loop=False, params=None, fmt=1, fs=FS):
     Lb = suscan.load()
     mq = suscan.MQ()
     assert Lb.suscan_mq_init(C.byref(mq))
-    cfg = Lb.suscan_source_config_new(b"file", 1)
-    Lb.suscan_source_config_set_samp_rate(cfg, FS)
+    cfg = Lb.suscan_source_config_new(b"file", fmt)
+    Lb.suscan_source_config_set_samp_rate(cfg, fs)
     Lb.suscan_source_config_set_freq(cfg, 433.92e6)
     assert Lb.suscan_source_config_set_path(cfg, str(path).encode())
     Lb.suscan_source_config_set_loop(cfg, int(loop))
@@ -82,6 +82,67 @@ def test_psd_stream_matches_oracle_and_eos(tmp_path, sdo):
     assert np.allclose(info["ts"], np.arange(nblocks) * L / FS, atol=1e-5)          # signal time stamps
     # what the consumer does next (PSDMessage ctor, in place on the message buffer)
     assert np.argmax(sdo.psd_shift_db(got[0])) == np.argmax(sdo.psd_shift_db(ref[0]))
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+
+
+def _write_wav(path, raw, rate, bits, tag):
+    import struct
+    data = raw.tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, tag, 2, rate, rate * 2 * bits // 8, 2 * bits // 8, bits))
+        f.write(b"LIST" + struct.pack("<I", 4) + b"abcd")                     # a chunk to skip
+        f.write(b"data" + struct.pack("<I", len(data)) + data)
+
+
+@pytest.mark.parametrize("kind", ["u8", "s8", "s16", "wav16", "wav8", "sigmf-ci16", "auto-cu8"])
+def test_compact_file_formats_are_expanded_on_the_gpu(tmp_path, sdo, kind):
+    """File sources in the compact formats of FileSourcePage.cpp:80-104: the PSD stream must equal the
+    oracle's PSD of the oracle-converted samples (ingest is bit exact, so the same 1e-5 bound holds)."""
+    nblocks = 3
+    x = synth.psk_carriers(L * nblocks, [0.15], sps=8, seed=11)
+    x = (0.5 * x / np.max(np.abs(x.view(np.float32)))).astype(np.complex64)
+    iq = x.view(np.float32)
+    fs = FS
+    if kind in ("u8", "wav8", "auto-cu8"):
+        raw, ofmt = np.clip(np.round(iq * 128 + 128), 0, 255).astype(np.uint8), 2
+    elif kind == "s8":
+        raw, ofmt = np.clip(np.round(iq * 128), -128, 127).astype(np.int8), 3
+    else:
+        raw, ofmt = np.clip(np.round(iq * 32768), -32768, 32767).astype(np.int16), 4
+    if kind in ("u8", "s8", "s16"):
+        path, fmt = tmp_path / "iq.bin", {"u8": 2, "s8": 3, "s16": 4}[kind]
+        raw.tofile(path)
+    elif kind == "auto-cu8":
+        path, fmt = tmp_path / "capture.cu8", 0
+        raw.tofile(path)
+    elif kind.startswith("wav"):
+        path, fmt, fs = tmp_path / "iq.wav", 5, 250_000                     # the header's rate wins
+        _write_wav(path, raw, fs, 8 if kind == "wav8" else 16, 1)
+    else:
+        path, fmt, fs = tmp_path / "rec.sigmf-data", 6, 2_000_000
+        raw.tofile(path)
+        (tmp_path / "rec.sigmf-meta").write_text(
+            '{"global": {"core:datatype": "ci16_le", "core:sample_rate": 2000000, "core:version": "1.0.0"}, '
+            '"captures": [{"core:sample_start": 0}], "annotations": []}')
+    Lb, mq, an = _start(path, L * FS / fs, fmt=fmt, fs=FS)      # psd_update_int = L / fs
+    frames, rates = [], []
+
+    def on_msg(t, ptr):
+        if t == suscan.MSG_PSD:
+            m = C.cast(ptr, C.POINTER(suscan.PSDMsg)).contents
+            frames.append(np.ctypeslib.as_array(m.psd_data, shape=(N,)).copy())
+            rates.append(m.samp_rate)
+
+    seen = _pump(Lb, an, on_msg)
+    assert seen[-1] == suscan.MSG_HALT and len(frames) == nblocks
+    assert all(r == fs for r in rates) and Lb.suscan_analyzer_get_samp_rate(an) == fs
+    xc = sdo.ingest_iq(ofmt, raw)
+    ref = sdo.psd_frames(xc, nblocks * NAVG, N, N, sdo.window(4, N), navg=NAVG, scale=1.0 / N)
+    got = np.stack(frames)
+    err = np.max(np.abs(got - ref), axis=1) / np.max(ref, axis=1)
+    assert np.all(err < 1e-5), err
     Lb.suscan_analyzer_destroy(an)
     Lb.suscan_mq_finalize(C.byref(mq))
 

@@ -588,6 +588,30 @@ def test_conj_prev_and_gardner_frequency_space(ctx, sdo):
 
 
 # ------------------------------------------------------------------------------------------
+# section 8f #1: sample-format ingest -- bit exact
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt,dtype", [(engine.FORMAT_U8, np.uint8), (engine.FORMAT_S8, np.int8),
+                                       (engine.FORMAT_S16, np.int16), (engine.FORMAT_F32, np.float32)])
+@pytest.mark.parametrize("nsamp", [0, 1, 7, 8, 4099, 1 << 20])
+def test_ingest_formats_bit_exact(ctx, sdo, fmt, dtype, nsamp):
+    rng = np.random.default_rng(nsamp + fmt)
+    if dtype == np.float32:
+        raw = rng.standard_normal(2 * nsamp).astype(np.float32)
+    else:
+        info = np.iinfo(dtype)
+        raw = rng.integers(info.min, info.max + 1, 2 * nsamp).astype(dtype)
+        raw[:4] = [info.min, info.max, 0, 1][:raw[:4].size]              # extremes
+    if nsamp == 0:
+        assert ctx.ingest(torch.zeros(16, dtype=torch.uint8, device="cuda")[:0], fmt).numel() == 0
+        return
+    ref = sdo.ingest_iq(fmt, raw)
+    got = host(ctx.ingest(torch.from_numpy(raw).cuda(), fmt))
+    assert_bits(got, ref, f"ingest format {fmt}")
+    if dtype != np.float32:
+        assert np.max(np.abs(got.view(np.float32))) <= 1.0
+
+
+# ------------------------------------------------------------------------------------------
 # T9 / T10: whole-capture FFT tasks
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("log2n", [4, 7, 12, 15, 18, 22])
