@@ -322,13 +322,16 @@ __device__ __forceinline__ float2 costas_step(const sdk::CostasParams &p, Costas
   float e;
   if (KIND == 1) {
     e = z.re * z.im;
-  } else if (KIND == 2) {
-    e = sd::sgn(z.re) * z.im - sd::sgn(z.im) * z.re;
   } else {
-    if (__builtin_fabsf(z.re) >= __builtin_fabsf(z.im))
-      e = sd::sgn(z.re) * z.im - (sd::sgn(z.im) * z.re) * 0.41421356237309504880f;
-    else
-      e = (sd::sgn(z.re) * z.im) * 0.41421356237309504880f - sd::sgn(z.im) * z.re;
+    float sr, si;
+    sd::sgn2(z.re, z.im, sr, si);
+    if (KIND == 2) {
+      e = sr * z.im - si * z.re;
+    } else if (__builtin_fabsf(z.re) >= __builtin_fabsf(z.im)) {
+      e = sr * z.im - (si * z.re) * 0.41421356237309504880f;
+    } else {
+      e = (sr * z.im) * 0.41421356237309504880f - si * z.re;
+    }
   }
   const float dphi = sd::fma_(p.a, e, r.omega);
   r.omega = sd::fma_(p.b, e, r.omega);

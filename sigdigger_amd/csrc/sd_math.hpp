@@ -17,8 +17,9 @@ __device__ __forceinline__ float fma_(float a, float b, float c) { return __buil
 // D1: 32-bit phase (2^32 per turn) -> cos/sin. Quadrant reduction + Cephes minimax kernels.
 __device__ __forceinline__ void phasor_u32(uint32_t p, float &c, float &s)
 {
-  const uint32_t q = (p + 0x20000000u) >> 30;
-  const int32_t  r = (int32_t)(p - (q << 30));
+  // r = p - (q << 30) with q = (p + 0x20000000) >> 30 is the low 30 bits of p, sign-extended:
+  // one v_bfe_i32 instead of add / and / sub on the loop-carried phase -> sample path
+  const int32_t  r = (int32_t)(p << 2) >> 2;
   const float x  = (float)r * 1.46291807926715968e-9f;
   const float z  = x * x;
   float sp = fma_(z, -1.9515295891e-4f, 8.3321608736e-3f);
@@ -137,5 +138,20 @@ __device__ __forceinline__ c32 cmul_conj(c32 a, c32 b)
 }
 
 __device__ __forceinline__ float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+// (sgn(a), sgn(b)) without compares: a v_cmp -> v_cndmask pair costs a lone wavefront about four
+// dependent-op slots (VCC hazard) and the four pairs of a QPSK detector serialise on VCC.
+// v * 2^126 * 2^126 is >= 1 in magnitude for every non-zero binary32 (denormals included; inf stays
+// inf), so clamping to [-1, 1] gives exactly +-1, and 0 stays 0; the "+ 0.0f" of the fma turns a
+// -0 into the +0 the compare form returns.  Bit-identical to sgn() for all non-NaN inputs.
+__device__ __forceinline__ void sgn2(float a, float b, float &sa, float &sb)
+{
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f big = {8.5070591730234616e37f, 8.5070591730234616e37f};   // 2^126
+  v2f s = v2f{a, b} * big;
+  s = __builtin_elementwise_fma(s, big, v2f{0.0f, 0.0f});
+  sa = __builtin_amdgcn_fmed3f(s.x, -1.0f, 1.0f);
+  sb = __builtin_amdgcn_fmed3f(s.y, -1.0f, 1.0f);
+}
 
 }  // namespace sd

@@ -310,6 +310,34 @@ def test_costas_bank_bit_exact(ctx, sdo, kind, order, arm_order, layout):
         assert np.float32(st.omega).view(np.uint32) == om[c].view(np.uint32) and st.phase == ph[c]
 
 
+@pytest.mark.parametrize("kind", [2, 3])
+def test_costas_detector_special_values(ctx, sdo, kind):
+    """The compare-free sign of the QPSK / 8PSK detectors (v * 2^126 * 2^126 clamped to +-1) must equal
+    sgn() for zeros of either sign, denormals, the smallest normals and huge magnitudes -- including the
+    sign of zero that ends up in omega."""
+    sp = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-41, -3e-39, 1.1754944e-38, -1.1754944e-38, 1e-30, -1e-20,
+                   1.0, -1.0, 1e18, -3e18], dtype=np.float32)
+    re, im = np.meshgrid(sp, sp)
+    base = (re.ravel() + 1j * im.ravel()).astype(np.complex64)                    # 196 combinations
+    rng = np.random.default_rng(kind)
+    rows = []
+    for c in range(8):
+        pad = np.zeros(3, np.complex64) if c % 2 else np.full(3, 1e-42 + 0j, np.complex64)
+        seq = np.concatenate([np.concatenate([pad, [v]]) for v in rng.permutation(base)])
+        rows.append(seq.astype(np.complex64))
+    x = np.stack(rows)
+    for arm_order in (1, 3):
+        bank = engine.CostasBank(ctx, x.shape[0], kind, 0.0, 0.25, arm_order, 0.01)
+        got = host(bank.feed(dev_rows(x, "cm")))
+        om, ph = bank.state()
+        for c in range(x.shape[0]):
+            st = sdo.costas_new(kind, 0.0, 0.25, arm_order, 0.01)
+            with np.errstate(all="ignore"):
+                ref = sdo.costas_feed_bulk(st, x[c])
+            assert_bits(got[c], ref, f"costas special values ch {c}")
+            assert np.float32(st.omega).view(np.uint32) == om[c].view(np.uint32) and st.phase == ph[c]
+
+
 @pytest.mark.parametrize("layout", ["cm", "tm"])
 def test_pll_bank_bit_exact(ctx, sdo, layout):
     nchan, n = 9, 5000
