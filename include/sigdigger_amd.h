@@ -220,6 +220,48 @@ SUAMD_API SUBOOL suamd_clock_bank_feed(suamd_clock_bank_t *b, const suamd_comple
                                        SUSCOUNT len, suamd_complex *d_sym, SUSCOUNT sym_stride,
                                        uint32_t *d_count, void *stream);
 SUAMD_API SUBOOL suamd_clock_bank_get_state(suamd_clock_bank_t *b, SUFLOAT *bnor, SUFLOAT *phi, void *stream);
+/* clock.type = MANUAL with clock.phase (InspectorCtl/ClockRecovery.cpp:59-93): a bank made with
+ * loop_gain = 0 keeps its baud; this sets the sampling phase accumulator of every channel
+ * (0.5 * clock.phase; Gardner's start value is 0.25).  Synchronises. */
+SUAMD_API SUBOOL suamd_clock_bank_set_phase(suamd_clock_bank_t *b, SUFLOAT phi, void *stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* A7: stages behind the rest of the inspector config vocabulary                         */
+/* (Default/GenericInspector/InspectorCtl/{GainControl,AfcControl,MfControl,Equalizer-   */
+/* Control}.cpp; semantics frozen in SPEC.md section I -- libsuscan is absent)           */
+/* ------------------------------------------------------------------------------------ */
+/* agc.enabled = false: rows scaled by the fixed agc.gain */
+SUAMD_API SUBOOL suamd_rows_scale(suamd_ctx_t *ctx, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y,
+                                  suamd_view yv, unsigned nchan, SUSCOUNT len, SUFLOAT gain, void *stream);
+/* afc.costas-order = 0 (manual) with afc.offset: a free-running NCO per channel,
+ * y_c[n] = x_c[n] * exp(j pi fnor_c n), n counted across feeds; pass fnor = -2 offset / equiv_fs */
+typedef struct suamd_nco_bank suamd_nco_bank_t;
+SUAMD_API suamd_nco_bank_t *suamd_nco_bank_new(suamd_ctx_t *ctx, unsigned nchan, const double *fnor);
+SUAMD_API void   suamd_nco_bank_destroy(suamd_nco_bank_t *b);
+SUAMD_API SUBOOL suamd_nco_bank_feed(suamd_nco_bank_t *b, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y,
+                                     suamd_view yv, SUSCOUNT len, void *stream);
+/* mf.type = MANUAL with mf.roll-off: root-raised-cosine taps spanning six symbols
+ * (suamd_rrc_ntaps(sps) = 2 ceil(3 sps) + 1, unit DC gain), and a real-tap FIR at the channel rate for a
+ * bank of rows (history carried across feeds; d_y must not alias d_x) */
+SUAMD_API unsigned suamd_rrc_ntaps(double sps);
+SUAMD_API void     suamd_rrc_design(SUFLOAT *taps, unsigned ntaps, double sps, double rolloff);
+typedef struct suamd_fir_bank suamd_fir_bank_t;
+SUAMD_API suamd_fir_bank_t *suamd_fir_bank_new(suamd_ctx_t *ctx, unsigned nchan, const SUFLOAT *taps, unsigned ntaps);
+SUAMD_API void   suamd_fir_bank_destroy(suamd_fir_bank_t *b);
+SUAMD_API SUBOOL suamd_fir_bank_feed(suamd_fir_bank_t *b, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y,
+                                     suamd_view yv, SUSCOUNT len, void *stream);
+/* equalizer.type = CMA with equalizer.rate / equalizer.locked: constant-modulus equalizer of `ntaps`
+ * (1..16) complex weights per channel at the symbol rate, w[0] = 1 initially.  Rows are channel-major;
+ * channel c consumes d_count[c] symbols (the clock bank's counts) or fixed_len when d_count is NULL. */
+typedef struct suamd_cma_bank suamd_cma_bank_t;
+SUAMD_API suamd_cma_bank_t *suamd_cma_bank_new(suamd_ctx_t *ctx, unsigned nchan, unsigned ntaps, SUFLOAT rate);
+SUAMD_API void   suamd_cma_bank_destroy(suamd_cma_bank_t *b);
+SUAMD_API void   suamd_cma_bank_set_locked(suamd_cma_bank_t *b, SUBOOL locked);
+SUAMD_API void   suamd_cma_bank_set_rate(suamd_cma_bank_t *b, SUFLOAT rate);
+SUAMD_API SUBOOL suamd_cma_bank_feed(suamd_cma_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride,
+                                     const uint32_t *d_count, SUSCOUNT fixed_len, suamd_complex *d_y,
+                                     SUSCOUNT y_stride, void *stream);
+SUAMD_API SUBOOL suamd_cma_bank_get_weights(suamd_cma_bank_t *b, suamd_complex *weights /* [ntaps][nchan] */, void *stream);
 
 /* struct su_agc_params (Tasks/AGCTask.cpp:41-47) + su_agc_params_INITIALIZER defaults */
 struct suamd_agc_params {

@@ -759,6 +759,98 @@ void sdo_sample_manual(const sdo_c32 *data, size_t length, double symbol_count,
   }
 }
 
+/* ===================================================================================== */
+/* A7 stages [UPSTREAM-RECOLLECTION]: matched filter, fixed gain, CMA equalizer           */
+/* ===================================================================================== */
+size_t sdo_rrc_ntaps(double sps) { return 2 * (size_t)ceil(3.0 * sps) + 1; }
+
+void sdo_rrc_design(float *h, size_t ntaps, double sps, double beta)
+{
+  double *d = malloc(sizeof(double) * ntaps), sum = 0;
+  size_t i;
+  for (i = 0; i < ntaps; ++i) {
+    double t = ((double)i - 0.5 * (double)(ntaps - 1)) / sps;          /* in symbols */
+    double v;
+    if (fabs(t) < 1e-12) {
+      v = 1.0 - beta + 4.0 * beta / SDO_PI;
+    } else if (beta > 0 && fabs(fabs(4.0 * beta * t) - 1.0) < 1e-9) {
+      v = beta / sqrt(2.0) * ((1.0 + 2.0 / SDO_PI) * sin(SDO_PI / (4.0 * beta)) + (1.0 - 2.0 / SDO_PI) * cos(SDO_PI / (4.0 * beta)));
+    } else {
+      double a = SDO_PI * t;
+      v = (sin(a * (1.0 - beta)) + 4.0 * beta * t * cos(a * (1.0 + beta))) / (a * (1.0 - 16.0 * beta * beta * t * t));
+    }
+    d[i] = v;
+    sum += v;
+  }
+  for (i = 0; i < ntaps; ++i) h[i] = (float)(d[i] / sum);
+  free(d);
+}
+
+void sdo_fir_feed(sdo_c32 *hist, const float *h, size_t ntaps, const sdo_c32 *x, size_t len, sdo_c32 *y)
+{
+  size_t m, k, hl = ntaps - 1;
+  for (m = 0; m < len; ++m) {
+    float yr = 0, yi = 0;
+    for (k = 0; k < ntaps; ++k) {
+      sdo_c32 v = (k <= m) ? x[m - k] : hist[hl + m - k];    /* sample m-k of [hist ; x] */
+      yr = fmaf(h[k], v.re, yr);
+      yi = fmaf(h[k], v.im, yi);
+    }
+    y[m] = (sdo_c32){ yr, yi };
+  }
+  if (hl) {                                                   /* last hl samples of [hist ; x] */
+    sdo_c32 *nh = malloc(sizeof(sdo_c32) * hl);
+    for (k = 0; k < hl; ++k) {
+      long src = (long)k + (long)len;                         /* index into [hist ; x] */
+      nh[k] = src < (long)hl ? hist[src] : x[src - (long)hl];
+    }
+    memcpy(hist, nh, sizeof(sdo_c32) * hl);
+    free(nh);
+  }
+}
+
+void sdo_scale(const sdo_c32 *x, size_t len, float g, sdo_c32 *y)
+{
+  size_t i;
+  for (i = 0; i < len; ++i) { y[i].re = g * x[i].re; y[i].im = g * x[i].im; }
+}
+
+void sdo_cma_init(sdo_cma *q, int n, float mu)
+{
+  memset(q, 0, sizeof *q);
+  q->n = n < 1 ? 1 : (n > SDO_CMA_MAX ? SDO_CMA_MAX : n);
+  q->mu = mu;
+  q->w[0].re = 1.0f;
+}
+
+sdo_c32 sdo_cma_feed(sdo_cma *q, sdo_c32 x)
+{
+  int i;
+  float yr = 0, yi = 0;
+  for (i = q->n - 1; i > 0; --i) q->d[i] = q->d[i - 1];
+  q->d[0] = x;
+  for (i = 0; i < q->n; ++i) {                               /* y = sum w[i] d[i] */
+    yr = fmaf(q->w[i].re, q->d[i].re, yr); yr = fmaf(-q->w[i].im, q->d[i].im, yr);
+    yi = fmaf(q->w[i].re, q->d[i].im, yi); yi = fmaf(q->w[i].im, q->d[i].re, yi);
+  }
+  if (!q->locked) {                                          /* w[i] -= mu (|y|^2 - 1) y conj(d[i]) */
+    float g = fmaf(yi, yi, yr * yr) - 1.0f;
+    sdo_c32 e = { yr * g, yi * g };
+    for (i = 0; i < q->n; ++i) {
+      sdo_c32 t = cmul_conj(e, q->d[i]);
+      q->w[i].re = fmaf(-q->mu, t.re, q->w[i].re);
+      q->w[i].im = fmaf(-q->mu, t.im, q->w[i].im);
+    }
+  }
+  return (sdo_c32){ yr, yi };
+}
+
+void sdo_cma_feed_bulk(sdo_cma *q, const sdo_c32 *x, size_t len, sdo_c32 *y)
+{
+  size_t i;
+  for (i = 0; i < len; ++i) y[i] = sdo_cma_feed(q, x[i]);
+}
+
 void sdo_ingest_iq(int format, const void *raw, size_t n, sdo_c32 *out)
 {
   size_t i;

@@ -167,6 +167,25 @@ size_t sdo_sample_zero_crossing(const sdo_c32 *data, size_t length, float bnor, 
 /* Tasks/WaveSampler.cpp:188-196 (GARDNER, FREQUENCY space): y[p] = x[p] conj(x[p-1]), x[-1] = prev0 */
 void sdo_conj_prev(const sdo_c32 *x, size_t n, sdo_c32 prev0, sdo_c32 *y);
 
+/* ---- A7: inspector stages behind the rest of the config vocabulary [UPSTREAM-RECOLLECTION] ------- */
+/* mf.type = MANUAL, mf.roll-off (Default/GenericInspector/InspectorCtl/MfControl.cpp:56-78):
+ * root-raised-cosine taps, n = 2*ceil(3*sps)+1 (six symbols), unit DC gain, double precision */
+size_t sdo_rrc_ntaps(double sps);
+void   sdo_rrc_design(float *h, size_t ntaps, double sps, double rolloff);
+/* real-tap FIR at the channel rate: y[m] = sum_k h[k] x[m-k], k ascending fma chain; hist = the
+ * ntaps-1 samples before x (updated) */
+void   sdo_fir_feed(sdo_c32 *hist, const float *h, size_t ntaps, const sdo_c32 *x, size_t len, sdo_c32 *y);
+/* agc.enabled = false, agc.gain (InspectorCtl/GainControl.cpp:51-60): y = g x */
+void   sdo_scale(const sdo_c32 *x, size_t len, float g, sdo_c32 *y);
+/* clock.type = MANUAL, clock.phase (InspectorCtl/ClockRecovery.cpp:59-93): the Gardner detector with
+ * loop gain 0 (fixed baud) and initial phase 0.5 * phase -> sdo_clock_init(cd, 0, bnor); cd->phi = 0.5f * phase */
+/* equalizer.type = CMA, equalizer.rate, equalizer.locked (InspectorCtl/EqualizerControl.cpp:56-75) */
+#define SDO_CMA_MAX 16
+typedef struct { int n; float mu; int locked; sdo_c32 w[SDO_CMA_MAX], d[SDO_CMA_MAX]; } sdo_cma;
+void   sdo_cma_init(sdo_cma *q, int n, float mu);
+sdo_c32 sdo_cma_feed(sdo_cma *q, sdo_c32 x);
+void   sdo_cma_feed_bulk(sdo_cma *q, const sdo_c32 *x, size_t len, sdo_c32 *y);
+
 /* ---- ingest (section 8f #1): file-source sample formats -> SUCOMPLEX ------------------------------ */
 /* format 1 f32, 2 u8 (v-128)/128, 3 s8 v/128, 4 s16 v/32768 [UPSTREAM-RECOLLECTION: libsndfile norm] */
 void sdo_ingest_iq(int format, const void *raw, size_t nsamples, sdo_c32 *out);

@@ -49,6 +49,10 @@ class Clock(C.Structure):
                 ("x1", C.c_float * 2), ("x2", C.c_float * 2)]
 
 
+class CMA(C.Structure):
+    _fields_ = [("n", C.c_int), ("mu", C.c_float), ("locked", C.c_int), ("w", C.c_float * 32), ("d", C.c_float * 32)]
+
+
 class AGCParams(C.Structure):
     _fields_ = [("threshold", C.c_float), ("slope_factor", C.c_float), ("hang_max", C.c_uint),
                 ("delay_line_size", C.c_uint), ("mag_history_size", C.c_uint),
@@ -89,6 +93,13 @@ def lib():
         L.sdo_histogram_feed.restype = C.c_size_t
         L.sdo_clock_feed_bulk.restype = C.c_size_t
         L.sdo_carrier_detect.restype = C.c_float
+        L.sdo_rrc_ntaps.restype = C.c_size_t
+        L.sdo_rrc_ntaps.argtypes = [C.c_double]
+        L.sdo_rrc_design.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double]
+        L.sdo_fir_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.sdo_scale.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]
+        L.sdo_cma_init.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.sdo_cma_feed_bulk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.sdo_sample_zero_crossing.restype = C.c_size_t
         L.sdo_sample_zero_crossing.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_int, C32, C32,
                                                C.c_void_p, C.c_size_t]
@@ -348,6 +359,44 @@ def sample_zero_crossing(data, bnor, space, amplitude=False, threshold=0j, zc_an
                                        C32(float(np.real(zc_angle)), float(np.imag(zc_angle))),
                                        out.ctypes.data_as(C.c_void_p), out.size)
     return out[:n].copy()
+
+
+def rrc_design(sps, rolloff, ntaps=None):
+    n = int(lib().sdo_rrc_ntaps(float(sps))) if ntaps is None else int(ntaps)
+    h = np.empty(n, dtype=np.float32)
+    lib().sdo_rrc_design(h.ctypes.data_as(C.c_void_p), n, float(sps), float(rolloff))
+    return h
+
+
+def fir_feed(hist, h, x):
+    """hist (ntaps-1 complex64, updated in place), real taps h, block x -> y"""
+    x = _c(x)
+    h = np.ascontiguousarray(h, dtype=np.float32)
+    assert hist.dtype == c32 and hist.size == h.size - 1
+    y = np.empty(x.size, dtype=c32)
+    lib().sdo_fir_feed(_p(hist), h.ctypes.data_as(C.c_void_p), h.size, _p(x), x.size, _p(y))
+    return y
+
+
+def scale(x, g):
+    x = _c(x)
+    y = np.empty(x.size, dtype=c32)
+    lib().sdo_scale(_p(x), x.size, float(g), _p(y))
+    return y
+
+
+def cma_new(n, mu, locked=False):
+    q = CMA()
+    lib().sdo_cma_init(C.byref(q), int(n), float(mu))
+    q.locked = int(bool(locked))
+    return q
+
+
+def cma_feed_bulk(q, x):
+    x = _c(x)
+    y = np.empty(x.size, dtype=c32)
+    lib().sdo_cma_feed_bulk(C.byref(q), _p(x), x.size, _p(y))
+    return y
 
 
 def ingest_iq(fmt, raw):

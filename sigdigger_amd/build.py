@@ -25,6 +25,7 @@ SOURCES = {
     "specview.hip": ["-ffp-contract=off"],
     "fft.hip": ["-ffp-contract=fast"],
     "ingest.hip": ["-ffp-contract=off"],
+    "stages.hip": ["-ffp-contract=off"],
     "capi.hip":  ["-ffp-contract=off"],
     "analyzer.cpp": ["-ffp-contract=off"],
 }

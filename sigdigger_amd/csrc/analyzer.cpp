@@ -293,6 +293,10 @@ struct Inspector {
   suamd_agc_bank_t *agc = nullptr;
   suamd_costas_bank_t *costas = nullptr;
   suamd_clock_bank_t *clock = nullptr;
+  suamd_nco_bank_t *nco = nullptr;            // afc.costas-order = 0 with afc.offset
+  suamd_fir_bank_t *mf = nullptr;             // mf.type = MANUAL
+  suamd_cma_bank_t *cma = nullptr;            // equalizer.type = CMA
+  float fixed_gain = 0;                       // agc.enabled = false: linear agc.gain (0 = none)
   bool quad = false, first = true;
   suamd_complex *d_y = nullptr, *d_a = nullptr, *d_z = nullptr, *d_sym = nullptr, *d_prev = nullptr;
   uint32_t *d_count = nullptr;
@@ -303,7 +307,11 @@ struct Inspector {
     if (agc) suamd_agc_bank_destroy(agc);
     if (costas) suamd_costas_bank_destroy(costas);
     if (clock) suamd_clock_bank_destroy(clock);
-    bank = nullptr; agc = nullptr; costas = nullptr; clock = nullptr;
+    if (nco) suamd_nco_bank_destroy(nco);
+    if (mf) suamd_fir_bank_destroy(mf);
+    if (cma) suamd_cma_bank_destroy(cma);
+    bank = nullptr; agc = nullptr; costas = nullptr; clock = nullptr; nco = nullptr; mf = nullptr; cma = nullptr;
+    fixed_gain = 0;
   }
   void free_all()
   {
@@ -408,11 +416,15 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
   if (in.cls == "raw") return true;
   const double baud = cfg_get(in.config, "clock.baud", 0);
   const double sps = baud > 0 ? in.equiv_fs / baud : 8.0;
+  // stage order of the generic inspector: gain control -> carrier control -> matched filter ->
+  // clock recovery -> equalizer (Default/GenericInspector/InspectorCtl/*.cpp, one control each)
   if (cfg_get(in.config, "agc.enabled", 1) != 0) {
     struct suamd_agc_params prm;
     suamd_agc_params_from_tau(&prm, (float)sps);
     in.agc = suamd_agc_bank_new(a->ctx, 1, &prm);
     if (!in.agc) { err = suamd_last_error(); return false; }
+  } else {
+    in.fixed_gain = (float)std::pow(10.0, cfg_get(in.config, "agc.gain", 0) / 20.0);     // dB spin box
   }
   if (in.cls == "psk") {
     const int order = (int)cfg_get(in.config, "afc.costas-order", 0);
@@ -421,13 +433,32 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
       in.costas = suamd_costas_bank_new(a->ctx, 1, order, 0.0f, (float)std::fmin(2.0 / sps, 0.95), 3,
                                         (float)(2.0 * loop_bw / in.equiv_fs));
       if (!in.costas) { err = suamd_last_error(); return false; }
+    } else if (cfg_get(in.config, "afc.offset", 0) != 0) {  // manual: mix the offset away
+      const double fn = -2.0 * cfg_get(in.config, "afc.offset", 0) / in.equiv_fs;
+      in.nco = suamd_nco_bank_new(a->ctx, 1, &fn);
+      if (!in.nco) { err = suamd_last_error(); return false; }
     }
   } else {                                                // fsk
     in.quad = cfg_get(in.config, "fsk.quad-demod", 1) != 0;
   }
-  if ((int)cfg_get(in.config, "clock.type", 0) == 1 && baud > 0) {
-    in.clock = suamd_clock_bank_new(a->ctx, 1, (float)cfg_get(in.config, "clock.gain", .2), (float)(baud / in.equiv_fs));
+  if ((int)cfg_get(in.config, "mf.type", 0) == 1 && baud > 0) {
+    const unsigned nt = suamd_rrc_ntaps(sps);
+    std::vector<float> h(nt);
+    suamd_rrc_design(h.data(), nt, sps, cfg_get(in.config, "mf.roll-off", .35));
+    in.mf = suamd_fir_bank_new(a->ctx, 1, h.data(), nt);
+    if (!in.mf) { err = suamd_last_error(); return false; }
+  }
+  if (baud > 0) {
+    const bool gardner = (int)cfg_get(in.config, "clock.type", 0) == 1;
+    in.clock = suamd_clock_bank_new(a->ctx, 1, gardner ? (float)cfg_get(in.config, "clock.gain", .2) : 0.0f,
+                                    (float)(baud / in.equiv_fs));
     if (!in.clock) { err = suamd_last_error(); return false; }
+    if (!gardner) suamd_clock_bank_set_phase(in.clock, 0.5f * (float)cfg_get(in.config, "clock.phase", 0), a->stream);
+    if ((int)cfg_get(in.config, "equalizer.type", 0) == 1) {
+      in.cma = suamd_cma_bank_new(a->ctx, 1, 8, (float)cfg_get(in.config, "equalizer.rate", 1e-3));
+      if (!in.cma) { err = suamd_last_error(); return false; }
+      suamd_cma_bank_set_locked(in.cma, cfg_get(in.config, "equalizer.locked", 0) != 0);
+    }
   }
   return true;
 }
@@ -454,17 +485,31 @@ void run_inspector(suscan_analyzer *a, Inspector &in, size_t len)
   const suamd_view row = {(SUSCOUNT)in.cap, 1};
   SUSCOUNT m = 0;
   if (!suamd_chanbank_feed(in.bank, a->d_x, len, in.d_y, row, &m, a->stream)) return;
+  // ping-pong through d_a / d_z so that no stage runs in place
   const suamd_complex *cur = in.d_y;
+  auto other = [&](const suamd_complex *p) { return p == in.d_a ? in.d_z : in.d_a; };
   if (in.agc) { suamd_agc_bank_feed(in.agc, cur, row, in.d_a, row, m, a->stream); cur = in.d_a; }
+  else if (in.fixed_gain > 0) { suamd_rows_scale(a->ctx, cur, row, in.d_a, row, 1, m, in.fixed_gain, a->stream); cur = in.d_a; }
   if (in.costas) {
-    suamd_costas_bank_feed(in.costas, cur, row, in.d_z, row, m, a->stream);
-    cur = in.d_z;
+    suamd_complex *o = other(cur);
+    suamd_costas_bank_feed(in.costas, cur, row, o, row, m, a->stream);
+    cur = o;
+  } else if (in.nco) {
+    suamd_complex *o = other(cur);
+    suamd_nco_bank_feed(in.nco, cur, row, o, row, m, a->stream);
+    cur = o;
   } else if (in.quad) {
-    suamd_quad_demod_batch(a->ctx, cur, row, in.d_z, row, 1, m, in.d_prev, in.first ? SU_TRUE : SU_FALSE, in.d_sym /*tmp*/,
+    suamd_complex *o = other(cur);
+    suamd_quad_demod_batch(a->ctx, cur, row, o, row, 1, m, in.d_prev, in.first ? SU_TRUE : SU_FALSE, in.d_sym /*tmp*/,
                            a->stream);
     (void)hipMemcpyAsync(in.d_prev, in.d_sym, 8, hipMemcpyDeviceToDevice, a->stream);
     in.first = false;
-    cur = in.d_z;
+    cur = o;
+  }
+  if (in.mf) {
+    suamd_complex *o = other(cur);
+    suamd_fir_bank_feed(in.mf, cur, row, o, row, m, a->stream);
+    cur = o;
   }
   if (in.clock) {
     (void)hipMemsetAsync(in.d_count, 0, 4, a->stream);
@@ -472,6 +517,7 @@ void run_inspector(suscan_analyzer *a, Inspector &in, size_t len)
     uint32_t n = 0;
     (void)hipMemcpyAsync(&n, in.d_count, 4, hipMemcpyDeviceToHost, a->stream);
     (void)hipStreamSynchronize(a->stream);
+    if (in.cma && n) suamd_cma_bank_feed(in.cma, in.d_sym, (SUSCOUNT)in.cap, nullptr, n, in.d_sym, (SUSCOUNT)in.cap, a->stream);
     emit_samples(a, in, in.d_sym, n);
   } else {
     emit_samples(a, in, cur, m);

@@ -564,6 +564,159 @@ SUSDIFF suamd_sample_zero_crossing_bulk(suamd_ctx_t *ctx, const suamd_complex *d
   return total;
 }
 
+// ---- A7 stages: fixed gain, manual carrier offset, matched filter, CMA equalizer ---------------------
+SUBOOL suamd_rows_scale(suamd_ctx_t *ctx, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y, suamd_view yv,
+                        unsigned nchan, SUSCOUNT len, SUFLOAT gain, void *stream)
+{
+  if (!ctx || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(sdk::rows_scale(d_x, as_view(xv), d_y, as_view(yv), (int)nchan, (long long)len, gain, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+struct suamd_nco_bank { suamd_ctx *ctx; unsigned nchan; uint32_t *d_dphase, *d_phase0; uint64_t n; };
+
+suamd_nco_bank_t *suamd_nco_bank_new(suamd_ctx_t *ctx, unsigned nchan, const double *fnor)
+{
+  if (!ctx || !fnor || nchan == 0) { set_err("bad argument"); return nullptr; }
+  HIP_TRY(hipSetDevice(ctx->device), nullptr);
+  suamd_nco_bank *b = new (std::nothrow) suamd_nco_bank;
+  if (!b) { set_err("out of memory"); return nullptr; }
+  b->ctx = ctx; b->nchan = nchan; b->n = 0;
+  std::vector<uint32_t> dp(nchan);
+  for (unsigned c = 0; c < nchan; ++c) dp[c] = suamd_fnor_to_dphase(fnor[c]);
+  b->d_dphase = dev_from_host(dp);
+  b->d_phase0 = dev_zeros<uint32_t>(nchan);
+  if (!b->d_dphase || !b->d_phase0) { set_err("device allocation failed"); suamd_nco_bank_destroy(b); return nullptr; }
+  return b;
+}
+
+void suamd_nco_bank_destroy(suamd_nco_bank_t *b)
+{
+  if (!b) return;
+  if (b->d_dphase) hipFree(b->d_dphase);
+  if (b->d_phase0) hipFree(b->d_phase0);
+  delete b;
+}
+
+SUBOOL suamd_nco_bank_feed(suamd_nco_bank_t *b, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y, suamd_view yv,
+                           SUSCOUNT len, void *stream)
+{
+  if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(sdk::rows_xlate(d_x, as_view(xv), d_y, as_view(yv), (int)b->nchan, (long long)len, b->d_dphase, b->d_phase0,
+                          b->n, as_stream(stream)), SU_FALSE);
+  b->n += len;
+  return SU_TRUE;
+}
+
+unsigned suamd_rrc_ntaps(double sps) { return 2u * (unsigned)std::ceil(3.0 * sps) + 1u; }
+
+void suamd_rrc_design(SUFLOAT *taps, unsigned ntaps, double sps, double beta)
+{
+  std::vector<double> d(ntaps);
+  double sum = 0;
+  for (unsigned i = 0; i < ntaps; ++i) {
+    const double t = ((double)i - 0.5 * (double)(ntaps - 1)) / sps;     // in symbols
+    double v;
+    if (std::fabs(t) < 1e-12) {
+      v = 1.0 - beta + 4.0 * beta / kPi;
+    } else if (beta > 0 && std::fabs(std::fabs(4.0 * beta * t) - 1.0) < 1e-9) {
+      v = beta / std::sqrt(2.0) * ((1.0 + 2.0 / kPi) * std::sin(kPi / (4.0 * beta)) + (1.0 - 2.0 / kPi) * std::cos(kPi / (4.0 * beta)));
+    } else {
+      const double a = kPi * t;
+      v = (std::sin(a * (1.0 - beta)) + 4.0 * beta * t * std::cos(a * (1.0 + beta))) / (a * (1.0 - 16.0 * beta * beta * t * t));
+    }
+    d[i] = v;
+    sum += v;
+  }
+  for (unsigned i = 0; i < ntaps; ++i) taps[i] = (float)(d[i] / sum);
+}
+
+struct suamd_fir_bank { suamd_ctx *ctx; unsigned nchan, ntaps; float *d_taps; suamd_complex *d_hist[2]; int cur; };
+
+suamd_fir_bank_t *suamd_fir_bank_new(suamd_ctx_t *ctx, unsigned nchan, const SUFLOAT *taps, unsigned ntaps)
+{
+  if (!ctx || !taps || nchan == 0 || ntaps == 0) { set_err("bad argument"); return nullptr; }
+  if (ntaps > 8192) { set_err("ntaps %u unsupported (<= 8192)", ntaps); return nullptr; }
+  HIP_TRY(hipSetDevice(ctx->device), nullptr);
+  suamd_fir_bank *b = new (std::nothrow) suamd_fir_bank;
+  if (!b) { set_err("out of memory"); return nullptr; }
+  std::memset(b, 0, sizeof *b);
+  b->ctx = ctx; b->nchan = nchan; b->ntaps = ntaps;
+  b->d_taps = dev_from_host(std::vector<float>(taps, taps + ntaps));
+  const size_t hn = (size_t)(ntaps - 1) * nchan;
+  b->d_hist[0] = dev_zeros<suamd_complex>(hn);
+  b->d_hist[1] = dev_zeros<suamd_complex>(hn);
+  if (!b->d_taps || !b->d_hist[0] || !b->d_hist[1]) { set_err("device allocation failed"); suamd_fir_bank_destroy(b); return nullptr; }
+  return b;
+}
+
+void suamd_fir_bank_destroy(suamd_fir_bank_t *b)
+{
+  if (!b) return;
+  if (b->d_taps) hipFree(b->d_taps);
+  if (b->d_hist[0]) hipFree(b->d_hist[0]);
+  if (b->d_hist[1]) hipFree(b->d_hist[1]);
+  delete b;
+}
+
+SUBOOL suamd_fir_bank_feed(suamd_fir_bank_t *b, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y, suamd_view yv,
+                           SUSCOUNT len, void *stream)
+{
+  if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  if (d_x == d_y) { set_err("in-place filtering is not supported"); return SU_FALSE; }
+  if (len == 0) return SU_TRUE;
+  HIP_TRY(sdk::rows_fir(d_x, as_view(xv), d_y, as_view(yv), (int)b->nchan, (long long)len, b->d_taps, (int)b->ntaps,
+                        b->d_hist[b->cur], b->d_hist[b->cur ^ 1], as_stream(stream)), SU_FALSE);
+  b->cur ^= 1;
+  return SU_TRUE;
+}
+
+struct suamd_cma_bank { suamd_ctx *ctx; unsigned nchan, n; float mu; int locked; suamd_complex *d_w, *d_dl; };
+
+suamd_cma_bank_t *suamd_cma_bank_new(suamd_ctx_t *ctx, unsigned nchan, unsigned ntaps, SUFLOAT mu)
+{
+  if (!ctx || nchan == 0) { set_err("bad argument"); return nullptr; }
+  if (ntaps < 1 || ntaps > 16) { set_err("equalizer length %u unsupported (1..16)", ntaps); return nullptr; }
+  HIP_TRY(hipSetDevice(ctx->device), nullptr);
+  suamd_cma_bank *b = new (std::nothrow) suamd_cma_bank;
+  if (!b) { set_err("out of memory"); return nullptr; }
+  b->ctx = ctx; b->nchan = nchan; b->n = ntaps; b->mu = mu; b->locked = 0;
+  std::vector<suamd_complex> w((size_t)ntaps * nchan);
+  for (size_t i = 0; i < w.size(); ++i) { w[i].re = i < nchan ? 1.0f : 0.0f; w[i].im = 0.0f; }   // w[0] = 1
+  b->d_w = dev_from_host(w);
+  b->d_dl = dev_zeros<suamd_complex>((size_t)ntaps * nchan);
+  if (!b->d_w || !b->d_dl) { set_err("device allocation failed"); suamd_cma_bank_destroy(b); return nullptr; }
+  return b;
+}
+
+void suamd_cma_bank_destroy(suamd_cma_bank_t *b)
+{
+  if (!b) return;
+  if (b->d_w) hipFree(b->d_w);
+  if (b->d_dl) hipFree(b->d_dl);
+  delete b;
+}
+
+void suamd_cma_bank_set_locked(suamd_cma_bank_t *b, SUBOOL locked) { if (b) b->locked = locked ? 1 : 0; }
+void suamd_cma_bank_set_rate(suamd_cma_bank_t *b, SUFLOAT mu) { if (b) b->mu = mu; }
+
+SUBOOL suamd_cma_bank_feed(suamd_cma_bank_t *b, const suamd_complex *d_x, SUSCOUNT x_stride, const uint32_t *d_count,
+                           SUSCOUNT fixed_len, suamd_complex *d_y, SUSCOUNT y_stride, void *stream)
+{
+  if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(sdk::cma_feed((int)b->n, b->mu, b->locked, b->d_w, b->d_dl, (int)b->nchan, d_x, (long long)x_stride, d_count,
+                        (long long)fixed_len, d_y, (long long)y_stride, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUBOOL suamd_cma_bank_get_weights(suamd_cma_bank_t *b, suamd_complex *weights, void *stream)
+{
+  if (!b || !weights) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(hipMemcpyAsync(weights, b->d_w, sizeof(suamd_complex) * (size_t)b->n * b->nchan, hipMemcpyDeviceToHost, as_stream(stream)), SU_FALSE);
+  HIP_TRY(hipStreamSynchronize(as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
 // ---- Costas --------------------------------------------------------------------------------------
 suamd_costas_bank_t *suamd_costas_bank_new(suamd_ctx_t *ctx, unsigned nchan, int kind, SUFLOAT fhint, SUFLOAT arm_bw,
                                            unsigned arm_order, SUFLOAT loop_bw)
@@ -696,6 +849,15 @@ suamd_clock_bank_t *suamd_clock_bank_new(suamd_ctx_t *ctx, unsigned nchan, SUFLO
     return nullptr;
   }
   return b;
+}
+
+SUBOOL suamd_clock_bank_set_phase(suamd_clock_bank_t *b, SUFLOAT phi, void *stream)
+{
+  if (!b) { set_err("null argument"); return SU_FALSE; }
+  std::vector<float> v(b->nchan, phi);
+  HIP_TRY(hipMemcpyAsync(b->s.phi, v.data(), sizeof(float) * b->nchan, hipMemcpyHostToDevice, as_stream(stream)), SU_FALSE);
+  HIP_TRY(hipStreamSynchronize(as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
 }
 
 void suamd_clock_bank_destroy(suamd_clock_bank_t *b)

@@ -111,6 +111,17 @@ hipError_t specview_interpolate(float *psd, float *accum, float *cnt, int n, hip
 hipError_t specview_sweep_linear(const SpecViewLinear *d_geom, int nframes, const float *frames, long long frame_stride,
                                  const float *cnt_before, float *accum, float *cnt, int n, hipStream_t st);
 
+// ---- stages.hip ----
+hipError_t rows_scale(const void *x, View xv, void *y, View yv, int nchan, long long len, float g, hipStream_t st);
+hipError_t rows_xlate(const void *x, View xv, void *y, View yv, int nchan, long long len, const uint32_t *dphase,
+                      const uint32_t *phase0, uint64_t n0, hipStream_t st);
+// hist / hist_next: [ntaps-1][nchan] complex (time-major), ping-pong
+hipError_t rows_fir(const void *x, View xv, void *y, View yv, int nchan, long long len, const float *h, int ntaps,
+                    const void *hist, void *hist_next, hipStream_t st);
+// w, dl: [n][nchan] complex; rows x / y channel-major with the given strides; count == nullptr -> fixed_len each
+hipError_t cma_feed(int n, float mu, int locked, void *w, void *dl, int nchan, const void *x, long long x_stride,
+                    const uint32_t *count, long long fixed_len, void *y, long long y_stride, hipStream_t st);
+
 // ---- ingest.hip ----
 // format: 1 float32, 2 unsigned 8, 3 signed 8, 4 signed 16 (interleaved I/Q) -> SUCOMPLEX
 hipError_t ingest_iq(int format, const void *raw, long long nsamp, void *out, hipStream_t st);

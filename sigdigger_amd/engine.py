@@ -207,6 +207,20 @@ class Context:
                                           C.byref(mx), _stream(stream)), "suamd_doppler_calc")
         return pk.value, sg.value, mx.value, spec
 
+    def rrc_design(self, sps, rolloff, ntaps=None):
+        n = int(self.lib.suamd_rrc_ntaps(float(sps))) if ntaps is None else int(ntaps)
+        h = np.empty(n, dtype=np.float32)
+        self.lib.suamd_rrc_design(h.ctypes.data_as(C.c_void_p), n, float(sps), float(rolloff))
+        return h
+
+    def rows_scale(self, x, gain, out=None, stream=None):
+        _chk_rows(x, "x")
+        if out is None:
+            out = torch.empty_like(x)
+        check(self.lib.suamd_rows_scale(self.h, _ptr(x), _view(x), _ptr(out), _view(out), x.shape[0], x.shape[1],
+                                        float(gain), _stream(stream)), "suamd_rows_scale")
+        return out
+
     def lpf_design(self, ntaps, fc):
         h = np.empty(ntaps, dtype=np.float32)
         self.lib.suamd_lpf_design(h.ctypes.data_as(C.c_void_p), ntaps, float(fc))
@@ -369,6 +383,74 @@ class PLLBank(_LoopBank):
         return om, ph
 
 
+class NCOBank(_LoopBank):
+    """free-running su_ncqo per channel (afc.offset, InspectorCtl/AfcControl.cpp:54-83)."""
+    _destroy = "suamd_nco_bank_destroy"
+
+    def __init__(self, ctx, fnor):
+        fn = np.ascontiguousarray(fnor, dtype=np.float64)
+        self.ctx, self.nchan = ctx, int(fn.size)
+        self.h = ctx.lib.suamd_nco_bank_new(ctx.h, self.nchan, fn.ctypes.data_as(C.c_void_p))
+        if not self.h:
+            raise SigDiggerAmdError("suamd_nco_bank_new: " + _l.last_error())
+
+    def feed(self, x, out=None, stream=None):
+        out = self._rows(x, out)
+        check(self.ctx.lib.suamd_nco_bank_feed(self.h, _ptr(x), _view(x), _ptr(out), _view(out), x.shape[1],
+                                               _stream(stream)), "suamd_nco_bank_feed")
+        return out
+
+
+class FIRBank(_LoopBank):
+    """real-tap FIR at the channel rate for a bank of rows (matched filter, InspectorCtl/MfControl.cpp:56-78)."""
+    _destroy = "suamd_fir_bank_destroy"
+
+    def __init__(self, ctx, nchan, taps):
+        t = np.ascontiguousarray(taps, dtype=np.float32)
+        self.ctx, self.nchan, self.ntaps = ctx, int(nchan), int(t.size)
+        self.h = ctx.lib.suamd_fir_bank_new(ctx.h, self.nchan, t.ctypes.data_as(C.c_void_p), self.ntaps)
+        if not self.h:
+            raise SigDiggerAmdError("suamd_fir_bank_new: " + _l.last_error())
+
+    def feed(self, x, out=None, stream=None):
+        out = self._rows(x, out)
+        check(self.ctx.lib.suamd_fir_bank_feed(self.h, _ptr(x), _view(x), _ptr(out), _view(out), x.shape[1],
+                                               _stream(stream)), "suamd_fir_bank_feed")
+        return out
+
+
+class CMABank(_LoopBank):
+    """constant-modulus equalizer per channel at the symbol rate (InspectorCtl/EqualizerControl.cpp:56-75)."""
+    _destroy = "suamd_cma_bank_destroy"
+
+    def __init__(self, ctx, nchan, ntaps, rate):
+        self.ctx, self.nchan, self.ntaps = ctx, int(nchan), int(ntaps)
+        self.h = ctx.lib.suamd_cma_bank_new(ctx.h, self.nchan, self.ntaps, float(rate))
+        if not self.h:
+            raise SigDiggerAmdError("suamd_cma_bank_new: " + _l.last_error())
+
+    def set_locked(self, locked):
+        self.ctx.lib.suamd_cma_bank_set_locked(self.h, int(bool(locked)))
+
+    def feed(self, sym, count=None, out=None, stream=None):
+        """sym: [nchan, M] channel-major symbol rows; count: int32 [nchan] symbols per row (None = all M)."""
+        _chk_rows(sym, "sym")
+        if sym.stride(1) != 1:
+            raise SigDiggerAmdError("sym must be channel-major")
+        if out is None:
+            out = torch.empty_like(sym)
+        check(self.ctx.lib.suamd_cma_bank_feed(self.h, _ptr(sym), sym.stride(0), _ptr(count) if count is not None else None,
+                                               sym.shape[1], _ptr(out), out.stride(0), _stream(stream)),
+              "suamd_cma_bank_feed")
+        return out
+
+    def weights(self, stream=None):
+        w = np.empty((self.ntaps, self.nchan), dtype=np.complex64)
+        check(self.ctx.lib.suamd_cma_bank_get_weights(self.h, w.ctypes.data_as(C.c_void_p), _stream(stream)),
+              "suamd_cma_bank_get_weights")
+        return w
+
+
 class ClockBank(_LoopBank):
     """nchan x su_clock_detector_t, Gardner (Tasks/WaveSampler.cpp:177-213)."""
     _destroy = "suamd_clock_bank_destroy"
@@ -389,6 +471,9 @@ class ClockBank(_LoopBank):
                                                  sym.stride(0), _ptr(count), _stream(stream)),
               "suamd_clock_bank_feed")
         return sym, count
+
+    def set_phase(self, phi, stream=None):
+        check(self.ctx.lib.suamd_clock_bank_set_phase(self.h, float(phi), _stream(stream)), "suamd_clock_bank_set_phase")
 
     def state(self, stream=None):
         bn = np.empty(self.nchan, dtype=np.float32)

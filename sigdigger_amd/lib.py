@@ -60,6 +60,22 @@ PROTOTYPES = {
     "suamd_sample_zero_crossing_bulk": (C.c_int64, [VP, VP, U64, F32, INT, INT, F32, F32, F32, F32, VP, U64, VP]),
     "suamd_conj_prev_bulk": (INT, [VP, VP, VP, U64, F32, F32, VP]),
     "suamd_ingest_iq": (INT, [VP, INT, VP, U64, VP, VP]),
+    "suamd_rows_scale": (INT, [VP, VP, View, VP, View, UINT, U64, F32, VP]),
+    "suamd_nco_bank_new": (VP, [VP, UINT, VP]),
+    "suamd_nco_bank_destroy": (None, [VP]),
+    "suamd_nco_bank_feed": (INT, [VP, VP, View, VP, View, U64, VP]),
+    "suamd_rrc_ntaps": (UINT, [F64]),
+    "suamd_rrc_design": (None, [VP, UINT, F64, F64]),
+    "suamd_fir_bank_new": (VP, [VP, UINT, VP, UINT]),
+    "suamd_fir_bank_destroy": (None, [VP]),
+    "suamd_fir_bank_feed": (INT, [VP, VP, View, VP, View, U64, VP]),
+    "suamd_cma_bank_new": (VP, [VP, UINT, UINT, F32]),
+    "suamd_cma_bank_destroy": (None, [VP]),
+    "suamd_cma_bank_set_locked": (None, [VP, INT]),
+    "suamd_cma_bank_set_rate": (None, [VP, F32]),
+    "suamd_cma_bank_feed": (INT, [VP, VP, U64, VP, U64, VP, U64, VP]),
+    "suamd_cma_bank_get_weights": (INT, [VP, VP, VP]),
+    "suamd_clock_bank_set_phase": (INT, [VP, F32, VP]),
     "suamd_format_bytes_per_sample": (UINT, [INT]),
     "suamd_costas_bank_new": (VP, [VP, UINT, INT, F32, F32, UINT, F32]),
     "suamd_costas_bank_destroy": (None, [VP]),

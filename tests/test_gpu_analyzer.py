@@ -219,6 +219,73 @@ def test_psk_inspector_protocol_and_symbols(tmp_path, sdo):
     Lb.suscan_mq_finalize(C.byref(mq))
 
 
+def test_manual_chain_config_vocabulary(tmp_path, sdo):
+    """The rest of the inspector vocabulary (GainControl / AfcControl / MfControl / ClockRecovery /
+    EqualizerControl): fixed gain, manual carrier offset, RRC matched filter, fixed-baud sampler with a
+    phase, CMA equalizer -- the SAMPLES stream must equal the oracle chain bit for bit."""
+    nblocks = 10
+    fc, baud, bw, offs = -200e3, 15625.0, 40e3, 310.0
+    x = synth.psk_carriers(L * nblocks, [2 * (fc + offs) / FS], sps=int(FS / baud), order=4, seed=5, snr_db=25)
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    Lb, mq, an = _start(path, L)
+    Lb.suscan_analyzer_set_throttle_async(an, 4 * FS, 0)
+    ch = suscan.Channel(fc=fc, f_lo=fc - bw / 2, f_hi=fc + bw / 2, bw=bw, ft=433.92e6)
+    assert Lb.suscan_analyzer_open_ex_async(an, b"psk", C.byref(ch), 1, -1, 7)
+    st = {"psd": 0, "samples": [], "cfg_at": None}
+
+    def on_msg(t, ptr):
+        if t == suscan.MSG_PSD:
+            st["psd"] += 1
+        elif t == suscan.MSG_INSPECTOR:
+            m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
+            if m.kind == suscan.KIND_OPEN:
+                cfg = Lb.suscan_config_dup(m.config)
+                Lb.suscan_config_set_bool(cfg, b"agc.enabled", 0)
+                Lb.suscan_config_set_float(cfg, b"agc.gain", -20.0)
+                Lb.suscan_config_set_integer(cfg, b"afc.costas-order", 0)
+                Lb.suscan_config_set_float(cfg, b"afc.offset", offs)
+                Lb.suscan_config_set_integer(cfg, b"mf.type", 1)
+                Lb.suscan_config_set_float(cfg, b"mf.roll-off", 0.35)
+                Lb.suscan_config_set_integer(cfg, b"clock.type", 0)
+                Lb.suscan_config_set_float(cfg, b"clock.baud", baud)
+                Lb.suscan_config_set_float(cfg, b"clock.phase", 0.3)
+                Lb.suscan_config_set_integer(cfg, b"equalizer.type", 1)
+                Lb.suscan_config_set_float(cfg, b"equalizer.rate", 2e-3)
+                assert Lb.suscan_analyzer_set_inspector_config_async(an, m.handle, cfg, 8)
+                Lb.suscan_config_destroy(cfg)
+            elif m.kind == suscan.KIND_SET_CONFIG:
+                st["cfg_at"] = st["psd"]
+                st["samples"] = []
+        elif t == suscan.MSG_SAMPLES and st["cfg_at"] is not None:
+            m = C.cast(ptr, C.POINTER(suscan.SampleBatchMsg)).contents
+            st["samples"].append(np.ctypeslib.as_array(m.samples, shape=(m.sample_count * 2,)).copy().view(np.complex64))
+
+    _pump(Lb, an, on_msg)
+    b0 = st["cfg_at"]
+    assert b0 is not None and b0 < nblocks - 4
+    D, efs = 8, FS / 8
+    taps = sdo.lpf_design(255, bw / FS)
+    dp = sdo.fnor_to_dphase(-2 * fc / FS)
+    y = sdo.chan_feed(np.zeros(254, np.complex64), x[b0 * L:], 0, sdo.chan_modulate_taps(taps, dp), D, 0, dp)
+    y = sdo.scale(y, np.float32(10.0 ** (-20.0 / 20.0)))
+    y = sdo.xlate_bulk(y, 0, sdo.fnor_to_dphase(-2.0 * offs / efs), 0)
+    sps = efs / baud
+    h = sdo.rrc_design(sps, float(np.float32(0.35)))            # config values are SUFLOAT
+    y = sdo.fir_feed(np.zeros(h.size - 1, np.complex64), h, y)
+    cd = sdo.clock_new(0.0, baud / efs)
+    cd.phi = np.float32(0.5) * np.float32(0.3)
+    sym = sdo.clock_feed_bulk(cd, y)
+    # the equalizer sees the symbols block by block, but its state carries over: one run is the same
+    ref = sdo.cma_feed_bulk(sdo.cma_new(8, 2e-3), sym)
+    got = np.concatenate(st["samples"])
+    assert len(got) == len(ref) and abs(len(got) - (nblocks - b0) * L / D / sps) <= 2, "symbol count"
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "symbols differ from the oracle"
+    assert np.all(np.isfinite(got.view(np.float32))) and np.mean(np.abs(got)) > 0.01
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+
+
 def test_halt_wakes_the_reader_and_bad_source_reports_failure(tmp_path):
     x = synth.tone_noise(L * 2, seed=1)
     path = tmp_path / "iq.raw"

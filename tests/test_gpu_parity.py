@@ -616,6 +616,91 @@ def test_conj_prev_and_gardner_frequency_space(ctx, sdo):
 
 
 # ------------------------------------------------------------------------------------------
+# A7: stages behind the rest of the inspector config vocabulary -- bit exact
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", ["cm", "tm"])
+def test_rows_scale_and_nco_bank_bit_exact(ctx, sdo, layout):
+    nchan, n = 5, 7001
+    x = _rows(nchan, n)
+    got = host(ctx.rows_scale(dev_rows(x, layout), 0.37, out=empty_rows(nchan, n, layout)))
+    for c in range(nchan):
+        assert_bits(got[c], sdo.scale(x[c], 0.37), f"fixed gain ch {c}")
+    fn = np.array([-0.013, 0.0, 0.25, -0.9, 0.00041])
+    bank = engine.NCOBank(ctx, fn)
+    dx = dev_rows(x, layout)
+    got = np.concatenate([host(bank.feed(dx[:, a:b], out=empty_rows(nchan, b - a, layout)))
+                          for a, b in ((0, 3), (3, 4099), (4099, n))], axis=1)
+    for c in range(nchan):
+        ref = sdo.xlate_bulk(x[c], 0, sdo.fnor_to_dphase(fn[c]), 0)
+        assert_bits(got[c], ref, f"manual carrier offset ch {c}")
+
+
+@pytest.mark.parametrize("layout", ["cm", "tm"])
+@pytest.mark.parametrize("sps,beta", [(4.0, 0.35), (15.625, 0.2), (2.0, 1.0)])
+def test_matched_filter_bank_bit_exact(ctx, sdo, layout, sps, beta):
+    nchan, n = 67, 3000
+    x = _rows(nchan, n, sps=int(sps))
+    h = ctx.rrc_design(sps, beta)
+    href = sdo.rrc_design(sps, beta)
+    assert h.size == 2 * int(np.ceil(3 * sps)) + 1 and np.array_equal(h.view(np.uint32), href.view(np.uint32))
+    bank = engine.FIRBank(ctx, nchan, h)
+    dx = dev_rows(x, layout)
+    cuts = ((0, 1), (1, 2), (2, 50), (50, 1029), (1029, n))       # blocks shorter and longer than the filter
+    got = np.concatenate([host(bank.feed(dx[:, a:b], out=empty_rows(nchan, b - a, layout))) for a, b in cuts], axis=1)
+    for c in (0, 1, 33, 63, 64, 66):
+        hist = np.zeros(h.size - 1, np.complex64)
+        ref = sdo.fir_feed(hist, href, x[c])
+        assert_bits(got[c], ref, f"matched filter ch {c}")
+
+
+@pytest.mark.parametrize("ntaps", [1, 5, 8, 16])
+def test_cma_bank_bit_exact(ctx, sdo, ntaps):
+    nchan, n = 66, 1500
+    rng = np.random.default_rng(ntaps)
+    sym = ((rng.integers(0, 2, (nchan, n)) * 2 - 1) + 1j * (rng.integers(0, 2, (nchan, n)) * 2 - 1)) / np.sqrt(2)
+    x = (sym + 0.3 * np.roll(sym, 1, axis=1) * np.exp(0.5j) + 0.02 * rng.standard_normal((nchan, n))).astype(np.complex64)
+    counts = rng.integers(0, n + 1, nchan).astype(np.int32)        # every channel its own symbol count
+    counts[:3] = [n, 0, 1]
+    bank = engine.CMABank(ctx, nchan, ntaps, 2e-3)
+    dx = dev(x)
+    y1 = host(bank.feed(dx[:, :700].contiguous(), count=dev(np.minimum(counts, 700))))
+    bank.set_locked(True)                                          # equalizer.locked: weights frozen
+    rest = np.maximum(counts - 700, 0).astype(np.int32)
+    y2 = host(bank.feed(dx[:, 700:].contiguous(), count=dev(rest)))
+    w = bank.weights()
+    for c in range(nchan):
+        q = sdo.cma_new(ntaps, 2e-3)
+        k1 = min(int(counts[c]), 700)
+        r1 = sdo.cma_feed_bulk(q, x[c, :k1])
+        q.locked = 1
+        r2 = sdo.cma_feed_bulk(q, x[c, 700:700 + int(rest[c])])
+        assert_bits(y1[c, :k1], r1, f"cma ch {c} (adapting)")
+        assert_bits(y2[c, :int(rest[c])], r2, f"cma ch {c} (locked)")
+        wref = np.array(q.w[:2 * ntaps], dtype=np.float32).view(np.complex64)
+        assert_bits(w[:, c], wref, f"cma weights ch {c}")
+
+
+def test_manual_clock_is_gardner_without_feedback(ctx, sdo):
+    """clock.type = MANUAL: loop gain 0 keeps the baud, clock.phase sets the sampling phase."""
+    nchan, n, bn = 3, 5000, 0.125
+    x = _rows(nchan, n)
+    bank = engine.ClockBank(ctx, nchan, 0.0, bn)
+    bank.set_phase(0.5 * 0.3)
+    sym = torch.zeros((nchan, n), dtype=torch.complex64, device="cuda")
+    cnt = torch.zeros(nchan, dtype=torch.int32, device="cuda")
+    bank.feed(dev(x), sym, cnt)
+    bnor, _ = bank.state()
+    assert np.all(bnor == np.float32(bn))
+    for c in range(nchan):
+        cd = sdo.clock_new(0.0, bn)
+        cd.phi = 0.5 * 0.3
+        ref = sdo.clock_feed_bulk(cd, x[c])
+        k = int(cnt.cpu()[c])
+        assert k == ref.size and abs(k - n * bn) <= 1
+        assert_bits(host(sym[c, :k]), ref, f"manual clock ch {c}")
+
+
+# ------------------------------------------------------------------------------------------
 # section 8f #1: sample-format ingest -- bit exact
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("fmt,dtype", [(engine.FORMAT_U8, np.uint8), (engine.FORMAT_S8, np.int8),
