@@ -63,6 +63,18 @@ const FieldDef kFskFields[] = {
   {"fsk.quad-demod", SUSCAN_FIELD_TYPE_BOOLEAN, 1},
 };
 
+// "ask": amplitude keying, optionally carrier-locked by a PLL (InspectorCtl/AskControl.cpp:53-76)
+const FieldDef kAskFields[] = {
+  {"agc.enabled", SUSCAN_FIELD_TYPE_BOOLEAN, 1}, {"agc.gain", SUSCAN_FIELD_TYPE_FLOAT, 1},
+  {"mf.type", SUSCAN_FIELD_TYPE_INTEGER, 0}, {"mf.roll-off", SUSCAN_FIELD_TYPE_FLOAT, .35},
+  {"clock.type", SUSCAN_FIELD_TYPE_INTEGER, 0}, {"clock.baud", SUSCAN_FIELD_TYPE_FLOAT, 0},
+  {"clock.gain", SUSCAN_FIELD_TYPE_FLOAT, .2}, {"clock.phase", SUSCAN_FIELD_TYPE_FLOAT, 0},
+  {"clock.running", SUSCAN_FIELD_TYPE_BOOLEAN, 1},
+  {"ask.bits-per-symbol", SUSCAN_FIELD_TYPE_INTEGER, 1}, {"ask.use-pll", SUSCAN_FIELD_TYPE_BOOLEAN, 0},
+  {"ask.loop-bw", SUSCAN_FIELD_TYPE_FLOAT, 100}, {"ask.offset", SUSCAN_FIELD_TYPE_FLOAT, 0},
+  {"ask.channel", SUSCAN_FIELD_TYPE_INTEGER, 0},
+};
+
 struct DescHolder {
   suscan_config_desc_t desc{};
   std::vector<suscan_field> fields;
@@ -83,12 +95,14 @@ struct DescHolder {
 };
 DescHolder &psk_desc() { static DescHolder d("psk", kPskFields, sizeof kPskFields / sizeof kPskFields[0]); return d; }
 DescHolder &fsk_desc() { static DescHolder d("fsk", kFskFields, sizeof kFskFields / sizeof kFskFields[0]); return d; }
+DescHolder &ask_desc() { static DescHolder d("ask", kAskFields, sizeof kAskFields / sizeof kAskFields[0]); return d; }
 DescHolder &raw_desc() { static DescHolder d("raw", nullptr, 0); return d; }
 DescHolder *holder_for(const char *cls)
 {
   if (!cls) return nullptr;
   if (!std::strcmp(cls, "psk")) return &psk_desc();
   if (!std::strcmp(cls, "fsk")) return &fsk_desc();
+  if (!std::strcmp(cls, "ask")) return &ask_desc();
   if (!std::strcmp(cls, "raw")) return &raw_desc();
   return nullptr;
 }
@@ -294,6 +308,7 @@ struct Inspector {
   suamd_costas_bank_t *costas = nullptr;
   suamd_clock_bank_t *clock = nullptr;
   suamd_nco_bank_t *nco = nullptr;            // afc.costas-order = 0 with afc.offset
+  suamd_pll_bank_t *pll = nullptr;            // ask.use-pll
   suamd_fir_bank_t *mf = nullptr;             // mf.type = MANUAL
   suamd_cma_bank_t *cma = nullptr;            // equalizer.type = CMA
   float fixed_gain = 0;                       // agc.enabled = false: linear agc.gain (0 = none)
@@ -308,9 +323,10 @@ struct Inspector {
     if (costas) suamd_costas_bank_destroy(costas);
     if (clock) suamd_clock_bank_destroy(clock);
     if (nco) suamd_nco_bank_destroy(nco);
+    if (pll) suamd_pll_bank_destroy(pll);
     if (mf) suamd_fir_bank_destroy(mf);
     if (cma) suamd_cma_bank_destroy(cma);
-    bank = nullptr; agc = nullptr; costas = nullptr; clock = nullptr; nco = nullptr; mf = nullptr; cma = nullptr;
+    bank = nullptr; agc = nullptr; costas = nullptr; clock = nullptr; nco = nullptr; pll = nullptr; mf = nullptr; cma = nullptr;
     fixed_gain = 0;
   }
   void free_all()
@@ -438,6 +454,12 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
       in.nco = suamd_nco_bank_new(a->ctx, 1, &fn);
       if (!in.nco) { err = suamd_last_error(); return false; }
     }
+  } else if (in.cls == "ask") {
+    if (cfg_get(in.config, "ask.use-pll", 0) != 0) {      // su_pll_init(fhint = offset, fc = loop bandwidth)
+      in.pll = suamd_pll_bank_new(a->ctx, 1, (float)(2.0 * cfg_get(in.config, "ask.offset", 0) / in.equiv_fs),
+                                  (float)(2.0 * cfg_get(in.config, "ask.loop-bw", 100) / in.equiv_fs));
+      if (!in.pll) { err = suamd_last_error(); return false; }
+    }
   } else {                                                // fsk
     in.quad = cfg_get(in.config, "fsk.quad-demod", 1) != 0;
   }
@@ -497,6 +519,10 @@ void run_inspector(suscan_analyzer *a, Inspector &in, size_t len)
   } else if (in.nco) {
     suamd_complex *o = other(cur);
     suamd_nco_bank_feed(in.nco, cur, row, o, row, m, a->stream);
+    cur = o;
+  } else if (in.pll) {
+    suamd_complex *o = other(cur);
+    suamd_pll_bank_feed(in.pll, cur, row, o, row, m, a->stream);
     cur = o;
   } else if (in.quad) {
     suamd_complex *o = other(cur);

@@ -286,6 +286,68 @@ def test_manual_chain_config_vocabulary(tmp_path, sdo):
     Lb.suscan_mq_finalize(C.byref(mq))
 
 
+def test_ask_inspector_with_pll(tmp_path, sdo):
+    """class "ask" (InspectorCtl/AskControl.cpp:53-76): AGC -> PLL (ask.use-pll, ask.loop-bw, ask.offset) ->
+    Gardner; bit exact against the oracle chain."""
+    nblocks = 9
+    fc, baud, bw = 90e3, 7812.5, 30e3
+    n = L * nblocks
+    rng = np.random.default_rng(21)
+    sps = int(FS / baud)
+    env = np.repeat(0.25 + 0.75 * rng.integers(0, 2, n // sps + 1), sps)[:n]            # on-off keying with a floor
+    x = (env * np.exp(1j * (2 * np.pi * (fc + 40.0) / FS * np.arange(n) + 0.7)) +
+         0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    Lb, mq, an = _start(path, L)
+    Lb.suscan_analyzer_set_throttle_async(an, 4 * FS, 0)
+    ch = suscan.Channel(fc=fc, f_lo=fc - bw / 2, f_hi=fc + bw / 2, bw=bw, ft=433.92e6)
+    assert Lb.suscan_analyzer_open_ex_async(an, b"ask", C.byref(ch), 1, -1, 3)
+    st = {"psd": 0, "samples": [], "cfg_at": None}
+
+    def on_msg(t, ptr):
+        if t == suscan.MSG_PSD:
+            st["psd"] += 1
+        elif t == suscan.MSG_INSPECTOR:
+            m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
+            if m.kind == suscan.KIND_OPEN:
+                assert m.class_name == b"ask"
+                cfg = Lb.suscan_config_dup(m.config)
+                Lb.suscan_config_set_bool(cfg, b"ask.use-pll", 1)
+                Lb.suscan_config_set_float(cfg, b"ask.loop-bw", 200.0)
+                Lb.suscan_config_set_float(cfg, b"ask.offset", 0.0)
+                Lb.suscan_config_set_integer(cfg, b"clock.type", 1)
+                Lb.suscan_config_set_float(cfg, b"clock.baud", baud)
+                assert Lb.suscan_analyzer_set_inspector_config_async(an, m.handle, cfg, 4)
+                Lb.suscan_config_destroy(cfg)
+            elif m.kind == suscan.KIND_SET_CONFIG:
+                st["cfg_at"] = st["psd"]
+                st["samples"] = []
+        elif t == suscan.MSG_SAMPLES and st["cfg_at"] is not None:
+            m = C.cast(ptr, C.POINTER(suscan.SampleBatchMsg)).contents
+            st["samples"].append(np.ctypeslib.as_array(m.samples, shape=(m.sample_count * 2,)).copy().view(np.complex64))
+
+    _pump(Lb, an, on_msg)
+    b0 = st["cfg_at"]
+    assert b0 is not None and b0 < nblocks - 4
+    D = 16                                              # pow2floor(1e6 / 60e3)
+    efs = FS / D
+    taps = sdo.lpf_design(255, bw / FS)
+    dp = sdo.fnor_to_dphase(-2 * fc / FS)
+    y = sdo.chan_feed(np.zeros(254, np.complex64), x[b0 * L:], 0, sdo.chan_modulate_taps(taps, dp), D, 0, dp)
+    sps_c = efs / baud
+    a = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(sps_c)), y)
+    z = sdo.pll_track_bulk(sdo.pll_new(0.0, 2 * 200.0 / efs), a)
+    ref = sdo.clock_feed_bulk(sdo.clock_new(0.2, baud / efs), z)
+    got = np.concatenate(st["samples"])
+    assert len(got) == len(ref) and len(ref) > 100
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "symbols differ from the oracle"
+    tail = got[len(got) // 2:]
+    assert np.mean(np.abs(tail.imag)) < 0.35 * np.mean(np.abs(tail.real))        # carrier locked: energy on I
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+
+
 def test_halt_wakes_the_reader_and_bad_source_reports_failure(tmp_path):
     x = synth.tone_noise(L * 2, seed=1)
     path = tmp_path / "iq.raw"
