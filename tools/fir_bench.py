@@ -10,7 +10,7 @@ from sigdigger_amd import engine, synth
 ctx = engine.Context(0)
 L = 1 << 22
 x = torch.randn(L, dtype=torch.complex64, device="cuda")
-for C, D in ((1, 16), (1, 64), (4, 16), (16, 64), (64, 64)):
+for C, D in ((1, 16), (1, 64), (4, 16), (16, 64), (32, 64), (64, 64), (256, 64)):
     fn = synth.raster(C, 1.0 / (C + 1))
     bank = engine.ChannelBank(ctx, fn, D, ctx.lpf_design(255, 0.75 / D))
     out = engine.time_major(C, L // D + 4, "cuda")
