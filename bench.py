@@ -363,7 +363,7 @@ def main():
                             "stage_ms": {k: round(v, 4) for k, v in st2.items()}}
             extra["c5"] = run_c5(args, dev, ctx)
             out["other_workloads"] = extra
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_samples, fn_rank, os.cpu_count() or 1)
         print(json.dumps(out), flush=True)
 

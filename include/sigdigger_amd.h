@@ -226,6 +226,23 @@ SUAMD_API SUBOOL suamd_clock_bank_get_state(suamd_clock_bank_t *b, SUFLOAT *bnor
 SUAMD_API SUBOOL suamd_clock_bank_set_phase(suamd_clock_bank_t *b, SUFLOAT phi, void *stream);
 
 /* ------------------------------------------------------------------------------------ */
+/* section 8f #4: fast autocorrelation of the inspector's sample stream                    */
+/* FACTab::feed (Default/GenericInspector/FACTab.cpp:181-246): per full buffer of `size` samples   */
+/* FFT -> x conj(x) -> inverse FFT -> |.| of the first half; running max / min over               */
+/* [view_start, view_end); fac[i] += alpha (|.|/max - fac[i]).                                      */
+/* ------------------------------------------------------------------------------------ */
+typedef struct suamd_fac suamd_fac_t;
+SUAMD_API suamd_fac_t *suamd_fac_new(suamd_ctx_t *ctx, unsigned size /* 2^k, 16..2^24 */, SUFLOAT alpha);
+SUAMD_API void     suamd_fac_destroy(suamd_fac_t *f);
+SUAMD_API void     suamd_fac_set_alpha(suamd_fac_t *f, SUFLOAT alpha);
+SUAMD_API SUBOOL   suamd_fac_reset(suamd_fac_t *f, void *stream);           /* resizeFAC / setSampleRate: fac = 0, max / min reset */
+/* d_data: nbuffers consecutive buffers of `size` samples (the caller keeps the partial-buffer remainder) */
+SUAMD_API SUBOOL   suamd_fac_feed(suamd_fac_t *f, const suamd_complex *d_data, SUSCOUNT nbuffers, SUSDIFF view_start,
+                                  SUSDIFF view_end, void *stream);
+SUAMD_API SUFLOAT *suamd_fac_array(suamd_fac_t *f);                          /* device pointer, size/2 floats */
+SUAMD_API SUBOOL   suamd_fac_get_range(suamd_fac_t *f, SUFLOAT *min, SUFLOAT *max, void *stream);
+
+/* ------------------------------------------------------------------------------------ */
 /* A7: stages behind the rest of the inspector config vocabulary                         */
 /* (Default/GenericInspector/InspectorCtl/{GainControl,AfcControl,MfControl,Equalizer-   */
 /* Control}.cpp; semantics frozen in SPEC.md section I -- libsuscan is absent)           */

@@ -930,6 +930,37 @@ void sdo_conj_prev(const sdo_c32 *x, size_t n, sdo_c32 prev0, sdo_c32 *y)
 }
 
 /* ===================================================================================== */
+/* FAC [REF-PINNED structure] Default/GenericInspector/FACTab.cpp:181-246                  */
+/* ===================================================================================== */
+void sdo_fac_feed(const sdo_c32 *buf, size_t n, float alpha, long view_start, long view_end,
+                  float *fac, float *max, float *min)
+{
+  double *re = malloc(sizeof(double) * n), *im = malloc(sizeof(double) * n);
+  size_t i;
+  for (i = 0; i < n; ++i) { re[i] = buf[i].re; im[i] = buf[i].im; }
+  sdo_fft_f64(re, im, n);                                   /* SU_FFTW(_execute(direct)) :212 */
+  for (i = 0; i < n; ++i) {                                 /* bufData[i] *= conj(bufData[i]) :214-215 */
+    float a = (float)re[i], b = (float)im[i];
+    re[i] = (double)fmaf(b, b, a * a);
+    im[i] = 0.0;
+  }
+  for (i = 0; i < n; ++i) im[i] = -im[i];                   /* inverse = conj(FFT(conj(.))), unnormalised :217 */
+  sdo_fft_f64(re, im, n);
+  for (i = 0; i < n / 2; ++i) {                             /* :219-236 */
+    float a = (float)re[i], b = (float)(-im[i]);
+    float v = sqrtf(fmaf(b, b, a * a));
+    re[i] = (double)v;
+    if (view_start <= (long)i && (long)i < view_end) {
+      if (v > *max) *max = v;
+      if (v < *min) *min = v;
+    }
+  }
+  for (i = 0; i < n / 2; ++i)                               /* SU_SPLPF_FEED :238-239 */
+    fac[i] += alpha * ((float)re[i] / *max - fac[i]);
+  free(re); free(im);
+}
+
+/* ===================================================================================== */
 /* T9: carrier centroid [REF-PINNED structure] Tasks/CarrierDetector.cpp:80-143            */
 /* ===================================================================================== */
 

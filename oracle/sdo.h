@@ -197,6 +197,13 @@ void  sdo_blackmann_harris_complex(sdo_c32 *h, size_t n);
 /* ---- T10: Doppler centroid [REF-PINNED structure] Tasks/DopplerCalculator.cpp:85-175 --- */
 void  sdo_doppler_calc(const sdo_c32 *data, size_t len, float fs, double f0, float *spectrum, float *res);
 
+/* ---- section 8f #4: fast autocorrelation, FACTab::feed [REF-PINNED structure] -------------------- */
+/* Default/GenericInspector/FACTab.cpp:181-246: one full buffer of n = 2^k samples -> FFT -> x conj(x) ->
+ * inverse FFT (unnormalised) -> |.| of the first half; running max / min over [view_start, view_end);
+ * fac[i] += alpha (|.|/max - fac[i]).  fac: n/2 floats, *max / *min: running extrema (init -inf / +inf). */
+void sdo_fac_feed(const sdo_c32 *buf, size_t n, float alpha, long view_start, long view_end,
+                  float *fac, float *max, float *min);
+
 /* ---- P2/P3: SpectrumView [REF-PINNED] ----------------------------------------------- */
 #define SDO_SCANNER_SPECTRUM_SIZE 65536
 typedef struct {

@@ -414,6 +414,24 @@ def conj_prev(x, prev0=0j):
     return y
 
 
+class FAC:
+    """FACTab state: fac (n/2 floats), running max / min"""
+
+    def __init__(self, n, alpha):
+        self.n, self.alpha = int(n), float(alpha)
+        self.fac = np.zeros(self.n // 2, dtype=np.float32)
+        self.max = C.c_float(-np.inf)
+        self.min = C.c_float(np.inf)
+
+    def feed(self, buf, view_start=0, view_end=None):
+        buf = _c(buf)
+        assert buf.size == self.n
+        ve = self.n // 2 if view_end is None else int(view_end)
+        lib().sdo_fac_feed(_p(buf), C.c_size_t(self.n), C.c_float(self.alpha), C.c_long(int(view_start)), C.c_long(ve),
+                           self.fac.ctypes.data_as(C.c_void_p), C.byref(self.max), C.byref(self.min))
+        return self.fac
+
+
 def carrier_detect(data, avg_rel_bw, dc_notch_rel_bw):
     data = _c(data)
     return float(lib().sdo_carrier_detect(_p(data), C.c_size_t(data.size), C.c_float(avg_rel_bw),

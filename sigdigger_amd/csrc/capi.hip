@@ -981,6 +981,78 @@ SUBOOL suamd_fft_forward_bulk(suamd_ctx_t *ctx, const suamd_complex *d_in, suamd
   return SU_TRUE;
 }
 
+// ---- FAC (section 8f #4) ------------------------------------------------------------------------------
+struct suamd_fac { suamd_ctx *ctx; unsigned log2n; float alpha; void *a, *b; float *d_abs, *d_fac; unsigned *d_mx, *d_mn; };
+
+static SUBOOL fac_reset_state(suamd_fac *f, hipStream_t st)
+{
+  const unsigned init[2] = {0u, 0x7f800000u};               // max: nothing seen; min: +inf
+  HIP_TRY(hipMemsetAsync(f->d_fac, 0, sizeof(float) << (f->log2n - 1), st), SU_FALSE);
+  HIP_TRY(hipMemcpyAsync(f->d_mx, &init[0], 4, hipMemcpyHostToDevice, st), SU_FALSE);
+  HIP_TRY(hipMemcpyAsync(f->d_mn, &init[1], 4, hipMemcpyHostToDevice, st), SU_FALSE);
+  HIP_TRY(hipStreamSynchronize(st), SU_FALSE);
+  return SU_TRUE;
+}
+
+suamd_fac_t *suamd_fac_new(suamd_ctx_t *ctx, unsigned size, SUFLOAT alpha)
+{
+  if (!ctx) { set_err("null context"); return nullptr; }
+  unsigned l2 = 0;
+  while ((1u << l2) < size && l2 < 31) ++l2;
+  if ((1u << l2) != size || l2 < 4 || l2 > 24) { set_err("FAC size must be a power of two, 16..2^24"); return nullptr; }
+  HIP_TRY(hipSetDevice(ctx->device), nullptr);
+  suamd_fac *f = new (std::nothrow) suamd_fac;
+  if (!f) { set_err("out of memory"); return nullptr; }
+  std::memset(f, 0, sizeof *f);
+  f->ctx = ctx; f->log2n = l2; f->alpha = alpha;
+  const size_t n = (size_t)1 << l2;
+  bool ok = hipMalloc(&f->a, n * 8) == hipSuccess && hipMalloc(&f->b, n * 8) == hipSuccess &&
+            hipMalloc((void **)&f->d_abs, n * 2) == hipSuccess && hipMalloc((void **)&f->d_fac, n * 2) == hipSuccess &&
+            hipMalloc((void **)&f->d_mx, 4) == hipSuccess && hipMalloc((void **)&f->d_mn, 4) == hipSuccess;
+  if (!ok || !fac_reset_state(f, nullptr)) { set_err("device allocation failed"); suamd_fac_destroy(f); return nullptr; }
+  return f;
+}
+
+void suamd_fac_destroy(suamd_fac_t *f)
+{
+  if (!f) return;
+  for (void *p : {f->a, f->b, (void *)f->d_abs, (void *)f->d_fac, (void *)f->d_mx, (void *)f->d_mn}) if (p) (void)hipFree(p);
+  delete f;
+}
+
+void suamd_fac_set_alpha(suamd_fac_t *f, SUFLOAT alpha) { if (f) f->alpha = alpha; }
+SUBOOL suamd_fac_reset(suamd_fac_t *f, void *stream) { if (!f) { set_err("null argument"); return SU_FALSE; } return fac_reset_state(f, as_stream(stream)); }
+SUFLOAT *suamd_fac_array(suamd_fac_t *f) { return f ? f->d_fac : nullptr; }
+
+SUBOOL suamd_fac_feed(suamd_fac_t *f, const suamd_complex *d_data, SUSCOUNT nbuffers, SUSDIFF view_start, SUSDIFF view_end,
+                      void *stream)
+{
+  if (!f || !d_data) { set_err("null argument"); return SU_FALSE; }
+  hipStream_t st = as_stream(stream);
+  const size_t n = (size_t)1 << f->log2n;
+  for (SUSCOUNT k = 0; k < nbuffers; ++k) {                  // buffers are sequential: the EMA and the maximum carry over
+    HIP_TRY(hipMemcpyAsync(f->a, d_data + k * n, n * 8, hipMemcpyDeviceToDevice, st), SU_FALSE);
+    HIP_TRY(sdk::fac_feed(f->a, f->b, (int)f->log2n, f->alpha, (long long)view_start, (long long)view_end, f->d_abs, f->d_fac,
+                          f->d_mx, f->d_mn, st), SU_FALSE);
+  }
+  return SU_TRUE;
+}
+
+SUBOOL suamd_fac_get_range(suamd_fac_t *f, SUFLOAT *min, SUFLOAT *max, void *stream)
+{
+  if (!f) { set_err("null argument"); return SU_FALSE; }
+  unsigned v[2];
+  HIP_TRY(hipMemcpyAsync(&v[0], f->d_mx, 4, hipMemcpyDeviceToHost, as_stream(stream)), SU_FALSE);
+  HIP_TRY(hipMemcpyAsync(&v[1], f->d_mn, 4, hipMemcpyDeviceToHost, as_stream(stream)), SU_FALSE);
+  HIP_TRY(hipStreamSynchronize(as_stream(stream)), SU_FALSE);
+  float mx, mn;
+  std::memcpy(&mx, &v[0], 4); std::memcpy(&mn, &v[1], 4);
+  if (v[0] == 0u) mx = -INFINITY;
+  if (max) *max = mx;
+  if (min) *min = mn;
+  return SU_TRUE;
+}
+
 namespace {
 struct CaptureFft {                      // scratch of one whole-capture task
   void *a = nullptr, *b = nullptr, *res = nullptr;

@@ -229,6 +229,45 @@ inline unsigned grid_for(long long n, int block) {
 
 namespace sdk {
 
+// ---- FAC (Default/GenericInspector/FACTab.cpp:181-246) -------------------------------------------
+// X -> X conj(X) as a complex with zero imaginary part (:214-215)
+__global__ void fac_power_kernel(const float2 *__restrict__ X, float2 *__restrict__ P, long long n)
+{
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float2 v = X[i];
+    P[i] = float2{__builtin_fmaf(v.y, v.y, v.x * v.x), 0.0f};
+  }
+}
+
+// |.| of the first half (:220) and the running extrema over the view range (:222-235).  Non-negative
+// floats order like their bit patterns, so atomicMax / atomicMin on the bits are exact and
+// order-independent.  The inverse transform of a real spectrum is the conjugate of its forward
+// transform, so the forward result is used as is (|.| is the same).
+__global__ void fac_abs_kernel(const float2 *__restrict__ R, float *__restrict__ a, long long half,
+                               long long view_start, long long view_end, unsigned *__restrict__ mx, unsigned *__restrict__ mn)
+{
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < half; i += (long long)gridDim.x * blockDim.x) {
+    const float2 v = R[i];
+    const float m = __builtin_sqrtf(__builtin_fmaf(v.y, v.y, v.x * v.x));
+    a[i] = m;
+    if (view_start <= i && i < view_end) {
+      atomicMax(mx, __float_as_uint(m));
+      atomicMin(mn, __float_as_uint(m));
+    }
+  }
+}
+
+// SU_SPLPF_FEED(fac[i], a[i] / max, alpha) (:238-239)
+__global__ void fac_ema_kernel(float *__restrict__ fac, const float *__restrict__ a, long long half, float alpha,
+                               const unsigned *__restrict__ mx)
+{
+  const unsigned mb = *mx;
+  // the running maximum starts at -inf (bits of +0 here: nothing seen yet); dividing by -inf gives -0
+  const float m = mb == 0u ? -__builtin_inff() : __uint_as_float(mb);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < half; i += (long long)gridDim.x * blockDim.x)
+    fac[i] += alpha * (a[i] / m - fac[i]);
+}
+
 // forward FFT of n = 2^log2n points; a and b are ping-pong buffers (input in a); returns the
 // buffer holding the result through *result
 hipError_t fft_forward(void *a, void *b, int log2n, void **result, hipStream_t st)
@@ -274,6 +313,27 @@ hipError_t psd_frames_large(int log2n, const void *x, long long hop, int navg, c
                          scale / (float)navg, mode, out + o * n);
     }
   }
+  return hipGetLastError();
+}
+
+// one FAC buffer: a holds the n input samples (destroyed), b is scratch, absbuf n/2 floats
+hipError_t fac_feed(void *a, void *b, int log2n, float alpha, long long view_start, long long view_end, float *absbuf,
+                    float *fac, unsigned *mx, unsigned *mn, hipStream_t st)
+{
+  const long long n = 1ll << log2n;
+  void *res = nullptr;
+  hipError_t e = fft_forward(a, b, log2n, &res, st);
+  if (e != hipSuccess) return e;
+  void *other = res == a ? b : a;
+  hipLaunchKernelGGL(fac_power_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, reinterpret_cast<const float2 *>(res),
+                     reinterpret_cast<float2 *>(other), n);
+  // second transform: input in `other`, ping-pong with `res`
+  void *res2 = nullptr;
+  e = fft_forward(other, res, log2n, &res2, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fac_abs_kernel, dim3(grid_for(n / 2, 256)), dim3(256), 0, st, reinterpret_cast<const float2 *>(res2),
+                     absbuf, n / 2, view_start, view_end, mx, mn);
+  hipLaunchKernelGGL(fac_ema_kernel, dim3(grid_for(n / 2, 256)), dim3(256), 0, st, fac, absbuf, n / 2, alpha, mx);
   return hipGetLastError();
 }
 

@@ -130,6 +130,8 @@ hipError_t ingest_iq(int format, const void *raw, long long nsamp, void *out, hi
 hipError_t fft_forward(void *a, void *b, int log2n, void **result, hipStream_t st);
 hipError_t psd_frames_large(int log2n, const void *x, long long hop, int navg, const float *window, float scale,
                             int mode, float *out, long long nout, void *a, void *b, float *acc, hipStream_t st);
+hipError_t fac_feed(void *a, void *b, int log2n, float alpha, long long view_start, long long view_end, float *absbuf,
+                    float *fac, unsigned *mx, unsigned *mn, hipStream_t st);
 hipError_t window_pad(const void *data, long long len, long long alloc, void *buf, hipStream_t st);
 hipError_t spectrum_centroid(void *buf, long long alloc, long long lo, long long hi, float *mirror, long long bins,
                              long long delta, int with_dispersion, float *blk_max, long long *blk_idx, double *blk_sum,

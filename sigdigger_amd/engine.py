@@ -383,6 +383,34 @@ class PLLBank(_LoopBank):
         return om, ph
 
 
+class FAC(_LoopBank):
+    """FACTab::feed (Default/GenericInspector/FACTab.cpp:181-246): fast autocorrelation with EMA."""
+    _destroy = "suamd_fac_destroy"
+
+    def __init__(self, ctx, size, alpha):
+        self.ctx, self.size = ctx, int(size)
+        self.h = ctx.lib.suamd_fac_new(ctx.h, self.size, float(alpha))
+        if not self.h:
+            raise SigDiggerAmdError("suamd_fac_new: " + _l.last_error())
+
+    def feed(self, x, view_start=0, view_end=None, stream=None):
+        _chk_c64(x, "x")
+        nb = x.numel() // self.size
+        ve = self.size // 2 if view_end is None else int(view_end)
+        check(self.ctx.lib.suamd_fac_feed(self.h, _ptr(x), nb, int(view_start), ve, _stream(stream)), "suamd_fac_feed")
+
+    def array(self):
+        torch.cuda.synchronize()
+        t = torch.empty(self.size // 2, dtype=torch.float32, device="cuda")
+        _memcpy_d2d(t, self.ctx.lib.suamd_fac_array(self.h), self.size * 2)
+        return t.cpu().numpy()
+
+    def range(self):
+        mn, mx = C.c_float(), C.c_float()
+        check(self.ctx.lib.suamd_fac_get_range(self.h, C.byref(mn), C.byref(mx), None), "suamd_fac_get_range")
+        return mn.value, mx.value
+
+
 class NCOBank(_LoopBank):
     """free-running su_ncqo per channel (afc.offset, InspectorCtl/AfcControl.cpp:54-83)."""
     _destroy = "suamd_nco_bank_destroy"

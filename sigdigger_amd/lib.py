@@ -60,6 +60,13 @@ PROTOTYPES = {
     "suamd_sample_zero_crossing_bulk": (C.c_int64, [VP, VP, U64, F32, INT, INT, F32, F32, F32, F32, VP, U64, VP]),
     "suamd_conj_prev_bulk": (INT, [VP, VP, VP, U64, F32, F32, VP]),
     "suamd_ingest_iq": (INT, [VP, INT, VP, U64, VP, VP]),
+    "suamd_fac_new": (VP, [VP, UINT, F32]),
+    "suamd_fac_destroy": (None, [VP]),
+    "suamd_fac_set_alpha": (None, [VP, F32]),
+    "suamd_fac_reset": (INT, [VP, VP]),
+    "suamd_fac_feed": (INT, [VP, VP, U64, C.c_int64, C.c_int64, VP]),
+    "suamd_fac_array": (VP, [VP]),
+    "suamd_fac_get_range": (INT, [VP, VP, VP, VP]),
     "suamd_rows_scale": (INT, [VP, VP, View, VP, View, UINT, U64, F32, VP]),
     "suamd_nco_bank_new": (VP, [VP, UINT, VP]),
     "suamd_nco_bank_destroy": (None, [VP]),

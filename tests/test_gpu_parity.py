@@ -701,6 +701,28 @@ def test_manual_clock_is_gardner_without_feedback(ctx, sdo):
 
 
 # ------------------------------------------------------------------------------------------
+# section 8f #4: FAC (FACTab::feed) -- FFT-tolerance
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("size,alpha", [(1024, 1.0), (8192, 0.25), (65536, 0.5)])
+def test_fac_matches_oracle(ctx, sdo, size, alpha):
+    nb = 4
+    x = synth.psk_carriers(size * nb, [0.01], sps=16, order=2, seed=size % 97)
+    x[size:2 * size] *= 3.0                                  # a louder buffer: the running maximum moves
+    ref = sdo.FAC(size, alpha)
+    fac = engine.FAC(ctx, size, alpha)
+    vs, ve = 3, size // 2 - 5                                # the waveform view's sample range
+    for k in range(nb):
+        ref.feed(x[k * size:(k + 1) * size], vs, ve)
+    fac.feed(dev(x[:size]), vs, ve)                          # one buffer, then the rest in one call
+    fac.feed(dev(x[size:]), vs, ve)
+    got = fac.array()
+    assert np.max(np.abs(got - ref.fac)) < 2e-5              # values are normalised to the running maximum (<= 1)
+    mn, mx = fac.range()
+    assert abs(mx - ref.max.value) <= 1e-5 * ref.max.value and abs(mn - ref.min.value) <= 1e-4 * ref.max.value
+    assert np.argmax(got[1:]) == np.argmax(ref.fac[1:]) and got[0] > 0.05
+
+
+# ------------------------------------------------------------------------------------------
 # section 8f #1: sample-format ingest -- bit exact
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("fmt,dtype", [(engine.FORMAT_U8, np.uint8), (engine.FORMAT_S8, np.int8),
