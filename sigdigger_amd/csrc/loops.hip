@@ -360,9 +360,22 @@ __global__ __launch_bounds__(64) void costas_kernel(sdk::CostasParams p, sdk::Co
   }
   const uint32_t xo = (uint32_t)((long long)c * xv.cs * 8), yo = (uint32_t)((long long)c * yv.cs * 8);
   const long long yms = yv.ms;
-  stream_row(x, xv.ms, xo, len, [&](long long m, float2 v) {
-    st_elem(y, m * yms, yo, costas_step<KIND, ORDER, GAIN1>(p, r, v));
-  });
+  // time-major rows of a 64-channel bank (pitch 64) or a single row (pitch 1): with the pitch a
+  // compile-time constant every access of a chunk is scalar base + immediate offset (no 64-bit
+  // vector address arithmetic per sample: 6.44 -> 6.03 ms per block)
+  if (xv.ms == 64 && yms == 64) {
+    stream_row(x, 64, xo, len, [&](long long m, float2 v) {
+      st_elem(y, m * 64, yo, costas_step<KIND, ORDER, GAIN1>(p, r, v));
+    });
+  } else if (xv.ms == 1 && yms == 1) {
+    stream_row(x, 1, xo, len, [&](long long m, float2 v) {
+      st_elem(y, m, yo, costas_step<KIND, ORDER, GAIN1>(p, r, v));
+    });
+  } else {
+    stream_row(x, xv.ms, xo, len, [&](long long m, float2 v) {
+      st_elem(y, m * yms, yo, costas_step<KIND, ORDER, GAIN1>(p, r, v));
+    });
+  }
   s.phase[c] = r.phase;
   s.omega[c] = r.omega;
 #pragma unroll
@@ -400,9 +413,13 @@ __global__ __launch_bounds__(64) void pll_kernel(float alpha, float beta, sdk::P
   float omega = s.omega[c];
   const uint32_t xo = (uint32_t)((long long)c * xv.cs * 8), yo = (uint32_t)((long long)c * yv.cs * 8);
   const long long yms = yv.ms;
-  stream_row(x, xv.ms, xo, len, [&](long long m, float2 v) {
-    st_elem(y, m * yms, yo, pll_step(alpha, beta, phase, omega, v));
-  });
+  if (xv.ms == 64 && yms == 64) {                          // constant pitch: immediate offsets (see costas_kernel)
+    stream_row(x, 64, xo, len, [&](long long m, float2 v) { st_elem(y, m * 64, yo, pll_step(alpha, beta, phase, omega, v)); });
+  } else {
+    stream_row(x, xv.ms, xo, len, [&](long long m, float2 v) {
+      st_elem(y, m * yms, yo, pll_step(alpha, beta, phase, omega, v));
+    });
+  }
   s.phase[c] = phase;
   s.omega[c] = omega;
 }
@@ -461,7 +478,9 @@ __global__ __launch_bounds__(64) void clock_kernel(sdk::ClockParams p, sdk::Cloc
   r.n = count[c];
   const uint32_t xo = (uint32_t)((long long)c * xv.cs * 8);
   float2 *out = sym + (long long)c * sym_stride;
-  stream_row(x, xv.ms, xo, len, [&](long long, float2 v) { clock_step(p, r, v, out); });
+  if (xv.ms == 64) stream_row(x, 64, xo, len, [&](long long, float2 v) { clock_step(p, r, v, out); });
+  else if (xv.ms == 1) stream_row(x, 1, xo, len, [&](long long, float2 v) { clock_step(p, r, v, out); });
+  else stream_row(x, xv.ms, xo, len, [&](long long, float2 v) { clock_step(p, r, v, out); });
   s.phi[c] = r.phi; s.bnor[c] = r.bnor; s.halfcycle[c] = r.halfcycle;
   s.prev[c] = r.prev.x; s.prev[nchan + c] = r.prev.y;
   s.x0[c] = r.x0.x; s.x0[nchan + c] = r.x0.y;
@@ -540,7 +559,7 @@ __global__ __launch_bounds__(64) void agc_level_kernel(sdk::AgcParams p, sdk::Ag
   const float far = p.fast_alpha_rise, faf = p.fast_alpha_fall, sar = p.slow_alpha_rise, saf = p.slow_alpha_fall;
   const float knee = p.knee;
   const unsigned hang_max = p.hang_max;
-  stream_row(peak, (long long)nchan, lo, len, [&](long long m, float pk) {
+  auto level = [&](float pk) {
     float d = pk - fast;
     const float fa = d > 0.0f ? far : faf;
     fast = sd::fma_(fa, d, fast);
@@ -554,8 +573,11 @@ __global__ __launch_bounds__(64) void agc_level_kernel(sdk::AgcParams p, sdk::Ag
     hang_n = rise ? 0u : (fall ? hang_n : hang_n + 1u);
     float lvl = fast > slow ? fast : slow;
     if (lvl < knee) lvl = knee;
-    st_elem(peak, m * (long long)nchan, lo, lvl);
-  });
+    return lvl;
+  };
+  if (nchan == 64) stream_row(peak, 64, lo, len, [&](long long m, float pk) { st_elem(peak, m * 64, lo, level(pk)); });
+  else if (nchan == 1) stream_row(peak, 1, lo, len, [&](long long m, float pk) { st_elem(peak, m, lo, level(pk)); });
+  else stream_row(peak, (long long)nchan, lo, len, [&](long long m, float pk) { st_elem(peak, m * (long long)nchan, lo, level(pk)); });
   s.hang_n[c] = hang_n; s.fast_level[c] = fast; s.slow_level[c] = slow;
 }
 
