@@ -422,7 +422,9 @@ SUSCOUNT suamd_chanbank_output_count(const suamd_chanbank_t *b, SUSCOUNT len)
 SUBOOL suamd_chanbank_feed(suamd_chanbank_t *b, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_y,
                            suamd_view yv, SUSCOUNT *n_out, void *stream)
 {
-  if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  if (!b) { set_err("null argument"); return SU_FALSE; }
+  if (len == 0) { if (n_out) *n_out = 0; return SU_TRUE; }          // an empty block is a no-op
+  if (!d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
   uint64_t mf; SUSCOUNT no;
   chan_out_range(b, len, &mf, &no);
   if (yv.time_stride == 1 && b->nchan > 1 && no > yv.chan_stride) {
@@ -525,9 +527,10 @@ SUSDIFF suamd_sample_zero_crossing_bulk(suamd_ctx_t *ctx, const suamd_complex *d
                                         int space, SUBOOL amplitude, SUFLOAT thr_re, SUFLOAT thr_im, SUFLOAT ang_re,
                                         SUFLOAT ang_im, unsigned char *d_symbols, SUSCOUNT capacity, void *stream)
 {
-  if (!ctx || !d_data || !d_symbols) { set_err("null argument"); return -1; }
+  if (!ctx) { set_err("null context"); return -1; }
   if (space < 0 || space > 2) { set_err("bad space %d", space); return -1; }
   if (length == 0) return 0;
+  if (!d_data || !d_symbols) { set_err("null argument"); return -1; }
   const long long nblocks = (long long)((length + 4095) / 4096);
   if (capacity < (SUSCOUNT)nblocks * 4096) { set_err("d_symbols must hold 4096 * ceil(length / 4096) symbols"); return -1; }
   hipStream_t st = as_stream(stream);
@@ -601,7 +604,9 @@ void suamd_nco_bank_destroy(suamd_nco_bank_t *b)
 SUBOOL suamd_nco_bank_feed(suamd_nco_bank_t *b, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y, suamd_view yv,
                            SUSCOUNT len, void *stream)
 {
-  if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  if (!b) { set_err("null argument"); return SU_FALSE; }
+  if (len == 0) return SU_TRUE;                                      // an empty block is a no-op
+  if (!d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
   HIP_TRY(sdk::rows_xlate(d_x, as_view(xv), d_y, as_view(yv), (int)b->nchan, (long long)len, b->d_dphase, b->d_phase0,
                           b->n, as_stream(stream)), SU_FALSE);
   b->n += len;
@@ -662,7 +667,9 @@ void suamd_fir_bank_destroy(suamd_fir_bank_t *b)
 SUBOOL suamd_fir_bank_feed(suamd_fir_bank_t *b, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y, suamd_view yv,
                            SUSCOUNT len, void *stream)
 {
-  if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  if (!b) { set_err("null argument"); return SU_FALSE; }
+  if (len == 0) return SU_TRUE;                                      // an empty block is a no-op
+  if (!d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
   if (d_x == d_y) { set_err("in-place filtering is not supported"); return SU_FALSE; }
   if (len == 0) return SU_TRUE;
   HIP_TRY(sdk::rows_fir(d_x, as_view(xv), d_y, as_view(yv), (int)b->nchan, (long long)len, b->d_taps, (int)b->ntaps,
@@ -761,7 +768,9 @@ void suamd_costas_bank_destroy(suamd_costas_bank_t *b)
 SUBOOL suamd_costas_bank_feed(suamd_costas_bank_t *b, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y,
                               suamd_view yv, SUSCOUNT len, void *stream)
 {
-  if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  if (!b) { set_err("null argument"); return SU_FALSE; }
+  if (len == 0) return SU_TRUE;                                      // an empty block is a no-op
+  if (!d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
   HIP_TRY(sdk::costas_feed(b->p, b->s, (int)b->nchan, d_x, as_view(xv), d_y, as_view(yv),
                            (long long)len, as_stream(stream)), SU_FALSE);
   return SU_TRUE;
@@ -807,7 +816,9 @@ void suamd_pll_bank_destroy(suamd_pll_bank_t *b)
 SUBOOL suamd_pll_bank_feed(suamd_pll_bank_t *b, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y,
                            suamd_view yv, SUSCOUNT len, void *stream)
 {
-  if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  if (!b) { set_err("null argument"); return SU_FALSE; }
+  if (len == 0) return SU_TRUE;                                      // an empty block is a no-op
+  if (!d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
   HIP_TRY(sdk::pll_feed(b->alpha, b->beta, b->s, (int)b->nchan, d_x, as_view(xv), d_y, as_view(yv),
                         (long long)len, as_stream(stream)), SU_FALSE);
   return SU_TRUE;
@@ -876,7 +887,9 @@ void suamd_clock_bank_destroy(suamd_clock_bank_t *b)
 SUBOOL suamd_clock_bank_feed(suamd_clock_bank_t *b, const suamd_complex *d_x, suamd_view xv, SUSCOUNT len,
                              suamd_complex *d_sym, SUSCOUNT sym_stride, uint32_t *d_count, void *stream)
 {
-  if (!b || !d_x || !d_sym || !d_count) { set_err("null argument"); return SU_FALSE; }
+  if (!b) { set_err("null argument"); return SU_FALSE; }
+  if (len == 0) return SU_TRUE;                                      // an empty block is a no-op
+  if (!d_x || !d_sym || !d_count) { set_err("null argument"); return SU_FALSE; }
   HIP_TRY(sdk::clock_feed(b->p, b->s, (int)b->nchan, d_x, as_view(xv), (long long)len, d_sym,
                           (long long)sym_stride, d_count, as_stream(stream)), SU_FALSE);
   return SU_TRUE;
@@ -952,7 +965,9 @@ void suamd_agc_bank_destroy(suamd_agc_bank_t *b)
 SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y,
                            suamd_view yv, SUSCOUNT len, void *stream)
 {
-  if (!b || !d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  if (!b) { set_err("null argument"); return SU_FALSE; }
+  if (len == 0) return SU_TRUE;                                      // an empty block is a no-op
+  if (!d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
   if (d_x == d_y) { set_err("the AGC bank cannot run in place (the output is the input delayed)"); return SU_FALSE; }
   if (len == 0) return SU_TRUE;
   if (!b->scratch.reserve(2 * sizeof(float) * (size_t)len * b->nchan)) { set_err("scratch allocation failed"); return SU_FALSE; }
