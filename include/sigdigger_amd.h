@@ -226,6 +226,19 @@ SUAMD_API SUBOOL suamd_clock_bank_get_state(suamd_clock_bank_t *b, SUFLOAT *bnor
 SUAMD_API SUBOOL suamd_clock_bank_set_phase(suamd_clock_bank_t *b, SUFLOAT phi, void *stream);
 
 /* ------------------------------------------------------------------------------------ */
+/* section 8f #2: inspector spectrum sources (INSPECTOR/SPECTRUM messages,                 */
+/* Suscan/Analyzer.cpp:539-547, Default/GenericInspector/GenericInspector.cpp:231-254).            */
+/* Source ids are 1-based (0 = none, RMSInspector.cpp:721-727): psd, cyclo (x conj(prev)), fmspect */
+/* (arg(x conj(prev))), pmspect (arg x), timediff (x - prev), abstimediff (|x - prev|), exp_2/4/8  */
+/* (x^2, x^4, x^8).  This is the per-sample transform; the spectrum itself is suamd_psd_feed on    */
+/* the result (linear power, natural order: the consumer takes dB and rotates, A9).                 */
+/* ------------------------------------------------------------------------------------ */
+SUAMD_API unsigned    suamd_spectsrc_count(void);
+SUAMD_API const char *suamd_spectsrc_name(unsigned id);
+SUAMD_API SUBOOL      suamd_spectsrc_preproc(suamd_ctx_t *ctx, unsigned id, const suamd_complex *d_x, SUSCOUNT len,
+                                             SUFLOAT prev_re, SUFLOAT prev_im, suamd_complex *d_y, void *stream);
+
+/* ------------------------------------------------------------------------------------ */
 /* section 8f #4: fast autocorrelation of the inspector's sample stream                    */
 /* FACTab::feed (Default/GenericInspector/FACTab.cpp:181-246): per full buffer of `size` samples   */
 /* FFT -> x conj(x) -> inverse FFT -> |.| of the first half; running max / min over               */

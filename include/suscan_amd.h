@@ -194,6 +194,11 @@ SUAMD_API SUBOOL suscan_analyzer_set_inspector_config_async(suscan_analyzer_t *a
                                                             const suscan_config_t *config, uint32_t req_id);
 SUAMD_API SUBOOL suscan_analyzer_set_inspector_watermark_async(suscan_analyzer_t *analyzer, SUHANDLE handle,
                                                                SUSCOUNT watermark, uint32_t req_id);
+/* Analyzer::setSpectrumSource (Suscan/Analyzer.cpp:539-547): 0 = none, k = spectsrc_list[k-1] of the OPEN
+ * message; afterwards every block yields an INSPECTOR message of kind SPECTRUM with spectrum_data
+ * (linear power, natural order), spectrum_size, samp_rate = equiv_fs and spectsrc_id */
+SUAMD_API SUBOOL suscan_analyzer_inspector_set_spectrum_async(suscan_analyzer_t *analyzer, SUHANDLE handle,
+                                                              uint32_t spectsrc_id, uint32_t req_id);
 SUAMD_API SUBOOL suscan_analyzer_set_inspector_freq_overridable(suscan_analyzer_t *analyzer, SUHANDLE handle,
                                                                 SUFREQ freq);
 SUAMD_API SUBOOL suscan_analyzer_set_inspector_bandwidth_overridable(suscan_analyzer_t *analyzer, SUHANDLE handle,

@@ -851,6 +851,35 @@ void sdo_cma_feed_bulk(sdo_cma *q, const sdo_c32 *x, size_t len, sdo_c32 *y)
   for (i = 0; i < len; ++i) y[i] = sdo_cma_feed(q, x[i]);
 }
 
+static inline sdo_c32 csq(sdo_c32 a)                        /* a * a, translate-product form (SPEC C) */
+{
+  sdo_c32 r = { fmaf(-a.im, a.im, a.re * a.re), fmaf(a.im, a.re, a.re * a.im) };
+  return r;
+}
+
+void sdo_spectsrc_preproc(int kind, const sdo_c32 *x, size_t len, sdo_c32 prev0, sdo_c32 *y)
+{
+  size_t i;
+  sdo_c32 prev = prev0;
+  for (i = 0; i < len; ++i) {
+    sdo_c32 v = x[i], r = { 0, 0 }, d;
+    switch (kind) {
+      case 1: r = v; break;
+      case 2: r = cmul_conj(v, prev); break;
+      case 3: d = cmul_conj(v, prev); r.re = sdo_atan2f(d.im, d.re); break;
+      case 4: r.re = sdo_atan2f(v.im, v.re); break;
+      case 5: r.re = v.re - prev.re; r.im = v.im - prev.im; break;
+      case 6: d.re = v.re - prev.re; d.im = v.im - prev.im; r.re = sqrtf(fmaf(d.im, d.im, d.re * d.re)); break;
+      case 7: r = csq(v); break;
+      case 8: r = csq(csq(v)); break;
+      case 9: r = csq(csq(csq(v))); break;
+      default: break;
+    }
+    y[i] = r;
+    prev = v;
+  }
+}
+
 void sdo_ingest_iq(int format, const void *raw, size_t n, sdo_c32 *out)
 {
   size_t i;

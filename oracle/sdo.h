@@ -186,6 +186,13 @@ void   sdo_cma_init(sdo_cma *q, int n, float mu);
 sdo_c32 sdo_cma_feed(sdo_cma *q, sdo_c32 x);
 void   sdo_cma_feed_bulk(sdo_cma *q, const sdo_c32 *x, size_t len, sdo_c32 *y);
 
+/* ---- section 8f #2: inspector spectrum sources [UPSTREAM-RECOLLECTION of libsuscan's spectsrc list] --- */
+/* the per-sample transform in front of the inspector PSD; prev0 = last sample of the previous block.
+ * kind: 1 psd (identity), 2 cyclo (x conj(prev)), 3 fmspect (arg(x conj(prev)), 0), 4 pmspect (arg x, 0),
+ * 5 timediff (x - prev), 6 abstimediff (|x - prev|, 0), 7 exp_2 (x^2), 8 exp_4, 9 exp_8 */
+#define SDO_SPECTSRC_COUNT 9
+void sdo_spectsrc_preproc(int kind, const sdo_c32 *x, size_t len, sdo_c32 prev0, sdo_c32 *y);
+
 /* ---- ingest (section 8f #1): file-source sample formats -> SUCOMPLEX ------------------------------ */
 /* format 1 f32, 2 u8 (v-128)/128, 3 s8 v/128, 4 s16 v/32768 [UPSTREAM-RECOLLECTION: libsndfile norm] */
 void sdo_ingest_iq(int format, const void *raw, size_t nsamples, sdo_c32 *out);

@@ -93,6 +93,7 @@ def lib():
         L.sdo_histogram_feed.restype = C.c_size_t
         L.sdo_clock_feed_bulk.restype = C.c_size_t
         L.sdo_carrier_detect.restype = C.c_float
+        L.sdo_spectsrc_preproc.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C32, C.c_void_p]
         L.sdo_rrc_ntaps.restype = C.c_size_t
         L.sdo_rrc_ntaps.argtypes = [C.c_double]
         L.sdo_rrc_design.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double]
@@ -396,6 +397,16 @@ def cma_feed_bulk(q, x):
     x = _c(x)
     y = np.empty(x.size, dtype=c32)
     lib().sdo_cma_feed_bulk(C.byref(q), _p(x), x.size, _p(y))
+    return y
+
+
+SPECTSRC = ("psd", "cyclo", "fmspect", "pmspect", "timediff", "abstimediff", "exp_2", "exp_4", "exp_8")
+
+
+def spectsrc_preproc(kind, x, prev0=0j):
+    x = _c(x)
+    y = np.empty(x.size, dtype=c32)
+    lib().sdo_spectsrc_preproc(int(kind), _p(x), x.size, C32(float(np.real(prev0)), float(np.imag(prev0))), _p(y))
     return y
 
 

@@ -312,6 +312,12 @@ struct Inspector {
   suamd_fir_bank_t *mf = nullptr;             // mf.type = MANUAL
   suamd_cma_bank_t *cma = nullptr;            // equalizer.type = CMA
   float fixed_gain = 0;                       // agc.enabled = false: linear agc.gain (0 = none)
+  uint32_t spectsrc_id = 0;                   // 0 = none (Suscan/Analyzer.cpp:539-547)
+  suamd_psd_t *spect_psd = nullptr;           // spectrum of the channel samples, one frame set per block
+  unsigned spect_n = 0;
+  suamd_complex *d_spre = nullptr;            // transformed samples
+  float *d_spec = nullptr;
+  suamd_complex spect_prev = {0, 0};          // last channel sample of the previous block
   bool quad = false, first = true;
   suamd_complex *d_y = nullptr, *d_a = nullptr, *d_z = nullptr, *d_sym = nullptr, *d_prev = nullptr;
   uint32_t *d_count = nullptr;
@@ -329,8 +335,16 @@ struct Inspector {
     bank = nullptr; agc = nullptr; costas = nullptr; clock = nullptr; nco = nullptr; pll = nullptr; mf = nullptr; cma = nullptr;
     fixed_gain = 0;
   }
+  void free_spectrum()
+  {
+    if (spect_psd) suamd_psd_destroy(spect_psd);
+    if (d_spre) (void)hipFree(d_spre);
+    if (d_spec) (void)hipFree(d_spec);
+    spect_psd = nullptr; d_spre = nullptr; d_spec = nullptr; spect_n = 0;
+  }
   void free_all()
   {
+    free_spectrum();
     free_chain();
     for (void *p : {(void *)d_y, (void *)d_a, (void *)d_z, (void *)d_sym, (void *)d_prev, (void *)d_count})
       if (p) (void)hipFree(p);
@@ -341,7 +355,7 @@ struct Inspector {
 };
 
 struct Request {
-  enum Kind { OPEN, CLOSE, SET_ID, SET_CONFIG, SET_WATERMARK, SET_FREQ, SET_BW, SET_PARAMS, SET_THROTTLE } kind;
+  enum Kind { OPEN, CLOSE, SET_ID, SET_CONFIG, SET_WATERMARK, SET_FREQ, SET_BW, SET_PARAMS, SET_THROTTLE, SET_SPECTRUM } kind;
   uint32_t req_id = 0;
   SUHANDLE handle = -1;
   std::string cls;
@@ -497,6 +511,42 @@ void emit_samples(suscan_analyzer *a, const Inspector &in, const suamd_complex *
   push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_SAMPLES, m);
 }
 
+// INSPECTOR/SPECTRUM: the selected source's transform of this block's channel samples, then every whole
+// frame of the block Welch-averaged into one spectrum (linear power, natural order: the tab takes dB and
+// rotates, GenericInspector.cpp:231-247); frame = the largest power of two <= min(block, 8192)
+void emit_spectrum(suscan_analyzer *a, Inspector &in, SUSCOUNT m)
+{
+  unsigned n = 512;
+  while (n * 2 <= m && n < 8192) n *= 2;
+  if (m < n) return;
+  if (n != in.spect_n) {
+    in.free_spectrum();
+    in.spect_psd = suamd_psd_new(a->ctx, n, a->params.detector_params.window);
+    if (!in.spect_psd || hipMalloc((void **)&in.d_spre, in.cap * sizeof(suamd_complex)) != hipSuccess ||
+        hipMalloc((void **)&in.d_spec, n * sizeof(float)) != hipSuccess) {
+      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, "inspector spectrum: allocation failed");
+      in.free_spectrum();
+      in.spectsrc_id = 0;
+      return;
+    }
+    in.spect_n = n;
+  }
+  if (!suamd_spectsrc_preproc(a->ctx, in.spectsrc_id, in.d_y, m, in.spect_prev.re, in.spect_prev.im, in.d_spre, a->stream)) return;
+  (void)hipMemcpyAsync(&in.spect_prev, in.d_y + (m - 1), sizeof(suamd_complex), hipMemcpyDeviceToHost, a->stream);
+  const unsigned frames = (unsigned)(m / n);
+  if (!suamd_psd_feed(in.spect_psd, in.d_spre, frames, n, frames, 1.0f / (float)n, SUAMD_PSD_LINEAR, in.d_spec, a->stream)) return;
+  auto *msg = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SPECTRUM, 0);
+  msg->handle = in.handle;
+  msg->inspector_id = in.inspector_id;
+  msg->spectsrc_id = in.spectsrc_id;
+  msg->spectrum_size = n;
+  msg->samp_rate = (SUSCOUNT)in.equiv_fs;
+  msg->spectrum_data = static_cast<SUFLOAT *>(std::malloc(n * sizeof(SUFLOAT)));
+  (void)hipMemcpyAsync(msg->spectrum_data, in.d_spec, n * sizeof(float), hipMemcpyDeviceToHost, a->stream);
+  (void)hipStreamSynchronize(a->stream);
+  push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, msg);
+}
+
 void run_inspector(suscan_analyzer *a, Inspector &in, size_t len)
 {
   if (in.dirty) {
@@ -507,6 +557,7 @@ void run_inspector(suscan_analyzer *a, Inspector &in, size_t len)
   const suamd_view row = {(SUSCOUNT)in.cap, 1};
   SUSCOUNT m = 0;
   if (!suamd_chanbank_feed(in.bank, a->d_x, len, in.d_y, row, &m, a->stream)) return;
+  if (in.spectsrc_id) emit_spectrum(a, in, m);
   // ping-pong through d_a / d_z so that no stage runs in place
   const suamd_complex *cur = in.d_y;
   auto other = [&](const suamd_complex *p) { return p == in.d_a ? in.d_z : in.d_a; };
@@ -587,6 +638,9 @@ void handle_request(suscan_analyzer *a, Request &r)
       m->equiv_fs = (SUFLOAT)in->equiv_fs;
       m->bandwidth = (SUFLOAT)r.channel.bw;
       m->lo = (SUFLOAT)in->fnor;
+      m->spectsrc_count = suamd_spectsrc_count();             // names borrowed from the library (static storage)
+      m->spectsrc_list = static_cast<char **>(std::calloc(m->spectsrc_count, sizeof(char *)));
+      for (unsigned k = 0; k < m->spectsrc_count; ++k) m->spectsrc_list[k] = const_cast<char *>(suamd_spectsrc_name(k + 1));
       a->inspectors[in->handle] = std::move(in);
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
       return;
@@ -642,6 +696,15 @@ void handle_request(suscan_analyzer *a, Request &r)
       m->handle = r.handle;
       m->watermark = r.value;
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
+      break;
+    }
+    case Request::SET_SPECTRUM: {
+      const bool ok = r.value <= suamd_spectsrc_count();
+      if (ok) { it->second->spectsrc_id = (uint32_t)r.value; it->second->spect_prev = suamd_complex{0, 0}; }
+      auto *m = new_insp_msg(ok ? SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SPECTRUM : SUSCAN_ANALYZER_INSPECTOR_MSGKIND_INVALID_ARGUMENT, r.req_id);
+      m->handle = r.handle;
+      m->spectsrc_id = (uint32_t)r.value;
+      push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);   // acknowledgement: no spectrum_data yet
       break;
     }
     case Request::SET_FREQ: it->second->channel.fc = r.fvalue; it->second->dirty = true; break;
@@ -1027,6 +1090,7 @@ void suscan_analyzer_dispose_message(uint32_t type, void *ptr)
       std::free(m->class_name);
       if (m->config) suscan_config_destroy(m->config);
       std::free(m->spectrum_data);
+      std::free(m->spectsrc_list);                           // the names themselves are static
       break;
     }
     case SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INIT:
@@ -1097,6 +1161,12 @@ SUBOOL suscan_analyzer_set_inspector_config_async(suscan_analyzer_t *a, SUHANDLE
 SUBOOL suscan_analyzer_set_inspector_watermark_async(suscan_analyzer_t *a, SUHANDLE h, SUSCOUNT wm, uint32_t req)
 {
   Request r; r.kind = Request::SET_WATERMARK; r.req_id = req; r.handle = h; r.value = wm;
+  return post(a, std::move(r));
+}
+
+SUBOOL suscan_analyzer_inspector_set_spectrum_async(suscan_analyzer_t *a, SUHANDLE h, uint32_t spectsrc_id, uint32_t req)
+{
+  Request r; r.kind = Request::SET_SPECTRUM; r.req_id = req; r.handle = h; r.value = spectsrc_id;
   return post(a, std::move(r));
 }
 

@@ -576,6 +576,23 @@ SUBOOL suamd_rows_scale(suamd_ctx_t *ctx, const suamd_complex *d_x, suamd_view x
   return SU_TRUE;
 }
 
+static const char *const kSpectsrcNames[] = {"psd", "cyclo", "fmspect", "pmspect", "timediff", "abstimediff", "exp_2", "exp_4", "exp_8"};
+
+unsigned suamd_spectsrc_count(void) { return (unsigned)(sizeof kSpectsrcNames / sizeof kSpectsrcNames[0]); }
+const char *suamd_spectsrc_name(unsigned id) { return id >= 1 && id <= suamd_spectsrc_count() ? kSpectsrcNames[id - 1] : nullptr; }
+
+SUBOOL suamd_spectsrc_preproc(suamd_ctx_t *ctx, unsigned id, const suamd_complex *d_x, SUSCOUNT len, SUFLOAT prev_re,
+                              SUFLOAT prev_im, suamd_complex *d_y, void *stream)
+{
+  if (!ctx) { set_err("null context"); return SU_FALSE; }
+  if (id < 1 || id > suamd_spectsrc_count()) { set_err("unknown spectrum source %u", id); return SU_FALSE; }
+  if (len == 0) return SU_TRUE;
+  if (!d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  if (d_x == d_y && id != 1 && id != 4 && id < 7) { set_err("sources that look at the previous sample cannot run in place"); return SU_FALSE; }
+  HIP_TRY(sdk::spectsrc_preproc((int)id, d_x, (long long)len, prev_re, prev_im, d_y, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
 struct suamd_nco_bank { suamd_ctx *ctx; unsigned nchan; uint32_t *d_dphase, *d_phase0; uint64_t n; };
 
 suamd_nco_bank_t *suamd_nco_bank_new(suamd_ctx_t *ctx, unsigned nchan, const double *fnor)

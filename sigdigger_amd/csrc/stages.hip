@@ -65,6 +65,32 @@ __global__ void rows_xlate_kernel(const float2 *__restrict__ x, sdk::View xv, fl
   }
 }
 
+// inspector spectrum sources (section 8f #2): the per-sample transform in front of the inspector PSD
+__device__ __forceinline__ c32 csq(c32 a) { return c32{sd::fma_(-a.im, a.im, a.re * a.re), sd::fma_(a.im, a.re, a.re * a.im)}; }
+
+__global__ void spectsrc_kernel(int kind, const float2 *__restrict__ x, long long len, float2 prev0, float2 *__restrict__ y)
+{
+  __builtin_amdgcn_s_setprio(3);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
+    const float2 vv = x[i], pp = i > 0 ? x[i - 1] : prev0;
+    const c32 v = {vv.x, vv.y}, prev = {pp.x, pp.y};
+    c32 r = {0.0f, 0.0f}, d;
+    switch (kind) {
+      case 1: r = v; break;
+      case 2: r = sd::cmul_conj(v, prev); break;
+      case 3: d = sd::cmul_conj(v, prev); r.re = sd::atan2_(d.im, d.re); break;
+      case 4: r.re = sd::atan2_(v.im, v.re); break;
+      case 5: r = c32{v.re - prev.re, v.im - prev.im}; break;
+      case 6: d = c32{v.re - prev.re, v.im - prev.im}; r.re = __builtin_sqrtf(sd::fma_(d.im, d.im, d.re * d.re)); break;
+      case 7: r = csq(v); break;
+      case 8: r = csq(csq(v)); break;
+      case 9: r = csq(csq(csq(v))); break;
+      default: break;
+    }
+    y[i] = float2{r.re, r.im};
+  }
+}
+
 // mf.type = MANUAL: y_c[m] = sum_k h[k] x_c[m-k], k ascending (one fma chain per component).
 // A thread owns R consecutive outputs of one channel and walks the samples they need from the
 // newest to the oldest, so every sample is loaded once and each output sees its taps in ascending
@@ -203,6 +229,14 @@ hipError_t rows_xlate(const void *x, View xv, void *y, View yv, int nchan, long 
   if (len <= 0 || nchan <= 0) return hipSuccess;
   hipLaunchKernelGGL(rows_xlate_kernel, dim3(grid_for(len * nchan, 256)), dim3(256), 0, st,
                      reinterpret_cast<const float2 *>(x), xv, reinterpret_cast<float2 *>(y), yv, nchan, len, dphase, phase0, n0);
+  return hipGetLastError();
+}
+
+hipError_t spectsrc_preproc(int kind, const void *x, long long len, float prev_re, float prev_im, void *y, hipStream_t st)
+{
+  if (len <= 0) return hipSuccess;
+  hipLaunchKernelGGL(spectsrc_kernel, dim3(grid_for(len, 256)), dim3(256), 0, st, kind, reinterpret_cast<const float2 *>(x), len,
+                     float2{prev_re, prev_im}, reinterpret_cast<float2 *>(y));
   return hipGetLastError();
 }
 

@@ -153,6 +153,15 @@ class Context:
         check(self.lib.suamd_ingest_iq(self.h, int(fmt), _ptr(raw), n, _ptr(out), _stream(stream)), "suamd_ingest_iq")
         return out
 
+    def spectsrc_preproc(self, kind, x, prev0=0j, out=None, stream=None):
+        """per-sample transform of an inspector spectrum source (1-based id, suamd_spectsrc_name)"""
+        _chk_c64(x, "x")
+        if out is None:
+            out = torch.empty_like(x)
+        check(self.lib.suamd_spectsrc_preproc(self.h, int(kind), _ptr(x), x.numel(), float(prev0.real), float(prev0.imag),
+                                              _ptr(out), _stream(stream)), "suamd_spectsrc_preproc")
+        return out
+
     def sample_zero_crossing(self, data, bnor, space, amplitude=False, threshold=0j, zc_angle=1 + 0j, stream=None):
         """WaveSampler::sampleZeroCrossing over a whole capture (Tasks/WaveSampler.cpp:215-292) -> uint8 symbols."""
         _chk_c64(data, "data")

@@ -60,6 +60,9 @@ PROTOTYPES = {
     "suamd_sample_zero_crossing_bulk": (C.c_int64, [VP, VP, U64, F32, INT, INT, F32, F32, F32, F32, VP, U64, VP]),
     "suamd_conj_prev_bulk": (INT, [VP, VP, VP, U64, F32, F32, VP]),
     "suamd_ingest_iq": (INT, [VP, INT, VP, U64, VP, VP]),
+    "suamd_spectsrc_count": (UINT, []),
+    "suamd_spectsrc_name": (C.c_char_p, [UINT]),
+    "suamd_spectsrc_preproc": (INT, [VP, UINT, VP, U64, F32, F32, VP, VP]),
     "suamd_fac_new": (VP, [VP, UINT, F32]),
     "suamd_fac_destroy": (None, [VP]),
     "suamd_fac_set_alpha": (None, [VP, F32]),

@@ -8,6 +8,7 @@ MSG_SOURCE_INFO, MSG_SOURCE_INIT, MSG_CHANNEL, MSG_EOS, MSG_READ_ERROR, MSG_INTE
 MSG_INSPECTOR, MSG_PSD, MSG_SAMPLES, MSG_PARAMS = 7, 8, 9, 0xB
 MSG_HALT = 0xFFFFFFFF
 KIND_OPEN, KIND_SET_ID, KIND_GET_CONFIG, KIND_SET_CONFIG = 0, 1, 2, 3
+KIND_ESTIMATOR, KIND_SPECTRUM, KIND_INVALID_ARGUMENT = 4, 5, 13
 KIND_CLOSE, KIND_SET_WATERMARK, KIND_WRONG_HANDLE, KIND_WRONG_KIND, KIND_INVALID_CHANNEL = 7, 10, 11, 14, 15
 
 
@@ -103,6 +104,7 @@ PROTOTYPES = {
     "suscan_analyzer_set_inspector_id_async": (INT, [VP, C.c_int32, U32, U32]),
     "suscan_analyzer_set_inspector_config_async": (INT, [VP, C.c_int32, VP, U32]),
     "suscan_analyzer_set_inspector_watermark_async": (INT, [VP, C.c_int32, U64, U32]),
+    "suscan_analyzer_inspector_set_spectrum_async": (INT, [VP, C.c_int32, U32, U32]),
     "suscan_analyzer_set_inspector_freq_overridable": (INT, [VP, C.c_int32, C.c_double]),
     "suscan_analyzer_set_inspector_bandwidth_overridable": (INT, [VP, C.c_int32, C.c_double]),
 }

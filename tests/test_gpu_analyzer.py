@@ -348,6 +348,75 @@ def test_ask_inspector_with_pll(tmp_path, sdo):
     Lb.suscan_mq_finalize(C.byref(mq))
 
 
+def test_inspector_spectrum_sources(tmp_path, sdo):
+    """Analyzer::setSpectrumSource (Suscan/Analyzer.cpp:539-547): the OPEN reply lists the sources, id k selects
+    spectsrc_list[k-1], every block then yields an INSPECTOR/SPECTRUM message (linear power, natural order) that
+    the tab post-processes in place (GenericInspector.cpp:231-247).  Checked against the oracle for "psd" and,
+    after switching, "exp_2" (a BPSK carrier squared is a spectral line at twice its offset)."""
+    nblocks = 10
+    fc, baud, bw, offs = 100e3, 15625.0, 60e3, 1500.0
+    x = synth.psk_carriers(L * nblocks, [2 * (fc + offs) / FS], sps=int(FS / baud), order=2, seed=9, snr_db=30)
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    Lb, mq, an = _start(path, L)
+    Lb.suscan_analyzer_set_throttle_async(an, 4 * FS, 0)
+    ch = suscan.Channel(fc=fc, f_lo=fc - bw / 2, f_hi=fc + bw / 2, bw=bw, ft=433.92e6)
+    assert Lb.suscan_analyzer_open_ex_async(an, b"psk", C.byref(ch), 1, -1, 1)
+    st = {"psd": 0, "spec": [], "names": None, "acks": []}
+
+    def on_msg(t, ptr):
+        if t == suscan.MSG_PSD:
+            st["psd"] += 1
+        elif t == suscan.MSG_INSPECTOR:
+            m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
+            if m.kind == suscan.KIND_OPEN:
+                lst = C.cast(m.spectsrc_list, C.POINTER(C.c_char_p))
+                st["names"] = [lst[i].decode() for i in range(m.spectsrc_count)]
+                st["open_at"] = st["psd"]                   # blocks processed before the chain existed
+                assert Lb.suscan_analyzer_inspector_set_spectrum_async(an, m.handle, 99, 2)      # no such source
+                assert Lb.suscan_analyzer_inspector_set_spectrum_async(an, m.handle, 1, 3)       # "psd"
+            elif m.kind == suscan.KIND_SPECTRUM:
+                if not m.spectrum_data:
+                    st["acks"].append((m.req_id, m.spectsrc_id, st["psd"]))
+                else:
+                    d = np.ctypeslib.as_array(C.cast(m.spectrum_data, C.POINTER(C.c_float)), shape=(m.spectrum_size,)).copy()
+                    st["spec"].append((st["psd"], m.spectsrc_id, m.samp_rate, d))
+                    if len(st["spec"]) == 3:                                                  # switch source mid-stream
+                        assert Lb.suscan_analyzer_inspector_set_spectrum_async(an, m.handle, 7, 4)   # "exp_2"
+            elif m.kind == suscan.KIND_INVALID_ARGUMENT:
+                st["acks"].append((m.req_id, None, st["psd"]))
+
+    _pump(Lb, an, on_msg)
+    assert st["names"] == list(sdo.SPECTSRC)
+    acks = {a[0]: a for a in st["acks"]}
+    assert acks[2][1] is None and acks[3][1] == 1 and acks[4][1] == 7
+    D, efs = 8, FS / 8
+    taps = sdo.lpf_design(255, bw / FS)
+    dp = sdo.fnor_to_dphase(-2 * fc / FS)
+    b0 = st["open_at"]
+    y = sdo.chan_feed(np.zeros(254, np.complex64), x[b0 * L:], 0, sdo.chan_modulate_taps(taps, dp), D, 0, dp)
+    mb = L // D                                                      # channel samples per block
+    n = 8192
+    win = sdo.window(4, n)
+    seen = {1: 0, 7: 0}
+    for npsd, sid, rate, d in st["spec"]:
+        blk = npsd - 1 - b0                                          # the block's PSD message precedes its inspector output
+        assert rate == int(efs) and d.size == n and blk >= 0
+        seg = y[blk * mb:(blk + 1) * mb]
+        prev = 0j if (sid == 7 and seen[7] == 0) or blk == 0 else complex(y[blk * mb - 1])
+        pre = sdo.spectsrc_preproc(sid, seg, prev)
+        ref = sdo.psd_frames(pre, mb // n, n, n, win, navg=mb // n, scale=1.0 / n)[0]
+        assert np.max(np.abs(d - ref)) < 1e-5 * np.max(ref), (blk, sid)
+        seen[sid] += 1
+        if sid == 7:                                                 # what the tab does next: dB + rotate, then look
+            shown = sdo.inspector_spectrum_db_shift(d)
+            k = int(np.argmax(shown)) - n // 2
+            assert abs(k * efs / n - 2 * offs) < 2 * efs / n
+    assert seen[1] >= 3 and seen[7] >= 2
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+
+
 def test_halt_wakes_the_reader_and_bad_source_reports_failure(tmp_path):
     x = synth.tone_noise(L * 2, seed=1)
     path = tmp_path / "iq.raw"

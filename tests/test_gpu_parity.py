@@ -701,6 +701,21 @@ def test_manual_clock_is_gardner_without_feedback(ctx, sdo):
 
 
 # ------------------------------------------------------------------------------------------
+# section 8f #2: inspector spectrum sources -- per-sample transform bit exact
+# ------------------------------------------------------------------------------------------
+def test_spectsrc_transforms_bit_exact(ctx, sdo):
+    assert ctx.lib.suamd_spectsrc_count() == len(sdo.SPECTSRC)
+    x = synth.psk_carriers(10007, [0.03], sps=8, order=4, seed=12)
+    for kind, name in enumerate(sdo.SPECTSRC, start=1):
+        assert ctx.lib.suamd_spectsrc_name(kind) == name.encode()
+        ref = sdo.spectsrc_preproc(kind, x, 0.25 - 0.5j)
+        a = host(ctx.spectsrc_preproc(kind, dev(x[:4000]), 0.25 - 0.5j))
+        b = host(ctx.spectsrc_preproc(kind, dev(x[4000:]), complex(x[3999])))      # previous sample carried over
+        assert_bits(np.concatenate([a, b]), ref, f"spectrum source {name}")
+    assert ctx.lib.suamd_spectsrc_name(0) is None and ctx.lib.suamd_spectsrc_name(10) is None
+
+
+# ------------------------------------------------------------------------------------------
 # section 8f #4: FAC (FACTab::feed) -- FFT-tolerance
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("size,alpha", [(1024, 1.0), (8192, 0.25), (65536, 0.5)])
