@@ -318,6 +318,15 @@ struct Inspector {
   suamd_complex *d_spre = nullptr;            // transformed samples
   float *d_spec = nullptr;
   suamd_complex spect_prev = {0, 0};          // last channel sample of the previous block
+  // every inspector enqueues its whole chain on one of the analyzer's inspector streams and is
+  // collected after all of them were enqueued: the one-wavefront recurrence kernels of different
+  // inspectors overlap instead of queueing behind each other
+  hipStream_t stream = nullptr;
+  struct Pinned { uint32_t count; suamd_complex prev; float spec[8192]; } *pin = nullptr;   // D2H landing zone
+  SUSCOUNT pend_m = 0;                        // channel samples of the block in flight
+  bool pend_samples = false, pend_spectrum = false, pend_symbols = false;
+  const suamd_complex *pend_src = nullptr;
+  unsigned pend_spec_n = 0;
   bool quad = false, first = true;
   suamd_complex *d_y = nullptr, *d_a = nullptr, *d_z = nullptr, *d_sym = nullptr, *d_prev = nullptr;
   uint32_t *d_count = nullptr;
@@ -345,6 +354,8 @@ struct Inspector {
   void free_all()
   {
     free_spectrum();
+    if (pin) (void)hipHostFree(pin);
+    pin = nullptr;
     free_chain();
     for (void *p : {(void *)d_y, (void *)d_a, (void *)d_z, (void *)d_sym, (void *)d_prev, (void *)d_count})
       if (p) (void)hipFree(p);
@@ -386,6 +397,9 @@ struct suscan_analyzer {
   suamd_psd_t *psd = nullptr;
   std::map<SUHANDLE, std::unique_ptr<Inspector>> inspectors;
   hipStream_t stream = nullptr;
+  static constexpr int NISTREAMS = 8;
+  hipStream_t istream[NISTREAMS] = {};
+  hipEvent_t ev_input = nullptr;              // the block is in d_x
   suamd_complex *h_x = nullptr, *d_x = nullptr;
   void *d_raw = nullptr;                       // compact-format payload before suamd_ingest_iq
   float *d_psd = nullptr;
@@ -440,7 +454,11 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
     if (!ok) { err = "device allocation failed"; return false; }
     in.cap = need;
   }
-  (void)hipMemsetAsync(in.d_prev, 0, 8, a->stream);
+  if (!in.stream) in.stream = a->istream[(unsigned)in.handle % suscan_analyzer::NISTREAMS];
+  if (!in.pin && hipHostMalloc((void **)&in.pin, sizeof(Inspector::Pinned), hipHostMallocDefault) != hipSuccess) {
+    err = "pinned allocation failed"; return false;
+  }
+  (void)hipMemsetAsync(in.d_prev, 0, 8, in.stream);
   in.first = true;
   in.quad = false;
   if (in.cls == "raw") return true;
@@ -489,7 +507,7 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
     in.clock = suamd_clock_bank_new(a->ctx, 1, gardner ? (float)cfg_get(in.config, "clock.gain", .2) : 0.0f,
                                     (float)(baud / in.equiv_fs));
     if (!in.clock) { err = suamd_last_error(); return false; }
-    if (!gardner) suamd_clock_bank_set_phase(in.clock, 0.5f * (float)cfg_get(in.config, "clock.phase", 0), a->stream);
+    if (!gardner) suamd_clock_bank_set_phase(in.clock, 0.5f * (float)cfg_get(in.config, "clock.phase", 0), in.stream);
     if ((int)cfg_get(in.config, "equalizer.type", 0) == 1) {
       in.cma = suamd_cma_bank_new(a->ctx, 1, 8, (float)cfg_get(in.config, "equalizer.rate", 1e-3));
       if (!in.cma) { err = suamd_last_error(); return false; }
@@ -506,15 +524,15 @@ void emit_samples(suscan_analyzer *a, const Inspector &in, const suamd_complex *
   m->inspector_id = in.inspector_id;
   m->sample_count = count;
   m->samples = static_cast<suamd_complex *>(std::malloc(count * sizeof(suamd_complex)));
-  (void)hipMemcpyAsync(m->samples, d_src, count * sizeof(suamd_complex), hipMemcpyDeviceToHost, a->stream);
-  (void)hipStreamSynchronize(a->stream);
+  (void)hipMemcpyAsync(m->samples, d_src, count * sizeof(suamd_complex), hipMemcpyDeviceToHost, in.stream);
+  (void)hipStreamSynchronize(in.stream);
   push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_SAMPLES, m);
 }
 
 // INSPECTOR/SPECTRUM: the selected source's transform of this block's channel samples, then every whole
 // frame of the block Welch-averaged into one spectrum (linear power, natural order: the tab takes dB and
 // rotates, GenericInspector.cpp:231-247); frame = the largest power of two <= min(block, 8192)
-void emit_spectrum(suscan_analyzer *a, Inspector &in, SUSCOUNT m)
+void enqueue_spectrum(suscan_analyzer *a, Inspector &in, SUSCOUNT m)
 {
   unsigned n = 512;
   while (n * 2 <= m && n < 8192) n *= 2;
@@ -531,74 +549,93 @@ void emit_spectrum(suscan_analyzer *a, Inspector &in, SUSCOUNT m)
     }
     in.spect_n = n;
   }
-  if (!suamd_spectsrc_preproc(a->ctx, in.spectsrc_id, in.d_y, m, in.spect_prev.re, in.spect_prev.im, in.d_spre, a->stream)) return;
-  (void)hipMemcpyAsync(&in.spect_prev, in.d_y + (m - 1), sizeof(suamd_complex), hipMemcpyDeviceToHost, a->stream);
+  if (!suamd_spectsrc_preproc(a->ctx, in.spectsrc_id, in.d_y, m, in.spect_prev.re, in.spect_prev.im, in.d_spre, in.stream)) return;
+  (void)hipMemcpyAsync(&in.pin->prev, in.d_y + (m - 1), sizeof(suamd_complex), hipMemcpyDeviceToHost, in.stream);
   const unsigned frames = (unsigned)(m / n);
-  if (!suamd_psd_feed(in.spect_psd, in.d_spre, frames, n, frames, 1.0f / (float)n, SUAMD_PSD_LINEAR, in.d_spec, a->stream)) return;
-  auto *msg = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SPECTRUM, 0);
-  msg->handle = in.handle;
-  msg->inspector_id = in.inspector_id;
-  msg->spectsrc_id = in.spectsrc_id;
-  msg->spectrum_size = n;
-  msg->samp_rate = (SUSCOUNT)in.equiv_fs;
-  msg->spectrum_data = static_cast<SUFLOAT *>(std::malloc(n * sizeof(SUFLOAT)));
-  (void)hipMemcpyAsync(msg->spectrum_data, in.d_spec, n * sizeof(float), hipMemcpyDeviceToHost, a->stream);
-  (void)hipStreamSynchronize(a->stream);
-  push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, msg);
+  if (!suamd_psd_feed(in.spect_psd, in.d_spre, frames, n, frames, 1.0f / (float)n, SUAMD_PSD_LINEAR, in.d_spec, in.stream)) return;
+  (void)hipMemcpyAsync(in.pin->spec, in.d_spec, n * sizeof(float), hipMemcpyDeviceToHost, in.stream);
+  in.pend_spectrum = true;
+  in.pend_spec_n = n;
 }
 
-void run_inspector(suscan_analyzer *a, Inspector &in, size_t len)
+// phase A: the inspector's whole chain for this block, asynchronously on its own stream
+void enqueue_inspector(suscan_analyzer *a, Inspector &in, size_t len)
 {
+  in.pend_samples = in.pend_spectrum = in.pend_symbols = false;
   if (in.dirty) {
     std::string err;
     if (!build_chain(a, in, err)) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, err); return; }
     in.dirty = false;
   }
+  hipStream_t st = in.stream;
+  (void)hipStreamWaitEvent(st, a->ev_input, 0);
   const suamd_view row = {(SUSCOUNT)in.cap, 1};
   SUSCOUNT m = 0;
-  if (!suamd_chanbank_feed(in.bank, a->d_x, len, in.d_y, row, &m, a->stream)) return;
-  if (in.spectsrc_id) emit_spectrum(a, in, m);
+  if (!suamd_chanbank_feed(in.bank, a->d_x, len, in.d_y, row, &m, st)) return;
+  in.pend_m = m;
+  if (in.spectsrc_id) enqueue_spectrum(a, in, m);
   // ping-pong through d_a / d_z so that no stage runs in place
   const suamd_complex *cur = in.d_y;
   auto other = [&](const suamd_complex *p) { return p == in.d_a ? in.d_z : in.d_a; };
-  if (in.agc) { suamd_agc_bank_feed(in.agc, cur, row, in.d_a, row, m, a->stream); cur = in.d_a; }
-  else if (in.fixed_gain > 0) { suamd_rows_scale(a->ctx, cur, row, in.d_a, row, 1, m, in.fixed_gain, a->stream); cur = in.d_a; }
+  if (in.agc) { suamd_agc_bank_feed(in.agc, cur, row, in.d_a, row, m, st); cur = in.d_a; }
+  else if (in.fixed_gain > 0) { suamd_rows_scale(a->ctx, cur, row, in.d_a, row, 1, m, in.fixed_gain, st); cur = in.d_a; }
   if (in.costas) {
     suamd_complex *o = other(cur);
-    suamd_costas_bank_feed(in.costas, cur, row, o, row, m, a->stream);
+    suamd_costas_bank_feed(in.costas, cur, row, o, row, m, st);
     cur = o;
   } else if (in.nco) {
     suamd_complex *o = other(cur);
-    suamd_nco_bank_feed(in.nco, cur, row, o, row, m, a->stream);
+    suamd_nco_bank_feed(in.nco, cur, row, o, row, m, st);
     cur = o;
   } else if (in.pll) {
     suamd_complex *o = other(cur);
-    suamd_pll_bank_feed(in.pll, cur, row, o, row, m, a->stream);
+    suamd_pll_bank_feed(in.pll, cur, row, o, row, m, st);
     cur = o;
   } else if (in.quad) {
     suamd_complex *o = other(cur);
-    suamd_quad_demod_batch(a->ctx, cur, row, o, row, 1, m, in.d_prev, in.first ? SU_TRUE : SU_FALSE, in.d_sym /*tmp*/,
-                           a->stream);
-    (void)hipMemcpyAsync(in.d_prev, in.d_sym, 8, hipMemcpyDeviceToDevice, a->stream);
+    suamd_quad_demod_batch(a->ctx, cur, row, o, row, 1, m, in.d_prev, in.first ? SU_TRUE : SU_FALSE, in.d_sym /*tmp*/, st);
+    (void)hipMemcpyAsync(in.d_prev, in.d_sym, 8, hipMemcpyDeviceToDevice, st);
     in.first = false;
     cur = o;
   }
   if (in.mf) {
     suamd_complex *o = other(cur);
-    suamd_fir_bank_feed(in.mf, cur, row, o, row, m, a->stream);
+    suamd_fir_bank_feed(in.mf, cur, row, o, row, m, st);
     cur = o;
   }
   if (in.clock) {
-    (void)hipMemsetAsync(in.d_count, 0, 4, a->stream);
-    suamd_clock_bank_feed(in.clock, cur, row, m, in.d_sym, (SUSCOUNT)in.cap, in.d_count, a->stream);
-    uint32_t n = 0;
-    (void)hipMemcpyAsync(&n, in.d_count, 4, hipMemcpyDeviceToHost, a->stream);
-    (void)hipStreamSynchronize(a->stream);
-    if (in.cma && n) suamd_cma_bank_feed(in.cma, in.d_sym, (SUSCOUNT)in.cap, nullptr, n, in.d_sym, (SUSCOUNT)in.cap, a->stream);
-    emit_samples(a, in, in.d_sym, n);
+    (void)hipMemsetAsync(in.d_count, 0, 4, st);
+    suamd_clock_bank_feed(in.clock, cur, row, m, in.d_sym, (SUSCOUNT)in.cap, in.d_count, st);
+    // the equalizer takes its symbol count from the device: no host round trip inside the chain
+    if (in.cma) suamd_cma_bank_feed(in.cma, in.d_sym, (SUSCOUNT)in.cap, in.d_count, 0, in.d_sym, (SUSCOUNT)in.cap, st);
+    (void)hipMemcpyAsync(&in.pin->count, in.d_count, 4, hipMemcpyDeviceToHost, st);
+    in.pend_symbols = true;
   } else {
-    emit_samples(a, in, cur, m);
+    in.pend_samples = true;
+    in.pend_src = cur;
   }
+}
+
+// phase B: wait for the inspector's stream and turn its results into messages
+void collect_inspector(suscan_analyzer *a, Inspector &in)
+{
+  if (!in.stream || !(in.pend_samples || in.pend_spectrum || in.pend_symbols)) return;
+  (void)hipStreamSynchronize(in.stream);
+  if (in.pend_spectrum) {
+    in.spect_prev = in.pin->prev;
+    auto *msg = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SPECTRUM, 0);
+    msg->handle = in.handle;
+    msg->inspector_id = in.inspector_id;
+    msg->spectsrc_id = in.spectsrc_id;
+    msg->spectrum_size = in.pend_spec_n;
+    msg->samp_rate = (SUSCOUNT)in.equiv_fs;
+    msg->spectrum_data = static_cast<SUFLOAT *>(std::malloc(in.pend_spec_n * sizeof(SUFLOAT)));
+    std::memcpy(msg->spectrum_data, in.pin->spec, in.pend_spec_n * sizeof(float));
+    push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, msg);
+  }
+  if (in.pend_symbols) emit_samples(a, in, in.d_sym, in.pin->count);
+  else if (in.pend_samples) emit_samples(a, in, in.pend_src, in.pend_m);
+  in.pend_samples = in.pend_spectrum = in.pend_symbols = false;
 }
 
 void handle_request(suscan_analyzer *a, Request &r)
@@ -762,6 +799,9 @@ void worker_main(suscan_analyzer *a)
   bool ok = a->ctx != nullptr;
   if (!ok) err = suamd_last_error();
   if (ok && hipStreamCreate(&a->stream) != hipSuccess) { ok = false; err = "hipStreamCreate failed"; }
+  for (int k = 0; ok && k < suscan_analyzer::NISTREAMS; ++k)
+    if (hipStreamCreateWithFlags(&a->istream[k], hipStreamNonBlocking) != hipSuccess) { ok = false; err = "hipStreamCreate failed"; }
+  if (ok && hipEventCreateWithFlags(&a->ev_input, hipEventDisableTiming) != hipSuccess) { ok = false; err = "hipEventCreate failed"; }
   if (ok) ok = src.open(err);
   if (ok && src.cfg.samp_rate != a->source_cfg.samp_rate) {       // a WAV / SigMF header carries its own rate
     a->source_cfg.samp_rate = src.cfg.samp_rate;
@@ -823,6 +863,9 @@ void worker_main(suscan_analyzer *a)
         break;
       }
     }
+    (void)hipEventRecord(a->ev_input, a->stream);
+    // the inspectors' chains start as soon as the block is on the device, next to the PSD
+    for (auto &kv : a->inspectors) enqueue_inspector(a, *kv.second, a->block);
     const unsigned n = (unsigned)a->params.detector_params.window_size;
     if (!suamd_psd_feed(a->psd, a->d_x, a->navg, n, a->navg, 1.0f / (float)n, SUAMD_PSD_LINEAR, a->d_psd, a->stream)) {
       push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, suamd_last_error());
@@ -844,7 +887,7 @@ void worker_main(suscan_analyzer *a)
       m->timestamp.tv_usec = (suseconds_t)((ts - std::floor(ts)) * 1e6);
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_PSD, m);
     }
-    for (auto &kv : a->inspectors) run_inspector(a, *kv.second, a->block);
+    for (auto &kv : a->inspectors) collect_inspector(a, *kv.second);
     consumed += a->block;
     // ---- rate bookkeeping / throttle ----
     auto now = std::chrono::steady_clock::now();
@@ -871,6 +914,9 @@ void worker_main(suscan_analyzer *a)
   if (a->d_raw) (void)hipFree(a->d_raw);
   if (a->d_psd) (void)hipFree(a->d_psd);
   if (a->stream) (void)hipStreamDestroy(a->stream);
+  for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) { if (a->istream[k]) (void)hipStreamDestroy(a->istream[k]); a->istream[k] = nullptr; }
+  if (a->ev_input) (void)hipEventDestroy(a->ev_input);
+  a->ev_input = nullptr;
   if (a->ctx) suamd_ctx_destroy(a->ctx);
   a->psd = nullptr; a->h_x = nullptr; a->d_x = nullptr; a->d_raw = nullptr; a->d_psd = nullptr; a->stream = nullptr; a->ctx = nullptr;
   push(a, SUSCAN_WORKER_MSG_TYPE_HALT, nullptr);
@@ -1050,6 +1096,9 @@ suscan_analyzer_t *suscan_analyzer_new(const struct suscan_analyzer_params *para
                                        struct suscan_mq *mq)
 {
   if (!params || !config || !mq || !mq->impl) return nullptr;
+  // one hardware queue per inspector stream (the HIP default is 4); only effective when this is the
+  // process's first use of the HIP runtime, and never overrides the user's choice
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   auto *a = new (std::nothrow) suscan_analyzer;
   if (!a) return nullptr;
   a->params = *params;

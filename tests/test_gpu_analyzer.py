@@ -417,6 +417,74 @@ def test_inspector_spectrum_sources(tmp_path, sdo):
     Lb.suscan_mq_finalize(C.byref(mq))
 
 
+def test_many_concurrent_inspectors(tmp_path, sdo):
+    """20 inspectors opened on one analyzer (their chains run concurrently on the analyzer's inspector streams):
+    every SAMPLES stream is attributed to the right inspector_id and equals that channel's oracle chain."""
+    import time
+    nblocks, nins = 8, 20
+    baud, bw = 15625.0, 30e3
+    fcs = (np.arange(nins) - nins / 2 + 0.5) * 40e3
+    x = synth.psk_carriers(L * nblocks, list(2 * fcs / FS), sps=int(FS / baud), order=4, seed=3, snr_db=25)
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    Lb, mq, an = _start(path, L)
+    Lb.suscan_analyzer_set_throttle_async(an, 3 * FS, 0)
+    for k, fc in enumerate(fcs):
+        ch = suscan.Channel(fc=float(fc), f_lo=float(fc - bw / 2), f_hi=float(fc + bw / 2), bw=bw, ft=433.92e6)
+        assert Lb.suscan_analyzer_open_ex_async(an, b"psk", C.byref(ch), 1, -1, 100 + k)
+    st = {"psd": 0, "cfg_at": {}, "samples": {}, "handle_of": {}}
+
+    def on_msg(t, ptr):
+        if t == suscan.MSG_PSD:
+            st["psd"] += 1
+        elif t == suscan.MSG_INSPECTOR:
+            m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
+            if m.kind == suscan.KIND_OPEN:
+                k = m.req_id - 100
+                st["handle_of"][m.handle] = k
+                assert Lb.suscan_analyzer_set_inspector_id_async(an, m.handle, 5000 + k, 200 + k)
+                cfg = Lb.suscan_config_dup(m.config)
+                Lb.suscan_config_set_integer(cfg, b"afc.costas-order", 2)
+                Lb.suscan_config_set_float(cfg, b"afc.loop-bw", 40.0)
+                Lb.suscan_config_set_integer(cfg, b"clock.type", 1)
+                Lb.suscan_config_set_float(cfg, b"clock.baud", baud)
+                assert Lb.suscan_analyzer_set_inspector_config_async(an, m.handle, cfg, 300 + k)
+                Lb.suscan_config_destroy(cfg)
+            elif m.kind == suscan.KIND_SET_CONFIG:
+                k = m.req_id - 300
+                st["cfg_at"][k] = st["psd"]
+                st["samples"][k] = []
+        elif t == suscan.MSG_SAMPLES:
+            m = C.cast(ptr, C.POINTER(suscan.SampleBatchMsg)).contents
+            k = m.inspector_id - 5000
+            if 0 <= k < nins and k in st["cfg_at"]:
+                st["samples"][k].append(np.ctypeslib.as_array(m.samples, shape=(m.sample_count * 2,)).copy().view(np.complex64))
+
+    t0 = time.time()
+    _pump(Lb, an, on_msg)
+    assert len(st["cfg_at"]) == nins and time.time() - t0 < 60
+    D, efs = 16, FS / 16                                   # pow2floor(1e6 / 60e3)
+    taps = sdo.lpf_design(255, bw / FS)
+    sps = efs / baud
+    checked = 0
+    for k in range(nins):
+        b0 = st["cfg_at"][k]
+        if b0 > nblocks - 3:
+            continue
+        dp = sdo.fnor_to_dphase(-2 * fcs[k] / FS)
+        y = sdo.chan_feed(np.zeros(254, np.complex64), x[b0 * L:], 0, sdo.chan_modulate_taps(taps, dp), D, 0, dp)
+        a = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(sps)), y)
+        z = sdo.costas_feed_bulk(sdo.costas_new(2, 0.0, min(2.0 / sps, 0.95), 3, 2 * 40.0 / efs), a)
+        ref = sdo.clock_feed_bulk(sdo.clock_new(0.2, baud / efs), z)
+        got = np.concatenate(st["samples"][k])
+        assert len(got) == len(ref), f"inspector {k}: symbol count"
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"inspector {k}: symbols differ from the oracle"
+        checked += 1
+    assert checked >= nins // 2
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+
+
 def test_halt_wakes_the_reader_and_bad_source_reports_failure(tmp_path):
     x = synth.tone_noise(L * 2, seed=1)
     path = tmp_path / "iq.raw"
