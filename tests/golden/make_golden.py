@@ -1,4 +1,4 @@
-"""Generates tests/golden/oracle_v1.npz from the CPU oracle.
+"""Generates tests/golden/oracle_v1.npz and oracle_v2.npz from the CPU oracle.
 
 The reference (SigDigger) ships NO golden vectors and its DSP libraries are absent
 (SURVEY.md section 8c), so these fixtures are produced by oracle/sdo.c itself on seeded inputs: they
@@ -42,10 +42,52 @@ def compute(sdo):
     return out
 
 
+def compute_v2(sdo):
+    """second fixture set: the stages added after v1 (samplers, A7 stages, ingest, spectrum sources, FAC)"""
+    from sigdigger_amd import synth
+    out = {}
+    x = synth.psk_carriers(3 * 4096 + 500, [0.0], sps=8, order=2, seed=77, snr_db=25)
+    out["input_iq"] = x
+    out["zc_amplitude"] = sdo.sample_zero_crossing(x, 1.0 / 8, 0, False, 0.05 + 0j, 1 + 0j)
+    out["zc_phase"] = sdo.sample_zero_crossing(x, 1.0 / 8, 1, False, 0j, -1j)
+    out["zc_frequency"] = sdo.sample_zero_crossing(x, 1.0 / 8, 2)
+    out["conj_prev"] = sdo.conj_prev(x[:2048], 0.5 - 0.25j)
+    out["manual_amp"] = sdo.sample_manual(x[:4096], 500.0, 3, 0)
+    out["manual_freq"] = sdo.sample_manual(x[:4096], 500.0, 3, 2)
+    h = sdo.rrc_design(8.0, 0.35)
+    out["rrc_taps"] = h
+    out["matched"] = sdo.fir_feed(np.zeros(h.size - 1, np.complex64), h, x[:3000])
+    cd = sdo.clock_new(0.0, 1.0 / 8)
+    cd.phi = np.float32(0.5) * np.float32(0.3)
+    sym = sdo.clock_feed_bulk(cd, out["matched"])
+    out["manual_clock"] = sym
+    q = sdo.cma_new(8, 2e-3)
+    out["cma"] = sdo.cma_feed_bulk(q, sym)
+    out["cma_weights"] = np.array(q.w[:16], dtype=np.float32)
+    out["scale"] = sdo.scale(x[:1000], 0.37)
+    rng = np.random.default_rng(5)
+    raw8 = rng.integers(0, 256, 2 * 999).astype(np.uint8)
+    raw16 = rng.integers(-32768, 32768, 2 * 999).astype(np.int16)
+    out["raw_u8"], out["raw_s16"] = raw8, raw16
+    out["ingest_u8"] = sdo.ingest_iq(2, raw8)
+    out["ingest_s8"] = sdo.ingest_iq(3, raw8.view(np.int8))
+    out["ingest_s16"] = sdo.ingest_iq(4, raw16)
+    for k, name in enumerate(sdo.SPECTSRC, start=1):
+        out["spectsrc_" + name] = sdo.spectsrc_preproc(k, x[:2048], 0.1 + 0.2j)
+    f = sdo.FAC(1024, 0.5)
+    f.feed(x[:1024], 2, 500)
+    f.feed(x[1024:2048] * np.complex64(2), 2, 500)
+    out["fac_1024"] = f.fac.copy()
+    out["fac_range"] = np.array([f.min.value, f.max.value], dtype=np.float32)
+    return out
+
+
 def main():
     from oracle import sdo
     np.savez_compressed(os.path.join(HERE, "oracle_v1.npz"), **compute(sdo))
     print("wrote", os.path.join(HERE, "oracle_v1.npz"))
+    np.savez_compressed(os.path.join(HERE, "oracle_v2.npz"), **compute_v2(sdo))
+    print("wrote", os.path.join(HERE, "oracle_v2.npz"))
 
 
 if __name__ == "__main__":
