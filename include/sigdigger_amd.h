@@ -239,6 +239,30 @@ SUAMD_API SUBOOL      suamd_spectsrc_preproc(suamd_ctx_t *ctx, unsigned id, cons
                                              SUFLOAT prev_re, SUFLOAT prev_im, suamd_complex *d_y, void *stream);
 
 /* ------------------------------------------------------------------------------------ */
+/* section 8f #3: symbol decision and SNR analytics on the device (1 B/symbol to the host)  */
+/* ------------------------------------------------------------------------------------ */
+enum suamd_decision_mode { SUAMD_DECIDER_MODULUS = 0, SUAMD_DECIDER_ARGUMENT = 1 };   /* InspectorUI.cpp:229-250 */
+/* the decision-space floats InspectorUI::feed forwards (Default/GenericInspector/InspectorUI.cpp:863-873):
+ * MODULUS |x|, ARGUMENT arg(j x) / pi */
+SUAMD_API SUBOOL suamd_decision_space(suamd_ctx_t *ctx, const suamd_complex *d_x, SUSCOUNT len, int mode,
+                                      SUFLOAT *d_out, void *stream);
+/* Decider::feed: v = |x| (range [0, 1]) or arg x (range [-pi, pi]); symbol = the interval of 2^bps equal ones
+ * v falls into, clamped (SuWidgets is absent: semantics frozen in SPEC.md section K) */
+SUAMD_API SUBOOL suamd_decide(suamd_ctx_t *ctx, const suamd_complex *d_x, SUSCOUNT len, int mode, unsigned bps,
+                              SUFLOAT vmin, SUFLOAT vmax, unsigned char *d_sym, void *stream);
+/* the Histogram widget's history: counts of v over nbins equal bins of [vmin, vmax), added to d_hist */
+SUAMD_API SUBOOL suamd_symbol_histogram(suamd_ctx_t *ctx, const suamd_complex *d_x, SUSCOUNT len, int mode,
+                                        SUFLOAT vmin, SUFLOAT vmax, unsigned nbins, unsigned *d_hist, void *stream);
+/* SNREstimator (Misc/SNREstimator.cpp:30-169): setBps + setAlpha at creation, feed(history) = one model
+ * recalculation + gradient step on sigma; get: sigma, getSNR() = 1 / (2^bps sigma), sum of squared errors^2 */
+typedef struct suamd_snr_estimator suamd_snr_estimator_t;
+SUAMD_API suamd_snr_estimator_t *suamd_snr_estimator_new(suamd_ctx_t *ctx, unsigned bps, SUFLOAT alpha);
+SUAMD_API void     suamd_snr_estimator_destroy(suamd_snr_estimator_t *e);
+SUAMD_API SUBOOL   suamd_snr_estimator_feed(suamd_snr_estimator_t *e, const unsigned *d_history, unsigned length, void *stream);
+SUAMD_API SUBOOL   suamd_snr_estimator_get(suamd_snr_estimator_t *e, SUFLOAT *sigma, SUFLOAT *snr, SUFLOAT *sqerr, void *stream);
+SUAMD_API SUFLOAT *suamd_snr_estimator_model(suamd_snr_estimator_t *e);     /* device pointer: getModel(), `length` floats */
+
+/* ------------------------------------------------------------------------------------ */
 /* section 8f #4: fast autocorrelation of the inspector's sample stream                    */
 /* FACTab::feed (Default/GenericInspector/FACTab.cpp:181-246): per full buffer of `size` samples   */
 /* FFT -> x conj(x) -> inverse FFT -> |.| of the first half; running max / min over               */

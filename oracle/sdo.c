@@ -880,6 +880,105 @@ void sdo_spectsrc_preproc(int kind, const sdo_c32 *x, size_t len, sdo_c32 prev0,
   }
 }
 
+/* ===================================================================================== */
+/* section 8f #3: decision space / decider / histogram / SNR estimator                      */
+/* ===================================================================================== */
+static float dec_value(sdo_c32 x, int mode)
+{
+  return mode == 0 ? sqrtf(fmaf(x.im, x.im, x.re * x.re)) : sdo_atan2f(x.im, x.re);
+}
+
+void sdo_decision_space(const sdo_c32 *x, size_t len, int mode, float *out)
+{
+  size_t i;
+  for (i = 0; i < len; ++i)                                  /* :864-871 */
+    out[i] = mode == 0 ? sqrtf(fmaf(x[i].im, x[i].im, x[i].re * x[i].re))
+                       : (float)((double)sdo_atan2f(x[i].re, -x[i].im) / SDO_PI);      /* arg(j x) / PI */
+}
+
+void sdo_decide(const sdo_c32 *x, size_t len, int mode, unsigned bps, float vmin, float vmax, unsigned char *sym)
+{
+  size_t i;
+  const int intervals = 1 << bps;
+  const float d = (vmax - vmin) / (float)intervals;
+  for (i = 0; i < len; ++i) {
+    int s = (int)floorf((dec_value(x[i], mode) - vmin) / d);
+    sym[i] = (unsigned char)(s < 0 ? 0 : (s > intervals - 1 ? intervals - 1 : s));
+  }
+}
+
+void sdo_symbol_histogram(const sdo_c32 *x, size_t len, int mode, float vmin, float vmax, unsigned nbins, unsigned *hist)
+{
+  size_t i;
+  const float d = (vmax - vmin) / (float)nbins;
+  for (i = 0; i < len; ++i) {
+    int b = (int)floorf((dec_value(x[i], mode) - vmin) / d);
+    if (b >= 0 && b < (int)nbins) ++hist[b];
+  }
+}
+
+void sdo_snr_init(sdo_snr *e, unsigned bps, float alpha)
+{
+  memset(e, 0, sizeof *e);
+  e->sigma = 1.f / 8.f;                                      /* SNR_ESTIMATOR_DEFAULT_SIGMA */
+  e->alpha = alpha;
+  e->bps = bps;
+  e->intervals = 1u << bps;                                  /* setBps :134-142 */
+}
+
+void sdo_snr_feed(sdo_snr *e, const unsigned *history, unsigned length, float *Hi)
+{
+  unsigned i, j, max = 0;
+  float *gaussian = malloc(sizeof(float) * length), *Htilde = malloc(sizeof(float) * length);
+  e->length = length;
+  e->hx = 1.f / length;                                      /* feed :147-153 */
+  for (i = 0; i < length; ++i) if (max < history[i]) max = history[i];
+  if (max == 0) max = 1;
+  for (i = 0; i < length; ++i) Htilde[i] = (float)history[i] / max;
+  if (length > 0 && e->intervals > 0) {                      /* iterate() :83-117 */
+    float delta = 0, x, term, intlen, start, skip, mx = 0;
+    float sigmainv = 1.f / e->sigma, sigma3inv = sigmainv * sigmainv * sigmainv, sigma2 = e->sigma * e->sigma;
+    /* recalculateModel() :30-80 */
+    for (i = 0; i < length; ++i) {
+      x = i * e->hx;
+      if (x >= .5f) x -= 1.f;
+      gaussian[i] = expf(-x * x / sigma2);
+    }
+    intlen = 1.f / e->intervals;
+    start = .5f * intlen;
+    for (i = 0; i < length; ++i) Hi[i] = 0.f;
+    for (j = 0; j < e->intervals; ++j) {
+      float sk = start + j * intlen;
+      float t = 1.f - (sk - floorf(sk));
+      unsigned skipint = (unsigned)floorf(length * sk), i1, i2;
+      for (i = 0; i < length; ++i) {
+        i1 = (unsigned)(length + i - skipint) % length;
+        i2 = (unsigned)(length + i1 - 1) % length;
+        Hi[i] += t * gaussian[i1];
+        Hi[i] += (1 - t) * gaussian[i2];
+      }
+    }
+    for (i = 0; i < length; ++i) if (Hi[i] > mx) mx = Hi[i];
+    if (mx > 0.f) for (i = 0; i < length; ++i) Hi[i] /= mx;
+    /* back in iterate() */
+    for (i = 0; i < length; ++i) {
+      x = i * e->hx;
+      if (x >= .5f) x -= 1.f;
+      term = 0;
+      for (j = 0; j < e->intervals; ++j) { skip = start + j * intlen; term += (x - skip) * (x - skip); }
+      term *= (Hi[i] - Htilde[i]) / sigma3inv;
+      delta += term;
+    }
+    e->delta = delta / length;
+    e->sigma += -e->alpha * e->delta;
+    e->sqerr = 0;                                            /* calculateSquareError() :119-131 */
+    for (i = 0; i < length; ++i) { float er = (Hi[i] - Htilde[i]) * (Hi[i] - Htilde[i]); e->sqerr += er * er; }
+  }
+  free(gaussian); free(Htilde);
+}
+
+float sdo_snr_get(const sdo_snr *e) { return 1.f / (e->intervals * e->sigma); }
+
 void sdo_ingest_iq(int format, const void *raw, size_t n, sdo_c32 *out)
 {
   size_t i;

@@ -193,6 +193,21 @@ void   sdo_cma_feed_bulk(sdo_cma *q, const sdo_c32 *x, size_t len, sdo_c32 *y);
 #define SDO_SPECTSRC_COUNT 9
 void sdo_spectsrc_preproc(int kind, const sdo_c32 *x, size_t len, sdo_c32 prev0, sdo_c32 *y);
 
+/* ---- section 8f #3: decision space, decider, symbol histogram, SNR estimator ------------------------- */
+/* decision space delivered by InspectorUI::feed (Default/GenericInspector/InspectorUI.cpp:863-873) [REF-PINNED]:
+ * mode 0 MODULUS |x|, mode 1 ARGUMENT arg(j x)/pi */
+void sdo_decision_space(const sdo_c32 *x, size_t len, int mode, float *out);
+/* Decider (SuWidgets, absent) [UPSTREAM-RECOLLECTION]; range per InspectorUI.cpp:229-250 (MODULUS [0,1],
+ * ARGUMENT [-pi,pi]): v = |x| or arg(x); sym = clamp(floor((v - vmin) / ((vmax - vmin) / 2^bps)), 0, 2^bps - 1) */
+void sdo_decide(const sdo_c32 *x, size_t len, int mode, unsigned bps, float vmin, float vmax, unsigned char *sym);
+/* history of the Histogram widget [UPSTREAM-RECOLLECTION]: counts of v over nbins equal bins of [vmin, vmax) */
+void sdo_symbol_histogram(const sdo_c32 *x, size_t len, int mode, float vmin, float vmax, unsigned nbins, unsigned *hist);
+/* SNREstimator (Misc/SNREstimator.cpp:30-169, include/SNREstimator.h) [REF-PINNED] */
+typedef struct { float sigma, alpha, hx, delta, sqerr; unsigned bps, intervals, length; } sdo_snr;
+void  sdo_snr_init(sdo_snr *e, unsigned bps, float alpha);            /* setBps + setAlpha; sigma = 1/8 */
+void  sdo_snr_feed(sdo_snr *e, const unsigned *history, unsigned length, float *model /* Hi, length */);
+float sdo_snr_get(const sdo_snr *e);                                  /* getSNR(): 1 / (intervals * sigma) */
+
 /* ---- ingest (section 8f #1): file-source sample formats -> SUCOMPLEX ------------------------------ */
 /* format 1 f32, 2 u8 (v-128)/128, 3 s8 v/128, 4 s16 v/32768 [UPSTREAM-RECOLLECTION: libsndfile norm] */
 void sdo_ingest_iq(int format, const void *raw, size_t nsamples, sdo_c32 *out);

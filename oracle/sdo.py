@@ -53,6 +53,11 @@ class CMA(C.Structure):
     _fields_ = [("n", C.c_int), ("mu", C.c_float), ("locked", C.c_int), ("w", C.c_float * 32), ("d", C.c_float * 32)]
 
 
+class SNR(C.Structure):
+    _fields_ = [("sigma", C.c_float), ("alpha", C.c_float), ("hx", C.c_float), ("delta", C.c_float), ("sqerr", C.c_float),
+                ("bps", C.c_uint), ("intervals", C.c_uint), ("length", C.c_uint)]
+
+
 class AGCParams(C.Structure):
     _fields_ = [("threshold", C.c_float), ("slope_factor", C.c_float), ("hang_max", C.c_uint),
                 ("delay_line_size", C.c_uint), ("mag_history_size", C.c_uint),
@@ -94,6 +99,10 @@ def lib():
         L.sdo_clock_feed_bulk.restype = C.c_size_t
         L.sdo_carrier_detect.restype = C.c_float
         L.sdo_spectsrc_preproc.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C32, C.c_void_p]
+        L.sdo_snr_get.restype = C.c_float
+        L.sdo_snr_init.argtypes = [C.c_void_p, C.c_uint, C.c_float]
+        L.sdo_decide.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.c_float, C.c_float, C.c_void_p]
+        L.sdo_symbol_histogram.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_uint, C.c_void_p]
         L.sdo_rrc_ntaps.restype = C.c_size_t
         L.sdo_rrc_ntaps.argtypes = [C.c_double]
         L.sdo_rrc_design.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double]
@@ -408,6 +417,45 @@ def spectsrc_preproc(kind, x, prev0=0j):
     y = np.empty(x.size, dtype=c32)
     lib().sdo_spectsrc_preproc(int(kind), _p(x), x.size, C32(float(np.real(prev0)), float(np.imag(prev0))), _p(y))
     return y
+
+
+def decision_space(x, mode):
+    x = _c(x)
+    out = np.empty(x.size, dtype=np.float32)
+    lib().sdo_decision_space(_p(x), C.c_size_t(x.size), C.c_int(mode), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def decide(x, mode, bps, vmin, vmax):
+    x = _c(x)
+    out = np.empty(x.size, dtype=np.uint8)
+    lib().sdo_decide(_p(x), x.size, int(mode), int(bps), float(vmin), float(vmax), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def symbol_histogram(x, mode, vmin, vmax, nbins, hist=None):
+    x = _c(x)
+    if hist is None:
+        hist = np.zeros(nbins, dtype=np.uint32)
+    lib().sdo_symbol_histogram(_p(x), x.size, int(mode), float(vmin), float(vmax), int(nbins), hist.ctypes.data_as(C.c_void_p))
+    return hist
+
+
+def snr_new(bps, alpha):
+    e = SNR()
+    lib().sdo_snr_init(C.byref(e), int(bps), float(alpha))
+    return e
+
+
+def snr_feed(e, history):
+    h = np.ascontiguousarray(history, dtype=np.uint32)
+    model = np.empty(h.size, dtype=np.float32)
+    lib().sdo_snr_feed(C.byref(e), h.ctypes.data_as(C.c_void_p), C.c_uint(h.size), model.ctypes.data_as(C.c_void_p))
+    return model
+
+
+def snr_get(e):
+    return float(lib().sdo_snr_get(C.byref(e)))
 
 
 def ingest_iq(fmt, raw):

@@ -576,6 +576,87 @@ SUBOOL suamd_rows_scale(suamd_ctx_t *ctx, const suamd_complex *d_x, suamd_view x
   return SU_TRUE;
 }
 
+// ---- section 8f #3 --------------------------------------------------------------------------------------
+SUBOOL suamd_decision_space(suamd_ctx_t *ctx, const suamd_complex *d_x, SUSCOUNT len, int mode, SUFLOAT *d_out, void *stream)
+{
+  if (!ctx) { set_err("null context"); return SU_FALSE; }
+  if (mode != SUAMD_DECIDER_MODULUS && mode != SUAMD_DECIDER_ARGUMENT) { set_err("bad decision mode %d", mode); return SU_FALSE; }
+  if (len == 0) return SU_TRUE;
+  if (!d_x || !d_out) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(sdk::decision_space(d_x, (long long)len, mode, d_out, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUBOOL suamd_decide(suamd_ctx_t *ctx, const suamd_complex *d_x, SUSCOUNT len, int mode, unsigned bps, SUFLOAT vmin, SUFLOAT vmax,
+                    unsigned char *d_sym, void *stream)
+{
+  if (!ctx) { set_err("null context"); return SU_FALSE; }
+  if (mode != SUAMD_DECIDER_MODULUS && mode != SUAMD_DECIDER_ARGUMENT) { set_err("bad decision mode %d", mode); return SU_FALSE; }
+  if (bps < 1 || bps > 8 || !(vmax > vmin)) { set_err("bad bits per symbol / range"); return SU_FALSE; }
+  if (len == 0) return SU_TRUE;
+  if (!d_x || !d_sym) { set_err("null argument"); return SU_FALSE; }
+  const int intervals = 1 << bps;
+  HIP_TRY(sdk::decide(d_x, (long long)len, mode, intervals, vmin, (vmax - vmin) / (float)intervals, d_sym, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUBOOL suamd_symbol_histogram(suamd_ctx_t *ctx, const suamd_complex *d_x, SUSCOUNT len, int mode, SUFLOAT vmin, SUFLOAT vmax,
+                              unsigned nbins, unsigned *d_hist, void *stream)
+{
+  if (!ctx) { set_err("null context"); return SU_FALSE; }
+  if (mode != SUAMD_DECIDER_MODULUS && mode != SUAMD_DECIDER_ARGUMENT) { set_err("bad decision mode %d", mode); return SU_FALSE; }
+  if (nbins < 1 || nbins > 8192 || !(vmax > vmin)) { set_err("bad bin count / range"); return SU_FALSE; }
+  if (len == 0) return SU_TRUE;
+  if (!d_x || !d_hist) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(sdk::symbol_histogram(d_x, (long long)len, mode, vmin, (vmax - vmin) / (float)nbins, (int)nbins, d_hist, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+struct suamd_snr_estimator { suamd_ctx *ctx; unsigned bps, intervals; float alpha; float *d_state, *d_model; };
+
+suamd_snr_estimator_t *suamd_snr_estimator_new(suamd_ctx_t *ctx, unsigned bps, SUFLOAT alpha)
+{
+  if (!ctx || bps < 1 || bps > 8) { set_err("bad argument"); return nullptr; }
+  HIP_TRY(hipSetDevice(ctx->device), nullptr);
+  suamd_snr_estimator *e = new (std::nothrow) suamd_snr_estimator;
+  if (!e) { set_err("out of memory"); return nullptr; }
+  e->ctx = ctx; e->bps = bps; e->intervals = 1u << bps; e->alpha = alpha;
+  e->d_state = dev_from_host(std::vector<float>{1.f / 8.f, 0.f, INFINITY});    // SNR_ESTIMATOR_DEFAULT_SIGMA
+  e->d_model = dev_zeros<float>(4096);
+  if (!e->d_state || !e->d_model) { set_err("device allocation failed"); suamd_snr_estimator_destroy(e); return nullptr; }
+  return e;
+}
+
+void suamd_snr_estimator_destroy(suamd_snr_estimator_t *e)
+{
+  if (!e) return;
+  if (e->d_state) hipFree(e->d_state);
+  if (e->d_model) hipFree(e->d_model);
+  delete e;
+}
+
+SUBOOL suamd_snr_estimator_feed(suamd_snr_estimator_t *e, const unsigned *d_history, unsigned length, void *stream)
+{
+  if (!e || !d_history) { set_err("null argument"); return SU_FALSE; }
+  if (length < 1 || length > 4096) { set_err("history length %u unsupported (1..4096)", length); return SU_FALSE; }
+  HIP_TRY(sdk::snr_feed(d_history, (int)length, (int)e->intervals, e->alpha, e->d_state, e->d_model, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUBOOL suamd_snr_estimator_get(suamd_snr_estimator_t *e, SUFLOAT *sigma, SUFLOAT *snr, SUFLOAT *mse_sum, void *stream)
+{
+  if (!e) { set_err("null argument"); return SU_FALSE; }
+  float st[3];
+  HIP_TRY(hipMemcpyAsync(st, e->d_state, sizeof st, hipMemcpyDeviceToHost, as_stream(stream)), SU_FALSE);
+  HIP_TRY(hipStreamSynchronize(as_stream(stream)), SU_FALSE);
+  if (sigma) *sigma = st[0];
+  if (snr) *snr = 1.f / (e->intervals * st[0]);              // getSNR()
+  if (mse_sum) *mse_sum = st[2];
+  return SU_TRUE;
+}
+
+SUFLOAT *suamd_snr_estimator_model(suamd_snr_estimator_t *e) { return e ? e->d_model : nullptr; }
+
 static const char *const kSpectsrcNames[] = {"psd", "cyclo", "fmspect", "pmspect", "timediff", "abstimediff", "exp_2", "exp_4", "exp_8"};
 
 unsigned suamd_spectsrc_count(void) { return (unsigned)(sizeof kSpectsrcNames / sizeof kSpectsrcNames[0]); }

@@ -115,6 +115,11 @@ hipError_t specview_sweep_linear(const SpecViewLinear *d_geom, int nframes, cons
 hipError_t rows_scale(const void *x, View xv, void *y, View yv, int nchan, long long len, float g, hipStream_t st);
 hipError_t rows_xlate(const void *x, View xv, void *y, View yv, int nchan, long long len, const uint32_t *dphase,
                       const uint32_t *phase0, uint64_t n0, hipStream_t st);
+hipError_t decision_space(const void *x, long long len, int mode, float *out, hipStream_t st);
+hipError_t decide(const void *x, long long len, int mode, int intervals, float vmin, float d, unsigned char *sym, hipStream_t st);
+hipError_t symbol_histogram(const void *x, long long len, int mode, float vmin, float d, int nbins, unsigned *hist, hipStream_t st);
+// state: {sigma, delta, sqerr}; length <= 4096
+hipError_t snr_feed(const unsigned *history, int length, int intervals, float alpha, float *state, float *model, hipStream_t st);
 hipError_t spectsrc_preproc(int kind, const void *x, long long len, float prev_re, float prev_im, void *y, hipStream_t st);
 // hist / hist_next: [ntaps-1][nchan] complex (time-major), ping-pong
 hipError_t rows_fir(const void *x, View xv, void *y, View yv, int nchan, long long len, const float *h, int ntaps,

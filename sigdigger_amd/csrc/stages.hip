@@ -91,6 +91,131 @@ __global__ void spectsrc_kernel(int kind, const float2 *__restrict__ x, long lon
   }
 }
 
+// ---- section 8f #3: decision space, decider, symbol histogram, SNR estimator ------------------------------
+__device__ __forceinline__ float dec_value(float2 x, int mode)
+{
+  return mode == 0 ? __builtin_sqrtf(sd::fma_(x.y, x.y, x.x * x.x)) : sd::atan2_(x.y, x.x);
+}
+
+// InspectorUI::feed, decision-space forwarding (Default/GenericInspector/InspectorUI.cpp:863-873)
+__global__ void decision_space_kernel(const float2 *__restrict__ x, long long len, int mode, float *__restrict__ out)
+{
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
+    const float2 v = x[i];
+    out[i] = mode == 0 ? __builtin_sqrtf(sd::fma_(v.y, v.y, v.x * v.x))
+                       : (float)((double)sd::atan2_(v.x, -v.y) / 3.14159265358979323846);        // arg(j x) / PI
+  }
+}
+
+// one byte per symbol instead of eight: sym = clamp(floor((v - vmin) / d), 0, intervals - 1)
+__global__ void decide_kernel(const float2 *__restrict__ x, long long len, int mode, int intervals, float vmin, float d,
+                              unsigned char *__restrict__ sym)
+{
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
+    const int s = (int)__builtin_floorf((dec_value(x[i], mode) - vmin) / d);
+    sym[i] = (unsigned char)(s < 0 ? 0 : (s > intervals - 1 ? intervals - 1 : s));
+  }
+}
+
+// integer counts: atomics are exact and order-independent; a block first counts into LDS
+__global__ __launch_bounds__(256) void symbol_histogram_kernel(const float2 *__restrict__ x, long long len, int mode,
+                                                               float vmin, float d, int nbins, unsigned *__restrict__ hist)
+{
+  extern __shared__ unsigned lhist[];
+  unsigned *lh = lhist;
+  for (int i = threadIdx.x; i < nbins; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)__builtin_floorf((dec_value(x[i], mode) - vmin) / d);
+    if (b >= 0 && b < nbins) atomicAdd(&lh[b], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nbins; i += blockDim.x) if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+// SNREstimator::feed -> iterate -> recalculateModel (Misc/SNREstimator.cpp:30-169), one workgroup.
+// state: [0] sigma, [1] delta, [2] sqerr.  Sums over the bins are fixed-order tree reductions
+// (deterministic; the reference adds sequentially -- binary32 rounding differs in the last bits).
+constexpr int SNR_T = 256, SNR_MAXLEN = 4096;
+__device__ float snr_block_sum(float v, float *red)
+{
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = SNR_T / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+  const float r = red[0];
+  __syncthreads();
+  return r;
+}
+__device__ float snr_block_max(float v, float *red)
+{
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = SNR_T / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
+  const float r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(SNR_T) void snr_feed_kernel(const unsigned *__restrict__ history, int length, int intervals,
+                                                         float alpha, float *__restrict__ state, float *__restrict__ model)
+{
+  __shared__ float gaussian[SNR_MAXLEN], red[SNR_T];
+  const int tid = threadIdx.x;
+  const float sigma = state[0];
+  const float hx = 1.f / length;
+  // feed(): Htilde = history / max
+  float m = 0;
+  for (int i = tid; i < length; i += SNR_T) m = fmaxf(m, (float)history[i]);
+  unsigned hmax = (unsigned)snr_block_max(m, red);           // exact: counts < 2^24 in practice; guarded below
+  for (int i = tid; i < length; i += SNR_T) if (history[i] > hmax) hmax = history[i];
+  if (hmax == 0) hmax = 1;
+  // recalculateModel(): step 1
+  const float sigma2 = sigma * sigma;
+  for (int i = tid; i < length; i += SNR_T) {
+    float x = i * hx;
+    if (x >= .5f) x -= 1.f;
+    gaussian[i] = expf(-x * x / sigma2);
+  }
+  __syncthreads();
+  // step 2: every interval adds its shifted gaussian, in interval order
+  const float intlen = 1.f / intervals, start = .5f * intlen;
+  float himax = 0;
+  for (int i = tid; i < length; i += SNR_T) {
+    float h = 0.f;
+    for (int j = 0; j < intervals; ++j) {
+      const float skip = start + j * intlen;
+      const float t = 1.f - (skip - floorf(skip));
+      const unsigned skipint = (unsigned)floorf(length * skip);
+      const unsigned i1 = (unsigned)(length + i - skipint) % (unsigned)length;
+      const unsigned i2 = (unsigned)(length + i1 - 1) % (unsigned)length;
+      h += t * gaussian[i1];
+      h += (1 - t) * gaussian[i2];
+    }
+    model[i] = h;
+    himax = fmaxf(himax, h);
+  }
+  // step 3: normalise
+  const float mx = snr_block_max(himax, red);
+  if (mx > 0.f) for (int i = tid; i < length; i += SNR_T) model[i] /= mx;
+  // iterate(): gradient step on sigma
+  const float sigmainv = 1.f / sigma, sigma3inv = sigmainv * sigmainv * sigmainv;
+  float dsum = 0, esum = 0;
+  for (int i = tid; i < length; i += SNR_T) {
+    float x = i * hx;
+    if (x >= .5f) x -= 1.f;
+    float term = 0;
+    for (int j = 0; j < intervals; ++j) { const float skip = start + j * intlen; term += (x - skip) * (x - skip); }
+    const float diff = model[i] - (float)history[i] / hmax;
+    term *= diff / sigma3inv;
+    dsum += term;
+    const float er = diff * diff;
+    esum += er * er;
+  }
+  const float delta = snr_block_sum(dsum, red) / length;
+  const float sqerr = snr_block_sum(esum, red);
+  if (tid == 0) { state[1] = delta; state[0] = sigma + -alpha * delta; state[2] = sqerr; }
+}
+
 // mf.type = MANUAL: y_c[m] = sum_k h[k] x_c[m-k], k ascending (one fma chain per component).
 // A thread owns R consecutive outputs of one channel and walks the samples they need from the
 // newest to the oldest, so every sample is loaded once and each output sees its taps in ascending
@@ -229,6 +354,38 @@ hipError_t rows_xlate(const void *x, View xv, void *y, View yv, int nchan, long 
   if (len <= 0 || nchan <= 0) return hipSuccess;
   hipLaunchKernelGGL(rows_xlate_kernel, dim3(grid_for(len * nchan, 256)), dim3(256), 0, st,
                      reinterpret_cast<const float2 *>(x), xv, reinterpret_cast<float2 *>(y), yv, nchan, len, dphase, phase0, n0);
+  return hipGetLastError();
+}
+
+hipError_t decision_space(const void *x, long long len, int mode, float *out, hipStream_t st)
+{
+  if (len <= 0) return hipSuccess;
+  hipLaunchKernelGGL(decision_space_kernel, dim3(grid_for(len, 256)), dim3(256), 0, st, reinterpret_cast<const float2 *>(x), len, mode, out);
+  return hipGetLastError();
+}
+
+hipError_t decide(const void *x, long long len, int mode, int intervals, float vmin, float d, unsigned char *sym, hipStream_t st)
+{
+  if (len <= 0) return hipSuccess;
+  hipLaunchKernelGGL(decide_kernel, dim3(grid_for(len, 256)), dim3(256), 0, st, reinterpret_cast<const float2 *>(x), len, mode,
+                     intervals, vmin, d, sym);
+  return hipGetLastError();
+}
+
+hipError_t symbol_histogram(const void *x, long long len, int mode, float vmin, float d, int nbins, unsigned *hist, hipStream_t st)
+{
+  if (len <= 0) return hipSuccess;
+  unsigned g = grid_for(len, 256 * 16);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(symbol_histogram_kernel, dim3(g), dim3(256), sizeof(unsigned) * (size_t)nbins, st,
+                     reinterpret_cast<const float2 *>(x), len, mode, vmin, d, nbins, hist);
+  return hipGetLastError();
+}
+
+hipError_t snr_feed(const unsigned *history, int length, int intervals, float alpha, float *state, float *model, hipStream_t st)
+{
+  if (length <= 0 || length > SNR_MAXLEN) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(snr_feed_kernel, dim3(1), dim3(SNR_T), 0, st, history, length, intervals, alpha, state, model);
   return hipGetLastError();
 }
 

@@ -153,6 +153,27 @@ class Context:
         check(self.lib.suamd_ingest_iq(self.h, int(fmt), _ptr(raw), n, _ptr(out), _stream(stream)), "suamd_ingest_iq")
         return out
 
+    def decision_space(self, x, mode, stream=None):
+        _chk_c64(x, "x")
+        out = torch.empty(x.numel(), dtype=torch.float32, device=x.device)
+        check(self.lib.suamd_decision_space(self.h, _ptr(x), x.numel(), int(mode), _ptr(out), _stream(stream)), "suamd_decision_space")
+        return out
+
+    def decide(self, x, mode, bps, vmin, vmax, stream=None):
+        _chk_c64(x, "x")
+        out = torch.empty(x.numel(), dtype=torch.uint8, device=x.device)
+        check(self.lib.suamd_decide(self.h, _ptr(x), x.numel(), int(mode), int(bps), float(vmin), float(vmax), _ptr(out),
+                                    _stream(stream)), "suamd_decide")
+        return out
+
+    def symbol_histogram(self, x, mode, vmin, vmax, nbins, hist=None, stream=None):
+        _chk_c64(x, "x")
+        if hist is None:
+            hist = torch.zeros(nbins, dtype=torch.int32, device=x.device)
+        check(self.lib.suamd_symbol_histogram(self.h, _ptr(x), x.numel(), int(mode), float(vmin), float(vmax), int(nbins),
+                                              _ptr(hist), _stream(stream)), "suamd_symbol_histogram")
+        return hist
+
     def spectsrc_preproc(self, kind, x, prev0=0j, out=None, stream=None):
         """per-sample transform of an inspector spectrum source (1-based id, suamd_spectsrc_name)"""
         _chk_c64(x, "x")
@@ -418,6 +439,31 @@ class FAC(_LoopBank):
         mn, mx = C.c_float(), C.c_float()
         check(self.ctx.lib.suamd_fac_get_range(self.h, C.byref(mn), C.byref(mx), None), "suamd_fac_get_range")
         return mn.value, mx.value
+
+
+class SNREstimator(_LoopBank):
+    """SigDigger::SNREstimator (Misc/SNREstimator.cpp) on the device."""
+    _destroy = "suamd_snr_estimator_destroy"
+
+    def __init__(self, ctx, bps, alpha):
+        self.ctx = ctx
+        self.h = ctx.lib.suamd_snr_estimator_new(ctx.h, int(bps), float(alpha))
+        if not self.h:
+            raise SigDiggerAmdError("suamd_snr_estimator_new: " + _l.last_error())
+
+    def feed(self, hist, stream=None):
+        self.length = hist.numel()
+        check(self.ctx.lib.suamd_snr_estimator_feed(self.h, _ptr(hist), self.length, _stream(stream)), "suamd_snr_estimator_feed")
+
+    def get(self):
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        check(self.ctx.lib.suamd_snr_estimator_get(self.h, C.byref(a), C.byref(b), C.byref(c), None), "suamd_snr_estimator_get")
+        return a.value, b.value, c.value
+
+    def model(self):
+        t = torch.empty(self.length, dtype=torch.float32, device="cuda")
+        _memcpy_d2d(t, self.ctx.lib.suamd_snr_estimator_model(self.h), self.length * 4)
+        return t.cpu().numpy()
 
 
 class NCOBank(_LoopBank):

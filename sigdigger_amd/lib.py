@@ -60,6 +60,14 @@ PROTOTYPES = {
     "suamd_sample_zero_crossing_bulk": (C.c_int64, [VP, VP, U64, F32, INT, INT, F32, F32, F32, F32, VP, U64, VP]),
     "suamd_conj_prev_bulk": (INT, [VP, VP, VP, U64, F32, F32, VP]),
     "suamd_ingest_iq": (INT, [VP, INT, VP, U64, VP, VP]),
+    "suamd_decision_space": (INT, [VP, VP, U64, INT, VP, VP]),
+    "suamd_decide": (INT, [VP, VP, U64, INT, UINT, F32, F32, VP, VP]),
+    "suamd_symbol_histogram": (INT, [VP, VP, U64, INT, F32, F32, UINT, VP, VP]),
+    "suamd_snr_estimator_new": (VP, [VP, UINT, F32]),
+    "suamd_snr_estimator_destroy": (None, [VP]),
+    "suamd_snr_estimator_feed": (INT, [VP, VP, UINT, VP]),
+    "suamd_snr_estimator_get": (INT, [VP, VP, VP, VP, VP]),
+    "suamd_snr_estimator_model": (VP, [VP]),
     "suamd_spectsrc_count": (UINT, []),
     "suamd_spectsrc_name": (C.c_char_p, [UINT]),
     "suamd_spectsrc_preproc": (INT, [VP, UINT, VP, U64, F32, F32, VP, VP]),

@@ -701,6 +701,45 @@ def test_manual_clock_is_gardner_without_feedback(ctx, sdo):
 
 
 # ------------------------------------------------------------------------------------------
+# section 8f #3: decision space / decider / histogram (bit exact, integer exact) and the SNR estimator
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,vmin,vmax", [(1, -np.pi, np.pi), (0, 0.0, 1.0)])
+def test_decider_and_histogram_exact(ctx, sdo, mode, vmin, vmax):
+    x = (0.6 * synth.psk_carriers(100003, [0.0], sps=4, order=8, seed=6, snr_db=18)).astype(np.complex64)
+    x[:6] = [0, 1, -1, 1j, -1j, 1e-30]                                 # range edges, exact axes
+    dx = dev(x)
+    assert_bits(host(ctx.decision_space(dx, mode)), sdo.decision_space(x, mode), "decision space")
+    for bps in (1, 2, 3, 8):
+        assert np.array_equal(host(ctx.decide(dx, mode, bps, vmin, vmax)), sdo.decide(x, mode, bps, vmin, vmax)), bps
+    for nbins in (16, 256, 1000):
+        h = ctx.symbol_histogram(dx, mode, vmin, vmax, nbins)
+        h = ctx.symbol_histogram(dx[:5000].contiguous(), mode, vmin, vmax, nbins, hist=h)          # accumulates
+        ref = sdo.symbol_histogram(x[:5000], mode, vmin, vmax, nbins, sdo.symbol_histogram(x, mode, vmin, vmax, nbins))
+        assert np.array_equal(host(h).astype(np.uint32), ref), nbins
+
+
+@pytest.mark.parametrize("bps,length", [(2, 256), (1, 100), (3, 1024), (2, 4096)])
+def test_snr_estimator_matches_reference_port(ctx, sdo, bps, length):
+    rng = np.random.default_rng(bps * 100 + length)
+    M = 1 << bps
+    s = np.exp(1j * (np.pi / M + 2 * np.pi / M * rng.integers(0, M, 200000)))
+    x = (s + 0.12 * (rng.standard_normal(s.size) + 1j * rng.standard_normal(s.size)) / np.sqrt(2)).astype(np.complex64)
+    hist = sdo.symbol_histogram(x, 1, -np.pi, np.pi, length)
+    ref = sdo.snr_new(bps, 1.0 / M)                                    # InspectorUI.cpp:788: alpha = 1 / intervals
+    est = engine.SNREstimator(ctx, bps, 1.0 / M)
+    dh = dev(hist.astype(np.int32))
+    for it in range(40):
+        model = sdo.snr_feed(ref, hist)
+        est.feed(dh)
+        if it in (0, 39):
+            sigma, snr, sqerr = est.get()
+            assert abs(sigma - ref.sigma) <= 2e-5 * abs(ref.sigma), (it, sigma, ref.sigma)
+            assert abs(snr - sdo.snr_get(ref)) <= 2e-5 * sdo.snr_get(ref)
+            assert np.max(np.abs(est.model() - model)) < 2e-5            # the model histogram is normalised to 1
+            assert abs(sqerr - ref.sqerr) <= 1e-3 * max(ref.sqerr, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------
 # section 8f #2: inspector spectrum sources -- per-sample transform bit exact
 # ------------------------------------------------------------------------------------------
 def test_spectsrc_transforms_bit_exact(ctx, sdo):
