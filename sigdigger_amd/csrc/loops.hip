@@ -304,11 +304,8 @@ __device__ __forceinline__ float2 costas_step(const sdk::CostasParams &p, Costas
   for (int q = ORDER; q >= 1; --q) { tr = sd::fma_(p.fb[q], r.xh[q].re, tr); ti = sd::fma_(p.fb[q], r.xh[q].im, ti); }
 #pragma unroll
   for (int q = ORDER; q >= 1; --q) { tr = sd::fma_(-p.fa[q], r.yh[q].re, tr); ti = sd::fma_(-p.fa[q], r.yh[q].im, ti); }
-  float cs, sn;
-  sd::phasor_u32(r.phase, cs, sn);
-  c32 m;                                                      // x * conj(ref)
-  m.re = sd::fma_(v.y, sn, v.x * cs);
-  m.im = sd::fma_(v.y, cs, -(v.x * sn));
+  const sd::v2f_ mm = sd::mix_conj(sd::v2f_{v.x, v.y}, sd::phasor_pk(r.phase));   // x * conj(ref)
+  const c32 m = {mm.x, mm.y};
   c32 z;
   z.re = sd::fma_(p.fb[0], m.re, tr);
   z.im = sd::fma_(p.fb[0], m.im, ti);
@@ -389,11 +386,8 @@ __global__ __launch_bounds__(64) void costas_kernel(sdk::CostasParams p, sdk::Co
 // K7: PLL
 __device__ __forceinline__ float2 pll_step(float alpha, float beta, uint32_t &phase, float &omega, float2 v)
 {
-  float cs, sn;
-  sd::phasor_u32(phase, cs, sn);
-  float2 m;
-  m.x = sd::fma_(v.y, sn, v.x * cs);
-  m.y = sd::fma_(v.y, cs, -(v.x * sn));
+  const sd::v2f_ mm = sd::mix_conj(sd::v2f_{v.x, v.y}, sd::phasor_pk(phase));
+  const float2 m = {mm.x, mm.y};
   float err = sd::atan2_(v.y, v.x) - sd::phase_to_rad(phase);
   if (err >  3.14159265358979323846f) err -= 6.28318530717958647692f;
   if (err < -3.14159265358979323846f) err += 6.28318530717958647692f;

@@ -40,6 +40,42 @@ __device__ __forceinline__ void phasor_u32(uint32_t p, float &c, float &s)
   s = __uint_as_float(b ^ (t & 0x80000000u));                  // negate for q = 2, 3
 }
 
+typedef float v2f_ __attribute__((ext_vector_type(2)));
+
+// phasor_u32 with the two polynomials evaluated as one packed chain, result as the pair (cos, sin):
+// the same binary32 operations as phasor_u32 (each half of a v_pk_fma_f32 is an IEEE fma), laid out
+// so that no register shuffling is needed between the steps -- for the one-wavefront recurrence
+// kernels every instruction is 4 issue cycles.
+__device__ __forceinline__ v2f_ phasor_pk(uint32_t p)
+{
+  const int32_t r = (int32_t)(p << 2) >> 2;
+  const float x = (float)r * 1.46291807926715968e-9f;
+  const float z = x * x;
+  const v2f_ zz = {z, z};
+  v2f_ q = __builtin_elementwise_fma(zz, v2f_{-1.9515295891e-4f, 2.443315711809948e-5f}, v2f_{8.3321608736e-3f, -1.388731625493765e-3f});
+  q = __builtin_elementwise_fma(q, zz, v2f_{-1.6666654611e-1f, 4.166664568298827e-2f});
+  q = q * zz;                                                   // (sp * z, cp * z)
+  const v2f_ sc = __builtin_elementwise_fma(q, v2f_{x, z}, v2f_{x, fma_(z, -0.5f, 1.0f)});   // (sn, cs)
+  const uint32_t t = p + 0x20000000u;                           // bits 31:30 = quadrant
+  const bool odd = (int32_t)(t << 1) < 0;
+  const uint32_t ia = __float_as_uint(odd ? sc.x : sc.y);       // q odd ? sn : cs
+  const uint32_t ib = __float_as_uint(odd ? sc.y : sc.x);       // q odd ? cs : sn
+  v2f_ cs;
+  cs.x = __uint_as_float(ia ^ ((t ^ (t << 1)) & 0x80000000u));  // negate for q = 1, 2
+  cs.y = __uint_as_float(ib ^ (t & 0x80000000u));               // negate for q = 2, 3
+  return cs;
+}
+
+// x * conj(ref), ref = (cos, sin):  re = fma(x.im, sin, x.re * cos),  im = fma(x.im, cos, -(x.re * sin))
+// as two VOP3P instructions (operand halves picked with op_sel, the negation is neg_hi)
+__device__ __forceinline__ v2f_ mix_conj(v2f_ x, v2f_ cs)
+{
+  v2f_ t, m;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(x), "v"(cs));            // (x.re cos, x.re sin)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,0,1]" : "=v"(m) : "v"(x), "v"(cs), "v"(t));
+  return m;
+}
+
 // D2: atan2 (radians), Cephes atanf kernel on min/max.
 __device__ __forceinline__ float atan2_(float y, float x)
 {
