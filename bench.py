@@ -265,14 +265,19 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hook: SUAMD_BENCH_SHARE_GPU=1 puts every rank on GPU 0 with the gloo backend, so that the
+    # N > 1 control flow (sharding, block broadcast, barriers, max-over-ranks) can be exercised on a
+    # one-GPU box; RCCL itself refuses two ranks on one device
+    share = os.environ.get("SUAMD_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    ctx = engine.Context(local_rank)
+        dist.init_process_group("gloo" if share else "nccl", rank=rank, world_size=world)
+    ctx = engine.Context(dev_index)
 
     cfg, L, dt, stages, fn_rank, pipe = run_workload(args.workload, args, rank, world, dev, ctx, dist)
 

@@ -1,0 +1,59 @@
+"""bench.py contract: one JSON line with the required keys at N = 1, and the N > 1 control flow (torchrun launch,
+channel sharding, block broadcast, barriers, max over ranks, rank-0 print) exercised with two ranks sharing the
+one GPU of the test box over gloo (SUAMD_BENCH_SHARE_GPU=1 -- RCCL refuses two ranks on one device)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _last_json(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--no-extra", "--cpu-samples", "65536"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert REQUIRED <= set(d) and "cpu_baseline" in d
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "MS/s" and d["value"] > 50.0 and d["dtype"] == "f32" and d["data"] == "synthetic"
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
+    assert abs(d["value"] - d["config"]["block_samples"] * 4 / (d["ms_per_step"] * 4e-3) / 1e6) < 0.01 * d["value"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+def test_two_ranks_share_the_gpu_over_gloo():
+    env = dict(os.environ, SUAMD_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["inspectors_total"] == 2 * d["config"]["inspectors_per_gpu"]
+    assert "cpu_baseline" not in d and "other_workloads" not in d                  # N = 1 only
+    # whole-job aggregate: both ranks push the same block through their own bank
+    assert abs(d["value"] - 2 * d["config"]["block_samples"] / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+    assert abs(d["stream_rate_MSps"] - d["value"] / 2) < 1e-2
