@@ -216,7 +216,9 @@ def _oracle_bank(sdo, x, fnors, D, taps, blocks):
 
 
 @pytest.mark.parametrize("nchan,D,T", [(1, 16, 255), (3, 64, 255), (8, 64, 255), (5, 1, 31), (2, 7, 64),
-                                       (64, 64, 255), (4, 256, 255)])
+                                       (64, 64, 255), (4, 256, 255),
+                                       # large banks with ragged channel-group / output counts
+                                       (33, 16, 255), (70, 64, 255), (130, 8, 63), (64, 3, 100), (32, 1, 9)])
 def test_chanbank_bit_exact(ctx, sdo, nchan, D, T):
     n = 40000 if nchan < 64 else 24000
     fn = synth.raster(nchan, 1.6 / max(nchan, 2))
