@@ -120,6 +120,18 @@ __device__ __forceinline__ void fir_load(FirChunk<NCH, NOUT, TC> &c, const float
   }
 }
 
+template <int NCH, int NOUT, int TC, bool LDS_TAPS>
+__device__ __forceinline__ void fir_touch(const FirChunk<NCH, NOUT, TC> &c)
+{
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) asm volatile("" :: "v"(c.x[o][0]), "v"(c.x[o][TC - 1]));
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    if (LDS_TAPS) asm volatile("" :: "v"(c.t[j][0].x), "v"(c.t[j][TC - 1].w));
+    else          asm volatile("" :: "s"(c.t[j][0].x), "s"(c.t[j][TC - 1].w));
+  }
+}
+
 template <int NCH, int NOUT, int TC>
 __device__ __forceinline__ void fir_mac(v2f (&acc)[NCH][NOUT], const FirChunk<NCH, NOUT, TC> &c)
 {
@@ -267,7 +279,8 @@ __global__ __launch_bounds__(FIR_THREADS) void chan_fir_kernel(const float2 *__r
       int r = 0;
       if (run >= TC) {
         FirChunk<NCH, NOUT, TC> ca;
-        if (DB) {
+        if (DB && LDS_TAPS) {
+          // taps and window both come from LDS (in order): counted waits let chunk c+1 load during c's fmas
           FirChunk<NCH, NOUT, TC> cb;
           fir_load<NCH, NOUT, TC>(ca, xr - (TC - 1), ostride, gp, k);
           for (; r + 2 * TC <= run; r += TC) {
@@ -277,6 +290,31 @@ __global__ __launch_bounds__(FIR_THREADS) void chan_fir_kernel(const float2 *__r
           }
           fir_mac<NCH, NOUT, TC>(acc, ca);
           r += TC;
+        } else if (DB) {
+          // scalar taps: ping-pong, no register copies.  Scalar loads return out of order and share lgkmcnt
+          // with the LDS reads, so every wait is lgkmcnt(0): fir_touch() (an empty asm reading the chunk's
+          // registers) makes the compiler wait for chunk c BEFORE chunk c+1's loads are issued -- then c+1
+          // is in flight during c's fmas and is the only thing the next wait covers.
+          FirChunk<NCH, NOUT, TC> cb;
+          fir_load<NCH, NOUT, TC>(ca, xr - (TC - 1), ostride, gp, k);
+          for (; r + 3 * TC <= run; r += 2 * TC) {
+            fir_touch<NCH, NOUT, TC, LDS_TAPS>(ca);
+            fir_load<NCH, NOUT, TC>(cb, xr - (r + 2 * TC - 1), ostride, gp, k + r + TC);
+            __builtin_amdgcn_sched_barrier(0);
+            fir_mac<NCH, NOUT, TC>(acc, ca);
+            __builtin_amdgcn_sched_barrier(0);
+            fir_touch<NCH, NOUT, TC, LDS_TAPS>(cb);
+            fir_load<NCH, NOUT, TC>(ca, xr - (r + 3 * TC - 1), ostride, gp, k + r + 2 * TC);
+            __builtin_amdgcn_sched_barrier(0);
+            fir_mac<NCH, NOUT, TC>(acc, cb);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          fir_mac<NCH, NOUT, TC>(acc, ca);
+          r += TC;
+          for (; r + TC <= run; r += TC) {
+            fir_load<NCH, NOUT, TC>(ca, xr - (r + TC - 1), ostride, gp, k + r);
+            fir_mac<NCH, NOUT, TC>(acc, ca);
+          }
         } else {
           for (; r + TC <= run; r += TC) {
             fir_load<NCH, NOUT, TC>(ca, xr - (r + TC - 1), ostride, gp, k + r);
@@ -386,8 +424,7 @@ hipError_t chan_feed(const ChanFeedArgs &a, hipStream_t st)
   static const int force_smem = getenv("SUAMD_FIR_SMEM_TAPS") ? atoi(getenv("SUAMD_FIR_SMEM_TAPS")) : 0;   // tuning knobs
   static const int force_nout = getenv("SUAMD_FIR_NOUT") ? atoi(getenv("SUAMD_FIR_NOUT")) : 0;
   const bool lds_taps = !force_smem && (size_t)a.nchan * a.ntaps * sizeof(float4) <= 16 * 1024;
-  // (measured alternatives at C = D = 64, 114 us as is: 8 channels per lane 124 us -- 61 SGPRs spill;
-  // 2-tap chunks with the next chunk's scalar loads in flight 141 us)
+  // (measured alternative at C = D = 64: 8 channels per lane 124 us -- 61 SGPRs spill)
   const int nch = a.nchan >= 4 ? 4 : (a.nchan >= 2 ? 2 : 1);
   const int ngrp = (a.nchan + nch - 1) / nch;
   // outputs per lane: taps fetched once are reused for NOUT outputs (halves the scalar-cache tap
@@ -418,6 +455,10 @@ hipError_t chan_feed(const ChanFeedArgs &a, hipStream_t st)
     if (nch == 4) SD_FIR(4, 1, 2, true, true); if (nch == 2) SD_FIR(2, 1, 4, true, true); SD_FIR(1, 1, 8, true, true);
   }
   // taps from scalar loads: 4 channels x 4 taps = 64 SGPRs per chunk, so no second chunk in flight
+  // 4 channels x 2 taps = 32 SGPRs per chunk, two chunks in flight (ping-pong): 114.7 -> 109.1 us at C = D = 64,
+  // 51.7 -> 42.2 us at C = 16 against single chunks of 4 taps
+  static const int tc4 = getenv("SUAMD_FIR_TC4") ? atoi(getenv("SUAMD_FIR_TC4")) : 0;
+  if (!tc4 && nch == 4) { if (nout == 2) SD_FIR(4, 2, 2, false, true); SD_FIR(4, 1, 2, false, true); }
   if (nout == 2) { if (nch == 4) SD_FIR(4, 2, 4, false, false); if (nch == 2) SD_FIR(2, 2, 4, false, true); SD_FIR(1, 2, 8, false, true); }
   if (nch == 4) SD_FIR(4, 1, 4, false, false); if (nch == 2) SD_FIR(2, 1, 4, false, true); SD_FIR(1, 1, 8, false, true);
 #undef SD_FIR
