@@ -7,6 +7,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -139,6 +141,13 @@ void make_window(int type, std::vector<float> &w)
 // ==========================================================================================
 struct suamd_ctx {
   int device;
+  // descriptor tables of the gang launches: a ring of slots in device memory (a slot is reused 16 gang
+  // calls later; gang calls of one context are expected on one stream, or externally ordered)
+  static constexpr int GANG_SLOTS = 16;
+  static constexpr size_t GANG_SLOT_BYTES = 64 * 1024;
+  char *gang_ring = nullptr;
+  int gang_next = 0;
+  ~suamd_ctx() { if (gang_ring) (void)hipFree(gang_ring); }
 };
 
 struct suamd_psd {
@@ -189,6 +198,20 @@ struct suamd_agc_bank {
   sdk::AgcState  s;
   Scratch scratch;       // 2 x [len][nchan] floats: magnitudes in dB; their sliding maximum, then levels
 };
+
+template <typename Item>
+static Item *gang_upload(suamd_ctx *ctx, const std::vector<Item> &items, hipStream_t st)
+{
+  const size_t bytes = items.size() * sizeof(Item);
+  if (bytes > suamd_ctx::GANG_SLOT_BYTES) { set_err("gang too large (%zu items)", items.size()); return nullptr; }
+  if (!ctx->gang_ring && hipMalloc((void **)&ctx->gang_ring, suamd_ctx::GANG_SLOTS * suamd_ctx::GANG_SLOT_BYTES) != hipSuccess) {
+    set_err("device allocation failed"); return nullptr;
+  }
+  char *slot = ctx->gang_ring + (size_t)ctx->gang_next * suamd_ctx::GANG_SLOT_BYTES;
+  ctx->gang_next = (ctx->gang_next + 1) % suamd_ctx::GANG_SLOTS;
+  if (hipMemcpyAsync(slot, items.data(), bytes, hipMemcpyHostToDevice, st) != hipSuccess) { set_err("descriptor upload failed"); return nullptr; }
+  return reinterpret_cast<Item *>(slot);
+}
 
 extern "C" {
 
@@ -1072,6 +1095,84 @@ SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d_x, suamd_
   HIP_TRY(sdk::agc_feed(b->p, b->s, (int)b->nchan, d_x, as_view(xv), d_y, as_view(yv), (long long)len,
                         static_cast<float *>(b->scratch.p), as_stream(stream)), SU_FALSE);
   b->n_fed += len;
+  return SU_TRUE;
+}
+
+// ---- gangs: many 1-channel banks, each with its own parameters, side by side in one launch -----------
+SUBOOL suamd_costas_gang_feed(suamd_ctx_t *ctx, suamd_costas_bank_t *const *banks, unsigned n, const suamd_complex *const *d_x,
+                              suamd_complex *const *d_y, const SUSCOUNT *len, void *stream)
+{
+  if (!ctx || (n && (!banks || !d_x || !d_y || !len))) { set_err("null argument"); return SU_FALSE; }
+  hipStream_t st = as_stream(stream);
+  // one launch per (kind, order): the loop type is compiled in, everything else is per lane
+  std::map<int, std::vector<sdk::CostasGangItem>> groups;
+  for (unsigned i = 0; i < n; ++i) {
+    if (!banks[i] || banks[i]->nchan != 1) { set_err("gang members must be 1-channel banks"); return SU_FALSE; }
+    if (len[i] == 0) continue;
+    if (!d_x[i] || !d_y[i]) { set_err("null row"); return SU_FALSE; }
+    groups[banks[i]->p.kind * 8 + banks[i]->p.order].push_back(sdk::CostasGangItem{banks[i]->p, banks[i]->s, d_x[i], d_y[i], (long long)len[i]});
+  }
+  for (auto &kv : groups) {
+    for (size_t o = 0; o < kv.second.size(); o += 512) {                       // <= 512 items per descriptor slot
+      std::vector<sdk::CostasGangItem> part(kv.second.begin() + o, kv.second.begin() + std::min(kv.second.size(), o + 512));
+      sdk::CostasGangItem *d = gang_upload(ctx, part, st);
+      if (!d) return SU_FALSE;
+      HIP_TRY(sdk::costas_gang(d, (int)part.size(), kv.first / 8, kv.first % 8, st), SU_FALSE);
+    }
+  }
+  return SU_TRUE;
+}
+
+SUBOOL suamd_clock_gang_feed(suamd_ctx_t *ctx, suamd_clock_bank_t *const *banks, unsigned n, const suamd_complex *const *d_x,
+                             const SUSCOUNT *len, suamd_complex *const *d_sym, uint32_t *const *d_count, void *stream)
+{
+  if (!ctx || (n && (!banks || !d_x || !len || !d_sym || !d_count))) { set_err("null argument"); return SU_FALSE; }
+  hipStream_t st = as_stream(stream);
+  std::vector<sdk::ClockGangItem> items;
+  for (unsigned i = 0; i < n; ++i) {
+    if (!banks[i] || banks[i]->nchan != 1) { set_err("gang members must be 1-channel banks"); return SU_FALSE; }
+    if (len[i] == 0) continue;
+    if (!d_x[i] || !d_sym[i] || !d_count[i]) { set_err("null row"); return SU_FALSE; }
+    items.push_back(sdk::ClockGangItem{banks[i]->p, banks[i]->s, d_x[i], (long long)len[i], d_sym[i], d_count[i]});
+  }
+  for (size_t o = 0; o < items.size(); o += 512) {
+    std::vector<sdk::ClockGangItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
+    sdk::ClockGangItem *d = gang_upload(ctx, part, st);
+    if (!d) return SU_FALSE;
+    HIP_TRY(sdk::clock_gang(d, (int)part.size(), st), SU_FALSE);
+  }
+  return SU_TRUE;
+}
+
+SUBOOL suamd_agc_gang_feed(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n, const suamd_complex *const *d_x,
+                           suamd_complex *const *d_y, const SUSCOUNT *len, void *stream)
+{
+  if (!ctx || (n && (!banks || !d_x || !d_y || !len))) { set_err("null argument"); return SU_FALSE; }
+  hipStream_t st = as_stream(stream);
+  const suamd_view row = {0, 1};
+  std::vector<sdk::AgcGangItem> items;
+  for (unsigned i = 0; i < n; ++i) {
+    suamd_agc_bank *b = banks[i];
+    if (!b || b->nchan != 1) { set_err("gang members must be 1-channel banks"); return SU_FALSE; }
+    if (len[i] == 0) continue;
+    if (!d_x[i] || !d_y[i] || d_x[i] == d_y[i]) { set_err("null or aliased row"); return SU_FALSE; }
+    if (!b->scratch.reserve(2 * sizeof(float) * (size_t)len[i])) { set_err("scratch allocation failed"); return SU_FALSE; }
+    HIP_TRY(sdk::agc_feed_pre(b->p, b->s, 1, d_x[i], as_view(row), (long long)len[i], static_cast<float *>(b->scratch.p), st), SU_FALSE);
+    items.push_back(sdk::AgcGangItem{b->p, b->s, static_cast<float *>(b->scratch.p) + len[i], (long long)len[i]});
+  }
+  for (size_t o = 0; o < items.size(); o += 512) {                             // the level trackers of all banks, one lane each
+    std::vector<sdk::AgcGangItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
+    sdk::AgcGangItem *d = gang_upload(ctx, part, st);
+    if (!d) return SU_FALSE;
+    HIP_TRY(sdk::agc_level_gang(d, (int)part.size(), st), SU_FALSE);
+  }
+  for (unsigned i = 0; i < n; ++i) {
+    suamd_agc_bank *b = banks[i];
+    if (len[i] == 0) continue;
+    HIP_TRY(sdk::agc_feed_post(b->p, b->s, 1, d_x[i], as_view(row), d_y[i], as_view(row), (long long)len[i],
+                               static_cast<float *>(b->scratch.p), st), SU_FALSE);
+    b->n_fed += len[i];
+  }
   return SU_TRUE;
 }
 

@@ -81,6 +81,15 @@ struct ClockParams { float alpha, beta, gain, bmin, bmax; };
 hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, const void *x, View xv,
                       long long len, void *sym, long long sym_stride, uint32_t *count, hipStream_t st);
 
+// ---- gangs: many 1-channel banks with their OWN parameters, one lane each, in one launch -------------
+// (the live analyzer's inspectors differ in loop bandwidth, baud, decimation ... and cannot share a bank;
+// a gang runs their recurrences side by side like a bank does).  Rows are contiguous (unit time stride),
+// lengths may differ per item.  items: device array.
+struct CostasGangItem { CostasParams p; CostasState s; const void *x; void *y; long long len; };
+struct ClockGangItem { ClockParams p; ClockState s; const void *x; long long len; void *sym; uint32_t *count; };
+hipError_t costas_gang(const CostasGangItem *d_items, int n, int kind, int order, hipStream_t st);
+hipError_t clock_gang(const ClockGangItem *d_items, int n, hipStream_t st);
+
 struct AgcParams {
   float knee, gain_slope;
   float fast_alpha_rise, fast_alpha_fall, slow_alpha_rise, slow_alpha_fall;
@@ -96,6 +105,13 @@ struct AgcState {               // device
 // (parallel), state carry.  scratch: >= 2 * len * nchan floats.
 hipError_t agc_feed(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv,
                     void *y, View yv, long long len, float *scratch, hipStream_t st);
+// the same in three steps, so that the level trackers of many 1-channel banks can run as one gang
+hipError_t agc_feed_pre(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv, long long len,
+                        float *scratch, hipStream_t st);
+hipError_t agc_feed_post(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv, void *y, View yv,
+                         long long len, float *scratch, hipStream_t st);
+struct AgcGangItem { AgcParams p; AgcState s; float *peak; long long len; };
+hipError_t agc_level_gang(const AgcGangItem *d_items, int n, hipStream_t st);
 
 // ---- specview.hip ----
 struct SpecViewLinear {          // geometry of one frame, computed on the host in double precision

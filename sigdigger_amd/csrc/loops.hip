@@ -636,6 +636,129 @@ inline unsigned grid_for(long long n, int block) {
   return (unsigned)g;
 }
 
+// ---------------------------------------------------------------------------------------
+// Gangs: lane j runs item j -- a 1-channel bank with its own parameters, state, rows and length.
+// Rows are streamed 16 steps ahead per lane (each lane its own pointer; a chunk is 128 contiguous
+// bytes per lane); steps beyond a lane's length are skipped by predication.
+__device__ __forceinline__ long long wave_max(long long v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const long long w = __shfl_xor(v, o); v = w > v ? w : v; }
+  return v;
+}
+
+template <typename T, typename F>
+__device__ __forceinline__ void stream_ptr(const T *__restrict__ x, long long len, long long maxlen, F step)
+{
+  if (maxlen <= 0) return;
+  const long long last = len > 0 ? len - 1 : 0;
+  T cur[CHUNK], nxt[CHUNK];
+#pragma unroll
+  for (int j = 0; j < CHUNK; ++j) cur[j] = len > 0 ? x[j < len ? j : last] : T{};
+  for (long long i = 0; i < maxlen; i += CHUNK) {
+    if (i + CHUNK < maxlen) {
+#pragma unroll
+      for (int j = 0; j < CHUNK; ++j) { const long long m = i + CHUNK + j; nxt[j] = len > 0 ? x[m < len ? m : last] : T{}; }
+    }
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) if (i + j < len) step(i + j, cur[j]);
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) cur[j] = nxt[j];
+  }
+}
+
+template <int KIND, int ORDER>
+__global__ __launch_bounds__(64) void costas_gang_kernel(const sdk::CostasGangItem *__restrict__ items, int n)
+{
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const bool live = j < n;
+  const sdk::CostasGangItem it = items[live ? j : 0];
+  const sdk::CostasParams p = it.p;                           // per lane: every item its own loop
+  const sdk::CostasState s = it.s;
+  CostasRegs<ORDER> r;
+  r.phase = s.phase[0];
+  r.omega = s.omega[0];
+#pragma unroll
+  for (int i = 1; i <= ORDER; ++i) {
+    r.xh[i] = c32{s.xh[(i - 1) * 2 + 0], s.xh[(i - 1) * 2 + 1]};
+    r.yh[i] = c32{s.yh[(i - 1) * 2 + 0], s.yh[(i - 1) * 2 + 1]};
+  }
+  const long long len = live ? it.len : 0;
+  const long long maxlen = wave_max(len);
+  const float2 *x = reinterpret_cast<const float2 *>(it.x);
+  float2 *y = reinterpret_cast<float2 *>(it.y);
+  stream_ptr(x, len, maxlen, [&](long long m, float2 v) { y[m] = costas_step<KIND, ORDER, false>(p, r, v); });
+  if (!live) return;
+  s.phase[0] = r.phase;
+  s.omega[0] = r.omega;
+#pragma unroll
+  for (int i2 = 1; i2 <= ORDER; ++i2) {
+    s.xh[(i2 - 1) * 2 + 0] = r.xh[i2].re; s.xh[(i2 - 1) * 2 + 1] = r.xh[i2].im;
+    s.yh[(i2 - 1) * 2 + 0] = r.yh[i2].re; s.yh[(i2 - 1) * 2 + 1] = r.yh[i2].im;
+  }
+}
+
+__global__ __launch_bounds__(64) void clock_gang_kernel(const sdk::ClockGangItem *__restrict__ items, int n)
+{
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const bool live = j < n;
+  const sdk::ClockGangItem it = items[live ? j : 0];
+  const sdk::ClockParams p = it.p;
+  const sdk::ClockState s = it.s;
+  ClockRegs r;
+  r.phi = s.phi[0]; r.bnor = s.bnor[0];
+  r.halfcycle = s.halfcycle[0];
+  r.prev = float2{s.prev[0], s.prev[1]};
+  r.x0 = float2{s.x0[0], s.x0[1]};
+  r.x1 = float2{s.x1[0], s.x1[1]};
+  r.x2 = float2{s.x2[0], s.x2[1]};
+  r.n = it.count[0];
+  const long long len = live ? it.len : 0;
+  const long long maxlen = wave_max(len);
+  float2 *out = reinterpret_cast<float2 *>(it.sym);
+  stream_ptr(reinterpret_cast<const float2 *>(it.x), len, maxlen, [&](long long, float2 v) { clock_step(p, r, v, out); });
+  if (!live) return;
+  s.phi[0] = r.phi; s.bnor[0] = r.bnor; s.halfcycle[0] = r.halfcycle;
+  s.prev[0] = r.prev.x; s.prev[1] = r.prev.y;
+  s.x0[0] = r.x0.x; s.x0[1] = r.x0.y;
+  s.x1[0] = r.x1.x; s.x1[1] = r.x1.y;
+  s.x2[0] = r.x2.x; s.x2[1] = r.x2.y;
+  it.count[0] = r.n;
+}
+
+__global__ __launch_bounds__(64) void agc_level_gang_kernel(const sdk::AgcGangItem *__restrict__ items, int n)
+{
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const bool live = j < n;
+  const sdk::AgcGangItem it = items[live ? j : 0];
+  const sdk::AgcState s = it.s;
+  unsigned hang_n = s.hang_n[0];
+  float fast = s.fast_level[0], slow = s.slow_level[0];
+  const float far = it.p.fast_alpha_rise, faf = it.p.fast_alpha_fall, sar = it.p.slow_alpha_rise, saf = it.p.slow_alpha_fall;
+  const float knee = it.p.knee;
+  const unsigned hang_max = it.p.hang_max;
+  const long long len = live ? it.len : 0;
+  const long long maxlen = wave_max(len);
+  float *peak = it.peak;
+  stream_ptr(peak, len, maxlen, [&](long long m, float pk) {
+    float d = pk - fast;
+    const float fa = d > 0.0f ? far : faf;
+    fast = sd::fma_(fa, d, fast);
+    d = pk - slow;
+    const bool rise = d > 0.0f;
+    const bool fall = !rise && hang_n >= hang_max;
+    const float sa = rise ? sar : saf;
+    const float upd = sd::fma_(sa, d, slow);
+    slow = (rise || fall) ? upd : slow;
+    hang_n = rise ? 0u : (fall ? hang_n : hang_n + 1u);
+    float lvl = fast > slow ? fast : slow;
+    if (lvl < knee) lvl = knee;
+    peak[m] = lvl;
+  });
+  if (!live) return;
+  s.hang_n[0] = hang_n; s.fast_level[0] = fast; s.slow_level[0] = slow;
+}
+
 }  // namespace
 
 namespace sdk {
@@ -756,23 +879,72 @@ hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, cons
   return hipGetLastError();
 }
 
-hipError_t agc_feed(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv,
-                    void *y, View yv, long long len, float *scratch, hipStream_t st)
+hipError_t agc_feed_pre(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv, long long len,
+                        float *scratch, hipStream_t st)
 {
   if (len <= 0 || nchan <= 0) return hipSuccess;
   const float2 *xx = reinterpret_cast<const float2 *>(x);
-  float2 *yy = reinterpret_cast<float2 *>(y);
   const long long total = len * nchan;
   float *db = scratch, *peak = scratch + total;
   const int H = (int)p.mag_history_size;
   hipLaunchKernelGGL(agc_mag_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, xx, xv, nchan, len, db);
   hipLaunchKernelGGL(agc_peak_kernel, dim3((unsigned)((len + PEAK_TM - 1) / PEAK_TM), (unsigned)((nchan + 63) / 64)), dim3(256), 0, st,
                      db, s.mag_history, nchan, len, H, peak);
-  hipLaunchKernelGGL(agc_level_kernel, dim3((nchan + 63) / 64), dim3(64), 0, st, p, s, nchan, len, peak);
+  return hipGetLastError();
+}
+
+hipError_t agc_feed_post(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv, void *y, View yv,
+                         long long len, float *scratch, hipStream_t st)
+{
+  if (len <= 0 || nchan <= 0) return hipSuccess;
+  const float2 *xx = reinterpret_cast<const float2 *>(x);
+  float2 *yy = reinterpret_cast<float2 *>(y);
+  const long long total = len * nchan;
+  float *db = scratch, *peak = scratch + total;
   hipLaunchKernelGGL(agc_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, p, s.delay_line, nchan, xx, xv,
                      yy, yv, len, peak);
   hipLaunchKernelGGL(agc_state_kernel, dim3((nchan + 63) / 64), dim3(64), 0, st, s.delay_line, s.mag_history, nchan,
-                     (int)p.delay_line_size, H, xx, xv, db, len);
+                     (int)p.delay_line_size, (int)p.mag_history_size, xx, xv, db, len);
+  return hipGetLastError();
+}
+
+hipError_t agc_feed(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv,
+                    void *y, View yv, long long len, float *scratch, hipStream_t st)
+{
+  if (len <= 0 || nchan <= 0) return hipSuccess;
+  hipError_t e = agc_feed_pre(p, s, nchan, x, xv, len, scratch, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(agc_level_kernel, dim3((nchan + 63) / 64), dim3(64), 0, st, p, s, nchan, len, scratch + len * nchan);
+  return agc_feed_post(p, s, nchan, x, xv, y, yv, len, scratch, st);
+}
+
+hipError_t agc_level_gang(const AgcGangItem *d_items, int n, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(agc_level_gang_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_items, n);
+  return hipGetLastError();
+}
+
+hipError_t clock_gang(const ClockGangItem *d_items, int n, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(clock_gang_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_items, n);
+  return hipGetLastError();
+}
+
+hipError_t costas_gang(const CostasGangItem *d_items, int n, int kind, int order, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  const dim3 grid((n + 63) / 64), block(64);
+#define SD_GANG_CASE(K, O) case (K) * 8 + (O): hipLaunchKernelGGL((costas_gang_kernel<K, O>), grid, block, 0, st, d_items, n); break;
+  if (order < 0 || order > 4 || kind < 1 || kind > 3) return hipErrorInvalidValue;
+  switch (kind * 8 + order) {
+    SD_GANG_CASE(1, 0) SD_GANG_CASE(1, 1) SD_GANG_CASE(1, 2) SD_GANG_CASE(1, 3) SD_GANG_CASE(1, 4)
+    SD_GANG_CASE(2, 0) SD_GANG_CASE(2, 1) SD_GANG_CASE(2, 2) SD_GANG_CASE(2, 3) SD_GANG_CASE(2, 4)
+    SD_GANG_CASE(3, 0) SD_GANG_CASE(3, 1) SD_GANG_CASE(3, 2) SD_GANG_CASE(3, 3) SD_GANG_CASE(3, 4)
+    default: return hipErrorInvalidValue;
+  }
+#undef SD_GANG_CASE
   return hipGetLastError();
 }
 

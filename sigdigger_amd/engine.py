@@ -441,6 +441,33 @@ class FAC(_LoopBank):
         return mn.value, mx.value
 
 
+def _ptr_array(ptrs):
+    return (C.c_void_p * len(ptrs))(*ptrs)
+
+
+def gang_costas(ctx, banks, xs, ys, stream=None):
+    """banks: 1-channel CostasBanks; xs / ys: contiguous 1-D complex64 rows (own length each)."""
+    n = len(banks)
+    lens = (C.c_uint64 * n)(*[x.numel() for x in xs])
+    check(ctx.lib.suamd_costas_gang_feed(ctx.h, _ptr_array([b.h for b in banks]), n, _ptr_array([_ptr(x) for x in xs]),
+                                         _ptr_array([_ptr(y) for y in ys]), lens, _stream(stream)), "suamd_costas_gang_feed")
+
+
+def gang_agc(ctx, banks, xs, ys, stream=None):
+    n = len(banks)
+    lens = (C.c_uint64 * n)(*[x.numel() for x in xs])
+    check(ctx.lib.suamd_agc_gang_feed(ctx.h, _ptr_array([b.h for b in banks]), n, _ptr_array([_ptr(x) for x in xs]),
+                                      _ptr_array([_ptr(y) for y in ys]), lens, _stream(stream)), "suamd_agc_gang_feed")
+
+
+def gang_clock(ctx, banks, xs, syms, counts, stream=None):
+    n = len(banks)
+    lens = (C.c_uint64 * n)(*[x.numel() for x in xs])
+    check(ctx.lib.suamd_clock_gang_feed(ctx.h, _ptr_array([b.h for b in banks]), n, _ptr_array([_ptr(x) for x in xs]), lens,
+                                        _ptr_array([_ptr(s) for s in syms]), _ptr_array([_ptr(c) for c in counts]),
+                                        _stream(stream)), "suamd_clock_gang_feed")
+
+
 class SNREstimator(_LoopBank):
     """SigDigger::SNREstimator (Misc/SNREstimator.cpp) on the device."""
     _destroy = "suamd_snr_estimator_destroy"

@@ -78,6 +78,9 @@ PROTOTYPES = {
     "suamd_fac_feed": (INT, [VP, VP, U64, C.c_int64, C.c_int64, VP]),
     "suamd_fac_array": (VP, [VP]),
     "suamd_fac_get_range": (INT, [VP, VP, VP, VP]),
+    "suamd_costas_gang_feed": (INT, [VP, VP, UINT, VP, VP, VP, VP]),
+    "suamd_agc_gang_feed": (INT, [VP, VP, UINT, VP, VP, VP, VP]),
+    "suamd_clock_gang_feed": (INT, [VP, VP, UINT, VP, VP, VP, VP, VP]),
     "suamd_rows_scale": (INT, [VP, VP, View, VP, View, UINT, U64, F32, VP]),
     "suamd_nco_bank_new": (VP, [VP, UINT, VP]),
     "suamd_nco_bank_destroy": (None, [VP]),

@@ -618,6 +618,50 @@ def test_conj_prev_and_gardner_frequency_space(ctx, sdo):
 
 
 # ------------------------------------------------------------------------------------------
+# gangs: heterogeneous 1-channel banks side by side -- bit exact against each bank's own oracle
+# ------------------------------------------------------------------------------------------
+def test_gangs_of_heterogeneous_banks_bit_exact(ctx, sdo):
+    rng = np.random.default_rng(42)
+    n = 70                                                   # more than one wavefront of items
+    lens = rng.integers(0, 5000, n)
+    lens[:4] = [0, 1, 17, 4999]
+    kinds = rng.integers(1, 4, n)
+    arm = rng.integers(1, 6, n)                              # arm filter orders 0..4: several loop types
+    lbw = rng.uniform(0.002, 0.02, n)
+    sps = rng.choice([4, 8, 16], n)
+    xs_h = [synth.psk_carriers(max(int(L_), 1), [0.002 * (i % 7 - 3)], sps=int(sps[i]), order=int(2 ** kinds[i]), seed=100 + i)[:int(L_)]
+            for i, L_ in enumerate(lens)]
+    # two rounds: state (and the AGC's history / delay line) carries across gang calls
+    cuts = [(0, int(L_) // 3) for L_ in lens], [(int(L_) // 3, int(L_)) for L_ in lens]
+    agc = [engine.AGCBank(ctx, 1, tau=float(sps[i])) for i in range(n)]
+    cos = [engine.CostasBank(ctx, 1, int(kinds[i]), 0.0, 2.0 / sps[i], int(arm[i]), float(lbw[i])) for i in range(n)]
+    clk = [engine.ClockBank(ctx, 1, 0.2, 1.0 / sps[i]) for i in range(n)]
+    syms = [torch.zeros(int(L_) + 2, dtype=torch.complex64, device="cuda") for L_ in lens]
+    cnts = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(n)]
+    outs = [[] for _ in range(n)]
+    for rnd in cuts:
+        xs = [dev(xs_h[i][a:b]) if b > a else torch.empty(0, dtype=torch.complex64, device="cuda") for i, (a, b) in enumerate(rnd)]
+        ya = [torch.empty_like(x) for x in xs]
+        yz = [torch.empty_like(x) for x in xs]
+        engine.gang_agc(ctx, agc, xs, ya)
+        engine.gang_costas(ctx, cos, ya, yz)
+        engine.gang_clock(ctx, clk, yz, syms, cnts)
+        for i in range(n):
+            outs[i].append(host(yz[i]))
+    for i in range(n):
+        a = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(float(sps[i]))), xs_h[i]) if lens[i] else np.zeros(0, np.complex64)
+        st = sdo.costas_new(int(kinds[i]), 0.0, 2.0 / sps[i], int(arm[i]), float(lbw[i]))
+        z = sdo.costas_feed_bulk(st, a) if lens[i] else a
+        assert_bits(np.concatenate(outs[i]), z, f"gang item {i}: costas output")
+        om, ph = cos[i].state()
+        assert ph[0] == st.phase and np.float32(st.omega) == om[0]
+        ref = sdo.clock_feed_bulk(sdo.clock_new(0.2, 1.0 / sps[i]), z) if lens[i] else z
+        k = int(cnts[i].cpu()[0])
+        assert k == ref.size, f"gang item {i}: symbol count"
+        assert_bits(host(syms[i][:k]), ref, f"gang item {i}: symbols")
+
+
+# ------------------------------------------------------------------------------------------
 # A7: stages behind the rest of the inspector config vocabulary -- bit exact
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("layout", ["cm", "tm"])
