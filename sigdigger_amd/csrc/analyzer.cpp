@@ -254,6 +254,12 @@ struct Source {
   }
   size_t bytes_per_sample() const { return cfg.type == "tonegen" ? 8 : suamd_format_bytes_per_sample(raw_format); }
 
+  // the worker reads one block ahead while the GPU works; when a request changes the block size the
+  // prefetched block is pushed back
+  long mark_pos = 0; uint64_t mark_n = 0; uint32_t mark_lcg = 0;
+  void mark() { mark_pos = fp ? std::ftell(fp) : 0; mark_n = n; mark_lcg = lcg; }
+  void rewind_to_mark() { if (fp) std::fseek(fp, mark_pos, SEEK_SET); n = mark_n; lcg = mark_lcg; }
+
   // fills dst with `want` samples in the payload format (bytes_per_sample() each); returns the
   // samples read (< want only at end of stream)
   size_t read(void *dst, size_t want, bool *looped)
@@ -318,9 +324,8 @@ struct Inspector {
   suamd_complex *d_spre = nullptr;            // transformed samples
   float *d_spec = nullptr;
   suamd_complex spect_prev = {0, 0};          // last channel sample of the previous block
-  // every inspector enqueues its whole chain on one of the analyzer's inspector streams and is
-  // collected after all of them were enqueued: the one-wavefront recurrence kernels of different
-  // inspectors overlap instead of queueing behind each other
+  // all inspectors work on the analyzer's inspector stream, stage by stage (enqueue_inspectors); results
+  // land in pinned memory and become messages after one synchronisation (collect_inspectors)
   hipStream_t stream = nullptr;
   struct Pinned { uint32_t count; suamd_complex prev; float spec[8192]; } *pin = nullptr;   // D2H landing zone
   SUSCOUNT pend_m = 0;                        // channel samples of the block in flight
@@ -397,7 +402,7 @@ struct suscan_analyzer {
   suamd_psd_t *psd = nullptr;
   std::map<SUHANDLE, std::unique_ptr<Inspector>> inspectors;
   hipStream_t stream = nullptr;
-  static constexpr int NISTREAMS = 8;
+  static constexpr int NISTREAMS = 1;
   hipStream_t istream[NISTREAMS] = {};
   hipEvent_t ev_input = nullptr;              // the block is in d_x
   suamd_complex *h_x = nullptr, *d_x = nullptr;
@@ -454,7 +459,7 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
     if (!ok) { err = "device allocation failed"; return false; }
     in.cap = need;
   }
-  if (!in.stream) in.stream = a->istream[(unsigned)in.handle % suscan_analyzer::NISTREAMS];
+  if (!in.stream) in.stream = a->istream[0];
   if (!in.pin && hipHostMalloc((void **)&in.pin, sizeof(Inspector::Pinned), hipHostMallocDefault) != hipSuccess) {
     err = "pinned allocation failed"; return false;
   }
@@ -558,84 +563,130 @@ void enqueue_spectrum(suscan_analyzer *a, Inspector &in, SUSCOUNT m)
   in.pend_spec_n = n;
 }
 
-// phase A: the inspector's whole chain for this block, asynchronously on its own stream
-void enqueue_inspector(suscan_analyzer *a, Inspector &in, size_t len)
+// One block through every open inspector, stage by stage on the analyzer's inspector stream.  The
+// per-inspector kernels (channel FIR, spectrum, the parallel parts of the AGC, matched filter) are short
+// and queue back to back; the serial recurrences -- AGC level trackers, Costas loops, Gardner detectors --
+// of ALL inspectors run as gangs (one lane per inspector, its own parameters and length), so their cost is
+// that of one inspector, not the sum.  Results are bit-identical to running every chain on its own.
+void enqueue_inspectors(suscan_analyzer *a, size_t len)
 {
-  in.pend_samples = in.pend_spectrum = in.pend_symbols = false;
-  if (in.dirty) {
-    std::string err;
-    if (!build_chain(a, in, err)) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, err); return; }
-    in.dirty = false;
-  }
-  hipStream_t st = in.stream;
+  hipStream_t st = a->istream[0];
   (void)hipStreamWaitEvent(st, a->ev_input, 0);
-  const suamd_view row = {(SUSCOUNT)in.cap, 1};
-  SUSCOUNT m = 0;
-  if (!suamd_chanbank_feed(in.bank, a->d_x, len, in.d_y, row, &m, st)) return;
-  in.pend_m = m;
-  if (in.spectsrc_id) enqueue_spectrum(a, in, m);
-  // ping-pong through d_a / d_z so that no stage runs in place
-  const suamd_complex *cur = in.d_y;
-  auto other = [&](const suamd_complex *p) { return p == in.d_a ? in.d_z : in.d_a; };
-  if (in.agc) { suamd_agc_bank_feed(in.agc, cur, row, in.d_a, row, m, st); cur = in.d_a; }
-  else if (in.fixed_gain > 0) { suamd_rows_scale(a->ctx, cur, row, in.d_a, row, 1, m, in.fixed_gain, st); cur = in.d_a; }
-  if (in.costas) {
-    suamd_complex *o = other(cur);
-    suamd_costas_bank_feed(in.costas, cur, row, o, row, m, st);
-    cur = o;
-  } else if (in.nco) {
-    suamd_complex *o = other(cur);
-    suamd_nco_bank_feed(in.nco, cur, row, o, row, m, st);
-    cur = o;
-  } else if (in.pll) {
-    suamd_complex *o = other(cur);
-    suamd_pll_bank_feed(in.pll, cur, row, o, row, m, st);
-    cur = o;
-  } else if (in.quad) {
-    suamd_complex *o = other(cur);
-    suamd_quad_demod_batch(a->ctx, cur, row, o, row, 1, m, in.d_prev, in.first ? SU_TRUE : SU_FALSE, in.d_sym /*tmp*/, st);
-    (void)hipMemcpyAsync(in.d_prev, in.d_sym, 8, hipMemcpyDeviceToDevice, st);
-    in.first = false;
-    cur = o;
+  std::vector<Inspector *> live;
+  for (auto &kv : a->inspectors) {
+    Inspector &in = *kv.second;
+    in.pend_samples = in.pend_spectrum = in.pend_symbols = false;
+    in.stream = st;
+    if (in.dirty) {
+      std::string err;
+      if (!build_chain(a, in, err)) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, err); continue; }
+      in.dirty = false;
+    }
+    const suamd_view row = {(SUSCOUNT)in.cap, 1};
+    SUSCOUNT m = 0;
+    if (!suamd_chanbank_feed(in.bank, a->d_x, len, in.d_y, row, &m, st)) continue;
+    in.pend_m = m;
+    in.pend_src = in.d_y;
+    if (in.spectsrc_id) enqueue_spectrum(a, in, m);
+    live.push_back(&in);
   }
-  if (in.mf) {
-    suamd_complex *o = other(cur);
-    suamd_fir_bank_feed(in.mf, cur, row, o, row, m, st);
-    cur = o;
+  auto other = [](Inspector &in) { return in.pend_src == in.d_a ? in.d_z : in.d_a; };   // ping-pong: no stage in place
+  // ---- gain control ----
+  {
+    std::vector<suamd_agc_bank_t *> banks; std::vector<const suamd_complex *> xs; std::vector<suamd_complex *> ys; std::vector<SUSCOUNT> ls;
+    for (Inspector *pi : live) {
+      Inspector &in = *pi;
+      const suamd_view row = {(SUSCOUNT)in.cap, 1};
+      if (in.agc) { banks.push_back(in.agc); xs.push_back(in.pend_src); ys.push_back(in.d_a); ls.push_back(in.pend_m); in.pend_src = in.d_a; }
+      else if (in.fixed_gain > 0) { suamd_rows_scale(a->ctx, in.pend_src, row, in.d_a, row, 1, in.pend_m, in.fixed_gain, st); in.pend_src = in.d_a; }
+    }
+    if (!banks.empty()) suamd_agc_gang_feed(a->ctx, banks.data(), (unsigned)banks.size(), xs.data(), ys.data(), ls.data(), st);
   }
-  if (in.clock) {
-    (void)hipMemsetAsync(in.d_count, 0, 4, st);
-    suamd_clock_bank_feed(in.clock, cur, row, m, in.d_sym, (SUSCOUNT)in.cap, in.d_count, st);
-    // the equalizer takes its symbol count from the device: no host round trip inside the chain
-    if (in.cma) suamd_cma_bank_feed(in.cma, in.d_sym, (SUSCOUNT)in.cap, in.d_count, 0, in.d_sym, (SUSCOUNT)in.cap, st);
-    (void)hipMemcpyAsync(&in.pin->count, in.d_count, 4, hipMemcpyDeviceToHost, st);
-    in.pend_symbols = true;
-  } else {
-    in.pend_samples = true;
-    in.pend_src = cur;
+  // ---- carrier control ----
+  {
+    std::vector<suamd_costas_bank_t *> banks; std::vector<const suamd_complex *> xs; std::vector<suamd_complex *> ys; std::vector<SUSCOUNT> ls;
+    for (Inspector *pi : live) {
+      Inspector &in = *pi;
+      const suamd_view row = {(SUSCOUNT)in.cap, 1};
+      const SUSCOUNT m = in.pend_m;
+      if (in.costas) {
+        suamd_complex *o = other(in);
+        banks.push_back(in.costas); xs.push_back(in.pend_src); ys.push_back(o); ls.push_back(m);
+        in.pend_src = o;
+      } else if (in.nco) {
+        suamd_complex *o = other(in);
+        suamd_nco_bank_feed(in.nco, in.pend_src, row, o, row, m, st);
+        in.pend_src = o;
+      } else if (in.pll) {
+        suamd_complex *o = other(in);
+        suamd_pll_bank_feed(in.pll, in.pend_src, row, o, row, m, st);
+        in.pend_src = o;
+      } else if (in.quad) {
+        suamd_complex *o = other(in);
+        suamd_quad_demod_batch(a->ctx, in.pend_src, row, o, row, 1, m, in.d_prev, in.first ? SU_TRUE : SU_FALSE, in.d_sym /*tmp*/, st);
+        (void)hipMemcpyAsync(in.d_prev, in.d_sym, 8, hipMemcpyDeviceToDevice, st);
+        in.first = false;
+        in.pend_src = o;
+      }
+    }
+    if (!banks.empty()) suamd_costas_gang_feed(a->ctx, banks.data(), (unsigned)banks.size(), xs.data(), ys.data(), ls.data(), st);
+  }
+  // ---- matched filter ----
+  for (Inspector *pi : live) {
+    Inspector &in = *pi;
+    if (!in.mf) continue;
+    const suamd_view row = {(SUSCOUNT)in.cap, 1};
+    suamd_complex *o = other(in);
+    suamd_fir_bank_feed(in.mf, in.pend_src, row, o, row, in.pend_m, st);
+    in.pend_src = o;
+  }
+  // ---- clock recovery, equalizer ----
+  {
+    std::vector<suamd_clock_bank_t *> banks; std::vector<const suamd_complex *> xs; std::vector<SUSCOUNT> ls;
+    std::vector<suamd_complex *> syms; std::vector<uint32_t *> cnts;
+    for (Inspector *pi : live) {
+      Inspector &in = *pi;
+      if (!in.clock) { in.pend_samples = true; continue; }
+      (void)hipMemsetAsync(in.d_count, 0, 4, st);
+      banks.push_back(in.clock); xs.push_back(in.pend_src); ls.push_back(in.pend_m); syms.push_back(in.d_sym); cnts.push_back(in.d_count);
+      in.pend_symbols = true;
+    }
+    if (!banks.empty()) suamd_clock_gang_feed(a->ctx, banks.data(), (unsigned)banks.size(), xs.data(), ls.data(), syms.data(), cnts.data(), st);
+    for (Inspector *pi : live) {
+      Inspector &in = *pi;
+      if (!in.pend_symbols) continue;
+      // the equalizer takes its symbol count from the device: no host round trip inside the chain
+      if (in.cma) suamd_cma_bank_feed(in.cma, in.d_sym, (SUSCOUNT)in.cap, in.d_count, 0, in.d_sym, (SUSCOUNT)in.cap, st);
+      (void)hipMemcpyAsync(&in.pin->count, in.d_count, 4, hipMemcpyDeviceToHost, st);
+    }
   }
 }
 
-// phase B: wait for the inspector's stream and turn its results into messages
-void collect_inspector(suscan_analyzer *a, Inspector &in)
+// after the PSD message went out: wait for the inspector stream once and turn the results into messages
+void collect_inspectors(suscan_analyzer *a)
 {
-  if (!in.stream || !(in.pend_samples || in.pend_spectrum || in.pend_symbols)) return;
-  (void)hipStreamSynchronize(in.stream);
-  if (in.pend_spectrum) {
-    in.spect_prev = in.pin->prev;
-    auto *msg = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SPECTRUM, 0);
-    msg->handle = in.handle;
-    msg->inspector_id = in.inspector_id;
-    msg->spectsrc_id = in.spectsrc_id;
-    msg->spectrum_size = in.pend_spec_n;
-    msg->samp_rate = (SUSCOUNT)in.equiv_fs;
-    msg->spectrum_data = static_cast<SUFLOAT *>(std::malloc(in.pend_spec_n * sizeof(SUFLOAT)));
-    std::memcpy(msg->spectrum_data, in.pin->spec, in.pend_spec_n * sizeof(float));
-    push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, msg);
+  bool any = false;
+  for (auto &kv : a->inspectors) any = any || kv.second->pend_samples || kv.second->pend_spectrum || kv.second->pend_symbols;
+  if (!any) return;
+  (void)hipStreamSynchronize(a->istream[0]);
+  for (auto &kv : a->inspectors) {
+    Inspector &in = *kv.second;
+    if (in.pend_spectrum) {
+      in.spect_prev = in.pin->prev;
+      auto *msg = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SPECTRUM, 0);
+      msg->handle = in.handle;
+      msg->inspector_id = in.inspector_id;
+      msg->spectsrc_id = in.spectsrc_id;
+      msg->spectrum_size = in.pend_spec_n;
+      msg->samp_rate = (SUSCOUNT)in.equiv_fs;
+      msg->spectrum_data = static_cast<SUFLOAT *>(std::malloc(in.pend_spec_n * sizeof(SUFLOAT)));
+      std::memcpy(msg->spectrum_data, in.pin->spec, in.pend_spec_n * sizeof(float));
+      push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, msg);
+    }
+    if (in.pend_symbols) emit_samples(a, in, in.d_sym, in.pin->count);
+    else if (in.pend_samples) emit_samples(a, in, in.pend_src, in.pend_m);
+    in.pend_samples = in.pend_spectrum = in.pend_symbols = false;
   }
-  if (in.pend_symbols) emit_samples(a, in, in.d_sym, in.pin->count);
-  else if (in.pend_samples) emit_samples(a, in, in.pend_src, in.pend_m);
-  in.pend_samples = in.pend_spectrum = in.pend_symbols = false;
 }
 
 void handle_request(suscan_analyzer *a, Request &r)
@@ -777,7 +828,7 @@ bool setup_psd(suscan_analyzer *a, std::string &err)
     if (a->d_raw) (void)hipFree(a->d_raw);
     if (a->d_psd) (void)hipFree(a->d_psd);
     a->h_x = nullptr; a->d_x = nullptr; a->d_raw = nullptr; a->d_psd = nullptr;
-    if (hipHostMalloc((void **)&a->h_x, block * sizeof(suamd_complex), hipHostMallocDefault) != hipSuccess ||
+    if (hipHostMalloc((void **)&a->h_x, 2 * block * sizeof(suamd_complex), hipHostMallocDefault) != hipSuccess ||   // two halves
         hipMalloc((void **)&a->d_x, block * sizeof(suamd_complex)) != hipSuccess ||
         hipMalloc(&a->d_raw, block * 4) != hipSuccess ||
         hipMalloc((void **)&a->d_psd, n * sizeof(float)) != hipSuccess) {
@@ -823,6 +874,10 @@ void worker_main(suscan_analyzer *a)
   auto t_prev = std::chrono::steady_clock::now();
   const auto t_start = t_prev;
   uint64_t consumed = 0;
+  // double-buffered reading: block k+1 is read from the source while the GPU works on block k
+  bool have_next = false, looped_next = false;
+  size_t got_next = 0;
+  int cur = 0;
   while (!a->halt) {
     // ---- requests posted by the GUI thread ----
     for (;;) {
@@ -840,6 +895,7 @@ void worker_main(suscan_analyzer *a)
       if (r.kind == Request::SET_PARAMS && (old_n != a->params.detector_params.window_size ||
                                            old_w != a->params.detector_params.window ||
                                            old_i != a->params.psd_update_int)) {
+        if (have_next) { src.rewind_to_mark(); have_next = false; }        // it was read with the old block size
         if (!setup_psd(a, err)) {
           push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, err);
           a->halt = true;
@@ -848,16 +904,19 @@ void worker_main(suscan_analyzer *a)
     }
     if (a->halt) break;
     // ---- one block ----
-    bool looped = false;
-    const size_t got = src.read(a->h_x, a->block, &looped);
+    bool looped = looped_next;
+    suamd_complex *h_cur = a->h_x + (size_t)cur * a->block;
+    if (!have_next) { looped = false; src.mark(); got_next = src.read(h_cur, a->block, &looped); }
+    have_next = false;
+    const size_t got = got_next;
     if (got < a->block) {                                  // a partial last block is dropped, as a
       push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_EOS, 0, "end of stream");   // whole PSD frame set is needed
       break;
     }
     if (src.bytes_per_sample() == sizeof(suamd_complex)) {
-      (void)hipMemcpyAsync(a->d_x, a->h_x, a->block * sizeof(suamd_complex), hipMemcpyHostToDevice, a->stream);
+      (void)hipMemcpyAsync(a->d_x, h_cur, a->block * sizeof(suamd_complex), hipMemcpyHostToDevice, a->stream);
     } else {                                               // 2-4 B/sample over PCIe, expanded on the GPU
-      (void)hipMemcpyAsync(a->d_raw, a->h_x, a->block * src.bytes_per_sample(), hipMemcpyHostToDevice, a->stream);
+      (void)hipMemcpyAsync(a->d_raw, h_cur, a->block * src.bytes_per_sample(), hipMemcpyHostToDevice, a->stream);
       if (!suamd_ingest_iq(a->ctx, src.raw_format, a->d_raw, a->block, a->d_x, a->stream)) {
         push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, suamd_last_error());
         break;
@@ -865,7 +924,7 @@ void worker_main(suscan_analyzer *a)
     }
     (void)hipEventRecord(a->ev_input, a->stream);
     // the inspectors' chains start as soon as the block is on the device, next to the PSD
-    for (auto &kv : a->inspectors) enqueue_inspector(a, *kv.second, a->block);
+    enqueue_inspectors(a, a->block);
     const unsigned n = (unsigned)a->params.detector_params.window_size;
     if (!suamd_psd_feed(a->psd, a->d_x, a->navg, n, a->navg, 1.0f / (float)n, SUAMD_PSD_LINEAR, a->d_psd, a->stream)) {
       push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, suamd_last_error());
@@ -876,6 +935,12 @@ void worker_main(suscan_analyzer *a)
       m->psd_size = n;
       m->psd_data = static_cast<SUFLOAT *>(std::malloc(n * sizeof(SUFLOAT)));
       (void)hipMemcpyAsync(m->psd_data, a->d_psd, n * sizeof(float), hipMemcpyDeviceToHost, a->stream);
+      // the next block comes off the source while the GPU is busy with this one
+      cur ^= 1;
+      looped_next = false;
+      src.mark();
+      got_next = src.read(a->h_x + (size_t)cur * a->block, a->block, &looped_next);
+      have_next = true;
       (void)hipStreamSynchronize(a->stream);
       m->fc = (int64_t)a->source_cfg.freq;
       m->samp_rate = (SUFLOAT)a->source_cfg.samp_rate;
@@ -887,7 +952,7 @@ void worker_main(suscan_analyzer *a)
       m->timestamp.tv_usec = (suseconds_t)((ts - std::floor(ts)) * 1e6);
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_PSD, m);
     }
-    for (auto &kv : a->inspectors) collect_inspector(a, *kv.second);
+    collect_inspectors(a);
     consumed += a->block;
     // ---- rate bookkeeping / throttle ----
     auto now = std::chrono::steady_clock::now();

@@ -147,7 +147,27 @@ struct suamd_ctx {
   static constexpr size_t GANG_SLOT_BYTES = 64 * 1024;
   char *gang_ring = nullptr;
   int gang_next = 0;
-  ~suamd_ctx() { if (gang_ring) (void)hipFree(gang_ring); }
+  // loop types of one gang call are independent: they fork onto side streams and join back
+  static constexpr int GANG_SIDE = 4;
+  hipStream_t side[GANG_SIDE] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[GANG_SIDE] = {};
+  bool side_ready = false;
+  bool init_side()
+  {
+    if (side_ready) return true;
+    if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return false;
+    for (int i = 0; i < GANG_SIDE; ++i)
+      if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess) return false;
+    side_ready = true;
+    return true;
+  }
+  ~suamd_ctx()
+  {
+    if (gang_ring) (void)hipFree(gang_ring);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    for (int i = 0; i < GANG_SIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
+  }
 };
 
 struct suamd_psd {
@@ -1112,13 +1132,30 @@ SUBOOL suamd_costas_gang_feed(suamd_ctx_t *ctx, suamd_costas_bank_t *const *bank
     if (!d_x[i] || !d_y[i]) { set_err("null row"); return SU_FALSE; }
     groups[banks[i]->p.kind * 8 + banks[i]->p.order].push_back(sdk::CostasGangItem{banks[i]->p, banks[i]->s, d_x[i], d_y[i], (long long)len[i]});
   }
+  // the first loop type runs on the caller's stream, the others fork onto side streams (they are independent
+  // single-wavefront kernels and would otherwise queue behind each other) and join back
+  const bool fork = groups.size() > 1 && ctx->init_side();
+  if (fork) HIP_TRY(hipEventRecord(ctx->ev_fork, st), SU_FALSE);
+  int gi = 0;
+  std::vector<int> used;
   for (auto &kv : groups) {
+    hipStream_t gs = st;
+    if (fork && gi > 0) {
+      const int sidx = (gi - 1) % suamd_ctx::GANG_SIDE;
+      gs = ctx->side[sidx];
+      if (std::find(used.begin(), used.end(), sidx) == used.end()) { HIP_TRY(hipStreamWaitEvent(gs, ctx->ev_fork, 0), SU_FALSE); used.push_back(sidx); }
+    }
     for (size_t o = 0; o < kv.second.size(); o += 512) {                       // <= 512 items per descriptor slot
       std::vector<sdk::CostasGangItem> part(kv.second.begin() + o, kv.second.begin() + std::min(kv.second.size(), o + 512));
-      sdk::CostasGangItem *d = gang_upload(ctx, part, st);
+      sdk::CostasGangItem *d = gang_upload(ctx, part, gs);
       if (!d) return SU_FALSE;
-      HIP_TRY(sdk::costas_gang(d, (int)part.size(), kv.first / 8, kv.first % 8, st), SU_FALSE);
+      HIP_TRY(sdk::costas_gang(d, (int)part.size(), kv.first / 8, kv.first % 8, gs), SU_FALSE);
     }
+    ++gi;
+  }
+  for (int sidx : used) {
+    HIP_TRY(hipEventRecord(ctx->ev_join[sidx], ctx->side[sidx]), SU_FALSE);
+    HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join[sidx], 0), SU_FALSE);
   }
   return SU_TRUE;
 }
