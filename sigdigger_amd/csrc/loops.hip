@@ -666,7 +666,7 @@ __device__ __forceinline__ void gang_stream(GangLds<T> &lds, const T *__restrict
   const int lane = threadIdx.x;
   const long long maxlen = wave_max(len);
   if (maxlen <= 0) return;
-  const long long minlen = -wave_max(-len);
+  const long long minlen = -wave_max(len > 0 ? -len : -(1ll << 62));      // shortest non-empty row
   // a tile is GT = 32 samples: the 64 lanes cover two rows per access (lane >> 5 picks the row of the pair).
   // The rows a lane touches (2k + half, k < 32) never change: their pointers and lengths are fetched once,
   // through LDS, into registers -- a single wavefront owns the SIMD's whole register file.
@@ -699,10 +699,12 @@ __device__ __forceinline__ void gang_stream(GangLds<T> &lds, const T *__restrict
 #pragma unroll
       for (int j = 0; j < CHUNK; ++j) vin[j] = lds.in[(g + j) * GP + lane];
       if (s0 + g + CHUNK <= minlen) {
+        if (len > 0) {                                        // empty rows (and lanes without an item) sit the group out
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j) {
-          if constexpr (HAS_OUT) vout[j] = step(s0 + g + j, vin[j]);
-          else step(s0 + g + j, vin[j]);
+          for (int j = 0; j < CHUNK; ++j) {
+            if constexpr (HAS_OUT) vout[j] = step(s0 + g + j, vin[j]);
+            else step(s0 + g + j, vin[j]);
+          }
         }
       } else {
 #pragma unroll
