@@ -540,6 +540,23 @@ __global__ __launch_bounds__(256) void agc_peak_kernel(const float *__restrict__
   }
 }
 
+// single-channel banks (the live analyzer's inspectors): threads along time, each output scans its own H
+// magnitudes (coalesced across the threads; the maximum does not depend on the order)
+__global__ __launch_bounds__(256) void agc_peak1_kernel(const float *__restrict__ db, const float *__restrict__ hist,
+                                                        long long len, int H, float *__restrict__ peak)
+{
+  __builtin_amdgcn_s_setprio(3);
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= len) return;
+  float pk = db[m];
+  for (int i = 1; i < H; ++i) {
+    const long long q = m - i;
+    const float v = q >= 0 ? db[q] : hist[q + (H - 1)];
+    pk = pk > v ? pk : v;
+  }
+  peak[m] = pk;
+}
+
 __global__ __launch_bounds__(64) void agc_level_kernel(sdk::AgcParams p, sdk::AgcState s, int nchan,
                                                        long long len, float *__restrict__ peak)
 {
@@ -949,8 +966,11 @@ hipError_t agc_feed_pre(const AgcParams &p, const AgcState &s, int nchan, const 
   float *db = scratch, *peak = scratch + total;
   const int H = (int)p.mag_history_size;
   hipLaunchKernelGGL(agc_mag_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, xx, xv, nchan, len, db);
-  hipLaunchKernelGGL(agc_peak_kernel, dim3((unsigned)((len + PEAK_TM - 1) / PEAK_TM), (unsigned)((nchan + 63) / 64)), dim3(256), 0, st,
-                     db, s.mag_history, nchan, len, H, peak);
+  if (nchan == 1)
+    hipLaunchKernelGGL(agc_peak1_kernel, dim3(grid_for(len, 256)), dim3(256), 0, st, db, s.mag_history, len, H, peak);
+  else
+    hipLaunchKernelGGL(agc_peak_kernel, dim3((unsigned)((len + PEAK_TM - 1) / PEAK_TM), (unsigned)((nchan + 63) / 64)), dim3(256), 0, st,
+                       db, s.mag_history, nchan, len, H, peak);
   return hipGetLastError();
 }
 
