@@ -280,23 +280,6 @@ SUAMD_API SUFLOAT *suamd_fac_array(suamd_fac_t *f);                          /* 
 SUAMD_API SUBOOL   suamd_fac_get_range(suamd_fac_t *f, SUFLOAT *min, SUFLOAT *max, void *stream);
 
 /* ------------------------------------------------------------------------------------ */
-/* Gangs: n one-channel banks -- each with its OWN parameters, state, row and length -- run side by     */
-/* side, one lane each, in one launch per loop type.  This is how the live analyzer serves many            */
-/* inspectors that cannot share a bank (different loop bandwidths, bauds, decimations): the serial       */
-/* recurrences of all of them cost the time of one.  Rows are contiguous; results are bit-identical to    */
-/* feeding every bank on its own.  Gang calls of one context go on one stream (or are ordered otherwise). */
-/* ------------------------------------------------------------------------------------ */
-SUAMD_API SUBOOL suamd_costas_gang_feed(suamd_ctx_t *ctx, suamd_costas_bank_t *const *banks, unsigned n,
-                                        const suamd_complex *const *d_x, suamd_complex *const *d_y,
-                                        const SUSCOUNT *len, void *stream);
-SUAMD_API SUBOOL suamd_agc_gang_feed(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n,
-                                     const suamd_complex *const *d_x, suamd_complex *const *d_y,
-                                     const SUSCOUNT *len, void *stream);
-SUAMD_API SUBOOL suamd_clock_gang_feed(suamd_ctx_t *ctx, suamd_clock_bank_t *const *banks, unsigned n,
-                                       const suamd_complex *const *d_x, const SUSCOUNT *len,
-                                       suamd_complex *const *d_sym, uint32_t *const *d_count, void *stream);
-
-/* ------------------------------------------------------------------------------------ */
 /* A7: stages behind the rest of the inspector config vocabulary                         */
 /* (Default/GenericInspector/InspectorCtl/{GainControl,AfcControl,MfControl,Equalizer-   */
 /* Control}.cpp; semantics frozen in SPEC.md section I -- libsuscan is absent)           */
@@ -333,6 +316,30 @@ SUAMD_API SUBOOL suamd_cma_bank_feed(suamd_cma_bank_t *b, const suamd_complex *d
                                      const uint32_t *d_count, SUSCOUNT fixed_len, suamd_complex *d_y,
                                      SUSCOUNT y_stride, void *stream);
 SUAMD_API SUBOOL suamd_cma_bank_get_weights(suamd_cma_bank_t *b, suamd_complex *weights /* [ntaps][nchan] */, void *stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Gangs: n one-channel banks -- each with its OWN parameters, state, row and length -- run side by     */
+/* side, one lane each, in one launch per loop type.  This is how the live analyzer serves many            */
+/* inspectors that cannot share a bank (different loop bandwidths, bauds, decimations): the serial       */
+/* recurrences of all of them cost the time of one.  Rows are contiguous; results are bit-identical to    */
+/* feeding every bank on its own.  Gang calls of one context go on one stream (or are ordered otherwise). */
+/* ------------------------------------------------------------------------------------ */
+SUAMD_API SUBOOL suamd_costas_gang_feed(suamd_ctx_t *ctx, suamd_costas_bank_t *const *banks, unsigned n,
+                                        const suamd_complex *const *d_x, suamd_complex *const *d_y,
+                                        const SUSCOUNT *len, void *stream);
+SUAMD_API SUBOOL suamd_agc_gang_feed(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n,
+                                     const suamd_complex *const *d_x, suamd_complex *const *d_y,
+                                     const SUSCOUNT *len, void *stream);
+SUAMD_API SUBOOL suamd_pll_gang_feed(suamd_ctx_t *ctx, suamd_pll_bank_t *const *banks, unsigned n,
+                                     const suamd_complex *const *d_x, suamd_complex *const *d_y,
+                                     const SUSCOUNT *len, void *stream);
+/* symbol rows: item i consumes *d_count[i] symbols (d_count may be NULL: then fixed_len[i]); in place allowed */
+SUAMD_API SUBOOL suamd_cma_gang_feed(suamd_ctx_t *ctx, suamd_cma_bank_t *const *banks, unsigned n,
+                                     const suamd_complex *const *d_x, const uint32_t *const *d_count,
+                                     const SUSCOUNT *fixed_len, suamd_complex *const *d_y, void *stream);
+SUAMD_API SUBOOL suamd_clock_gang_feed(suamd_ctx_t *ctx, suamd_clock_bank_t *const *banks, unsigned n,
+                                       const suamd_complex *const *d_x, const SUSCOUNT *len,
+                                       suamd_complex *const *d_sym, uint32_t *const *d_count, void *stream);
 
 /* struct su_agc_params (Tasks/AGCTask.cpp:41-47) + su_agc_params_INITIALIZER defaults */
 struct suamd_agc_params {

@@ -605,6 +605,7 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
   // ---- carrier control ----
   {
     std::vector<suamd_costas_bank_t *> banks; std::vector<const suamd_complex *> xs; std::vector<suamd_complex *> ys; std::vector<SUSCOUNT> ls;
+    std::vector<suamd_pll_bank_t *> pbanks; std::vector<const suamd_complex *> pxs; std::vector<suamd_complex *> pys; std::vector<SUSCOUNT> pls;
     for (Inspector *pi : live) {
       Inspector &in = *pi;
       const suamd_view row = {(SUSCOUNT)in.cap, 1};
@@ -619,7 +620,7 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
         in.pend_src = o;
       } else if (in.pll) {
         suamd_complex *o = other(in);
-        suamd_pll_bank_feed(in.pll, in.pend_src, row, o, row, m, st);
+        pbanks.push_back(in.pll); pxs.push_back(in.pend_src); pys.push_back(o); pls.push_back(m);
         in.pend_src = o;
       } else if (in.quad) {
         suamd_complex *o = other(in);
@@ -630,6 +631,7 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
       }
     }
     if (!banks.empty()) suamd_costas_gang_feed(a->ctx, banks.data(), (unsigned)banks.size(), xs.data(), ys.data(), ls.data(), st);
+    if (!pbanks.empty()) suamd_pll_gang_feed(a->ctx, pbanks.data(), (unsigned)pbanks.size(), pxs.data(), pys.data(), pls.data(), st);
   }
   // ---- matched filter ----
   for (Inspector *pi : live) {
@@ -652,12 +654,16 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
       in.pend_symbols = true;
     }
     if (!banks.empty()) suamd_clock_gang_feed(a->ctx, banks.data(), (unsigned)banks.size(), xs.data(), ls.data(), syms.data(), cnts.data(), st);
+    // the equalizers take their symbol counts from the device: no host round trip inside the chain
+    std::vector<suamd_cma_bank_t *> eq; std::vector<const suamd_complex *> ex; std::vector<suamd_complex *> ey; std::vector<const uint32_t *> ec;
     for (Inspector *pi : live) {
       Inspector &in = *pi;
-      if (!in.pend_symbols) continue;
-      // the equalizer takes its symbol count from the device: no host round trip inside the chain
-      if (in.cma) suamd_cma_bank_feed(in.cma, in.d_sym, (SUSCOUNT)in.cap, in.d_count, 0, in.d_sym, (SUSCOUNT)in.cap, st);
-      (void)hipMemcpyAsync(&in.pin->count, in.d_count, 4, hipMemcpyDeviceToHost, st);
+      if (in.pend_symbols && in.cma) { eq.push_back(in.cma); ex.push_back(in.d_sym); ey.push_back(in.d_sym); ec.push_back(in.d_count); }
+    }
+    if (!eq.empty()) suamd_cma_gang_feed(a->ctx, eq.data(), (unsigned)eq.size(), ex.data(), ec.data(), nullptr, ey.data(), st);
+    for (Inspector *pi : live) {
+      Inspector &in = *pi;
+      if (in.pend_symbols) (void)hipMemcpyAsync(&in.pin->count, in.d_count, 4, hipMemcpyDeviceToHost, st);
     }
   }
 }

@@ -1160,6 +1160,52 @@ SUBOOL suamd_costas_gang_feed(suamd_ctx_t *ctx, suamd_costas_bank_t *const *bank
   return SU_TRUE;
 }
 
+SUBOOL suamd_pll_gang_feed(suamd_ctx_t *ctx, suamd_pll_bank_t *const *banks, unsigned n, const suamd_complex *const *d_x,
+                           suamd_complex *const *d_y, const SUSCOUNT *len, void *stream)
+{
+  if (!ctx || (n && (!banks || !d_x || !d_y || !len))) { set_err("null argument"); return SU_FALSE; }
+  hipStream_t st = as_stream(stream);
+  std::vector<sdk::PllGangItem> items;
+  for (unsigned i = 0; i < n; ++i) {
+    if (!banks[i] || banks[i]->nchan != 1) { set_err("gang members must be 1-channel banks"); return SU_FALSE; }
+    if (len[i] == 0) continue;
+    if (!d_x[i] || !d_y[i]) { set_err("null row"); return SU_FALSE; }
+    items.push_back(sdk::PllGangItem{banks[i]->alpha, banks[i]->beta, banks[i]->s, d_x[i], d_y[i], (long long)len[i]});
+  }
+  for (size_t o = 0; o < items.size(); o += 512) {
+    std::vector<sdk::PllGangItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
+    sdk::PllGangItem *d = gang_upload(ctx, part, st);
+    if (!d) return SU_FALSE;
+    HIP_TRY(sdk::pll_gang(d, (int)part.size(), st), SU_FALSE);
+  }
+  return SU_TRUE;
+}
+
+SUBOOL suamd_cma_gang_feed(suamd_ctx_t *ctx, suamd_cma_bank_t *const *banks, unsigned n, const suamd_complex *const *d_x,
+                           const uint32_t *const *d_count, const SUSCOUNT *fixed_len, suamd_complex *const *d_y, void *stream)
+{
+  if (!ctx || (n && (!banks || !d_x || !d_y))) { set_err("null argument"); return SU_FALSE; }
+  hipStream_t st = as_stream(stream);
+  std::map<unsigned, std::vector<sdk::CmaGangItem>> groups;                    // one launch per equalizer length
+  for (unsigned i = 0; i < n; ++i) {
+    suamd_cma_bank *b = banks[i];
+    if (!b || b->nchan != 1) { set_err("gang members must be 1-channel banks"); return SU_FALSE; }
+    if (!d_x[i] || !d_y[i]) { set_err("null row"); return SU_FALSE; }
+    const uint32_t *cnt = d_count ? d_count[i] : nullptr;
+    if (!cnt && !fixed_len) { set_err("neither counts nor lengths"); return SU_FALSE; }
+    groups[b->n].push_back(sdk::CmaGangItem{b->mu, b->locked, b->d_w, b->d_dl, d_x[i], d_y[i], cnt, fixed_len ? (long long)fixed_len[i] : 0});
+  }
+  for (auto &kv : groups) {
+    for (size_t o = 0; o < kv.second.size(); o += 512) {
+      std::vector<sdk::CmaGangItem> part(kv.second.begin() + o, kv.second.begin() + std::min(kv.second.size(), o + 512));
+      sdk::CmaGangItem *d = gang_upload(ctx, part, st);
+      if (!d) return SU_FALSE;
+      HIP_TRY(sdk::cma_gang(d, (int)part.size(), (int)kv.first, st), SU_FALSE);
+    }
+  }
+  return SU_TRUE;
+}
+
 SUBOOL suamd_clock_gang_feed(suamd_ctx_t *ctx, suamd_clock_bank_t *const *banks, unsigned n, const suamd_complex *const *d_x,
                              const SUSCOUNT *len, suamd_complex *const *d_sym, uint32_t *const *d_count, void *stream)
 {

@@ -87,6 +87,11 @@ hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, cons
 // lengths may differ per item.  items: device array.
 struct CostasGangItem { CostasParams p; CostasState s; const void *x; void *y; long long len; };
 struct ClockGangItem { ClockParams p; ClockState s; const void *x; long long len; void *sym; uint32_t *count; };
+struct PllGangItem { float alpha, beta; PllState s; const void *x; void *y; long long len; };
+// symbol rows: the length is *count when count != nullptr (the clock gang's device-side counts), else fixed_len
+struct CmaGangItem { float mu; int locked; void *w; void *dl; const void *x; void *y; const uint32_t *count; long long fixed_len; };
+hipError_t pll_gang(const PllGangItem *d_items, int n, hipStream_t st);
+hipError_t cma_gang(const CmaGangItem *d_items, int n, int ntaps, hipStream_t st);
 hipError_t costas_gang(const CostasGangItem *d_items, int n, int kind, int order, hipStream_t st);
 hipError_t clock_gang(const ClockGangItem *d_items, int n, hipStream_t st);
 

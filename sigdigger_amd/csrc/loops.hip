@@ -775,6 +775,66 @@ __global__ __launch_bounds__(64) void costas_gang_kernel(const sdk::CostasGangIt
   }
 }
 
+__global__ __launch_bounds__(64) void pll_gang_kernel(const sdk::PllGangItem *__restrict__ items, int n)
+{
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const bool live = j < n;
+  const sdk::PllGangItem it = items[live ? j : 0];
+  const float alpha = it.alpha, beta = it.beta;
+  uint32_t phase = it.s.phase[0];
+  float omega = it.s.omega[0];
+  const long long len = live ? it.len : 0;
+  __shared__ GangLds<float2> lds;
+  gang_stream<true>(lds, reinterpret_cast<const float2 *>(it.x), reinterpret_cast<float2 *>(it.y), len,
+                    [&](long long, float2 v) { return pll_step(alpha, beta, phase, omega, v); });
+  if (!live) return;
+  it.s.phase[0] = phase;
+  it.s.omega[0] = omega;
+}
+
+// CMA equalizers (SPEC.md section I) of many inspectors: N weights and the delay line per lane
+template <int N>
+__global__ __launch_bounds__(64) void cma_gang_kernel(const sdk::CmaGangItem *__restrict__ items, int n)
+{
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const bool live = j < n;
+  const sdk::CmaGangItem it = items[live ? j : 0];
+  const float mu = it.mu;
+  const bool locked = it.locked != 0;
+  float2 *w = reinterpret_cast<float2 *>(it.w), *dl = reinterpret_cast<float2 *>(it.dl);
+  c32 wr[N], d[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { const float2 a = w[i], b = dl[i]; wr[i] = c32{a.x, a.y}; d[i] = c32{b.x, b.y}; }
+  const long long len = live ? (it.count ? (long long)it.count[0] : it.fixed_len) : 0;
+  __shared__ GangLds<float2> lds;
+  gang_stream<true>(lds, reinterpret_cast<const float2 *>(it.x), reinterpret_cast<float2 *>(it.y), len,
+                    [&](long long, float2 v) {
+#pragma unroll
+    for (int i = N - 1; i > 0; --i) d[i] = d[i - 1];
+    d[0] = c32{v.x, v.y};
+    float yr = 0.0f, yi = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      yr = sd::fma_(wr[i].re, d[i].re, yr); yr = sd::fma_(-wr[i].im, d[i].im, yr);
+      yi = sd::fma_(wr[i].re, d[i].im, yi); yi = sd::fma_(wr[i].im, d[i].re, yi);
+    }
+    if (!locked) {
+      const float g = sd::fma_(yi, yi, yr * yr) - 1.0f;
+      const c32 e = {yr * g, yi * g};
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const c32 t = sd::cmul_conj(e, d[i]);
+        wr[i].re = sd::fma_(-mu, t.re, wr[i].re);
+        wr[i].im = sd::fma_(-mu, t.im, wr[i].im);
+      }
+    }
+    return float2{yr, yi};
+  });
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < N; ++i) { w[i] = float2{wr[i].re, wr[i].im}; dl[i] = float2{d[i].re, d[i].im}; }
+}
+
 __global__ __launch_bounds__(64) void clock_gang_kernel(const sdk::ClockGangItem *__restrict__ items, int n)
 {
   const int j = blockIdx.x * 64 + threadIdx.x;
@@ -1003,6 +1063,27 @@ hipError_t agc_level_gang(const AgcGangItem *d_items, int n, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(agc_level_gang_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_items, n);
+  return hipGetLastError();
+}
+
+hipError_t pll_gang(const PllGangItem *d_items, int n, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pll_gang_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_items, n);
+  return hipGetLastError();
+}
+
+hipError_t cma_gang(const CmaGangItem *d_items, int n, int ntaps, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  const dim3 grid((n + 63) / 64), block(64);
+  switch (ntaps) {
+#define SD_CMA_GANG(N) case N: hipLaunchKernelGGL(cma_gang_kernel<N>, grid, block, 0, st, d_items, n); break;
+    SD_CMA_GANG(1) SD_CMA_GANG(2) SD_CMA_GANG(3) SD_CMA_GANG(4) SD_CMA_GANG(5) SD_CMA_GANG(6) SD_CMA_GANG(7) SD_CMA_GANG(8)
+    SD_CMA_GANG(9) SD_CMA_GANG(10) SD_CMA_GANG(11) SD_CMA_GANG(12) SD_CMA_GANG(13) SD_CMA_GANG(14) SD_CMA_GANG(15) SD_CMA_GANG(16)
+#undef SD_CMA_GANG
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -460,6 +460,21 @@ def gang_agc(ctx, banks, xs, ys, stream=None):
                                       _ptr_array([_ptr(y) for y in ys]), lens, _stream(stream)), "suamd_agc_gang_feed")
 
 
+def gang_pll(ctx, banks, xs, ys, stream=None):
+    n = len(banks)
+    lens = (C.c_uint64 * n)(*[x.numel() for x in xs])
+    check(ctx.lib.suamd_pll_gang_feed(ctx.h, _ptr_array([b.h for b in banks]), n, _ptr_array([_ptr(x) for x in xs]),
+                                      _ptr_array([_ptr(y) for y in ys]), lens, _stream(stream)), "suamd_pll_gang_feed")
+
+
+def gang_cma(ctx, banks, syms, counts, outs, stream=None):
+    """syms / outs: 1-D complex64 symbol rows; counts: 1-element int32 device tensors (symbols present per row)."""
+    n = len(banks)
+    check(ctx.lib.suamd_cma_gang_feed(ctx.h, _ptr_array([b.h for b in banks]), n, _ptr_array([_ptr(s) for s in syms]),
+                                      _ptr_array([_ptr(c) for c in counts]), None, _ptr_array([_ptr(o) for o in outs]),
+                                      _stream(stream)), "suamd_cma_gang_feed")
+
+
 def gang_clock(ctx, banks, xs, syms, counts, stream=None):
     n = len(banks)
     lens = (C.c_uint64 * n)(*[x.numel() for x in xs])

@@ -80,6 +80,8 @@ PROTOTYPES = {
     "suamd_fac_get_range": (INT, [VP, VP, VP, VP]),
     "suamd_costas_gang_feed": (INT, [VP, VP, UINT, VP, VP, VP, VP]),
     "suamd_agc_gang_feed": (INT, [VP, VP, UINT, VP, VP, VP, VP]),
+    "suamd_pll_gang_feed": (INT, [VP, VP, UINT, VP, VP, VP, VP]),
+    "suamd_cma_gang_feed": (INT, [VP, VP, UINT, VP, VP, VP, VP, VP]),
     "suamd_clock_gang_feed": (INT, [VP, VP, UINT, VP, VP, VP, VP, VP]),
     "suamd_rows_scale": (INT, [VP, VP, View, VP, View, UINT, U64, F32, VP]),
     "suamd_nco_bank_new": (VP, [VP, UINT, VP]),

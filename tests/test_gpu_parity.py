@@ -661,6 +661,40 @@ def test_gangs_of_heterogeneous_banks_bit_exact(ctx, sdo):
         assert_bits(host(syms[i][:k]), ref, f"gang item {i}: symbols")
 
 
+def test_pll_and_cma_gangs_bit_exact(ctx, sdo):
+    rng = np.random.default_rng(7)
+    n = 40
+    lens = rng.integers(0, 3000, n); lens[:3] = [0, 1, 2999]
+    fcs = rng.uniform(0.005, 0.05, n)
+    xs_h = [(np.exp(1j * (np.pi * 0.004 * (i % 5 + 1) * np.arange(L_) + i)) + 0.05 * synth.tone_noise(max(int(L_), 1), seed=i)[:int(L_)]).astype(np.complex64)
+            for i, L_ in enumerate(lens)]
+    plls = [engine.PLLBank(ctx, 1, 0.0, float(fcs[i])) for i in range(n)]
+    ntaps = rng.choice([1, 4, 8, 16], n)
+    mus = rng.uniform(5e-4, 4e-3, n)
+    cmas = [engine.CMABank(ctx, 1, int(ntaps[i]), float(mus[i])) for i in range(n)]
+    for i in range(0, n, 5):
+        cmas[i].set_locked(True)
+    got_p, got_c = [[] for _ in range(n)], [[] for _ in range(n)]
+    for a_, b_ in ((0.0, 0.4), (0.4, 1.0)):                       # two rounds: state carries over
+        xs = [dev(xs_h[i][int(a_ * lens[i]):int(b_ * lens[i])]) if int(b_ * lens[i]) > int(a_ * lens[i])
+              else torch.empty(0, dtype=torch.complex64, device="cuda") for i in range(n)]
+        yp = [torch.empty_like(x) for x in xs]
+        engine.gang_pll(ctx, plls, xs, yp)
+        cnts = [torch.tensor([x.numel()], dtype=torch.int32, device="cuda") for x in xs]
+        xs_c = [x if x.numel() else torch.zeros(1, dtype=torch.complex64, device="cuda") for x in yp]
+        yc = [torch.empty_like(x) for x in xs_c]
+        engine.gang_cma(ctx, cmas, xs_c, cnts, yc)
+        for i in range(n):
+            got_p[i].append(host(yp[i])); got_c[i].append(host(yc[i])[:xs[i].numel()])
+    for i in range(n):
+        rp = sdo.pll_track_bulk(sdo.pll_new(0.0, float(fcs[i])), xs_h[i]) if lens[i] else np.zeros(0, np.complex64)
+        assert_bits(np.concatenate(got_p[i]), rp, f"pll gang item {i}")
+        q = sdo.cma_new(int(ntaps[i]), float(mus[i]), locked=(i % 5 == 0))
+        rc = sdo.cma_feed_bulk(q, rp) if lens[i] else rp
+        assert_bits(np.concatenate(got_c[i]), rc, f"cma gang item {i}")
+        assert_bits(cmas[i].weights()[:, 0], np.array(q.w[:2 * int(ntaps[i])], dtype=np.float32).view(np.complex64), f"cma weights {i}")
+
+
 # ------------------------------------------------------------------------------------------
 # A7: stages behind the rest of the inspector config vocabulary -- bit exact
 # ------------------------------------------------------------------------------------------
