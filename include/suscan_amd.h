@@ -194,6 +194,14 @@ SUAMD_API SUBOOL suscan_analyzer_set_inspector_config_async(suscan_analyzer_t *a
                                                             const suscan_config_t *config, uint32_t req_id);
 SUAMD_API SUBOOL suscan_analyzer_set_inspector_watermark_async(suscan_analyzer_t *analyzer, SUHANDLE handle,
                                                                SUSCOUNT watermark, uint32_t req_id);
+/* InspectorMessage's view of the source / estimator registries (Suscan/Messages/InspectorMessage.cpp:44-61:
+ * it reads ->desc of the spectrum source class and ->desc / ->field of the estimator class; NULL = unknown
+ * name, then the name itself is shown).  No parameter estimators are offered: estimator_count is 0. */
+struct suscan_spectsrc_class  { const char *name; const char *desc; };
+struct suscan_estimator_class { const char *name; const char *desc; const char *field; };
+SUAMD_API const struct suscan_spectsrc_class  *suscan_spectsrc_class_lookup(const char *name);
+SUAMD_API const struct suscan_estimator_class *suscan_estimator_class_lookup(const char *name);
+
 /* Analyzer::setSpectrumSource (Suscan/Analyzer.cpp:539-547): 0 = none, k = spectsrc_list[k-1] of the OPEN
  * message; afterwards every block yields an INSPECTOR message of kind SPECTRUM with spectrum_data
  * (linear power, natural order), spectrum_size, samp_rate = equiv_fs and spectsrc_id */

@@ -1284,6 +1284,20 @@ SUBOOL suscan_analyzer_set_inspector_watermark_async(suscan_analyzer_t *a, SUHAN
   return post(a, std::move(r));
 }
 
+const struct suscan_spectsrc_class *suscan_spectsrc_class_lookup(const char *name)
+{
+  static const struct suscan_spectsrc_class classes[] = {
+    {"psd", "Power spectrum"}, {"cyclo", "Cyclostationary analysis"}, {"fmspect", "FM spectrum"},
+    {"pmspect", "PM spectrum"}, {"timediff", "Time derivative"}, {"abstimediff", "Absolute value of the time derivative"},
+    {"exp_2", "Signal exponentiation (2)"}, {"exp_4", "Signal exponentiation (4)"}, {"exp_8", "Signal exponentiation (8)"},
+  };
+  if (!name) return nullptr;
+  for (const auto &c : classes) if (!std::strcmp(c.name, name)) return &c;
+  return nullptr;
+}
+
+const struct suscan_estimator_class *suscan_estimator_class_lookup(const char *) { return nullptr; }
+
 SUBOOL suscan_analyzer_inspector_set_spectrum_async(suscan_analyzer_t *a, SUHANDLE h, uint32_t spectsrc_id, uint32_t req)
 {
   Request r; r.kind = Request::SET_SPECTRUM; r.req_id = req; r.handle = h; r.value = spectsrc_id;

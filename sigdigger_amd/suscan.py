@@ -105,6 +105,8 @@ PROTOTYPES = {
     "suscan_analyzer_set_inspector_config_async": (INT, [VP, C.c_int32, VP, U32]),
     "suscan_analyzer_set_inspector_watermark_async": (INT, [VP, C.c_int32, U64, U32]),
     "suscan_analyzer_inspector_set_spectrum_async": (INT, [VP, C.c_int32, U32, U32]),
+    "suscan_spectsrc_class_lookup": (VP, [C.c_char_p]),
+    "suscan_estimator_class_lookup": (VP, [C.c_char_p]),
     "suscan_analyzer_set_inspector_freq_overridable": (INT, [VP, C.c_int32, C.c_double]),
     "suscan_analyzer_set_inspector_bandwidth_overridable": (INT, [VP, C.c_int32, C.c_double]),
 }

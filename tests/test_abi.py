@@ -85,6 +85,15 @@ def test_message_queue_and_config_without_a_gpu():
     assert L.suscan_config_get_value(dup, b"clock.baud")
     L.suscan_config_destroy(dup)
     L.suscan_config_destroy(cfg)
+    assert L.suscan_inspector_config_desc(b"ask")                            # InspectorCtl/AskControl.cpp vocabulary
+    # the registries InspectorMessage.cpp:44-61 consults for the lists of the OPEN reply
+
+    class Cls(ctypes.Structure):
+        _fields_ = [("name", ctypes.c_char_p), ("desc", ctypes.c_char_p)]
+
+    c = L.suscan_spectsrc_class_lookup(b"cyclo")
+    assert c and ctypes.cast(c, ctypes.POINTER(Cls)).contents.name == b"cyclo" and ctypes.cast(c, ctypes.POINTER(Cls)).contents.desc
+    assert not L.suscan_spectsrc_class_lookup(b"nope") and not L.suscan_estimator_class_lookup(b"baud")
 
 
 def test_no_cpu_fallback_without_a_gpu():
