@@ -193,6 +193,47 @@ def run_workload(name, args, rank, world, dev, ctx, dist):
     return cfg, L, dt, stages, fn_rank, pipe
 
 
+def run_host_fed(name, args, dev, ctx):
+    """PCIe-inclusive rate of the default workload (never `value`): every block starts in pinned host memory and
+    crosses PCIe on a copy stream into one of two device buffers while the previous block is processed."""
+    cfg = WORKLOADS[name]
+    L = 1 << args.block
+    fn = synth.raster(cfg["per_gpu"], cfg["spacing"])
+    bank = pipeline.InspectorBankConfig(kind=cfg["kind"], fnor=fn, decimation=cfg["D"], ntaps=cfg["T"], sps=cfg["sps_in"] / cfg["D"])
+    pipe = pipeline.AnalyzerPipeline(ctx, L, psd_size=cfg["psd"], psd_navg=min(256, L // cfg["psd"]), bank=bank, do_psd=True)
+    host = make_block(L, fn, cfg["sps_in"], cfg["kind"], dev, seed=99).cpu().pin_memory()
+    bufs = [torch.empty(L, dtype=torch.complex64, device=dev) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(k):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(consumed[k & 1])           # the FIR / PSD of the block that used this buffer are done
+            bufs[k & 1].copy_(host, non_blocking=True)
+            ready[k & 1].record(copy_stream)
+
+    for e in consumed:
+        e.record(main)
+    steps, warm = max(6, args.steps // 2), 2
+    upload(0)
+    t0 = None
+    for k in range(warm + steps):
+        if k == warm:
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+        upload(k + 1)
+        main.wait_event(ready[k & 1])
+        pipe.step(bufs[k & 1], timed=False)
+        consumed[k & 1].record(main)                          # step() enqueued its readers of the block on `main`
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return {"value_MSps": round(L * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 4),
+            "what": "same workload with every block crossing PCIe (pinned host -> HBM on a copy stream, double-buffered)",
+            "pcie_GBps": round(8.0 * L * steps / dt / 1e9, 2)}
+
+
 def run_c5(args, dev, ctx, log2_file=30, N=8192, tile=256):
     """C5: panoramic-scanner sweep over a captured file resident in HBM -- every dwell is `tile` frames of
     N points averaged into one shifted-dB PSD message (PSDMessage.cpp:26-39 fused), fed to the SpectrumView
@@ -367,6 +408,7 @@ def main():
                             "ms_per_step": round(dt2 / a2.steps * 1e3, 4),
                             "stage_ms": {k: round(v, 4) for k, v in st2.items()}}
             extra["c5"] = run_c5(args, dev, ctx)
+            out["host_fed"] = run_host_fed(args.workload, args, dev, ctx)
             out["other_workloads"] = extra
         if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_samples, fn_rank, os.cpu_count() or 1)
