@@ -600,7 +600,8 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
       if (in.agc) { banks.push_back(in.agc); xs.push_back(in.pend_src); ys.push_back(in.d_a); ls.push_back(in.pend_m); in.pend_src = in.d_a; }
       else if (in.fixed_gain > 0) { suamd_rows_scale(a->ctx, in.pend_src, row, in.d_a, row, 1, in.pend_m, in.fixed_gain, st); in.pend_src = in.d_a; }
     }
-    if (!banks.empty()) suamd_agc_gang_feed(a->ctx, banks.data(), (unsigned)banks.size(), xs.data(), ys.data(), ls.data(), st);
+    if (!banks.empty() && !suamd_agc_gang_feed(a->ctx, banks.data(), (unsigned)banks.size(), xs.data(), ys.data(), ls.data(), st))
+      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("gain control: ") + suamd_last_error());
   }
   // ---- carrier control ----
   {
@@ -630,8 +631,10 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
         in.pend_src = o;
       }
     }
-    if (!banks.empty()) suamd_costas_gang_feed(a->ctx, banks.data(), (unsigned)banks.size(), xs.data(), ys.data(), ls.data(), st);
-    if (!pbanks.empty()) suamd_pll_gang_feed(a->ctx, pbanks.data(), (unsigned)pbanks.size(), pxs.data(), pys.data(), pls.data(), st);
+    if (!banks.empty() && !suamd_costas_gang_feed(a->ctx, banks.data(), (unsigned)banks.size(), xs.data(), ys.data(), ls.data(), st))
+      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("carrier control: ") + suamd_last_error());
+    if (!pbanks.empty() && !suamd_pll_gang_feed(a->ctx, pbanks.data(), (unsigned)pbanks.size(), pxs.data(), pys.data(), pls.data(), st))
+      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("carrier control: ") + suamd_last_error());
   }
   // ---- matched filter ----
   for (Inspector *pi : live) {
@@ -653,14 +656,16 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
       banks.push_back(in.clock); xs.push_back(in.pend_src); ls.push_back(in.pend_m); syms.push_back(in.d_sym); cnts.push_back(in.d_count);
       in.pend_symbols = true;
     }
-    if (!banks.empty()) suamd_clock_gang_feed(a->ctx, banks.data(), (unsigned)banks.size(), xs.data(), ls.data(), syms.data(), cnts.data(), st);
+    if (!banks.empty() && !suamd_clock_gang_feed(a->ctx, banks.data(), (unsigned)banks.size(), xs.data(), ls.data(), syms.data(), cnts.data(), st))
+      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("clock recovery: ") + suamd_last_error());
     // the equalizers take their symbol counts from the device: no host round trip inside the chain
     std::vector<suamd_cma_bank_t *> eq; std::vector<const suamd_complex *> ex; std::vector<suamd_complex *> ey; std::vector<const uint32_t *> ec;
     for (Inspector *pi : live) {
       Inspector &in = *pi;
       if (in.pend_symbols && in.cma) { eq.push_back(in.cma); ex.push_back(in.d_sym); ey.push_back(in.d_sym); ec.push_back(in.d_count); }
     }
-    if (!eq.empty()) suamd_cma_gang_feed(a->ctx, eq.data(), (unsigned)eq.size(), ex.data(), ec.data(), nullptr, ey.data(), st);
+    if (!eq.empty() && !suamd_cma_gang_feed(a->ctx, eq.data(), (unsigned)eq.size(), ex.data(), ec.data(), nullptr, ey.data(), st))
+      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("equalizer: ") + suamd_last_error());
     for (Inspector *pi : live) {
       Inspector &in = *pi;
       if (in.pend_symbols) (void)hipMemcpyAsync(&in.pin->count, in.d_count, 4, hipMemcpyDeviceToHost, st);
