@@ -337,6 +337,17 @@ SUAMD_API SUBOOL suamd_pll_gang_feed(suamd_ctx_t *ctx, suamd_pll_bank_t *const *
 SUAMD_API SUBOOL suamd_cma_gang_feed(suamd_ctx_t *ctx, suamd_cma_bank_t *const *banks, unsigned n,
                                      const suamd_complex *const *d_x, const uint32_t *const *d_count,
                                      const SUSCOUNT *fixed_len, suamd_complex *const *d_y, void *stream);
+/* suamd_agc_gang_feed in its four steps, for callers that pipeline sub-ranges [m0, m1) of a block through the level
+ * trackers and the stages behind them: pre (whole block) -> { level, apply } per sub-range in order -> finish */
+SUAMD_API SUBOOL suamd_agc_gang_pre(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n,
+                                    const suamd_complex *const *d_x, const SUSCOUNT *len, void *stream);
+SUAMD_API SUBOOL suamd_agc_gang_level(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n, const SUSCOUNT *len,
+                                      const SUSCOUNT *m0, const SUSCOUNT *m1, void *stream);
+SUAMD_API SUBOOL suamd_agc_gang_apply(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n,
+                                      const suamd_complex *const *d_x, suamd_complex *const *d_y, const SUSCOUNT *len,
+                                      const SUSCOUNT *m0, const SUSCOUNT *m1, void *stream);
+SUAMD_API SUBOOL suamd_agc_gang_finish(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n,
+                                       const suamd_complex *const *d_x, const SUSCOUNT *len, void *stream);
 SUAMD_API SUBOOL suamd_clock_gang_feed(suamd_ctx_t *ctx, suamd_clock_bank_t *const *banks, unsigned n,
                                        const suamd_complex *const *d_x, const SUSCOUNT *len,
                                        suamd_complex *const *d_sym, uint32_t *const *d_count, void *stream);

@@ -402,7 +402,9 @@ struct suscan_analyzer {
   suamd_psd_t *psd = nullptr;
   std::map<SUHANDLE, std::unique_ptr<Inspector>> inspectors;
   hipStream_t stream = nullptr;
-  static constexpr int NISTREAMS = 1;
+  static constexpr int NISTREAMS = 3;          // gain control / carrier control / clock recovery
+  static constexpr int NSUB = 4;              // sub-ranges of a block pipelined through those stages
+  hipEvent_t ev_stage[3][NSUB] = {};
   hipStream_t istream[NISTREAMS] = {};
   hipEvent_t ev_input = nullptr;              // the block is in d_x
   suamd_complex *h_x = nullptr, *d_x = nullptr;
@@ -563,20 +565,24 @@ void enqueue_spectrum(suscan_analyzer *a, Inspector &in, SUSCOUNT m)
   in.pend_spec_n = n;
 }
 
-// One block through every open inspector, stage by stage on the analyzer's inspector stream.  The
-// per-inspector kernels (channel FIR, spectrum, the parallel parts of the AGC, matched filter) are short
-// and queue back to back; the serial recurrences -- AGC level trackers, Costas loops, Gardner detectors --
-// of ALL inspectors run as gangs (one lane per inspector, its own parameters and length), so their cost is
-// that of one inspector, not the sum.  Results are bit-identical to running every chain on its own.
+// One block through every open inspector.  The per-inspector kernels (channel FIR, spectrum, the parallel
+// parts of the AGC, matched filter) are short and queue back to back; the serial recurrences -- AGC level
+// trackers, Costas loops / PLLs, Gardner detectors, equalizers -- of ALL inspectors run as gangs (one lane per
+// inspector, its own parameters and length), so their cost is that of one inspector, not the sum.  The three
+// gang stages sit on three streams and the block is pushed through them in NSUB sub-ranges: while the Costas
+// gang works on sub-range j the level trackers are already on j+1 and the Gardner gang on j-1 (every stage
+// is invariant under splitting its input, which the parity tests pin).  Bit-identical to running every chain
+// on its own, whole block at once.
 void enqueue_inspectors(suscan_analyzer *a, size_t len)
 {
-  hipStream_t st = a->istream[0];
-  (void)hipStreamWaitEvent(st, a->ev_input, 0);
+  constexpr int P = suscan_analyzer::NSUB;
+  hipStream_t sA = a->istream[0], sC = a->istream[1], sK = a->istream[2];
+  (void)hipStreamWaitEvent(sA, a->ev_input, 0);
   std::vector<Inspector *> live;
   for (auto &kv : a->inspectors) {
     Inspector &in = *kv.second;
     in.pend_samples = in.pend_spectrum = in.pend_symbols = false;
-    in.stream = st;
+    in.stream = sA;
     if (in.dirty) {
       std::string err;
       if (!build_chain(a, in, err)) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, err); continue; }
@@ -584,91 +590,110 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
     }
     const suamd_view row = {(SUSCOUNT)in.cap, 1};
     SUSCOUNT m = 0;
-    if (!suamd_chanbank_feed(in.bank, a->d_x, len, in.d_y, row, &m, st)) continue;
+    if (!suamd_chanbank_feed(in.bank, a->d_x, len, in.d_y, row, &m, sA)) continue;
     in.pend_m = m;
     in.pend_src = in.d_y;
     if (in.spectsrc_id) enqueue_spectrum(a, in, m);
     live.push_back(&in);
   }
-  auto other = [](Inspector &in) { return in.pend_src == in.d_a ? in.d_z : in.d_a; };   // ping-pong: no stage in place
-  // ---- gain control ----
-  {
-    std::vector<suamd_agc_bank_t *> banks; std::vector<const suamd_complex *> xs; std::vector<suamd_complex *> ys; std::vector<SUSCOUNT> ls;
-    for (Inspector *pi : live) {
-      Inspector &in = *pi;
-      const suamd_view row = {(SUSCOUNT)in.cap, 1};
-      if (in.agc) { banks.push_back(in.agc); xs.push_back(in.pend_src); ys.push_back(in.d_a); ls.push_back(in.pend_m); in.pend_src = in.d_a; }
-      else if (in.fixed_gain > 0) { suamd_rows_scale(a->ctx, in.pend_src, row, in.d_a, row, 1, in.pend_m, in.fixed_gain, st); in.pend_src = in.d_a; }
-    }
-    if (!banks.empty() && !suamd_agc_gang_feed(a->ctx, banks.data(), (unsigned)banks.size(), xs.data(), ys.data(), ls.data(), st))
-      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("gain control: ") + suamd_last_error());
+  if (live.empty()) return;
+  auto fail = [&](const char *what) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string(what) + ": " + suamd_last_error()); };
+  auto sub = [&](const Inspector &in, int j) { return (SUSCOUNT)((unsigned long long)in.pend_m * (unsigned)j / P); };
+  // per inspector: the row every stage reads and the one it writes (ping-pong d_a / d_z, nothing runs in place)
+  struct Route { const suamd_complex *agc_in, *car_in, *mf_in, *clk_in; suamd_complex *agc_out, *car_out, *mf_out; };
+  std::vector<Route> rt(live.size());
+  std::vector<suamd_agc_bank_t *> gb; std::vector<const suamd_complex *> gx; std::vector<suamd_complex *> gy; std::vector<SUSCOUNT> gl;
+  for (size_t i = 0; i < live.size(); ++i) {
+    Inspector &in = *live[i];
+    Route &r = rt[i];
+    const suamd_complex *cur = in.d_y;
+    auto other = [&](const suamd_complex *p) { return p == in.d_a ? in.d_z : in.d_a; };
+    r.agc_in = cur; r.agc_out = nullptr;
+    if (in.agc || in.fixed_gain > 0) { r.agc_out = in.d_a; cur = in.d_a; }
+    r.car_in = cur; r.car_out = nullptr;
+    if (in.costas || in.nco || in.pll || in.quad) { r.car_out = other(cur); cur = r.car_out; }
+    r.mf_in = cur; r.mf_out = nullptr;
+    if (in.mf) { r.mf_out = other(cur); cur = r.mf_out; }
+    r.clk_in = cur;
+    in.pend_src = cur;
+    if (in.agc) { gb.push_back(in.agc); gx.push_back(r.agc_in); gy.push_back(r.agc_out); gl.push_back(in.pend_m); }
+    if (in.clock) { (void)hipMemsetAsync(in.d_count, 0, 4, sA); in.pend_symbols = true; } else in.pend_samples = true;
   }
-  // ---- carrier control ----
-  {
-    std::vector<suamd_costas_bank_t *> banks; std::vector<const suamd_complex *> xs; std::vector<suamd_complex *> ys; std::vector<SUSCOUNT> ls;
-    std::vector<suamd_pll_bank_t *> pbanks; std::vector<const suamd_complex *> pxs; std::vector<suamd_complex *> pys; std::vector<SUSCOUNT> pls;
-    for (Inspector *pi : live) {
-      Inspector &in = *pi;
-      const suamd_view row = {(SUSCOUNT)in.cap, 1};
-      const SUSCOUNT m = in.pend_m;
-      if (in.costas) {
-        suamd_complex *o = other(in);
-        banks.push_back(in.costas); xs.push_back(in.pend_src); ys.push_back(o); ls.push_back(m);
-        in.pend_src = o;
-      } else if (in.nco) {
-        suamd_complex *o = other(in);
-        suamd_nco_bank_feed(in.nco, in.pend_src, row, o, row, m, st);
-        in.pend_src = o;
-      } else if (in.pll) {
-        suamd_complex *o = other(in);
-        pbanks.push_back(in.pll); pxs.push_back(in.pend_src); pys.push_back(o); pls.push_back(m);
-        in.pend_src = o;
-      } else if (in.quad) {
-        suamd_complex *o = other(in);
-        suamd_quad_demod_batch(a->ctx, in.pend_src, row, o, row, 1, m, in.d_prev, in.first ? SU_TRUE : SU_FALSE, in.d_sym /*tmp*/, st);
-        (void)hipMemcpyAsync(in.d_prev, in.d_sym, 8, hipMemcpyDeviceToDevice, st);
-        in.first = false;
-        in.pend_src = o;
+  if (!gb.empty() && !suamd_agc_gang_pre(a->ctx, gb.data(), (unsigned)gb.size(), gx.data(), gl.data(), sA)) fail("gain control");
+  for (int j = 0; j < P; ++j) {
+    // ---- gain control on sA ----
+    {
+      std::vector<SUSCOUNT> m0, m1;
+      for (size_t i = 0; i < live.size(); ++i) {
+        Inspector &in = *live[i];
+        if (in.agc) { m0.push_back(sub(in, j)); m1.push_back(sub(in, j + 1)); }
+        else if (in.fixed_gain > 0 && sub(in, j + 1) > sub(in, j)) {
+          const suamd_view row = {(SUSCOUNT)in.cap, 1};
+          suamd_rows_scale(a->ctx, rt[i].agc_in + sub(in, j), row, rt[i].agc_out + sub(in, j), row, 1, sub(in, j + 1) - sub(in, j), in.fixed_gain, sA);
+        }
       }
+      if (!gb.empty()) {
+        if (!suamd_agc_gang_level(a->ctx, gb.data(), (unsigned)gb.size(), gl.data(), m0.data(), m1.data(), sA) ||
+            !suamd_agc_gang_apply(a->ctx, gb.data(), (unsigned)gb.size(), gx.data(), gy.data(), gl.data(), m0.data(), m1.data(), sA)) fail("gain control");
+      }
+      (void)hipEventRecord(a->ev_stage[0][j], sA);
     }
-    if (!banks.empty() && !suamd_costas_gang_feed(a->ctx, banks.data(), (unsigned)banks.size(), xs.data(), ys.data(), ls.data(), st))
-      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("carrier control: ") + suamd_last_error());
-    if (!pbanks.empty() && !suamd_pll_gang_feed(a->ctx, pbanks.data(), (unsigned)pbanks.size(), pxs.data(), pys.data(), pls.data(), st))
-      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("carrier control: ") + suamd_last_error());
+    // ---- carrier control on sC ----
+    {
+      (void)hipStreamWaitEvent(sC, a->ev_stage[0][j], 0);
+      std::vector<suamd_costas_bank_t *> cb; std::vector<const suamd_complex *> cx; std::vector<suamd_complex *> cy; std::vector<SUSCOUNT> cl;
+      std::vector<suamd_pll_bank_t *> pb; std::vector<const suamd_complex *> px; std::vector<suamd_complex *> py; std::vector<SUSCOUNT> pl;
+      for (size_t i = 0; i < live.size(); ++i) {
+        Inspector &in = *live[i];
+        const SUSCOUNT b0 = sub(in, j), n = sub(in, j + 1) - b0;
+        if (!rt[i].car_out || n == 0) continue;
+        const suamd_view row = {(SUSCOUNT)in.cap, 1};
+        const suamd_complex *xi = rt[i].car_in + b0;
+        suamd_complex *yo = rt[i].car_out + b0;
+        if (in.costas) { cb.push_back(in.costas); cx.push_back(xi); cy.push_back(yo); cl.push_back(n); }
+        else if (in.pll) { pb.push_back(in.pll); px.push_back(xi); py.push_back(yo); pl.push_back(n); }
+        else if (in.nco) suamd_nco_bank_feed(in.nco, xi, row, yo, row, n, sC);
+        else if (in.quad) {
+          // the sample before a later sub-range is still in the row; only the block's first one needs the carry
+          suamd_quad_demod_batch(a->ctx, xi, row, yo, row, 1, n, b0 ? xi - 1 : in.d_prev, in.first ? SU_TRUE : SU_FALSE, nullptr, sC);
+          if (b0 + n == in.pend_m) (void)hipMemcpyAsync(in.d_prev, xi + n - 1, 8, hipMemcpyDeviceToDevice, sC);
+          in.first = false;
+        }
+      }
+      if (!cb.empty() && !suamd_costas_gang_feed(a->ctx, cb.data(), (unsigned)cb.size(), cx.data(), cy.data(), cl.data(), sC)) fail("carrier control");
+      if (!pb.empty() && !suamd_pll_gang_feed(a->ctx, pb.data(), (unsigned)pb.size(), px.data(), py.data(), pl.data(), sC)) fail("carrier control");
+      (void)hipEventRecord(a->ev_stage[1][j], sC);
+    }
+    // ---- matched filter, clock recovery on sK ----
+    {
+      (void)hipStreamWaitEvent(sK, a->ev_stage[1][j], 0);
+      std::vector<suamd_clock_bank_t *> kb; std::vector<const suamd_complex *> kx; std::vector<SUSCOUNT> kl;
+      std::vector<suamd_complex *> ks; std::vector<uint32_t *> kc;
+      for (size_t i = 0; i < live.size(); ++i) {
+        Inspector &in = *live[i];
+        const SUSCOUNT b0 = sub(in, j), n = sub(in, j + 1) - b0;
+        if (n == 0) continue;
+        const suamd_view row = {(SUSCOUNT)in.cap, 1};
+        if (in.mf) suamd_fir_bank_feed(in.mf, rt[i].mf_in + b0, row, rt[i].mf_out + b0, row, n, sK);
+        if (in.clock) { kb.push_back(in.clock); kx.push_back(rt[i].clk_in + b0); kl.push_back(n); ks.push_back(in.d_sym); kc.push_back(in.d_count); }
+      }
+      if (!kb.empty() && !suamd_clock_gang_feed(a->ctx, kb.data(), (unsigned)kb.size(), kx.data(), kl.data(), ks.data(), kc.data(), sK)) fail("clock recovery");
+      (void)hipEventRecord(a->ev_stage[2][j], sK);
+    }
   }
-  // ---- matched filter ----
-  for (Inspector *pi : live) {
-    Inspector &in = *pi;
-    if (!in.mf) continue;
-    const suamd_view row = {(SUSCOUNT)in.cap, 1};
-    suamd_complex *o = other(in);
-    suamd_fir_bank_feed(in.mf, in.pend_src, row, o, row, in.pend_m, st);
-    in.pend_src = o;
-  }
-  // ---- clock recovery, equalizer ----
+  // ---- tails: AGC state carry on sA; equalizers and the symbol counts on sK ----
+  if (!gb.empty() && !suamd_agc_gang_finish(a->ctx, gb.data(), (unsigned)gb.size(), gx.data(), gl.data(), sA)) fail("gain control");
   {
-    std::vector<suamd_clock_bank_t *> banks; std::vector<const suamd_complex *> xs; std::vector<SUSCOUNT> ls;
-    std::vector<suamd_complex *> syms; std::vector<uint32_t *> cnts;
-    for (Inspector *pi : live) {
-      Inspector &in = *pi;
-      if (!in.clock) { in.pend_samples = true; continue; }
-      (void)hipMemsetAsync(in.d_count, 0, 4, st);
-      banks.push_back(in.clock); xs.push_back(in.pend_src); ls.push_back(in.pend_m); syms.push_back(in.d_sym); cnts.push_back(in.d_count);
-      in.pend_symbols = true;
-    }
-    if (!banks.empty() && !suamd_clock_gang_feed(a->ctx, banks.data(), (unsigned)banks.size(), xs.data(), ls.data(), syms.data(), cnts.data(), st))
-      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("clock recovery: ") + suamd_last_error());
-    // the equalizers take their symbol counts from the device: no host round trip inside the chain
     std::vector<suamd_cma_bank_t *> eq; std::vector<const suamd_complex *> ex; std::vector<suamd_complex *> ey; std::vector<const uint32_t *> ec;
     for (Inspector *pi : live) {
       Inspector &in = *pi;
       if (in.pend_symbols && in.cma) { eq.push_back(in.cma); ex.push_back(in.d_sym); ey.push_back(in.d_sym); ec.push_back(in.d_count); }
     }
-    if (!eq.empty() && !suamd_cma_gang_feed(a->ctx, eq.data(), (unsigned)eq.size(), ex.data(), ec.data(), nullptr, ey.data(), st))
-      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("equalizer: ") + suamd_last_error());
+    // the equalizers take their symbol counts from the device: no host round trip inside the chain
+    if (!eq.empty() && !suamd_cma_gang_feed(a->ctx, eq.data(), (unsigned)eq.size(), ex.data(), ec.data(), nullptr, ey.data(), sK)) fail("equalizer");
     for (Inspector *pi : live) {
       Inspector &in = *pi;
-      if (in.pend_symbols) (void)hipMemcpyAsync(&in.pin->count, in.d_count, 4, hipMemcpyDeviceToHost, st);
+      if (in.pend_symbols) (void)hipMemcpyAsync(&in.pin->count, in.d_count, 4, hipMemcpyDeviceToHost, sK);
     }
   }
 }
@@ -679,7 +704,7 @@ void collect_inspectors(suscan_analyzer *a)
   bool any = false;
   for (auto &kv : a->inspectors) any = any || kv.second->pend_samples || kv.second->pend_spectrum || kv.second->pend_symbols;
   if (!any) return;
-  (void)hipStreamSynchronize(a->istream[0]);
+  for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) (void)hipStreamSynchronize(a->istream[k]);
   for (auto &kv : a->inspectors) {
     Inspector &in = *kv.second;
     if (in.pend_spectrum) {
@@ -864,6 +889,9 @@ void worker_main(suscan_analyzer *a)
   for (int k = 0; ok && k < suscan_analyzer::NISTREAMS; ++k)
     if (hipStreamCreateWithFlags(&a->istream[k], hipStreamNonBlocking) != hipSuccess) { ok = false; err = "hipStreamCreate failed"; }
   if (ok && hipEventCreateWithFlags(&a->ev_input, hipEventDisableTiming) != hipSuccess) { ok = false; err = "hipEventCreate failed"; }
+  for (int g = 0; ok && g < 3; ++g)
+    for (int j = 0; ok && j < suscan_analyzer::NSUB; ++j)
+      if (hipEventCreateWithFlags(&a->ev_stage[g][j], hipEventDisableTiming) != hipSuccess) { ok = false; err = "hipEventCreate failed"; }
   if (ok) ok = src.open(err);
   if (ok && src.cfg.samp_rate != a->source_cfg.samp_rate) {       // a WAV / SigMF header carries its own rate
     a->source_cfg.samp_rate = src.cfg.samp_rate;
@@ -993,6 +1021,8 @@ void worker_main(suscan_analyzer *a)
   for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) { if (a->istream[k]) (void)hipStreamDestroy(a->istream[k]); a->istream[k] = nullptr; }
   if (a->ev_input) (void)hipEventDestroy(a->ev_input);
   a->ev_input = nullptr;
+  for (int g = 0; g < 3; ++g)
+    for (int j = 0; j < suscan_analyzer::NSUB; ++j) { if (a->ev_stage[g][j]) (void)hipEventDestroy(a->ev_stage[g][j]); a->ev_stage[g][j] = nullptr; }
   if (a->ctx) suamd_ctx_destroy(a->ctx);
   a->psd = nullptr; a->h_x = nullptr; a->d_x = nullptr; a->d_raw = nullptr; a->d_psd = nullptr; a->stream = nullptr; a->ctx = nullptr;
   push(a, SUSCAN_WORKER_MSG_TYPE_HALT, nullptr);

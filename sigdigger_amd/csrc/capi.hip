@@ -141,9 +141,9 @@ void make_window(int type, std::vector<float> &w)
 // ==========================================================================================
 struct suamd_ctx {
   int device;
-  // descriptor tables of the gang launches: a ring of slots in device memory (a slot is reused 16 gang
+  // descriptor tables of the gang launches: a ring of slots in device memory (a slot is reused 128 gang
   // calls later; gang calls of one context are expected on one stream, or externally ordered)
-  static constexpr int GANG_SLOTS = 16;
+  static constexpr int GANG_SLOTS = 128;
   static constexpr size_t GANG_SLOT_BYTES = 64 * 1024;
   char *gang_ring = nullptr;
   int gang_next = 0;
@@ -1223,6 +1223,87 @@ SUBOOL suamd_clock_gang_feed(suamd_ctx_t *ctx, suamd_clock_bank_t *const *banks,
     sdk::ClockGangItem *d = gang_upload(ctx, part, st);
     if (!d) return SU_FALSE;
     HIP_TRY(sdk::clock_gang(d, (int)part.size(), st), SU_FALSE);
+  }
+  return SU_TRUE;
+}
+
+// The AGC of a gang in its four steps, so that a caller can pipeline sub-ranges of a block through the
+// level trackers and the stages behind them: pre (|x|^2 in dB and its sliding maximum, whole block),
+// level (recurrence, any sub-range in order), apply (gain on the delayed input, same sub-range),
+// finish (history / delay-line carry, whole block, after the last apply).
+SUBOOL suamd_agc_gang_pre(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n, const suamd_complex *const *d_x,
+                          const SUSCOUNT *len, void *stream)
+{
+  if (!ctx || (n && (!banks || !d_x || !len))) { set_err("null argument"); return SU_FALSE; }
+  const suamd_view row = {0, 1};
+  for (unsigned i = 0; i < n; ++i) {
+    suamd_agc_bank *b = banks[i];
+    if (!b || b->nchan != 1) { set_err("gang members must be 1-channel banks"); return SU_FALSE; }
+    if (len[i] == 0) continue;
+    if (!d_x[i]) { set_err("null row"); return SU_FALSE; }
+    if (!b->scratch.reserve(2 * sizeof(float) * (size_t)len[i])) { set_err("scratch allocation failed"); return SU_FALSE; }
+    HIP_TRY(sdk::agc_feed_pre(b->p, b->s, 1, d_x[i], as_view(row), (long long)len[i], static_cast<float *>(b->scratch.p), as_stream(stream)), SU_FALSE);
+  }
+  return SU_TRUE;
+}
+
+SUBOOL suamd_agc_gang_level(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n, const SUSCOUNT *len,
+                            const SUSCOUNT *m0, const SUSCOUNT *m1, void *stream)
+{
+  if (!ctx || (n && (!banks || !len || !m0 || !m1))) { set_err("null argument"); return SU_FALSE; }
+  hipStream_t st = as_stream(stream);
+  std::vector<sdk::AgcGangItem> items;
+  for (unsigned i = 0; i < n; ++i) {
+    suamd_agc_bank *b = banks[i];
+    if (!b || m1[i] > len[i] || m0[i] > m1[i]) { set_err("bad sub-range"); return SU_FALSE; }
+    if (m1[i] == m0[i]) continue;
+    items.push_back(sdk::AgcGangItem{b->p, b->s, static_cast<float *>(b->scratch.p) + len[i] + m0[i], (long long)(m1[i] - m0[i])});
+  }
+  for (size_t o = 0; o < items.size(); o += 512) {
+    std::vector<sdk::AgcGangItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
+    sdk::AgcGangItem *d = gang_upload(ctx, part, st);
+    if (!d) return SU_FALSE;
+    HIP_TRY(sdk::agc_level_gang(d, (int)part.size(), st), SU_FALSE);
+  }
+  return SU_TRUE;
+}
+
+SUBOOL suamd_agc_gang_apply(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n, const suamd_complex *const *d_x,
+                            suamd_complex *const *d_y, const SUSCOUNT *len, const SUSCOUNT *m0, const SUSCOUNT *m1, void *stream)
+{
+  if (!ctx || (n && (!banks || !d_x || !d_y || !len || !m0 || !m1))) { set_err("null argument"); return SU_FALSE; }
+  hipStream_t st = as_stream(stream);
+  std::vector<sdk::AgcApplyItem> items;
+  long long span = 0;
+  for (unsigned i = 0; i < n; ++i) {
+    suamd_agc_bank *b = banks[i];
+    if (!b || m1[i] > len[i] || m0[i] > m1[i]) { set_err("bad sub-range"); return SU_FALSE; }
+    if (m1[i] == m0[i]) continue;
+    if (!d_x[i] || !d_y[i] || d_x[i] == d_y[i]) { set_err("null or aliased row"); return SU_FALSE; }
+    items.push_back(sdk::AgcApplyItem{b->p, b->s.delay_line, d_x[i], d_y[i], static_cast<const float *>(b->scratch.p) + len[i],
+                                      (long long)m0[i], (long long)m1[i]});
+    span = std::max(span, (long long)(m1[i] - m0[i]));
+  }
+  for (size_t o = 0; o < items.size(); o += 512) {
+    std::vector<sdk::AgcApplyItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
+    sdk::AgcApplyItem *d = gang_upload(ctx, part, st);
+    if (!d) return SU_FALSE;
+    HIP_TRY(sdk::agc_apply_items(d, (int)part.size(), span, st), SU_FALSE);
+  }
+  return SU_TRUE;
+}
+
+SUBOOL suamd_agc_gang_finish(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n, const suamd_complex *const *d_x,
+                             const SUSCOUNT *len, void *stream)
+{
+  if (!ctx || (n && (!banks || !d_x || !len))) { set_err("null argument"); return SU_FALSE; }
+  const suamd_view row = {0, 1};
+  for (unsigned i = 0; i < n; ++i) {
+    suamd_agc_bank *b = banks[i];
+    if (!b || len[i] == 0) continue;
+    HIP_TRY(sdk::agc_state_update(b->p, b->s, 1, d_x[i], as_view(row), (long long)len[i], static_cast<const float *>(b->scratch.p),
+                                  as_stream(stream)), SU_FALSE);
+    b->n_fed += len[i];
   }
   return SU_TRUE;
 }

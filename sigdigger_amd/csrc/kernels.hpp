@@ -116,6 +116,11 @@ hipError_t agc_feed_pre(const AgcParams &p, const AgcState &s, int nchan, const 
 hipError_t agc_feed_post(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv, void *y, View yv,
                          long long len, float *scratch, hipStream_t st);
 struct AgcGangItem { AgcParams p; AgcState s; float *peak; long long len; };
+// gain on the delayed input for outputs [m0, m1) of many 1-channel banks (rows contiguous): one launch, grid.y = item
+struct AgcApplyItem { AgcParams p; const float *delay_line; const void *x; void *y; const float *lvl; long long m0, m1; };
+hipError_t agc_apply_items(const AgcApplyItem *d_items, int n, long long max_span, hipStream_t st);
+hipError_t agc_state_update(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv, long long len,
+                            const float *db, hipStream_t st);
 hipError_t agc_level_gang(const AgcGangItem *d_items, int n, hipStream_t st);
 
 // ---- specview.hip ----

@@ -617,6 +617,21 @@ __global__ void agc_apply_kernel(sdk::AgcParams p, const float *__restrict__ del
 
 // delay line <- last `delay` samples of [delay line ; x];  magnitude history <- last H-1 values of
 // [history ; db]   (one lane per channel; both are tiny)
+__global__ void agc_apply_items_kernel(const sdk::AgcApplyItem *__restrict__ items)
+{
+  __builtin_amdgcn_s_setprio(3);
+  const sdk::AgcApplyItem it = items[blockIdx.y];
+  const long long delay = it.p.delay_line_size;
+  const float2 *x = reinterpret_cast<const float2 *>(it.x);
+  float2 *y = reinterpret_cast<float2 *>(it.y);
+  for (long long m = it.m0 + blockIdx.x * (long long)blockDim.x + threadIdx.x; m < it.m1; m += (long long)gridDim.x * blockDim.x) {
+    const float2 xd = m >= delay ? x[m - delay] : float2{it.delay_line[m * 2 + 0], it.delay_line[m * 2 + 1]};
+    const float g_db = it.lvl[m] * (it.p.gain_slope - 1.0f);
+    const float g = sd::exp2_(g_db * 0.166096404744368117f) * 0.7f;
+    y[m] = float2{xd.x * g, xd.y * g};
+  }
+}
+
 __global__ __launch_bounds__(64) void agc_state_kernel(float *delay_line, float *hist, int nchan, int delay, int H,
                                                        const float2 *__restrict__ x, sdk::View xv,
                                                        const float *__restrict__ db, long long len)
@@ -1057,6 +1072,22 @@ hipError_t agc_feed(const AgcParams &p, const AgcState &s, int nchan, const void
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(agc_level_kernel, dim3((nchan + 63) / 64), dim3(64), 0, st, p, s, nchan, len, scratch + len * nchan);
   return agc_feed_post(p, s, nchan, x, xv, y, yv, len, scratch, st);
+}
+
+hipError_t agc_apply_items(const AgcApplyItem *d_items, int n, long long max_span, hipStream_t st)
+{
+  if (n <= 0 || max_span <= 0) return hipSuccess;
+  hipLaunchKernelGGL(agc_apply_items_kernel, dim3(grid_for(max_span, 256), (unsigned)n), dim3(256), 0, st, d_items);
+  return hipGetLastError();
+}
+
+hipError_t agc_state_update(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv, long long len,
+                            const float *db, hipStream_t st)
+{
+  if (len <= 0 || nchan <= 0) return hipSuccess;
+  hipLaunchKernelGGL(agc_state_kernel, dim3((nchan + 63) / 64), dim3(64), 0, st, s.delay_line, s.mag_history, nchan,
+                     (int)p.delay_line_size, (int)p.mag_history_size, reinterpret_cast<const float2 *>(x), xv, db, len);
+  return hipGetLastError();
 }
 
 hipError_t agc_level_gang(const AgcGangItem *d_items, int n, hipStream_t st)

@@ -460,6 +460,24 @@ def gang_agc(ctx, banks, xs, ys, stream=None):
                                       _ptr_array([_ptr(y) for y in ys]), lens, _stream(stream)), "suamd_agc_gang_feed")
 
 
+def gang_agc_split(ctx, banks, xs, ys, parts=4, stream=None):
+    """suamd_agc_gang_feed in its four steps: pre over the whole block, {level, apply} over `parts` consecutive
+    sub-ranges of every row, finish.  Same result as gang_agc (the analyzer pipelines its stages this way)."""
+    n = len(banks)
+    lens_l = [x.numel() for x in xs]
+    lens = (C.c_uint64 * n)(*lens_l)
+    b = _ptr_array([bk.h for bk in banks])
+    px, py = _ptr_array([_ptr(x) for x in xs]), _ptr_array([_ptr(y) for y in ys])
+    st = _stream(stream)
+    check(ctx.lib.suamd_agc_gang_pre(ctx.h, b, n, px, lens, st), "suamd_agc_gang_pre")
+    for j in range(parts):
+        m0 = (C.c_uint64 * n)(*[L * j // parts for L in lens_l])
+        m1 = (C.c_uint64 * n)(*[L * (j + 1) // parts for L in lens_l])
+        check(ctx.lib.suamd_agc_gang_level(ctx.h, b, n, lens, m0, m1, st), "suamd_agc_gang_level")
+        check(ctx.lib.suamd_agc_gang_apply(ctx.h, b, n, px, py, lens, m0, m1, st), "suamd_agc_gang_apply")
+    check(ctx.lib.suamd_agc_gang_finish(ctx.h, b, n, px, lens, st), "suamd_agc_gang_finish")
+
+
 def gang_pll(ctx, banks, xs, ys, stream=None):
     n = len(banks)
     lens = (C.c_uint64 * n)(*[x.numel() for x in xs])

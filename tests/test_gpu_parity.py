@@ -620,6 +620,33 @@ def test_conj_prev_and_gardner_frequency_space(ctx, sdo):
 # ------------------------------------------------------------------------------------------
 # gangs: heterogeneous 1-channel banks side by side -- bit exact against each bank's own oracle
 # ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("parts", [1, 4, 7])
+def test_agc_gang_in_sub_ranges_bit_exact(ctx, sdo, parts):
+    """pre -> {level, apply} per sub-range -> finish == suamd_agc_gang_feed == the oracle's su_agc_feed loop,
+    over two blocks (history, delay line and level state carry)."""
+    rng = np.random.default_rng(7)
+    n = 67
+    lens = rng.integers(0, 6000, n)
+    lens[:6] = [0, 1, 2, 3, 41, 5999]
+    taus = rng.choice([4.0, 8.0, 16.0, 37.0], n)
+    xs_h = [((rng.standard_normal(int(L_)) + 1j * rng.standard_normal(int(L_))) * np.exp(rng.uniform(-6, 2))).astype(np.complex64) for L_ in lens]
+    split = [engine.AGCBank(ctx, 1, tau=float(t)) for t in taus]
+    whole = [engine.AGCBank(ctx, 1, tau=float(t)) for t in taus]
+    got_s, got_w = [[] for _ in range(n)], [[] for _ in range(n)]
+    for a, b in ((0.0, 0.4), (0.4, 1.0)):
+        xs = [dev(xs_h[i][int(L_ * a):int(L_ * b)]) if int(L_ * b) > int(L_ * a) else torch.empty(0, dtype=torch.complex64, device="cuda")
+              for i, L_ in enumerate(lens)]
+        ys, yw = [torch.empty_like(x) for x in xs], [torch.empty_like(x) for x in xs]
+        engine.gang_agc_split(ctx, split, xs, ys, parts=parts)
+        engine.gang_agc(ctx, whole, xs, yw)
+        for i in range(n):
+            got_s[i].append(host(ys[i])); got_w[i].append(host(yw[i]))
+    for i in range(n):
+        ref = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(float(taus[i]))), xs_h[i]) if lens[i] else np.zeros(0, np.complex64)
+        assert_bits(np.concatenate(got_w[i]), ref, f"item {i}: whole-block gang")
+        assert_bits(np.concatenate(got_s[i]), ref, f"item {i}: sub-range gang")
+
+
 def test_gangs_of_heterogeneous_banks_bit_exact(ctx, sdo):
     rng = np.random.default_rng(42)
     n = 70                                                   # more than one wavefront of items
