@@ -348,6 +348,14 @@ SUAMD_API SUBOOL suamd_agc_gang_apply(suamd_ctx_t *ctx, suamd_agc_bank_t *const 
                                       const SUSCOUNT *m0, const SUSCOUNT *m1, void *stream);
 SUAMD_API SUBOOL suamd_agc_gang_finish(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n,
                                        const suamd_complex *const *d_x, const SUSCOUNT *len, void *stream);
+/* Results of many rows to their landing zones in one launch (the analyzer's message hand-off,
+ * Suscan/Messages/SamplesMessage.h: one batch per inspector per block): row i delivers n_i = *d_count[i] samples
+ * (d_count[i] NULL, or d_count NULL: fixed_len[i]) of d_src[i] to dst[i] and n_i to *count_out[i]; a device counter
+ * is cleared afterwards, ready for the next suamd_clock_gang_feed.  dst / count_out may be device memory or
+ * host memory mapped into the device (hipHostMalloc): then no copy is left for the host to issue. */
+SUAMD_API SUBOOL suamd_rows_deliver(suamd_ctx_t *ctx, unsigned n, const suamd_complex *const *d_src,
+                                    uint32_t *const *d_count, const SUSCOUNT *fixed_len,
+                                    suamd_complex *const *dst, uint32_t *const *count_out, void *stream);
 SUAMD_API SUBOOL suamd_clock_gang_feed(suamd_ctx_t *ctx, suamd_clock_bank_t *const *banks, unsigned n,
                                        const suamd_complex *const *d_x, const SUSCOUNT *len,
                                        suamd_complex *const *d_sym, uint32_t *const *d_count, void *stream);

@@ -328,6 +328,7 @@ struct Inspector {
   // land in pinned memory and become messages after one synchronisation (collect_inspectors)
   hipStream_t stream = nullptr;
   struct Pinned { uint32_t count; suamd_complex prev; float spec[8192]; } *pin = nullptr;   // D2H landing zone
+  suamd_complex *h_out = nullptr;             // samples / symbols of the block, written by the device (mapped, cap long)
   SUSCOUNT pend_m = 0;                        // channel samples of the block in flight
   bool pend_samples = false, pend_spectrum = false, pend_symbols = false;
   const suamd_complex *pend_src = nullptr;
@@ -360,7 +361,8 @@ struct Inspector {
   {
     free_spectrum();
     if (pin) (void)hipHostFree(pin);
-    pin = nullptr;
+    if (h_out) (void)hipHostFree(h_out);
+    pin = nullptr; h_out = nullptr;
     free_chain();
     for (void *p : {(void *)d_y, (void *)d_a, (void *)d_z, (void *)d_sym, (void *)d_prev, (void *)d_count})
       if (p) (void)hipFree(p);
@@ -403,7 +405,11 @@ struct suscan_analyzer {
   std::map<SUHANDLE, std::unique_ptr<Inspector>> inspectors;
   hipStream_t stream = nullptr;
   static constexpr int NISTREAMS = 3;          // gain control / carrier control / clock recovery
-  static constexpr int NSUB = 4;              // sub-ranges of a block pipelined through those stages
+  static constexpr int NSUB = 16;             // at most this many sub-ranges of a block pipelined through those stages
+  int nsub = 4;
+  bool trace = false;                         // SUAMD_ANALYZER_TRACE: per-block host timeline on stderr
+  double t_chains_done = 0;
+  std::chrono::steady_clock::time_point t_block0;
   hipEvent_t ev_stage[3][NSUB] = {};
   hipStream_t istream[NISTREAMS] = {};
   hipEvent_t ev_input = nullptr;              // the block is in d_x
@@ -458,6 +464,9 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
     bool ok = hipMalloc((void **)&in.d_y, need * 8) == hipSuccess && hipMalloc((void **)&in.d_a, need * 8) == hipSuccess &&
               hipMalloc((void **)&in.d_z, need * 8) == hipSuccess && hipMalloc((void **)&in.d_sym, need * 8) == hipSuccess &&
               hipMalloc((void **)&in.d_prev, 8) == hipSuccess && hipMalloc((void **)&in.d_count, 4) == hipSuccess;
+    if (in.h_out) (void)hipHostFree(in.h_out);
+    in.h_out = nullptr;
+    ok = ok && hipHostMalloc((void **)&in.h_out, need * 8, hipHostMallocMapped) == hipSuccess;
     if (!ok) { err = "device allocation failed"; return false; }
     in.cap = need;
   }
@@ -466,6 +475,7 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
     err = "pinned allocation failed"; return false;
   }
   (void)hipMemsetAsync(in.d_prev, 0, 8, in.stream);
+  (void)hipMemsetAsync(in.d_count, 0, 4, in.stream);     // from here on cleared by every hand-off (suamd_rows_deliver)
   in.first = true;
   in.quad = false;
   if (in.cls == "raw") return true;
@@ -524,15 +534,14 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
   return true;
 }
 
-void emit_samples(suscan_analyzer *a, const Inspector &in, const suamd_complex *d_src, size_t count)
+void emit_samples(suscan_analyzer *a, const Inspector &in, size_t count)
 {
-  if (count == 0) return;
+  if (count == 0 || count > in.cap) return;
   auto *m = static_cast<suscan_analyzer_sample_batch_msg *>(std::calloc(1, sizeof(suscan_analyzer_sample_batch_msg)));
   m->inspector_id = in.inspector_id;
   m->sample_count = count;
   m->samples = static_cast<suamd_complex *>(std::malloc(count * sizeof(suamd_complex)));
-  (void)hipMemcpyAsync(m->samples, d_src, count * sizeof(suamd_complex), hipMemcpyDeviceToHost, in.stream);
-  (void)hipStreamSynchronize(in.stream);
+  std::memcpy(m->samples, in.h_out, count * sizeof(suamd_complex));       // delivered by the device before the sync
   push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_SAMPLES, m);
 }
 
@@ -575,7 +584,7 @@ void enqueue_spectrum(suscan_analyzer *a, Inspector &in, SUSCOUNT m)
 // on its own, whole block at once.
 void enqueue_inspectors(suscan_analyzer *a, size_t len)
 {
-  constexpr int P = suscan_analyzer::NSUB;
+  const int P = a->nsub;
   hipStream_t sA = a->istream[0], sC = a->istream[1], sK = a->istream[2];
   (void)hipStreamWaitEvent(sA, a->ev_input, 0);
   std::vector<Inspector *> live;
@@ -617,7 +626,7 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
     r.clk_in = cur;
     in.pend_src = cur;
     if (in.agc) { gb.push_back(in.agc); gx.push_back(r.agc_in); gy.push_back(r.agc_out); gl.push_back(in.pend_m); }
-    if (in.clock) { (void)hipMemsetAsync(in.d_count, 0, 4, sA); in.pend_symbols = true; } else in.pend_samples = true;
+    if (in.clock) in.pend_symbols = true; else in.pend_samples = true;
   }
   if (!gb.empty() && !suamd_agc_gang_pre(a->ctx, gb.data(), (unsigned)gb.size(), gx.data(), gl.data(), sA)) fail("gain control");
   for (int j = 0; j < P; ++j) {
@@ -691,10 +700,18 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
     }
     // the equalizers take their symbol counts from the device: no host round trip inside the chain
     if (!eq.empty() && !suamd_cma_gang_feed(a->ctx, eq.data(), (unsigned)eq.size(), ex.data(), ec.data(), nullptr, ey.data(), sK)) fail("equalizer");
+    // hand-off: every inspector's batch goes to its mapped landing zone in one launch (sK is downstream of all stages)
+    std::vector<const suamd_complex *> src; std::vector<uint32_t *> cnt; std::vector<SUSCOUNT> fixed;
+    std::vector<suamd_complex *> dst; std::vector<uint32_t *> cout;
     for (Inspector *pi : live) {
       Inspector &in = *pi;
-      if (in.pend_symbols) (void)hipMemcpyAsync(&in.pin->count, in.d_count, 4, hipMemcpyDeviceToHost, sK);
+      src.push_back(in.pend_symbols ? in.d_sym : in.pend_src);
+      cnt.push_back(in.pend_symbols ? in.d_count : nullptr);
+      fixed.push_back(in.pend_symbols ? 0 : in.pend_m);
+      dst.push_back(in.h_out);
+      cout.push_back(&in.pin->count);
     }
+    if (!suamd_rows_deliver(a->ctx, (unsigned)live.size(), src.data(), cnt.data(), fixed.data(), dst.data(), cout.data(), sK)) fail("hand-off");
   }
 }
 
@@ -705,6 +722,7 @@ void collect_inspectors(suscan_analyzer *a)
   for (auto &kv : a->inspectors) any = any || kv.second->pend_samples || kv.second->pend_spectrum || kv.second->pend_symbols;
   if (!any) return;
   for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) (void)hipStreamSynchronize(a->istream[k]);
+  if (a->trace) a->t_chains_done = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a->t_block0).count();
   for (auto &kv : a->inspectors) {
     Inspector &in = *kv.second;
     if (in.pend_spectrum) {
@@ -719,8 +737,7 @@ void collect_inspectors(suscan_analyzer *a)
       std::memcpy(msg->spectrum_data, in.pin->spec, in.pend_spec_n * sizeof(float));
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, msg);
     }
-    if (in.pend_symbols) emit_samples(a, in, in.d_sym, in.pin->count);
-    else if (in.pend_samples) emit_samples(a, in, in.pend_src, in.pend_m);
+    if (in.pend_symbols || in.pend_samples) emit_samples(a, in, in.pin->count);
     in.pend_samples = in.pend_spectrum = in.pend_symbols = false;
   }
 }
@@ -889,6 +906,11 @@ void worker_main(suscan_analyzer *a)
   for (int k = 0; ok && k < suscan_analyzer::NISTREAMS; ++k)
     if (hipStreamCreateWithFlags(&a->istream[k], hipStreamNonBlocking) != hipSuccess) { ok = false; err = "hipStreamCreate failed"; }
   if (ok && hipEventCreateWithFlags(&a->ev_input, hipEventDisableTiming) != hipSuccess) { ok = false; err = "hipEventCreate failed"; }
+  a->trace = std::getenv("SUAMD_ANALYZER_TRACE") != nullptr;
+  if (const char *e = std::getenv("SUAMD_ANALYZER_SUBRANGES")) {           // tuning knob: 1 = whole block per stage
+    const int v = std::atoi(e);
+    if (v >= 1 && v <= suscan_analyzer::NSUB) a->nsub = v;
+  }
   for (int g = 0; ok && g < 3; ++g)
     for (int j = 0; ok && j < suscan_analyzer::NSUB; ++j)
       if (hipEventCreateWithFlags(&a->ev_stage[g][j], hipEventDisableTiming) != hipSuccess) { ok = false; err = "hipEventCreate failed"; }
@@ -943,6 +965,10 @@ void worker_main(suscan_analyzer *a)
     }
     if (a->halt) break;
     // ---- one block ----
+    const auto tb0 = std::chrono::steady_clock::now();
+    a->t_block0 = tb0;
+    double tmark[8] = {};
+    auto tick = [&](int i) { if (a->trace) tmark[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(); };
     bool looped = looped_next;
     suamd_complex *h_cur = a->h_x + (size_t)cur * a->block;
     if (!have_next) { looped = false; src.mark(); got_next = src.read(h_cur, a->block, &looped); }
@@ -962,8 +988,10 @@ void worker_main(suscan_analyzer *a)
       }
     }
     (void)hipEventRecord(a->ev_input, a->stream);
+    tick(0);
     // the inspectors' chains start as soon as the block is on the device, next to the PSD
     enqueue_inspectors(a, a->block);
+    tick(1);
     const unsigned n = (unsigned)a->params.detector_params.window_size;
     if (!suamd_psd_feed(a->psd, a->d_x, a->navg, n, a->navg, 1.0f / (float)n, SUAMD_PSD_LINEAR, a->d_psd, a->stream)) {
       push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, suamd_last_error());
@@ -980,7 +1008,9 @@ void worker_main(suscan_analyzer *a)
       src.mark();
       got_next = src.read(a->h_x + (size_t)cur * a->block, a->block, &looped_next);
       have_next = true;
+      tick(2);
       (void)hipStreamSynchronize(a->stream);
+      tick(3);
       m->fc = (int64_t)a->source_cfg.freq;
       m->samp_rate = (SUFLOAT)a->source_cfg.samp_rate;
       m->measured_samp_rate = a->measured_rate;
@@ -992,6 +1022,10 @@ void worker_main(suscan_analyzer *a)
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_PSD, m);
     }
     collect_inspectors(a);
+    tick(5);
+    if (a->trace && (consumed / a->block) % 8 == 7)
+      std::fprintf(stderr, "[analyzer] block: input issued %.2f  chains issued %.2f  next block read %.2f  psd done %.2f  chains done %.2f  delivered %.2f ms\n",
+                   tmark[0], tmark[1], tmark[2], tmark[3], a->t_chains_done, tmark[5]);
     consumed += a->block;
     // ---- rate bookkeeping / throttle ----
     auto now = std::chrono::steady_clock::now();

@@ -1293,6 +1293,27 @@ SUBOOL suamd_agc_gang_apply(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, un
   return SU_TRUE;
 }
 
+SUBOOL suamd_rows_deliver(suamd_ctx_t *ctx, unsigned n, const suamd_complex *const *d_src, uint32_t *const *d_count,
+                          const SUSCOUNT *fixed_len, suamd_complex *const *dst, uint32_t *const *count_out, void *stream)
+{
+  if (!ctx || (n && (!d_src || !dst || !count_out || (!d_count && !fixed_len)))) { set_err("null argument"); return SU_FALSE; }
+  hipStream_t st = as_stream(stream);
+  std::vector<sdk::DeliverItem> items;
+  for (unsigned i = 0; i < n; ++i) {
+    uint32_t *cnt = d_count ? d_count[i] : nullptr;
+    if (!d_src[i] || !dst[i] || !count_out[i] || (!cnt && !fixed_len)) { set_err("null row"); return SU_FALSE; }
+    if (!cnt && fixed_len[i] > 0xffffffffull) { set_err("row too long"); return SU_FALSE; }
+    items.push_back(sdk::DeliverItem{d_src[i], dst[i], cnt, cnt ? 0u : (unsigned)fixed_len[i], count_out[i]});
+  }
+  for (size_t o = 0; o < items.size(); o += 512) {
+    std::vector<sdk::DeliverItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
+    sdk::DeliverItem *d = gang_upload(ctx, part, st);
+    if (!d) return SU_FALSE;
+    HIP_TRY(sdk::rows_deliver(d, (int)part.size(), st), SU_FALSE);
+  }
+  return SU_TRUE;
+}
+
 SUBOOL suamd_agc_gang_finish(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n, const suamd_complex *const *d_x,
                              const SUSCOUNT *len, void *stream)
 {

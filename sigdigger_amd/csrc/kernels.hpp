@@ -123,6 +123,11 @@ hipError_t agc_state_update(const AgcParams &p, const AgcState &s, int nchan, co
                             const float *db, hipStream_t st);
 hipError_t agc_level_gang(const AgcGangItem *d_items, int n, hipStream_t st);
 
+// rows -> landing zones (host-mapped or device), grid.x = item: n = count ? *count : fixed samples of src go to dst,
+// n to *count_out; count (a device counter the producer accumulates into) is cleared for the next block
+struct DeliverItem { const void *src; void *dst; uint32_t *count; unsigned fixed; uint32_t *count_out; };
+hipError_t rows_deliver(const DeliverItem *d_items, int n, hipStream_t st);
+
 // ---- specview.hip ----
 struct SpecViewLinear {          // geometry of one frame, computed on the host in double precision
   double viewFreqMin, dstBinW, freqMin, srcBinW, delta;

@@ -336,6 +336,21 @@ hipError_t launch_cma(float mu, int locked, void *w, void *dl, int nchan, const 
   return hipGetLastError();
 }
 
+// one workgroup per row: the host-mapped destination is written in 64 B lane pairs, front to back
+__global__ __launch_bounds__(1024) void rows_deliver_kernel(const sdk::DeliverItem *__restrict__ items)
+{
+  const sdk::DeliverItem it = items[blockIdx.x];
+  const unsigned n = it.count ? *it.count : it.fixed;
+  __syncthreads();                                        // every lane has the count before it is cleared
+  if (threadIdx.x == 0) {
+    if (it.count) *it.count = 0;
+    *it.count_out = n;
+  }
+  const float2 *src = static_cast<const float2 *>(it.src);
+  float2 *dst = static_cast<float2 *>(it.dst);
+  for (unsigned m = threadIdx.x; m < n; m += 1024) dst[m] = src[m];
+}
+
 }  // namespace
 
 namespace sdk {
@@ -422,6 +437,13 @@ hipError_t cma_feed(int n, float mu, int locked, void *w, void *dl, int nchan, c
 #undef CMA_CASE
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t rows_deliver(const DeliverItem *d_items, int n, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rows_deliver_kernel, dim3((unsigned)n), dim3(1024), 0, st, d_items);
+  return hipGetLastError();
 }
 
 }  // namespace sdk

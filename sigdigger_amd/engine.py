@@ -478,6 +478,16 @@ def gang_agc_split(ctx, banks, xs, ys, parts=4, stream=None):
     check(ctx.lib.suamd_agc_gang_finish(ctx.h, b, n, px, lens, st), "suamd_agc_gang_finish")
 
 
+def rows_deliver(ctx, srcs, counts, dsts, count_outs, stream=None):
+    """suamd_rows_deliver: row i hands counts[i] samples (an int, or a 1-element int32 device counter that is
+    cleared afterwards) of srcs[i] to dsts[i] (device, or pinned host tensors) and the number to count_outs[i]."""
+    n = len(srcs)
+    dc = _ptr_array([None if isinstance(c, int) else _ptr(c) for c in counts])
+    fx = (C.c_uint64 * n)(*[c if isinstance(c, int) else 0 for c in counts])
+    check(ctx.lib.suamd_rows_deliver(ctx.h, n, _ptr_array([_ptr(x) for x in srcs]), dc, fx, _ptr_array([_ptr(d) for d in dsts]),
+                                     _ptr_array([_ptr(c) for c in count_outs]), _stream(stream)), "suamd_rows_deliver")
+
+
 def gang_pll(ctx, banks, xs, ys, stream=None):
     n = len(banks)
     lens = (C.c_uint64 * n)(*[x.numel() for x in xs])

@@ -620,6 +620,28 @@ def test_conj_prev_and_gardner_frequency_space(ctx, sdo):
 # ------------------------------------------------------------------------------------------
 # gangs: heterogeneous 1-channel banks side by side -- bit exact against each bank's own oracle
 # ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pinned", [False, True])
+def test_rows_deliver_hands_every_row_over(ctx, pinned):
+    """one launch: fixed-length rows and counter-driven rows to device or host-mapped landing zones; counters cleared"""
+    rng = np.random.default_rng(3)
+    n = 70
+    lens = rng.integers(0, 9000, n)
+    lens[:4] = [0, 1, 1024, 1025]
+    rows = [dev((rng.standard_normal(int(L_) + 5) + 1j * rng.standard_normal(int(L_) + 5)).astype(np.complex64)) for L_ in lens]
+    counters = [torch.tensor([int(L_)], dtype=torch.int32, device="cuda") if i % 2 else int(L_) for i, L_ in enumerate(lens)]
+    mk = (lambda k, dt: torch.zeros(k, dtype=dt).pin_memory()) if pinned else (lambda k, dt: torch.zeros(k, dtype=dt, device="cuda"))
+    dsts = [mk(int(L_) + 5, torch.complex64) for L_ in lens]
+    outs = [mk(1, torch.int32) for _ in range(n)]
+    engine.rows_deliver(ctx, rows, counters, dsts, outs)
+    torch.cuda.synchronize()
+    for i, L_ in enumerate(lens):
+        assert int(outs[i][0]) == L_
+        assert_bits(host(dsts[i][:L_]), host(rows[i][:L_]), f"row {i}")
+        assert not host(dsts[i][L_:]).any(), "nothing past the count is written"
+        if i % 2:
+            assert int(counters[i][0]) == 0, "a device counter is cleared for the next block"
+
+
 @pytest.mark.parametrize("parts", [1, 4, 7])
 def test_agc_gang_in_sub_ranges_bit_exact(ctx, sdo, parts):
     """pre -> {level, apply} per sub-range -> finish == suamd_agc_gang_feed == the oracle's su_agc_feed loop,
