@@ -130,6 +130,13 @@ SUAMD_API SUSCOUNT suamd_chanbank_output_count(const suamd_chanbank_t *bank, SUS
 SUAMD_API SUBOOL suamd_chanbank_feed(suamd_chanbank_t *bank, const suamd_complex *d_x, SUSCOUNT len,
                                      suamd_complex *d_y, suamd_view yv, SUSCOUNT *n_out, void *stream);
 SUAMD_API SUBOOL suamd_chanbank_reset(suamd_chanbank_t *bank, void *stream);
+/* Many 1-channel banks (each its own centre frequency, decimation, taps and stream position) fed the SAME wideband
+ * block in one launch -- the analyzer's inspectors, which all channelise the block the source just delivered
+ * (suscan's inspector scheduler, Suscan/Analyzer.h:137-168).  d_y[i]: contiguous output row of bank i, n_out[i]
+ * (may be NULL) its number of output samples.  Identical to n suamd_chanbank_feed calls. */
+SUAMD_API SUBOOL suamd_chanbank_gang_feed(suamd_ctx_t *ctx, suamd_chanbank_t *const *banks, unsigned n,
+                                          const suamd_complex *d_x, SUSCOUNT len, suamd_complex *const *d_y,
+                                          SUSCOUNT *n_out, void *stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* T5 / T7 / T11: element-wise demodulators (batched: nchan rows of len samples)         */

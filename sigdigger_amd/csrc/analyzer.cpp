@@ -597,16 +597,22 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
       if (!build_chain(a, in, err)) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, err); continue; }
       in.dirty = false;
     }
-    const suamd_view row = {(SUSCOUNT)in.cap, 1};
-    SUSCOUNT m = 0;
-    if (!suamd_chanbank_feed(in.bank, a->d_x, len, in.d_y, row, &m, sA)) continue;
-    in.pend_m = m;
-    in.pend_src = in.d_y;
-    if (in.spectsrc_id) enqueue_spectrum(a, in, m);
     live.push_back(&in);
   }
   if (live.empty()) return;
   auto fail = [&](const char *what) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string(what) + ": " + suamd_last_error()); };
+  {
+    // every inspector channelises the same wideband block: one launch for all of them
+    std::vector<suamd_chanbank_t *> fb; std::vector<suamd_complex *> fy; std::vector<SUSCOUNT> fm(live.size());
+    for (Inspector *pi : live) { fb.push_back(pi->bank); fy.push_back(pi->d_y); }
+    if (!suamd_chanbank_gang_feed(a->ctx, fb.data(), (unsigned)fb.size(), a->d_x, len, fy.data(), fm.data(), sA)) { fail("channeliser"); return; }
+    for (size_t i = 0; i < live.size(); ++i) {
+      Inspector &in = *live[i];
+      in.pend_m = fm[i];
+      in.pend_src = in.d_y;
+      if (in.spectsrc_id) enqueue_spectrum(a, in, fm[i]);
+    }
+  }
   auto sub = [&](const Inspector &in, int j) { return (SUSCOUNT)((unsigned long long)in.pend_m * (unsigned)j / P); };
   // per inspector: the row every stage reads and the one it writes (ping-pong d_a / d_z, nothing runs in place)
   struct Route { const suamd_complex *agc_in, *car_in, *mf_in, *clk_in; suamd_complex *agc_out, *car_out, *mf_out; };

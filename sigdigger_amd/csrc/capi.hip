@@ -487,6 +487,42 @@ SUBOOL suamd_chanbank_feed(suamd_chanbank_t *b, const suamd_complex *d_x, SUSCOU
   return SU_TRUE;
 }
 
+SUBOOL suamd_chanbank_gang_feed(suamd_ctx_t *ctx, suamd_chanbank_t *const *banks, unsigned n, const suamd_complex *d_x, SUSCOUNT len,
+                                suamd_complex *const *d_y, SUSCOUNT *n_out, void *stream)
+{
+  if (!ctx || (n && (!banks || !d_y))) { set_err("null argument"); return SU_FALSE; }
+  if (len == 0) { for (unsigned i = 0; n_out && i < n; ++i) n_out[i] = 0; return SU_TRUE; }
+  if (!d_x) { set_err("null argument"); return SU_FALSE; }
+  hipStream_t st = as_stream(stream);
+  std::vector<sdk::ChanGangItem> items(n);
+  unsigned max_tiles = 0, max_lds = 0;
+  for (unsigned i = 0; i < n; ++i) {
+    suamd_chanbank *b = banks[i];
+    if (!b || b->nchan != 1) { set_err("gang members must be 1-channel banks"); return SU_FALSE; }
+    if (!d_y[i]) { set_err("null row"); return SU_FALSE; }
+    uint64_t mf; SUSCOUNT no;
+    chan_out_range(b, len, &mf, &no);
+    sdk::ChanFeedArgs a;
+    a.x = d_x; a.hist = b->d_hist[b->hist_cur]; a.hist_next = b->d_hist[b->hist_cur ^ 1];
+    a.len = (long long)len; a.n0 = b->n_total;
+    a.g = b->d_g; a.dphase = b->d_dphase; a.phase0 = b->d_phase0;
+    a.ntaps = (int)b->ntaps; a.nchan = 1; a.D = b->D;
+    a.m_first = mf; a.n_out = (long long)no; a.y = d_y[i]; a.yv = sdk::View{0, 1};
+    if (sdk::chan_gang_plan(a, &items[i]) != hipSuccess) { set_err("bank %u does not fit the gang kernel (decimation %u, %u taps)", i, b->D, b->ntaps); return SU_FALSE; }
+    max_tiles = std::max(max_tiles, items[i].ntiles);
+    max_lds = std::max(max_lds, items[i].lds);
+    if (n_out) n_out[i] = no;
+  }
+  for (size_t o = 0; o < items.size(); o += 256) {
+    std::vector<sdk::ChanGangItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 256));
+    sdk::ChanGangItem *d = gang_upload(ctx, part, st);
+    if (!d) return SU_FALSE;
+    HIP_TRY(sdk::chan_gang_feed(d, (int)part.size(), max_tiles, max_lds, st), SU_FALSE);
+  }
+  for (unsigned i = 0; i < n; ++i) { banks[i]->hist_cur ^= 1; banks[i]->n_total += len; }
+  return SU_TRUE;
+}
+
 SUBOOL suamd_chanbank_reset(suamd_chanbank_t *b, void *stream)
 {
   if (!b) { set_err("null argument"); return SU_FALSE; }
@@ -1235,14 +1271,24 @@ SUBOOL suamd_agc_gang_pre(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsi
                           const SUSCOUNT *len, void *stream)
 {
   if (!ctx || (n && (!banks || !d_x || !len))) { set_err("null argument"); return SU_FALSE; }
-  const suamd_view row = {0, 1};
+  hipStream_t st = as_stream(stream);
+  std::vector<sdk::AgcPreItem> items;
+  long long span = 0;
   for (unsigned i = 0; i < n; ++i) {
     suamd_agc_bank *b = banks[i];
     if (!b || b->nchan != 1) { set_err("gang members must be 1-channel banks"); return SU_FALSE; }
     if (len[i] == 0) continue;
     if (!d_x[i]) { set_err("null row"); return SU_FALSE; }
     if (!b->scratch.reserve(2 * sizeof(float) * (size_t)len[i])) { set_err("scratch allocation failed"); return SU_FALSE; }
-    HIP_TRY(sdk::agc_feed_pre(b->p, b->s, 1, d_x[i], as_view(row), (long long)len[i], static_cast<float *>(b->scratch.p), as_stream(stream)), SU_FALSE);
+    float *db = static_cast<float *>(b->scratch.p);
+    items.push_back(sdk::AgcPreItem{d_x[i], b->s.mag_history, db, db + len[i], (long long)len[i], (int)b->p.mag_history_size});
+    span = std::max(span, (long long)len[i]);
+  }
+  for (size_t o = 0; o < items.size(); o += 512) {
+    std::vector<sdk::AgcPreItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
+    sdk::AgcPreItem *d = gang_upload(ctx, part, st);
+    if (!d) return SU_FALSE;
+    HIP_TRY(sdk::agc_pre_items(d, (int)part.size(), span, st), SU_FALSE);
   }
   return SU_TRUE;
 }
@@ -1318,13 +1364,21 @@ SUBOOL suamd_agc_gang_finish(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, u
                              const SUSCOUNT *len, void *stream)
 {
   if (!ctx || (n && (!banks || !d_x || !len))) { set_err("null argument"); return SU_FALSE; }
-  const suamd_view row = {0, 1};
+  hipStream_t st = as_stream(stream);
+  std::vector<sdk::AgcStateItem> items;
   for (unsigned i = 0; i < n; ++i) {
     suamd_agc_bank *b = banks[i];
     if (!b || len[i] == 0) continue;
-    HIP_TRY(sdk::agc_state_update(b->p, b->s, 1, d_x[i], as_view(row), (long long)len[i], static_cast<const float *>(b->scratch.p),
-                                  as_stream(stream)), SU_FALSE);
+    if (!d_x[i] || !b->scratch.p) { set_err("null row"); return SU_FALSE; }
+    items.push_back(sdk::AgcStateItem{b->s.delay_line, b->s.mag_history, d_x[i], static_cast<const float *>(b->scratch.p), (long long)len[i],
+                                      (int)b->p.delay_line_size, (int)b->p.mag_history_size});
     b->n_fed += len[i];
+  }
+  for (size_t o = 0; o < items.size(); o += 512) {
+    std::vector<sdk::AgcStateItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
+    sdk::AgcStateItem *d = gang_upload(ctx, part, st);
+    if (!d) return SU_FALSE;
+    HIP_TRY(sdk::agc_state_items(d, (int)part.size(), st), SU_FALSE);
   }
   return SU_TRUE;
 }
@@ -1333,32 +1387,12 @@ SUBOOL suamd_agc_gang_feed(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, uns
                            suamd_complex *const *d_y, const SUSCOUNT *len, void *stream)
 {
   if (!ctx || (n && (!banks || !d_x || !d_y || !len))) { set_err("null argument"); return SU_FALSE; }
-  hipStream_t st = as_stream(stream);
-  const suamd_view row = {0, 1};
-  std::vector<sdk::AgcGangItem> items;
-  for (unsigned i = 0; i < n; ++i) {
-    suamd_agc_bank *b = banks[i];
-    if (!b || b->nchan != 1) { set_err("gang members must be 1-channel banks"); return SU_FALSE; }
-    if (len[i] == 0) continue;
-    if (!d_x[i] || !d_y[i] || d_x[i] == d_y[i]) { set_err("null or aliased row"); return SU_FALSE; }
-    if (!b->scratch.reserve(2 * sizeof(float) * (size_t)len[i])) { set_err("scratch allocation failed"); return SU_FALSE; }
-    HIP_TRY(sdk::agc_feed_pre(b->p, b->s, 1, d_x[i], as_view(row), (long long)len[i], static_cast<float *>(b->scratch.p), st), SU_FALSE);
-    items.push_back(sdk::AgcGangItem{b->p, b->s, static_cast<float *>(b->scratch.p) + len[i], (long long)len[i]});
-  }
-  for (size_t o = 0; o < items.size(); o += 512) {                             // the level trackers of all banks, one lane each
-    std::vector<sdk::AgcGangItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
-    sdk::AgcGangItem *d = gang_upload(ctx, part, st);
-    if (!d) return SU_FALSE;
-    HIP_TRY(sdk::agc_level_gang(d, (int)part.size(), st), SU_FALSE);
-  }
-  for (unsigned i = 0; i < n; ++i) {
-    suamd_agc_bank *b = banks[i];
-    if (len[i] == 0) continue;
-    HIP_TRY(sdk::agc_feed_post(b->p, b->s, 1, d_x[i], as_view(row), d_y[i], as_view(row), (long long)len[i],
-                               static_cast<float *>(b->scratch.p), st), SU_FALSE);
-    b->n_fed += len[i];
-  }
-  return SU_TRUE;
+  for (unsigned i = 0; i < n; ++i)
+    if (len[i] && (!d_x[i] || !d_y[i] || d_x[i] == d_y[i])) { set_err("null or aliased row"); return SU_FALSE; }
+  const std::vector<SUSCOUNT> zero(n, 0);                    // the whole block as one sub-range: five launches in all
+  return suamd_agc_gang_pre(ctx, banks, n, d_x, len, stream) && suamd_agc_gang_level(ctx, banks, n, len, zero.data(), len, stream) &&
+         suamd_agc_gang_apply(ctx, banks, n, d_x, d_y, len, zero.data(), len, stream) &&
+         suamd_agc_gang_finish(ctx, banks, n, d_x, len, stream) ? SU_TRUE : SU_FALSE;
 }
 
 // ---- whole-capture FFT tasks ------------------------------------------------------------------------

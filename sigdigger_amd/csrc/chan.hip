@@ -83,14 +83,7 @@ __global__ void modulate_taps_kernel(const float *__restrict__ h, int ntaps, con
 }
 
 // ---------------------------------------------------------------------------------------
-struct FirGeom {
-  int D, ntaps, nchan;
-  int MT;            // outputs per workgroup tile (multiple of 64)
-  int KD;            // ceil((ntaps-1)/D)*D : window starts KD samples before the tile's first output
-  int span;          // samples staged = MT*D + KD   (window index i <-> absolute n = nbase + i)
-  int PAD;           // LDS index of window sample i = i + (i / D) * PAD, with D + PAD odd
-  int lds_samples;   // padded window size in samples
-};
+using sdk::FirGeom;
 
 constexpr int FIR_THREADS = 512;   // 8 waves share one staged window
 
@@ -164,14 +157,15 @@ __device__ __forceinline__ void fir_mac(v2f (&acc)[NCH][NOUT], const FirChunk<NC
 // NOUT: outputs per lane (64 apart); DB: double-buffer the chunks (not when the taps of two chunks
 // would not fit the SGPR file).
 template <int NCH, int NOUT, int TC, bool LDS_TAPS, bool DB>
-__global__ __launch_bounds__(FIR_THREADS) void chan_fir_kernel(const float2 *__restrict__ x, const float2 *__restrict__ hist,
-                                                       float2 *__restrict__ hist_next,
-                                                       long long len, uint64_t n0,
-                                                       const float4 *__restrict__ g,
-                                                       const uint32_t *__restrict__ dphase,
-                                                       const uint32_t *__restrict__ phase0, FirGeom ge,
-                                                       uint64_t m_first, long long n_out,
-                                                       float2 *__restrict__ y, sdk::View yv)
+__device__ __forceinline__ void chan_fir_body(const float2 *__restrict__ x, const float2 *__restrict__ hist,
+                                              float2 *__restrict__ hist_next,
+                                              long long len, uint64_t n0,
+                                              const float4 *__restrict__ g,
+                                              const uint32_t *__restrict__ dphase,
+                                              const uint32_t *__restrict__ phase0, const FirGeom &ge,
+                                              uint64_t m_first, long long n_out,
+                                              float2 *__restrict__ y, sdk::View yv,
+                                              const unsigned tile, const unsigned ntiles)   // this workgroup's tile of the feed
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2 *win = reinterpret_cast<float2 *>(smem);
@@ -183,13 +177,13 @@ __global__ __launch_bounds__(FIR_THREADS) void chan_fir_kernel(const float2 *__r
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x;
   const int D = ge.D, T = ge.ntaps, PAD = ge.PAD;
-  const long long tile_m0 = (long long)blockIdx.x * ge.MT;           // relative to m_first
+  const long long tile_m0 = (long long)tile * ge.MT;                 // relative to m_first
   const long long nbase = (long long)(m_first + (uint64_t)tile_m0) * D - ge.KD;   // absolute index of window sample 0
   const int span = ge.span;
   const long long hist0 = (long long)n0 - (T - 1);                    // absolute index of hist[0]
 
   // ---- carry: history for the next block = last T-1 samples of [hist ; x] (ping-pong buffer) ----
-  if (blockIdx.x == gridDim.x - 1) {
+  if (tile == ntiles - 1) {
     const int hl = T - 1;
     for (int i = tid; i < hl; i += FIR_THREADS) {
       const long long src = (long long)i + len;                       // index into [hist ; x]
@@ -356,6 +350,99 @@ __global__ __launch_bounds__(FIR_THREADS) void chan_fir_kernel(const float2 *__r
   }
 }
 
+// Decimations whose 64-output window does not fit LDS (D > ~300 at 255 taps: a narrow channel in a wide capture).
+// There the outputs are sparse -- each needs ntaps samples out of every D -- so nothing is staged: a lane owns one
+// (output, channel), walks its taps in the SPEC's order straight from memory (8 consecutive taps share a cache
+// line) and de-rotates.  Same operations per output as chan_fir_body, so the same bits.
+__device__ __forceinline__ void chan_fir_sparse_body(const float2 *__restrict__ x, const float2 *__restrict__ hist,
+                                                     float2 *__restrict__ hist_next, long long len, uint64_t n0,
+                                                     const float4 *__restrict__ g, const uint32_t *__restrict__ dphase,
+                                                     const uint32_t *__restrict__ phase0, int D, int T, int nchan,
+                                                     uint64_t m_first, long long n_out, float2 *__restrict__ y, sdk::View yv,
+                                                     const unsigned tile, const unsigned ntiles)
+{
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x;
+  if (tile == ntiles - 1) {
+    const int hl = T - 1;
+    for (int i = tid; i < hl; i += FIR_THREADS) {
+      const long long src = (long long)i + len;                       // index into [hist ; x]
+      hist_next[i] = src < hl ? hist[src] : x[src - hl];
+    }
+  }
+  const long long t = (long long)tile * FIR_THREADS + tid;
+  if (t >= n_out * nchan) return;
+  const int c = (int)(t / n_out);
+  const long long m_rel = t - (long long)c * n_out;
+  const uint64_t n = (m_first + (uint64_t)m_rel) * (uint64_t)D;
+  const long long hist0 = (long long)n0 - (T - 1);
+  const float4 *gc = g + (long long)c * T;
+  v2f acc = {0.0f, 0.0f};
+  for (int k = 0; k < T; ++k) {
+    const long long q = (long long)n - k;
+    float2 w = float2{0.0f, 0.0f};
+    if (q >= (long long)n0) { if (q < (long long)n0 + len) w = x[q - (long long)n0]; }
+    else if (q >= hist0) w = hist[q - hist0];
+    acc = tap_mac(acc, gc[k], v2f{w.x, w.y});
+  }
+  float cs, sn;
+  sd::phasor_u32(phase0[c] + (uint32_t)(n * (uint64_t)dphase[c]), cs, sn);
+  const c32 r2 = sd::cmul_cs(c32{acc.x, acc.y}, cs, sn);
+  y[(long long)c * yv.cs + m_rel * yv.ms] = float2{r2.re, r2.im};
+}
+
+__global__ __launch_bounds__(FIR_THREADS) void chan_fir_sparse_kernel(const float2 *__restrict__ x, const float2 *__restrict__ hist,
+                                                              float2 *__restrict__ hist_next, long long len, uint64_t n0,
+                                                              const float4 *__restrict__ g, const uint32_t *__restrict__ dphase,
+                                                              const uint32_t *__restrict__ phase0, int D, int T, int nchan,
+                                                              uint64_t m_first, long long n_out, float2 *__restrict__ y, sdk::View yv)
+{
+  chan_fir_sparse_body(x, hist, hist_next, len, n0, g, dphase, phase0, D, T, nchan, m_first, n_out, y, yv, blockIdx.x, gridDim.x);
+}
+
+template <int NCH, int NOUT, int TC, bool LDS_TAPS, bool DB>
+__global__ __launch_bounds__(FIR_THREADS) void chan_fir_kernel(const float2 *__restrict__ x, const float2 *__restrict__ hist,
+                                                       float2 *__restrict__ hist_next,
+                                                       long long len, uint64_t n0,
+                                                       const float4 *__restrict__ g,
+                                                       const uint32_t *__restrict__ dphase,
+                                                       const uint32_t *__restrict__ phase0, FirGeom ge,
+                                                       uint64_t m_first, long long n_out,
+                                                       float2 *__restrict__ y, sdk::View yv)
+{
+  chan_fir_body<NCH, NOUT, TC, LDS_TAPS, DB>(x, hist, hist_next, len, n0, g, dphase, phase0, ge, m_first, n_out, y, yv,
+                                             blockIdx.x, gridDim.x);
+}
+
+// the feeds of many 1-channel banks side by side (the live analyzer's inspectors, all reading the same wideband
+// block): grid.y = bank, grid.x covers the longest feed; everything a workgroup needs is uniform -> scalar loads
+__global__ __launch_bounds__(FIR_THREADS) void chan_fir_gang_kernel(const sdk::ChanGangItem *__restrict__ items)
+{
+  const sdk::ChanGangItem &it = items[blockIdx.y];
+  const sdk::ChanFeedArgs &a = it.a;
+  if (it.ntiles == 0 && blockIdx.x == 0) {                            // a feed too short for an output: history only
+    const int hl = a.ntaps - 1;
+    const float2 *hist = reinterpret_cast<const float2 *>(a.hist), *x = reinterpret_cast<const float2 *>(a.x);
+    float2 *hist_next = reinterpret_cast<float2 *>(a.hist_next);
+    for (int i = threadIdx.x; i < hl; i += FIR_THREADS) {
+      const long long src = (long long)i + a.len;
+      hist_next[i] = src < hl ? hist[src] : x[src - hl];
+    }
+  }
+  if (blockIdx.x >= it.ntiles) return;
+  if (it.sparse) {
+    chan_fir_sparse_body(reinterpret_cast<const float2 *>(a.x), reinterpret_cast<const float2 *>(a.hist),
+                         reinterpret_cast<float2 *>(a.hist_next), a.len, a.n0, reinterpret_cast<const float4 *>(a.g),
+                         a.dphase, a.phase0, (int)a.D, a.ntaps, 1, a.m_first, a.n_out, reinterpret_cast<float2 *>(a.y), a.yv,
+                         blockIdx.x, it.ntiles);
+    return;
+  }
+  chan_fir_body<1, 1, 8, true, true>(reinterpret_cast<const float2 *>(a.x), reinterpret_cast<const float2 *>(a.hist),
+                                     reinterpret_cast<float2 *>(a.hist_next), a.len, a.n0, reinterpret_cast<const float4 *>(a.g),
+                                     a.dphase, a.phase0, it.ge, a.m_first, a.n_out, reinterpret_cast<float2 *>(a.y), a.yv,
+                                     blockIdx.x, it.ntiles);
+}
+
 // new history = last (ntaps-1) samples of [old hist ; x]   (only used when a feed produces no output;
 // otherwise the last FIR workgroup writes it)
 __global__ void update_hist_kernel(float2 *__restrict__ hist_next, const float2 *__restrict__ hist,
@@ -414,10 +501,13 @@ hipError_t chan_modulate_taps(const float *h, int ntaps, const uint32_t *dphase,
   return hipGetLastError();
 }
 
-hipError_t chan_feed(const ChanFeedArgs &a, hipStream_t st)
+namespace {
+struct FirPlan { FirGeom ge; size_t lds; unsigned ntiles; int nch, nout; bool lds_taps, sparse; };
+}
+
+static hipError_t fir_plan(const ChanFeedArgs &a, FirPlan &pl)
 {
-  if (a.n_out <= 0) return chan_update_hist(a.hist_next, a.hist, a.x, a.len, a.ntaps, st);
-  FirGeom ge;
+  FirGeom &ge = pl.ge;
   ge.D = (int)a.D; ge.ntaps = a.ntaps; ge.nchan = a.nchan;
   ge.KD = ((a.ntaps - 1 + ge.D - 1) / ge.D) * ge.D;
   ge.PAD = (ge.D & 1) ? 0 : 1;                                      // D + PAD odd
@@ -447,8 +537,35 @@ hipError_t chan_feed(const ChanFeedArgs &a, hipStream_t st)
   ge.lds_samples = ge.span + (ge.span / ge.D + 1) * ge.PAD;
   size_t lds = (((size_t)ge.lds_samples + 1) & ~(size_t)1) * sizeof(float2);
   if (lds_taps) lds += (size_t)a.nchan * a.ntaps * sizeof(float4);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;               // decimation too large for one tile
-  const unsigned ntiles = (unsigned)((a.n_out + ge.MT - 1) / ge.MT);
+  pl.sparse = false;
+  if (lds > 160 * 1024) {                                          // the window of 64 outputs does not fit: sparse outputs
+    pl.sparse = true; pl.lds = 0; pl.nch = nch; pl.nout = 1; pl.lds_taps = false;
+    pl.ntiles = (unsigned)((a.n_out * a.nchan + FIR_THREADS - 1) / FIR_THREADS);
+    return hipSuccess;
+  }
+  pl.lds = lds; pl.ntiles = (unsigned)((a.n_out + ge.MT - 1) / ge.MT);
+  pl.nch = nch; pl.nout = nout; pl.lds_taps = lds_taps;
+  return hipSuccess;
+}
+
+hipError_t chan_feed(const ChanFeedArgs &a, hipStream_t st)
+{
+  if (a.n_out <= 0) return chan_update_hist(a.hist_next, a.hist, a.x, a.len, a.ntaps, st);
+  FirPlan pl;
+  hipError_t e = fir_plan(a, pl);
+  if (e != hipSuccess) return e;
+  const FirGeom &ge = pl.ge;
+  const size_t lds = pl.lds;
+  const unsigned ntiles = pl.ntiles;
+  const int nch = pl.nch, nout = pl.nout;
+  const bool lds_taps = pl.lds_taps;
+  if (pl.sparse) {
+    hipLaunchKernelGGL(chan_fir_sparse_kernel, dim3(ntiles), dim3(FIR_THREADS), 0, st,
+                       reinterpret_cast<const float2 *>(a.x), reinterpret_cast<const float2 *>(a.hist),
+                       reinterpret_cast<float2 *>(a.hist_next), a.len, a.n0, reinterpret_cast<const float4 *>(a.g), a.dphase,
+                       a.phase0, (int)a.D, a.ntaps, a.nchan, a.m_first, a.n_out, reinterpret_cast<float2 *>(a.y), a.yv);
+    return hipGetLastError();
+  }
 #define SD_FIR(NCH_, NOUT_, TC_, LT_, DB_) return launch_fir<NCH_, NOUT_, TC_, LT_, DB_>(a, ge, lds, ntiles, st)
   if (lds_taps) {                                                   // taps from LDS: chunks double-buffered
     if (nout == 2) { if (nch == 4) SD_FIR(4, 2, 2, true, true); if (nch == 2) SD_FIR(2, 2, 4, true, true); SD_FIR(1, 2, 8, true, true); }
@@ -462,6 +579,41 @@ hipError_t chan_feed(const ChanFeedArgs &a, hipStream_t st)
   if (nout == 2) { if (nch == 4) SD_FIR(4, 2, 4, false, false); if (nch == 2) SD_FIR(2, 2, 4, false, true); SD_FIR(1, 2, 8, false, true); }
   if (nch == 4) SD_FIR(4, 1, 4, false, false); if (nch == 2) SD_FIR(2, 1, 4, false, true); SD_FIR(1, 1, 8, false, true);
 #undef SD_FIR
+}
+
+hipError_t chan_gang_plan(const ChanFeedArgs &a, ChanGangItem *item)
+{
+  if (a.nchan != 1) return hipErrorInvalidValue;
+  item->a = a;
+  item->ntiles = 0;
+  item->lds = 0;
+  item->sparse = 0;
+  item->ge = FirGeom{};
+  item->ge.ntaps = a.ntaps;
+  if (a.n_out <= 0) return hipSuccess;                               // only the history moves on
+  FirPlan pl;
+  hipError_t e = fir_plan(a, pl);
+  if (e != hipSuccess) return e;
+  if (!pl.sparse && (pl.nch != 1 || pl.nout != 1 || !pl.lds_taps)) {          // the gang kernel has the one tiled variant:
+    pl.sparse = true; pl.lds = 0;                                             // anything else (> 1024 taps) walks its taps
+    pl.ntiles = (unsigned)((a.n_out + FIR_THREADS - 1) / FIR_THREADS);
+  }
+  item->ge = pl.ge; item->ntiles = pl.ntiles; item->lds = (unsigned)pl.lds; item->sparse = pl.sparse ? 1 : 0;
+  return hipSuccess;
+}
+
+hipError_t chan_gang_feed(const ChanGangItem *d_items, int n, unsigned max_tiles, unsigned max_lds, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  static size_t attr_lds = 0;
+  if (max_lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chan_fir_gang_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+    if (e != hipSuccess) return e;
+    attr_lds = max_lds;
+  }
+  hipLaunchKernelGGL(chan_fir_gang_kernel, dim3(max_tiles ? max_tiles : 1, (unsigned)n), dim3(FIR_THREADS), max_lds, st, d_items);
+  return hipGetLastError();
 }
 
 hipError_t chan_update_hist(void *hist_next, const void *hist, const void *x, long long len, int ntaps, hipStream_t st)

@@ -43,6 +43,20 @@ struct ChanFeedArgs {
   View        yv;
 };
 hipError_t chan_feed(const ChanFeedArgs &a, hipStream_t st);
+// tiling of one feed (chan.hip plans it)
+struct FirGeom {
+  int D, ntaps, nchan;
+  int MT;            // outputs per workgroup tile (multiple of 64)
+  int KD;            // ceil((ntaps-1)/D)*D : window starts KD samples before the tile's first output
+  int span;          // samples staged = MT*D + KD   (window index i <-> absolute n = nbase + i)
+  int PAD;           // LDS index of window sample i = i + (i / D) * PAD, with D + PAD odd
+  int lds_samples;   // padded window size in samples
+};
+// many 1-channel banks (their own taps, carrier, decimation, state) fed in ONE launch, grid.y = bank:
+// chan_gang_plan fills an item per bank, the caller puts the table on the device, chan_gang_feed launches
+struct ChanGangItem { ChanFeedArgs a; FirGeom ge; unsigned ntiles; unsigned lds; int sparse; };
+hipError_t chan_gang_plan(const ChanFeedArgs &a, ChanGangItem *item);
+hipError_t chan_gang_feed(const ChanGangItem *d_items, int n, unsigned max_tiles, unsigned max_lds, hipStream_t st);
 hipError_t chan_update_hist(void *hist_next, const void *hist, const void *x, long long len, int ntaps, hipStream_t st);
 
 // ---- loops.hip ----
@@ -122,6 +136,11 @@ hipError_t agc_apply_items(const AgcApplyItem *d_items, int n, long long max_spa
 hipError_t agc_state_update(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv, long long len,
                             const float *db, hipStream_t st);
 hipError_t agc_level_gang(const AgcGangItem *d_items, int n, hipStream_t st);
+// steps (1)+(2) and (5) of agc_feed for many 1-channel banks with contiguous rows: one launch each
+struct AgcPreItem { const void *x; const float *hist; float *db, *peak; long long len; int H; };
+struct AgcStateItem { float *delay_line, *hist; const void *x; const float *db; long long len; int delay, H; };
+hipError_t agc_pre_items(const AgcPreItem *d_items, int n, long long max_len, hipStream_t st);
+hipError_t agc_state_items(const AgcStateItem *d_items, int n, hipStream_t st);
 
 // rows -> landing zones (host-mapped or device), grid.x = item: n = count ? *count : fixed samples of src go to dst,
 // n to *count_out; count (a device counter the producer accumulates into) is cleared for the next block

@@ -557,6 +557,58 @@ __global__ __launch_bounds__(256) void agc_peak1_kernel(const float *__restrict_
   peak[m] = pk;
 }
 
+// (1)+(2) for the items of a gang: a workgroup takes tiles of 256 outputs of its item, stages the 256 + H - 1
+// magnitudes they look at in LDS (the history stands in before the row's start) and scans them in the order
+// agc_peak1_kernel does.  Same operations per value, so the same bits.
+__global__ __launch_bounds__(256) void agc_pre_items_kernel(const sdk::AgcPreItem *__restrict__ items)
+{
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ float t[256 + 63];
+  const sdk::AgcPreItem it = items[blockIdx.y];
+  const float2 *x = static_cast<const float2 *>(it.x);
+  const int hl = it.H - 1;
+  for (long long m0 = (long long)blockIdx.x * 256; m0 < it.len; m0 += (long long)gridDim.x * 256) {
+    for (int r = threadIdx.x; r < 256 + hl; r += 256) {
+      const long long q = m0 - hl + r;
+      float v = 0.f;
+      if (q < 0) v = it.hist[q + hl];
+      else if (q < it.len) {
+        const float2 s = x[q];
+        v = 3.01029995663981195f * sd::log2_(sd::fma_(s.x, s.x, s.y * s.y) + 1e-8f);
+        if (q >= m0) it.db[q] = v;
+      }
+      t[r] = v;
+    }
+    __syncthreads();
+    const long long m = m0 + threadIdx.x;
+    if (m < it.len) {
+      float pk = t[threadIdx.x + hl];
+      for (int i = 1; i <= hl; ++i) {
+        const float v = t[threadIdx.x + hl - i];
+        pk = pk > v ? pk : v;
+      }
+      it.peak[m] = pk;
+    }
+    __syncthreads();
+  }
+}
+
+// (5) for the items of a gang: lane i carries delay-line slot i and history slot i (both at most 64 long)
+__global__ __launch_bounds__(64) void agc_state_items_kernel(const sdk::AgcStateItem *__restrict__ items)
+{
+  const sdk::AgcStateItem it = items[blockIdx.x];
+  const float2 *x = static_cast<const float2 *>(it.x);
+  const int i = threadIdx.x, hl = it.H - 1;
+  const long long src = (long long)i + it.len;
+  float2 d = {0.f, 0.f};
+  float h = 0.f;
+  if (i < it.delay) d = src < it.delay ? float2{it.delay_line[src * 2 + 0], it.delay_line[src * 2 + 1]} : x[src - it.delay];
+  if (i < hl) h = src < hl ? it.hist[src] : it.db[src - hl];
+  __syncthreads();                                        // every slot is read before any is overwritten
+  if (i < it.delay) { it.delay_line[i * 2 + 0] = d.x; it.delay_line[i * 2 + 1] = d.y; }
+  if (i < hl) it.hist[i] = h;
+}
+
 __global__ __launch_bounds__(64) void agc_level_kernel(sdk::AgcParams p, sdk::AgcState s, int nchan,
                                                        long long len, float *__restrict__ peak)
 {
@@ -1087,6 +1139,20 @@ hipError_t agc_state_update(const AgcParams &p, const AgcState &s, int nchan, co
   if (len <= 0 || nchan <= 0) return hipSuccess;
   hipLaunchKernelGGL(agc_state_kernel, dim3((nchan + 63) / 64), dim3(64), 0, st, s.delay_line, s.mag_history, nchan,
                      (int)p.delay_line_size, (int)p.mag_history_size, reinterpret_cast<const float2 *>(x), xv, db, len);
+  return hipGetLastError();
+}
+
+hipError_t agc_pre_items(const AgcPreItem *d_items, int n, long long max_len, hipStream_t st)
+{
+  if (n <= 0 || max_len <= 0) return hipSuccess;
+  hipLaunchKernelGGL(agc_pre_items_kernel, dim3(grid_for(max_len, 256), (unsigned)n), dim3(256), 0, st, d_items);
+  return hipGetLastError();
+}
+
+hipError_t agc_state_items(const AgcStateItem *d_items, int n, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(agc_state_items_kernel, dim3((unsigned)n), dim3(64), 0, st, d_items);
   return hipGetLastError();
 }
 

@@ -445,6 +445,20 @@ def _ptr_array(ptrs):
     return (C.c_void_p * len(ptrs))(*ptrs)
 
 
+def gang_chan(ctx, banks, x, outs, stream=None):
+    """suamd_chanbank_gang_feed: 1-channel ChannelBanks (own carrier / decimation / taps / stream position) fed the
+    same block x in one launch; outs[i]: contiguous 1-D complex64 row.  Returns the rows trimmed to their output counts."""
+    _chk_c64(x, "x")
+    n = len(banks)
+    nout = (C.c_uint64 * n)()
+    for b, o in zip(banks, outs):
+        if o.numel() < b.output_count(x.numel()):
+            raise SigDiggerAmdError("output row too short")
+    check(ctx.lib.suamd_chanbank_gang_feed(ctx.h, _ptr_array([b.h for b in banks]), n, _ptr(x), x.numel(),
+                                           _ptr_array([_ptr(o) for o in outs]), nout, _stream(stream)), "suamd_chanbank_gang_feed")
+    return [o[:int(k)] for o, k in zip(outs, nout)]
+
+
 def gang_costas(ctx, banks, xs, ys, stream=None):
     """banks: 1-channel CostasBanks; xs / ys: contiguous 1-D complex64 rows (own length each)."""
     n = len(banks)

@@ -86,6 +86,7 @@ PROTOTYPES = {
     "suamd_agc_gang_level": (INT, [VP, VP, UINT, VP, VP, VP, VP]),
     "suamd_agc_gang_apply": (INT, [VP, VP, UINT, VP, VP, VP, VP, VP, VP]),
     "suamd_agc_gang_finish": (INT, [VP, VP, UINT, VP, VP, VP]),
+    "suamd_chanbank_gang_feed": (INT, [VP, VP, UINT, VP, U64, VP, VP, VP]),
     "suamd_rows_deliver": (INT, [VP, UINT, VP, VP, VP, VP, VP, VP]),
     "suamd_clock_gang_feed": (INT, [VP, VP, UINT, VP, VP, VP, VP, VP]),
     "suamd_rows_scale": (INT, [VP, VP, View, VP, View, UINT, U64, F32, VP]),

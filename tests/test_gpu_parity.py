@@ -218,7 +218,9 @@ def _oracle_bank(sdo, x, fnors, D, taps, blocks):
 @pytest.mark.parametrize("nchan,D,T", [(1, 16, 255), (3, 64, 255), (8, 64, 255), (5, 1, 31), (2, 7, 64),
                                        (64, 64, 255), (4, 256, 255),
                                        # large banks with ragged channel-group / output counts
-                                       (33, 16, 255), (70, 64, 255), (130, 8, 63), (64, 3, 100), (32, 1, 9)])
+                                       (33, 16, 255), (70, 64, 255), (130, 8, 63), (64, 3, 100), (32, 1, 9),
+                                       # decimations beyond the LDS window: the sparse-output kernel
+                                       (1, 512, 255), (3, 1000, 255), (2, 2048, 64), (5, 333, 255)])
 def test_chanbank_bit_exact(ctx, sdo, nchan, D, T):
     n = 40000 if nchan < 64 else 24000
     fn = synth.raster(nchan, 1.6 / max(nchan, 2))
@@ -238,6 +240,38 @@ def test_chanbank_bit_exact(ctx, sdo, nchan, D, T):
         assert got.shape[1] == len(ref[0]) == (n + D - 1) // D
         for c in range(nchan):
             assert_bits(got[c], ref[c], f"chanbank channel {c} ({layout})")
+
+
+def test_chanbank_gang_bit_exact(ctx, sdo):
+    """many 1-channel banks -- different carriers, decimations (powers of two and not), tap counts -- on the same
+    blocks in one launch each: every row equals the oracle's channel, history and sample clock carried; includes
+    blocks too short for an output and an empty one"""
+    rng = np.random.default_rng(5)
+    nb, n = 70, 50000
+    Ds = rng.choice([1, 3, 16, 64, 100, 128, 500, 1024], nb)
+    Ts = rng.choice([31, 64, 255], nb)
+    fns = rng.uniform(-0.9, 0.9, nb)
+    x = synth.psk_carriers(n, list(fns[:4]), sps=16, seed=23)
+    blocks = [(0, 9000), (9000, 9001), (9001, 9001), (9001, 9003), (9003, 30000), (30000, n)]
+    taps = [sdo.lpf_design(int(T), 0.8 / int(D)) for T, D in zip(Ts, Ds)]
+    banks = [engine.ChannelBank(ctx, [fns[i]], int(Ds[i]), taps[i]) for i in range(nb)]
+    got = [[] for _ in range(nb)]
+    for a, b in blocks:
+        xb = dev(x[a:b]) if b > a else torch.empty(0, dtype=torch.complex64, device="cuda")
+        outs = [torch.empty(bk.output_count(b - a) + 2, dtype=torch.complex64, device="cuda") for bk in banks]
+        ys = engine.gang_chan(ctx, banks, xb, outs)
+        for i in range(nb):
+            got[i].append(host(ys[i]))
+    for i in range(nb):
+        ref = _oracle_bank(sdo, x, fns[i:i + 1], int(Ds[i]), taps[i], blocks)[0]
+        assert_bits(np.concatenate(got[i]), ref, f"gang bank {i} (D = {Ds[i]}, {Ts[i]} taps)")
+    # banks stay usable one by one afterwards (same state as if fed alone)
+    solo = engine.ChannelBank(ctx, [fns[3]], int(Ds[3]), taps[3])
+    for a, b in blocks:
+        if b > a:
+            solo.feed(dev(x[a:b]))
+    tail = dev(synth.tone_noise(4096, f_rel=0.01, sigma2=0.1, seed=9))
+    assert_bits(host(banks[3].feed(tail)), host(solo.feed(tail)), "gang-fed bank continues like a solo one")
 
 
 def test_chanbank_block_size_invariance_large(ctx, sdo):
