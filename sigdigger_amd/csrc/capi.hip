@@ -11,6 +11,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <deque>
 #include <vector>
 
 #include "../../include/sigdigger_amd.h"
@@ -162,8 +163,54 @@ struct suamd_ctx {
     side_ready = true;
     return true;
   }
+  // time-major slabs of the gang launches: a stream-ordered ring.  A region is handed out again only behind the event
+  // its previous user recorded when it was done with it (a device-side wait on the new user's stream: the host
+  // never blocks; hipMallocAsync / hipFreeAsync cost ~240 us per pair here)
+  struct SlabUse { size_t off, size; hipEvent_t ev; };
+  char *slab_base = nullptr;
+  size_t slab_size = 0, slab_head = 0;
+  std::deque<SlabUse> slab_live;
+  std::vector<hipEvent_t> slab_spare;
+  void *slab_take(size_t bytes, hipStream_t st, size_t *off_out)
+  {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes > slab_size) {                                 // grow: rare, and the only place that waits for the device
+      (void)hipDeviceSynchronize();
+      for (SlabUse &u : slab_live) slab_spare.push_back(u.ev);
+      slab_live.clear();
+      if (slab_base) (void)hipFree(slab_base);
+      slab_base = nullptr; slab_size = 0; slab_head = 0;
+      const size_t want = std::max<size_t>((size_t)256 << 20, 8 * bytes);
+      if (hipMalloc((void **)&slab_base, want) != hipSuccess) { slab_base = nullptr; return nullptr; }
+      slab_size = want;
+    }
+    if (slab_head + bytes > slab_size) slab_head = 0;
+    const size_t off = slab_head;
+    slab_head += bytes;
+    for (auto it = slab_live.begin(); it != slab_live.end();) {
+      if (it->off < off + bytes && off < it->off + it->size) {
+        (void)hipStreamWaitEvent(st, it->ev, 0);
+        slab_spare.push_back(it->ev);
+        it = slab_live.erase(it);
+      } else ++it;
+    }
+    *off_out = off;
+    return slab_base + off;
+  }
+  void slab_give(size_t off, size_t bytes, hipStream_t st)
+  {
+    bytes = (bytes + 255) & ~(size_t)255;
+    hipEvent_t ev = nullptr;
+    if (!slab_spare.empty()) { ev = slab_spare.back(); slab_spare.pop_back(); }
+    else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamSynchronize(st); return; }
+    (void)hipEventRecord(ev, st);
+    slab_live.push_back(SlabUse{off, bytes, ev});
+  }
   ~suamd_ctx()
   {
+    for (SlabUse &u : slab_live) (void)hipEventDestroy(u.ev);
+    for (hipEvent_t ev : slab_spare) (void)hipEventDestroy(ev);
+    if (slab_base) (void)hipFree(slab_base);
     if (gang_ring) (void)hipFree(gang_ring);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (int i = 0; i < GANG_SIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
@@ -231,6 +278,32 @@ static Item *gang_upload(suamd_ctx *ctx, const std::vector<Item> &items, hipStre
   ctx->gang_next = (ctx->gang_next + 1) % suamd_ctx::GANG_SLOTS;
   if (hipMemcpyAsync(slot, items.data(), bytes, hipMemcpyHostToDevice, st) != hipSuccess) { set_err("descriptor upload failed"); return nullptr; }
   return reinterpret_cast<Item *>(slot);
+}
+
+// One gang launch on its time-major slab: upload the items, gather their rows, run the recurrence, scatter the results.
+// The slab comes from the context's stream-ordered ring (no host synchronisation, reused across calls).
+template <typename Item, typename Launch>
+static SUBOOL gang_tm(suamd_ctx *ctx, const std::vector<Item> &part, int elem_bytes, size_t off_src, long long off_dst, size_t off_len,
+                      hipStream_t st, Launch launch)
+{
+  long long maxlen = 0;
+  for (const Item &it : part) maxlen = std::max(maxlen, (long long)it.len);
+  if (part.empty() || maxlen <= 0) return SU_TRUE;
+  Item *d = gang_upload(ctx, part, st);
+  if (!d) return SU_FALSE;
+  const long long slab = ((maxlen + 63) / 64 + 1) * 64 * 64;           // whole tiles + one of slack for the prefetch
+  const size_t groups = (part.size() + 63) / 64;
+  const size_t tm_bytes = groups * (size_t)slab * (size_t)elem_bytes;
+  size_t tm_off = 0;
+  void *tm = ctx->slab_take(tm_bytes, st, &tm_off);
+  if (!tm) { set_err("device allocation failed (%zu B of gang slabs)", tm_bytes); return SU_FALSE; }
+  hipError_t e = sdk::rows_tm_gather(d, (int)sizeof(Item), (int)off_src, (int)off_len, (int)part.size(), elem_bytes, tm, slab, maxlen, st);
+  if (e == hipSuccess) e = launch(d, tm, slab);
+  if (e == hipSuccess && off_dst >= 0)
+    e = sdk::rows_tm_scatter(d, (int)sizeof(Item), (int)off_dst, (int)off_len, (int)part.size(), elem_bytes, tm, slab, maxlen, st);
+  ctx->slab_give(tm_off, tm_bytes, st);
+  if (e != hipSuccess) { set_err("%s", hipGetErrorString(e)); return SU_FALSE; }
+  return SU_TRUE;
 }
 
 extern "C" {
@@ -1183,9 +1256,10 @@ SUBOOL suamd_costas_gang_feed(suamd_ctx_t *ctx, suamd_costas_bank_t *const *bank
     }
     for (size_t o = 0; o < kv.second.size(); o += 512) {                       // <= 512 items per descriptor slot
       std::vector<sdk::CostasGangItem> part(kv.second.begin() + o, kv.second.begin() + std::min(kv.second.size(), o + 512));
-      sdk::CostasGangItem *d = gang_upload(ctx, part, gs);
-      if (!d) return SU_FALSE;
-      HIP_TRY(sdk::costas_gang(d, (int)part.size(), kv.first / 8, kv.first % 8, gs), SU_FALSE);
+      const int kind = kv.first / 8, order = kv.first % 8;
+      if (!gang_tm(ctx, part, 8, offsetof(sdk::CostasGangItem, x), (long long)offsetof(sdk::CostasGangItem, y), offsetof(sdk::CostasGangItem, len), gs,
+                   [&](sdk::CostasGangItem *d, void *tm, long long slab) { return sdk::costas_gang(d, (int)part.size(), kind, order, tm, slab, gs); }))
+        return SU_FALSE;
     }
     ++gi;
   }
@@ -1210,9 +1284,9 @@ SUBOOL suamd_pll_gang_feed(suamd_ctx_t *ctx, suamd_pll_bank_t *const *banks, uns
   }
   for (size_t o = 0; o < items.size(); o += 512) {
     std::vector<sdk::PllGangItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
-    sdk::PllGangItem *d = gang_upload(ctx, part, st);
-    if (!d) return SU_FALSE;
-    HIP_TRY(sdk::pll_gang(d, (int)part.size(), st), SU_FALSE);
+    if (!gang_tm(ctx, part, 8, offsetof(sdk::PllGangItem, x), (long long)offsetof(sdk::PllGangItem, y), offsetof(sdk::PllGangItem, len), st,
+                 [&](sdk::PllGangItem *d, void *tm, long long slab) { return sdk::pll_gang(d, (int)part.size(), tm, slab, st); }))
+      return SU_FALSE;
   }
   return SU_TRUE;
 }
@@ -1256,9 +1330,9 @@ SUBOOL suamd_clock_gang_feed(suamd_ctx_t *ctx, suamd_clock_bank_t *const *banks,
   }
   for (size_t o = 0; o < items.size(); o += 512) {
     std::vector<sdk::ClockGangItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
-    sdk::ClockGangItem *d = gang_upload(ctx, part, st);
-    if (!d) return SU_FALSE;
-    HIP_TRY(sdk::clock_gang(d, (int)part.size(), st), SU_FALSE);
+    if (!gang_tm(ctx, part, 8, offsetof(sdk::ClockGangItem, x), -1, offsetof(sdk::ClockGangItem, len), st,
+                 [&](sdk::ClockGangItem *d, void *tm, long long slab) { return sdk::clock_gang(d, (int)part.size(), tm, slab, st); }))
+      return SU_FALSE;
   }
   return SU_TRUE;
 }
@@ -1307,9 +1381,9 @@ SUBOOL suamd_agc_gang_level(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, un
   }
   for (size_t o = 0; o < items.size(); o += 512) {
     std::vector<sdk::AgcGangItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
-    sdk::AgcGangItem *d = gang_upload(ctx, part, st);
-    if (!d) return SU_FALSE;
-    HIP_TRY(sdk::agc_level_gang(d, (int)part.size(), st), SU_FALSE);
+    if (!gang_tm(ctx, part, 4, offsetof(sdk::AgcGangItem, peak), (long long)offsetof(sdk::AgcGangItem, peak), offsetof(sdk::AgcGangItem, len), st,
+                 [&](sdk::AgcGangItem *d, void *tm, long long slab) { return sdk::agc_level_gang(d, (int)part.size(), tm, slab, st); }))
+      return SU_FALSE;
   }
   return SU_TRUE;
 }

@@ -104,10 +104,17 @@ struct ClockGangItem { ClockParams p; ClockState s; const void *x; long long len
 struct PllGangItem { float alpha, beta; PllState s; const void *x; void *y; long long len; };
 // symbol rows: the length is *count when count != nullptr (the clock gang's device-side counts), else fixed_len
 struct CmaGangItem { float mu; int locked; void *w; void *dl; const void *x; void *y; const uint32_t *count; long long fixed_len; };
-hipError_t pll_gang(const PllGangItem *d_items, int n, hipStream_t st);
+// The recurrence gangs work on time-major slabs (tm[group][m][lane], `slab` elements per group of 64 items, at least
+// (ceil(maxlen / 64) + 1) * 64 * 64): rows_tm_gather fills them from the items' rows, rows_tm_scatter writes them back.
+// item k of the device table sits at d_items + k * item_bytes with its row pointer / length (long long) at the offsets.
+hipError_t rows_tm_gather(const void *d_items, int item_bytes, int off_ptr, int off_len, int n, int elem_bytes, void *tm,
+                          long long slab, long long maxlen, hipStream_t st);
+hipError_t rows_tm_scatter(const void *d_items, int item_bytes, int off_ptr, int off_len, int n, int elem_bytes, const void *tm,
+                           long long slab, long long maxlen, hipStream_t st);
+hipError_t pll_gang(const PllGangItem *d_items, int n, void *tm, long long slab, hipStream_t st);
 hipError_t cma_gang(const CmaGangItem *d_items, int n, int ntaps, hipStream_t st);
-hipError_t costas_gang(const CostasGangItem *d_items, int n, int kind, int order, hipStream_t st);
-hipError_t clock_gang(const ClockGangItem *d_items, int n, hipStream_t st);
+hipError_t costas_gang(const CostasGangItem *d_items, int n, int kind, int order, void *tm, long long slab, hipStream_t st);
+hipError_t clock_gang(const ClockGangItem *d_items, int n, void *tm, long long slab, hipStream_t st);
 
 struct AgcParams {
   float knee, gain_slope;
@@ -135,7 +142,7 @@ struct AgcApplyItem { AgcParams p; const float *delay_line; const void *x; void 
 hipError_t agc_apply_items(const AgcApplyItem *d_items, int n, long long max_span, hipStream_t st);
 hipError_t agc_state_update(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv, long long len,
                             const float *db, hipStream_t st);
-hipError_t agc_level_gang(const AgcGangItem *d_items, int n, hipStream_t st);
+hipError_t agc_level_gang(const AgcGangItem *d_items, int n, void *tm, long long slab, hipStream_t st);
 // steps (1)+(2) and (5) of agc_feed for many 1-channel banks with contiguous rows: one launch each
 struct AgcPreItem { const void *x; const float *hist; float *db, *peak; long long len; int H; };
 struct AgcStateItem { float *delay_line, *hist; const void *x; const float *db; long long len; int delay, H; };

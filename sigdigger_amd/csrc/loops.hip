@@ -812,8 +812,108 @@ __device__ __forceinline__ void gang_stream(GangLds<T> &lds, const T *__restrict
   }
 }
 
+// The transposition above costs the lone wavefront ~90 ns per sample (address arithmetic, predicates, LDS round trips:
+// a gang ran 2x slower per sample than a bank, tools/gang_bench.py).  It is throughput work, so it moves out of the
+// recurrence: a parallel kernel gathers the 64 rows of a group into a time-major slab tm[m][lane] (LDS-transposed
+// tiles, coalesced both ways), the recurrence streams the slab exactly like a 64-channel bank (scalar base +
+// immediate offsets, one chunk prefetched ahead) -- in place -- and a second parallel kernel scatters the results to
+// the rows.  The slab has whole 64-sample tiles plus one tile of slack for the prefetch.
+__device__ __forceinline__ long long uniform64(long long v)
+{
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(unsigned long long)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+template <bool HAS_OUT, typename T, typename F>
+__device__ __forceinline__ void gang_stream_tm(T *tm, long long len, F step)
+{
+  const uint32_t lo = threadIdx.x * (uint32_t)sizeof(T);
+  const long long maxlen = uniform64(wave_max(len));
+  if (maxlen <= 0) return;
+  const long long minlen = uniform64(-wave_max(len > 0 ? -len : -(1ll << 62)));   // shortest non-empty row
+  T cur[CHUNK], nxt[CHUNK];
+#pragma unroll
+  for (int j = 0; j < CHUNK; ++j) cur[j] = ld_elem(tm, (long long)j * 64, lo);
+  for (long long i = 0; i < maxlen; i += CHUNK) {
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) nxt[j] = ld_elem(tm, (i + CHUNK + j) * 64, lo);
+    if (i + CHUNK <= minlen) {                               // inside every row: no per-step predication
+      if (len > 0) {
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j) {
+          if constexpr (HAS_OUT) st_elem(tm, (i + j) * 64, lo, step(i + j, cur[j]));
+          else step(i + j, cur[j]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CHUNK; ++j) {
+        if (i + j < len) {
+          if constexpr (HAS_OUT) st_elem(tm, (i + j) * 64, lo, step(i + j, cur[j]));
+          else step(i + j, cur[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) cur[j] = nxt[j];
+  }
+}
+
+// rows of a gang's items <-> slabs: item k of the table (item_bytes apart; its row pointer and length sit at off_ptr /
+// off_len) is lane k % 64 of group k / 64.  Tile = 64 samples x 64 rows through LDS (pitch 65).
+template <typename T>
+__global__ __launch_bounds__(256) void rows_tm_gather_kernel(const char *__restrict__ items, int item_bytes, int off_ptr, int off_len,
+                                                             int n, T *__restrict__ tm, long long slab)
+{
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ T tile[64][65];
+  const int g = blockIdx.y, s = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long long m0 = (long long)blockIdx.x * 64;
+#pragma unroll 4
+  for (int p = 0; p < 16; ++p) {
+    const int row = p * 4 + q, item = g * 64 + row;
+    T v = T{};
+    if (item < n) {
+      const char *it = items + (size_t)item * item_bytes;
+      const T *src = *reinterpret_cast<const T *const *>(it + off_ptr);
+      const long long len = *reinterpret_cast<const long long *>(it + off_len);
+      if (m0 + s < len) v = src[m0 + s];
+    }
+    tile[row][s] = v;
+  }
+  __syncthreads();
+  T *dst = tm + (size_t)g * slab + m0 * 64;
+#pragma unroll 4
+  for (int p = 0; p < 16; ++p) { const int ss = p * 4 + q; dst[ss * 64 + s] = tile[s][ss]; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rows_tm_scatter_kernel(const char *__restrict__ items, int item_bytes, int off_ptr, int off_len,
+                                                              int n, const T *__restrict__ tm, long long slab)
+{
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ T tile[64][65];
+  const int g = blockIdx.y, s = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long long m0 = (long long)blockIdx.x * 64;
+  const T *src = tm + (size_t)g * slab + m0 * 64;
+#pragma unroll 4
+  for (int p = 0; p < 16; ++p) { const int ss = p * 4 + q; tile[s][ss] = src[ss * 64 + s]; }
+  __syncthreads();
+#pragma unroll 4
+  for (int p = 0; p < 16; ++p) {
+    const int row = p * 4 + q, item = g * 64 + row;
+    if (item < n) {
+      const char *it = items + (size_t)item * item_bytes;
+      T *dst = *reinterpret_cast<T *const *>(it + off_ptr);
+      const long long len = *reinterpret_cast<const long long *>(it + off_len);
+      if (m0 + s < len) dst[m0 + s] = tile[row][s];
+    }
+  }
+}
+
 template <int KIND, int ORDER>
-__global__ __launch_bounds__(64) void costas_gang_kernel(const sdk::CostasGangItem *__restrict__ items, int n)
+__global__ __launch_bounds__(64) void costas_gang_kernel(const sdk::CostasGangItem *__restrict__ items, int n, float2 *tm, long long slab)
 {
   const int j = blockIdx.x * 64 + threadIdx.x;
   const bool live = j < n;
@@ -829,9 +929,7 @@ __global__ __launch_bounds__(64) void costas_gang_kernel(const sdk::CostasGangIt
     r.yh[i] = c32{s.yh[(i - 1) * 2 + 0], s.yh[(i - 1) * 2 + 1]};
   }
   const long long len = live ? it.len : 0;
-  __shared__ GangLds<float2> lds;
-  gang_stream<true>(lds, reinterpret_cast<const float2 *>(it.x), reinterpret_cast<float2 *>(it.y), len,
-                    [&](long long, float2 v) { return costas_step<KIND, ORDER, false>(p, r, v); });
+  gang_stream_tm<true>(tm + (size_t)blockIdx.x * slab, len, [&](long long, float2 v) { return costas_step<KIND, ORDER, false>(p, r, v); });
   if (!live) return;
   s.phase[0] = r.phase;
   s.omega[0] = r.omega;
@@ -842,7 +940,7 @@ __global__ __launch_bounds__(64) void costas_gang_kernel(const sdk::CostasGangIt
   }
 }
 
-__global__ __launch_bounds__(64) void pll_gang_kernel(const sdk::PllGangItem *__restrict__ items, int n)
+__global__ __launch_bounds__(64) void pll_gang_kernel(const sdk::PllGangItem *__restrict__ items, int n, float2 *tm, long long slab)
 {
   const int j = blockIdx.x * 64 + threadIdx.x;
   const bool live = j < n;
@@ -851,9 +949,7 @@ __global__ __launch_bounds__(64) void pll_gang_kernel(const sdk::PllGangItem *__
   uint32_t phase = it.s.phase[0];
   float omega = it.s.omega[0];
   const long long len = live ? it.len : 0;
-  __shared__ GangLds<float2> lds;
-  gang_stream<true>(lds, reinterpret_cast<const float2 *>(it.x), reinterpret_cast<float2 *>(it.y), len,
-                    [&](long long, float2 v) { return pll_step(alpha, beta, phase, omega, v); });
+  gang_stream_tm<true>(tm + (size_t)blockIdx.x * slab, len, [&](long long, float2 v) { return pll_step(alpha, beta, phase, omega, v); });
   if (!live) return;
   it.s.phase[0] = phase;
   it.s.omega[0] = omega;
@@ -902,7 +998,7 @@ __global__ __launch_bounds__(64) void cma_gang_kernel(const sdk::CmaGangItem *__
   for (int i = 0; i < N; ++i) { w[i] = float2{wr[i].re, wr[i].im}; dl[i] = float2{d[i].re, d[i].im}; }
 }
 
-__global__ __launch_bounds__(64) void clock_gang_kernel(const sdk::ClockGangItem *__restrict__ items, int n)
+__global__ __launch_bounds__(64) void clock_gang_kernel(const sdk::ClockGangItem *__restrict__ items, int n, float2 *tm, long long slab)
 {
   const int j = blockIdx.x * 64 + threadIdx.x;
   const bool live = j < n;
@@ -919,9 +1015,7 @@ __global__ __launch_bounds__(64) void clock_gang_kernel(const sdk::ClockGangItem
   r.n = it.count[0];
   const long long len = live ? it.len : 0;
   float2 *out = reinterpret_cast<float2 *>(it.sym);
-  __shared__ GangLds<float2> lds;
-  gang_stream<false>(lds, reinterpret_cast<const float2 *>(it.x), (float2 *)nullptr, len,
-                     [&](long long, float2 v) { clock_step(p, r, v, out); });
+  gang_stream_tm<false>(tm + (size_t)blockIdx.x * slab, len, [&](long long, float2 v) { clock_step(p, r, v, out); });
   if (!live) return;
   s.phi[0] = r.phi; s.bnor[0] = r.bnor; s.halfcycle[0] = r.halfcycle;
   s.prev[0] = r.prev.x; s.prev[1] = r.prev.y;
@@ -931,7 +1025,7 @@ __global__ __launch_bounds__(64) void clock_gang_kernel(const sdk::ClockGangItem
   it.count[0] = r.n;
 }
 
-__global__ __launch_bounds__(64) void agc_level_gang_kernel(const sdk::AgcGangItem *__restrict__ items, int n)
+__global__ __launch_bounds__(64) void agc_level_gang_kernel(const sdk::AgcGangItem *__restrict__ items, int n, float *tm, long long slab)
 {
   const int j = blockIdx.x * 64 + threadIdx.x;
   const bool live = j < n;
@@ -943,9 +1037,7 @@ __global__ __launch_bounds__(64) void agc_level_gang_kernel(const sdk::AgcGangIt
   const float knee = it.p.knee;
   const unsigned hang_max = it.p.hang_max;
   const long long len = live ? it.len : 0;
-  float *peak = it.peak;
-  __shared__ GangLds<float> lds;
-  gang_stream<true>(lds, peak, peak, len, [&](long long, float pk) {
+  gang_stream_tm<true>(tm + (size_t)blockIdx.x * slab, len, [&](long long, float pk) {
     float d = pk - fast;
     const float fa = d > 0.0f ? far : faf;
     fast = sd::fma_(fa, d, fast);
@@ -1156,17 +1248,47 @@ hipError_t agc_state_items(const AgcStateItem *d_items, int n, hipStream_t st)
   return hipGetLastError();
 }
 
-hipError_t agc_level_gang(const AgcGangItem *d_items, int n, hipStream_t st)
+hipError_t rows_tm_gather(const void *d_items, int item_bytes, int off_ptr, int off_len, int n, int elem_bytes, void *tm,
+                          long long slab, long long maxlen, hipStream_t st)
 {
-  if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(agc_level_gang_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_items, n);
+  if (n <= 0 || maxlen <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((maxlen + 63) / 64), (unsigned)((n + 63) / 64)), block(256);
+  if (elem_bytes == 8)
+    hipLaunchKernelGGL(rows_tm_gather_kernel<float2>, grid, block, 0, st, static_cast<const char *>(d_items), item_bytes, off_ptr, off_len, n,
+                       static_cast<float2 *>(tm), slab);
+  else if (elem_bytes == 4)
+    hipLaunchKernelGGL(rows_tm_gather_kernel<float>, grid, block, 0, st, static_cast<const char *>(d_items), item_bytes, off_ptr, off_len, n,
+                       static_cast<float *>(tm), slab);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
-hipError_t pll_gang(const PllGangItem *d_items, int n, hipStream_t st)
+hipError_t rows_tm_scatter(const void *d_items, int item_bytes, int off_ptr, int off_len, int n, int elem_bytes, const void *tm,
+                           long long slab, long long maxlen, hipStream_t st)
+{
+  if (n <= 0 || maxlen <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((maxlen + 63) / 64), (unsigned)((n + 63) / 64)), block(256);
+  if (elem_bytes == 8)
+    hipLaunchKernelGGL(rows_tm_scatter_kernel<float2>, grid, block, 0, st, static_cast<const char *>(d_items), item_bytes, off_ptr, off_len, n,
+                       static_cast<const float2 *>(tm), slab);
+  else if (elem_bytes == 4)
+    hipLaunchKernelGGL(rows_tm_scatter_kernel<float>, grid, block, 0, st, static_cast<const char *>(d_items), item_bytes, off_ptr, off_len, n,
+                       static_cast<const float *>(tm), slab);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t agc_level_gang(const AgcGangItem *d_items, int n, void *tm, long long slab, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(pll_gang_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_items, n);
+  hipLaunchKernelGGL(agc_level_gang_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_items, n, static_cast<float *>(tm), slab);
+  return hipGetLastError();
+}
+
+hipError_t pll_gang(const PllGangItem *d_items, int n, void *tm, long long slab, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pll_gang_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_items, n, static_cast<float2 *>(tm), slab);
   return hipGetLastError();
 }
 
@@ -1184,18 +1306,18 @@ hipError_t cma_gang(const CmaGangItem *d_items, int n, int ntaps, hipStream_t st
   return hipGetLastError();
 }
 
-hipError_t clock_gang(const ClockGangItem *d_items, int n, hipStream_t st)
+hipError_t clock_gang(const ClockGangItem *d_items, int n, void *tm, long long slab, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(clock_gang_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_items, n);
+  hipLaunchKernelGGL(clock_gang_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_items, n, static_cast<float2 *>(tm), slab);
   return hipGetLastError();
 }
 
-hipError_t costas_gang(const CostasGangItem *d_items, int n, int kind, int order, hipStream_t st)
+hipError_t costas_gang(const CostasGangItem *d_items, int n, int kind, int order, void *tm, long long slab, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
   const dim3 grid((n + 63) / 64), block(64);
-#define SD_GANG_CASE(K, O) case (K) * 8 + (O): hipLaunchKernelGGL((costas_gang_kernel<K, O>), grid, block, 0, st, d_items, n); break;
+#define SD_GANG_CASE(K, O) case (K) * 8 + (O): hipLaunchKernelGGL((costas_gang_kernel<K, O>), grid, block, 0, st, d_items, n, static_cast<float2 *>(tm), slab); break;
   if (order < 0 || order > 4 || kind < 1 || kind > 3) return hipErrorInvalidValue;
   switch (kind * 8 + order) {
     SD_GANG_CASE(1, 0) SD_GANG_CASE(1, 1) SD_GANG_CASE(1, 2) SD_GANG_CASE(1, 3) SD_GANG_CASE(1, 4)
