@@ -409,6 +409,7 @@ struct suscan_analyzer {
   int nsub = 4;
   bool trace = false;                         // SUAMD_ANALYZER_TRACE: per-block host timeline on stderr
   double t_chains_done = 0;
+  hipEvent_t ev_t0 = nullptr, ev_tfir = nullptr, ev_tpre = nullptr, ev_tdone = nullptr, ev_tstage[3][NSUB] = {};   // timed, trace only
   std::chrono::steady_clock::time_point t_block0;
   hipEvent_t ev_stage[3][NSUB] = {};
   hipStream_t istream[NISTREAMS] = {};
@@ -606,6 +607,7 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
     std::vector<suamd_chanbank_t *> fb; std::vector<suamd_complex *> fy; std::vector<SUSCOUNT> fm(live.size());
     for (Inspector *pi : live) { fb.push_back(pi->bank); fy.push_back(pi->d_y); }
     if (!suamd_chanbank_gang_feed(a->ctx, fb.data(), (unsigned)fb.size(), a->d_x, len, fy.data(), fm.data(), sA)) { fail("channeliser"); return; }
+    if (a->trace) (void)hipEventRecord(a->ev_tfir, sA);
     for (size_t i = 0; i < live.size(); ++i) {
       Inspector &in = *live[i];
       in.pend_m = fm[i];
@@ -635,6 +637,7 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
     if (in.clock) in.pend_symbols = true; else in.pend_samples = true;
   }
   if (!gb.empty() && !suamd_agc_gang_pre(a->ctx, gb.data(), (unsigned)gb.size(), gx.data(), gl.data(), sA)) fail("gain control");
+  if (a->trace) (void)hipEventRecord(a->ev_tpre, sA);
   for (int j = 0; j < P; ++j) {
     // ---- gain control on sA ----
     {
@@ -652,6 +655,7 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
             !suamd_agc_gang_apply(a->ctx, gb.data(), (unsigned)gb.size(), gx.data(), gy.data(), gl.data(), m0.data(), m1.data(), sA)) fail("gain control");
       }
       (void)hipEventRecord(a->ev_stage[0][j], sA);
+      if (a->trace) (void)hipEventRecord(a->ev_tstage[0][j], sA);
     }
     // ---- carrier control on sC ----
     {
@@ -678,6 +682,7 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
       if (!cb.empty() && !suamd_costas_gang_feed(a->ctx, cb.data(), (unsigned)cb.size(), cx.data(), cy.data(), cl.data(), sC)) fail("carrier control");
       if (!pb.empty() && !suamd_pll_gang_feed(a->ctx, pb.data(), (unsigned)pb.size(), px.data(), py.data(), pl.data(), sC)) fail("carrier control");
       (void)hipEventRecord(a->ev_stage[1][j], sC);
+      if (a->trace) (void)hipEventRecord(a->ev_tstage[1][j], sC);
     }
     // ---- matched filter, clock recovery on sK ----
     {
@@ -694,6 +699,7 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
       }
       if (!kb.empty() && !suamd_clock_gang_feed(a->ctx, kb.data(), (unsigned)kb.size(), kx.data(), kl.data(), ks.data(), kc.data(), sK)) fail("clock recovery");
       (void)hipEventRecord(a->ev_stage[2][j], sK);
+      if (a->trace) (void)hipEventRecord(a->ev_tstage[2][j], sK);
     }
   }
   // ---- tails: AGC state carry on sA; equalizers and the symbol counts on sK ----
@@ -718,6 +724,7 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
       cout.push_back(&in.pin->count);
     }
     if (!suamd_rows_deliver(a->ctx, (unsigned)live.size(), src.data(), cnt.data(), fixed.data(), dst.data(), cout.data(), sK)) fail("hand-off");
+    if (a->trace) (void)hipEventRecord(a->ev_tdone, sK);
   }
 }
 
@@ -920,6 +927,10 @@ void worker_main(suscan_analyzer *a)
   for (int g = 0; ok && g < 3; ++g)
     for (int j = 0; ok && j < suscan_analyzer::NSUB; ++j)
       if (hipEventCreateWithFlags(&a->ev_stage[g][j], hipEventDisableTiming) != hipSuccess) { ok = false; err = "hipEventCreate failed"; }
+  if (ok && a->trace) {
+    (void)hipEventCreate(&a->ev_t0); (void)hipEventCreate(&a->ev_tfir); (void)hipEventCreate(&a->ev_tpre); (void)hipEventCreate(&a->ev_tdone);
+    for (int g = 0; g < 3; ++g) for (int j = 0; j < suscan_analyzer::NSUB; ++j) (void)hipEventCreate(&a->ev_tstage[g][j]);
+  }
   if (ok) ok = src.open(err);
   if (ok && src.cfg.samp_rate != a->source_cfg.samp_rate) {       // a WAV / SigMF header carries its own rate
     a->source_cfg.samp_rate = src.cfg.samp_rate;
@@ -994,6 +1005,7 @@ void worker_main(suscan_analyzer *a)
       }
     }
     (void)hipEventRecord(a->ev_input, a->stream);
+    if (a->trace) (void)hipEventRecord(a->ev_t0, a->stream);
     tick(0);
     // the inspectors' chains start as soon as the block is on the device, next to the PSD
     enqueue_inspectors(a, a->block);
@@ -1030,8 +1042,14 @@ void worker_main(suscan_analyzer *a)
     collect_inspectors(a);
     tick(5);
     if (a->trace && (consumed / a->block) % 8 == 7)
+    {
+      auto el = [&](hipEvent_t e) { float ms = -1.f; if (e && hipEventElapsedTime(&ms, a->ev_t0, e) != hipSuccess) ms = -1.f; return ms; };
+      std::fprintf(stderr, "[analyzer] device: channeliser done %.2f  agc pre %.2f |", el(a->ev_tfir), el(a->ev_tpre));
+      for (int j = 0; j < a->nsub; ++j) std::fprintf(stderr, " [%d] agc %.2f carrier %.2f clock %.2f", j, el(a->ev_tstage[0][j]), el(a->ev_tstage[1][j]), el(a->ev_tstage[2][j]));
+      std::fprintf(stderr, " | handed off %.2f ms after the block was on the device\n", el(a->ev_tdone));
       std::fprintf(stderr, "[analyzer] block: input issued %.2f  chains issued %.2f  next block read %.2f  psd done %.2f  chains done %.2f  delivered %.2f ms\n",
                    tmark[0], tmark[1], tmark[2], tmark[3], a->t_chains_done, tmark[5]);
+    }
     consumed += a->block;
     // ---- rate bookkeeping / throttle ----
     auto now = std::chrono::steady_clock::now();
