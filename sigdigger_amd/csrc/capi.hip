@@ -283,24 +283,26 @@ static Item *gang_upload(suamd_ctx *ctx, const std::vector<Item> &items, hipStre
 // One gang launch on its time-major slab: upload the items, gather their rows, run the recurrence, scatter the results.
 // The slab comes from the context's stream-ordered ring (no host synchronisation, reused across calls).
 template <typename Item, typename Launch>
-static SUBOOL gang_tm(suamd_ctx *ctx, const std::vector<Item> &part, int elem_bytes, size_t off_src, long long off_dst, size_t off_len,
-                      hipStream_t st, Launch launch)
+static SUBOOL gang_tm(suamd_ctx *ctx, const std::vector<Item> &part, const std::vector<sdk::GangGroup> *groups, int elem_bytes, size_t off_src,
+                      long long off_dst, size_t off_len, hipStream_t st, Launch launch)
 {
   long long maxlen = 0;
   for (const Item &it : part) maxlen = std::max(maxlen, (long long)it.len);
   if (part.empty() || maxlen <= 0) return SU_TRUE;
   Item *d = gang_upload(ctx, part, st);
   if (!d) return SU_FALSE;
+  sdk::GangGroup *dg = nullptr;
+  if (groups) { dg = gang_upload(ctx, *groups, st); if (!dg) return SU_FALSE; }
   const long long slab = ((maxlen + 63) / 64 + 1) * 64 * 64;           // whole tiles + one of slack for the prefetch
-  const size_t groups = (part.size() + 63) / 64;
-  const size_t tm_bytes = groups * (size_t)slab * (size_t)elem_bytes;
+  const size_t ngroups = groups ? groups->size() : (part.size() + 63) / 64;
+  const size_t tm_bytes = ngroups * (size_t)slab * (size_t)elem_bytes;
   size_t tm_off = 0;
   void *tm = ctx->slab_take(tm_bytes, st, &tm_off);
   if (!tm) { set_err("device allocation failed (%zu B of gang slabs)", tm_bytes); return SU_FALSE; }
-  hipError_t e = sdk::rows_tm_gather(d, (int)sizeof(Item), (int)off_src, (int)off_len, (int)part.size(), elem_bytes, tm, slab, maxlen, st);
-  if (e == hipSuccess) e = launch(d, tm, slab);
+  hipError_t e = sdk::rows_tm_gather(d, (int)sizeof(Item), (int)off_src, (int)off_len, (int)part.size(), dg, (int)ngroups, elem_bytes, tm, slab, maxlen, st);
+  if (e == hipSuccess) e = launch(d, dg, tm, slab);
   if (e == hipSuccess && off_dst >= 0)
-    e = sdk::rows_tm_scatter(d, (int)sizeof(Item), (int)off_dst, (int)off_len, (int)part.size(), elem_bytes, tm, slab, maxlen, st);
+    e = sdk::rows_tm_scatter(d, (int)sizeof(Item), (int)off_dst, (int)off_len, (int)part.size(), dg, (int)ngroups, elem_bytes, tm, slab, maxlen, st);
   ctx->slab_give(tm_off, tm_bytes, st);
   if (e != hipSuccess) { set_err("%s", hipGetErrorString(e)); return SU_FALSE; }
   return SU_TRUE;
@@ -1233,41 +1235,37 @@ SUBOOL suamd_costas_gang_feed(suamd_ctx_t *ctx, suamd_costas_bank_t *const *bank
 {
   if (!ctx || (n && (!banks || !d_x || !d_y || !len))) { set_err("null argument"); return SU_FALSE; }
   hipStream_t st = as_stream(stream);
-  // one launch per (kind, order): the loop type is compiled in, everything else is per lane
-  std::map<int, std::vector<sdk::CostasGangItem>> groups;
+  // items sorted by loop type (kind, arm-filter order): the type is compiled in, everything else is per lane
+  std::map<int, std::vector<sdk::CostasGangItem>> types;
   for (unsigned i = 0; i < n; ++i) {
     if (!banks[i] || banks[i]->nchan != 1) { set_err("gang members must be 1-channel banks"); return SU_FALSE; }
     if (len[i] == 0) continue;
     if (!d_x[i] || !d_y[i]) { set_err("null row"); return SU_FALSE; }
-    groups[banks[i]->p.kind * 8 + banks[i]->p.order].push_back(sdk::CostasGangItem{banks[i]->p, banks[i]->s, d_x[i], d_y[i], (long long)len[i]});
+    types[banks[i]->p.kind * 8 + banks[i]->p.order].push_back(sdk::CostasGangItem{banks[i]->p, banks[i]->s, d_x[i], d_y[i], (long long)len[i]});
   }
-  // the first loop type runs on the caller's stream, the others fork onto side streams (they are independent
-  // single-wavefront kernels and would otherwise queue behind each other) and join back
-  const bool fork = groups.size() > 1 && ctx->init_side();
-  if (fork) HIP_TRY(hipEventRecord(ctx->ev_fork, st), SU_FALSE);
-  int gi = 0;
-  std::vector<int> used;
-  for (auto &kv : groups) {
-    hipStream_t gs = st;
-    if (fork && gi > 0) {
-      const int sidx = (gi - 1) % suamd_ctx::GANG_SIDE;
-      gs = ctx->side[sidx];
-      if (std::find(used.begin(), used.end(), sidx) == used.end()) { HIP_TRY(hipStreamWaitEvent(gs, ctx->ev_fork, 0), SU_FALSE); used.push_back(sidx); }
+  // one workgroup per <= 64 items of one type; all of them in one launch (<= 448 items per descriptor slot)
+  static_assert(448 * sizeof(sdk::CostasGangItem) <= suamd_ctx::GANG_SLOT_BYTES, "a descriptor slot holds 448 Costas items");
+  std::vector<sdk::CostasGangItem> items;
+  std::vector<sdk::GangGroup> groups;
+  auto flush = [&]() -> SUBOOL {
+    if (items.empty()) return SU_TRUE;
+    const SUBOOL ok = gang_tm(ctx, items, &groups, 8, offsetof(sdk::CostasGangItem, x), (long long)offsetof(sdk::CostasGangItem, y),
+                              offsetof(sdk::CostasGangItem, len), st,
+                              [&](sdk::CostasGangItem *d, sdk::GangGroup *dg, void *tm, long long slab) {
+                                return sdk::costas_gang(d, dg, (int)groups.size(), tm, slab, st);
+                              });
+    items.clear(); groups.clear();
+    return ok;
+  };
+  for (auto &kv : types) {
+    for (size_t o = 0; o < kv.second.size(); o += 64) {
+      const size_t cnt = std::min<size_t>(64, kv.second.size() - o);
+      if (items.size() + cnt > 448 && !flush()) return SU_FALSE;
+      groups.push_back(sdk::GangGroup{(int)items.size(), (int)cnt, kv.first / 8, kv.first % 8});
+      items.insert(items.end(), kv.second.begin() + o, kv.second.begin() + o + cnt);
     }
-    for (size_t o = 0; o < kv.second.size(); o += 512) {                       // <= 512 items per descriptor slot
-      std::vector<sdk::CostasGangItem> part(kv.second.begin() + o, kv.second.begin() + std::min(kv.second.size(), o + 512));
-      const int kind = kv.first / 8, order = kv.first % 8;
-      if (!gang_tm(ctx, part, 8, offsetof(sdk::CostasGangItem, x), (long long)offsetof(sdk::CostasGangItem, y), offsetof(sdk::CostasGangItem, len), gs,
-                   [&](sdk::CostasGangItem *d, void *tm, long long slab) { return sdk::costas_gang(d, (int)part.size(), kind, order, tm, slab, gs); }))
-        return SU_FALSE;
-    }
-    ++gi;
   }
-  for (int sidx : used) {
-    HIP_TRY(hipEventRecord(ctx->ev_join[sidx], ctx->side[sidx]), SU_FALSE);
-    HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join[sidx], 0), SU_FALSE);
-  }
-  return SU_TRUE;
+  return flush();
 }
 
 SUBOOL suamd_pll_gang_feed(suamd_ctx_t *ctx, suamd_pll_bank_t *const *banks, unsigned n, const suamd_complex *const *d_x,
@@ -1284,8 +1282,8 @@ SUBOOL suamd_pll_gang_feed(suamd_ctx_t *ctx, suamd_pll_bank_t *const *banks, uns
   }
   for (size_t o = 0; o < items.size(); o += 512) {
     std::vector<sdk::PllGangItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
-    if (!gang_tm(ctx, part, 8, offsetof(sdk::PllGangItem, x), (long long)offsetof(sdk::PllGangItem, y), offsetof(sdk::PllGangItem, len), st,
-                 [&](sdk::PllGangItem *d, void *tm, long long slab) { return sdk::pll_gang(d, (int)part.size(), tm, slab, st); }))
+    if (!gang_tm(ctx, part, nullptr, 8, offsetof(sdk::PllGangItem, x), (long long)offsetof(sdk::PllGangItem, y), offsetof(sdk::PllGangItem, len), st,
+                 [&](sdk::PllGangItem *d, sdk::GangGroup *, void *tm, long long slab) { return sdk::pll_gang(d, (int)part.size(), tm, slab, st); }))
       return SU_FALSE;
   }
   return SU_TRUE;
@@ -1330,8 +1328,8 @@ SUBOOL suamd_clock_gang_feed(suamd_ctx_t *ctx, suamd_clock_bank_t *const *banks,
   }
   for (size_t o = 0; o < items.size(); o += 512) {
     std::vector<sdk::ClockGangItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
-    if (!gang_tm(ctx, part, 8, offsetof(sdk::ClockGangItem, x), -1, offsetof(sdk::ClockGangItem, len), st,
-                 [&](sdk::ClockGangItem *d, void *tm, long long slab) { return sdk::clock_gang(d, (int)part.size(), tm, slab, st); }))
+    if (!gang_tm(ctx, part, nullptr, 8, offsetof(sdk::ClockGangItem, x), -1, offsetof(sdk::ClockGangItem, len), st,
+                 [&](sdk::ClockGangItem *d, sdk::GangGroup *, void *tm, long long slab) { return sdk::clock_gang(d, (int)part.size(), tm, slab, st); }))
       return SU_FALSE;
   }
   return SU_TRUE;
@@ -1381,8 +1379,8 @@ SUBOOL suamd_agc_gang_level(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, un
   }
   for (size_t o = 0; o < items.size(); o += 512) {
     std::vector<sdk::AgcGangItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
-    if (!gang_tm(ctx, part, 4, offsetof(sdk::AgcGangItem, peak), (long long)offsetof(sdk::AgcGangItem, peak), offsetof(sdk::AgcGangItem, len), st,
-                 [&](sdk::AgcGangItem *d, void *tm, long long slab) { return sdk::agc_level_gang(d, (int)part.size(), tm, slab, st); }))
+    if (!gang_tm(ctx, part, nullptr, 4, offsetof(sdk::AgcGangItem, peak), (long long)offsetof(sdk::AgcGangItem, peak), offsetof(sdk::AgcGangItem, len), st,
+                 [&](sdk::AgcGangItem *d, sdk::GangGroup *, void *tm, long long slab) { return sdk::agc_level_gang(d, (int)part.size(), tm, slab, st); }))
       return SU_FALSE;
   }
   return SU_TRUE;

@@ -107,13 +107,16 @@ struct CmaGangItem { float mu; int locked; void *w; void *dl; const void *x; voi
 // The recurrence gangs work on time-major slabs (tm[group][m][lane], `slab` elements per group of 64 items, at least
 // (ceil(maxlen / 64) + 1) * 64 * 64): rows_tm_gather fills them from the items' rows, rows_tm_scatter writes them back.
 // item k of the device table sits at d_items + k * item_bytes with its row pointer / length (long long) at the offsets.
-hipError_t rows_tm_gather(const void *d_items, int item_bytes, int off_ptr, int off_len, int n, int elem_bytes, void *tm,
-                          long long slab, long long maxlen, hipStream_t st);
-hipError_t rows_tm_scatter(const void *d_items, int item_bytes, int off_ptr, int off_len, int n, int elem_bytes, const void *tm,
-                           long long slab, long long maxlen, hipStream_t st);
+// optional group table: group g = items [first, first + count) (at most 64), e.g. one loop type each; without it
+// group g = items [64 g, 64 g + 64)
+struct GangGroup { int first, count, kind, order; };
+hipError_t rows_tm_gather(const void *d_items, int item_bytes, int off_ptr, int off_len, int n, const GangGroup *d_groups, int ngroups,
+                          int elem_bytes, void *tm, long long slab, long long maxlen, hipStream_t st);
+hipError_t rows_tm_scatter(const void *d_items, int item_bytes, int off_ptr, int off_len, int n, const GangGroup *d_groups, int ngroups,
+                           int elem_bytes, const void *tm, long long slab, long long maxlen, hipStream_t st);
 hipError_t pll_gang(const PllGangItem *d_items, int n, void *tm, long long slab, hipStream_t st);
 hipError_t cma_gang(const CmaGangItem *d_items, int n, int ntaps, hipStream_t st);
-hipError_t costas_gang(const CostasGangItem *d_items, int n, int kind, int order, void *tm, long long slab, hipStream_t st);
+hipError_t costas_gang(const CostasGangItem *d_items, const GangGroup *d_groups, int ngroups, void *tm, long long slab, hipStream_t st);
 hipError_t clock_gang(const ClockGangItem *d_items, int n, void *tm, long long slab, hipStream_t st);
 
 struct AgcParams {

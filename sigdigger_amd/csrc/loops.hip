@@ -864,17 +864,19 @@ __device__ __forceinline__ void gang_stream_tm(T *tm, long long len, F step)
 // off_len) is lane k % 64 of group k / 64.  Tile = 64 samples x 64 rows through LDS (pitch 65).
 template <typename T>
 __global__ __launch_bounds__(256) void rows_tm_gather_kernel(const char *__restrict__ items, int item_bytes, int off_ptr, int off_len,
-                                                             int n, T *__restrict__ tm, long long slab)
+                                                             int n, const sdk::GangGroup *__restrict__ groups, T *__restrict__ tm, long long slab)
 {
   __builtin_amdgcn_s_setprio(3);
   __shared__ T tile[64][65];
   const int g = blockIdx.y, s = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int first = groups ? groups[g].first : g * 64;
+  const int last = groups ? first + groups[g].count : n;
   const long long m0 = (long long)blockIdx.x * 64;
 #pragma unroll 4
   for (int p = 0; p < 16; ++p) {
-    const int row = p * 4 + q, item = g * 64 + row;
+    const int row = p * 4 + q, item = first + row;
     T v = T{};
-    if (item < n) {
+    if (item < last) {
       const char *it = items + (size_t)item * item_bytes;
       const T *src = *reinterpret_cast<const T *const *>(it + off_ptr);
       const long long len = *reinterpret_cast<const long long *>(it + off_len);
@@ -890,11 +892,13 @@ __global__ __launch_bounds__(256) void rows_tm_gather_kernel(const char *__restr
 
 template <typename T>
 __global__ __launch_bounds__(256) void rows_tm_scatter_kernel(const char *__restrict__ items, int item_bytes, int off_ptr, int off_len,
-                                                              int n, const T *__restrict__ tm, long long slab)
+                                                              int n, const sdk::GangGroup *__restrict__ groups, const T *__restrict__ tm, long long slab)
 {
   __builtin_amdgcn_s_setprio(3);
   __shared__ T tile[64][65];
   const int g = blockIdx.y, s = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int first = groups ? groups[g].first : g * 64;
+  const int last = groups ? first + groups[g].count : n;
   const long long m0 = (long long)blockIdx.x * 64;
   const T *src = tm + (size_t)g * slab + m0 * 64;
 #pragma unroll 4
@@ -902,8 +906,8 @@ __global__ __launch_bounds__(256) void rows_tm_scatter_kernel(const char *__rest
   __syncthreads();
 #pragma unroll 4
   for (int p = 0; p < 16; ++p) {
-    const int row = p * 4 + q, item = g * 64 + row;
-    if (item < n) {
+    const int row = p * 4 + q, item = first + row;
+    if (item < last) {
       const char *it = items + (size_t)item * item_bytes;
       T *dst = *reinterpret_cast<T *const *>(it + off_ptr);
       const long long len = *reinterpret_cast<const long long *>(it + off_len);
@@ -913,10 +917,10 @@ __global__ __launch_bounds__(256) void rows_tm_scatter_kernel(const char *__rest
 }
 
 template <int KIND, int ORDER>
-__global__ __launch_bounds__(64) void costas_gang_kernel(const sdk::CostasGangItem *__restrict__ items, int n, float2 *tm, long long slab)
+__device__ __forceinline__ void costas_gang_body(const sdk::CostasGangItem *__restrict__ items, int count, float2 *tm)
 {
-  const int j = blockIdx.x * 64 + threadIdx.x;
-  const bool live = j < n;
+  const int j = threadIdx.x;
+  const bool live = j < count;
   const sdk::CostasGangItem it = items[live ? j : 0];
   const sdk::CostasParams p = it.p;                           // per lane: every item its own loop
   const sdk::CostasState s = it.s;
@@ -929,7 +933,7 @@ __global__ __launch_bounds__(64) void costas_gang_kernel(const sdk::CostasGangIt
     r.yh[i] = c32{s.yh[(i - 1) * 2 + 0], s.yh[(i - 1) * 2 + 1]};
   }
   const long long len = live ? it.len : 0;
-  gang_stream_tm<true>(tm + (size_t)blockIdx.x * slab, len, [&](long long, float2 v) { return costas_step<KIND, ORDER, false>(p, r, v); });
+  gang_stream_tm<true>(tm, len, [&](long long, float2 v) { return costas_step<KIND, ORDER, false>(p, r, v); });
   if (!live) return;
   s.phase[0] = r.phase;
   s.omega[0] = r.omega;
@@ -937,6 +941,25 @@ __global__ __launch_bounds__(64) void costas_gang_kernel(const sdk::CostasGangIt
   for (int i2 = 1; i2 <= ORDER; ++i2) {
     s.xh[(i2 - 1) * 2 + 0] = r.xh[i2].re; s.xh[(i2 - 1) * 2 + 1] = r.xh[i2].im;
     s.yh[(i2 - 1) * 2 + 0] = r.yh[i2].re; s.yh[(i2 - 1) * 2 + 1] = r.yh[i2].im;
+  }
+}
+
+// every loop type of a gang in ONE launch: workgroup g runs the items of groups[g] (all of one kind and arm-filter
+// order, which selects the compiled-in loop).  The types used to fork onto side streams and join back: four event
+// hops and three sets of gather / scatter launches per call.
+__global__ __launch_bounds__(64) void costas_gang_kernel(const sdk::CostasGangItem *__restrict__ items,
+                                                         const sdk::GangGroup *__restrict__ groups, float2 *tm, long long slab)
+{
+  const sdk::GangGroup gd = groups[blockIdx.x];
+  const sdk::CostasGangItem *mine = items + gd.first;
+  float2 *my = tm + (size_t)blockIdx.x * slab;
+  switch (gd.kind * 8 + gd.order) {
+#define SD_GANG_CASE(K, O) case (K) * 8 + (O): costas_gang_body<K, O>(mine, gd.count, my); break;
+    SD_GANG_CASE(1, 0) SD_GANG_CASE(1, 1) SD_GANG_CASE(1, 2) SD_GANG_CASE(1, 3) SD_GANG_CASE(1, 4)
+    SD_GANG_CASE(2, 0) SD_GANG_CASE(2, 1) SD_GANG_CASE(2, 2) SD_GANG_CASE(2, 3) SD_GANG_CASE(2, 4)
+    SD_GANG_CASE(3, 0) SD_GANG_CASE(3, 1) SD_GANG_CASE(3, 2) SD_GANG_CASE(3, 3) SD_GANG_CASE(3, 4)
+#undef SD_GANG_CASE
+    default: break;
   }
 }
 
@@ -1315,32 +1338,32 @@ hipError_t agc_state_items(const AgcStateItem *d_items, int n, hipStream_t st)
   return hipGetLastError();
 }
 
-hipError_t rows_tm_gather(const void *d_items, int item_bytes, int off_ptr, int off_len, int n, int elem_bytes, void *tm,
-                          long long slab, long long maxlen, hipStream_t st)
+hipError_t rows_tm_gather(const void *d_items, int item_bytes, int off_ptr, int off_len, int n, const GangGroup *d_groups, int ngroups,
+                          int elem_bytes, void *tm, long long slab, long long maxlen, hipStream_t st)
 {
   if (n <= 0 || maxlen <= 0) return hipSuccess;
-  const dim3 grid((unsigned)((maxlen + 63) / 64), (unsigned)((n + 63) / 64)), block(256);
+  const dim3 grid((unsigned)((maxlen + 63) / 64), (unsigned)(d_groups ? ngroups : (n + 63) / 64)), block(256);
   if (elem_bytes == 8)
     hipLaunchKernelGGL(rows_tm_gather_kernel<float2>, grid, block, 0, st, static_cast<const char *>(d_items), item_bytes, off_ptr, off_len, n,
-                       static_cast<float2 *>(tm), slab);
+                       d_groups, static_cast<float2 *>(tm), slab);
   else if (elem_bytes == 4)
     hipLaunchKernelGGL(rows_tm_gather_kernel<float>, grid, block, 0, st, static_cast<const char *>(d_items), item_bytes, off_ptr, off_len, n,
-                       static_cast<float *>(tm), slab);
+                       d_groups, static_cast<float *>(tm), slab);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
-hipError_t rows_tm_scatter(const void *d_items, int item_bytes, int off_ptr, int off_len, int n, int elem_bytes, const void *tm,
-                           long long slab, long long maxlen, hipStream_t st)
+hipError_t rows_tm_scatter(const void *d_items, int item_bytes, int off_ptr, int off_len, int n, const GangGroup *d_groups, int ngroups,
+                           int elem_bytes, const void *tm, long long slab, long long maxlen, hipStream_t st)
 {
   if (n <= 0 || maxlen <= 0) return hipSuccess;
-  const dim3 grid((unsigned)((maxlen + 63) / 64), (unsigned)((n + 63) / 64)), block(256);
+  const dim3 grid((unsigned)((maxlen + 63) / 64), (unsigned)(d_groups ? ngroups : (n + 63) / 64)), block(256);
   if (elem_bytes == 8)
     hipLaunchKernelGGL(rows_tm_scatter_kernel<float2>, grid, block, 0, st, static_cast<const char *>(d_items), item_bytes, off_ptr, off_len, n,
-                       static_cast<const float2 *>(tm), slab);
+                       d_groups, static_cast<const float2 *>(tm), slab);
   else if (elem_bytes == 4)
     hipLaunchKernelGGL(rows_tm_scatter_kernel<float>, grid, block, 0, st, static_cast<const char *>(d_items), item_bytes, off_ptr, off_len, n,
-                       static_cast<const float *>(tm), slab);
+                       d_groups, static_cast<const float *>(tm), slab);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -1380,19 +1403,10 @@ hipError_t clock_gang(const ClockGangItem *d_items, int n, void *tm, long long s
   return hipGetLastError();
 }
 
-hipError_t costas_gang(const CostasGangItem *d_items, int n, int kind, int order, void *tm, long long slab, hipStream_t st)
+hipError_t costas_gang(const CostasGangItem *d_items, const GangGroup *d_groups, int ngroups, void *tm, long long slab, hipStream_t st)
 {
-  if (n <= 0) return hipSuccess;
-  const dim3 grid((n + 63) / 64), block(64);
-#define SD_GANG_CASE(K, O) case (K) * 8 + (O): hipLaunchKernelGGL((costas_gang_kernel<K, O>), grid, block, 0, st, d_items, n, static_cast<float2 *>(tm), slab); break;
-  if (order < 0 || order > 4 || kind < 1 || kind > 3) return hipErrorInvalidValue;
-  switch (kind * 8 + order) {
-    SD_GANG_CASE(1, 0) SD_GANG_CASE(1, 1) SD_GANG_CASE(1, 2) SD_GANG_CASE(1, 3) SD_GANG_CASE(1, 4)
-    SD_GANG_CASE(2, 0) SD_GANG_CASE(2, 1) SD_GANG_CASE(2, 2) SD_GANG_CASE(2, 3) SD_GANG_CASE(2, 4)
-    SD_GANG_CASE(3, 0) SD_GANG_CASE(3, 1) SD_GANG_CASE(3, 2) SD_GANG_CASE(3, 3) SD_GANG_CASE(3, 4)
-    default: return hipErrorInvalidValue;
-  }
-#undef SD_GANG_CASE
+  if (ngroups <= 0) return hipSuccess;
+  hipLaunchKernelGGL(costas_gang_kernel, dim3((unsigned)ngroups), dim3(64), 0, st, d_items, d_groups, static_cast<float2 *>(tm), slab);
   return hipGetLastError();
 }
 
