@@ -485,6 +485,63 @@ def test_many_concurrent_inspectors(tmp_path, sdo):
     Lb.suscan_mq_finalize(C.byref(mq))
 
 
+def test_narrow_channel_in_a_wide_capture(tmp_path, sdo):
+    """bw = 800 Hz at 1 MS/s: decimation 512, beyond the channeliser's LDS window (its sparse-output kernel), 128
+    channel samples per block split over the analyzer's stage sub-ranges -- symbols equal the oracle chain's"""
+    nblocks = 24
+    baud, bw, fc = 200.0, 800.0, 123e3
+    D, efs = 512, FS / 512
+    sps = efs / baud
+    t = np.arange(L * nblocks)
+    rng = np.random.default_rng(8)
+    nsym = int(L * nblocks / (FS / baud)) + 2
+    bits = (rng.integers(0, 4, nsym) * 2 + 1) * np.pi / 4
+    ph = np.repeat(bits, int(FS / baud))[:L * nblocks]
+    x = (0.5 * np.exp(1j * (2 * np.pi * fc / FS * t + ph)) + 0.01 * (rng.standard_normal(t.size) + 1j * rng.standard_normal(t.size))).astype(np.complex64)
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    Lb, mq, an = _start(path, L)
+    Lb.suscan_analyzer_set_throttle_async(an, 4 * FS, 0)
+    ch = suscan.Channel(fc=fc, f_lo=fc - bw / 2, f_hi=fc + bw / 2, bw=bw, ft=433.92e6)
+    assert Lb.suscan_analyzer_open_ex_async(an, b"psk", C.byref(ch), 1, -1, 7)
+    st = {"psd": 0, "cfg_at": None, "samples": [], "status": []}
+
+    def on_msg(tp, ptr):
+        if tp == suscan.MSG_PSD:
+            st["psd"] += 1
+        elif tp == suscan.MSG_INSPECTOR:
+            m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
+            if m.kind == suscan.KIND_OPEN:
+                assert abs(m.equiv_fs - efs) < 1e-3
+                cfg = Lb.suscan_config_dup(m.config)
+                Lb.suscan_config_set_integer(cfg, b"afc.costas-order", 2)
+                Lb.suscan_config_set_float(cfg, b"afc.loop-bw", 5.0)
+                Lb.suscan_config_set_integer(cfg, b"clock.type", 1)
+                Lb.suscan_config_set_float(cfg, b"clock.baud", baud)
+                assert Lb.suscan_analyzer_set_inspector_config_async(an, m.handle, cfg, 8)
+                Lb.suscan_config_destroy(cfg)
+            elif m.kind == suscan.KIND_SET_CONFIG:
+                st["cfg_at"] = st["psd"]
+        elif tp == suscan.MSG_SAMPLES and st["cfg_at"] is not None:
+            m = C.cast(ptr, C.POINTER(suscan.SampleBatchMsg)).contents
+            st["samples"].append(np.ctypeslib.as_array(m.samples, shape=(m.sample_count * 2,)).copy().view(np.complex64))
+
+    _pump(Lb, an, on_msg)
+    b0 = st["cfg_at"]
+    assert b0 is not None and b0 < nblocks - 8
+    dp = sdo.fnor_to_dphase(-2 * fc / FS)
+    taps = sdo.lpf_design(255, bw / FS)
+    y = sdo.chan_feed(np.zeros(254, np.complex64), x[b0 * L:], 0, sdo.chan_modulate_taps(taps, dp), D, 0, dp)
+    a = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(sps)), y)
+    z = sdo.costas_feed_bulk(sdo.costas_new(2, 0.0, min(2.0 / sps, 0.95), 3, 2 * 5.0 / efs), a)
+    ref = sdo.clock_feed_bulk(sdo.clock_new(0.2, baud / efs), z)
+    got = np.concatenate(st["samples"])
+    assert len(ref) > 100 and len(got) == len(ref)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "symbols differ from the oracle"
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+
+
 def test_halt_wakes_the_reader_and_bad_source_reports_failure(tmp_path):
     x = synth.tone_noise(L * 2, seed=1)
     path = tmp_path / "iq.raw"
