@@ -9,6 +9,7 @@
 // prefetched one chunk ahead of the serial arithmetic.
 // Compiled with -ffp-contract=off: the arithmetic is the SPEC's fixed binary32 sequence and
 // matches the CPU oracle bit for bit.
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.hpp"
@@ -430,7 +431,12 @@ struct ClockRegs {
 __device__ __forceinline__ void clock_step(const sdk::ClockParams &p, ClockRegs &r, float2 v, float2 *__restrict__ out)
 {
   r.phi = r.phi + r.bnor;
-  if (r.phi >= 0.5f) {
+  // The straight path must not touch EXEC: a divergent `if` costs a lone wavefront ~100 cycles per sample in
+  // v_cmp -> s_and_saveexec -> VALU hazards even when no lane takes it.  A wave-uniform test (scalar branch on the
+  // ballot) keeps the sample that only advances the phase at add + compare + branch; the crossing code sits off the
+  // straight path and is entered -- with its lane mask -- only when some lane crosses.
+  const bool cross = r.phi >= 0.5f;
+  if (__builtin_expect(__any(cross), 0) && cross) {
     const float mu = (r.phi - 0.5f) / r.bnor;
     float2 q;
     q.x = sd::fma_(mu, r.prev.x - v.x, v.x);
@@ -455,33 +461,7 @@ __device__ __forceinline__ void clock_step(const sdk::ClockParams &p, ClockRegs 
   r.prev = v;
 }
 
-__global__ __launch_bounds__(64) void clock_kernel(sdk::ClockParams p, sdk::ClockState s, int nchan,
-                                                   const float2 *__restrict__ x, sdk::View xv, long long len,
-                                                   float2 *__restrict__ sym, long long sym_stride,
-                                                   uint32_t *__restrict__ count)
-{
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= nchan) return;
-  ClockRegs r;
-  r.phi = s.phi[c]; r.bnor = s.bnor[c];
-  r.halfcycle = s.halfcycle[c];
-  r.prev = float2{s.prev[c], s.prev[nchan + c]};
-  r.x0 = float2{s.x0[c], s.x0[nchan + c]};
-  r.x1 = float2{s.x1[c], s.x1[nchan + c]};
-  r.x2 = float2{s.x2[c], s.x2[nchan + c]};
-  r.n = count[c];
-  const uint32_t xo = (uint32_t)((long long)c * xv.cs * 8);
-  float2 *out = sym + (long long)c * sym_stride;
-  if (xv.ms == 64) stream_row(x, 64, xo, len, [&](long long, float2 v) { clock_step(p, r, v, out); });
-  else if (xv.ms == 1) stream_row(x, 1, xo, len, [&](long long, float2 v) { clock_step(p, r, v, out); });
-  else stream_row(x, xv.ms, xo, len, [&](long long, float2 v) { clock_step(p, r, v, out); });
-  s.phi[c] = r.phi; s.bnor[c] = r.bnor; s.halfcycle[c] = r.halfcycle;
-  s.prev[c] = r.prev.x; s.prev[nchan + c] = r.prev.y;
-  s.x0[c] = r.x0.x; s.x0[nchan + c] = r.x0.y;
-  s.x1[c] = r.x1.x; s.x1[nchan + c] = r.x1.y;
-  s.x2[c] = r.x2.x; s.x2[nchan + c] = r.x2.y;
-  count[c] = r.n;
-}
+// (clock_kernel: further down, next to the crossing-driven stream it shares with the gangs)
 
 // ---------------------------------------------------------------------------------------
 // K9: AGC (SPEC.md section H).  Only the fast / slow level trackers are a recurrence.  The dB
@@ -1031,23 +1011,31 @@ __global__ __launch_bounds__(64) void cma_gang_kernel(const sdk::CmaGangItem *__
 // (Measured alternative: advancing four samples per pass with selects instead of the branchy one-sample loop is
 // slower, 7.3 vs 6.3 ms per 64 x 65536 samples -- the loop is mostly scalar instructions, the selects are vector ones.)
 constexpr int CT = 64;          // samples per LDS tile
-__device__ __forceinline__ void clock_stream_tm(const float2 *tm, long long len, const sdk::ClockParams &p, ClockRegs &r, float2 *__restrict__ out)
+// SLACK: the rows extend (readably) to a whole tile past the longest one -- the gangs' slabs; otherwise the last tile's
+// loads are bounded.  Sample m of the lane sits at base[m * pitch] + lo bytes.
+template <bool SLACK>
+__device__ __forceinline__ void clock_stream_tm(const float2 *base, const long long pitch, const uint32_t lo, long long len,
+                                                const sdk::ClockParams &p, ClockRegs &r, float2 *__restrict__ out)
 {
   __shared__ float2 tile[CT * 64];
   const int lane = threadIdx.x;
-  const uint32_t lo = lane * 8u;
   const long long maxlen = uniform64(wave_max(len));
   if (maxlen <= 0) return;
   float2 pre[CT];
+  auto request = [&](long long t0) {
+    if (SLACK || t0 + CT <= maxlen) {
 #pragma unroll
-  for (int j = 0; j < CT; ++j) pre[j] = ld_elem(tm, (long long)j * 64, lo);
+      for (int j = 0; j < CT; ++j) pre[j] = ld_elem(base, (t0 + j) * pitch, lo);
+    } else {
+#pragma unroll
+      for (int j = 0; j < CT; ++j) pre[j] = t0 + j < maxlen ? ld_elem(base, (t0 + j) * pitch, lo) : float2{0.0f, 0.0f};
+    }
+  };
+  request(0);
   for (long long s0 = 0; s0 < maxlen; s0 += CT) {
 #pragma unroll
     for (int j = 0; j < CT; ++j) tile[j * 64 + lane] = pre[j];
-    if (s0 + CT < maxlen) {                                   // the next tile waits in registers while this one is worked on
-#pragma unroll
-      for (int j = 0; j < CT; ++j) pre[j] = ld_elem(tm, (s0 + CT + j) * 64, lo);
-    }
+    if (s0 + CT < maxlen) request(s0 + CT);                   // the next tile waits in registers while this one is worked on
     const long long left = len - s0;
     const int end = left <= 0 ? 0 : (left < CT ? (int)left : CT);
     int j = 0;
@@ -1088,6 +1076,43 @@ __device__ __forceinline__ void clock_stream_tm(const float2 *tm, long long len,
   }
 }
 
+__global__ __launch_bounds__(64) void clock_kernel(sdk::ClockParams p, sdk::ClockState s, int nchan,
+                                                   const float2 *__restrict__ x, sdk::View xv, long long len,
+                                                   float2 *__restrict__ sym, long long sym_stride,
+                                                   uint32_t *__restrict__ count, int mode)
+{
+  const int cc = blockIdx.x * 64 + threadIdx.x;
+  const bool live = cc < nchan;                               // idle lanes take part in the wave-wide steps with length 0
+  const int c = live ? cc : 0;
+  ClockRegs r;
+  r.phi = s.phi[c]; r.bnor = s.bnor[c];
+  r.halfcycle = s.halfcycle[c];
+  r.prev = float2{s.prev[c], s.prev[nchan + c]};
+  r.x0 = float2{s.x0[c], s.x0[nchan + c]};
+  r.x1 = float2{s.x1[c], s.x1[nchan + c]};
+  r.x2 = float2{s.x2[c], s.x2[nchan + c]};
+  r.n = count[c];
+  const uint32_t xo = (uint32_t)((long long)c * xv.cs * 8);
+  float2 *out = sym + (long long)c * sym_stride;
+  const long long mylen = live ? len : 0;
+  if (mode == 1) {
+    if (xv.ms == 64) clock_stream_tm<false>(x, 64, xo, mylen, p, r, out);
+    else if (xv.ms == 1) clock_stream_tm<false>(x, 1, xo, mylen, p, r, out);
+    else clock_stream_tm<false>(x, xv.ms, xo, mylen, p, r, out);
+  } else {
+    if (xv.ms == 64) stream_row(x, 64, xo, mylen, [&](long long, float2 v) { clock_step(p, r, v, out); });
+    else if (xv.ms == 1) stream_row(x, 1, xo, mylen, [&](long long, float2 v) { clock_step(p, r, v, out); });
+    else stream_row(x, xv.ms, xo, mylen, [&](long long, float2 v) { clock_step(p, r, v, out); });
+  }
+  if (!live) return;
+  s.phi[c] = r.phi; s.bnor[c] = r.bnor; s.halfcycle[c] = r.halfcycle;
+  s.prev[c] = r.prev.x; s.prev[nchan + c] = r.prev.y;
+  s.x0[c] = r.x0.x; s.x0[nchan + c] = r.x0.y;
+  s.x1[c] = r.x1.x; s.x1[nchan + c] = r.x1.y;
+  s.x2[c] = r.x2.x; s.x2[nchan + c] = r.x2.y;
+  count[c] = r.n;
+}
+
 __global__ __launch_bounds__(64) void clock_gang_kernel(const sdk::ClockGangItem *__restrict__ items, int n, float2 *tm, long long slab)
 {
   const int j = blockIdx.x * 64 + threadIdx.x;
@@ -1105,7 +1130,7 @@ __global__ __launch_bounds__(64) void clock_gang_kernel(const sdk::ClockGangItem
   r.n = it.count[0];
   const long long len = live ? it.len : 0;
   float2 *out = reinterpret_cast<float2 *>(it.sym);
-  clock_stream_tm(tm + (size_t)blockIdx.x * slab, len, p, r, out);
+  clock_stream_tm<true>(tm + (size_t)blockIdx.x * slab, 64, threadIdx.x * 8u, len, p, r, out);
   if (!live) return;
   s.phi[0] = r.phi; s.bnor[0] = r.bnor; s.halfcycle[0] = r.halfcycle;
   s.prev[0] = r.prev.x; s.prev[1] = r.prev.y;
@@ -1261,8 +1286,9 @@ hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, cons
                       long long len, void *sym, long long sym_stride, uint32_t *count, hipStream_t st)
 {
   if (len <= 0 || nchan <= 0) return hipSuccess;
+  static const int mode = getenv("SUAMD_CLOCK_MODE") ? atoi(getenv("SUAMD_CLOCK_MODE")) : 0;   // tuning knob: 1 = crossing by crossing
   hipLaunchKernelGGL(clock_kernel, dim3((nchan + 63) / 64), dim3(64), 0, st, p, s, nchan,
-                     reinterpret_cast<const float2 *>(x), xs, len, reinterpret_cast<float2 *>(sym), sym_stride, count);
+                     reinterpret_cast<const float2 *>(x), xs, len, reinterpret_cast<float2 *>(sym), sym_stride, count, mode);
   return hipGetLastError();
 }
 
