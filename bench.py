@@ -408,6 +408,11 @@ def main():
                             "ms_per_step": round(dt2 / a2.steps * 1e3, 4),
                             "stage_ms": {k: round(v, 4) for k, v in st2.items()}}
             extra["c5"] = run_c5(args, dev, ctx)
+            try:                                              # the drop-in boundary itself, end to end (host thread, file source)
+                from sigdigger_amd.livebench import live_rate
+                extra["live64"] = live_rate(64, 30)
+            except Exception as e:                            # a secondary figure must not take the bench line down
+                extra["live64"] = {"error": repr(e)}
             out["host_fed"] = run_host_fed(args.workload, args, dev, ctx)
             out["other_workloads"] = extra
         if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (rank 0's host cores)

@@ -1,0 +1,87 @@
+"""Throughput of the live path: the suscan_analyzer_* C ABI (include/suscan_amd.h) with N PSK inspectors that share
+nothing -- different carriers, bandwidths, bauds, Costas orders and loop bandwidths -- on a looping capture in the
+page cache, unthrottled.  Used by bench.py ("live64" under other_workloads) and tools/analyzer_bench.py."""
+import ctypes as C
+import os
+import shutil
+import tempfile
+import time
+
+import numpy as np
+
+from . import suscan
+
+
+def live_rate(n_inspectors=64, nblocks=40, fs=50_000_000, nfft=8192, block=1 << 21, timeout_s=60.0):
+    Lb = suscan.load()
+    d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    path = os.path.join(d, "cap.raw")
+    try:
+        rng = np.random.default_rng(1)
+        (0.1 * rng.standard_normal(2 * block * 4).astype(np.float32)).tofile(path)          # 4 blocks, looped
+        mq = suscan.MQ()
+        assert Lb.suscan_mq_init(C.byref(mq))
+        cfg = Lb.suscan_source_config_new(b"file", 1)
+        Lb.suscan_source_config_set_samp_rate(cfg, fs)
+        Lb.suscan_source_config_set_path(cfg, path.encode())
+        Lb.suscan_source_config_set_loop(cfg, 1)
+        p = suscan.AnalyzerParams.default()
+        p.detector_params.window_size = nfft
+        p.detector_params.window = 4
+        p.psd_update_int = block / fs
+        an = Lb.suscan_analyzer_new(C.byref(p), cfg, C.byref(mq))
+        assert an
+        Lb.suscan_source_config_destroy(cfg)
+        Lb.suscan_analyzer_set_throttle_async(an, 0, 0)
+        spacing = min(300e3, 0.9 * fs / n_inspectors)                                       # every channel inside +-fs/2
+        for k in range(n_inspectors):
+            fc = (k - n_inspectors / 2 + 0.5) * spacing
+            bw = (100e3 + 10e3 * (k % 7)) * spacing / 300e3
+            ch = suscan.Channel(fc=float(fc), f_lo=float(fc - bw / 2), f_hi=float(fc + bw / 2), bw=float(bw), ft=100e6)
+            assert Lb.suscan_analyzer_open_ex_async(an, b"psk", C.byref(ch), 1, -1, 1000 + k)
+        st = {"psd": 0, "sym": 0, "t0": None, "cfg": 0, "result": None}
+        deadline = time.time() + timeout_s
+        while True:
+            t = C.c_uint32(0)
+            ptr = Lb.suscan_analyzer_read(an, C.byref(t))
+            if t.value == suscan.MSG_HALT:
+                break
+            if t.value == suscan.MSG_INSPECTOR:
+                m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
+                if m.kind == suscan.KIND_OPEN:
+                    k = m.req_id - 1000
+                    c2 = Lb.suscan_config_dup(m.config)
+                    Lb.suscan_config_set_integer(c2, b"afc.costas-order", 1 + k % 3)
+                    Lb.suscan_config_set_float(c2, b"afc.loop-bw", 50.0 + 5 * (k % 11))
+                    Lb.suscan_config_set_integer(c2, b"clock.type", 1)
+                    Lb.suscan_config_set_float(c2, b"clock.baud", (20e3 + 1e3 * (k % 13)) * spacing / 300e3)
+                    Lb.suscan_analyzer_set_inspector_config_async(an, m.handle, c2, 2000 + k)
+                    Lb.suscan_config_destroy(c2)
+                elif m.kind == suscan.KIND_SET_CONFIG:
+                    st["cfg"] += 1
+            elif t.value == suscan.MSG_PSD:
+                if st["cfg"] == n_inspectors and st["t0"] is None:
+                    st["t0"], st["psd"] = time.time(), 0
+                st["psd"] += 1
+                if st["t0"] is not None and st["psd"] == nblocks and st["result"] is None:
+                    dt = time.time() - st["t0"]
+                    st["result"] = {"workload": f"live analyzer through the suscan ABI: {nfft}-pt PSD + {n_inspectors} heterogeneous PSK "
+                                                f"inspectors (own carrier / bandwidth / baud / Costas order / loop bandwidth), file source, "
+                                                f"{block}-sample blocks at {fs / 1e6:g} MS/s",
+                                    "value_MSps": round(nblocks * block / dt / 1e6, 3), "ms_per_block": round(dt / nblocks * 1e3, 4),
+                                    "symbols_Msps": round(st["sym"] / dt / 1e6, 3), "inspectors": n_inspectors, "blocks": nblocks}
+                    Lb.suscan_analyzer_req_halt(an)
+                elif time.time() > deadline and st["result"] is None:
+                    st["result"] = {"error": f"only {st['cfg']} of {n_inspectors} inspectors configured within {timeout_s} s"}
+                    Lb.suscan_analyzer_req_halt(an)
+            elif t.value == suscan.MSG_SAMPLES and st["t0"] is not None:
+                st["sym"] += C.cast(ptr, C.POINTER(suscan.SampleBatchMsg)).contents.sample_count
+            elif t.value == suscan.MSG_EOS:
+                Lb.suscan_analyzer_dispose_message(t.value, ptr)
+                break
+            Lb.suscan_analyzer_dispose_message(t.value, ptr)
+        Lb.suscan_analyzer_destroy(an)
+        Lb.suscan_mq_finalize(C.byref(mq))
+        return st["result"] or {"error": "analyzer halted before the measurement finished"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
