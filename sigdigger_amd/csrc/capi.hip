@@ -142,27 +142,16 @@ void make_window(int type, std::vector<float> &w)
 // ==========================================================================================
 struct suamd_ctx {
   int device;
-  // descriptor tables of the gang launches: a ring of slots in device memory (a slot is reused 128 gang
-  // calls later; gang calls of one context are expected on one stream, or externally ordered)
+  // descriptor tables of the gang launches: a ring of slots in device memory.  A slot comes round again 128 uploads
+  // later; if that is on another stream than its previous use, the new stream first waits (on the device) for
+  // everything the old one has been given so far
   static constexpr int GANG_SLOTS = 128;
   static constexpr size_t GANG_SLOT_BYTES = 64 * 1024;
   char *gang_ring = nullptr;
   int gang_next = 0;
-  // loop types of one gang call are independent: they fork onto side streams and join back
-  static constexpr int GANG_SIDE = 4;
-  hipStream_t side[GANG_SIDE] = {};
-  hipEvent_t ev_fork = nullptr, ev_join[GANG_SIDE] = {};
-  bool side_ready = false;
-  bool init_side()
-  {
-    if (side_ready) return true;
-    if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return false;
-    for (int i = 0; i < GANG_SIDE; ++i)
-      if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess) return false;
-    side_ready = true;
-    return true;
-  }
+  hipStream_t gang_user[GANG_SLOTS] = {};
+  bool gang_used[GANG_SLOTS] = {};
+  hipEvent_t gang_ev = nullptr;
   // time-major slabs of the gang launches: a stream-ordered ring.  A region is handed out again only behind the event
   // its previous user recorded when it was done with it (a device-side wait on the new user's stream: the host
   // never blocks; hipMallocAsync / hipFreeAsync cost ~240 us per pair here)
@@ -212,8 +201,7 @@ struct suamd_ctx {
     for (hipEvent_t ev : slab_spare) (void)hipEventDestroy(ev);
     if (slab_base) (void)hipFree(slab_base);
     if (gang_ring) (void)hipFree(gang_ring);
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    for (int i = 0; i < GANG_SIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
+    if (gang_ev) (void)hipEventDestroy(gang_ev);
   }
 };
 
@@ -274,8 +262,16 @@ static Item *gang_upload(suamd_ctx *ctx, const std::vector<Item> &items, hipStre
   if (!ctx->gang_ring && hipMalloc((void **)&ctx->gang_ring, suamd_ctx::GANG_SLOTS * suamd_ctx::GANG_SLOT_BYTES) != hipSuccess) {
     set_err("device allocation failed"); return nullptr;
   }
-  char *slot = ctx->gang_ring + (size_t)ctx->gang_next * suamd_ctx::GANG_SLOT_BYTES;
+  const int si = ctx->gang_next;
+  char *slot = ctx->gang_ring + (size_t)si * suamd_ctx::GANG_SLOT_BYTES;
   ctx->gang_next = (ctx->gang_next + 1) % suamd_ctx::GANG_SLOTS;
+  if (ctx->gang_used[si] && ctx->gang_user[si] != st) {
+    if (!ctx->gang_ev && hipEventCreateWithFlags(&ctx->gang_ev, hipEventDisableTiming) != hipSuccess) ctx->gang_ev = nullptr;
+    if (ctx->gang_ev && hipEventRecord(ctx->gang_ev, ctx->gang_user[si]) == hipSuccess) (void)hipStreamWaitEvent(st, ctx->gang_ev, 0);
+    else (void)hipGetLastError();                              // the old stream is gone: nothing of it can be in flight
+  }
+  ctx->gang_used[si] = true;
+  ctx->gang_user[si] = st;
   if (hipMemcpyAsync(slot, items.data(), bytes, hipMemcpyHostToDevice, st) != hipSuccess) { set_err("descriptor upload failed"); return nullptr; }
   return reinterpret_cast<Item *>(slot);
 }
