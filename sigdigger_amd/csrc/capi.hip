@@ -142,16 +142,16 @@ void make_window(int type, std::vector<float> &w)
 // ==========================================================================================
 struct suamd_ctx {
   int device;
-  // descriptor tables of the gang launches: a ring of slots in device memory.  A slot comes round again 128 uploads
-  // later; if that is on another stream than its previous use, the new stream first waits (on the device) for
-  // everything the old one has been given so far
+  // descriptor tables of the gang launches: a ring of slots in device memory.  The launches that read a slot are
+  // enqueued right after its upload, so the next upload marks the slot's stream with the slot's event; when the
+  // slot comes round again (128 uploads later) on another stream, that stream waits for the event on the device
   static constexpr int GANG_SLOTS = 128;
   static constexpr size_t GANG_SLOT_BYTES = 64 * 1024;
   char *gang_ring = nullptr;
-  int gang_next = 0;
+  int gang_next = 0, gang_open = -1;                        // gang_open: the slot whose launches are being enqueued
   hipStream_t gang_user[GANG_SLOTS] = {};
-  bool gang_used[GANG_SLOTS] = {};
-  hipEvent_t gang_ev = nullptr;
+  hipEvent_t gang_ev[GANG_SLOTS] = {};
+  bool gang_marked[GANG_SLOTS] = {};
   // time-major slabs of the gang launches: a stream-ordered ring.  A region is handed out again only behind the event
   // its previous user recorded when it was done with it (a device-side wait on the new user's stream: the host
   // never blocks; hipMallocAsync / hipFreeAsync cost ~240 us per pair here)
@@ -201,7 +201,7 @@ struct suamd_ctx {
     for (hipEvent_t ev : slab_spare) (void)hipEventDestroy(ev);
     if (slab_base) (void)hipFree(slab_base);
     if (gang_ring) (void)hipFree(gang_ring);
-    if (gang_ev) (void)hipEventDestroy(gang_ev);
+    for (hipEvent_t ev : gang_ev) if (ev) (void)hipEventDestroy(ev);
   }
 };
 
@@ -265,12 +265,15 @@ static Item *gang_upload(suamd_ctx *ctx, const std::vector<Item> &items, hipStre
   const int si = ctx->gang_next;
   char *slot = ctx->gang_ring + (size_t)si * suamd_ctx::GANG_SLOT_BYTES;
   ctx->gang_next = (ctx->gang_next + 1) % suamd_ctx::GANG_SLOTS;
-  if (ctx->gang_used[si] && ctx->gang_user[si] != st) {
-    if (!ctx->gang_ev && hipEventCreateWithFlags(&ctx->gang_ev, hipEventDisableTiming) != hipSuccess) ctx->gang_ev = nullptr;
-    if (ctx->gang_ev && hipEventRecord(ctx->gang_ev, ctx->gang_user[si]) == hipSuccess) (void)hipStreamWaitEvent(st, ctx->gang_ev, 0);
-    else (void)hipGetLastError();                              // the old stream is gone: nothing of it can be in flight
+  if (ctx->gang_open >= 0) {                                  // the previous slot's launches are all enqueued by now
+    const int po = ctx->gang_open;
+    if (!ctx->gang_ev[po] && hipEventCreateWithFlags(&ctx->gang_ev[po], hipEventDisableTiming) != hipSuccess) ctx->gang_ev[po] = nullptr;
+    ctx->gang_marked[po] = ctx->gang_ev[po] && hipEventRecord(ctx->gang_ev[po], ctx->gang_user[po]) == hipSuccess;
+    if (!ctx->gang_marked[po]) (void)hipGetLastError();
   }
-  ctx->gang_used[si] = true;
+  if (ctx->gang_marked[si] && ctx->gang_user[si] != st) (void)hipStreamWaitEvent(st, ctx->gang_ev[si], 0);
+  ctx->gang_marked[si] = false;
+  ctx->gang_open = si;
   ctx->gang_user[si] = st;
   if (hipMemcpyAsync(slot, items.data(), bytes, hipMemcpyHostToDevice, st) != hipSuccess) { set_err("descriptor upload failed"); return nullptr; }
   return reinterpret_cast<Item *>(slot);

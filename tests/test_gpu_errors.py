@@ -92,3 +92,40 @@ def test_degenerate_inputs_are_no_ops(ctx, sdo):
     cma = engine.CMABank(ctx, 3, 4, 1e-3)
     cma.feed(sym, count=cnt)
     assert np.array_equal(cma.weights()[0], np.ones(3, np.complex64)) and not cma.weights()[1:].any()
+
+
+def test_gang_calls_refuse_bad_arguments(ctx):
+    """gangs: only 1-channel banks, no aliased AGC rows, sub-ranges inside the block; empty gangs / blocks are no-ops"""
+    lib = ctx.lib
+    taps = ctx.lpf_design(63, 0.1)
+    wide = engine.ChannelBank(ctx, [0.1, -0.1], 4, taps)
+    one = engine.ChannelBank(ctx, [0.1], 4, taps)
+    x = dev(synth.tone_noise(4096, seed=2))
+    y = torch.empty(2048, dtype=torch.complex64, device="cuda")
+    with pytest.raises(L.SigDiggerAmdError, match="1-channel"):
+        engine.gang_chan(ctx, [wide], x, [y])
+    with pytest.raises(L.SigDiggerAmdError):
+        engine.gang_chan(ctx, [one], x, [torch.empty(8, dtype=torch.complex64, device="cuda")])        # row too short
+    assert [t.numel() for t in engine.gang_chan(ctx, [one], x[:0], [y])] == [0]                        # empty block
+    assert engine.gang_chan(ctx, [], x, []) == []                                                      # empty gang
+    ptrs = (C.c_void_p * 1)(one.h)
+    assert not lib.suamd_chanbank_gang_feed(ctx.h, ptrs, 1, x.data_ptr(), 4096, None, None, None)     # no output rows
+    assert b"null" in lib.suamd_last_error()
+    agc = engine.AGCBank(ctx, 1, tau=8.0)
+    with pytest.raises(L.SigDiggerAmdError, match="alias"):
+        engine.gang_agc(ctx, [agc], [x], [x])
+    two = engine.AGCBank(ctx, 2, tau=8.0)
+    with pytest.raises(L.SigDiggerAmdError, match="1-channel"):
+        engine.gang_agc(ctx, [two], [x], [y.new_empty(4096)])
+    b = (C.c_void_p * 1)(agc.h)
+    lens, m0, m1 = (C.c_uint64 * 1)(4096), (C.c_uint64 * 1)(100), (C.c_uint64 * 1)(5000)
+    assert not lib.suamd_agc_gang_level(ctx.h, b, 1, lens, m0, m1, None)                               # sub-range past the block
+    assert b"sub-range" in lib.suamd_last_error()
+    m1[0] = 50
+    assert not lib.suamd_agc_gang_level(ctx.h, b, 1, lens, m0, m1, None)                               # m0 > m1
+    out = torch.zeros(16, dtype=torch.complex64, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert not lib.suamd_rows_deliver(ctx.h, 1, (C.c_void_p * 1)(x.data_ptr()), None, None, (C.c_void_p * 1)(out.data_ptr()),
+                                      (C.c_void_p * 1)(cnt.data_ptr()), None)                          # neither counter nor length
+    engine.rows_deliver(ctx, [], [], [], [])                                                           # nothing to hand over
+    torch.cuda.synchronize()
