@@ -175,6 +175,13 @@ enum suamd_sample_format {
 SUAMD_API SUBOOL   suamd_ingest_iq(suamd_ctx_t *ctx, int format, const void *d_raw, SUSCOUNT nsamples,
                                    suamd_complex *d_out, void *stream);
 SUAMD_API unsigned suamd_format_bytes_per_sample(int format);   /* per complex sample; 0 = unknown */
+/* Source conditioning in front of the path (Suscan::Analyzer::setIQReverse / setDCRemove, Suscan/Analyzer.cpp:
+ * 240-256; the arithmetic lives in libsuscan's source worker -- absent -- and is frozen in SPEC.md section L):
+ * in place, x <- swap(x) if iq_reverse, then x <- x - dc if d_dc != NULL, where the level d_dc[0..1] (device)
+ * follows the block means of the swapped signal: dc = first ? mean : dc + alpha (mean - dc), updated BEFORE
+ * the block is corrected. */
+SUAMD_API SUBOOL suamd_source_fix(suamd_ctx_t *ctx, suamd_complex *d_x, SUSCOUNT nsamples, SUBOOL iq_reverse,
+                                  SUFLOAT *d_dc, SUFLOAT alpha, SUBOOL first, void *stream);
 
 /* WaveSampler::sampleZeroCrossing (Tasks/WaveSampler.cpp:215-292), all work() calls of one capture:
  * run lengths between sign changes of `var` -> round(samples * bnor) symbols of value (var > 0).
@@ -393,6 +400,25 @@ SUAMD_API SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d
  * Tasks/CarrierDetector.cpp:58-75,94.  d_work: scratch of n complex values. */
 SUAMD_API SUBOOL suamd_fft_forward_bulk(suamd_ctx_t *ctx, const suamd_complex *d_in, suamd_complex *d_out,
                                         suamd_complex *d_work, unsigned log2n, void *stream);
+/* Baud estimators behind the inspectors' ESTIMATOR messages (Suscan/Analyzer.cpp:549-565,
+ * InspectorUI::updateEstimator, Default/GenericInspector/InspectorUI.cpp:1003-1015; the estimators themselves are
+ * libsuscan's -- absent -- and are frozen in SPEC.md section M).  Both work on the first `size` samples of a block:
+ *   NONLINEAR: y[n] = |x[n] - x[n-1]|^2 has spectral lines at the baud and its harmonics; Blackman-Harris, FFT, the
+ *              LOWEST local maximum of |Y|^2 outside a 1 % DC notch that reaches half of the strongest one (which must
+ *              stand 20x above the mean level: otherwise no estimate), 9-bin power centroid;
+ *   FAC:       fast autocorrelation (suamd_fac, alpha 0.25) -> first valley of the 3-tap smoothed curve below a
+ *              quarter of lag 0; baud = 1 / lag (whole samples).
+ * feed() only enqueues (results land in host-mapped memory); get() is valid after the stream was synchronised and
+ * returns the normalised baud (symbols per sample, x equiv_fs = Hz), 0 = no estimate.  Blocks shorter than `size`
+ * leave the estimate as it is. */
+typedef struct suamd_baud_estimator suamd_baud_estimator_t;
+enum suamd_baud_estimator_kind { SUAMD_BAUD_ESTIMATOR_FAC = 0, SUAMD_BAUD_ESTIMATOR_NONLINEAR = 1 };
+SUAMD_API suamd_baud_estimator_t *suamd_baud_estimator_new(suamd_ctx_t *ctx, int kind, unsigned size /* 2^k, 512..2^20 */);
+SUAMD_API void     suamd_baud_estimator_destroy(suamd_baud_estimator_t *e);
+SUAMD_API unsigned suamd_baud_estimator_size(const suamd_baud_estimator_t *e);
+SUAMD_API SUBOOL   suamd_baud_estimator_feed(suamd_baud_estimator_t *e, const suamd_complex *d_x, SUSCOUNT len, void *stream);
+SUAMD_API SUFLOAT  suamd_baud_estimator_get(const suamd_baud_estimator_t *e);
+
 /* CarrierDetector::work, all states (Tasks/CarrierDetector.cpp:49-147): zero-pad to a power of two,
  * Blackman-Harris over len, FFT, |X|^2 arg-max outside the DC notch, circular centroid over
  * alloc*avg_rel_bw + 1 bins.  *peak = carrier in rad/sample.  Synchronises the stream. */

@@ -165,6 +165,8 @@ struct suscan_analyzer_inspector_msg {
   uint32_t spectsrc_id, estimator_id;
   SUFLOAT *spectrum_data; SUSCOUNT spectrum_size; SUSCOUNT samp_rate;
   SUSCOUNT watermark;
+  SUBOOL   enabled;                           /* ESTIMATOR: estimator switched on; SET_TLE: correction enabled */
+  SUFLOAT  value;                             /* ESTIMATOR: the estimate, in the unit of the config field it feeds (Hz / baud) */
 };
 struct suscan_analyzer_status_msg { int code; char *err_msg; };
 
@@ -196,7 +198,7 @@ SUAMD_API SUBOOL suscan_analyzer_set_inspector_watermark_async(suscan_analyzer_t
                                                                SUSCOUNT watermark, uint32_t req_id);
 /* InspectorMessage's view of the source / estimator registries (Suscan/Messages/InspectorMessage.cpp:44-61:
  * it reads ->desc of the spectrum source class and ->desc / ->field of the estimator class; NULL = unknown
- * name, then the name itself is shown).  No parameter estimators are offered: estimator_count is 0. */
+ * name, then the name itself is shown). */
 struct suscan_spectsrc_class  { const char *name; const char *desc; };
 struct suscan_estimator_class { const char *name; const char *desc; const char *field; };
 SUAMD_API const struct suscan_spectsrc_class  *suscan_spectsrc_class_lookup(const char *name);
@@ -211,6 +213,57 @@ SUAMD_API SUBOOL suscan_analyzer_set_inspector_freq_overridable(suscan_analyzer_
                                                                 SUFREQ freq);
 SUAMD_API SUBOOL suscan_analyzer_set_inspector_bandwidth_overridable(suscan_analyzer_t *analyzer, SUHANDLE handle,
                                                                      SUFREQ bw);
+/* Analyzer::setInspectorEnabled (Suscan/Analyzer.cpp:549-565): estimator_id indexes estimator_list of the OPEN
+ * message; while enabled, INSPECTOR messages of kind ESTIMATOR carry {estimator_id, enabled, value} (value 0 = no
+ * estimate yet, which is how InspectorUI::updateEstimator reads it, InspectorUI.cpp:1003-1015) */
+SUAMD_API SUBOOL suscan_analyzer_inspector_estimator_cmd_async(suscan_analyzer_t *analyzer, SUHANDLE handle,
+                                                               uint32_t estimator_id, SUBOOL enabled, uint32_t req_id);
+/* Analyzer::setInspectorDopplerCorrection / disableDopplerCorrection (Suscan/Analyzer.cpp:567-591).  Orbit propagation
+ * is outside this path: tle == NULL (disable) is acknowledged with a SET_TLE message, anything else with
+ * INVALID_ARGUMENT */
+typedef struct orbit orbit_t;
+SUAMD_API SUBOOL suscan_analyzer_inspector_set_tle_async(suscan_analyzer_t *analyzer, SUHANDLE handle,
+                                                         const orbit_t *tle, uint32_t req_id);
+
+/* ---- baseband filters (Suscan/Analyzer.cpp:127-142; Default/Source/SourceWidget.cpp:1155-1171) -------------
+ * Called on the analyzer's worker thread with every block of SUCOMPLEX samples before anything else sees it
+ * (lower prio first; plain registration = prio 0 in call order); what they write is what the PSD and the
+ * inspectors get; returning SU_FALSE stops the analyzer with a READ_ERROR.  `offset` = samples delivered so far. */
+typedef SUBOOL (*suscan_analyzer_baseband_filter_func_t)(void *privdata, suscan_analyzer_t *analyzer,
+                                                         suamd_complex *samples, SUSCOUNT length, SUSCOUNT offset);
+SUAMD_API SUBOOL suscan_analyzer_register_baseband_filter(suscan_analyzer_t *analyzer,
+                                                          suscan_analyzer_baseband_filter_func_t func, void *privdata);
+SUAMD_API SUBOOL suscan_analyzer_register_baseband_filter_with_prio(suscan_analyzer_t *analyzer,
+                                                                    suscan_analyzer_baseband_filter_func_t func,
+                                                                    void *privdata, int64_t prio);
+
+/* ---- source controls (Suscan/Analyzer.cpp:144-281).  A file / generator source has no tuner: frequency, LNB,
+ * bandwidth, ppm, gain, antenna and AGC settings are recorded and reflected in the source info (a SOURCE_INFO
+ * message follows every change); I/Q reversal and DC removal act on the samples (suamd_source_fix); seek moves the
+ * file position; history / replay are accepted (the file is its own history). */
+SUAMD_API SUBOOL suscan_analyzer_set_freq(suscan_analyzer_t *analyzer, SUFREQ freq, SUFREQ lnb);
+SUAMD_API SUBOOL suscan_analyzer_set_gain(suscan_analyzer_t *analyzer, const char *name, SUFLOAT value);
+SUAMD_API SUBOOL suscan_analyzer_set_antenna(suscan_analyzer_t *analyzer, const char *name);
+SUAMD_API SUBOOL suscan_analyzer_set_bw(suscan_analyzer_t *analyzer, SUFLOAT bw);
+SUAMD_API SUBOOL suscan_analyzer_set_ppm(suscan_analyzer_t *analyzer, SUFLOAT ppm);
+SUAMD_API SUBOOL suscan_analyzer_set_agc(suscan_analyzer_t *analyzer, SUBOOL enabled);
+SUAMD_API SUBOOL suscan_analyzer_set_dc_remove(suscan_analyzer_t *analyzer, SUBOOL remove);
+SUAMD_API SUBOOL suscan_analyzer_set_iq_reverse(suscan_analyzer_t *analyzer, SUBOOL reverse);
+SUAMD_API SUBOOL suscan_analyzer_seek(suscan_analyzer_t *analyzer, const struct timeval *pos);
+SUAMD_API SUBOOL suscan_analyzer_set_history_size(suscan_analyzer_t *analyzer, SUSCOUNT size);
+SUAMD_API SUBOOL suscan_analyzer_replay(suscan_analyzer_t *analyzer, SUBOOL replay);
+SUAMD_API void   suscan_analyzer_get_source_time(const suscan_analyzer_t *analyzer, struct timeval *tv);
+
+/* ---- wide-spectrum (panoramic) controls (Suscan/Analyzer.cpp:177-195, 258-281; Panoramic/Scanner.cpp:295-370).
+ * Valid in SUSCAN_ANALYZER_MODE_WIDE_SPECTRUM only (SU_FALSE otherwise).  Hopping needs a tuner; with a file source
+ * the values are recorded and every PSD frame carries the source's own frequency (the noHop case of the Scanner). */
+enum suscan_analyzer_sweep_strategy { SUSCAN_ANALYZER_SWEEP_STRATEGY_STOCHASTIC = 0, SUSCAN_ANALYZER_SWEEP_STRATEGY_PROGRESSIVE = 1 };
+enum suscan_analyzer_spectrum_partitioning { SUSCAN_ANALYZER_SPECTRUM_PARTITIONING_DISCRETE = 0, SUSCAN_ANALYZER_SPECTRUM_PARTITIONING_CONTINUOUS = 1 };
+SUAMD_API SUBOOL suscan_analyzer_set_sweep_stratrgy(suscan_analyzer_t *analyzer, enum suscan_analyzer_sweep_strategy strategy);  /* sic */
+SUAMD_API SUBOOL suscan_analyzer_set_spectrum_partitioning(suscan_analyzer_t *analyzer, enum suscan_analyzer_spectrum_partitioning p);
+SUAMD_API SUBOOL suscan_analyzer_set_hop_range(suscan_analyzer_t *analyzer, SUFREQ min, SUFREQ max);
+SUAMD_API SUBOOL suscan_analyzer_set_rel_bandwidth(suscan_analyzer_t *analyzer, SUFLOAT rel_bw);
+SUAMD_API SUBOOL suscan_analyzer_set_buffering_size(suscan_analyzer_t *analyzer, SUSCOUNT size);
 
 #ifdef __cplusplus
 }

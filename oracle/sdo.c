@@ -994,6 +994,74 @@ void sdo_ingest_iq(int format, const void *raw, size_t n, sdo_c32 *out)
   }
 }
 
+float sdo_baud_nonlinear(const sdo_c32 *x, size_t n)
+{
+  sdo_c32 *y = malloc(n * sizeof *y);
+  double *re = malloc(sizeof(double) * n), *im = malloc(sizeof(double) * n);
+  float *P = malloc(sizeof(float) * n);
+  size_t t;
+  int k, half = (int)(n / 2), skip = (int)(0.01 * (double)n), first = -1;
+  float pmax = 0.f, thr;
+  double c = 0.0;
+  if (skip < 4) skip = 4;
+  y[0].re = y[0].im = 0.f;
+  for (t = 1; t < n; ++t) {
+    const float dr = x[t].re - x[t - 1].re, di = x[t].im - x[t - 1].im;
+    y[t].re = fmaf(dr, dr, di * di);
+    y[t].im = 0.f;
+  }
+  sdo_blackmann_harris_complex(y, n);
+  for (t = 0; t < n; ++t) { re[t] = y[t].re; im[t] = y[t].im; }
+  sdo_fft_f64(re, im, n);
+  for (k = 0; k < half; ++k) { const float a = (float)re[k], b = (float)im[k]; P[k] = fmaf(a, a, b * b); }
+  {
+    double sum = 0;
+    for (k = skip; k < half; ++k) { if (P[k] > pmax) pmax = P[k]; sum += (double)P[k]; }
+    thr = (double)pmax * (double)(half - skip) >= 20.0 * sum ? 0.5f * pmax : 0.f;   /* a line, not the tallest noise bin */
+  }
+  for (k = skip + 1; k < half - 1 && first < 0; ++k)
+    if (P[k] >= thr && P[k] >= P[k - 1] && P[k] >= P[k + 1]) first = k;
+  if (thr > 0.f && first >= 0) {
+    double num = 0, den = 0;
+    for (k = first - 4; k <= first + 4; ++k) {
+      if (k < skip || k >= half) continue;
+      num += (double)P[k] * (double)k; den += (double)P[k];
+    }
+    c = den > 0 ? num / den : 0.0;
+  }
+  free(y); free(re); free(im); free(P);
+  return (float)(c / (double)n);
+}
+
+float sdo_fac_first_valley(const float *R, size_t H)
+{
+  const float thr = 0.25f * R[0];
+  size_t l;
+#define SDO_S3(l_) ((R[(l_) - 1] + R[(l_)] + R[(l_) + 1]) * 0.33333334f)
+  for (l = 2; l + 2 < H; ++l) {
+    const float c = SDO_S3(l);
+    if (c < thr && c <= SDO_S3(l + 1)) return (float)l;
+  }
+#undef SDO_S3
+  return 0.f;
+}
+
+void sdo_source_fix(sdo_c32 *x, size_t n, int iq_reverse, float *dc, float alpha, int first)
+{
+  size_t i;
+  if (n == 0) return;
+  if (iq_reverse) for (i = 0; i < n; ++i) { float t = x[i].re; x[i].re = x[i].im; x[i].im = t; }
+  if (dc) {
+    double sr = 0, si = 0;
+    float mr, mi;
+    for (i = 0; i < n; ++i) { sr += x[i].re; si += x[i].im; }
+    mr = (float)(sr / (double)n); mi = (float)(si / (double)n);
+    if (first) { dc[0] = mr; dc[1] = mi; }
+    else { dc[0] = dc[0] + alpha * (mr - dc[0]); dc[1] = dc[1] + alpha * (mi - dc[1]); }
+    for (i = 0; i < n; ++i) { x[i].re = x[i].re - dc[0]; x[i].im = x[i].im - dc[1]; }
+  }
+}
+
 #define SDO_WS_BLOCK 4096   /* SIGDIGGER_WAVESAMPLER_FEEDER_BLOCK_LENGTH, include/WaveSampler.h:28 */
 
 /* var of sample p (Tasks/WaveSampler.cpp:240-267); products as in SPEC "element-wise" */

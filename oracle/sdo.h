@@ -211,6 +211,10 @@ float sdo_snr_get(const sdo_snr *e);                                  /* getSNR(
 /* ---- ingest (section 8f #1): file-source sample formats -> SUCOMPLEX ------------------------------ */
 /* format 1 f32, 2 u8 (v-128)/128, 3 s8 v/128, 4 s16 v/32768 [UPSTREAM-RECOLLECTION: libsndfile norm] */
 void sdo_ingest_iq(int format, const void *raw, size_t nsamples, sdo_c32 *out);
+/* source conditioning (SPEC.md section L) [UPSTREAM-RECOLLECTION: the arithmetic is libsuscan's]: in place, I/Q swap,
+ * then the tracked DC level dc[2] (NULL: none) follows the block mean -- dc = first ? mean : dc + alpha (mean - dc) --
+ * and is subtracted.  Setters: Suscan/Analyzer.cpp:240-256 */
+void sdo_source_fix(sdo_c32 *x, size_t nsamples, int iq_reverse, float *dc, float alpha, int first);
 
 /* ---- T9: carrier centroid [REF-PINNED structure] ------------------------------------ */
 /* Tasks/CarrierDetector.cpp:80-143. returns peak in rad/sample */
@@ -225,6 +229,15 @@ void  sdo_doppler_calc(const sdo_c32 *data, size_t len, float fs, double f0, flo
  * fac[i] += alpha (|.|/max - fac[i]).  fac: n/2 floats, *max / *min: running extrema (init -inf / +inf). */
 void sdo_fac_feed(const sdo_c32 *buf, size_t n, float alpha, long view_start, long view_end,
                   float *fac, float *max, float *min);
+
+/* ---- section 8f #2: baud estimators (SPEC.md section M) [UPSTREAM-RECOLLECTION: libsuscan's estimators] --- */
+/* nonlinear: y[n] = |x[n] - x[n-1]|^2 (y[0] = 0), Blackman-Harris, FFT; the lowest local maximum of |Y|^2 in
+ * [max(4, n/100), n/2) that reaches half of the strongest one -- provided that one stands 20x above the mean level,
+ * else there is no estimate (0) --, power centroid over +-4 bins; returns centroid / n.
+ * n = 2^k. */
+float sdo_baud_nonlinear(const sdo_c32 *x, size_t n);
+/* first valley of the 3-tap smoothed autocorrelation below fac[0] / 4; returns the lag in samples (0: none) */
+float sdo_fac_first_valley(const float *fac, size_t n_half);
 
 /* ---- P2/P3: SpectrumView [REF-PINNED] ----------------------------------------------- */
 #define SDO_SCANNER_SPECTRUM_SIZE 65536

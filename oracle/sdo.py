@@ -466,6 +466,14 @@ def ingest_iq(fmt, raw):
     return out
 
 
+def source_fix(x, iq_reverse, dc=None, alpha=0.1, first=True):
+    """in place on a copy; dc: float32[2] state (updated) or None"""
+    y = _c(x).copy()
+    lib().sdo_source_fix(_p(y), C.c_size_t(y.size), C.c_int(int(iq_reverse)),
+                         dc.ctypes.data_as(C.c_void_p) if dc is not None else None, C.c_float(alpha), C.c_int(int(first)))
+    return y
+
+
 def conj_prev(x, prev0=0j):
     x = _c(x)
     y = np.empty(x.size, dtype=c32)
@@ -489,6 +497,20 @@ class FAC:
         lib().sdo_fac_feed(_p(buf), C.c_size_t(self.n), C.c_float(self.alpha), C.c_long(int(view_start)), C.c_long(ve),
                            self.fac.ctypes.data_as(C.c_void_p), C.byref(self.max), C.byref(self.min))
         return self.fac
+
+
+def baud_nonlinear(x):
+    x = _c(x)
+    f = lib().sdo_baud_nonlinear
+    f.restype = C.c_float
+    return float(f(_p(x), C.c_size_t(x.size)))
+
+
+def fac_first_valley(fac):
+    fac = np.ascontiguousarray(fac, dtype=np.float32)
+    f = lib().sdo_fac_first_valley
+    f.restype = C.c_float
+    return float(f(fac.ctypes.data_as(C.c_void_p), C.c_size_t(fac.size)))
 
 
 def carrier_detect(data, avg_rel_bw, dc_notch_rel_bw):

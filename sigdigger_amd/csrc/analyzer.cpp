@@ -260,6 +260,17 @@ struct Source {
   void mark() { mark_pos = fp ? std::ftell(fp) : 0; mark_n = n; mark_lcg = lcg; }
   void rewind_to_mark() { if (fp) std::fseek(fp, mark_pos, SEEK_SET); n = mark_n; lcg = mark_lcg; }
 
+  // Suscan::Analyzer::seek: the next read starts at sample `pos` (clamped to the payload)
+  void seek(uint64_t pos)
+  {
+    if (fp) {
+      const size_t bps = bytes_per_sample();
+      if (data_bytes >= 0 && pos * bps > (uint64_t)data_bytes) pos = (uint64_t)data_bytes / bps;
+      std::fseek(fp, data_start + (long)(pos * bps), SEEK_SET);
+    }
+    n = pos;
+  }
+
   // fills dst with `want` samples in the payload format (bytes_per_sample() each); returns the
   // samples read (< want only at end of stream)
   size_t read(void *dst, size_t want, bool *looped)
@@ -319,6 +330,8 @@ struct Inspector {
   suamd_cma_bank_t *cma = nullptr;            // equalizer.type = CMA
   float fixed_gain = 0;                       // agc.enabled = false: linear agc.gain (0 = none)
   uint32_t spectsrc_id = 0;                   // 0 = none (Suscan/Analyzer.cpp:539-547)
+  suamd_baud_estimator_t *est[2] = {nullptr, nullptr};   // "baud-fac", "baud-nonlinear" (estimator_list of the OPEN message)
+  bool est_on[2] = {false, false}, est_fed[2] = {false, false};
   suamd_psd_t *spect_psd = nullptr;           // spectrum of the channel samples, one frame set per block
   unsigned spect_n = 0;
   suamd_complex *d_spre = nullptr;            // transformed samples
@@ -357,9 +370,14 @@ struct Inspector {
     if (d_spec) (void)hipFree(d_spec);
     spect_psd = nullptr; d_spre = nullptr; d_spec = nullptr; spect_n = 0;
   }
+  void free_estimators()
+  {
+    for (auto &e : est) { if (e) suamd_baud_estimator_destroy(e); e = nullptr; }
+  }
   void free_all()
   {
     free_spectrum();
+    free_estimators();
     if (pin) (void)hipHostFree(pin);
     if (h_out) (void)hipHostFree(h_out);
     pin = nullptr; h_out = nullptr;
@@ -373,7 +391,8 @@ struct Inspector {
 };
 
 struct Request {
-  enum Kind { OPEN, CLOSE, SET_ID, SET_CONFIG, SET_WATERMARK, SET_FREQ, SET_BW, SET_PARAMS, SET_THROTTLE, SET_SPECTRUM } kind;
+  enum Kind { OPEN, CLOSE, SET_ID, SET_CONFIG, SET_WATERMARK, SET_FREQ, SET_BW, SET_PARAMS, SET_THROTTLE, SET_SPECTRUM,
+              SEEK, SOURCE_INFO, ESTIMATOR, SET_TLE } kind;
   uint32_t req_id = 0;
   SUHANDLE handle = -1;
   std::string cls;
@@ -399,6 +418,21 @@ struct suscan_analyzer {
   std::atomic<uint64_t> throttle{0};
   struct suscan_source_info info{};
   SUHANDLE next_handle = 0;
+  // baseband filters (registered from the GUI thread, called on the worker thread): under req_m
+  struct Filter { suscan_analyzer_baseband_filter_func_t func; void *priv; int64_t prio; uint64_t seq; };
+  std::vector<Filter> filters;
+  uint64_t filter_seq = 0;
+  // source controls
+  std::atomic<bool> iq_reverse{false}, dc_remove{false};
+  std::atomic<uint64_t> position{0};            // samples delivered so far (get_source_time, filter offsets)
+  std::map<std::string, float> gains;
+  std::string antenna;
+  SUSCOUNT history_size = 0;
+  bool replay = false;
+  int sweep_strategy = 0, partitioning = 0;
+  double hop_min = 0, hop_max = 0;
+  float rel_bw = 1.0f;
+  SUSCOUNT buffering_size = 0;
   // worker-owned
   suamd_ctx_t *ctx = nullptr;
   suamd_psd_t *psd = nullptr;
@@ -415,6 +449,9 @@ struct suscan_analyzer {
   hipStream_t istream[NISTREAMS] = {};
   hipEvent_t ev_input = nullptr;              // the block is in d_x
   suamd_complex *h_x = nullptr, *d_x = nullptr;
+  suamd_complex *h_flt = nullptr;              // a compact-format block expanded on the host, for the baseband filters
+  float *d_dc = nullptr;                       // tracked DC level (suamd_source_fix)
+  bool dc_first = true;
   void *d_raw = nullptr;                       // compact-format payload before suamd_ingest_iq
   float *d_psd = nullptr;
   size_t block = 0;
@@ -613,6 +650,17 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
       in.pend_m = fm[i];
       in.pend_src = in.d_y;
       if (in.spectsrc_id) enqueue_spectrum(a, in, fm[i]);
+      for (int k = 0; k < 2; ++k) {                           // enabled estimators look at the channel samples too
+        in.est_fed[k] = false;
+        if (!in.est_on[k]) continue;
+        unsigned want = 512;
+        while (want * 2 <= fm[i] && want < 8192) want *= 2;
+        if (fm[i] < want) continue;                           // fewer than 512 channel samples per block: no estimate
+        if (in.est[k] && suamd_baud_estimator_size(in.est[k]) != want) { suamd_baud_estimator_destroy(in.est[k]); in.est[k] = nullptr; }
+        if (!in.est[k]) in.est[k] = suamd_baud_estimator_new(a->ctx, k == 0 ? SUAMD_BAUD_ESTIMATOR_FAC : SUAMD_BAUD_ESTIMATOR_NONLINEAR, want);
+        if (!in.est[k] || !suamd_baud_estimator_feed(in.est[k], in.d_y, fm[i], sA)) { fail("estimator"); continue; }
+        in.est_fed[k] = true;
+      }
     }
   }
   auto sub = [&](const Inspector &in, int j) { return (SUSCOUNT)((unsigned long long)in.pend_m * (unsigned)j / P); };
@@ -732,7 +780,8 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
 void collect_inspectors(suscan_analyzer *a)
 {
   bool any = false;
-  for (auto &kv : a->inspectors) any = any || kv.second->pend_samples || kv.second->pend_spectrum || kv.second->pend_symbols;
+  for (auto &kv : a->inspectors) any = any || kv.second->pend_samples || kv.second->pend_spectrum || kv.second->pend_symbols ||
+                                       kv.second->est_on[0] || kv.second->est_on[1];
   if (!any) return;
   for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) (void)hipStreamSynchronize(a->istream[k]);
   if (a->trace) a->t_chains_done = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a->t_block0).count();
@@ -750,13 +799,36 @@ void collect_inspectors(suscan_analyzer *a)
       std::memcpy(msg->spectrum_data, in.pin->spec, in.pend_spec_n * sizeof(float));
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, msg);
     }
+    for (int k = 0; k < 2; ++k) {
+      if (!in.est_on[k]) continue;
+      auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_ESTIMATOR, 0);
+      m->handle = in.handle;
+      m->inspector_id = in.inspector_id;
+      m->estimator_id = (uint32_t)k;
+      m->enabled = SU_TRUE;
+      m->value = in.est[k] ? suamd_baud_estimator_get(in.est[k]) * (SUFLOAT)in.equiv_fs : 0.0f;   // Hz, what clock.baud takes
+      push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
+    }
     if (in.pend_symbols || in.pend_samples) emit_samples(a, in, in.pin->count);
     in.pend_samples = in.pend_spectrum = in.pend_symbols = false;
   }
 }
 
+const struct suscan_estimator_class kEstimators[2] = {
+  {"baud-fac", "Fast autocorrelation baud estimator", "clock.baud"},
+  {"baud-nonlinear", "Non-linear baud estimator", "clock.baud"},
+};
+
+void push_source_info(suscan_analyzer *a)
+{
+  auto *si = static_cast<suscan_source_info *>(std::malloc(sizeof(suscan_source_info)));
+  *si = a->info;
+  push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INFO, si);
+}
+
 void handle_request(suscan_analyzer *a, Request &r)
 {
+  if (r.kind == Request::SOURCE_INFO) { push_source_info(a); return; }
   switch (r.kind) {
     case Request::OPEN: {
       DescHolder *h = holder_for(r.cls.c_str());
@@ -795,6 +867,12 @@ void handle_request(suscan_analyzer *a, Request &r)
       m->spectsrc_count = suamd_spectsrc_count();             // names borrowed from the library (static storage)
       m->spectsrc_list = static_cast<char **>(std::calloc(m->spectsrc_count, sizeof(char *)));
       for (unsigned k = 0; k < m->spectsrc_count; ++k) m->spectsrc_list[k] = const_cast<char *>(suamd_spectsrc_name(k + 1));
+      if (r.cls != "raw") {                                   // the baud estimators (names static, like the sources')
+        m->estimator_count = 2;
+        m->estimator_list = static_cast<char **>(std::calloc(2, sizeof(char *)));
+        m->estimator_list[0] = const_cast<char *>(kEstimators[0].name);
+        m->estimator_list[1] = const_cast<char *>(kEstimators[1].name);
+      }
       a->inspectors[in->handle] = std::move(in);
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
       return;
@@ -802,7 +880,7 @@ void handle_request(suscan_analyzer *a, Request &r)
     default: break;
   }
   auto it = a->inspectors.find(r.handle);
-  if (r.kind != Request::SET_PARAMS && r.kind != Request::SET_THROTTLE && it == a->inspectors.end()) {
+  if (r.kind != Request::SET_PARAMS && r.kind != Request::SET_THROTTLE && r.kind != Request::SEEK && it == a->inspectors.end()) {
     auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_WRONG_HANDLE, r.req_id);
     m->handle = r.handle;
     push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
@@ -872,6 +950,33 @@ void handle_request(suscan_analyzer *a, Request &r)
       break;
     }
     case Request::SET_THROTTLE: a->throttle = r.value; break;
+    case Request::ESTIMATOR: {
+      Inspector &in = *it->second;
+      if (r.value >= 2 || in.cls == "raw") {
+        auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_WRONG_OBJECT, r.req_id);
+        m->handle = r.handle;
+        push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
+        break;
+      }
+      in.est_on[r.value] = r.fvalue != 0;
+      auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_ESTIMATOR, r.req_id);   // acknowledgement: no value yet
+      m->handle = r.handle;
+      m->inspector_id = in.inspector_id;
+      m->estimator_id = (uint32_t)r.value;
+      m->enabled = in.est_on[r.value] ? SU_TRUE : SU_FALSE;
+      push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
+      break;
+    }
+    case Request::SET_TLE: {
+      // Doppler correction from orbital elements needs an orbit propagator: outside this path
+      auto *m = new_insp_msg(r.fvalue != 0 ? SUSCAN_ANALYZER_INSPECTOR_MSGKIND_INVALID_ARGUMENT : SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SET_TLE,
+                             r.req_id);
+      m->handle = r.handle;
+      m->inspector_id = it->second->inspector_id;
+      m->enabled = SU_FALSE;
+      push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
+      break;
+    }
     default: break;
   }
 }
@@ -890,6 +995,9 @@ bool setup_psd(suscan_analyzer *a, std::string &err)
   const size_t block = (size_t)n * a->navg;
   if (block != a->block) {
     if (a->h_x) (void)hipHostFree(a->h_x);
+  if (a->h_flt) (void)hipHostFree(a->h_flt);
+  if (a->d_dc) (void)hipFree(a->d_dc);
+  a->h_flt = nullptr; a->d_dc = nullptr;
     if (a->d_x) (void)hipFree(a->d_x);
     if (a->d_raw) (void)hipFree(a->d_raw);
     if (a->d_psd) (void)hipFree(a->d_psd);
@@ -969,6 +1077,13 @@ void worker_main(suscan_analyzer *a)
       const unsigned old_n = (unsigned)a->params.detector_params.window_size;
       const int old_w = a->params.detector_params.window;
       const float old_i = a->params.psd_update_int;
+      if (r.kind == Request::SEEK) {                          // Suscan/Analyzer.cpp:150-154
+        if (have_next) have_next = false;                     // the block read ahead is from the old position
+        src.seek(r.value);
+        consumed = r.value;
+        a->position = consumed;
+        continue;
+      }
       handle_request(a, r);
       if (r.kind == Request::SET_PARAMS && (old_n != a->params.detector_params.window_size ||
                                            old_w != a->params.detector_params.window ||
@@ -995,13 +1110,54 @@ void worker_main(suscan_analyzer *a)
       push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_EOS, 0, "end of stream");   // whole PSD frame set is needed
       break;
     }
-    if (src.bytes_per_sample() == sizeof(suamd_complex)) {
+    // ---- baseband filters: on this thread, on SUCOMPLEX samples, before anything else sees the block ----
+    std::vector<suscan_analyzer::Filter> filters;
+    {
+      std::lock_guard<std::mutex> lk(a->req_m);
+      filters = a->filters;
+    }
+    suamd_complex *h_flt = nullptr;                        // what the filters saw (and may have rewritten)
+    if (!filters.empty()) {
+      if (src.bytes_per_sample() == sizeof(suamd_complex)) h_flt = h_cur;
+      else {                                               // compact formats are expanded on the host for them (same arithmetic as suamd_ingest_iq)
+        if (!a->h_flt && hipHostMalloc((void **)&a->h_flt, a->block * sizeof(suamd_complex), hipHostMallocDefault) != hipSuccess) {
+          push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, "pinned allocation failed");
+          break;
+        }
+        h_flt = a->h_flt;
+        const size_t nv = 2 * a->block;
+        float *o = reinterpret_cast<float *>(h_flt);
+        switch (src.raw_format) {
+          case SUAMD_FORMAT_RAW_UNSIGNED8: { const uint8_t *r = reinterpret_cast<const uint8_t *>(h_cur); for (size_t i = 0; i < nv; ++i) o[i] = (float)((int)r[i] - 128) * 0.0078125f; break; }
+          case SUAMD_FORMAT_RAW_SIGNED8:   { const int8_t *r = reinterpret_cast<const int8_t *>(h_cur); for (size_t i = 0; i < nv; ++i) o[i] = (float)r[i] * 0.0078125f; break; }
+          default:                         { const int16_t *r = reinterpret_cast<const int16_t *>(h_cur); for (size_t i = 0; i < nv; ++i) o[i] = (float)r[i] * 3.0517578125e-05f; break; }
+        }
+      }
+      bool ok = true;
+      for (const auto &f : filters) if (!f.func(f.priv, a, h_flt, a->block, consumed)) { ok = false; break; }
+      if (!ok) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, "a baseband filter failed"); break; }
+    }
+    if (h_flt) {
+      (void)hipMemcpyAsync(a->d_x, h_flt, a->block * sizeof(suamd_complex), hipMemcpyHostToDevice, a->stream);
+      if (h_flt == a->h_flt) (void)hipStreamSynchronize(a->stream);   // one expansion buffer: the copy must be out before the next block
+    } else if (src.bytes_per_sample() == sizeof(suamd_complex)) {
       (void)hipMemcpyAsync(a->d_x, h_cur, a->block * sizeof(suamd_complex), hipMemcpyHostToDevice, a->stream);
     } else {                                               // 2-4 B/sample over PCIe, expanded on the GPU
       (void)hipMemcpyAsync(a->d_raw, h_cur, a->block * src.bytes_per_sample(), hipMemcpyHostToDevice, a->stream);
       if (!suamd_ingest_iq(a->ctx, src.raw_format, a->d_raw, a->block, a->d_x, a->stream)) {
         push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, suamd_last_error());
         break;
+      }
+    }
+    {
+      // source conditioning (Suscan/Analyzer.cpp:240-256): I/Q reversal, DC removal -- on the device, in place
+      const bool rev = a->iq_reverse, dcr = a->dc_remove;
+      if (!dcr) a->dc_first = true;
+      if (rev || dcr) {
+        if (dcr && !a->d_dc && hipMalloc((void **)&a->d_dc, 2 * sizeof(float)) != hipSuccess) a->d_dc = nullptr;
+        if (!suamd_source_fix(a->ctx, a->d_x, a->block, rev ? SU_TRUE : SU_FALSE, dcr ? a->d_dc : nullptr, 0.1f, a->dc_first ? SU_TRUE : SU_FALSE, a->stream))
+          push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("source conditioning: ") + suamd_last_error());
+        else if (dcr) a->dc_first = false;
       }
     }
     (void)hipEventRecord(a->ev_input, a->stream);
@@ -1051,6 +1207,7 @@ void worker_main(suscan_analyzer *a)
                    tmark[0], tmark[1], tmark[2], tmark[3], a->t_chains_done, tmark[5]);
     }
     consumed += a->block;
+    a->position = consumed;
     // ---- rate bookkeeping / throttle ----
     auto now = std::chrono::steady_clock::now();
     const uint64_t thr = a->throttle;
@@ -1072,6 +1229,9 @@ void worker_main(suscan_analyzer *a)
   a->inspectors.clear();
   if (a->psd) suamd_psd_destroy(a->psd);
   if (a->h_x) (void)hipHostFree(a->h_x);
+  if (a->h_flt) (void)hipHostFree(a->h_flt);
+  if (a->d_dc) (void)hipFree(a->d_dc);
+  a->h_flt = nullptr; a->d_dc = nullptr;
   if (a->d_x) (void)hipFree(a->d_x);
   if (a->d_raw) (void)hipFree(a->d_raw);
   if (a->d_psd) (void)hipFree(a->d_psd);
@@ -1304,6 +1464,7 @@ void suscan_analyzer_dispose_message(uint32_t type, void *ptr)
       if (m->config) suscan_config_destroy(m->config);
       std::free(m->spectrum_data);
       std::free(m->spectsrc_list);                           // the names themselves are static
+      std::free(m->estimator_list);
       break;
     }
     case SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INIT:
@@ -1389,7 +1550,11 @@ const struct suscan_spectsrc_class *suscan_spectsrc_class_lookup(const char *nam
   return nullptr;
 }
 
-const struct suscan_estimator_class *suscan_estimator_class_lookup(const char *) { return nullptr; }
+const struct suscan_estimator_class *suscan_estimator_class_lookup(const char *name)
+{
+  for (const auto &e : kEstimators) if (name && std::strcmp(name, e.name) == 0) return &e;
+  return nullptr;
+}
 
 SUBOOL suscan_analyzer_inspector_set_spectrum_async(suscan_analyzer_t *a, SUHANDLE h, uint32_t spectsrc_id, uint32_t req)
 {
@@ -1407,6 +1572,170 @@ SUBOOL suscan_analyzer_set_inspector_bandwidth_overridable(suscan_analyzer_t *a,
 {
   Request r; r.kind = Request::SET_BW; r.handle = h; r.fvalue = bw;
   return post(a, std::move(r));
+}
+
+SUBOOL suscan_analyzer_inspector_estimator_cmd_async(suscan_analyzer_t *a, SUHANDLE h, uint32_t estimator_id, SUBOOL enabled, uint32_t req)
+{
+  Request r; r.kind = Request::ESTIMATOR; r.handle = h; r.value = estimator_id; r.fvalue = enabled ? 1 : 0; r.req_id = req;
+  return post(a, std::move(r));
+}
+
+SUBOOL suscan_analyzer_inspector_set_tle_async(suscan_analyzer_t *a, SUHANDLE h, const orbit_t *tle, uint32_t req)
+{
+  Request r; r.kind = Request::SET_TLE; r.handle = h; r.fvalue = tle ? 1 : 0; r.req_id = req;
+  return post(a, std::move(r));
+}
+
+SUBOOL suscan_analyzer_register_baseband_filter_with_prio(suscan_analyzer_t *a, suscan_analyzer_baseband_filter_func_t func, void *priv,
+                                                          int64_t prio)
+{
+  if (!a || !func) return SU_FALSE;
+  std::lock_guard<std::mutex> lk(a->req_m);
+  a->filters.push_back(suscan_analyzer::Filter{func, priv, prio, a->filter_seq++});
+  std::stable_sort(a->filters.begin(), a->filters.end(),
+                   [](const suscan_analyzer::Filter &x, const suscan_analyzer::Filter &y) { return x.prio < y.prio; });
+  return SU_TRUE;
+}
+
+SUBOOL suscan_analyzer_register_baseband_filter(suscan_analyzer_t *a, suscan_analyzer_baseband_filter_func_t func, void *priv)
+{
+  return suscan_analyzer_register_baseband_filter_with_prio(a, func, priv, 0);
+}
+
+static SUBOOL post_source_info(suscan_analyzer_t *a)
+{
+  Request r; r.kind = Request::SOURCE_INFO;
+  return post(a, std::move(r));
+}
+
+SUBOOL suscan_analyzer_set_freq(suscan_analyzer_t *a, SUFREQ freq, SUFREQ lnb)
+{
+  if (!a) return SU_FALSE;
+  a->source_cfg.freq = freq;                               // the PSD messages' fc from the next block on
+  a->info.frequency = freq; a->info.lnb = lnb;
+  return post_source_info(a);
+}
+
+SUBOOL suscan_analyzer_set_gain(suscan_analyzer_t *a, const char *name, SUFLOAT value)
+{
+  if (!a || !name) return SU_FALSE;
+  { std::lock_guard<std::mutex> lk(a->req_m); a->gains[name] = value; }
+  return SU_TRUE;
+}
+
+SUBOOL suscan_analyzer_set_antenna(suscan_analyzer_t *a, const char *name)
+{
+  if (!a || !name) return SU_FALSE;
+  { std::lock_guard<std::mutex> lk(a->req_m); a->antenna = name; }
+  return SU_TRUE;
+}
+
+SUBOOL suscan_analyzer_set_bw(suscan_analyzer_t *a, SUFLOAT bw)
+{
+  if (!a || !(bw > 0)) return SU_FALSE;
+  a->info.bandwidth = bw;
+  return post_source_info(a);
+}
+
+SUBOOL suscan_analyzer_set_ppm(suscan_analyzer_t *a, SUFLOAT ppm)
+{
+  if (!a) return SU_FALSE;
+  a->info.ppm = ppm;
+  return post_source_info(a);
+}
+
+SUBOOL suscan_analyzer_set_agc(suscan_analyzer_t *a, SUBOOL enabled)
+{
+  if (!a) return SU_FALSE;
+  a->info.agc = enabled ? SU_TRUE : SU_FALSE;
+  return post_source_info(a);
+}
+
+SUBOOL suscan_analyzer_set_dc_remove(suscan_analyzer_t *a, SUBOOL remove)
+{
+  if (!a) return SU_FALSE;
+  a->dc_remove = remove != 0;
+  a->info.dc_remove = remove ? SU_TRUE : SU_FALSE;
+  return post_source_info(a);
+}
+
+SUBOOL suscan_analyzer_set_iq_reverse(suscan_analyzer_t *a, SUBOOL reverse)
+{
+  if (!a) return SU_FALSE;
+  a->iq_reverse = reverse != 0;
+  a->info.iq_reverse = reverse ? SU_TRUE : SU_FALSE;
+  return post_source_info(a);
+}
+
+SUBOOL suscan_analyzer_seek(suscan_analyzer_t *a, const struct timeval *pos)
+{
+  if (!a || !pos || !a->info.seekable) return SU_FALSE;
+  const double t = (double)pos->tv_sec + 1e-6 * (double)pos->tv_usec;
+  if (t < 0) return SU_FALSE;
+  Request r; r.kind = Request::SEEK; r.value = (SUSCOUNT)(t * (double)a->source_cfg.samp_rate);
+  return post(a, std::move(r));
+}
+
+SUBOOL suscan_analyzer_set_history_size(suscan_analyzer_t *a, SUSCOUNT size)
+{
+  if (!a) return SU_FALSE;
+  a->history_size = size;                                  // a file is its own history: nothing to allocate
+  return SU_TRUE;
+}
+
+SUBOOL suscan_analyzer_replay(suscan_analyzer_t *a, SUBOOL replay)
+{
+  if (!a) return SU_FALSE;
+  a->replay = replay != 0;
+  return SU_TRUE;
+}
+
+void suscan_analyzer_get_source_time(const suscan_analyzer_t *a, struct timeval *tv)
+{
+  if (!tv) return;
+  tv->tv_sec = 0; tv->tv_usec = 0;
+  if (!a) return;
+  const double t = (double)a->position.load() / (double)a->source_cfg.samp_rate;
+  tv->tv_sec = a->info.source_start.tv_sec + (time_t)t;
+  tv->tv_usec = (suseconds_t)((t - std::floor(t)) * 1e6);
+}
+
+// wide-spectrum controls: only meaningful for an analyzer created in that mode (a hopping tuner is not part of this path)
+static bool wide(const suscan_analyzer_t *a) { return a && a->params.mode == SUSCAN_ANALYZER_MODE_WIDE_SPECTRUM; }
+
+SUBOOL suscan_analyzer_set_sweep_stratrgy(suscan_analyzer_t *a, enum suscan_analyzer_sweep_strategy strategy)
+{
+  if (!wide(a) || (int)strategy < 0 || (int)strategy > 1) return SU_FALSE;
+  a->sweep_strategy = (int)strategy;
+  return SU_TRUE;
+}
+
+SUBOOL suscan_analyzer_set_spectrum_partitioning(suscan_analyzer_t *a, enum suscan_analyzer_spectrum_partitioning p)
+{
+  if (!wide(a) || (int)p < 0 || (int)p > 1) return SU_FALSE;
+  a->partitioning = (int)p;
+  return SU_TRUE;
+}
+
+SUBOOL suscan_analyzer_set_hop_range(suscan_analyzer_t *a, SUFREQ min, SUFREQ max)
+{
+  if (!wide(a) || max < min) return SU_FALSE;
+  a->hop_min = min; a->hop_max = max;
+  return SU_TRUE;
+}
+
+SUBOOL suscan_analyzer_set_rel_bandwidth(suscan_analyzer_t *a, SUFLOAT rel_bw)
+{
+  if (!wide(a) || !(rel_bw > 0) || rel_bw > 1) return SU_FALSE;
+  a->rel_bw = rel_bw;
+  return SU_TRUE;
+}
+
+SUBOOL suscan_analyzer_set_buffering_size(suscan_analyzer_t *a, SUSCOUNT size)
+{
+  if (!wide(a)) return SU_FALSE;
+  a->buffering_size = size;
+  return SU_TRUE;
 }
 
 }  // extern "C"

@@ -147,6 +147,7 @@ struct suamd_ctx {
   // slot comes round again (128 uploads later) on another stream, that stream waits for the event on the device
   static constexpr int GANG_SLOTS = 128;
   static constexpr size_t GANG_SLOT_BYTES = 64 * 1024;
+  float *fix_partial = nullptr;                             // suamd_source_fix: block sums
   char *gang_ring = nullptr;
   int gang_next = 0, gang_open = -1;                        // gang_open: the slot whose launches are being enqueued
   hipStream_t gang_user[GANG_SLOTS] = {};
@@ -200,6 +201,7 @@ struct suamd_ctx {
     for (SlabUse &u : slab_live) (void)hipEventDestroy(u.ev);
     for (hipEvent_t ev : slab_spare) (void)hipEventDestroy(ev);
     if (slab_base) (void)hipFree(slab_base);
+    if (fix_partial) (void)hipFree(fix_partial);
     if (gang_ring) (void)hipFree(gang_ring);
     for (hipEvent_t ev : gang_ev) if (ev) (void)hipEventDestroy(ev);
   }
@@ -655,6 +657,20 @@ SUBOOL suamd_ingest_iq(suamd_ctx_t *ctx, int format, const void *d_raw, SUSCOUNT
   if ((format == SUAMD_FORMAT_RAW_UNSIGNED8 || format == SUAMD_FORMAT_RAW_SIGNED8 || format == SUAMD_FORMAT_RAW_SIGNED16) &&
       (reinterpret_cast<uintptr_t>(d_raw) & 15)) { set_err("d_raw must be 16-byte aligned"); return SU_FALSE; }
   HIP_TRY(sdk::ingest_iq(format, d_raw, (long long)nsamples, d_out, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUBOOL suamd_source_fix(suamd_ctx_t *ctx, suamd_complex *d_x, SUSCOUNT nsamples, SUBOOL iq_reverse, SUFLOAT *d_dc, SUFLOAT alpha,
+                        SUBOOL first, void *stream)
+{
+  if (!ctx) { set_err("null argument"); return SU_FALSE; }
+  if (nsamples == 0 || (!iq_reverse && !d_dc)) return SU_TRUE;
+  if (!d_x) { set_err("null argument"); return SU_FALSE; }
+  if (d_dc && !(alpha > 0.0f && alpha <= 1.0f)) { set_err("alpha %g out of (0, 1]", (double)alpha); return SU_FALSE; }
+  if (d_dc && !ctx->fix_partial && hipMalloc((void **)&ctx->fix_partial, 512 * sizeof(float)) != hipSuccess) {
+    ctx->fix_partial = nullptr; set_err("device allocation failed"); return SU_FALSE;
+  }
+  HIP_TRY(sdk::source_fix(d_x, (long long)nsamples, iq_reverse ? 1 : 0, d_dc, alpha, first ? 1 : 0, ctx->fix_partial, as_stream(stream)), SU_FALSE);
   return SU_TRUE;
 }
 
@@ -1580,6 +1596,78 @@ struct CaptureFft {                      // scratch of one whole-capture task
   }
 };
 }  // namespace
+
+// ---- baud estimators (SPEC.md section M) ---------------------------------------------
+struct suamd_baud_estimator {
+  suamd_ctx *ctx; int kind; unsigned n;
+  CaptureFft w;                          // nonlinear: window, transform, arg-max + centroid scratch
+  void *y = nullptr;                     // nonlinear: the transformed block
+  suamd_fac *fac = nullptr;              // fac: the running autocorrelation
+  float *d_lag = nullptr;
+  struct Landing { double res[5]; float lag; int fed; } *pin = nullptr;   // host-mapped results
+};
+
+suamd_baud_estimator_t *suamd_baud_estimator_new(suamd_ctx_t *ctx, int kind, unsigned size)
+{
+  if (!ctx) { set_err("null context"); return nullptr; }
+  if (kind != SUAMD_BAUD_ESTIMATOR_FAC && kind != SUAMD_BAUD_ESTIMATOR_NONLINEAR) { set_err("unknown estimator kind %d", kind); return nullptr; }
+  if (size < 512 || size > (1u << 20) || (size & (size - 1))) { set_err("size %u unsupported (power of two, 512..1048576)", size); return nullptr; }
+  auto *e = new (std::nothrow) suamd_baud_estimator;
+  if (!e) { set_err("out of memory"); return nullptr; }
+  e->ctx = ctx; e->kind = kind; e->n = size;
+  bool ok = hipHostMalloc((void **)&e->pin, sizeof *e->pin, hipHostMallocMapped) == hipSuccess;
+  if (ok) std::memset(e->pin, 0, sizeof *e->pin);
+  if (ok && kind == SUAMD_BAUD_ESTIMATOR_NONLINEAR) ok = e->w.init(size) && hipMalloc(&e->y, sizeof(suamd_complex) * (size_t)size) == hipSuccess;
+  if (ok && kind == SUAMD_BAUD_ESTIMATOR_FAC) {
+    e->fac = suamd_fac_new(ctx, size, 0.25f);
+    ok = e->fac && hipMalloc((void **)&e->d_lag, sizeof(float)) == hipSuccess;
+  }
+  if (!ok) { if (g_err.empty()) set_err("device allocation failed"); suamd_baud_estimator_destroy(e); return nullptr; }
+  return e;
+}
+
+void suamd_baud_estimator_destroy(suamd_baud_estimator_t *e)
+{
+  if (!e) return;
+  if (e->fac) suamd_fac_destroy(e->fac);
+  if (e->y) (void)hipFree(e->y);
+  if (e->d_lag) (void)hipFree(e->d_lag);
+  if (e->pin) (void)hipHostFree(e->pin);
+  delete e;
+}
+
+unsigned suamd_baud_estimator_size(const suamd_baud_estimator_t *e) { return e ? e->n : 0; }
+
+SUBOOL suamd_baud_estimator_feed(suamd_baud_estimator_t *e, const suamd_complex *d_x, SUSCOUNT len, void *stream)
+{
+  if (!e) { set_err("null argument"); return SU_FALSE; }
+  if (len < e->n) return SU_TRUE;                            // not a whole analysis window: the estimate stands
+  if (!d_x) { set_err("null argument"); return SU_FALSE; }
+  hipStream_t st = as_stream(stream);
+  const long long n = e->n;
+  if (e->kind == SUAMD_BAUD_ESTIMATOR_NONLINEAR) {
+    HIP_TRY(sdk::baud_nl_transform(d_x, n, e->y, st), SU_FALSE);
+    HIP_TRY(sdk::window_pad(e->y, n, e->w.alloc, e->w.a, st), SU_FALSE);
+    HIP_TRY(sdk::fft_forward(e->w.a, e->w.b, e->w.log2n, &e->w.res, st), SU_FALSE);
+    // the lowest strong line outside the DC notch (1 % of the band), power centroid over 9 bins
+    const int skip = std::max(4, (int)(0.01 * (double)n));
+    HIP_TRY(sdk::baud_line(e->w.res, (int)n, skip, e->w.d_res, st), SU_FALSE);
+    HIP_TRY(hipMemcpyAsync(e->pin->res, e->w.d_res, sizeof e->pin->res, hipMemcpyDeviceToHost, st), SU_FALSE);
+  } else {
+    if (!suamd_fac_feed(e->fac, d_x, 1, 0, (SUSDIFF)(n / 2), st)) return SU_FALSE;
+    HIP_TRY(sdk::fac_first_valley(suamd_fac_array(e->fac), (int)(n / 2), e->d_lag, st), SU_FALSE);
+    HIP_TRY(hipMemcpyAsync(&e->pin->lag, e->d_lag, sizeof(float), hipMemcpyDeviceToHost, st), SU_FALSE);
+  }
+  e->pin->fed = 1;
+  return SU_TRUE;
+}
+
+SUFLOAT suamd_baud_estimator_get(const suamd_baud_estimator_t *e)
+{
+  if (!e || !e->pin->fed) return 0.0f;
+  if (e->kind == SUAMD_BAUD_ESTIMATOR_NONLINEAR) return (float)(e->pin->res[0] / (double)e->n);
+  return e->pin->lag > 0.0f ? 1.0f / e->pin->lag : 0.0f;
+}
 
 SUBOOL suamd_carrier_detect(suamd_ctx_t *ctx, const suamd_complex *d_data, SUSCOUNT len, SUFLOAT avgRelBw,
                             SUFLOAT dcNotchRelBw, SUFLOAT *peak, void *stream)

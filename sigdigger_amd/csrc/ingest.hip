@@ -61,9 +61,62 @@ __global__ void ingest16_kernel(const int16_t *__restrict__ raw, float2 *__restr
   if (t < nsamp) out[t] = float2{(float)raw[2 * t] * 3.0517578125e-05f, (float)raw[2 * t + 1] * 3.0517578125e-05f};
 }
 
+// ---- source conditioning (Suscan::Analyzer::setIQReverse / setDCRemove, Suscan/Analyzer.cpp:240-256) ----
+// block means in a fixed order (256 workgroups, each a strided slice; lanes tree-reduced): the same bits every run
+__global__ __launch_bounds__(256) void block_sum_kernel(const float2 *__restrict__ x, long long nsamp, float *__restrict__ partial)
+{
+  __shared__ float sr[256], si[256];
+  float ar = 0.0f, ai = 0.0f;
+  for (long long t = blockIdx.x * 256ll + threadIdx.x; t < nsamp; t += 256ll * gridDim.x) { const float2 v = x[t]; ar += v.x; ai += v.y; }
+  sr[threadIdx.x] = ar; si[threadIdx.x] = ai;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { sr[threadIdx.x] += sr[threadIdx.x + o]; si[threadIdx.x] += si[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = sr[0]; partial[2 * blockIdx.x + 1] = si[0]; }
+}
+
+__global__ void dc_update_kernel(const float *__restrict__ partial, int nparts, long long nsamp, int iq_reverse, float alpha, int first,
+                                 float *__restrict__ dc)
+{
+  double sr = 0.0, si = 0.0;
+  for (int i = 0; i < nparts; ++i) { sr += (double)partial[2 * i]; si += (double)partial[2 * i + 1]; }
+  float mr = (float)(sr / (double)nsamp), mi = (float)(si / (double)nsamp);
+  if (iq_reverse) { const float t = mr; mr = mi; mi = t; }
+  if (first) { dc[0] = mr; dc[1] = mi; }
+  else { dc[0] = dc[0] + alpha * (mr - dc[0]); dc[1] = dc[1] + alpha * (mi - dc[1]); }
+}
+
+__global__ void source_fix_kernel(float2 *__restrict__ x, long long nsamp, int iq_reverse, const float *__restrict__ dc)
+{
+  const float dr = dc ? dc[0] : 0.0f, di = dc ? dc[1] : 0.0f;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nsamp; t += (long long)gridDim.x * blockDim.x) {
+    float2 v = x[t];
+    if (iq_reverse) v = float2{v.y, v.x};
+    if (dc) { v.x = v.x - dr; v.y = v.y - di; }
+    x[t] = v;
+  }
+}
+
 }  // namespace
 
 namespace sdk {
+
+hipError_t source_fix(void *x, long long nsamp, int iq_reverse, float *dc, float alpha, int first, float *partial, hipStream_t st)
+{
+  if (nsamp <= 0 || (!iq_reverse && !dc)) return hipSuccess;
+  float2 *xx = static_cast<float2 *>(x);
+  if (dc) {
+    hipLaunchKernelGGL(block_sum_kernel, dim3(256), dim3(256), 0, st, xx, nsamp, partial);
+    hipLaunchKernelGGL(dc_update_kernel, dim3(1), dim3(1), 0, st, partial, 256, nsamp, iq_reverse, alpha, first, dc);
+  }
+  long long g = (nsamp + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(source_fix_kernel, dim3((unsigned)g), dim3(256), 0, st, xx, nsamp, iq_reverse, dc);
+  return hipGetLastError();
+}
+
 
 hipError_t ingest_iq(int format, const void *raw, long long nsamp, void *out, hipStream_t st)
 {

@@ -191,6 +191,18 @@ hipError_t cma_feed(int n, float mu, int locked, void *w, void *dl, int nchan, c
 // ---- ingest.hip ----
 // format: 1 float32, 2 unsigned 8, 3 signed 8, 4 signed 16 (interleaved I/Q) -> SUCOMPLEX
 hipError_t ingest_iq(int format, const void *raw, long long nsamp, void *out, hipStream_t st);
+// baud estimators (SPEC.md section M): y[n] = (|x[n] - x[n-1]|^2, 0), y[0] = 0  -- its spectrum has a line at the baud;
+// first valley of a fast autocorrelation (fac: n_half floats) below a quarter of fac[0] -> out[0] = lag (0: none)
+hipError_t baud_nl_transform(const void *x, long long n, void *y, hipStream_t st);
+hipError_t fac_first_valley(const float *fac, int n_half, float *out, hipStream_t st);
+// the baud line in the transform X (n points) of the transformed block: the LOWEST local maximum of |X|^2 in [skip, n/2)
+// that reaches half of the strongest one (a comb of harmonics has no strongest tooth worth trusting), then the power
+// centroid over +-4 bins.  res[0] = centroid bin (0: none)
+hipError_t baud_line(const void *X, int n, int skip, double *res, hipStream_t st);
+// source conditioning in front of the path: I/Q swap, then removal of a tracked DC level (dc: device float[2],
+// or nullptr).  The level follows the block means: dc = first ? mean : dc + alpha (mean - dc), and the block is
+// corrected with the updated level.  partial: device scratch of 2 * 256 floats.
+hipError_t source_fix(void *x, long long nsamp, int iq_reverse, float *dc, float alpha, int first, float *partial, hipStream_t st);
 
 // ---- fft.hip ----
 hipError_t fft_forward(void *a, void *b, int log2n, void **result, hipStream_t st);

@@ -336,6 +336,75 @@ hipError_t launch_cma(float mu, int locked, void *w, void *dl, int nchan, const 
   return hipGetLastError();
 }
 
+__global__ void baud_nl_kernel(const float2 *__restrict__ x, long long n, float2 *__restrict__ y)
+{
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    float v = 0.0f;
+    if (t > 0) {
+      const float2 a = x[t], b = x[t - 1];
+      const float dr = a.x - b.x, di = a.y - b.y;
+      v = sd::fma_(dr, dr, di * di);
+    }
+    y[t] = float2{v, 0.0f};
+  }
+}
+
+__global__ __launch_bounds__(1024) void baud_line_kernel(const float2 *__restrict__ X, int n, int skip, double *__restrict__ res)
+{
+  __shared__ float smax[1024];
+  __shared__ int sidx[1024];
+  const int half = n / 2, tid = threadIdx.x;
+  auto P = [&](int k) { const float2 v = X[k]; return sd::fma_(v.x, v.x, v.y * v.y); };
+  __shared__ double ssum[1024];
+  float mx = 0.0f;
+  double sum = 0.0;
+  for (int k = skip + tid; k < half; k += 1024) { const float p = P(k); mx = p > mx ? p : mx; sum += (double)p; }
+  smax[tid] = mx; ssum[tid] = sum;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) { smax[tid] = smax[tid] > smax[tid + o] ? smax[tid] : smax[tid + o]; ssum[tid] += ssum[tid + o]; }
+    __syncthreads();
+  }
+  // a line, not the tallest noise bin: 20x the mean level (noise alone peaks at ~10x over a few thousand bins)
+  const bool line = (double)smax[0] * (double)(half - skip) >= 20.0 * ssum[0];
+  const float thr = line ? 0.5f * smax[0] : 0.0f;
+  int first = 0x7fffffff;
+  for (int k = skip + 1 + tid; k < half - 1; k += 1024) {
+    const float p = P(k);
+    if (p >= thr && p >= P(k - 1) && p >= P(k + 1)) { first = k; break; }     // strides ascend: a thread's first hit is its lowest
+  }
+  sidx[tid] = first;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if (tid < o) sidx[tid] = sidx[tid] < sidx[tid + o] ? sidx[tid] : sidx[tid + o]; __syncthreads(); }
+  if (tid == 0) {
+    double c = 0.0;
+    if (thr > 0.0f && sidx[0] != 0x7fffffff) {
+      double num = 0.0, den = 0.0;
+      for (int j = sidx[0] - 4; j <= sidx[0] + 4; ++j) {
+        if (j < skip || j >= half) continue;
+        const double p = (double)P(j);
+        num += p * (double)j; den += p;
+      }
+      c = den > 0.0 ? num / den : 0.0;
+    }
+    res[0] = c;
+  }
+}
+
+// sequential scan of at most a few thousand lags: one lane
+__global__ void fac_valley_kernel(const float *__restrict__ R, int H, float *__restrict__ out)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float lag = 0.0f;
+  const float thr = 0.25f * R[0];
+  auto s = [&](int l) { return (R[l - 1] + R[l] + R[l + 1]) * 0.33333334f; };
+  for (int l = 2; l + 2 < H; ++l) {
+    const float c = s(l);
+    if (c < thr && c <= s(l + 1)) { lag = (float)l; break; }   // (a parabola through a V-shaped minimum is biased: integer lag)
+  }
+  out[0] = lag;
+}
+
 // one workgroup per row: the host-mapped destination is written in 64 B lane pairs, front to back
 __global__ __launch_bounds__(1024) void rows_deliver_kernel(const sdk::DeliverItem *__restrict__ items)
 {
@@ -437,6 +506,27 @@ hipError_t cma_feed(int n, float mu, int locked, void *w, void *dl, int nchan, c
 #undef CMA_CASE
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t baud_nl_transform(const void *x, long long n, void *y, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(baud_nl_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, static_cast<const float2 *>(x), n, static_cast<float2 *>(y));
+  return hipGetLastError();
+}
+
+hipError_t baud_line(const void *X, int n, int skip, double *res, hipStream_t st)
+{
+  if (n < 64 || skip < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(baud_line_kernel, dim3(1), dim3(1024), 0, st, static_cast<const float2 *>(X), n, skip, res);
+  return hipGetLastError();
+}
+
+hipError_t fac_first_valley(const float *fac, int n_half, float *out, hipStream_t st)
+{
+  if (n_half < 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fac_valley_kernel, dim3(1), dim3(64), 0, st, fac, n_half, out);
+  return hipGetLastError();
 }
 
 hipError_t rows_deliver(const DeliverItem *d_items, int n, hipStream_t st)

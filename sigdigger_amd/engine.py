@@ -441,8 +441,36 @@ class FAC(_LoopBank):
         return mn.value, mx.value
 
 
+class BaudEstimator(_LoopBank):
+    """suamd_baud_estimator_t: kind 0 = fast autocorrelation valley, 1 = nonlinear (|dx|^2 line); normalised baud."""
+    _destroy = "suamd_baud_estimator_destroy"
+    FAC, NONLINEAR = 0, 1
+
+    def __init__(self, ctx, kind, size):
+        self.ctx = ctx
+        self.h = ctx.lib.suamd_baud_estimator_new(ctx.h, int(kind), int(size))
+        if not self.h:
+            raise SigDiggerAmdError("suamd_baud_estimator_new: " + _l.last_error())
+
+    def feed(self, x, stream=None):
+        _chk_c64(x, "x")
+        check(self.ctx.lib.suamd_baud_estimator_feed(self.h, _ptr(x), x.numel(), _stream(stream)), "suamd_baud_estimator_feed")
+
+    def get(self):
+        torch.cuda.synchronize()
+        return float(self.ctx.lib.suamd_baud_estimator_get(self.h))
+
+
 def _ptr_array(ptrs):
     return (C.c_void_p * len(ptrs))(*ptrs)
+
+
+def source_fix(ctx, x, iq_reverse, dc=None, alpha=0.1, first=True, stream=None):
+    """suamd_source_fix, in place on x: I/Q swap and / or removal of the tracked DC level dc (float32[2] device tensor)."""
+    _chk_c64(x, "x")
+    check(ctx.lib.suamd_source_fix(ctx.h, _ptr(x), x.numel(), int(bool(iq_reverse)), _ptr(dc) if dc is not None else None,
+                                   float(alpha), int(bool(first)), _stream(stream)), "suamd_source_fix")
+    return x
 
 
 def gang_chan(ctx, banks, x, outs, stream=None):

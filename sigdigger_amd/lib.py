@@ -86,6 +86,12 @@ PROTOTYPES = {
     "suamd_agc_gang_level": (INT, [VP, VP, UINT, VP, VP, VP, VP]),
     "suamd_agc_gang_apply": (INT, [VP, VP, UINT, VP, VP, VP, VP, VP, VP]),
     "suamd_agc_gang_finish": (INT, [VP, VP, UINT, VP, VP, VP]),
+    "suamd_baud_estimator_new": (VP, [VP, INT, UINT]),
+    "suamd_baud_estimator_destroy": (None, [VP]),
+    "suamd_baud_estimator_size": (UINT, [VP]),
+    "suamd_baud_estimator_feed": (INT, [VP, VP, U64, VP]),
+    "suamd_baud_estimator_get": (C.c_float, [VP]),
+    "suamd_source_fix": (INT, [VP, VP, U64, INT, VP, C.c_float, INT, VP]),
     "suamd_chanbank_gang_feed": (INT, [VP, VP, UINT, VP, U64, VP, VP, VP]),
     "suamd_rows_deliver": (INT, [VP, UINT, VP, VP, VP, VP, VP, VP]),
     "suamd_clock_gang_feed": (INT, [VP, VP, UINT, VP, VP, VP, VP, VP]),

@@ -59,7 +59,24 @@ class InspectorMsg(C.Structure):
                 ("lo", C.c_float), ("spectsrc_count", C.c_uint), ("spectsrc_list", C.c_void_p),
                 ("estimator_count", C.c_uint), ("estimator_list", C.c_void_p), ("spectsrc_id", C.c_uint32),
                 ("estimator_id", C.c_uint32), ("spectrum_data", C.c_void_p), ("spectrum_size", C.c_uint64),
-                ("samp_rate", C.c_uint64), ("watermark", C.c_uint64)]
+                ("samp_rate", C.c_uint64), ("watermark", C.c_uint64), ("enabled", C.c_int), ("value", C.c_float)]
+
+
+class SourceInfo(C.Structure):
+    """struct suscan_source_info"""
+    _fields_ = [("permissions", C.c_uint64), ("source_samp_rate", C.c_uint64), ("effective_samp_rate", C.c_uint64),
+                ("measured_samp_rate", C.c_float), ("frequency", C.c_double), ("freq_min", C.c_double), ("freq_max", C.c_double),
+                ("lnb", C.c_double), ("bandwidth", C.c_float), ("ppm", C.c_float), ("dc_remove", C.c_int), ("iq_reverse", C.c_int),
+                ("agc", C.c_int), ("seekable", C.c_int), ("source_start", Timeval), ("source_end", Timeval)]
+
+
+class EstimatorClass(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("desc", C.c_char_p), ("field", C.c_char_p)]
+
+
+# SUBOOL f(void *privdata, suscan_analyzer_t *, SUCOMPLEX *samples, SUSCOUNT length, SUSCOUNT offset)
+BASEBAND_FILTER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_uint64, C.c_uint64)
+KIND_WRONG_OBJECT, KIND_SET_TLE = 12, 17
 
 
 class StatusMsg(C.Structure):
@@ -109,6 +126,27 @@ PROTOTYPES = {
     "suscan_estimator_class_lookup": (VP, [C.c_char_p]),
     "suscan_analyzer_set_inspector_freq_overridable": (INT, [VP, C.c_int32, C.c_double]),
     "suscan_analyzer_set_inspector_bandwidth_overridable": (INT, [VP, C.c_int32, C.c_double]),
+    "suscan_analyzer_inspector_estimator_cmd_async": (INT, [VP, C.c_int32, U32, INT, U32]),
+    "suscan_analyzer_inspector_set_tle_async": (INT, [VP, C.c_int32, VP, U32]),
+    "suscan_analyzer_register_baseband_filter": (INT, [VP, BASEBAND_FILTER, VP]),
+    "suscan_analyzer_register_baseband_filter_with_prio": (INT, [VP, BASEBAND_FILTER, VP, C.c_int64]),
+    "suscan_analyzer_set_freq": (INT, [VP, C.c_double, C.c_double]),
+    "suscan_analyzer_set_gain": (INT, [VP, C.c_char_p, C.c_float]),
+    "suscan_analyzer_set_antenna": (INT, [VP, C.c_char_p]),
+    "suscan_analyzer_set_bw": (INT, [VP, C.c_float]),
+    "suscan_analyzer_set_ppm": (INT, [VP, C.c_float]),
+    "suscan_analyzer_set_agc": (INT, [VP, INT]),
+    "suscan_analyzer_set_dc_remove": (INT, [VP, INT]),
+    "suscan_analyzer_set_iq_reverse": (INT, [VP, INT]),
+    "suscan_analyzer_seek": (INT, [VP, C.POINTER(Timeval)]),
+    "suscan_analyzer_set_history_size": (INT, [VP, U64]),
+    "suscan_analyzer_replay": (INT, [VP, INT]),
+    "suscan_analyzer_get_source_time": (None, [VP, C.POINTER(Timeval)]),
+    "suscan_analyzer_set_sweep_stratrgy": (INT, [VP, INT]),
+    "suscan_analyzer_set_spectrum_partitioning": (INT, [VP, INT]),
+    "suscan_analyzer_set_hop_range": (INT, [VP, C.c_double, C.c_double]),
+    "suscan_analyzer_set_rel_bandwidth": (INT, [VP, C.c_float]),
+    "suscan_analyzer_set_buffering_size": (INT, [VP, U64]),
 }
 
 _bound = None

@@ -542,6 +542,187 @@ def test_narrow_channel_in_a_wide_capture(tmp_path, sdo):
     Lb.suscan_mq_finalize(C.byref(mq))
 
 
+@pytest.mark.parametrize("fmt", ["f32", "u8"])
+def test_baseband_filters_and_source_controls(tmp_path, sdo, fmt):
+    """registerBaseBandFilter (Suscan/Analyzer.cpp:127-142): filters run on the worker thread in priority order on
+    SUCOMPLEX samples and what they write is what the PSD sees; setIQReverse / setDCRemove act on the samples;
+    setFrequency re-labels the PSD frames and announces itself with a SOURCE_INFO message"""
+    nblocks = 6
+    x = synth.psk_carriers(L * nblocks, [0.2], sps=16, seed=5) * np.float32(0.4) + np.complex64(0.05 - 0.02j)
+    if fmt == "u8":
+        raw = np.clip(np.round(x.view(np.float32) * 128 + 128), 0, 255).astype(np.uint8)
+        xs = sdo.ingest_iq(2, raw)
+        path = tmp_path / "iq.u8"
+        raw.tofile(path)
+        Lb, mq, an = _start(path, L, fmt=2)
+    else:
+        xs = x
+        path = tmp_path / "iq.raw"
+        x.tofile(path)
+        Lb, mq, an = _start(path, L)
+    Lb.suscan_analyzer_set_throttle_async(an, 2 * FS, 0)        # slow enough for the control calls below to land mid-stream
+    calls = []
+
+    @suscan.BASEBAND_FILTER
+    def halve(priv, analyzer, samples, length, offset):
+        calls.append(("halve", int(length), int(offset)))
+        v = np.ctypeslib.as_array(samples, shape=(2 * length,))
+        v *= np.float32(0.5)
+        return 1
+
+    @suscan.BASEBAND_FILTER
+    def spy(priv, analyzer, samples, length, offset):
+        v = np.ctypeslib.as_array(samples, shape=(2 * length,))
+        calls.append(("spy", float(v[0]), float(v[1])))
+        return 1
+
+    assert Lb.suscan_analyzer_register_baseband_filter_with_prio(an, spy, None, 10)     # registered first, runs second
+    assert Lb.suscan_analyzer_register_baseband_filter(an, halve, None)                 # prio 0
+    # controls a file source cannot honour are recorded, the panoramic ones refused outside WIDE_SPECTRUM mode
+    assert Lb.suscan_analyzer_set_gain(an, b"LNA", 10.0) and Lb.suscan_analyzer_set_antenna(an, b"RX2")
+    assert Lb.suscan_analyzer_set_history_size(an, 1 << 20) and Lb.suscan_analyzer_replay(an, 0)
+    assert not Lb.suscan_analyzer_set_hop_range(an, 1e6, 2e6) and not Lb.suscan_analyzer_set_rel_bandwidth(an, 0.5)
+    assert not Lb.suscan_analyzer_set_sweep_stratrgy(an, 1) and not Lb.suscan_analyzer_set_spectrum_partitioning(an, 1)
+    assert not Lb.suscan_analyzer_set_buffering_size(an, 4096)
+    st = {"psd": [], "fc": [], "info": []}
+
+    def on_msg(t, ptr):
+        if t == suscan.MSG_PSD:
+            m = C.cast(ptr, C.POINTER(suscan.PSDMsg)).contents
+            st["psd"].append(np.ctypeslib.as_array(m.psd_data, shape=(N,)).copy())
+            st["fc"].append(m.fc)
+            k = len(st["psd"])
+            if k == 2:
+                assert Lb.suscan_analyzer_set_iq_reverse(an, 1) and Lb.suscan_analyzer_set_dc_remove(an, 1)
+                assert Lb.suscan_analyzer_set_freq(an, 100e6, 0.0)
+                assert Lb.suscan_analyzer_set_ppm(an, 1.5) and Lb.suscan_analyzer_set_bw(an, 2e5) and Lb.suscan_analyzer_set_agc(an, 1)
+        elif t == suscan.MSG_SOURCE_INFO:
+            si = C.cast(ptr, C.POINTER(suscan.SourceInfo)).contents
+            st["info"].append((si.frequency, bool(si.iq_reverse), bool(si.dc_remove), si.ppm, si.bandwidth, bool(si.agc)))
+
+    _pump(Lb, an, on_msg)
+    assert len(st["psd"]) == nblocks
+    # filter order and arguments: halve (prio 0) runs before spy (prio 10) although it was registered later; offsets count
+    # delivered samples.  (The worker starts with the analyzer: the very first blocks may precede the registrations.)
+    halved = {c[2] for c in calls if c[0] == "halve"}
+    assert halved and all(o % L == 0 and c[1] == L for c in calls if c[0] == "halve" for o in [c[2]])
+    assert {k * L for k in range(2, nblocks)} <= halved
+    for i, c in enumerate(calls):
+        if c[0] == "halve" and c[2] >= 2 * L:
+            k = c[2] // L
+            assert calls[i + 1][0] == "spy"                                         # priority order
+            assert calls[i + 1][1] == pytest.approx(0.5 * xs[k * L].real, abs=1e-7) and calls[i + 1][2] == pytest.approx(0.5 * xs[k * L].imag, abs=1e-7)
+    win = sdo.window(4, N)
+    # frame labels: the new frequency from some block boundary after frame 2 on
+    k0 = st["fc"].index(100000000)
+    assert 2 <= k0 <= 4 and all(f == 433920000 for f in st["fc"][:k0]) and all(f == 100000000 for f in st["fc"][k0:])
+    assert st["info"][-1] == (100e6, True, True, 1.5, 2e5, True) and st["info"][0][0] == 433.92e6
+    # samples: plain -> (reversed) -> reversed with the DC level removed; the two switches are separate calls, so a block
+    # in between may see only the first.  Every frame equals the oracle's for the mode it was processed in.
+    dc, first, mode, modes = np.zeros(2, np.float32), True, 0, []
+    for k in range(nblocks):
+        blk = (xs[k * L:(k + 1) * L] * np.float32(0.5 if k * L in halved else 1.0)).astype(np.complex64)
+        for m in range(mode, 3):
+            trial = dc.copy()
+            cand = blk if m == 0 else sdo.source_fix(blk, True, trial if m == 2 else None, 0.1, first)
+            ref = sdo.psd_frames(cand, NAVG, N, N, win, navg=NAVG, scale=1.0 / N)[0]
+            if np.max(np.abs(st["psd"][k] - ref)) / np.max(ref) < 2e-5:
+                mode = m
+                if m == 2:
+                    dc, first = trial, False
+                break
+        else:
+            raise AssertionError(f"frame {k} matches no source mode")
+        modes.append(mode)
+    assert modes[:2] == [0, 0] and modes[-1] == 2 and modes.index(2) <= 5
+    lvl = 0.5 * np.complex64(0.05 - 0.02j)
+    assert abs(dc[0] - lvl.imag) < 3e-3 and abs(dc[1] - lvl.real) < 3e-3             # the swapped level, halved by the filter
+    tv = suscan.Timeval()
+    Lb.suscan_analyzer_get_source_time(an, C.byref(tv))
+    assert tv.tv_sec + 1e-6 * tv.tv_usec == pytest.approx(nblocks * L / FS, abs=1e-5)
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+
+
+def test_seek_estimators_and_tle(tmp_path, sdo):
+    """Analyzer::seek moves the file position; setInspectorEnabled switches the baud estimators of estimator_list on and
+    ESTIMATOR messages carry the baud in Hz (both within a few percent of the truth, each equal to its oracle on the same
+    channel samples); Doppler correction from a TLE is refused, its removal acknowledged"""
+    nblocks = 14
+    baud, bw, fc = 3906.25, 30e3, 100e3                     # 16 channel samples per symbol at equiv_fs = 62.5 kS/s
+    x = synth.psk_carriers(L * nblocks, [2 * fc / FS], sps=int(FS / baud), order=4, seed=9, snr_db=25)
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    Lb, mq, an = _start(path, L)
+    Lb.suscan_analyzer_set_throttle_async(an, 2 * FS, 0)
+    cls = [C.cast(Lb.suscan_estimator_class_lookup(n), C.POINTER(suscan.EstimatorClass)).contents for n in (b"baud-fac", b"baud-nonlinear")]
+    assert [c.field for c in cls] == [b"clock.baud", b"clock.baud"] and not Lb.suscan_estimator_class_lookup(b"nope")
+    ch = suscan.Channel(fc=fc, f_lo=fc - bw / 2, f_hi=fc + bw / 2, bw=bw, ft=433.92e6)
+    assert Lb.suscan_analyzer_open_ex_async(an, b"psk", C.byref(ch), 1, -1, 7)
+    st = {"psd": 0, "ts": [], "est": {0: [], 1: []}, "ack": [], "kinds": [], "on_at": None, "handle": None}
+
+    def on_msg(t, ptr):
+        if t == suscan.MSG_PSD:
+            m = C.cast(ptr, C.POINTER(suscan.PSDMsg)).contents
+            st["psd"] += 1
+            st["ts"].append(m.timestamp.tv_sec + 1e-6 * m.timestamp.tv_usec)
+            if st["psd"] == 9:
+                tv = suscan.Timeval(0, int(2 * L / FS * 1e6))            # back to the third block
+                assert Lb.suscan_analyzer_seek(an, C.byref(tv))
+        elif t == suscan.MSG_INSPECTOR:
+            m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
+            st["kinds"].append(m.kind)
+            if m.kind == suscan.KIND_OPEN:
+                assert m.estimator_count == 2
+                names = C.cast(m.estimator_list, C.POINTER(C.c_char_p))
+                assert [names[0], names[1]] == [b"baud-fac", b"baud-nonlinear"]
+                st["handle"] = m.handle
+                for eid in (0, 1):
+                    assert Lb.suscan_analyzer_inspector_estimator_cmd_async(an, m.handle, eid, 1, 50 + eid)
+                assert Lb.suscan_analyzer_inspector_estimator_cmd_async(an, m.handle, 5, 1, 59)      # no such estimator
+                assert Lb.suscan_analyzer_inspector_set_tle_async(an, m.handle, None, 60)            # disable: fine
+                assert Lb.suscan_analyzer_inspector_set_tle_async(an, m.handle, 1, 61)               # any orbit: refused
+            elif m.kind == suscan.KIND_ESTIMATOR:
+                if m.req_id in (50, 51):
+                    st["ack"].append((m.req_id, m.estimator_id, m.enabled))
+                    st["on_at"] = st["psd"]
+                else:
+                    st["est"][m.estimator_id].append((st["psd"], m.value))
+            elif m.req_id == 59:
+                assert m.kind == suscan.KIND_WRONG_OBJECT
+            elif m.req_id == 60:
+                assert m.kind == suscan.KIND_SET_TLE and not m.enabled
+            elif m.req_id == 61:
+                assert m.kind == suscan.KIND_INVALID_ARGUMENT
+
+    _pump(Lb, an, on_msg)
+    assert sorted(st["ack"]) == [(50, 0, 1), (51, 1, 1)]
+    assert {suscan.KIND_WRONG_OBJECT, suscan.KIND_SET_TLE, suscan.KIND_INVALID_ARGUMENT} <= set(st["kinds"])
+    # seek: 9 blocks, then the position jumps back to block 2 and the remaining 12 blocks follow
+    assert st["psd"] == 9 + (nblocks - 2) or st["psd"] == 10 + (nblocks - 2)           # the request lands one block later at most
+    back = [i for i in range(1, len(st["ts"])) if st["ts"][i] < st["ts"][i - 1]]
+    assert len(back) == 1 and st["ts"][back[0]] == pytest.approx(2 * L / FS, abs=1e-5)
+    # estimates: a value per block once enabled
+    D, efs = 16, FS / 16
+    for eid, tol in ((0, 0.07), (1, 0.01)):               # the autocorrelation valley is a whole number of samples
+        vals = [v for _, v in st["est"][eid]]
+        assert len(vals) >= st["psd"] - st["on_at"] - 1
+        assert abs(np.median(vals[2:]) - baud) / baud < tol, (eid, vals)
+    # against the oracle on the channel samples of the block after the estimators were switched on
+    b0 = st["on_at"]                                                                # estimators see blocks b0, b0 + 1, ...
+    dp = sdo.fnor_to_dphase(-2 * fc / FS)
+    taps = sdo.lpf_design(255, bw / FS)
+    open_at = 0
+    y = sdo.chan_feed(np.zeros(254, np.complex64), x[open_at * L:], 0, sdo.chan_modulate_taps(taps, dp), D, 0, dp)
+    m = L // D
+    blk = y[b0 * m:(b0 + 1) * m][:4096]
+    nl = sdo.baud_nonlinear(blk) * efs
+    got = dict(st["est"][1])[b0 + 1]                                                # messages of block b0 arrive before PSD b0 + 1
+    assert abs(got - nl) / nl < 2e-3, (got, nl)
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+
+
 def test_halt_wakes_the_reader_and_bad_source_reports_failure(tmp_path):
     x = synth.tone_noise(L * 2, seed=1)
     path = tmp_path / "iq.raw"

@@ -654,6 +654,64 @@ def test_conj_prev_and_gardner_frequency_space(ctx, sdo):
 # ------------------------------------------------------------------------------------------
 # gangs: heterogeneous 1-channel banks side by side -- bit exact against each bank's own oracle
 # ------------------------------------------------------------------------------------------
+def test_source_fix_matches_oracle(ctx, sdo):
+    """I/Q reversal is exact; the tracked DC level follows the oracle's block means (double sums there, a fixed-order float
+    tree here: 1e-6), over several blocks with the state carried; flags off = untouched"""
+    rng = np.random.default_rng(12)
+    blocks = [((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.3 + (0.2 - 0.1j)).astype(np.complex64) for n in (70000, 1, 4097, 65536)]
+    dc_d, dc_o = torch.zeros(2, dtype=torch.float32, device="cuda"), np.zeros(2, np.float32)
+    for k, b in enumerate(blocks):
+        x = dev(b)
+        engine.source_fix(ctx, x, True)
+        assert_bits(host(x), sdo.source_fix(b, True), "reversal only")
+        y = dev(b)
+        engine.source_fix(ctx, y, k % 2 == 0, dc_d, 0.1, first=(k == 0))
+        ref = sdo.source_fix(b, k % 2 == 0, dc_o, 0.1, first=(k == 0))
+        assert np.max(np.abs(host(y) - ref)) < 1e-6
+        assert np.max(np.abs(host(dc_d) - dc_o)) < 1e-6
+        z = dev(b)
+        engine.source_fix(ctx, z, False)
+        assert_bits(host(z), b, "no flags: untouched")
+    with pytest.raises(Exception):
+        engine.source_fix(ctx, dev(blocks[0]), False, dc_d, 1.5)                  # alpha out of range
+
+
+@pytest.mark.parametrize("sps,order", [(8, 4), (16, 4), (11, 2), (4, 8)])
+def test_baud_estimators_match_oracle_and_truth(ctx, sdo, sps, order):
+    """nonlinear: the |dx|^2 line through the carrier detector's search -- same estimate as the oracle (FFT tolerance) and
+    within 0.5 % of the true baud; fac: the autocorrelation's first valley, a whole number of samples, same lag as the
+    oracle and within one sample of the symbol length.  Short blocks leave the estimate alone."""
+    n = 8192
+    x = synth.psk_carriers(n * 5, [0.013], sps=sps, order=order, seed=31, snr_db=20)
+    nl = engine.BaudEstimator(ctx, engine.BaudEstimator.NONLINEAR, n)
+    fac = engine.BaudEstimator(ctx, engine.BaudEstimator.FAC, n)
+    assert nl.get() == 0.0 and fac.get() == 0.0
+    ofac = sdo.FAC(n, 0.25)
+    for k in range(5):
+        blk = x[k * n:(k + 1) * n]
+        nl.feed(dev(blk))
+        fac.feed(dev(blk))
+        ref_nl = sdo.baud_nonlinear(blk)
+        ref_lag = sdo.fac_first_valley(ofac.feed(blk))
+        got_nl, got_fac = nl.get(), fac.get()
+        assert abs(got_nl - ref_nl) < 2e-6 * max(1.0, ref_nl * n), (k, got_nl, ref_nl)
+        assert abs(got_nl * sps - 1) < 5e-3
+        assert ref_lag > 0 and got_fac == pytest.approx(1.0 / ref_lag, rel=1e-6)
+        assert abs(ref_lag - sps) <= 1
+    noise = synth.tone_noise(n, f_rel=0.0, sigma2=1.0, seed=3) - 1.0              # no symbol clock in it: no estimate, not a guess
+    nl.feed(dev(noise.astype(np.complex64)))
+    assert nl.get() == 0.0 and sdo.baud_nonlinear(noise.astype(np.complex64)) == 0.0
+    nl.feed(dev(x[:n]))
+    before = nl.get()
+    assert before > 0
+    nl.feed(dev(x[:n - 1]))                                                        # not a whole window
+    assert nl.get() == before
+    with pytest.raises(Exception):
+        engine.BaudEstimator(ctx, 7, n)
+    with pytest.raises(Exception):
+        engine.BaudEstimator(ctx, 0, 1000)
+
+
 @pytest.mark.parametrize("pinned", [False, True])
 def test_rows_deliver_hands_every_row_over(ctx, pinned):
     """one launch: fixed-length rows and counter-driven rows to device or host-mapped landing zones; counters cleared"""
