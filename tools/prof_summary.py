@@ -59,7 +59,7 @@ with open(os.path.join(prof, f"{tag}_kernel_stats_summary.md"), "w") as f:
             "to more than the wall time; the step time is the slowest of them.\n")
     stats_all = glob.glob(os.path.join(out, "trace_all", "**", "*kernel_stats.csv"), recursive=True)
     if stats_all:
-        f.write("\n## with the secondary workloads (C2, C3, C5 after the default one)\n\n"
+        f.write("\n## with the secondary workloads (C2, C3, C5 and the live analyzer with 64 inspectors after the default one)\n\n"
                 "Same command without `--no-extra`; kernels shared by several workloads aggregate all of them "
                 "(psd_kernel<13, 512> includes C5's 8.6 GB launches, the recurrence kernels C2's 16x longer rows).\n\n")
         table(list(csv.DictReader(open(stats_all[0]))))
