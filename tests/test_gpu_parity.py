@@ -802,6 +802,48 @@ def test_gangs_of_heterogeneous_banks_bit_exact(ctx, sdo):
         assert_bits(host(syms[i][:k]), ref, f"gang item {i}: symbols")
 
 
+def test_gangs_larger_than_a_descriptor_slot(ctx, sdo):
+    """700 inspectors' worth of items: the gangs split into several descriptor tables / launches (512 items per slot,
+    448 for the Costas loops, 256 for the channeliser) and every item still equals its oracle"""
+    rng = np.random.default_rng(77)
+    n = 700
+    lens = rng.integers(40, 400, n)
+    kinds = rng.integers(1, 4, n)
+    arm = rng.integers(1, 5, n)
+    sps = rng.choice([4, 8], n)
+    base = synth.psk_carriers(4000, [0.003], sps=8, order=4, seed=5)
+    xs_h = [np.roll(base, 13 * i)[:int(L_)].copy() for i, L_ in enumerate(lens)]
+    agc = [engine.AGCBank(ctx, 1, tau=float(sps[i])) for i in range(n)]
+    cos = [engine.CostasBank(ctx, 1, int(kinds[i]), 0.0, 2.0 / sps[i], int(arm[i]), 0.01) for i in range(n)]
+    clk = [engine.ClockBank(ctx, 1, 0.2, 1.0 / sps[i]) for i in range(n)]
+    xs = [dev(v) for v in xs_h]
+    ya, yz = [torch.empty_like(x) for x in xs], [torch.empty_like(x) for x in xs]
+    syms = [torch.zeros(int(L_) + 2, dtype=torch.complex64, device="cuda") for L_ in lens]
+    cnts = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(n)]
+    engine.gang_agc(ctx, agc, xs, ya)
+    engine.gang_costas(ctx, cos, ya, yz)
+    engine.gang_clock(ctx, clk, yz, syms, cnts)
+    for i in range(0, n, 7):
+        a = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(float(sps[i]))), xs_h[i])
+        z = sdo.costas_feed_bulk(sdo.costas_new(int(kinds[i]), 0.0, 2.0 / sps[i], int(arm[i]), 0.01), a)
+        assert_bits(host(yz[i]), z, f"item {i}: costas output")
+        ref = sdo.clock_feed_bulk(sdo.clock_new(0.2, 1.0 / sps[i]), z)
+        k = int(cnts[i].cpu()[0])
+        assert k == ref.size
+        assert_bits(host(syms[i][:k]), ref, f"item {i}: symbols")
+    # channeliser: 300 banks on one block
+    nb = 300
+    fns = rng.uniform(-0.8, 0.8, nb)
+    taps = sdo.lpf_design(63, 0.1)
+    banks = [engine.ChannelBank(ctx, [fns[i]], 8, taps) for i in range(nb)]
+    blk = synth.tone_noise(4096, f_rel=0.05, sigma2=0.05, seed=6)
+    outs = [torch.empty(520, dtype=torch.complex64, device="cuda") for _ in range(nb)]
+    ys = engine.gang_chan(ctx, banks, dev(blk), outs)
+    for i in range(0, nb, 11):
+        ref = _oracle_bank(sdo, blk, fns[i:i + 1], 8, taps, [(0, 4096)])[0]
+        assert_bits(host(ys[i]), ref, f"channeliser bank {i}")
+
+
 def test_pll_and_cma_gangs_bit_exact(ctx, sdo):
     rng = np.random.default_rng(7)
     n = 40
