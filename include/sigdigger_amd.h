@@ -400,6 +400,17 @@ SUAMD_API SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d
  * Tasks/CarrierDetector.cpp:58-75,94.  d_work: scratch of n complex values. */
 SUAMD_API SUBOOL suamd_fft_forward_bulk(suamd_ctx_t *ctx, const suamd_complex *d_in, suamd_complex *d_out,
                                         suamd_complex *d_work, unsigned log2n, void *stream);
+/* Capture export: ExportSamplesTask (Tasks/ExportSamplesTask.cpp:41-284) for a capture that
+ * lives in HBM -- streamed to the host a pinned chunk at a time and written in the reference's formats:
+ *   "raw"  interleaved float32 I/Q                       (:250-270, libsndfile RAW | FLOAT)
+ *   "wav"  RIFF/WAVE, IEEE float, 2 channels, (int) fs   (:226-248, libsndfile WAV | FLOAT; fmt + fact + data chunks)
+ *   "m"    exportToMatlab's text, character for character (:41-68: 6 significant digits, "re + imi, ")
+ *   "mat"  MAT-file level 5 with sampleRate (1x1), deltaT (1x1), X (2 x N: rows I, Q), single precision (:164-206;
+ *          libsigutils' su_mat_file is absent: layout per the published format, readable by scipy.io.loadmat)
+ * Any other format string is refused with the reference's message.  Synchronises the stream. */
+SUAMD_API SUBOOL suamd_export_capture(suamd_ctx_t *ctx, const char *path, const char *format, const suamd_complex *d_data,
+                                      SUSCOUNT len, SUFLOAT fs, void *stream);
+
 /* Baud estimators behind the inspectors' ESTIMATOR messages (Suscan/Analyzer.cpp:549-565,
  * InspectorUI::updateEstimator, Default/GenericInspector/InspectorUI.cpp:1003-1015; the estimators themselves are
  * libsuscan's -- absent -- and are frozen in SPEC.md section M).  Both work on the first `size` samples of a block:

@@ -28,6 +28,7 @@ SOURCES = {
     "stages.hip": ["-ffp-contract=off"],
     "capi.hip":  ["-ffp-contract=off"],
     "analyzer.cpp": ["-ffp-contract=off"],
+    "export.cpp": ["-ffp-contract=off"],
 }
 HEADERS = ["kernels.hpp", "sd_math.hpp", os.path.join("..", "..", "include", "sigdigger_amd.h"),
            os.path.join("..", "..", "include", "suscan_amd.h")]

@@ -31,6 +31,21 @@ void set_err(const char *fmt, ...)
   g_err = buf;
 }
 
+}  // namespace
+
+// the other translation units of the library report through the same thread-local message
+void suamd_set_error(const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+namespace {
+
 #define HIP_TRY(expr, ret)                                                          \
   do {                                                                              \
     hipError_t e__ = (expr);                                                        \

@@ -465,6 +465,13 @@ def _ptr_array(ptrs):
     return (C.c_void_p * len(ptrs))(*ptrs)
 
 
+def export_capture(ctx, path, fmt, x, fs, stream=None):
+    """suamd_export_capture: a device capture to disk as "raw" / "wav" / "m" / "mat" (ExportSamplesTask's formats)."""
+    _chk_c64(x, "x")
+    check(ctx.lib.suamd_export_capture(ctx.h, str(path).encode(), fmt.encode(), _ptr(x), x.numel(), float(fs), _stream(stream)),
+          "suamd_export_capture")
+
+
 def source_fix(ctx, x, iq_reverse, dc=None, alpha=0.1, first=True, stream=None):
     """suamd_source_fix, in place on x: I/Q swap and / or removal of the tracked DC level dc (float32[2] device tensor)."""
     _chk_c64(x, "x")

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "suamd_baud_estimator_size": (UINT, [VP]),
     "suamd_baud_estimator_feed": (INT, [VP, VP, U64, VP]),
     "suamd_baud_estimator_get": (C.c_float, [VP]),
+    "suamd_export_capture": (INT, [VP, C.c_char_p, C.c_char_p, VP, U64, C.c_float, VP]),
     "suamd_source_fix": (INT, [VP, VP, U64, INT, VP, C.c_float, INT, VP]),
     "suamd_chanbank_gang_feed": (INT, [VP, VP, UINT, VP, U64, VP, VP, VP]),
     "suamd_rows_deliver": (INT, [VP, UINT, VP, VP, VP, VP, VP, VP]),

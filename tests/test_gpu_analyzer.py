@@ -96,7 +96,7 @@ def _write_wav(path, raw, rate, bits, tag):
         f.write(b"data" + struct.pack("<I", len(data)) + data)
 
 
-@pytest.mark.parametrize("kind", ["u8", "s8", "s16", "wav16", "wav8", "sigmf-ci16", "auto-cu8"])
+@pytest.mark.parametrize("kind", ["u8", "s8", "s16", "wav16", "wav8", "sigmf-ci16", "auto-cu8", "exported-wav"])
 def test_compact_file_formats_are_expanded_on_the_gpu(tmp_path, sdo, kind):
     """File sources in the compact formats of FileSourcePage.cpp:80-104: the PSD stream must equal the
     oracle's PSD of the oracle-converted samples (ingest is bit exact, so the same 1e-5 bound holds)."""
@@ -117,6 +117,17 @@ def test_compact_file_formats_are_expanded_on_the_gpu(tmp_path, sdo, kind):
     elif kind == "auto-cu8":
         path, fmt = tmp_path / "capture.cu8", 0
         raw.tofile(path)
+    elif kind == "exported-wav":                                            # round trip: suamd_export_capture's float WAV is a source
+        from sigdigger_amd import lib as sdlib                               # plain ctypes + HIP: this module stays torch-free
+        path, fmt, fs, raw, ofmt = tmp_path / "cap.wav", 0, 250_000, x, 1
+        lb, hip = sdlib.load(), C.CDLL("libamdhip64.so")
+        ctx, dptr = lb.suamd_ctx_new(0), C.c_void_p()
+        hip.hipMalloc.argtypes, hip.hipMemcpy.argtypes, hip.hipFree.argtypes = [C.c_void_p, C.c_size_t], [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int], [C.c_void_p]
+        assert ctx and hip.hipMalloc(C.byref(dptr), x.nbytes) == 0
+        assert hip.hipMemcpy(dptr, x.ctypes.data, x.nbytes, 1) == 0
+        assert lb.suamd_export_capture(ctx, str(path).encode(), b"wav", dptr, x.size, float(fs), None), lb.suamd_last_error()
+        hip.hipFree(dptr)
+        lb.suamd_ctx_destroy(ctx)
     elif kind.startswith("wav"):
         path, fmt, fs = tmp_path / "iq.wav", 5, 250_000                     # the header's rate wins
         _write_wav(path, raw, fs, 8 if kind == "wav8" else 16, 1)

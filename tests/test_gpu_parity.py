@@ -654,6 +654,42 @@ def test_conj_prev_and_gardner_frequency_space(ctx, sdo):
 # ------------------------------------------------------------------------------------------
 # gangs: heterogeneous 1-channel banks side by side -- bit exact against each bank's own oracle
 # ------------------------------------------------------------------------------------------
+def test_capture_export_formats(ctx, tmp_path):
+    """ExportSamplesTask's formats for a capture in HBM (more than one pinned chunk): raw / wav / mat carry the float32
+    samples bit for bit (read back with numpy / scipy), "m" is the reference's text character for character"""
+    from scipy.io import loadmat, wavfile
+    n = (1 << 20) + 12345
+    rng = np.random.default_rng(21)
+    x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.3).astype(np.complex64)
+    x[:4] = [1.5 - 2.25j, 1e-7 + 123456.789j, 0, -1j]
+    d, fs = dev(x), 250000.0
+    engine.export_capture(ctx, tmp_path / "c.raw", "raw", d, fs)
+    assert_bits(np.fromfile(tmp_path / "c.raw", dtype=np.complex64), x, "raw")
+    engine.export_capture(ctx, tmp_path / "c.wav", "wav", d, fs)
+    rate, w = wavfile.read(tmp_path / "c.wav")
+    assert rate == 250000 and w.dtype == np.float32 and w.shape == (n, 2)
+    assert_bits(np.ascontiguousarray(w).view(np.complex64).ravel(), x, "wav")
+    engine.export_capture(ctx, tmp_path / "c.mat", "mat", d, fs)
+    m = loadmat(tmp_path / "c.mat")
+    assert m["sampleRate"].shape == (1, 1) and m["sampleRate"][0, 0] == np.float32(fs) and m["deltaT"][0, 0] == np.float32(1 / fs)
+    assert m["X"].dtype == np.float32 and m["X"].shape == (2, n)
+    assert np.array_equal(m["X"][0], x.real) and np.array_equal(m["X"][1], x.imag)
+    k = 70000                                                                      # text is bulky: a shorter capture
+    engine.export_capture(ctx, tmp_path / "c.m", "m", d[:k].contiguous(), fs)
+    txt = open(tmp_path / "c.m").read()
+    g = lambda v: format(float(v), ".6g")                                          # ostream << float, precision digits10
+    want = ("%\n% Time domain capture file generated by SigDigger\n%\n\nsampleRate = 250000;\ndeltaT = 4e-06;\nX = [ " +
+            "".join(f"{g(v.real)} + {g(v.imag)}i, " for v in x[:k]) + "];\n")
+    assert txt == want
+    # the float WAV is a source the analyzer reads back; empty captures and unknown formats
+    engine.export_capture(ctx, tmp_path / "e.raw", "raw", d[:0], fs)
+    assert (tmp_path / "e.raw").stat().st_size == 0
+    with pytest.raises(Exception, match="Unsupported data format"):
+        engine.export_capture(ctx, tmp_path / "c.xyz", "xyz", d, fs)
+    with pytest.raises(Exception, match="Cannot open"):
+        engine.export_capture(ctx, tmp_path / "nodir" / "c.raw", "raw", d, fs)
+
+
 def test_source_fix_matches_oracle(ctx, sdo):
     """I/Q reversal is exact; the tracked DC level follows the oracle's block means (double sums there, a fixed-order float
     tree here: 1e-6), over several blocks with the state carried; flags off = untouched"""
