@@ -400,6 +400,18 @@ SUAMD_API SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d
  * Tasks/CarrierDetector.cpp:58-75,94.  d_work: scratch of n complex values. */
 SUAMD_API SUBOOL suamd_fft_forward_bulk(suamd_ctx_t *ctx, const suamd_complex *d_in, suamd_complex *d_out,
                                         suamd_complex *d_work, unsigned log2n, void *stream);
+/* The "power" inspector class (A6; consumer: RMSInspector, Default/RMSInspector/RMSInspector.cpp:255-338, 538-562, config
+ * key power.integrate-samples :415): every window of N consecutive channel samples yields one output sample
+ * (mean of Re(x conj x), 0).  The arithmetic is the one the reference runs itself in raw mode -- binary64 sum of the
+ * binary32 powers over the count (Kahan there, a fixed-order tree here).  Windows span feeds; set_integrate starts over. */
+typedef struct suamd_power_bank suamd_power_bank_t;
+SUAMD_API suamd_power_bank_t *suamd_power_bank_new(suamd_ctx_t *ctx, SUSCOUNT integrate_samples);
+SUAMD_API void     suamd_power_bank_destroy(suamd_power_bank_t *bank);
+SUAMD_API SUBOOL   suamd_power_bank_set_integrate(suamd_power_bank_t *bank, SUSCOUNT integrate_samples, void *stream);
+SUAMD_API SUSCOUNT suamd_power_bank_output_count(const suamd_power_bank_t *bank, SUSCOUNT len);
+SUAMD_API SUBOOL   suamd_power_bank_feed(suamd_power_bank_t *bank, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_out,
+                                         SUSCOUNT *n_out, void *stream);
+
 /* Capture export: ExportSamplesTask (Tasks/ExportSamplesTask.cpp:41-284) for a capture that
  * lives in HBM -- streamed to the host a pinned chunk at a time and written in the reference's formats:
  *   "raw"  interleaved float32 I/Q                       (:250-270, libsndfile RAW | FLOAT)

@@ -112,7 +112,7 @@ typedef struct suscan_config_desc { char *global_name; struct suscan_field **fie
   suscan_config_desc_t;
 typedef struct suscan_config { const suscan_config_desc_t *desc; struct suscan_field_value **values; }
   suscan_config_t;
-SUAMD_API const suscan_config_desc_t *suscan_inspector_config_desc(const char *class_name);  /* "psk", "fsk", "raw" */
+SUAMD_API const suscan_config_desc_t *suscan_inspector_config_desc(const char *class_name);  /* "psk", "fsk", "ask", "raw", "power" */
 SUAMD_API suscan_config_t *suscan_config_new(const suscan_config_desc_t *desc);
 SUAMD_API suscan_config_t *suscan_config_dup(const suscan_config_t *cfg);
 SUAMD_API void   suscan_config_destroy(suscan_config_t *cfg);

@@ -994,6 +994,25 @@ void sdo_ingest_iq(int format, const void *raw, size_t n, sdo_c32 *out)
   }
 }
 
+void sdo_power_init(sdo_power *p, unsigned long long max_samples) { p->acc = p->c = 0; p->count = 0; p->max_samples = max_samples; }
+
+size_t sdo_power_feed(sdo_power *p, const sdo_c32 *x, size_t len, sdo_c32 *out)
+{
+  size_t i, k = 0;
+  for (i = 0; i < len; ++i) {
+    const double input = (double)fmaf(x[i].im, x[i].im, x[i].re * x[i].re);   /* SU_C_REAL(x conj(x)), binary32 */
+    const double y = input - p->c, t = p->acc + y;                             /* RMSInspector.cpp:551-556 */
+    p->c = (t - p->acc) - y;
+    p->acc = t;
+    ++p->count;
+    if (p->count >= p->max_samples) {                                          /* checkMaxSamples, :327-338 */
+      out[k].re = (float)(p->acc / (double)p->count); out[k].im = 0.f; ++k;
+      p->c = p->acc = 0; p->count = 0;
+    }
+  }
+  return k;
+}
+
 float sdo_baud_nonlinear(const sdo_c32 *x, size_t n)
 {
   sdo_c32 *y = malloc(n * sizeof *y);

@@ -230,6 +230,12 @@ void  sdo_doppler_calc(const sdo_c32 *data, size_t len, float fs, double f0, flo
 void sdo_fac_feed(const sdo_c32 *buf, size_t n, float alpha, long view_start, long view_end,
                   float *fac, float *max, float *min);
 
+/* ---- "power" inspector class [REF-PINNED: the raw-mode loop of RMSInspector::samplesMessage] ------------------ */
+/* Default/RMSInspector/RMSInspector.cpp:538-562 (Kahan sum of Re(x conj x) in binary64), :327-338 (mean at count >= N) */
+typedef struct { double acc, c; unsigned long long count, max_samples; } sdo_power;
+void   sdo_power_init(sdo_power *p, unsigned long long max_samples);
+size_t sdo_power_feed(sdo_power *p, const sdo_c32 *x, size_t len, sdo_c32 *out /* >= (count + len) / N */);
+
 /* ---- section 8f #2: baud estimators (SPEC.md section M) [UPSTREAM-RECOLLECTION: libsuscan's estimators] --- */
 /* nonlinear: y[n] = |x[n] - x[n-1]|^2 (y[0] = 0), Blackman-Harris, FFT; the lowest local maximum of |Y|^2 in
  * [max(4, n/100), n/2) that reaches half of the strongest one -- provided that one stands 20x above the mean level,

@@ -499,6 +499,23 @@ class FAC:
         return self.fac
 
 
+class Power(C.Structure):
+    """sdo_power: the "power" class / RMSInspector raw-mode integrator"""
+    _fields_ = [("acc", C.c_double), ("c", C.c_double), ("count", C.c_ulonglong), ("max_samples", C.c_ulonglong)]
+
+    def __init__(self, n):
+        super().__init__()
+        lib().sdo_power_init(C.byref(self), C.c_ulonglong(int(n)))
+
+    def feed(self, x):
+        x = _c(x)
+        out = np.empty((int(self.count) + x.size) // int(self.max_samples) + 1, dtype=c32)
+        f = lib().sdo_power_feed
+        f.restype = C.c_size_t
+        k = f(C.byref(self), _p(x), C.c_size_t(x.size), _p(out))
+        return out[:k]
+
+
 def baud_nonlinear(x):
     x = _c(x)
     f = lib().sdo_baud_nonlinear

@@ -97,6 +97,9 @@ DescHolder &psk_desc() { static DescHolder d("psk", kPskFields, sizeof kPskField
 DescHolder &fsk_desc() { static DescHolder d("fsk", kFskFields, sizeof kFskFields / sizeof kFskFields[0]); return d; }
 DescHolder &ask_desc() { static DescHolder d("ask", kAskFields, sizeof kAskFields / sizeof kAskFields[0]); return d; }
 DescHolder &raw_desc() { static DescHolder d("raw", nullptr, 0); return d; }
+// "power": mean channel power over windows of power.integrate-samples (Default/RMSInspector/RMSInspector.cpp:415,438)
+const FieldDef kPowerFields[] = { {"power.integrate-samples", SUSCAN_FIELD_TYPE_INTEGER, 1000} };
+DescHolder &power_desc() { static DescHolder d("power", kPowerFields, 1); return d; }
 DescHolder *holder_for(const char *cls)
 {
   if (!cls) return nullptr;
@@ -104,6 +107,7 @@ DescHolder *holder_for(const char *cls)
   if (!std::strcmp(cls, "fsk")) return &fsk_desc();
   if (!std::strcmp(cls, "ask")) return &ask_desc();
   if (!std::strcmp(cls, "raw")) return &raw_desc();
+  if (!std::strcmp(cls, "power")) return &power_desc();
   return nullptr;
 }
 
@@ -330,6 +334,7 @@ struct Inspector {
   suamd_cma_bank_t *cma = nullptr;            // equalizer.type = CMA
   float fixed_gain = 0;                       // agc.enabled = false: linear agc.gain (0 = none)
   uint32_t spectsrc_id = 0;                   // 0 = none (Suscan/Analyzer.cpp:539-547)
+  suamd_power_bank_t *power = nullptr;         // class "power"
   suamd_baud_estimator_t *est[2] = {nullptr, nullptr};   // "baud-fac", "baud-nonlinear" (estimator_list of the OPEN message)
   bool est_on[2] = {false, false}, est_fed[2] = {false, false};
   suamd_psd_t *spect_psd = nullptr;           // spectrum of the channel samples, one frame set per block
@@ -360,6 +365,8 @@ struct Inspector {
     if (pll) suamd_pll_bank_destroy(pll);
     if (mf) suamd_fir_bank_destroy(mf);
     if (cma) suamd_cma_bank_destroy(cma);
+    if (power) suamd_power_bank_destroy(power);
+    power = nullptr;
     bank = nullptr; agc = nullptr; costas = nullptr; clock = nullptr; nco = nullptr; pll = nullptr; mf = nullptr; cma = nullptr;
     fixed_gain = 0;
   }
@@ -517,6 +524,12 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
   in.first = true;
   in.quad = false;
   if (in.cls == "raw") return true;
+  if (in.cls == "power") {
+    const double n = cfg_get(in.config, "power.integrate-samples", 1000);
+    in.power = suamd_power_bank_new(a->ctx, n >= 1 ? (SUSCOUNT)n : 1);
+    if (!in.power) { err = suamd_last_error(); return false; }
+    return true;
+  }
   const double baud = cfg_get(in.config, "clock.baud", 0);
   const double sps = baud > 0 ? in.equiv_fs / baud : 8.0;
   // stage order of the generic inspector: gain control -> carrier control -> matched filter ->
@@ -760,6 +773,15 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
     }
     // the equalizers take their symbol counts from the device: no host round trip inside the chain
     if (!eq.empty() && !suamd_cma_gang_feed(a->ctx, eq.data(), (unsigned)eq.size(), ex.data(), ec.data(), nullptr, ey.data(), sK)) fail("equalizer");
+    // "power" inspectors: the block's channel samples fold into their integration windows
+    for (Inspector *pi : live) {
+      Inspector &in = *pi;
+      if (!in.power) continue;
+      SUSCOUNT k = 0;
+      if (!suamd_power_bank_feed(in.power, in.d_y, in.pend_m, in.d_sym, &k, sK)) fail("power");
+      in.pend_src = in.d_sym;
+      in.pend_m = k;
+    }
     // hand-off: every inspector's batch goes to its mapped landing zone in one launch (sK is downstream of all stages)
     std::vector<const suamd_complex *> src; std::vector<uint32_t *> cnt; std::vector<SUSCOUNT> fixed;
     std::vector<suamd_complex *> dst; std::vector<uint32_t *> cout;
@@ -867,7 +889,7 @@ void handle_request(suscan_analyzer *a, Request &r)
       m->spectsrc_count = suamd_spectsrc_count();             // names borrowed from the library (static storage)
       m->spectsrc_list = static_cast<char **>(std::calloc(m->spectsrc_count, sizeof(char *)));
       for (unsigned k = 0; k < m->spectsrc_count; ++k) m->spectsrc_list[k] = const_cast<char *>(suamd_spectsrc_name(k + 1));
-      if (r.cls != "raw") {                                   // the baud estimators (names static, like the sources')
+      if (r.cls != "raw" && r.cls != "power") {               // the baud estimators (names static, like the sources')
         m->estimator_count = 2;
         m->estimator_list = static_cast<char **>(std::calloc(2, sizeof(char *)));
         m->estimator_list[0] = const_cast<char *>(kEstimators[0].name);
@@ -952,7 +974,7 @@ void handle_request(suscan_analyzer *a, Request &r)
     case Request::SET_THROTTLE: a->throttle = r.value; break;
     case Request::ESTIMATOR: {
       Inspector &in = *it->second;
-      if (r.value >= 2 || in.cls == "raw") {
+      if (r.value >= 2 || in.cls == "raw" || in.cls == "power") {
         auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_WRONG_OBJECT, r.req_id);
         m->handle = r.handle;
         push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);

@@ -1612,6 +1612,55 @@ struct CaptureFft {                      // scratch of one whole-capture task
 };
 }  // namespace
 
+// ---- "power" inspector class ----------------------------------------------------------------------------------
+struct suamd_power_bank { suamd_ctx *ctx; uint64_t N, cnt; double *d_acc = nullptr; int cur = 0; };
+
+suamd_power_bank_t *suamd_power_bank_new(suamd_ctx_t *ctx, SUSCOUNT integrate_samples)
+{
+  if (!ctx) { set_err("null context"); return nullptr; }
+  if (integrate_samples == 0) { set_err("integrate_samples must be > 0"); return nullptr; }
+  auto *b = new (std::nothrow) suamd_power_bank;
+  if (!b) { set_err("out of memory"); return nullptr; }
+  b->ctx = ctx; b->N = integrate_samples; b->cnt = 0;
+  if (hipMalloc((void **)&b->d_acc, 2 * sizeof(double)) != hipSuccess || hipMemset(b->d_acc, 0, 2 * sizeof(double)) != hipSuccess) {
+    set_err("device allocation failed"); suamd_power_bank_destroy(b); return nullptr;
+  }
+  return b;
+}
+
+void suamd_power_bank_destroy(suamd_power_bank_t *b)
+{
+  if (!b) return;
+  if (b->d_acc) (void)hipFree(b->d_acc);
+  delete b;
+}
+
+SUBOOL suamd_power_bank_set_integrate(suamd_power_bank_t *b, SUSCOUNT integrate_samples, void *stream)
+{
+  if (!b || integrate_samples == 0) { set_err("bad argument"); return SU_FALSE; }
+  b->N = integrate_samples; b->cnt = 0;                      // RMSInspector::updateMaxSamples -> checkMaxSamples: start over
+  HIP_TRY(hipMemsetAsync(b->d_acc, 0, 2 * sizeof(double), as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUSCOUNT suamd_power_bank_output_count(const suamd_power_bank_t *b, SUSCOUNT len) { return b ? (b->cnt + len) / b->N : 0; }
+
+SUBOOL suamd_power_bank_feed(suamd_power_bank_t *b, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_out, SUSCOUNT *n_out,
+                             void *stream)
+{
+  if (!b) { set_err("null argument"); return SU_FALSE; }
+  if (n_out) *n_out = 0;
+  if (len == 0) return SU_TRUE;
+  const uint64_t K = (b->cnt + len) / b->N;
+  if (!d_x || (K && !d_out)) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(sdk::power_integrate(d_x, (long long)len, (long long)b->N, (long long)b->cnt, b->d_acc + b->cur, b->d_acc + (b->cur ^ 1), d_out,
+                               as_stream(stream)), SU_FALSE);
+  b->cur ^= 1;
+  b->cnt = (b->cnt + len) % b->N;
+  if (n_out) *n_out = K;
+  return SU_TRUE;
+}
+
 // ---- baud estimators (SPEC.md section M) ---------------------------------------------
 struct suamd_baud_estimator {
   suamd_ctx *ctx; int kind; unsigned n;

@@ -191,6 +191,10 @@ hipError_t cma_feed(int n, float mu, int locked, void *w, void *dl, int nchan, c
 // ---- ingest.hip ----
 // format: 1 float32, 2 unsigned 8, 3 signed 8, 4 signed 16 (interleaved I/Q) -> SUCOMPLEX
 hipError_t ingest_iq(int format, const void *raw, long long nsamp, void *out, hipStream_t st);
+// "power" inspector class: mean of |x|^2 over consecutive windows of N samples; window j of a feed covers samples
+// [j N - cnt, (j + 1) N - cnt) (cnt = samples carried in acc_in), out[j] = (mean, 0); the unfinished tail goes to acc_out
+hipError_t power_integrate(const void *x, long long len, long long N, long long cnt, const double *acc_in, double *acc_out,
+                           void *out, hipStream_t st);
 // baud estimators (SPEC.md section M): y[n] = (|x[n] - x[n-1]|^2, 0), y[0] = 0  -- its spectrum has a line at the baud;
 // first valley of a fast autocorrelation (fac: n_half floats) below a quarter of fac[0] -> out[0] = lag (0: none)
 hipError_t baud_nl_transform(const void *x, long long n, void *y, hipStream_t st);

@@ -336,6 +336,31 @@ hipError_t launch_cma(float mu, int locked, void *w, void *dl, int nchan, const 
   return hipGetLastError();
 }
 
+// RMSInspector::samplesMessage, raw mode (Default/RMSInspector/RMSInspector.cpp:538-562, :327-338): the power of a sample
+// is Re(x conj x), a window's mean its binary64 sum over the count.  One workgroup per window (fixed-order tree);
+// the workgroup after the last whole window sums the tail into the carry.
+__global__ __launch_bounds__(256) void power_integrate_kernel(const float2 *__restrict__ x, long long len, long long N, long long cnt,
+                                                              const double *__restrict__ acc_in, double *__restrict__ acc_out,
+                                                              float2 *__restrict__ out, long long K)
+{
+  __shared__ double sh[256];
+  const long long j = blockIdx.x;
+  long long lo = j * N - cnt, hi = lo + N;
+  if (lo < 0) lo = 0;
+  if (hi > len) hi = len;
+  double a = 0.0;
+  for (long long t = lo + threadIdx.x; t < hi; t += 256) { const float2 v = x[t]; a += (double)sd::fma_(v.y, v.y, v.x * v.x); }
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    double tot = sh[0];
+    if (j == 0) tot += acc_in[0];                           // what earlier feeds left of this window
+    if (j < K) out[j] = float2{(float)(tot / (double)N), 0.0f};
+    else acc_out[0] = tot;
+  }
+}
+
 __global__ void baud_nl_kernel(const float2 *__restrict__ x, long long n, float2 *__restrict__ y)
 {
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
@@ -506,6 +531,17 @@ hipError_t cma_feed(int n, float mu, int locked, void *w, void *dl, int nchan, c
 #undef CMA_CASE
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t power_integrate(const void *x, long long len, long long N, long long cnt, const double *acc_in, double *acc_out,
+                           void *out, hipStream_t st)
+{
+  if (len <= 0 || N <= 0) return hipErrorInvalidValue;
+  const long long K = (cnt + len) / N;
+  if (K + 1 > 0x7fffffffll) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(power_integrate_kernel, dim3((unsigned)(K + 1)), dim3(256), 0, st, static_cast<const float2 *>(x), len, N, cnt,
+                     acc_in, acc_out, static_cast<float2 *>(out), K);
+  return hipGetLastError();
 }
 
 hipError_t baud_nl_transform(const void *x, long long n, void *y, hipStream_t st)

@@ -441,6 +441,28 @@ class FAC(_LoopBank):
         return mn.value, mx.value
 
 
+class PowerBank(_LoopBank):
+    """suamd_power_bank_t: the "power" inspector class -- mean |x|^2 over windows of N channel samples."""
+    _destroy = "suamd_power_bank_destroy"
+
+    def __init__(self, ctx, integrate_samples):
+        self.ctx = ctx
+        self.h = ctx.lib.suamd_power_bank_new(ctx.h, int(integrate_samples))
+        if not self.h:
+            raise SigDiggerAmdError("suamd_power_bank_new: " + _l.last_error())
+
+    def set_integrate(self, n, stream=None):
+        check(self.ctx.lib.suamd_power_bank_set_integrate(self.h, int(n), _stream(stream)), "suamd_power_bank_set_integrate")
+
+    def feed(self, x, stream=None):
+        _chk_c64(x, "x")
+        k = int(self.ctx.lib.suamd_power_bank_output_count(self.h, x.numel()))
+        out = torch.empty(max(k, 1), dtype=torch.complex64, device=x.device)
+        n = C.c_uint64(0)
+        check(self.ctx.lib.suamd_power_bank_feed(self.h, _ptr(x), x.numel(), _ptr(out), C.byref(n), _stream(stream)), "suamd_power_bank_feed")
+        return out[:n.value]
+
+
 class BaudEstimator(_LoopBank):
     """suamd_baud_estimator_t: kind 0 = fast autocorrelation valley, 1 = nonlinear (|dx|^2 line); normalised baud."""
     _destroy = "suamd_baud_estimator_destroy"

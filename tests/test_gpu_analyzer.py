@@ -655,6 +655,51 @@ def test_baseband_filters_and_source_controls(tmp_path, sdo, fmt):
     Lb.suscan_mq_finalize(C.byref(mq))
 
 
+def test_power_inspector_class(tmp_path, sdo):
+    """class "power" (RMSInspector's server-side mode): every power.integrate-samples channel samples one SAMPLES value,
+    the mean channel power -- equal to the reference's own integrator on the oracle's channel samples"""
+    nblocks, nint = 10, 1500
+    bw, fc = 50e3, -120e3
+    x = (synth.psk_carriers(L * nblocks, [2 * fc / FS], sps=16, order=4, seed=4, snr_db=15) * np.float32(0.3)).astype(np.complex64)
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    Lb, mq, an = _start(path, L)
+    Lb.suscan_analyzer_set_throttle_async(an, 3 * FS, 0)
+    ch = suscan.Channel(fc=fc, f_lo=fc - bw / 2, f_hi=fc + bw / 2, bw=bw, ft=433.92e6)
+    assert Lb.suscan_analyzer_open_ex_async(an, b"power", C.byref(ch), 1, -1, 3)
+    st = {"psd": 0, "cfg_at": None, "vals": []}
+
+    def on_msg(t, ptr):
+        if t == suscan.MSG_PSD:
+            st["psd"] += 1
+        elif t == suscan.MSG_INSPECTOR:
+            m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
+            if m.kind == suscan.KIND_OPEN:
+                assert m.class_name == b"power" and m.estimator_count == 0
+                cfg = Lb.suscan_config_dup(m.config)
+                assert Lb.suscan_config_set_integer(cfg, b"power.integrate-samples", nint)
+                assert Lb.suscan_analyzer_set_inspector_config_async(an, m.handle, cfg, 4)
+                Lb.suscan_config_destroy(cfg)
+            elif m.kind == suscan.KIND_SET_CONFIG:
+                st["cfg_at"] = st["psd"]
+        elif t == suscan.MSG_SAMPLES and st["cfg_at"] is not None:
+            m = C.cast(ptr, C.POINTER(suscan.SampleBatchMsg)).contents
+            st["vals"].append(np.ctypeslib.as_array(m.samples, shape=(m.sample_count * 2,)).copy().view(np.complex64))
+
+    _pump(Lb, an, on_msg)
+    b0 = st["cfg_at"]
+    assert b0 is not None and b0 < nblocks - 4
+    D = 8                                                  # pow2floor(1e6 / 100e3)
+    dp = sdo.fnor_to_dphase(-2 * fc / FS)
+    y = sdo.chan_feed(np.zeros(254, np.complex64), x[b0 * L:], 0, sdo.chan_modulate_taps(sdo.lpf_design(255, bw / FS), dp), D, 0, dp)
+    want = sdo.Power(nint).feed(y)
+    got = np.concatenate(st["vals"])
+    assert got.size == want.size == y.size // nint and got.size > 20
+    assert np.all(got.imag == 0) and np.max(np.abs(got.real - want.real) / want.real) < 2e-7
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+
+
 def test_seek_estimators_and_tle(tmp_path, sdo):
     """Analyzer::seek moves the file position; setInspectorEnabled switches the baud estimators of estimator_list on and
     ESTIMATOR messages carry the baud in Hz (both within a few percent of the truth, each equal to its oracle on the same

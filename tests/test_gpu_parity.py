@@ -654,6 +654,33 @@ def test_conj_prev_and_gardner_frequency_space(ctx, sdo):
 # ------------------------------------------------------------------------------------------
 # gangs: heterogeneous 1-channel banks side by side -- bit exact against each bank's own oracle
 # ------------------------------------------------------------------------------------------
+def test_power_bank_matches_the_reference_loop(ctx, sdo):
+    """the "power" class against RMSInspector's own raw-mode loop (Kahan sum in binary64 of the binary32 powers, mean at
+    the window's end): windows span feeds of ragged sizes; N = 1 and N larger than a feed; set_integrate starts over"""
+    rng = np.random.default_rng(33)
+    x = ((rng.standard_normal(300000) + 1j * rng.standard_normal(300000)) * rng.uniform(0.01, 3.0)).astype(np.complex64)
+    for N in (1, 7, 1000, 4096, 50001, 400000):
+        bank, ref = engine.PowerBank(ctx, N), sdo.Power(N)
+        cuts = [0, 1, 4097, 4097, 70000, 70003, 200000, 300000]
+        got, want = [], []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            blk = x[a:b]
+            got.append(host(bank.feed(dev(blk) if b > a else torch.empty(0, dtype=torch.complex64, device="cuda"))))
+            want.append(ref.feed(blk))
+        got, want = np.concatenate(got), np.concatenate(want)
+        assert got.size == want.size == 300000 // N
+        if got.size:
+            assert np.all(got.imag == 0) and np.max(np.abs(got.real - want.real) / want.real) < 2e-7
+    bank, ref = engine.PowerBank(ctx, 1000), sdo.Power(1000)
+    bank.feed(dev(x[:1500]))
+    bank.set_integrate(250)                                                      # updateMaxSamples: the running window is dropped
+    ref = sdo.Power(250)
+    got, want = host(bank.feed(dev(x[1500:3000]))), ref.feed(x[1500:3000])
+    assert got.size == 6 and np.max(np.abs(got.real - want.real) / want.real) < 2e-7
+    with pytest.raises(Exception):
+        engine.PowerBank(ctx, 0)
+
+
 def test_capture_export_formats(ctx, tmp_path):
     """ExportSamplesTask's formats for a capture in HBM (more than one pinned chunk): raw / wav / mat carry the float32
     samples bit for bit (read back with numpy / scipy), "m" is the reference's text character for character"""
