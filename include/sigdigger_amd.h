@@ -251,6 +251,9 @@ SUAMD_API unsigned    suamd_spectsrc_count(void);
 SUAMD_API const char *suamd_spectsrc_name(unsigned id);
 SUAMD_API SUBOOL      suamd_spectsrc_preproc(suamd_ctx_t *ctx, unsigned id, const suamd_complex *d_x, SUSCOUNT len,
                                              SUFLOAT prev_re, SUFLOAT prev_im, suamd_complex *d_y, void *stream);
+/* the same with the sample before the block taken from device memory (NULL: zero) -- no host round trip between blocks */
+SUAMD_API SUBOOL      suamd_spectsrc_preproc_from(suamd_ctx_t *ctx, unsigned id, const suamd_complex *d_x, SUSCOUNT len,
+                                                  const suamd_complex *d_prev, suamd_complex *d_y, void *stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* section 8f #3: symbol decision and SNR analytics on the device (1 B/symbol to the host)  */
@@ -441,6 +444,10 @@ SUAMD_API void     suamd_baud_estimator_destroy(suamd_baud_estimator_t *e);
 SUAMD_API unsigned suamd_baud_estimator_size(const suamd_baud_estimator_t *e);
 SUAMD_API SUBOOL   suamd_baud_estimator_feed(suamd_baud_estimator_t *e, const suamd_complex *d_x, SUSCOUNT len, void *stream);
 SUAMD_API SUFLOAT  suamd_baud_estimator_get(const suamd_baud_estimator_t *e);
+/* the same with the estimate landing in the caller's own (pinned) host location when the stream gets there: for
+ * callers with several blocks in flight.  len must cover the analysis window. */
+SUAMD_API SUBOOL   suamd_baud_estimator_feed_to(suamd_baud_estimator_t *e, const suamd_complex *d_x, SUSCOUNT len,
+                                                SUFLOAT *h_value, void *stream);
 
 /* CarrierDetector::work, all states (Tasks/CarrierDetector.cpp:49-147): zero-pad to a power of two,
  * Blackman-Harris over len, FFT, |X|^2 arg-max outside the DC notch, circular centroid over

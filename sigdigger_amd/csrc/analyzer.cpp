@@ -337,15 +337,17 @@ struct Inspector {
   suamd_power_bank_t *power = nullptr;         // class "power"
   suamd_baud_estimator_t *est[2] = {nullptr, nullptr};   // "baud-fac", "baud-nonlinear" (estimator_list of the OPEN message)
   bool est_on[2] = {false, false}, est_fed[2] = {false, false};
+  SUFLOAT last_est[2] = {0, 0};                           // a block too short for the analysis window repeats the last estimate
   suamd_psd_t *spect_psd = nullptr;           // spectrum of the channel samples, one frame set per block
   unsigned spect_n = 0;
   suamd_complex *d_spre = nullptr;            // transformed samples
   float *d_spec = nullptr;
-  suamd_complex spect_prev = {0, 0};          // last channel sample of the previous block
+  bool spect_have_prev = false;               // the sample before the block: the other slot's last channel sample
+  int last_slot = 0; SUSCOUNT last_fir_m = 0;
   // all inspectors work on the analyzer's inspector stream, stage by stage (enqueue_inspectors); results
   // land in pinned memory and become messages after one synchronisation (collect_inspectors)
   hipStream_t stream = nullptr;
-  struct Pinned { uint32_t count; suamd_complex prev; float spec[8192]; } *pin = nullptr;   // D2H landing zone
+  struct Pinned { uint32_t count; float est[2]; float spec[8192]; } *pin = nullptr;   // D2H landing zone
   suamd_complex *h_out = nullptr;             // samples / symbols of the block, written by the device (mapped, cap long)
   SUSCOUNT pend_m = 0;                        // channel samples of the block in flight
   bool pend_samples = false, pend_spectrum = false, pend_symbols = false;
@@ -355,6 +357,35 @@ struct Inspector {
   suamd_complex *d_y = nullptr, *d_a = nullptr, *d_z = nullptr, *d_sym = nullptr, *d_prev = nullptr;
   uint32_t *d_count = nullptr;
   size_t cap = 0;
+  // Two blocks are in flight at a time (block k+1 is enqueued before block k's results are collected), so every
+  // per-block buffer and every "pending" note exists twice; the names above are the aliases of the slot in use.
+  struct Slot {
+    suamd_complex *d_y = nullptr, *d_a = nullptr, *d_z = nullptr, *d_sym = nullptr, *h_out = nullptr;
+    uint32_t *d_count = nullptr;
+    Pinned *pin = nullptr;
+    SUSCOUNT pend_m = 0;
+    bool pend_samples = false, pend_spectrum = false, pend_symbols = false, est_fed[2] = {false, false};
+    const suamd_complex *pend_src = nullptr;
+    unsigned pend_spec_n = 0;
+  } slot[2];
+  void use(int p)
+  {
+    Slot &s = slot[p];
+    d_y = s.d_y; d_a = s.d_a; d_z = s.d_z; d_sym = s.d_sym; h_out = s.h_out; d_count = s.d_count; pin = s.pin;
+  }
+  void stash(int p)
+  {
+    Slot &s = slot[p];
+    s.pend_m = pend_m; s.pend_samples = pend_samples; s.pend_spectrum = pend_spectrum; s.pend_symbols = pend_symbols;
+    s.pend_src = pend_src; s.pend_spec_n = pend_spec_n; s.est_fed[0] = est_fed[0]; s.est_fed[1] = est_fed[1];
+  }
+  void recall(int p)
+  {
+    use(p);
+    const Slot &s = slot[p];
+    pend_m = s.pend_m; pend_samples = s.pend_samples; pend_spectrum = s.pend_spectrum; pend_symbols = s.pend_symbols;
+    pend_src = s.pend_src; pend_spec_n = s.pend_spec_n; est_fed[0] = s.est_fed[0]; est_fed[1] = s.est_fed[1];
+  }
   void free_chain()
   {
     if (bank) suamd_chanbank_destroy(bank);
@@ -381,17 +412,25 @@ struct Inspector {
   {
     for (auto &e : est) { if (e) suamd_baud_estimator_destroy(e); e = nullptr; }
   }
+  void free_rows()
+  {
+    for (Slot &s : slot) {
+      for (void *p : {(void *)s.d_y, (void *)s.d_a, (void *)s.d_z, (void *)s.d_sym, (void *)s.d_count}) if (p) (void)hipFree(p);
+      if (s.h_out) (void)hipHostFree(s.h_out);
+      s.d_y = s.d_a = s.d_z = s.d_sym = s.h_out = nullptr; s.d_count = nullptr;
+    }
+    d_y = d_a = d_z = d_sym = h_out = nullptr; d_count = nullptr; cap = 0;
+  }
   void free_all()
   {
     free_spectrum();
     free_estimators();
-    if (pin) (void)hipHostFree(pin);
-    if (h_out) (void)hipHostFree(h_out);
-    pin = nullptr; h_out = nullptr;
     free_chain();
-    for (void *p : {(void *)d_y, (void *)d_a, (void *)d_z, (void *)d_sym, (void *)d_prev, (void *)d_count})
-      if (p) (void)hipFree(p);
-    d_y = d_a = d_z = d_sym = d_prev = nullptr; d_count = nullptr;
+    free_rows();
+    for (Slot &s : slot) { if (s.pin) (void)hipHostFree(s.pin); s.pin = nullptr; }
+    pin = nullptr;
+    if (d_prev) (void)hipFree(d_prev);
+    d_prev = nullptr;
     if (config) suscan_config_destroy(config);
     config = nullptr;
   }
@@ -455,6 +494,14 @@ struct suscan_analyzer {
   hipEvent_t ev_stage[3][NSUB] = {};
   hipStream_t istream[NISTREAMS] = {};
   hipEvent_t ev_input = nullptr;              // the block is in d_x
+  hipEvent_t ev_xfree = nullptr;              // ... and every kernel that reads it has run
+  bool xfree_set = false;
+  hipEvent_t ev_done[2][NISTREAMS] = {};      // the inspector work of the block in slot p is through stream k
+  hipEvent_t ev_psd[2] = {};                  // the PSD of the block in slot p is in h_psd[p]
+  float *h_psd[2] = {nullptr, nullptr};       // pinned landing zones of the PSD frames
+  hipEvent_t ev_h2d[2] = {};                  // the host half h has been copied out: it may take the next read
+  bool h2d_set[2] = {false, false};
+  bool pipelined = true;                      // two blocks in flight (SUAMD_ANALYZER_PIPELINE=0 or the trace knob: one)
   suamd_complex *h_x = nullptr, *d_x = nullptr;
   suamd_complex *h_flt = nullptr;              // a compact-format block expanded on the host, for the baseband filters
   float *d_dc = nullptr;                       // tracked DC level (suamd_source_fix)
@@ -504,23 +551,25 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
   if (!in.bank) { err = suamd_last_error(); return false; }
   const size_t need = a->block / in.D + 8;
   if (need > in.cap) {
-    for (void *p : {(void *)in.d_y, (void *)in.d_a, (void *)in.d_z, (void *)in.d_sym, (void *)in.d_prev, (void *)in.d_count})
-      if (p) (void)hipFree(p);
-    bool ok = hipMalloc((void **)&in.d_y, need * 8) == hipSuccess && hipMalloc((void **)&in.d_a, need * 8) == hipSuccess &&
-              hipMalloc((void **)&in.d_z, need * 8) == hipSuccess && hipMalloc((void **)&in.d_sym, need * 8) == hipSuccess &&
-              hipMalloc((void **)&in.d_prev, 8) == hipSuccess && hipMalloc((void **)&in.d_count, 4) == hipSuccess;
-    if (in.h_out) (void)hipHostFree(in.h_out);
-    in.h_out = nullptr;
-    ok = ok && hipHostMalloc((void **)&in.h_out, need * 8, hipHostMallocMapped) == hipSuccess;
+    in.free_rows();
+    bool ok = true;
+    for (Inspector::Slot &sl : in.slot)
+      ok = ok && hipMalloc((void **)&sl.d_y, need * 8) == hipSuccess && hipMalloc((void **)&sl.d_a, need * 8) == hipSuccess &&
+           hipMalloc((void **)&sl.d_z, need * 8) == hipSuccess && hipMalloc((void **)&sl.d_sym, need * 8) == hipSuccess &&
+           hipMalloc((void **)&sl.d_count, 4) == hipSuccess &&
+           hipHostMalloc((void **)&sl.h_out, need * 8, hipHostMallocMapped) == hipSuccess;
+    if (ok && !in.d_prev) ok = hipMalloc((void **)&in.d_prev, 8) == hipSuccess;
     if (!ok) { err = "device allocation failed"; return false; }
     in.cap = need;
   }
   if (!in.stream) in.stream = a->istream[0];
-  if (!in.pin && hipHostMalloc((void **)&in.pin, sizeof(Inspector::Pinned), hipHostMallocDefault) != hipSuccess) {
-    err = "pinned allocation failed"; return false;
-  }
+  for (Inspector::Slot &sl : in.slot)
+    if (!sl.pin && hipHostMalloc((void **)&sl.pin, sizeof(Inspector::Pinned), hipHostMallocDefault) != hipSuccess) {
+      err = "pinned allocation failed"; return false;
+    }
+  in.spect_have_prev = false;                            // a new chain starts its channel from scratch
   (void)hipMemsetAsync(in.d_prev, 0, 8, in.stream);
-  (void)hipMemsetAsync(in.d_count, 0, 4, in.stream);     // from here on cleared by every hand-off (suamd_rows_deliver)
+  for (Inspector::Slot &sl : in.slot) (void)hipMemsetAsync(sl.d_count, 0, 4, in.stream);   // from here on cleared by every hand-off (suamd_rows_deliver)
   in.first = true;
   in.quad = false;
   if (in.cls == "raw") return true;
@@ -616,8 +665,8 @@ void enqueue_spectrum(suscan_analyzer *a, Inspector &in, SUSCOUNT m)
     }
     in.spect_n = n;
   }
-  if (!suamd_spectsrc_preproc(a->ctx, in.spectsrc_id, in.d_y, m, in.spect_prev.re, in.spect_prev.im, in.d_spre, in.stream)) return;
-  (void)hipMemcpyAsync(&in.pin->prev, in.d_y + (m - 1), sizeof(suamd_complex), hipMemcpyDeviceToHost, in.stream);
+  const suamd_complex *d_before = in.spect_have_prev && in.last_fir_m ? in.slot[in.last_slot].d_y + (in.last_fir_m - 1) : nullptr;
+  if (!suamd_spectsrc_preproc_from(a->ctx, in.spectsrc_id, in.d_y, m, d_before, in.d_spre, in.stream)) return;
   const unsigned frames = (unsigned)(m / n);
   if (!suamd_psd_feed(in.spect_psd, in.d_spre, frames, n, frames, 1.0f / (float)n, SUAMD_PSD_LINEAR, in.d_spec, in.stream)) return;
   (void)hipMemcpyAsync(in.pin->spec, in.d_spec, n * sizeof(float), hipMemcpyDeviceToHost, in.stream);
@@ -633,7 +682,18 @@ void enqueue_spectrum(suscan_analyzer *a, Inspector &in, SUSCOUNT m)
 // gang works on sub-range j the level trackers are already on j+1 and the Gardner gang on j-1 (every stage
 // is invariant under splitting its input, which the parity tests pin).  Bit-identical to running every chain
 // on its own, whole block at once.
-void enqueue_inspectors(suscan_analyzer *a, size_t len)
+void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot);
+
+// Block k goes into slot k & 1 while block k-1 (the other slot) may still be on the device: every stream takes the
+// blocks in order, so the loop states carry over by themselves, and the two slots share no per-block buffer.
+void enqueue_inspectors(suscan_analyzer *a, size_t len, int slot)
+{
+  enqueue_inspectors_slot(a, len, slot);
+  for (auto &kv : a->inspectors) kv.second->stash(slot);
+  for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) (void)hipEventRecord(a->ev_done[slot][k], a->istream[k]);
+}
+
+void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
 {
   const int P = a->nsub;
   hipStream_t sA = a->istream[0], sC = a->istream[1], sK = a->istream[2];
@@ -641,7 +701,9 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
   std::vector<Inspector *> live;
   for (auto &kv : a->inspectors) {
     Inspector &in = *kv.second;
+    in.use(slot);
     in.pend_samples = in.pend_spectrum = in.pend_symbols = false;
+    in.est_fed[0] = in.est_fed[1] = false;
     in.stream = sA;
     if (in.dirty) {
       std::string err;
@@ -657,21 +719,23 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
     std::vector<suamd_chanbank_t *> fb; std::vector<suamd_complex *> fy; std::vector<SUSCOUNT> fm(live.size());
     for (Inspector *pi : live) { fb.push_back(pi->bank); fy.push_back(pi->d_y); }
     if (!suamd_chanbank_gang_feed(a->ctx, fb.data(), (unsigned)fb.size(), a->d_x, len, fy.data(), fm.data(), sA)) { fail("channeliser"); return; }
+    (void)hipEventRecord(a->ev_xfree, sA);                    // the wideband block may be overwritten from here on (the PSD is on the input stream itself)
+    a->xfree_set = true;
     if (a->trace) (void)hipEventRecord(a->ev_tfir, sA);
     for (size_t i = 0; i < live.size(); ++i) {
       Inspector &in = *live[i];
       in.pend_m = fm[i];
       in.pend_src = in.d_y;
       if (in.spectsrc_id) enqueue_spectrum(a, in, fm[i]);
+      in.spect_have_prev = true; in.last_slot = slot; in.last_fir_m = fm[i];   // for the next block's "sample before"
       for (int k = 0; k < 2; ++k) {                           // enabled estimators look at the channel samples too
-        in.est_fed[k] = false;
         if (!in.est_on[k]) continue;
         unsigned want = 512;
         while (want * 2 <= fm[i] && want < 8192) want *= 2;
         if (fm[i] < want) continue;                           // fewer than 512 channel samples per block: no estimate
         if (in.est[k] && suamd_baud_estimator_size(in.est[k]) != want) { suamd_baud_estimator_destroy(in.est[k]); in.est[k] = nullptr; }
         if (!in.est[k]) in.est[k] = suamd_baud_estimator_new(a->ctx, k == 0 ? SUAMD_BAUD_ESTIMATOR_FAC : SUAMD_BAUD_ESTIMATOR_NONLINEAR, want);
-        if (!in.est[k] || !suamd_baud_estimator_feed(in.est[k], in.d_y, fm[i], sA)) { fail("estimator"); continue; }
+        if (!in.est[k] || !suamd_baud_estimator_feed_to(in.est[k], in.d_y, fm[i], &in.pin->est[k], sA)) { fail("estimator"); continue; }
         in.est_fed[k] = true;
       }
     }
@@ -798,19 +862,21 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len)
   }
 }
 
-// after the PSD message went out: wait for the inspector stream once and turn the results into messages
-void collect_inspectors(suscan_analyzer *a)
+// after the PSD message of the block in `slot` went out: wait for that block's work (its events -- the streams may
+// already hold the next block) and turn the results into messages
+void collect_inspectors(suscan_analyzer *a, int slot)
 {
   bool any = false;
-  for (auto &kv : a->inspectors) any = any || kv.second->pend_samples || kv.second->pend_spectrum || kv.second->pend_symbols ||
-                                       kv.second->est_on[0] || kv.second->est_on[1];
+  for (auto &kv : a->inspectors) {
+    kv.second->recall(slot);
+    any = any || kv.second->pend_samples || kv.second->pend_spectrum || kv.second->pend_symbols || kv.second->est_on[0] || kv.second->est_on[1];
+  }
   if (!any) return;
-  for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) (void)hipStreamSynchronize(a->istream[k]);
+  for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) (void)hipEventSynchronize(a->ev_done[slot][k]);
   if (a->trace) a->t_chains_done = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a->t_block0).count();
   for (auto &kv : a->inspectors) {
     Inspector &in = *kv.second;
     if (in.pend_spectrum) {
-      in.spect_prev = in.pin->prev;
       auto *msg = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SPECTRUM, 0);
       msg->handle = in.handle;
       msg->inspector_id = in.inspector_id;
@@ -828,7 +894,8 @@ void collect_inspectors(suscan_analyzer *a)
       m->inspector_id = in.inspector_id;
       m->estimator_id = (uint32_t)k;
       m->enabled = SU_TRUE;
-      m->value = in.est[k] ? suamd_baud_estimator_get(in.est[k]) * (SUFLOAT)in.equiv_fs : 0.0f;   // Hz, what clock.baud takes
+      m->value = in.est_fed[k] ? in.pin->est[k] * (SUFLOAT)in.equiv_fs : in.last_est[k];   // Hz, what clock.baud takes
+      in.last_est[k] = m->value;
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
     }
     if (in.pend_symbols || in.pend_samples) emit_samples(a, in, in.pin->count);
@@ -954,7 +1021,7 @@ void handle_request(suscan_analyzer *a, Request &r)
     }
     case Request::SET_SPECTRUM: {
       const bool ok = r.value <= suamd_spectsrc_count();
-      if (ok) { it->second->spectsrc_id = (uint32_t)r.value; it->second->spect_prev = suamd_complex{0, 0}; }
+      if (ok) { it->second->spectsrc_id = (uint32_t)r.value; it->second->spect_have_prev = false; }
       auto *m = new_insp_msg(ok ? SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SPECTRUM : SUSCAN_ANALYZER_INSPECTOR_MSGKIND_INVALID_ARGUMENT, r.req_id);
       m->handle = r.handle;
       m->spectsrc_id = (uint32_t)r.value;
@@ -1015,6 +1082,14 @@ bool setup_psd(suscan_analyzer *a, std::string &err)
   if (frames > 4096) frames = 4096;
   a->navg = (unsigned)frames;
   const size_t block = (size_t)n * a->navg;
+  for (int k = 0; k < 2; ++k) {                              // the PSD landing zones follow the frame size
+    if (a->h_psd[k]) (void)hipHostFree(a->h_psd[k]);
+    a->h_psd[k] = nullptr;
+    if (hipHostMalloc((void **)&a->h_psd[k], n * sizeof(float), hipHostMallocDefault) != hipSuccess) { err = "pinned allocation failed"; return false; }
+  }
+  if (a->d_psd) (void)hipFree(a->d_psd);
+  a->d_psd = nullptr;
+  if (hipMalloc((void **)&a->d_psd, n * sizeof(float)) != hipSuccess) { err = "device allocation failed"; return false; }
   if (block != a->block) {
     if (a->h_x) (void)hipHostFree(a->h_x);
   if (a->h_flt) (void)hipHostFree(a->h_flt);
@@ -1022,12 +1097,11 @@ bool setup_psd(suscan_analyzer *a, std::string &err)
   a->h_flt = nullptr; a->d_dc = nullptr;
     if (a->d_x) (void)hipFree(a->d_x);
     if (a->d_raw) (void)hipFree(a->d_raw);
-    if (a->d_psd) (void)hipFree(a->d_psd);
-    a->h_x = nullptr; a->d_x = nullptr; a->d_raw = nullptr; a->d_psd = nullptr;
+    a->h_x = nullptr; a->d_x = nullptr; a->d_raw = nullptr;
+    a->h2d_set[0] = a->h2d_set[1] = false; a->xfree_set = false;
     if (hipHostMalloc((void **)&a->h_x, 2 * block * sizeof(suamd_complex), hipHostMallocDefault) != hipSuccess ||   // two halves
         hipMalloc((void **)&a->d_x, block * sizeof(suamd_complex)) != hipSuccess ||
-        hipMalloc(&a->d_raw, block * 4) != hipSuccess ||
-        hipMalloc((void **)&a->d_psd, n * sizeof(float)) != hipSuccess) {
+        hipMalloc(&a->d_raw, block * 4) != hipSuccess) {
       err = "allocation of the block buffers failed";
       return false;
     }
@@ -1057,6 +1131,17 @@ void worker_main(suscan_analyzer *a)
   for (int g = 0; ok && g < 3; ++g)
     for (int j = 0; ok && j < suscan_analyzer::NSUB; ++j)
       if (hipEventCreateWithFlags(&a->ev_stage[g][j], hipEventDisableTiming) != hipSuccess) { ok = false; err = "hipEventCreate failed"; }
+  if (ok) {
+    bool e = hipEventCreateWithFlags(&a->ev_xfree, hipEventDisableTiming) == hipSuccess;
+    for (int p = 0; p < 2; ++p) {
+      e = e && hipEventCreateWithFlags(&a->ev_psd[p], hipEventDisableTiming) == hipSuccess &&
+          hipEventCreateWithFlags(&a->ev_h2d[p], hipEventDisableTiming) == hipSuccess;
+      for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) e = e && hipEventCreateWithFlags(&a->ev_done[p][k], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!e) { ok = false; err = "hipEventCreate failed"; }
+    const char *pe = std::getenv("SUAMD_ANALYZER_PIPELINE");
+    a->pipelined = !a->trace && !(pe && std::atoi(pe) == 0);
+  }
   if (ok && a->trace) {
     (void)hipEventCreate(&a->ev_t0); (void)hipEventCreate(&a->ev_tfir); (void)hipEventCreate(&a->ev_tpre); (void)hipEventCreate(&a->ev_tdone);
     for (int g = 0; g < 3; ++g) for (int j = 0; j < suscan_analyzer::NSUB; ++j) (void)hipEventCreate(&a->ev_tstage[g][j]);
@@ -1086,8 +1171,27 @@ void worker_main(suscan_analyzer *a)
   bool have_next = false, looped_next = false;
   size_t got_next = 0;
   int cur = 0;
+  // Two blocks in flight: block k is enqueued (copy, PSD, every inspector stage) before block k-1's results are turned
+  // into messages, so the device never waits for the host between blocks.  `flight` is the enqueued, uncollected block.
+  struct InFlight { bool on = false; int slot = 0; suscan_analyzer_psd_msg *msg = nullptr; unsigned n = 0; } flight;
+  int slot = 0;
+  double tmark[8] = {};
+  auto finish = [&](InFlight &f) {                          // PSD message first, then the inspectors' messages, as ever
+    if (!f.on) return;
+    (void)hipEventSynchronize(a->ev_psd[f.slot]);
+    std::memcpy(f.msg->psd_data, a->h_psd[f.slot], f.n * sizeof(float));
+    gettimeofday(&f.msg->rt_time, nullptr);
+    push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_PSD, f.msg);
+    collect_inspectors(a, f.slot);
+    f.on = false; f.msg = nullptr;
+  };
   while (!a->halt) {
-    // ---- requests posted by the GUI thread ----
+    // ---- requests posted by the GUI thread (they touch what a block in flight is using: let it finish first) ----
+    {
+      bool pending;
+      { std::lock_guard<std::mutex> lk(a->req_m); pending = !a->requests.empty(); }
+      if (pending) finish(flight);
+    }
     for (;;) {
       Request r;
       {
@@ -1121,14 +1225,18 @@ void worker_main(suscan_analyzer *a)
     // ---- one block ----
     const auto tb0 = std::chrono::steady_clock::now();
     a->t_block0 = tb0;
-    double tmark[8] = {};
     auto tick = [&](int i) { if (a->trace) tmark[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(); };
     bool looped = looped_next;
     suamd_complex *h_cur = a->h_x + (size_t)cur * a->block;
-    if (!have_next) { looped = false; src.mark(); got_next = src.read(h_cur, a->block, &looped); }
+    if (!have_next) {
+      looped = false; src.mark();
+      if (a->h2d_set[cur]) (void)hipEventSynchronize(a->ev_h2d[cur]);
+      got_next = src.read(h_cur, a->block, &looped);
+    }
     have_next = false;
     const size_t got = got_next;
     if (got < a->block) {                                  // a partial last block is dropped, as a
+      finish(flight);
       push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_EOS, 0, "end of stream");   // whole PSD frame set is needed
       break;
     }
@@ -1139,26 +1247,30 @@ void worker_main(suscan_analyzer *a)
       filters = a->filters;
     }
     suamd_complex *h_flt = nullptr;                        // what the filters saw (and may have rewritten)
+    std::string fatal;
     if (!filters.empty()) {
       if (src.bytes_per_sample() == sizeof(suamd_complex)) h_flt = h_cur;
       else {                                               // compact formats are expanded on the host for them (same arithmetic as suamd_ingest_iq)
-        if (!a->h_flt && hipHostMalloc((void **)&a->h_flt, a->block * sizeof(suamd_complex), hipHostMallocDefault) != hipSuccess) {
-          push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, "pinned allocation failed");
-          break;
-        }
-        h_flt = a->h_flt;
-        const size_t nv = 2 * a->block;
-        float *o = reinterpret_cast<float *>(h_flt);
-        switch (src.raw_format) {
-          case SUAMD_FORMAT_RAW_UNSIGNED8: { const uint8_t *r = reinterpret_cast<const uint8_t *>(h_cur); for (size_t i = 0; i < nv; ++i) o[i] = (float)((int)r[i] - 128) * 0.0078125f; break; }
-          case SUAMD_FORMAT_RAW_SIGNED8:   { const int8_t *r = reinterpret_cast<const int8_t *>(h_cur); for (size_t i = 0; i < nv; ++i) o[i] = (float)r[i] * 0.0078125f; break; }
-          default:                         { const int16_t *r = reinterpret_cast<const int16_t *>(h_cur); for (size_t i = 0; i < nv; ++i) o[i] = (float)r[i] * 3.0517578125e-05f; break; }
+        if (!a->h_flt && hipHostMalloc((void **)&a->h_flt, a->block * sizeof(suamd_complex), hipHostMallocDefault) != hipSuccess) fatal = "pinned allocation failed";
+        else {
+          h_flt = a->h_flt;
+          const size_t nv = 2 * a->block;
+          float *o = reinterpret_cast<float *>(h_flt);
+          switch (src.raw_format) {
+            case SUAMD_FORMAT_RAW_UNSIGNED8: { const uint8_t *r = reinterpret_cast<const uint8_t *>(h_cur); for (size_t i = 0; i < nv; ++i) o[i] = (float)((int)r[i] - 128) * 0.0078125f; break; }
+            case SUAMD_FORMAT_RAW_SIGNED8:   { const int8_t *r = reinterpret_cast<const int8_t *>(h_cur); for (size_t i = 0; i < nv; ++i) o[i] = (float)r[i] * 0.0078125f; break; }
+            default:                         { const int16_t *r = reinterpret_cast<const int16_t *>(h_cur); for (size_t i = 0; i < nv; ++i) o[i] = (float)r[i] * 3.0517578125e-05f; break; }
+          }
         }
       }
-      bool ok = true;
-      for (const auto &f : filters) if (!f.func(f.priv, a, h_flt, a->block, consumed)) { ok = false; break; }
-      if (!ok) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, "a baseband filter failed"); break; }
+      for (const auto &f : filters) {
+        if (!fatal.empty()) break;
+        if (!f.func(f.priv, a, h_flt, a->block, consumed)) fatal = "a baseband filter failed";
+      }
     }
+    if (!fatal.empty()) { finish(flight); push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, fatal); break; }
+    // the previous block's channeliser must be done with d_x before this block lands in it (its PSD is on this stream)
+    if (a->xfree_set) (void)hipStreamWaitEvent(a->stream, a->ev_xfree, 0);
     if (h_flt) {
       (void)hipMemcpyAsync(a->d_x, h_flt, a->block * sizeof(suamd_complex), hipMemcpyHostToDevice, a->stream);
       if (h_flt == a->h_flt) (void)hipStreamSynchronize(a->stream);   // one expansion buffer: the copy must be out before the next block
@@ -1166,11 +1278,11 @@ void worker_main(suscan_analyzer *a)
       (void)hipMemcpyAsync(a->d_x, h_cur, a->block * sizeof(suamd_complex), hipMemcpyHostToDevice, a->stream);
     } else {                                               // 2-4 B/sample over PCIe, expanded on the GPU
       (void)hipMemcpyAsync(a->d_raw, h_cur, a->block * src.bytes_per_sample(), hipMemcpyHostToDevice, a->stream);
-      if (!suamd_ingest_iq(a->ctx, src.raw_format, a->d_raw, a->block, a->d_x, a->stream)) {
-        push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, suamd_last_error());
-        break;
-      }
+      if (!suamd_ingest_iq(a->ctx, src.raw_format, a->d_raw, a->block, a->d_x, a->stream)) fatal = suamd_last_error();
     }
+    (void)hipEventRecord(a->ev_h2d[cur], a->stream);
+    a->h2d_set[cur] = true;
+    if (!fatal.empty()) { finish(flight); push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, fatal); break; }
     {
       // source conditioning (Suscan/Analyzer.cpp:240-256): I/Q reversal, DC removal -- on the device, in place
       const bool rev = a->iq_reverse, dcr = a->dc_remove;
@@ -1186,38 +1298,44 @@ void worker_main(suscan_analyzer *a)
     if (a->trace) (void)hipEventRecord(a->ev_t0, a->stream);
     tick(0);
     // the inspectors' chains start as soon as the block is on the device, next to the PSD
-    enqueue_inspectors(a, a->block);
+    enqueue_inspectors(a, a->block, slot);
     tick(1);
     const unsigned n = (unsigned)a->params.detector_params.window_size;
     if (!suamd_psd_feed(a->psd, a->d_x, a->navg, n, a->navg, 1.0f / (float)n, SUAMD_PSD_LINEAR, a->d_psd, a->stream)) {
-      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, suamd_last_error());
+      fatal = suamd_last_error();
+      for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) (void)hipStreamSynchronize(a->istream[k]);
+      finish(flight);
+      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, fatal);
       break;
     }
+    (void)hipMemcpyAsync(a->h_psd[slot], a->d_psd, n * sizeof(float), hipMemcpyDeviceToHost, a->stream);
+    (void)hipEventRecord(a->ev_psd[slot], a->stream);
+    InFlight now_f;
     {
       auto *m = static_cast<suscan_analyzer_psd_msg *>(std::calloc(1, sizeof(suscan_analyzer_psd_msg)));
       m->psd_size = n;
       m->psd_data = static_cast<SUFLOAT *>(std::malloc(n * sizeof(SUFLOAT)));
-      (void)hipMemcpyAsync(m->psd_data, a->d_psd, n * sizeof(float), hipMemcpyDeviceToHost, a->stream);
-      // the next block comes off the source while the GPU is busy with this one
-      cur ^= 1;
-      looped_next = false;
-      src.mark();
-      got_next = src.read(a->h_x + (size_t)cur * a->block, a->block, &looped_next);
-      have_next = true;
-      tick(2);
-      (void)hipStreamSynchronize(a->stream);
-      tick(3);
       m->fc = (int64_t)a->source_cfg.freq;
       m->samp_rate = (SUFLOAT)a->source_cfg.samp_rate;
       m->measured_samp_rate = a->measured_rate;
       m->looped = looped ? SU_TRUE : SU_FALSE;
-      gettimeofday(&m->rt_time, nullptr);
       const double ts = (double)consumed / a->source_cfg.samp_rate;
       m->timestamp.tv_sec = (time_t)ts;
       m->timestamp.tv_usec = (suseconds_t)((ts - std::floor(ts)) * 1e6);
-      push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_PSD, m);
+      now_f.on = true; now_f.slot = slot; now_f.msg = m; now_f.n = n;
     }
-    collect_inspectors(a);
+    // the next block comes off the source while the GPU is busy
+    cur ^= 1;
+    looped_next = false;
+    src.mark();
+    if (a->h2d_set[cur]) (void)hipEventSynchronize(a->ev_h2d[cur]);       // that half's copy (two blocks ago) is long out
+    got_next = src.read(a->h_x + (size_t)cur * a->block, a->block, &looped_next);
+    have_next = true;
+    tick(2);
+    finish(flight);                                        // the block before this one: its messages go out now
+    flight = now_f;
+    if (!a->pipelined) finish(flight);
+    slot ^= 1;
     tick(5);
     if (a->trace && (consumed / a->block) % 8 == 7)
     {
@@ -1225,8 +1343,8 @@ void worker_main(suscan_analyzer *a)
       std::fprintf(stderr, "[analyzer] device: channeliser done %.2f  agc pre %.2f |", el(a->ev_tfir), el(a->ev_tpre));
       for (int j = 0; j < a->nsub; ++j) std::fprintf(stderr, " [%d] agc %.2f carrier %.2f clock %.2f", j, el(a->ev_tstage[0][j]), el(a->ev_tstage[1][j]), el(a->ev_tstage[2][j]));
       std::fprintf(stderr, " | handed off %.2f ms after the block was on the device\n", el(a->ev_tdone));
-      std::fprintf(stderr, "[analyzer] block: input issued %.2f  chains issued %.2f  next block read %.2f  psd done %.2f  chains done %.2f  delivered %.2f ms\n",
-                   tmark[0], tmark[1], tmark[2], tmark[3], a->t_chains_done, tmark[5]);
+      std::fprintf(stderr, "[analyzer] block (one in flight while tracing): input issued %.2f  chains issued %.2f  next block read %.2f  chains done %.2f  delivered %.2f ms\n",
+                   tmark[0], tmark[1], tmark[2], a->t_chains_done, tmark[5]);
     }
     consumed += a->block;
     a->position = consumed;
@@ -1247,9 +1365,21 @@ void worker_main(suscan_analyzer *a)
       a->measured_rate = prev == 0.f ? inst : prev + 0.2f * (inst - prev);
     }
   }
+  finish(flight);
+  (void)hipDeviceSynchronize();
   for (auto &kv : a->inspectors) kv.second->free_all();
   a->inspectors.clear();
   if (a->psd) suamd_psd_destroy(a->psd);
+  for (int p = 0; p < 2; ++p) {
+    if (a->h_psd[p]) (void)hipHostFree(a->h_psd[p]);
+    a->h_psd[p] = nullptr;
+    if (a->ev_psd[p]) (void)hipEventDestroy(a->ev_psd[p]);
+    if (a->ev_h2d[p]) (void)hipEventDestroy(a->ev_h2d[p]);
+    a->ev_psd[p] = a->ev_h2d[p] = nullptr;
+    for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) { if (a->ev_done[p][k]) (void)hipEventDestroy(a->ev_done[p][k]); a->ev_done[p][k] = nullptr; }
+  }
+  if (a->ev_xfree) (void)hipEventDestroy(a->ev_xfree);
+  a->ev_xfree = nullptr;
   if (a->h_x) (void)hipHostFree(a->h_x);
   if (a->h_flt) (void)hipHostFree(a->h_flt);
   if (a->d_dc) (void)hipFree(a->d_dc);

@@ -854,7 +854,19 @@ SUBOOL suamd_spectsrc_preproc(suamd_ctx_t *ctx, unsigned id, const suamd_complex
   if (len == 0) return SU_TRUE;
   if (!d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
   if (d_x == d_y && id != 1 && id != 4 && id < 7) { set_err("sources that look at the previous sample cannot run in place"); return SU_FALSE; }
-  HIP_TRY(sdk::spectsrc_preproc((int)id, d_x, (long long)len, prev_re, prev_im, d_y, as_stream(stream)), SU_FALSE);
+  HIP_TRY(sdk::spectsrc_preproc((int)id, d_x, (long long)len, prev_re, prev_im, nullptr, d_y, as_stream(stream)), SU_FALSE);
+  return SU_TRUE;
+}
+
+SUBOOL suamd_spectsrc_preproc_from(suamd_ctx_t *ctx, unsigned id, const suamd_complex *d_x, SUSCOUNT len, const suamd_complex *d_prev,
+                                   suamd_complex *d_y, void *stream)
+{
+  if (!ctx) { set_err("null context"); return SU_FALSE; }
+  if (id < 1 || id > suamd_spectsrc_count()) { set_err("unknown spectrum source %u", id); return SU_FALSE; }
+  if (len == 0) return SU_TRUE;
+  if (!d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  if (d_x == d_y && id != 1 && id != 4 && id < 7) { set_err("sources that look at the previous sample cannot run in place"); return SU_FALSE; }
+  HIP_TRY(sdk::spectsrc_preproc((int)id, d_x, (long long)len, 0.0f, 0.0f, d_prev, d_y, as_stream(stream)), SU_FALSE);
   return SU_TRUE;
 }
 
@@ -1667,8 +1679,8 @@ struct suamd_baud_estimator {
   CaptureFft w;                          // nonlinear: window, transform, arg-max + centroid scratch
   void *y = nullptr;                     // nonlinear: the transformed block
   suamd_fac *fac = nullptr;              // fac: the running autocorrelation
-  float *d_lag = nullptr;
-  struct Landing { double res[5]; float lag; int fed; } *pin = nullptr;   // host-mapped results
+  float *d_val = nullptr;                // fac: {lag, 1 / lag}; nonlinear: {centroid / n}
+  struct Landing { float value; int fed; } *pin = nullptr;   // host landing zone of the plain feed()
 };
 
 suamd_baud_estimator_t *suamd_baud_estimator_new(suamd_ctx_t *ctx, int kind, unsigned size)
@@ -1684,8 +1696,9 @@ suamd_baud_estimator_t *suamd_baud_estimator_new(suamd_ctx_t *ctx, int kind, uns
   if (ok && kind == SUAMD_BAUD_ESTIMATOR_NONLINEAR) ok = e->w.init(size) && hipMalloc(&e->y, sizeof(suamd_complex) * (size_t)size) == hipSuccess;
   if (ok && kind == SUAMD_BAUD_ESTIMATOR_FAC) {
     e->fac = suamd_fac_new(ctx, size, 0.25f);
-    ok = e->fac && hipMalloc((void **)&e->d_lag, sizeof(float)) == hipSuccess;
+    ok = e->fac != nullptr;
   }
+  ok = ok && hipMalloc((void **)&e->d_val, 2 * sizeof(float)) == hipSuccess;
   if (!ok) { if (g_err.empty()) set_err("device allocation failed"); suamd_baud_estimator_destroy(e); return nullptr; }
   return e;
 }
@@ -1695,7 +1708,7 @@ void suamd_baud_estimator_destroy(suamd_baud_estimator_t *e)
   if (!e) return;
   if (e->fac) suamd_fac_destroy(e->fac);
   if (e->y) (void)hipFree(e->y);
-  if (e->d_lag) (void)hipFree(e->d_lag);
+  if (e->d_val) (void)hipFree(e->d_val);
   if (e->pin) (void)hipHostFree(e->pin);
   delete e;
 }
@@ -1706,6 +1719,15 @@ SUBOOL suamd_baud_estimator_feed(suamd_baud_estimator_t *e, const suamd_complex 
 {
   if (!e) { set_err("null argument"); return SU_FALSE; }
   if (len < e->n) return SU_TRUE;                            // not a whole analysis window: the estimate stands
+  if (!suamd_baud_estimator_feed_to(e, d_x, len, &e->pin->value, stream)) return SU_FALSE;
+  e->pin->fed = 1;
+  return SU_TRUE;
+}
+
+SUBOOL suamd_baud_estimator_feed_to(suamd_baud_estimator_t *e, const suamd_complex *d_x, SUSCOUNT len, SUFLOAT *h_value, void *stream)
+{
+  if (!e || !h_value) { set_err("null argument"); return SU_FALSE; }
+  if (len < e->n) { set_err("block shorter than the analysis window (%llu < %u)", (unsigned long long)len, e->n); return SU_FALSE; }
   if (!d_x) { set_err("null argument"); return SU_FALSE; }
   hipStream_t st = as_stream(stream);
   const long long n = e->n;
@@ -1715,22 +1737,19 @@ SUBOOL suamd_baud_estimator_feed(suamd_baud_estimator_t *e, const suamd_complex 
     HIP_TRY(sdk::fft_forward(e->w.a, e->w.b, e->w.log2n, &e->w.res, st), SU_FALSE);
     // the lowest strong line outside the DC notch (1 % of the band), power centroid over 9 bins
     const int skip = std::max(4, (int)(0.01 * (double)n));
-    HIP_TRY(sdk::baud_line(e->w.res, (int)n, skip, e->w.d_res, st), SU_FALSE);
-    HIP_TRY(hipMemcpyAsync(e->pin->res, e->w.d_res, sizeof e->pin->res, hipMemcpyDeviceToHost, st), SU_FALSE);
+    HIP_TRY(sdk::baud_line(e->w.res, (int)n, skip, e->w.d_res, e->d_val, st), SU_FALSE);
+    HIP_TRY(hipMemcpyAsync(h_value, e->d_val, sizeof(float), hipMemcpyDeviceToHost, st), SU_FALSE);
   } else {
     if (!suamd_fac_feed(e->fac, d_x, 1, 0, (SUSDIFF)(n / 2), st)) return SU_FALSE;
-    HIP_TRY(sdk::fac_first_valley(suamd_fac_array(e->fac), (int)(n / 2), e->d_lag, st), SU_FALSE);
-    HIP_TRY(hipMemcpyAsync(&e->pin->lag, e->d_lag, sizeof(float), hipMemcpyDeviceToHost, st), SU_FALSE);
+    HIP_TRY(sdk::fac_first_valley(suamd_fac_array(e->fac), (int)(n / 2), e->d_val, st), SU_FALSE);
+    HIP_TRY(hipMemcpyAsync(h_value, e->d_val + 1, sizeof(float), hipMemcpyDeviceToHost, st), SU_FALSE);
   }
-  e->pin->fed = 1;
   return SU_TRUE;
 }
 
 SUFLOAT suamd_baud_estimator_get(const suamd_baud_estimator_t *e)
 {
-  if (!e || !e->pin->fed) return 0.0f;
-  if (e->kind == SUAMD_BAUD_ESTIMATOR_NONLINEAR) return (float)(e->pin->res[0] / (double)e->n);
-  return e->pin->lag > 0.0f ? 1.0f / e->pin->lag : 0.0f;
+  return e && e->pin->fed ? e->pin->value : 0.0f;
 }
 
 SUBOOL suamd_carrier_detect(suamd_ctx_t *ctx, const suamd_complex *d_data, SUSCOUNT len, SUFLOAT avgRelBw,

@@ -180,7 +180,7 @@ hipError_t decide(const void *x, long long len, int mode, int intervals, float v
 hipError_t symbol_histogram(const void *x, long long len, int mode, float vmin, float d, int nbins, unsigned *hist, hipStream_t st);
 // state: {sigma, delta, sqerr}; length <= 4096
 hipError_t snr_feed(const unsigned *history, int length, int intervals, float alpha, float *state, float *model, hipStream_t st);
-hipError_t spectsrc_preproc(int kind, const void *x, long long len, float prev_re, float prev_im, void *y, hipStream_t st);
+hipError_t spectsrc_preproc(int kind, const void *x, long long len, float prev_re, float prev_im, const void *prev_dev, void *y, hipStream_t st);
 // hist / hist_next: [ntaps-1][nchan] complex (time-major), ping-pong
 hipError_t rows_fir(const void *x, View xv, void *y, View yv, int nchan, long long len, const float *h, int ntaps,
                     const void *hist, void *hist_next, hipStream_t st);
@@ -196,13 +196,13 @@ hipError_t ingest_iq(int format, const void *raw, long long nsamp, void *out, hi
 hipError_t power_integrate(const void *x, long long len, long long N, long long cnt, const double *acc_in, double *acc_out,
                            void *out, hipStream_t st);
 // baud estimators (SPEC.md section M): y[n] = (|x[n] - x[n-1]|^2, 0), y[0] = 0  -- its spectrum has a line at the baud;
-// first valley of a fast autocorrelation (fac: n_half floats) below a quarter of fac[0] -> out[0] = lag (0: none)
+// first valley of a fast autocorrelation (fac: n_half floats) below a quarter of fac[0] -> out[0] = lag (0: none), out[1] = 1 / lag
 hipError_t baud_nl_transform(const void *x, long long n, void *y, hipStream_t st);
 hipError_t fac_first_valley(const float *fac, int n_half, float *out, hipStream_t st);
 // the baud line in the transform X (n points) of the transformed block: the LOWEST local maximum of |X|^2 in [skip, n/2)
 // that reaches half of the strongest one (a comb of harmonics has no strongest tooth worth trusting), then the power
-// centroid over +-4 bins.  res[0] = centroid bin (0: none)
-hipError_t baud_line(const void *X, int n, int skip, double *res, hipStream_t st);
+// centroid over +-4 bins.  res[0] = centroid bin (0: none), value[0] = centroid / n
+hipError_t baud_line(const void *X, int n, int skip, double *res, float *value, hipStream_t st);
 // source conditioning in front of the path: I/Q swap, then removal of a tracked DC level (dc: device float[2],
 // or nullptr).  The level follows the block means: dc = first ? mean : dc + alpha (mean - dc), and the block is
 // corrected with the updated level.  partial: device scratch of 2 * 256 floats.

@@ -68,9 +68,11 @@ __global__ void rows_xlate_kernel(const float2 *__restrict__ x, sdk::View xv, fl
 // inspector spectrum sources (section 8f #2): the per-sample transform in front of the inspector PSD
 __device__ __forceinline__ c32 csq(c32 a) { return c32{sd::fma_(-a.im, a.im, a.re * a.re), sd::fma_(a.im, a.re, a.re * a.im)}; }
 
-__global__ void spectsrc_kernel(int kind, const float2 *__restrict__ x, long long len, float2 prev0, float2 *__restrict__ y)
+__global__ void spectsrc_kernel(int kind, const float2 *__restrict__ x, long long len, float2 prev0, const float2 *__restrict__ prev_dev,
+                                float2 *__restrict__ y)
 {
   __builtin_amdgcn_s_setprio(3);
+  if (prev_dev) prev0 = *prev_dev;                           // the sample before the block, still on the device
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
     const float2 vv = x[i], pp = i > 0 ? x[i - 1] : prev0;
     const c32 v = {vv.x, vv.y}, prev = {pp.x, pp.y};
@@ -374,7 +376,8 @@ __global__ void baud_nl_kernel(const float2 *__restrict__ x, long long n, float2
   }
 }
 
-__global__ __launch_bounds__(1024) void baud_line_kernel(const float2 *__restrict__ X, int n, int skip, double *__restrict__ res)
+__global__ __launch_bounds__(1024) void baud_line_kernel(const float2 *__restrict__ X, int n, int skip, double *__restrict__ res,
+                                                         float *__restrict__ value)
 {
   __shared__ float smax[1024];
   __shared__ int sidx[1024];
@@ -413,6 +416,7 @@ __global__ __launch_bounds__(1024) void baud_line_kernel(const float2 *__restric
       c = den > 0.0 ? num / den : 0.0;
     }
     res[0] = c;
+    value[0] = (float)(c / (double)n);                       // normalised baud
   }
 }
 
@@ -428,6 +432,7 @@ __global__ void fac_valley_kernel(const float *__restrict__ R, int H, float *__r
     if (c < thr && c <= s(l + 1)) { lag = (float)l; break; }   // (a parabola through a V-shaped minimum is biased: integer lag)
   }
   out[0] = lag;
+  out[1] = lag > 0.0f ? 1.0f / lag : 0.0f;                   // normalised baud
 }
 
 // one workgroup per row: the host-mapped destination is written in 64 B lane pairs, front to back
@@ -498,11 +503,11 @@ hipError_t snr_feed(const unsigned *history, int length, int intervals, float al
   return hipGetLastError();
 }
 
-hipError_t spectsrc_preproc(int kind, const void *x, long long len, float prev_re, float prev_im, void *y, hipStream_t st)
+hipError_t spectsrc_preproc(int kind, const void *x, long long len, float prev_re, float prev_im, const void *prev_dev, void *y, hipStream_t st)
 {
   if (len <= 0) return hipSuccess;
   hipLaunchKernelGGL(spectsrc_kernel, dim3(grid_for(len, 256)), dim3(256), 0, st, kind, reinterpret_cast<const float2 *>(x), len,
-                     float2{prev_re, prev_im}, reinterpret_cast<float2 *>(y));
+                     float2{prev_re, prev_im}, reinterpret_cast<const float2 *>(prev_dev), reinterpret_cast<float2 *>(y));
   return hipGetLastError();
 }
 
@@ -551,10 +556,10 @@ hipError_t baud_nl_transform(const void *x, long long n, void *y, hipStream_t st
   return hipGetLastError();
 }
 
-hipError_t baud_line(const void *X, int n, int skip, double *res, hipStream_t st)
+hipError_t baud_line(const void *X, int n, int skip, double *res, float *value, hipStream_t st)
 {
   if (n < 64 || skip < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(baud_line_kernel, dim3(1), dim3(1024), 0, st, static_cast<const float2 *>(X), n, skip, res);
+  hipLaunchKernelGGL(baud_line_kernel, dim3(1), dim3(1024), 0, st, static_cast<const float2 *>(X), n, skip, res, value);
   return hipGetLastError();
 }
 

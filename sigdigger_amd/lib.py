@@ -91,6 +91,8 @@ PROTOTYPES = {
     "suamd_baud_estimator_size": (UINT, [VP]),
     "suamd_baud_estimator_feed": (INT, [VP, VP, U64, VP]),
     "suamd_baud_estimator_get": (C.c_float, [VP]),
+    "suamd_baud_estimator_feed_to": (INT, [VP, VP, U64, VP, VP]),
+    "suamd_spectsrc_preproc_from": (INT, [VP, UINT, VP, U64, VP, VP, VP]),
     "suamd_power_bank_new": (VP, [VP, U64]),
     "suamd_power_bank_destroy": (None, [VP]),
     "suamd_power_bank_set_integrate": (INT, [VP, U64, VP]),
