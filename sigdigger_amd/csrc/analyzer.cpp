@@ -486,7 +486,7 @@ struct suscan_analyzer {
   hipStream_t stream = nullptr;
   static constexpr int NISTREAMS = 3;          // gain control / carrier control / clock recovery
   static constexpr int NSUB = 16;             // at most this many sub-ranges of a block pipelined through those stages
-  int nsub = 6;
+  int nsub = 4;
   bool trace = false;                         // SUAMD_ANALYZER_TRACE: per-block host timeline on stderr
   double t_chains_done = 0;
   hipEvent_t ev_t0 = nullptr, ev_tfir = nullptr, ev_tpre = nullptr, ev_tdone = nullptr, ev_tstage[3][NSUB] = {};   // timed, trace only
