@@ -1111,6 +1111,51 @@ bool setup_psd(suscan_analyzer *a, std::string &err)
   return true;
 }
 
+// The next block comes off the source on a helper thread while the worker issues the current one: reading 16 MB out
+// of the page cache takes longer (1.6 ms) than everything else the worker does for a block.  One read at a time; the
+// worker touches the source itself (mark, rewind, seek) only while no read is pending.
+struct AsyncRead {
+  Source &src;
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  void *dst = nullptr; size_t want = 0, got = 0; bool looped = false, pending = false, quit = false;
+  explicit AsyncRead(Source &s) : src(s), th([this] { run(); }) {}
+  ~AsyncRead()
+  {
+    { std::lock_guard<std::mutex> lk(m); quit = true; }
+    cv.notify_all();
+    th.join();
+  }
+  void run()
+  {
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv.wait(lk, [this] { return pending || quit; });
+      if (quit) return;
+      void *d = dst; const size_t w = want;
+      lk.unlock();
+      bool lp = false;
+      const size_t g = src.read(d, w, &lp);
+      lk.lock();
+      got = g; looped = lp; pending = false;
+      cv.notify_all();
+    }
+  }
+  void start(void *d, size_t w)
+  {
+    { std::lock_guard<std::mutex> lk(m); dst = d; want = w; pending = true; }
+    cv.notify_all();
+  }
+  size_t wait(bool *lp)
+  {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [this] { return !pending; });
+    *lp = looped;
+    return got;
+  }
+};
+
 void worker_main(suscan_analyzer *a)
 {
   std::string err;
@@ -1164,6 +1209,7 @@ void worker_main(suscan_analyzer *a)
     *si = a->info;
     push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INFO, si);
   }
+  AsyncRead reader(src);
   auto t_prev = std::chrono::steady_clock::now();
   const auto t_start = t_prev;
   uint64_t consumed = 0;
@@ -1240,6 +1286,10 @@ void worker_main(suscan_analyzer *a)
       push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_EOS, 0, "end of stream");   // whole PSD frame set is needed
       break;
     }
+    // the block after this one starts coming off the source now, on the helper thread
+    src.mark();
+    if (a->h2d_set[cur ^ 1]) (void)hipEventSynchronize(a->ev_h2d[cur ^ 1]);   // that half's copy (the previous block) is out
+    reader.start(a->h_x + (size_t)(cur ^ 1) * a->block, a->block);
     // ---- baseband filters: on this thread, on SUCOMPLEX samples, before anything else sees the block ----
     std::vector<suscan_analyzer::Filter> filters;
     {
@@ -1324,17 +1374,14 @@ void worker_main(suscan_analyzer *a)
       m->timestamp.tv_usec = (suseconds_t)((ts - std::floor(ts)) * 1e6);
       now_f.on = true; now_f.slot = slot; now_f.msg = m; now_f.n = n;
     }
-    // the next block comes off the source while the GPU is busy
-    cur ^= 1;
-    looped_next = false;
-    src.mark();
-    if (a->h2d_set[cur]) (void)hipEventSynchronize(a->ev_h2d[cur]);       // that half's copy (two blocks ago) is long out
-    got_next = src.read(a->h_x + (size_t)cur * a->block, a->block, &looped_next);
-    have_next = true;
-    tick(2);
     finish(flight);                                        // the block before this one: its messages go out now
     flight = now_f;
     if (!a->pipelined) finish(flight);
+    cur ^= 1;
+    looped_next = false;
+    got_next = reader.wait(&looped_next);                  // the next block is in the other half by now
+    have_next = true;
+    tick(2);
     slot ^= 1;
     tick(5);
     if (a->trace && (consumed / a->block) % 8 == 7)
