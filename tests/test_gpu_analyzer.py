@@ -779,6 +779,100 @@ def test_seek_estimators_and_tle(tmp_path, sdo):
     Lb.suscan_mq_finalize(C.byref(mq))
 
 
+def test_requests_while_two_blocks_are_in_flight(tmp_path, sdo):
+    """a looping source at full speed while the GUI thread opens, reconfigures, retunes and closes inspectors: requests
+    drain the two-block pipeline before they touch anything, so every reply arrives, nothing crashes or hangs, and an
+    inspector that was left alone throughout still delivers exactly the oracle's symbols"""
+    import time
+    nloop = 6
+    baud, bw = 15625.0, 30e3
+    fcs = [-200e3, 100e3, 260e3]
+    x = synth.psk_carriers(L * nloop, [2 * f / FS for f in fcs], sps=int(FS / baud), order=4, seed=13, snr_db=25)
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    Lb, mq, an = _start(path, L, loop=True)
+    Lb.suscan_analyzer_set_throttle_async(an, 0, 0)
+
+    def chan(fc):
+        return suscan.Channel(fc=float(fc), f_lo=float(fc - bw / 2), f_hi=float(fc + bw / 2), bw=bw, ft=433.92e6)
+
+    assert Lb.suscan_analyzer_open_ex_async(an, b"psk", C.byref(chan(fcs[0])), 1, -1, 1)        # the quiet one
+    st = {"psd": 0, "quiet": None, "quiet_cfg_at": None, "quiet_syms": [], "opened": [], "closed": 0, "cfgs": 0, "replies": 0,
+          "looped_at": None, "next_req": 100, "live": []}
+
+    def configure(handle, req, order=2):
+        cfg_desc = Lb.suscan_inspector_config_desc(b"psk")
+        cfg = Lb.suscan_config_new(cfg_desc)
+        Lb.suscan_config_set_integer(cfg, b"afc.costas-order", order)
+        Lb.suscan_config_set_float(cfg, b"afc.loop-bw", 40.0)
+        Lb.suscan_config_set_integer(cfg, b"clock.type", 1)
+        Lb.suscan_config_set_float(cfg, b"clock.baud", baud)
+        assert Lb.suscan_analyzer_set_inspector_config_async(an, handle, cfg, req)
+        Lb.suscan_config_destroy(cfg)
+
+    def on_msg(t, ptr):
+        if t == suscan.MSG_PSD:
+            m = C.cast(ptr, C.POINTER(suscan.PSDMsg)).contents
+            st["psd"] += 1
+            if m.looped and st["looped_at"] is None:
+                st["looped_at"] = st["psd"]
+            k = st["psd"]
+            if k >= 60:
+                Lb.suscan_analyzer_req_halt(an)
+            elif k % 3 == 0:                                   # churn: open one, poke the live ones, close the oldest
+                st["next_req"] += 1
+                assert Lb.suscan_analyzer_open_ex_async(an, b"psk" if k % 2 else b"fsk", C.byref(chan(fcs[1 + k % 2])), 1, -1, st["next_req"])
+                for h in st["live"][-2:]:
+                    assert Lb.suscan_analyzer_set_inspector_freq_overridable(an, h, fcs[1] + 1e3 * (k % 7))
+                    assert Lb.suscan_analyzer_inspector_set_spectrum_async(an, h, 1 + k % 5, 0)
+                if len(st["live"]) > 3:
+                    assert Lb.suscan_analyzer_close_async(an, st["live"].pop(0), 7)
+        elif t == suscan.MSG_INSPECTOR:
+            m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
+            st["replies"] += 1
+            if m.kind == suscan.KIND_OPEN:
+                if m.req_id == 1:
+                    st["quiet"] = m.handle
+                    assert Lb.suscan_analyzer_set_inspector_id_async(an, m.handle, 4242, 2)
+                    configure(m.handle, 3)
+                else:
+                    st["opened"].append(m.handle)
+                    st["live"].append(m.handle)
+                    configure(m.handle, 50, order=1 + m.handle % 3)
+            elif m.kind == suscan.KIND_SET_CONFIG:
+                st["cfgs"] += 1
+                if m.req_id == 3:
+                    st["quiet_cfg_at"] = st["psd"]
+            elif m.kind == suscan.KIND_CLOSE:
+                st["closed"] += 1
+        elif t == suscan.MSG_SAMPLES:
+            m = C.cast(ptr, C.POINTER(suscan.SampleBatchMsg)).contents
+            v = np.ctypeslib.as_array(m.samples, shape=(m.sample_count * 2,))
+            assert np.all(np.isfinite(v))
+            if m.inspector_id == 4242 and st["quiet_cfg_at"] is not None:
+                st["quiet_syms"].append(v.copy().view(np.complex64))
+
+    t0 = time.time()
+    seen = _pump(Lb, an, on_msg, limit=200000)
+    assert seen[-1] == suscan.MSG_HALT and time.time() - t0 < 60
+    assert st["psd"] >= 60 and len(st["opened"]) >= 15 and st["closed"] >= 10 and st["cfgs"] >= 15
+    # the quiet inspector: its symbols up to the first loop of the source are the oracle chain's
+    b0 = st["quiet_cfg_at"]
+    assert b0 is not None and b0 < nloop - 2
+    D, efs = 16, FS / 16
+    sps = efs / baud
+    dp = sdo.fnor_to_dphase(-2 * fcs[0] / FS)
+    y = sdo.chan_feed(np.zeros(254, np.complex64), x[b0 * L:], 0, sdo.chan_modulate_taps(sdo.lpf_design(255, bw / FS), dp), D, 0, dp)
+    a_ = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(sps)), y)
+    z = sdo.costas_feed_bulk(sdo.costas_new(2, 0.0, min(2.0 / sps, 0.95), 3, 2 * 40.0 / efs), a_)
+    ref = sdo.clock_feed_bulk(sdo.clock_new(0.2, baud / efs), z)
+    got = np.concatenate(st["quiet_syms"])
+    assert len(got) > len(ref) > 1000                          # the stream went on past the first loop
+    assert np.array_equal(got[:len(ref)].view(np.uint32), ref.view(np.uint32))
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+
+
 def test_halt_wakes_the_reader_and_bad_source_reports_failure(tmp_path):
     x = synth.tone_noise(L * 2, seed=1)
     path = tmp_path / "iq.raw"
