@@ -1222,13 +1222,18 @@ void worker_main(suscan_analyzer *a)
   struct InFlight { bool on = false; int slot = 0; suscan_analyzer_psd_msg *msg = nullptr; unsigned n = 0; } flight;
   int slot = 0;
   double tmark[8] = {};
+  static const bool dbg = std::getenv("SUAMD_ANALYZER_DEBUG") != nullptr;
+#define DBG(...) do { if (dbg) { std::fprintf(stderr, "[worker] " __VA_ARGS__); std::fputc('\n', stderr); std::fflush(stderr); } } while (0)
   auto finish = [&](InFlight &f) {                          // PSD message first, then the inspectors' messages, as ever
     if (!f.on) return;
+    DBG("finish slot %d: wait psd", f.slot);
     (void)hipEventSynchronize(a->ev_psd[f.slot]);
+    DBG("finish slot %d: psd ok, collect", f.slot);
     std::memcpy(f.msg->psd_data, a->h_psd[f.slot], f.n * sizeof(float));
     gettimeofday(&f.msg->rt_time, nullptr);
     push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_PSD, f.msg);
     collect_inspectors(a, f.slot);
+    DBG("finish slot %d: done", f.slot);
     f.on = false; f.msg = nullptr;
   };
   while (!a->halt) {
@@ -1288,8 +1293,10 @@ void worker_main(suscan_analyzer *a)
     }
     // the block after this one starts coming off the source now, on the helper thread
     src.mark();
+    DBG("block at %llu: wait h2d of the other half", (unsigned long long)consumed);
     if (a->h2d_set[cur ^ 1]) (void)hipEventSynchronize(a->ev_h2d[cur ^ 1]);   // that half's copy (the previous block) is out
     reader.start(a->h_x + (size_t)(cur ^ 1) * a->block, a->block);
+    DBG("read-ahead started");
     // ---- baseband filters: on this thread, on SUCOMPLEX samples, before anything else sees the block ----
     std::vector<suscan_analyzer::Filter> filters;
     {
@@ -1348,7 +1355,9 @@ void worker_main(suscan_analyzer *a)
     if (a->trace) (void)hipEventRecord(a->ev_t0, a->stream);
     tick(0);
     // the inspectors' chains start as soon as the block is on the device, next to the PSD
+    DBG("enqueue slot %d", slot);
     enqueue_inspectors(a, a->block, slot);
+    DBG("enqueued");
     tick(1);
     const unsigned n = (unsigned)a->params.detector_params.window_size;
     if (!suamd_psd_feed(a->psd, a->d_x, a->navg, n, a->navg, 1.0f / (float)n, SUAMD_PSD_LINEAR, a->d_psd, a->stream)) {
@@ -1379,7 +1388,9 @@ void worker_main(suscan_analyzer *a)
     if (!a->pipelined) finish(flight);
     cur ^= 1;
     looped_next = false;
+    DBG("wait for the read-ahead");
     got_next = reader.wait(&looped_next);                  // the next block is in the other half by now
+    DBG("read-ahead got %zu", got_next);
     have_next = true;
     tick(2);
     slot ^= 1;

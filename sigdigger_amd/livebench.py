@@ -42,8 +42,11 @@ def live_rate(n_inspectors=64, nblocks=40, fs=50_000_000, nfft=8192, block=1 << 
         st = {"psd": 0, "sym": 0, "t0": None, "cfg": 0, "result": None}
         deadline = time.time() + timeout_s
         while True:
-            t = C.c_uint32(0)
-            ptr = Lb.suscan_analyzer_read(an, C.byref(t))
+            try:                                                  # a deadline on every read: a benchmark must not hang
+                tv, ptr = suscan.read_message(Lb, mq, min(timeout_s, 30.0))
+            except suscan.AnalyzerStalled as e:
+                return {"error": str(e)}                          # the analyzer is left alone (destroying it would join its worker)
+            t = C.c_uint32(tv)
             if t.value == suscan.MSG_HALT:
                 break
             if t.value == suscan.MSG_INSPECTOR:

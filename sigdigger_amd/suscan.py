@@ -152,6 +152,25 @@ PROTOTYPES = {
 _bound = None
 
 
+class AnalyzerStalled(RuntimeError):
+    pass
+
+
+def read_message(lib, mq, timeout_s=60.0):
+    """suscan_analyzer_read with a deadline (Analyzer::read blocks for ever; tests and benchmarks must not): polls the
+    analyzer's queue and raises AnalyzerStalled if nothing arrives in time.  Returns (type, pointer)."""
+    import time
+    t, ptr = C.c_uint32(0), C.c_void_p()
+    deadline = time.time() + timeout_s
+    pause = 0.0
+    while not lib.suscan_mq_poll(C.byref(mq), C.byref(t), C.byref(ptr)):
+        if time.time() > deadline:
+            raise AnalyzerStalled(f"no message from the analyzer for {timeout_s} s")
+        time.sleep(pause)
+        pause = min(0.002, pause + 0.0001)
+    return t.value, ptr.value
+
+
 def load():
     global _bound
     if _bound is None:

@@ -33,21 +33,26 @@ def _start(path, L_, loop=False, params=None, fmt=1, fs=FS):
     p.psd_update_int = L_ / FS
     an = Lb.suscan_analyzer_new(C.byref(p), cfg, C.byref(mq))
     assert an
+    _MQ_OF[an] = mq
     Lb.suscan_source_config_destroy(cfg)          # the analyzer keeps its own copy
     return Lb, mq, an
 
 
+_MQ_OF = {}
+
+
 def _pump(Lb, an, on_msg, limit=10000):
-    """AsyncThread::run: read until HALT / EOS; every message disposed exactly once."""
+    """AsyncThread::run: read until HALT / EOS; every message disposed exactly once.  (Analyzer::read blocks for ever;
+    here the queue is polled with a deadline so that a stalled worker fails the test instead of hanging the run.)"""
     seen = []
+    mq = _MQ_OF[an]
     for _ in range(limit):
-        t = C.c_uint32(0)
-        ptr = Lb.suscan_analyzer_read(an, C.byref(t))
-        seen.append(t.value)
-        if t.value == suscan.MSG_HALT:
+        t, ptr = suscan.read_message(Lb, mq, 60.0)
+        seen.append(t)
+        if t == suscan.MSG_HALT:
             break
-        on_msg(t.value, ptr)
-        Lb.suscan_analyzer_dispose_message(t.value, ptr)
+        on_msg(t, ptr)
+        Lb.suscan_analyzer_dispose_message(t, ptr)
     return seen
 
 
@@ -856,19 +861,22 @@ def test_requests_while_two_blocks_are_in_flight(tmp_path, sdo):
     seen = _pump(Lb, an, on_msg, limit=200000)
     assert seen[-1] == suscan.MSG_HALT and time.time() - t0 < 60
     assert st["psd"] >= 60 and len(st["opened"]) >= 15 and st["closed"] >= 10 and st["cfgs"] >= 15
-    # the quiet inspector: its symbols up to the first loop of the source are the oracle chain's
+    # the quiet inspector: its symbols are the oracle chain's on the looping stream from the block its configuration
+    # landed at (at full speed that may be several loops in: the stream is periodic, the chain runs through the seams)
     b0 = st["quiet_cfg_at"]
-    assert b0 is not None and b0 < nloop - 2
+    assert b0 is not None and b0 < 40
     D, efs = 16, FS / 16
     sps = efs / baud
     dp = sdo.fnor_to_dphase(-2 * fcs[0] / FS)
-    y = sdo.chan_feed(np.zeros(254, np.complex64), x[b0 * L:], 0, sdo.chan_modulate_taps(sdo.lpf_design(255, bw / FS), dp), D, 0, dp)
+    xin = np.concatenate([x[(b0 % nloop) * L:], x])
+    y = sdo.chan_feed(np.zeros(254, np.complex64), xin, 0, sdo.chan_modulate_taps(sdo.lpf_design(255, bw / FS), dp), D, 0, dp)
     a_ = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(sps)), y)
     z = sdo.costas_feed_bulk(sdo.costas_new(2, 0.0, min(2.0 / sps, 0.95), 3, 2 * 40.0 / efs), a_)
     ref = sdo.clock_feed_bulk(sdo.clock_new(0.2, baud / efs), z)
     got = np.concatenate(st["quiet_syms"])
-    assert len(got) > len(ref) > 1000                          # the stream went on past the first loop
-    assert np.array_equal(got[:len(ref)].view(np.uint32), ref.view(np.uint32))
+    k = min(len(got), len(ref))
+    assert k > 1000
+    assert np.array_equal(got[:k].view(np.uint32), ref[:k].view(np.uint32))
     Lb.suscan_analyzer_destroy(an)
     Lb.suscan_mq_finalize(C.byref(mq))
 
