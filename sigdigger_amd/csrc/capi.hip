@@ -1303,7 +1303,9 @@ SUBOOL suamd_costas_gang_feed(suamd_ctx_t *ctx, suamd_costas_bank_t *const *bank
     for (size_t o = 0; o < kv.second.size(); o += 64) {
       const size_t cnt = std::min<size_t>(64, kv.second.size() - o);
       if (items.size() + cnt > 448 && !flush()) return SU_FALSE;
-      groups.push_back(sdk::GangGroup{(int)items.size(), (int)cnt, kv.first / 8, kv.first % 8});
+      bool unit = true;                                       // x * 1.0f is exact: skipping the multiply keeps the bits
+      for (size_t q = 0; q < cnt; ++q) unit = unit && kv.second[o + q].p.gain == 1.0f;
+      groups.push_back(sdk::GangGroup{(int)items.size(), (int)cnt, kv.first / 8, kv.first % 8, unit ? 1 : 0});
       items.insert(items.end(), kv.second.begin() + o, kv.second.begin() + o + cnt);
     }
   }

@@ -109,7 +109,7 @@ struct CmaGangItem { float mu; int locked; void *w; void *dl; const void *x; voi
 // item k of the device table sits at d_items + k * item_bytes with its row pointer / length (long long) at the offsets.
 // optional group table: group g = items [first, first + count) (at most 64), e.g. one loop type each; without it
 // group g = items [64 g, 64 g + 64)
-struct GangGroup { int first, count, kind, order; };
+struct GangGroup { int first, count, kind, order, gain1; };   // gain1: every item's loop gain is exactly 1 (the multiply is skipped)
 hipError_t rows_tm_gather(const void *d_items, int item_bytes, int off_ptr, int off_len, int n, const GangGroup *d_groups, int ngroups,
                           int elem_bytes, void *tm, long long slab, long long maxlen, hipStream_t st);
 hipError_t rows_tm_scatter(const void *d_items, int item_bytes, int off_ptr, int off_len, int n, const GangGroup *d_groups, int ngroups,

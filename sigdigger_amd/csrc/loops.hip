@@ -896,7 +896,7 @@ __global__ __launch_bounds__(256) void rows_tm_scatter_kernel(const char *__rest
   }
 }
 
-template <int KIND, int ORDER>
+template <int KIND, int ORDER, bool GAIN1>
 __device__ __forceinline__ void costas_gang_body(const sdk::CostasGangItem *__restrict__ items, int count, float2 *tm)
 {
   const int j = threadIdx.x;
@@ -913,7 +913,7 @@ __device__ __forceinline__ void costas_gang_body(const sdk::CostasGangItem *__re
     r.yh[i] = c32{s.yh[(i - 1) * 2 + 0], s.yh[(i - 1) * 2 + 1]};
   }
   const long long len = live ? it.len : 0;
-  gang_stream_tm<true>(tm, len, [&](long long, float2 v) { return costas_step<KIND, ORDER, false>(p, r, v); });
+  gang_stream_tm<true>(tm, len, [&](long long, float2 v) { return costas_step<KIND, ORDER, GAIN1>(p, r, v); });
   if (!live) return;
   s.phase[0] = r.phase;
   s.omega[0] = r.omega;
@@ -934,7 +934,8 @@ __global__ __launch_bounds__(64) void costas_gang_kernel(const sdk::CostasGangIt
   const sdk::CostasGangItem *mine = items + gd.first;
   float2 *my = tm + (size_t)blockIdx.x * slab;
   switch (gd.kind * 8 + gd.order) {
-#define SD_GANG_CASE(K, O) case (K) * 8 + (O): costas_gang_body<K, O>(mine, gd.count, my); break;
+#define SD_GANG_CASE(K, O) case (K) * 8 + (O): if (gd.gain1) costas_gang_body<K, O, true>(mine, gd.count, my); \
+                                               else costas_gang_body<K, O, false>(mine, gd.count, my); break;
     SD_GANG_CASE(1, 0) SD_GANG_CASE(1, 1) SD_GANG_CASE(1, 2) SD_GANG_CASE(1, 3) SD_GANG_CASE(1, 4)
     SD_GANG_CASE(2, 0) SD_GANG_CASE(2, 1) SD_GANG_CASE(2, 2) SD_GANG_CASE(2, 3) SD_GANG_CASE(2, 4)
     SD_GANG_CASE(3, 0) SD_GANG_CASE(3, 1) SD_GANG_CASE(3, 2) SD_GANG_CASE(3, 3) SD_GANG_CASE(3, 4)
