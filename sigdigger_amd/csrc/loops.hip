@@ -325,10 +325,13 @@ __device__ __forceinline__ float2 costas_step(const sdk::CostasParams &p, Costas
     sd::sgn2(z.re, z.im, sr, si);
     if (KIND == 2) {
       e = sr * z.im - si * z.re;
-    } else if (__builtin_fabsf(z.re) >= __builtin_fabsf(z.im)) {
-      e = sr * z.im - (si * z.re) * 0.41421356237309504880f;
     } else {
-      e = (sr * z.im) * 0.41421356237309504880f - si * z.re;
+      // |re| >= |im|:  e = A - B k,  else  e = A k - B   (A = sgn(re) im, B = sgn(im) re, k = tan(pi/8)).
+      // No branch: a lone wavefront pays ~100 cycles for the EXEC bookkeeping of a divergent if / else.  The factor that
+      // is not k is 1.0f, and x * 1.0f is exact, so both products are the ones the two-way form computes.
+      const bool wide = __builtin_fabsf(z.re) >= __builtin_fabsf(z.im);
+      const float ka = wide ? 1.0f : 0.41421356237309504880f, kb = wide ? 0.41421356237309504880f : 1.0f;
+      e = (sr * z.im) * ka - (si * z.re) * kb;
     }
   }
   const float dphi = sd::fma_(p.a, e, r.omega);
