@@ -392,7 +392,7 @@ __device__ __forceinline__ float2 pll_step(float alpha, float beta, uint32_t &ph
 {
   const sd::v2f_ mm = sd::mix_conj(sd::v2f_{v.x, v.y}, sd::phasor_pk(phase));
   const float2 m = {mm.x, mm.y};
-  float err = sd::atan2_(v.y, v.x) - sd::phase_to_rad(phase);
+  float err = sd::atan2_nb_(v.y, v.x) - sd::phase_to_rad(phase);
   if (err >  3.14159265358979323846f) err -= 6.28318530717958647692f;
   if (err < -3.14159265358979323846f) err += 6.28318530717958647692f;
   const float dphi = sd::fma_(beta, err, omega);

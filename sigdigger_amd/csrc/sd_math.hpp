@@ -190,4 +190,29 @@ __device__ __forceinline__ void sgn2(float a, float b, float &sa, float &sb)
   sb = __builtin_amdgcn_fmed3f(s.y, -1.0f, 1.0f);
 }
 
+// atan2_ without its two data-dependent branches, for the one-wavefront recurrences (a divergent `if` costs such a
+// wavefront ~100 cycles of EXEC bookkeeping per sample whether or not a lane takes it): both range reductions are
+// computed and selected.  The operations behind the selected values are atan2_'s, so are the bits (the unselected
+// side may be inf / NaN: it is never used).
+__device__ __forceinline__ float atan2_nb_(float y, float x)
+{
+  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+  const float mx = ax > ay ? ax : ay;
+  const float mn = ax > ay ? ay : ax;
+  const float t0 = mn / mx;
+  const bool hi = t0 > 0.4142135623730950f;
+  const float t1 = (t0 - 1.0f) / (t0 + 1.0f);
+  const float t = hi ? t1 : t0;
+  const float y0 = hi ? 0.78539816339744830962f : 0.0f;
+  const float z = t * t;
+  float p = fma_(8.05374449538e-2f, z, -1.38776856032e-1f);
+  p = fma_(p, z, 1.99777106478e-1f);
+  p = fma_(p, z, -3.33329491539e-1f);
+  float a = fma_(p * z, t, t) + y0;
+  if (ay > ax)  a = 1.57079632679489661923f - a;
+  if (x < 0.0f) a = 3.14159265358979323846f - a;
+  if (y < 0.0f) a = -a;
+  return mx == 0.0f ? 0.0f : a;
+}
+
 }  // namespace sd
