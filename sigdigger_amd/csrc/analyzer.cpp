@@ -1092,9 +1092,8 @@ bool setup_psd(suscan_analyzer *a, std::string &err)
   if (hipMalloc((void **)&a->d_psd, n * sizeof(float)) != hipSuccess) { err = "device allocation failed"; return false; }
   if (block != a->block) {
     if (a->h_x) (void)hipHostFree(a->h_x);
-  if (a->h_flt) (void)hipHostFree(a->h_flt);
-  if (a->d_dc) (void)hipFree(a->d_dc);
-  a->h_flt = nullptr; a->d_dc = nullptr;
+    if (a->h_flt) (void)hipHostFree(a->h_flt);               // the filters' expansion buffer is a block long too
+    a->h_flt = nullptr;
     if (a->d_x) (void)hipFree(a->d_x);
     if (a->d_raw) (void)hipFree(a->d_raw);
     a->h_x = nullptr; a->d_x = nullptr; a->d_raw = nullptr;
