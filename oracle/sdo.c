@@ -1000,7 +1000,7 @@ size_t sdo_power_feed(sdo_power *p, const sdo_c32 *x, size_t len, sdo_c32 *out)
 {
   size_t i, k = 0;
   for (i = 0; i < len; ++i) {
-    const double input = (double)fmaf(x[i].im, x[i].im, x[i].re * x[i].re);   /* SU_C_REAL(x conj(x)), binary32 */
+    const double input = (double)(x[i].re * x[i].re + x[i].im * x[i].im);      /* SU_C_REAL(x conj(x)): two binary32 products, one sum */
     const double y = input - p->c, t = p->acc + y;                             /* RMSInspector.cpp:551-556 */
     p->c = (t - p->acc) - y;
     p->acc = t;

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void power_integrate_kernel(const float2 *__re
   if (lo < 0) lo = 0;
   if (hi > len) hi = len;
   double a = 0.0;
-  for (long long t = lo + threadIdx.x; t < hi; t += 256) { const float2 v = x[t]; a += (double)sd::fma_(v.y, v.y, v.x * v.x); }
+  for (long long t = lo + threadIdx.x; t < hi; t += 256) { const float2 v = x[t]; a += (double)(v.x * v.x + v.y * v.y); }   // unfused, as the complex multiply
   sh[threadIdx.x] = a;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
