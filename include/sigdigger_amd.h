@@ -415,6 +415,16 @@ SUAMD_API SUSCOUNT suamd_power_bank_output_count(const suamd_power_bank_t *bank,
 SUAMD_API SUBOOL   suamd_power_bank_feed(suamd_power_bank_t *bank, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_out,
                                          SUSCOUNT *n_out, void *stream);
 
+/* A5: the frame time-to-live rule in front of the averager (UIMediator::feedPSD, UIMediator/SpectrumMediator.cpp:35-85,
+ * 127): a PSD frame whose age (now - rt_time), less the running estimate of the intrinsic delivery delay, exceeds
+ * ttl_ms is dropped -- unless the source has just looped.  Host arithmetic on time stamps (binary64), state in the
+ * caller's struct; the delay estimate is SU_SPLPF_FEED with SU_SPLPF_ALPHA(10) (recollection: 1 - exp(-1/10)) after a
+ * calibration phase (SIGDIGGER_UI_MEDIATOR_PSD_CAL_LEN = 10, include/UIMediator.h:36). */
+typedef struct { double rt_delta_real; unsigned rt_calibrations; SUBOOL have_rt_delta; } suamd_psd_ttl_t;
+#define suamd_psd_ttl_INITIALIZER { 0.0, 0, SU_FALSE }
+/* SU_TRUE = feed the frame to the averager / spectrum (not expired, or looped) */
+SUAMD_API SUBOOL suamd_psd_ttl_accept(suamd_psd_ttl_t *state, double now_s, double rt_time_s, double ttl_ms, SUBOOL looped);
+
 /* Capture export: ExportSamplesTask (Tasks/ExportSamplesTask.cpp:41-284) for a capture that
  * lives in HBM -- streamed to the host a pinned chunk at a time and written in the reference's formats:
  *   "raw"  interleaved float32 I/Q                       (:250-270, libsndfile RAW | FLOAT)

@@ -689,6 +689,25 @@ SUBOOL suamd_source_fix(suamd_ctx_t *ctx, suamd_complex *d_x, SUSCOUNT nsamples,
   return SU_TRUE;
 }
 
+// A5: UIMediator::feedPSD's expiry rule (UIMediator/SpectrumMediator.cpp:35-85, :127); the lag warning for remote
+// analyzers (:87-124) is GUI and not part of it
+SUBOOL suamd_psd_ttl_accept(suamd_psd_ttl_t *s, double now_s, double rt_time_s, double ttl_ms, SUBOOL looped)
+{
+  if (!s) return SU_TRUE;
+  bool expired = false;
+  const double max_delta = ttl_ms * 1e-3;
+  double delta = now_s - rt_time_s;                        // :50-51
+  if (s->rt_calibrations++ == 0) s->rt_delta_real = delta; // :58-59
+  else s->rt_delta_real += (1.0 - std::exp(-1.0 / 10.0)) * (delta - s->rt_delta_real);   // SU_SPLPF_FEED(.., SU_SPLPF_ALPHA(CAL_LEN)) :65-68
+  if (!s->have_rt_delta) {
+    if (++s->rt_calibrations > 10) s->have_rt_delta = SU_TRUE;   // :76-78
+  } else {
+    delta -= s->rt_delta_real;                             // :81-82
+    expired = delta > max_delta;
+  }
+  return (!expired || looped) ? SU_TRUE : SU_FALSE;        // :127
+}
+
 unsigned suamd_format_bytes_per_sample(int format)
 {
   switch (format) {

@@ -98,6 +98,7 @@ PROTOTYPES = {
     "suamd_power_bank_set_integrate": (INT, [VP, U64, VP]),
     "suamd_power_bank_output_count": (U64, [VP, U64]),
     "suamd_power_bank_feed": (INT, [VP, VP, U64, VP, VP, VP]),
+    "suamd_psd_ttl_accept": (INT, [VP, C.c_double, C.c_double, C.c_double, INT]),
     "suamd_export_capture": (INT, [VP, C.c_char_p, C.c_char_p, VP, U64, C.c_float, VP]),
     "suamd_source_fix": (INT, [VP, VP, U64, INT, VP, C.c_float, INT, VP]),
     "suamd_chanbank_gang_feed": (INT, [VP, VP, UINT, VP, U64, VP, VP, VP]),

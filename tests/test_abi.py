@@ -134,3 +134,49 @@ def test_product_never_imports_the_oracle():
     from sigdigger_amd import lib
     needed = subprocess.run(["readelf", "-d", lib.SO_PATH], capture_output=True, text=True).stdout
     assert "sdo" not in needed
+
+
+def test_psd_ttl_rule_literal_transcription():
+    """A5, host-only: UIMediator::feedPSD's expiry rule (UIMediator/SpectrumMediator.cpp:35-85,127) against a line-by-line
+    Python transcription -- frames that arrive late by more than the TTL (after the calibration phase) are dropped unless
+    the source looped"""
+    import ctypes as C
+    import math
+    import numpy as np
+    from sigdigger_amd import lib as sdlib
+
+    class TTL(C.Structure):
+        _fields_ = [("rt_delta_real", C.c_double), ("rt_calibrations", C.c_uint), ("have_rt_delta", C.c_int)]
+
+    L = sdlib.load()
+    rng = np.random.default_rng(2)
+    st = TTL(0.0, 0, 0)
+    m_rtDeltaReal, m_rtCalibrations, m_haveRtDelta = 0.0, 0, False
+    alpha = 1.0 - math.exp(-1.0 / 10)
+    now, dropped = 100.0, 0
+    for k in range(200):
+        now += 0.04
+        lag = 0.003 + (0.5 if k in (50, 51, 120) else 0.0) + 1e-4 * rng.standard_normal()
+        rt = now - lag
+        looped = k == 51
+        delta = now - rt
+        expired = False
+        first = m_rtCalibrations == 0
+        m_rtCalibrations += 1
+        if first:
+            m_rtDeltaReal = delta
+        else:
+            m_rtDeltaReal += alpha * (delta - m_rtDeltaReal)
+        if not m_haveRtDelta:
+            m_rtCalibrations += 1
+            if m_rtCalibrations > 10:
+                m_haveRtDelta = True
+        else:
+            delta -= m_rtDeltaReal
+            expired = delta > 100e-3
+        want = (not expired) or looped
+        got = bool(L.suamd_psd_ttl_accept(C.byref(st), now, rt, 100.0, int(looped)))
+        assert got == want, k
+        assert st.rt_delta_real == m_rtDeltaReal and st.rt_calibrations == m_rtCalibrations
+        dropped += not got
+    assert dropped == 2                                    # frames 50 and 120; 51 is late too but the source looped
