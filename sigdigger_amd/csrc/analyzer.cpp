@@ -484,7 +484,7 @@ struct suscan_analyzer {
   suamd_psd_t *psd = nullptr;
   std::map<SUHANDLE, std::unique_ptr<Inspector>> inspectors;
   hipStream_t stream = nullptr;
-  static constexpr int NISTREAMS = 3;          // gain control / carrier control / clock recovery
+  static constexpr int NISTREAMS = 4;          // gain control / carrier control / clock recovery / channeliser (+ spectra, estimators)
   static constexpr int NSUB = 16;             // at most this many sub-ranges of a block pipelined through those stages
   int nsub = 4;
   bool trace = false;                         // SUAMD_ANALYZER_TRACE: per-block host timeline on stderr
@@ -495,6 +495,7 @@ struct suscan_analyzer {
   hipStream_t istream[NISTREAMS] = {};
   hipEvent_t ev_input = nullptr;              // the block is in d_x
   hipEvent_t ev_xfree = nullptr;              // ... and every kernel that reads it has run
+  hipEvent_t ev_fir = nullptr;                // the channel samples of the block are in the inspectors' rows
   bool xfree_set = false;
   hipEvent_t ev_done[2][NISTREAMS] = {};      // the inspector work of the block in slot p is through stream k
   hipEvent_t ev_psd[2] = {};                  // the PSD of the block in slot p is in h_psd[p]
@@ -696,8 +697,12 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len, int slot)
 void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
 {
   const int P = a->nsub;
-  hipStream_t sA = a->istream[0], sC = a->istream[1], sK = a->istream[2];
-  (void)hipStreamWaitEvent(sA, a->ev_input, 0);
+  hipStream_t sA = a->istream[0], sC = a->istream[1], sK = a->istream[2], sF = a->istream[3];
+  // the channeliser has its own stream: with hundreds of inspectors it is as long as a recurrence stage, and block
+  // k+1's may run beside block k's gain control.  It overwrites this slot's channel rows: their readers two blocks ago
+  // (every other stream) must be through
+  (void)hipStreamWaitEvent(sF, a->ev_input, 0);
+  for (int k = 0; k < 3; ++k) (void)hipStreamWaitEvent(sF, a->ev_done[slot][k], 0);
   std::vector<Inspector *> live;
   for (auto &kv : a->inspectors) {
     Inspector &in = *kv.second;
@@ -718,14 +723,17 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
     // every inspector channelises the same wideband block: one launch for all of them
     std::vector<suamd_chanbank_t *> fb; std::vector<suamd_complex *> fy; std::vector<SUSCOUNT> fm(live.size());
     for (Inspector *pi : live) { fb.push_back(pi->bank); fy.push_back(pi->d_y); }
-    if (!suamd_chanbank_gang_feed(a->ctx, fb.data(), (unsigned)fb.size(), a->d_x, len, fy.data(), fm.data(), sA)) { fail("channeliser"); return; }
-    (void)hipEventRecord(a->ev_xfree, sA);                    // the wideband block may be overwritten from here on (the PSD is on the input stream itself)
+    if (!suamd_chanbank_gang_feed(a->ctx, fb.data(), (unsigned)fb.size(), a->d_x, len, fy.data(), fm.data(), sF)) { fail("channeliser"); return; }
+    (void)hipEventRecord(a->ev_xfree, sF);                    // the wideband block may be overwritten from here on (the PSD is on the input stream itself)
     a->xfree_set = true;
-    if (a->trace) (void)hipEventRecord(a->ev_tfir, sA);
+    (void)hipEventRecord(a->ev_fir, sF);
+    (void)hipStreamWaitEvent(sA, a->ev_fir, 0);               // every other stage is downstream of the gain-control stream
+    if (a->trace) (void)hipEventRecord(a->ev_tfir, sF);
     for (size_t i = 0; i < live.size(); ++i) {
       Inspector &in = *live[i];
       in.pend_m = fm[i];
       in.pend_src = in.d_y;
+      in.stream = sF;                                         // spectra and estimators read the channel samples: beside the chain
       if (in.spectsrc_id) enqueue_spectrum(a, in, fm[i]);
       in.spect_have_prev = true; in.last_slot = slot; in.last_fir_m = fm[i];   // for the next block's "sample before"
       for (int k = 0; k < 2; ++k) {                           // enabled estimators look at the channel samples too
@@ -735,7 +743,7 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
         if (fm[i] < want) continue;                           // fewer than 512 channel samples per block: no estimate
         if (in.est[k] && suamd_baud_estimator_size(in.est[k]) != want) { suamd_baud_estimator_destroy(in.est[k]); in.est[k] = nullptr; }
         if (!in.est[k]) in.est[k] = suamd_baud_estimator_new(a->ctx, k == 0 ? SUAMD_BAUD_ESTIMATOR_FAC : SUAMD_BAUD_ESTIMATOR_NONLINEAR, want);
-        if (!in.est[k] || !suamd_baud_estimator_feed_to(in.est[k], in.d_y, fm[i], &in.pin->est[k], sA)) { fail("estimator"); continue; }
+        if (!in.est[k] || !suamd_baud_estimator_feed_to(in.est[k], in.d_y, fm[i], &in.pin->est[k], sF)) { fail("estimator"); continue; }
         in.est_fed[k] = true;
       }
     }
@@ -1176,7 +1184,8 @@ void worker_main(suscan_analyzer *a)
     for (int j = 0; ok && j < suscan_analyzer::NSUB; ++j)
       if (hipEventCreateWithFlags(&a->ev_stage[g][j], hipEventDisableTiming) != hipSuccess) { ok = false; err = "hipEventCreate failed"; }
   if (ok) {
-    bool e = hipEventCreateWithFlags(&a->ev_xfree, hipEventDisableTiming) == hipSuccess;
+    bool e = hipEventCreateWithFlags(&a->ev_xfree, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&a->ev_fir, hipEventDisableTiming) == hipSuccess;
     for (int p = 0; p < 2; ++p) {
       e = e && hipEventCreateWithFlags(&a->ev_psd[p], hipEventDisableTiming) == hipSuccess &&
           hipEventCreateWithFlags(&a->ev_h2d[p], hipEventDisableTiming) == hipSuccess;
@@ -1436,7 +1445,8 @@ void worker_main(suscan_analyzer *a)
     for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) { if (a->ev_done[p][k]) (void)hipEventDestroy(a->ev_done[p][k]); a->ev_done[p][k] = nullptr; }
   }
   if (a->ev_xfree) (void)hipEventDestroy(a->ev_xfree);
-  a->ev_xfree = nullptr;
+  if (a->ev_fir) (void)hipEventDestroy(a->ev_fir);
+  a->ev_xfree = a->ev_fir = nullptr;
   if (a->h_x) (void)hipHostFree(a->h_x);
   if (a->h_flt) (void)hipHostFree(a->h_flt);
   if (a->d_dc) (void)hipFree(a->d_dc);

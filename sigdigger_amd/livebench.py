@@ -68,11 +68,15 @@ def live_rate(n_inspectors=64, nblocks=40, fs=50_000_000, nfft=8192, block=1 << 
                 st["psd"] += 1
                 if st["t0"] is not None and st["psd"] == nblocks and st["result"] is None:
                     dt = time.time() - st["t0"]
+                    worker = float(Lb.suscan_analyzer_get_measured_samp_rate(an))   # the worker's own rate (EMA over blocks): this
                     st["result"] = {"workload": f"live analyzer through the suscan ABI: {nfft}-pt PSD + {n_inspectors} heterogeneous PSK "
                                                 f"inspectors (own carrier / bandwidth / baud / Costas order / loop bandwidth), file source, "
                                                 f"{block}-sample blocks at {fs / 1e6:g} MS/s",
                                     "value_MSps": round(nblocks * block / dt / 1e6, 3), "ms_per_block": round(dt / nblocks * 1e3, 4),
-                                    "symbols_Msps": round(st["sym"] / dt / 1e6, 3), "inspectors": n_inspectors, "blocks": nblocks}
+                                    "symbols_Msps": round(st["sym"] / dt / 1e6, 3), "inspectors": n_inspectors, "blocks": nblocks,
+                                    "worker_MSps": round(worker / 1e6, 3),
+                                    "note": "value_MSps is timed at this Python consumer (one message per inspector and block: it "
+                                            "becomes the limit beyond ~100 inspectors); worker_MSps is suscan_analyzer_get_measured_samp_rate"}
                     Lb.suscan_analyzer_req_halt(an)
                 elif time.time() > deadline and st["result"] is None:
                     st["result"] = {"error": f"only {st['cfg']} of {n_inspectors} inspectors configured within {timeout_s} s"}

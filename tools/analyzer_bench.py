@@ -12,4 +12,4 @@ r = live_rate(N, NBLK)
 if "error" in r:
     sys.exit(r["error"])
 print(f"{N} inspectors: {r['value_MSps']:.1f} MS/s sustained ({r['ms_per_block']:.2f} ms per 2097152-sample block, "
-      f"{r['symbols_Msps']:.2f} Msym/s delivered)")
+      f"{r['symbols_Msps']:.2f} Msym/s delivered); the worker's own measured rate {r['worker_MSps']:.1f} MS/s")
