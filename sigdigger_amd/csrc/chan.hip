@@ -378,12 +378,27 @@ __device__ __forceinline__ void chan_fir_sparse_body(const float2 *__restrict__ 
   const long long hist0 = (long long)n0 - (T - 1);
   const float4 *gc = g + (long long)c * T;
   v2f acc = {0.0f, 0.0f};
-  for (int k = 0; k < T; ++k) {
-    const long long q = (long long)n - k;
-    float2 w = float2{0.0f, 0.0f};
-    if (q >= (long long)n0) { if (q < (long long)n0 + len) w = x[q - (long long)n0]; }
-    else if (q >= hist0) w = hist[q - hist0];
-    acc = tap_mac(acc, gc[k], v2f{w.x, w.y});
+  if ((long long)n - (T - 1) >= (long long)n0 && (long long)n < (long long)n0 + len) {
+    // the whole tap window lies inside this block (every output but the block's first few): a straight walk, eight
+    // loads in flight, no bounds tests -- the same taps in the same order
+    const float2 *xp = x + ((long long)n - (long long)n0);
+    int k = 0;
+    for (; k + 8 <= T; k += 8) {
+      float2 w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = xp[-(k + u)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = tap_mac(acc, gc[k + u], v2f{w[u].x, w[u].y});
+    }
+    for (; k < T; ++k) { const float2 w = xp[-k]; acc = tap_mac(acc, gc[k], v2f{w.x, w.y}); }
+  } else {
+    for (int k = 0; k < T; ++k) {
+      const long long q = (long long)n - k;
+      float2 w = float2{0.0f, 0.0f};
+      if (q >= (long long)n0) { if (q < (long long)n0 + len) w = x[q - (long long)n0]; }
+      else if (q >= hist0) w = hist[q - hist0];
+      acc = tap_mac(acc, gc[k], v2f{w.x, w.y});
+    }
   }
   float cs, sn;
   sd::phasor_u32(phase0[c] + (uint32_t)(n * (uint64_t)dphase[c]), cs, sn);
