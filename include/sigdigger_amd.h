@@ -32,7 +32,11 @@ typedef double   SUFREQ;
 typedef uint64_t SUSCOUNT;
 typedef int64_t  SUSDIFF;
 typedef int      SUBOOL;
+#ifdef SUAMD_COMPLEX_IS_SUCOMPLEX                    /* <sigutils/types.h> came first: one sample type   */
+typedef SUCOMPLEX suamd_complex;
+#else
 typedef struct { SUFLOAT re, im; } suamd_complex;   /* layout-identical to SUCOMPLEX */
+#endif
 #ifndef SU_TRUE
 #  define SU_TRUE  1
 #  define SU_FALSE 0

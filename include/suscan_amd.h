@@ -21,7 +21,10 @@
 extern "C" {
 #endif
 
+#ifndef SUHANDLE_DEFINED
+#  define SUHANDLE_DEFINED
 typedef int32_t SUHANDLE;
+#endif
 
 /* ---- message queue (Suscan/MQ.cpp:28-43) --------------------------------------------------- */
 struct suscan_mq { void *impl; };
@@ -52,10 +55,15 @@ SUAMD_API SUBOOL suscan_mq_write(struct suscan_mq *mq, uint32_t type, void *msg)
 
 /* ---- analyzer parameters (Suscan/AnalyzerParams.cpp:27-71) ----------------------------------- */
 enum suscan_analyzer_mode { SUSCAN_ANALYZER_MODE_CHANNEL = 0, SUSCAN_ANALYZER_MODE_WIDE_SPECTRUM = 1 };
+/* include/Suscan/AnalyzerParams.h:37-43; same values as enum suamd_window */
+enum sigutils_channel_detector_window {
+  SU_CHANNEL_DETECTOR_WINDOW_NONE = 0, SU_CHANNEL_DETECTOR_WINDOW_HAMMING = 1, SU_CHANNEL_DETECTOR_WINDOW_HANN = 2,
+  SU_CHANNEL_DETECTOR_WINDOW_FLAT_TOP = 3, SU_CHANNEL_DETECTOR_WINDOW_BLACKMANN_HARRIS = 4
+};
 struct sigutils_channel_detector_params {
-  SUFLOAT alpha, beta, gamma, snr;
+  SUFLOAT alpha, beta, gamma, snr;           /* spectrum / signal-level / noise-level averaging, SNR threshold */
   SUSCOUNT window_size;
-  int window;                                /* enum suamd_window == sigutils_channel_detector_window */
+  enum sigutils_channel_detector_window window;
 };
 struct suscan_analyzer_params {
   enum suscan_analyzer_mode mode;
@@ -65,7 +73,7 @@ struct suscan_analyzer_params {
   SUFREQ  min_freq, max_freq;
 };
 #define suscan_analyzer_params_INITIALIZER \
-  { SUSCAN_ANALYZER_MODE_CHANNEL, { 1e-2f, 1e-3f, .5f, 2.f, 4096, SUAMD_WINDOW_BLACKMANN_HARRIS }, .1f, .04f, -1, -1 }
+  { SUSCAN_ANALYZER_MODE_CHANNEL, { 1e-2f, 1e-3f, .5f, 2.f, 4096, SU_CHANNEL_DETECTOR_WINDOW_BLACKMANN_HARRIS }, .1f, .04f, -1, -1 }
 
 /* struct sigutils_channel (Suscan/Analyzer.cpp:417-424) */
 struct sigutils_channel { SUFREQ fc, f_lo, f_hi; SUFLOAT bw, snr, S0, N0; SUFREQ ft; uint32_t age, present; };
@@ -87,16 +95,70 @@ SUAMD_API void   suscan_source_config_set_freq(suscan_source_config_t *cfg, SUFR
 SUAMD_API SUBOOL suscan_source_config_set_path(suscan_source_config_t *cfg, const char *path);
 SUAMD_API void   suscan_source_config_set_loop(suscan_source_config_t *cfg, SUBOOL loop);
 SUAMD_API SUBOOL suscan_source_config_set_param(suscan_source_config_t *cfg, const char *key, const char *val);
+/* the rest of what Suscan::Source::Config calls on a source config (Suscan/Source.cpp:27-645).  A file / generator
+ * source keeps every value; what it cannot act on (LNB, gains, antenna, ppm ...) is recorded and read back.  Device
+ * specs, XML (de)serialisation and metadata guessing belong to libsuscan's control plane and are not served. */
+SUAMD_API suscan_source_config_t *suscan_source_config_clone(const suscan_source_config_t *cfg);
+SUAMD_API const char *suscan_source_config_get_label(const suscan_source_config_t *cfg);
+SUAMD_API SUBOOL suscan_source_config_set_label(suscan_source_config_t *cfg, const char *label);
+SUAMD_API const char *suscan_source_config_get_type(const suscan_source_config_t *cfg);
+SUAMD_API enum suscan_source_format suscan_source_config_get_format(const suscan_source_config_t *cfg);
+SUAMD_API void   suscan_source_config_set_type_format(suscan_source_config_t *cfg, const char *type, enum suscan_source_format fmt);
+SUAMD_API const char *suscan_source_config_get_path(const suscan_source_config_t *cfg);      /* NULL: none */
+SUAMD_API SUFREQ suscan_source_config_get_freq(const suscan_source_config_t *cfg);
+SUAMD_API SUFREQ suscan_source_config_get_lnb_freq(const suscan_source_config_t *cfg);
+SUAMD_API void   suscan_source_config_set_lnb_freq(suscan_source_config_t *cfg, SUFREQ lnb);
+SUAMD_API unsigned int suscan_source_config_get_samp_rate(const suscan_source_config_t *cfg);
+SUAMD_API unsigned int suscan_source_config_get_average(const suscan_source_config_t *cfg);  /* decimation, >= 1 */
+SUAMD_API SUBOOL suscan_source_config_set_average(suscan_source_config_t *cfg, unsigned int average);
+SUAMD_API SUFLOAT suscan_source_config_get_bandwidth(const suscan_source_config_t *cfg);
+SUAMD_API void   suscan_source_config_set_bandwidth(suscan_source_config_t *cfg, SUFLOAT bw);
+SUAMD_API SUFLOAT suscan_source_config_get_ppm(const suscan_source_config_t *cfg);
+SUAMD_API void   suscan_source_config_set_ppm(suscan_source_config_t *cfg, SUFLOAT ppm);
+SUAMD_API SUBOOL suscan_source_config_get_loop(const suscan_source_config_t *cfg);
+SUAMD_API SUBOOL suscan_source_config_get_dc_remove(const suscan_source_config_t *cfg);
+SUAMD_API void   suscan_source_config_set_dc_remove(suscan_source_config_t *cfg, SUBOOL dc_remove);
+SUAMD_API SUBOOL suscan_source_config_get_iq_balance(const suscan_source_config_t *cfg);
+SUAMD_API void   suscan_source_config_set_iq_balance(suscan_source_config_t *cfg, SUBOOL iq_balance);
+SUAMD_API void   suscan_source_config_get_start_time(const suscan_source_config_t *cfg, struct timeval *tv);
+SUAMD_API void   suscan_source_config_set_start_time(suscan_source_config_t *cfg, struct timeval tv);
+/* start time + file length / sample rate; SU_FALSE when the length is unknown (generator, unreadable file) */
+SUAMD_API SUBOOL suscan_source_config_get_end_time(const suscan_source_config_t *cfg, struct timeval *tv);
+SUAMD_API SUBOOL suscan_source_config_file_is_valid(const suscan_source_config_t *cfg);
+SUAMD_API SUBOOL suscan_source_config_is_real_time(const suscan_source_config_t *cfg);       /* never: file / generator */
+SUAMD_API SUBOOL suscan_source_config_is_seekable(const suscan_source_config_t *cfg);
+SUAMD_API SUBOOL suscan_source_config_get_freq_limits(const suscan_source_config_t *cfg, SUFREQ *min, SUFREQ *max);
+SUAMD_API const char *suscan_source_config_get_antenna(const suscan_source_config_t *cfg);   /* NULL: none */
+SUAMD_API SUBOOL suscan_source_config_set_antenna(suscan_source_config_t *cfg, const char *antenna);
+SUAMD_API SUFLOAT suscan_source_config_get_gain(const suscan_source_config_t *cfg, const char *name);
+SUAMD_API SUBOOL suscan_source_config_set_gain(suscan_source_config_t *cfg, const char *name, SUFLOAT value);
+SUAMD_API const char *suscan_source_config_get_param(const suscan_source_config_t *cfg, const char *key);   /* NULL: unset */
+SUAMD_API void   suscan_source_config_clear_params(suscan_source_config_t *cfg);
+SUAMD_API SUBOOL suscan_source_config_walk_params(const suscan_source_config_t *cfg,
+                     SUBOOL (*func)(const suscan_source_config_t *cfg, const char *key, const char *value, void *userdata),
+                     void *userdata);
 
+/* fields read by Suscan::AnalyzerSourceInfo (include/Suscan/Analyzer.h:113-254).  A SOURCE_INFO message and the
+ * loaned pointer of suscan_analyzer_get_source_info() own their strings / lists; copies are deep
+ * (suscan_source_info_init_copy) */
+struct suscan_source_gain_info { char *name; SUFLOAT min, max, step, value; };
 struct suscan_source_info {
   uint64_t permissions;
   SUSCOUNT source_samp_rate, effective_samp_rate;
   SUFLOAT  measured_samp_rate;
   SUFREQ   frequency, freq_min, freq_max, lnb;
   SUFLOAT  bandwidth, ppm;
+  char    *antenna;                          /* NULL: none selected ("N/A", Analyzer.h:173-178) */
   SUBOOL   dc_remove, iq_reverse, agc, seekable;
+  SUBOOL   replay;
+  SUSCOUNT history_length;
   struct timeval source_start, source_end;
+  struct suscan_source_gain_info **gain_list; unsigned int gain_count;      /* a file source has no gains ... */
+  char   **antenna_list;                      unsigned int antenna_count;   /* ... and no antennas            */
 };
+SUAMD_API void   suscan_source_info_init(struct suscan_source_info *info);
+SUAMD_API SUBOOL suscan_source_info_init_copy(struct suscan_source_info *dst, const struct suscan_source_info *src);
+SUAMD_API void   suscan_source_info_finalize(struct suscan_source_info *info);
 
 /* ---- inspector configuration (Suscan/Config.cpp; key vocabulary: Default/GenericInspector/InspectorCtl) */
 enum suscan_field_type { SUSCAN_FIELD_TYPE_STRING, SUSCAN_FIELD_TYPE_INTEGER, SUSCAN_FIELD_TYPE_FLOAT,
@@ -120,6 +182,8 @@ SUAMD_API struct suscan_field_value *suscan_config_get_value(const suscan_config
 SUAMD_API SUBOOL suscan_config_set_integer(suscan_config_t *cfg, const char *name, uint64_t v);
 SUAMD_API SUBOOL suscan_config_set_float(suscan_config_t *cfg, const char *name, SUFLOAT v);
 SUAMD_API SUBOOL suscan_config_set_bool(suscan_config_t *cfg, const char *name, SUBOOL v);
+SUAMD_API SUBOOL suscan_config_set_string(suscan_config_t *cfg, const char *name, const char *v);
+SUAMD_API SUBOOL suscan_config_desc_has_prefix(const suscan_config_desc_t *desc, const char *prefix);
 
 /* ---- messages (fields SigDigger dereferences: SURVEY.md Appendix B) --------------------------- */
 struct suscan_analyzer_psd_msg {
@@ -146,8 +210,21 @@ enum suscan_analyzer_inspector_msgkind {
   SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SET_WATERMARK, SUSCAN_ANALYZER_INSPECTOR_MSGKIND_WRONG_HANDLE,
   SUSCAN_ANALYZER_INSPECTOR_MSGKIND_WRONG_OBJECT, SUSCAN_ANALYZER_INSPECTOR_MSGKIND_INVALID_ARGUMENT,
   SUSCAN_ANALYZER_INSPECTOR_MSGKIND_WRONG_KIND, SUSCAN_ANALYZER_INSPECTOR_MSGKIND_INVALID_CHANNEL,
-  SUSCAN_ANALYZER_INSPECTOR_MSGKIND_ORBIT_REPORT, SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SET_TLE
+  SUSCAN_ANALYZER_INSPECTOR_MSGKIND_ORBIT_REPORT, SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SET_TLE,
+  SUSCAN_ANALYZER_INSPECTOR_MSGKIND_SIGNAL
 };
+/* sgdp4's xyz_t and the report of kind ORBIT_REPORT (include/Suscan/Messages/InspectorMessage.h:33-78) */
+#ifndef SUAMD_XYZ_T_DEFINED
+#  define SUAMD_XYZ_T_DEFINED
+typedef struct xyz {
+  union { double x, lon, azimuth; };
+  union { double y, lat, elevation; };
+  union { double z, height, distance; };
+} xyz_t;
+#endif
+struct suscan_orbit_report { struct timeval rx_time; xyz_t satpos; SUFLOAT freq_corr; double vlos_vel; };
+/* su_channel_detector's result at channel_update_int (Suscan/Analyzer.cpp:75-98 disposes it, ChannelMessage.cpp:26) */
+struct suscan_analyzer_channel_msg { struct sigutils_channel **channel_list; unsigned int channel_count; };
 struct suscan_analyzer_inspector_msg {
   enum suscan_analyzer_inspector_msgkind kind;
   uint32_t inspector_id;
@@ -167,6 +244,10 @@ struct suscan_analyzer_inspector_msg {
   SUSCOUNT watermark;
   SUBOOL   enabled;                           /* ESTIMATOR: estimator switched on; SET_TLE: correction enabled */
   SUFLOAT  value;                             /* ESTIMATOR: the estimate, in the unit of the config field it feeds (Hz / baud) */
+  struct suscan_orbit_report orbit_report;    /* ORBIT_REPORT (InspectorMessage.cpp:65) */
+  SUBOOL   tle_enable;                        /* SET_TLE (InspectorMessage.cpp:230) */
+  char    *signal_name;                       /* SIGNAL (InspectorMessage.cpp:239): never NULL in a delivered message */
+  double   signal_value;                      /* SIGNAL (InspectorMessage.cpp:248) */
 };
 struct suscan_analyzer_status_msg { int code; char *err_msg; };
 

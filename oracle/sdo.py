@@ -567,3 +567,6 @@ class SpectrumView:
         cp = _p(_f(count)) if count is not None else None
         lib().sdo_specview_feed(C.byref(self.v), _p(psd), cp, C.c_size_t(psd.size),
                                 C.c_double(fmin), C.c_double(fmax), C.c_int(int(adjust_sides)))
+
+    def interpolate(self):
+        lib().sdo_specview_interpolate(C.byref(self.v))

@@ -137,6 +137,14 @@ struct suscan_source_config {
   std::string path;
   bool loop = false;
   std::map<std::string, std::string> params;
+  // recorded and read back (Suscan/Source.cpp getters); a file / generator source does not act on them
+  std::string label = "Unlabeled source", antenna;
+  bool has_antenna = false, dc_remove = false, iq_balance = false;
+  double lnb_freq = 0;
+  unsigned average = 1;
+  float bandwidth = 0, ppm = 0;
+  struct timeval start_time{0, 0};
+  std::map<std::string, float> gains;
 };
 
 namespace {
@@ -213,8 +221,9 @@ struct Source {
       k = js.find(':', k + std::strlen(key));
       if (k == std::string::npos) return "";
       size_t b = js.find_first_not_of(" \t\r\n\"", k + 1);
+      if (b == std::string::npos) return "";               // the meta file ends right after the ':'
       size_t e = js.find_first_of(",\"}\r\n", b);
-      return js.substr(b, e - b);
+      return js.substr(b, e == std::string::npos ? e : e - b);
     };
     const std::string dt = value_of("\"core:datatype\"");
     if (dt == "cf32_le" || dt == "cf32") raw_format = SUAMD_FORMAT_RAW_FLOAT32;
@@ -531,6 +540,8 @@ suscan_analyzer_inspector_msg *new_insp_msg(suscan_analyzer_inspector_msgkind ki
   m->kind = kind;
   m->req_id = req_id;
   m->handle = -1;
+  m->signal_name = strdup("");                              // InspectorMessage.cpp:239 builds a std::string from it
+  m->signal_value = std::nan("");
   return m;
 }
 
@@ -919,7 +930,10 @@ const struct suscan_estimator_class kEstimators[2] = {
 void push_source_info(suscan_analyzer *a)
 {
   auto *si = static_cast<suscan_source_info *>(std::malloc(sizeof(suscan_source_info)));
-  *si = a->info;
+  {
+    std::lock_guard<std::mutex> lk(a->req_m);               // the setters write a->info under req_m
+    (void)suscan_source_info_init_copy(si, &a->info);
+  }
   push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INFO, si);
 }
 
@@ -1071,6 +1085,7 @@ void handle_request(suscan_analyzer *a, Request &r)
       m->handle = r.handle;
       m->inspector_id = it->second->inspector_id;
       m->enabled = SU_FALSE;
+      m->tle_enable = SU_FALSE;
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
       break;
     }
@@ -1212,15 +1227,13 @@ void worker_main(suscan_analyzer *a)
     return;
   }
   push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INIT, SUSCAN_ANALYZER_INIT_SUCCESS, "");
-  {
-    auto *si = static_cast<suscan_source_info *>(std::malloc(sizeof(suscan_source_info)));
-    *si = a->info;
-    push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INFO, si);
-  }
+  push_source_info(a);
   AsyncRead reader(src);
   auto t_prev = std::chrono::steady_clock::now();
-  const auto t_start = t_prev;
   uint64_t consumed = 0;
+  // throttle anchor: the pace is (consumed - thr_c0) / rate seconds after thr_t0; re-anchored by SET_THROTTLE and SEEK
+  auto thr_t0 = t_prev;
+  uint64_t thr_c0 = 0;
   // double-buffered reading: block k+1 is read from the source while the GPU works on block k
   bool have_next = false, looped_next = false;
   size_t got_next = 0;
@@ -1246,11 +1259,6 @@ void worker_main(suscan_analyzer *a)
   };
   while (!a->halt) {
     // ---- requests posted by the GUI thread (they touch what a block in flight is using: let it finish first) ----
-    {
-      bool pending;
-      { std::lock_guard<std::mutex> lk(a->req_m); pending = !a->requests.empty(); }
-      if (pending) finish(flight);
-    }
     for (;;) {
       Request r;
       {
@@ -1259,6 +1267,7 @@ void worker_main(suscan_analyzer *a)
         r = std::move(a->requests.front());
         a->requests.pop_front();
       }
+      finish(flight);                                         // no request is handled under a block in flight
       const unsigned old_n = (unsigned)a->params.detector_params.window_size;
       const int old_w = a->params.detector_params.window;
       const float old_i = a->params.psd_update_int;
@@ -1267,9 +1276,11 @@ void worker_main(suscan_analyzer *a)
         src.seek(r.value);
         consumed = r.value;
         a->position = consumed;
+        thr_t0 = std::chrono::steady_clock::now(); thr_c0 = consumed;       // the throttle paces from here
         continue;
       }
       handle_request(a, r);
+      if (r.kind == Request::SET_THROTTLE) { thr_t0 = std::chrono::steady_clock::now(); thr_c0 = consumed; }
       if (r.kind == Request::SET_PARAMS && (old_n != a->params.detector_params.window_size ||
                                            old_w != a->params.detector_params.window ||
                                            old_i != a->params.psd_update_int)) {
@@ -1333,7 +1344,7 @@ void worker_main(suscan_analyzer *a)
         if (!f.func(f.priv, a, h_flt, a->block, consumed)) fatal = "a baseband filter failed";
       }
     }
-    if (!fatal.empty()) { finish(flight); push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, fatal); break; }
+    if (!fatal.empty()) { (void)reader.wait(&looped_next); finish(flight); push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, fatal); break; }
     // the previous block's channeliser must be done with d_x before this block lands in it (its PSD is on this stream)
     if (a->xfree_set) (void)hipStreamWaitEvent(a->stream, a->ev_xfree, 0);
     if (h_flt) {
@@ -1347,7 +1358,7 @@ void worker_main(suscan_analyzer *a)
     }
     (void)hipEventRecord(a->ev_h2d[cur], a->stream);
     a->h2d_set[cur] = true;
-    if (!fatal.empty()) { finish(flight); push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, fatal); break; }
+    if (!fatal.empty()) { (void)reader.wait(&looped_next); finish(flight); push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, fatal); break; }
     {
       // source conditioning (Suscan/Analyzer.cpp:240-256): I/Q reversal, DC removal -- on the device, in place
       const bool rev = a->iq_reverse, dcr = a->dc_remove;
@@ -1370,6 +1381,7 @@ void worker_main(suscan_analyzer *a)
     const unsigned n = (unsigned)a->params.detector_params.window_size;
     if (!suamd_psd_feed(a->psd, a->d_x, a->navg, n, a->navg, 1.0f / (float)n, SUAMD_PSD_LINEAR, a->d_psd, a->stream)) {
       fatal = suamd_last_error();
+      (void)reader.wait(&looped_next);                        // the helper thread is off the pinned buffer before it is freed
       for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) (void)hipStreamSynchronize(a->istream[k]);
       finish(flight);
       push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, fatal);
@@ -1382,7 +1394,7 @@ void worker_main(suscan_analyzer *a)
       auto *m = static_cast<suscan_analyzer_psd_msg *>(std::calloc(1, sizeof(suscan_analyzer_psd_msg)));
       m->psd_size = n;
       m->psd_data = static_cast<SUFLOAT *>(std::malloc(n * sizeof(SUFLOAT)));
-      m->fc = (int64_t)a->source_cfg.freq;
+      { std::lock_guard<std::mutex> lk(a->req_m); m->fc = (int64_t)a->source_cfg.freq; }
       m->samp_rate = (SUFLOAT)a->source_cfg.samp_rate;
       m->measured_samp_rate = a->measured_rate;
       m->looped = looped ? SU_TRUE : SU_FALSE;
@@ -1418,9 +1430,12 @@ void worker_main(suscan_analyzer *a)
     auto now = std::chrono::steady_clock::now();
     const uint64_t thr = a->throttle;
     if (thr > 0) {
-      const double due = (double)consumed / (double)thr;
-      const double el = std::chrono::duration<double>(now - t_start).count();
-      if (due > el) std::this_thread::sleep_for(std::chrono::duration<double>(due - el));
+      const double due = (double)(consumed - thr_c0) / (double)thr;
+      for (;;) {                                             // short slices: halt / destroy are never kept waiting
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - thr_t0).count();
+        if (!(due > el) || a->halt) break;
+        std::this_thread::sleep_for(std::chrono::duration<double>(std::min(due - el, 0.02)));
+      }
       now = std::chrono::steady_clock::now();
     }
     const double dt = std::chrono::duration<double>(now - t_prev).count();
@@ -1547,6 +1562,96 @@ SUBOOL suscan_source_config_set_path(suscan_source_config_t *c, const char *p)
   return SU_TRUE;
 }
 void suscan_source_config_set_loop(suscan_source_config_t *c, SUBOOL l) { if (c) c->loop = l != 0; }
+suscan_source_config_t *suscan_source_config_clone(const suscan_source_config_t *c) { return c ? new (std::nothrow) suscan_source_config(*c) : nullptr; }
+const char *suscan_source_config_get_label(const suscan_source_config_t *c) { return c ? c->label.c_str() : nullptr; }
+SUBOOL suscan_source_config_set_label(suscan_source_config_t *c, const char *l) { if (!c || !l) return SU_FALSE; c->label = l; return SU_TRUE; }
+const char *suscan_source_config_get_type(const suscan_source_config_t *c) { return c ? c->type.c_str() : nullptr; }
+enum suscan_source_format suscan_source_config_get_format(const suscan_source_config_t *c) { return c ? c->format : SUSCAN_SOURCE_FORMAT_AUTO; }
+void suscan_source_config_set_type_format(suscan_source_config_t *c, const char *t, enum suscan_source_format f)
+{
+  if (!c) return;
+  if (t) c->type = t;
+  c->format = f;
+}
+const char *suscan_source_config_get_path(const suscan_source_config_t *c) { return c && !c->path.empty() ? c->path.c_str() : nullptr; }
+SUFREQ suscan_source_config_get_freq(const suscan_source_config_t *c) { return c ? c->freq : 0; }
+SUFREQ suscan_source_config_get_lnb_freq(const suscan_source_config_t *c) { return c ? c->lnb_freq : 0; }
+void suscan_source_config_set_lnb_freq(suscan_source_config_t *c, SUFREQ f) { if (c) c->lnb_freq = f; }
+unsigned int suscan_source_config_get_samp_rate(const suscan_source_config_t *c) { return c ? c->samp_rate : 0; }
+unsigned int suscan_source_config_get_average(const suscan_source_config_t *c) { return c ? c->average : 1; }
+SUBOOL suscan_source_config_set_average(suscan_source_config_t *c, unsigned int a) { if (!c || a < 1) return SU_FALSE; c->average = a; return SU_TRUE; }
+SUFLOAT suscan_source_config_get_bandwidth(const suscan_source_config_t *c) { return c ? c->bandwidth : 0; }
+void suscan_source_config_set_bandwidth(suscan_source_config_t *c, SUFLOAT b) { if (c) c->bandwidth = b; }
+SUFLOAT suscan_source_config_get_ppm(const suscan_source_config_t *c) { return c ? c->ppm : 0; }
+void suscan_source_config_set_ppm(suscan_source_config_t *c, SUFLOAT p) { if (c) c->ppm = p; }
+SUBOOL suscan_source_config_get_loop(const suscan_source_config_t *c) { return c && c->loop ? SU_TRUE : SU_FALSE; }
+SUBOOL suscan_source_config_get_dc_remove(const suscan_source_config_t *c) { return c && c->dc_remove ? SU_TRUE : SU_FALSE; }
+void suscan_source_config_set_dc_remove(suscan_source_config_t *c, SUBOOL v) { if (c) c->dc_remove = v != 0; }
+SUBOOL suscan_source_config_get_iq_balance(const suscan_source_config_t *c) { return c && c->iq_balance ? SU_TRUE : SU_FALSE; }
+void suscan_source_config_set_iq_balance(suscan_source_config_t *c, SUBOOL v) { if (c) c->iq_balance = v != 0; }
+void suscan_source_config_get_start_time(const suscan_source_config_t *c, struct timeval *tv) { if (c && tv) *tv = c->start_time; }
+void suscan_source_config_set_start_time(suscan_source_config_t *c, struct timeval tv) { if (c) c->start_time = tv; }
+SUBOOL suscan_source_config_file_is_valid(const suscan_source_config_t *c)
+{
+  if (!c || c->type != "file" || c->path.empty()) return SU_FALSE;
+  FILE *fp = std::fopen(c->path.c_str(), "rb");
+  if (!fp) return SU_FALSE;
+  std::fclose(fp);
+  return SU_TRUE;
+}
+SUBOOL suscan_source_config_get_end_time(const suscan_source_config_t *c, struct timeval *tv)
+{
+  // raw payload length / bytes per sample / rate after the start time (a WAV / SigMF container's header is a few
+  // dozen bytes: below the microsecond at any rate this path is used at)
+  if (!c || !tv || c->type != "file" || c->path.empty() || c->samp_rate == 0) return SU_FALSE;
+  FILE *fp = std::fopen(c->path.c_str(), "rb");
+  if (!fp) return SU_FALSE;
+  std::fseek(fp, 0, SEEK_END);
+  const long bytes = std::ftell(fp);
+  std::fclose(fp);
+  if (bytes < 0) return SU_FALSE;
+  unsigned bps = 8;
+  switch (c->format) {
+    case SUSCAN_SOURCE_FORMAT_RAW_UNSIGNED8: case SUSCAN_SOURCE_FORMAT_RAW_SIGNED8: bps = 2; break;
+    case SUSCAN_SOURCE_FORMAT_RAW_SIGNED16: case SUSCAN_SOURCE_FORMAT_WAV: bps = 4; break;
+    default: break;
+  }
+  const double t = (double)c->start_time.tv_sec + 1e-6 * (double)c->start_time.tv_usec + (double)(bytes / bps) / (double)c->samp_rate;
+  tv->tv_sec = (time_t)t;
+  tv->tv_usec = (suseconds_t)((t - std::floor(t)) * 1e6);
+  return SU_TRUE;
+}
+SUBOOL suscan_source_config_is_real_time(const suscan_source_config_t *) { return SU_FALSE; }
+SUBOOL suscan_source_config_is_seekable(const suscan_source_config_t *c) { return c && c->type == "file" ? SU_TRUE : SU_FALSE; }
+SUBOOL suscan_source_config_get_freq_limits(const suscan_source_config_t *c, SUFREQ *mn, SUFREQ *mx)
+{
+  if (!c || !mn || !mx) return SU_FALSE;
+  *mn = -3e11; *mx = 3e11;                                   // what suscan_analyzer_new reports in the source info
+  return SU_TRUE;
+}
+const char *suscan_source_config_get_antenna(const suscan_source_config_t *c) { return c && c->has_antenna ? c->antenna.c_str() : nullptr; }
+SUBOOL suscan_source_config_set_antenna(suscan_source_config_t *c, const char *a) { if (!c || !a) return SU_FALSE; c->antenna = a; c->has_antenna = true; return SU_TRUE; }
+SUFLOAT suscan_source_config_get_gain(const suscan_source_config_t *c, const char *n)
+{
+  if (!c || !n) return 0;
+  auto it = c->gains.find(n);
+  return it == c->gains.end() ? 0 : it->second;
+}
+SUBOOL suscan_source_config_set_gain(suscan_source_config_t *c, const char *n, SUFLOAT v) { if (!c || !n) return SU_FALSE; c->gains[n] = v; return SU_TRUE; }
+const char *suscan_source_config_get_param(const suscan_source_config_t *c, const char *k)
+{
+  if (!c || !k) return nullptr;
+  auto it = c->params.find(k);
+  return it == c->params.end() ? nullptr : it->second.c_str();
+}
+void suscan_source_config_clear_params(suscan_source_config_t *c) { if (c) c->params.clear(); }
+SUBOOL suscan_source_config_walk_params(const suscan_source_config_t *c,
+                                        SUBOOL (*func)(const suscan_source_config_t *, const char *, const char *, void *), void *priv)
+{
+  if (!c || !func) return SU_FALSE;
+  for (const auto &kv : c->params) if (!func(c, kv.first.c_str(), kv.second.c_str(), priv)) return SU_FALSE;
+  return SU_TRUE;
+}
 SUBOOL suscan_source_config_set_param(suscan_source_config_t *c, const char *k, const char *v)
 {
   if (!c || !k || !v) return SU_FALSE;
@@ -1633,6 +1738,62 @@ SUBOOL suscan_config_set_bool(suscan_config_t *cfg, const char *name, SUBOOL v)
   f->as_int = 0; f->as_bool = v ? SU_TRUE : SU_FALSE; f->set = SU_TRUE;
   return SU_TRUE;
 }
+SUBOOL suscan_config_set_string(suscan_config_t *cfg, const char *name, const char *v)
+{
+  auto *f = suscan_config_get_value(cfg, name);
+  if (!f || !v || (f->field->type != SUSCAN_FIELD_TYPE_STRING && f->field->type != SUSCAN_FIELD_TYPE_FILE)) return SU_FALSE;
+  char *dup = strdup(v);
+  if (!dup) return SU_FALSE;
+  std::free(f->as_string); f->as_string = dup; f->set = SU_TRUE;
+  return SU_TRUE;
+}
+SUBOOL suscan_config_desc_has_prefix(const suscan_config_desc_t *desc, const char *prefix)
+{
+  if (!desc || !prefix) return SU_FALSE;
+  const size_t n = std::strlen(prefix);
+  for (unsigned i = 0; i < desc->field_count; ++i)
+    if (!std::strncmp(desc->field_list[i]->name, prefix, n)) return SU_TRUE;
+  return SU_FALSE;
+}
+
+// ---- source info (include/Suscan/Analyzer.h:50-105: init / deep copy / finalize) ----
+void suscan_source_info_init(struct suscan_source_info *info)
+{
+  if (info) std::memset(info, 0, sizeof *info);
+}
+void suscan_source_info_finalize(struct suscan_source_info *info)
+{
+  if (!info) return;
+  std::free(info->antenna);
+  for (unsigned i = 0; i < info->gain_count; ++i) {
+    if (info->gain_list[i]) std::free(info->gain_list[i]->name);
+    std::free(info->gain_list[i]);
+  }
+  std::free(info->gain_list);
+  for (unsigned i = 0; i < info->antenna_count; ++i) std::free(info->antenna_list[i]);
+  std::free(info->antenna_list);
+  std::memset(info, 0, sizeof *info);
+}
+SUBOOL suscan_source_info_init_copy(struct suscan_source_info *dst, const struct suscan_source_info *src)
+{
+  if (!dst || !src) return SU_FALSE;
+  *dst = *src;
+  dst->antenna = src->antenna ? strdup(src->antenna) : nullptr;
+  dst->gain_list = nullptr; dst->antenna_list = nullptr;
+  if (src->gain_count) {
+    dst->gain_list = static_cast<suscan_source_gain_info **>(std::calloc(src->gain_count, sizeof(void *)));
+    for (unsigned i = 0; i < src->gain_count; ++i) {
+      dst->gain_list[i] = static_cast<suscan_source_gain_info *>(std::malloc(sizeof(suscan_source_gain_info)));
+      *dst->gain_list[i] = *src->gain_list[i];
+      dst->gain_list[i]->name = src->gain_list[i]->name ? strdup(src->gain_list[i]->name) : nullptr;
+    }
+  }
+  if (src->antenna_count) {
+    dst->antenna_list = static_cast<char **>(std::calloc(src->antenna_count, sizeof(char *)));
+    for (unsigned i = 0; i < src->antenna_count; ++i) dst->antenna_list[i] = strdup(src->antenna_list[i]);
+  }
+  return SU_TRUE;
+}
 
 // ---- analyzer ----
 suscan_analyzer_t *suscan_analyzer_new(const struct suscan_analyzer_params *params, suscan_source_config_t *config,
@@ -1652,7 +1813,19 @@ suscan_analyzer_t *suscan_analyzer_new(const struct suscan_analyzer_params *para
   a->info.freq_min = -3e11; a->info.freq_max = 3e11;
   a->info.bandwidth = (SUFLOAT)config->samp_rate;
   a->info.seekable = config->type == "file" ? SU_TRUE : SU_FALSE;
-  a->worker = std::thread(worker_main, a);
+  a->worker = std::thread([a] {
+    // an exception on this thread (std::bad_alloc from a per-block vector, a malformed header) must not take the host
+    // process down with std::terminate: the reader gets READ_ERROR + HALT, as for any other source failure
+    try { worker_main(a); }
+    catch (const std::exception &e) {
+      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, std::string("analyzer worker: ") + e.what());
+      push(a, SUSCAN_WORKER_MSG_TYPE_HALT, nullptr);
+    }
+    catch (...) {
+      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, "analyzer worker: unknown exception");
+      push(a, SUSCAN_WORKER_MSG_TYPE_HALT, nullptr);
+    }
+  });
   return a;
 }
 
@@ -1662,6 +1835,7 @@ void suscan_analyzer_destroy(suscan_analyzer_t *a)
   a->halt = true;
   if (a->worker.joinable()) a->worker.join();
   for (auto &r : a->requests) if (r.config) suscan_config_destroy(r.config);
+  suscan_source_info_finalize(&a->info);
   delete a;
 }
 
@@ -1684,6 +1858,16 @@ void suscan_analyzer_dispose_message(uint32_t type, void *ptr)
       std::free(m->spectrum_data);
       std::free(m->spectsrc_list);                           // the names themselves are static
       std::free(m->estimator_list);
+      std::free(m->signal_name);
+      break;
+    }
+    case SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INFO:
+      suscan_source_info_finalize(static_cast<suscan_source_info *>(ptr));
+      break;
+    case SUSCAN_ANALYZER_MESSAGE_TYPE_CHANNEL: {
+      auto *m = static_cast<suscan_analyzer_channel_msg *>(ptr);
+      for (unsigned i = 0; i < m->channel_count; ++i) std::free(m->channel_list[i]);
+      std::free(m->channel_list);
       break;
     }
     case SUSCAN_ANALYZER_MESSAGE_TYPE_SOURCE_INIT:
@@ -1830,8 +2014,11 @@ static SUBOOL post_source_info(suscan_analyzer_t *a)
 SUBOOL suscan_analyzer_set_freq(suscan_analyzer_t *a, SUFREQ freq, SUFREQ lnb)
 {
   if (!a) return SU_FALSE;
-  a->source_cfg.freq = freq;                               // the PSD messages' fc from the next block on
-  a->info.frequency = freq; a->info.lnb = lnb;
+  {
+    std::lock_guard<std::mutex> lk(a->req_m);
+    a->source_cfg.freq = freq;                             // the PSD messages' fc from the next block on
+    a->info.frequency = freq; a->info.lnb = lnb;
+  }
   return post_source_info(a);
 }
 
@@ -1845,28 +2032,32 @@ SUBOOL suscan_analyzer_set_gain(suscan_analyzer_t *a, const char *name, SUFLOAT 
 SUBOOL suscan_analyzer_set_antenna(suscan_analyzer_t *a, const char *name)
 {
   if (!a || !name) return SU_FALSE;
-  { std::lock_guard<std::mutex> lk(a->req_m); a->antenna = name; }
+  {
+    std::lock_guard<std::mutex> lk(a->req_m);
+    a->antenna = name;
+    std::free(a->info.antenna); a->info.antenna = strdup(name);
+  }
   return SU_TRUE;
 }
 
 SUBOOL suscan_analyzer_set_bw(suscan_analyzer_t *a, SUFLOAT bw)
 {
   if (!a || !(bw > 0)) return SU_FALSE;
-  a->info.bandwidth = bw;
+  { std::lock_guard<std::mutex> lk(a->req_m); a->info.bandwidth = bw; }
   return post_source_info(a);
 }
 
 SUBOOL suscan_analyzer_set_ppm(suscan_analyzer_t *a, SUFLOAT ppm)
 {
   if (!a) return SU_FALSE;
-  a->info.ppm = ppm;
+  { std::lock_guard<std::mutex> lk(a->req_m); a->info.ppm = ppm; }
   return post_source_info(a);
 }
 
 SUBOOL suscan_analyzer_set_agc(suscan_analyzer_t *a, SUBOOL enabled)
 {
   if (!a) return SU_FALSE;
-  a->info.agc = enabled ? SU_TRUE : SU_FALSE;
+  { std::lock_guard<std::mutex> lk(a->req_m); a->info.agc = enabled ? SU_TRUE : SU_FALSE; }
   return post_source_info(a);
 }
 
@@ -1874,7 +2065,7 @@ SUBOOL suscan_analyzer_set_dc_remove(suscan_analyzer_t *a, SUBOOL remove)
 {
   if (!a) return SU_FALSE;
   a->dc_remove = remove != 0;
-  a->info.dc_remove = remove ? SU_TRUE : SU_FALSE;
+  { std::lock_guard<std::mutex> lk(a->req_m); a->info.dc_remove = remove ? SU_TRUE : SU_FALSE; }
   return post_source_info(a);
 }
 
@@ -1882,7 +2073,7 @@ SUBOOL suscan_analyzer_set_iq_reverse(suscan_analyzer_t *a, SUBOOL reverse)
 {
   if (!a) return SU_FALSE;
   a->iq_reverse = reverse != 0;
-  a->info.iq_reverse = reverse ? SU_TRUE : SU_FALSE;
+  { std::lock_guard<std::mutex> lk(a->req_m); a->info.iq_reverse = reverse ? SU_TRUE : SU_FALSE; }
   return post_source_info(a);
 }
 
@@ -1898,14 +2089,18 @@ SUBOOL suscan_analyzer_seek(suscan_analyzer_t *a, const struct timeval *pos)
 SUBOOL suscan_analyzer_set_history_size(suscan_analyzer_t *a, SUSCOUNT size)
 {
   if (!a) return SU_FALSE;
-  a->history_size = size;                                  // a file is its own history: nothing to allocate
+  {
+    std::lock_guard<std::mutex> lk(a->req_m);
+    a->history_size = size;                                // a file is its own history: nothing to allocate
+    a->info.history_length = size;
+  }
   return SU_TRUE;
 }
 
 SUBOOL suscan_analyzer_replay(suscan_analyzer_t *a, SUBOOL replay)
 {
   if (!a) return SU_FALSE;
-  a->replay = replay != 0;
+  { std::lock_guard<std::mutex> lk(a->req_m); a->replay = replay != 0; a->info.replay = replay ? SU_TRUE : SU_FALSE; }
   return SU_TRUE;
 }
 

@@ -52,6 +52,16 @@ class SampleBatchMsg(C.Structure):
     _fields_ = [("inspector_id", C.c_uint32), ("samples", C.POINTER(C.c_float)), ("sample_count", C.c_uint64)]
 
 
+class OrbitReport(C.Structure):
+    """struct suscan_orbit_report"""
+    _fields_ = [("rx_time", Timeval), ("satpos", C.c_double * 3), ("freq_corr", C.c_float), ("vlos_vel", C.c_double)]
+
+
+class ChannelMsg(C.Structure):
+    """struct suscan_analyzer_channel_msg"""
+    _fields_ = [("channel_list", C.POINTER(C.POINTER(Channel))), ("channel_count", C.c_uint)]
+
+
 class InspectorMsg(C.Structure):
     _fields_ = [("kind", C.c_int), ("inspector_id", C.c_uint32), ("req_id", C.c_uint32), ("handle", C.c_int32),
                 ("status", C.c_int), ("class_name", C.c_char_p), ("channel", Channel), ("config", C.c_void_p),
@@ -59,15 +69,19 @@ class InspectorMsg(C.Structure):
                 ("lo", C.c_float), ("spectsrc_count", C.c_uint), ("spectsrc_list", C.c_void_p),
                 ("estimator_count", C.c_uint), ("estimator_list", C.c_void_p), ("spectsrc_id", C.c_uint32),
                 ("estimator_id", C.c_uint32), ("spectrum_data", C.c_void_p), ("spectrum_size", C.c_uint64),
-                ("samp_rate", C.c_uint64), ("watermark", C.c_uint64), ("enabled", C.c_int), ("value", C.c_float)]
+                ("samp_rate", C.c_uint64), ("watermark", C.c_uint64), ("enabled", C.c_int), ("value", C.c_float),
+                ("orbit_report", OrbitReport), ("tle_enable", C.c_int), ("signal_name", C.c_char_p),
+                ("signal_value", C.c_double)]
 
 
 class SourceInfo(C.Structure):
     """struct suscan_source_info"""
     _fields_ = [("permissions", C.c_uint64), ("source_samp_rate", C.c_uint64), ("effective_samp_rate", C.c_uint64),
                 ("measured_samp_rate", C.c_float), ("frequency", C.c_double), ("freq_min", C.c_double), ("freq_max", C.c_double),
-                ("lnb", C.c_double), ("bandwidth", C.c_float), ("ppm", C.c_float), ("dc_remove", C.c_int), ("iq_reverse", C.c_int),
-                ("agc", C.c_int), ("seekable", C.c_int), ("source_start", Timeval), ("source_end", Timeval)]
+                ("lnb", C.c_double), ("bandwidth", C.c_float), ("ppm", C.c_float), ("antenna", C.c_char_p),
+                ("dc_remove", C.c_int), ("iq_reverse", C.c_int), ("agc", C.c_int), ("seekable", C.c_int),
+                ("replay", C.c_int), ("history_length", C.c_uint64), ("source_start", Timeval), ("source_end", Timeval),
+                ("gain_list", C.c_void_p), ("gain_count", C.c_uint), ("antenna_list", C.c_void_p), ("antenna_count", C.c_uint)]
 
 
 class EstimatorClass(C.Structure):
@@ -105,6 +119,11 @@ PROTOTYPES = {
     "suscan_config_set_integer": (INT, [VP, C.c_char_p, U64]),
     "suscan_config_set_float": (INT, [VP, C.c_char_p, C.c_float]),
     "suscan_config_set_bool": (INT, [VP, C.c_char_p, INT]),
+    "suscan_config_set_string": (INT, [VP, C.c_char_p, C.c_char_p]),
+    "suscan_config_desc_has_prefix": (INT, [VP, C.c_char_p]),
+    "suscan_source_info_init": (None, [C.POINTER(SourceInfo)]),
+    "suscan_source_info_init_copy": (INT, [C.POINTER(SourceInfo), C.POINTER(SourceInfo)]),
+    "suscan_source_info_finalize": (None, [C.POINTER(SourceInfo)]),
     "suscan_analyzer_new": (VP, [C.POINTER(AnalyzerParams), VP, C.POINTER(MQ)]),
     "suscan_analyzer_destroy": (None, [VP]),
     "suscan_analyzer_read": (VP, [VP, C.POINTER(U32)]),

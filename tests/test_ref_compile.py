@@ -1,0 +1,91 @@
+"""The drop-in boundary, proven by the compiler and the linker.
+
+oracle/Makefile.ref compiles the reference's own live-path wrappers -- Suscan/Analyzer.cpp, MQ.cpp, Message.cpp,
+AnalyzerParams.cpp, AnalyzerRequestTracker.cpp, Config.cpp, Source.cpp, Messages/{PSD,Samples,Inspector,Status,
+SourceInfo,Channel,Generic}Message.cpp -- UNCHANGED, from where they lie under /root/reference, against the product's
+public headers (include/analyzer/analyzer.h, include/sigutils/types.h ...), and links them against
+sigdigger_amd/libsigdigger_amd.so with -Wl,--no-undefined: every suscan_analyzer_* / suscan_mq_* / suscan_config_* /
+suscan_source_config_* / suscan_source_info_* symbol those files call resolves to the product.  (The control plane they
+mention next to it -- XML objects, device discovery, config database -- is stubbed in oracle/ref_stubs.cpp.)
+
+CPU only: here the reference's Suscan::Analyzer must FAIL LOUDLY (no GPU, no CPU path); tests/test_gpu_ref_live.py runs
+the same binary on the MI355X.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import sdref  # noqa: E402
+
+HAVE_REF = os.path.isdir("/root/reference")
+pytestmark = pytest.mark.skipif(not HAVE_REF, reason="/root/reference is not on this machine")
+
+LIVE_TUS = ["Analyzer", "MQ", "Message", "AnalyzerParams", "AnalyzerRequestTracker", "Config", "Source", "Exception"]
+MSG_TUS = ["PSDMessage", "SamplesMessage", "InspectorMessage", "StatusMessage", "SourceInfoMessage", "ChannelMessage",
+           "GenericMessage"]
+
+
+@pytest.fixture(scope="module")
+def built():
+    from sigdigger_amd import build as b
+    b.build()
+    assert sdref.build()
+    return os.path.join(ROOT, "oracle", "_ref")
+
+
+def test_reference_wrappers_compile_unchanged_against_public_headers(built):
+    for tu in LIVE_TUS:
+        assert os.path.exists(os.path.join(built, "obj", "Suscan", tu + ".o")), tu
+    for tu in MSG_TUS:
+        assert os.path.exists(os.path.join(built, "obj", "Suscan", "Messages", tu + ".o")), tu
+    # ... and the Tasks whose work() loops the oracle restates
+    for tu in ["QuadDemodTask", "DelayedConjTask", "HistogramFeeder", "WaveSampler", "CarrierDetector", "DopplerCalculator",
+               "CarrierXlator", "AGCTask", "CostasRecoveryTask", "PLLSyncTask"]:
+        assert os.path.exists(os.path.join(built, "obj", "Tasks", tu + ".o")), tu
+
+
+def test_every_live_path_symbol_resolves_to_the_product_library(built):
+    """nm -u of the reference objects: each undefined suscan_* / su_specttuner_* symbol is exported by libsigdigger_amd.so
+    (or is control plane, listed in oracle/ref_stubs.cpp)."""
+    so = os.path.join(ROOT, "sigdigger_amd", "libsigdigger_amd.so")
+    exported = {l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", so], text=True).splitlines() if l}
+    stubs = open(os.path.join(ROOT, "oracle", "ref_stubs.cpp")).read()
+    wanted = set()
+    for tu in LIVE_TUS:
+        wanted |= _undefined(os.path.join(built, "obj", "Suscan", tu + ".o"))
+    for tu in MSG_TUS:
+        wanted |= _undefined(os.path.join(built, "obj", "Suscan", "Messages", tu + ".o"))
+    wanted = {s for s in wanted if s.startswith(("suscan_", "su_", "sigutils_"))}
+    assert len(wanted) > 80
+    served = {s for s in wanted if s in exported}
+    control_plane = {s for s in wanted - served if s in stubs}
+    assert wanted == served | control_plane, sorted(wanted - served - control_plane)
+    # the whole live ABI is served, none of it stubbed
+    for s in wanted:
+        if s.startswith(("suscan_analyzer_", "suscan_mq_", "suscan_config_", "suscan_source_info_", "su_specttuner_")):
+            assert s in served, s
+
+
+def _undefined(obj):
+    out = subprocess.check_output(["nm", "-u", obj], text=True)
+    return {l.split()[-1] for l in out.splitlines() if l.strip()}
+
+
+def test_reference_analyzer_fails_loudly_without_a_gpu(built, tmp_path):
+    import numpy as np
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present: tests/test_gpu_ref_live.py covers this binary")
+    except ImportError:
+        pass
+    iq = tmp_path / "iq.f32"
+    np.zeros(1 << 16, dtype=np.complex64).tofile(iq)
+    r = subprocess.run([os.path.join(built, "ref_live"), str(iq), "1000000", "4096", "0", "50000", str(tmp_path / "o.bin")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2
+    assert "no CPU fallback" in r.stderr
