@@ -98,6 +98,8 @@ class StatusMsg(C.Structure):
 
 
 VP, U32, U64, INT = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+# SUBOOL f(const suscan_source_config_t *, const char *key, const char *value, void *userdata)
+WALK_PARAMS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p)
 PROTOTYPES = {
     "suscan_mq_init": (INT, [C.POINTER(MQ)]),
     "suscan_mq_finalize": (None, [C.POINTER(MQ)]),
@@ -111,6 +113,42 @@ PROTOTYPES = {
     "suscan_source_config_set_path": (INT, [VP, C.c_char_p]),
     "suscan_source_config_set_loop": (None, [VP, INT]),
     "suscan_source_config_set_param": (INT, [VP, C.c_char_p, C.c_char_p]),
+    "suscan_source_config_clone": (VP, [VP]),
+    "suscan_source_config_get_label": (C.c_char_p, [VP]),
+    "suscan_source_config_set_label": (INT, [VP, C.c_char_p]),
+    "suscan_source_config_get_type": (C.c_char_p, [VP]),
+    "suscan_source_config_get_format": (INT, [VP]),
+    "suscan_source_config_set_type_format": (None, [VP, C.c_char_p, INT]),
+    "suscan_source_config_get_path": (C.c_char_p, [VP]),
+    "suscan_source_config_get_freq": (C.c_double, [VP]),
+    "suscan_source_config_get_lnb_freq": (C.c_double, [VP]),
+    "suscan_source_config_set_lnb_freq": (None, [VP, C.c_double]),
+    "suscan_source_config_get_samp_rate": (C.c_uint, [VP]),
+    "suscan_source_config_get_average": (C.c_uint, [VP]),
+    "suscan_source_config_set_average": (INT, [VP, C.c_uint]),
+    "suscan_source_config_get_bandwidth": (C.c_float, [VP]),
+    "suscan_source_config_set_bandwidth": (None, [VP, C.c_float]),
+    "suscan_source_config_get_ppm": (C.c_float, [VP]),
+    "suscan_source_config_set_ppm": (None, [VP, C.c_float]),
+    "suscan_source_config_get_loop": (INT, [VP]),
+    "suscan_source_config_get_dc_remove": (INT, [VP]),
+    "suscan_source_config_set_dc_remove": (None, [VP, INT]),
+    "suscan_source_config_get_iq_balance": (INT, [VP]),
+    "suscan_source_config_set_iq_balance": (None, [VP, INT]),
+    "suscan_source_config_get_start_time": (None, [VP, C.POINTER(Timeval)]),
+    "suscan_source_config_set_start_time": (None, [VP, Timeval]),
+    "suscan_source_config_get_end_time": (INT, [VP, C.POINTER(Timeval)]),
+    "suscan_source_config_file_is_valid": (INT, [VP]),
+    "suscan_source_config_is_real_time": (INT, [VP]),
+    "suscan_source_config_is_seekable": (INT, [VP]),
+    "suscan_source_config_get_freq_limits": (INT, [VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "suscan_source_config_get_antenna": (C.c_char_p, [VP]),
+    "suscan_source_config_set_antenna": (INT, [VP, C.c_char_p]),
+    "suscan_source_config_get_gain": (C.c_float, [VP, C.c_char_p]),
+    "suscan_source_config_set_gain": (INT, [VP, C.c_char_p, C.c_float]),
+    "suscan_source_config_get_param": (C.c_char_p, [VP, C.c_char_p]),
+    "suscan_source_config_clear_params": (None, [VP]),
+    "suscan_source_config_walk_params": (INT, [VP, WALK_PARAMS, VP]),
     "suscan_inspector_config_desc": (VP, [C.c_char_p]),
     "suscan_config_new": (VP, [VP]),
     "suscan_config_dup": (VP, [VP]),

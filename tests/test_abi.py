@@ -180,3 +180,58 @@ def test_psd_ttl_rule_literal_transcription():
         assert st.rt_delta_real == m_rtDeltaReal and st.rt_calibrations == m_rtCalibrations
         dropped += not got
     assert dropped == 2                                    # frames 50 and 120; 51 is late too but the source looped
+
+
+def test_source_config_round_trips_what_source_cpp_reads():
+    """Suscan::Source::Config's getters (Suscan/Source.cpp:120-410) on a config built the way ProfileConfigTab does; no GPU
+    involved (a source config is host state)."""
+    import ctypes as C
+    from sigdigger_amd import suscan
+    L = suscan.load()
+    c = L.suscan_source_config_new(b"file", 4)
+    assert L.suscan_source_config_get_type(c) == b"file" and L.suscan_source_config_get_format(c) == 4
+    assert L.suscan_source_config_get_path(c) is None and L.suscan_source_config_get_antenna(c) is None
+    L.suscan_source_config_set_samp_rate(c, 2_400_000)
+    L.suscan_source_config_set_freq(c, 433.92e6)
+    L.suscan_source_config_set_lnb_freq(c, 9.75e9)
+    assert L.suscan_source_config_set_average(c, 4) and not L.suscan_source_config_set_average(c, 0)
+    L.suscan_source_config_set_bandwidth(c, 2e6)
+    L.suscan_source_config_set_ppm(c, 1.5)
+    L.suscan_source_config_set_dc_remove(c, 1)
+    L.suscan_source_config_set_iq_balance(c, 1)
+    L.suscan_source_config_set_loop(c, 1)
+    assert L.suscan_source_config_set_label(c, b"capture") and L.suscan_source_config_set_antenna(c, b"RX2")
+    assert L.suscan_source_config_set_gain(c, b"LNA", 12.5)
+    assert L.suscan_source_config_set_param(c, b"k1", b"v1") and L.suscan_source_config_set_param(c, b"k2", b"v2")
+    L.suscan_source_config_set_start_time(c, suscan.Timeval(1000, 250000))
+    d = L.suscan_source_config_clone(c)
+    L.suscan_source_config_destroy(c)
+    assert L.suscan_source_config_get_samp_rate(d) == 2_400_000 and L.suscan_source_config_get_average(d) == 4
+    assert L.suscan_source_config_get_freq(d) == 433.92e6 and L.suscan_source_config_get_lnb_freq(d) == 9.75e9
+    assert L.suscan_source_config_get_bandwidth(d) == 2e6 and L.suscan_source_config_get_ppm(d) == 1.5
+    assert L.suscan_source_config_get_dc_remove(d) and L.suscan_source_config_get_iq_balance(d) and L.suscan_source_config_get_loop(d)
+    assert L.suscan_source_config_get_label(d) == b"capture" and L.suscan_source_config_get_antenna(d) == b"RX2"
+    assert L.suscan_source_config_get_gain(d, b"LNA") == 12.5 and L.suscan_source_config_get_gain(d, b"nope") == 0
+    assert L.suscan_source_config_get_param(d, b"k2") == b"v2" and L.suscan_source_config_get_param(d, b"zz") is None
+    seen = []
+    cb = suscan.WALK_PARAMS(lambda cfg, k, v, u: (seen.append((k, v)), 1)[1])
+    assert L.suscan_source_config_walk_params(d, cb, None) and seen == [(b"k1", b"v1"), (b"k2", b"v2")]
+    tv = suscan.Timeval()
+    L.suscan_source_config_get_start_time(d, C.byref(tv))
+    assert (tv.tv_sec, tv.tv_usec) == (1000, 250000)
+    assert not L.suscan_source_config_is_real_time(d) and L.suscan_source_config_is_seekable(d)
+    assert not L.suscan_source_config_file_is_valid(d) and not L.suscan_source_config_get_end_time(d, C.byref(tv))
+    lo, hi = C.c_double(), C.c_double()
+    assert L.suscan_source_config_get_freq_limits(d, C.byref(lo), C.byref(hi)) and lo.value < 0 < hi.value
+    L.suscan_source_config_set_type_format(d, b"tonegen", 1)
+    assert L.suscan_source_config_get_type(d) == b"tonegen" and not L.suscan_source_config_is_seekable(d)
+    L.suscan_source_config_clear_params(d)
+    assert L.suscan_source_config_get_param(d, b"k1") is None
+    L.suscan_source_config_destroy(d)
+    # source info: init / deep copy / finalize (include/Suscan/Analyzer.h:50-105)
+    a, b = suscan.SourceInfo(), suscan.SourceInfo()
+    L.suscan_source_info_init(C.byref(a))
+    a.frequency, a.history_length = 1e9, 77
+    assert L.suscan_source_info_init_copy(C.byref(b), C.byref(a)) and b.frequency == 1e9 and b.history_length == 77
+    L.suscan_source_info_finalize(C.byref(b))
+    L.suscan_source_info_finalize(C.byref(a))
