@@ -8,7 +8,7 @@
  * source, let the request tracker open a "psk" inspector and set its id, push an inspector config, collect
  * PSDMessage / SamplesMessage objects from the Qt signals until end of stream, then halt.
  *
- * usage: ref_live <iq.f32> <samp_rate> <window_size> <chan_fc_hz> <chan_bw_hz> <out.bin>
+ * usage: ref_live <iq.f32> <samp_rate> <window_size> <chan_fc_hz> <chan_bw_hz> <out.bin> [class = psk | raw]
  * out.bin: u32 magic 'RLV1', u32 npsd, u32 psd_size, u32 nbatches, u64 nsamples, f32 fs, f32 equiv_fs, f32 bandwidth,
  *          u32 inspector_id_seen, then psd_size floats (first PSD frame as PSDMessage delivers it: shifted dB),
  *          then nsamples complex64 (all SamplesMessage payloads in order).
@@ -32,6 +32,7 @@ int main(int argc, char **argv)
   const unsigned window = (unsigned)std::atol(argv[3]);
   const double chan_fc = std::atof(argv[4]), chan_bw = std::atof(argv[5]);
   const char *out_path = argv[6];
+  const std::string cls = argc > 7 ? argv[7] : "psk";
 
   Suscan::Source::Config cfg("file", SUSCAN_SOURCE_FORMAT_RAW_FLOAT32);
   cfg.setPath(path);
@@ -71,10 +72,11 @@ int main(int argc, char **argv)
     Suscan::Channel ch;
     ch.fc = chan_fc; ch.ft = 0; ch.bw = chan_bw;
     ch.fLow = -0.5 * chan_bw; ch.fHigh = 0.5 * chan_bw;
-    tracker.requestOpen("psk", ch, QVariant(), false);
+    tracker.requestOpen(cls, ch, QVariant(), false);
   });
   QObject::connect(&tracker, &Suscan::AnalyzerRequestTracker::opened, [&](Suscan::AnalyzerRequest const &req) {
     bb_fs = (float)req.basebandRate; equiv_fs = req.equivRate; bandwidth = req.bandwidth;
+    if (cls != "psk") return;                                 // "raw": the channel samples as they are
     Suscan::Config c(req.config);                             // dup'd by the tracker (AnalyzerRequestTracker.cpp:139-141)
     c.set("afc.costas-order", (uint64_t)2);
     c.set("afc.bits-per-symbol", (uint64_t)2);

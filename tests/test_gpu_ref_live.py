@@ -22,8 +22,8 @@ REF_LIVE = os.path.join(ROOT, "oracle", "_ref", "ref_live")
 FS, N = 1_000_000, 4096
 
 
-def _run_ref_live(iq, out, fc, bw):
-    r = subprocess.run([REF_LIVE, str(iq), str(FS), str(N), str(fc), str(bw), str(out)], capture_output=True, text=True,
+def _run_ref_live(iq, out, fc, bw, cls):
+    r = subprocess.run([REF_LIVE, str(iq), str(FS), str(N), str(fc), str(bw), str(out), cls], capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0, r.stderr
     raw = open(out, "rb").read()
@@ -37,7 +37,7 @@ def _run_ref_live(iq, out, fc, bw):
     return dict(npsd=npsd, nbatches=nb, fs=bb, equiv_fs=eq, bw=bwr, id=seen_id, psd=psd.copy(), samples=sam.copy())
 
 
-def _run_ctypes(iq, fc, bw, equiv_fs):
+def _run_ctypes(iq, fc, bw, equiv_fs, cls):
     """The same requests, in the same order, through the ctypes binding."""
     Lb = suscan.load()
     mq = suscan.MQ()
@@ -60,14 +60,14 @@ def _run_ctypes(iq, fc, bw, equiv_fs):
             break
         if t == suscan.MSG_SOURCE_INFO and "req" not in state:
             ch = suscan.Channel(fc=fc, f_lo=-bw / 2, f_hi=bw / 2, bw=bw, ft=0)
-            assert Lb.suscan_analyzer_open_ex_async(an, b"psk", C.byref(ch), 0, -1, 1)
+            assert Lb.suscan_analyzer_open_ex_async(an, cls.encode(), C.byref(ch), 0, -1, 1)
             state["req"] = True
         elif t == suscan.MSG_INSPECTOR:
             m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
             if m.kind == suscan.KIND_OPEN:
                 state["handle"] = m.handle
                 assert Lb.suscan_analyzer_set_inspector_id_async(an, m.handle, state.get("id", 1), 2)
-            elif m.kind == suscan.KIND_SET_ID:
+            elif m.kind == suscan.KIND_SET_ID and cls == "psk":
                 desc = Lb.suscan_inspector_config_desc(b"psk")
                 c = Lb.suscan_config_new(desc)
                 assert Lb.suscan_config_set_integer(c, b"afc.costas-order", 2)
@@ -97,14 +97,23 @@ def test_reference_analyzer_class_drives_the_gpu_library(tmp_path, sdo):
     iq = tmp_path / "iq.f32"
     x.tofile(iq)
     fc, bw = 0.1 * FS, 0.12 * FS
-    ref = _run_ref_live(iq, tmp_path / "o.bin", fc, bw)
+    # "raw": the channel samples themselves.  A request lands on whatever block boundary the worker has reached, so the
+    # two runs open the channel at different instants; the channeliser carries no state beyond its taps, hence the tails
+    # of the two streams (both end at the end of the file) are bit-identical
+    ref = _run_ref_live(iq, tmp_path / "o.bin", fc, bw, "raw")
     assert ref["npsd"] >= nblk and ref["nbatches"] > 0 and ref["samples"].size > 1000
     assert ref["fs"] == FS and 0 < ref["equiv_fs"] <= FS and ref["id"] != 0
-    psd, samples = _run_ctypes(iq, fc, bw, ref["equiv_fs"])
+    psd, samples = _run_ctypes(iq, fc, bw, ref["equiv_fs"], "raw")
     # PSDMessage's constructor has shifted the frame and taken dB in place (Suscan/Messages/PSDMessage.cpp:26-39)
     assert np.array_equal(ref["psd"], sdo.psd_shift_db(psd))
-    # the request order is the same, but a request lands on whatever block boundary the worker is at: compare the
-    # streams from the first symbol both runs delivered after the config took effect -- the tail is bit-identical
     n = min(samples.size, ref["samples"].size, 4096)
     assert n > 500
     assert np.array_equal(ref["samples"][-n:], samples[-n:])
+    # "psk" with a config pushed through Suscan::Config: recovered QPSK symbols (the loops' state depends on when the
+    # config took effect, so this is a constellation check, not a bit comparison)
+    psk = _run_ref_live(iq, tmp_path / "p.bin", fc, bw, "psk")
+    sym = psk["samples"][-2000:]
+    assert sym.size == 2000
+    ang = np.angle(sym[np.abs(sym) > 0.3 * np.median(np.abs(sym))])
+    off = np.abs(((ang - np.pi / 4) + np.pi / 4) % (np.pi / 2) - np.pi / 4)
+    assert np.median(off) < 0.2
