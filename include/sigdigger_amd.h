@@ -105,6 +105,33 @@ SUAMD_API SUBOOL suamd_inspector_spectrum_db_shift(suamd_ctx_t *ctx, SUFLOAT *d_
                                                    SUSCOUNT nspectra, void *stream);
 
 /* ------------------------------------------------------------------------------------ */
+/* T2 / N2: FFT channeliser (su_specttuner)                                              */
+/* ------------------------------------------------------------------------------------ */
+/* The device side of su_specttuner_new / _open_channel / _feed_bulk (Tasks/LPFTask.cpp:52-69,83-87; the channeliser
+ * behind every suscan inspector): windows of `window_size` samples advancing by half a window, ONE forward FFT per
+ * window shared by all channels, per channel a bin pick around its (even) centre bin, its frequency response, an
+ * inverse FFT at the decimated rate window_size / size and a sin^2 cross-fade with the previous window (SPEC.md C2).
+ * include/sigutils/specttuner.h is the sigutils-named host front end of the same object. */
+typedef struct suamd_specttuner suamd_specttuner_t;
+SUAMD_API suamd_specttuner_t *suamd_specttuner_new(suamd_ctx_t *ctx, unsigned window_size /* 4096 */);
+SUAMD_API void   suamd_specttuner_destroy(suamd_specttuner_t *st);
+/* f0, bw: angular frequency (rad / sample); guard >= 1 sizes the channel for bw * guard (guard = 2 pi / bw: no
+ * decimation, LPFTask.cpp:65); precise: the rounding of f0 to an even bin is corrected by an NCO at the output rate.
+ * Returns the channel index (>= 0) or -1.  Channels opened / closed between feeds keep the others' state. */
+SUAMD_API int    suamd_specttuner_open_channel(suamd_specttuner_t *st, double f0, double bw, double guard, SUBOOL precise);
+SUAMD_API SUBOOL suamd_specttuner_close_channel(suamd_specttuner_t *st, int channel);
+SUAMD_API unsigned suamd_specttuner_channel_size(const suamd_specttuner_t *st, int channel);        /* bins = inverse FFT size */
+SUAMD_API unsigned suamd_specttuner_channel_decimation(const suamd_specttuner_t *st, int channel);  /* window_size / size */
+/* Feeds `len` samples (device), len a multiple of window_size / 2.  The first feed needs a whole window before it
+ * yields anything (len / (W/2) - 1 blocks); later feeds yield len / (W/2) blocks of size / 2 samples per channel.
+ * Channel c's samples of this feed go to d_y[c*view.chan_stride + m*view.time_stride], m = 0 ..; counts[c] (host,
+ * may be NULL) receives how many.  Any split of a stream into feeds gives the same samples. */
+SUAMD_API SUBOOL suamd_specttuner_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len,
+                                       suamd_complex *d_y, suamd_view view, SUSCOUNT *counts, void *stream);
+/* windows per workgroup run (default 8): a run re-transforms the window before it */
+SUAMD_API SUBOOL suamd_specttuner_set_run(suamd_specttuner_t *st, unsigned run);
+
+/* ------------------------------------------------------------------------------------ */
 /* T1 / K4: NCO carrier translate                                                        */
 /* ------------------------------------------------------------------------------------ */
 /* su_ncqo_init(-relFreq) + su_ncqo_set_phase(-phase) + per-sample su_ncqo_read loop

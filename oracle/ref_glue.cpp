@@ -43,6 +43,7 @@
 #include <AGCTask.h>
 #include <CostasRecoveryTask.h>
 #include <PLLSyncTask.h>
+#include <LPFTask.h>
 #include <Scanner.h>
 #include <SNREstimator.h>
 #include <Decider.h>
@@ -232,6 +233,20 @@ void ref_pll_task(const SUCOMPLEX *x, SUCOMPLEX *y, size_t len, float cutoff)
   ensure_app();
   PLLSyncTask t(x, y, len, cutoff);
   while (t.work()) {}
+}
+
+/* LPFTask (Tasks/LPFTask.cpp:44-124), unchanged, on the PRODUCT's su_specttuner_* (the GPU channeliser): needs a device */
+int ref_lpf_task(const SUCOMPLEX *x, SUCOMPLEX *y, size_t len, float bw)
+{
+  ensure_app();
+  try {
+    LPFTask t(x, y, len, bw);
+    while (t.work()) {}
+  } catch (Suscan::Exception &e) {
+    std::fprintf(stderr, "ref_lpf_task: %s\n", e.what());
+    return 0;
+  }
+  return 1;
 }
 
 /* HistogramFeeder::work (Tasks/HistogramFeeder.cpp:35-87): space 0 amplitude, 1 phase, 2 frequency; returns count */

@@ -1447,3 +1447,121 @@ void sdo_doppler_calc(const sdo_c32 *data, size_t len, float fs, double f0, floa
   res[2] = maxVal;
   free(buf); free(re); free(im);
 }
+
+/* ---- C2: FFT channeliser (su_specttuner semantics) [SPEC, UPSTREAM-RECOLLECTION] ------------------------------------
+ * SPEC.md section C2.  Window W, hop H = W/2.  Window k = stream samples [kH, kH + W); output block k (halfsz samples)
+ * = alpha .* y_k[0:halfsz] + beta .* y_{k-1}[halfsz:size], y_k = IDFT_size(h .* pick(DFT_W(window k))), y_{-1} = 0. */
+void sdo_specttuner_geometry(unsigned W, double f0, double bw, double guard, sdo_st_geom *g)
+{
+  double actual_bw = bw * guard, k;
+  unsigned min_size, size = 1;
+  if (actual_bw > 2.0 * SDO_PI) actual_bw = 2.0 * SDO_PI;
+  k = actual_bw / (2.0 * SDO_PI);
+  min_size = (unsigned)ceil(k * (double)W);
+  while (size < min_size) size <<= 1;
+  if (size < 16) size = 16;                              /* smallest inverse transform served (a wider guard band) */
+  if (size > W) size = W;
+  g->size = size;
+  g->halfsz = size / 2;
+  g->width = (unsigned)ceil((double)min_size / guard);
+  if (g->width > size) g->width = size;
+  g->halfw = g->width >> 1;
+  if (g->halfw < 1) g->halfw = 1;
+  g->decimation = W / size;
+  g->center = (int)(2.0 * floor(f0 / (4.0 * SDO_PI) * (double)W + 0.5));    /* even bin: a hop advances it by whole turns */
+  g->center &= (int)(W - 1);
+  {
+    /* residual of the rounding, corrected at the output rate when `precise` */
+    double f0w = fmod(f0, 2.0 * SDO_PI), ef = (double)g->center * 2.0 * SDO_PI / (double)W, lo;
+    if (f0w < 0) f0w += 2.0 * SDO_PI;
+    lo = f0w - ef;
+    if (lo > SDO_PI) lo -= 2.0 * SDO_PI;
+    if (lo < -SDO_PI) lo += 2.0 * SDO_PI;
+    g->lo = lo;
+    g->dphase = (uint32_t)(int64_t)llround(-lo * (double)g->decimation / (2.0 * SDO_PI) * 4294967296.0);
+  }
+}
+
+void sdo_specttuner_response(unsigned W, unsigned size, unsigned halfw, sdo_c32 *hk)
+{
+  /* brick wall -> time domain -> centred, Blackman-Harris, back -> frequency domain; k = 1/W folded in */
+  double *re = calloc(size, sizeof *re), *im = calloc(size, sizeof *im);
+  const unsigned half = size / 2;
+  unsigned i;
+  for (i = 0; i < size; ++i) re[i] = (i < halfw || i >= size - halfw) ? 1.0 : 0.0;
+  for (i = 0; i < size; ++i) im[i] = -im[i];
+  sdo_fft_f64(re, im, size);                              /* backward transform = conj(forward(conj)) */
+  for (i = 0; i < size; ++i) { re[i] /= (double)size; im[i] = -im[i] / (double)size; }
+  for (i = 0; i < half; ++i) {                            /* centre */
+    double t = re[i]; re[i] = re[i + half]; re[i + half] = t;
+    t = im[i]; im[i] = im[i + half]; im[i + half] = t;
+  }
+  for (i = 0; i < size; ++i) {
+    const double t = 2.0 * SDO_PI * (double)i / (double)(size - 1);
+    const double w = 0.35875 - 0.48829 * cos(t) + 0.14128 * cos(2 * t) - 0.01168 * cos(3 * t);
+    re[i] *= w; im[i] *= w;
+  }
+  for (i = 0; i < half; ++i) {                            /* ... and back */
+    double t = re[i]; re[i] = re[i + half]; re[i + half] = t;
+    t = im[i]; im[i] = im[i + half]; im[i + half] = t;
+  }
+  sdo_fft_f64(re, im, size);
+  for (i = 0; i < size; ++i) {
+    const int pass = i < halfw || i >= size - halfw;
+    hk[i].re = pass ? (float)(re[i] / (double)W) : 0.0f;
+    hk[i].im = pass ? (float)(im[i] / (double)W) : 0.0f;
+  }
+  free(re); free(im);
+}
+
+void sdo_specttuner_crossfade(unsigned size, float *win)
+{
+  unsigned i;
+  for (i = 0; i < size; ++i) { const double s = sin(SDO_PI * (double)i / (double)size); win[i] = (float)(s * s); }
+}
+
+size_t sdo_specttuner_run(const sdo_c32 *x, size_t len, unsigned W, double f0, double bw, double guard, int precise,
+                          sdo_c32 *out, size_t cap)
+{
+  sdo_st_geom g;
+  const unsigned H = W / 2;
+  size_t k, nwin, n = 0;
+  unsigned i;
+  sdo_c32 *hk, *prev;
+  float *win;
+  double *re, *im, *cr, *ci;
+  sdo_specttuner_geometry(W, f0, bw, guard, &g);
+  if (len < W) return 0;
+  nwin = (len - W) / H + 1;
+  hk = malloc(sizeof *hk * g.size); prev = calloc(g.size, sizeof *prev); win = malloc(sizeof *win * g.size);
+  re = malloc(sizeof *re * W); im = malloc(sizeof *im * W); cr = malloc(sizeof *cr * g.size); ci = malloc(sizeof *ci * g.size);
+  sdo_specttuner_response(W, g.size, g.halfw, hk);
+  sdo_specttuner_crossfade(g.size, win);
+  for (k = 0; k < nwin; ++k) {
+    const sdo_c32 *w = x + k * H;
+    for (i = 0; i < W; ++i) { re[i] = w[i].re; im[i] = w[i].im; }
+    sdo_fft_f64(re, im, W);
+    for (i = 0; i < g.size; ++i) {
+      const unsigned idx = (i < g.halfsz ? (unsigned)g.center + i : (unsigned)g.center + i + W - g.size) & (W - 1);
+      /* the spectrum is binary32 on the device; the products are binary32 too */
+      const float xr = (float)re[idx], xi = (float)im[idx];
+      const float yr = xr * hk[i].re - xi * hk[i].im, yi = xr * hk[i].im + xi * hk[i].re;
+      cr[i] = yr; ci[i] = -(double)yi;
+    }
+    sdo_fft_f64(cr, ci, g.size);                          /* unnormalised backward transform */
+    for (i = 0; i < g.halfsz && n < cap; ++i, ++n) {
+      const float a = win[i], b = win[i + g.halfsz];
+      const float yr = (float)cr[i], yi = (float)-ci[i];
+      float orr = a * yr + b * prev[i + g.halfsz].re, oi = a * yi + b * prev[i + g.halfsz].im;
+      if (precise) {
+        float c, s;
+        sdo_phasor_u32((uint32_t)n * g.dphase, &c, &s);
+        { const float tr = orr * c - oi * s, ti = orr * s + oi * c; orr = tr; oi = ti; }
+      }
+      out[n].re = orr; out[n].im = oi;
+    }
+    for (i = 0; i < g.size; ++i) { prev[i].re = (float)cr[i]; prev[i].im = (float)-ci[i]; }
+  }
+  free(hk); free(prev); free(win); free(re); free(im); free(cr); free(ci);
+  return n;
+}

@@ -260,6 +260,16 @@ void sdo_specview_feed(sdo_specview *v, const float *psd, const float *count, si
                        double freqMin, double freqMax, int adjustSides);  /* Scanner.cpp:239-256 */
 void sdo_specview_interpolate(sdo_specview *v);                          /* Scanner.cpp:56-116 */
 
+/* ---- C2: FFT channeliser, su_specttuner semantics (SPEC.md section C2) [UPSTREAM-RECOLLECTION] -------------------------
+ * Tasks/LPFTask.cpp:52-69,83-87 (f0, bw, guard in angular units; guard = 2 pi / bw: no decimation) */
+typedef struct { unsigned size, halfsz, width, halfw, decimation; int center; double lo; uint32_t dphase; } sdo_st_geom;
+void   sdo_specttuner_geometry(unsigned W, double f0, double bw, double guard, sdo_st_geom *g);
+void   sdo_specttuner_response(unsigned W, unsigned size, unsigned halfw, sdo_c32 *hk);   /* k h[i], k = 1/W */
+void   sdo_specttuner_crossfade(unsigned size, float *win);                              /* sin^2(pi i / size) */
+/* one channel over a whole stream: windows k = 0 .. (len - W)/(W/2), halfsz outputs each; returns the count */
+size_t sdo_specttuner_run(const sdo_c32 *x, size_t len, unsigned W, double f0, double bw, double guard, int precise,
+                          sdo_c32 *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

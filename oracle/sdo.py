@@ -570,3 +570,33 @@ class SpectrumView:
 
     def interpolate(self):
         lib().sdo_specview_interpolate(C.byref(self.v))
+
+
+# ---- C2: FFT channeliser (su_specttuner semantics) ------------------------------------------------
+class StGeom(C.Structure):
+    _fields_ = [("size", C.c_uint), ("halfsz", C.c_uint), ("width", C.c_uint), ("halfw", C.c_uint), ("decimation", C.c_uint),
+                ("center", C.c_int), ("lo", C.c_double), ("dphase", C.c_uint32)]
+
+
+def specttuner_geometry(W, f0, bw, guard):
+    g = StGeom()
+    lib().sdo_specttuner_geometry(C.c_uint(W), C.c_double(f0), C.c_double(bw), C.c_double(guard), C.byref(g))
+    return g
+
+
+def specttuner_response(W, size, halfw):
+    hk = np.empty(size, dtype=c32)
+    lib().sdo_specttuner_response(C.c_uint(W), C.c_uint(size), C.c_uint(halfw), _p(hk))
+    return hk
+
+
+def specttuner_run(x, W, f0, bw, guard, precise=False):
+    x = _c(x)
+    g = specttuner_geometry(W, f0, bw, guard)
+    cap = (x.size // (W // 2) + 1) * g.halfsz
+    out = np.empty(cap, dtype=c32)
+    f = lib().sdo_specttuner_run
+    f.restype = C.c_size_t
+    n = f(_p(x), C.c_size_t(x.size), C.c_uint(W), C.c_double(f0), C.c_double(bw), C.c_double(guard), C.c_int(int(precise)),
+          _p(out), C.c_size_t(cap))
+    return out[:n].copy()

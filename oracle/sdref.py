@@ -110,6 +110,14 @@ def pll_task(x, cutoff):
     return _task2(lib().ref_pll_task, x, C.c_float(cutoff))
 
 
+def lpf_task(x, bw):
+    """The reference's LPFTask on the product's GPU-backed su_specttuner_* (GPU only).  None if the task threw."""
+    x = _c(x)
+    y = np.zeros_like(x)
+    ok = lib().ref_lpf_task(_p(x), _p(y), C.c_size_t(x.size), C.c_float(bw))
+    return y if ok else None
+
+
 def histogram_feeder(x, space):
     x = _c(x)
     out = np.empty(x.size, dtype=np.float32)

@@ -24,13 +24,15 @@ SOURCES = {
     "loops.hip": ["-ffp-contract=off"],
     "specview.hip": ["-ffp-contract=off"],
     "fft.hip": ["-ffp-contract=fast"],
+    "specttuner.hip": ["-ffp-contract=off"],
+    "specttuner_host.cpp": ["-ffp-contract=off"],
     "ingest.hip": ["-ffp-contract=off"],
     "stages.hip": ["-ffp-contract=off"],
     "capi.hip":  ["-ffp-contract=off"],
     "analyzer.cpp": ["-ffp-contract=off"],
     "export.cpp": ["-ffp-contract=off"],
 }
-HEADERS = ["kernels.hpp", "sd_math.hpp", os.path.join("..", "..", "include", "sigdigger_amd.h"),
+HEADERS = ["kernels.hpp", "sd_math.hpp", "fft_core.hpp", os.path.join("..", "..", "include", "sigdigger_amd.h"),
            os.path.join("..", "..", "include", "suscan_amd.h")]
 
 

@@ -59,6 +59,33 @@ hipError_t chan_gang_plan(const ChanFeedArgs &a, ChanGangItem *item);
 hipError_t chan_gang_feed(const ChanGangItem *d_items, int n, unsigned max_tiles, unsigned max_lds, hipStream_t st);
 hipError_t chan_update_hist(void *hist_next, const void *hist, const void *x, long long len, int ntaps, hipStream_t st);
 
+// ---- specttuner.hip: FFT channeliser (SPEC.md section C2) ----
+struct StChan {                 // one channel of a size group
+  int center;                   // centre bin (even) of the W-point spectrum
+  int hsel;                     // which response table hk[hsel][size]
+  int row;                      // output row: element m of the feed at y[row*cs + m*ms]
+  int precise;                  // residual NCO on
+  uint32_t dphase;              // its step per OUTPUT sample
+  unsigned long long n_open;    // the group's output counter when the channel was opened (its NCO starts there)
+};
+struct StArgs {
+  const void *x;                // len samples (device); the virtual stream is hist ++ x when have_hist
+  const void *hist;             // the W/2 samples before x[0]
+  int have_hist;
+  long long nwin;               // windows in this feed: window w = virtual samples [w W/2, w W/2 + W)
+  int run;                      // windows per workgroup
+  const void *tw_w, *tw_s;      // W- and size-point twiddle tables (complex)
+  const StChan *chans; int nchan;
+  const void *hk;               // [nsel][size] complex: k h[i] (zero outside the pass band)
+  const float *win;             // [size]: sin^2(pi i / size)
+  const void *prev_in; void *prev_out;   // [nchan][size/2]: second half of the last block of the previous feed (ping-pong)
+  unsigned long long n0;        // outputs per channel emitted by earlier feeds (phase of the residual NCO)
+  void *y; View yv;
+};
+// channels one workgroup serves side by side for inverse transforms of 2^log2s points
+int st_channels_per_group(int log2s);
+hipError_t specttuner_feed(int log2w, int log2s, const StArgs &a, hipStream_t st);
+
 // ---- loops.hip ----
 hipError_t quad_demod_batch(const void *x, View xv, void *y, View yv, int nchan, long long len,
                             const void *prev, int first, void *prev_out, hipStream_t st);

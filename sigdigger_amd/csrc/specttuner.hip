@@ -1,0 +1,218 @@
+// specttuner.hip -- FFT channeliser for gfx950 (SPEC.md section C2; rows T2 / N2): what su_specttuner does for
+// Tasks/LPFTask.cpp:52-69,83-87 and for every inspector channel of the analyzer, as ONE launch per channel size.
+//
+// Overlap-save filter bank: the wideband stream is cut into windows of W samples that advance by H = W/2; a window is
+// transformed ONCE (W-point forward FFT) and every channel takes what it needs from that spectrum: `size` bins around
+// its (even) centre bin, times its frequency response, a `size`-point inverse FFT back to the time domain at the
+// decimated rate W/size, and a sin^2 / cos^2 cross-fade of the first half of this window's block with the second half of
+// the previous window's.  Compulsory HBM traffic 8 B per input sample + 8 B per output sample; per channel the work no
+// longer scales with the tap count but with size log size per W/2 input samples.
+//
+// One workgroup (256 threads) owns a run of R consecutive windows (after a warm-up window that only provides the
+// "previous half" of the run's first block; the first run takes it from the carried state instead).  Per window:
+//   1. forward FFT: three radix-16 passes on registers (fft_core.hpp, as psd.hip), spectrum left in LDS in natural order;
+//      the samples of the NEXT window are requested from HBM right after pass 0 (software pipeline);
+//   2. channel stage: the workgroup's threads split into groups of TPI = size/16 threads, one channel per group,
+//      256/TPI channels side by side (grid.y covers more): gather the channel's bins from the LDS spectrum, multiply by
+//      k h[i], inverse transform (conjugate, forward passes on the group's own LDS scratch, conjugate), cross-fade with
+//      the previous window's half (kept in registers: in the last pass's geometry a thread holds y[i] and y[i + size/2]
+//      for the same i), optional residual NCO ("precise"), store through the view.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.hpp"
+#include "fft_core.hpp"
+#include "sd_math.hpp"
+
+namespace {
+using namespace fftcore;
+
+constexpr int ST_THREADS = 256;
+
+template <int LOG2S> struct StGeomT {
+  static constexpr int S    = 1 << LOG2S;
+  static constexpr int TPI  = (LOG2S == 5) ? 4 : (S / 16);     // threads per inverse transform (E = 16 points each; 8 for S = 32)
+  static constexpr int E    = S / TPI;
+  static constexpr int CPP  = ST_THREADS / TPI;                // channels side by side in one workgroup
+  static constexpr int PADS = S + S / 16 + 1;                  // a group's LDS scratch (elements)
+};
+
+template <int LOG2W, int LOG2S>
+__global__ __launch_bounds__(ST_THREADS, 2) void st_kernel(sdk::StArgs a)
+{
+  __builtin_amdgcn_s_setprio(3);   // ahead of the resident recurrence wavefronts (see chan_fir_kernel)
+  using G = StGeomT<LOG2S>;
+  using PW = Plan<LOG2W>;
+  using PS = Plan<LOG2S>;
+  constexpr int W = 1 << LOG2W, H = W / 2, S = G::S, HS = S / 2;
+  constexpr int EW = W / ST_THREADS;                           // forward: points per thread
+  constexpr int R0W = 1 << PW::bits(0), NB0W = EW / R0W;
+  constexpr int RLW = 1 << PW::bits(PW::P - 1), NBLW = EW / RLW;
+  constexpr int R0S = 1 << PS::bits(0), NB0S = G::E / R0S;
+  constexpr int RLS = 1 << PS::bits(PS::P - 1), NBLS = G::E / RLS;
+  static_assert(RLS >= 2, "the cross-fade pairs outputs q and q + RL/2 of one butterfly");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cf *spec = reinterpret_cast<cf *>(smem);                     // W + W/16 + 1: forward passes in place, then the spectrum
+  cf *scratch = spec + (W + W / 16 + 1);
+  const int tid0 = threadIdx.x;
+  const int grp = tid0 / G::TPI, tl0 = tid0 % G::TPI;
+  const int ch = blockIdx.y * G::CPP + grp;                    // channel of this thread's group (in the size group)
+  const bool live = ch < a.nchan;
+  const sdk::StChan cd = a.chans[live ? ch : 0];
+  cf *gscr = scratch + grp * G::PADS;
+
+  TwBase tbw, tbs;
+  load_tw_base<LOG2W, ST_THREADS, 0>(tbw, reinterpret_cast<const cf *>(a.tw_w), tid0);
+  load_tw_base<LOG2S, G::TPI, 0>(tbs, reinterpret_cast<const cf *>(a.tw_s), tl0);
+
+  // run of windows [w_begin, w_end); w_begin - 1 is the warm-up window (none for the first run: carried state)
+  const long long w_begin = (long long)blockIdx.x * a.run, w_end = (w_begin + a.run < a.nwin) ? w_begin + a.run : a.nwin;
+  const long long w_first = w_begin > 0 ? w_begin - 1 : 0;
+  const cf *x = reinterpret_cast<const cf *>(a.x), *hist = reinterpret_cast<const cf *>(a.hist);
+  const long long off = a.have_hist ? H : 0;                   // virtual stream = hist (H samples) ++ x
+
+  cf prev[NBLS][RLS / 2];                                      // y_{w-1}[i + S/2] for this thread's i
+#pragma unroll
+  for (int b = 0; b < NBLS; ++b)
+#pragma unroll
+    for (int q = 0; q < RLS / 2; ++q) {
+      const int i = tl0 + b * G::TPI + q * (S / RLS);
+      prev[b][q] = (w_begin == 0 && live) ? reinterpret_cast<const cf *>(a.prev_in)[(long long)ch * HS + i] : cf{0.f, 0.f};
+    }
+
+  cf nxt[EW];
+  auto request = [&](long long w) {
+    const cf *pa = (w == 0 && a.have_hist) ? hist : x + (w * H - off);
+    const cf *pb = x + (w * H + H - off);
+#pragma unroll
+    for (int b = 0; b < NB0W; ++b) {
+      const int j = tid0 + b * ST_THREADS;
+#pragma unroll
+      for (int q = 0; q < R0W; ++q) {
+        const int i = j + q * (W / R0W);                         // j < W / R0W: the first half of the window is q < R0W / 2
+        nxt[b * R0W + q] = q < R0W / 2 ? pa[i] : pb[i - H];
+      }
+    }
+  };
+  request(w_first);
+  for (long long w = w_first; w < w_end; ++w) {
+    int tid = tid0, tl = tl0;
+    asm volatile("" : "+v"(tid), "+v"(tl));                    // see psd_kernel: keeps LICM from hoisting every derived twiddle
+    cf v[EW];
+#pragma unroll
+    for (int i = 0; i < EW; ++i) v[i] = nxt[i];
+    // ---- 1. forward transform (no window function: su_specttuner's forward FFT is rectangular) ----
+    fft_pass<LOG2W, ST_THREADS, 0, 1>(v, spec, tbw, tid, nullptr);
+    if (w + 1 < w_end) request(w + 1);
+    PassRunner<LOG2W, ST_THREADS, 1, 1>::run(v, spec, tbw, tid, nullptr);
+    // v[b*RL + q] = X[j + q*W/RL]; the last pass's gather was followed by a barrier: spec may take the spectrum
+#pragma unroll
+    for (int b = 0; b < NBLW; ++b) {
+      cf *sp = spec + lpad(tid + b * ST_THREADS);
+#pragma unroll
+      for (int q = 0; q < RLW; ++q) sp[q * ((W / RLW) + (W / RLW) / 16)] = v[b * RLW + q];
+    }
+    __syncthreads();
+    // ---- 2. channel stage ----
+    cf u[G::E];
+    {
+      const cf *hk = reinterpret_cast<const cf *>(a.hk) + (long long)cd.hsel * S;
+#pragma unroll
+      for (int b = 0; b < NB0S; ++b) {
+        const int j = tl + b * G::TPI;
+#pragma unroll
+        for (int q = 0; q < R0S; ++q) {
+          const int i = j + q * (S / R0S);
+          const int idx = (cd.center + i + (i < HS ? 0 : W - S)) & (W - 1);
+          const cf X = spec[lpad(idx)], hh = hk[i];
+          // binary32 products as SPEC.md C2 states them (unfused), conjugated for the inverse transform
+          const float yr = X.x * hh.x - X.y * hh.y, yi = X.x * hh.y + X.y * hh.x;
+          u[b * R0S + q] = cf{yr, -yi};
+        }
+      }
+    }
+    PassRunner<LOG2S, G::TPI, 0, 1>::run(u, gscr, tbs, tl, nullptr);
+    // u[b*RL + q] = conj(y[j + q*S/RL]), j = tl + b*TPI: q < RL/2 is the first half of the block, q + RL/2 its partner
+    const bool emit = w >= w_begin;
+    const float *win = a.win;
+#pragma unroll
+    for (int b = 0; b < NBLS; ++b) {
+#pragma unroll
+      for (int q = 0; q < RLS / 2; ++q) {
+        const int i = tl + b * G::TPI + q * (S / RLS);
+        const cf cur = cf{u[b * RLS + q].x, -u[b * RLS + q].y};
+        const cf nx = cf{u[b * RLS + q + RLS / 2].x, -u[b * RLS + q + RLS / 2].y};
+        if (emit && live) {
+          const float al = win[i], be = win[i + HS];
+          float orr = al * cur.x + be * prev[b][q].x, oi = al * cur.y + be * prev[b][q].y;
+          const unsigned long long m = (unsigned long long)w * HS + i;      // output index within this feed
+          if (cd.precise) {
+            float c, s;
+            sd::phasor_u32((uint32_t)(a.n0 - cd.n_open + m) * cd.dphase, c, s);
+            const float tr = orr * c - oi * s, ti = orr * s + oi * c;
+            orr = tr; oi = ti;
+          }
+          reinterpret_cast<cf *>(a.y)[(long long)cd.row * a.yv.cs + (long long)m * a.yv.ms] = cf{orr, oi};
+        }
+        prev[b][q] = nx;
+      }
+    }
+    // the group scratch and the spectrum are rewritten by the next window's passes: its pass 0 ends with a barrier
+    // only after writing spec -- order this window's spectrum reads before that
+    __syncthreads();
+  }
+  // carry the last window's second half to the next feed
+  if (w_end == a.nwin && live) {
+#pragma unroll
+    for (int b = 0; b < NBLS; ++b)
+#pragma unroll
+      for (int q = 0; q < RLS / 2; ++q) {
+        const int i = tl0 + b * G::TPI + q * (S / RLS);
+        reinterpret_cast<cf *>(a.prev_out)[(long long)ch * HS + i] = prev[b][q];
+      }
+  }
+}
+
+template <int LOG2W, int LOG2S>
+hipError_t launch_st(const sdk::StArgs &a, hipStream_t st)
+{
+  using G = StGeomT<LOG2S>;
+  constexpr int W = 1 << LOG2W;
+  const size_t lds = sizeof(cf) * ((size_t)(W + W / 16 + 1) + (size_t)G::CPP * G::PADS);
+  auto kern = st_kernel<LOG2W, LOG2S>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const unsigned nruns = (unsigned)((a.nwin + a.run - 1) / a.run);
+  const unsigned ny = (unsigned)((a.nchan + G::CPP - 1) / G::CPP);
+  hipLaunchKernelGGL(kern, dim3(nruns, ny), dim3(ST_THREADS), lds, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+namespace sdk {
+
+int st_channels_per_group(int log2s) { return log2s == 5 ? 64 : (256 * 16) >> log2s; }
+
+hipError_t specttuner_feed(int log2w, int log2s, const StArgs &a, hipStream_t st)
+{
+  if (log2w != 12) return hipErrorInvalidValue;
+  if (a.nwin <= 0 || a.nchan <= 0) return hipSuccess;
+  switch (log2s) {
+    case 4:  return launch_st<12, 4>(a, st);
+    case 5:  return launch_st<12, 5>(a, st);
+    case 6:  return launch_st<12, 6>(a, st);
+    case 7:  return launch_st<12, 7>(a, st);
+    case 8:  return launch_st<12, 8>(a, st);
+    case 9:  return launch_st<12, 9>(a, st);
+    case 10: return launch_st<12, 10>(a, st);
+    case 11: return launch_st<12, 11>(a, st);
+    case 12: return launch_st<12, 12>(a, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace sdk

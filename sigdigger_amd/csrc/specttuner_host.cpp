@@ -1,0 +1,505 @@
+// specttuner_host.cpp -- host side of the FFT channeliser (kernel: specttuner.hip; SPEC.md section C2):
+//   suamd_specttuner_*   device-resident block interface (include/sigdigger_amd.h), used by the analyzer and the bench;
+//   su_specttuner_*      the libsigutils names and callback contract (include/sigutils/specttuner.h) that
+//                        Tasks/LPFTask.cpp:52-69,83-87,104-107,123 is written against -- it links unchanged.
+// Channel geometry and the frequency response are designed here in double precision (not on the hot path); there is
+// no CPU implementation of the channeliser itself: without a gfx950 device the constructors fail.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "../../include/sigdigger_amd.h"
+#include "kernels.hpp"
+
+void suamd_set_error(const char *fmt, ...);                // capi.hip
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+struct c32 { float re, im; };
+
+// iterative radix-2 transform in binary64 (design only), sign = -1 forward, +1 backward, unnormalised
+void fft64(std::vector<double> &re, std::vector<double> &im, int sign)
+{
+  const size_t n = re.size();
+  for (size_t i = 1, j = 0; i < n; ++i) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const size_t half = len >> 1;
+    for (size_t k = 0; k < half; ++k) {
+      const double ang = (double)sign * 2.0 * kPi * (double)k / (double)len, wr = std::cos(ang), wi = std::sin(ang);
+      for (size_t i = k; i < n; i += len) {
+        const double ur = re[i], ui = im[i];
+        const double vr = re[i + half] * wr - im[i + half] * wi, vi = re[i + half] * wi + im[i + half] * wr;
+        re[i] = ur + vr; im[i] = ui + vi; re[i + half] = ur - vr; im[i + half] = ui - vi;
+      }
+    }
+  }
+}
+
+struct Geom { unsigned size, halfsz, width, halfw, decimation; int center, log2s; uint32_t dphase; };
+
+// SPEC.md C2: channel sizing (su_specttuner_open_channel's arithmetic as recollected in SURVEY.md Appendix C)
+Geom design_geometry(unsigned W, double f0, double bw, double guard)
+{
+  Geom g{};
+  double actual_bw = bw * guard;
+  if (actual_bw > 2.0 * kPi) actual_bw = 2.0 * kPi;
+  const double k = actual_bw / (2.0 * kPi);
+  const unsigned min_size = (unsigned)std::ceil(k * (double)W);
+  unsigned size = 1;
+  while (size < min_size) size <<= 1;
+  if (size < 16) size = 16;
+  if (size > W) size = W;
+  g.size = size; g.halfsz = size / 2;
+  g.width = (unsigned)std::ceil((double)min_size / guard);
+  if (g.width > size) g.width = size;
+  g.halfw = std::max(1u, g.width >> 1);
+  g.decimation = W / size;
+  g.center = (int)(2.0 * std::floor(f0 / (4.0 * kPi) * (double)W + 0.5)) & (int)(W - 1);
+  double f0w = std::fmod(f0, 2.0 * kPi);
+  if (f0w < 0) f0w += 2.0 * kPi;
+  double lo = f0w - (double)g.center * 2.0 * kPi / (double)W;
+  if (lo > kPi) lo -= 2.0 * kPi;
+  if (lo < -kPi) lo += 2.0 * kPi;
+  g.dphase = (uint32_t)(int64_t)std::llround(-lo * (double)g.decimation / (2.0 * kPi) * 4294967296.0);
+  g.log2s = 0;
+  while ((1u << g.log2s) < size) ++g.log2s;
+  return g;
+}
+
+// k h[i]: brick wall of 2 halfw bins -> time domain -> centred, Blackman-Harris, back -> frequency domain; k = 1/W
+std::vector<c32> design_response(unsigned W, unsigned size, unsigned halfw)
+{
+  std::vector<double> re(size, 0.0), im(size, 0.0);
+  const unsigned half = size / 2;
+  for (unsigned i = 0; i < size; ++i) re[i] = (i < halfw || i >= size - halfw) ? 1.0 : 0.0;
+  fft64(re, im, +1);
+  for (unsigned i = 0; i < size; ++i) { re[i] /= (double)size; im[i] /= (double)size; }
+  for (unsigned i = 0; i < half; ++i) { std::swap(re[i], re[i + half]); std::swap(im[i], im[i + half]); }
+  for (unsigned i = 0; i < size; ++i) {
+    const double t = 2.0 * kPi * (double)i / (double)(size - 1);
+    const double w = 0.35875 - 0.48829 * std::cos(t) + 0.14128 * std::cos(2 * t) - 0.01168 * std::cos(3 * t);
+    re[i] *= w; im[i] *= w;
+  }
+  for (unsigned i = 0; i < half; ++i) { std::swap(re[i], re[i + half]); std::swap(im[i], im[i + half]); }
+  fft64(re, im, -1);
+  std::vector<c32> hk(size);
+  for (unsigned i = 0; i < size; ++i) {
+    const bool pass = i < halfw || i >= size - halfw;
+    hk[i].re = pass ? (float)(re[i] / (double)W) : 0.0f;
+    hk[i].im = pass ? (float)(im[i] / (double)W) : 0.0f;
+  }
+  return hk;
+}
+
+std::vector<c32> twiddles(unsigned n)
+{
+  std::vector<c32> tw(n);
+  for (unsigned i = 0; i < n; ++i) {
+    const double ang = -2.0 * kPi * (double)i / (double)n;
+    tw[i].re = (float)std::cos(ang); tw[i].im = (float)std::sin(ang);
+  }
+  return tw;
+}
+
+template <typename T> T *dev_upload_new(const std::vector<T> &v)
+{
+  void *p = nullptr;
+  if (hipMalloc(&p, std::max<size_t>(1, v.size()) * sizeof(T)) != hipSuccess) return nullptr;
+  if (!v.empty() && hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p); return nullptr; }
+  return static_cast<T *>(p);
+}
+
+struct Channel {
+  bool open = false;
+  Geom g{};
+  bool precise = false;
+  unsigned long long n_open = 0;       // the size group's output counter when the channel joined it
+};
+
+// all open channels of one inverse-transform size: one launch
+struct SizeGroup {
+  int log2s = 0;
+  std::vector<int> members;            // channel indices, in table order
+  sdk::StChan *d_chans = nullptr;
+  c32 *d_hk = nullptr, *d_tw = nullptr;
+  float *d_win = nullptr;
+  c32 *d_prev[2] = {nullptr, nullptr};
+  int prev_cur = 0;
+  unsigned long long nout = 0;         // outputs per channel emitted so far
+  bool dirty = true;
+  void release()
+  {
+    for (void *p : {(void *)d_chans, (void *)d_hk, (void *)d_tw, (void *)d_win, (void *)d_prev[0], (void *)d_prev[1]}) if (p) (void)hipFree(p);
+    d_chans = nullptr; d_hk = d_tw = nullptr; d_win = nullptr; d_prev[0] = d_prev[1] = nullptr;
+  }
+};
+
+}  // namespace
+
+struct suamd_specttuner {
+  suamd_ctx_t *ctx = nullptr;
+  unsigned W = 4096, H = 2048;
+  int log2w = 12;
+  unsigned run = 8;
+  c32 *d_tw_w = nullptr;
+  c32 *d_hist[2] = {nullptr, nullptr};
+  int hist_cur = 0;
+  bool have_hist = false;
+  std::vector<Channel> ch;
+  std::map<int, SizeGroup> groups;
+};
+
+namespace {
+
+// (re)builds a group's device tables after its membership changed; surviving members keep their cross-fade state
+bool rebuild_group(suamd_specttuner *st, SizeGroup &g, const std::vector<int> &old_members, c32 *old_prev)
+{
+  const unsigned S = 1u << g.log2s, HS = S / 2;
+  const size_t n = g.members.size();
+  std::vector<sdk::StChan> tab(n);
+  std::vector<unsigned> halfws;
+  for (size_t k = 0; k < n; ++k) {
+    const Channel &c = st->ch[g.members[k]];
+    size_t sel = std::find(halfws.begin(), halfws.end(), c.g.halfw) - halfws.begin();
+    if (sel == halfws.size()) halfws.push_back(c.g.halfw);
+    tab[k].center = c.g.center; tab[k].hsel = (int)sel; tab[k].row = g.members[k]; tab[k].precise = c.precise ? 1 : 0;
+    tab[k].dphase = c.g.dphase;
+    tab[k].n_open = c.n_open;
+  }
+  std::vector<c32> hk;
+  for (unsigned hw : halfws) { std::vector<c32> h = design_response(st->W, S, hw); hk.insert(hk.end(), h.begin(), h.end()); }
+  if (g.d_chans) (void)hipFree(g.d_chans);
+  if (g.d_hk) (void)hipFree(g.d_hk);
+  g.d_chans = dev_upload_new(tab);
+  g.d_hk = dev_upload_new(hk);
+  if (!g.d_tw) g.d_tw = dev_upload_new(twiddles(S));
+  if (!g.d_win) {
+    std::vector<float> win(S);
+    for (unsigned i = 0; i < S; ++i) { const double s = std::sin(kPi * (double)i / (double)S); win[i] = (float)(s * s); }
+    g.d_win = dev_upload_new(win);
+  }
+  c32 *np[2] = {nullptr, nullptr};
+  for (int p = 0; p < 2; ++p) {
+    if (hipMalloc((void **)&np[p], std::max<size_t>(1, n) * HS * sizeof(c32)) != hipSuccess) return false;
+    if (hipMemset(np[p], 0, std::max<size_t>(1, n) * HS * sizeof(c32)) != hipSuccess) return false;
+  }
+  if (old_prev) {
+    for (size_t k = 0; k < n; ++k) {
+      const auto it = std::find(old_members.begin(), old_members.end(), g.members[k]);
+      if (it == old_members.end()) continue;
+      const size_t ok = (size_t)(it - old_members.begin());
+      if (hipMemcpy(np[0] + k * HS, old_prev + ok * HS, HS * sizeof(c32), hipMemcpyDeviceToDevice) != hipSuccess) return false;
+    }
+  }
+  for (int p = 0; p < 2; ++p) { if (g.d_prev[p]) (void)hipFree(g.d_prev[p]); g.d_prev[p] = np[p]; }
+  g.prev_cur = 0;
+  g.dirty = false;
+  return g.d_chans && g.d_hk && g.d_tw && g.d_win;
+}
+
+}  // namespace
+
+extern "C" {
+
+suamd_specttuner_t *suamd_specttuner_new(suamd_ctx_t *ctx, unsigned window_size)
+{
+  if (!ctx) { suamd_set_error("null context"); return nullptr; }
+  if (window_size != 4096) { suamd_set_error("specttuner window_size %u unsupported (4096, su_specttuner's default)", window_size); return nullptr; }
+  if (hipSetDevice(suamd_ctx_device(ctx)) != hipSuccess) { suamd_set_error("hipSetDevice failed"); return nullptr; }
+  auto *st = new (std::nothrow) suamd_specttuner();
+  if (!st) { suamd_set_error("out of memory"); return nullptr; }
+  st->ctx = ctx; st->W = window_size; st->H = window_size / 2; st->log2w = 12;
+  st->d_tw_w = dev_upload_new(twiddles(st->W));
+  bool ok = st->d_tw_w != nullptr;
+  for (int p = 0; p < 2 && ok; ++p) ok = hipMalloc((void **)&st->d_hist[p], st->H * sizeof(c32)) == hipSuccess;
+  if (!ok) { suamd_set_error("device allocation failed"); suamd_specttuner_destroy(st); return nullptr; }
+  return st;
+}
+
+void suamd_specttuner_destroy(suamd_specttuner_t *st)
+{
+  if (!st) return;
+  for (auto &kv : st->groups) kv.second.release();
+  if (st->d_tw_w) (void)hipFree(st->d_tw_w);
+  for (int p = 0; p < 2; ++p) if (st->d_hist[p]) (void)hipFree(st->d_hist[p]);
+  delete st;
+}
+
+int suamd_specttuner_open_channel(suamd_specttuner_t *st, double f0, double bw, double guard, SUBOOL precise)
+{
+  if (!st) { suamd_set_error("null specttuner"); return -1; }
+  if (!(bw > 0) || !(guard >= 1) || !std::isfinite(f0)) { suamd_set_error("bad channel parameters (bw > 0, guard >= 1)"); return -1; }
+  if (hipSetDevice(suamd_ctx_device(st->ctx)) != hipSuccess) { suamd_set_error("hipSetDevice failed"); return -1; }
+  Channel c;
+  c.open = true; c.g = design_geometry(st->W, f0, bw, guard); c.precise = precise != 0;
+  int idx = -1;
+  for (size_t i = 0; i < st->ch.size(); ++i) if (!st->ch[i].open) { idx = (int)i; break; }
+  if (idx < 0) { st->ch.push_back(Channel()); idx = (int)st->ch.size() - 1; }
+  SizeGroup &g = st->groups[c.g.log2s];
+  g.log2s = c.g.log2s;
+  c.n_open = g.nout;
+  st->ch[idx] = c;
+  // keep the others' state: the old table / prev buffer stay until the rebuild has copied from them
+  const std::vector<int> old = g.members;
+  g.members.push_back(idx);
+  (void)hipDeviceSynchronize();                               // a feed still in flight reads the old tables
+  c32 *old_prev = g.d_prev[g.prev_cur];
+  g.d_prev[g.prev_cur] = nullptr;
+  const bool ok = rebuild_group(st, g, old, old_prev);
+  if (old_prev) (void)hipFree(old_prev);
+  if (!ok) { suamd_set_error("device allocation failed"); return -1; }
+  return idx;
+}
+
+SUBOOL suamd_specttuner_close_channel(suamd_specttuner_t *st, int channel)
+{
+  if (!st || channel < 0 || (size_t)channel >= st->ch.size() || !st->ch[channel].open) { suamd_set_error("no such channel"); return SU_FALSE; }
+  if (hipSetDevice(suamd_ctx_device(st->ctx)) != hipSuccess) { suamd_set_error("hipSetDevice failed"); return SU_FALSE; }
+  SizeGroup &g = st->groups[st->ch[channel].g.log2s];
+  const std::vector<int> old = g.members;
+  g.members.erase(std::find(g.members.begin(), g.members.end(), channel));
+  st->ch[channel].open = false;
+  (void)hipDeviceSynchronize();
+  c32 *old_prev = g.d_prev[g.prev_cur];
+  g.d_prev[g.prev_cur] = nullptr;
+  const bool ok = rebuild_group(st, g, old, old_prev);
+  if (old_prev) (void)hipFree(old_prev);
+  if (g.members.empty()) { g.release(); st->groups.erase(g.log2s); }
+  if (!ok) { suamd_set_error("device allocation failed"); return SU_FALSE; }
+  return SU_TRUE;
+}
+
+unsigned suamd_specttuner_channel_size(const suamd_specttuner_t *st, int c)
+{
+  return (st && c >= 0 && (size_t)c < st->ch.size() && st->ch[c].open) ? st->ch[c].g.size : 0;
+}
+unsigned suamd_specttuner_channel_decimation(const suamd_specttuner_t *st, int c)
+{
+  return (st && c >= 0 && (size_t)c < st->ch.size() && st->ch[c].open) ? st->ch[c].g.decimation : 0;
+}
+
+SUBOOL suamd_specttuner_set_run(suamd_specttuner_t *st, unsigned run)
+{
+  if (!st || run < 1 || run > 4096) { suamd_set_error("run out of range"); return SU_FALSE; }
+  st->run = run;
+  return SU_TRUE;
+}
+
+SUBOOL suamd_specttuner_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_y, suamd_view view,
+                             SUSCOUNT *counts, void *stream)
+{
+  if (!st || (len && !d_x)) { suamd_set_error("null argument"); return SU_FALSE; }
+  if (len % st->H) { suamd_set_error("len must be a multiple of half a window (%u)", st->H); return SU_FALSE; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (counts) for (size_t i = 0; i < st->ch.size(); ++i) counts[i] = 0;
+  if (len == 0) return SU_TRUE;
+  const long long nwin = (long long)(len / st->H) - (st->have_hist ? 0 : 1);
+  if (nwin > 0) {
+    for (auto &kv : st->groups) {
+      SizeGroup &g = kv.second;
+      if (g.members.empty()) continue;
+      if (!d_y) { suamd_set_error("null output"); return SU_FALSE; }
+      sdk::StArgs a{};
+      a.x = d_x; a.hist = st->d_hist[st->hist_cur]; a.have_hist = st->have_hist ? 1 : 0;
+      a.nwin = nwin; a.run = (int)st->run;
+      a.tw_w = st->d_tw_w; a.tw_s = g.d_tw;
+      a.chans = g.d_chans; a.nchan = (int)g.members.size();
+      a.hk = g.d_hk; a.win = g.d_win;
+      a.prev_in = g.d_prev[g.prev_cur]; a.prev_out = g.d_prev[g.prev_cur ^ 1];
+      a.n0 = g.nout;
+      a.y = d_y; a.yv = sdk::View{(long long)view.chan_stride, (long long)view.time_stride};
+      const hipError_t e = sdk::specttuner_feed(st->log2w, g.log2s, a, s);
+      if (e != hipSuccess) { suamd_set_error("specttuner launch failed: %s", hipGetErrorString(e)); return SU_FALSE; }
+      g.prev_cur ^= 1;
+      const unsigned HS = (1u << g.log2s) / 2;
+      g.nout += (unsigned long long)nwin * HS;
+      if (counts) for (int c : g.members) counts[c] = (SUSCOUNT)nwin * HS;
+    }
+  }
+  // the last half window is the next feed's history
+  if (hipMemcpyAsync(st->d_hist[st->hist_cur ^ 1], reinterpret_cast<const c32 *>(d_x) + (len - st->H), st->H * sizeof(c32),
+                     hipMemcpyDeviceToDevice, s) != hipSuccess) { suamd_set_error("history copy failed"); return SU_FALSE; }
+  st->hist_cur ^= 1;
+  st->have_hist = true;
+  return SU_TRUE;
+}
+
+}  // extern "C"
+
+// ==========================================================================================================
+// libsigutils front end: su_specttuner_* (include/sigutils/specttuner.h)
+// ==========================================================================================================
+#include <complex>
+#define SUCOMPLEX std::complex<float>
+struct sigutils_specttuner_params { SUSCOUNT window_size; SUBOOL early_windowing; };
+struct sigutils_specttuner_channel;
+struct sigutils_specttuner_channel_params {
+  SUFLOAT f0, delta_f, bw, guard; SUBOOL precise; void *privdata;
+  SUBOOL (*on_data)(const struct sigutils_specttuner_channel *channel, void *privdata, const SUCOMPLEX *data, SUSCOUNT size);
+};
+struct sigutils_specttuner;
+struct sigutils_specttuner_channel {
+  sigutils_specttuner_channel_params params;
+  sigutils_specttuner *owner;
+  int index;
+};
+
+struct sigutils_specttuner {
+  suamd_ctx_t *ctx = nullptr;
+  suamd_specttuner_t *st = nullptr;
+  unsigned W = 0, H = 0;
+  static constexpr unsigned CAP_HALVES = 64;           // staging capacity, half windows
+  c32 *h_in = nullptr, *d_in = nullptr;                // pinned staging / device input
+  c32 *h_out = nullptr, *d_out = nullptr;              // [channel][row_len]
+  size_t out_rows = 0, row_len = 0;
+  size_t fill = 0;
+  hipStream_t stream = nullptr;
+  std::vector<std::unique_ptr<sigutils_specttuner_channel>> channels;
+
+  bool ensure_out(size_t rows)
+  {
+    // a channel yields size/2 <= W/2 samples per half window fed: CAP_HALVES * H per flush at most
+    if (rows <= out_rows) return true;
+    if (h_out) (void)hipHostFree(h_out);
+    if (d_out) (void)hipFree(d_out);
+    h_out = d_out = nullptr;
+    out_rows = std::max<size_t>(rows, 4); row_len = (size_t)CAP_HALVES * H + 16;
+    if (hipHostMalloc((void **)&h_out, out_rows * row_len * sizeof(c32), hipHostMallocDefault) != hipSuccess) return false;
+    if (hipMalloc((void **)&d_out, out_rows * row_len * sizeof(c32)) != hipSuccess) return false;
+    return true;
+  }
+
+  // runs every complete half window in the staging buffer through the device and hands the results out
+  bool flush()
+  {
+    const size_t nproc = (fill / H) * H;
+    if (nproc == 0) return true;
+    size_t rows = 0;
+    for (auto &c : channels) if (c) rows = std::max<size_t>(rows, (size_t)c->index + 1);
+    if (!ensure_out(std::max<size_t>(rows, 1))) { suamd_set_error("allocation failed"); return false; }
+    if (hipMemcpyAsync(d_in, h_in, nproc * sizeof(c32), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
+    std::vector<SUSCOUNT> counts(std::max<size_t>(rows, 1), 0);
+    const suamd_view v{(SUSCOUNT)row_len, 1};
+    if (!suamd_specttuner_feed(st, reinterpret_cast<const suamd_complex *>(d_in), nproc, reinterpret_cast<suamd_complex *>(d_out), v,
+                               counts.data(), stream)) return false;
+    for (auto &c : channels) {
+      if (!c || counts[c->index] == 0) continue;
+      if (hipMemcpyAsync(h_out + (size_t)c->index * row_len, d_out + (size_t)c->index * row_len, counts[c->index] * sizeof(c32),
+                         hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
+    }
+    if (hipStreamSynchronize(stream) != hipSuccess) { suamd_set_error("device failure in the channeliser"); return false; }
+    std::memmove(h_in, h_in + nproc, (fill - nproc) * sizeof(c32));
+    fill -= nproc;
+    bool ok = true;
+    for (auto &c : channels) {
+      if (!c || counts[c->index] == 0 || !c->params.on_data) continue;
+      // the pointer stays valid until the next feed (Tasks/LPFTask.cpp:32)
+      if (!c->params.on_data(c.get(), c->params.privdata, reinterpret_cast<const SUCOMPLEX *>(h_out + (size_t)c->index * row_len),
+                             counts[c->index])) ok = false;
+    }
+    return ok;
+  }
+};
+
+extern "C" {
+
+SUAMD_API sigutils_specttuner *su_specttuner_new(const struct sigutils_specttuner_params *params)
+{
+  if (!params) { suamd_set_error("null parameters"); return nullptr; }
+  auto *t = new (std::nothrow) sigutils_specttuner();
+  if (!t) return nullptr;
+  const char *dev = std::getenv("SUAMD_DEVICE");
+  t->ctx = suamd_ctx_new(dev ? std::atoi(dev) : 0);
+  if (t->ctx) t->st = suamd_specttuner_new(t->ctx, (unsigned)params->window_size);
+  bool ok = t->st != nullptr;
+  if (ok) {
+    t->W = (unsigned)params->window_size; t->H = t->W / 2;
+    const size_t cap = (size_t)sigutils_specttuner::CAP_HALVES * t->H;
+    ok = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) == hipSuccess &&
+         hipHostMalloc((void **)&t->h_in, cap * sizeof(c32), hipHostMallocDefault) == hipSuccess &&
+         hipMalloc((void **)&t->d_in, cap * sizeof(c32)) == hipSuccess;
+    if (!ok) suamd_set_error("allocation failed");
+  }
+  if (!ok) {
+    if (t->st) suamd_specttuner_destroy(t->st);
+    if (t->ctx) suamd_ctx_destroy(t->ctx);
+    if (t->h_in) (void)hipHostFree(t->h_in);
+    if (t->d_in) (void)hipFree(t->d_in);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+    return nullptr;
+  }
+  return t;
+}
+
+SUAMD_API void su_specttuner_destroy(sigutils_specttuner *t)
+{
+  if (!t) return;
+  if (t->stream) (void)hipStreamSynchronize(t->stream);
+  if (t->st) suamd_specttuner_destroy(t->st);
+  if (t->h_in) (void)hipHostFree(t->h_in);
+  if (t->d_in) (void)hipFree(t->d_in);
+  if (t->h_out) (void)hipHostFree(t->h_out);
+  if (t->d_out) (void)hipFree(t->d_out);
+  if (t->stream) (void)hipStreamDestroy(t->stream);
+  if (t->ctx) suamd_ctx_destroy(t->ctx);
+  delete t;
+}
+
+SUAMD_API sigutils_specttuner_channel *su_specttuner_open_channel(sigutils_specttuner *t, const struct sigutils_specttuner_channel_params *p)
+{
+  if (!t || !p) { suamd_set_error("null argument"); return nullptr; }
+  const int idx = suamd_specttuner_open_channel(t->st, (double)p->f0, (double)p->bw, (double)p->guard, p->precise);
+  if (idx < 0) return nullptr;
+  std::unique_ptr<sigutils_specttuner_channel> c(new sigutils_specttuner_channel{*p, t, idx});
+  if ((size_t)idx >= t->channels.size()) t->channels.resize((size_t)idx + 1);
+  t->channels[idx] = std::move(c);
+  return t->channels[idx].get();
+}
+
+SUAMD_API SUBOOL su_specttuner_close_channel(sigutils_specttuner *t, sigutils_specttuner_channel *c)
+{
+  if (!t || !c || c->owner != t) { suamd_set_error("no such channel"); return SU_FALSE; }
+  const int idx = c->index;
+  if (!suamd_specttuner_close_channel(t->st, idx)) return SU_FALSE;
+  t->channels[idx].reset();
+  return SU_TRUE;
+}
+
+SUAMD_API SUBOOL su_specttuner_feed_bulk(sigutils_specttuner *t, const SUCOMPLEX *buf, SUSCOUNT size)
+{
+  if (!t || (size && !buf)) { suamd_set_error("null argument"); return SU_FALSE; }
+  const size_t cap = (size_t)sigutils_specttuner::CAP_HALVES * t->H;
+  while (size > 0) {
+    const size_t n = std::min<size_t>(size, cap - t->fill);
+    std::memcpy(static_cast<void *>(t->h_in + t->fill), buf, n * sizeof(c32));
+    t->fill += n; buf += n; size -= n;
+    if (t->fill == cap && !t->flush()) return SU_FALSE;
+  }
+  return t->flush() ? SU_TRUE : SU_FALSE;
+}
+
+SUAMD_API SUFLOAT su_specttuner_channel_get_decimation(const sigutils_specttuner_channel *c)
+{
+  return c ? (SUFLOAT)suamd_specttuner_channel_decimation(c->owner->st, c->index) : 0;
+}
+SUAMD_API SUFLOAT su_specttuner_channel_get_bw(const sigutils_specttuner_channel *c) { return c ? c->params.bw : 0; }
+SUAMD_API SUFLOAT su_specttuner_channel_get_f0(const sigutils_specttuner_channel *c) { return c ? c->params.f0 : 0; }
+SUAMD_API unsigned su_specttuner_channel_get_size(const sigutils_specttuner_channel *c)
+{
+  return c ? suamd_specttuner_channel_size(c->owner->st, c->index) : 0;
+}
+
+}  // extern "C"

@@ -338,6 +338,60 @@ class ChannelBank:
         check(self.ctx.lib.suamd_chanbank_reset(self.h, _stream(stream)), "suamd_chanbank_reset")
 
 
+class SpectTuner:
+    """suamd_specttuner_t: the FFT channeliser (su_specttuner semantics, SPEC.md C2)."""
+
+    def __init__(self, ctx, window_size=4096):
+        self.ctx = ctx
+        self.W = int(window_size)
+        self.h = ctx.lib.suamd_specttuner_new(ctx.h, self.W)
+        if not self.h:
+            raise SigDiggerAmdError("suamd_specttuner_new: " + _l.last_error())
+        self.nchan = 0
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.suamd_specttuner_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def open_channel(self, f0, bw, guard=1.0, precise=False):
+        """f0, bw in angular units (rad / sample).  Returns the channel index."""
+        c = self.ctx.lib.suamd_specttuner_open_channel(self.h, float(f0), float(bw), float(guard), int(bool(precise)))
+        if c < 0:
+            raise SigDiggerAmdError("suamd_specttuner_open_channel: " + _l.last_error())
+        self.nchan = max(self.nchan, c + 1)
+        return c
+
+    def close_channel(self, c):
+        check(self.ctx.lib.suamd_specttuner_close_channel(self.h, int(c)), "suamd_specttuner_close_channel")
+
+    def channel_size(self, c):
+        return int(self.ctx.lib.suamd_specttuner_channel_size(self.h, int(c)))
+
+    def decimation(self, c):
+        return int(self.ctx.lib.suamd_specttuner_channel_decimation(self.h, int(c)))
+
+    def set_run(self, run):
+        check(self.ctx.lib.suamd_specttuner_set_run(self.h, int(run)), "suamd_specttuner_set_run")
+
+    def feed(self, x, out=None, stream=None):
+        """x: [len] complex64, len a multiple of W/2.  Returns (out, counts): out [nchan, cap] channel-major (or the
+        tensor passed in: any 2-D view), counts[c] samples valid in row c."""
+        _chk_c64(x, "x")
+        if out is None:
+            out = torch.empty((max(self.nchan, 1), x.numel() // 2 + 16), dtype=torch.complex64, device=x.device)
+        counts = (C.c_uint64 * max(self.nchan, 1))()
+        check(self.ctx.lib.suamd_specttuner_feed(self.h, _ptr(x), x.numel(), _ptr(out), _view(out), counts, _stream(stream)),
+              "suamd_specttuner_feed")
+        return out, [int(v) for v in counts]
+
+
 class _LoopBank:
     _destroy = None
 

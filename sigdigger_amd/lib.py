@@ -45,6 +45,14 @@ PROTOTYPES = {
     "suamd_psd_shift_db": (INT, [VP, VP, U64, U64, VP]),
     "suamd_averager_feed": (INT, [VP, VP, VP, U64, F32, INT, VP]),
     "suamd_inspector_spectrum_db_shift": (INT, [VP, VP, U64, U64, VP]),
+    "suamd_specttuner_new": (VP, [VP, UINT]),
+    "suamd_specttuner_destroy": (None, [VP]),
+    "suamd_specttuner_open_channel": (INT, [VP, F64, F64, F64, INT]),
+    "suamd_specttuner_close_channel": (INT, [VP, INT]),
+    "suamd_specttuner_channel_size": (UINT, [VP, INT]),
+    "suamd_specttuner_channel_decimation": (UINT, [VP, INT]),
+    "suamd_specttuner_feed": (INT, [VP, VP, U64, VP, View, C.POINTER(U64), VP]),
+    "suamd_specttuner_set_run": (INT, [VP, UINT]),
     "suamd_fnor_to_dphase": (U32, [F64]),
     "suamd_xlate_bulk": (INT, [VP, VP, VP, U64, U32, U32, U64, VP]),
     "suamd_lpf_design": (None, [VP, UINT, F64]),

@@ -1,0 +1,220 @@
+"""FFT channeliser (rows T2 / N2; SPEC.md section C2): csrc/specttuner.hip against the oracle's restatement
+(oracle/sdo.c sdo_specttuner_*), through both front ends of the same object -- suamd_specttuner_* (device block
+interface) and su_specttuner_* (the libsigutils names and callback contract of Tasks/LPFTask.cpp).
+
+Tolerance: the device transforms are binary32, the oracle's binary64: |y - y_ref| <= TOL * max|y_ref| per channel with
+TOL = 1e-5 (the north star's bound) on inputs whose channels carry comparable power; the measured error is ~1e-6.
+Index geometry (sizes, centre bins, block counts, which samples a feed yields) is exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from sigdigger_amd import engine, sigutils, synth
+
+pytestmark = pytest.mark.gpu
+
+W, H = 4096, 2048
+TOL = 1e-5
+
+
+def cnoise(n, seed):
+    r = np.random.default_rng(seed)
+    return ((r.standard_normal(n) + 1j * r.standard_normal(n)) / np.sqrt(2)).astype(np.complex64)
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30))
+
+
+def run_gpu(ctx, x, chans, splits=None, run=None):
+    """chans: list of (f0, bw, guard, precise).  Returns the per-channel streams."""
+    st = engine.SpectTuner(ctx, W)
+    if run:
+        st.set_run(run)
+    ids = [st.open_channel(*c) for c in chans]
+    dx = torch.from_numpy(x).cuda()
+    cuts = [0] + list(splits or []) + [x.size]
+    outs = [[] for _ in ids]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        out, counts = st.feed(dx[a:b])
+        torch.cuda.synchronize()
+        for k, c in enumerate(ids):
+            outs[k].append(out[c, :counts[c]].cpu().numpy())
+    st.close()
+    return [np.concatenate(o) for o in outs]
+
+
+@pytest.mark.parametrize("dec", [1, 2, 4, 16, 64, 128, 256])
+def test_one_channel_every_size_matches_oracle(ctx, sdo, dec):
+    size = W // dec
+    bw = 2 * np.pi * (0.75 * size / W)
+    f0 = 2 * np.pi * 0.137
+    x = cnoise(H * 21, 100 + dec)
+    g = sdo.specttuner_geometry(W, f0, bw, 1.0)
+    assert g.size == size and g.decimation == dec and g.center % 2 == 0
+    ref = sdo.specttuner_run(x, W, f0, bw, 1.0)
+    got = run_gpu(ctx, x, [(f0, bw, 1.0, False)])[0]
+    assert got.size == ref.size == 20 * (size // 2)
+    assert relerr(got, ref) <= TOL
+
+
+def test_bank_of_64_psk_channels_d64(ctx, sdo):
+    """the C4 slice's shape: 64 channels of 64 bins on a raster, here with real carriers in them"""
+    nch = 64
+    fn = synth.raster(nch, 2 * 700e3 / 50e6)
+    x = synth.psk_carriers(H * 40, fn, sps=100, order=4, seed=7, snr_db=30)
+    bw = 2 * np.pi * 0.75 / 64
+    chans = [(np.pi * f % (2 * np.pi), bw, 1.0, False) for f in fn]
+    got = run_gpu(ctx, x, chans)
+    for c in (0, 1, 31, 32, 63):
+        ref = sdo.specttuner_run(x, W, chans[c][0], bw, 1.0)
+        assert got[c].size == ref.size
+        assert relerr(got[c], ref) <= TOL, c
+
+
+def test_any_split_of_the_stream_gives_the_same_samples(ctx):
+    x = cnoise(H * 48, 5)
+    chans = [(0.3, 2 * np.pi / 64 * 0.7, 1.0, False), (2.1, 2 * np.pi / 64 * 0.5, 1.0, True), (4.0, 2 * np.pi / 16 * 0.8, 1.0, False)]
+    one = run_gpu(ctx, x, chans)
+    for splits, run in (([H], 8), ([H * 3, H * 4, H * 30], 8), ([H * 10], 3), ([], 1), ([H * 7], 64)):
+        parts = run_gpu(ctx, x, chans, splits, run)
+        for a, b in zip(one, parts):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (splits, run)
+
+
+def test_precise_channel_corrects_the_bin_rounding(ctx, sdo):
+    f0 = 2 * np.pi * 0.1 + 0.0007                 # between two even bins
+    n = H * 60
+    x = np.exp(1j * f0 * np.arange(n)).astype(np.complex64)
+    bw = 2 * np.pi / 64 * 0.75
+    ref = sdo.specttuner_run(x, W, f0, bw, 1.0, precise=True)
+    got = run_gpu(ctx, x, [(f0, bw, 1.0, True)], splits=[H * 20])[0]
+    assert relerr(got, ref) <= TOL
+    tail = got[200:]
+    assert np.max(np.abs(np.angle(tail[1:] * np.conj(tail[:-1])))) < 2e-3     # the tone lands on DC
+    coarse = run_gpu(ctx, x, [(f0, bw, 1.0, False)])[0][200:]
+    assert np.median(np.abs(np.angle(coarse[1:] * np.conj(coarse[:-1])))) > 1e-2
+
+
+def test_more_channels_than_one_workgroup_serves_and_mixed_responses(ctx, sdo):
+    nch = 150                                                     # 64 per workgroup at 64 bins: grid.y = 3
+    r = np.random.default_rng(9)
+    x = cnoise(H * 12, 9)
+    chans = [(float(r.uniform(0, 2 * np.pi)), 2 * np.pi / 64 * float(r.uniform(0.3, 0.9)), 1.0, bool(c % 2)) for c in range(nch)]
+    got = run_gpu(ctx, x, chans)
+    for c in (0, 63, 64, 127, 128, 149):
+        ref = sdo.specttuner_run(x, W, chans[c][0], chans[c][1], 1.0, chans[c][3])
+        assert relerr(got[c], ref) <= TOL, c
+
+
+def test_channels_of_different_sizes_and_open_close_between_feeds(ctx, sdo):
+    x = cnoise(H * 30, 11)
+    st = engine.SpectTuner(ctx, W)
+    a = st.open_channel(1.0, 2 * np.pi / 64 * 0.8)
+    b = st.open_channel(2.0, 2 * np.pi / 8 * 0.8)
+    dx = torch.from_numpy(x).cuda()
+    o1, c1 = st.feed(dx[:H * 10])
+    ya, yb = [o1[a, :c1[a]].cpu().numpy()], [o1[b, :c1[b]].cpu().numpy()]
+    c = st.open_channel(3.0, 2 * np.pi / 64 * 0.6)                 # joins a's size group mid-stream
+    o2, c2 = st.feed(dx[H * 10:H * 20])
+    ya.append(o2[a, :c2[a]].cpu().numpy()); yb.append(o2[b, :c2[b]].cpu().numpy())
+    yc = [o2[c, :c2[c]].cpu().numpy()]
+    st.close_channel(b)
+    o3, c3 = st.feed(dx[H * 20:])
+    ya.append(o3[a, :c3[a]].cpu().numpy()); yc.append(o3[c, :c3[c]].cpu().numpy())
+    assert c3[b] == 0
+    st.close()
+    ra = sdo.specttuner_run(x, W, 1.0, 2 * np.pi / 64 * 0.8, 1.0)
+    rb = sdo.specttuner_run(x[:H * 20], W, 2.0, 2 * np.pi / 8 * 0.8, 1.0)
+    assert relerr(np.concatenate(ya), ra) <= TOL
+    assert relerr(np.concatenate(yb), rb) <= TOL
+    # the late channel starts with an empty previous block: from its second block on it equals a channel that had
+    # been open all along (same windows: it joined on a window boundary)
+    rc = sdo.specttuner_run(x, W, 3.0, 2 * np.pi / 64 * 0.6, 1.0)
+    yc = np.concatenate(yc)
+    off = 9 * 32                                                   # blocks 0..8 came out of the first feed
+    assert yc.size == rc.size - off
+    assert relerr(yc[32:], rc[off + 32:]) <= TOL
+
+
+def test_lpftask_contract_through_the_sigutils_names(sdo):
+    """Tasks/LPFTask.cpp: window 4096, f0 = 0, bw = pi * rel_bw, guard = 2 pi / bw ("no decimation"), fed 8192 samples
+    per work(), then single zero samples until `length` outputs have arrived (:104-107)."""
+    n = 40000
+    x = (cnoise(n, 13) + np.exp(1j * 0.05 * np.arange(n))).astype(np.complex64)
+    rel_bw = 0.1
+    bw = np.float32(np.pi * rel_bw)
+    guard = np.float32(2 * np.pi / bw)
+    t = sigutils.SpectTuner(W)
+    k = t.open_channel(0.0, float(bw), float(guard))
+    assert t.L.su_specttuner_channel_get_decimation(t.channel(k)) == 1.0
+    for p in range(0, n, 8192):
+        t.feed(x[p:p + 8192])
+    fed = n
+    zero = np.zeros(1, np.complex64)
+    while t.samples(k).size < n:
+        t.feed(zero)
+        fed += 1
+        assert fed < n + 2 * W
+    got = t.samples(k)[:n]
+    t.close()
+    ref = sdo.specttuner_run(np.concatenate([x, np.zeros(fed - n, np.complex64)]), W, 0.0, float(bw), float(guard))
+    assert ref.size >= n
+    assert relerr(got, ref[:n]) <= TOL
+    # it is a low-pass: the tone at 0.05 rad/sample (inside pi * 0.1 / 2 ... ) survives, the wideband noise drops
+    assert np.var(got[W:]) < 0.5 * np.var(x)
+
+
+def test_full_size_block_64_channels(ctx, sdo):
+    """BASELINE's C4 slice: 4 Mi samples, 64 channels of 64 bins; oracle spot checks + split invariance at full size"""
+    L = 1 << 22
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    x = torch.empty(L, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(x).normal_(generator=g)
+    fn = synth.raster(64, 2 * 90e3 / 50e6)
+    bw = 2 * np.pi * 0.75 / 64
+    st = engine.SpectTuner(ctx, W)
+    for f in fn:
+        st.open_channel(np.pi * f % (2 * np.pi), bw)
+    out, counts = st.feed(x)
+    torch.cuda.synchronize()
+    assert counts == [(L // H - 1) * 32] * 64
+    st.close()
+    xh = x.cpu().numpy()
+    for c, k0 in ((0, 0), (40, 1000), (63, L // H - 1 - 12)):
+        # blocks k0 .. k0+9 depend on windows k0-1 .. k0+9 only
+        lo = max(k0 - 1, 0)
+        ref = sdo.specttuner_run(xh[lo * H:(k0 + 11) * H], W, np.pi * fn[c] % (2 * np.pi), bw, 1.0)
+        skip = (k0 - lo) * 32
+        got = out[c, k0 * 32:(k0 + 10) * 32].cpu().numpy()
+        assert relerr(got, ref[skip:skip + 320]) <= TOL, (c, k0)
+    st2 = engine.SpectTuner(ctx, W)
+    for f in fn:
+        st2.open_channel(np.pi * f % (2 * np.pi), bw)
+    o1, c1 = st2.feed(x[:L // 2])
+    first = o1[:, :c1[0]].clone()
+    o2, c2 = st2.feed(x[L // 2:])
+    both = torch.cat([first, o2[:, :c2[0]]], dim=1)
+    assert torch.equal(torch.view_as_real(both.contiguous()), torch.view_as_real(out[:, :counts[0]].contiguous()))
+    st2.close()
+
+
+def test_reference_lpftask_unchanged_on_the_gpu_channeliser(sdo):
+    """Tasks/LPFTask.cpp compiled UNCHANGED from the reference (oracle/_ref/libsdref.so, built where /root/reference is),
+    linked against the product's su_specttuner_*: the whole task -- constructor, work() loop, zero flush -- against
+    the oracle."""
+    from oracle import sdref
+    if not sdref.available():
+        pytest.skip("oracle/_ref/libsdref.so was not built (it needs /root/reference)")
+    n = 50000
+    x = (cnoise(n, 17) + np.exp(1j * 0.02 * np.arange(n))).astype(np.complex64)
+    rel_bw = np.float32(0.08)
+    got = sdref.lpf_task(x, float(rel_bw))
+    assert got is not None
+    bw = np.float32(np.pi) * rel_bw                       # SU_NORM2ANG_FREQ(bw): PI * SU_ASFLOAT(bw) in double, stored as SUFLOAT
+    bw = np.float32(np.pi * float(rel_bw))
+    guard = np.float32(2 * np.pi / float(bw))
+    ref = sdo.specttuner_run(np.concatenate([x, np.zeros(2 * W, np.complex64)]), W, 0.0, float(bw), float(guard))
+    assert relerr(got, ref[:n]) <= TOL

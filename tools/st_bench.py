@@ -1,0 +1,31 @@
+"""FFT channeliser micro-benchmark: C channels of W/D bins on a resident block (HIP events on the launch stream)."""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+from sigdigger_amd import engine, synth
+
+L = 1 << 22
+ctx = engine.Context(0)
+x = torch.empty(L, dtype=torch.complex64, device="cuda")
+torch.view_as_real(x).normal_()
+for C, D, run in [(64, 64, 8), (64, 64, 4), (64, 64, 16), (64, 64, 2), (1, 64, 8), (1, 16, 8), (16, 64, 8), (512, 64, 8), (64, 16, 8), (1, 1, 8)]:
+    st = engine.SpectTuner(ctx, 4096)
+    st.set_run(run)
+    fn = synth.raster(C, 1.8 / max(C, 2))
+    for f in fn:
+        st.open_channel(np.pi * f % (2 * np.pi), 2 * np.pi * 0.75 / D)
+    out = torch.empty((C, L // D + 64), dtype=torch.complex64, device="cuda")
+    st.feed(x, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        st.feed(x, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    alg = 8 * L + 8 * C * L / D
+    print(f"C={C:4d} D={D:3d} run={run:3d}: {ms * 1e3:8.1f} us  {alg / ms / 1e6:8.1f} GB/s algorithmic  {L / ms / 1e3:8.1f} MS/s")
+    st.close()
