@@ -111,8 +111,9 @@ def cpu_baseline(cfg, nsamples, fnor_rank, ncores):
         "value": round(nsamples / tn / 1e6, 4), "unit": "MS/s", "cores": cores, "kind": "port",
         "value_1thread": round(nsamples / t1 / 1e6, 4),
         "sample": f"{nsamples} complex samples of the same workload (PSD {N}-pt + {len(fnor_rank)} "
-                  f"inspector chains) through oracle/sdo.c, {cores} thread(s), channels partitioned "
-                  f"across threads; oracle is a restatement, not upstream sigutils",
+                  f"inspector chains, direct-form channeliser) through oracle/sdo.c; `cores` = threads of the pool "
+                  f"({os.cpu_count()} logical CPUs), at most {len(fnor_rank)} of them busy (one channel per task); "
+                  f"oracle is a restatement (gcc -O2, scalar), not upstream sigutils",
         "cpu_model": _cpu_model(),
     }
 
@@ -151,10 +152,11 @@ def run_workload(name, args, rank, world, dev, ctx, dist):
     fn_all = synth.raster(nch_total, cfg["spacing"])
     fn_rank = pipeline.shard_channels(fn_all, rank, world)
     bank = pipeline.InspectorBankConfig(kind=cfg["kind"], fnor=fn_rank, decimation=cfg["D"], ntaps=cfg["T"],
-                                        sps=cfg["sps_in"] / cfg["D"])
+                                        sps=cfg["sps_in"] / cfg["D"], channeliser=args.channeliser)
     # PSD runs on rank 0 only; frames averaged to ~25 fps at 50 MS/s
     navg = min(256, L // cfg["psd"])
     pipe = pipeline.AnalyzerPipeline(ctx, L, psd_size=cfg["psd"], psd_navg=navg, bank=bank, do_psd=(rank == 0))
+    pipe.enable_delivery()       # the recovered symbols reach (pinned) host memory inside the timed region
 
     bufs = [make_block(L, fn_all, cfg["sps_in"], cfg["kind"], dev, seed=1234),
             torch.empty(L, dtype=torch.complex64, device=dev)]
@@ -166,6 +168,7 @@ def run_workload(name, args, rank, world, dev, ctx, dist):
         # rank 0's next block -> every GPU over xGMI, overlapped with this step's compute
         work = pipeline.broadcast_block(bufs[(k + 1) & 1], dist)
         pipe.step(cur, timed=timed)
+        pipe.deliver()
         if work is not None:
             work.wait()
 
@@ -199,8 +202,10 @@ def run_host_fed(name, args, dev, ctx):
     cfg = WORKLOADS[name]
     L = 1 << args.block
     fn = synth.raster(cfg["per_gpu"], cfg["spacing"])
-    bank = pipeline.InspectorBankConfig(kind=cfg["kind"], fnor=fn, decimation=cfg["D"], ntaps=cfg["T"], sps=cfg["sps_in"] / cfg["D"])
+    bank = pipeline.InspectorBankConfig(kind=cfg["kind"], fnor=fn, decimation=cfg["D"], ntaps=cfg["T"], sps=cfg["sps_in"] / cfg["D"],
+                                        channeliser=args.channeliser)
     pipe = pipeline.AnalyzerPipeline(ctx, L, psd_size=cfg["psd"], psd_navg=min(256, L // cfg["psd"]), bank=bank, do_psd=True)
+    pipe.enable_delivery()
     host = make_block(L, fn, cfg["sps_in"], cfg["kind"], dev, seed=99).cpu().pin_memory()
     bufs = [torch.empty(L, dtype=torch.complex64, device=dev) for _ in range(2)]
     copy_stream = torch.cuda.Stream(device=dev)
@@ -226,6 +231,7 @@ def run_host_fed(name, args, dev, ctx):
         upload(k + 1)
         main.wait_event(ready[k & 1])
         pipe.step(bufs[k & 1], timed=False)
+        pipe.deliver()
         consumed[k & 1].record(main)                          # step() enqueued its readers of the block on `main`
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
@@ -292,6 +298,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--block", type=int, default=22, help="log2 of the IQ block length (samples)")
+    ap.add_argument("--channeliser", default="fft", choices=("fft", "fir"),
+                    help="fft: the FFT filter bank with su_specttuner's semantics (what the reference runs behind its "
+                         "channels); fir: translate + 255-tap direct-form low-pass + decimate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (c2, c3, c5)")
     ap.add_argument("--cpu-samples", type=int, default=1 << 23)
@@ -324,30 +333,32 @@ def main():
 
     if rank == 0:
         K = args.steps
-        # units all ranks processed: every rank pushes the same L-sample block through its own
-        # 64-inspector bank each step
-        total_samples = float(L) * K * world
-        value = total_samples / dt / 1e6
+        # `value` is the rate of the IQ STREAM: every rank consumes the same broadcast block and runs its own shard of
+        # the inspectors on it, so N GPUs carry N x the inspectors at (ideally) the same stream rate -- weak scaling in
+        # inspectors.  The aggregate channel rate (stream rate x inspectors) is reported beside it.
+        value = float(L) * K / dt / 1e6
         C, D, T = len(fn_rank), cfg["D"], cfg["T"]
         m_out = L // D
-        # dominant memory/compute-streaming kernel of the north star: the FIR channel bank.
-        # algorithmic (compulsory) bytes per launch: shared input + per-channel decimated output
+        fft_bank = args.channeliser == "fft"
+        # the north star's "FIR stage": the channeliser.  Algorithmic (compulsory) bytes per launch:
+        # the shared input once + every channel's decimated output
         fir_bytes = 8.0 * L + 8.0 * C * m_out
-        fir_flops = float(C) * m_out * T * 8.0 + 14.0 * C * m_out      # 4 fma/tap + de-rotation
+        fir_flops_built = float(C) * m_out * T * 8.0 + 14.0 * C * m_out      # direct form as built: 4 fma / tap + de-rotation
+        fir_flops_survey = float(C) * L * (6.0 + 4.0 * T / D)                # translate + real taps
         fir_ms = stages.get("fir")
         psd_ms = stages.get("psd")
         psd_bytes = 8.0 * L + 4.0 * cfg["psd"] * (L // cfg["psd"] // pipe.navg)
+        kname = "st_kernel" if fft_bank else "chan_fir_kernel"
         roof = {
-            "kernel": "chan_fir_kernel (translate + 255-tap polyphase decimating FIR bank)",
+            "kernel": ("st_kernel (FFT channeliser: one 4096-pt forward FFT per half window shared by all channels, per "
+                       "channel bin pick x response, 64-pt inverse FFT, cross-fade)") if fft_bank else
+                      "chan_fir_kernel (translate + 255-tap polyphase decimating FIR bank)",
             "bound": "hbm", "achieved": round(fir_bytes / (fir_ms * 1e-3) / 1e9, 2) if fir_ms else None,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(fir_bytes / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if fir_ms else None,
-            "traffic": pmc_traffic("chan_fir_kernel", args.workload, L),
+            "traffic": pmc_traffic(kname, args.workload, L),
             "algorithmic_bytes_per_launch": fir_bytes,
             "kernel_ms": round(fir_ms, 4) if fir_ms else None,
-            "fp32_vector": {"achieved_tflops": round(fir_flops / (fir_ms * 1e-3) / 1e12, 3) if fir_ms else None,
-                            "peak_tflops": FP32_PEAK_TFLOPS,
-                            "frac": round(fir_flops / (fir_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4) if fir_ms else None},
             "psd_kernel": {"achieved": round(psd_bytes / (psd_ms * 1e-3) / 1e9, 2) if psd_ms else None,
                            "frac": round(psd_bytes / (psd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if psd_ms else None,
                            "kernel_ms": round(psd_ms, 4) if psd_ms else None,
@@ -356,6 +367,10 @@ def main():
             "note": "recurrence stages (AGC/Costas/Gardner) are one-lane-per-channel and latency-bound; "
                     "they are reported in stage_ms, not against a roofline (SURVEY.md section 8d)",
         }
+        if not fft_bank and fir_ms:
+            roof["fp32_vector"] = {"peak_tflops": FP32_PEAK_TFLOPS,
+                                   "flops_as_built": fir_flops_built, "frac_as_built": round(fir_flops_built / (fir_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                                   "flops_survey_8d": fir_flops_survey, "frac_survey_8d": round(fir_flops_survey / (fir_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
         out = {
             "metric": "MS/s complex IQ sustained (PSD + N inspectors)", "value": round(value, 3), "unit": "MS/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 4),
@@ -365,10 +380,11 @@ def main():
                        "decimation": D, "taps": T,
                        "parallelism": f"channel-sharded x{world}, RCCL broadcast of the IQ block" if world > 1
                        else "single GPU",
-                       "value_definition": "sum over ranks of IQ samples pushed through that rank's PSD+inspector "
-                                           "bank per second; every rank consumes the same broadcast stream, so "
-                                           "stream rate = value / n_gpus"},
-            "stream_rate_MSps": round(value / world, 3),
+                       "channeliser": args.channeliser,
+                       "value_definition": "rate of the IQ stream: every rank consumes the same broadcast block and runs "
+                                           "its shard of the inspectors on it; symbols are copied to pinned host memory "
+                                           "inside the timed region"},
+            "aggregate_inspector_MSps": round(value * cfg["per_gpu"] * world, 1),
             "roofline": roof,
         }
         if args.isolated:
@@ -376,7 +392,7 @@ def main():
             # AGC / Costas / Gardner kernels of neighbouring blocks)
             iso = {}
             x = torch.randn(L, dtype=torch.complex64, device=dev)
-            for name, fn in (("fir", lambda: pipe.chan.feed(x, out=pipe.y[0])),
+            for name, fn in (("fir", lambda: pipe._channelise(x, pipe.y[0], torch.cuda.current_stream(dev))),
                              ("psd", (lambda: pipe.psd.feed(x, nframes=pipe.nframes, navg=pipe.navg,
                                                             scale=1.0 / pipe.psd_size, out=pipe.psd_out))
                               if pipe.do_psd else None)):
@@ -392,7 +408,19 @@ def main():
                 torch.cuda.synchronize(dev)
                 iso[name + "_ms"] = round(e0.elapsed_time(e1) / 10, 4)
             iso["fir_hbm_frac"] = round(fir_bytes / (iso["fir_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-            iso["fir_fp32_frac"] = round(fir_flops / (iso["fir_ms"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
+            if fft_bank:                                       # the direct-form bank on the same block, for comparison
+                taps = ctx.lpf_design(T, 0.75 / D)
+                direct = engine.ChannelBank(ctx, fn_rank, D, taps)
+                direct.feed(x, out=pipe.y[1])
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    direct.feed(x, out=pipe.y[1])
+                e1.record()
+                torch.cuda.synchronize(dev)
+                iso["direct_fir_ms"] = round(e0.elapsed_time(e1) / 10, 4)
+                iso["direct_fir_hbm_frac"] = round(fir_bytes / (iso["direct_fir_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             if "psd_ms" in iso:
                 iso["psd_hbm_frac"] = round(psd_bytes / (iso["psd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             roof["isolated"] = iso

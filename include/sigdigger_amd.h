@@ -128,7 +128,7 @@ SUAMD_API unsigned suamd_specttuner_channel_decimation(const suamd_specttuner_t 
  * may be NULL) receives how many.  Any split of a stream into feeds gives the same samples. */
 SUAMD_API SUBOOL suamd_specttuner_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len,
                                        suamd_complex *d_y, suamd_view view, SUSCOUNT *counts, void *stream);
-/* windows per workgroup run (default 8): a run re-transforms the window before it */
+/* windows per workgroup run (default 4): a run re-transforms the window before it */
 SUAMD_API SUBOOL suamd_specttuner_set_run(suamd_specttuner_t *st, unsigned run);
 
 /* ------------------------------------------------------------------------------------ */

@@ -8,7 +8,7 @@
  * source, let the request tracker open a "psk" inspector and set its id, push an inspector config, collect
  * PSDMessage / SamplesMessage objects from the Qt signals until end of stream, then halt.
  *
- * usage: ref_live <iq.f32> <samp_rate> <window_size> <chan_fc_hz> <chan_bw_hz> <out.bin> [class = psk | raw]
+ * usage: ref_live <iq.f32> <samp_rate> <window_size> <chan_fc_hz> <chan_bw_hz> <out.bin> [class = psk | raw] [baud]
  * out.bin: u32 magic 'RLV1', u32 npsd, u32 psd_size, u32 nbatches, u64 nsamples, f32 fs, f32 equiv_fs, f32 bandwidth,
  *          u32 inspector_id_seen, then psd_size floats (first PSD frame as PSDMessage delivers it: shifted dB),
  *          then nsamples complex64 (all SamplesMessage payloads in order).
@@ -33,6 +33,7 @@ int main(int argc, char **argv)
   const double chan_fc = std::atof(argv[4]), chan_bw = std::atof(argv[5]);
   const char *out_path = argv[6];
   const std::string cls = argc > 7 ? argv[7] : "psk";
+  const float baud = argc > 8 ? (float)std::atof(argv[8]) : 0.f;
 
   Suscan::Source::Config cfg("file", SUSCAN_SOURCE_FORMAT_RAW_FLOAT32);
   cfg.setPath(path);
@@ -81,7 +82,7 @@ int main(int argc, char **argv)
     c.set("afc.costas-order", (uint64_t)2);
     c.set("afc.bits-per-symbol", (uint64_t)2);
     c.set("clock.type", (uint64_t)1);
-    c.set("clock.baud", (SUFLOAT)(equiv_fs / 8.f));
+    c.set("clock.baud", (SUFLOAT)(baud > 0 ? baud : equiv_fs / 8.f));
     c.set("clock.running", true);
     an->setInspectorConfig(req.handle, c);
   });

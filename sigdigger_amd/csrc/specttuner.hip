@@ -19,6 +19,8 @@
 //      for the same i), optional residual NCO ("precise"), store through the view.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
 #include "kernels.hpp"
 #include "fft_core.hpp"
 #include "sd_math.hpp"
@@ -36,8 +38,10 @@ template <int LOG2S> struct StGeomT {
   static constexpr int PADS = S + S / 16 + 1;                  // a group's LDS scratch (elements)
 };
 
-template <int LOG2W, int LOG2S>
-__global__ __launch_bounds__(ST_THREADS, 2) void st_kernel(sdk::StArgs a)
+// OCC: workgroups per CU the register budget is cut for (the LDS of one workgroup is ~35 KB: up to 4 fit);
+// PREFETCH: request the next window's samples right after pass 0 of this one (32 VGPRs)
+template <int LOG2W, int LOG2S, int OCC, bool PREFETCH>
+__global__ __launch_bounds__(ST_THREADS, OCC) void st_kernel(sdk::StArgs a)
 {
   __builtin_amdgcn_s_setprio(3);   // ahead of the resident recurrence wavefronts (see chan_fir_kernel)
   using G = StGeomT<LOG2S>;
@@ -51,8 +55,8 @@ __global__ __launch_bounds__(ST_THREADS, 2) void st_kernel(sdk::StArgs a)
   constexpr int RLS = 1 << PS::bits(PS::P - 1), NBLS = G::E / RLS;
   static_assert(RLS >= 2, "the cross-fade pairs outputs q and q + RL/2 of one butterfly");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  cf *spec = reinterpret_cast<cf *>(smem);                     // W + W/16 + 1: forward passes in place, then the spectrum
-  cf *scratch = spec + (W + W / 16 + 1);
+  cf *spec = reinterpret_cast<cf *>(smem);                     // W + W/16 + 1: forward passes in place, then the spectrum,
+  cf *scratch = spec;                                          // then (once every group holds its bins) the groups' scratch
   const int tid0 = threadIdx.x;
   const int grp = tid0 / G::TPI, tl0 = tid0 % G::TPI;
   const int ch = blockIdx.y * G::CPP + grp;                    // channel of this thread's group (in the size group)
@@ -93,8 +97,9 @@ __global__ __launch_bounds__(ST_THREADS, 2) void st_kernel(sdk::StArgs a)
       }
     }
   };
-  request(w_first);
+  if (PREFETCH) request(w_first);
   for (long long w = w_first; w < w_end; ++w) {
+    if (!PREFETCH) request(w);
     int tid = tid0, tl = tl0;
     asm volatile("" : "+v"(tid), "+v"(tl));                    // see psd_kernel: keeps LICM from hoisting every derived twiddle
     cf v[EW];
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void st_kernel(sdk::StArgs a)
     for (int i = 0; i < EW; ++i) v[i] = nxt[i];
     // ---- 1. forward transform (no window function: su_specttuner's forward FFT is rectangular) ----
     fft_pass<LOG2W, ST_THREADS, 0, 1>(v, spec, tbw, tid, nullptr);
-    if (w + 1 < w_end) request(w + 1);
+    if (PREFETCH && w + 1 < w_end) request(w + 1);
     PassRunner<LOG2W, ST_THREADS, 1, 1>::run(v, spec, tbw, tid, nullptr);
     // v[b*RL + q] = X[j + q*W/RL]; the last pass's gather was followed by a barrier: spec may take the spectrum
 #pragma unroll
@@ -130,10 +135,18 @@ __global__ __launch_bounds__(ST_THREADS, 2) void st_kernel(sdk::StArgs a)
         }
       }
     }
+    if constexpr (PS::P > 1) __syncthreads();                // every group holds its bins: the spectrum's LDS becomes scratch
     PassRunner<LOG2S, G::TPI, 0, 1>::run(u, gscr, tbs, tl, nullptr);
     // u[b*RL + q] = conj(y[j + q*S/RL]), j = tl + b*TPI: q < RL/2 is the first half of the block, q + RL/2 its partner
     const bool emit = w >= w_begin;
     const float *win = a.win;
+    // time-major output ([m][channel] in memory, what the one-lane-per-channel loops stream): the block goes through an
+    // LDS tile [i][channel] so that a wavefront stores 64 channels of one instant = 512 contiguous bytes; otherwise
+    // (channel-major rows) a thread stores its own samples (32-byte runs per 4 lanes)
+    constexpr bool CAN_TILE = G::CPP >= 16;                      // tile = S/2 rows x (CPP + 4): fits the LDS region
+    constexpr int TP = G::CPP + 4;                               // row pitch = 4 mod 32 elements: 16-lane store groups hit 16 bank pairs
+    const bool tile = CAN_TILE && a.yv.cs == 1;
+    if (tile && PS::P == 1) __syncthreads();                     // (P > 1: the last pass's gather ended with a barrier) the LDS becomes the tile
 #pragma unroll
     for (int b = 0; b < NBLS; ++b) {
 #pragma unroll
@@ -151,9 +164,26 @@ __global__ __launch_bounds__(ST_THREADS, 2) void st_kernel(sdk::StArgs a)
             const float tr = orr * c - oi * s, ti = orr * s + oi * c;
             orr = tr; oi = ti;
           }
-          reinterpret_cast<cf *>(a.y)[(long long)cd.row * a.yv.cs + (long long)m * a.yv.ms] = cf{orr, oi};
+          if (tile) spec[i * TP + grp] = cf{orr, oi};
+          else reinterpret_cast<cf *>(a.y)[(long long)cd.row * a.yv.cs + (long long)m * a.yv.ms] = cf{orr, oi};
         }
         prev[b][q] = nx;
+      }
+    }
+    if (tile) {
+      __syncthreads();
+      if (emit) {
+        const int col = tid % G::CPP, r0 = tid / G::CPP;
+        const int cch = blockIdx.y * G::CPP + col;
+        if (cch < a.nchan) {
+          const long long orow = a.chans[cch].row;
+          cf *yb = reinterpret_cast<cf *>(a.y) + orow * a.yv.cs + (long long)((unsigned long long)w * HS) * a.yv.ms;
+#pragma unroll
+          for (int k = 0; k < (HS * G::CPP) / ST_THREADS; ++k) {
+            const int r = r0 + k * (ST_THREADS / G::CPP);
+            yb[(long long)r * a.yv.ms] = spec[r * TP + col];
+          }
+        }
       }
     }
     // the group scratch and the spectrum are rewritten by the next window's passes: its pass 0 ends with a barrier
@@ -172,13 +202,13 @@ __global__ __launch_bounds__(ST_THREADS, 2) void st_kernel(sdk::StArgs a)
   }
 }
 
-template <int LOG2W, int LOG2S>
-hipError_t launch_st(const sdk::StArgs &a, hipStream_t st)
+template <int LOG2W, int LOG2S, int OCC, bool PREFETCH>
+hipError_t launch_st_v(const sdk::StArgs &a, hipStream_t st)
 {
   using G = StGeomT<LOG2S>;
   constexpr int W = 1 << LOG2W;
-  const size_t lds = sizeof(cf) * ((size_t)(W + W / 16 + 1) + (size_t)G::CPP * G::PADS);
-  auto kern = st_kernel<LOG2W, LOG2S>;
+  const size_t lds = sizeof(cf) * std::max((size_t)(W + W / 16 + 1), (size_t)G::CPP * G::PADS);
+  auto kern = st_kernel<LOG2W, LOG2S, OCC, PREFETCH>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -189,6 +219,18 @@ hipError_t launch_st(const sdk::StArgs &a, hipStream_t st)
   const unsigned ny = (unsigned)((a.nchan + G::CPP - 1) / G::CPP);
   hipLaunchKernelGGL(kern, dim3(nruns, ny), dim3(ST_THREADS), lds, st, a);
   return hipGetLastError();
+}
+
+template <int LOG2W, int LOG2S>
+hipError_t launch_st(const sdk::StArgs &a, hipStream_t st)
+{
+  static const int variant = [] { const char *e = getenv("SUAMD_ST_VARIANT"); return e ? atoi(e) : 0; }();
+  switch (variant) {
+    case 1:  return launch_st_v<LOG2W, LOG2S, 2, true>(a, st);
+    case 2:  return launch_st_v<LOG2W, LOG2S, 4, false>(a, st);
+    case 3:  return launch_st_v<LOG2W, LOG2S, 3, false>(a, st);
+    default: return launch_st_v<LOG2W, LOG2S, 3, true>(a, st);
+  }
 }
 
 }  // namespace

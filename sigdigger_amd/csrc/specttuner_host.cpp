@@ -152,7 +152,7 @@ struct suamd_specttuner {
   suamd_ctx_t *ctx = nullptr;
   unsigned W = 4096, H = 2048;
   int log2w = 12;
-  unsigned run = 8;
+  unsigned run = 4;                    // windows per workgroup: 512 workgroups per 4 Mi-sample block, 25 % re-transformed
   c32 *d_tw_w = nullptr;
   c32 *d_hist[2] = {nullptr, nullptr};
   int hist_cur = 0;
@@ -163,11 +163,59 @@ struct suamd_specttuner {
 
 namespace {
 
+// Order of a size group's channels in the kernel's table.  In the channel stage a group of TPI = size/16 lanes serves one
+// channel and reads its bins straight from the LDS spectrum; the 32 lanes of half a wavefront (= 32/TPI channels) go
+// through the 32 bank pairs together, so two channels of one half wavefront whose bins fall on the same bank pairs
+// serialise (a dense raster like C4's -- centres 6 or 8 bins apart -- gave 4-way conflicts and +25 % kernel time in
+// table order).  Which channels share a half wavefront is free: a greedy pass puts those together whose accesses
+// collide least.  Per channel and operand slot the bank pairs its lanes touch are a 32-bit mask.
+std::vector<int> bank_friendly_order(unsigned W, int log2s, const std::vector<int> &members, const std::vector<Channel> &ch)
+{
+  const unsigned S = 1u << log2s, HS = S / 2;
+  const unsigned TPI = log2s == 5 ? 4 : S / 16, E = S / TPI;
+  if (TPI >= 32 || members.size() < 2) return members;
+  const unsigned per_half = 32 / TPI;
+  // pass-0 operand geometry of fft_core's plan: i = tl + b*TPI + q*(S/R0); as a set over (b, q) it is {tl + TPI*e, e < E}
+  std::vector<std::vector<uint32_t>> mask(members.size(), std::vector<uint32_t>(E, 0));
+  for (size_t k = 0; k < members.size(); ++k) {
+    const int center = ch[members[k]].g.center;
+    for (unsigned e = 0; e < E; ++e)
+      for (unsigned tl = 0; tl < TPI; ++tl) {
+        const unsigned i = tl + TPI * e;
+        const unsigned idx = ((unsigned)center + i + (i < HS ? 0 : W - S)) & (W - 1);
+        mask[k][e] |= 1u << ((idx + (idx >> 4)) & 31);
+      }
+  }
+  std::vector<char> used(members.size(), 0);
+  std::vector<int> order;
+  std::vector<size_t> half;
+  size_t next_free = 0;
+  while (order.size() < members.size()) {
+    if (half.size() == per_half) half.clear();
+    size_t best = members.size();
+    if (half.empty()) {
+      while (used[next_free]) ++next_free;
+      best = next_free;
+    } else {
+      unsigned best_cost = ~0u;
+      for (size_t k = 0; k < members.size(); ++k) {
+        if (used[k]) continue;
+        unsigned cost = 0;
+        for (size_t o : half) for (unsigned e = 0; e < E; ++e) cost += (unsigned)__builtin_popcount(mask[k][e] & mask[o][e]);
+        if (cost < best_cost) { best_cost = cost; best = k; if (!cost) break; }
+      }
+    }
+    used[best] = 1; half.push_back(best); order.push_back(members[best]);
+  }
+  return order;
+}
+
 // (re)builds a group's device tables after its membership changed; surviving members keep their cross-fade state
 bool rebuild_group(suamd_specttuner *st, SizeGroup &g, const std::vector<int> &old_members, c32 *old_prev)
 {
   const unsigned S = 1u << g.log2s, HS = S / 2;
   const size_t n = g.members.size();
+  g.members = bank_friendly_order(st->W, g.log2s, g.members, st->ch);
   std::vector<sdk::StChan> tab(n);
   std::vector<unsigned> halfws;
   for (size_t k = 0; k < n; ++k) {

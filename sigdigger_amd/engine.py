@@ -385,7 +385,7 @@ class SpectTuner:
         tensor passed in: any 2-D view), counts[c] samples valid in row c."""
         _chk_c64(x, "x")
         if out is None:
-            out = torch.empty((max(self.nchan, 1), x.numel() // 2 + 16), dtype=torch.complex64, device=x.device)
+            out = torch.empty((max(self.nchan, 1), x.numel() + 16), dtype=torch.complex64, device=x.device)   # decimation 1 at worst
         counts = (C.c_uint64 * max(self.nchan, 1))()
         check(self.ctx.lib.suamd_specttuner_feed(self.h, _ptr(x), x.numel(), _ptr(out), _view(out), counts, _stream(stream)),
               "suamd_specttuner_feed")

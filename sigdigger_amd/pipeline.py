@@ -16,7 +16,7 @@ class InspectorBankConfig:
     """Parameters shared by the inspectors of one bank (one decimation)."""
 
     def __init__(self, kind="psk", fnor=(), decimation=64, ntaps=255, bw_rel=0.75, sps=16.0,
-                 costas_kind=engine.COSTAS_QPSK, loop_bw=0.005, agc=True, clock_gain=0.2):
+                 costas_kind=engine.COSTAS_QPSK, loop_bw=0.005, agc=True, clock_gain=0.2, channeliser="fir"):
         self.kind = kind                      # "psk": AGC -> Costas -> Gardner ; "fsk": quad demod -> Gardner
         self.fnor = np.asarray(fnor, dtype=np.float64)
         self.decimation = int(decimation)
@@ -27,6 +27,10 @@ class InspectorBankConfig:
         self.loop_bw = float(loop_bw)
         self.agc = bool(agc)
         self.clock_gain = float(clock_gain)
+        # "fir": translate + `ntaps`-tap low-pass + decimate per channel (SPEC.md C, bit-exact against the oracle);
+        # "fft": the FFT filter bank with su_specttuner's semantics (SPEC.md C2) -- what the reference itself runs
+        # behind its channels (Tasks/LPFTask.cpp:52-69); the decimation is the power of two W / size
+        self.channeliser = channeliser
 
 
 class AnalyzerPipeline:
@@ -63,8 +67,16 @@ class AnalyzerPipeline:
         if bank is not None and len(bank.fnor):
             self.nchan = len(bank.fnor)
             D = bank.decimation
-            taps = ctx.lpf_design(bank.ntaps, bank.bw_rel / D)
-            self.chan = engine.ChannelBank(ctx, bank.fnor, D, taps)
+            if bank.channeliser == "fft":
+                self.chan = None
+                self.st = engine.SpectTuner(ctx, 4096)
+                for f in bank.fnor:
+                    c = self.st.open_channel((np.pi * f) % (2 * np.pi), 2 * np.pi * bank.bw_rel / D, 1.0)
+                    assert self.st.decimation(c) == D, "the FFT channeliser decimates by powers of two"
+                assert self.block_len % 2048 == 0
+            else:
+                taps = ctx.lpf_design(bank.ntaps, bank.bw_rel / D)
+                self.chan = engine.ChannelBank(ctx, bank.fnor, D, taps)
             self.m_max = self.block_len // D + 2
             nb = self.NBUF if overlap else 1
             # intermediates between stages are time-major ([time][channel] in memory): each
@@ -87,6 +99,7 @@ class AnalyzerPipeline:
                 self.qprev = [torch.zeros(self.nchan, dtype=torch.complex64, device=self.dev) for _ in range(2)]
                 self.first = True
             self.clock = engine.ClockBank(ctx, self.nchan, bank.clock_gain, 1.0 / bank.sps)
+        self.host_sym = None
         if overlap:
             self.s_agc = torch.cuda.Stream(self.dev)
             self.s_dem = torch.cuda.Stream(self.dev)      # Costas / quad demod
@@ -113,6 +126,12 @@ class AnalyzerPipeline:
         if e is not None:
             stream.wait_event(e)
 
+    def _channelise(self, x, out, st):
+        if self.chan is not None:
+            return self.chan.feed(x, out=out, stream=st)
+        y, counts = self.st.feed(x, out=out, stream=st)           # the first block is one half window short
+        return y[:, :counts[0]]
+
     def step(self, x, timed=False, stream=None):
         """One pass of the hot path over one resident IQ block x (complex64 [block_len])."""
         st = stream or torch.cuda.current_stream(self.dev)
@@ -137,7 +156,7 @@ class AnalyzerPipeline:
         # ---- channel bank: many workgroups, on the caller's stream ----
         self._wait(st, "agc" if (psk and self.agc is not None) else "dem", k - nb)   # y[i] free again
         self._mark("fir0", st, timed)
-        y = self.chan.feed(x, out=self.y[i], stream=st)
+        y = self._channelise(x, self.y[i], st)
         self._mark("fir1", st, timed)
         self._signal("fir", k, st)
         m = y.shape[1]
@@ -181,7 +200,7 @@ class AnalyzerPipeline:
         if self.nchan:
             cfg = self.bank_cfg
             self._mark("fir0", st, timed)
-            y = self.chan.feed(x, out=self.y[0], stream=st)
+            y = self._channelise(x, self.y[0], st)
             self._mark("fir1", st, timed)
             m = y.shape[1]
             with torch.cuda.stream(st):
@@ -206,6 +225,24 @@ class AnalyzerPipeline:
             self.clock.feed(z, self.sym[0], self.count[0], stream=st)
             self._mark("clk1", st, timed)
         return self.psd_out if self.do_psd else None
+
+    def enable_delivery(self):
+        """Hand-off to the host, as the analyzer's SAMPLES messages need it: after every step the recovered symbols and
+        their counts are copied to pinned host memory on the clock stage's stream (overlap=True only)."""
+        assert self.overlap and self.nchan
+        nb = self.NBUF
+        self.sym_cap = min(self.m_max, int(self.m_max / max(1.0, 0.5 * self.bank_cfg.sps)) + 64)
+        self.host_sym = [torch.empty((self.nchan, self.sym_cap), dtype=torch.complex64).pin_memory() for _ in range(nb)]
+        self.host_count = [torch.zeros(self.nchan, dtype=torch.int32).pin_memory() for _ in range(nb)]
+
+    def deliver(self):
+        """Enqueues the device -> host copy of the block just fed; returns (host symbols, host counts) of that slot --
+        valid once the clock stream has passed (latest_symbols() / sync())."""
+        i = (self.k - 1) % self.NBUF
+        with torch.cuda.stream(self.s_clk):
+            self.host_sym[i].copy_(self.sym[i][:, :self.sym_cap], non_blocking=True)
+            self.host_count[i].copy_(self.count[i], non_blocking=True)
+        return self.host_sym[i], self.host_count[i]
 
     def latest_symbols(self):
         """(sym, count) of the most recently fed block (synchronises the clock stage)."""

@@ -28,7 +28,7 @@ def relerr(a, b):
     return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30))
 
 
-def run_gpu(ctx, x, chans, splits=None, run=None):
+def run_gpu(ctx, x, chans, splits=None, run=None, time_major=False):
     """chans: list of (f0, bw, guard, precise).  Returns the per-channel streams."""
     st = engine.SpectTuner(ctx, W)
     if run:
@@ -38,7 +38,8 @@ def run_gpu(ctx, x, chans, splits=None, run=None):
     cuts = [0] + list(splits or []) + [x.size]
     outs = [[] for _ in ids]
     for a, b in zip(cuts[:-1], cuts[1:]):
-        out, counts = st.feed(dx[a:b])
+        buf = engine.time_major(len(ids), (b - a) + 16, "cuda") if time_major else None
+        out, counts = st.feed(dx[a:b], out=buf)
         torch.cuda.synchronize()
         for k, c in enumerate(ids):
             outs[k].append(out[c, :counts[c]].cpu().numpy())
@@ -72,6 +73,10 @@ def test_bank_of_64_psk_channels_d64(ctx, sdo):
         ref = sdo.specttuner_run(x, W, chans[c][0], bw, 1.0)
         assert got[c].size == ref.size
         assert relerr(got[c], ref) <= TOL, c
+    # time-major rows ([m][channel] in memory, what the recurrence kernels stream) go through the LDS tile: same bits
+    tm = run_gpu(ctx, x, chans, splits=[H * 9], time_major=True)
+    for a, b in zip(got, tm):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
 def test_any_split_of_the_stream_gives_the_same_samples(ctx):
@@ -85,7 +90,7 @@ def test_any_split_of_the_stream_gives_the_same_samples(ctx):
 
 
 def test_precise_channel_corrects_the_bin_rounding(ctx, sdo):
-    f0 = 2 * np.pi * 0.1 + 0.0007                 # between two even bins
+    f0 = 2 * np.pi * 411 / W                      # an odd bin: as far from the even centre bins as it gets
     n = H * 60
     x = np.exp(1j * f0 * np.arange(n)).astype(np.complex64)
     bw = 2 * np.pi / 64 * 0.75
@@ -95,7 +100,7 @@ def test_precise_channel_corrects_the_bin_rounding(ctx, sdo):
     tail = got[200:]
     assert np.max(np.abs(np.angle(tail[1:] * np.conj(tail[:-1])))) < 2e-3     # the tone lands on DC
     coarse = run_gpu(ctx, x, [(f0, bw, 1.0, False)])[0][200:]
-    assert np.median(np.abs(np.angle(coarse[1:] * np.conj(coarse[:-1])))) > 1e-2
+    assert np.median(np.abs(np.angle(coarse[1:] * np.conj(coarse[:-1])))) > 5e-2   # one bin, times the decimation
 
 
 def test_more_channels_than_one_workgroup_serves_and_mixed_responses(ctx, sdo):
@@ -107,6 +112,9 @@ def test_more_channels_than_one_workgroup_serves_and_mixed_responses(ctx, sdo):
     for c in (0, 63, 64, 127, 128, 149):
         ref = sdo.specttuner_run(x, W, chans[c][0], chans[c][1], 1.0, chans[c][3])
         assert relerr(got[c], ref) <= TOL, c
+    tm = run_gpu(ctx, x, chans, time_major=True)
+    for a, b in zip(got, tm):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
 def test_channels_of_different_sizes_and_open_close_between_feeds(ctx, sdo):
@@ -164,7 +172,7 @@ def test_lpftask_contract_through_the_sigutils_names(sdo):
     assert ref.size >= n
     assert relerr(got, ref[:n]) <= TOL
     # it is a low-pass: the tone at 0.05 rad/sample (inside pi * 0.1 / 2 ... ) survives, the wideband noise drops
-    assert np.var(got[W:]) < 0.5 * np.var(x)
+    assert np.var(got[W:]) < 0.6 * np.var(x)                # the unit tone + 5 % of the unit noise, out of 2
 
 
 def test_full_size_block_64_channels(ctx, sdo):
