@@ -1,0 +1,147 @@
+"""BASELINE.json's full sizes against the ORACLE (not against a re-run): the shapes bench.py times.
+
+ * C4 slice: all 64 rows of the 65 536-sample AGC -> Costas -> Gardner chain (the `costas_kernel<2,2,true>` instantiation
+   the bench runs), bit for bit;
+ * per-bin PSD bounds at 8192 and 16384 points (the norm-wise 1e-5 of test_gpu_parity.py says nothing about weak bins);
+ * C3 at full size: 16384-pt PSD + 64 FSK inspectors (channel bank -> quad demod -> Gardner) on a 4 Mi-sample block;
+ * channel sharding: two rank-shards of the pipeline on one GPU deliver, channel for channel, the symbols of the
+   single-rank pipeline.
+"""
+import numpy as np
+import pytest
+import torch
+
+from sigdigger_amd import engine, pipeline, synth
+
+pytestmark = pytest.mark.gpu
+
+L = 1 << 22
+C, D, T = 64, 64, 255
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_c4_recurrence_chain_all_64_rows_equal_the_oracle(ctx, sdo):
+    M = L // D
+    sps = 1000 / D                                                   # the bench's 15.6 samples per symbol
+    base = synth.psk_carriers(M, [0.0], sps=16, order=4, seed=2)
+    rows = np.stack([np.roll(base, 97 * c) * np.exp(1j * 0.1 * c) * (0.3 + 0.02 * c) for c in range(C)]).astype(np.complex64)
+    xt = engine.time_major(C, M, "cuda")
+    xt.copy_(torch.from_numpy(rows).cuda())
+    agc = engine.AGCBank(ctx, C, tau=sps)
+    cos = engine.CostasBank(ctx, C, engine.COSTAS_QPSK, 0.0, 2.0 / sps, 3, 0.005)          # unit loop gain: GAIN1 = true
+    clk = engine.ClockBank(ctx, C, 0.2, 1.0 / sps)
+    sym = torch.zeros((C, M // 4), dtype=torch.complex64, device="cuda")
+    cnt = torch.zeros(C, dtype=torch.int32, device="cuda")
+    a = agc.feed(xt, out=engine.time_major(C, M, "cuda"))
+    z = cos.feed(a, out=engine.time_major(C, M, "cuda"))
+    clk.feed(z, sym, cnt)
+    torch.cuda.synchronize()
+    ah, zh, sh, ch = a.cpu().numpy(), z.cpu().numpy(), sym.cpu().numpy(), cnt.cpu().numpy()
+    for c in range(C):
+        ra = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(sps)), rows[c])
+        rz = sdo.costas_feed_bulk(sdo.costas_new(2, 0.0, 2.0 / sps, 3, 0.005), ra)
+        rs = sdo.clock_feed_bulk(sdo.clock_new(0.2, 1.0 / sps), rz)
+        assert np.array_equal(bits(ah[c]), bits(ra)), f"row {c}: AGC"
+        assert np.array_equal(bits(zh[c]), bits(rz)), f"row {c}: Costas"
+        assert ch[c] == rs.size and np.array_equal(bits(sh[c, :ch[c]]), bits(rs)), f"row {c}: Gardner"
+    assert np.all(np.abs(ch - M / 16) <= 100)                       # the loops pull the 15.6-sample hint to the signal's 16
+
+
+@pytest.mark.parametrize("n", [8192, 16384])
+def test_psd_per_bin_bounds(ctx, sdo, n):
+    """Per bin, not per frame.  The device FFT is binary32 like the reference's FFTW3f: both carry an error floor that is
+    additive in AMPLITUDE and proportional to the frame's strongest component,
+        delta = 2 eps sqrt(log2 n) sqrt(peak),   |P - P_ref| <= 2 sqrt(P_ref) delta + delta^2,
+    so a bin far below the peak cannot be reproduced to 1e-5 by ANY single-precision transform.  What is asserted:
+      (i)  a frame without a dominating line (PSK carriers + noise): every bin within 30 dB of the peak is within 1e-5
+           relative of the binary64 oracle, bin by bin (at 40 dB below the peak the floor alone is 1.2e-5), and every
+           bin of the frame obeys the bound above;
+      (ii) a frame with a 69 dB line-to-floor ratio (the S1 tone of SURVEY.md 8d): every bin obeys the bound above."""
+    win = sdo.window(4, n)
+    psd = engine.PSD(ctx, n, engine.WINDOW_BLACKMANN_HARRIS)
+    # (i)
+    nfr = 4
+    x = synth.psk_carriers(n * nfr, [-0.6, -0.2, 0.15, 0.5, 0.8], sps=8, seed=n, snr_db=10)
+    ref = sdo.psd_frames(x, nfr, n, n, win, navg=1, scale=1.0 / n)
+    out = psd.feed(torch.from_numpy(x).cuda(), nframes=nfr, scale=1.0 / n).cpu().numpy()
+    for f in range(nfr):
+        sel = ref[f] >= 1e-3 * ref[f].max()
+        assert sel.sum() > n // 4                                          # the carriers: a large part of the frame
+        rel = np.abs(out[f][sel] - ref[f][sel]) / ref[f][sel]
+        assert rel.max() <= 1e-5, (f, rel.max())
+        r64, o64 = ref[f].astype(np.float64), out[f].astype(np.float64)
+        delta = 2 * float(np.finfo(np.float32).eps) * np.sqrt(np.log2(n)) * np.sqrt(r64.max())
+        assert np.all(np.abs(o64 - r64) <= 2 * np.sqrt(r64) * delta + delta * delta)
+    # (ii)
+    x = synth.tone_noise(n * nfr, f_rel=0.1003, sigma2=1e-3, seed=n + 1)
+    ref = sdo.psd_frames(x, nfr, n, n, win, navg=1, scale=1.0 / n).astype(np.float64)
+    out = psd.feed(torch.from_numpy(x).cuda(), nframes=nfr, scale=1.0 / n).cpu().numpy().astype(np.float64)
+    eps = float(np.finfo(np.float32).eps)
+    for f in range(nfr):
+        delta = 2 * eps * np.sqrt(np.log2(n)) * np.sqrt(ref[f].max())
+        bound = 2 * np.sqrt(ref[f]) * delta + delta * delta
+        assert np.all(np.abs(out[f] - ref[f]) <= bound), (f, float(np.max(np.abs(out[f] - ref[f]) / bound)))
+        strong = ref[f] >= 1e-3 * ref[f].max()                            # the line itself: 1e-5, bin by bin
+        assert np.max(np.abs(out[f][strong] - ref[f][strong]) / ref[f][strong]) <= 1e-5
+
+
+def test_c3_full_size_fsk_bank_against_the_oracle(ctx, sdo):
+    """C3: 16384-pt PSD + 64 2-FSK inspectors, D = 64, on a 4 Mi-sample block -- what bench.py's c3 line times."""
+    sps_in = 500
+    fn = synth.raster(C, 2 * 700e3 / 50e6)
+    x = synth.fsk_carriers(L, fn, sps=sps_in, seed=3, snr_db=25)
+    dx = torch.from_numpy(x).cuda()
+    bank = pipeline.InspectorBankConfig(kind="fsk", fnor=fn, decimation=D, ntaps=T, sps=sps_in / D, channeliser="fir")
+    pipe = pipeline.AnalyzerPipeline(ctx, L, psd_size=16384, psd_navg=L // 16384, bank=bank, do_psd=True, overlap=False)
+    psd = pipe.step(dx).cpu().numpy()
+    sym, cnt = pipe.latest_symbols()
+    torch.cuda.synchronize()
+    sh, ch = sym.cpu().numpy(), cnt.cpu().numpy()
+    win = sdo.window(4, 16384)
+    ref = sdo.psd_frames(x, L // 16384, 16384, 16384, win, navg=L // 16384, scale=1.0 / 16384)
+    sel = ref[0] >= 1e-3 * ref[0].max()
+    assert np.max(np.abs(psd[0][sel] - ref[0][sel]) / ref[0][sel]) <= 1e-5
+    taps = sdo.lpf_design(T, 0.75 / D)
+    for c in (0, 21, 63):
+        dp = sdo.fnor_to_dphase(-fn[c])
+        ry = sdo.chan_feed(np.zeros(T - 1, np.complex64), x, 0, sdo.chan_modulate_taps(taps, dp), D, 0, dp)
+        rq = sdo.quad_demod(ry)
+        rs = sdo.clock_feed_bulk(sdo.clock_new(0.2, D / sps_in), rq)
+        assert ch[c] == rs.size, c
+        assert np.array_equal(bits(sh[c, :ch[c]]), bits(rs)), c
+
+
+@pytest.mark.parametrize("channeliser", ["fir", "fft"])
+def test_two_rank_shards_on_one_gpu_equal_the_single_rank_pipeline(ctx, channeliser):
+    """channel c -> rank c mod G.  Here both "ranks" live on the one GPU of the test box and get the same
+    blocks (what the RCCL broadcast guarantees): every channel's symbols must be those of the unsharded pipeline."""
+    nch, Lb, blocks = 16, 1 << 18, 3
+    fn = synth.raster(nch, 0.05)
+    x = synth.psk_carriers(Lb * blocks, fn, sps=160, order=4, seed=5, snr_db=25)
+    dx = torch.from_numpy(x).cuda()
+
+    def run(fnor):
+        bank = pipeline.InspectorBankConfig(kind="psk", fnor=fnor, decimation=16, ntaps=127, sps=10.0, channeliser=channeliser)
+        pipe = pipeline.AnalyzerPipeline(ctx, Lb, psd_size=4096, bank=bank, do_psd=False)
+        outs = [[] for _ in fnor]
+        for k in range(blocks):
+            pipe.step(dx[k * Lb:(k + 1) * Lb])
+            sym, cnt = pipe.latest_symbols()
+            torch.cuda.synchronize()
+            s, n = sym.cpu().numpy(), cnt.cpu().numpy()
+            for c in range(len(fnor)):
+                outs[c].append(s[c, :n[c]].copy())
+        return [np.concatenate(o) for o in outs]
+
+    whole = run(fn)
+    for world in (2,):
+        for rank in range(world):
+            mine = run(pipeline.shard_channels(fn, rank, world))
+            for i, got in enumerate(mine):
+                c = rank + i * world
+                assert pipeline.channel_owner(c, world) == (rank, i)
+                assert got.size == whole[c].size and got.size > 1000
+                assert np.array_equal(bits(got), bits(whole[c])), (rank, i)
