@@ -128,6 +128,10 @@ SUAMD_API unsigned suamd_specttuner_channel_decimation(const suamd_specttuner_t 
  * may be NULL) receives how many.  Any split of a stream into feeds gives the same samples. */
 SUAMD_API SUBOOL suamd_specttuner_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len,
                                        suamd_complex *d_y, suamd_view view, SUSCOUNT *counts, void *stream);
+/* the same with one row per channel anywhere in device memory: d_rows (a DEVICE array indexed by channel) holds where
+ * each channel's samples of this feed start (contiguous in time) */
+SUAMD_API SUBOOL suamd_specttuner_feed_rows(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len,
+                                            suamd_complex *const *d_rows, SUSCOUNT *counts, void *stream);
 /* windows per workgroup run (default 4): a run re-transforms the window before it */
 SUAMD_API SUBOOL suamd_specttuner_set_run(suamd_specttuner_t *st, unsigned run);
 

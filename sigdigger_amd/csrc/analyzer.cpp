@@ -333,7 +333,11 @@ struct Inspector {
   double equiv_fs = 0, fnor = 0;
   SUSCOUNT watermark = 0;
   bool dirty = true;                          // chain must be (re)built
-  suamd_chanbank_t *bank = nullptr;
+  suamd_chanbank_t *bank = nullptr;           // channeliser "fir": translate + 255-tap low-pass + decimate (SPEC.md C)
+  suamd_specttuner_t *st = nullptr;           // channeliser "fft": a channel of the analyzer's su_specttuner (SPEC.md C2)
+  int st_chan = -1;
+  double st_f0 = 0, st_bw = 0, st_guard = 0; bool st_precise = false;   // what the open channel was opened with
+  bool precise = false;                       // open_ex_async's flag: the FFT channel corrects its centre-bin rounding
   suamd_agc_bank_t *agc = nullptr;
   suamd_costas_bank_t *costas = nullptr;
   suamd_clock_bank_t *clock = nullptr;
@@ -395,9 +399,17 @@ struct Inspector {
     pend_m = s.pend_m; pend_samples = s.pend_samples; pend_spectrum = s.pend_spectrum; pend_symbols = s.pend_symbols;
     pend_src = s.pend_src; pend_spec_n = s.pend_spec_n; est_fed[0] = s.est_fed[0]; est_fed[1] = s.est_fed[1];
   }
-  void free_chain()
+  void close_channel()
+  {
+    if (st && st_chan >= 0) (void)suamd_specttuner_close_channel(st, st_chan);
+    st_chan = -1;
+  }
+  // keep_channel: the FFT channel survives a rebuild of the stages behind it (a configuration change does not touch
+  // the channeliser: its stream goes on without a seam)
+  void free_chain(bool keep_channel = false)
   {
     if (bank) suamd_chanbank_destroy(bank);
+    if (!keep_channel) close_channel();
     if (agc) suamd_agc_bank_destroy(agc);
     if (costas) suamd_costas_bank_destroy(costas);
     if (clock) suamd_clock_bank_destroy(clock);
@@ -452,6 +464,7 @@ struct Request {
   SUHANDLE handle = -1;
   std::string cls;
   struct sigutils_channel channel{};
+  bool precise = false;
   uint32_t inspector_id = 0;
   suscan_config_t *config = nullptr;
   SUSCOUNT value = 0;
@@ -491,6 +504,14 @@ struct suscan_analyzer {
   // worker-owned
   suamd_ctx_t *ctx = nullptr;
   suamd_psd_t *psd = nullptr;
+  // the inspectors' channeliser: the FFT filter bank (su_specttuner semantics: one forward FFT of the block shared by all
+  // inspectors -- what libsuscan itself runs) whenever the block is a whole number of half windows, else -- or with
+  // SUAMD_ANALYZER_CHANNELISER=fir -- one translate + 255-tap FIR per inspector
+  bool want_fft = true, use_fft = false;
+  suamd_specttuner_t *st = nullptr;
+  suamd_complex **d_rowptr[2] = {nullptr, nullptr};   // per slot: where each FFT channel's row starts (device table)
+  suamd_complex **h_rowptr[2] = {nullptr, nullptr};   // pinned staging, and what the device table holds
+  size_t rowptr_cap = 0;
   std::map<SUHANDLE, std::unique_ptr<Inspector>> inspectors;
   hipStream_t stream = nullptr;
   static constexpr int NISTREAMS = 4;          // gain control / carrier control / clock recovery / channeliser (+ spectra, estimators)
@@ -550,17 +571,39 @@ unsigned pow2floor(double v) { unsigned d = 1; while ((double)(d * 2) <= v && d 
 // (re)builds the GPU chain of one inspector from its channel + config
 bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
 {
-  in.free_chain();
+  in.free_chain(/* keep_channel = */ a->use_fft);
   const double fs = a->source_cfg.samp_rate;
   const double bw = in.channel.bw > 0 ? in.channel.bw : fs / 4;
   in.D = pow2floor(fs / (2.0 * bw));
   in.equiv_fs = fs / in.D;
   in.fnor = 2.0 * in.channel.fc / fs;                    // channel centre relative to the tuner
-  float taps[255];
-  suamd_lpf_design(taps, 255, bw / fs);                  // cut-off bw/2 in Hz = (bw/fs) of Nyquist
-  const double fn = in.fnor;
-  in.bank = suamd_chanbank_new(a->ctx, 1, &fn, in.D, taps, 255);
-  if (!in.bank) { err = suamd_last_error(); return false; }
+  if (a->use_fft) {
+    // a channel of the shared FFT filter bank: f0, bw as angular frequencies; the guard band sizes the channel for
+    // exactly W / D bins (guard = fs / (D bw) >= 2), so the channel decimates by D like the FIR path does
+    if (!a->st) a->st = suamd_specttuner_new(a->ctx, 4096);
+    if (!a->st) { err = suamd_last_error(); return false; }
+    constexpr double kTwoPi = 6.283185307179586476925286766559;
+    double f0 = std::fmod(kTwoPi * in.channel.fc / fs, kTwoPi);
+    if (f0 < 0) f0 += kTwoPi;
+    const double bwa = kTwoPi * bw / fs, guard = fs / ((double)in.D * bw);
+    if (in.st_chan >= 0 && (in.st != a->st || in.st_f0 != f0 || in.st_bw != bwa || in.st_guard != guard || in.st_precise != in.precise)) in.close_channel();
+    in.st = a->st;
+    if (in.st_chan < 0) {
+      in.st_chan = suamd_specttuner_open_channel(a->st, f0, bwa, guard, in.precise ? SU_TRUE : SU_FALSE);
+      if (in.st_chan < 0) { err = suamd_last_error(); return false; }
+      in.st_f0 = f0; in.st_bw = bwa; in.st_guard = guard; in.st_precise = in.precise;
+    }
+    if (suamd_specttuner_channel_decimation(a->st, in.st_chan) != in.D) {
+      err = "FFT channeliser: unexpected decimation";
+      return false;
+    }
+  } else {
+    float taps[255];
+    suamd_lpf_design(taps, 255, bw / fs);                // cut-off bw/2 in Hz = (bw/fs) of Nyquist
+    const double fn = in.fnor;
+    in.bank = suamd_chanbank_new(a->ctx, 1, &fn, in.D, taps, 255);
+    if (!in.bank) { err = suamd_last_error(); return false; }
+  }
   const size_t need = a->block / in.D + 8;
   if (need > in.cap) {
     in.free_rows();
@@ -733,8 +776,36 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
   {
     // every inspector channelises the same wideband block: one launch for all of them
     std::vector<suamd_chanbank_t *> fb; std::vector<suamd_complex *> fy; std::vector<SUSCOUNT> fm(live.size());
-    for (Inspector *pi : live) { fb.push_back(pi->bank); fy.push_back(pi->d_y); }
-    if (!suamd_chanbank_gang_feed(a->ctx, fb.data(), (unsigned)fb.size(), a->d_x, len, fy.data(), fm.data(), sF)) { fail("channeliser"); return; }
+    if (a->use_fft) {
+      // the FFT filter bank: ONE forward transform of the block for all inspectors (per size group); every channel's row
+      // of this slot is looked up in a device table indexed by channel
+      size_t nrows = 0;
+      for (Inspector *pi : live) nrows = std::max(nrows, (size_t)pi->st_chan + 1);
+      if (nrows > a->rowptr_cap) {
+        const size_t cap = std::max<size_t>(64, 2 * nrows);
+        for (int p = 0; p < 2; ++p) {
+          if (a->d_rowptr[p]) (void)hipFree(a->d_rowptr[p]);
+          if (a->h_rowptr[p]) (void)hipHostFree(a->h_rowptr[p]);
+          a->d_rowptr[p] = a->h_rowptr[p] = nullptr;
+          if (hipMalloc((void **)&a->d_rowptr[p], cap * sizeof(void *)) != hipSuccess ||
+              hipHostMalloc((void **)&a->h_rowptr[p], cap * sizeof(void *), hipHostMallocDefault) != hipSuccess) { fail("channeliser tables"); return; }
+          std::memset(a->h_rowptr[p], 0, cap * sizeof(void *));
+        }
+        a->rowptr_cap = cap;
+        for (int p = 0; p < 2; ++p) (void)hipMemcpyAsync(a->d_rowptr[p], a->h_rowptr[p], cap * sizeof(void *), hipMemcpyHostToDevice, sF);
+      }
+      bool changed = false;
+      for (Inspector *pi : live)
+        if (a->h_rowptr[slot][pi->st_chan] != pi->d_y) { a->h_rowptr[slot][pi->st_chan] = pi->d_y; changed = true; }
+      // (the slot's previous block has been collected by now: its table and staging are free to change)
+      if (changed) (void)hipMemcpyAsync(a->d_rowptr[slot], a->h_rowptr[slot], nrows * sizeof(void *), hipMemcpyHostToDevice, sF);
+      std::vector<SUSCOUNT> counts(nrows, 0);
+      if (!suamd_specttuner_feed_rows(a->st, a->d_x, len, a->d_rowptr[slot], counts.data(), sF)) { fail("channeliser"); return; }
+      for (size_t i = 0; i < live.size(); ++i) fm[i] = counts[live[i]->st_chan];
+    } else {
+      for (Inspector *pi : live) { fb.push_back(pi->bank); fy.push_back(pi->d_y); }
+      if (!suamd_chanbank_gang_feed(a->ctx, fb.data(), (unsigned)fb.size(), a->d_x, len, fy.data(), fm.data(), sF)) { fail("channeliser"); return; }
+    }
     (void)hipEventRecord(a->ev_xfree, sF);                    // the wideband block may be overwritten from here on (the PSD is on the input stream itself)
     a->xfree_set = true;
     (void)hipEventRecord(a->ev_fir, sF);
@@ -958,6 +1029,7 @@ void handle_request(suscan_analyzer *a, Request &r)
       in->handle = a->next_handle++;
       in->cls = r.cls;
       in->channel = r.channel;
+      in->precise = r.precise;
       in->config = suscan_config_new(&h->desc);
       std::string err;
       if (!build_chain(a, *in, err)) {
@@ -1130,6 +1202,12 @@ bool setup_psd(suscan_analyzer *a, std::string &err)
     a->block = block;
     for (auto &kv : a->inspectors) kv.second->dirty = true;      // buffer capacities depend on the block
   }
+  const bool fft = a->want_fft && block % 2048 == 0;             // whole half windows of the 4096-point filter bank per block
+  if (fft != a->use_fft) {
+    for (auto &kv : a->inspectors) { kv.second->free_chain(); kv.second->dirty = true; }
+    a->use_fft = fft;
+    if (!fft && a->st) { suamd_specttuner_destroy(a->st); a->st = nullptr; }
+  }
   return true;
 }
 
@@ -1207,6 +1285,8 @@ void worker_main(suscan_analyzer *a)
       for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) e = e && hipEventCreateWithFlags(&a->ev_done[p][k], hipEventDisableTiming) == hipSuccess;
     }
     if (!e) { ok = false; err = "hipEventCreate failed"; }
+    const char *ce = std::getenv("SUAMD_ANALYZER_CHANNELISER");
+    a->want_fft = !(ce && !strcasecmp(ce, "fir"));
     const char *pe = std::getenv("SUAMD_ANALYZER_PIPELINE");
     a->pipelined = !a->trace && !(pe && std::atoi(pe) == 0);
   }
@@ -1450,6 +1530,14 @@ void worker_main(suscan_analyzer *a)
   (void)hipDeviceSynchronize();
   for (auto &kv : a->inspectors) kv.second->free_all();
   a->inspectors.clear();
+  if (a->st) suamd_specttuner_destroy(a->st);
+  a->st = nullptr;
+  for (int p = 0; p < 2; ++p) {
+    if (a->d_rowptr[p]) (void)hipFree(a->d_rowptr[p]);
+    if (a->h_rowptr[p]) (void)hipHostFree(a->h_rowptr[p]);
+    a->d_rowptr[p] = a->h_rowptr[p] = nullptr;
+  }
+  a->rowptr_cap = 0;
   if (a->psd) suamd_psd_destroy(a->psd);
   for (int p = 0; p < 2; ++p) {
     if (a->h_psd[p]) (void)hipHostFree(a->h_psd[p]);
@@ -1904,10 +1992,10 @@ struct suscan_source_info *suscan_analyzer_get_source_info(const suscan_analyzer
 }
 
 SUBOOL suscan_analyzer_open_ex_async(suscan_analyzer_t *a, const char *cls, const struct sigutils_channel *ch,
-                                     SUBOOL, SUHANDLE, uint32_t req)
+                                     SUBOOL precise, SUHANDLE, uint32_t req)
 {
   if (!cls || !ch) return SU_FALSE;
-  Request r; r.kind = Request::OPEN; r.req_id = req; r.cls = cls; r.channel = *ch;
+  Request r; r.kind = Request::OPEN; r.req_id = req; r.cls = cls; r.channel = *ch; r.precise = precise != 0;
   return post(a, std::move(r));
 }
 

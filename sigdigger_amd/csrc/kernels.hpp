@@ -81,6 +81,7 @@ struct StArgs {
   const void *prev_in; void *prev_out;   // [nchan][size/2]: second half of the last block of the previous feed (ping-pong)
   unsigned long long n0;        // outputs per channel emitted by earlier feeds (phase of the residual NCO)
   void *y; View yv;
+  const void *const *rows;      // when set: channel `row`'s samples of this feed start at rows[row] (unit time stride), y / yv.cs unused
 };
 // channels one workgroup serves side by side for inverse transforms of 2^log2s points
 int st_channels_per_group(int log2s);

@@ -145,7 +145,9 @@ __global__ __launch_bounds__(ST_THREADS, OCC) void st_kernel(sdk::StArgs a)
     // (channel-major rows) a thread stores its own samples (32-byte runs per 4 lanes)
     constexpr bool CAN_TILE = G::CPP >= 16;                      // tile = S/2 rows x (CPP + 4): fits the LDS region
     constexpr int TP = G::CPP + 4;                               // row pitch = 4 mod 32 elements: 16-lane store groups hit 16 bank pairs
-    const bool tile = CAN_TILE && a.yv.cs == 1;
+    const bool tile = CAN_TILE && a.yv.cs == 1 && !a.rows;
+    cf *ybase = a.rows ? static_cast<cf *>(const_cast<void *>(a.rows[cd.row])) : reinterpret_cast<cf *>(a.y) + (long long)cd.row * a.yv.cs;
+    const long long yms = a.rows ? 1 : a.yv.ms;
     if (tile && PS::P == 1) __syncthreads();                     // (P > 1: the last pass's gather ended with a barrier) the LDS becomes the tile
 #pragma unroll
     for (int b = 0; b < NBLS; ++b) {
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(ST_THREADS, OCC) void st_kernel(sdk::StArgs a)
             orr = tr; oi = ti;
           }
           if (tile) spec[i * TP + grp] = cf{orr, oi};
-          else reinterpret_cast<cf *>(a.y)[(long long)cd.row * a.yv.cs + (long long)m * a.yv.ms] = cf{orr, oi};
+          else ybase[(long long)m * yms] = cf{orr, oi};
         }
         prev[b][q] = nx;
       }

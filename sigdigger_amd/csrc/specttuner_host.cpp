@@ -345,8 +345,24 @@ SUBOOL suamd_specttuner_set_run(suamd_specttuner_t *st, unsigned run)
   return SU_TRUE;
 }
 
+static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_y, suamd_view view,
+                      suamd_complex *const *d_rows, SUSCOUNT *counts, void *stream);
+
 SUBOOL suamd_specttuner_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_y, suamd_view view,
                              SUSCOUNT *counts, void *stream)
+{
+  return st_feed(st, d_x, len, d_y, view, nullptr, counts, stream);
+}
+
+SUBOOL suamd_specttuner_feed_rows(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *const *d_rows,
+                                  SUSCOUNT *counts, void *stream)
+{
+  if (!d_rows) { suamd_set_error("null row table"); return SU_FALSE; }
+  return st_feed(st, d_x, len, nullptr, suamd_view{0, 1}, d_rows, counts, stream);
+}
+
+static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_y, suamd_view view,
+                      suamd_complex *const *d_rows, SUSCOUNT *counts, void *stream)
 {
   if (!st || (len && !d_x)) { suamd_set_error("null argument"); return SU_FALSE; }
   if (len % st->H) { suamd_set_error("len must be a multiple of half a window (%u)", st->H); return SU_FALSE; }
@@ -358,7 +374,7 @@ SUBOOL suamd_specttuner_feed(suamd_specttuner_t *st, const suamd_complex *d_x, S
     for (auto &kv : st->groups) {
       SizeGroup &g = kv.second;
       if (g.members.empty()) continue;
-      if (!d_y) { suamd_set_error("null output"); return SU_FALSE; }
+      if (!d_y && !d_rows) { suamd_set_error("null output"); return SU_FALSE; }
       sdk::StArgs a{};
       a.x = d_x; a.hist = st->d_hist[st->hist_cur]; a.have_hist = st->have_hist ? 1 : 0;
       a.nwin = nwin; a.run = (int)st->run;
@@ -368,6 +384,7 @@ SUBOOL suamd_specttuner_feed(suamd_specttuner_t *st, const suamd_complex *d_x, S
       a.prev_in = g.d_prev[g.prev_cur]; a.prev_out = g.d_prev[g.prev_cur ^ 1];
       a.n0 = g.nout;
       a.y = d_y; a.yv = sdk::View{(long long)view.chan_stride, (long long)view.time_stride};
+      a.rows = reinterpret_cast<const void *const *>(d_rows);
       const hipError_t e = sdk::specttuner_feed(st->log2w, g.log2s, a, s);
       if (e != hipSuccess) { suamd_set_error("specttuner launch failed: %s", hipGetErrorString(e)); return SU_FALSE; }
       g.prev_cur ^= 1;

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "suamd_specttuner_channel_size": (UINT, [VP, INT]),
     "suamd_specttuner_channel_decimation": (UINT, [VP, INT]),
     "suamd_specttuner_feed": (INT, [VP, VP, U64, VP, View, C.POINTER(U64), VP]),
+    "suamd_specttuner_feed_rows": (INT, [VP, VP, U64, VP, C.POINTER(U64), VP]),
     "suamd_specttuner_set_run": (INT, [VP, UINT]),
     "suamd_fnor_to_dphase": (U32, [F64]),
     "suamd_xlate_bulk": (INT, [VP, VP, VP, U64, U32, U32, U64, VP]),

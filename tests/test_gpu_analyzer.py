@@ -12,6 +12,14 @@ from sigdigger_amd import suscan, synth
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _fir_channeliser(monkeypatch):
+    """These tests pin the inspector chains bit for bit against the oracle's translate + 255-tap FIR channeliser
+    (SPEC.md C); the analyzer's default, the FFT filter bank (SPEC.md C2), has its own file: test_gpu_analyzer_fft.py."""
+    monkeypatch.setenv("SUAMD_ANALYZER_CHANNELISER", "fir")
+
+
 FS = 1_000_000
 N = 4096
 NAVG = 16                       # psd_update_int = N*NAVG/FS
