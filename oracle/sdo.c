@@ -1457,7 +1457,7 @@ void sdo_specttuner_geometry(unsigned W, double f0, double bw, double guard, sdo
   unsigned min_size, size = 1;
   if (actual_bw > 2.0 * SDO_PI) actual_bw = 2.0 * SDO_PI;
   k = actual_bw / (2.0 * SDO_PI);
-  min_size = (unsigned)ceil(k * (double)W);
+  min_size = (unsigned)ceil(k * (double)W - 1e-6);       /* bw * guard = 2 pi / D must give W / D bins, not one more */
   while (size < min_size) size <<= 1;
   if (size < 16) size = 16;                              /* smallest inverse transform served (a wider guard band) */
   if (size > W) size = W;

@@ -56,7 +56,7 @@ Geom design_geometry(unsigned W, double f0, double bw, double guard)
   double actual_bw = bw * guard;
   if (actual_bw > 2.0 * kPi) actual_bw = 2.0 * kPi;
   const double k = actual_bw / (2.0 * kPi);
-  const unsigned min_size = (unsigned)std::ceil(k * (double)W);
+  const unsigned min_size = (unsigned)std::ceil(k * (double)W - 1e-6);   // bw * guard = 2 pi / D must give W / D bins, not one more
   unsigned size = 1;
   while (size < min_size) size <<= 1;
   if (size < 16) size = 16;
