@@ -1459,7 +1459,7 @@ void sdo_specttuner_geometry(unsigned W, double f0, double bw, double guard, sdo
   k = actual_bw / (2.0 * SDO_PI);
   min_size = (unsigned)ceil(k * (double)W - 1e-6);       /* bw * guard = 2 pi / D must give W / D bins, not one more */
   while (size < min_size) size <<= 1;
-  if (size < 16) size = 16;                              /* smallest inverse transform served (a wider guard band) */
+  if (size < 2) size = 2;
   if (size > W) size = W;
   g->size = size;
   g->halfsz = size / 2;

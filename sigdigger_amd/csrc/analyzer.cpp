@@ -578,6 +578,7 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
   in.equiv_fs = fs / in.D;
   in.fnor = 2.0 * in.channel.fc / fs;                    // channel centre relative to the tuner
   if (a->use_fft) {
+    if (in.D > 2048) { in.D = 2048; in.equiv_fs = fs / in.D; }   // the filter bank's smallest channel is 2 of its 4096 bins
     // a channel of the shared FFT filter bank: f0, bw as angular frequencies; the guard band sizes the channel for
     // exactly W / D bins (guard = fs / (D bw) >= 2), so the channel decimates by D like the FIR path does
     if (!a->st) a->st = suamd_specttuner_new(a->ctx, 4096);

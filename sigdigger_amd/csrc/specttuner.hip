@@ -32,7 +32,7 @@ constexpr int ST_THREADS = 256;
 
 template <int LOG2S> struct StGeomT {
   static constexpr int S    = 1 << LOG2S;
-  static constexpr int TPI  = (LOG2S == 5) ? 4 : (S / 16);     // threads per inverse transform (E = 16 points each; 8 for S = 32)
+  static constexpr int TPI  = (LOG2S == 5) ? 4 : (LOG2S < 4 ? 1 : S / 16);   // threads per inverse transform (16 points each; 8 for S = 32; S for S < 16)
   static constexpr int E    = S / TPI;
   static constexpr int CPP  = ST_THREADS / TPI;                // channels side by side in one workgroup
   static constexpr int PADS = S + S / 16 + 1;                  // a group's LDS scratch (elements)
@@ -239,13 +239,16 @@ hipError_t launch_st(const sdk::StArgs &a, hipStream_t st)
 
 namespace sdk {
 
-int st_channels_per_group(int log2s) { return log2s == 5 ? 64 : (256 * 16) >> log2s; }
+int st_channels_per_group(int log2s) { return log2s == 5 ? 64 : (log2s < 4 ? 256 : (256 * 16) >> log2s); }
 
 hipError_t specttuner_feed(int log2w, int log2s, const StArgs &a, hipStream_t st)
 {
   if (log2w != 12) return hipErrorInvalidValue;
   if (a.nwin <= 0 || a.nchan <= 0) return hipSuccess;
   switch (log2s) {
+    case 1:  return launch_st<12, 1>(a, st);
+    case 2:  return launch_st<12, 2>(a, st);
+    case 3:  return launch_st<12, 3>(a, st);
     case 4:  return launch_st<12, 4>(a, st);
     case 5:  return launch_st<12, 5>(a, st);
     case 6:  return launch_st<12, 6>(a, st);

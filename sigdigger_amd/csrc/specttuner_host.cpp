@@ -59,7 +59,7 @@ Geom design_geometry(unsigned W, double f0, double bw, double guard)
   const unsigned min_size = (unsigned)std::ceil(k * (double)W - 1e-6);   // bw * guard = 2 pi / D must give W / D bins, not one more
   unsigned size = 1;
   while (size < min_size) size <<= 1;
-  if (size < 16) size = 16;
+  if (size < 2) size = 2;
   if (size > W) size = W;
   g.size = size; g.halfsz = size / 2;
   g.width = (unsigned)std::ceil((double)min_size / guard);
@@ -138,11 +138,15 @@ struct SizeGroup {
   c32 *d_prev[2] = {nullptr, nullptr};
   int prev_cur = 0;
   unsigned long long nout = 0;         // outputs per channel emitted so far
-  bool dirty = true;
+  // membership changes are applied at the next feed (one table rebuild for any number of opens / closes); until then
+  // the table the device last used and its cross-fade state are kept aside
+  bool dirty = false;
+  std::vector<int> snap_members;
+  c32 *snap_prev = nullptr;
   void release()
   {
-    for (void *p : {(void *)d_chans, (void *)d_hk, (void *)d_tw, (void *)d_win, (void *)d_prev[0], (void *)d_prev[1]}) if (p) (void)hipFree(p);
-    d_chans = nullptr; d_hk = d_tw = nullptr; d_win = nullptr; d_prev[0] = d_prev[1] = nullptr;
+    for (void *p : {(void *)d_chans, (void *)d_hk, (void *)d_tw, (void *)d_win, (void *)d_prev[0], (void *)d_prev[1], (void *)snap_prev}) if (p) (void)hipFree(p);
+    d_chans = nullptr; d_hk = d_tw = nullptr; d_win = nullptr; d_prev[0] = d_prev[1] = nullptr; snap_prev = nullptr;
   }
 };
 
@@ -158,6 +162,7 @@ struct suamd_specttuner {
   int hist_cur = 0;
   bool have_hist = false;
   std::vector<Channel> ch;
+  std::vector<int> closed_pending;     // closed since the last feed: not handed out again before the tables are rebuilt
   std::map<int, SizeGroup> groups;
 };
 
@@ -172,7 +177,7 @@ namespace {
 std::vector<int> bank_friendly_order(unsigned W, int log2s, const std::vector<int> &members, const std::vector<Channel> &ch)
 {
   const unsigned S = 1u << log2s, HS = S / 2;
-  const unsigned TPI = log2s == 5 ? 4 : S / 16, E = S / TPI;
+  const unsigned TPI = log2s == 5 ? 4 : (log2s < 4 ? 1 : S / 16), E = S / TPI;
   if (TPI >= 32 || members.size() < 2) return members;
   const unsigned per_half = 32 / TPI;
   // pass-0 operand geometry of fft_core's plan: i = tl + b*TPI + q*(S/R0); as a set over (b, q) it is {tl + TPI*e, e < E}
@@ -257,6 +262,17 @@ bool rebuild_group(suamd_specttuner *st, SizeGroup &g, const std::vector<int> &o
   return g.d_chans && g.d_hk && g.d_tw && g.d_win;
 }
 
+// first membership change since the last feed: set the device's view of the group aside
+void touch_group(SizeGroup &g)
+{
+  if (g.dirty) return;
+  (void)hipDeviceSynchronize();                               // a feed still in flight reads the old tables
+  g.snap_members = g.members;
+  g.snap_prev = g.d_prev[g.prev_cur];
+  g.d_prev[g.prev_cur] = nullptr;
+  g.dirty = true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -293,21 +309,15 @@ int suamd_specttuner_open_channel(suamd_specttuner_t *st, double f0, double bw, 
   Channel c;
   c.open = true; c.g = design_geometry(st->W, f0, bw, guard); c.precise = precise != 0;
   int idx = -1;
-  for (size_t i = 0; i < st->ch.size(); ++i) if (!st->ch[i].open) { idx = (int)i; break; }
+  for (size_t i = 0; i < st->ch.size(); ++i)
+    if (!st->ch[i].open && std::find(st->closed_pending.begin(), st->closed_pending.end(), (int)i) == st->closed_pending.end()) { idx = (int)i; break; }
   if (idx < 0) { st->ch.push_back(Channel()); idx = (int)st->ch.size() - 1; }
   SizeGroup &g = st->groups[c.g.log2s];
   g.log2s = c.g.log2s;
   c.n_open = g.nout;
   st->ch[idx] = c;
-  // keep the others' state: the old table / prev buffer stay until the rebuild has copied from them
-  const std::vector<int> old = g.members;
+  touch_group(g);
   g.members.push_back(idx);
-  (void)hipDeviceSynchronize();                               // a feed still in flight reads the old tables
-  c32 *old_prev = g.d_prev[g.prev_cur];
-  g.d_prev[g.prev_cur] = nullptr;
-  const bool ok = rebuild_group(st, g, old, old_prev);
-  if (old_prev) (void)hipFree(old_prev);
-  if (!ok) { suamd_set_error("device allocation failed"); return -1; }
   return idx;
 }
 
@@ -316,16 +326,10 @@ SUBOOL suamd_specttuner_close_channel(suamd_specttuner_t *st, int channel)
   if (!st || channel < 0 || (size_t)channel >= st->ch.size() || !st->ch[channel].open) { suamd_set_error("no such channel"); return SU_FALSE; }
   if (hipSetDevice(suamd_ctx_device(st->ctx)) != hipSuccess) { suamd_set_error("hipSetDevice failed"); return SU_FALSE; }
   SizeGroup &g = st->groups[st->ch[channel].g.log2s];
-  const std::vector<int> old = g.members;
+  touch_group(g);
   g.members.erase(std::find(g.members.begin(), g.members.end(), channel));
   st->ch[channel].open = false;
-  (void)hipDeviceSynchronize();
-  c32 *old_prev = g.d_prev[g.prev_cur];
-  g.d_prev[g.prev_cur] = nullptr;
-  const bool ok = rebuild_group(st, g, old, old_prev);
-  if (old_prev) (void)hipFree(old_prev);
-  if (g.members.empty()) { g.release(); st->groups.erase(g.log2s); }
-  if (!ok) { suamd_set_error("device allocation failed"); return SU_FALSE; }
+  st->closed_pending.push_back(channel);
   return SU_TRUE;
 }
 
@@ -373,6 +377,12 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
   if (nwin > 0) {
     for (auto &kv : st->groups) {
       SizeGroup &g = kv.second;
+      if (g.dirty) {
+        const bool ok = g.members.empty() || rebuild_group(st, g, g.snap_members, g.snap_prev);
+        if (g.snap_prev) (void)hipFree(g.snap_prev);
+        g.snap_prev = nullptr; g.snap_members.clear(); g.dirty = false;
+        if (!ok) { suamd_set_error("device allocation failed"); return SU_FALSE; }
+      }
       if (g.members.empty()) continue;
       if (!d_y && !d_rows) { suamd_set_error("null output"); return SU_FALSE; }
       sdk::StArgs a{};
@@ -392,6 +402,7 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
       g.nout += (unsigned long long)nwin * HS;
       if (counts) for (int c : g.members) counts[c] = (SUSCOUNT)nwin * HS;
     }
+    st->closed_pending.clear();                               // every group's table has been rebuilt
   }
   // the last half window is the next feed's history
   if (hipMemcpyAsync(st->d_hist[st->hist_cur ^ 1], reinterpret_cast<const c32 *>(d_x) + (len - st->H), st->H * sizeof(c32),

@@ -47,7 +47,7 @@ def run_gpu(ctx, x, chans, splits=None, run=None, time_major=False):
     return [np.concatenate(o) for o in outs]
 
 
-@pytest.mark.parametrize("dec", [1, 2, 4, 16, 64, 128, 256])
+@pytest.mark.parametrize("dec", [1, 2, 4, 16, 64, 128, 256, 512, 1024, 2048])
 def test_one_channel_every_size_matches_oracle(ctx, sdo, dec):
     size = W // dec
     bw = 2 * np.pi * (0.75 * size / W)
