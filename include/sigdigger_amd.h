@@ -105,6 +105,30 @@ SUAMD_API SUBOOL suamd_inspector_spectrum_db_shift(suamd_ctx_t *ctx, SUFLOAT *d_
                                                    SUSCOUNT nspectra, void *stream);
 
 /* ------------------------------------------------------------------------------------ */
+/* N1: channel detector (su_channel_detector)                                            */
+/* ------------------------------------------------------------------------------------ */
+/* What libsuscan runs on the analyzer's spectrum to announce channels (SUSCAN_ANALYZER_MESSAGE_TYPE_CHANNEL,
+ * Suscan/Analyzer.cpp:75-98) with struct sigutils_channel_detector_params' alpha (spectrum smoothing), gamma (noise
+ * floor smoothing), snr (threshold as a linear power ratio over the floor) -- Suscan/AnalyzerParams.cpp:53-71; beta (signal
+ * level smoothing) smooths the reported peak level.  SPEC.md section O: smoothed spectrum, floor = smoothed median, runs
+ * of bins above snr * floor (gaps of up to two bins bridged, single-bin runs dropped). */
+typedef struct suamd_chandet suamd_chandet_t;
+struct suamd_channel { SUFREQ fc, f_lo, f_hi; SUFLOAT bw, snr, S0, N0; };   /* Hz relative to the spectrum's centre; snr, S0, N0 in dB */
+SUAMD_API suamd_chandet_t *suamd_chandet_new(suamd_ctx_t *ctx, unsigned n /* power of two, 512 .. 16384 */,
+                                             SUFLOAT alpha, SUFLOAT beta, SUFLOAT gamma, SUFLOAT snr);
+SUAMD_API void   suamd_chandet_destroy(suamd_chandet_t *det);
+/* one frame of n floats: linear power, natural FFT order (what suamd_psd_feed writes in mode LINEAR) */
+SUAMD_API SUBOOL suamd_chandet_feed(suamd_chandet_t *det, const SUFLOAT *d_psd, void *stream);
+/* the channels of the smoothed spectrum, ordered by frequency: at most cap; returns the count (-1 on error).
+ * Synchronises the stream. */
+SUAMD_API int    suamd_chandet_channels(suamd_chandet_t *det, SUFLOAT samp_rate, struct suamd_channel *out, unsigned cap, void *stream);
+/* the same in two steps for callers that must not wait: _find enqueues detection + the copy into the detector's pinned
+ * landing zone `slot` (0 / 1); _collect reads it after the caller has synchronised with the stream */
+SUAMD_API SUBOOL suamd_chandet_find(suamd_chandet_t *det, int slot, void *stream);
+SUAMD_API int    suamd_chandet_collect(suamd_chandet_t *det, int slot, SUFLOAT samp_rate, struct suamd_channel *out, unsigned cap);
+SUAMD_API SUFLOAT suamd_chandet_noise_floor(suamd_chandet_t *det, void *stream);    /* linear; synchronises */
+
+/* ------------------------------------------------------------------------------------ */
 /* T2 / N2: FFT channeliser (su_specttuner)                                              */
 /* ------------------------------------------------------------------------------------ */
 /* The device side of su_specttuner_new / _open_channel / _feed_bulk (Tasks/LPFTask.cpp:52-69,83-87; the channeliser

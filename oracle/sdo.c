@@ -1565,3 +1565,47 @@ size_t sdo_specttuner_run(const sdo_c32 *x, size_t len, unsigned W, double f0, d
   free(hk); free(prev); free(win); free(re); free(im); free(cr); free(ci);
   return n;
 }
+
+/* ---- O: channel detector (su_channel_detector) [SPEC, UPSTREAM-RECOLLECTION] ----------------------------------------
+ * SPEC.md section O; parameters of Suscan/AnalyzerParams.cpp:53-71. */
+static int cmp_float(const void *a, const void *b) { const float x = *(const float *)a, y = *(const float *)b; return (x > y) - (x < y); }
+
+void sdo_chandet_feed(sdo_chandet *d, const float *P)
+{
+  unsigned i;
+  float *tmp = malloc(sizeof(float) * d->n), med;
+  for (i = 0; i < d->n; ++i) d->S[i] = d->first ? P[i] : d->S[i] + d->alpha * (P[i] - d->S[i]);
+  memcpy(tmp, d->S, sizeof(float) * d->n);
+  qsort(tmp, d->n, sizeof(float), cmp_float);
+  med = tmp[d->n / 2];
+  d->N0 = d->first ? med : d->N0 + d->gamma * (med - d->N0);
+  d->first = 0;
+  free(tmp);
+}
+
+unsigned sdo_chandet_find(const sdo_chandet *d, sdo_chandet_record *rec, unsigned cap)
+{
+  const float thr = d->snr * d->N0;
+  const int n = (int)d->n, half = n / 2, GAP = 2, MINW = 2;
+  int j, b, t;
+  unsigned k = 0;
+#define AT(j) (d->S[((j) + half) & (n - 1)])
+  for (j = 0; j < n; ++j) {
+    int starts = 1, last = j, down = 0, width = 0;
+    double sum = 0, wsum = 0;
+    float peak = 0;
+    if (!(AT(j) > thr)) continue;
+    for (b = 1; b <= GAP + 1 && j - b >= 0; ++b) if (AT(j - b) > thr) { starts = 0; break; }
+    if (!starts) continue;
+    for (t = j; t < n && down <= GAP; ++t) {
+      const float p = AT(t);
+      if (p > thr) { last = t; down = 0; ++width; sum += (double)p; wsum += (double)p * (double)t; if (p > peak) peak = p; }
+      else ++down;
+    }
+    if (width < MINW) continue;
+    if (k < cap) { rec[k].first = j; rec[k].last = last; rec[k].width = width; rec[k].peak = peak; rec[k].sum = sum; rec[k].wsum = wsum; }
+    ++k;
+  }
+#undef AT
+  return k < cap ? k : cap;
+}

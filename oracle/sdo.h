@@ -270,6 +270,12 @@ void   sdo_specttuner_crossfade(unsigned size, float *win);                     
 size_t sdo_specttuner_run(const sdo_c32 *x, size_t len, unsigned W, double f0, double bw, double guard, int precise,
                           sdo_c32 *out, size_t cap);
 
+/* ---- O: channel detector, su_channel_detector (SPEC.md section O) [UPSTREAM-RECOLLECTION] ---------------------------- */
+typedef struct { unsigned n; float alpha, gamma, snr; int first; float N0; float *S; } sdo_chandet;   /* S: n floats, caller-owned */
+typedef struct { int first, last, width; float peak; double sum, wsum; } sdo_chandet_record;
+void     sdo_chandet_feed(sdo_chandet *d, const float *P);                          /* P: linear power, natural FFT order */
+unsigned sdo_chandet_find(const sdo_chandet *d, sdo_chandet_record *rec, unsigned cap);   /* ordered by first bin */
+
 #ifdef __cplusplus
 }
 #endif

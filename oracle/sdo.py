@@ -600,3 +600,33 @@ def specttuner_run(x, W, f0, bw, guard, precise=False):
     n = f(_p(x), C.c_size_t(x.size), C.c_uint(W), C.c_double(f0), C.c_double(bw), C.c_double(guard), C.c_int(int(precise)),
           _p(out), C.c_size_t(cap))
     return out[:n].copy()
+
+
+# ---- O: channel detector ----------------------------------------------------------------------------
+class _ChanDet(C.Structure):
+    _fields_ = [("n", C.c_uint), ("alpha", C.c_float), ("gamma", C.c_float), ("snr", C.c_float), ("first", C.c_int),
+                ("N0", C.c_float), ("S", C.c_void_p)]
+
+
+class _ChanDetRecord(C.Structure):
+    _fields_ = [("first", C.c_int), ("last", C.c_int), ("width", C.c_int), ("peak", C.c_float), ("sum", C.c_double), ("wsum", C.c_double)]
+
+
+class ChannelDetector:
+    def __init__(self, n, alpha, gamma, snr):
+        self.S = np.zeros(n, dtype=np.float32)
+        self.d = _ChanDet(n, alpha, gamma, snr, 1, 0.0, self.S.ctypes.data)
+
+    def feed(self, P):
+        lib().sdo_chandet_feed(C.byref(self.d), _p(_f(P)))
+
+    def find(self, cap=1024):
+        rec = (_ChanDetRecord * cap)()
+        f = lib().sdo_chandet_find
+        f.restype = C.c_uint
+        n = f(C.byref(self.d), rec, C.c_uint(cap))
+        return [(r.first, r.last, r.width, r.peak, r.sum, r.wsum) for r in rec[:n]]
+
+    @property
+    def N0(self):
+        return float(self.d.N0)

@@ -26,6 +26,8 @@ SOURCES = {
     "fft.hip": ["-ffp-contract=fast"],
     "specttuner.hip": ["-ffp-contract=off"],
     "specttuner_host.cpp": ["-ffp-contract=off"],
+    "chandet.hip": ["-ffp-contract=off"],
+    "chandet_host.cpp": ["-ffp-contract=off"],
     "ingest.hip": ["-ffp-contract=off"],
     "stages.hip": ["-ffp-contract=off"],
     "capi.hip":  ["-ffp-contract=off"],

@@ -507,6 +507,8 @@ struct suscan_analyzer {
   // the inspectors' channeliser: the FFT filter bank (su_specttuner semantics: one forward FFT of the block shared by all
   // inspectors -- what libsuscan itself runs) whenever the block is a whole number of half windows, else -- or with
   // SUAMD_ANALYZER_CHANNELISER=fir -- one translate + 255-tap FIR per inspector
+  suamd_chandet_t *chandet = nullptr;         // su_channel_detector on the block spectra -> CHANNEL messages
+  unsigned chan_every = 1, chan_phase = 0;    // a list every chan_every blocks (channel_update_int of signal time)
   bool want_fft = true, use_fft = false;
   suamd_specttuner_t *st = nullptr;
   suamd_complex **d_rowptr[2] = {nullptr, nullptr};   // per slot: where each FFT channel's row starts (device table)
@@ -1166,6 +1168,23 @@ void handle_request(suscan_analyzer *a, Request &r)
   }
 }
 
+// (re)creates the channel detector from the analyzer parameters (window size, alpha / beta / gamma / snr, channel_update_int)
+void setup_chandet(suscan_analyzer *a)
+{
+  const unsigned n = (unsigned)a->params.detector_params.window_size;
+  const size_t block = (size_t)n * a->navg;
+  if (a->chandet) { suamd_chandet_destroy(a->chandet); a->chandet = nullptr; }
+  {
+    const auto &dp = a->params.detector_params;
+    if (a->params.mode == SUSCAN_ANALYZER_MODE_CHANNEL && n >= 512 && n <= 16384 && dp.alpha > 0 && dp.alpha <= 1 &&
+        dp.gamma > 0 && dp.gamma <= 1 && dp.snr > 0 && a->params.channel_update_int > 0)
+      a->chandet = suamd_chandet_new(a->ctx, n, dp.alpha, dp.beta, dp.gamma, dp.snr);    // (out-of-range parameters: no lists)
+    const double blocks = (double)a->params.channel_update_int * a->source_cfg.samp_rate / (double)block;
+    a->chan_every = blocks < 1 ? 1u : (unsigned)(blocks + 0.5);
+    a->chan_phase = 0;
+  }
+}
+
 bool setup_psd(suscan_analyzer *a, std::string &err)
 {
   if (a->psd) { suamd_psd_destroy(a->psd); a->psd = nullptr; }
@@ -1203,6 +1222,7 @@ bool setup_psd(suscan_analyzer *a, std::string &err)
     a->block = block;
     for (auto &kv : a->inspectors) kv.second->dirty = true;      // buffer capacities depend on the block
   }
+  setup_chandet(a);
   const bool fft = a->want_fft && block % 2048 == 0;             // whole half windows of the 4096-point filter bank per block
   if (fft != a->use_fft) {
     for (auto &kv : a->inspectors) { kv.second->free_chain(); kv.second->dirty = true; }
@@ -1256,6 +1276,27 @@ struct AsyncRead {
     return got;
   }
 };
+
+// CHANNEL message (Suscan/Analyzer.cpp:75-98 lets it through to ChannelMessage): the detector's list of the block in `slot`
+void push_channels(suscan_analyzer *a, int slot)
+{
+  struct suamd_channel list[256];
+  const int n = suamd_chandet_collect(a->chandet, slot, (SUFLOAT)a->source_cfg.samp_rate, list, 256);
+  if (n < 0) return;
+  auto *m = static_cast<suscan_analyzer_channel_msg *>(std::calloc(1, sizeof(suscan_analyzer_channel_msg)));
+  m->channel_count = (unsigned)n;
+  m->channel_list = static_cast<sigutils_channel **>(std::calloc(n ? n : 1, sizeof(void *)));
+  double ft;
+  { std::lock_guard<std::mutex> lk(a->req_m); ft = a->source_cfg.freq; }
+  for (int k = 0; k < n; ++k) {
+    auto *c = static_cast<sigutils_channel *>(std::calloc(1, sizeof(sigutils_channel)));
+    c->fc = list[k].fc; c->f_lo = list[k].f_lo; c->f_hi = list[k].f_hi;      // relative to the tuner, like Analyzer::open's channels
+    c->bw = list[k].bw; c->snr = list[k].snr; c->S0 = list[k].S0; c->N0 = list[k].N0;
+    c->ft = ft; c->age = 0; c->present = 1;
+    m->channel_list[k] = c;
+  }
+  push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_CHANNEL, m);
+}
 
 void worker_main(suscan_analyzer *a)
 {
@@ -1321,7 +1362,7 @@ void worker_main(suscan_analyzer *a)
   int cur = 0;
   // Two blocks in flight: block k is enqueued (copy, PSD, every inspector stage) before block k-1's results are turned
   // into messages, so the device never waits for the host between blocks.  `flight` is the enqueued, uncollected block.
-  struct InFlight { bool on = false; int slot = 0; suscan_analyzer_psd_msg *msg = nullptr; unsigned n = 0; } flight;
+  struct InFlight { bool on = false; int slot = 0; suscan_analyzer_psd_msg *msg = nullptr; unsigned n = 0; bool chan = false; } flight;
   int slot = 0;
   double tmark[8] = {};
   static const bool dbg = std::getenv("SUAMD_ANALYZER_DEBUG") != nullptr;
@@ -1334,6 +1375,7 @@ void worker_main(suscan_analyzer *a)
     std::memcpy(f.msg->psd_data, a->h_psd[f.slot], f.n * sizeof(float));
     gettimeofday(&f.msg->rt_time, nullptr);
     push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_PSD, f.msg);
+    if (f.chan && a->chandet) push_channels(a, f.slot);
     collect_inspectors(a, f.slot);
     DBG("finish slot %d: done", f.slot);
     f.on = false; f.msg = nullptr;
@@ -1370,6 +1412,8 @@ void worker_main(suscan_analyzer *a)
           push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, err);
           a->halt = true;
         }
+      } else if (r.kind == Request::SET_PARAMS) {
+        setup_chandet(a);                                     // alpha / beta / gamma / snr / channel_update_int may have changed
       }
     }
     if (a->halt) break;
@@ -1469,6 +1513,11 @@ void worker_main(suscan_analyzer *a)
       break;
     }
     (void)hipMemcpyAsync(a->h_psd[slot], a->d_psd, n * sizeof(float), hipMemcpyDeviceToHost, a->stream);
+    bool chan_now = false;
+    if (a->chandet) {                                        // the detector follows every block's spectrum; a list now and then
+      if (!suamd_chandet_feed(a->chandet, a->d_psd, a->stream)) push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("channel detector: ") + suamd_last_error());
+      else if (++a->chan_phase >= a->chan_every) { a->chan_phase = 0; chan_now = suamd_chandet_find(a->chandet, slot, a->stream) != 0; }
+    }
     (void)hipEventRecord(a->ev_psd[slot], a->stream);
     InFlight now_f;
     {
@@ -1482,7 +1531,7 @@ void worker_main(suscan_analyzer *a)
       const double ts = (double)consumed / a->source_cfg.samp_rate;
       m->timestamp.tv_sec = (time_t)ts;
       m->timestamp.tv_usec = (suseconds_t)((ts - std::floor(ts)) * 1e6);
-      now_f.on = true; now_f.slot = slot; now_f.msg = m; now_f.n = n;
+      now_f.on = true; now_f.slot = slot; now_f.msg = m; now_f.n = n; now_f.chan = chan_now;
     }
     finish(flight);                                        // the block before this one: its messages go out now
     flight = now_f;
@@ -1533,6 +1582,8 @@ void worker_main(suscan_analyzer *a)
   a->inspectors.clear();
   if (a->st) suamd_specttuner_destroy(a->st);
   a->st = nullptr;
+  if (a->chandet) suamd_chandet_destroy(a->chandet);
+  a->chandet = nullptr;
   for (int p = 0; p < 2; ++p) {
     if (a->d_rowptr[p]) (void)hipFree(a->d_rowptr[p]);
     if (a->h_rowptr[p]) (void)hipHostFree(a->h_rowptr[p]);

@@ -87,6 +87,13 @@ struct StArgs {
 int st_channels_per_group(int log2s);
 hipError_t specttuner_feed(int log2w, int log2s, const StArgs &a, hipStream_t st);
 
+// ---- chandet.hip: su_channel_detector (SPEC.md section O) ----
+struct ChanDetRecord { int first, last, width; float peak; double sum, wsum; };   // bins in frequency order (0 = -fs/2)
+// n = 2^k <= 16384 bins, linear power in natural FFT order
+hipError_t chandet_feed(float *S, const float *P, int n, float alpha, float gamma, int first, float *N0, hipStream_t st);
+hipError_t chandet_find(const float *S, int n, const float *N0, float snr, ChanDetRecord *rec, unsigned *count, unsigned cap,
+                        hipStream_t st);
+
 // ---- loops.hip ----
 hipError_t quad_demod_batch(const void *x, View xv, void *y, View yv, int nchan, long long len,
                             const void *prev, int first, void *prev_out, hipStream_t st);

@@ -338,6 +338,41 @@ class ChannelBank:
         check(self.ctx.lib.suamd_chanbank_reset(self.h, _stream(stream)), "suamd_chanbank_reset")
 
 
+class ChannelDetector:
+    """suamd_chandet_t: su_channel_detector on the device (SPEC.md section O)."""
+
+    def __init__(self, ctx, n, alpha=1e-2, beta=1e-3, gamma=0.5, snr=2.0):
+        self.ctx, self.n = ctx, int(n)
+        self.h = ctx.lib.suamd_chandet_new(ctx.h, self.n, float(alpha), float(beta), float(gamma), float(snr))
+        if not self.h:
+            raise SigDiggerAmdError("suamd_chandet_new: " + _l.last_error())
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.suamd_chandet_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def feed(self, psd, stream=None):
+        assert psd.dtype == torch.float32 and psd.is_contiguous() and psd.numel() == self.n
+        check(self.ctx.lib.suamd_chandet_feed(self.h, _ptr(psd), _stream(stream)), "suamd_chandet_feed")
+
+    def channels(self, samp_rate, cap=1024, stream=None):
+        out = (_l.Channel * cap)()
+        n = self.ctx.lib.suamd_chandet_channels(self.h, float(samp_rate), out, cap, _stream(stream))
+        if n < 0:
+            raise SigDiggerAmdError("suamd_chandet_channels: " + _l.last_error())
+        return [dict(fc=c.fc, f_lo=c.f_lo, f_hi=c.f_hi, bw=c.bw, snr=c.snr, S0=c.S0, N0=c.N0) for c in out[:n]]
+
+    def noise_floor(self, stream=None):
+        return float(self.ctx.lib.suamd_chandet_noise_floor(self.h, _stream(stream)))
+
+
 class SpectTuner:
     """suamd_specttuner_t: the FFT channeliser (su_specttuner semantics, SPEC.md C2)."""
 

@@ -25,6 +25,11 @@ class View(C.Structure):
     _fields_ = [("chan_stride", U64), ("time_stride", U64)]
 
 
+class Channel(C.Structure):
+    """struct suamd_channel"""
+    _fields_ = [("fc", F64), ("f_lo", F64), ("f_hi", F64), ("bw", F32), ("snr", F32), ("S0", F32), ("N0", F32)]
+
+
 class AgcParams(C.Structure):
     """struct suamd_agc_params"""
     _fields_ = [("threshold", F32), ("slope_factor", F32), ("hang_max", UINT),
@@ -45,6 +50,13 @@ PROTOTYPES = {
     "suamd_psd_shift_db": (INT, [VP, VP, U64, U64, VP]),
     "suamd_averager_feed": (INT, [VP, VP, VP, U64, F32, INT, VP]),
     "suamd_inspector_spectrum_db_shift": (INT, [VP, VP, U64, U64, VP]),
+    "suamd_chandet_new": (VP, [VP, UINT, F32, F32, F32, F32]),
+    "suamd_chandet_destroy": (None, [VP]),
+    "suamd_chandet_feed": (INT, [VP, VP, VP]),
+    "suamd_chandet_channels": (INT, [VP, F32, VP, UINT, VP]),
+    "suamd_chandet_find": (INT, [VP, INT, VP]),
+    "suamd_chandet_collect": (INT, [VP, INT, F32, VP, UINT]),
+    "suamd_chandet_noise_floor": (F32, [VP, VP]),
     "suamd_specttuner_new": (VP, [VP, UINT]),
     "suamd_specttuner_destroy": (None, [VP]),
     "suamd_specttuner_open_channel": (INT, [VP, F64, F64, F64, INT]),

@@ -180,3 +180,58 @@ def test_blocks_that_are_not_whole_half_windows_fall_back_to_the_fir_channeliser
     ref = sdo.chan_feed(np.zeros(254, np.complex64), x[b0 * Lb_:], 0, sdo.chan_modulate_taps(sdo.lpf_design(255, bw / FS), dp), D, 0, dp)
     got = np.concatenate(st["samples"])
     assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_channel_detector_bit_exact_and_channel_messages(tmp_path, sdo, ctx):
+    """Row N1: su_channel_detector on the device -- (a) the object against the oracle on the same frames: smoothed spectrum,
+    noise floor and every channel record bit for bit; (b) the analyzer's CHANNEL messages find the carriers of a capture."""
+    import torch
+    from sigdigger_amd import engine
+    n = 8192
+    rng = np.random.default_rng(4)
+    det = engine.ChannelDetector(ctx, n, alpha=0.2, beta=1e-3, gamma=0.5, snr=4.0)
+    ora = sdo.ChannelDetector(n, 0.2, 0.5, 4.0)
+    base = np.full(n, 1e-3, np.float32)
+    for lo, hi, lvl in ((300, 420, 0.05), (2000, 2003, 0.2), (4090, 4110, 0.01), (7000, 7001, 1.0), (7500, 7800, 0.004)):
+        base[lo:hi] += lvl
+    base[7600:7602] = 1e-3                                                  # a two-bin gap inside a channel: bridged
+    for k in range(6):
+        P = (base * rng.chisquare(8, n).astype(np.float32) / 8).astype(np.float32)
+        P = np.roll(P, n // 2)                                              # natural FFT order
+        det.feed(torch.from_numpy(P).cuda())
+        ora.feed(P)
+    assert det.noise_floor() == np.float32(ora.N0)
+    got = det.channels(1e6)
+    ref = ora.find()
+    assert len(got) == len(ref) >= 4
+    df = 1e6 / n
+    for g, (first, last, width, peak, s, ws) in zip(got, ref):
+        assert g["f_lo"] == (first - n / 2 - 0.5) * df and g["f_hi"] == (last - n / 2 + 0.5) * df
+        assert g["fc"] == (ws / s - n / 2) * df
+        assert g["S0"] == np.float32(10) * np.log10(np.float32(peak) + np.float32(1e-8))
+    # (b)
+    nblocks = 12
+    fcs = [-300e3, 50e3, 220e3]
+    x = synth.psk_carriers(L * nblocks, [2 * f / FS for f in fcs], sps=32, order=4, seed=9, snr_db=15)
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    p = suscan.AnalyzerParams.default()
+    p.detector_params.alpha, p.detector_params.gamma, p.detector_params.snr = 0.3, 0.5, 6.0
+    p.channel_update_int = 3 * L / FS
+    Lb, mq, an = _start(path, L, params=p)
+    lists = []
+
+    def on_msg(t, ptr):
+        if t == suscan.MSG_CHANNEL:
+            m = C.cast(ptr, C.POINTER(suscan.ChannelMsg)).contents
+            lists.append([(m.channel_list[i].contents.fc, m.channel_list[i].contents.bw, m.channel_list[i].contents.snr)
+                          for i in range(m.channel_count)])
+
+    seen = _pump(Lb, an, on_msg)
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+    assert seen.count(suscan.MSG_CHANNEL) == nblocks // 3
+    last = lists[-1]
+    assert len(last) == 3
+    for (fc, bw, snr), want in zip(last, fcs):
+        assert abs(fc - want) < 3e3 and 25e3 < bw < 60e3 and snr > 8.0       # 31.25 kBd RRC carriers, 15 dB over the noise
