@@ -12,6 +12,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_runtime_first():
+    """PyTorch ships its own HIP / ROCr runtime; libsigdigger_amd.so uses the system's.  Both live in one process during
+    the tests, and torch must bring its runtime up BEFORE the library's first HIP call or it no longer sees the GPU --
+    whatever order the test files are collected in."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def sdo():
     """The CPU oracle (test infrastructure)."""

@@ -208,7 +208,7 @@ def test_channel_detector_bit_exact_and_channel_messages(tmp_path, sdo, ctx):
     for g, (first, last, width, peak, s, ws) in zip(got, ref):
         assert g["f_lo"] == (first - n / 2 - 0.5) * df and g["f_hi"] == (last - n / 2 + 0.5) * df
         assert g["fc"] == (ws / s - n / 2) * df
-        assert g["S0"] == np.float32(10) * np.log10(np.float32(peak) + np.float32(1e-8))
+        assert abs(g["S0"] - 10 * np.log10(peak + 1e-8)) < 1e-5                 # dB formatting on the host: libm log10f
     # (b)
     nblocks = 12
     fcs = [-300e3, 50e3, 220e3]
