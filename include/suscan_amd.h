@@ -336,8 +336,12 @@ SUAMD_API SUBOOL suscan_analyzer_replay(suscan_analyzer_t *analyzer, SUBOOL repl
 SUAMD_API void   suscan_analyzer_get_source_time(const suscan_analyzer_t *analyzer, struct timeval *tv);
 
 /* ---- wide-spectrum (panoramic) controls (Suscan/Analyzer.cpp:177-195, 258-281; Panoramic/Scanner.cpp:295-370).
- * Valid in SUSCAN_ANALYZER_MODE_WIDE_SPECTRUM only (SU_FALSE otherwise).  Hopping needs a tuner; with a file source
- * the values are recorded and every PSD frame carries the source's own frequency (the noHop case of the Scanner). */
+ * Valid in SUSCAN_ANALYZER_MODE_WIDE_SPECTRUM only (SU_FALSE otherwise).  A file source has no tuner: the capture is the
+ * sweep -- every block is one dwell -- and the PSD frames are labelled with the frequencies the sweep strategy visits
+ * (SPEC.md section P): step = rel_bandwidth * samp_rate over [hop min, hop max] (the analyzer parameters' min_freq /
+ * max_freq until set_hop_range is called); PROGRESSIVE walks the slots in order, STOCHASTIC draws them (DISCRETE: slot
+ * centres, CONTINUOUS: anywhere); min == max is the Scanner's noHop case.  Scanner::onPSDMessage (Panoramic/Scanner.cpp:
+ * 503-523) feeds each frame to its SpectrumView at that frequency. */
 enum suscan_analyzer_sweep_strategy { SUSCAN_ANALYZER_SWEEP_STRATEGY_STOCHASTIC = 0, SUSCAN_ANALYZER_SWEEP_STRATEGY_PROGRESSIVE = 1 };
 enum suscan_analyzer_spectrum_partitioning { SUSCAN_ANALYZER_SPECTRUM_PARTITIONING_DISCRETE = 0, SUSCAN_ANALYZER_SPECTRUM_PARTITIONING_CONTINUOUS = 1 };
 SUAMD_API SUBOOL suscan_analyzer_set_sweep_stratrgy(suscan_analyzer_t *analyzer, enum suscan_analyzer_sweep_strategy strategy);  /* sic */

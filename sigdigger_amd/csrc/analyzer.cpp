@@ -497,9 +497,12 @@ struct suscan_analyzer {
   std::string antenna;
   SUSCOUNT history_size = 0;
   bool replay = false;
+  // wide-spectrum (panoramic) mode, under req_m: every block of the source is one dwell of the sweep
   int sweep_strategy = 0, partitioning = 0;
   double hop_min = 0, hop_max = 0;
   float rel_bw = 1.0f;
+  uint64_t hop_k = 0;                          // dwells so far
+  uint32_t hop_lcg = 0x2545f491u;              // the stochastic strategy's generator
   SUSCOUNT buffering_size = 0;
   // worker-owned
   suamd_ctx_t *ctx = nullptr;
@@ -1277,6 +1280,29 @@ struct AsyncRead {
   }
 };
 
+// WIDE_SPECTRUM analyzers (Panoramic/Scanner.cpp:295-370): the tuner hops over [hop_min, hop_max] and every PSD frame
+// carries the frequency it was taken at (Scanner::onPSDMessage feeds it to the SpectrumView there, :503-523).  A
+// file / generator source has no tuner: the capture IS the sweep -- consecutive blocks are consecutive dwells -- and the
+// analyzer labels them the way the sweep strategy visits the range (SPEC.md section P):
+//   step = rel_bw * fs, nsteps = max(1, ceil((max - min) / step));
+//   PROGRESSIVE: dwell k at min + (k mod nsteps + 1/2) step;  STOCHASTIC: a pseudo-random slot (DISCRETE partitioning:
+//   the same slot centres; CONTINUOUS: anywhere in the range);  min == max (the Scanner's noHop): that frequency.
+// Called under req_m.
+double next_hop_frequency(suscan_analyzer *a)
+{
+  double lo = a->hop_min, hi = a->hop_max;
+  if (!(hi > lo)) { lo = a->params.min_freq; hi = a->params.max_freq; }     // set_hop_range not called yet: the analyzer parameters
+  const uint64_t k = a->hop_k++;
+  if (!(hi > lo)) return hi == lo && hi > 0 ? hi : a->source_cfg.freq;
+  const double step = (double)a->rel_bw * (double)a->source_cfg.samp_rate;
+  const uint64_t nsteps = std::max<uint64_t>(1, (uint64_t)std::ceil((hi - lo) / step - 1e-9));
+  if (a->sweep_strategy == SUSCAN_ANALYZER_SWEEP_STRATEGY_PROGRESSIVE) return lo + ((double)(k % nsteps) + 0.5) * step;
+  a->hop_lcg = a->hop_lcg * 1664525u + 1013904223u;
+  const double u = (double)(a->hop_lcg >> 8) / 16777216.0;                    // [0, 1)
+  if (a->partitioning == SUSCAN_ANALYZER_SPECTRUM_PARTITIONING_DISCRETE) return lo + ((double)(uint64_t)(u * (double)nsteps) + 0.5) * step;
+  return lo + u * (hi - lo);
+}
+
 // CHANNEL message (Suscan/Analyzer.cpp:75-98 lets it through to ChannelMessage): the detector's list of the block in `slot`
 void push_channels(suscan_analyzer *a, int slot)
 {
@@ -1524,7 +1550,10 @@ void worker_main(suscan_analyzer *a)
       auto *m = static_cast<suscan_analyzer_psd_msg *>(std::calloc(1, sizeof(suscan_analyzer_psd_msg)));
       m->psd_size = n;
       m->psd_data = static_cast<SUFLOAT *>(std::malloc(n * sizeof(SUFLOAT)));
-      { std::lock_guard<std::mutex> lk(a->req_m); m->fc = (int64_t)a->source_cfg.freq; }
+      {
+        std::lock_guard<std::mutex> lk(a->req_m);
+        m->fc = (int64_t)(a->params.mode == SUSCAN_ANALYZER_MODE_WIDE_SPECTRUM ? next_hop_frequency(a) : a->source_cfg.freq);
+      }
       m->samp_rate = (SUFLOAT)a->source_cfg.samp_rate;
       m->measured_samp_rate = a->measured_rate;
       m->looped = looped ? SU_TRUE : SU_FALSE;
@@ -2260,28 +2289,28 @@ static bool wide(const suscan_analyzer_t *a) { return a && a->params.mode == SUS
 SUBOOL suscan_analyzer_set_sweep_stratrgy(suscan_analyzer_t *a, enum suscan_analyzer_sweep_strategy strategy)
 {
   if (!wide(a) || (int)strategy < 0 || (int)strategy > 1) return SU_FALSE;
-  a->sweep_strategy = (int)strategy;
+  { std::lock_guard<std::mutex> lk(a->req_m); a->sweep_strategy = (int)strategy; }
   return SU_TRUE;
 }
 
 SUBOOL suscan_analyzer_set_spectrum_partitioning(suscan_analyzer_t *a, enum suscan_analyzer_spectrum_partitioning p)
 {
   if (!wide(a) || (int)p < 0 || (int)p > 1) return SU_FALSE;
-  a->partitioning = (int)p;
+  { std::lock_guard<std::mutex> lk(a->req_m); a->partitioning = (int)p; }
   return SU_TRUE;
 }
 
 SUBOOL suscan_analyzer_set_hop_range(suscan_analyzer_t *a, SUFREQ min, SUFREQ max)
 {
   if (!wide(a) || max < min) return SU_FALSE;
-  a->hop_min = min; a->hop_max = max;
+  { std::lock_guard<std::mutex> lk(a->req_m); a->hop_min = min; a->hop_max = max; a->hop_k = 0; }   // the sweep starts over
   return SU_TRUE;
 }
 
 SUBOOL suscan_analyzer_set_rel_bandwidth(suscan_analyzer_t *a, SUFLOAT rel_bw)
 {
   if (!wide(a) || !(rel_bw > 0) || rel_bw > 1) return SU_FALSE;
-  a->rel_bw = rel_bw;
+  { std::lock_guard<std::mutex> lk(a->req_m); a->rel_bw = rel_bw; }
   return SU_TRUE;
 }
 

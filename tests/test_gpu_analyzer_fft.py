@@ -235,3 +235,73 @@ def test_channel_detector_bit_exact_and_channel_messages(tmp_path, sdo, ctx):
     assert len(last) == 3
     for (fc, bw, snr), want in zip(last, fcs):
         assert abs(fc - want) < 3e3 and 25e3 < bw < 60e3 and snr > 8.0       # 31.25 kBd RRC carriers, 15 dB over the noise
+
+
+def test_wide_spectrum_sweep_through_the_abi_feeds_a_spectrum_view(tmp_path, sdo, ctx):
+    """Row P1: a WIDE_SPECTRUM analyzer (Panoramic/Scanner.cpp:295-370) on a capture: every block is a dwell, the PSD frames
+    carry the hop frequencies of the sweep strategy, and what Scanner::onPSDMessage does with them (PSDMessage ctor, then
+    SpectrumView::feed at msg.getFrequency(), :503-523) gives the panorama -- oracle SpectrumView on the analyzer's frames
+    against the device SpectrumView on the same frames, and the progressive hop sequence itself."""
+    import torch
+    from sigdigger_amd import engine
+    ndw = 24
+    fs, n, navg = FS, 1024, 4
+    Lw = n * navg
+    rng = np.random.default_rng(12)
+    x = (0.05 * (rng.standard_normal(Lw * ndw) + 1j * rng.standard_normal(Lw * ndw))).astype(np.complex64)
+    for d in range(ndw):                                           # a line per dwell whose offset grows with the dwell
+        t = np.arange(Lw)
+        x[d * Lw:(d + 1) * Lw] += np.exp(2j * np.pi * (0.3 * (d / ndw) - 0.15) * t).astype(np.complex64)
+    path = tmp_path / "sweep.raw"
+    x.tofile(path)
+    Lb = suscan.load()
+    mq = suscan.MQ()
+    assert Lb.suscan_mq_init(C.byref(mq))
+    cfg = Lb.suscan_source_config_new(b"file", 1)
+    Lb.suscan_source_config_set_samp_rate(cfg, fs)
+    assert Lb.suscan_source_config_set_path(cfg, str(path).encode())
+    p = suscan.AnalyzerParams.default()
+    p.mode = 1                                                     # SUSCAN_ANALYZER_MODE_WIDE_SPECTRUM
+    p.detector_params.window_size = n
+    p.psd_update_int = Lw / fs
+    fmin, fmax, rel = 400e6, 406e6, 0.5
+    p.min_freq, p.max_freq = fmin, fmax
+    an = Lb.suscan_analyzer_new(C.byref(p), cfg, C.byref(mq))
+    assert an
+    Lb.suscan_source_config_destroy(cfg)
+    assert Lb.suscan_analyzer_set_rel_bandwidth(an, rel) and Lb.suscan_analyzer_set_sweep_stratrgy(an, 1)
+    frames, fcs = [], []
+    while True:
+        t, ptr = suscan.read_message(Lb, mq, 60.0)
+        if t == suscan.MSG_HALT:
+            break
+        if t == suscan.MSG_PSD:
+            m = C.cast(ptr, C.POINTER(suscan.PSDMsg)).contents
+            frames.append(np.ctypeslib.as_array(m.psd_data, shape=(n,)).copy())
+            fcs.append(float(m.fc))
+        Lb.suscan_analyzer_dispose_message(t, ptr)
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+    assert len(frames) == ndw
+    step = rel * fs
+    nsteps = int(np.ceil((fmax - fmin) / step))
+    # the setters land a block or two into the stream: from the first frame labelled by the progressive walk on, the
+    # sequence is the slots in order
+    k0 = next(i for i in range(ndw - nsteps) if all(abs(fcs[i + j + 1] - fcs[i + j] - step) < 1 or fcs[i + j + 1] < fcs[i + j] for j in range(nsteps)))
+    walk = fcs[k0:]
+    slots = [int(round((f - fmin) / step - 0.5)) for f in walk]
+    assert all(0 <= s < nsteps for s in slots)
+    assert all((b - a) % nsteps == 1 for a, b in zip(slots, slots[1:]))
+    # Scanner::onPSDMessage on every frame, on the device and in the oracle
+    view, oview = engine.SpectrumView(ctx), sdo.SpectrumView()
+    for v in (view, oview):
+        v.set_range(fmin, fmax)
+    view.set_fft(fs, rel)
+    oview.v.fftBandwidth, oview.v.fftRelBw = fs, rel
+    for f, fc in zip(frames[k0:], walk):
+        db = sdo.psd_shift_db(f)                                   # the PSDMessage constructor
+        view.feed(torch.from_numpy(db).cuda(), fc - fs / 2, fc + fs / 2)
+        oview.feed(db, fc - fs / 2, fc + fs / 2)
+    psd, accum, count = view.arrays()
+    assert np.array_equal(accum, oview.accum) and np.array_equal(count, oview.count) and np.array_equal(psd, oview.psd)
+    assert np.count_nonzero(count) > 0.9 * view.spectrum_size          # the panorama is filled (6 MHz at 1 kHz: 8192 bins)
