@@ -105,6 +105,23 @@ SUAMD_API SUBOOL suamd_inspector_spectrum_db_shift(suamd_ctx_t *ctx, SUFLOAT *d_
                                                    SUSCOUNT nspectra, void *stream);
 
 /* ------------------------------------------------------------------------------------ */
+/* A6: the "audio" inspector class                                                       */
+/* ------------------------------------------------------------------------------------ */
+/* What libsuscan's audio inspector does behind AudioProcessor (Default/Audio/AudioProcessor.cpp:94-169, 251-270):
+ * demodulate the channel samples (audio.demodulator: 1 AM, 2 FM, 3 USB, 4 LSB, 5 RAW), low-pass at audio.cutoff and
+ * resample from the channel rate to audio.sample-rate, times audio.volume, muted while the channel power is below
+ * audio.squelch-level when audio.squelch is set (SPEC.md section Q).  The consumer plays the real part
+ * (Audio/AudioPlayback.cpp:603-604). */
+typedef struct suamd_audio suamd_audio_t;
+SUAMD_API suamd_audio_t *suamd_audio_new(suamd_ctx_t *ctx, SUFLOAT equiv_fs, SUFLOAT bandwidth);
+SUAMD_API void     suamd_audio_destroy(suamd_audio_t *au);
+SUAMD_API SUBOOL   suamd_audio_configure(suamd_audio_t *au, int demodulator, SUFLOAT sample_rate, SUFLOAT cutoff, SUFLOAT volume,
+                                         SUBOOL squelch, SUFLOAT squelch_level);
+SUAMD_API SUSCOUNT suamd_audio_output_count(const suamd_audio_t *au, SUSCOUNT len);    /* of the next feed of len samples */
+SUAMD_API SUBOOL   suamd_audio_feed(suamd_audio_t *au, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_out,
+                                    SUSCOUNT *n_out, void *stream);
+
+/* ------------------------------------------------------------------------------------ */
 /* N1: channel detector (su_channel_detector)                                            */
 /* ------------------------------------------------------------------------------------ */
 /* What libsuscan runs on the analyzer's spectrum to announce channels (SUSCAN_ANALYZER_MESSAGE_TYPE_CHANNEL,

@@ -1609,3 +1609,51 @@ unsigned sdo_chandet_find(const sdo_chandet *d, sdo_chandet_record *rec, unsigne
 #undef AT
   return k < cap ? k : cap;
 }
+
+/* ---- Q: the "audio" inspector [SPEC, UPSTREAM-RECOLLECTION] ------------------------------------------------------------
+ * SPEC.md section Q (Default/Audio/AudioProcessor.cpp:94-169, 251-270).  One-shot over a whole channel stream. */
+size_t sdo_audio_run(const sdo_c32 *x, size_t len, int mode, double efs, double bw, double fa, double cutoff, float volume,
+                     sdo_c32 *out, size_t cap)
+{
+  const double cut = cutoff < 0.45 * fa ? cutoff : 0.45 * fa;
+  const float fc = (float)(cut / efs);
+  int M = (int)ceil(2.0 / (double)fc), m;
+  const double ratio = efs / fa;
+  const double w = SDO_PI * bw / efs;
+  const uint32_t dphase = (uint32_t)(int64_t)llround((mode == 3 ? w : -w) / (2 * SDO_PI) * 4294967296.0);
+  sdo_c32 *a = malloc(sizeof *a * (len ? len : 1));
+  size_t i, k = 0;
+  if (M < 2) M = 2;
+  if (M > 128) M = 128;
+  for (i = 0; i < len; ++i) {
+    const sdo_c32 v = x[i];
+    if (mode == 1) { a[i].re = sqrtf(v.re * v.re + v.im * v.im); a[i].im = 0; }
+    else if (mode == 2) {
+      const sdo_c32 p = i ? x[i - 1] : (sdo_c32){0, 0};
+      a[i].re = sdo_atan2f(v.im * p.re - v.re * p.im, v.re * p.re + v.im * p.im) * 0.318309886183790671538f; a[i].im = 0;
+    } else if (mode == 3 || mode == 4) {
+      float c, s;
+      sdo_phasor_u32((uint32_t)i * dphase, &c, &s);
+      a[i].re = v.re * c - v.im * s; a[i].im = 0;
+    } else a[i] = v;
+  }
+  for (k = 0; k < cap; ++k) {
+    const double t = (double)k * ratio, fl = floor(t);
+    const long long n0 = (long long)fl;
+    const float frac = (float)(t - fl), w0 = 3.14159265358979323846f / (float)(M + 1);
+    float accx = 0, accy = 0, norm = 0, sc;
+    if (n0 + M + 1 > (long long)len - 1) break;
+    for (m = -M; m <= M + 1; ++m) {
+      const float u = (float)m - frac, arg = 6.28318530717958647692f * fc * u;
+      const float sinc = fabsf(arg) < 1e-6f ? 1.0f : sinf(arg) / arg;
+      const float g = sinc * (0.54f + 0.46f * cosf(w0 * u));
+      const long long j = n0 + m;
+      const sdo_c32 v = j >= 0 ? a[j] : (sdo_c32){0, 0};
+      accx += v.re * g; accy += v.im * g; norm += g;
+    }
+    sc = volume / norm;
+    out[k].re = accx * sc; out[k].im = accy * sc;
+  }
+  free(a);
+  return k;
+}

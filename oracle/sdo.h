@@ -276,6 +276,11 @@ typedef struct { int first, last, width; float peak; double sum, wsum; } sdo_cha
 void     sdo_chandet_feed(sdo_chandet *d, const float *P);                          /* P: linear power, natural FFT order */
 unsigned sdo_chandet_find(const sdo_chandet *d, sdo_chandet_record *rec, unsigned cap);   /* ordered by first bin */
 
+/* ---- Q: the "audio" inspector class (SPEC.md section Q) [UPSTREAM-RECOLLECTION] ----------------------------------------
+ * mode 1 AM, 2 FM, 3 USB, 4 LSB, 5 RAW; efs: channel rate; fa: audio rate; returns the number of output samples */
+size_t sdo_audio_run(const sdo_c32 *x, size_t len, int mode, double efs, double bw, double fa, double cutoff, float volume,
+                     sdo_c32 *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

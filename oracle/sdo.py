@@ -630,3 +630,15 @@ class ChannelDetector:
     @property
     def N0(self):
         return float(self.d.N0)
+
+
+# ---- Q: audio inspector ---------------------------------------------------------------------------------
+def audio_run(x, mode, efs, bw, fa, cutoff, volume=1.0):
+    x = _c(x)
+    cap = int(x.size * fa / efs) + 8
+    out = np.empty(cap, dtype=c32)
+    f = lib().sdo_audio_run
+    f.restype = C.c_size_t
+    n = f(_p(x), C.c_size_t(x.size), C.c_int(mode), C.c_double(efs), C.c_double(bw), C.c_double(fa), C.c_double(cutoff),
+          C.c_float(volume), _p(out), C.c_size_t(cap))
+    return out[:n].copy()

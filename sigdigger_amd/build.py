@@ -27,6 +27,7 @@ SOURCES = {
     "specttuner.hip": ["-ffp-contract=off"],
     "specttuner_host.cpp": ["-ffp-contract=off"],
     "chandet.hip": ["-ffp-contract=off"],
+    "audio.hip": ["-ffp-contract=off"],
     "chandet_host.cpp": ["-ffp-contract=off"],
     "ingest.hip": ["-ffp-contract=off"],
     "stages.hip": ["-ffp-contract=off"],

@@ -100,9 +100,18 @@ DescHolder &raw_desc() { static DescHolder d("raw", nullptr, 0); return d; }
 // "power": mean channel power over windows of power.integrate-samples (Default/RMSInspector/RMSInspector.cpp:415,438)
 const FieldDef kPowerFields[] = { {"power.integrate-samples", SUSCAN_FIELD_TYPE_INTEGER, 1000} };
 DescHolder &power_desc() { static DescHolder d("power", kPowerFields, 1); return d; }
+// "audio": Default/Audio/AudioProcessor.cpp:251-270 (demodulator 1 AM, 2 FM, 3 USB, 4 LSB, 5 RAW)
+const FieldDef kAudioFields[] = {
+  {"audio.volume", SUSCAN_FIELD_TYPE_FLOAT, 1}, {"audio.cutoff", SUSCAN_FIELD_TYPE_FLOAT, 15000},
+  {"audio.sample-rate", SUSCAN_FIELD_TYPE_INTEGER, 44100}, {"audio.demodulator", SUSCAN_FIELD_TYPE_INTEGER, 2},
+  {"audio.squelch", SUSCAN_FIELD_TYPE_BOOLEAN, 0}, {"audio.squelch-level", SUSCAN_FIELD_TYPE_FLOAT, 0.5},
+  {"agc.enabled", SUSCAN_FIELD_TYPE_BOOLEAN, 0}, {"agc.ts", SUSCAN_FIELD_TYPE_FLOAT, 0.2},
+};
+DescHolder &audio_desc() { static DescHolder d("audio", kAudioFields, sizeof kAudioFields / sizeof kAudioFields[0]); return d; }
 DescHolder *holder_for(const char *cls)
 {
   if (!cls) return nullptr;
+  if (!std::strcmp(cls, "audio")) return &audio_desc();
   if (!std::strcmp(cls, "psk")) return &psk_desc();
   if (!std::strcmp(cls, "fsk")) return &fsk_desc();
   if (!std::strcmp(cls, "ask")) return &ask_desc();
@@ -348,6 +357,7 @@ struct Inspector {
   float fixed_gain = 0;                       // agc.enabled = false: linear agc.gain (0 = none)
   uint32_t spectsrc_id = 0;                   // 0 = none (Suscan/Analyzer.cpp:539-547)
   suamd_power_bank_t *power = nullptr;         // class "power"
+  suamd_audio_t *audio = nullptr;              // class "audio"
   suamd_baud_estimator_t *est[2] = {nullptr, nullptr};   // "baud-fac", "baud-nonlinear" (estimator_list of the OPEN message)
   bool est_on[2] = {false, false}, est_fed[2] = {false, false};
   SUFLOAT last_est[2] = {0, 0};                           // a block too short for the analysis window repeats the last estimate
@@ -419,6 +429,8 @@ struct Inspector {
     if (cma) suamd_cma_bank_destroy(cma);
     if (power) suamd_power_bank_destroy(power);
     power = nullptr;
+    if (audio) suamd_audio_destroy(audio);
+    audio = nullptr;
     bank = nullptr; agc = nullptr; costas = nullptr; clock = nullptr; nco = nullptr; pll = nullptr; mf = nullptr; cma = nullptr;
     fixed_gain = 0;
   }
@@ -638,6 +650,21 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
     const double n = cfg_get(in.config, "power.integrate-samples", 1000);
     in.power = suamd_power_bank_new(a->ctx, n >= 1 ? (SUSCOUNT)n : 1);
     if (!in.power) { err = suamd_last_error(); return false; }
+    return true;
+  }
+  if (in.cls == "audio") {
+    // gain control (optional) -> demodulator -> cut-off low-pass + resampler to the sound card's rate (SPEC.md section Q)
+    if (cfg_get(in.config, "agc.enabled", 0) != 0) {
+      struct suamd_agc_params prm;
+      suamd_agc_params_from_tau(&prm, (float)std::fmax(8.0, cfg_get(in.config, "agc.ts", 0.2) * in.equiv_fs * 1e-2));
+      in.agc = suamd_agc_bank_new(a->ctx, 1, &prm);
+      if (!in.agc) { err = suamd_last_error(); return false; }
+    }
+    in.audio = suamd_audio_new(a->ctx, (SUFLOAT)in.equiv_fs, (SUFLOAT)bw);
+    if (!in.audio || !suamd_audio_configure(in.audio, (int)cfg_get(in.config, "audio.demodulator", 2),
+                                            (SUFLOAT)cfg_get(in.config, "audio.sample-rate", 44100), (SUFLOAT)cfg_get(in.config, "audio.cutoff", 15000),
+                                            (SUFLOAT)cfg_get(in.config, "audio.volume", 1), cfg_get(in.config, "audio.squelch", 0) != 0 ? SU_TRUE : SU_FALSE,
+                                            (SUFLOAT)cfg_get(in.config, "audio.squelch-level", 0.5))) { err = suamd_last_error(); return false; }
     return true;
   }
   const double baud = cfg_get(in.config, "clock.baud", 0);
@@ -942,6 +969,15 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
       in.pend_src = in.d_sym;
       in.pend_m = k;
     }
+    // "audio" inspectors: demodulate + resample what the (optional) gain control left
+    for (Inspector *pi : live) {
+      Inspector &in = *pi;
+      if (!in.audio) continue;
+      SUSCOUNT k = 0;
+      if (!suamd_audio_feed(in.audio, in.pend_src, in.pend_m, in.d_sym, &k, sK)) fail("audio");
+      in.pend_src = in.d_sym;
+      in.pend_m = k;
+    }
     // hand-off: every inspector's batch goes to its mapped landing zone in one launch (sK is downstream of all stages)
     std::vector<const suamd_complex *> src; std::vector<uint32_t *> cnt; std::vector<SUSCOUNT> fixed;
     std::vector<suamd_complex *> dst; std::vector<uint32_t *> cout;
@@ -1056,7 +1092,7 @@ void handle_request(suscan_analyzer *a, Request &r)
       m->spectsrc_count = suamd_spectsrc_count();             // names borrowed from the library (static storage)
       m->spectsrc_list = static_cast<char **>(std::calloc(m->spectsrc_count, sizeof(char *)));
       for (unsigned k = 0; k < m->spectsrc_count; ++k) m->spectsrc_list[k] = const_cast<char *>(suamd_spectsrc_name(k + 1));
-      if (r.cls != "raw" && r.cls != "power") {               // the baud estimators (names static, like the sources')
+      if (r.cls != "raw" && r.cls != "power" && r.cls != "audio") {   // the baud estimators (names static, like the sources')
         m->estimator_count = 2;
         m->estimator_list = static_cast<char **>(std::calloc(2, sizeof(char *)));
         m->estimator_list[0] = const_cast<char *>(kEstimators[0].name);

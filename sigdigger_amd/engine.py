@@ -338,6 +338,39 @@ class ChannelBank:
         check(self.ctx.lib.suamd_chanbank_reset(self.h, _stream(stream)), "suamd_chanbank_reset")
 
 
+class Audio:
+    """suamd_audio_t: the "audio" inspector's demodulator + resampler (SPEC.md section Q)."""
+
+    def __init__(self, ctx, equiv_fs, bandwidth):
+        self.ctx = ctx
+        self.h = ctx.lib.suamd_audio_new(ctx.h, float(equiv_fs), float(bandwidth))
+        if not self.h:
+            raise SigDiggerAmdError("suamd_audio_new: " + _l.last_error())
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.suamd_audio_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def configure(self, demodulator, sample_rate, cutoff, volume=1.0, squelch=False, squelch_level=0.0):
+        check(self.ctx.lib.suamd_audio_configure(self.h, int(demodulator), float(sample_rate), float(cutoff), float(volume),
+                                                 int(bool(squelch)), float(squelch_level)), "suamd_audio_configure")
+
+    def feed(self, x, stream=None):
+        _chk_c64(x, "x")
+        n = int(self.ctx.lib.suamd_audio_output_count(self.h, x.numel()))
+        out = torch.empty(max(n, 1), dtype=torch.complex64, device=x.device)
+        got = C.c_uint64(0)
+        check(self.ctx.lib.suamd_audio_feed(self.h, _ptr(x), x.numel(), _ptr(out), C.byref(got), _stream(stream)), "suamd_audio_feed")
+        return out[:got.value]
+
+
 class ChannelDetector:
     """suamd_chandet_t: su_channel_detector on the device (SPEC.md section O)."""
 

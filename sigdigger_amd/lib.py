@@ -50,6 +50,11 @@ PROTOTYPES = {
     "suamd_psd_shift_db": (INT, [VP, VP, U64, U64, VP]),
     "suamd_averager_feed": (INT, [VP, VP, VP, U64, F32, INT, VP]),
     "suamd_inspector_spectrum_db_shift": (INT, [VP, VP, U64, U64, VP]),
+    "suamd_audio_new": (VP, [VP, F32, F32]),
+    "suamd_audio_destroy": (None, [VP]),
+    "suamd_audio_configure": (INT, [VP, INT, F32, F32, F32, INT, F32]),
+    "suamd_audio_output_count": (U64, [VP, U64]),
+    "suamd_audio_feed": (INT, [VP, VP, U64, VP, C.POINTER(U64), VP]),
     "suamd_chandet_new": (VP, [VP, UINT, F32, F32, F32, F32]),
     "suamd_chandet_destroy": (None, [VP]),
     "suamd_chandet_feed": (INT, [VP, VP, VP]),

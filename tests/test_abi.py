@@ -73,7 +73,8 @@ def test_message_queue_and_config_without_a_gpu():
     assert L.suscan_mq_poll(ctypes.byref(mq), ctypes.byref(t), ctypes.byref(p)) and t.value == suscan.MSG_HALT
     L.suscan_mq_finalize(ctypes.byref(mq))
     desc = L.suscan_inspector_config_desc(b"psk")
-    assert desc and L.suscan_inspector_config_desc(b"fsk") and not L.suscan_inspector_config_desc(b"audio")
+    assert desc and L.suscan_inspector_config_desc(b"fsk") and L.suscan_inspector_config_desc(b"audio")
+    assert not L.suscan_inspector_config_desc(b"drm")                              # an unknown class
     cfg = L.suscan_config_new(desc)
     # key vocabulary of Default/GenericInspector/InspectorCtl/{Afc,Clock,Gain}Control.cpp
     assert L.suscan_config_set_integer(cfg, b"afc.costas-order", 2)

@@ -181,7 +181,7 @@ def test_psk_inspector_protocol_and_symbols(tmp_path, sdo):
     Lb.suscan_analyzer_set_throttle_async(an, 4 * FS, 0)     # leave time for the requests to land early
     ch = suscan.Channel(fc=fc, f_lo=fc - bw / 2, f_hi=fc + bw / 2, bw=bw, ft=433.92e6)
     assert Lb.suscan_analyzer_open_ex_async(an, b"psk", C.byref(ch), 1, -1, 77)
-    assert Lb.suscan_analyzer_open_async(an, b"audio", C.byref(ch), 78)          # unsupported class
+    assert Lb.suscan_analyzer_open_async(an, b"drm", C.byref(ch), 78)            # unsupported class
     bad = suscan.Channel(fc=0.0, bw=0.0)
     assert Lb.suscan_analyzer_open_async(an, b"psk", C.byref(bad), 79)
     assert Lb.suscan_analyzer_close_async(an, 1234, 80)                          # unknown handle

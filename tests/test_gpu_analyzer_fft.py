@@ -305,3 +305,86 @@ def test_wide_spectrum_sweep_through_the_abi_feeds_a_spectrum_view(tmp_path, sdo
     psd, accum, count = view.arrays()
     assert np.array_equal(accum, oview.accum) and np.array_equal(count, oview.count) and np.array_equal(psd, oview.psd)
     assert np.count_nonzero(count) > 0.9 * view.spectrum_size          # the panorama is filled (6 MHz at 1 kHz: 8192 bins)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
+def test_audio_demodulators_and_resampler_match_the_oracle(ctx, sdo, mode):
+    """Row A6, the "audio" class's arithmetic (SPEC.md section Q): AM / FM / USB / LSB / RAW, cut-off low-pass and resampler,
+    in one block and in ragged pieces."""
+    import torch
+    from sigdigger_amd import engine
+    efs, fa, bw, cutoff = 250e3, 48e3, 40e3, 12e3
+    n = 120000
+    t = np.arange(n)
+    tone = np.sin(2 * np.pi * 1000 * t / efs)
+    if mode == 1:
+        x = (1 + 0.5 * tone) * np.exp(1j * 0.3)
+    elif mode == 2:
+        x = np.exp(1j * np.cumsum(2 * np.pi * 5e3 * tone / efs))
+    elif mode in (3, 4):
+        sgn = 1 if mode == 3 else -1
+        x = np.exp(sgn * 2j * np.pi * (1000 - bw / 2) * t / efs)            # a 1 kHz tone of the upper / lower sideband
+    else:
+        x = np.exp(2j * np.pi * 3e3 * t / efs)
+    x = (x + 0.01 * (np.random.default_rng(mode).standard_normal(n) + 1j * np.random.default_rng(9).standard_normal(n))).astype(np.complex64)
+    ref = sdo.audio_run(x, mode, efs, bw, fa, cutoff, 0.8)
+    dx = torch.from_numpy(x).cuda()
+    for cuts in ([0, n], [0, 777, 50000, 50001, 90000, n]):
+        au = engine.Audio(ctx, efs, bw)
+        au.configure(mode, fa, cutoff, volume=0.8)
+        got = np.concatenate([au.feed(dx[a:b]).cpu().numpy() for a, b in zip(cuts[:-1], cuts[1:])])
+        assert abs(got.size - ref.size) <= 0 and got.size > 0.99 * n * fa / efs - 300
+        assert np.max(np.abs(got - ref)) <= 1e-5 * max(1.0, np.abs(ref).max()) * 3
+    if mode != 5:                                                      # the 1 kHz tone comes out (skip the filter's run-in)
+        a = got.real[2000:] - np.mean(got.real[2000:])
+        spec = np.abs(np.fft.rfft(a * np.hanning(a.size)))
+        assert abs(np.argmax(spec) * fa / a.size - 1000) < 30
+
+
+def test_audio_inspector_through_the_abi(tmp_path, sdo):
+    """AudioProcessor's protocol: open "audio" on a 200 kHz channel, push the audio.* configuration, play what arrives"""
+    nblocks = 16
+    fc, dev_hz, ftone = 150e3, 5e3, 800.0
+    t = np.arange(L * nblocks)
+    x = (np.exp(1j * (2 * np.pi * fc * t / FS + (dev_hz / ftone) * np.sin(2 * np.pi * ftone * t / FS))) +
+         0.01 * (np.random.default_rng(1).standard_normal(t.size) + 1j * np.random.default_rng(2).standard_normal(t.size))).astype(np.complex64)
+    path = tmp_path / "fm.raw"
+    x.tofile(path)
+    Lb, mq, an = _start(path, L)
+    Lb.suscan_analyzer_set_throttle_async(an, 4 * FS, 0)
+    bw = 100e3
+    ch = suscan.Channel(fc=fc, f_lo=-bw / 2, f_hi=bw / 2, bw=bw, ft=0)
+    assert Lb.suscan_analyzer_open_async(an, b"audio", C.byref(ch), 31)
+    st = {"audio": [], "cfg": False, "efs": None}
+
+    def on_msg(t_, ptr):
+        if t_ == suscan.MSG_INSPECTOR:
+            m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
+            if m.kind == suscan.KIND_OPEN:
+                assert m.class_name == b"audio" and m.estimator_count == 0
+                st["efs"] = m.equiv_fs
+                cfg = Lb.suscan_config_dup(m.config)
+                assert Lb.suscan_config_set_float(cfg, b"audio.cutoff", 5000.0)
+                assert Lb.suscan_config_set_float(cfg, b"audio.volume", 1.0)
+                assert Lb.suscan_config_set_integer(cfg, b"audio.sample-rate", 48000)
+                assert Lb.suscan_config_set_integer(cfg, b"audio.demodulator", 2)
+                assert Lb.suscan_config_set_bool(cfg, b"audio.squelch", 0)
+                assert Lb.suscan_analyzer_set_inspector_config_async(an, m.handle, cfg, 32)
+                Lb.suscan_config_destroy(cfg)
+            elif m.kind == suscan.KIND_SET_CONFIG:
+                st["cfg"] = True
+                st["audio"] = []
+        elif t_ == suscan.MSG_SAMPLES and st["cfg"]:
+            m = C.cast(ptr, C.POINTER(suscan.SampleBatchMsg)).contents
+            st["audio"].append(np.ctypeslib.as_array(m.samples, shape=(m.sample_count * 2,)).copy().view(np.complex64))
+
+    _pump(Lb, an, on_msg)
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+    assert st["cfg"] and abs(st["efs"] - FS / 4) < 1e-3                # D = pow2floor(1e6 / 2e5) = 4
+    audio = np.concatenate(st["audio"]).real
+    assert audio.size > 0.5 * nblocks * L / FS * 48000
+    a = audio[4000:] - np.mean(audio[4000:])
+    spec = np.abs(np.fft.rfft(a * np.hanning(a.size)))
+    assert abs(np.argmax(spec) * 48000 / a.size - ftone) < 20           # the modulating tone
+    assert 0.6 * dev_hz / (st["efs"] / 2) < np.max(np.abs(a)) < 1.4 * dev_hz / (st["efs"] / 2)   # (1/pi) arg: deviation / Nyquist
