@@ -1646,7 +1646,7 @@ size_t sdo_audio_run(const sdo_c32 *x, size_t len, int mode, double efs, double 
     for (m = -M; m <= M + 1; ++m) {
       const float u = (float)m - frac, arg = 6.28318530717958647692f * fc * u;
       const float sinc = fabsf(arg) < 1e-6f ? 1.0f : sinf(arg) / arg;
-      const float g = sinc * (0.54f + 0.46f * cosf(w0 * u));
+      const float g = sinc * (0.5f + 0.5f * cosf(w0 * u));
       const long long j = n0 + m;
       const sdo_c32 v = j >= 0 ? a[j] : (sdo_c32){0, 0};
       accx += v.re * g; accy += v.im * g; norm += g;

@@ -9,7 +9,8 @@
 //                  channel centre half a bandwidth off the carrier (AudioProcessor.cpp:201-228): this puts it back
 //               5 RAW: a = x (both components)
 //   resampler:  output k sits at t_k = t0 + k efs / fa input samples; y_k = sum_m a[n0 + m] g(m - frac) / sum_m g(m - frac),
-//               n0 = floor(t_k), frac = t_k - n0, m = -M .. M + 1, g(u) = sinc(2 fc u) (0.54 + 0.46 cos(pi u / (M + 1))),
+//               n0 = floor(t_k), frac = t_k - n0, m = -M .. M + 1, g(u) = sinc(2 fc u) (0.5 + 0.5 cos(pi u / (M + 1))) -- a window that vanishes at the ends of the tap range, so the result does not
+//               depend on which side of an integer a rounding of t_k falls --,
 //               fc = min(cutoff, 0.45 fa) / efs, M = min(ceil(2 / fc), 128): a windowed sinc evaluated where it is
 //               needed (audio rates: a few hundred thousand taps per block), one thread per output sample.
 //   squelch:    the block is muted when its mean channel power is below audio.squelch-level.
@@ -87,7 +88,7 @@ __global__ void audio_resample_kernel(const cf *a, long long count, double t0, d
     const float u = (float)m - frac;
     const float arg = 6.28318530717958647692f * fc * u;
     const float sinc = fabsf(arg) < 1e-6f ? 1.0f : sinf(arg) / arg;
-    const float g = sinc * (0.54f + 0.46f * cosf(w0 * u));
+    const float g = sinc * (0.5f + 0.5f * cosf(w0 * u));
     const cf v = a[HIST + n0 + m];
     accx += v.x * g; accy += v.y * g; norm += g;
   }
