@@ -66,7 +66,7 @@ def build(force=False, verbose=False):
             list(ex.map(run, jobs))
     if force or jobs or _stale(OUT, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs +
-            ["-Wl,-rpath,/opt/rocm/lib", "-lpthread"])
+            ["-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-ldl"])
     return OUT
 
 

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <strings.h>
+#include <dlfcn.h>
 #include <deque>
 #include <map>
 #include <memory>
@@ -486,7 +487,32 @@ struct Request {
 
 }  // namespace
 
+// Multi-GPU: inspector channels are sharded over the devices of SUAMD_DEVICES (handle h lives on
+// shard h mod G); shard 0 -- the analyzer the caller holds -- owns the source, the PSD and the channel detector and
+// PUBLISHES every block (after the baseband filters) on this bus; every other shard is a worker thread bound to its
+// GPU that takes the block from the publisher's pinned host buffer over its own PCIe link (or, with
+// SUAMD_ANALYZER_BCAST=rccl, from GPU 0 over xGMI with one ncclBroadcast per block), runs its inspectors and posts their
+// messages to the same queue.  No other exchange: the chains are independent after the shared input.
+struct BlockBus {
+  std::mutex m;
+  std::condition_variable cv;
+  uint64_t seq = 0;                             // blocks published so far; block k sits in entry k & 1
+  struct Entry { const void *host = nullptr; size_t samples = 0; int raw_format = 0; unsigned bytes_per_sample = 8; uint64_t position = 0; unsigned samp_rate = 0; } e[2];
+  bool closed = false;                          // the publisher is done (end of stream, halt, error)
+  std::vector<uint64_t> done;                   // per subscriber: blocks whose host buffer it no longer needs
+  // RCCL variant (opt-in): one communicator per shard, created by shard 0
+  void *rccl_lib = nullptr;
+  std::vector<void *> comm;
+  int (*bcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+};
+
 struct suscan_analyzer {
+  int device = 0;                               // the GPU this shard is bound to
+  int shard = 0, nshards = 1;
+  suscan_analyzer *primary = nullptr;           // shard 0 (itself for shard 0)
+  std::vector<suscan_analyzer *> secondaries;   // shard 0 only: shards 1 .. G-1
+  std::shared_ptr<BlockBus> bus;
+  std::atomic<uint32_t> open_rr{0};             // shard 0: round-robin placement of OPEN requests
   struct suscan_analyzer_params params;
   suscan_source_config source_cfg;
   struct suscan_mq *mq;
@@ -1068,7 +1094,8 @@ void handle_request(suscan_analyzer *a, Request &r)
         return;
       }
       auto in = std::make_unique<Inspector>();
-      in->handle = a->next_handle++;
+      in->handle = a->next_handle;                            // shard s hands out s, s + G, s + 2G ...: a handle names its shard
+      a->next_handle += a->nshards;
       in->cls = r.cls;
       in->channel = r.channel;
       in->precise = r.precise;
@@ -1207,6 +1234,8 @@ void handle_request(suscan_analyzer *a, Request &r)
   }
 }
 
+void bus_wait_done(suscan_analyzer *a, uint64_t upto);
+
 // (re)creates the channel detector from the analyzer parameters (window size, alpha / beta / gamma / snr, channel_update_int)
 void setup_chandet(suscan_analyzer *a)
 {
@@ -1245,6 +1274,7 @@ bool setup_psd(suscan_analyzer *a, std::string &err)
   a->d_psd = nullptr;
   if (hipMalloc((void **)&a->d_psd, n * sizeof(float)) != hipSuccess) { err = "device allocation failed"; return false; }
   if (block != a->block) {
+    if (a->bus) bus_wait_done(a, a->bus->seq);               // no shard reads the old host buffers any more
     if (a->h_x) (void)hipHostFree(a->h_x);
     if (a->h_flt) (void)hipHostFree(a->h_flt);               // the filters' expansion buffer is a block long too
     a->h_flt = nullptr;
@@ -1252,7 +1282,7 @@ bool setup_psd(suscan_analyzer *a, std::string &err)
     if (a->d_raw) (void)hipFree(a->d_raw);
     a->h_x = nullptr; a->d_x = nullptr; a->d_raw = nullptr;
     a->h2d_set[0] = a->h2d_set[1] = false; a->xfree_set = false;
-    if (hipHostMalloc((void **)&a->h_x, 2 * block * sizeof(suamd_complex), hipHostMallocDefault) != hipSuccess ||   // two halves
+    if (hipHostMalloc((void **)&a->h_x, 2 * block * sizeof(suamd_complex), hipHostMallocPortable) != hipSuccess ||   // two halves
         hipMalloc((void **)&a->d_x, block * sizeof(suamd_complex)) != hipSuccess ||
         hipMalloc(&a->d_raw, block * 4) != hipSuccess) {
       err = "allocation of the block buffers failed";
@@ -1360,12 +1390,54 @@ void push_channels(suscan_analyzer *a, int slot)
   push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_CHANNEL, m);
 }
 
-void worker_main(suscan_analyzer *a)
+void free_device(suscan_analyzer *a)
 {
-  std::string err;
-  Source src;
-  src.cfg = a->source_cfg;
-  a->ctx = suamd_ctx_new(0);
+  (void)hipDeviceSynchronize();
+  for (auto &kv : a->inspectors) kv.second->free_all();
+  a->inspectors.clear();
+  if (a->st) suamd_specttuner_destroy(a->st);
+  a->st = nullptr;
+  if (a->chandet) suamd_chandet_destroy(a->chandet);
+  a->chandet = nullptr;
+  for (int p = 0; p < 2; ++p) {
+    if (a->d_rowptr[p]) (void)hipFree(a->d_rowptr[p]);
+    if (a->h_rowptr[p]) (void)hipHostFree(a->h_rowptr[p]);
+    a->d_rowptr[p] = a->h_rowptr[p] = nullptr;
+  }
+  a->rowptr_cap = 0;
+  if (a->psd) suamd_psd_destroy(a->psd);
+  for (int p = 0; p < 2; ++p) {
+    if (a->h_psd[p]) (void)hipHostFree(a->h_psd[p]);
+    a->h_psd[p] = nullptr;
+    if (a->ev_psd[p]) (void)hipEventDestroy(a->ev_psd[p]);
+    if (a->ev_h2d[p]) (void)hipEventDestroy(a->ev_h2d[p]);
+    a->ev_psd[p] = a->ev_h2d[p] = nullptr;
+    for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) { if (a->ev_done[p][k]) (void)hipEventDestroy(a->ev_done[p][k]); a->ev_done[p][k] = nullptr; }
+  }
+  if (a->ev_xfree) (void)hipEventDestroy(a->ev_xfree);
+  if (a->ev_fir) (void)hipEventDestroy(a->ev_fir);
+  a->ev_xfree = a->ev_fir = nullptr;
+  if (a->h_x) (void)hipHostFree(a->h_x);
+  if (a->h_flt) (void)hipHostFree(a->h_flt);
+  if (a->d_dc) (void)hipFree(a->d_dc);
+  a->h_flt = nullptr; a->d_dc = nullptr;
+  if (a->d_x) (void)hipFree(a->d_x);
+  if (a->d_raw) (void)hipFree(a->d_raw);
+  if (a->d_psd) (void)hipFree(a->d_psd);
+  if (a->stream) (void)hipStreamDestroy(a->stream);
+  for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) { if (a->istream[k]) (void)hipStreamDestroy(a->istream[k]); a->istream[k] = nullptr; }
+  if (a->ev_input) (void)hipEventDestroy(a->ev_input);
+  a->ev_input = nullptr;
+  for (int g = 0; g < 3; ++g)
+    for (int j = 0; j < suscan_analyzer::NSUB; ++j) { if (a->ev_stage[g][j]) (void)hipEventDestroy(a->ev_stage[g][j]); a->ev_stage[g][j] = nullptr; }
+  if (a->ctx) suamd_ctx_destroy(a->ctx);
+  a->psd = nullptr; a->h_x = nullptr; a->d_x = nullptr; a->d_raw = nullptr; a->d_psd = nullptr; a->stream = nullptr; a->ctx = nullptr;
+}
+
+// streams, events and knobs of one shard, on its device (the calling thread stays bound to that device)
+bool init_device(suscan_analyzer *a, std::string &err)
+{
+  a->ctx = suamd_ctx_new(a->device);
   bool ok = a->ctx != nullptr;
   if (!ok) err = suamd_last_error();
   if (ok && hipStreamCreate(&a->stream) != hipSuccess) { ok = false; err = "hipStreamCreate failed"; }
@@ -1398,6 +1470,175 @@ void worker_main(suscan_analyzer *a)
     (void)hipEventCreate(&a->ev_t0); (void)hipEventCreate(&a->ev_tfir); (void)hipEventCreate(&a->ev_tpre); (void)hipEventCreate(&a->ev_tdone);
     for (int g = 0; g < 3; ++g) for (int j = 0; j < suscan_analyzer::NSUB; ++j) (void)hipEventCreate(&a->ev_tstage[g][j]);
   }
+  return ok;
+}
+
+void secondary_main(suscan_analyzer *a);
+
+// ---- the block bus (multi-GPU) -------------------------------------------------------------------------------------
+// shard 0, before it reuses host memory that block `upto - 1` lived in: every subscriber has copied blocks < upto
+void bus_wait_done(suscan_analyzer *a, uint64_t upto)
+{
+  if (!a->bus || a->secondaries.empty()) return;
+  BlockBus &b = *a->bus;
+  std::unique_lock<std::mutex> lk(b.m);
+  b.cv.wait(lk, [&] { for (uint64_t d : b.done) if (d < upto) return false; return true; });
+}
+
+void bus_publish(suscan_analyzer *a, const void *host, size_t samples, int raw_format, unsigned bps, uint64_t position)
+{
+  if (!a->bus || a->secondaries.empty()) return;
+  BlockBus &b = *a->bus;
+  {
+    std::lock_guard<std::mutex> lk(b.m);
+    BlockBus::Entry &e = b.e[b.seq & 1];
+    e.host = host; e.samples = samples; e.raw_format = raw_format; e.bytes_per_sample = bps; e.position = position;
+    e.samp_rate = a->source_cfg.samp_rate;
+    ++b.seq;
+  }
+  b.cv.notify_all();
+}
+
+void bus_close(suscan_analyzer *a)
+{
+  if (!a->bus) return;
+  { std::lock_guard<std::mutex> lk(a->bus->m); a->bus->closed = true; }
+  a->bus->cv.notify_all();
+  for (suscan_analyzer *s : a->secondaries) { s->halt = true; if (s->worker.joinable()) s->worker.join(); }
+}
+
+// shards 1 .. G-1: no source, no PSD, no detector -- the published blocks through this GPU's inspectors
+void secondary_main(suscan_analyzer *a)
+{
+  std::string err;
+  BlockBus &bus = *a->bus;
+  const size_t me = (size_t)a->shard - 1;
+  auto give_up = [&] { { std::lock_guard<std::mutex> lk(bus.m); bus.done[me] = ~0ull; } bus.cv.notify_all(); };
+  if (!init_device(a, err)) {
+    push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, "GPU shard " + std::to_string(a->shard) + " (device " + std::to_string(a->device) + "): " + err);
+    give_up();
+    return;
+  }
+  struct { bool on = false; int slot = 0; } flight;
+  auto finish = [&] { if (flight.on) { collect_inspectors(a, flight.slot); flight.on = false; } };
+  uint64_t k = 0;
+  int slot = 0;
+  bool failed = false;
+  while (!failed) {
+    for (;;) {                                                // requests routed to this shard's inspectors
+      Request r;
+      {
+        std::lock_guard<std::mutex> lk(a->req_m);
+        if (a->requests.empty()) break;
+        r = std::move(a->requests.front());
+        a->requests.pop_front();
+      }
+      finish();
+      handle_request(a, r);
+    }
+    BlockBus::Entry e;
+    {
+      std::unique_lock<std::mutex> lk(bus.m);
+      bus.cv.wait_for(lk, std::chrono::milliseconds(20), [&] { return bus.seq > k || bus.closed || a->halt.load(); });
+      if (bus.seq <= k) {
+        if (bus.closed || a->halt) break;
+        continue;                                             // nothing yet: look at the request queue again
+      }
+      e = bus.e[k & 1];
+    }
+    if (e.samples != a->block || e.samp_rate != a->source_cfg.samp_rate) {   // first block, or the analyzer parameters changed
+      finish();
+      (void)hipDeviceSynchronize();
+      if (a->d_x) (void)hipFree(a->d_x);
+      if (a->d_raw) (void)hipFree(a->d_raw);
+      a->d_x = nullptr; a->d_raw = nullptr; a->xfree_set = false;
+      if (hipMalloc((void **)&a->d_x, e.samples * sizeof(suamd_complex)) != hipSuccess || hipMalloc(&a->d_raw, e.samples * 4) != hipSuccess) {
+        push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, "GPU shard " + std::to_string(a->shard) + ": allocation of the block buffers failed");
+        failed = true;
+        break;
+      }
+      a->block = e.samples;
+      a->source_cfg.samp_rate = e.samp_rate;
+      const bool fft = a->want_fft && a->block % 2048 == 0;
+      for (auto &kv : a->inspectors) { kv.second->free_chain(); kv.second->dirty = true; }
+      if (fft != a->use_fft && !fft && a->st) { suamd_specttuner_destroy(a->st); a->st = nullptr; }
+      a->use_fft = fft;
+    }
+    if (a->xfree_set) (void)hipStreamWaitEvent(a->stream, a->ev_xfree, 0);
+    const bool compact = e.bytes_per_sample != sizeof(suamd_complex);
+    void *dst = compact ? a->d_raw : (void *)a->d_x;
+    const size_t bytes = e.samples * e.bytes_per_sample;
+    bool sent = false;
+    if (bus.bcast) sent = bus.bcast(nullptr, dst, bytes, 0 /* ncclInt8 */, 0, bus.comm[a->shard], a->stream) == 0;
+    if (!sent) (void)hipMemcpyAsync(dst, e.host, bytes, hipMemcpyHostToDevice, a->stream);
+    (void)hipEventRecord(a->ev_h2d[0], a->stream);
+    if (compact && !suamd_ingest_iq(a->ctx, e.raw_format, a->d_raw, e.samples, a->d_x, a->stream))
+      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("GPU shard ingest: ") + suamd_last_error());
+    {
+      // the same source conditioning as shard 0 (same input, same arithmetic: the shards see the same samples)
+      const bool rev = a->primary->iq_reverse, dcr = a->primary->dc_remove;
+      if (!dcr) a->dc_first = true;
+      if (rev || dcr) {
+        if (dcr && !a->d_dc && hipMalloc((void **)&a->d_dc, 2 * sizeof(float)) != hipSuccess) a->d_dc = nullptr;
+        if (suamd_source_fix(a->ctx, a->d_x, a->block, rev ? SU_TRUE : SU_FALSE, dcr ? a->d_dc : nullptr, 0.1f, a->dc_first ? SU_TRUE : SU_FALSE, a->stream) && dcr)
+          a->dc_first = false;
+      }
+    }
+    (void)hipEventRecord(a->ev_input, a->stream);
+    enqueue_inspectors(a, a->block, slot);
+    // the publisher may reuse its host buffer once this shard's copy is out
+    (void)hipEventSynchronize(a->ev_h2d[0]);
+    { std::lock_guard<std::mutex> lk(bus.m); bus.done[me] = k + 1; }
+    bus.cv.notify_all();
+    finish();
+    flight.on = true; flight.slot = slot;
+    if (!a->pipelined) finish();
+    slot ^= 1;
+    ++k;
+  }
+  finish();
+  give_up();
+  free_device(a);
+}
+
+// SUAMD_ANALYZER_BCAST=rccl (opt-in; the default is one host-to-device copy per GPU over its own PCIe link): the block goes
+// host -> GPU 0 once and from there to every other shard with one ncclBroadcast per block over xGMI (SURVEY.md 8e;
+// 16 MiB per 2 Mi-sample block against ~153 GB/s per link: ~0.1 ms).  librccl is loaded on demand, one communicator per
+// shard from ncclCommInitAll (single process, one thread per device).  Needs distinct devices.
+void setup_rccl(suscan_analyzer *a)
+{
+  if (!a->bus || a->secondaries.empty()) return;
+  const char *mode = std::getenv("SUAMD_ANALYZER_BCAST");
+  if (!mode || strcasecmp(mode, "rccl")) return;
+  std::vector<int> devs{a->device};
+  for (suscan_analyzer *s : a->secondaries) devs.push_back(s->device);
+  for (size_t i = 0; i < devs.size(); ++i) for (size_t j = i + 1; j < devs.size(); ++j) if (devs[i] == devs[j]) return;
+  void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, 0, "SUAMD_ANALYZER_BCAST=rccl: librccl not found, using per-GPU host copies"); return; }
+  using InitAll = int (*)(void **, int, const int *);
+  using Bcast = int (*)(const void *, void *, size_t, int, int, void *, hipStream_t);
+  auto init_all = reinterpret_cast<InitAll>(dlsym(lib, "ncclCommInitAll"));
+  auto bcast = reinterpret_cast<Bcast>(dlsym(lib, "ncclBroadcast"));
+  std::vector<void *> comm(devs.size(), nullptr);
+  if (!init_all || !bcast || init_all(comm.data(), (int)devs.size(), devs.data()) != 0) {
+    push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, 0, "SUAMD_ANALYZER_BCAST=rccl: ncclCommInitAll failed, using per-GPU host copies");
+    dlclose(lib);
+    return;
+  }
+  (void)hipSetDevice(a->device);                             // ncclCommInitAll walks the devices
+  std::lock_guard<std::mutex> lk(a->bus->m);
+  a->bus->rccl_lib = lib; a->bus->comm = comm; a->bus->bcast = bcast;
+}
+
+void worker_main(suscan_analyzer *a)
+{
+  std::string err;
+  Source src;
+  src.cfg = a->source_cfg;
+  struct BusGuard { suscan_analyzer *a; ~BusGuard() { bus_close(a); } } bus_guard{a};   // the other shards stop with this one
+  bool ok = init_device(a, err);
+  if (ok) setup_rccl(a);
   if (ok) ok = src.open(err);
   if (ok && src.cfg.samp_rate != a->source_cfg.samp_rate) {       // a WAV / SigMF header carries its own rate
     a->source_cfg.samp_rate = src.cfg.samp_rate;
@@ -1480,6 +1721,7 @@ void worker_main(suscan_analyzer *a)
     }
     if (a->halt) break;
     // ---- one block ----
+    if (a->bus) bus_wait_done(a, a->bus->seq);               // the other shards have copied every published block: the host halves are free
     const auto tb0 = std::chrono::steady_clock::now();
     a->t_block0 = tb0;
     auto tick = [&](int i) { if (a->trace) tmark[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(); };
@@ -1514,7 +1756,7 @@ void worker_main(suscan_analyzer *a)
     if (!filters.empty()) {
       if (src.bytes_per_sample() == sizeof(suamd_complex)) h_flt = h_cur;
       else {                                               // compact formats are expanded on the host for them (same arithmetic as suamd_ingest_iq)
-        if (!a->h_flt && hipHostMalloc((void **)&a->h_flt, a->block * sizeof(suamd_complex), hipHostMallocDefault) != hipSuccess) fatal = "pinned allocation failed";
+        if (!a->h_flt && hipHostMalloc((void **)&a->h_flt, a->block * sizeof(suamd_complex), hipHostMallocPortable) != hipSuccess) fatal = "pinned allocation failed";
         else {
           h_flt = a->h_flt;
           const size_t nv = 2 * a->block;
@@ -1532,6 +1774,9 @@ void worker_main(suscan_analyzer *a)
       }
     }
     if (!fatal.empty()) { (void)reader.wait(&looped_next); finish(flight); push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, fatal); break; }
+    // every other GPU shard takes the block from here (what the filters left)
+    if (h_flt) bus_publish(a, h_flt, a->block, SUAMD_FORMAT_RAW_FLOAT32, sizeof(suamd_complex), consumed);
+    else bus_publish(a, h_cur, a->block, src.raw_format, src.bytes_per_sample(), consumed);
     // the previous block's channeliser must be done with d_x before this block lands in it (its PSD is on this stream)
     if (a->xfree_set) (void)hipStreamWaitEvent(a->stream, a->ev_xfree, 0);
     if (h_flt) {
@@ -1542,6 +1787,11 @@ void worker_main(suscan_analyzer *a)
     } else {                                               // 2-4 B/sample over PCIe, expanded on the GPU
       (void)hipMemcpyAsync(a->d_raw, h_cur, a->block * src.bytes_per_sample(), hipMemcpyHostToDevice, a->stream);
       if (!suamd_ingest_iq(a->ctx, src.raw_format, a->d_raw, a->block, a->d_x, a->stream)) fatal = suamd_last_error();
+    }
+    if (a->bus && a->bus->bcast && !a->secondaries.empty()) {   // SUAMD_ANALYZER_BCAST=rccl: GPU 0 is the root of one broadcast per block
+      void *root = src.bytes_per_sample() == sizeof(suamd_complex) || h_flt ? (void *)a->d_x : a->d_raw;
+      const size_t bytes = a->block * (h_flt ? sizeof(suamd_complex) : src.bytes_per_sample());
+      if (a->bus->bcast(root, root, bytes, 0, 0, a->bus->comm[0], a->stream) != 0) { a->bus->bcast = nullptr; }
     }
     (void)hipEventRecord(a->ev_h2d[cur], a->stream);
     a->h2d_set[cur] = true;
@@ -1642,55 +1892,27 @@ void worker_main(suscan_analyzer *a)
     }
   }
   finish(flight);
-  (void)hipDeviceSynchronize();
-  for (auto &kv : a->inspectors) kv.second->free_all();
-  a->inspectors.clear();
-  if (a->st) suamd_specttuner_destroy(a->st);
-  a->st = nullptr;
-  if (a->chandet) suamd_chandet_destroy(a->chandet);
-  a->chandet = nullptr;
-  for (int p = 0; p < 2; ++p) {
-    if (a->d_rowptr[p]) (void)hipFree(a->d_rowptr[p]);
-    if (a->h_rowptr[p]) (void)hipHostFree(a->h_rowptr[p]);
-    a->d_rowptr[p] = a->h_rowptr[p] = nullptr;
-  }
-  a->rowptr_cap = 0;
-  if (a->psd) suamd_psd_destroy(a->psd);
-  for (int p = 0; p < 2; ++p) {
-    if (a->h_psd[p]) (void)hipHostFree(a->h_psd[p]);
-    a->h_psd[p] = nullptr;
-    if (a->ev_psd[p]) (void)hipEventDestroy(a->ev_psd[p]);
-    if (a->ev_h2d[p]) (void)hipEventDestroy(a->ev_h2d[p]);
-    a->ev_psd[p] = a->ev_h2d[p] = nullptr;
-    for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) { if (a->ev_done[p][k]) (void)hipEventDestroy(a->ev_done[p][k]); a->ev_done[p][k] = nullptr; }
-  }
-  if (a->ev_xfree) (void)hipEventDestroy(a->ev_xfree);
-  if (a->ev_fir) (void)hipEventDestroy(a->ev_fir);
-  a->ev_xfree = a->ev_fir = nullptr;
-  if (a->h_x) (void)hipHostFree(a->h_x);
-  if (a->h_flt) (void)hipHostFree(a->h_flt);
-  if (a->d_dc) (void)hipFree(a->d_dc);
-  a->h_flt = nullptr; a->d_dc = nullptr;
-  if (a->d_x) (void)hipFree(a->d_x);
-  if (a->d_raw) (void)hipFree(a->d_raw);
-  if (a->d_psd) (void)hipFree(a->d_psd);
-  if (a->stream) (void)hipStreamDestroy(a->stream);
-  for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) { if (a->istream[k]) (void)hipStreamDestroy(a->istream[k]); a->istream[k] = nullptr; }
-  if (a->ev_input) (void)hipEventDestroy(a->ev_input);
-  a->ev_input = nullptr;
-  for (int g = 0; g < 3; ++g)
-    for (int j = 0; j < suscan_analyzer::NSUB; ++j) { if (a->ev_stage[g][j]) (void)hipEventDestroy(a->ev_stage[g][j]); a->ev_stage[g][j] = nullptr; }
-  if (a->ctx) suamd_ctx_destroy(a->ctx);
-  a->psd = nullptr; a->h_x = nullptr; a->d_x = nullptr; a->d_raw = nullptr; a->d_psd = nullptr; a->stream = nullptr; a->ctx = nullptr;
+  free_device(a);
   push(a, SUSCAN_WORKER_MSG_TYPE_HALT, nullptr);
 }
 
 SUBOOL post(suscan_analyzer *a, Request &&r)
 {
   if (!a) return SU_FALSE;
-  std::lock_guard<std::mutex> lk(a->req_m);
-  a->requests.push_back(std::move(r));
+  {
+    std::lock_guard<std::mutex> lk(a->req_m);
+    a->requests.push_back(std::move(r));
+  }
+  if (a->shard > 0 && a->bus) a->bus->cv.notify_all();         // a GPU shard waiting for the next block looks at its requests
   return SU_TRUE;
+}
+
+// the shard an inspector handle lives on (handles are dealt s, s + G, s + 2G ... by shard s)
+suscan_analyzer *shard_of(suscan_analyzer *a, SUHANDLE h)
+{
+  if (!a || a->nshards <= 1 || h < 0) return a;
+  const int s = (int)(h % a->nshards);
+  return s == 0 ? a : a->secondaries[(size_t)s - 1];
 }
 
 }  // namespace
@@ -2018,6 +2240,48 @@ suscan_analyzer_t *suscan_analyzer_new(const struct suscan_analyzer_params *para
   a->info.freq_min = -3e11; a->info.freq_max = 3e11;
   a->info.bandwidth = (SUFLOAT)config->samp_rate;
   a->info.seekable = config->type == "file" ? SU_TRUE : SU_FALSE;
+  a->primary = a;
+  // SUAMD_DEVICES="0,1,2,3": the inspectors are sharded over these GPUs (the first one also owns the source and the PSD)
+  {
+    std::vector<int> devs;
+    if (const char *e = std::getenv("SUAMD_DEVICES")) {
+      for (const char *q = e; *q;) {
+        char *end = nullptr;
+        const long v = std::strtol(q, &end, 10);
+        if (end == q) break;
+        if (v >= 0 && v < 64) devs.push_back((int)v);
+        q = *end == ',' ? end + 1 : end;
+      }
+    }
+    if (devs.empty()) devs.push_back(0);
+    a->device = devs[0];
+    a->nshards = (int)devs.size();
+    if (devs.size() > 1) {
+      a->bus = std::make_shared<BlockBus>();
+      a->bus->done.assign(devs.size() - 1, 0);
+      for (size_t i = 1; i < devs.size(); ++i) {
+        auto *s = new (std::nothrow) suscan_analyzer;
+        if (!s) break;
+        s->params = *params; s->source_cfg = *config; s->mq = mq;
+        s->device = devs[i]; s->shard = (int)i; s->nshards = a->nshards; s->primary = a; s->bus = a->bus;
+        s->next_handle = (SUHANDLE)i;
+        a->secondaries.push_back(s);
+      }
+      if (a->secondaries.size() != devs.size() - 1) {          // out of memory: one GPU then
+        for (suscan_analyzer *s : a->secondaries) delete s;
+        a->secondaries.clear(); a->bus.reset(); a->nshards = 1;
+      }
+      for (suscan_analyzer *s : a->secondaries)
+        s->worker = std::thread([s] {
+          try { secondary_main(s); }
+          catch (const std::exception &e) {
+            push_status(s, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("GPU shard worker: ") + e.what());
+            { std::lock_guard<std::mutex> lk(s->bus->m); s->bus->done[(size_t)s->shard - 1] = ~0ull; }
+            s->bus->cv.notify_all();
+          }
+        });
+    }
+  }
   a->worker = std::thread([a] {
     // an exception on this thread (std::bad_alloc from a per-block vector, a malformed header) must not take the host
     // process down with std::terminate: the reader gets READ_ERROR + HALT, as for any other source failure
@@ -2038,7 +2302,12 @@ void suscan_analyzer_destroy(suscan_analyzer_t *a)
 {
   if (!a) return;
   a->halt = true;
-  if (a->worker.joinable()) a->worker.join();
+  if (a->worker.joinable()) a->worker.join();                 // joins the other shards' workers on its way out
+  for (suscan_analyzer *s : a->secondaries) {
+    if (s->worker.joinable()) s->worker.join();
+    for (auto &r : s->requests) if (r.config) suscan_config_destroy(r.config);
+    delete s;
+  }
   for (auto &r : a->requests) if (r.config) suscan_config_destroy(r.config);
   suscan_source_info_finalize(&a->info);
   delete a;
@@ -2113,7 +2382,8 @@ SUBOOL suscan_analyzer_open_ex_async(suscan_analyzer_t *a, const char *cls, cons
 {
   if (!cls || !ch) return SU_FALSE;
   Request r; r.kind = Request::OPEN; r.req_id = req; r.cls = cls; r.channel = *ch; r.precise = precise != 0;
-  return post(a, std::move(r));
+  // new inspectors go round the GPU shards (channel c -> GPU c mod G)
+  return post(a && a->nshards > 1 ? shard_of(a, (SUHANDLE)(a->open_rr++ % (uint32_t)a->nshards)) : a, std::move(r));
 }
 
 SUBOOL suscan_analyzer_open_async(suscan_analyzer_t *a, const char *cls, const struct sigutils_channel *ch, uint32_t req)
@@ -2124,26 +2394,26 @@ SUBOOL suscan_analyzer_open_async(suscan_analyzer_t *a, const char *cls, const s
 SUBOOL suscan_analyzer_close_async(suscan_analyzer_t *a, SUHANDLE h, uint32_t req)
 {
   Request r; r.kind = Request::CLOSE; r.req_id = req; r.handle = h;
-  return post(a, std::move(r));
+  return post(shard_of(a, h), std::move(r));
 }
 
 SUBOOL suscan_analyzer_set_inspector_id_async(suscan_analyzer_t *a, SUHANDLE h, uint32_t id, uint32_t req)
 {
   Request r; r.kind = Request::SET_ID; r.req_id = req; r.handle = h; r.inspector_id = id;
-  return post(a, std::move(r));
+  return post(shard_of(a, h), std::move(r));
 }
 
 SUBOOL suscan_analyzer_set_inspector_config_async(suscan_analyzer_t *a, SUHANDLE h, const suscan_config_t *cfg, uint32_t req)
 {
   if (!cfg) return SU_FALSE;
   Request r; r.kind = Request::SET_CONFIG; r.req_id = req; r.handle = h; r.config = suscan_config_dup(cfg);
-  return post(a, std::move(r));
+  return post(shard_of(a, h), std::move(r));
 }
 
 SUBOOL suscan_analyzer_set_inspector_watermark_async(suscan_analyzer_t *a, SUHANDLE h, SUSCOUNT wm, uint32_t req)
 {
   Request r; r.kind = Request::SET_WATERMARK; r.req_id = req; r.handle = h; r.value = wm;
-  return post(a, std::move(r));
+  return post(shard_of(a, h), std::move(r));
 }
 
 const struct suscan_spectsrc_class *suscan_spectsrc_class_lookup(const char *name)
@@ -2167,31 +2437,31 @@ const struct suscan_estimator_class *suscan_estimator_class_lookup(const char *n
 SUBOOL suscan_analyzer_inspector_set_spectrum_async(suscan_analyzer_t *a, SUHANDLE h, uint32_t spectsrc_id, uint32_t req)
 {
   Request r; r.kind = Request::SET_SPECTRUM; r.req_id = req; r.handle = h; r.value = spectsrc_id;
-  return post(a, std::move(r));
+  return post(shard_of(a, h), std::move(r));
 }
 
 SUBOOL suscan_analyzer_set_inspector_freq_overridable(suscan_analyzer_t *a, SUHANDLE h, SUFREQ f)
 {
   Request r; r.kind = Request::SET_FREQ; r.handle = h; r.fvalue = f;
-  return post(a, std::move(r));
+  return post(shard_of(a, h), std::move(r));
 }
 
 SUBOOL suscan_analyzer_set_inspector_bandwidth_overridable(suscan_analyzer_t *a, SUHANDLE h, SUFREQ bw)
 {
   Request r; r.kind = Request::SET_BW; r.handle = h; r.fvalue = bw;
-  return post(a, std::move(r));
+  return post(shard_of(a, h), std::move(r));
 }
 
 SUBOOL suscan_analyzer_inspector_estimator_cmd_async(suscan_analyzer_t *a, SUHANDLE h, uint32_t estimator_id, SUBOOL enabled, uint32_t req)
 {
   Request r; r.kind = Request::ESTIMATOR; r.handle = h; r.value = estimator_id; r.fvalue = enabled ? 1 : 0; r.req_id = req;
-  return post(a, std::move(r));
+  return post(shard_of(a, h), std::move(r));
 }
 
 SUBOOL suscan_analyzer_inspector_set_tle_async(suscan_analyzer_t *a, SUHANDLE h, const orbit_t *tle, uint32_t req)
 {
   Request r; r.kind = Request::SET_TLE; r.handle = h; r.fvalue = tle ? 1 : 0; r.req_id = req;
-  return post(a, std::move(r));
+  return post(shard_of(a, h), std::move(r));
 }
 
 SUBOOL suscan_analyzer_register_baseband_filter_with_prio(suscan_analyzer_t *a, suscan_analyzer_baseband_filter_func_t func, void *priv,

@@ -27,7 +27,13 @@ def _chan_params(fc, bw):
     return D, f0, 2 * np.pi * bw / FS, FS / (D * bw)
 
 
-def test_raw_inspectors_share_one_forward_fft_and_match_the_oracle(tmp_path, sdo):
+@pytest.mark.parametrize("devices", [None, "0,0", "0,0,0"])
+def test_raw_inspectors_share_one_forward_fft_and_match_the_oracle(tmp_path, sdo, monkeypatch, devices):
+    """devices: SUAMD_DEVICES.  "0,0" / "0,0,0" run two / three GPU shards (csrc/analyzer.cpp: BlockBus) on the one GPU of
+    the test box: inspector handle h lives on shard h mod G, every shard gets every block from shard 0's pinned buffer
+    and posts to the same queue -- channel for channel the same samples as on one shard, one PSD stream."""
+    if devices:
+        monkeypatch.setenv("SUAMD_DEVICES", devices)
     nblocks = 10
     chans = [(125e3, 40e3), (-200e3, 40e3), (310e3, 9e3), (0.0, 300e3), (-50e3, 2.5e3)]          # D = 8, 8, 32, 1, 128
     x = synth.psk_carriers(L * nblocks, [2 * c[0] / FS for c in chans], sps=64, order=4, seed=8, snr_db=25)
@@ -38,7 +44,7 @@ def test_raw_inspectors_share_one_forward_fft_and_match_the_oracle(tmp_path, sdo
     for k, (fc, bw) in enumerate(chans):
         ch = suscan.Channel(fc=fc, f_lo=fc - bw / 2, f_hi=fc + bw / 2, bw=bw, ft=433.92e6)
         assert Lb.suscan_analyzer_open_ex_async(an, b"raw", C.byref(ch), int(k % 2 == 0), -1, 100 + k)
-    st = {"psd": 0, "open_at": {}, "id": {}, "samples": {}, "efs": {}}
+    st = {"psd": 0, "open_at": {}, "id": {}, "samples": {}, "efs": {}, "handles": {}}
 
     def on_msg(t, ptr):
         if t == suscan.MSG_PSD:
@@ -49,6 +55,7 @@ def test_raw_inspectors_share_one_forward_fft_and_match_the_oracle(tmp_path, sdo
                 k = m.req_id - 100
                 st["open_at"][k] = st["psd"]
                 st["efs"][k] = m.equiv_fs
+                st["handles"][k] = m.handle
                 assert Lb.suscan_analyzer_set_inspector_id_async(an, m.handle, 500 + k, 0)
         elif t == suscan.MSG_SAMPLES:
             m = C.cast(ptr, C.POINTER(suscan.SampleBatchMsg)).contents
@@ -58,15 +65,23 @@ def test_raw_inspectors_share_one_forward_fft_and_match_the_oracle(tmp_path, sdo
     _pump(Lb, an, on_msg)
     Lb.suscan_analyzer_destroy(an)
     Lb.suscan_mq_finalize(C.byref(mq))
-    assert len(st["open_at"]) == len(chans)
-    b0 = st["open_at"][0]
-    assert all(b == b0 for b in st["open_at"].values()), "the five requests were posted together"
-    assert b0 < nblocks - 4
+    assert len(st["open_at"]) == len(chans) and st["psd"] == nblocks            # one PSD stream whatever the shard count
+    G = len(devices.split(",")) if devices else 1
+    assert len(set(st["handles"].values())) == len(chans)
+    assert sorted(h % G for h in st["handles"].values()) == sorted(k % G for k in range(len(chans)))   # dealt round the shards
+    if G == 1:
+        b0 = st["open_at"][0]
+        assert all(b == b0 for b in st["open_at"].values()), "the five requests were posted together"
+    assert max(st["open_at"].values()) < nblocks - 4
     for k, (fc, bw) in enumerate(chans):
         D, f0, bwa, guard = _chan_params(fc, bw)
         assert abs(st["efs"][k] - FS / D) < 1e-3
-        ref = sdo.specttuner_run(x[b0 * L:], W, f0, bwa, guard, precise=(k % 2 == 0))
+        # a shard's filter bank starts with the first block that finds an inspector on it.  (The OPEN reply of another
+        # shard may reach the queue a PSD frame later than its work started: both candidates are tried.)
         got = np.concatenate(st["samples"][k])
+        cands = [st["open_at"][k]] if G == 1 else sorted({max(0, st["open_at"][j] - d) for j in st["open_at"] if st["handles"][j] % G == st["handles"][k] % G for d in (0, 1)})
+        refs = [sdo.specttuner_run(x[b * L:], W, f0, bwa, guard, precise=(k % 2 == 0)) for b in cands]
+        ref = min(refs, key=lambda r: _relerr(got[-min(got.size, r.size):], r[-min(got.size, r.size):]) if min(got.size, r.size) else 9)
         # (samples below the inspector id hand-shake of the first block may have gone out under id 0: compare the tail)
         n = min(got.size, ref.size)
         assert n > 0.8 * ref.size
