@@ -827,6 +827,7 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
       std::string err;
       if (!build_chain(a, in, err)) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, err); continue; }
       in.dirty = false;
+      in.use(slot);                                           // the rebuild may have re-allocated the slot's rows
     }
     live.push_back(&in);
   }
@@ -1736,6 +1737,7 @@ void worker_main(suscan_analyzer *a)
     const size_t got = got_next;
     if (got < a->block) {                                  // a partial last block is dropped, as a
       finish(flight);
+      bus_close(a);                                          // the other GPU shards deliver what they still hold: before EOS
       push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_EOS, 0, "end of stream");   // whole PSD frame set is needed
       break;
     }
@@ -1892,6 +1894,7 @@ void worker_main(suscan_analyzer *a)
     }
   }
   finish(flight);
+  bus_close(a);                                              // ... and before this worker's HALT
   free_device(a);
   push(a, SUSCAN_WORKER_MSG_TYPE_HALT, nullptr);
 }

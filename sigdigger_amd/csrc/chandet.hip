@@ -83,7 +83,10 @@ hipError_t chandet_feed(float *S, const float *P, int n, float alpha, float gamm
 {
   hipLaunchKernelGGL(chandet_update_kernel, dim3((n + 255) / 256), dim3(256), 0, st, S, P, n, alpha, first);
   auto kern = chandet_floor_kernel;
-  static bool attr_done = false;
+  static bool attr_done_dev[64] = {};                        // a function attribute belongs to a device
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  bool &attr_done = attr_done_dev[dev_ & 63];
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     if (e != hipSuccess) return e;

@@ -156,7 +156,10 @@ hipError_t launch_psd(const void *x, long long hop, int navg, const float *windo
   constexpr int N = 1 << LOG2N;
   const size_t lds = sizeof(cf) * (size_t)(N + (N >> 4) + 1);
   auto kern = psd_kernel<LOG2N, THREADS>;
-  static bool attr_done = false;
+  static bool attr_done_dev[64] = {};                        // a function attribute belongs to a device
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  bool &attr_done = attr_done_dev[dev_ & 63];
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -211,7 +211,10 @@ hipError_t launch_st_v(const sdk::StArgs &a, hipStream_t st)
   constexpr int W = 1 << LOG2W;
   const size_t lds = sizeof(cf) * std::max((size_t)(W + W / 16 + 1), (size_t)G::CPP * G::PADS);
   auto kern = st_kernel<LOG2W, LOG2S, OCC, PREFETCH>;
-  static bool attr_done = false;
+  static bool attr_done_dev[64] = {};                        // a function attribute belongs to a device
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  bool &attr_done = attr_done_dev[dev_ & 63];
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
