@@ -173,7 +173,7 @@ SUAMD_API SUBOOL suamd_specttuner_feed(suamd_specttuner_t *st, const suamd_compl
  * each channel's samples of this feed start (contiguous in time) */
 SUAMD_API SUBOOL suamd_specttuner_feed_rows(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len,
                                             suamd_complex *const *d_rows, SUSCOUNT *counts, void *stream);
-/* windows per workgroup run (default 4): a run re-transforms the window before it */
+/* windows per workgroup run (default 3): a run re-transforms the window before it */
 SUAMD_API SUBOOL suamd_specttuner_set_run(suamd_specttuner_t *st, unsigned run);
 
 /* ------------------------------------------------------------------------------------ */

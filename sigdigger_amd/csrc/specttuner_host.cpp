@@ -156,7 +156,7 @@ struct suamd_specttuner {
   suamd_ctx_t *ctx = nullptr;
   unsigned W = 4096, H = 2048;
   int log2w = 12;
-  unsigned run = 4;                    // windows per workgroup: 512 workgroups per 4 Mi-sample block, 25 % re-transformed
+  unsigned run = 3;                    // windows per workgroup: 683 workgroups per 4 Mi-sample block, a third re-transformed
   c32 *d_tw_w = nullptr;
   c32 *d_hist[2] = {nullptr, nullptr};
   int hist_cur = 0;
@@ -285,6 +285,7 @@ suamd_specttuner_t *suamd_specttuner_new(suamd_ctx_t *ctx, unsigned window_size)
   auto *st = new (std::nothrow) suamd_specttuner();
   if (!st) { suamd_set_error("out of memory"); return nullptr; }
   st->ctx = ctx; st->W = window_size; st->H = window_size / 2; st->log2w = 12;
+  if (const char *e = std::getenv("SUAMD_ST_RUN")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) st->run = (unsigned)v; }   // tuning knob
   st->d_tw_w = dev_upload_new(twiddles(st->W));
   bool ok = st->d_tw_w != nullptr;
   for (int p = 0; p < 2 && ok; ++p) ok = hipMalloc((void **)&st->d_hist[p], st->H * sizeof(c32)) == hipSuccess;

@@ -14,7 +14,7 @@ def short(name):
     return re.sub(r"\(.*$", "", name)
 
 
-OURS = re.compile(r"^(psd_|chan_fir|costas_|clock_|agc_|pll_|quad_|xlate_|modulate_|update_hist|interpolate_|sweep_linear|"
+OURS = re.compile(r"^(st_kernel|chandet_|audio_|psd_|chan_fir|costas_|clock_|agc_|pll_|quad_|xlate_|modulate_|update_hist|interpolate_|sweep_linear|"
                   r"feed_|fft_pass|frame_|window_pad|power_argmax|centroid|ingest|rows_|cma_|zc_|conj_prev|fac_|"
                   r"histogram_|delayed_|sample_manual|averager_|insp_spectrum|psd_shift)")
 stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
@@ -86,6 +86,17 @@ def collect(prefix, by_grid):
     return res
 
 
+def _prev_calibration():
+    for f in sorted(glob.glob(os.path.join(prof, "*_pmc_traffic.json")), reverse=True):
+        try:
+            c = json.load(open(f)).get("calibration")
+        except Exception:
+            c = None
+        if c:
+            return c
+    return None
+
+
 best = collect("pmc", False)          # default workload only (--no-extra): what bench.py's roofline.traffic reads
 res = collect("pmcall", True)         # all workloads, split by launch grid (C2 / C3 / C5 launches differ in grid)
 old = {}
@@ -99,7 +110,7 @@ doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
                  "--no-cpu-baseline` (tools/profile_round.sh), MI355X",
        "units": "counter values are KiB; per-launch averages; HBM bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 "
                 "(FETCH_SIZE counts half of the streamed bytes on gfx950, see calibration)",
-       "calibration": old.get("calibration"),
+       "calibration": old.get("calibration") or _prev_calibration(),
        "workload": {"name": "c4", "block_samples": 4194304},
        "kernels_by_grid": res}
 doc["kernels"] = best

@@ -18,7 +18,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 python bench.py --no-extra --no-cpu-baseline --isolated > $OUT/bench_isolated.json 2>> $OUT/bench.err
-python tools/fir_bench.py > $OUT/kernel_microbench.txt 2>&1
+python tools/st_bench.py > $OUT/kernel_microbench.txt 2>&1
+python tools/fir_bench.py >> $OUT/kernel_microbench.txt 2>&1
 python tools/psd_bench.py >> $OUT/kernel_microbench.txt 2>&1
+bash tools/st_pmc.sh > $OUT/st_sq_counters.txt 2>&1
 python tools/prof_summary.py $OUT $TAG
+cp $OUT/st_sq_counters.txt profiles/${TAG}_st_sq_counters.txt 2>/dev/null
 ls -la $OUT
