@@ -25,6 +25,7 @@ SOURCES = {
     "specview.hip": ["-ffp-contract=off"],
     "fft.hip": ["-ffp-contract=fast"],
     "specttuner.hip": ["-ffp-contract=off"],
+    "specttuner_wave.hip": ["-ffp-contract=fast"],
     "specttuner_host.cpp": ["-ffp-contract=off"],
     "chandet.hip": ["-ffp-contract=off"],
     "audio.hip": ["-ffp-contract=off"],

@@ -77,6 +77,9 @@ struct StArgs {
   const void *tw_w, *tw_s;      // W- and size-point twiddle tables (complex)
   const StChan *chans; int nchan;
   const void *hk;               // [nsel][size] complex: k h[i] (zero outside the pass band)
+  int hk_uniform;               // every channel of the launch has hsel == chans[0].hsel (wavefront kernel: response kept in LDS)
+  void *handoff; unsigned *flags;   // wavefront kernel: [runs * blocks][16 KiB] seam payload, one flag per run (all zero between launches)
+  const void *hkt;              // the same per channel, transposed for the wavefront kernel: [ceil(nchan/64)][size][64]
   const float *win;             // [size]: sin^2(pi i / size)
   const void *prev_in; void *prev_out;   // [nchan][size/2]: second half of the last block of the previous feed (ping-pong)
   unsigned long long n0;        // outputs per channel emitted by earlier feeds (phase of the residual NCO)
@@ -86,6 +89,9 @@ struct StArgs {
 // channels one workgroup serves side by side for inverse transforms of 2^log2s points
 int st_channels_per_group(int log2s);
 hipError_t specttuner_feed(int log2w, int log2s, const StArgs &a, hipStream_t st);
+// specttuner_wave.hip: one wavefront per window, sizes 8..64 (W = 4096); channels one wavefront serves
+int stw_channels_per_wave(int log2s);
+hipError_t specttuner_feed_wave(int log2s, const StArgs &a, hipStream_t st);
 
 // ---- chandet.hip: su_channel_detector (SPEC.md section O) ----
 struct ChanDetRecord { int first, last, width; float peak; double sum, wsum; };   // bins in frequency order (0 = -fs/2)

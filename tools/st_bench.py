@@ -10,14 +10,17 @@ ctx = engine.Context(0)
 x = torch.empty(L, dtype=torch.complex64, device="cuda")
 torch.view_as_real(x).normal_()
 import os
-CASES = [(64, 64, 4)] if os.environ.get('ST_ONE') else [(64, 64, 8), (64, 64, 4), (64, 64, 3), (64, 64, 2), (64, 64, 1)] if os.environ.get('ST_QUICK') else [(64, 64, 8), (64, 64, 4), (64, 64, 2), (1, 64, 4), (512, 64, 4), (64, 16, 4), (1, 1, 4)]
+CASES = [(64, 64, int(os.environ.get('ST_RUN', 0)))] if os.environ.get('ST_ONE') else [(64, 64, 0), (64, 64, 2), (64, 64, 3), (64, 64, 4), (64, 32, 0), (128, 128, 0), (512, 512, 0), (16, 64, 0)] if os.environ.get('ST_WAVE') else [(64, 64, 8), (64, 64, 4), (64, 64, 3), (64, 64, 2), (64, 64, 1)] if os.environ.get('ST_QUICK') else [(64, 64, 8), (64, 64, 4), (64, 64, 2), (1, 64, 4), (512, 64, 4), (64, 16, 4), (1, 1, 4)]
 for C, D, run in CASES:
     st = engine.SpectTuner(ctx, 4096)
-    st.set_run(run)
+    if run:
+        st.set_run(run)
     fn = synth.raster(C, float(os.environ.get('ST_SPACING', 1.8 / max(C, 2))))
     for f in fn:
         st.open_channel(np.pi * f % (2 * np.pi), 2 * np.pi * 0.75 / D)
-    out = torch.empty((C, L // D + 64), dtype=torch.complex64, device="cuda")
+    # ST_LAYOUT=tm (default): time-major output, what the inspector loops stream; cm: channel-major rows
+    out = (engine.time_major(C, L // D + 64, "cuda") if os.environ.get('ST_LAYOUT', 'tm') == 'tm'
+           else torch.empty((C, L // D + 64), dtype=torch.complex64, device="cuda"))
     st.feed(x, out=out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
