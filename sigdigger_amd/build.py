@@ -15,7 +15,7 @@ OUT = os.path.join(HERE, "libsigdigger_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-          "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+          "-Wall", "-Wno-unused-function", "-Wno-unused-value"] + os.environ.get("SUAMD_BUILD_DEFS", "").split()
 # SPEC.md section D: the inspector chain is a fixed sequence of binary32 operations; only the
 # fma calls written in the source may fuse.  The FFT PSD is not bit-pinned and may contract.
 SOURCES = {
@@ -25,7 +25,7 @@ SOURCES = {
     "specview.hip": ["-ffp-contract=off"],
     "fft.hip": ["-ffp-contract=fast"],
     "specttuner.hip": ["-ffp-contract=off"],
-    "specttuner_wave.hip": ["-ffp-contract=fast"],
+    "specttuner_wave.hip": ["-ffp-contract=off"],
     "specttuner_host.cpp": ["-ffp-contract=off"],
     "chandet.hip": ["-ffp-contract=off"],
     "audio.hip": ["-ffp-contract=off"],

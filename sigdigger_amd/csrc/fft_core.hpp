@@ -54,6 +54,19 @@ __device__ __forceinline__ void dft4(cf &a0, cf &a1, cf &a2, cf &a3)
 
 __device__ __forceinline__ cf mul_w8_1(cf a) { return add_mj(a, a) * 0.70710678118654752440f; }            // * (1 - j)/sqrt2
 __device__ __forceinline__ cf mul_w8_3(cf a) { return add_mj(-a, a) * 0.70710678118654752440f; }           // * (-1 - j)/sqrt2
+// e +- o W8^1 and e +- o W8^3 as explicit fused multiply-adds: the same roundings in every instantiation and under
+// every -ffp-contract setting (different instantiations of one transform must agree bit for bit)
+__device__ __forceinline__ cf fmac(cf a, float c, cf b) { return __builtin_elementwise_fma(a, cf{c, c}, b); }
+__device__ __forceinline__ void bfly_w8_1(cf e, cf o, cf &p, cf &m)
+{
+  const cf r = add_mj(o, o);
+  p = fmac(r, 0.70710678118654752440f, e); m = fmac(r, -0.70710678118654752440f, e);
+}
+__device__ __forceinline__ void bfly_w8_3(cf e, cf o, cf &p, cf &m)
+{
+  const cf r = add_mj(-o, o);
+  p = fmac(r, 0.70710678118654752440f, e); m = fmac(r, -0.70710678118654752440f, e);
+}
 
 __device__ __forceinline__ void dft8(cf *v)
 {
@@ -61,12 +74,10 @@ __device__ __forceinline__ void dft8(cf *v)
   cf o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
   dft4(e0, e1, e2, e3);
   dft4(o0, o1, o2, o3);
-  o1 = mul_w8_1(o1);
-  o3 = mul_w8_3(o3);
   v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
-  v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+  bfly_w8_1(e1, o1, v[1], v[5]);
   v[2] = add_mj(e2, o2); v[6] = sub_mj(e2, o2);          // o2 * (-j) folded into the butterfly
-  v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+  bfly_w8_3(e3, o3, v[3], v[7]);
 }
 
 __device__ __forceinline__ void dft16(cf *v)
@@ -78,14 +89,14 @@ __device__ __forceinline__ void dft16(cf *v)
   dft8(o);
   const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;
   o[1] = cmul(o[1], cf{ c1, -s1});
-  o[2] = mul_w8_1(o[2]);
   o[3] = cmul(o[3], cf{ s1, -c1});
   o[5] = cmul(o[5], cf{-s1, -c1});
-  o[6] = mul_w8_3(o[6]);
   o[7] = cmul(o[7], cf{-c1, -s1});
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     if (i == 4) { v[4] = add_mj(e[4], o[4]); v[12] = sub_mj(e[4], o[4]); }
+    else if (i == 2) bfly_w8_1(e[2], o[2], v[2], v[10]);
+    else if (i == 6) bfly_w8_3(e[6], o[6], v[6], v[14]);
     else { v[i] = cadd(e[i], o[i]); v[i + 8] = csub(e[i], o[i]); }
   }
 }

@@ -77,6 +77,8 @@ struct StArgs {
   const void *tw_w, *tw_s;      // W- and size-point twiddle tables (complex)
   const StChan *chans; int nchan;
   const void *hk;               // [nsel][size] complex: k h[i] (zero outside the pass band)
+  unsigned long long *tstamp;   // STW_TSTAMP builds only: [run][window of the run][16] s_memtime stamps
+  int y32;                      // wavefront kernel: every byte offset (row * cs + time * ms) * 8 of this feed's outputs is below 2^31
   int hk_uniform;               // every channel of the launch has hsel == chans[0].hsel (wavefront kernel: response kept in LDS)
   void *handoff; unsigned *flags;   // wavefront kernel: [runs * blocks][16 KiB] seam payload, one flag per run (all zero between launches)
   const void *hkt;              // the same per channel, transposed for the wavefront kernel: [ceil(nchan/64)][size][64]

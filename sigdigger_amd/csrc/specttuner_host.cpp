@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 #include <map>
 #include <memory>
 #include <new>
@@ -466,6 +467,12 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
         // re-transforms the window before its run for the first cross-fade partner)
         a.hkt = g.d_hkt;
         a.hk_uniform = g.hk_uniform ? 1 : 0;
+        {
+          // 32-bit buffer addressing of the outputs when the whole view of this feed lies below 2 GiB
+          const long long hs = (1ll << g.log2s) / 2;
+          const long long last = ((long long)st->ch.size() * (long long)view.chan_stride + (nwin * hs + hs) * (long long)view.time_stride) * 8;
+          a.y32 = (!d_rows && last < (1ll << 31)) ? 1 : 0;
+        }
         if (st->run_wave) a.run = (int)st->run_wave;
         else {
           const long long ny = ((long long)g.members.size() + sdk::stw_channels_per_wave(g.log2s) - 1) / sdk::stw_channels_per_wave(g.log2s);
@@ -486,7 +493,45 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
           }
           a.handoff = g.d_handoff; a.flags = g.d_flags;
         }
+#ifdef STW_TSTAMP
+        static unsigned long long *d_ts = nullptr;
+        const size_t nts = (size_t)((nwin + a.run - 1) / a.run) * (size_t)a.run * 16;
+        if (!d_ts) (void)hipMalloc((void **)&d_ts, (1 << 20) * sizeof(unsigned long long));
+        (void)hipMemsetAsync(d_ts, 0, nts * sizeof(unsigned long long), s);
+        a.tstamp = d_ts;
+#endif
         e = sdk::specttuner_feed_wave(g.log2s, a, s);
+#ifdef STW_TSTAMP
+        if (std::getenv("SUAMD_STW_TSTAMP")) {
+          (void)hipStreamSynchronize(s);
+          std::vector<unsigned long long> ts(nts);
+          (void)hipMemcpy(ts.data(), d_ts, nts * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+          const size_t nr = (size_t)((nwin + a.run - 1) / a.run);
+          unsigned long long tmin = 0;
+          {
+            double pro = 0, tail = 0, life = 0; size_t nw = 0;
+            unsigned long long lo[8], hi[8];
+            for (int q = 0; q < 8; ++q) { lo[q] = ~0ull; hi[q] = 0; }
+            for (size_t r = 0; r < nr; ++r) {
+              const unsigned long long *p0 = &ts[(r * a.run) * 16];
+              unsigned long long e1 = 0;
+              for (int k = 0; k < a.run; ++k) e1 = std::max(e1, ts[(r * a.run + k) * 16 + 9]);
+              if (!p0[10] || !p0[11]) continue;
+              pro += (double)(p0[0] - p0[10]); tail += (double)(p0[11] - e1); life += (double)(p0[11] - p0[10]); ++nw;
+              lo[r & 7] = std::min(lo[r & 7], p0[10]); hi[r & 7] = std::max(hi[r & 7], p0[11]);
+            }
+            double span = 0; for (int q = 0; q < 8; ++q) span += (double)(hi[q] - lo[q]) / 8;
+            std::fprintf(stderr, "stw tstamp: %zu runs x %d; per wave: entry -> first window %.0f, last window -> exit %.0f, life %.0f ticks; per XCD first entry -> last exit %.0f ticks\n",
+                         nr, a.run, pro / nw, tail / nw, life / nw, span);
+          }
+          for (int k = 0; k < a.run; ++k) {
+            double acc[10] = {0}; double start = 0; size_t cnt = 0;
+            for (size_t r = 0; r < nr; ++r) { const unsigned long long *p = &ts[(r * a.run + k) * 16]; if (!p[0]) continue; ++cnt; start += 0.0 * (double)tmin; for (int n = 1; n < 10; ++n) acc[n] += (double)(p[n] - p[n - 1]); }
+            std::fprintf(stderr, "  window %d: start %.0f | dft1 %.0f issue %.0f twid %.0f (ts3) transp %.0f dft2 %.0f hk+spec %.0f gather %.0f ifft %.0f xfade+store %.0f\n", k, start / cnt,
+                         acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt, acc[6] / cnt, acc[7] / cnt, acc[8] / cnt, acc[9] / cnt);
+          }
+        }
+#endif
       } else e = sdk::specttuner_feed(st->log2w, g.log2s, a, s);
       if (e != hipSuccess) { suamd_set_error("specttuner launch failed: %s", hipGetErrorString(e)); return SU_FALSE; }
       g.prev_cur ^= 1;

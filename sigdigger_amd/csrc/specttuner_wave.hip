@@ -23,6 +23,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "kernels.hpp"
 #include "fft_core.hpp"
 #include "sd_math.hpp"
@@ -63,6 +64,25 @@ __device__ __forceinline__ cf cmul_u(cf a, cf b)
   return r;
 }
 
+// a * b and a * (b * c) as ONE asm statement each: between two dependent asm statements the compiler inserts an s_nop
+// (it cannot see inside them), and for a lone wavefront an s_nop costs a full issue slot like any instruction
+__device__ __forceinline__ cf cmul1(cf a, cf b)
+{
+  cf r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=&v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ cf cmul3(cf a, cf b, cf c)
+{
+  cf w, r;
+  asm("v_pk_mul_f32 %1, %3, %4 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %1, %3, %4, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+      "v_pk_mul_f32 %0, %2, %1 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=&v"(r), "=&v"(w) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // al cur + be prv with ONE rounding pattern wherever it is written (the seam block must equal the in-run block bit for bit)
 __device__ __forceinline__ cf xfade(float al, cf cur, float be, cf prv)
 {
@@ -86,8 +106,11 @@ __device__ __forceinline__ cf mul_w64(cf a, int m)
 }
 
 // N = R1 * R2 points on registers, natural order in and out: n = n1 + R1 n2, k = k2 + R2 k1
-template <int R1, int R2>
-__device__ __forceinline__ void dft_2f(const cf *in, cf *out)
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+// `hook(step)` is called after each of the R1 + R2 sub-transforms: a place to slip other work (memory requests) in
+template <int R1, int R2, class Hook = NoHook>
+__device__ __forceinline__ void dft_2f(const cf *in, cf *out, Hook hook = Hook())
 {
   constexpr int N = R1 * R2;
   cf mid[N];
@@ -99,6 +122,7 @@ __device__ __forceinline__ void dft_2f(const cf *in, cf *out)
     dftR<R2>(a);
 #pragma unroll
     for (int k2 = 0; k2 < R2; ++k2) mid[n1 + R1 * k2] = mul_w64(a[k2], n1 * k2 * (64 / N));
+    hook(n1);
   }
 #pragma unroll
   for (int k2 = 0; k2 < R2; ++k2) {
@@ -108,14 +132,15 @@ __device__ __forceinline__ void dft_2f(const cf *in, cf *out)
     dftR<R1>(b);
 #pragma unroll
     for (int k1 = 0; k1 < R1; ++k1) out[k2 + R2 * k1] = b[k1];
+    hook(R1 + k2);
   }
 }
 
-template <int LOG2N> __device__ __forceinline__ void dft_reg(const cf *in, cf *out)
+template <int LOG2N, class Hook = NoHook> __device__ __forceinline__ void dft_reg(const cf *in, cf *out, Hook hook = Hook())
 {
   constexpr int N = 1 << LOG2N;
-  if constexpr (LOG2N == 6) dft_2f<8, 8>(in, out);
-  else if constexpr (LOG2N == 5) dft_2f<4, 8>(in, out);
+  if constexpr (LOG2N == 6) dft_2f<8, 8>(in, out, hook);
+  else if constexpr (LOG2N == 5) dft_2f<4, 8>(in, out, hook);
   else {
 #pragma unroll
     for (int i = 0; i < N; ++i) out[i] = in[i];
@@ -142,22 +167,25 @@ constexpr int WV_LDS = (WV_HK + 64) * 8;
 // the flag: every launch leaves the flag array zeroed.  A run only ever waits for the NEXT workgroup in dispatch order,
 // and only for that workgroup's first step: when workgroups queue for a slot the wait ends as soon as any resident
 // one retires.
+#ifdef STW_TSTAMP
+#define TS(n) do { __builtin_amdgcn_sched_barrier(0); ts[n] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TS(n) do { } while (0)
+#endif
 constexpr int AUX_SC1 = 16;                                    // cache-policy bit of the raw buffer builtins: sc1 (agent scope)
 
-template <int LOG2S, bool UNIFORM>
+template <int LOG2S, bool UNIFORM, bool Y32>
 __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
 {
+#ifdef STW_TSTAMP
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
   __builtin_amdgcn_s_setprio(3);   // ahead of the resident recurrence wavefronts
   constexpr int W = WV_W, H = WV_H, S = 1 << LOG2S, HS = S / 2, NG = WAVE / S;
   static_assert(HS <= WV_REP && S >= 4, "size out of range for the wavefront kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf *buf = reinterpret_cast<cf *>(smem);
   const int t = threadIdx.x;
-
-  // W_4096^(t 2^j): exact table values; every other power is at most five products away
-  cf wb[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) wb[j] = reinterpret_cast<const cf *>(a.tw_w)[t << j];
 
   const long long w_begin = (long long)blockIdx.x * a.run, w_end = (w_begin + a.run < a.nwin) ? w_begin + a.run : a.nwin;
   const cf *x = reinterpret_cast<const cf *>(a.x), *hist = reinterpret_cast<const cf *>(a.hist);
@@ -166,6 +194,48 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
   const long long slot = (long long)blockIdx.x * gridDim.y + blockIdx.y;          // this run's hand-off slot
   cf *const ho = reinterpret_cast<cf *>(a.handoff);
   constexpr long long HO = (long long)NG * HS * WAVE;          // elements per slot
+
+  // The window's samples are requested one window ahead straight into the registers the first DFT reads, by 64 buffer
+  // loads (wave-uniform descriptor + 32-bit lane offset + immediate: no per-load address arithmetic).  The same 64
+  // instructions serve three purposes, chosen by the descriptors: next window / the seam payload of the next run (first 32,
+  // sc1) / nothing (zero-length descriptor: returns 0 without touching memory) -- so the number of loads in flight is
+  // the same on every path and the waits are exact.
+  cf nxt[WAVE];
+  __amdgpu_buffer_rsrc_t ra, rb;                               // descriptors of the request in progress
+  auto aim = [&](const cf *pa, unsigned na, const cf *pb, unsigned nb) {
+    ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(pa), 0, na, 0x00020000);
+    rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(pb), 0, nb, 0x00020000);
+  };
+  auto load_one = [&](int r) {
+    if (r < WAVE / 2) nxt[r] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(ra, t * 8, r * WAVE * 8, AUX_SC1));
+    else nxt[r] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(rb, t * 8, (r - WAVE / 2) * WAVE * 8, 0));
+  };
+  auto issue_all = [&]() {
+#pragma unroll
+    for (int r = 0; r < WAVE; ++r) load_one(r);
+  };
+  auto aim_window = [&](long long w) { aim((w == 0 && a.have_hist) ? hist : x + (w * H - off), H * 8, x + (w * H + H - off), H * 8); };
+  const bool final_run = w_end == a.nwin;
+  const bool single = w_end - w_begin == 1;                    // degenerate run: publish and pick-up both after the loop
+  const long long nslot = slot + gridDim.y;
+  // what follows window w in the load registers (branch-free: the loads themselves are spread over the window's arithmetic)
+  auto aim_next = [&](long long w) {
+    const bool more = w + 1 < w_end, pay = !more && !final_run && !single;
+    const long long wn = more ? w + 1 : w;
+    const cf *pa = pay ? ho + nslot * HO : ((wn == 0 && a.have_hist) ? hist : x + (wn * H - off));
+    aim(pa, more ? H * 8 : (pay ? (unsigned)HO * 8 : 0u), x + (wn * H + H - off), more ? H * 8 : 0u);
+  };
+
+  // the first window's samples before anything else: every other load of the prologue then travels in their shadow
+  aim_window(w_begin);
+  issue_all();
+  __builtin_amdgcn_sched_barrier(0);
+
+
+  // W_4096^(t 2^j): exact table values; every other power is at most five products away
+  cf wb[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) wb[j] = reinterpret_cast<const cf *>(a.tw_w)[t << j];
 
   cf prev[NG][HS];                                             // y_{w-1}[i + S/2] of this lane's channels
 #pragma unroll
@@ -176,10 +246,11 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
       prev[g][i] = (w_begin == 0 && k < a.nchan) ? reinterpret_cast<const cf *>(a.prev_in)[(long long)k * HS + i] : cf{0.f, 0.f};
   }
 
-  // per lane and group, fixed for the launch: centre bin, output base, residual-NCO flag (loads inside the window loop
-  // would have to be waited for with vmcnt(0), i.e. together with the prefetch)
+  // per lane and group, fixed for the launch: centre bin, output base, residual-NCO parameters (loads inside the window
+  // loop would have to be waited for with vmcnt(0), i.e. together with the prefetch)
   int center[NG];
-  cf *ybase[NG];
+  cf *ybase[NG];                                               // 64-bit addressing (row pointers, or views beyond 2 GiB)
+  unsigned yvoff[NG];                                          // 32-bit addressing: the lane's byte offset, out of range for lanes without a channel
   bool precise[NG];
   uint32_t dphase[NG], phase0[NG];                             // residual NCO: step and (n0 - n_open) mod 2^32
 #pragma unroll
@@ -191,77 +262,67 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
     dphase[g] = cd.dphase;
     phase0[g] = (uint32_t)(a.n0 - cd.n_open);
     ybase[g] = a.rows ? static_cast<cf *>(const_cast<void *>(a.rows[cd.row])) : reinterpret_cast<cf *>(a.y) + (long long)cd.row * a.yv.cs;
+    yvoff[g] = k < a.nchan ? (unsigned)((long long)cd.row * a.yv.cs * 8) : 0x80000000u;
   }
   const long long yms = a.rows ? 1 : a.yv.ms;
+  const unsigned yms8 = (unsigned)(yms * 8);
 
-  // output block `wo` of group g: residual NCO ("precise"), store through the view
-  auto store_block = [&](int g, long long wo, cf *o) {
-    const int k = kbase + g * WAVE;
-    if (k >= a.nchan) return;
-    if (precise[g]) {
+  // sample i of output block `wo` of group g: residual NCO ("precise"), store through the view.  With 32-bit offsets the
+  // store is a buffer store: wave-uniform descriptor (the block's first instant) + the lane's offset + a scalar i * stride
+  // Y32: host-checked, every byte offset of the view fits 31 bits.  `rot`: some lane of this wavefront has a residual NCO
+  // (then every lane rotates, the others by exactly 1 + 0j: no divergent branch per sample)
+  bool any_precise = false;
 #pragma unroll
-      for (int i = 0; i < HS; ++i) {
-        const uint32_t m = (uint32_t)((unsigned long long)wo * HS + i);
-        float c, s;
-        sd::phasor_u32((phase0[g] + m) * dphase[g], c, s);
-        o[i] = cf{__builtin_fmaf(o[i].x, c, -(o[i].y * s)), __builtin_fmaf(o[i].x, s, o[i].y * c)};   // one rounding pattern at every call site
-      }
+  for (int g = 0; g < NG; ++g) any_precise |= __builtin_amdgcn_ballot_w64(precise[g]) != 0;
+  auto emit_one = [&](auto rot, int g, long long wo, int i, cf o) {
+    if constexpr (decltype(rot)::value) {
+      const uint32_t m = (uint32_t)((unsigned long long)wo * HS + i);
+      float c, s;
+      sd::phasor_u32((phase0[g] + m) * dphase[g], c, s);
+      c = precise[g] ? c : 1.0f;
+      s = precise[g] ? s : 0.0f;
+      o = cf{__builtin_fmaf(o.x, c, -(o.y * s)), __builtin_fmaf(o.x, s, o.y * c)};   // one rounding pattern at every call site
     }
-    gcf *yp = (gcf *)(ybase[g] + (long long)((unsigned long long)wo * HS) * yms);
-    // a running pointer: 32 separately hoisted 64-bit addresses would not fit the register budget
-    const long long ystep = opaque_ll(yms);
-#pragma unroll
-    for (int i = 0; i < HS; ++i) { *yp = o[i]; yp += ystep; }
-  };
-
-  // The window's samples are requested one window ahead straight into the registers the first DFT reads, by 64 buffer
-  // loads (wave-uniform descriptor + 32-bit lane offset + immediate: no per-load address arithmetic).  The same 64
-  // instructions serve three purposes, chosen by the descriptors: next window / the seam payload of the next run (first 32,
-  // sc1) / nothing (zero-length descriptor: returns 0 without touching memory) -- so the number of loads in flight is
-  // the same on every path and the waits are exact.
-  cf nxt[WAVE];
-  auto issue = [&](const cf *pa, unsigned na, const cf *pb, unsigned nb) {
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(pa), 0, na, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(pb), 0, nb, 0x00020000);
-#pragma unroll
-    for (int r = 0; r < WAVE / 2; ++r) nxt[r] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(ra, t * 8, r * WAVE * 8, AUX_SC1));
-#pragma unroll
-    for (int r = 0; r < WAVE / 2; ++r) nxt[r + WAVE / 2] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(rb, t * 8, r * WAVE * 8, 0));
-  };
-  auto request = [&](long long w) {
-    issue((w == 0 && a.have_hist) ? hist : x + (w * H - off), H * 8, x + (w * H + H - off), H * 8);
-  };
-  const bool final_run = w_end == a.nwin;
-  const bool single = w_end - w_begin == 1;                    // degenerate run: publish and pick-up both after the loop
-  const long long nslot = slot + gridDim.y;
-  // what follows window w in the load registers
-  auto issue_next = [&](long long w) {
-    if (w + 1 < w_end) request(w + 1);
-    else if (!final_run && !single) {
-      // the seam block's first half, published by the next run at its first step (its second window's top): long ago
-      while (__hip_atomic_load(a.flags + nslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
-      asm volatile("" ::: "memory");
-      issue(ho + nslot * HO, (unsigned)HO * 8, x, 0);
-    } else issue(x, 0, x, 0);
+    if constexpr (Y32) {
+      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<cf *>(a.y) + (long long)((unsigned long long)wo * HS) * yms, 0, 0x7fffffff, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), ry, yvoff[g], (unsigned)i * yms8, 0);
+    } else if (kbase + g * WAVE < a.nchan) {
+      *(gcf *)(ybase[g] + ((long long)((unsigned long long)wo * HS) + i) * yms) = o;
+    }
   };
 
   if constexpr (UNIFORM) {
     // one response for every channel of the launch: 512 bytes of LDS, read as a broadcast
-    if (t < S) buf[WV_HK + t] = reinterpret_cast<const cf *>(a.hk)[(long long)a.chans[0].hsel * S + t];
+    if (t < S) buf[WV_HK + t] = reinterpret_cast<const cf *>(a.hk)[t];    // a uniform launch has one response: selector 0
   }
-  request(w_begin);
   bool publish = false;
   for (long long w = w_begin; w < w_end; ++w) {
     cf v[WAVE], A[WAVE];
-    // ---- forward transform ----
-    dft_reg<6>(nxt, A);
+#ifdef STW_TSTAMP
+    unsigned long long ts[16] = {0};
+#endif
+    TS(0);
     if (publish) {
       // the wait for this window's samples (needed here anyway) also drains the seam stores issued before them
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (t == 0) __hip_atomic_store(a.flags + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       publish = false;
     }
-    if constexpr (UNIFORM) issue_next(w);                      // nxt is dead after the first DFT: no copies, no second set
+    // ---- forward transform ----
+    dft_reg<6>(nxt, A);
+    TS(1);
+    if (w + 1 == w_end && !final_run && !single) {
+      // the seam block's first half, published by the next run at its first step (its second window's top);
+      // this run's own flag went out above, BEFORE this wait: no chain of runs waiting for each other
+      while (__hip_atomic_load(a.flags + nslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+      asm volatile("" ::: "memory");
+    }
+    // nxt is dead after the first DFT: the next request goes into the same registers (no copies, no second set).  Its
+    // 64 loads are SPREAD over the arithmetic that follows (4 per 8 twiddles, 2 per sub-transform of the second DFT):
+    // a burst of 64 x 512 B fills the CU's memory pipeline and the lone wavefront then sits in the issue stage
+    if constexpr (UNIFORM) aim_next(w);
+    TS(2);
     {
       cf lo[8], hi[8];
       lo[1] = opaque(wb[0]); lo[2] = opaque(wb[1]); lo[4] = opaque(wb[2]);
@@ -271,10 +332,17 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
 #pragma unroll
       for (int k2 = 1; k2 < WAVE; ++k2) {
         const int l = k2 & 7, h = k2 >> 3;
-        const cf wk = h == 0 ? lo[l] : (l == 0 ? hi[h] : cmul(hi[h], lo[l]));
-        A[k2] = cmul(A[k2], wk);
+        A[k2] = (h == 0 || l == 0) ? cmul1(A[k2], h == 0 ? lo[l] : hi[h]) : cmul3(A[k2], hi[h], lo[l]);
+        if constexpr (UNIFORM) {
+          if (l == 7) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) load_one(4 * h + r);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
     }
+    TS(3);
     {
       cf *wr = buf + t * WV_PITCH;
 #pragma unroll
@@ -284,7 +352,17 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
 #pragma unroll
       for (int tt = 0; tt < WAVE; ++tt) v[tt] = rd[tt * WV_PITCH];
     }
-    dft_reg<6>(v, A);                                          // A[k1] = X[t + 64 k1]
+    TS(4);
+    if constexpr (UNIFORM) {
+      dft_reg<6>(v, A, [&](int step) {                         // A[k1] = X[t + 64 k1]
+        if (step < 8) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) load_one(WAVE / 2 + 4 * step + r);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+    } else dft_reg<6>(v, A);
+    TS(5);
     cf hkr[UNIFORM ? 1 : NG][UNIFORM ? 1 : S];
     if constexpr (!UNIFORM) {
       // per-channel responses: one batch of loads (L2 hits) issued behind the spectrum's way to LDS; VMEM returns in
@@ -296,7 +374,8 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
 #pragma unroll
         for (int i = 0; i < S; ++i) hkr[g][i] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(rh, t * 8, i * WAVE * 8, 0));
       }
-      issue_next(w);
+      aim_next(w);
+      issue_all();
     }
     __builtin_amdgcn_wave_barrier();
     {
@@ -306,46 +385,94 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
       if (t < WV_REP) buf[W + t] = A[0];
     }
     __builtin_amdgcn_wave_barrier();
+    TS(6);
     // ---- channel stage ----
     const bool seam = w == w_begin && w_begin > 0;             // this block belongs to the previous run: publish, do not emit
+    auto chan = [&](auto seam_tag, auto rot) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int c0 = center[g], c1 = (center[g] - HS) & (W - 1);
       cf u[S], F[S];
+      if constexpr (UNIFORM) {
+        // all the bin reads first (two bins per ds_read_b128: the centre bin is even), then the response in chunks of 16
+        // bins, each requested one chunk ahead of its products: left to itself the compiler alternates read / wait / use
+        // and the lone wavefront pays the LDS latency 32 times
+        float4 X2[S / 2];
 #pragma unroll
-      for (int i = 0; i < S; i += 2) {
-        // two bins per read: the centre bin is even, so is i
-        const float4 X2 = *reinterpret_cast<const float4 *>(buf + (i < HS ? c0 + i : c1 + (i - HS)));
-        if constexpr (UNIFORM) {
-          const float4 H2 = *reinterpret_cast<const float4 *>(buf + WV_HK + i);
-          u[i] = cmul(cf{X2.x, X2.y}, cf{H2.x, H2.y});
-          u[i + 1] = cmul(cf{X2.z, X2.w}, cf{H2.z, H2.w});
-        } else {
+        for (int i = 0; i < S; i += 2) X2[i / 2] = *reinterpret_cast<const float4 *>(buf + (i < HS ? c0 + i : c1 + (i - HS)));
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int CH = S / 2 < 8 ? S / 2 : 8, NCH = (S / 2) / CH;
+        float4 Hq[2][CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) Hq[0][j] = *reinterpret_cast<const float4 *>(buf + WV_HK + 2 * j);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          if (c + 1 < NCH) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) Hq[(c + 1) & 1][j] = *reinterpret_cast<const float4 *>(buf + WV_HK + 2 * ((c + 1) * CH + j));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            const float4 X = X2[c * CH + j], Hh = Hq[c & 1][j];
+            u[2 * (c * CH + j)] = cmul1(cf{X.x, X.y}, cf{Hh.x, Hh.y});
+            u[2 * (c * CH + j) + 1] = cmul1(cf{X.z, X.w}, cf{Hh.z, Hh.w});
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < S; i += 2) {
+          const float4 X2 = *reinterpret_cast<const float4 *>(buf + (i < HS ? c0 + i : c1 + (i - HS)));
           u[i] = cmul(cf{X2.x, X2.y}, hkr[g][i]);
           u[i + 1] = cmul(cf{X2.z, X2.w}, hkr[g][i + 1]);
         }
       }
-      dft_reg<LOG2S>(u, F);                                    // y[n] = F[(S - n) mod S]: the inverse transform read backwards
-      if (seam) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ho + slot * HO, 0, (int)HO * 8, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < HS; ++i) {
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, F[(S - i) & (S - 1)]), rs, t * 8, (g * HS + i) * WAVE * 8, AUX_SC1);
-          prev[g][i] = F[HS - i];
-        }
-      } else {
-        cf o[HS];
-#pragma unroll
-        for (int i = 0; i < HS; ++i) {
+      if (g == 0) TS(7);
+      // y[n] = F[(S - n) mod S] (the inverse transform is a forward DFT read backwards).  Output i needs F[(S - i) mod S]
+      // (this block's first half) and F[S/2 - i] (its second half, the next block's partner): both come out of the same
+      // second-stage sub-transform, so each sub-transform is followed by ITS cross-fades and stores -- the stores are
+      // spread over the arithmetic like the loads
+      auto finish = [&](int i) {
+        const cf cur = F[(S - i) & (S - 1)], nx = F[HS - i];
+        if constexpr (decltype(seam_tag)::value) {
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ho + slot * HO, 0, (int)HO * 8, 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, cur), rs, t * 8, (g * HS + i) * WAVE * 8, AUX_SC1);
+        } else {
           constexpr int ws = 64 / S;
-          const float al = kWin64[i * ws], be = kWin64[(i + HS) * ws];   // compile-time constants
-          o[i] = xfade(al, F[(S - i) & (S - 1)], be, prev[g][i]);
-          prev[g][i] = F[HS - i];
+          emit_one(rot, g, w, i, xfade(kWin64[i * ws], cur, kWin64[(i + HS) * ws], prev[g][i]));
         }
-        store_block(g, w, o);
+        prev[g][i] = nx;
+      };
+      if constexpr (LOG2S >= 5) {
+        dft_reg<LOG2S>(u, F, [&](int step) {
+          constexpr int R1 = S / 8;
+          if (step >= R1) {
+            const int k2 = step - R1;
+#pragma unroll
+            for (int m = 0; m < HS / 8; ++m) finish(((8 - k2) & 7) + 8 * m);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+      } else {
+        dft_reg<LOG2S>(u, F);
+#pragma unroll
+        for (int i = 0; i < HS; ++i) finish(i);
       }
+      if (g == 0) TS(8);
     }
+    };
+    if (seam) chan(std::true_type{}, std::false_type{});
+    else if (any_precise) chan(std::false_type{}, std::true_type{});
+    else chan(std::false_type{}, std::false_type{});
     if (seam) publish = true;                                  // the flag follows once the stores have drained (next window's top)
+    TS(9);
+#ifdef STW_TSTAMP
+    if (a.tstamp && t == 0) {
+      unsigned long long *tp = a.tstamp + ((long long)slot * a.run + (w - w_begin)) * 16;
+      for (int n = 0; n < 10; ++n) tp[n] = ts[n];
+    }
+#endif
     __builtin_amdgcn_wave_barrier();                           // the next window's transposition overwrites the spectrum
   }
   if (publish) {
@@ -366,29 +493,33 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
     if (single) {
       while (__hip_atomic_load(a.flags + nslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
       asm volatile("" ::: "memory");
-      issue(ho + nslot * HO, (unsigned)HO * 8, x, 0);
+      aim(ho + nslot * HO, (unsigned)HO * 8, x, 0);
+      issue_all();
     }
     // the seam block: nxt[g HS + i] = first half of the next run's first window
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      cf o[HS];
 #pragma unroll
       for (int i = 0; i < HS; ++i) {
         constexpr int ws = 64 / S;
-        const float al = kWin64[i * ws], be = kWin64[(i + HS) * ws];
-        o[i] = xfade(al, nxt[g * HS + i], be, prev[g][i]);
+        const cf o = xfade(kWin64[i * ws], nxt[g * HS + i], kWin64[(i + HS) * ws], prev[g][i]);
+        if (any_precise) emit_one(std::true_type{}, g, w_end, i, o);
+        else emit_one(std::false_type{}, g, w_end, i, o);
       }
-      store_block(g, w_end, o);
     }
     if (t == 0) __hip_atomic_store(a.flags + nslot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+#ifdef STW_TSTAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (a.tstamp && t == 0) { unsigned long long *tp = a.tstamp + ((long long)slot * a.run) * 16; tp[10] = t_entry; tp[11] = __builtin_amdgcn_s_memtime(); }
+#endif
 }
 
-template <int LOG2S, bool UNIFORM>
+template <int LOG2S, bool UNIFORM, bool Y32>
 hipError_t launch_stw_u(const sdk::StArgs &a, hipStream_t st)
 {
   constexpr int NG = WAVE >> LOG2S;
-  auto kern = stw_kernel<LOG2S, UNIFORM>;
+  auto kern = stw_kernel<LOG2S, UNIFORM, Y32>;
   const unsigned nruns = (unsigned)((a.nwin + a.run - 1) / a.run);
   const unsigned ny = (unsigned)((a.nchan + NG * WAVE - 1) / (NG * WAVE));
   hipLaunchKernelGGL(kern, dim3(nruns, ny), dim3(WAVE), WV_LDS, st, a);
@@ -398,7 +529,8 @@ hipError_t launch_stw_u(const sdk::StArgs &a, hipStream_t st)
 template <int LOG2S>
 hipError_t launch_stw(const sdk::StArgs &a, hipStream_t st)
 {
-  return a.hk_uniform ? launch_stw_u<LOG2S, true>(a, st) : launch_stw_u<LOG2S, false>(a, st);
+  if (a.y32) return a.hk_uniform ? launch_stw_u<LOG2S, true, true>(a, st) : launch_stw_u<LOG2S, false, true>(a, st);
+  return a.hk_uniform ? launch_stw_u<LOG2S, true, false>(a, st) : launch_stw_u<LOG2S, false, false>(a, st);
 }
 
 }  // namespace
