@@ -348,10 +348,11 @@ def main():
         fir_ms = stages.get("fir")
         psd_ms = stages.get("psd")
         psd_bytes = 8.0 * L + 4.0 * cfg["psd"] * (L // cfg["psd"] // pipe.navg)
-        kname = "st_kernel" if fft_bank else "chan_fir_kernel"
+        kname = "stw_kernel" if fft_bank else "chan_fir_kernel"
         roof = {
-            "kernel": ("st_kernel (FFT channeliser: one 4096-pt forward FFT per half window shared by all channels, per "
-                       "channel bin pick x response, 64-pt inverse FFT, cross-fade)") if fft_bank else
+            "kernel": ("stw_kernel (FFT channeliser, one wavefront per window: 4096-pt forward FFT as two register DFT64 "
+                       "around an LDS transposition, shared by all channels; lane = channel: bin pick x response, 64-pt "
+                       "inverse FFT, cross-fade)") if fft_bank else
                       "chan_fir_kernel (translate + 255-tap polyphase decimating FIR bank)",
             "bound": "hbm", "achieved": round(fir_bytes / (fir_ms * 1e-3) / 1e9, 2) if fir_ms else None,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",

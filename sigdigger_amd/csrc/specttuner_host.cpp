@@ -463,8 +463,11 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
       a.rows = reinterpret_cast<const void *const *>(d_rows);
       hipError_t e;
       if (g.d_hkt) {
-        // one wavefront per window, 4 resident per CU: a single round of 1024 wavefronts when the block allows it (each
-        // re-transforms the window before its run for the first cross-fade partner)
+        // One wavefront per window and SIMD (it takes the whole register file), 1024 slots on the chip.  A launch must
+        // fit ONE round with room to spare: the recurrence kernels of earlier blocks hold a few SIMDs for milliseconds, and
+        // a wavefront that finds no free SIMD waits for a whole run of another -- 1024 wavefronts of 2 windows measured
+        // 32 us on an idle chip and 56 us inside the pipeline.  3/4 of the slots: 683 wavefronts of 3 windows for a
+        // 4 Mi-sample block.
         a.hkt = g.d_hkt;
         a.hk_uniform = g.hk_uniform ? 1 : 0;
         {
@@ -476,7 +479,7 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
         if (st->run_wave) a.run = (int)st->run_wave;
         else {
           const long long ny = ((long long)g.members.size() + sdk::stw_channels_per_wave(g.log2s) - 1) / sdk::stw_channels_per_wave(g.log2s);
-          a.run = (int)std::max<long long>(1, (nwin * ny + 1023) / 1024);
+          a.run = (int)std::max<long long>(1, (nwin * ny + 767) / 768);
         }
         {
           const long long ny = ((long long)g.members.size() + sdk::stw_channels_per_wave(g.log2s) - 1) / sdk::stw_channels_per_wave(g.log2s);

@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, ".")
 from sigdigger_amd import engine, synth
 
-L = 1 << 22
+L = 1 << int(__import__('os').environ.get('ST_LOG2L', 22))
 ctx = engine.Context(0)
 x = torch.empty(L, dtype=torch.complex64, device="cuda")
 torch.view_as_real(x).normal_()
