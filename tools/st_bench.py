@@ -10,7 +10,7 @@ ctx = engine.Context(0)
 x = torch.empty(L, dtype=torch.complex64, device="cuda")
 torch.view_as_real(x).normal_()
 import os
-CASES = [(64, 64, int(os.environ.get('ST_RUN', 0)))] if os.environ.get('ST_ONE') else [(64, 64, 0), (64, 64, 2), (64, 64, 3), (64, 64, 4), (64, 32, 0), (128, 128, 0), (512, 512, 0), (16, 64, 0)] if os.environ.get('ST_WAVE') else [(64, 64, 8), (64, 64, 4), (64, 64, 3), (64, 64, 2), (64, 64, 1)] if os.environ.get('ST_QUICK') else [(64, 64, 8), (64, 64, 4), (64, 64, 2), (1, 64, 4), (512, 64, 4), (64, 16, 4), (1, 1, 4)]
+CASES = [(64, 64, int(os.environ.get('ST_RUN', 0)))] if os.environ.get('ST_ONE') else [(64, 64, 0), (64, 64, 2), (64, 64, 3), (64, 64, 4), (64, 32, 0), (128, 128, 0), (512, 512, 0), (16, 64, 0)] if os.environ.get('ST_WAVE') else [(64, 64, 8), (64, 64, 4), (64, 64, 3), (64, 64, 2), (64, 64, 1)] if os.environ.get('ST_QUICK') else [(64, 64, 0), (64, 64, 2), (64, 64, 3), (64, 64, 4), (16, 64, 0), (128, 128, 0), (512, 512, 0), (64, 32, 0), (64, 16, 0), (1, 1, 0)]
 for C, D, run in CASES:
     st = engine.SpectTuner(ctx, 4096)
     if run:
