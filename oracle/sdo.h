@@ -5,11 +5,14 @@
  * used ONLY as the checker by tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg.  Nothing under sigdigger_amd/ may include, link or call it.
  *
- * PARITY STATUS: "parity unpinned" versus upstream sigutils/suscan.  The reference
- * tree (/root/reference = SigDigger GUI) contains no golden vectors and the DSP
- * libraries (sigutils, suscan, FFTW3f; unpinned master, Scripts/dist-common.sh:331-333)
- * are absent.  Functions marked [REF-PINNED] restate
- * arithmetic that IS present in /root/reference, line by line; functions marked
+ * PARITY STATUS: two classes.  (1) [REF-PINNED] functions restate arithmetic that IS present in
+ * /root/reference, line by line, and since round 2 are checked against the reference's OWN compiled
+ * code: oracle/Makefile.ref builds the cited translation units from where they lie (g++ -O2 + moc,
+ * outputs only into oracle/_ref/) and tests/test_ref_pin.py compares this file with them on seeded
+ * inputs.  (2) "parity unpinned" versus upstream sigutils/suscan for the rest: the reference tree
+ * (the SigDigger GUI) contains no golden vectors and the DSP libraries (sigutils, suscan, FFTW3f;
+ * unpinned master, Scripts/dist-common.sh:331-333) are absent;
+ * functions marked
  * [SPEC] follow the semantics frozen in SPEC.md (seeded from SURVEY.md Appendix C)
  * and are validated from first principles in tests/ (numpy.fft, scipy.signal,
  * libm, lock/convergence tests).

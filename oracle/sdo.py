@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg.  Nothing under sigdigger_amd/ imports this module.
-"parity unpinned" vs upstream sigutils/suscan (see oracle/sdo.h).
+Parity: reference-pinned (oracle/_ref, tests/test_ref_pin.py) for the rows the reference owns, "parity unpinned" vs upstream
+sigutils/suscan for the rest (see oracle/sdo.h).
 """
 import ctypes as C
 import os
