@@ -34,13 +34,21 @@ __device__ __forceinline__ cf sub_mj(cf t, cf d)          // t - (-j) d = (t.x -
   asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(t), "v"(d));
   return r;
 }
+// (Between two consecutive inline-asm statements the compiler inserts an s_nop -- it cannot see inside them -- and for a
+// lone wavefront an s_nop is a full issue slot: instructions that belong together are ONE statement.)
 __device__ __forceinline__ cf cmul(cf a, cf b)
 {
   // (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
-  cf t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  cf r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=&v"(r) : "v"(a), "v"(b));
   return r;
+}
+// p = t + (-j) d, m = t - (-j) d
+__device__ __forceinline__ void addsub_mj(cf t, cf d, cf &p, cf &m)
+{
+  asm("v_pk_add_f32 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=&v"(p), "=&v"(m) : "v"(t), "v"(d));
 }
 
 // forward DFTs on registers, natural order in, natural order out (DIT, even/odd split)
@@ -49,7 +57,7 @@ __device__ __forceinline__ void dft2(cf &a, cf &b) { cf t = a; a = cadd(t, b); b
 __device__ __forceinline__ void dft4(cf &a0, cf &a1, cf &a2, cf &a3)
 {
   cf t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), d = csub(a1, a3);
-  a0 = cadd(t0, t2); a1 = add_mj(t1, d); a2 = csub(t0, t2); a3 = sub_mj(t1, d);
+  a0 = cadd(t0, t2); a2 = csub(t0, t2); addsub_mj(t1, d, a1, a3);
 }
 
 __device__ __forceinline__ cf mul_w8_1(cf a) { return add_mj(a, a) * 0.70710678118654752440f; }            // * (1 - j)/sqrt2
@@ -76,7 +84,7 @@ __device__ __forceinline__ void dft8(cf *v)
   dft4(o0, o1, o2, o3);
   v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
   bfly_w8_1(e1, o1, v[1], v[5]);
-  v[2] = add_mj(e2, o2); v[6] = sub_mj(e2, o2);          // o2 * (-j) folded into the butterfly
+  addsub_mj(e2, o2, v[2], v[6]);                         // o2 * (-j) folded into the butterfly
   bfly_w8_3(e3, o3, v[3], v[7]);
 }
 
@@ -94,7 +102,7 @@ __device__ __forceinline__ void dft16(cf *v)
   o[7] = cmul(o[7], cf{-c1, -s1});
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    if (i == 4) { v[4] = add_mj(e[4], o[4]); v[12] = sub_mj(e[4], o[4]); }
+    if (i == 4) addsub_mj(e[4], o[4], v[4], v[12]);
     else if (i == 2) bfly_w8_1(e[2], o[2], v[2], v[10]);
     else if (i == 6) bfly_w8_3(e[6], o[6], v[6], v[14]);
     else { v[i] = cadd(e[i], o[i]); v[i + 8] = csub(e[i], o[i]); }

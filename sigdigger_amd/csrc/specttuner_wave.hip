@@ -58,9 +58,9 @@ __device__ constexpr float kWin64[64] = {
 // a * b with b wave-uniform (a compile-time constant): the constant travels in an SGPR pair, not in VGPRs
 __device__ __forceinline__ cf cmul_u(cf a, cf b)
 {
-  cf t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(b));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "s"(b), "v"(t));
+  cf r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=&v"(r) : "v"(a), "s"(b));
   return r;
 }
 
@@ -81,6 +81,30 @@ __device__ __forceinline__ cf cmul3(cf a, cf b, cf c)
       "v_pk_mul_f32 %0, %2, %1 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
       "v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=&v"(r), "=&v"(w) : "v"(a), "v"(b), "v"(c));
   return r;
+}
+
+// two independent a * (b * c) in one statement
+__device__ __forceinline__ void cmul3x2(cf a0, cf b0, cf c0, cf a1, cf b1, cf c1, cf &r0, cf &r1)
+{
+  cf w0, w1;
+  asm("v_pk_mul_f32 %2, %6, %7 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %3, %8, %9 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %2, %6, %7, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+      "v_pk_fma_f32 %3, %8, %9, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+      "v_pk_mul_f32 %0, %4, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %1, %5, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %4, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+      "v_pk_fma_f32 %1, %5, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "=&v"(r0), "=&v"(r1), "=&v"(w0), "=&v"(w1) : "v"(a0), "v"(a1), "v"(b0), "v"(c0), "v"(b1), "v"(c1));
+}
+// two independent a * b in one statement
+__device__ __forceinline__ void cmul1x2(cf a0, cf b0, cf a1, cf b1, cf &r0, cf &r1)
+{
+  asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %1, %4, %5 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+      "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
 }
 
 // al cur + be prv with ONE rounding pattern wherever it is written (the seam block must equal the in-run block bit for bit)
@@ -330,15 +354,22 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
       hi[1] = opaque(wb[3]); hi[2] = opaque(wb[4]); hi[4] = opaque(wb[5]);
       hi[3] = cmul(hi[1], hi[2]); hi[5] = cmul(hi[1], hi[4]); hi[6] = cmul(hi[2], hi[4]); hi[7] = cmul(hi[3], hi[4]);
 #pragma unroll
-      for (int k2 = 1; k2 < WAVE; ++k2) {
-        const int l = k2 & 7, h = k2 >> 3;
-        A[k2] = (h == 0 || l == 0) ? cmul1(A[k2], h == 0 ? lo[l] : hi[h]) : cmul3(A[k2], hi[h], lo[l]);
-        if constexpr (UNIFORM) {
-          if (l == 7) {
+      for (int h = 0; h < 8; ++h) {
+        // W^(t (8h + l)) = hi[h] lo[l]; two elements per asm statement
+        if (h == 0) {
+          A[1] = cmul1(A[1], lo[1]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) load_one(4 * h + r);
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          for (int l = 2; l < 8; l += 2) cmul1x2(A[l], lo[l], A[l + 1], lo[l + 1], A[l], A[l + 1]);
+        } else {
+          A[8 * h] = cmul1(A[8 * h], hi[h]);
+          A[8 * h + 1] = cmul3(A[8 * h + 1], hi[h], lo[1]);
+#pragma unroll
+          for (int l = 2; l < 8; l += 2) cmul3x2(A[8 * h + l], hi[h], lo[l], A[8 * h + l + 1], hi[h], lo[l + 1], A[8 * h + l], A[8 * h + l + 1]);
+        }
+        if constexpr (UNIFORM) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) load_one(4 * h + r);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -415,8 +446,7 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
 #pragma unroll
           for (int j = 0; j < CH; ++j) {
             const float4 X = X2[c * CH + j], Hh = Hq[c & 1][j];
-            u[2 * (c * CH + j)] = cmul1(cf{X.x, X.y}, cf{Hh.x, Hh.y});
-            u[2 * (c * CH + j) + 1] = cmul1(cf{X.z, X.w}, cf{Hh.z, Hh.w});
+            cmul1x2(cf{X.x, X.y}, cf{Hh.x, Hh.y}, cf{X.z, X.w}, cf{Hh.z, Hh.w}, u[2 * (c * CH + j)], u[2 * (c * CH + j) + 1]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
