@@ -71,6 +71,7 @@ struct StChan {                 // one channel of a size group
 struct StArgs {
   const void *x;                // len samples (device); the virtual stream is hist ++ x when have_hist
   const void *hist;             // the W/2 samples before x[0]
+  void *hist_out;               // wavefront kernel, optional: receives the last W/2 samples of x (the next feed's history)
   int have_hist;
   long long nwin;               // windows in this feed: window w = virtual samples [w W/2, w W/2 + W)
   int run;                      // windows per workgroup

@@ -440,6 +440,7 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
   if (counts) for (size_t i = 0; i < st->ch.size(); ++i) counts[i] = 0;
   if (len == 0) return SU_TRUE;
   const long long nwin = (long long)(len / st->H) - (st->have_hist ? 0 : 1);
+  bool hist_written = false;
   if (nwin > 0) {
     for (auto &kv : st->groups) {
       SizeGroup &g = kv.second;
@@ -463,6 +464,7 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
       a.rows = reinterpret_cast<const void *const *>(d_rows);
       hipError_t e;
       if (g.d_hkt) {
+        if (!hist_written) { a.hist_out = st->d_hist[st->hist_cur ^ 1]; hist_written = true; }   // the kernel carries the history over
         // One wavefront per window and SIMD (it takes the whole register file), 1024 slots on the chip.  A launch must
         // fit ONE round with room to spare: the recurrence kernels of earlier blocks hold a few SIMDs for milliseconds, and
         // a wavefront that finds no free SIMD waits for a whole run of another -- 1024 wavefronts of 2 windows measured
@@ -545,7 +547,8 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
     st->closed_pending.clear();                               // every group's table has been rebuilt
   }
   // the last half window is the next feed's history
-  if (hipMemcpyAsync(st->d_hist[st->hist_cur ^ 1], reinterpret_cast<const c32 *>(d_x) + (len - st->H), st->H * sizeof(c32),
+  if (!hist_written &&
+      hipMemcpyAsync(st->d_hist[st->hist_cur ^ 1], reinterpret_cast<const c32 *>(d_x) + (len - st->H), st->H * sizeof(c32),
                      hipMemcpyDeviceToDevice, s) != hipSuccess) { suamd_set_error("history copy failed"); return SU_FALSE; }
   st->hist_cur ^= 1;
   st->have_hist = true;

@@ -333,6 +333,13 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
       if (t == 0) __hip_atomic_store(a.flags + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       publish = false;
     }
+    if (final_run && w + 1 == w_end && a.hist_out != nullptr && blockIdx.y == 0) {
+      // the stream's last half window is the next feed's history: this wavefront holds it (no separate copy launch)
+      const __amdgpu_buffer_rsrc_t rhs = __builtin_amdgcn_make_buffer_rsrc(a.hist_out, 0, H * 8, 0x00020000);
+#pragma unroll
+      for (int r = 0; r < WAVE / 2; ++r)
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, nxt[WAVE / 2 + r]), rhs, t * 8, r * WAVE * 8, 0);
+    }
     // ---- forward transform ----
     dft_reg<6>(nxt, A);
     TS(1);
