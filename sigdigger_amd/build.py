@@ -36,7 +36,7 @@ SOURCES = {
     "analyzer.cpp": ["-ffp-contract=off"],
     "export.cpp": ["-ffp-contract=off"],
 }
-HEADERS = ["kernels.hpp", "sd_math.hpp", "fft_core.hpp", os.path.join("..", "..", "include", "sigdigger_amd.h"),
+HEADERS = ["kernels.hpp", "sd_math.hpp", "fft_core.hpp", "fft_reg.hpp", os.path.join("..", "..", "include", "sigdigger_amd.h"),
            os.path.join("..", "..", "include", "suscan_amd.h")]
 
 
