@@ -57,12 +57,17 @@ __device__ __forceinline__ v2f_ phasor_pk(uint32_t p)
   q = q * zz;                                                   // (sp * z, cp * z)
   const v2f_ sc = __builtin_elementwise_fma(q, v2f_{x, z}, v2f_{x, fma_(z, -0.5f, 1.0f)});   // (sn, cs)
   const uint32_t t = p + 0x20000000u;                           // bits 31:30 = quadrant
-  const bool odd = (int32_t)(t << 1) < 0;
-  const uint32_t ia = __float_as_uint(odd ? sc.x : sc.y);       // q odd ? sn : cs
-  const uint32_t ib = __float_as_uint(odd ? sc.y : sc.x);       // q odd ? cs : sn
+  // swap (sn, cs) for odd quadrants with three-input bit operations (v_bitop3): a compare + two selects costs a lone
+  // wavefront a VCC write -> read stall (s_nop 1) on top of its three instructions
+  const uint32_t t1 = t << 1;
+  const uint32_t m = (uint32_t)((int32_t)t1 >> 31);             // all ones when the quadrant is odd
+  const uint32_t isn = __float_as_uint(sc.x), ics = __float_as_uint(sc.y);
+  // bitop3 truth tables with a = 0xF0, b = 0xCC, c = 0xAA:  a ^ ((a ^ b) & c) = 0xD8,  a ^ (b & c) = 0x78
+  const uint32_t ia = __builtin_amdgcn_bitop3_b32(ics, isn, m, 0xD8);   // q odd ? sn : cs
+  const uint32_t ib = __builtin_amdgcn_bitop3_b32(isn, ics, m, 0xD8);   // q odd ? cs : sn
   v2f_ cs;
-  cs.x = __uint_as_float(ia ^ ((t ^ (t << 1)) & 0x80000000u));  // negate for q = 1, 2
-  cs.y = __uint_as_float(ib ^ (t & 0x80000000u));               // negate for q = 2, 3
+  cs.x = __uint_as_float(__builtin_amdgcn_bitop3_b32(ia, t ^ t1, 0x80000000u, 0x78));   // negate for q = 1, 2
+  cs.y = __uint_as_float(__builtin_amdgcn_bitop3_b32(ib, t, 0x80000000u, 0x78));        // negate for q = 2, 3
   return cs;
 }
 
