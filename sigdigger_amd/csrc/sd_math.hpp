@@ -51,11 +51,22 @@ __device__ __forceinline__ v2f_ phasor_pk(uint32_t p)
   const int32_t r = (int32_t)(p << 2) >> 2;
   const float x = (float)r * 1.46291807926715968e-9f;
   const float z = x * x;
-  const v2f_ zz = {z, z};
-  v2f_ q = __builtin_elementwise_fma(zz, v2f_{-1.9515295891e-4f, 2.443315711809948e-5f}, v2f_{8.3321608736e-3f, -1.388731625493765e-3f});
-  q = __builtin_elementwise_fma(q, zz, v2f_{-1.6666654611e-1f, 4.166664568298827e-2f});
-  q = q * zz;                                                   // (sp * z, cp * z)
-  const v2f_ sc = __builtin_elementwise_fma(q, v2f_{x, z}, v2f_{x, fma_(z, -0.5f, 1.0f)});   // (sn, cs)
+  // everything hangs off the one pair P = (x, z): (z, z) is P's high half broadcast (an operand modifier), and
+  // (x, fma(z, -0.5, 1)) is fma(P, (1, -0.5), (0, 1)) -- x * 1 + 0 is x exactly (x is never -0: it comes from an
+  // integer) -- so no register is copied to build a packed operand
+  const v2f_ P = {x, z};
+  // the five packed operations as ONE asm statement: the compiler puts an s_nop behind every v_pk whose result the next
+  // instruction reads, and a lone wavefront pays a full issue slot for it (the hardware interlocks by itself:
+  // tools/ubench/issue.hip measures the same rate for dependent and independent chains)
+  v2f_ q, xc, sc;
+  asm("v_pk_fma_f32 %0, %3, %4, %5 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"        // q  = (z,z) K1 + K2
+      "v_pk_fma_f32 %1, %3, %8, %9\n\t"                                          // xc = P (1,-0.5) + (0,1)
+      "v_pk_fma_f32 %0, %0, %3, %6 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"        // q  = q (z,z) + K3
+      "v_pk_mul_f32 %0, %0, %3 op_sel:[0,1] op_sel_hi:[1,1]\n\t"                // q  = q (z,z)
+      "v_pk_fma_f32 %2, %0, %3, %1"                                               // sc = q P + xc
+      : "=&v"(q), "=&v"(xc), "=&v"(sc)
+      : "v"(P), "s"(v2f_{-1.9515295891e-4f, 2.443315711809948e-5f}), "v"(v2f_{8.3321608736e-3f, -1.388731625493765e-3f}),
+        "s"(v2f_{-1.6666654611e-1f, 4.166664568298827e-2f}), "v"(0), "s"(v2f_{1.0f, -0.5f}), "v"(v2f_{0.0f, 1.0f}));
   const uint32_t t = p + 0x20000000u;                           // bits 31:30 = quadrant
   // swap (sn, cs) for odd quadrants with three-input bit operations (v_bitop3): a compare + two selects costs a lone
   // wavefront a VCC write -> read stall (s_nop 1) on top of its three instructions
