@@ -81,7 +81,9 @@ struct StArgs {
   unsigned long long *tstamp;   // STW_TSTAMP builds only: [run][window of the run][16] s_memtime stamps
   int y32;                      // wavefront kernel: every byte offset (row * cs + time * ms) * 8 of this feed's outputs is below 2^31
   int hk_uniform;               // every channel of the launch has hsel == chans[0].hsel (wavefront kernel: response kept in LDS)
-  void *handoff; unsigned *flags;   // wavefront kernel: [runs * blocks][16 KiB] seam payload, one flag per run (all zero between launches)
+  int seam_polls;               // wavefront kernel: polls (~0.25 us each) a run waits for its successor's payload before it transforms the seam window itself
+  unsigned epoch;               // wavefront kernel: the flag value of this launch (a host counter per size group, never 0)
+  void *handoff; unsigned *flags;   // wavefront kernel: [runs * blocks][16 KiB] seam payload, one flag per run (holds the epoch of the launch that published it)
   const void *hkt;              // the same per channel, transposed for the wavefront kernel: [ceil(nchan/64)][size][64]
   const float *win;             // [size]: sin^2(pi i / size)
   const void *prev_in; void *prev_out;   // [nchan][size/2]: second half of the last block of the previous feed (ping-pong)

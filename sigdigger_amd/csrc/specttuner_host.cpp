@@ -137,8 +137,9 @@ struct SizeGroup {
   c32 *d_hk = nullptr, *d_tw = nullptr;
   c32 *d_hkt = nullptr;                // per-channel responses, [block of 64 channels][bin][lane] (wavefront kernel)
   c32 *d_handoff = nullptr;            // wavefront kernel: seam payload between consecutive runs, 16 KiB per run and block
-  unsigned *d_flags = nullptr;         // one flag per run and block; zero between launches
+  unsigned *d_flags = nullptr;         // one flag per run and block: the epoch of the launch that published it
   size_t ho_slots = 0;
+  unsigned epoch = 0;                  // flag value of the next launch
   bool hk_uniform = false;             // one response for all members
   float *d_win = nullptr;
   c32 *d_prev[2] = {nullptr, nullptr};
@@ -164,6 +165,7 @@ struct suamd_specttuner {
   int log2w = 12;
   unsigned run = 3;                    // windows per workgroup: 683 workgroups per 4 Mi-sample block, a third re-transformed
   unsigned run_wave = 0;               // wavefront kernel: windows per wavefront (0: one round of 4 wavefronts per CU)
+  int seam_polls = 256;                // wavefront kernel: bounded wait for a run's successor (SUAMD_ST_SEAM_POLLS; 0: never wait)
   bool use_wave = true;                // sizes 8..64 go to specttuner_wave.hip (SUAMD_ST_KERNEL=wg keeps them on specttuner.hip)
   c32 *d_tw_w = nullptr;
   c32 *d_hist[2] = {nullptr, nullptr};
@@ -351,6 +353,7 @@ suamd_specttuner_t *suamd_specttuner_new(suamd_ctx_t *ctx, unsigned window_size)
   st->ctx = ctx; st->W = window_size; st->H = window_size / 2; st->log2w = 12;
   if (const char *e = std::getenv("SUAMD_ST_RUN")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) st->run = st->run_wave = (unsigned)v; }   // tuning knob
   if (const char *e = std::getenv("SUAMD_ST_KERNEL")) st->use_wave = std::strcmp(e, "wg") != 0;
+  if (const char *e = std::getenv("SUAMD_ST_SEAM_POLLS")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 20)) st->seam_polls = v; }
   st->d_tw_w = dev_upload_new(twiddles(st->W));
   bool ok = st->d_tw_w != nullptr;
   for (int p = 0; p < 2 && ok; ++p) ok = hipMalloc((void **)&st->d_hist[p], st->H * sizeof(c32)) == hipSuccess;
@@ -497,6 +500,9 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
             g.ho_slots = slots;
           }
           a.handoff = g.d_handoff; a.flags = g.d_flags;
+          if (++g.epoch == 0) g.epoch = 1;
+          a.epoch = g.epoch;
+          a.seam_polls = st->seam_polls;
         }
 #ifdef STW_TSTAMP
         static unsigned long long *d_ts = nullptr;

@@ -58,10 +58,12 @@ constexpr int WV_LDS = (WV_HK + 64) * 8;
 // publishes the (unweighted) first half of its first window as soon as it has it -- its very first step -- and run b
 // picks it up after its own last window, long after.  Payload and flag are sc1 (agent-scope) accesses on both sides
 // (they bypass the non-coherent L1 / per-XCD L2), the flag goes out after the producer's s_waitcnt vmcnt(0)
-// (MI355X_MICROARCH.md, inter-workgroup visibility: "sc1 payload -> asm vmcnt(0) -> sc1 flag").  The consumer clears
-// the flag: every launch leaves the flag array zeroed.  A run only ever waits for the NEXT workgroup in dispatch order,
-// and only for that workgroup's first step: when workgroups queue for a slot the wait ends as soon as any resident
-// one retires.
+// (MI355X_MICROARCH.md, inter-workgroup visibility: "sc1 payload -> asm vmcnt(0) -> sc1 flag").  The flag's value
+// is the launch's epoch (a host counter), so nothing is ever cleared.  A run only waits for the NEXT workgroup in
+// dispatch order, only for that workgroup's first step, and only for a bounded time: if the payload has not appeared
+// after ~60 us (that workgroup has not started -- every other slot of the device is held by something else), the run
+// transforms the seam window itself (one more iteration of its loop) and ignores the payload when it comes.  No launch
+// can hang on residency.
 #ifdef STW_TSTAMP
 #define TS(n) do { __builtin_amdgcn_sched_barrier(0); ts[n] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -111,11 +113,25 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
   };
   auto aim_window = [&](long long w) { aim((w == 0 && a.have_hist) ? hist : x + (w * H - off), H * 8, x + (w * H + H - off), H * 8); };
   const bool final_run = w_end == a.nwin;
-  const bool single = w_end - w_begin == 1;                    // degenerate run: publish and pick-up both after the loop
+  const bool single = w_end - w_begin == 1;                    // degenerate run: publish and pick-up both at the end of its only window
   const long long nslot = slot + gridDim.y;
+  const unsigned epoch = a.epoch;                              // flag value of THIS launch
+  long long w_stop = w_end;                                    // w_end + 1 when this run ends up transforming the seam window itself
+  bool self_seam = false;
+  // Has the next run published its seam payload?  Bounded wait: if that workgroup has not even started (every other
+  // slot of the chip held by something else), this run transforms the seam window itself instead of waiting -- no
+  // launch can hang on residency, whatever else occupies the device.  a.seam_polls (256) polls x ~0.25 us.
+  auto seam_ready = [&]() -> bool {
+    for (int n = 0; n < a.seam_polls; ++n) {
+      const unsigned f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.flags + nslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (f == epoch) return true;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    return false;
+  };
   // what follows window w in the load registers (branch-free: the loads themselves are spread over the window's arithmetic)
   auto aim_next = [&](long long w) {
-    const bool more = w + 1 < w_end, pay = !more && !final_run && !single;
+    const bool more = w + 1 < w_stop, pay = !more && !final_run && !single && !self_seam;
     const long long wn = more ? w + 1 : w;
     const cf *pa = pay ? ho + nslot * HO : ((wn == 0 && a.have_hist) ? hist : x + (wn * H - off));
     aim(pa, more ? H * 8 : (pay ? (unsigned)HO * 8 : 0u), x + (wn * H + H - off), more ? H * 8 : 0u);
@@ -192,7 +208,7 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
     if (t < S) buf[WV_HK + t] = reinterpret_cast<const cf *>(a.hk)[t];    // a uniform launch has one response: selector 0
   }
   bool publish = false;
-  for (long long w = w_begin; w < w_end; ++w) {
+  for (long long w = w_begin; w < w_stop; ++w) {
     cf v[WAVE], A[WAVE];
 #ifdef STW_TSTAMP
     unsigned long long ts[16] = {0};
@@ -201,7 +217,7 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
     if (publish) {
       // the wait for this window's samples (needed here anyway) also drains the seam stores issued before them
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (t == 0) __hip_atomic_store(a.flags + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == 0) __hip_atomic_store(a.flags + slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       publish = false;
     }
     if (final_run && w + 1 == w_end && a.hist_out != nullptr && blockIdx.y == 0) {
@@ -217,7 +233,7 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
     if (w + 1 == w_end && !final_run && !single) {
       // the seam block's first half, published by the next run at its first step (its second window's top);
       // this run's own flag went out above, BEFORE this wait: no chain of runs waiting for each other
-      while (__hip_atomic_load(a.flags + nslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+      if (!seam_ready()) { self_seam = true; w_stop = w_end + 1; }
       asm volatile("" ::: "memory");
     }
     // nxt is dead after the first DFT: the next request goes into the same registers (no copies, no second set).  Its
@@ -374,6 +390,18 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
     else if (any_precise) chan(std::false_type{}, std::true_type{});
     else chan(std::false_type{}, std::false_type{});
     if (seam) publish = true;                                  // the flag follows once the stores have drained (next window's top)
+    if (single && !final_run && w + 1 == w_end) {
+      // a run of one window: its own flag first (nobody may wait for a run that is itself waiting), then the pick-up
+      if (publish) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t == 0) __hip_atomic_store(a.flags + slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        publish = false;
+      }
+      if (seam_ready()) aim(ho + nslot * HO, (unsigned)HO * 8, x, 0);
+      else { self_seam = true; w_stop = w_end + 1; aim_window(w_end); }
+      asm volatile("" ::: "memory");
+      issue_all();
+    }
     TS(9);
 #ifdef STW_TSTAMP
     if (a.tstamp && t == 0) {
@@ -385,7 +413,7 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
   }
   if (publish) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (t == 0) __hip_atomic_store(a.flags + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) __hip_atomic_store(a.flags + slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (final_run) {
     // carry the last window's second half to the next feed
@@ -397,13 +425,7 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
         for (int i = 0; i < HS; ++i) reinterpret_cast<cf *>(a.prev_out)[(long long)k * HS + i] = prev[g][i];
       }
     }
-  } else {
-    if (single) {
-      while (__hip_atomic_load(a.flags + nslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
-      asm volatile("" ::: "memory");
-      aim(ho + nslot * HO, (unsigned)HO * 8, x, 0);
-      issue_all();
-    }
+  } else if (!self_seam) {
     // the seam block: nxt[g HS + i] = first half of the next run's first window
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -415,7 +437,6 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
         else emit_one(std::false_type{}, g, w_end, i, o);
       }
     }
-    if (t == 0) __hip_atomic_store(a.flags + nslot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #ifdef STW_TSTAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

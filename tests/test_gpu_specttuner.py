@@ -89,6 +89,21 @@ def test_any_split_of_the_stream_gives_the_same_samples(ctx):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (splits, run)
 
 
+def test_a_run_that_cannot_get_its_seam_payload_transforms_the_seam_window_itself(ctx, monkeypatch):
+    """The wavefront kernel hands the block at the seam of two runs over through global memory; a run whose successor has
+    not published in time (not resident: the device full of something else) computes that block itself.  Forced here with
+    a zero wait budget: every run takes the fallback, and the samples are those of the normal path bit for bit."""
+    x = cnoise(H * 40, 21)
+    chans = [(0.3 + 0.09 * c, 2 * np.pi / 64 * 0.7, 1.0, bool(c % 3 == 0)) for c in range(70)]       # two blocks of 64 lanes
+    chans += [(1.1, 2 * np.pi / 16 * 0.8, 1.0, False)]
+    ref = run_gpu(ctx, x, chans, splits=[H * 13], run=3)
+    monkeypatch.setenv("SUAMD_ST_SEAM_POLLS", "0")
+    for run in (1, 3):
+        got = run_gpu(ctx, x, chans, splits=[H * 13], run=run)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), run
+
+
 def test_precise_channel_corrects_the_bin_rounding(ctx, sdo):
     f0 = 2 * np.pi * 411 / W                      # an odd bin: as far from the even centre bins as it gets
     n = H * 60
