@@ -40,7 +40,7 @@ def test_single_gpu_line():
     roof = d["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
-    assert d["config"]["channeliser"] == "fft" and roof["kernel"].startswith("stw_kernel") and roof["frac"] > 0.15
+    assert d["config"]["channeliser"] == "fft" and roof["kernel"].startswith("stw_kernel") and roof["frac"] > 0.08
     assert abs(d["value"] - d["config"]["block_samples"] * 4 / (d["ms_per_step"] * 4e-3) / 1e6) < 0.01 * d["value"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
