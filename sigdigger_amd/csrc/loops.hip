@@ -18,7 +18,7 @@
 namespace {
 
 using sd::c32;
-constexpr int CHUNK = 16;    // time steps prefetched per lane (one chunk ahead of the arithmetic)
+constexpr int CHUNK = 32;    // time steps prefetched per lane (one chunk ahead of the arithmetic)
 
 // Element (c, m) of a view = base[c*cs + m*ms]: the m*ms part is wave-uniform (scalar base
 // address), the c*cs part is a 32-bit per-lane byte offset -> "saddr + voffset" addressing, no
