@@ -109,20 +109,54 @@ __device__ __forceinline__ void dft16(cf *v)
   }
 }
 
+// 32 points: two 16-point transforms of the even/odd inputs, odd half times W32^k, one butterfly
+__device__ __forceinline__ void dft32(cf *v)
+{
+  cf e[16], o[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+  dft16(e);
+  dft16(o);
+  // W32^k = (cos, -sin)(2 pi k / 32), k = 1..15 (k = 4, 8, 12 fold into the butterfly)
+  constexpr float C[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                           0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
+                           0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508977173f,
+                           -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f,
+                           -0.92387953251128675613f, -0.98078528040323044913f};
+  constexpr float S[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                           0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f,
+                           0.98078528040323044913f, 1.0f, 0.98078528040323044913f, 0.92387953251128675613f,
+                           0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f,
+                           0.38268343236508977173f, 0.19509032201612826785f};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (i == 0) { v[0] = cadd(e[0], o[0]); v[16] = csub(e[0], o[0]); }
+    else if (i == 8) addsub_mj(e[8], o[8], v[8], v[24]);
+    else if (i == 4) bfly_w8_1(e[4], o[4], v[4], v[20]);
+    else if (i == 12) bfly_w8_3(e[12], o[12], v[12], v[28]);
+    else { const cf t = cmul(o[i], cf{C[i], -S[i]}); v[i] = cadd(e[i], t); v[i + 16] = csub(e[i], t); }
+  }
+}
+
 template <int R> __device__ __forceinline__ void dftR(cf *v);
 template <> __device__ __forceinline__ void dftR<2>(cf *v)  { dft2(v[0], v[1]); }
 template <> __device__ __forceinline__ void dftR<4>(cf *v)  { dft4(v[0], v[1], v[2], v[3]); }
 template <> __device__ __forceinline__ void dftR<8>(cf *v)  { dft8(v); }
 template <> __device__ __forceinline__ void dftR<16>(cf *v) { dft16(v); }
+template <> __device__ __forceinline__ void dftR<32>(cf *v) { dft32(v); }
 
 __device__ __forceinline__ int lpad(int i) { return i + (i >> 4); }
 
-// compile-time pass plan: ceil(bits/4) passes, the first (bits % P) passes one bit wider
-template <int LOG2N> struct Plan {
-  static constexpr int P     = (LOG2N + 3) / 4;
+// compile-time pass plan: ceil(bits/MB) passes, the first (bits % P) passes one bit wider
+// (MB = 4: radix <= 16, sixteen points per thread; MB = 5: radix <= 32, thirty-two points per thread)
+// MB = 5 puts the wider passes LAST and gives a thread ADJACENT butterflies in pass 0 (j = NB tid + b instead of
+// tid + b THREADS): its pass-0 operands are then pairs of neighbouring samples, one 16-byte request each (see psd.hip)
+template <int LOG2N, int MB = 4> struct Plan {
+  static constexpr int P     = (LOG2N + MB - 1) / MB;
   static constexpr int BASE  = LOG2N / P;
   static constexpr int EXTRA = LOG2N % P;
-  static constexpr int bits(int p) { return BASE + (p < EXTRA ? 1 : 0); }
+  static constexpr bool PAIR0 = (MB == 5);
+  static constexpr int bits(int p) { return BASE + ((PAIR0 ? p >= P - EXTRA : p < EXTRA) ? 1 : 0); }
   static constexpr int ns_log2(int p) { int s = 0; for (int i = 0; i < p; ++i) s += bits(i); return s; }
 };
 
@@ -152,12 +186,13 @@ __device__ __forceinline__ void apply_twiddles(cf *v, const cf *__restrict__ tw,
 // (W^(4k), W^(8k) are squared from W^(2k) per frame: two instructions each, and 12 VGPRs fewer
 // than keeping them -- the kernel sits exactly at the 128-VGPR budget of two workgroups per CU)
 constexpr int MAXP = 4, MAXNB = 2;
+template <int LOG2N, int THREADS> using PlanFor = Plan<LOG2N, (((1 << LOG2N) / THREADS >= 32) ? 5 : 4)>;
 struct TwBase { cf w[MAXP][MAXNB][2]; };
 
 template <int LOG2N, int THREADS, int PASS>
 __device__ __forceinline__ void load_tw_base(TwBase &tb, const cf *__restrict__ tw, int tid)
 {
-  using PL = Plan<LOG2N>;
+  using PL = PlanFor<LOG2N, THREADS>;
   constexpr int N = 1 << LOG2N, E = N / THREADS;
   if constexpr (PASS < PL::P) {
     constexpr int RB = PL::bits(PASS), R = 1 << RB, NB = E / R, NSL = PL::ns_log2(PASS), NS = 1 << NSL;
@@ -182,8 +217,12 @@ __device__ __forceinline__ cf opaque(cf a)
   return a;
 }
 
-template <int R>
-__device__ __forceinline__ void apply_twiddles_base(cf *v, const cf *base)
+// a place to slip other work (memory requests) between the steps of a transform
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+// hook(q) is called once per operand q = 0..R-1, spread over the twiddle products
+template <int R, class Hook = NoHook>
+__device__ __forceinline__ void apply_twiddles_base(cf *v, const cf *base, Hook hook = Hook())
 {
   cf w[R];
   w[1] = opaque(base[0]);
@@ -196,17 +235,24 @@ __device__ __forceinline__ void apply_twiddles_base(cf *v, const cf *base)
 #pragma unroll
     for (int q = 9; q < 16; ++q) w[q] = cmul(w[q - 8], w[8]);
   }
+  if (R > 16) {
+    w[16] = cmul(w[8], w[8]);
 #pragma unroll
-  for (int q = 1; q < R; ++q) v[q] = cmul(v[q], w[q]);
+    for (int q = 17; q < 32; ++q) w[q] = cmul(w[q - 16], w[16]);
+  }
+  hook(0);
+#pragma unroll
+  for (int q = 1; q < R; ++q) { v[q] = cmul(v[q], w[q]); hook(q); }
 }
 
 // LASTMODE 0: the last pass accumulates |X|^2 into pw (PSD); 1: it leaves the spectrum in v -- v[b*R + q] = X[j + q*N/R],
 // j = tid + b*THREADS -- for the caller
-template <int LOG2N, int THREADS, int PASS, int LASTMODE = 0>
+// hook(i), i = 0..E-1: called once per operand of the pass, between its twiddle products (passes > 0 only)
+template <int LOG2N, int THREADS, int PASS, int LASTMODE = 0, class Hook = NoHook>
 __device__ __forceinline__ void fft_pass(cf *v /*[E]*/, cf *lds, const TwBase &tb, int tid,
-                                         float *pw /*[E]*/)
+                                         float *pw /*[E]*/, Hook hook = Hook())
 {
-  using PL = Plan<LOG2N>;
+  using PL = PlanFor<LOG2N, THREADS>;
   constexpr int N  = 1 << LOG2N;
   constexpr int E  = N / THREADS;
   constexpr int RB = PL::bits(PASS);
@@ -239,10 +285,10 @@ __device__ __forceinline__ void fft_pass(cf *v /*[E]*/, cf *lds, const TwBase &t
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const int j = tid + b * THREADS;
+    const int j = (PASS == 0 && PL::PAIR0) ? tid * NB + b : tid + b * THREADS;
     const int k = j & (NS - 1);
     cf *vb = v + b * R;
-    if (PASS > 0) apply_twiddles_base<R>(vb, tb.w[PASS][b]);
+    if (PASS > 0) apply_twiddles_base<R>(vb, tb.w[PASS][b], [&](int q) { hook(b * R + q); });
     dftR<R>(vb);
     const int j0 = ((j - k) << RB) + k;
     if (!LAST) {
@@ -250,10 +296,10 @@ __device__ __forceinline__ void fft_pass(cf *v /*[E]*/, cf *lds, const TwBase &t
         cf *sp = lds + lpad(j0);
 #pragma unroll
         for (int q = 0; q < R; ++q) sp[q * (NS + NS / 16)] = vb[q];
-      } else if constexpr (PASS == 0 && R <= 16) {   // j0 = j*R, q < R <= 16: no carry into the pad term
+      } else if constexpr (PASS == 0 && R <= 32) {   // j0 = j*R, q < R: the pad term of q is a constant
         cf *sp = lds + lpad(j0);
 #pragma unroll
-        for (int q = 0; q < R; ++q) sp[q] = vb[q];
+        for (int q = 0; q < R; ++q) sp[q + (q >> 4)] = vb[q];
       } else {
 #pragma unroll
         for (int q = 0; q < R; ++q) lds[lpad(j0 + q * NS)] = vb[q];
@@ -274,7 +320,7 @@ struct PassRunner {
   static __device__ __forceinline__ void run(cf *v, cf *lds, const TwBase &tb, int tid, float *pw)
   {
     fft_pass<LOG2N, THREADS, PASS, LASTMODE>(v, lds, tb, tid, pw);
-    if constexpr (PASS + 1 < Plan<LOG2N>::P) PassRunner<LOG2N, THREADS, PASS + 1, LASTMODE>::run(v, lds, tb, tid, pw);
+    if constexpr (PASS + 1 < PlanFor<LOG2N, THREADS>::P) PassRunner<LOG2N, THREADS, PASS + 1, LASTMODE>::run(v, lds, tb, tid, pw);
   }
 };
 

@@ -94,7 +94,6 @@ __device__ __forceinline__ cf mul_w64(cf a, int m)
 }
 
 // N = R1 * R2 points on registers, natural order in and out: n = n1 + R1 n2, k = k2 + R2 k1
-struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 
 // `hook(step)` is called after each of the R1 + R2 sub-transforms: a place to slip other work (memory requests) in
 template <int R1, int R2, class Hook = NoHook>

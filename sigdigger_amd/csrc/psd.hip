@@ -2,8 +2,8 @@
 // optional fused fftshift + dB (PSDMessage ctor) -- rows A2/A3/A4/A9 of SURVEY.md section 8(a).
 //
 // One workgroup transforms one output frame (navg consecutive input frames, accumulated in
-// registers).  The N-point FFT is a Stockham autosort FFT whose passes (radix 8/16) run on
-// registers; the frame lives in ONE LDS buffer (in place: all of a pass's operands are
+// registers).  The N-point FFT is a Stockham autosort FFT whose passes (radix 8/16, 16/32 for the
+// 8192- and 16384-point frames: three passes, 32 points per thread) run on registers; the frame lives in ONE LDS buffer (in place: all of a pass's operands are
 // pulled into VGPRs, barrier, results are written back to the autosorted positions).  The
 // first pass reads HBM directly (coalesced float2), the last writes power straight to HBM,
 // so the HBM traffic is the compulsory 8 B/sample in and 4 B/bin/output-frame out.
@@ -17,21 +17,31 @@
 
 #include "fft_core.hpp"
 
+#ifdef PSD_TSTAMP
+// debug build only: per-phase clock stamps of one wavefront (tools/psd_tstamp.py reads them)
+__device__ unsigned long long g_psd_ts[64 * 8];
+#define PTS(n) do { __builtin_amdgcn_sched_barrier(0); ts[n] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PTS(n) do { } while (0)
+#endif
+
 namespace {
 using namespace fftcore;
+typedef float __attribute__((ext_vector_type(4))) f4;
+typedef float __attribute__((ext_vector_type(2))) f2;
 
 // grid.x = number of output frames, grid.y = S (split of the navg frames of one output over S
 // workgroups; S > 1 writes unscaled partial sums to `partial`, reduced by psd_reduce_kernel in a
 // fixed order so the result is deterministic)
 template <int LOG2N, int THREADS>
 // second launch bound: two workgroups per CU must fit the register file (N = 16384 is LDS-limited to one)
-__global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : (THREADS >= 128 ? THREADS / 128 : 1))) void psd_kernel(const cf *__restrict__ x, long long hop, int navg,
+__global__ __launch_bounds__(THREADS, ((1 << LOG2N) / THREADS >= 32 ? 2 : (THREADS >= 1024 ? 4 : (THREADS >= 128 ? THREADS / 128 : 1)))) void psd_kernel(const cf *__restrict__ x, long long hop, int navg,
                                                       const float *__restrict__ window,
                                                       const cf *__restrict__ tw, float scale, int mode,
                                                       float *__restrict__ out, float *__restrict__ partial)
 {
   __builtin_amdgcn_s_setprio(3);   // ahead of the resident recurrence wavefronts (see chan_fir_kernel)
-  using PL = Plan<LOG2N>;
+  using PL = PlanFor<LOG2N, THREADS>;
   constexpr int N  = 1 << LOG2N;
   constexpr int E  = N / THREADS;
   constexpr int R0 = 1 << PL::bits(0);
@@ -52,22 +62,35 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : (THREADS >= 128 ? T
   const int fps = (navg + S - 1) / S;
   const int f_begin = blockIdx.y * fps;
   const int f_end = (f_begin + fps < navg) ? f_begin + fps : navg;
-  // Software pipeline over the frames of this workgroup: the raw samples of frame f+1 are requested
-  // right after pass 0 of frame f has moved its operands to LDS, so the HBM latency hides behind
-  // passes 1..P-1 (with two workgroups per CU there is not enough other work to hide it otherwise:
-  // one-frame workgroups reached 51 % of the HBM peak where the in-loop version stayed at 38 %).
-  // (measured: pays for N = 4096 / 8192; N = 2048 loses a wave of occupancy to the 32 extra VGPRs,
-  // N = 16384 spills, smaller frames have enough workgroups per CU anyway)
+  // Software pipeline over the frames of this workgroup (see the frame loop): the raw samples of frame f+1 are
+  // requested while frame f is in passes 1 and 2.  With two workgroups per CU there is not enough other work to hide
+  // the HBM latency otherwise: one-frame workgroups reached 51 % of the HBM peak where the in-loop version stayed at
+  // 38 %.  (measured: pays for N = 4096 / 8192; N = 2048 loses a wave of occupancy to the 32 extra VGPRs, N = 16384
+  // spills, smaller frames have enough workgroups per CU anyway)
   constexpr bool PREFETCH = (LOG2N == 12 || LOG2N == 13);
   cf nxt[E];
-  auto request = [&](int f) {
+  // one request of frame `fr`: operand i = b * R0 + q of pass 0 (a buffer load: the lane offset is the only VGPR, the
+  // rest of the address is scalar; a zero-length descriptor makes the request of the frame after the last a no-op)
+  auto descr = [&](int f) {
     const cf *fr = x + (o * navg + f) * hop;
-#pragma unroll
-    for (int b = 0; b < NB0; ++b) {
-      const int j = tid0 + b * THREADS;
-#pragma unroll
-      for (int q = 0; q < R0; ++q) nxt[b * R0 + q] = fr[j + q * (N / R0)];
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(fr), 0, f < f_end ? N * 8 : 0, 0x00020000);
+  };
+  // (PAIR0 plans: the thread's NB0 = 2 butterflies are neighbours, so request q fetches operand q of both: 16 bytes)
+  constexpr int NREQ = PL::PAIR0 ? R0 : E;
+  static_assert(!PL::PAIR0 || NB0 == 2, "pair requests assume two butterflies per thread in pass 0");
+  auto request_one = [&](__amdgpu_buffer_rsrc_t r, int i) {
+    if constexpr (PL::PAIR0) {
+      const f4 s2 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, tid0 * 16, i * (N / R0) * 8, 0));
+      nxt[i] = s2.xy; nxt[R0 + i] = s2.zw;
+    } else {
+      const int b = i / R0, q = i % R0;
+      nxt[i] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(r, tid0 * 8, (b * THREADS + q * (N / R0)) * 8, 0));
     }
+  };
+  auto request = [&](int f) {
+    const __amdgpu_buffer_rsrc_t r = descr(f);
+#pragma unroll
+    for (int i = 0; i < NREQ; ++i) request_one(r, i);
   };
   if (PREFETCH && f_begin < f_end) request(f_begin);
   for (int f = f_begin; f < f_end; ++f) {
@@ -78,20 +101,67 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : (THREADS >= 128 ? T
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     cf v[E];
+#ifdef PSD_TSTAMP
+    unsigned long long ts[8] = {0};
+#endif
+    PTS(0);
+#ifdef PSD_TSTAMP
+    if (PREFETCH) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+    PTS(1);
     // pass 0 operands: the prefetched samples, window applied on the fly
-#pragma unroll
-    for (int b = 0; b < NB0; ++b) {
-      const int j = tid + b * THREADS;
+    if constexpr (PL::PAIR0) {
+      const f2 *w2 = reinterpret_cast<const f2 *>(window) + tid;        // window[2 tid + q N/R0], window[2 tid + 1 + ...]
 #pragma unroll
       for (int q = 0; q < R0; ++q) {
-        const int i = j + q * (N / R0);
-        v[b * R0 + q] = nxt[b * R0 + q] * window[i];
+        const f2 wq = w2[q * (N / R0 / 2)];
+        v[q] = nxt[q] * wq.x; v[R0 + q] = nxt[R0 + q] * wq.y;
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < NB0; ++b) {
+        const int j = tid + b * THREADS;
+#pragma unroll
+        for (int q = 0; q < R0; ++q) {
+          const int i = j + q * (N / R0);
+          v[b * R0 + q] = nxt[b * R0 + q] * window[i];
+        }
       }
     }
+    PTS(2);
     // (the barrier after the previous frame's last gather already ordered LDS reuse)
     fft_pass<LOG2N, THREADS, 0>(v, lds, tb, tid, pw);
-    if (PREFETCH && f + 1 < f_end) request(f + 1);
-    PassRunner<LOG2N, THREADS, 1>::run(v, lds, tb, tid, pw);
+    PTS(3);
+    if constexpr (PREFETCH) {
+      // Software pipeline over the frames of this workgroup: the raw samples of frame f+1 are requested while passes 1
+      // and 2 of frame f run, ONE request between two twiddle products, half of them in each pass.  Issued back to
+      // back, the requests of a wavefront fill the CU's miss queue and the wavefront sits in the issue stage for as
+      // long as a whole pass takes (measured with 32 x 512 B: 2900 of the frame's 10900 clocks); spread out, the
+      // queue has drained by the time the next request comes.  (1 Gi samples, 8192-pt: 596 us back to back after pass
+      // 0, 554 us all in pass 1, 551 us split; 4096-pt: 526 / 516 / 472 us)
+      static_assert(PL::P == 3, "the prefetching sizes have three passes");
+      const __amdgpu_buffer_rsrc_t r = descr(f + 1);
+      auto hooked = [&](int i) {
+        __builtin_amdgcn_sched_barrier(0);
+        request_one(r, i);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      fft_pass<LOG2N, THREADS, 1>(v, lds, tb, tid, pw, [&](int i) {
+        if (i % 2 == 0 && i / 2 < NREQ / 2) hooked(i / 2);
+      });
+      PTS(5);
+      fft_pass<LOG2N, THREADS, 2>(v, lds, tb, tid, pw, [&](int i) {
+        if (i % 2 == 0 && i / 2 < NREQ - NREQ / 2) hooked(NREQ / 2 + i / 2);
+      });
+      PTS(6);
+#ifdef PSD_TSTAMP
+      if (blockIdx.x == 3 && blockIdx.y == 0 && tid0 == 0 && f - f_begin < 64) {
+        for (int n = 0; n < 8; ++n) g_psd_ts[(f - f_begin) * 8 + n] = ts[n];
+      }
+#endif
+    } else {
+      PassRunner<LOG2N, THREADS, 1>::run(v, lds, tb, tid, pw);
+    }
   }
 
   // epilogue: thread holds power of bins j + q*N/RL (last-pass geometry)
@@ -234,6 +304,13 @@ inline unsigned grid_for(long long n, int block) {
 
 }  // namespace
 
+#ifdef PSD_TSTAMP
+extern "C" __attribute__((visibility("default"))) int suamd_debug_psd_ts(unsigned long long *out)
+{
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_psd_ts), sizeof(unsigned long long) * 64 * 8);
+}
+#endif
+
 namespace sdk {
 
 // how many workgroups share the navg frames of one output: enough to put >= ~1024 workgroups
@@ -273,8 +350,8 @@ hipError_t psd_frames(int log2n, const void *x, long long hop, int navg, const f
     case 10: return launch_psd<10, 64>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
     case 11: return launch_psd<11, 128>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
     case 12: return launch_psd<12, 256>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
-    case 13: return launch_psd<13, 512>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
-    case 14: return launch_psd<14, 1024>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
+    case 13: return launch_psd<13, 256>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
+    case 14: return launch_psd<14, 512>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
     default: return hipErrorInvalidValue;
   }
 }
