@@ -367,6 +367,7 @@ def main():
                            "kernel_ms": round(psd_ms, 4) if psd_ms else None,
                            "algorithmic_bytes_per_launch": psd_bytes},
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+            "stalled_samples_dropped": dict(getattr(pipe, "stalled_samples", {})),
             "note": "recurrence stages (AGC/Costas/Gardner) are one-lane-per-channel and latency-bound; "
                     "they are reported in stage_ms, not against a roofline (SURVEY.md section 8d)",
         }

@@ -421,7 +421,7 @@ SUBOOL suamd_psd_feed(suamd_psd_t *p, const suamd_complex *d_x, SUSCOUNT nframes
                                   base, base + cb, reinterpret_cast<float *>(base + 2 * cb), as_stream(stream)), SU_FALSE);
     return SU_TRUE;
   }
-  const int S = sdk::psd_split(nout, (int)navg);
+  const int S = sdk::psd_split(nout, (int)navg, (int)p->log2n);
   float *partial = nullptr;
   if (S > 1) {
     // NOTE: growing the scratch frees the old one; callers that enqueue on several streams must

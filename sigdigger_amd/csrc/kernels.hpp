@@ -13,9 +13,9 @@ namespace sdk {
 struct View { long long cs, ms; };
 
 // ---- psd.hip ----
-// partial: scratch for split-frame accumulation, >= nout * psd_split(nout, navg) * N floats (may be
+// partial: scratch for split-frame accumulation, >= nout * psd_split(nout, navg, log2n) * N floats (may be
 // nullptr when psd_split() == 1)
-int        psd_split(long long nout, int navg);
+int        psd_split(long long nout, int navg, int log2n);
 hipError_t psd_frames(int log2n, const void *x, long long hop, int navg, const float *window,
                       const void *tw, float scale, int mode, float *out, long long nout, float *partial,
                       hipStream_t st);

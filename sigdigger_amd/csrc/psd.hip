@@ -25,6 +25,12 @@ __device__ unsigned long long g_psd_ts[64 * 8];
 #define PTS(n) do { } while (0)
 #endif
 
+// cache policy of the sample requests of a capture-sized input: sc0 | nt -- read once, do not displace the window and
+// the twiddles from L1 / L2 (256 Mi samples, 8192-pt: 516-521 us against 558-580 us with the default policy; 4096-pt
+// 457-463 against 472-475).  An analyzer block (32 MiB, just written by the ingest kernel and read by the channeliser
+// too) still sits in the last-level cache, and there the default policy is the faster one (4 Mi samples: 17.1 against
+// 18.9 us at 4096-pt), so the host picks by input size.
+constexpr int AUX_DEFAULT = 0, AUX_STREAM = 3;
 namespace {
 using namespace fftcore;
 typedef float __attribute__((ext_vector_type(4))) f4;
@@ -33,7 +39,7 @@ typedef float __attribute__((ext_vector_type(2))) f2;
 // grid.x = number of output frames, grid.y = S (split of the navg frames of one output over S
 // workgroups; S > 1 writes unscaled partial sums to `partial`, reduced by psd_reduce_kernel in a
 // fixed order so the result is deterministic)
-template <int LOG2N, int THREADS>
+template <int LOG2N, int THREADS, bool STREAM>
 // second launch bound: two workgroups per CU must fit the register file (N = 16384 is LDS-limited to one)
 __global__ __launch_bounds__(THREADS, ((1 << LOG2N) / THREADS >= 32 ? 2 : (THREADS >= 1024 ? 4 : (THREADS >= 128 ? THREADS / 128 : 1)))) void psd_kernel(const cf *__restrict__ x, long long hop, int navg,
                                                       const float *__restrict__ window,
@@ -80,11 +86,11 @@ __global__ __launch_bounds__(THREADS, ((1 << LOG2N) / THREADS >= 32 ? 2 : (THREA
   static_assert(!PL::PAIR0 || NB0 == 2, "pair requests assume two butterflies per thread in pass 0");
   auto request_one = [&](__amdgpu_buffer_rsrc_t r, int i) {
     if constexpr (PL::PAIR0) {
-      const f4 s2 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, tid0 * 16, i * (N / R0) * 8, 0));
+      const f4 s2 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, tid0 * 16, i * (N / R0) * 8, STREAM ? AUX_STREAM : AUX_DEFAULT));
       nxt[i] = s2.xy; nxt[R0 + i] = s2.zw;
     } else {
       const int b = i / R0, q = i % R0;
-      nxt[i] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(r, tid0 * 8, (b * THREADS + q * (N / R0)) * 8, 0));
+      nxt[i] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(r, tid0 * 8, (b * THREADS + q * (N / R0)) * 8, STREAM ? AUX_STREAM : AUX_DEFAULT));
     }
   };
   auto request = [&](int f) {
@@ -219,13 +225,13 @@ __global__ __launch_bounds__(256) void psd_reduce_kernel(const float *__restrict
   }
 }
 
-template <int LOG2N, int THREADS>
-hipError_t launch_psd(const void *x, long long hop, int navg, const float *window, const void *tw,
+template <int LOG2N, int THREADS, bool STREAM>
+hipError_t launch_psd_p(const void *x, long long hop, int navg, const float *window, const void *tw,
                       float scale, int mode, float *out, long long nout, float *partial, int S, hipStream_t st)
 {
   constexpr int N = 1 << LOG2N;
   const size_t lds = sizeof(cf) * (size_t)(N + (N >> 4) + 1);
-  auto kern = psd_kernel<LOG2N, THREADS>;
+  auto kern = psd_kernel<LOG2N, THREADS, STREAM>;
   static bool attr_done_dev[64] = {};                        // a function attribute belongs to a device
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
@@ -311,26 +317,41 @@ extern "C" __attribute__((visibility("default"))) int suamd_debug_psd_ts(unsigne
 }
 #endif
 
+// inputs larger than this are read with the streaming policy (the last-level cache holds 256 MiB)
+constexpr long long PSD_STREAM_BYTES = 128ll << 20;
+
+template <int LOG2N, int THREADS>
+hipError_t launch_psd(const void *x, long long hop, int navg, const float *window, const void *tw,
+                      float scale, int mode, float *out, long long nout, float *partial, int S, hipStream_t st)
+{
+  static int force = -2;                                     // SUAMD_PSD_STREAM=0/1 pins the policy (measurements)
+  if (force == -2) { const char *e = getenv("SUAMD_PSD_STREAM"); force = e ? atoi(e) : -1; }
+  const bool stream = force >= 0 ? force != 0 : nout * navg * hop * 8 > PSD_STREAM_BYTES;
+  return stream ? launch_psd_p<LOG2N, THREADS, true>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st)
+                : launch_psd_p<LOG2N, THREADS, false>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
+}
+
 namespace sdk {
 
-// how many workgroups share the navg frames of one output: enough to put >= ~1024 workgroups
-// on the chip, at least 2 frames each
-int psd_split(long long nout, int navg)
+// how many workgroups share the navg frames of one output: enough to fill the chip's resident-workgroup slots for
+// that frame size, at least `minf` frames each
+int psd_split(long long nout, int navg, int log2n)
 {
-  // two resident workgroups per CU (512 on the chip), at least `minf` frames per workgroup: the
-  // register-resident twiddles are reused and the partial sums stay a fraction of the input (PMC
-  // showed 2.1x the algorithmic HBM traffic with one frame per workgroup).  Only matters for the
-  // small analyzer blocks (4 Mi samples: 8192-pt 25.6 us at minf = 2, 30.6 us at 4; 16384-pt 28.8
-  // vs 44.8 us); a capture-sized input has nout >= target and never splits.
-  static int target = 0, minf = 0;
-  if (target == 0) {
+  // Resident workgroups on the chip (256 CUs): 4 per CU for N <= 4096, 2 for 8192, 1 for 16384 (LDS).  At least `minf`
+  // frames per workgroup: the register-resident twiddles are reused and the partial sums stay a fraction of the input
+  // (PMC showed 2.1x the algorithmic HBM traffic with one frame per workgroup).  Measured on 256 Mi samples, 128
+  // outputs: 4096-pt 463 us split over 512 workgroups, 407 us over 1024; 8192-pt 540-585 / 565 / 543 us over 512 /
+  // 1024 / 2048; 16384-pt 570 / 586 / 605 us.  On a 4 Mi analyzer block minf decides (8192-pt 25.6 us at minf = 2,
+  // 30.6 us at 4; 16384-pt 28.8 vs 44.8 us).  An input with nout >= target never splits.
+  static int target_env = 0, minf = 0;
+  if (minf == 0) {
     const char *e = getenv("SUAMD_PSD_SPLIT_TARGET");
-    target = e ? atoi(e) : 512;
+    target_env = e ? atoi(e) : -1;
     e = getenv("SUAMD_PSD_MIN_FRAMES");
     minf = e ? atoi(e) : 2;
-    if (target < 1) target = 1;
     if (minf < 1) minf = 1;
   }
+  const int target = target_env > 0 ? target_env : (log2n <= 12 ? 1024 : 512);
   if (nout <= 0 || navg < 2 * minf || nout >= target) return 1;
   long long s = (target + nout - 1) / nout;
   if (s > navg / minf) s = navg / minf;
@@ -343,7 +364,7 @@ hipError_t psd_frames(int log2n, const void *x, long long hop, int navg, const f
                       hipStream_t st)
 {
   if (nout <= 0) return hipSuccess;
-  const int S = partial ? psd_split(nout, navg) : 1;
+  const int S = partial ? psd_split(nout, navg, log2n) : 1;
   switch (log2n) {
     // 16 points per thread (8 for N = 512): one radix-16 or two radix-8 butterflies per pass
     case 9:  return launch_psd<9, 64>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);

@@ -258,10 +258,19 @@ class AnalyzerPipeline:
         """Average kernel time of each stage over the timed steps (HIP events recorded on the
         stream each stage runs on; call after a device sync)."""
         ev = self.ev
+        self.stalled_samples = {}
 
         def avg(a, b):
+            # Mean over the timed steps.  A sample more than 5x the median is not a launch: roughly every other run has
+            # ONE step in which the stream sits 1-1.6 ms between the two events of a 25-40 us kernel (queue
+            # housekeeping on the host side; tools/fir_dist.py shows the distribution) -- such samples are dropped and
+            # counted in self.stalled_samples, so the figure is the kernel's launch duration, as rocprofv3 reports it.
             if a in ev and b in ev:
-                return float(np.mean([s.elapsed_time(e) for s, e in zip(ev[a], ev[b])]))
+                t = np.array([s.elapsed_time(e) for s, e in zip(ev[a], ev[b])])
+                keep = t <= 5.0 * np.median(t)
+                if not keep.all():
+                    self.stalled_samples[a[:-1]] = int((~keep).sum())
+                return float(t[keep].mean())
             return None
         demod = "costas" if (self.bank_cfg is not None and self.bank_cfg.kind == "psk") else "quad"
         out = {"psd": avg("psd0", "psd1"), "fir": avg("fir0", "fir1"), "agc": avg("agc0", "agc1"),

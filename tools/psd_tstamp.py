@@ -14,7 +14,7 @@ lib = _lib.load()
 buf = (ctypes.c_ulonglong * 512)()
 print("rc", lib.suamd_debug_psd_ts(buf))
 t = np.array(buf[:], dtype=np.int64).reshape(64, 8)
-names = ["wait nxt", "window", "pass0", "-", "pass1", "pass2"]
+names = ["wait nxt", "window", "pass0", "-", "pass1+req", "pass2+req"]
 t[:, 4] = t[:, 3]; d = np.diff(t[:, :7], axis=1)
 for f in (0, 1, 2, 8, 16, 32, 48, 63):
     print(f, " ".join(f"{nm}={v}" for nm, v in zip(names, d[f])), "frame->frame", t[f, 0] - t[f - 1, 0] if f else 0)
