@@ -1840,6 +1840,8 @@ struct suamd_specview {
   unsigned spectrumSize;
   float *d_psd, *d_accum, *d_count;
   sdk::SpecViewLinear *d_geom = nullptr;      // per-frame geometry of a batched sweep
+  sdk::SpecViewLinear *h_geom = nullptr;      // its pinned staging copy (the upload must not make the host wait for the stream)
+  hipEvent_t geom_ev = nullptr;               // recorded after the upload: h_geom may be rewritten once it has passed
   size_t geom_cap = 0;
 };
 
@@ -1877,6 +1879,8 @@ void suamd_specview_destroy(suamd_specview_t *v)
   if (v->d_accum) hipFree(v->d_accum);
   if (v->d_count) hipFree(v->d_count);
   if (v->d_geom) hipFree(v->d_geom);
+  if (v->h_geom) hipHostFree(v->h_geom);
+  if (v->geom_ev) hipEventDestroy(v->geom_ev);
   delete v;
 }
 
@@ -1988,16 +1992,22 @@ SUBOOL suamd_specview_feed_sweep(suamd_specview_t *v, const SUFLOAT *d_psd, SUSC
   // then interpolate() once (its output after the earlier frames would have been overwritten anyway)
   hipStream_t st = as_stream(stream);
   HIP_TRY(hipSetDevice(v->ctx->device), SU_FALSE);
-  std::vector<sdk::SpecViewLinear> geom(nframes);
-  for (SUSCOUNT f = 0; f < nframes; ++f)
-    geom[f] = specview_linear_geom(v, psdSize, center[f] - v->fftBandwidth / 2, center[f] + v->fftBandwidth / 2, adjustSides);
+  // The geometry goes up through a pinned staging buffer owned by the view, so the call only enqueues: no host-side wait
+  // for the stream (the frames of the sweep are typically still being computed on it).
+  if (!v->geom_ev) HIP_TRY(hipEventCreateWithFlags(&v->geom_ev, hipEventDisableTiming), SU_FALSE);
+  else HIP_TRY(hipEventSynchronize(v->geom_ev), SU_FALSE);   // the previous sweep's upload (long done, normally)
   if (v->geom_cap < nframes) {
-    if (v->d_geom) { HIP_TRY(hipStreamSynchronize(st), SU_FALSE); hipFree(v->d_geom); v->d_geom = nullptr; v->geom_cap = 0; }
+    if (v->d_geom) { HIP_TRY(hipStreamSynchronize(st), SU_FALSE); hipFree(v->d_geom); v->d_geom = nullptr; }
+    if (v->h_geom) { hipHostFree(v->h_geom); v->h_geom = nullptr; }
+    v->geom_cap = 0;
     HIP_TRY(hipMalloc(&v->d_geom, nframes * sizeof(sdk::SpecViewLinear)), SU_FALSE);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&v->h_geom), nframes * sizeof(sdk::SpecViewLinear), hipHostMallocDefault), SU_FALSE);
     v->geom_cap = nframes;
   }
-  HIP_TRY(hipMemcpyAsync(v->d_geom, geom.data(), nframes * sizeof(sdk::SpecViewLinear), hipMemcpyHostToDevice, st), SU_FALSE);
-  HIP_TRY(hipStreamSynchronize(st), SU_FALSE);       // geom is a stack-lifetime host buffer
+  for (SUSCOUNT f = 0; f < nframes; ++f)
+    v->h_geom[f] = specview_linear_geom(v, psdSize, center[f] - v->fftBandwidth / 2, center[f] + v->fftBandwidth / 2, adjustSides);
+  HIP_TRY(hipMemcpyAsync(v->d_geom, v->h_geom, nframes * sizeof(sdk::SpecViewLinear), hipMemcpyHostToDevice, st), SU_FALSE);
+  HIP_TRY(hipEventRecord(v->geom_ev, st), SU_FALSE);
   // d_psd doubles as the snapshot of the counts before the sweep (neighbour validity)
   HIP_TRY(hipMemcpyAsync(v->d_psd, v->d_count, sizeof(float) * v->spectrumSize, hipMemcpyDeviceToDevice, st), SU_FALSE);
   HIP_TRY(sdk::specview_sweep_linear(v->d_geom, (int)nframes, d_psd, (long long)psdSize, v->d_psd, v->d_accum, v->d_count,

@@ -519,7 +519,8 @@ def _sweep_frames(sdo, ctx, nframes, n, seed):
     return psd.feed(dev(x), nframes=nframes, scale=1.0 / n, mode=engine.PSD_DB_SHIFTED)
 
 
-@pytest.mark.parametrize("span,fs,nframes", [(100e6, 20e6, 24), (30e6, 2.4e6, 40), (1000e6, 20e6, 30)])
+# (the last case has more frames than one round of the sweep kernel's per-workgroup frame list holds)
+@pytest.mark.parametrize("span,fs,nframes", [(100e6, 20e6, 24), (30e6, 2.4e6, 40), (1000e6, 20e6, 30), (400e6, 10e6, 600)])
 def test_specview_sweep_bit_exact(ctx, sdo, span, fs, nframes):
     n = 8192
     frames = _sweep_frames(sdo, ctx, nframes, n, seed=int(span / 1e6))
