@@ -122,3 +122,23 @@ def test_capture_psd_frames_do_not_depend_on_the_launch_shape(ctx):
     # different splits sum the same frames in a different association: equal to rounding, not bitwise
     assert torch.max(torch.abs(whole - halves)).item() < 1e-4                                      # dB
     assert abs(whole.mean().item() - 10 * np.log10(2 * 0.35875 ** 2 + 2 * (0.48829 ** 2 + 0.14128 ** 2 + 0.01168 ** 2) / 2)) < 0.1
+
+
+@pytest.mark.parametrize("n", [4096, 8192, 16384])
+def test_capture_sized_psd_input_read_with_the_streaming_policy_gives_the_same_bits(ctx, n):
+    """An input above 128 MiB is requested with the streaming cache policy, a smaller one with the default policy
+    (psd.hip, launch_psd): 2^25 samples in one launch equal the two 2^24-sample halves bit for bit (every output has its
+    own workgroup in both cases, so the arithmetic is the same)."""
+    total, navg = 1 << 25, 2
+    g = torch.Generator(device="cuda"); g.manual_seed(n)
+    x = torch.empty(total, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(x).normal_(generator=g)
+    psd = engine.PSD(ctx, n)
+    nf = total // n
+    whole = psd.feed(x, nframes=nf, navg=navg, scale=1.0 / n)
+    h = total // 2
+    halves = torch.cat([psd.feed(x[:h], nframes=nf // 2, navg=navg, scale=1.0 / n),
+                        psd.feed(x[h:], nframes=nf // 2, navg=navg, scale=1.0 / n)])
+    assert whole.shape == (nf // navg, n)
+    assert bits_equal(whole, halves)
+    assert abs(whole.mean().item() - 2 * (0.35875 ** 2 + (0.48829 ** 2 + 0.14128 ** 2 + 0.01168 ** 2) / 2)) < 0.01
