@@ -559,7 +559,8 @@ struct suscan_analyzer {
   hipStream_t stream = nullptr;
   static constexpr int NISTREAMS = 4;          // gain control / carrier control / clock recovery / channeliser (+ spectra, estimators)
   static constexpr int NSUB = 16;             // at most this many sub-ranges of a block pipelined through those stages
-  int nsub = 4;
+  int nsub = 4;                               // sub-ranges of the block being enqueued (nsub_env, or chosen by the inspector count)
+  int nsub_env = 0;                           // SUAMD_ANALYZER_SUBRANGES; 0: automatic
   bool trace = false;                         // SUAMD_ANALYZER_TRACE: per-block host timeline on stderr
   double t_chains_done = 0;
   hipEvent_t ev_t0 = nullptr, ev_tfir = nullptr, ev_tpre = nullptr, ev_tdone = nullptr, ev_tstage[3][NSUB] = {};   // timed, trace only
@@ -809,6 +810,11 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len, int slot)
 
 void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
 {
+  // Sub-ranges per stage: four let the three serial stages of a block overlap when a handful of wavefronts carry all
+  // inspectors; with hundreds of inspectors the worker's own enqueue time is what bounds the rate, and two sub-ranges
+  // halve it (2 Mi-sample blocks, MS/s at the consumer with 1 / 2 / 4 sub-ranges: 64 inspectors 797 / 1048 / 1055,
+  // 128: 779 / 1022 / 1011, 256: 1033 / 1180 / 950, 512: 1030 / 1017 / 891).
+  if (!a->nsub_env) a->nsub = a->inspectors.size() > 128 ? 2 : 4;
   const int P = a->nsub;
   hipStream_t sA = a->istream[0], sC = a->istream[1], sK = a->istream[2], sF = a->istream[3];
   // the channeliser has its own stream: with hundreds of inspectors it is as long as a recurrence stage, and block
@@ -1448,7 +1454,7 @@ bool init_device(suscan_analyzer *a, std::string &err)
   a->trace = std::getenv("SUAMD_ANALYZER_TRACE") != nullptr;
   if (const char *e = std::getenv("SUAMD_ANALYZER_SUBRANGES")) {           // tuning knob: 1 = whole block per stage
     const int v = std::atoi(e);
-    if (v >= 1 && v <= suscan_analyzer::NSUB) a->nsub = v;
+    if (v >= 1 && v <= suscan_analyzer::NSUB) a->nsub = a->nsub_env = v;
   }
   for (int g = 0; ok && g < 3; ++g)
     for (int j = 0; ok && j < suscan_analyzer::NSUB; ++j)
