@@ -366,7 +366,8 @@ hipError_t psd_frames(int log2n, const void *x, long long hop, int navg, const f
   if (nout <= 0) return hipSuccess;
   const int S = partial ? psd_split(nout, navg, log2n) : 1;
   switch (log2n) {
-    // 16 points per thread (8 for N = 512): one radix-16 or two radix-8 butterflies per pass
+    // 16 points per thread (8 for N = 512): one radix-16 or two radix-8 butterflies per pass; 32 points per thread for
+    // N = 8192 / 16384: three passes of radix 16 / 32, pass-0 operands requested as 16-byte pairs
     case 9:  return launch_psd<9, 64>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
     case 10: return launch_psd<10, 64>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
     case 11: return launch_psd<11, 128>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
