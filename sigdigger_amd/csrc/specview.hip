@@ -165,13 +165,22 @@ __global__ __launch_bounds__(1024) void interpolate_kernel(float *__restrict__ p
   __shared__ int lastv[2][1024], firstv[2][1024];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int G = (n + 63) >> 6;
-  // 1. the valid mask of every group
-#pragma unroll 8
-  for (int g = wv; g < 1024; g += 16) {
-    const int i = g * 64 + lane;
-    const float c = (g < G && i < n) ? psdCount[i] : 0.0f;
-    const unsigned long long m = __ballot(c > .5f);
-    if (lane == 0) mask[g] = m;
+  // 1. the valid mask of every group.  Wavefront wv owns groups 64 wv .. 64 wv + 63 (4096 consecutive bins); their
+  //    counts are requested 32 rows at a time, and step 3 asks for counts and sums 16 rows at a time (a loop that asks for
+  //    one row, waits and votes runs at one memory latency per row: 73 us for the 64 rows)
+#pragma unroll
+  for (int k0 = 0; k0 < 64; k0 += 32) {
+    float c[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const int i = (wv * 64 + k0 + u) * 64 + lane;
+      c[u] = i < n ? psdCount[i] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const unsigned long long m = __ballot(c[u] > .5f);
+      if (lane == 0) mask[wv * 64 + k0 + u] = m;
+    }
   }
   __syncthreads();
   // 2. per group: last valid bin of any earlier group (-1: none), first valid bin of any later group (n: none)
@@ -194,10 +203,21 @@ __global__ __launch_bounds__(1024) void interpolate_kernel(float *__restrict__ p
   // 3. every bin's output; the reference resets count / accum of over-counted bins while it walks, and those writes
   //    must not be seen by the bins that read them as neighbours: remember them, write after a barrier
   unsigned long long resets = 0;                                 // bit k: the bin of my k-th group is reset
-  int k = 0;
-#pragma unroll 4
-  for (int g = wv; g < G; g += 16, ++k) {
+#pragma unroll
+  for (int k0 = 0; k0 < 64; k0 += 16) {
+  float c[16], ac[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int i = (wv * 64 + k0 + u) * 64 + lane;
+    c[u] = i < n ? psdCount[i] : 0.0f;
+    ac[u] = i < n ? psdAccum[i] : 0.0f;
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int k = k0 + u;
+    const int g = wv * 64 + k;
     const int i = g * 64 + lane;
+    if (g >= G) continue;
     const unsigned long long m = mask[g];
     const unsigned long long below = m & ((1ull << lane) - 1ull);
     const unsigned long long above = lane < 63 ? (m >> (lane + 1)) : 0ull;
@@ -206,8 +226,8 @@ __global__ __launch_bounds__(1024) void interpolate_kernel(float *__restrict__ p
     if (i >= n) continue;
     float outv;
     if ((m >> lane) & 1ull) {
-      const float cnt = psdCount[i];
-      outv = psdAccum[i] / cnt;
+      const float cnt = c[u];
+      outv = ac[u] / cnt;
       // the bin that ends a gap is not cap-checked by the reference (Scanner.cpp:92-95)
       const bool ends_gap = (i > 0) && (left != i - 1);
       if (!ends_gap && cnt > kCountMax) resets |= 1ull << k;
@@ -231,11 +251,12 @@ __global__ __launch_bounds__(1024) void interpolate_kernel(float *__restrict__ p
     }
     psd[i] = outv;
   }
+  }
   __syncthreads();
-  k = 0;
-  for (int g = wv; g < G; g += 16, ++k) {
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
     if ((resets >> k) & 1ull) {
-      const int i = g * 64 + lane;
+      const int i = (wv * 64 + k) * 64 + lane;
       psdCount[i] = kCountReset;
       psdAccum[i] = psd[i] * kCountReset;
     }
