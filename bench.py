@@ -240,6 +240,35 @@ def run_host_fed(name, args, dev, ctx):
             "pcie_GBps": round(8.0 * L * steps / dt / 1e9, 2)}
 
 
+def run_fir_stage_large_block(cfg, dev, ctx, fn_rank, log2_block=24):
+    """The FFT channeliser of the default workload on a 16 Mi-sample block (same 64 channels, same kernel): the 4 Mi block
+    of the headline gives a wavefront three windows, so its start (the first 32 KiB of every wavefront at once) and the
+    2-or-3-windows quantisation weigh a third of the launch; on a longer block they amortise.  Reported beside the
+    headline's `roofline`, never instead of it."""
+    Lb, D = 1 << log2_block, cfg["D"]
+    x = torch.empty(Lb, dtype=torch.complex64, device=dev)
+    torch.view_as_real(x).normal_()
+    st = engine.SpectTuner(ctx, 4096)
+    for f in fn_rank:
+        st.open_channel(np.pi * f % (2 * np.pi), 2 * np.pi * 0.75 / D)
+    out = engine.time_major(len(fn_rank), Lb // D + 64, dev)
+    st.feed(x, out=out)
+    torch.cuda.synchronize(dev)
+    reps = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        st.feed(x, out=out)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    st.close()
+    nbytes = 8.0 * Lb + 8.0 * len(fn_rank) * Lb / D
+    return {"block_samples": Lb, "kernel_ms": round(ms, 4), "algorithmic_bytes_per_launch": nbytes,
+            "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "what": "stw_kernel alone on a 16 Mi-sample block, back-to-back launches (includes the history copy of a feed)"}
+
+
 def run_c5(args, dev, ctx, log2_file=30, N=8192, tile=256):
     """C5: panoramic-scanner sweep over a captured file resident in HBM -- every dwell is `tile` frames of
     N points averaged into one shifted-dB PSD message (PSDMessage.cpp:26-39 fused), fed to the SpectrumView
@@ -446,6 +475,11 @@ def main():
             except Exception as e:                            # a secondary figure must not take the bench line down
                 extra["live64"] = {"error": repr(e)}
             out["host_fed"] = run_host_fed(args.workload, args, dev, ctx)
+            if args.channeliser == "fft" and cfg["kind"] == "psk":
+                try:
+                    out["roofline"]["fir_stage_16Mi_block"] = run_fir_stage_large_block(cfg, dev, ctx, fn_rank)
+                except Exception as e:
+                    out["roofline"]["fir_stage_16Mi_block"] = {"error": repr(e)}
             out["other_workloads"] = extra
         if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_samples, fn_rank, os.cpu_count() or 1)
