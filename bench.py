@@ -471,7 +471,7 @@ def main():
             extra["c5"] = run_c5(args, dev, ctx)
             try:                                              # the drop-in boundary itself, end to end (host thread, file source)
                 from sigdigger_amd.livebench import live_rate
-                extra["live64"] = live_rate(64, 30)
+                extra["live64"] = live_rate(64, 60)
             except Exception as e:                            # a secondary figure must not take the bench line down
                 extra["live64"] = {"error": repr(e)}
             out["host_fed"] = run_host_fed(args.workload, args, dev, ctx)
