@@ -1839,6 +1839,7 @@ struct suamd_specview {
   float fftRelBw;
   unsigned spectrumSize;
   float *d_psd, *d_accum, *d_count;
+  unsigned long long *d_reset = nullptr;      // interpolate()'s count-cap resets, one mask per 64 bins
   sdk::SpecViewLinear *d_geom = nullptr;      // per-frame geometry of a batched sweep
   sdk::SpecViewLinear *h_geom = nullptr;      // its pinned staging copy (the upload must not make the host wait for the stream)
   hipEvent_t geom_ev = nullptr;               // recorded after the upload: h_geom may be rewritten once it has passed
@@ -1868,7 +1869,8 @@ suamd_specview_t *suamd_specview_new(suamd_ctx_t *ctx)
   v->d_psd = dev_zeros<float>(SUAMD_SCANNER_SPECTRUM_SIZE);
   v->d_accum = dev_zeros<float>(SUAMD_SCANNER_SPECTRUM_SIZE);
   v->d_count = dev_zeros<float>(SUAMD_SCANNER_SPECTRUM_SIZE);
-  if (!v->d_psd || !v->d_accum || !v->d_count) { set_err("device allocation failed"); suamd_specview_destroy(v); return nullptr; }
+  v->d_reset = dev_zeros<unsigned long long>(1024);
+  if (!v->d_psd || !v->d_accum || !v->d_count || !v->d_reset) { set_err("device allocation failed"); suamd_specview_destroy(v); return nullptr; }
   return v;
 }
 
@@ -1878,6 +1880,7 @@ void suamd_specview_destroy(suamd_specview_t *v)
   if (v->d_psd) hipFree(v->d_psd);
   if (v->d_accum) hipFree(v->d_accum);
   if (v->d_count) hipFree(v->d_count);
+  if (v->d_reset) hipFree(v->d_reset);
   if (v->d_geom) hipFree(v->d_geom);
   if (v->h_geom) hipHostFree(v->h_geom);
   if (v->geom_ev) hipEventDestroy(v->geom_ev);
@@ -1964,7 +1967,7 @@ SUBOOL suamd_specview_feed(suamd_specview_t *v, const SUFLOAT *d_psd, const SUFL
     g.t = g.split ? static_cast<float>((fStart - std::floor(fStart)) / relBw) : 0.0f;
     HIP_TRY(sdk::specview_feed_hist(g, d_psd, v->d_accum, v->d_count, st), SU_FALSE);
   }
-  HIP_TRY(sdk::specview_interpolate(v->d_psd, v->d_accum, v->d_count, (int)v->spectrumSize, st), SU_FALSE);
+  HIP_TRY(sdk::specview_interpolate(v->d_psd, v->d_accum, v->d_count, (int)v->spectrumSize, v->d_reset, st), SU_FALSE);
   return SU_TRUE;
 }
 
@@ -2012,7 +2015,7 @@ SUBOOL suamd_specview_feed_sweep(suamd_specview_t *v, const SUFLOAT *d_psd, SUSC
   HIP_TRY(hipMemcpyAsync(v->d_psd, v->d_count, sizeof(float) * v->spectrumSize, hipMemcpyDeviceToDevice, st), SU_FALSE);
   HIP_TRY(sdk::specview_sweep_linear(v->d_geom, (int)nframes, d_psd, (long long)psdSize, v->d_psd, v->d_accum, v->d_count,
                                      (int)v->spectrumSize, st), SU_FALSE);
-  HIP_TRY(sdk::specview_interpolate(v->d_psd, v->d_accum, v->d_count, (int)v->spectrumSize, st), SU_FALSE);
+  HIP_TRY(sdk::specview_interpolate(v->d_psd, v->d_accum, v->d_count, (int)v->spectrumSize, v->d_reset, st), SU_FALSE);
   return SU_TRUE;
 }
 

@@ -212,7 +212,8 @@ struct SpecViewHist { int psdSize; float inv, t; unsigned j, spectrumSize; int s
 hipError_t specview_feed_linear(const SpecViewLinear &g, const float *psd, const float *count, float *accum,
                                 float *cnt, hipStream_t st);
 hipError_t specview_feed_hist(const SpecViewHist &g, const float *psd, float *accum, float *cnt, hipStream_t st);
-hipError_t specview_interpolate(float *psd, float *accum, float *cnt, int n, hipStream_t st);
+// reset_scratch: 1024 x 64-bit device words (the count-cap resets of one call, one mask per 64 bins)
+hipError_t specview_interpolate(float *psd, float *accum, float *cnt, int n, unsigned long long *reset_scratch, hipStream_t st);
 // nframes linear-mode feeds (each followed by the count-cap reset of interpolate()) in one launch
 hipError_t specview_sweep_linear(const SpecViewLinear *d_geom, int nframes, const float *frames, long long frame_stride,
                                  const float *cnt_before, float *accum, float *cnt, int n, hipStream_t st);

@@ -153,21 +153,27 @@ __global__ void feed_hist_kernel(sdk::SpecViewHist g, const float *__restrict__ 
   }
 }
 
-// One workgroup of 1024 threads (16 wavefronts), lane = bin inside a group of 64 consecutive bins: the valid bins of a
-// group are one ballot, a bin's nearest valid neighbours inside its group are two bit scans of that mask, and the
-// neighbours beyond the group come from a prefix-max / suffix-min over the (at most 1024) groups' last / first valid
-// bin.  Every global access is a coalesced row (the walk of the reference, one thread per 64 consecutive bins, touched
-// 64 cache lines per request: 200 us; this one 20 us).  The expressions are the reference's (Scanner.cpp:56-116).
-__global__ __launch_bounds__(1024) void interpolate_kernel(float *__restrict__ psd, float *__restrict__ psdAccum,
-                                                           float *__restrict__ psdCount, int n)
+// interpolate(): lane = bin inside a group of 64 consecutive bins.  The valid bins of a group are one ballot, a bin's
+// nearest valid neighbours inside its group are two bit scans of that mask, and the neighbours beyond the group come from
+// a prefix-max / suffix-min over the (at most 1024) groups' last / first valid bin.  Every global access is a coalesced
+// row (the walk of the reference, one thread per 64 consecutive bins, touched 64 cache lines per request: 200 us).
+// INTERP_WGS workgroups of 1024 threads share the bins: each recomputes all masks and the group scan for itself (256 KiB
+// of counts out of L2, 10 barriers) and then evaluates its own 1/INTERP_WGS of the groups -- one workgroup alone spends
+// ~80 instructions per bin on ONE CU (57 us).  The reference resets count / accum of over-counted bins while it walks;
+// those writes must not tear under a neighbour's read of (accum, count), so this kernel only records them (one mask per
+// group) and interpolate_reset_kernel applies them afterwards.  The expressions are the reference's (Scanner.cpp:56-116).
+constexpr int INTERP_WGS = 16;
+
+__global__ __launch_bounds__(1024) void interpolate_kernel(float *__restrict__ psd, const float *__restrict__ psdAccum,
+                                                           const float *__restrict__ psdCount, int n,
+                                                           unsigned long long *__restrict__ resetMask)
 {
   __shared__ unsigned long long mask[1024];
   __shared__ int lastv[2][1024], firstv[2][1024];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int G = (n + 63) >> 6;
-  // 1. the valid mask of every group.  Wavefront wv owns groups 64 wv .. 64 wv + 63 (4096 consecutive bins); their
-  //    counts are requested 32 rows at a time, and step 3 asks for counts and sums 16 rows at a time (a loop that asks for
-  //    one row, waits and votes runs at one memory latency per row: 73 us for the 64 rows)
+  // 1. the valid mask of every group: wavefront wv votes on groups 64 wv .. 64 wv + 63, their counts requested 32 rows
+  //    at a time (a loop that asks for one row, waits and votes runs at one memory latency per row)
 #pragma unroll
   for (int k0 = 0; k0 < 64; k0 += 32) {
     float c[32];
@@ -200,22 +206,19 @@ __global__ __launch_bounds__(1024) void interpolate_kernel(float *__restrict__ p
     __syncthreads();
   }
   // (inclusive scans: group g's outside neighbours are entries g-1 and g+1)
-  // 3. every bin's output; the reference resets count / accum of over-counted bins while it walks, and those writes
-  //    must not be seen by the bins that read them as neighbours: remember them, write after a barrier
-  unsigned long long resets = 0;                                 // bit k: the bin of my k-th group is reset
+  // 3. the outputs of this workgroup's groups: 1024 / INTERP_WGS of them, 1024 / INTERP_WGS / 16 per wavefront
+  constexpr int GPW = 1024 / INTERP_WGS / 16;
+  const int g0 = blockIdx.x * (1024 / INTERP_WGS) + wv * GPW;
+  float c[GPW], ac[GPW];
 #pragma unroll
-  for (int k0 = 0; k0 < 64; k0 += 16) {
-  float c[16], ac[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int i = (wv * 64 + k0 + u) * 64 + lane;
+  for (int u = 0; u < GPW; ++u) {
+    const int i = (g0 + u) * 64 + lane;
     c[u] = i < n ? psdCount[i] : 0.0f;
     ac[u] = i < n ? psdAccum[i] : 0.0f;
   }
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int k = k0 + u;
-    const int g = wv * 64 + k;
+  for (int u = 0; u < GPW; ++u) {
+    const int g = g0 + u;
     const int i = g * 64 + lane;
     if (g >= G) continue;
     const unsigned long long m = mask[g];
@@ -223,43 +226,50 @@ __global__ __launch_bounds__(1024) void interpolate_kernel(float *__restrict__ p
     const unsigned long long above = lane < 63 ? (m >> (lane + 1)) : 0ull;
     const int left = below ? g * 64 + 63 - __clzll((long long)below) : (g > 0 ? lastv[cur][g - 1] : -1);
     const int R = above ? i + __ffsll(above) : (g + 1 < 1024 ? firstv[cur][g + 1] : n);
-    if (i >= n) continue;
-    float outv;
-    if ((m >> lane) & 1ull) {
-      const float cnt = c[u];
-      outv = ac[u] / cnt;
-      // the bin that ends a gap is not cap-checked by the reference (Scanner.cpp:92-95)
-      const bool ends_gap = (i > 0) && (left != i - 1);
-      if (!ends_gap && cnt > kCountMax) resets |= 1ull << k;
-    } else {
-      const bool first = (left < 0);
-      if (R >= n) {
-        // trailing zeroes: take the value on the left (default when the whole view is empty)
-        outv = first ? kDefaultBin : psdAccum[left] / psdCount[left];
+    bool reset = false;
+    if (i < n) {
+      float outv;
+      if ((m >> lane) & 1ull) {
+        const float cnt = c[u];
+        outv = ac[u] / cnt;
+        // the bin that ends a gap is not cap-checked by the reference (Scanner.cpp:92-95)
+        const bool ends_gap = (i > 0) && (left != i - 1);
+        reset = !ends_gap && cnt > kCountMax;
       } else {
-        const float rightv = psdAccum[R] / psdCount[R];
-        if (first) {
-          outv = rightv;
+        const bool first = (left < 0);
+        if (R >= n) {
+          // trailing zeroes: take the value on the left (default when the whole view is empty)
+          outv = first ? kDefaultBin : psdAccum[left] / psdCount[left];
         } else {
-          const float leftv = psdAccum[left] / psdCount[left];
-          const unsigned count = (unsigned)(R - left - 1);
-          const unsigned jj = (unsigned)(i - (left + 1));
-          const float tt = (float)((float)jj + .5f) / count;
-          outv = (1 - tt) * leftv + tt * rightv;
+          const float rightv = psdAccum[R] / psdCount[R];
+          if (first) {
+            outv = rightv;
+          } else {
+            const float leftv = psdAccum[left] / psdCount[left];
+            const unsigned count = (unsigned)(R - left - 1);
+            const unsigned jj = (unsigned)(i - (left + 1));
+            const float tt = (float)((float)jj + .5f) / count;
+            outv = (1 - tt) * leftv + tt * rightv;
+          }
         }
       }
+      psd[i] = outv;
     }
-    psd[i] = outv;
+    const unsigned long long rm = __ballot(reset);
+    if (lane == 0) resetMask[g] = rm;
   }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 64; ++k) {
-    if ((resets >> k) & 1ull) {
-      const int i = (wv * 64 + k) * 64 + lane;
-      psdCount[i] = kCountReset;
-      psdAccum[i] = psd[i] * kCountReset;
-    }
+}
+
+// count > 5 -> accum = mean, count = 1 for the bins interpolate_kernel marked (Scanner.cpp:87-90; psd[i] holds the mean)
+__global__ __launch_bounds__(256) void interpolate_reset_kernel(const float *__restrict__ psd, float *__restrict__ psdAccum,
+                                                                float *__restrict__ psdCount, int n,
+                                                                const unsigned long long *__restrict__ resetMask)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if ((resetMask[i >> 6] >> (i & 63)) & 1ull) {
+    psdCount[i] = kCountReset;
+    psdAccum[i] = psd[i] * kCountReset;
   }
 }
 
@@ -291,11 +301,14 @@ hipError_t specview_feed_hist(const SpecViewHist &g, const float *psd, float *ac
   return hipGetLastError();
 }
 
-hipError_t specview_interpolate(float *psd, float *accum, float *cnt, int n, hipStream_t st)
+hipError_t specview_interpolate(float *psd, float *accum, float *cnt, int n, unsigned long long *reset_scratch, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
-  if (n > 65536) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(interpolate_kernel, dim3(1), dim3(1024), 0, st, psd, accum, cnt, n);
+  if (n > 65536 || !reset_scratch) return hipErrorInvalidValue;
+  // only the workgroups that own a group below ceil(n / 64) have anything to do
+  const int groups = (n + 63) / 64, per = 1024 / INTERP_WGS;
+  hipLaunchKernelGGL(interpolate_kernel, dim3((groups + per - 1) / per), dim3(1024), 0, st, psd, accum, cnt, n, reset_scratch);
+  hipLaunchKernelGGL(interpolate_reset_kernel, dim3((n + 255) / 256), dim3(256), 0, st, psd, accum, cnt, n, reset_scratch);
   return hipGetLastError();
 }
 
