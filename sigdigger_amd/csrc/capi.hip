@@ -414,11 +414,16 @@ SUBOOL suamd_psd_feed(suamd_psd_t *p, const suamd_complex *d_x, SUSCOUNT nframes
   if (p->log2n > 14) {
     // FFTWidget offers 2^9..2^20 (Default/FFT/FFTWidget.cpp:350-351) and the scanner uses
     // nextPow2(fs / 1 kHz) (Panoramic/Scanner.cpp:323): frames beyond the LDS go pass by pass through HBM
-    const size_t cb = sizeof(suamd_complex) * (size_t)p->n;
+    // (batches of up to 16 Mi points = 128 MiB per ping-pong buffer, the whole job if it is smaller)
+    long long batch = (1ll << 24) / (long long)p->n;
+    if (batch > nout * (long long)navg) batch = nout * (long long)navg;
+    if (const char *e = getenv("SUAMD_PSD_LARGE_BATCH")) { const long long v = atoll(e); if (v >= 1 && v < batch) batch = v; }   // tests: awkward batch boundaries
+    if (batch < 1) batch = 1;
+    const size_t cb = sizeof(suamd_complex) * (size_t)p->n * (size_t)batch;
     if (!p->partial.reserve(2 * cb + sizeof(float) * (size_t)p->n)) { set_err("scratch allocation failed"); return SU_FALSE; }
     char *base = static_cast<char *>(p->partial.p);
     HIP_TRY(sdk::psd_frames_large((int)p->log2n, d_x, (long long)hop, (int)navg, p->d_window, scale, mode, d_out, nout,
-                                  base, base + cb, reinterpret_cast<float *>(base + 2 * cb), as_stream(stream)), SU_FALSE);
+                                  base, base + cb, reinterpret_cast<float *>(base + 2 * cb), (int)batch, as_stream(stream)), SU_FALSE);
     return SU_TRUE;
   }
   const int S = sdk::psd_split(nout, (int)navg, (int)p->log2n);

@@ -256,9 +256,10 @@ hipError_t baud_line(const void *X, int n, int skip, double *res, float *value, 
 hipError_t source_fix(void *x, long long nsamp, int iq_reverse, float *dc, float alpha, int first, float *partial, hipStream_t st);
 
 // ---- fft.hip ----
-hipError_t fft_forward(void *a, void *b, int log2n, void **result, hipStream_t st);
+// batch: that many transforms side by side (n elements apart in both buffers), one launch per pass for all of them
+hipError_t fft_forward(void *a, void *b, int log2n, void **result, hipStream_t st, int batch = 1);
 hipError_t psd_frames_large(int log2n, const void *x, long long hop, int navg, const float *window, float scale,
-                            int mode, float *out, long long nout, void *a, void *b, float *acc, hipStream_t st);
+                            int mode, float *out, long long nout, void *a, void *b, float *acc, int batch, hipStream_t st);
 hipError_t fac_feed(void *a, void *b, int log2n, float alpha, long long view_start, long long view_end, float *absbuf,
                     float *fac, unsigned *mx, unsigned *mn, hipStream_t st);
 hipError_t window_pad(const void *data, long long len, long long alloc, void *buf, hipStream_t st);

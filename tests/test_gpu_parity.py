@@ -99,6 +99,24 @@ def test_psd_large_frames(ctx, sdo, n, nframes, navg):
     assert np.max(np.abs(db - np.stack([sdo.psd_shift_db(f) for f in ref]))) < 5 * DB_TOL
 
 
+def test_psd_large_frames_batches_do_not_change_the_bits(ctx, sdo, monkeypatch):
+    """The large-frame path sends its frames through in batches (one launch per pass for a whole batch); where a batch
+    ends -- inside an output, on its last frame, several outputs later -- must not show in the result."""
+    n, nframes, navg = 32768, 40, 13
+    x = synth.tone_noise(n * nframes, f_rel=-0.1203, sigma2=1e-2, seed=5)
+    psd = engine.PSD(ctx, n, engine.WINDOW_BLACKMANN_HARRIS)
+    whole = host(psd.feed(dev(x), nframes=nframes, navg=navg, scale=1.0 / n))              # one batch of 39 frames
+    assert whole.shape == (3, n)
+    for b in ("1", "7", "13", "20"):
+        monkeypatch.setenv("SUAMD_PSD_LARGE_BATCH", b)
+        part = host(psd.feed(dev(x), nframes=nframes, navg=navg, scale=1.0 / n))
+        assert np.array_equal(part.view(np.uint32), whole.view(np.uint32)), b
+    monkeypatch.delenv("SUAMD_PSD_LARGE_BATCH")
+    ref = sdo.psd_frames(x, nframes, n, n, sdo.window(4, n), navg=navg, scale=1.0 / n)
+    err = np.max(np.abs(whole - ref), axis=1) / np.max(ref, axis=1)
+    assert np.all(err < PSD_TOL), err
+
+
 def test_psd_split_frame_accumulation(ctx, sdo):
     """many frames averaged into few outputs: the frames of one output are split over several
     workgroups and reduced in a fixed order (deterministic, run-to-run identical)."""
