@@ -58,11 +58,13 @@ template <> __device__ __forceinline__ void dft<16>(cf *v)
 
 // one Stockham pass: butterfly j reads in[j + q*N/R], multiplies by W_(Ns*R)^(q*k), k = j mod Ns,
 // writes out[(j - k)*R + k + q*Ns]
-// (blockIdx.y: the transform of a batch, n elements apart in both buffers)
-template <int R>
-__global__ void fft_pass_kernel(const cf *__restrict__ in, cf *__restrict__ out, long long n, long long ns)
+// (blockIdx.y: the transform of a batch, n elements apart in both buffers -- `in_stride` apart in the input of a WINDOWED
+// first pass, which reads the raw samples and applies the window on the way in: one round trip through HBM less)
+template <int R, bool WINDOWED>
+__global__ void fft_pass_kernel(const cf *__restrict__ in, cf *__restrict__ out, long long n, long long ns,
+                                long long in_stride, const float *__restrict__ window)
 {
-  in += (long long)blockIdx.y * n;
+  in += (long long)blockIdx.y * (WINDOWED ? in_stride : n);
   out += (long long)blockIdx.y * n;
   const long long nb = n / R;
   for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < nb;
@@ -71,6 +73,10 @@ __global__ void fft_pass_kernel(const cf *__restrict__ in, cf *__restrict__ out,
     cf v[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) v[q] = in[j + q * nb];
+    if (WINDOWED) {
+#pragma unroll
+      for (int q = 0; q < R; ++q) { const float w = window[j + q * nb]; v[q] = cf{v[q].x * w, v[q].y * w}; }
+    }
     if (ns > 1) {
       // angle(q) = -2 pi q k / (ns R): q k / (ns R) is a dyadic rational, exact in binary32 for n <= 2^24
       const float base = -2.0f * (float)k / (float)(ns * R);
@@ -196,19 +202,6 @@ __global__ __launch_bounds__(256) void centroid_kernel(const float2 *__restrict_
 }
 
 // large PSD frames (N > 16384): buf = window .* frame
-// (blockIdx.y: the frame of a batch, `hop` samples apart in x, n apart in buf)
-__global__ void frame_window_kernel(const float2 *__restrict__ x, long long hop, const float *__restrict__ window, long long n,
-                                    float2 *__restrict__ buf)
-{
-  x += (long long)blockIdx.y * hop;
-  buf += (long long)blockIdx.y * n;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float2 v = x[i];
-    const float w = window[i];
-    buf[i] = float2{v.x * w, v.y * w};
-  }
-}
-
 // The nb frames F0 .. F0 + nb - 1 of a batch fold into their outputs (frame F belongs to output F / navg): per bin the
 // powers are summed in frame order -- the sum an output's frames build is the same whatever the batch size --, an output
 // whose last frame is in the batch is scaled and written (optional fftshift + dB), one that continues in the next batch
@@ -286,30 +279,49 @@ __global__ void fac_ema_kernel(float *__restrict__ fac, const float *__restrict_
     fac[i] += alpha * (a[i] / m - fac[i]);
 }
 
-// forward FFT of n = 2^log2n points; a and b are ping-pong buffers (input in a); returns the
-// buffer holding the result through *result
-hipError_t fft_forward(void *a, void *b, int log2n, void **result, hipStream_t st, int batch)
+// the passes of `batch` forward FFTs of n = 2^log2n points between the ping-pong buffers a and b; with first_in the first
+// pass reads frames `first_stride` apart from there, windowed, instead of from a
+static hipError_t fft_forward_from(const cf *first_in, long long first_stride, const float *window, void *a, void *b,
+                                   int log2n, void **result, hipStream_t st, int batch)
 {
   const long long n = 1ll << log2n;
   cf *src = reinterpret_cast<cf *>(a), *dst = reinterpret_cast<cf *>(b);
   long long ns = 1;
   int bits = log2n;
+  bool first = first_in != nullptr;                            // the first pass reads the raw frames and windows them
   while (bits > 0) {
     const int rb = bits >= 4 ? 4 : bits;
     const long long nb = n >> rb;
     const dim3 grid(grid_for(nb, 256), (unsigned)batch), block(256);
-    switch (rb) {
-      case 4: hipLaunchKernelGGL(fft_pass_kernel<16>, grid, block, 0, st, src, dst, n, ns); break;
-      case 3: hipLaunchKernelGGL(fft_pass_kernel<8>, grid, block, 0, st, src, dst, n, ns); break;
-      case 2: hipLaunchKernelGGL(fft_pass_kernel<4>, grid, block, 0, st, src, dst, n, ns); break;
-      default: hipLaunchKernelGGL(fft_pass_kernel<2>, grid, block, 0, st, src, dst, n, ns); break;
+    if (first) {
+      switch (rb) {
+        case 4: hipLaunchKernelGGL((fft_pass_kernel<16, true>), grid, block, 0, st, first_in, dst, n, ns, first_stride, window); break;
+        case 3: hipLaunchKernelGGL((fft_pass_kernel<8, true>), grid, block, 0, st, first_in, dst, n, ns, first_stride, window); break;
+        case 2: hipLaunchKernelGGL((fft_pass_kernel<4, true>), grid, block, 0, st, first_in, dst, n, ns, first_stride, window); break;
+        default: hipLaunchKernelGGL((fft_pass_kernel<2, true>), grid, block, 0, st, first_in, dst, n, ns, first_stride, window); break;
+      }
+    } else {
+      switch (rb) {
+        case 4: hipLaunchKernelGGL((fft_pass_kernel<16, false>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        case 3: hipLaunchKernelGGL((fft_pass_kernel<8, false>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        case 2: hipLaunchKernelGGL((fft_pass_kernel<4, false>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        default: hipLaunchKernelGGL((fft_pass_kernel<2, false>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+      }
     }
+    first = false;
     ns <<= rb;
     bits -= rb;
     cf *t = src; src = dst; dst = t;
   }
   *result = src;
   return hipGetLastError();
+}
+
+// forward FFT of n = 2^log2n points; a and b are ping-pong buffers (input in a); returns the
+// buffer holding the result through *result
+hipError_t fft_forward(void *a, void *b, int log2n, void **result, hipStream_t st, int batch)
+{
+  return fft_forward_from(nullptr, 0, nullptr, a, b, log2n, result, st, batch);
 }
 
 // PSD of frames too large for the in-LDS kernel: window -> Stockham passes through HBM -> power, navg frames accumulated
@@ -324,10 +336,9 @@ hipError_t psd_frames_large(int log2n, const void *x, long long hop, int navg, c
   if (batch < 1) batch = 1;
   for (long long F0 = 0; F0 < total; F0 += batch) {
     const int nb = total - F0 < batch ? (int)(total - F0) : batch;
-    hipLaunchKernelGGL(frame_window_kernel, dim3(grid_for(n, 256), (unsigned)nb), dim3(256), 0, st, xx + F0 * hop, hop,
-                       window, n, reinterpret_cast<float2 *>(a));
+    // (the first pass reads the frames where they lie and writes into b; from there on the buffers alternate)
     void *res = nullptr;
-    hipError_t e = fft_forward(a, b, log2n, &res, st, nb);
+    hipError_t e = fft_forward_from(reinterpret_cast<const cf *>(xx + F0 * hop), hop, window, a, b, log2n, &res, st, nb);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(frame_power_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st,
                        reinterpret_cast<const float2 *>(res), n, F0, nb, navg, acc, scale / (float)navg, mode, out);
