@@ -60,7 +60,8 @@ template <> __device__ __forceinline__ void dft<16>(cf *v)
 // writes out[(j - k)*R + k + q*Ns]
 // (blockIdx.y: the transform of a batch, n elements apart in both buffers -- `in_stride` apart in the input of a WINDOWED
 // first pass, which reads the raw samples and applies the window on the way in: one round trip through HBM less)
-template <int R, bool WINDOWED>
+// POWER (the PSD's last pass): |X|^2 is written instead of X, as floats at the head of the frame's slot of `out`
+template <int R, bool WINDOWED, bool POWER = false>
 __global__ void fft_pass_kernel(const cf *__restrict__ in, cf *__restrict__ out, long long n, long long ns,
                                 long long in_stride, const float *__restrict__ window)
 {
@@ -89,8 +90,14 @@ __global__ void fft_pass_kernel(const cf *__restrict__ in, cf *__restrict__ out,
     }
     dft<R>(v);
     const long long j0 = (j - k) * R + k;
+    if (POWER) {
+      float *po = reinterpret_cast<float *>(out);
 #pragma unroll
-    for (int q = 0; q < R; ++q) out[j0 + q * ns] = v[q];
+      for (int q = 0; q < R; ++q) po[j0 + q * ns] = v[q].x * v[q].x + v[q].y * v[q].y;
+    } else {
+#pragma unroll
+      for (int q = 0; q < R; ++q) out[j0 + q * ns] = v[q];
+    }
   }
 }
 
@@ -214,8 +221,7 @@ __global__ void frame_power_kernel(const float2 *__restrict__ X, long long n, lo
     int r = (int)(F0 % navg);                                  // position of the batch's first frame inside its output
     long long o = F0 / navg;
     for (int f = 0; f < nb; ++f) {
-      const float2 v = X[(long long)f * n + i];
-      const float q = v.x * v.x + v.y * v.y;
+      const float q = reinterpret_cast<const float *>(X + (long long)f * n)[i];     // |X_f[i]|^2, left there by the last pass
       p = r == 0 ? q : q + (f == 0 ? acc[i] : p);
       if (++r == navg) {
         const float ps = p * sc;
@@ -280,9 +286,10 @@ __global__ void fac_ema_kernel(float *__restrict__ fac, const float *__restrict_
 }
 
 // the passes of `batch` forward FFTs of n = 2^log2n points between the ping-pong buffers a and b; with first_in the first
-// pass reads frames `first_stride` apart from there, windowed, instead of from a
+// pass reads frames `first_stride` apart from there, windowed, instead of from a; with power_last the last pass leaves
+// |X|^2 (floats at the head of every frame's slot) instead of X
 static hipError_t fft_forward_from(const cf *first_in, long long first_stride, const float *window, void *a, void *b,
-                                   int log2n, void **result, hipStream_t st, int batch)
+                                   int log2n, void **result, hipStream_t st, int batch, bool power_last = false)
 {
   const long long n = 1ll << log2n;
   cf *src = reinterpret_cast<cf *>(a), *dst = reinterpret_cast<cf *>(b);
@@ -299,6 +306,13 @@ static hipError_t fft_forward_from(const cf *first_in, long long first_stride, c
         case 3: hipLaunchKernelGGL((fft_pass_kernel<8, true>), grid, block, 0, st, first_in, dst, n, ns, first_stride, window); break;
         case 2: hipLaunchKernelGGL((fft_pass_kernel<4, true>), grid, block, 0, st, first_in, dst, n, ns, first_stride, window); break;
         default: hipLaunchKernelGGL((fft_pass_kernel<2, true>), grid, block, 0, st, first_in, dst, n, ns, first_stride, window); break;
+      }
+    } else if (power_last && bits == rb) {
+      switch (rb) {
+        case 4: hipLaunchKernelGGL((fft_pass_kernel<16, false, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        case 3: hipLaunchKernelGGL((fft_pass_kernel<8, false, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        case 2: hipLaunchKernelGGL((fft_pass_kernel<4, false, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        default: hipLaunchKernelGGL((fft_pass_kernel<2, false, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
       }
     } else {
       switch (rb) {
@@ -338,7 +352,7 @@ hipError_t psd_frames_large(int log2n, const void *x, long long hop, int navg, c
     const int nb = total - F0 < batch ? (int)(total - F0) : batch;
     // (the first pass reads the frames where they lie and writes into b; from there on the buffers alternate)
     void *res = nullptr;
-    hipError_t e = fft_forward_from(reinterpret_cast<const cf *>(xx + F0 * hop), hop, window, a, b, log2n, &res, st, nb);
+    hipError_t e = fft_forward_from(reinterpret_cast<const cf *>(xx + F0 * hop), hop, window, a, b, log2n, &res, st, nb, true);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(frame_power_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st,
                        reinterpret_cast<const float2 *>(res), n, F0, nb, navg, acc, scale / (float)navg, mode, out);
