@@ -61,7 +61,10 @@ template <> __device__ __forceinline__ void dft<16>(cf *v)
 // (blockIdx.y: the transform of a batch, n elements apart in both buffers -- `in_stride` apart in the input of a WINDOWED
 // first pass, which reads the raw samples and applies the window on the way in: one round trip through HBM less)
 // POWER (the PSD's last pass): |X|^2 is written instead of X, as floats at the head of the frame's slot of `out`
-template <int R, bool WINDOWED, bool POWER = false>
+// FASTTW (the PSD's passes): the powers 1, 2, 4, 8 of the butterfly's twiddle are evaluated, the others are one product each
+// (15 sincospif per radix-16 butterfly are four times the arithmetic of the butterfly itself); the Tasks' one-shot
+// transforms keep every twiddle exact
+template <int R, bool WINDOWED, bool POWER = false, bool FASTTW = false>
 __global__ void fft_pass_kernel(const cf *__restrict__ in, cf *__restrict__ out, long long n, long long ns,
                                 long long in_stride, const float *__restrict__ window)
 {
@@ -81,11 +84,21 @@ __global__ void fft_pass_kernel(const cf *__restrict__ in, cf *__restrict__ out,
     if (ns > 1) {
       // angle(q) = -2 pi q k / (ns R): q k / (ns R) is a dyadic rational, exact in binary32 for n <= 2^24
       const float base = -2.0f * (float)k / (float)(ns * R);
+      if (FASTTW) {
+        cf w[R];
 #pragma unroll
-      for (int q = 1; q < R; ++q) {
-        float sn, cs;
-        sincospif(base * (float)q, &sn, &cs);
-        v[q] = cmul(v[q], cf{cs, sn});
+        for (int q = 1; q < R; q <<= 1) { float sn, cs; sincospif(base * (float)q, &sn, &cs); w[q] = cf{cs, sn}; }
+#pragma unroll
+        for (int q = 3; q < R; ++q) if (q & (q - 1)) { const int hi = 1 << (31 - __builtin_clz(q)); w[q] = cmul(w[q - hi], w[hi]); }
+#pragma unroll
+        for (int q = 1; q < R; ++q) v[q] = cmul(v[q], w[q]);
+      } else {
+#pragma unroll
+        for (int q = 1; q < R; ++q) {
+          float sn, cs;
+          sincospif(base * (float)q, &sn, &cs);
+          v[q] = cmul(v[q], cf{cs, sn});
+        }
       }
     }
     dft<R>(v);
@@ -309,10 +322,17 @@ static hipError_t fft_forward_from(const cf *first_in, long long first_stride, c
       }
     } else if (power_last && bits == rb) {
       switch (rb) {
-        case 4: hipLaunchKernelGGL((fft_pass_kernel<16, false, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
-        case 3: hipLaunchKernelGGL((fft_pass_kernel<8, false, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
-        case 2: hipLaunchKernelGGL((fft_pass_kernel<4, false, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
-        default: hipLaunchKernelGGL((fft_pass_kernel<2, false, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        case 4: hipLaunchKernelGGL((fft_pass_kernel<16, false, true, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        case 3: hipLaunchKernelGGL((fft_pass_kernel<8, false, true, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        case 2: hipLaunchKernelGGL((fft_pass_kernel<4, false, true, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        default: hipLaunchKernelGGL((fft_pass_kernel<2, false, true, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+      }
+    } else if (power_last) {                                    // a middle pass of the PSD
+      switch (rb) {
+        case 4: hipLaunchKernelGGL((fft_pass_kernel<16, false, false, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        case 3: hipLaunchKernelGGL((fft_pass_kernel<8, false, false, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        case 2: hipLaunchKernelGGL((fft_pass_kernel<4, false, false, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        default: hipLaunchKernelGGL((fft_pass_kernel<2, false, false, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
       }
     } else {
       switch (rb) {
