@@ -64,7 +64,8 @@ template <> __device__ __forceinline__ void dft<16>(cf *v)
 // FASTTW (the PSD's passes): the powers 1, 2, 4, 8 of the butterfly's twiddle are evaluated, the others are one product each
 // (15 sincospif per radix-16 butterfly are four times the arithmetic of the butterfly itself); the Tasks' one-shot
 // transforms keep every twiddle exact
-template <int R, bool WINDOWED, bool POWER = false, bool FASTTW = false>
+// STAGED: see the store at the end (passes with ns < 256 of the batched PSD)
+template <int R, bool WINDOWED, bool POWER = false, bool FASTTW = false, bool STAGED = false>
 __global__ void fft_pass_kernel(const cf *__restrict__ in, cf *__restrict__ out, long long n, long long ns,
                                 long long in_stride, const float *__restrict__ window)
 {
@@ -107,6 +108,20 @@ __global__ void fft_pass_kernel(const cf *__restrict__ in, cf *__restrict__ out,
       float *po = reinterpret_cast<float *>(out);
 #pragma unroll
       for (int q = 0; q < R; ++q) po[j0 + q * ns] = v[q].x * v[q].x + v[q].y * v[q].y;
+    } else if (STAGED) {
+      // ns < 256: the 256 consecutive butterflies of the workgroup fill one contiguous run of 256 R outputs, but each
+      // store of a wavefront would touch 64 lines (stride R for ns = 1, runs of ns otherwise).  Through LDS the run
+      // goes out as whole rows.  (the grid-stride loop is uniform: nb is a multiple of the grid's 256-thread blocks)
+      __shared__ cf stage[256 * R + 16 * R];                    // one slot of padding every 16 (stride-R writes: see psd.hip)
+      auto pad = [](int i) { return i + (i >> 4); };
+      const int jl = threadIdx.x, kl = (int)k;                  // ns divides 256: k = j mod ns = jl mod ns
+      __syncthreads();                                          // the previous trip's copy-out is done
+#pragma unroll
+      for (int q = 0; q < R; ++q) stage[pad((jl - kl) * R + kl + q * (int)ns)] = v[q];
+      __syncthreads();
+      cf *dst = out + (j - jl) * R;
+#pragma unroll
+      for (int q = 0; q < R; ++q) dst[q * 256 + jl] = stage[pad(q * 256 + jl)];
     } else {
 #pragma unroll
       for (int q = 0; q < R; ++q) out[j0 + q * ns] = v[q];
@@ -315,10 +330,10 @@ static hipError_t fft_forward_from(const cf *first_in, long long first_stride, c
     const dim3 grid(grid_for(nb, 256), (unsigned)batch), block(256);
     if (first) {
       switch (rb) {
-        case 4: hipLaunchKernelGGL((fft_pass_kernel<16, true>), grid, block, 0, st, first_in, dst, n, ns, first_stride, window); break;
-        case 3: hipLaunchKernelGGL((fft_pass_kernel<8, true>), grid, block, 0, st, first_in, dst, n, ns, first_stride, window); break;
-        case 2: hipLaunchKernelGGL((fft_pass_kernel<4, true>), grid, block, 0, st, first_in, dst, n, ns, first_stride, window); break;
-        default: hipLaunchKernelGGL((fft_pass_kernel<2, true>), grid, block, 0, st, first_in, dst, n, ns, first_stride, window); break;
+        case 4: hipLaunchKernelGGL((fft_pass_kernel<16, true, false, false, true>), grid, block, 0, st, first_in, dst, n, ns, first_stride, window); break;
+        case 3: hipLaunchKernelGGL((fft_pass_kernel<8, true, false, false, true>), grid, block, 0, st, first_in, dst, n, ns, first_stride, window); break;
+        case 2: hipLaunchKernelGGL((fft_pass_kernel<4, true, false, false, true>), grid, block, 0, st, first_in, dst, n, ns, first_stride, window); break;
+        default: hipLaunchKernelGGL((fft_pass_kernel<2, true, false, false, true>), grid, block, 0, st, first_in, dst, n, ns, first_stride, window); break;
       }
     } else if (power_last && bits == rb) {
       switch (rb) {
@@ -326,6 +341,13 @@ static hipError_t fft_forward_from(const cf *first_in, long long first_stride, c
         case 3: hipLaunchKernelGGL((fft_pass_kernel<8, false, true, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
         case 2: hipLaunchKernelGGL((fft_pass_kernel<4, false, true, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
         default: hipLaunchKernelGGL((fft_pass_kernel<2, false, true, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+      }
+    } else if (power_last && ns < 256 && nb % (256ll * grid.x) == 0) {   // a middle pass of the PSD whose stores would scatter
+      switch (rb) {
+        case 4: hipLaunchKernelGGL((fft_pass_kernel<16, false, false, true, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        case 3: hipLaunchKernelGGL((fft_pass_kernel<8, false, false, true, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        case 2: hipLaunchKernelGGL((fft_pass_kernel<4, false, false, true, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
+        default: hipLaunchKernelGGL((fft_pass_kernel<2, false, false, true, true>), grid, block, 0, st, src, dst, n, ns, 0ll, nullptr); break;
       }
     } else if (power_last) {                                    // a middle pass of the PSD
       switch (rb) {
