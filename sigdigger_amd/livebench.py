@@ -12,7 +12,7 @@ import numpy as np
 from . import suscan
 
 
-def live_rate(n_inspectors=64, nblocks=40, fs=50_000_000, nfft=8192, block=1 << 21, timeout_s=60.0):
+def live_rate(n_inspectors=64, nblocks=40, fs=50_000_000, nfft=8192, block=1 << 21, timeout_s=60.0, cls=b"psk"):
     Lb = suscan.load()
     d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     path = os.path.join(d, "cap.raw")
@@ -38,7 +38,7 @@ def live_rate(n_inspectors=64, nblocks=40, fs=50_000_000, nfft=8192, block=1 << 
             fc = (k - n_inspectors / 2 + 0.5) * spacing
             bw = (100e3 + 10e3 * (k % 7)) * spacing / 300e3
             ch = suscan.Channel(fc=float(fc), f_lo=float(fc - bw / 2), f_hi=float(fc + bw / 2), bw=float(bw), ft=100e6)
-            assert Lb.suscan_analyzer_open_ex_async(an, b"psk", C.byref(ch), 1, -1, 1000 + k)
+            assert Lb.suscan_analyzer_open_ex_async(an, cls, C.byref(ch), 1, -1, 1000 + k)
         st = {"psd": 0, "sym": 0, "t0": None, "cfg": 0, "result": None}
         deadline = time.time() + timeout_s
         while True:
