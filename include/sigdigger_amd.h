@@ -175,6 +175,18 @@ SUAMD_API SUBOOL suamd_specttuner_feed_rows(suamd_specttuner_t *st, const suamd_
                                             suamd_complex *const *d_rows, SUSCOUNT *counts, void *stream);
 /* windows per workgroup run (default 3): a run re-transforms the window before it */
 SUAMD_API SUBOOL suamd_specttuner_set_run(suamd_specttuner_t *st, unsigned run);
+/* Entries a `counts` array passed to suamd_specttuner_feed / _feed_rows must hold: one per slot of the tuner's channel
+ * table (slots of closed channels are reused but the table never shrinks), i.e. the highest index ever returned by
+ * _open_channel plus one.  A feed zeroes every entry and fills those of the open channels. */
+SUAMD_API unsigned suamd_specttuner_channel_capacity(const suamd_specttuner_t *st);
+/* Forgets the stream position: the half-window history and every channel's cross-fade partner (the next feed starts
+ * like the first one: a whole window before anything comes out, y_{-1} = 0).  For a seek in the source, or when
+ * feeding resumes after a gap.  Channels stay open; their output counters (the `precise` NCO's phase) run on. */
+SUAMD_API SUBOOL suamd_specttuner_reset(suamd_specttuner_t *st, void *stream);
+/* The design of a channel without a device (host arithmetic only, SPEC.md C2): geometry and the binary32 response
+ * k h[i] the kernels multiply the picked bins with.  geom[0..5] = size, halfsz, halfw, decimation, center, dphase;
+ * hk (may be NULL) receives 2 * size floats (re, im interleaved).  Returns SU_FALSE on bad parameters. */
+SUAMD_API SUBOOL suamd_specttuner_design(unsigned window_size, double f0, double bw, double guard, uint32_t geom[6], SUFLOAT *hk);
 
 /* ------------------------------------------------------------------------------------ */
 /* T1 / K4: NCO carrier translate                                                        */

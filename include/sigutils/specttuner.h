@@ -20,16 +20,17 @@ extern "C" {
 #endif
 
 struct sigutils_specttuner_params {
-  SUSCOUNT window_size;                      /* power of two, 64 .. 16384 */
+  SUSCOUNT window_size;                      /* 4096 (su_specttuner's default, the only size the kernels are built for):
+                                              * su_specttuner_new returns NULL for anything else, suamd_last_error() says why */
   SUBOOL   early_windowing;                  /* accepted for source compatibility; the response is applied per channel */
 };
 #define sigutils_specttuner_params_INITIALIZER { 4096, SU_TRUE }
 
 struct sigutils_specttuner_channel;
 struct sigutils_specttuner_channel_params {
-  SUFLOAT f0;                                /* centre, angular frequency (rad / sample), [0, 2 pi) */
+  SUFLOAT f0;                                /* centre, angular frequency (rad / sample); taken modulo 2 pi (must be finite) */
   SUFLOAT delta_f;                           /* accepted, unused */
-  SUFLOAT bw;                                /* bandwidth, angular frequency */
+  SUFLOAT bw;                                /* bandwidth, angular frequency, > 0 (bw * guard is clipped to 2 pi); else NULL */
   SUFLOAT guard;                             /* relative guard band, >= 1: the channel is sized for bw * guard */
   SUBOOL  precise;                           /* correct the residual of the centre-bin rounding with an NCO */
   void   *privdata;

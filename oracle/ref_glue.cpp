@@ -6,10 +6,11 @@
  *
  *   ref_*()   extern "C" entry points that construct the reference's classes (SigDigger::Averager, Suscan::PSDMessage,
  *             the Tasks/ work loops, Panoramic SpectrumView, SNREstimator) and run them on caller-supplied arrays;
- *   su_*()    the per-sample libsigutils calls the Tasks make (libsigutils is absent): served by the oracle's per-sample
- *             restatements, so a Task pins its own loop structure, block handling and parameter mapping
- *             (Tasks/AGCTask.cpp:22-47, Tasks/CostasRecoveryTask.cpp:36-41, Tasks/CarrierXlator.cpp:36-37) -- not the
- *             upstream primitive, which stays "parity unpinned";
+ *   su_*()    the per-sample libsigutils calls the Tasks make (libsigutils is absent) are NOT here: they resolve in the
+ *             product library (csrc/sigutils_host.cpp), so a Task run through ref_*() is the reference's unchanged loop on
+ *             the product's per-sample implementation; tests/test_ref_pin.py compares that with the oracle's restatement
+ *             bit for bit -- two independent implementations of SPEC.md D - H.  The upstream primitive itself stays
+ *             "parity unpinned";
  *   fftwf_*   FFTW3f's five calls (absent) on the oracle's binary64 FFT, rounded to binary32.
  *
  * Nothing under sigdigger_amd/ or include/ refers to this file.
@@ -51,77 +52,12 @@
 static inline sdo_c32 to_sdo(SUCOMPLEX x) { sdo_c32 r = { x.real(), x.imag() }; return r; }
 static inline SUCOMPLEX from_sdo(sdo_c32 x) { return SUCOMPLEX(x.re, x.im); }
 
-/* ======================= libsigutils per-sample calls, on the oracle ======================= */
+/* ======================= FFTW3f (absent; SigDigger links it itself) on the oracle's FFT ======================= */
+/* The per-sample libsigutils calls the Tasks make (su_ncqo_*, su_pll_*, su_costas_*, su_agc_*, su_clock_detector_*,
+ * su_taps_apply_blackmann_harris_complex) are NOT defined here any more: the Tasks' objects resolve them in the PRODUCT
+ * library (sigdigger_amd/csrc/sigutils_host.cpp; the link is --no-undefined), through the product's own headers
+ * include/sigutils/{ncqo,pll,agc,clock,iir,taps}.h -- north_star: "Tasks/ ... link unchanged". */
 extern "C" {
-
-void su_ncqo_init(su_ncqo_t *n, SUFLOAT fnor) { n->phase = 0; n->n = 0; n->dphase = sdo_fnor_to_dphase((double)fnor); }
-void su_ncqo_set_phase(su_ncqo_t *n, SUFLOAT phi)
-{
-  /* radians -> 2^32 per turn (SPEC.md section B) */
-  n->phase = (uint32_t)(int64_t)llround((double)phi / (2.0 * M_PI) * 4294967296.0);
-}
-SUCOMPLEX su_ncqo_read(su_ncqo_t *n)
-{
-  float c, s;
-  sdo_phasor_u32(n->phase + (uint32_t)n->n * n->dphase, &c, &s);
-  ++n->n;
-  return SUCOMPLEX(c, s);
-}
-
-SUBOOL su_pll_init(su_pll_t *p, SUFLOAT fhint, SUFLOAT fc) { return sdo_pll_init(&p->impl, fhint, fc) ? SU_TRUE : SU_FALSE; }
-SUCOMPLEX su_pll_track(su_pll_t *p, SUCOMPLEX x) { return from_sdo(sdo_pll_track(&p->impl, to_sdo(x))); }
-void su_pll_finalize(su_pll_t *) {}
-
-SUBOOL su_costas_init(su_costas_t *c, enum sigutils_costas_kind kind, SUFLOAT fhint, SUFLOAT arm_bw, unsigned int arm_order,
-                      SUFLOAT loop_bw)
-{
-  return sdo_costas_init(&c->impl, (int)kind, fhint, arm_bw, arm_order, loop_bw) ? SU_TRUE : SU_FALSE;
-}
-SUCOMPLEX su_costas_feed(su_costas_t *c, SUCOMPLEX x) { return from_sdo(sdo_costas_feed(&c->impl, to_sdo(x))); }
-void su_costas_finalize(su_costas_t *) {}
-
-SUBOOL su_agc_init(su_agc_t *a, const struct su_agc_params *p)
-{
-  sdo_agc_params q;
-  q.threshold = p->threshold; q.slope_factor = p->slope_factor; q.hang_max = p->hang_max;
-  q.delay_line_size = p->delay_line_size; q.mag_history_size = p->mag_history_size;
-  q.fast_rise_t = p->fast_rise_t; q.fast_fall_t = p->fast_fall_t; q.slow_rise_t = p->slow_rise_t; q.slow_fall_t = p->slow_fall_t;
-  return sdo_agc_init(&a->impl, &q) ? SU_TRUE : SU_FALSE;
-}
-SUCOMPLEX su_agc_feed(su_agc_t *a, SUCOMPLEX x) { return from_sdo(sdo_agc_feed(&a->impl, to_sdo(x))); }
-void su_agc_finalize(su_agc_t *) {}
-
-SUBOOL su_clock_detector_init(su_clock_detector_t *cd, SUFLOAT loop_gain, SUFLOAT bhint, SUSCOUNT bufsiz)
-{
-  if (sdo_clock_init(&cd->impl, loop_gain, bhint) == -1) return -1;     /* compared with -1: Tasks/WaveSampler.cpp:60-65 */
-  cd->size = 4 * bufsiz + 16;
-  cd->buf = static_cast<SUCOMPLEX *>(std::malloc(cd->size * sizeof(SUCOMPLEX)));
-  cd->avail = 0;
-  return cd->buf ? SU_TRUE : -1;
-}
-void su_clock_detector_feed(su_clock_detector_t *cd, SUCOMPLEX x)
-{
-  sdo_c32 in = to_sdo(x), out[4];
-  const size_t n = sdo_clock_feed_bulk(&cd->impl, &in, 1, out);
-  for (size_t i = 0; i < n && cd->avail < cd->size; ++i) cd->buf[cd->avail++] = from_sdo(out[i]);
-}
-SUSDIFF su_clock_detector_read(su_clock_detector_t *cd, SUCOMPLEX *buf, size_t size)
-{
-  const size_t n = cd->avail < size ? cd->avail : size;
-  std::memcpy(static_cast<void *>(buf), cd->buf, n * sizeof(SUCOMPLEX));
-  std::memmove(static_cast<void *>(cd->buf), cd->buf + n, (cd->avail - n) * sizeof(SUCOMPLEX));
-  cd->avail -= n;
-  return (SUSDIFF)n;
-}
-void su_clock_detector_finalize(su_clock_detector_t *cd) { std::free(cd->buf); cd->buf = nullptr; }
-
-SUBOOL su_iir_rrc_init(su_iir_filt_t *, SUSCOUNT, SUFLOAT, SUFLOAT) { return SU_FALSE; }   /* compiled out in the reference */
-void   su_iir_filt_finalize(su_iir_filt_t *) {}
-
-void su_taps_apply_blackmann_harris_complex(SUCOMPLEX *h, SUSCOUNT size)
-{
-  sdo_blackmann_harris_complex(reinterpret_cast<sdo_c32 *>(h), size);
-}
 
 /* ---- FFTW3f ---- */
 struct refshim_fftwf_plan_s { int n; fftwf_complex *in, *out; int sign; };

@@ -1566,6 +1566,332 @@ size_t sdo_specttuner_run(const sdo_c32 *x, size_t len, unsigned W, double f0, d
   return n;
 }
 
+/* ---- C2, the binary32 statement (SPEC.md section C2, "binary32 arithmetic") ---------------------------------------------
+ * The device transforms are binary32; what follows restates, operation for operation, the arithmetic SPEC.md C2 freezes
+ * for them, so that HIP == oracle bit for bit and everything downstream of the channeliser (AGC, Costas, Gardner) can be
+ * compared exactly on the path the analyzer and the bench run by default.  Two forms, chosen by the channel size:
+ *   narrow (size 8 .. 64):  window = 64 x 64: DFT64 (8 x 8, constant twiddles) over r of x[t + 64 r], twiddle
+ *                           W_4096^(t k2), DFT64 over t; response product fused; inverse = DFT_size read backwards;
+ *                           cross-fade fma(beta, prev, alpha cur);
+ *   wide (every other size): window = three radix-16 Stockham passes; response product and cross-fade unfused;
+ *                           inverse = conj(Stockham passes(conj(.))).
+ * Complex product everywhere: re = fma(a.im, -b.im, a.re b.re), im = fma(a.im, b.re, a.re b.im). */
+typedef sdo_c32 cf_t;
+static inline cf_t cf_add(cf_t a, cf_t b) { cf_t r = {a.re + b.re, a.im + b.im}; return r; }
+static inline cf_t cf_sub(cf_t a, cf_t b) { cf_t r = {a.re - b.re, a.im - b.im}; return r; }
+static inline cf_t cf_neg(cf_t a) { cf_t r = {-a.re, -a.im}; return r; }
+static inline cf_t cf_scale(cf_t a, float c) { cf_t r = {a.re * c, a.im * c}; return r; }
+static inline cf_t cf_add_mj(cf_t t, cf_t d) { cf_t r = {t.re + d.im, t.im - d.re}; return r; }       /* t + (-j) d */
+static inline cf_t cf_sub_mj(cf_t t, cf_t d) { cf_t r = {t.re - d.im, t.im + d.re}; return r; }       /* t - (-j) d */
+static inline cf_t cf_mul(cf_t a, cf_t b)
+{
+  cf_t r;
+  r.re = fmaf(a.im, -b.im, a.re * b.re);
+  r.im = fmaf(a.im, b.re, a.re * b.im);
+  return r;
+}
+#define ST32_C8 0.70710678118654752440f
+
+static void st32_dft4(cf_t *a0, cf_t *a1, cf_t *a2, cf_t *a3)
+{
+  const cf_t t0 = cf_add(*a0, *a2), t1 = cf_sub(*a0, *a2), t2 = cf_add(*a1, *a3), d = cf_sub(*a1, *a3);
+  *a0 = cf_add(t0, t2); *a2 = cf_sub(t0, t2); *a1 = cf_add_mj(t1, d); *a3 = cf_sub_mj(t1, d);
+}
+/* e +- o W8^1 and e +- o W8^3 as fused multiply-adds */
+static void st32_bfly_w8_1(cf_t e, cf_t o, cf_t *p, cf_t *m)
+{
+  const cf_t r = cf_add_mj(o, o);
+  p->re = fmaf(r.re, ST32_C8, e.re); p->im = fmaf(r.im, ST32_C8, e.im);
+  m->re = fmaf(r.re, -ST32_C8, e.re); m->im = fmaf(r.im, -ST32_C8, e.im);
+}
+static void st32_bfly_w8_3(cf_t e, cf_t o, cf_t *p, cf_t *m)
+{
+  const cf_t r = cf_add_mj(cf_neg(o), o);
+  p->re = fmaf(r.re, ST32_C8, e.re); p->im = fmaf(r.im, ST32_C8, e.im);
+  m->re = fmaf(r.re, -ST32_C8, e.re); m->im = fmaf(r.im, -ST32_C8, e.im);
+}
+static void st32_dft8(cf_t *v)
+{
+  cf_t e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+  st32_dft4(&e0, &e1, &e2, &e3);
+  st32_dft4(&o0, &o1, &o2, &o3);
+  v[0] = cf_add(e0, o0); v[4] = cf_sub(e0, o0);
+  st32_bfly_w8_1(e1, o1, &v[1], &v[5]);
+  v[2] = cf_add_mj(e2, o2); v[6] = cf_sub_mj(e2, o2);
+  st32_bfly_w8_3(e3, o3, &v[3], &v[7]);
+}
+static void st32_dft16(cf_t *v)
+{
+  const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;
+  cf_t e[8], o[8];
+  int i;
+  for (i = 0; i < 8; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+  st32_dft8(e);
+  st32_dft8(o);
+  o[1] = cf_mul(o[1], (cf_t){ c1, -s1});
+  o[3] = cf_mul(o[3], (cf_t){ s1, -c1});
+  o[5] = cf_mul(o[5], (cf_t){-s1, -c1});
+  o[7] = cf_mul(o[7], (cf_t){-c1, -s1});
+  for (i = 0; i < 8; ++i) {
+    if (i == 4) { v[4] = cf_add_mj(e[4], o[4]); v[12] = cf_sub_mj(e[4], o[4]); }
+    else if (i == 2) st32_bfly_w8_1(e[2], o[2], &v[2], &v[10]);
+    else if (i == 6) st32_bfly_w8_3(e[6], o[6], &v[6], &v[14]);
+    else { v[i] = cf_add(e[i], o[i]); v[i + 8] = cf_sub(e[i], o[i]); }
+  }
+}
+static void st32_dftR(int R, cf_t *v)
+{
+  if (R == 2) { const cf_t t = v[0]; v[0] = cf_add(t, v[1]); v[1] = cf_sub(t, v[1]); }
+  else if (R == 4) st32_dft4(&v[0], &v[1], &v[2], &v[3]);
+  else if (R == 8) st32_dft8(v);
+  else { assert(R == 16); st32_dft16(v); }
+}
+
+static struct { int ready; cf_t w64[64]; cf_t tw[4096]; float win64[64]; } st32_tab;
+static void st32_init(void)
+{
+  int i;
+  if (st32_tab.ready) return;
+  for (i = 0; i < 64; ++i) {
+    const double a = -2.0 * SDO_PI * (double)i / 64.0, s = sin(SDO_PI * (double)i / 64.0);
+    st32_tab.w64[i].re = (float)cos(a); st32_tab.w64[i].im = (float)sin(a);
+    st32_tab.win64[i] = (float)(s * s);
+  }
+  for (i = 0; i < 4096; ++i) {
+    const double a = -2.0 * SDO_PI * (double)i / 4096.0;
+    st32_tab.tw[i].re = (float)cos(a); st32_tab.tw[i].im = (float)sin(a);
+  }
+  st32_tab.ready = 1;
+}
+void sdo_st32_tables(sdo_c32 *w64, float *win64)
+{
+  st32_init();
+  memcpy(w64, st32_tab.w64, sizeof st32_tab.w64);
+  memcpy(win64, st32_tab.win64, sizeof st32_tab.win64);
+}
+/* a W_64^m: the trivial and the 45-degree powers without a product */
+static cf_t st32_mul_w64(cf_t a, int m)
+{
+  m &= 63;
+  switch (m) {
+    case 0:  return a;
+    case 16: return (cf_t){a.im, -a.re};
+    case 32: return cf_neg(a);
+    case 48: return (cf_t){-a.im, a.re};
+    case 8:  return cf_scale(cf_add_mj(a, a), ST32_C8);
+    case 24: return cf_scale(cf_add_mj(cf_neg(a), a), ST32_C8);
+    case 40: return cf_neg(cf_scale(cf_add_mj(a, a), ST32_C8));
+    case 56: return cf_neg(cf_scale(cf_add_mj(cf_neg(a), a), ST32_C8));
+    default: return cf_mul(a, st32_tab.w64[m]);
+  }
+}
+/* N = R1 R2 <= 64 points, natural order in and out: n = n1 + R1 n2, k = k2 + R2 k1 */
+static void st32_dft_2f(int R1, int R2, const cf_t *in, cf_t *out)
+{
+  const int N = R1 * R2;
+  cf_t mid[64], a[8], b[8];
+  int n1, n2, k1, k2;
+  for (n1 = 0; n1 < R1; ++n1) {
+    for (n2 = 0; n2 < R2; ++n2) a[n2] = in[n1 + R1 * n2];
+    st32_dftR(R2, a);
+    for (k2 = 0; k2 < R2; ++k2) mid[n1 + R1 * k2] = st32_mul_w64(a[k2], n1 * k2 * (64 / N));
+  }
+  for (k2 = 0; k2 < R2; ++k2) {
+    for (n1 = 0; n1 < R1; ++n1) b[n1] = mid[n1 + R1 * k2];
+    st32_dftR(R1, b);
+    for (k1 = 0; k1 < R1; ++k1) out[k2 + R2 * k1] = b[k1];
+  }
+}
+static void st32_dft_reg(int log2n, const cf_t *in, cf_t *out)
+{
+  if (log2n == 6) st32_dft_2f(8, 8, in, out);
+  else if (log2n == 5) st32_dft_2f(4, 8, in, out);
+  else { memcpy(out, in, sizeof(cf_t) << log2n); st32_dftR(1 << log2n, out); }
+}
+
+/* narrow form: X = DFT_4096(win) as 64 x 64 */
+void sdo_st32_forward_narrow(const sdo_c32 *win, sdo_c32 *X)
+{
+  cf_t (*Bp)[64] = malloc(sizeof(cf_t) * 64 * 64);       /* B[t][k2] */
+  int t, r, l, h;
+  st32_init();
+  for (t = 0; t < 64; ++t) {
+    cf_t in[64], A[64], lo[8], hi[8];
+    for (r = 0; r < 64; ++r) in[r] = win[t + 64 * r];
+    st32_dft_2f(8, 8, in, A);
+    /* W_4096^(t (8h + l)) = hi[h] lo[l]; the six base powers W^(t 2^j) are table values */
+    lo[1] = st32_tab.tw[(t << 0) & 4095]; lo[2] = st32_tab.tw[(t << 1) & 4095]; lo[4] = st32_tab.tw[(t << 2) & 4095];
+    lo[3] = cf_mul(lo[1], lo[2]); lo[5] = cf_mul(lo[1], lo[4]); lo[6] = cf_mul(lo[2], lo[4]); lo[7] = cf_mul(lo[3], lo[4]);
+    hi[1] = st32_tab.tw[(t << 3) & 4095]; hi[2] = st32_tab.tw[(t << 4) & 4095]; hi[4] = st32_tab.tw[(t << 5) & 4095];
+    hi[3] = cf_mul(hi[1], hi[2]); hi[5] = cf_mul(hi[1], hi[4]); hi[6] = cf_mul(hi[2], hi[4]); hi[7] = cf_mul(hi[3], hi[4]);
+    for (h = 0; h < 8; ++h)
+      for (l = 0; l < 8; ++l) {
+        if (h == 0) { if (l) A[l] = cf_mul(A[l], lo[l]); }
+        else if (l == 0) A[8 * h] = cf_mul(A[8 * h], hi[h]);
+        else A[8 * h + l] = cf_mul(A[8 * h + l], cf_mul(hi[h], lo[l]));
+      }
+    memcpy(Bp[t], A, sizeof A);
+  }
+  for (l = 0; l < 64; ++l) {
+    cf_t v[64], A[64];
+    for (t = 0; t < 64; ++t) v[t] = Bp[t][l];
+    st32_dft_2f(8, 8, v, A);
+    for (r = 0; r < 64; ++r) X[l + 64 * r] = A[r];
+  }
+  free(Bp);
+}
+
+/* Stockham autosort passes, radix <= 16, of fft_core.hpp's plan (MB = 4): ceil(bits / 4) passes, the first (bits % P)
+ * one bit wider.  Twiddles of butterfly j in pass p: W_N^(q idx), idx = (j mod NS) N / (NS R); powers 1 and 2 are table
+ * values, 4 = 2^2, 8 = 4^2, 3 = 1*2, 5 = 1*4, 6 = 2*4, 7 = 3*4, q = (q - 8) * 8 above. */
+static void st32_stockham(int log2n, cf_t *d, cf_t *tmp, const cf_t *tw)
+{
+  const int N = 1 << log2n, P = (log2n + 3) / 4, BASE = log2n / P, EXTRA = log2n % P;
+  int p, nsl = 0, j, q;
+  cf_t *src = d, *dst = tmp;
+  for (p = 0; p < P; ++p) {
+    const int rb = BASE + (p < EXTRA ? 1 : 0), R = 1 << rb, NS = 1 << nsl;
+    for (j = 0; j < N / R; ++j) {
+      const int k = j & (NS - 1), j0 = ((j - k) << rb) + k;
+      cf_t v[16], w[16];
+      for (q = 0; q < R; ++q) v[q] = src[j + q * (N / R)];
+      if (p > 0) {
+        const int idx = k << (log2n - nsl - rb);
+        w[1] = tw[idx & (N - 1)];
+        if (R > 2) w[2] = tw[(2 * idx) & (N - 1)];
+        if (R > 4) w[4] = cf_mul(w[2], w[2]);
+        if (R > 8) w[8] = cf_mul(w[4], w[4]);
+        if (R > 2) w[3] = cf_mul(w[1], w[2]);
+        if (R > 4) { w[5] = cf_mul(w[1], w[4]); w[6] = cf_mul(w[2], w[4]); w[7] = cf_mul(w[3], w[4]); }
+        if (R > 8) for (q = 9; q < 16; ++q) w[q] = cf_mul(w[q - 8], w[8]);
+        for (q = 1; q < R; ++q) v[q] = cf_mul(v[q], w[q]);
+      }
+      st32_dftR(R, v);
+      for (q = 0; q < R; ++q) dst[j0 + q * NS] = v[q];
+    }
+    { cf_t *t = src; src = dst; dst = t; }
+    nsl += rb;
+  }
+  if (src != d) memcpy(d, src, sizeof(cf_t) * (size_t)N);
+}
+
+void sdo_st32_forward_wide(const sdo_c32 *win, sdo_c32 *X)
+{
+  cf_t *tmp = malloc(sizeof(cf_t) * 4096);
+  st32_init();
+  memcpy(X, win, sizeof(cf_t) * 4096);
+  st32_stockham(12, X, tmp, st32_tab.tw);
+  free(tmp);
+}
+
+/* one window of one channel: y[0 .. size) from the window's spectrum (the form follows the size) */
+static void st32_channel(const cf_t *X, unsigned W, const sdo_st_geom *g, const cf_t *hk, const cf_t *tw_s, cf_t *y)
+{
+  const unsigned S = g->size, HS = g->halfsz;
+  unsigned i, log2s = 0;
+  cf_t u[4096], F[4096];
+  while ((1u << log2s) < S) ++log2s;
+  if (S >= 8 && S <= 64) {
+    for (i = 0; i < S; ++i) {
+      const unsigned idx = (i < HS ? (unsigned)g->center + i : (unsigned)g->center + i + W - S) & (W - 1);
+      u[i] = cf_mul(X[idx], hk[i]);
+    }
+    st32_dft_reg((int)log2s, u, F);
+    for (i = 0; i < S; ++i) y[i] = F[(S - i) & (S - 1)];
+  } else {
+    for (i = 0; i < S; ++i) {
+      const unsigned idx = (i < HS ? (unsigned)g->center + i : (unsigned)g->center + i + W - S) & (W - 1);
+      const cf_t x = X[idx], h = hk[i];
+      u[i].re = x.re * h.re - x.im * h.im;
+      u[i].im = -(x.re * h.im + x.im * h.re);
+    }
+    st32_stockham((int)log2s, u, F, tw_s);
+    for (i = 0; i < S; ++i) { y[i].re = u[i].re; y[i].im = -u[i].im; }
+  }
+}
+
+/* A bank of channels over windows [w_begin, w_end) of a stream (window w = samples [w H, w H + W)); every channel opened
+ * at the start of the stream.  Channel c's output block w goes to out[c * row_stride + w * halfsz(c) ...].  w_begin > 0
+ * transforms window w_begin - 1 as well (the cross-fade partner), so ranges can be computed independently.
+ * Returns the number of windows the stream holds. */
+size_t sdo_specttuner_bank_f32(const sdo_c32 *x, size_t len, unsigned nchan, const double *f0, const double *bw, const double *guard,
+                               const int *precise, size_t w_begin, size_t w_end, sdo_c32 *out, size_t row_stride)
+{
+  const unsigned W = 4096, H = 2048;
+  const size_t nwin = len < W ? 0 : (len - W) / H + 1;
+  sdo_st_geom *g = malloc(sizeof *g * (nchan ? nchan : 1));
+  cf_t **hk = calloc(nchan ? nchan : 1, sizeof *hk), **tws = calloc(nchan ? nchan : 1, sizeof *tws), **prev = calloc(nchan ? nchan : 1, sizeof *prev);
+  cf_t *Xn = malloc(sizeof(cf_t) * W), *Xw = malloc(sizeof(cf_t) * W), *y = malloc(sizeof(cf_t) * W);
+  int any_narrow = 0, any_wide = 0;
+  unsigned c, i;
+  size_t w;
+  st32_init();
+  if (w_end > nwin) w_end = nwin;
+  for (c = 0; c < nchan; ++c) {
+    sdo_specttuner_geometry(W, f0[c], bw[c], guard[c], &g[c]);
+    hk[c] = malloc(sizeof(cf_t) * g[c].size);
+    prev[c] = calloc(g[c].size, sizeof(cf_t));
+    sdo_specttuner_response(W, g[c].size, g[c].halfw, hk[c]);
+    if (g[c].size >= 8 && g[c].size <= 64) any_narrow = 1;
+    else {
+      any_wide = 1;
+      tws[c] = malloc(sizeof(cf_t) * g[c].size);
+      for (i = 0; i < g[c].size; ++i) {
+        const double a = -2.0 * SDO_PI * (double)i / (double)g[c].size;
+        tws[c][i].re = (float)cos(a); tws[c][i].im = (float)sin(a);
+      }
+    }
+  }
+  for (w = w_begin > 0 ? w_begin - 1 : 0; w < w_end; ++w) {
+    const int emit = w >= w_begin;
+    if (any_narrow) sdo_st32_forward_narrow(x + w * H, Xn);
+    if (any_wide) sdo_st32_forward_wide(x + w * H, Xw);
+    for (c = 0; c < nchan; ++c) {
+      const unsigned S = g[c].size, HS = g[c].halfsz;
+      const int narrow = S >= 8 && S <= 64;
+      st32_channel(narrow ? Xn : Xw, W, &g[c], hk[c], tws[c], y);
+      if (emit) {
+        cf_t *o = out + (size_t)c * row_stride + w * HS;
+        for (i = 0; i < HS; ++i) {
+          cf_t r;
+          if (narrow) {
+            const float al = st32_tab.win64[i * (64 / S)], be = st32_tab.win64[(i + HS) * (64 / S)];
+            r.re = fmaf(be, prev[c][i + HS].re, y[i].re * al);
+            r.im = fmaf(be, prev[c][i + HS].im, y[i].im * al);
+          } else {
+            const double sa = sin(SDO_PI * (double)i / (double)S), sb = sin(SDO_PI * (double)(i + HS) / (double)S);
+            const float al = (float)(sa * sa), be = (float)(sb * sb);
+            r.re = al * y[i].re + be * prev[c][i + HS].re;
+            r.im = al * y[i].im + be * prev[c][i + HS].im;
+          }
+          if (precise && precise[c]) {
+            float cs, sn;
+            sdo_phasor_u32((uint32_t)(w * HS + i) * g[c].dphase, &cs, &sn);
+            if (narrow) { const cf_t t = {fmaf(r.re, cs, -(r.im * sn)), fmaf(r.re, sn, r.im * cs)}; r = t; }
+            else { const cf_t t = {r.re * cs - r.im * sn, r.re * sn + r.im * cs}; r = t; }
+          }
+          o[i] = r;
+        }
+      }
+      memcpy(prev[c], y, sizeof(cf_t) * S);
+    }
+  }
+  for (c = 0; c < nchan; ++c) { free(hk[c]); free(tws[c]); free(prev[c]); }
+  free(g); free(hk); free(tws); free(prev); free(Xn); free(Xw); free(y);
+  return nwin;
+}
+
+size_t sdo_specttuner_run_f32(const sdo_c32 *x, size_t len, double f0, double bw, double guard, int precise, sdo_c32 *out, size_t cap)
+{
+  sdo_st_geom g;
+  size_t nwin;
+  sdo_specttuner_geometry(4096, f0, bw, guard, &g);
+  nwin = len < 4096 ? 0 : (len - 4096) / 2048 + 1;
+  if (cap < nwin * g.halfsz) return 0;
+  sdo_specttuner_bank_f32(x, len, 1, &f0, &bw, &guard, &precise, 0, nwin, out, 0);
+  return nwin * g.halfsz;
+}
+
 /* ---- O: channel detector (su_channel_detector) [SPEC, UPSTREAM-RECOLLECTION] ----------------------------------------
  * SPEC.md section O; parameters of Suscan/AnalyzerParams.cpp:53-71. */
 static int cmp_float(const void *a, const void *b) { const float x = *(const float *)a, y = *(const float *)b; return (x > y) - (x < y); }

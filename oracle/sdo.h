@@ -273,6 +273,16 @@ void   sdo_specttuner_crossfade(unsigned size, float *win);                     
 size_t sdo_specttuner_run(const sdo_c32 *x, size_t len, unsigned W, double f0, double bw, double guard, int precise,
                           sdo_c32 *out, size_t cap);
 
+/* The binary32 statement of the same channeliser (SPEC.md C2 "binary32 arithmetic"): operation for operation what the
+ * device kernels compute (csrc/specttuner_wave.hip for sizes 8 .. 64, csrc/specttuner.hip for the others), so that the
+ * default channeliser of the analyzer and of the bench is compared bit for bit.  W = 4096 only. */
+void   sdo_st32_tables(sdo_c32 *w64 /*[64]: W_64^m*/, float *win64 /*[64]: sin^2(pi i / 64)*/);   /* the kernels' literal tables */
+void   sdo_st32_forward_narrow(const sdo_c32 *win, sdo_c32 *X);    /* DFT_4096 as 64 x 64 (8 x 8 register transforms) */
+void   sdo_st32_forward_wide(const sdo_c32 *win, sdo_c32 *X);      /* DFT_4096 as three radix-16 Stockham passes */
+size_t sdo_specttuner_bank_f32(const sdo_c32 *x, size_t len, unsigned nchan, const double *f0, const double *bw, const double *guard,
+                               const int *precise, size_t w_begin, size_t w_end, sdo_c32 *out, size_t row_stride);
+size_t sdo_specttuner_run_f32(const sdo_c32 *x, size_t len, double f0, double bw, double guard, int precise, sdo_c32 *out, size_t cap);
+
 /* ---- O: channel detector, su_channel_detector (SPEC.md section O) [UPSTREAM-RECOLLECTION] ---------------------------- */
 typedef struct { unsigned n; float alpha, gamma, snr; int first; float N0; float *S; } sdo_chandet;   /* S: n floats, caller-owned */
 typedef struct { int first, last, width; float peak; double sum, wsum; } sdo_chandet_record;

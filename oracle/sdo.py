@@ -603,6 +603,48 @@ def specttuner_run(x, W, f0, bw, guard, precise=False):
     return out[:n].copy()
 
 
+def st32_forward(win, narrow=True):
+    """DFT_4096 of one window in the binary32 arithmetic SPEC.md C2 freezes (narrow: 64 x 64; wide: radix-16 passes)"""
+    win = _c(win)
+    assert win.size == 4096
+    X = np.empty(4096, dtype=c32)
+    (lib().sdo_st32_forward_narrow if narrow else lib().sdo_st32_forward_wide)(_p(win), _p(X))
+    return X
+
+
+def specttuner_bank_f32(x, f0, bw, guard, precise=None, threads=1):
+    """The binary32 statement of the FFT channeliser for a bank of channels opened at the start of the stream.
+    Returns a list of rows (one array per channel).  threads > 1: window ranges computed side by side (every range
+    re-transforms the window before it; the result does not depend on the split)."""
+    x = _c(x)
+    n = len(f0)
+    W, H = 4096, 2048
+    nwin = 0 if x.size < W else (x.size - W) // H + 1
+    geoms = [specttuner_geometry(W, f0[c], bw[c], guard[c]) for c in range(n)]
+    stride = max([nwin * g.halfsz for g in geoms] + [1])
+    out = np.zeros((n, stride), dtype=c32)
+    F0 = (C.c_double * n)(*[float(v) for v in f0]); BW = (C.c_double * n)(*[float(v) for v in bw]); GU = (C.c_double * n)(*[float(v) for v in guard])
+    PR = (C.c_int * n)(*[int(bool(v)) for v in (precise if precise is not None else [0] * n)])
+    f = lib().sdo_specttuner_bank_f32
+    f.restype = C.c_size_t
+
+    def run(w0, w1):
+        f(_p(x), C.c_size_t(x.size), C.c_uint(n), F0, BW, GU, PR, C.c_size_t(w0), C.c_size_t(w1), _p(out), C.c_size_t(stride))
+
+    if threads <= 1 or nwin < 2 * threads:
+        run(0, nwin)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        edges = [nwin * k // threads for k in range(threads + 1)]
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            list(ex.map(lambda k: run(edges[k], edges[k + 1]), range(threads)))
+    return [out[c, :nwin * geoms[c].halfsz] for c in range(n)]
+
+
+def specttuner_run_f32(x, f0, bw, guard, precise=False):
+    return specttuner_bank_f32(x, [f0], [bw], [guard], [precise])[0].copy()
+
+
 # ---- O: channel detector ----------------------------------------------------------------------------
 class _ChanDet(C.Structure):
     _fields_ = [("n", C.c_uint), ("alpha", C.c_float), ("gamma", C.c_float), ("snr", C.c_float), ("first", C.c_int),

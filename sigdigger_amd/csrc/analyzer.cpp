@@ -497,7 +497,8 @@ struct BlockBus {
   std::mutex m;
   std::condition_variable cv;
   uint64_t seq = 0;                             // blocks published so far; block k sits in entry k & 1
-  struct Entry { const void *host = nullptr; size_t samples = 0; int raw_format = 0; unsigned bytes_per_sample = 8; uint64_t position = 0; unsigned samp_rate = 0; } e[2];
+  struct Entry { const void *host = nullptr; size_t samples = 0; size_t valid = 0;   // valid < samples: the stream's tail (no reallocation, no rebuild)
+                  int raw_format = 0; unsigned bytes_per_sample = 8; uint64_t position = 0; unsigned samp_rate = 0; } e[2];
   bool closed = false;                          // the publisher is done (end of stream, halt, error)
   std::vector<uint64_t> done;                   // per subscriber: blocks whose host buffer it no longer needs
   // RCCL variant (opt-in): one communicator per shard, created by shard 0
@@ -552,6 +553,8 @@ struct suscan_analyzer {
   unsigned chan_every = 1, chan_phase = 0;    // a list every chan_every blocks (channel_update_int of signal time)
   bool want_fft = true, use_fft = false;
   suamd_specttuner_t *st = nullptr;
+  bool st_idle = false;                       // the tuner was reset when the last inspector went away (no stale history at the next open)
+  std::atomic<bool> st_reset_pending{false};  // a SEEK moved the source: every shard forgets the tuner's stream position
   suamd_complex **d_rowptr[2] = {nullptr, nullptr};   // per slot: where each FFT channel's row starts (device table)
   suamd_complex **h_rowptr[2] = {nullptr, nullptr};   // pinned staging, and what the device table holds
   size_t rowptr_cap = 0;
@@ -810,6 +813,7 @@ void enqueue_inspectors(suscan_analyzer *a, size_t len, int slot)
 
 void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
 {
+  if (a->st_reset_pending.exchange(false) && a->st) (void)suamd_specttuner_reset(a->st, a->istream[3]);
   // Sub-ranges per stage: four let the three serial stages of a block overlap when a handful of wavefronts carry all
   // inspectors; with hundreds of inspectors the worker's own enqueue time is what bounds the rate, and two sub-ranges
   // halve it (2 Mi-sample blocks, MS/s at the consumer with 1 / 2 / 4 sub-ranges: 64 inspectors 797 / 1048 / 1055,
@@ -831,13 +835,24 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
     in.stream = sA;
     if (in.dirty) {
       std::string err;
-      if (!build_chain(a, in, err)) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, err); continue; }
+      if (!build_chain(a, in, err)) {
+        // the inspector sits this block out; its channel must not stay a member of the filter bank, whose kernel would
+        // store that channel's samples through a row pointer nobody maintains
+        in.close_channel();
+        push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, err);
+        continue;
+      }
       in.dirty = false;
       in.use(slot);                                           // the rebuild may have re-allocated the slot's rows
     }
     live.push_back(&in);
   }
-  if (live.empty()) return;
+  if (live.empty()) {
+    // nobody to feed: the tuner's half-window history would be from an unrelated stream position when feeding resumes
+    if (a->use_fft && a->st && !a->st_idle) { (void)suamd_specttuner_reset(a->st, sF); a->st_idle = true; }
+    return;
+  }
+  a->st_idle = false;
   auto fail = [&](const char *what) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string(what) + ": " + suamd_last_error()); };
   {
     // every inspector channelises the same wideband block: one launch for all of them
@@ -865,7 +880,9 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
         if (a->h_rowptr[slot][pi->st_chan] != pi->d_y) { a->h_rowptr[slot][pi->st_chan] = pi->d_y; changed = true; }
       // (the slot's previous block has been collected by now: its table and staging are free to change)
       if (changed) (void)hipMemcpyAsync(a->d_rowptr[slot], a->h_rowptr[slot], nrows * sizeof(void *), hipMemcpyHostToDevice, sF);
-      std::vector<SUSCOUNT> counts(nrows, 0);
+      // one count per slot of the tuner's channel table: it never shrinks, so after a close (or a retune, which closes
+      // and reopens) it can be longer than the highest live channel
+      std::vector<SUSCOUNT> counts(std::max(nrows, (size_t)suamd_specttuner_channel_capacity(a->st)), 0);
       if (!suamd_specttuner_feed_rows(a->st, a->d_x, len, a->d_rowptr[slot], counts.data(), sF)) { fail("channeliser"); return; }
       for (size_t i = 0; i < live.size(); ++i) fm[i] = counts[live[i]->st_chan];
     } else {
@@ -1492,14 +1509,14 @@ void bus_wait_done(suscan_analyzer *a, uint64_t upto)
   b.cv.wait(lk, [&] { for (uint64_t d : b.done) if (d < upto) return false; return true; });
 }
 
-void bus_publish(suscan_analyzer *a, const void *host, size_t samples, int raw_format, unsigned bps, uint64_t position)
+void bus_publish(suscan_analyzer *a, const void *host, size_t samples, size_t valid, int raw_format, unsigned bps, uint64_t position)
 {
   if (!a->bus || a->secondaries.empty()) return;
   BlockBus &b = *a->bus;
   {
     std::lock_guard<std::mutex> lk(b.m);
     BlockBus::Entry &e = b.e[b.seq & 1];
-    e.host = host; e.samples = samples; e.raw_format = raw_format; e.bytes_per_sample = bps; e.position = position;
+    e.host = host; e.samples = samples; e.valid = valid; e.raw_format = raw_format; e.bytes_per_sample = bps; e.position = position;
     e.samp_rate = a->source_cfg.samp_rate;
     ++b.seq;
   }
@@ -1574,12 +1591,12 @@ void secondary_main(suscan_analyzer *a)
     if (a->xfree_set) (void)hipStreamWaitEvent(a->stream, a->ev_xfree, 0);
     const bool compact = e.bytes_per_sample != sizeof(suamd_complex);
     void *dst = compact ? a->d_raw : (void *)a->d_x;
-    const size_t bytes = e.samples * e.bytes_per_sample;
+    const size_t bytes = e.valid * e.bytes_per_sample;
     bool sent = false;
     if (bus.bcast) sent = bus.bcast(nullptr, dst, bytes, 0 /* ncclInt8 */, 0, bus.comm[a->shard], a->stream) == 0;
     if (!sent) (void)hipMemcpyAsync(dst, e.host, bytes, hipMemcpyHostToDevice, a->stream);
     (void)hipEventRecord(a->ev_h2d[0], a->stream);
-    if (compact && !suamd_ingest_iq(a->ctx, e.raw_format, a->d_raw, e.samples, a->d_x, a->stream))
+    if (compact && !suamd_ingest_iq(a->ctx, e.raw_format, a->d_raw, e.valid, a->d_x, a->stream))
       push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("GPU shard ingest: ") + suamd_last_error());
     {
       // the same source conditioning as shard 0 (same input, same arithmetic: the shards see the same samples)
@@ -1587,12 +1604,12 @@ void secondary_main(suscan_analyzer *a)
       if (!dcr) a->dc_first = true;
       if (rev || dcr) {
         if (dcr && !a->d_dc && hipMalloc((void **)&a->d_dc, 2 * sizeof(float)) != hipSuccess) a->d_dc = nullptr;
-        if (suamd_source_fix(a->ctx, a->d_x, a->block, rev ? SU_TRUE : SU_FALSE, dcr ? a->d_dc : nullptr, 0.1f, a->dc_first ? SU_TRUE : SU_FALSE, a->stream) && dcr)
+        if (suamd_source_fix(a->ctx, a->d_x, e.valid, rev ? SU_TRUE : SU_FALSE, dcr ? a->d_dc : nullptr, 0.1f, a->dc_first ? SU_TRUE : SU_FALSE, a->stream) && dcr)
           a->dc_first = false;
       }
     }
     (void)hipEventRecord(a->ev_input, a->stream);
-    enqueue_inspectors(a, a->block, slot);
+    enqueue_inspectors(a, e.valid, slot);
     // the publisher may reuse its host buffer once this shard's copy is out
     (void)hipEventSynchronize(a->ev_h2d[0]);
     { std::lock_guard<std::mutex> lk(bus.m); bus.done[me] = k + 1; }
@@ -1682,9 +1699,11 @@ void worker_main(suscan_analyzer *a)
     DBG("finish slot %d: wait psd", f.slot);
     (void)hipEventSynchronize(a->ev_psd[f.slot]);
     DBG("finish slot %d: psd ok, collect", f.slot);
-    std::memcpy(f.msg->psd_data, a->h_psd[f.slot], f.n * sizeof(float));
-    gettimeofday(&f.msg->rt_time, nullptr);
-    push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_PSD, f.msg);
+    if (f.msg) {                                            // (the stream's tail may hold no whole PSD frame)
+      std::memcpy(f.msg->psd_data, a->h_psd[f.slot], f.n * sizeof(float));
+      gettimeofday(&f.msg->rt_time, nullptr);
+      push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_PSD, f.msg);
+    }
     if (f.chan && a->chandet) push_channels(a, f.slot);
     collect_inspectors(a, f.slot);
     DBG("finish slot %d: done", f.slot);
@@ -1707,6 +1726,10 @@ void worker_main(suscan_analyzer *a)
       if (r.kind == Request::SEEK) {                          // Suscan/Analyzer.cpp:150-154
         if (have_next) have_next = false;                     // the block read ahead is from the old position
         src.seek(r.value);
+        // the channeliser's half-window history and cross-fade partners belong to the old position (all shards)
+        if (a->bus) bus_wait_done(a, a->bus->seq);            // every shard has enqueued the blocks from before the seek
+        a->st_reset_pending = true;
+        for (suscan_analyzer *sh : a->secondaries) sh->st_reset_pending = true;
         consumed = r.value;
         a->position = consumed;
         thr_t0 = std::chrono::steady_clock::now(); thr_c0 = consumed;       // the throttle paces from here
@@ -1741,18 +1764,25 @@ void worker_main(suscan_analyzer *a)
     }
     have_next = false;
     const size_t got = got_next;
-    if (got < a->block) {                                  // a partial last block is dropped, as a
+    // The stream ends inside this block: what is left still goes through the inspectors (a file-source consumer must
+    // not lose the tail of every channel) -- whole half windows for the FFT filter bank, every sample for the FIR
+    // bank -- and through the PSD as far as whole frames go; then EOS.
+    const bool last = got < a->block;
+    const size_t blen = !last ? a->block : (a->use_fft ? got / 2048 * 2048 : got);
+    if (blen == 0) {
       finish(flight);
       bus_close(a);                                          // the other GPU shards deliver what they still hold: before EOS
-      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_EOS, 0, "end of stream");   // whole PSD frame set is needed
+      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_EOS, 0, "end of stream");
       break;
     }
-    // the block after this one starts coming off the source now, on the helper thread
-    src.mark();
-    DBG("block at %llu: wait h2d of the other half", (unsigned long long)consumed);
-    if (a->h2d_set[cur ^ 1]) (void)hipEventSynchronize(a->ev_h2d[cur ^ 1]);   // that half's copy (the previous block) is out
-    reader.start(a->h_x + (size_t)(cur ^ 1) * a->block, a->block);
-    DBG("read-ahead started");
+    if (!last) {
+      // the block after this one starts coming off the source now, on the helper thread
+      src.mark();
+      DBG("block at %llu: wait h2d of the other half", (unsigned long long)consumed);
+      if (a->h2d_set[cur ^ 1]) (void)hipEventSynchronize(a->ev_h2d[cur ^ 1]);   // that half's copy (the previous block) is out
+      reader.start(a->h_x + (size_t)(cur ^ 1) * a->block, a->block);
+      DBG("read-ahead started");
+    }
     // ---- baseband filters: on this thread, on SUCOMPLEX samples, before anything else sees the block ----
     std::vector<suscan_analyzer::Filter> filters;
     {
@@ -1767,7 +1797,7 @@ void worker_main(suscan_analyzer *a)
         if (!a->h_flt && hipHostMalloc((void **)&a->h_flt, a->block * sizeof(suamd_complex), hipHostMallocPortable) != hipSuccess) fatal = "pinned allocation failed";
         else {
           h_flt = a->h_flt;
-          const size_t nv = 2 * a->block;
+          const size_t nv = 2 * blen;
           float *o = reinterpret_cast<float *>(h_flt);
           switch (src.raw_format) {
             case SUAMD_FORMAT_RAW_UNSIGNED8: { const uint8_t *r = reinterpret_cast<const uint8_t *>(h_cur); for (size_t i = 0; i < nv; ++i) o[i] = (float)((int)r[i] - 128) * 0.0078125f; break; }
@@ -1778,27 +1808,27 @@ void worker_main(suscan_analyzer *a)
       }
       for (const auto &f : filters) {
         if (!fatal.empty()) break;
-        if (!f.func(f.priv, a, h_flt, a->block, consumed)) fatal = "a baseband filter failed";
+        if (!f.func(f.priv, a, h_flt, blen, consumed)) fatal = "a baseband filter failed";
       }
     }
     if (!fatal.empty()) { (void)reader.wait(&looped_next); finish(flight); push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, fatal); break; }
     // every other GPU shard takes the block from here (what the filters left)
-    if (h_flt) bus_publish(a, h_flt, a->block, SUAMD_FORMAT_RAW_FLOAT32, sizeof(suamd_complex), consumed);
-    else bus_publish(a, h_cur, a->block, src.raw_format, src.bytes_per_sample(), consumed);
+    if (h_flt) bus_publish(a, h_flt, a->block, blen, SUAMD_FORMAT_RAW_FLOAT32, sizeof(suamd_complex), consumed);
+    else bus_publish(a, h_cur, a->block, blen, src.raw_format, src.bytes_per_sample(), consumed);
     // the previous block's channeliser must be done with d_x before this block lands in it (its PSD is on this stream)
     if (a->xfree_set) (void)hipStreamWaitEvent(a->stream, a->ev_xfree, 0);
     if (h_flt) {
-      (void)hipMemcpyAsync(a->d_x, h_flt, a->block * sizeof(suamd_complex), hipMemcpyHostToDevice, a->stream);
+      (void)hipMemcpyAsync(a->d_x, h_flt, blen * sizeof(suamd_complex), hipMemcpyHostToDevice, a->stream);
       if (h_flt == a->h_flt) (void)hipStreamSynchronize(a->stream);   // one expansion buffer: the copy must be out before the next block
     } else if (src.bytes_per_sample() == sizeof(suamd_complex)) {
-      (void)hipMemcpyAsync(a->d_x, h_cur, a->block * sizeof(suamd_complex), hipMemcpyHostToDevice, a->stream);
+      (void)hipMemcpyAsync(a->d_x, h_cur, blen * sizeof(suamd_complex), hipMemcpyHostToDevice, a->stream);
     } else {                                               // 2-4 B/sample over PCIe, expanded on the GPU
-      (void)hipMemcpyAsync(a->d_raw, h_cur, a->block * src.bytes_per_sample(), hipMemcpyHostToDevice, a->stream);
-      if (!suamd_ingest_iq(a->ctx, src.raw_format, a->d_raw, a->block, a->d_x, a->stream)) fatal = suamd_last_error();
+      (void)hipMemcpyAsync(a->d_raw, h_cur, blen * src.bytes_per_sample(), hipMemcpyHostToDevice, a->stream);
+      if (!suamd_ingest_iq(a->ctx, src.raw_format, a->d_raw, blen, a->d_x, a->stream)) fatal = suamd_last_error();
     }
     if (a->bus && a->bus->bcast && !a->secondaries.empty()) {   // SUAMD_ANALYZER_BCAST=rccl: GPU 0 is the root of one broadcast per block
       void *root = src.bytes_per_sample() == sizeof(suamd_complex) || h_flt ? (void *)a->d_x : a->d_raw;
-      const size_t bytes = a->block * (h_flt ? sizeof(suamd_complex) : src.bytes_per_sample());
+      const size_t bytes = blen * (h_flt ? sizeof(suamd_complex) : src.bytes_per_sample());
       if (a->bus->bcast(root, root, bytes, 0, 0, a->bus->comm[0], a->stream) != 0) { a->bus->bcast = nullptr; }
     }
     (void)hipEventRecord(a->ev_h2d[cur], a->stream);
@@ -1810,7 +1840,7 @@ void worker_main(suscan_analyzer *a)
       if (!dcr) a->dc_first = true;
       if (rev || dcr) {
         if (dcr && !a->d_dc && hipMalloc((void **)&a->d_dc, 2 * sizeof(float)) != hipSuccess) a->d_dc = nullptr;
-        if (!suamd_source_fix(a->ctx, a->d_x, a->block, rev ? SU_TRUE : SU_FALSE, dcr ? a->d_dc : nullptr, 0.1f, a->dc_first ? SU_TRUE : SU_FALSE, a->stream))
+        if (!suamd_source_fix(a->ctx, a->d_x, blen, rev ? SU_TRUE : SU_FALSE, dcr ? a->d_dc : nullptr, 0.1f, a->dc_first ? SU_TRUE : SU_FALSE, a->stream))
           push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("source conditioning: ") + suamd_last_error());
         else if (dcr) a->dc_first = false;
       }
@@ -1820,11 +1850,12 @@ void worker_main(suscan_analyzer *a)
     tick(0);
     // the inspectors' chains start as soon as the block is on the device, next to the PSD
     DBG("enqueue slot %d", slot);
-    enqueue_inspectors(a, a->block, slot);
+    enqueue_inspectors(a, blen, slot);
     DBG("enqueued");
     tick(1);
     const unsigned n = (unsigned)a->params.detector_params.window_size;
-    if (!suamd_psd_feed(a->psd, a->d_x, a->navg, n, a->navg, 1.0f / (float)n, SUAMD_PSD_LINEAR, a->d_psd, a->stream)) {
+    const unsigned navg = last ? (unsigned)(blen / n) : a->navg;     // the tail: the whole frames it holds (none: no PSD message)
+    if (navg && !suamd_psd_feed(a->psd, a->d_x, navg, n, navg, 1.0f / (float)n, SUAMD_PSD_LINEAR, a->d_psd, a->stream)) {
       fatal = suamd_last_error();
       (void)reader.wait(&looped_next);                        // the helper thread is off the pinned buffer before it is freed
       for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) (void)hipStreamSynchronize(a->istream[k]);
@@ -1832,15 +1863,16 @@ void worker_main(suscan_analyzer *a)
       push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, fatal);
       break;
     }
-    (void)hipMemcpyAsync(a->h_psd[slot], a->d_psd, n * sizeof(float), hipMemcpyDeviceToHost, a->stream);
+    if (navg) (void)hipMemcpyAsync(a->h_psd[slot], a->d_psd, n * sizeof(float), hipMemcpyDeviceToHost, a->stream);
     bool chan_now = false;
-    if (a->chandet) {                                        // the detector follows every block's spectrum; a list now and then
+    if (a->chandet && navg) {                                        // the detector follows every block's spectrum; a list now and then
       if (!suamd_chandet_feed(a->chandet, a->d_psd, a->stream)) push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string("channel detector: ") + suamd_last_error());
       else if (++a->chan_phase >= a->chan_every) { a->chan_phase = 0; chan_now = suamd_chandet_find(a->chandet, slot, a->stream) != 0; }
     }
     (void)hipEventRecord(a->ev_psd[slot], a->stream);
     InFlight now_f;
-    {
+    now_f.on = true; now_f.slot = slot;
+    if (navg) {
       auto *m = static_cast<suscan_analyzer_psd_msg *>(std::calloc(1, sizeof(suscan_analyzer_psd_msg)));
       m->psd_size = n;
       m->psd_data = static_cast<SUFLOAT *>(std::malloc(n * sizeof(SUFLOAT)));
@@ -1859,6 +1891,14 @@ void worker_main(suscan_analyzer *a)
     finish(flight);                                        // the block before this one: its messages go out now
     flight = now_f;
     if (!a->pipelined) finish(flight);
+    if (last) {
+      finish(flight);
+      consumed += blen;
+      a->position = consumed;
+      bus_close(a);                                          // the other GPU shards deliver what they still hold: before EOS
+      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_EOS, 0, "end of stream");
+      break;
+    }
     cur ^= 1;
     looped_next = false;
     DBG("wait for the read-ahead");

@@ -16,6 +16,7 @@
 
 #include "../../include/sigdigger_amd.h"
 #include "kernels.hpp"
+#include "design.hpp"
 
 namespace {
 
@@ -103,31 +104,7 @@ struct Scratch {
 
 // ---- parameter design (host, double precision; not on the hot path) ----------------------
 
-// bilinear-transform Butterworth low-pass, order <= 4, cut-off fc (1 = Nyquist)
-void butter_lp(int order, double fc, float *b, float *a)
-{
-  const double wc = std::tan(0.5 * kPi * fc);
-  double ar[5] = {1, 0, 0, 0, 0}, ai[5] = {0, 0, 0, 0, 0};
-  const int n = order;
-  for (int i = 0; i < n; ++i) {
-    const double th = kPi * (2.0 * i + n + 1.0) / (2.0 * n);
-    const double pr = wc * std::cos(th), pi = wc * std::sin(th);
-    const double dr = 1.0 - pr, di = -pi, nr = 1.0 + pr, ni = pi;
-    const double den = dr * dr + di * di;
-    const double zr = (nr * dr + ni * di) / den, zi = (ni * dr - nr * di) / den;
-    for (int k = i + 1; k >= 1; --k) {
-      const double tr = ar[k] - (zr * ar[k - 1] - zi * ai[k - 1]);
-      const double ti = ai[k] - (zr * ai[k - 1] + zi * ar[k - 1]);
-      ar[k] = tr; ai[k] = ti;
-    }
-  }
-  double bn[5] = {1, 0, 0, 0, 0}, sa = 0, sb = 0;
-  for (int i = 0; i < n; ++i)
-    for (int k = i + 1; k >= 1; --k) bn[k] += bn[k - 1];
-  for (int k = 0; k <= n; ++k) { sa += ar[k]; sb += bn[k]; }
-  for (int k = 0; k <= 4; ++k) { b[k] = 0; a[k] = 0; }
-  for (int k = 0; k <= n; ++k) { b[k] = (float)(bn[k] * sa / sb); a[k] = (float)ar[k]; }
-}
+using sdk_design::butter_lp;                                // design.hpp (shared with sigutils_host.cpp)
 
 void make_window(int type, std::vector<float> &w)
 {

@@ -8,14 +8,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// SD_HD: the primitives that are plain binary32 C++ (no gfx950 instruction) also compile for the host, where
+// csrc/sigutils_host.cpp runs them one sample at a time behind libsigutils' by-value su_* calls -- the SAME sequence of
+// operations on both sides (the host pass must be compiled with -ffp-contract=off as well).
+#define SD_HD __host__ __device__ __forceinline__
+
 namespace sd {
 
 struct c32 { float re, im; };
 
-__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+SD_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+SD_HD uint32_t f2u(float v) { return __builtin_bit_cast(uint32_t, v); }
+SD_HD float u2f(uint32_t v) { return __builtin_bit_cast(float, v); }
 
 // D1: 32-bit phase (2^32 per turn) -> cos/sin. Quadrant reduction + Cephes minimax kernels.
-__device__ __forceinline__ void phasor_u32(uint32_t p, float &c, float &s)
+SD_HD void phasor_u32(uint32_t p, float &c, float &s)
 {
   // r = p - (q << 30) with q = (p + 0x20000000) >> 30 is the low 30 bits of p, sign-extended:
   // one v_bfe_i32 instead of add / and / sub on the loop-carried phase -> sample path
@@ -33,11 +40,11 @@ __device__ __forceinline__ void phasor_u32(uint32_t p, float &c, float &s)
   // VCC write->read hazard); the values are exactly the selected / negated polynomials.
   const uint32_t t    = p + 0x20000000u;                       // bits 31:30 = q
   const uint32_t swap = (uint32_t)((int32_t)(t << 1) >> 31);   // all ones when q is odd
-  const uint32_t ics = __float_as_uint(cs), isn = __float_as_uint(sn);
+  const uint32_t ics = f2u(cs), isn = f2u(sn);
   const uint32_t a = (isn & swap) | (ics & ~swap);             // q odd ? sn : cs
   const uint32_t b = (ics & swap) | (isn & ~swap);             // q odd ? cs : sn
-  c = __uint_as_float(a ^ ((t ^ (t << 1)) & 0x80000000u));     // negate for q = 1, 2
-  s = __uint_as_float(b ^ (t & 0x80000000u));                  // negate for q = 2, 3
+  c = u2f(a ^ ((t ^ (t << 1)) & 0x80000000u));                 // negate for q = 1, 2
+  s = u2f(b ^ (t & 0x80000000u));                              // negate for q = 2, 3
 }
 
 typedef float v2f_ __attribute__((ext_vector_type(2)));
@@ -93,7 +100,7 @@ __device__ __forceinline__ v2f_ mix_conj(v2f_ x, v2f_ cs)
 }
 
 // D2: atan2 (radians), Cephes atanf kernel on min/max.
-__device__ __forceinline__ float atan2_(float y, float x)
+SD_HD float atan2_(float y, float x)
 {
   const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
   const float mx = ax > ay ? ax : ay;
@@ -117,11 +124,11 @@ __device__ __forceinline__ float atan2_(float y, float x)
 }
 
 // D3: log2 of a normal positive float.
-__device__ __forceinline__ float log2_(float x)
+SD_HD float log2_(float x)
 {
-  const uint32_t bits = __float_as_uint(x);
+  const uint32_t bits = f2u(x);
   int32_t e = (int32_t)(bits >> 23) - 127;
-  float   m = __uint_as_float((bits & 0x007FFFFFu) | 0x3F800000u);
+  float   m = u2f((bits & 0x007FFFFFu) | 0x3F800000u);
   if (m > 1.41421356237309504880f) { m = m * 0.5f; e = e + 1; }
   const float f = m - 1.0f;
   const float z = f * f;
@@ -141,7 +148,7 @@ __device__ __forceinline__ float log2_(float x)
 }
 
 // D4: 2^x, x clamped to [-126, 126].
-__device__ __forceinline__ float exp2_(float x)
+SD_HD float exp2_(float x)
 {
   if (x >  126.0f) x =  126.0f;
   if (x < -126.0f) x = -126.0f;
@@ -156,23 +163,28 @@ __device__ __forceinline__ float exp2_(float x)
   y = fma_(y, t, 1.6666665459e-1f);
   y = fma_(y, t, 5.0000001201e-1f);
   y = fma_(y, z, t) + 1.0f;
-  return y * __uint_as_float((uint32_t)(n + 127) << 23);
+  return y * u2f((uint32_t)(n + 127) << 23);
 }
 
-__device__ __forceinline__ int32_t rad_to_dphase(float d)
+SD_HD int32_t rad_to_dphase(float d)
 {
   // clamp to (-pi, pi): one v_med3_f32 (identical to the two compares of the SPEC for non-NaN d)
+#if defined(__HIP_DEVICE_COMPILE__)
   d = __builtin_amdgcn_fmed3f(d, -3.1415925f, 3.1415925f);
+#else
+  if (d > 3.1415925f) d = 3.1415925f;
+  if (d < -3.1415925f) d = -3.1415925f;
+#endif
   return (int32_t)(d * 683565275.57643158978f);
 }
 
-__device__ __forceinline__ float phase_to_rad(uint32_t p)
+SD_HD float phase_to_rad(uint32_t p)
 {
   return (float)(int32_t)p * 1.46291807926715968e-9f;
 }
 
 // (a.re + j a.im)(c + j s)
-__device__ __forceinline__ c32 cmul_cs(c32 a, float c, float s)
+SD_HD c32 cmul_cs(c32 a, float c, float s)
 {
   c32 r;
   r.re = fma_(-a.im, s, a.re * c);
@@ -181,7 +193,7 @@ __device__ __forceinline__ c32 cmul_cs(c32 a, float c, float s)
 }
 
 // a * conj(b)
-__device__ __forceinline__ c32 cmul_conj(c32 a, c32 b)
+SD_HD c32 cmul_conj(c32 a, c32 b)
 {
   c32 r;
   r.re = fma_(a.im, b.im, a.re * b.re);
@@ -189,7 +201,7 @@ __device__ __forceinline__ c32 cmul_conj(c32 a, c32 b)
   return r;
 }
 
-__device__ __forceinline__ float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+SD_HD float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
 
 // (sgn(a), sgn(b)) without compares: a v_cmp -> v_cndmask pair costs a lone wavefront about four
 // dependent-op slots (VCC hazard) and the four pairs of a QPSK detector serialise on VCC.

@@ -411,6 +411,38 @@ unsigned suamd_specttuner_channel_decimation(const suamd_specttuner_t *st, int c
   return (st && c >= 0 && (size_t)c < st->ch.size() && st->ch[c].open) ? st->ch[c].g.decimation : 0;
 }
 
+unsigned suamd_specttuner_channel_capacity(const suamd_specttuner_t *st) { return st ? (unsigned)st->ch.size() : 0; }
+
+SUBOOL suamd_specttuner_reset(suamd_specttuner_t *st, void *stream)
+{
+  if (!st) { suamd_set_error("null specttuner"); return SU_FALSE; }
+  if (hipSetDevice(suamd_ctx_device(st->ctx)) != hipSuccess) { suamd_set_error("hipSetDevice failed"); return SU_FALSE; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  st->have_hist = false;
+  for (auto &kv : st->groups) {
+    SizeGroup &g = kv.second;
+    const size_t HS = ((size_t)1 << g.log2s) / 2;
+    if (g.dirty) {
+      // the tables are rebuilt at the next feed from the snapshot: clear what the rebuild would carry over
+      if (g.snap_prev && hipMemsetAsync(g.snap_prev, 0, std::max<size_t>(1, g.snap_members.size()) * HS * sizeof(c32), s) != hipSuccess) { suamd_set_error("reset failed"); return SU_FALSE; }
+    } else if (g.d_prev[g.prev_cur] && !g.members.empty() &&
+               hipMemsetAsync(g.d_prev[g.prev_cur], 0, g.members.size() * HS * sizeof(c32), s) != hipSuccess) { suamd_set_error("reset failed"); return SU_FALSE; }
+  }
+  return SU_TRUE;
+}
+
+SUBOOL suamd_specttuner_design(unsigned window_size, double f0, double bw, double guard, uint32_t geom[6], SUFLOAT *hk)
+{
+  if (window_size != 4096 || !(bw > 0) || !(guard >= 1) || !std::isfinite(f0) || !geom) { suamd_set_error("bad channel parameters (window 4096, bw > 0, guard >= 1)"); return SU_FALSE; }
+  const Geom g = design_geometry(window_size, f0, bw, guard);
+  geom[0] = g.size; geom[1] = g.halfsz; geom[2] = g.halfw; geom[3] = g.decimation; geom[4] = (uint32_t)g.center; geom[5] = g.dphase;
+  if (hk) {
+    const std::vector<c32> h = design_response(window_size, g.size, g.halfw);
+    std::memcpy(hk, h.data(), h.size() * sizeof(c32));
+  }
+  return SU_TRUE;
+}
+
 SUBOOL suamd_specttuner_set_run(suamd_specttuner_t *st, unsigned run)
 {
   if (!st || run < 1 || run > 4096) { suamd_set_error("run out of range"); return SU_FALSE; }
@@ -615,7 +647,8 @@ struct sigutils_specttuner {
     for (auto &c : channels) if (c) rows = std::max<size_t>(rows, (size_t)c->index + 1);
     if (!ensure_out(std::max<size_t>(rows, 1))) { suamd_set_error("allocation failed"); return false; }
     if (hipMemcpyAsync(d_in, h_in, nproc * sizeof(c32), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
-    std::vector<SUSCOUNT> counts(std::max<size_t>(rows, 1), 0);
+    // one entry per slot of the tuner's channel table (it never shrinks: closing the highest channel leaves its slot)
+    std::vector<SUSCOUNT> counts(std::max<size_t>({rows, (size_t)suamd_specttuner_channel_capacity(st), (size_t)1}), 0);
     const suamd_view v{(SUSCOUNT)row_len, 1};
     if (!suamd_specttuner_feed(st, reinterpret_cast<const suamd_complex *>(d_in), nproc, reinterpret_cast<suamd_complex *>(d_out), v,
                                counts.data(), stream)) return false;

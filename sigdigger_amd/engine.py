@@ -448,13 +448,21 @@ class SpectTuner:
     def set_run(self, run):
         check(self.ctx.lib.suamd_specttuner_set_run(self.h, int(run)), "suamd_specttuner_set_run")
 
+    def capacity(self):
+        """entries a counts array must hold (suamd_specttuner_channel_capacity)"""
+        return int(self.ctx.lib.suamd_specttuner_channel_capacity(self.h))
+
+    def reset(self, stream=None):
+        """forget the stream position (seek / gap): history and cross-fade partners"""
+        check(self.ctx.lib.suamd_specttuner_reset(self.h, _stream(stream)), "suamd_specttuner_reset")
+
     def feed(self, x, out=None, stream=None):
         """x: [len] complex64, len a multiple of W/2.  Returns (out, counts): out [nchan, cap] channel-major (or the
         tensor passed in: any 2-D view), counts[c] samples valid in row c."""
         _chk_c64(x, "x")
         if out is None:
             out = torch.empty((max(self.nchan, 1), x.numel() + 16), dtype=torch.complex64, device=x.device)   # decimation 1 at worst
-        counts = (C.c_uint64 * max(self.nchan, 1))()
+        counts = (C.c_uint64 * max(self.capacity(), 1))()
         check(self.ctx.lib.suamd_specttuner_feed(self.h, _ptr(x), x.numel(), _ptr(out), _view(out), counts, _stream(stream)),
               "suamd_specttuner_feed")
         return out, [int(v) for v in counts]

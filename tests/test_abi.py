@@ -37,6 +37,22 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     lib.load()
 
 
+def test_sigutils_headers_declare_only_what_the_library_exports():
+    """include/sigutils/*.h (the per-sample su_* calls of the offline Tasks and su_specttuner_*): every declared symbol is
+    exported by the product library -- no compute call here, the symbols only"""
+    from sigdigger_amd import build, lib
+    build.build()
+    so = ctypes.CDLL(lib.SO_PATH)
+    total = 0
+    for h in ("ncqo.h", "pll.h", "agc.h", "clock.h", "iir.h", "taps.h", "specttuner.h"):
+        syms = declared_symbols(os.path.join(ROOT, "include", "sigutils", h), "su_")
+        assert syms, h
+        missing = [s for s in syms if not hasattr(so, s)]
+        assert not missing, f"{h}: declared but not exported: {missing}"
+        total += len(syms)
+    assert total >= 30
+
+
 def test_live_path_abi_exports_and_headers_are_valid_c(tmp_path):
     """include/suscan_amd.h: every declared suscan_* symbol is exported, the ctypes table mirrors it,
     and both headers compile as plain C (the reference binds them from C/C++)."""

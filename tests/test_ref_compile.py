@@ -72,6 +72,42 @@ def test_every_live_path_symbol_resolves_to_the_product_library(built):
             assert s in served, s
 
 
+TASK_TUS = ["CarrierXlator", "LPFTask", "CostasRecoveryTask", "PLLSyncTask", "QuadDemodTask", "WaveSampler", "AGCTask",
+            "CarrierDetector", "DopplerCalculator", "DelayedConjTask", "HistogramFeeder"]
+
+
+def test_the_offline_tasks_link_unchanged_against_the_product(built):
+    """north_star: "Tasks/ (CarrierXlator, LPFTask, CostasRecoveryTask, PLLSyncTask, QuadDemodTask, WaveSampler) link
+    unchanged".  Every su_* symbol the reference's Task objects leave undefined -- the per-sample su_ncqo_* / su_pll_* /
+    su_costas_* / su_agc_* / su_clock_detector_* calls, su_taps_apply_blackmann_harris_complex, su_specttuner_* -- is
+    exported by libsigdigger_amd.so (csrc/sigutils_host.cpp, csrc/specttuner_host.cpp); none of them is defined by the
+    test glue or the oracle, and libsdref.so (linked --no-undefined) leaves them undefined for the product to resolve."""
+    so = os.path.join(ROOT, "sigdigger_amd", "libsigdigger_amd.so")
+    exported = {l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", so], text=True).splitlines() if l}
+    wanted = set()
+    for tu in TASK_TUS:
+        wanted |= {s for s in _undefined(os.path.join(built, "obj", "Tasks", tu + ".o")) if s.startswith("su_")}
+    for s in ("su_ncqo_init", "su_ncqo_set_phase", "su_ncqo_read", "su_pll_init", "su_pll_track", "su_pll_finalize",
+              "su_costas_init", "su_costas_feed", "su_costas_finalize", "su_agc_init", "su_agc_feed", "su_agc_finalize",
+              "su_clock_detector_init", "su_clock_detector_feed", "su_clock_detector_read", "su_clock_detector_finalize",
+              "su_taps_apply_blackmann_harris_complex", "su_specttuner_new", "su_specttuner_open_channel",
+              "su_specttuner_feed_bulk", "su_specttuner_destroy"):
+        assert s in wanted, s                                  # the call sites VERDICT r2 listed
+    assert wanted <= exported, sorted(wanted - exported)
+    # ... and nothing else serves them: not the glue, not the oracle
+    ref = os.path.join(built, "libsdref.so")
+    ref_defined = {l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", ref], text=True).splitlines() if l}
+    sdo_so = os.path.join(ROOT, "oracle", "libsdo.so")
+    sdo_defined = {l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", sdo_so], text=True).splitlines() if l}
+    assert not (wanted & ref_defined) and not (wanted & sdo_defined)
+    assert wanted <= _undefined_dyn(ref)
+
+
+def _undefined_dyn(so):
+    out = subprocess.check_output(["nm", "-D", "-u", so], text=True)
+    return {l.split()[-1] for l in out.splitlines() if l.strip()}
+
+
 def _undefined(obj):
     out = subprocess.check_output(["nm", "-u", obj], text=True)
     return {l.split()[-1] for l in out.splitlines() if l.strip()}

@@ -12,9 +12,12 @@ What "equal" means, per row:
   * libm where the oracle has its own deterministic function (std::arg -> sdo_atan2f, std::abs -> sqrtf(fma), the double
     1/(|prev| + 1e-3) of DelayedConjTask.cpp:76 -> binary32) or an unfused std::complex product where the oracle fuses:
     a stated bound of a few binary32 ulp, far inside the north star's 1e-5;
-  * Tasks that call libsigutils per sample (absent; served by the oracle through oracle/ref_glue.cpp): the Task's own
-    block loop and parameter mapping are what is pinned -- bit-exact against the oracle's bulk call with the oracle's
-    statement of that mapping.
+  * Tasks that call libsigutils per sample (absent): since round 3 those calls -- su_ncqo_*, su_pll_*, su_costas_*,
+    su_agc_*, su_clock_detector_*, su_taps_apply_blackmann_harris_complex -- resolve in the PRODUCT library
+    (sigdigger_amd/csrc/sigutils_host.cpp, host code with the reference's by-value structs), not in the oracle.  The
+    reference's unchanged Task therefore runs the product's per-sample implementation, and the test compares it with the
+    oracle's restatement: BIT-EXACT -- the Task's block loop and parameter mapping, and two independent implementations
+    of SPEC.md sections D - H against each other.
 
 CPU only; skipped where neither /root/reference nor a prebuilt oracle/_ref/ exists.
 """
@@ -123,7 +126,7 @@ def test_wave_sampler_zero_crossing_symbols_equal(space, angle):
 
 @pytest.mark.parametrize("space", [1, 2])
 def test_wave_sampler_gardner_block_structure(space):
-    # the loop itself is libsigutils' (served by the oracle): what is pinned is sampleGardner()'s 4096-sample feeding,
+    # the loop itself is libsigutils' (served by the product's su_clock_detector_*): pinned are sampleGardner()'s 4096-sample feeding,
     # the FREQUENCY-space x conj(prev) pre-product with prevSample carried across work() calls, and the read-out
     bits = np.random.default_rng(8).integers(0, 2, 1300) * 2 - 1
     base = np.repeat(bits, 10)[:3 * 4096 + 123].astype(np.float32)
