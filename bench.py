@@ -4,8 +4,9 @@
     python bench.py --gpus N --steps K --warmup W [--workload c4|c2|c3] [--block LOG2]
 
 A "step" is one pass of the hot path over one resident block of synthetic IQ: 8192-pt windowed FFT
-PSD over every window of the block + the bank of inspector chains (translate + 255-tap polyphase
-decimating low-pass -> AGC -> Costas -> Gardner).  With N>1 GPUs (one process per GPU, RCCL)
+PSD over every window of the block + the bank of inspector chains (channeliser -> AGC -> Costas -> Gardner; the
+channeliser is the FFT filter bank with su_specttuner's semantics by default, --channeliser fir = translate + 255-tap
+polyphase decimating low-pass).  With N>1 GPUs (one process per GPU, RCCL)
 the inspector channels are sharded 64 per GPU, rank 0's IQ block is broadcast every step
 (double-buffered, overlapped with compute), and there is no other collective.
 
@@ -34,18 +35,26 @@ FP32_PEAK_TFLOPS = 157.3     # vector FP32 spec peak
 
 WORKLOADS = {
     # C4 / north-star target line: 50 MS/s-class IQ, 8192-pt PSD + 64 QPSK inspectors per GPU
-    "c4": dict(desc="C4 slice / north-star target: 8192-pt PSD + 64 QPSK inspectors per GPU "
-                    "(AGC+Costas+Gardner), 255-tap LPF, D=64, 50 kBd @ 50 MS/s (15.6 sps)",
+    "c4": dict(what="C4 slice / north-star target: 8192-pt PSD + 64 QPSK inspectors per GPU (AGC+Costas+Gardner)",
+               rate="D=64, 50 kBd @ 50 MS/s (15.6 sps)",
                psd=8192, per_gpu=64, D=64, T=255, sps_in=1000, kind="psk", spacing=2 * 90e3 / 50e6),
     # C2: 20 MS/s, 8192-pt PSD + 1 PSK inspector
-    "c2": dict(desc="C2: 8192-pt PSD + 1 QPSK inspector (AGC+Costas+Gardner), 255-tap LPF, D=16, "
-                    "250 kBd @ 20 MS/s (5 sps)",
+    "c2": dict(what="C2: 8192-pt PSD + 1 QPSK inspector (AGC+Costas+Gardner)", rate="D=16, 250 kBd @ 20 MS/s (5 sps)",
                psd=8192, per_gpu=1, D=16, T=255, sps_in=80, kind="psk", spacing=0.25),
     # C3: 50 MS/s, 16384-pt PSD + 64 FSK inspectors (quad-demod path)
-    "c3": dict(desc="C3: 16384-pt PSD + 64 2-FSK inspectors (quad demod + Gardner), 255-tap LPF, D=64, "
-                    "100 kBd @ 50 MS/s (7.8 sps)",
+    "c3": dict(what="C3: 16384-pt PSD + 64 2-FSK inspectors (quad demod + Gardner)", rate="D=64, 100 kBd @ 50 MS/s (7.8 sps)",
                psd=16384, per_gpu=64, D=64, T=255, sps_in=500, kind="fsk", spacing=2 * 700e3 / 50e6),
 }
+
+
+def describe(cfg, channeliser):
+    """what ran, channeliser included: the bench line must not say "255-tap LPF" over a kernel that has no taps"""
+    if channeliser == "fft":
+        ch = (f"behind the FFT filter bank (su_specttuner semantics: one 4096-pt forward FFT per half window for all channels, "
+              f"{4096 // cfg['D']}-bin channels, inverse FFT + cross-fade per channel)")
+    else:
+        ch = f"behind translate + {cfg['T']}-tap polyphase decimating LPF per channel"
+    return f"{cfg['what']} {ch}, {cfg['rate']}"
 
 
 def make_block(n, fnor, sps_in, kind, device, seed=1234):
@@ -71,51 +80,136 @@ def make_block(n, fnor, sps_in, kind, device, seed=1234):
     return x
 
 
-def cpu_baseline(cfg, nsamples, fnor_rank, ncores):
-    """Times the CPU oracle (oracle/sdo.c, a restatement -- NOT upstream sigutils) on a bounded
-    sample of the same workload on this box's host cores."""
+def cpu_baseline(cfg, nsamples, fnor_rank, ncores, channeliser):
+    """Times the CPU oracle (oracle/sdo.c, a restatement -- NOT upstream sigutils) on a bounded sample of the SAME
+    pipeline the GPU leg ran -- same channeliser algorithm, same chains -- on this box's host cores, from the
+    -O3 -march=native build of the oracle (oracle/libsdo_fast.so).  Parallel form: the PSD over frame
+    ranges, the FFT filter bank over window ranges (every channel per window, the forward transform shared as on the
+    GPU), then the serial chains one channel per task."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import sdo
-    rng = np.random.default_rng(7)
-    x = (rng.standard_normal(nsamples) + 1j * rng.standard_normal(nsamples)).astype(np.complex64) * 0.3
-    N, D, T = cfg["psd"], cfg["D"], cfg["T"]
-    sps = cfg["sps_in"] / D
-    taps = sdo.lpf_design(T, 0.75 / D)
-    win = sdo.window(4, N)
+    sdo.build_fast(force=True)                                # -march=native: always built on the box that times it
+    sdo.use_fast(True)
+    try:
+        rng = np.random.default_rng(7)
+        x = (rng.standard_normal(nsamples) + 1j * rng.standard_normal(nsamples)).astype(np.complex64) * 0.3
+        N, D, T = cfg["psd"], cfg["D"], cfg["T"]
+        nch = len(fnor_rank)
+        sps = cfg["sps_in"] / D
+        win = sdo.window(4, N)
+        f0 = [(np.pi * f) % (2 * np.pi) for f in fnor_rank]
+        bw = 2 * np.pi * 0.75 / D
+        taps = sdo.lpf_design(T, 0.75 / D)
 
-    def chain(f):
-        dp = sdo.fnor_to_dphase(-f)
-        y = sdo.chan_feed(np.zeros(T - 1, np.complex64), x, 0, sdo.chan_modulate_taps(taps, dp), D, 0, dp)
-        if cfg["kind"] == "psk":
-            a = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(sps)), y)
-            z = sdo.costas_feed_bulk(sdo.costas_new(2, 0.0, 2.0 / sps, 3, 0.005), a)
-        else:
-            z = sdo.quad_demod(y)
-        return len(sdo.clock_feed_bulk(sdo.clock_new(0.2, 1.0 / sps), z))
+        def fir_row(c):
+            dp = sdo.fnor_to_dphase(-fnor_rank[c])
+            return sdo.chan_feed(np.zeros(T - 1, np.complex64), x, 0, sdo.chan_modulate_taps(taps, dp), D, 0, dp)
 
-    def run(threads):
-        t0 = time.perf_counter()
-        sdo.psd_frames(x, nsamples // N, N, N, win, navg=nsamples // N, scale=1.0 / N)
-        if threads == 1:
-            for f in fnor_rank:
-                chain(f)
-        else:
-            with ThreadPoolExecutor(threads) as ex:
-                list(ex.map(chain, fnor_rank))
-        return time.perf_counter() - t0
+        def chain(y):
+            if cfg["kind"] == "psk":
+                a = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(sps)), y)
+                z = sdo.costas_feed_bulk(sdo.costas_new(2, 0.0, 2.0 / sps, 3, 0.005), a)
+            else:
+                z = sdo.quad_demod(y)
+            return len(sdo.clock_feed_bulk(sdo.clock_new(0.2, 1.0 / sps), z))
 
-    t1 = run(1)
-    tn = run(ncores) if ncores > 1 and len(fnor_rank) > 1 else t1
-    cores = ncores if (ncores > 1 and len(fnor_rank) > 1) else 1
-    return {
-        "value": round(nsamples / tn / 1e6, 4), "unit": "MS/s", "cores": cores, "kind": "port",
-        "value_1thread": round(nsamples / t1 / 1e6, 4),
-        "sample": f"{nsamples} complex samples of the same workload (PSD {N}-pt + {len(fnor_rank)} "
-                  f"inspector chains, direct-form channeliser) through oracle/sdo.c; `cores` = threads of the pool "
-                  f"({os.cpu_count()} logical CPUs), at most {len(fnor_rank)} of them busy (one channel per task); "
-                  f"oracle is a restatement (gcc -O2, scalar), not upstream sigutils",
-        "cpu_model": _cpu_model(),
-    }
+        def psd_range(fr):
+            return sdo.psd_frames(x[fr[0] * N:fr[1] * N], fr[1] - fr[0], N, N, win, navg=fr[1] - fr[0], scale=1.0 / N)
+
+        def run(threads):
+            nfr = nsamples // N
+            t0 = time.perf_counter()
+            if threads == 1:
+                psd_range((0, nfr))
+                rows = sdo.specttuner_bank_f32(x, f0, [bw] * nch, [1.0] * nch) if channeliser == "fft" else [fir_row(c) for c in range(nch)]
+                for y in rows:
+                    chain(y)
+            else:
+                with ThreadPoolExecutor(threads) as ex:
+                    edges = [nfr * k // threads for k in range(threads + 1)]
+                    psd_job = ex.map(psd_range, [(edges[k], edges[k + 1]) for k in range(threads) if edges[k + 1] > edges[k]])
+                    if channeliser == "fft":
+                        list(psd_job)
+                        rows = sdo.specttuner_bank_f32(x, f0, [bw] * nch, [1.0] * nch, threads=threads)
+                    else:
+                        rows = list(ex.map(fir_row, range(nch)))
+                        list(psd_job)
+                    list(ex.map(chain, rows))
+            return time.perf_counter() - t0
+
+        t1 = run(1)
+        tn = run(ncores) if ncores > 1 else t1
+        alg = ("FFT filter bank in the oracle's binary32 statement (sdo_specttuner_bank_f32: 64 x 64 forward transform shared "
+               "by all channels, per-channel inverse transform + cross-fade)") if channeliser == "fft" else \
+              f"translate + {T}-tap direct-form FIR per channel (sdo_chan_feed)"
+        return {
+            "value": round(nsamples / tn / 1e6, 4), "unit": "MS/s", "cores": ncores, "kind": "port",
+            "value_1thread": round(nsamples / t1 / 1e6, 4),
+            "threads_busy": {"psd": ncores, "channeliser": ncores if channeliser == "fft" else min(ncores, nch), "chains": min(ncores, nch)},
+            "channeliser": channeliser,
+            "sample": f"{nsamples} complex samples of the same pipeline as the GPU leg: PSD {N}-pt over every window + {alg} + "
+                      f"{nch} chains ({'AGC -> Costas -> Gardner' if cfg['kind'] == 'psk' else 'quad demod -> Gardner'}) through "
+                      f"oracle/sdo.c built -O3 -march=native -ffp-contract=off (libsdo_fast.so; scalar code, a restatement, not "
+                      f"upstream sigutils); `cores` = threads of the pool ({os.cpu_count()} logical CPUs): PSD over frame ranges, "
+                      f"channeliser over window ranges, chains one channel per task (at most {nch} busy)",
+            "cpu_model": _cpu_model(),
+        }
+    finally:
+        sdo.use_fast(False)
+
+
+def reference_loops(cfg_c3_D=64):
+    """The reference's OWN compiled loops (oracle/_ref/libsdref.so: translation units of /root/reference built by
+    oracle/Makefile.ref, g++ -O2 as SigDigger.pro builds them), timed on this box's host cores, one thread -- as the
+    reference runs them (GUI thread / one task thread).  These are the literal "reference CPU path" for rows A3 + A4
+    (PSDMessage ctor + Averager::feed per PSD frame), P2 / P3 (SpectrumView::feed over C5's 512 dwells) and T5
+    (QuadDemodTask::work, C3's demodulator).  None if the library did not travel."""
+    try:
+        from oracle import sdref
+        if not sdref.available():
+            return None
+        sdref.lib()
+    except Exception as e:                                    # a reported extra must not take the bench line down
+        return {"error": repr(e)}
+    out = {"kind": "reference", "cores": 1,
+           "built_from": "Suscan/Messages/PSDMessage.cpp, Misc/Averager.cpp, Panoramic/Scanner.cpp, Tasks/QuadDemodTask.cpp "
+                         "(/root/reference, compiled unchanged: oracle/Makefile.ref)"}
+    rng = np.random.default_rng(11)
+    # A3 + A4: 8192-bin frames through PSDMessage's constructor (fftshift + dB) and Averager::feed
+    N, F = 8192, 2000
+    frames = [rng.random(N, dtype=np.float32) + 1e-3 for _ in range(8)] * (F // 8)
+    t0 = time.perf_counter()
+    sdref.averager(frames, 0.1)
+    dt = time.perf_counter() - t0
+    out["psd_message_plus_averager"] = {"frames_per_s": round(F / dt, 1), "frame_bins": N,
+                                        "equivalent_MSps": round(F * N / dt / 1e6, 2),
+                                        "what": "PSDMessage ctor + Averager::feed per frame (PSDMessage.cpp:26-39, Averager.cpp:25-50); "
+                                                "MS/s if every 8192-sample window became a frame"}
+    # P2 / P3: C5's sweep -- 512 dwells of 8192 bins into the 65536-bin view, interpolate after each (Scanner.cpp:239-256)
+    fs, rel, dw = 20e6, 0.5, 512
+    v = sdref.SpectrumView()
+    f_lo = 100e6
+    v.set_range(f_lo, f_lo + dw * fs * rel)
+    v.set_fft(fs, rel)
+    fr = (-100 + 30 * rng.random(N)).astype(np.float32)
+    t0 = time.perf_counter()
+    for k in range(dw):
+        fc = f_lo + (k + 0.5) * fs * rel
+        v.feed(fr, fc - fs / 2, fc + fs / 2)
+        v.interpolate()
+    dt = time.perf_counter() - t0
+    out["spectrum_view_sweep"] = {"dwells": dw, "ms_per_sweep": round(dt * 1e3, 2), "dwells_per_s": round(dw / dt, 1),
+                                  "what": "SpectrumView::feed + interpolate per dwell, 8192-bin frames (Scanner.cpp:56-256)"}
+    # T5: QuadDemodTask::work over one channel's samples (C3: 64 channels at 1/64 of the input rate each)
+    m = 1 << 20
+    y = (rng.standard_normal(m) + 1j * rng.standard_normal(m)).astype(np.complex64)
+    t0 = time.perf_counter()
+    sdref.quad_demod(y)
+    dt = time.perf_counter() - t0
+    out["quad_demod_task"] = {"channel_MSps": round(m / dt / 1e6, 2),
+                              "what": f"QuadDemodTask::work (QuadDemodTask.cpp:39-76) on one channel's stream; C3 has 64 channels at "
+                                      f"1/{cfg_c3_D} of the input rate each, i.e. this many input MS/s on one thread"}
+    return out
 
 
 def pmc_traffic(kernel, workload, block):
@@ -399,6 +493,8 @@ def main():
                            "algorithmic_bytes_per_launch": psd_bytes},
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},
             "stalled_samples_dropped": dict(getattr(pipe, "stalled_samples", {})),
+            "stage_ms_unfiltered": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                                    for k, v in getattr(pipe, "stage_raw", {}).items()},
             "note": "recurrence stages (AGC/Costas/Gardner) are one-lane-per-channel and latency-bound; "
                     "they are reported in stage_ms, not against a roofline (SURVEY.md section 8d)",
         }
@@ -410,15 +506,18 @@ def main():
             "metric": "MS/s complex IQ sustained (PSD + N inspectors)", "value": round(value, 3), "unit": "MS/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["desc"], "block_samples": L, "psd_size": cfg["psd"],
+            "config": {"workload": describe(cfg, args.channeliser), "block_samples": L, "psd_size": cfg["psd"],
                        "inspectors_per_gpu": cfg["per_gpu"], "inspectors_total": cfg["per_gpu"] * world,
-                       "decimation": D, "taps": T,
+                       "decimation": D, "taps": None if fft_bank else T,
+                       "channel_bins": 4096 // D if fft_bank else None,
                        "parallelism": f"channel-sharded x{world}, RCCL broadcast of the IQ block" if world > 1
                        else "single GPU",
                        "channeliser": args.channeliser,
                        "value_definition": "rate of the IQ stream: every rank consumes the same broadcast block and runs "
                                            "its shard of the inspectors on it; symbols are copied to pinned host memory "
-                                           "inside the timed region"},
+                                           "inside the timed region.  (Round 1 multiplied by the GPU count; since round 2 it "
+                                           "does not -- N GPUs carry N x the inspectors at the same stream rate; "
+                                           "aggregate_inspector_MSps is the product.)"},
             "aggregate_inspector_MSps": round(value * cfg["per_gpu"] * world, 1),
             "roofline": roof,
         }
@@ -467,7 +566,7 @@ def main():
                 a2 = argparse.Namespace(**vars(args))
                 a2.steps, a2.warmup = max(5, min(25, args.steps // 4)), 2
                 c2, L2, dt2, st2, _, _ = run_workload(w, a2, 0, 1, dev, ctx, None)
-                extra[w] = {"workload": c2["desc"], "value_MSps": round(L2 * a2.steps / dt2 / 1e6, 3),
+                extra[w] = {"workload": describe(c2, args.channeliser), "value_MSps": round(L2 * a2.steps / dt2 / 1e6, 3),
                             "ms_per_step": round(dt2 / a2.steps * 1e3, 4),
                             "stage_ms": {k: round(v, 4) for k, v in st2.items()}}
             extra["c5"] = run_c5(args, dev, ctx)
@@ -484,7 +583,10 @@ def main():
                     out["roofline"]["fir_stage_16Mi_block"] = {"error": repr(e)}
             out["other_workloads"] = extra
         if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (rank 0's host cores)
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_samples, fn_rank, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_samples, fn_rank, os.cpu_count() or 1, args.channeliser)
+            ref = reference_loops()
+            if ref is not None:
+                out["cpu_baseline"]["reference_loops"] = ref
         print(json.dumps(out), flush=True)
 
     if dist is not None:

@@ -4,6 +4,7 @@
  *
  * Build: gcc -O2 -std=c11 -ffp-contract=off -mfma -fPIC -shared  (see Makefile)
  */
+#define _GNU_SOURCE                                      /* sincos(): see st_fft64 */
 #include "sdo.h"
 #include <math.h>
 #include <string.h>
@@ -208,9 +209,9 @@ void sdo_window(int type, float *w, size_t n)
 
 void sdo_fft_f64(double *re, double *im, size_t n)
 {
-  /* iterative radix-2 DIT; twiddles for the last size used are cached (single-threaded use) */
-  static size_t tw_n = 0;
-  static double *twr = NULL, *twi = NULL;
+  /* iterative radix-2 DIT; twiddles for the last size used are cached per thread */
+  static _Thread_local size_t tw_n = 0;                 /* per thread: the bench's CPU baseline and the full-size tests run ranges side by side */
+  static _Thread_local double *twr = NULL, *twi = NULL;
   size_t i, j, len;
   if (tw_n != n) {
     free(twr); free(twi);
@@ -434,8 +435,9 @@ void sdo_butter_lp(int order, double fc, float *b, float *a)
   int i, k, n = order;
   assert(order >= 0 && order <= SDO_IIR_MAX_ORDER);
   for (i = 0; i < n; ++i) {
-    double th = SDO_PI * (2.0 * i + n + 1.0) / (2.0 * n);
-    double pr = wc * cos(th), pi = wc * sin(th);
+    double th = SDO_PI * (2.0 * i + n + 1.0) / (2.0 * n), cth, sth;
+    sincos(th, &sth, &cth);                               /* explicitly (see st_fft64): the coefficients are bit-pinned */
+    double pr = wc * cth, pi = wc * sth;
     /* z = (1 + p) / (1 - p) */
     double dr = 1.0 - pr, di = -pi, nr = 1.0 + pr, ni = pi;
     double den = dr * dr + di * di;
@@ -1482,6 +1484,35 @@ void sdo_specttuner_geometry(unsigned W, double f0, double bw, double guard, sdo
   }
 }
 
+/* The response is designed in binary64 and rounded to binary32; its imaginary part is rounding residue (~1e-11 of the
+ * real part: the kernel is real and symmetric), so for the channeliser to be bit-pinned the binary64 transform itself is
+ * part of SPEC.md C2: iterative radix-2, decimation in time, twiddle (cos, sin)(sign 2 pi k / len) from libm per
+ * butterfly group, sign = -1 forward / +1 backward, unnormalised. */
+static void st_fft64(double *re, double *im, size_t n, int sign)
+{
+  size_t i, j, len, k;
+  for (i = 1, j = 0; i < n; ++i) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) { double t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
+  }
+  for (len = 2; len <= n; len <<= 1) {
+    const size_t half = len >> 1;
+    for (k = 0; k < half; ++k) {
+      const double ang = (double)sign * 2.0 * SDO_PI * (double)k / (double)len;
+      double wr, wi;
+      sincos(ang, &wi, &wr);                              /* explicitly: glibc's sincos and its sin / cos differ in rare last bits,
+                                                           * and compilers disagree on merging the pair (gcc does, clang does not) */
+      for (i = k; i < n; i += len) {
+        const double ur = re[i], ui = im[i];
+        const double vr = re[i + half] * wr - im[i + half] * wi, vi = re[i + half] * wi + im[i + half] * wr;
+        re[i] = ur + vr; im[i] = ui + vi; re[i + half] = ur - vr; im[i + half] = ui - vi;
+      }
+    }
+  }
+}
+
 void sdo_specttuner_response(unsigned W, unsigned size, unsigned halfw, sdo_c32 *hk)
 {
   /* brick wall -> time domain -> centred, Blackman-Harris, back -> frequency domain; k = 1/W folded in */
@@ -1489,9 +1520,8 @@ void sdo_specttuner_response(unsigned W, unsigned size, unsigned halfw, sdo_c32 
   const unsigned half = size / 2;
   unsigned i;
   for (i = 0; i < size; ++i) re[i] = (i < halfw || i >= size - halfw) ? 1.0 : 0.0;
-  for (i = 0; i < size; ++i) im[i] = -im[i];
-  sdo_fft_f64(re, im, size);                              /* backward transform = conj(forward(conj)) */
-  for (i = 0; i < size; ++i) { re[i] /= (double)size; im[i] = -im[i] / (double)size; }
+  st_fft64(re, im, size, +1);
+  for (i = 0; i < size; ++i) { re[i] /= (double)size; im[i] /= (double)size; }
   for (i = 0; i < half; ++i) {                            /* centre */
     double t = re[i]; re[i] = re[i + half]; re[i + half] = t;
     t = im[i]; im[i] = im[i + half]; im[i + half] = t;
@@ -1505,7 +1535,7 @@ void sdo_specttuner_response(unsigned W, unsigned size, unsigned halfw, sdo_c32 
     double t = re[i]; re[i] = re[i + half]; re[i + half] = t;
     t = im[i]; im[i] = im[i + half]; im[i + half] = t;
   }
-  sdo_fft_f64(re, im, size);
+  st_fft64(re, im, size, -1);
   for (i = 0; i < size; ++i) {
     const int pass = i < halfw || i >= size - halfw;
     hk[i].re = pass ? (float)(re[i] / (double)W) : 0.0f;
@@ -1654,12 +1684,16 @@ static void st32_init(void)
   if (st32_tab.ready) return;
   for (i = 0; i < 64; ++i) {
     const double a = -2.0 * SDO_PI * (double)i / 64.0, s = sin(SDO_PI * (double)i / 64.0);
-    st32_tab.w64[i].re = (float)cos(a); st32_tab.w64[i].im = (float)sin(a);
+    double cr, ci;
+    sincos(a, &ci, &cr);
+    st32_tab.w64[i].re = (float)cr; st32_tab.w64[i].im = (float)ci;
     st32_tab.win64[i] = (float)(s * s);
   }
   for (i = 0; i < 4096; ++i) {
     const double a = -2.0 * SDO_PI * (double)i / 4096.0;
-    st32_tab.tw[i].re = (float)cos(a); st32_tab.tw[i].im = (float)sin(a);
+    double cr, ci;
+    sincos(a, &ci, &cr);
+    st32_tab.tw[i].re = (float)cr; st32_tab.tw[i].im = (float)ci;
   }
   st32_tab.ready = 1;
 }
@@ -1712,7 +1746,7 @@ static void st32_dft_reg(int log2n, const cf_t *in, cf_t *out)
 /* narrow form: X = DFT_4096(win) as 64 x 64 */
 void sdo_st32_forward_narrow(const sdo_c32 *win, sdo_c32 *X)
 {
-  cf_t (*Bp)[64] = malloc(sizeof(cf_t) * 64 * 64);       /* B[t][k2] */
+  static _Thread_local cf_t Bp[64][64];                   /* B[t][k2]; per thread (window ranges run side by side) */
   int t, r, l, h;
   st32_init();
   for (t = 0; t < 64; ++t) {
@@ -1738,7 +1772,6 @@ void sdo_st32_forward_narrow(const sdo_c32 *win, sdo_c32 *X)
     st32_dft_2f(8, 8, v, A);
     for (r = 0; r < 64; ++r) X[l + 64 * r] = A[r];
   }
-  free(Bp);
 }
 
 /* Stockham autosort passes, radix <= 16, of fft_core.hpp's plan (MB = 4): ceil(bits / 4) passes, the first (bits % P)
@@ -1777,11 +1810,10 @@ static void st32_stockham(int log2n, cf_t *d, cf_t *tmp, const cf_t *tw)
 
 void sdo_st32_forward_wide(const sdo_c32 *win, sdo_c32 *X)
 {
-  cf_t *tmp = malloc(sizeof(cf_t) * 4096);
+  static _Thread_local cf_t tmp[4096];
   st32_init();
   memcpy(X, win, sizeof(cf_t) * 4096);
   st32_stockham(12, X, tmp, st32_tab.tw);
-  free(tmp);
 }
 
 /* one window of one channel: y[0 .. size) from the window's spectrum (the form follows the size) */
@@ -1838,7 +1870,9 @@ size_t sdo_specttuner_bank_f32(const sdo_c32 *x, size_t len, unsigned nchan, con
       tws[c] = malloc(sizeof(cf_t) * g[c].size);
       for (i = 0; i < g[c].size; ++i) {
         const double a = -2.0 * SDO_PI * (double)i / (double)g[c].size;
-        tws[c][i].re = (float)cos(a); tws[c][i].im = (float)sin(a);
+        double cr, ci;
+        sincos(a, &ci, &cr);
+        tws[c][i].re = (float)cr; tws[c][i].im = (float)ci;
       }
     }
   }

@@ -25,6 +25,26 @@ def build(force=False):
     return so
 
 
+def build_fast(force=False):
+    """libsdo_fast.so: the same source at -O3 -march=native (SURVEY.md 8d's CPU-baseline build) -- bench.py's timed CPU
+    leg only; every parity test uses libsdo.so"""
+    so = os.path.join(_HERE, "libsdo_fast.so")
+    src = [os.path.join(_HERE, f) for f in ("sdo.c", "sdo.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libsdo_fast.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def use_fast(on=True):
+    """switch this module's functions to libsdo_fast.so (bench.py's cpu_baseline) and back"""
+    global _LIB
+    _LIB = None
+    _USE["fast"] = bool(on)
+
+
+_USE = {"fast": False}
+
+
 class C32(C.Structure):
     _fields_ = [("re", C.c_float), ("im", C.c_float)]
 
@@ -85,7 +105,7 @@ class SpecView(C.Structure):
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        _LIB = C.CDLL(build_fast() if _USE["fast"] else build())
         L = _LIB
         L.sdo_atan2f.restype = C.c_float
         L.sdo_atan2f.argtypes = [C.c_float, C.c_float]

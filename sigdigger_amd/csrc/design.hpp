@@ -16,7 +16,9 @@ inline void butter_lp(int order, double fc, float *b, float *a)
   const int n = order;
   for (int i = 0; i < n; ++i) {
     const double th = kPi * (2.0 * i + n + 1.0) / (2.0 * n);
-    const double pr = wc * std::cos(th), pi = wc * std::sin(th);
+    double cth, sth;
+    ::sincos(th, &sth, &cth);                              // explicitly: compilers disagree on merging sin + cos, glibc's sincos differs from them in rare last bits
+    const double pr = wc * cth, pi = wc * sth;
     const double dr = 1.0 - pr, di = -pi, nr = 1.0 + pr, ni = pi;
     const double den = dr * dr + di * di;
     const double zr = (nr * dr + ni * di) / den, zi = (ni * dr - nr * di) / den;

@@ -38,7 +38,11 @@ void fft64(std::vector<double> &re, std::vector<double> &im, int sign)
   for (size_t len = 2; len <= n; len <<= 1) {
     const size_t half = len >> 1;
     for (size_t k = 0; k < half; ++k) {
-      const double ang = (double)sign * 2.0 * kPi * (double)k / (double)len, wr = std::cos(ang), wi = std::sin(ang);
+      // sincos() explicitly: glibc's sincos and its separate sin / cos differ in rare last bits, and compilers disagree on
+      // merging the pair -- the response is bit-pinned (SPEC.md C2), so the call is part of its statement
+      const double ang = (double)sign * 2.0 * kPi * (double)k / (double)len;
+      double wr, wi;
+      ::sincos(ang, &wi, &wr);
       for (size_t i = k; i < n; i += len) {
         const double ur = re[i], ui = im[i];
         const double vr = re[i + half] * wr - im[i + half] * wi, vi = re[i + half] * wi + im[i + half] * wr;
@@ -109,7 +113,9 @@ std::vector<c32> twiddles(unsigned n)
   std::vector<c32> tw(n);
   for (unsigned i = 0; i < n; ++i) {
     const double ang = -2.0 * kPi * (double)i / (double)n;
-    tw[i].re = (float)std::cos(ang); tw[i].im = (float)std::sin(ang);
+    double c, s;
+    ::sincos(ang, &s, &c);
+    tw[i].re = (float)c; tw[i].im = (float)s;
   }
   return tw;
 }

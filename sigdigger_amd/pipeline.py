@@ -259,6 +259,7 @@ class AnalyzerPipeline:
         stream each stage runs on; call after a device sync)."""
         ev = self.ev
         self.stalled_samples = {}
+        self.stage_raw = {}                   # per stage: mean and median over ALL timed steps, nothing dropped
 
         def avg(a, b):
             # Mean over the timed steps.  A sample more than 5x the median is not a launch: roughly every other run has
@@ -268,6 +269,7 @@ class AnalyzerPipeline:
             if a in ev and b in ev:
                 t = np.array([s.elapsed_time(e) for s, e in zip(ev[a], ev[b])])
                 keep = t <= 5.0 * np.median(t)
+                self.stage_raw[a[:-1]] = {"mean": float(t.mean()), "median": float(np.median(t)), "max": float(t.max()), "n": int(t.size)}
                 if not keep.all():
                     self.stalled_samples[a[:-1]] = int((~keep).sum())
                 return float(t[keep].mean())

@@ -77,6 +77,10 @@ class SpectTuner:
     def channel(self, key):
         return self._keep[key][2]
 
+    def close_channel(self, key):
+        if not self.L.su_specttuner_close_channel(self.h, self._keep[key][2]):
+            raise RuntimeError("su_specttuner_close_channel: " + _l.last_error())
+
     def feed(self, x):
         x = np.ascontiguousarray(x, dtype=np.complex64)
         if not self.L.su_specttuner_feed_bulk(self.h, x.ctypes.data_as(C.c_void_p), x.size):

@@ -145,3 +145,57 @@ def test_two_rank_shards_on_one_gpu_equal_the_single_rank_pipeline(ctx, channeli
                 assert pipeline.channel_owner(c, world) == (rank, i)
                 assert got.size == whole[c].size and got.size > 1000
                 assert np.array_equal(bits(got), bits(whole[c])), (rank, i)
+
+
+@pytest.mark.parametrize("workload", ["c4", "c3", "c2"])
+def test_the_pipeline_as_bench_py_builds_it_is_exact_end_to_end(ctx, sdo, workload):
+    """VERDICT r2 #1.  The bench's DEFAULT path -- pipeline.AnalyzerPipeline with channeliser="fft", constructed with
+    bench.py's own WORKLOADS table, block generator and block length (4 Mi samples) -- over two consecutive blocks
+    (the second one starts from carried state: history, cross-fade partners, every loop):
+      * every channel row out of the FFT channeliser equals the oracle's binary32 statement BIT FOR BIT (64 of 64 rows);
+      * the oracle's AGC -> Costas -> Gardner (quad demod -> Gardner for c3) on those rows equals the recovered
+        symbols the pipeline delivers, BIT FOR BIT, count included, for every inspector.
+    So the recovered symbols of the as-benched path are exact, not "within 2e-3"."""
+    import os
+    import bench
+    cfg = bench.WORKLOADS[workload]
+    Lb = 1 << 22
+    fn = synth.raster(cfg["per_gpu"], cfg["spacing"])
+    Dd, sps = cfg["D"], cfg["sps_in"] / cfg["D"]
+    bank = pipeline.InspectorBankConfig(kind=cfg["kind"], fnor=fn, decimation=Dd, ntaps=cfg["T"], sps=sps, channeliser="fft")
+    pipe = pipeline.AnalyzerPipeline(ctx, Lb, psd_size=cfg["psd"], psd_navg=min(256, Lb // cfg["psd"]), bank=bank, do_psd=True)
+    pipe.enable_delivery()
+    x = bench.make_block(Lb, fn, cfg["sps_in"], cfg["kind"], torch.device("cuda", 0), seed=1234)
+    xh = x.cpu().numpy()
+    nch = len(fn)
+    f0 = [(np.pi * f) % (2 * np.pi) for f in fn]
+    bw = 2 * np.pi * bank.bw_rel / Dd
+    rows = sdo.specttuner_bank_f32(np.concatenate([xh, xh]), f0, [bw] * nch, [1.0] * nch, threads=min(32, os.cpu_count() or 1))
+    hs = 4096 // Dd // 2
+    edges = [0, (Lb // 2048 - 1) * hs, (2 * Lb // 2048 - 1) * hs]          # the first block is one half window short
+    if cfg["kind"] == "psk":
+        agc = [sdo.agc_new(sdo.agc_params_from_tau(sps)) for _ in range(nch)]
+        cos = [sdo.costas_new(2, 0.0, 2.0 / sps, 3, 0.005) for _ in range(nch)]
+    clk = [sdo.clock_new(0.2, 1.0 / sps) for _ in range(nch)]
+    qprev = [0j] * nch
+    for k in range(2):
+        pipe.step(x)
+        hsym, hcnt = pipe.deliver()
+        sym, cnt = pipe.latest_symbols()
+        torch.cuda.synchronize()
+        y = pipe.y[k % pipe.NBUF][:, :edges[k + 1] - edges[k]].cpu().numpy()
+        sh, ch = sym.cpu().numpy(), cnt.cpu().numpy()
+        for c in range(nch):
+            ry = rows[c][edges[k]:edges[k + 1]]
+            assert np.array_equal(bits(y[c]), bits(ry)), f"block {k} channel {c}: channeliser row"
+            if cfg["kind"] == "psk":
+                rz = sdo.costas_feed_bulk(cos[c], sdo.agc_feed_bulk(agc[c], ry))
+            else:
+                rz = sdo.quad_demod(ry, prev=qprev[c], first=(k == 0))
+                qprev[c] = ry[-1]
+            rs = sdo.clock_feed_bulk(clk[c], rz)
+            assert ch[c] == rs.size > 100, f"block {k} channel {c}: symbol count {ch[c]} vs {rs.size}"
+            assert np.array_equal(bits(sh[c, :ch[c]]), bits(rs)), f"block {k} channel {c}: symbols"
+            # ... and what reached pinned host memory inside the bench's timed region is that
+            n = min(int(hcnt[c]), hsym.shape[1])
+            assert int(hcnt[c]) == rs.size and np.array_equal(bits(hsym[c, :n].numpy()), bits(rs[:n]))

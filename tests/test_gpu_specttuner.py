@@ -241,3 +241,99 @@ def test_reference_lpftask_unchanged_on_the_gpu_channeliser(sdo):
     guard = np.float32(2 * np.pi / float(bw))
     ref = sdo.specttuner_run(np.concatenate([x, np.zeros(2 * W, np.complex64)]), W, 0.0, float(bw), float(guard))
     assert relerr(got, ref[:n]) <= TOL
+
+
+# ---- bit for bit against the binary32 statement (SPEC.md C2 "binary32 arithmetic"; oracle/sdo.c sdo_specttuner_bank_f32) ----
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("dec", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048])
+@pytest.mark.parametrize("precise", [False, True])
+def test_every_size_equals_the_binary32_statement_bit_for_bit(ctx, sdo, dec, precise):
+    """sizes 8 .. 64 run specttuner_wave.hip (64 x 64 forward transform, fused response and cross-fade), every other size
+    specttuner.hip (radix-16 passes, unfused): the oracle states both, operation for operation"""
+    size = W // dec
+    bw = 2 * np.pi * (0.75 * size / W)
+    f0 = 2 * np.pi * 0.1371
+    x = cnoise(H * 25, 300 + dec)
+    ref = sdo.specttuner_run_f32(x, f0, bw, 1.0, precise)
+    got = run_gpu(ctx, x, [(f0, bw, 1.0, precise)], splits=[H * 7])[0]
+    assert got.size == ref.size == 24 * max(size // 2, 1)
+    assert np.array_equal(_bits(got), _bits(ref))
+
+
+def test_a_mixed_bank_equals_the_binary32_statement_bit_for_bit(ctx, sdo):
+    """150 channels of 64 bins with different responses (the per-lane response table), precise and not, plus three other
+    sizes in the same tuner, fed in three pieces with runs of 3 windows: every sample of every channel"""
+    r = np.random.default_rng(19)
+    x = cnoise(H * 30, 23)
+    chans = [(float(r.uniform(0, 2 * np.pi)), 2 * np.pi / 64 * float(r.uniform(0.3, 0.9)), 1.0, bool(c % 2)) for c in range(150)]
+    chans += [(1.1, 2 * np.pi / 16 * 0.8, 1.0, False), (4.4, 2 * np.pi / 256 * 0.7, 1.0, True), (2.9, 2 * np.pi / 512 * 0.75, 1.0, False)]
+    got = run_gpu(ctx, x, chans, splits=[H * 4, H * 17], run=3)
+    ref = sdo.specttuner_bank_f32(x, [c[0] for c in chans], [c[1] for c in chans], [c[2] for c in chans], [c[3] for c in chans], threads=8)
+    for k in range(len(chans)):
+        assert got[k].size == ref[k].size, k
+        assert np.array_equal(_bits(got[k]), _bits(ref[k])), k
+
+
+def test_full_size_block_all_64_channels_equal_the_binary32_statement(ctx, sdo):
+    """BASELINE's C4 slice as the bench builds it: 4 Mi samples, 64 channels of 64 bins on the 90 kHz raster, time-major
+    rows -- ALL 64 rows against the oracle, bit for bit (the oracle transforms the 2047 windows on the host's cores)"""
+    L = 1 << 22
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    x = torch.empty(L, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(x).normal_(generator=g)
+    fn = synth.raster(64, 2 * 90e3 / 50e6)
+    bw = 2 * np.pi * 0.75 / 64
+    st = engine.SpectTuner(ctx, W)
+    for f in fn:
+        st.open_channel(np.pi * f % (2 * np.pi), bw)
+    out, counts = st.feed(x, out=engine.time_major(64, L // 64 + 16, "cuda"))
+    torch.cuda.synchronize()
+    st.close()
+    import os
+    ref = sdo.specttuner_bank_f32(x.cpu().numpy(), [np.pi * f % (2 * np.pi) for f in fn], [bw] * 64, [1.0] * 64,
+                                  threads=min(32, os.cpu_count() or 1))
+    got = out[:, :counts[0]].cpu().numpy()
+    for c in range(64):
+        assert counts[c] == ref[c].size
+        assert np.array_equal(_bits(got[c]), _bits(ref[c])), c
+
+
+def test_reset_forgets_the_stream_position_and_closing_the_higher_channel_is_safe(ctx, sdo):
+    """suamd_specttuner_reset (seek / gap): the next feed starts like a first feed; and the advisor's case -- two channels,
+    the higher one closed, then a retune of the other (close + open reuses slots) -- with counts sized by
+    suamd_specttuner_channel_capacity()"""
+    x = cnoise(H * 20, 31)
+    bw = 2 * np.pi / 64 * 0.8
+    st = engine.SpectTuner(ctx, W)
+    a = st.open_channel(1.0, bw)
+    b = st.open_channel(2.0, bw)
+    dx = torch.from_numpy(x).cuda()
+    st.feed(dx[:H * 6])
+    st.close_channel(b)
+    assert st.capacity() == 2
+    o, cnt = st.feed(dx[H * 6:H * 8])
+    assert len(cnt) == 2 and cnt[b] == 0 and cnt[a] == 2 * 32
+    for f in (1.5, 2.5):                                           # retune twice: index a -> (new slot) -> a again
+        st.close_channel(a)
+        a = st.open_channel(f, bw)
+        o, cnt = st.feed(dx[H * 8:H * 10])
+        assert len(cnt) == st.capacity() and cnt[a] == 2 * 32
+    st.reset()
+    o, cnt = st.feed(dx[H * 10:])
+    torch.cuda.synchronize()
+    got = o[a, :cnt[a]].cpu().numpy()
+    ref = sdo.specttuner_run_f32(x[H * 10:], 2.5, bw, 1.0)
+    assert cnt[a] == 9 * 32 and np.array_equal(_bits(got), _bits(ref))   # like a fresh tuner on the rest of the stream
+    st.close()
+    # the sigutils front end sizes its counts the same way (advisor r2: flush() wrote past the vector)
+    t = sigutils.SpectTuner(W)
+    k0 = t.open_channel(0.5, float(bw), 1.0)
+    k1 = t.open_channel(1.5, float(bw), 1.0)
+    t.feed(x[:H * 4])
+    t.close_channel(k1)
+    t.feed(x[H * 4:H * 8])
+    assert t.samples(k0).size == 7 * 32
+    t.close()
