@@ -24,6 +24,7 @@ SOURCES = {
     "loops.hip": ["-ffp-contract=off"],
     "specview.hip": ["-ffp-contract=off"],
     "fft.hip": ["-ffp-contract=fast"],
+    "psd_large.hip": ["-ffp-contract=fast"],
     "specttuner.hip": ["-ffp-contract=off"],
     "specttuner_wave.hip": ["-ffp-contract=off"],
     "specttuner_host.cpp": ["-ffp-contract=off"],

@@ -204,6 +204,7 @@ struct suamd_psd {
   unsigned n, log2n;
   float *d_window;
   void  *d_twiddle;      // float2[n]
+  void  *d_tw_row = nullptr;   // frames beyond the LDS (psd_large.hip): W_N1 table of the row transforms, float2[N1]
   Scratch partial;       // split-frame partial sums
 };
 
@@ -352,7 +353,7 @@ suamd_psd_t *suamd_psd_new(suamd_ctx_t *ctx, unsigned n, int window_type)
   HIP_TRY(hipSetDevice(ctx->device), nullptr);
   std::vector<float> w(n);
   make_window(window_type, w);
-  const unsigned ntw = log2n <= 14 ? n : 1;          // the in-LDS kernels use an N-entry twiddle table
+  const unsigned ntw = n;                            // W_N table (the in-LDS kernels' passes; the column pass of psd_large.hip)
   std::vector<float> tw(2 * (size_t)ntw);
   for (unsigned i = 0; i < ntw; ++i) {
     const double ang = -2.0 * kPi * (double)i / (double)n;
@@ -364,7 +365,17 @@ suamd_psd_t *suamd_psd_new(suamd_ctx_t *ctx, unsigned n, int window_type)
   p->ctx = ctx; p->n = n; p->log2n = log2n;
   p->d_window = dev_from_host(w);
   p->d_twiddle = dev_from_host(tw);
-  if (!p->d_window || !p->d_twiddle) {
+  if (log2n > 14) {                                  // rows of N1 = N / N2 points: their own table
+    const unsigned n1 = n >> sdk::psd_large_log2n2((int)log2n);
+    std::vector<float> tr(2 * (size_t)n1);
+    for (unsigned i = 0; i < n1; ++i) {
+      const double ang = -2.0 * kPi * (double)i / (double)n1;
+      tr[2 * i] = (float)std::cos(ang);
+      tr[2 * i + 1] = (float)std::sin(ang);
+    }
+    p->d_tw_row = dev_from_host(tr);
+  }
+  if (!p->d_window || !p->d_twiddle || (log2n > 14 && !p->d_tw_row)) {
     set_err("device allocation failed");
     suamd_psd_destroy(p);
     return nullptr;
@@ -377,6 +388,7 @@ void suamd_psd_destroy(suamd_psd_t *p)
   if (!p) return;
   if (p->d_window) hipFree(p->d_window);
   if (p->d_twiddle) hipFree(p->d_twiddle);
+  if (p->d_tw_row) hipFree(p->d_tw_row);
   p->partial.release();
   delete p;
 }
@@ -392,6 +404,24 @@ SUBOOL suamd_psd_feed(suamd_psd_t *p, const suamd_complex *d_x, SUSCOUNT nframes
     // FFTWidget offers 2^9..2^20 (Default/FFT/FFTWidget.cpp:350-351) and the scanner uses
     // nextPow2(fs / 1 kHz) (Panoramic/Scanner.cpp:323): frames beyond the LDS go pass by pass through HBM
     // (batches of up to 16 Mi points = 128 MiB per ping-pong buffer, the whole job if it is smaller)
+    static const bool passes = [] { const char *e = getenv("SUAMD_PSD_LARGE"); return e && !strcmp(e, "passes"); }();   // round 2's path, for comparison
+    if (!passes) {
+      // psd_large.hip: two trips through HBM (column transforms on registers, row transforms in LDS)
+      static const long long batch_points = [] { const char *e = getenv("SUAMD_PSD_LARGE_POINTS"); const long long v = e ? atoll(e) : 0; return v >= 15 && v <= 30 ? 1ll << v : 1ll << 27; }();
+      long long batch = batch_points / (long long)p->n;         // 128 Mi points = 1 GiB of intermediate (measured: small batches that would fit the last-level cache lose more to launch tails than they gain)
+      if (batch > 32768) batch = 32768;                         // grid.y of the column pass
+      if (batch > nout * (long long)navg) batch = nout * (long long)navg;
+      if (const char *e = getenv("SUAMD_PSD_LARGE_BATCH")) { const long long v = atoll(e); if (v >= 1 && v < batch) batch = v; }   // tests: awkward batch boundaries
+      if (batch < 1) batch = 1;
+      const int ch = sdk::psd_large_chunk((int)navg), cpo = ((int)navg + ch - 1) / ch;
+      const int pring = (int)(batch / ch) + 2 * cpo + 4;        // the chunks a batch touches + an output still open
+      const size_t ab = sizeof(suamd_complex) * (size_t)p->n * (size_t)batch;
+      if (!p->partial.reserve(ab + sizeof(float) * (size_t)p->n * (size_t)pring)) { set_err("scratch allocation failed"); return SU_FALSE; }
+      char *base = static_cast<char *>(p->partial.p);
+      HIP_TRY(sdk::psd_frames_large2((int)p->log2n, d_x, (long long)hop, (int)navg, p->d_window, p->d_twiddle, p->d_tw_row, scale, mode,
+                                     d_out, nout, base, reinterpret_cast<float *>(base + ab), pring, (int)batch, as_stream(stream)), SU_FALSE);
+      return SU_TRUE;
+    }
     long long batch = (1ll << 24) / (long long)p->n;
     if (batch > nout * (long long)navg) batch = nout * (long long)navg;
     if (const char *e = getenv("SUAMD_PSD_LARGE_BATCH")) { const long long v = atoll(e); if (v >= 1 && v < batch) batch = v; }   // tests: awkward batch boundaries

@@ -260,6 +260,12 @@ hipError_t source_fix(void *x, long long nsamp, int iq_reverse, float *dc, float
 hipError_t fft_forward(void *a, void *b, int log2n, void **result, hipStream_t st, int batch = 1);
 hipError_t psd_frames_large(int log2n, const void *x, long long hop, int navg, const float *window, float scale,
                             int mode, float *out, long long nout, void *a, void *b, float *acc, int batch, hipStream_t st);
+// ---- psd_large.hip ---- frames beyond the LDS in two trips through HBM (four-step transform)
+int        psd_large_log2n2(int log2n);
+int        psd_large_chunk(int navg);
+hipError_t psd_frames_large2(int log2n, const void *x, long long hop, int navg, const float *window, const void *tw_n,
+                             const void *tw_row, float scale, int mode, float *out, long long nout, void *a, float *P, int pring,
+                             int batch, hipStream_t st);
 hipError_t fac_feed(void *a, void *b, int log2n, float alpha, long long view_start, long long view_end, float *absbuf,
                     float *fac, unsigned *mx, unsigned *mn, hipStream_t st);
 hipError_t window_pad(const void *data, long long len, long long alloc, void *buf, hipStream_t st);
