@@ -498,6 +498,7 @@ struct BlockBus {
   std::condition_variable cv;
   uint64_t seq = 0;                             // blocks published so far; block k sits in entry k & 1
   struct Entry { const void *host = nullptr; size_t samples = 0; size_t valid = 0;   // valid < samples: the stream's tail (no reallocation, no rebuild)
+                 bool via_bcast = false;          // decided by the publisher per block: every shard takes part in ONE ncclBroadcast, or none does
                   int raw_format = 0; unsigned bytes_per_sample = 8; uint64_t position = 0; unsigned samp_rate = 0; } e[2];
   bool closed = false;                          // the publisher is done (end of stream, halt, error)
   std::vector<uint64_t> done;                   // per subscriber: blocks whose host buffer it no longer needs
@@ -505,6 +506,9 @@ struct BlockBus {
   void *rccl_lib = nullptr;
   std::vector<void *> comm;
   int (*bcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*comm_destroy)(void *) = nullptr;
+  bool bcast_off = false;                       // a broadcast failed, or a shard gave up: per-GPU host copies from here on
+  uint64_t bcast_blocks = 0;                    // blocks that went out through ncclBroadcast (diagnostic, SOURCE_INFO-independent)
 };
 
 struct suscan_analyzer {
@@ -1509,18 +1513,23 @@ void bus_wait_done(suscan_analyzer *a, uint64_t upto)
   b.cv.wait(lk, [&] { for (uint64_t d : b.done) if (d < upto) return false; return true; });
 }
 
-void bus_publish(suscan_analyzer *a, const void *host, size_t samples, size_t valid, int raw_format, unsigned bps, uint64_t position)
+bool bus_publish(suscan_analyzer *a, const void *host, size_t samples, size_t valid, int raw_format, unsigned bps, uint64_t position)
 {
-  if (!a->bus || a->secondaries.empty()) return;
+  if (!a->bus || a->secondaries.empty()) return false;
   BlockBus &b = *a->bus;
   {
     std::lock_guard<std::mutex> lk(b.m);
     BlockBus::Entry &e = b.e[b.seq & 1];
     e.host = host; e.samples = samples; e.valid = valid; e.raw_format = raw_format; e.bytes_per_sample = bps; e.position = position;
     e.samp_rate = a->source_cfg.samp_rate;
+    // a collective needs every rank: if a shard has given up (its `done` is pinned at ~0) the broadcast is over for good
+    for (uint64_t d : b.done) if (d == ~0ull) b.bcast_off = true;
+    e.via_bcast = b.bcast != nullptr && !b.bcast_off;
+    if (e.via_bcast) ++b.bcast_blocks;
     ++b.seq;
   }
   b.cv.notify_all();
+  return b.e[(b.seq - 1) & 1].via_bcast;                     // (only the publisher writes the entries)
 }
 
 void bus_close(suscan_analyzer *a)
@@ -1529,6 +1538,13 @@ void bus_close(suscan_analyzer *a)
   { std::lock_guard<std::mutex> lk(a->bus->m); a->bus->closed = true; }
   a->bus->cv.notify_all();
   for (suscan_analyzer *s : a->secondaries) { s->halt = true; if (s->worker.joinable()) s->worker.join(); }
+  if (a->bus->rccl_lib) {                                      // every shard's thread is gone: the communicators can go
+    (void)hipDeviceSynchronize();
+    if (a->bus->comm_destroy) for (void *c : a->bus->comm) if (c) (void)a->bus->comm_destroy(c);
+    a->bus->comm.clear(); a->bus->bcast = nullptr;
+    dlclose(a->bus->rccl_lib);
+    a->bus->rccl_lib = nullptr;
+  }
 }
 
 // shards 1 .. G-1: no source, no PSD, no detector -- the published blocks through this GPU's inspectors
@@ -1593,7 +1609,10 @@ void secondary_main(suscan_analyzer *a)
     void *dst = compact ? a->d_raw : (void *)a->d_x;
     const size_t bytes = e.valid * e.bytes_per_sample;
     bool sent = false;
-    if (bus.bcast) sent = bus.bcast(nullptr, dst, bytes, 0 /* ncclInt8 */, 0, bus.comm[a->shard], a->stream) == 0;
+    if (e.via_bcast) {
+      sent = bus.bcast(nullptr, dst, bytes, 0 /* ncclInt8 */, 0, bus.comm[a->shard], a->stream) == 0;
+      if (!sent) { std::lock_guard<std::mutex> lk(bus.m); bus.bcast_off = true; }
+    }
     if (!sent) (void)hipMemcpyAsync(dst, e.host, bytes, hipMemcpyHostToDevice, a->stream);
     (void)hipEventRecord(a->ev_h2d[0], a->stream);
     if (compact && !suamd_ingest_iq(a->ctx, e.raw_format, a->d_raw, e.valid, a->d_x, a->stream))
@@ -1636,9 +1655,16 @@ void setup_rccl(suscan_analyzer *a)
   if (!mode || strcasecmp(mode, "rccl")) return;
   std::vector<int> devs{a->device};
   for (suscan_analyzer *s : a->secondaries) devs.push_back(s->device);
-  for (size_t i = 0; i < devs.size(); ++i) for (size_t j = i + 1; j < devs.size(); ++j) if (devs[i] == devs[j]) return;
-  void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  // RCCL refuses two ranks on one device; SUAMD_RCCL_ALLOW_SAME_DEVICE=1 is for the test stand-in (tests/rccl_standin.cpp),
+  // which lets the one-GPU test box run this branch with the device list 0,0
+  const char *same = std::getenv("SUAMD_RCCL_ALLOW_SAME_DEVICE");
+  if (!(same && std::atoi(same) != 0))
+    for (size_t i = 0; i < devs.size(); ++i) for (size_t j = i + 1; j < devs.size(); ++j) if (devs[i] == devs[j]) return;
+  // SUAMD_RCCL_LIB: an explicit library path (site builds of RCCL; the test stand-in)
+  const char *path = std::getenv("SUAMD_RCCL_LIB");
+  void *lib = path && *path ? dlopen(path, RTLD_NOW | RTLD_LOCAL) : nullptr;
+  if (!lib && !(path && *path)) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!lib && !(path && *path)) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
   if (!lib) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, 0, "SUAMD_ANALYZER_BCAST=rccl: librccl not found, using per-GPU host copies"); return; }
   using InitAll = int (*)(void **, int, const int *);
   using Bcast = int (*)(const void *, void *, size_t, int, int, void *, hipStream_t);
@@ -1653,6 +1679,7 @@ void setup_rccl(suscan_analyzer *a)
   (void)hipSetDevice(a->device);                             // ncclCommInitAll walks the devices
   std::lock_guard<std::mutex> lk(a->bus->m);
   a->bus->rccl_lib = lib; a->bus->comm = comm; a->bus->bcast = bcast;
+  a->bus->comm_destroy = reinterpret_cast<int (*)(void *)>(dlsym(lib, "ncclCommDestroy"));
 }
 
 void worker_main(suscan_analyzer *a)
@@ -1813,8 +1840,8 @@ void worker_main(suscan_analyzer *a)
     }
     if (!fatal.empty()) { (void)reader.wait(&looped_next); finish(flight); push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, fatal); break; }
     // every other GPU shard takes the block from here (what the filters left)
-    if (h_flt) bus_publish(a, h_flt, a->block, blen, SUAMD_FORMAT_RAW_FLOAT32, sizeof(suamd_complex), consumed);
-    else bus_publish(a, h_cur, a->block, blen, src.raw_format, src.bytes_per_sample(), consumed);
+    const bool via_bcast = h_flt ? bus_publish(a, h_flt, a->block, blen, SUAMD_FORMAT_RAW_FLOAT32, sizeof(suamd_complex), consumed)
+                                 : bus_publish(a, h_cur, a->block, blen, src.raw_format, src.bytes_per_sample(), consumed);
     // the previous block's channeliser must be done with d_x before this block lands in it (its PSD is on this stream)
     if (a->xfree_set) (void)hipStreamWaitEvent(a->stream, a->ev_xfree, 0);
     if (h_flt) {
@@ -1826,10 +1853,13 @@ void worker_main(suscan_analyzer *a)
       (void)hipMemcpyAsync(a->d_raw, h_cur, blen * src.bytes_per_sample(), hipMemcpyHostToDevice, a->stream);
       if (!suamd_ingest_iq(a->ctx, src.raw_format, a->d_raw, blen, a->d_x, a->stream)) fatal = suamd_last_error();
     }
-    if (a->bus && a->bus->bcast && !a->secondaries.empty()) {   // SUAMD_ANALYZER_BCAST=rccl: GPU 0 is the root of one broadcast per block
+    if (via_bcast) {                                         // SUAMD_ANALYZER_BCAST=rccl: GPU 0 is the root of one broadcast per block
       void *root = src.bytes_per_sample() == sizeof(suamd_complex) || h_flt ? (void *)a->d_x : a->d_raw;
       const size_t bytes = blen * (h_flt ? sizeof(suamd_complex) : src.bytes_per_sample());
-      if (a->bus->bcast(root, root, bytes, 0, 0, a->bus->comm[0], a->stream) != 0) { a->bus->bcast = nullptr; }
+      if (a->bus->bcast(root, root, bytes, 0, 0, a->bus->comm[0], a->stream) != 0) {
+        std::lock_guard<std::mutex> lk(a->bus->m);
+        a->bus->bcast_off = true;                              // (the shards that could not take part fall back to their host copy themselves)
+      }
     }
     (void)hipEventRecord(a->ev_h2d[cur], a->stream);
     a->h2d_set[cur] = true;
