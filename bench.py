@@ -414,6 +414,32 @@ def run_c5(args, dev, ctx, log2_file=30, N=8192, tile=256):
                              "algorithmic_bytes_per_launch": psd_bytes}}
 
 
+def run_live_sharded(n_gpus, inspectors_per_gpu=64, nblocks=40, timeout_s=240):
+    """The drop-in itself on N GPUs: ONE process, the suscan_analyzer_* ABI with SUAMD_DEVICES=0..N-1 (csrc/analyzer.cpp:
+    one worker thread per GPU, inspector handle h on GPU h mod N, the block to every shard by ncclBroadcast over xGMI,
+    one message queue) and 64 heterogeneous PSK inspectors per GPU.  Run in a child process with a deadline: a secondary
+    figure must not be able to hang the bench."""
+    import subprocess
+    env = dict(os.environ, SUAMD_DEVICES=",".join(str(i) for i in range(n_gpus)))
+    if n_gpus > 1:
+        env["SUAMD_ANALYZER_BCAST"] = "rccl"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    code = ("import json, sys; sys.path.insert(0, %r); from sigdigger_amd.livebench import live_rate; "
+            "print('LIVE ' + json.dumps(live_rate(%d, %d)))" % (ROOT, inspectors_per_gpu * n_gpus, nblocks))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        for ln in r.stdout.splitlines():
+            if ln.startswith("LIVE "):
+                d = json.loads(ln[5:])
+                d["devices"] = env["SUAMD_DEVICES"]
+                d["block_exchange"] = "ncclBroadcast (RCCL over xGMI), root GPU 0" if n_gpus > 1 else "none (one GPU)"
+                return d
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -431,10 +457,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (c2, c3, c5)")
     ap.add_argument("--cpu-samples", type=int, default=1 << 23)
+    ap.add_argument("--live", action="store_true",
+                    help="time the sharded live analyzer instead (one process, SUAMD_DEVICES=0..N-1; run WITHOUT torchrun): "
+                         "the drop-in boundary itself on N GPUs")
     ap.add_argument("--isolated", action="store_true",
                     help="after the timed region also time the FIR and PSD kernels alone on an idle GPU")
     args = ap.parse_args()
 
+    if args.live:
+        d = run_live_sharded(args.gpus, nblocks=max(20, min(200, args.steps)))
+        val = d.get("value_MSps")
+        print(json.dumps({"metric": "MS/s complex IQ sustained (PSD + N inspectors)", "value": val, "unit": "MS/s", "n_gpus": args.gpus,
+                          "steps": d.get("blocks"), "warmup": 0, "ms_per_step": d.get("ms_per_block"), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": d.get("workload"), "parallelism": f"live analyzer, inspectors sharded over {args.gpus} GPU(s) "
+                                     f"behind one suscan_analyzer handle (SUAMD_DEVICES)", "inspectors_total": d.get("inspectors"),
+                                     "block_exchange": d.get("block_exchange")},
+                          "live": d}), flush=True)
+        return
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ       # under torch.distributed.run
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -582,6 +622,10 @@ def main():
                 except Exception as e:
                     out["roofline"]["fir_stage_16Mi_block"] = {"error": repr(e)}
             out["other_workloads"] = extra
+        if world > 1 and os.environ.get("SUAMD_BENCH_LIVE_SHARDED", "1") != "0" and not share:
+            # the curve of the drop-in itself: the C++ analyzer sharded over the same N GPUs (the other ranks idle at the
+            # barrier below; their GPUs are free)
+            out["live_sharded_analyzer"] = run_live_sharded(world)
         if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_samples, fn_rank, os.cpu_count() or 1, args.channeliser)
             ref = reference_loops()

@@ -130,7 +130,11 @@ SUAMD_API SUBOOL   suamd_audio_feed(suamd_audio_t *au, const suamd_complex *d_x,
  * level smoothing) smooths the reported peak level.  SPEC.md section O: smoothed spectrum, floor = smoothed median, runs
  * of bins above snr * floor (gaps of up to two bins bridged, single-bin runs dropped). */
 typedef struct suamd_chandet suamd_chandet_t;
-struct suamd_channel { SUFREQ fc, f_lo, f_hi; SUFLOAT bw, snr, S0, N0; };   /* Hz relative to the spectrum's centre; snr, S0, N0 in dB */
+/* Hz relative to the spectrum's centre; snr, S0, N0 in dB.  beta (the detector's signal-level smoothing): a channel
+ * that contains the centre of a channel of the previous list continues it -- S0 <- S0_prev + beta (S0_now - S0_prev) in
+ * dB, snr = S0 - N0 with it, age <- age_prev + 1 -- any other starts at S0_now with age 0 (SPEC.md section O).
+ * beta <= 0 or >= 1: no smoothing. */
+struct suamd_channel { SUFREQ fc, f_lo, f_hi; SUFLOAT bw, snr, S0, N0; unsigned age; };
 SUAMD_API suamd_chandet_t *suamd_chandet_new(suamd_ctx_t *ctx, unsigned n /* power of two, 512 .. 16384 */,
                                              SUFLOAT alpha, SUFLOAT beta, SUFLOAT gamma, SUFLOAT snr);
 SUAMD_API void   suamd_chandet_destroy(suamd_chandet_t *det);

@@ -695,6 +695,25 @@ class ChannelDetector:
         return float(self.d.N0)
 
 
+def chandet_track(prev, now, beta):
+    """SPEC.md section O, beta: `now` = [(fc, f_lo, f_hi, S0_dB), ...] of this update, `prev` = [(fc, S0_dB, age), ...] as
+    reported by the previous one.  A channel that contains the centre of a previous channel continues it (the first such, in
+    list order): S0 <- S0_prev + beta (S0_now - S0_prev) in binary32, age + 1; any other starts at S0_now, age 0.
+    Returns [(fc, S0, age), ...].  (A handful of values per update: plain Python.)"""
+    out = []
+    b = np.float32(beta)
+    for fc, lo, hi, s0 in now:
+        s0, age = np.float32(s0), 0
+        if 0.0 < beta < 1.0:
+            for pfc, ps0, page in prev:
+                if lo <= pfc <= hi:
+                    s0 = np.float32(np.float32(ps0) + np.float32(b * np.float32(s0 - np.float32(ps0))))
+                    age = page + 1
+                    break
+        out.append((fc, s0, age))
+    return out
+
+
 # ---- Q: audio inspector ---------------------------------------------------------------------------------
 def audio_run(x, mode, efs, bw, fa, cutoff, volume=1.0):
     x = _c(x)

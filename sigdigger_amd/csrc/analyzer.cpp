@@ -1412,7 +1412,7 @@ void push_channels(suscan_analyzer *a, int slot)
     auto *c = static_cast<sigutils_channel *>(std::calloc(1, sizeof(sigutils_channel)));
     c->fc = list[k].fc; c->f_lo = list[k].f_lo; c->f_hi = list[k].f_hi;      // relative to the tuner, like Analyzer::open's channels
     c->bw = list[k].bw; c->snr = list[k].snr; c->S0 = list[k].S0; c->N0 = list[k].N0;
-    c->ft = ft; c->age = 0; c->present = 1;
+    c->ft = ft; c->age = list[k].age; c->present = 1;
     m->channel_list[k] = c;
   }
   push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_CHANNEL, m);

@@ -21,6 +21,8 @@ struct suamd_chandet {
   sdk::ChanDetRecord *d_rec = nullptr;
   unsigned *d_count = nullptr;
   struct Landing { unsigned count; float N0; sdk::ChanDetRecord rec[CAP]; } *h[2] = {nullptr, nullptr};   // pinned
+  struct Track { double fc; float S0; unsigned age; };
+  std::vector<Track> tracks;                                   // the previous list: beta smooths a continuing channel's level
 };
 
 extern "C" {
@@ -90,8 +92,21 @@ int suamd_chandet_collect(suamd_chandet_t *d, int slot, SUFLOAT samp_rate, struc
     out[k].bw = (SUFLOAT)(out[k].f_hi - out[k].f_lo);
     out[k].S0 = 10.0f * std::log10(r.peak + 1e-8f);
     out[k].N0 = n0db;
+    out[k].age = 0;
+    // beta: the channel of the previous list whose centre lies inside this one is continued (the first such, in
+    // frequency order)
+    if (d->beta > 0.0f && d->beta < 1.0f) {
+      for (const suamd_chandet::Track &t : d->tracks)
+        if (t.fc >= out[k].f_lo && t.fc <= out[k].f_hi) {
+          out[k].S0 = t.S0 + d->beta * (out[k].S0 - t.S0);
+          out[k].age = t.age + 1;
+          break;
+        }
+    }
     out[k].snr = out[k].S0 - n0db;
   }
+  d->tracks.clear();
+  for (unsigned i = 0; i < k; ++i) d->tracks.push_back(suamd_chandet::Track{out[i].fc, out[i].S0, out[i].age});
   return (int)k;
 }
 

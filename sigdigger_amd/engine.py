@@ -400,7 +400,7 @@ class ChannelDetector:
         n = self.ctx.lib.suamd_chandet_channels(self.h, float(samp_rate), out, cap, _stream(stream))
         if n < 0:
             raise SigDiggerAmdError("suamd_chandet_channels: " + _l.last_error())
-        return [dict(fc=c.fc, f_lo=c.f_lo, f_hi=c.f_hi, bw=c.bw, snr=c.snr, S0=c.S0, N0=c.N0) for c in out[:n]]
+        return [dict(fc=c.fc, f_lo=c.f_lo, f_hi=c.f_hi, bw=c.bw, snr=c.snr, S0=c.S0, N0=c.N0, age=c.age) for c in out[:n]]
 
     def noise_floor(self, stream=None):
         return float(self.ctx.lib.suamd_chandet_noise_floor(self.h, _stream(stream)))

@@ -27,7 +27,7 @@ class View(C.Structure):
 
 class Channel(C.Structure):
     """struct suamd_channel"""
-    _fields_ = [("fc", F64), ("f_lo", F64), ("f_hi", F64), ("bw", F32), ("snr", F32), ("S0", F32), ("N0", F32)]
+    _fields_ = [("fc", F64), ("f_lo", F64), ("f_hi", F64), ("bw", F32), ("snr", F32), ("S0", F32), ("N0", F32), ("age", UINT)]
 
 
 class AgcParams(C.Structure):

@@ -268,6 +268,25 @@ def test_channel_detector_bit_exact_and_channel_messages(tmp_path, sdo, ctx):
         assert g["f_lo"] == (first - n / 2 - 0.5) * df and g["f_hi"] == (last - n / 2 + 0.5) * df
         assert g["fc"] == (ws / s - n / 2) * df
         assert abs(g["S0"] - 10 * np.log10(peak + 1e-8)) < 1e-5                 # dB formatting on the host: libm log10f
+        assert g["age"] == 0                                                      # the first list: nothing to continue
+    # beta (the detector's signal-level smoothing): a second list continues the channels of the first -- levels smoothed
+    # towards the new peaks, ages counted; a detector with beta = 0 reports the new peaks themselves
+    det0 = engine.ChannelDetector(ctx, n, alpha=0.2, beta=0.0, gamma=0.5, snr=4.0)
+    detb = engine.ChannelDetector(ctx, n, alpha=0.2, beta=0.25, gamma=0.5, snr=4.0)
+    lists0, listsb = [], []
+    for k in range(3):
+        P = np.roll((base * (1.0 + 0.5 * k) * rng.chisquare(8, n).astype(np.float32) / 8).astype(np.float32), n // 2)
+        for d_, ls in ((det0, lists0), (detb, listsb)):
+            d_.feed(torch.from_numpy(P).cuda())
+            ls.append(d_.channels(1e6))
+    prev = []
+    for raw, sm in zip(lists0, listsb):
+        assert [c["age"] for c in raw] == [0] * len(raw) and len(raw) == len(sm)
+        want = sdo.chandet_track(prev, [(c["fc"], c["f_lo"], c["f_hi"], c["S0"]) for c in raw], 0.25)
+        for c, (fc, s0, age) in zip(sm, want):
+            assert c["fc"] == fc and c["age"] == age and np.float32(c["S0"]) == s0 and c["snr"] == np.float32(np.float32(c["S0"]) - np.float32(c["N0"]))
+        prev = want
+    assert max(c["age"] for c in listsb[-1]) == 2
     # (b)
     nblocks = 12
     fcs = [-300e3, 50e3, 220e3]

@@ -59,3 +59,13 @@ def test_two_ranks_share_the_gpu_over_gloo():
     # inspectors on it); the aggregate channel rate is reported beside it
     assert abs(d["value"] - d["config"]["block_samples"] / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
     assert abs(d["aggregate_inspector_MSps"] - d["value"] * d["config"]["inspectors_total"]) < 0.01 * d["aggregate_inspector_MSps"]
+
+
+def test_live_mode_times_the_sharded_analyzer_itself():
+    """`bench.py --live --gpus N` (no torchrun): one process, the suscan_analyzer_* ABI with SUAMD_DEVICES = 0..N-1 -- the
+    C++ sharded analyzer that IS the drop-in (csrc/analyzer.cpp), not the Python harness.  N = 1 on the test box."""
+    r = subprocess.run([sys.executable, "bench.py", "--live", "--gpus", "1", "--steps", "20"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 1 and d["unit"] == "MS/s" and d["live"]["devices"] == "0" and "error" not in d["live"]
+    assert d["value"] > 50.0 and d["config"]["inspectors_total"] == 64
