@@ -522,7 +522,11 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
         if (st->run_wave) a.run = (int)st->run_wave;
         else {
           const long long ny = ((long long)g.members.size() + sdk::stw_channels_per_wave(g.log2s) - 1) / sdk::stw_channels_per_wave(g.log2s);
-          a.run = (int)std::max<long long>(1, (nwin * ny + 767) / 768);
+          // (SUAMD_ST_SLOTS: the wavefront budget of a launch, default 768; a long block rounds up to whole windows per
+          // wavefront far below the budget anyway, and there a larger budget is pure gain)
+          static const long long slots = [] { const char *e = std::getenv("SUAMD_ST_SLOTS"); const long long v = e ? std::atoll(e) : 0; return v >= 64 && v <= 4096 ? v : 0; }();
+          const long long budget = slots ? slots : 768;
+          a.run = (int)std::max<long long>(1, (nwin * ny + budget - 1) / budget);
         }
         {
           const long long ny = ((long long)g.members.size() + sdk::stw_channels_per_wave(g.log2s) - 1) / sdk::stw_channels_per_wave(g.log2s);

@@ -69,6 +69,10 @@ constexpr int WV_LDS = (WV_HK + 64) * 8;
 #else
 #define TS(n) do { } while (0)
 #endif
+#ifndef STW_EARLY_LDS
+#define STW_EARLY_LDS 1
+#endif
+constexpr bool EARLY_LDS = STW_EARLY_LDS != 0;                 // transposition writes / reads interleaved with the arithmetic around them
 constexpr int AUX_NT = 2;                                      // nt: the outputs are written once and not read back here (64 ch x 4 Mi: 36.1 -> 34.4 us)
 constexpr int AUX_SC1 = 16;                                    // cache-policy bit of the raw buffer builtins: sc1 (agent scope)
 
@@ -108,9 +112,14 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
     if (r < WAVE / 2) nxt[r] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(ra, t * 8, r * WAVE * 8, AUX_SC1));
     else nxt[r] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(rb, t * 8, (r - WAVE / 2) * WAVE * 8, 0));
   };
+  // (in the order the first transform consumes them -- its first-stage sub-transform n1 reads registers n1 + 8 n2 -- so
+  // that a wavefront whose requests trickle in, as at the start of a launch when every wavefront asks at once, can begin
+  // after the first eight)
   auto issue_all = [&]() {
 #pragma unroll
-    for (int r = 0; r < WAVE; ++r) load_one(r);
+    for (int n1 = 0; n1 < 8; ++n1)
+#pragma unroll
+      for (int n2 = 0; n2 < 8; ++n2) load_one(n1 + 8 * n2);
   };
   auto aim_window = [&](long long w) { aim((w == 0 && a.have_hist) ? hist : x + (w * H - off), H * 8, x + (w * H + H - off), H * 8); };
   const bool final_run = w_end == a.nwin;
@@ -261,6 +270,13 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
 #pragma unroll
           for (int l = 2; l < 8; l += 2) cmul3x2(A[8 * h + l], hi[h], lo[l], A[8 * h + l + 1], hi[h], lo[l + 1], A[8 * h + l], A[8 * h + l + 1]);
         }
+        // this group's eight products go to the transposition buffer right away: the LDS writes travel under the next
+        // group's arithmetic instead of in one burst behind the last
+        if constexpr (EARLY_LDS) {
+          cf *wr = buf + t * WV_PITCH;
+#pragma unroll
+          for (int l = 0; l < 8; ++l) wr[8 * h + l] = A[8 * h + l];
+        }
         if constexpr (UNIFORM) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) load_one(4 * h + r);
@@ -270,15 +286,41 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
     }
     TS(3);
     {
-      cf *wr = buf + t * WV_PITCH;
+      if constexpr (!EARLY_LDS) {
+        cf *wr = buf + t * WV_PITCH;
 #pragma unroll
-      for (int k2 = 0; k2 < WAVE; ++k2) wr[k2] = A[k2];
+        for (int k2 = 0; k2 < WAVE; ++k2) wr[k2] = A[k2];
+      }
       __builtin_amdgcn_wave_barrier();
       const cf *rd = buf + t;
+      if constexpr (EARLY_LDS) {
+        // in the order the second transform consumes them (its first-stage sub-transform n1 reads v[n1 + 8 n2]): the first
+        // sub-transform can start after 8 reads instead of 57
 #pragma unroll
-      for (int tt = 0; tt < WAVE; ++tt) v[tt] = rd[tt * WV_PITCH];
+        for (int n1 = 0; n1 < 8; ++n1)
+#pragma unroll
+          for (int n2 = 0; n2 < 8; ++n2) v[n1 + 8 * n2] = rd[(n1 + 8 * n2) * WV_PITCH];
+      } else {
+#pragma unroll
+        for (int tt = 0; tt < WAVE; ++tt) v[tt] = rd[tt * WV_PITCH];
+      }
     }
     TS(4);
+    // (EARLY_LDS: the rows of the spectrum a second-stage sub-transform completes -- X[t + 64 (k2 + 8 k1)], k1 = 0..7 --
+    // go to LDS behind it; every lane's reads of the transposition buffer are done by then: the second stage starts after
+    // the first has consumed all 64 values)
+    auto spectrum_rows = [&](int step) {
+      if constexpr (EARLY_LDS) {
+        if (step >= 8) {
+          if (step == 8) __builtin_amdgcn_wave_barrier();       // all lanes are through with the transposition buffer
+          const int k2 = step - 8;
+          cf *sp = buf + t;
+#pragma unroll
+          for (int k1 = 0; k1 < 8; ++k1) sp[(k2 + 8 * k1) * WAVE] = A[k2 + 8 * k1];
+          if (k2 == 0 && t < WV_REP) buf[W + t] = A[0];
+        }
+      }
+    };
     if constexpr (UNIFORM) {
       dft_reg<6>(v, A, [&](int step) {                         // A[k1] = X[t + 64 k1]
         if (step < 8) {
@@ -286,8 +328,9 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
           for (int r = 0; r < 4; ++r) load_one(WAVE / 2 + 4 * step + r);
           __builtin_amdgcn_sched_barrier(0);
         }
+        spectrum_rows(step);
       });
-    } else dft_reg<6>(v, A);
+    } else dft_reg<6>(v, A, spectrum_rows);
     TS(5);
     cf hkr[UNIFORM ? 1 : NG][UNIFORM ? 1 : S];
     if constexpr (!UNIFORM) {
@@ -303,8 +346,8 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
       aim_next(w);
       issue_all();
     }
-    __builtin_amdgcn_wave_barrier();
-    {
+    if constexpr (!EARLY_LDS) {
+      __builtin_amdgcn_wave_barrier();
       cf *sp = buf + t;
 #pragma unroll
       for (int k1 = 0; k1 < WAVE; ++k1) sp[k1 * WAVE] = A[k1];
