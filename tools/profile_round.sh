@@ -22,6 +22,36 @@ python tools/st_bench.py > $OUT/kernel_microbench.txt 2>&1
 python tools/fir_bench.py >> $OUT/kernel_microbench.txt 2>&1
 python tools/psd_bench.py >> $OUT/kernel_microbench.txt 2>&1
 bash tools/st_pmc.sh > $OUT/st_sq_counters.txt 2>&1
+python tools/psd_large.py > $OUT/psd_large_frames.txt 2>&1
+SUAMD_PSD_LARGE=passes python tools/psd_large.py > $OUT/psd_large_frames_passes.txt 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmcl_$c -o p -- python tools/psd_large.py > /dev/null 2> $OUT/pmcl_$c.err
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_psdl -o t -- python tools/psd_large.py > /dev/null 2> $OUT/trace_psdl.err
 python tools/prof_summary.py $OUT $TAG
 cp $OUT/st_sq_counters.txt profiles/${TAG}_st_sq_counters.txt 2>/dev/null
+python - <<PY
+import csv, glob, collections, json
+out = "$OUT"
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for fn in glob.glob(f"{out}/pmcl_{c}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(fn)):
+            if r["Counter_Name"] == c and ("psdl_" in r["Kernel_Name"] or "psd_kernel" in r["Kernel_Name"]):
+                k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0] + f" [grid {r['Grid_Size']}]"
+                acc[k][c].append(float(r["Counter_Value"]))
+res = {k: {"launches": len(v["FETCH_SIZE"]), "FETCH_SIZE_KiB": sum(v["FETCH_SIZE"]) / max(1, len(v["FETCH_SIZE"])),
+           "WRITE_SIZE_KiB": sum(v["WRITE_SIZE"]) / max(1, len(v["WRITE_SIZE"])),
+           "hbm_bytes_per_launch": int(2048 * sum(v["FETCH_SIZE"]) / max(1, len(v["FETCH_SIZE"])) + 1024 * sum(v["WRITE_SIZE"]) / max(1, len(v["WRITE_SIZE"])))}
+       for k, v in sorted(acc.items())}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/psd_large.py: 2^28 samples per feed, "
+                     "frames of 16384 (in-LDS kernel) .. 1048576 points (psd_large.hip); per-launch averages, KiB; "
+                     "HBM bytes = 2 FETCH + WRITE (gfx950 half-count of streamed reads)", "kernels_by_grid": res},
+          open(f"profiles/${TAG}_psd_large_pmc.json", "w"), indent=1)
+PY
+cp $OUT/psd_large_frames.txt profiles/${TAG}_psd_large_frames.txt
+echo "--- round 2's path (SUAMD_PSD_LARGE=passes: radix-16 passes through HBM) ---" >> profiles/${TAG}_psd_large_frames.txt
+cat $OUT/psd_large_frames_passes.txt >> profiles/${TAG}_psd_large_frames.txt
+f=$(find $OUT/trace_psdl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" profiles/${TAG}_psd_large_kernel_stats.csv
+mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
 ls -la $OUT
