@@ -117,6 +117,30 @@ def test_psd_large_frames_batches_do_not_change_the_bits(ctx, sdo, monkeypatch):
     assert np.all(err < PSD_TOL), err
 
 
+@pytest.mark.parametrize("n", [1 << 15, 1 << 16, 1 << 18, 1 << 19])
+def test_psd_large_frames_every_column_size_overlap_and_windows(ctx, sdo, n):
+    """psd_large.hip (four-step transform, two trips through HBM): both column sizes (32 points per thread up to 2^17, 64
+    above), overlapping frames (hop = N/2 + 3: the column pass reads frames where they lie), navg that does not divide the
+    frame count (the incomplete output is not produced), every window function, ragged chunking (navg = 5: chunks of 2)"""
+    navg, hop = 5, n // 2 + 3
+    nframes = 2 * navg + 3
+    x = synth.tone_noise((nframes - 1) * hop + n, f_rel=0.3317, sigma2=3e-2, seed=n % 977)
+    for wt in (0, 1, 2, 3, 4):
+        win = sdo.window(wt, n)
+        ref = sdo.psd_frames(x, nframes, n, hop, win, navg=navg, scale=1.0 / n)
+        psd = engine.PSD(ctx, n, wt)
+        out = host(psd.feed(dev(x), nframes=nframes, hop=hop, navg=navg, scale=1.0 / n))
+        assert out.shape == ref.shape == (2, n)
+        err = np.max(np.abs(out - ref), axis=1) / np.max(ref, axis=1)
+        assert np.all(err < PSD_TOL), (wt, err)
+        assert np.array_equal(np.argmax(out, axis=1), np.argmax(ref, axis=1))
+        if wt != 4:
+            continue
+        one = host(psd.feed(dev(x), nframes=3, hop=hop, navg=1, scale=1.0 / n))          # navg = 1: every frame an output
+        ref1 = sdo.psd_frames(x, 3, n, hop, win, navg=1, scale=1.0 / n)
+        assert np.all(np.max(np.abs(one - ref1), axis=1) / np.max(ref1, axis=1) < PSD_TOL)
+
+
 def test_psd_split_frame_accumulation(ctx, sdo):
     """many frames averaged into few outputs: the frames of one output are split over several
     workgroups and reduced in a fixed order (deterministic, run-to-run identical)."""
