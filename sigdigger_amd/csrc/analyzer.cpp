@@ -341,7 +341,8 @@ struct Inspector {
   suscan_config_t *config = nullptr;
   unsigned D = 1;
   double equiv_fs = 0, fnor = 0;
-  SUSCOUNT watermark = 0;
+  SUSCOUNT watermark = 0;                      // > 0: SAMPLES batches of exactly this many samples (Suscan/Analyzer.cpp:528-537)
+  std::vector<suamd_complex> wm_buf;           // what has not filled a batch yet (flushed at EOS / close)
   bool dirty = true;                          // chain must be (re)built
   suamd_chanbank_t *bank = nullptr;           // channeliser "fir": translate + 255-tap low-pass + decimate (SPEC.md C)
   suamd_specttuner_t *st = nullptr;           // channeliser "fft": a channel of the analyzer's su_specttuner (SPEC.md C2)
@@ -756,15 +757,34 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
   return true;
 }
 
-void emit_samples(suscan_analyzer *a, const Inspector &in, size_t count)
+void push_samples(suscan_analyzer *a, const Inspector &in, const suamd_complex *src, size_t count)
 {
-  if (count == 0 || count > in.cap) return;
   auto *m = static_cast<suscan_analyzer_sample_batch_msg *>(std::calloc(1, sizeof(suscan_analyzer_sample_batch_msg)));
   m->inspector_id = in.inspector_id;
   m->sample_count = count;
   m->samples = static_cast<suamd_complex *>(std::malloc(count * sizeof(suamd_complex)));
-  std::memcpy(m->samples, in.h_out, count * sizeof(suamd_complex));       // delivered by the device before the sync
+  std::memcpy(m->samples, src, count * sizeof(suamd_complex));
   push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_SAMPLES, m);
+}
+
+// One block's output of an inspector.  No watermark: one SAMPLES message per block.  Watermark w
+// (Analyzer::setInspectorWatermark, Suscan/Analyzer.cpp:528-537): batches of exactly w samples; what does not fill one
+// waits for the next block (flush_watermark at EOS / close).  The stream is the same either way.
+void emit_samples(suscan_analyzer *a, Inspector &in, size_t count)
+{
+  if (count == 0 || count > in.cap) return;
+  if (in.watermark == 0 && in.wm_buf.empty()) { push_samples(a, in, in.h_out, count); return; }   // delivered by the device before the sync
+  in.wm_buf.insert(in.wm_buf.end(), in.h_out, in.h_out + count);
+  const size_t w = in.watermark ? (size_t)in.watermark : in.wm_buf.size();    // (the watermark was just cleared: everything goes)
+  size_t off = 0;
+  for (; in.wm_buf.size() - off >= w && w > 0; off += w) push_samples(a, in, in.wm_buf.data() + off, w);
+  in.wm_buf.erase(in.wm_buf.begin(), in.wm_buf.begin() + (long)off);
+}
+
+void flush_watermark(suscan_analyzer *a, Inspector &in)
+{
+  if (!in.wm_buf.empty()) push_samples(a, in, in.wm_buf.data(), in.wm_buf.size());
+  in.wm_buf.clear();
 }
 
 // INSPECTOR/SPECTRUM: the selected source's transform of this block's channel samples, then every whole
@@ -1172,6 +1192,7 @@ void handle_request(suscan_analyzer *a, Request &r)
       auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_CLOSE, r.req_id);
       m->handle = r.handle;
       m->inspector_id = it->second->inspector_id;
+      flush_watermark(a, *it->second);                         // what had not filled a batch goes out before the CLOSE
       it->second->free_all();
       a->inspectors.erase(it);
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
@@ -1640,6 +1661,7 @@ void secondary_main(suscan_analyzer *a)
     ++k;
   }
   finish();
+  for (auto &kv : a->inspectors) flush_watermark(a, *kv.second);   // before the publisher's EOS (bus_close joins this thread first)
   give_up();
   free_device(a);
 }
@@ -1798,6 +1820,7 @@ void worker_main(suscan_analyzer *a)
     const size_t blen = !last ? a->block : (a->use_fft ? got / 2048 * 2048 : got);
     if (blen == 0) {
       finish(flight);
+      for (auto &kv : a->inspectors) flush_watermark(a, *kv.second);
       bus_close(a);                                          // the other GPU shards deliver what they still hold: before EOS
       push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_EOS, 0, "end of stream");
       break;
@@ -1923,6 +1946,7 @@ void worker_main(suscan_analyzer *a)
     if (!a->pipelined) finish(flight);
     if (last) {
       finish(flight);
+      for (auto &kv : a->inspectors) flush_watermark(a, *kv.second);
       consumed += blen;
       a->position = consumed;
       bus_close(a);                                          // the other GPU shards deliver what they still hold: before EOS

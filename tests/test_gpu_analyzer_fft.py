@@ -514,3 +514,50 @@ def test_end_of_stream_flushes_the_tail_of_every_channel(tmp_path, sdo):
     ref = sdo.specttuner_run_f32(x[b * H:], f0, bwa, guard)
     assert got.size == ref.size == (nh - 1) * hs
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+
+def test_watermark_sets_the_batch_size_and_the_stream_stays_the_same(tmp_path, sdo):
+    """Analyzer::setInspectorWatermark (Suscan/Analyzer.cpp:528-537): SAMPLES batches of exactly `watermark` samples; what
+    does not fill a batch waits, the rest goes out before EOS.  Concatenated, the batches are the stream without a
+    watermark -- here the oracle's, bit for bit."""
+    nblocks, wm = 6, 1000
+    fc, bw = -150e3, 40e3
+    x = synth.psk_carriers(L * nblocks, [2 * fc / FS], sps=64, order=4, seed=14, snr_db=25)
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    Lb, mq, an = _start(path, L)
+    Lb.suscan_analyzer_set_throttle_async(an, 4 * FS, 0)
+    ch = suscan.Channel(fc=fc, f_lo=fc - bw / 2, f_hi=fc + bw / 2, bw=bw, ft=433.92e6)
+    assert Lb.suscan_analyzer_open_ex_async(an, b"raw", C.byref(ch), 0, -1, 3)
+    st = {"psd": 0, "open_at": None, "sizes": [], "samples": [], "ack": None, "eos_at": None}
+
+    def on_msg(t, ptr):
+        if t == suscan.MSG_PSD:
+            st["psd"] += 1
+        elif t == suscan.MSG_EOS:
+            st["eos_at"] = len(st["sizes"])
+        elif t == suscan.MSG_INSPECTOR:
+            m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
+            if m.kind == suscan.KIND_OPEN:
+                st["open_at"] = st["psd"]
+                assert Lb.suscan_analyzer_set_inspector_watermark_async(an, m.handle, wm, 4)
+            elif m.kind == suscan.KIND_SET_WATERMARK:
+                st["ack"] = m.watermark
+        elif t == suscan.MSG_SAMPLES:
+            m = C.cast(ptr, C.POINTER(suscan.SampleBatchMsg)).contents
+            st["sizes"].append(int(m.sample_count))
+            st["samples"].append(np.ctypeslib.as_array(m.samples, shape=(m.sample_count * 2,)).copy().view(np.complex64))
+
+    _pump(Lb, an, on_msg)
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+    assert st["ack"] == wm and st["eos_at"] == len(st["sizes"])       # every batch, the flushed remainder included, before EOS
+    sizes = st["sizes"]
+    first_wm = next(i for i, n in enumerate(sizes) if n == wm)          # (a block may have gone out whole before the request took effect)
+    assert all(n == wm for n in sizes[first_wm:-1]) and 0 < sizes[-1] <= wm and len(sizes) - first_wm > 20
+    D, f0, bwa, guard = _chan_params(fc, bw)
+    got = np.concatenate(st["samples"])
+    b = nblocks - (got.size // (W // D // 2) + 1) * H // L
+    ref = sdo.specttuner_run_f32(x[b * L:], f0, bwa, guard)
+    assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32))

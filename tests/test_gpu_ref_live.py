@@ -106,8 +106,8 @@ def test_reference_analyzer_class_drives_the_gpu_library(tmp_path, sdo):
     psd, samples = _run_ctypes(iq, fc, bw, ref["equiv_fs"], "raw")
     # PSDMessage's constructor has shifted the frame and taken dB in place (Suscan/Messages/PSDMessage.cpp:26-39)
     assert np.array_equal(ref["psd"], sdo.psd_shift_db(psd))
-    # (what is still below an inspector's watermark at the end of the stream is not flushed, and a channel's oscillator
-    # starts when the channel is opened: the two streams may stop at different samples and differ by one constant phase.
+    # (a request lands on whatever block boundary the worker has reached and a channel's oscillator starts when the channel
+    # is opened: the two streams may start at different samples and differ by one constant phase.
     # Align on the reference run's last kilo-sample by magnitude, then require one constant unit phasor between them.)
     a, b = ref["samples"], samples
     assert a.size > 3000 and b.size > 3000
