@@ -1,4 +1,4 @@
-"""Generates tests/golden/oracle_v1.npz and oracle_v2.npz from the CPU oracle.
+"""Generates tests/golden/oracle_v1.npz, oracle_v2.npz and oracle_v3.npz from the CPU oracle.
 
 The reference (SigDigger) ships NO golden vectors and its DSP libraries are absent
 (SURVEY.md section 8c), so these fixtures are produced by oracle/sdo.c itself on seeded inputs: they
@@ -82,8 +82,40 @@ def compute_v2(sdo):
     return out
 
 
+V3_CHANNELS = [  # (f0, bw, guard, precise): sizes 64, 64, 16, 8 (narrow form), 256 and 2 (wide form)
+    (0.83, 2 * np.pi * 0.75 / 64, 1.0, False), (4.91, 2 * np.pi * 0.5 / 64, 1.0, True), (2.2, 2 * np.pi * 0.8 / 256, 1.0, False),
+    (5.9, 2 * np.pi * 0.7 / 512, 1.0, True), (1.4, 2 * np.pi * 0.75 / 16, 1.0, True), (3.3, 2 * np.pi * 0.9 / 2048, 1.0, False)]
+
+
+def compute_v3(sdo):
+    """third fixture set (round 3): the FFT channeliser in its binary32 statement (SPEC.md C2, "binary32 arithmetic") -- what
+    the device kernels equal bit for bit -- with the default chain behind one of its channels, and the channel designs"""
+    from sigdigger_amd import synth
+    out = {}
+    x = synth.psk_carriers(2048 * 9, [0.83 / np.pi, (4.91 - 2 * np.pi) / np.pi], sps=256, order=4, seed=321, snr_db=25)
+    out["input_iq"] = x
+    rows = sdo.specttuner_bank_f32(x, [c[0] for c in V3_CHANNELS], [c[1] for c in V3_CHANNELS], [c[2] for c in V3_CHANNELS],
+                                   [c[3] for c in V3_CHANNELS])
+    for k, r in enumerate(rows):
+        out[f"st32_row{k}"] = r
+    geom, hk = [], []
+    for f0, bw, guard, _ in V3_CHANNELS:
+        g = sdo.specttuner_geometry(4096, f0, bw, guard)
+        geom.append([g.size, g.halfsz, g.halfw, g.decimation, g.center, g.dphase])
+        hk.append(sdo.specttuner_response(4096, g.size, g.halfw))
+    out["st_geometry"] = np.array(geom, dtype=np.uint32)
+    out["st_response_64"] = hk[0]
+    out["st_response_256"] = hk[2].astype(np.complex64)
+    a = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(4.0)), rows[0])
+    z = sdo.costas_feed_bulk(sdo.costas_new(2, 0.0, 0.5, 3, 0.01), a)
+    out["st32_chain_symbols"] = sdo.clock_feed_bulk(sdo.clock_new(0.2, 0.25), z)
+    return out
+
+
 def main():
     from oracle import sdo
+    np.savez_compressed(os.path.join(HERE, "oracle_v3.npz"), **compute_v3(sdo))
+    print("wrote", os.path.join(HERE, "oracle_v3.npz"))
     np.savez_compressed(os.path.join(HERE, "oracle_v1.npz"), **compute(sdo))
     print("wrote", os.path.join(HERE, "oracle_v1.npz"))
     np.savez_compressed(os.path.join(HERE, "oracle_v2.npz"), **compute_v2(sdo))

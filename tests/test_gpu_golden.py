@@ -1,4 +1,4 @@
-"""HIP path against the COMMITTED fixtures (tests/golden/oracle_v1.npz, oracle_v2.npz) -- not against a live
+"""HIP path against the COMMITTED fixtures (tests/golden/oracle_v1.npz, oracle_v2.npz, oracle_v3.npz) -- not against a live
 oracle run: inputs and expected outputs both come out of the .npz files.  Bit exact for the inspector chain and
 the integer / byte work, the FFT-based entries within the stated tolerance."""
 import os
@@ -100,3 +100,42 @@ def test_v2_stages(ctx):
     assert np.max(np.abs(fac.array() - g["fac_1024"])) < 2e-5
     mn, mx = fac.range()
     assert abs(mx - g["fac_range"][1]) <= 1e-5 * g["fac_range"][1]
+
+
+
+def test_v3_fft_channeliser_and_the_default_chain(ctx):
+    """oracle_v3.npz: six channels of the FFT channeliser (sizes 64, 64, 256, 512 -> 8 ..., both arithmetic forms, precise and
+    not) -- every row bit for bit --, the product's channel designs, and AGC -> Costas -> Gardner behind row 0"""
+    import ctypes as C
+    from sigdigger_amd import lib
+    from tests.golden.make_golden import V3_CHANNELS
+    g = np.load(os.path.join(GOLDEN, "oracle_v3.npz"))
+    x = g["input_iq"]
+    st = engine.SpectTuner(ctx, 4096)
+    ids = [st.open_channel(*c) for c in V3_CHANNELS]
+    out, counts = st.feed(dev(x))
+    torch.cuda.synchronize()
+    rows = [host(out[c, :counts[c]]) for c in ids]
+    st.close()
+    for k, r in enumerate(rows):
+        same_bits(r.view(np.uint32), g[f"st32_row{k}"].view(np.uint32), f"channeliser row {k}")
+    L = lib.load()
+    for k, (f0, bw, guard, _) in enumerate(V3_CHANNELS):
+        geom = (C.c_uint32 * 6)()
+        hk = np.empty(int(g["st_geometry"][k][0]), np.complex64)
+        assert L.suamd_specttuner_design(4096, f0, bw, guard, geom, hk.ctypes.data_as(C.c_void_p))
+        assert list(geom) == list(g["st_geometry"][k])
+        if k == 0:
+            same_bits(hk.view(np.uint32), g["st_response_64"].view(np.uint32), "response, 64 bins")
+        if k == 2:
+            same_bits(hk.view(np.uint32), g["st_response_256"].view(np.uint32), "response, 256 bins")
+    y = rows1(rows[0])
+    a = engine.AGCBank(ctx, 1, tau=4.0).feed(y)
+    z = engine.CostasBank(ctx, 1, 2, 0.0, 0.5, 3, 0.01).feed(a)
+    sym = torch.zeros((1, z.shape[1] + 1), dtype=torch.complex64, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    engine.ClockBank(ctx, 1, 0.2, 0.25).feed(z, sym, cnt)
+    torch.cuda.synchronize()
+    n = int(cnt[0])
+    assert n == g["st32_chain_symbols"].size
+    same_bits(host(sym)[0, :n].view(np.uint32), g["st32_chain_symbols"].view(np.uint32), "symbols behind the channeliser")
