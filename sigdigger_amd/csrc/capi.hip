@@ -205,6 +205,7 @@ struct suamd_psd {
   float *d_window;
   void  *d_twiddle;      // float2[n]
   void  *d_tw_row = nullptr;   // frames beyond the LDS (psd_large.hip): W_N1 table of the row transforms, float2[N1]
+  void  *d_tw_half = nullptr;  // 32768-point frames in one trip (psd_kernel HALVES): W_16384 table
   Scratch partial;       // split-frame partial sums
 };
 
@@ -374,6 +375,15 @@ suamd_psd_t *suamd_psd_new(suamd_ctx_t *ctx, unsigned n, int window_type)
       tr[2 * i + 1] = (float)std::sin(ang);
     }
     p->d_tw_row = dev_from_host(tr);
+    if (log2n == 15) {
+      std::vector<float> th(2 * (size_t)(n / 2));
+      for (unsigned i = 0; i < n / 2; ++i) {
+        const double ang = -2.0 * kPi * (double)i / (double)(n / 2);
+        th[2 * i] = (float)std::cos(ang);
+        th[2 * i + 1] = (float)std::sin(ang);
+      }
+      p->d_tw_half = dev_from_host(th);
+    }
   }
   if (!p->d_window || !p->d_twiddle || (log2n > 14 && !p->d_tw_row)) {
     set_err("device allocation failed");
@@ -389,6 +399,7 @@ void suamd_psd_destroy(suamd_psd_t *p)
   if (p->d_window) hipFree(p->d_window);
   if (p->d_twiddle) hipFree(p->d_twiddle);
   if (p->d_tw_row) hipFree(p->d_tw_row);
+  if (p->d_tw_half) hipFree(p->d_tw_half);
   p->partial.release();
   delete p;
 }
@@ -404,7 +415,23 @@ SUBOOL suamd_psd_feed(suamd_psd_t *p, const suamd_complex *d_x, SUSCOUNT nframes
     // FFTWidget offers 2^9..2^20 (Default/FFT/FFTWidget.cpp:350-351) and the scanner uses
     // nextPow2(fs / 1 kHz) (Panoramic/Scanner.cpp:323): frames beyond the LDS go pass by pass through HBM
     // (batches of up to 16 Mi points = 128 MiB per ping-pong buffer, the whole job if it is smaller)
-    static const bool passes = [] { const char *e = getenv("SUAMD_PSD_LARGE"); return e && !strcmp(e, "passes"); }();   // round 2's path, for comparison
+    // SUAMD_PSD_LARGE (read per call: the tests switch it): "passes" = round 2's radix-16 passes through HBM, "twotrip" =
+    // psd_large.hip for 32768 points too
+    const char *mode_env = getenv("SUAMD_PSD_LARGE");
+    const bool passes = mode_env && !strcmp(mode_env, "passes"), two_trip = mode_env && !strcmp(mode_env, "twotrip");
+    if (p->log2n == 15 && !passes && !two_trip && p->d_tw_half) {
+      // 32768 points (the scanner at 20 MS/s): ONE trip through HBM -- two workgroups per output on the 16384-point kernel,
+      // each forms one of the two interleaved half spectra's operands from the whole frame on the way in (psd.hip, HALVES)
+      const int S = sdk::psd_split(2 * nout, (int)navg, 14);
+      float *partial = nullptr;
+      if (S > 1) {
+        if (!p->partial.reserve(sizeof(float) * (size_t)nout * S * p->n)) { set_err("scratch allocation failed"); return SU_FALSE; }
+        partial = static_cast<float *>(p->partial.p);
+      }
+      HIP_TRY(sdk::psd_frames_32k(d_x, (long long)hop, (int)navg, p->d_window, p->d_tw_half, p->d_twiddle, scale, mode, d_out, nout,
+                                  partial, as_stream(stream)), SU_FALSE);
+      return SU_TRUE;
+    }
     if (!passes) {
       // psd_large.hip: two trips through HBM (column transforms on registers, row transforms in LDS)
       static const long long batch_points = [] { const char *e = getenv("SUAMD_PSD_LARGE_POINTS"); const long long v = e ? atoll(e) : 0; return v >= 15 && v <= 30 ? 1ll << v : 1ll << 27; }();

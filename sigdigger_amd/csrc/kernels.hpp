@@ -19,6 +19,8 @@ int        psd_split(long long nout, int navg, int log2n);
 hipError_t psd_frames(int log2n, const void *x, long long hop, int navg, const float *window,
                       const void *tw, float scale, int mode, float *out, long long nout, float *partial,
                       hipStream_t st);
+hipError_t psd_frames_32k(const void *x, long long hop, int navg, const float *window, const void *tw, const void *tw2,
+                          float scale, int mode, float *out, long long nout, float *partial, hipStream_t st);
 hipError_t psd_shift_db(float *psd, long long n, long long nframes, hipStream_t st);
 hipError_t averager_feed(float *last, const float *x, long long n, float alpha, int blend, hipStream_t st);
 hipError_t insp_spectrum_db_shift(float *data, long long len, long long nspec, hipStream_t st);

@@ -39,12 +39,19 @@ typedef float __attribute__((ext_vector_type(2))) f2;
 // grid.x = number of output frames, grid.y = S (split of the navg frames of one output over S
 // workgroups; S > 1 writes unscaled partial sums to `partial`, reduced by psd_reduce_kernel in a
 // fixed order so the result is deterministic)
-template <int LOG2N, int THREADS, bool STREAM>
+// HALVES (round 3): a frame of 2 N points on this N-point kernel, in ONE trip through HBM.  Decimation in frequency by two:
+//   X[2k]     = DFT_N( w[n] x[n] + w[n+N] x[n+N] )[k]
+//   X[2k + 1] = DFT_N( (w[n] x[n] - w[n+N] x[n+N]) W_2N^n )[k]
+// Two workgroups per output (blockIdx.x = 2 o + r) each read the WHOLE frame -- the second read of a frame comes out of
+// the last-level cache, not HBM -- and form their half's operands on the way in; everything behind pass 0's operands is
+// the N-point kernel unchanged, bin k of half r lands at 2 k + r.  `tw2`: W_2N table (2 N entries).
+template <int LOG2N, int THREADS, bool STREAM, bool HALVES = false>
 // second launch bound: two workgroups per CU must fit the register file (N = 16384 is LDS-limited to one)
 __global__ __launch_bounds__(THREADS, ((1 << LOG2N) / THREADS >= 32 ? 2 : (THREADS >= 1024 ? 4 : (THREADS >= 128 ? THREADS / 128 : 1)))) void psd_kernel(const cf *__restrict__ x, long long hop, int navg,
                                                       const float *__restrict__ window,
                                                       const cf *__restrict__ tw, float scale, int mode,
-                                                      float *__restrict__ out, float *__restrict__ partial)
+                                                      float *__restrict__ out, float *__restrict__ partial,
+                                                      const cf *__restrict__ tw2 = nullptr)
 {
   __builtin_amdgcn_s_setprio(3);   // ahead of the resident recurrence wavefronts (see chan_fir_kernel)
   using PL = PlanFor<LOG2N, THREADS>;
@@ -56,7 +63,13 @@ __global__ __launch_bounds__(THREADS, ((1 << LOG2N) / THREADS >= 32 ? 2 : (THREA
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf *lds = reinterpret_cast<cf *>(smem);
   const int tid0 = threadIdx.x;
-  const long long o = blockIdx.x;
+  // HALVES: the two workgroups of an output sit 8 apart in dispatch order -- workgroups go round the 8 XCDs, so the pair
+  // shares an L2 and the frame's second reader finds it there (when the grid's width is a multiple of 16; any other
+  // width pairs neighbours: correct, just no shared L2)
+  const bool paired = HALVES && (gridDim.x & 15) == 0;
+  const long long o = !HALVES ? (long long)blockIdx.x : paired ? 8ll * (blockIdx.x >> 4) + (blockIdx.x & 7) : (long long)(blockIdx.x >> 1);
+  const int half = !HALVES ? 0 : paired ? (int)((blockIdx.x >> 3) & 1) : (int)(blockIdx.x & 1);   // which of the two interleaved half spectra
+  constexpr int NT = HALVES ? 2 * N : N;                       // points of a frame / bins of an output
 
   float pw[E];
 #pragma unroll
@@ -79,7 +92,7 @@ __global__ __launch_bounds__(THREADS, ((1 << LOG2N) / THREADS >= 32 ? 2 : (THREA
   // rest of the address is scalar; a zero-length descriptor makes the request of the frame after the last a no-op)
   auto descr = [&](int f) {
     const cf *fr = x + (o * navg + f) * hop;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(fr), 0, f < f_end ? N * 8 : 0, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(fr), 0, f < f_end ? NT * 8 : 0, 0x00020000);
   };
   // (PAIR0 plans: the thread's NB0 = 2 butterflies are neighbours, so request q fetches operand q of both: 16 bytes)
   constexpr int NREQ = PL::PAIR0 ? R0 : E;
@@ -116,7 +129,28 @@ __global__ __launch_bounds__(THREADS, ((1 << LOG2N) / THREADS >= 32 ? 2 : (THREA
 #endif
     PTS(1);
     // pass 0 operands: the prefetched samples, window applied on the fly
-    if constexpr (PL::PAIR0) {
+    if constexpr (HALVES) {
+      static_assert(!HALVES || PL::PAIR0, "the two-halves front is written for the 32-point threads");
+      // the frame's second half: requested now, combined with the first as it arrives
+      const __amdgpu_buffer_rsrc_t r = descr(f);
+#pragma unroll
+      for (int q = 0; q < R0; ++q) {
+        const f4 s2 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, tid0 * 16 + N * 8, q * (N / R0) * 8, STREAM ? AUX_STREAM : AUX_DEFAULT));
+        v[q] = s2.xy; v[R0 + q] = s2.zw;
+      }
+      const f2 *w2 = reinterpret_cast<const f2 *>(window) + tid;
+      const f4 *t2 = reinterpret_cast<const f4 *>(tw2) + tid;            // W_2N^(2 tid + q N/R0), W_2N^(2 tid + 1 + q N/R0)
+#pragma unroll
+      for (int q = 0; q < R0; ++q) {
+        const f2 wa = w2[q * (N / R0 / 2)], wb = w2[(N / 2) + q * (N / R0 / 2)];
+        const cf a0 = nxt[q] * wa.x, a1 = nxt[R0 + q] * wa.y, b0 = v[q] * wb.x, b1 = v[R0 + q] * wb.y;
+        if (half == 0) { v[q] = a0 + b0; v[R0 + q] = a1 + b1; }
+        else {
+          const f4 tq = t2[q * (N / R0 / 2)];
+          v[q] = cmul(a0 - b0, tq.xy); v[R0 + q] = cmul(a1 - b1, tq.zw);
+        }
+      }
+    } else if constexpr (PL::PAIR0) {
       const f2 *w2 = reinterpret_cast<const f2 *>(window) + tid;        // window[2 tid + q N/R0], window[2 tid + 1 + ...]
 #pragma unroll
       for (int q = 0; q < R0; ++q) {
@@ -173,20 +207,20 @@ __global__ __launch_bounds__(THREADS, ((1 << LOG2N) / THREADS >= 32 ? 2 : (THREA
   // epilogue: thread holds power of bins j + q*N/RL (last-pass geometry)
   const float sc = (S > 1) ? 1.0f : scale / (float)navg;
   if (S > 1) mode = 0;
-  float *dst = (S > 1) ? partial + (o * S + blockIdx.y) * N : out + o * N;
+  float *dst = (S > 1) ? partial + (o * S + blockIdx.y) * NT : out + o * NT;
   constexpr int NBL = E / RL;
 #pragma unroll
   for (int b = 0; b < NBL; ++b) {
     const int j = tid0 + b * THREADS;
 #pragma unroll
     for (int q = 0; q < RL; ++q) {
-      const int i = j + q * (N / RL);
+      const int i = HALVES ? 2 * (j + q * (N / RL)) + half : j + q * (N / RL);     // bin of the output frame
       float p = pw[b * RL + q] * sc;
       if (mode == 0) {
         dst[i] = p;
       } else {
         // Suscan/Messages/PSDMessage.cpp:29-38: out[(i + N/2) mod N] = 10 log10(p + 1e-8)
-        dst[(i + N / 2) & (N - 1)] = 10.0f * log10f(p + 1e-8f);
+        dst[(i + NT / 2) & (NT - 1)] = 10.0f * log10f(p + 1e-8f);
       }
     }
   }
@@ -225,13 +259,14 @@ __global__ __launch_bounds__(256) void psd_reduce_kernel(const float *__restrict
   }
 }
 
-template <int LOG2N, int THREADS, bool STREAM>
+template <int LOG2N, int THREADS, bool STREAM, bool HALVES = false>
 hipError_t launch_psd_p(const void *x, long long hop, int navg, const float *window, const void *tw,
-                      float scale, int mode, float *out, long long nout, float *partial, int S, hipStream_t st)
+                      float scale, int mode, float *out, long long nout, float *partial, int S, hipStream_t st,
+                      const void *tw2 = nullptr)
 {
-  constexpr int N = 1 << LOG2N;
+  constexpr int N = 1 << LOG2N, NT = HALVES ? 2 * N : N;
   const size_t lds = sizeof(cf) * (size_t)(N + (N >> 4) + 1);
-  auto kern = psd_kernel<LOG2N, THREADS, STREAM>;
+  auto kern = psd_kernel<LOG2N, THREADS, STREAM, HALVES>;
   static bool attr_done_dev[64] = {};                        // a function attribute belongs to a device
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
@@ -242,12 +277,12 @@ hipError_t launch_psd_p(const void *x, long long hop, int navg, const float *win
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nout, (unsigned)S), dim3(THREADS), lds, st,
+  hipLaunchKernelGGL(kern, dim3((unsigned)(HALVES ? 2 * nout : nout), (unsigned)S), dim3(THREADS), lds, st,
                      reinterpret_cast<const cf *>(x), hop, navg, window, reinterpret_cast<const cf *>(tw),
-                     scale, mode, out, partial);
+                     scale, mode, out, partial, reinterpret_cast<const cf *>(tw2));
   if (S > 1) {
-    hipLaunchKernelGGL(psd_reduce_kernel, dim3((N + 63) / 64, (unsigned)nout), dim3(256), 0, st,
-                       partial, S, N, scale / (float)navg, mode, out);
+    hipLaunchKernelGGL(psd_reduce_kernel, dim3((NT + 63) / 64, (unsigned)nout), dim3(256), 0, st,
+                       partial, S, NT, scale / (float)navg, mode, out);
   }
   return hipGetLastError();
 }
@@ -376,6 +411,20 @@ hipError_t psd_frames(int log2n, const void *x, long long hop, int navg, const f
     case 14: return launch_psd<14, 512>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
     default: return hipErrorInvalidValue;
   }
+}
+
+// 32768-point frames in one trip: two workgroups per output on the 16384-point kernel (see psd_kernel, HALVES).
+// tw: W_16384 table, tw2: W_32768 table; partial: nout * psd_split(2 nout, navg, 14) * 32768 floats (or nullptr)
+hipError_t psd_frames_32k(const void *x, long long hop, int navg, const float *window, const void *tw, const void *tw2,
+                          float scale, int mode, float *out, long long nout, float *partial, hipStream_t st)
+{
+  if (nout <= 0) return hipSuccess;
+  const int S = partial ? psd_split(2 * nout, navg, 14) : 1;
+  static int force = -2;
+  if (force == -2) { const char *e = getenv("SUAMD_PSD_STREAM"); force = e ? atoi(e) : -1; }
+  const bool stream = force >= 0 ? force != 0 : nout * navg * hop * 8 > PSD_STREAM_BYTES;
+  return stream ? launch_psd_p<14, 512, true, true>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st, tw2)
+                : launch_psd_p<14, 512, false, true>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st, tw2);
 }
 
 hipError_t psd_shift_db(float *psd, long long n, long long nframes, hipStream_t st)

@@ -99,10 +99,15 @@ def test_psd_large_frames(ctx, sdo, n, nframes, navg):
     assert np.max(np.abs(db - np.stack([sdo.psd_shift_db(f) for f in ref]))) < 5 * DB_TOL
 
 
-def test_psd_large_frames_batches_do_not_change_the_bits(ctx, sdo, monkeypatch):
-    """The large-frame path sends its frames through in batches (one launch per pass for a whole batch); where a batch
-    ends -- inside an output, on its last frame, several outputs later -- must not show in the result."""
-    n, nframes, navg = 32768, 40, 13
+@pytest.mark.parametrize("n,path", [(65536, None), (32768, "twotrip"), (32768, None)])
+def test_psd_large_frames_batches_do_not_change_the_bits(ctx, sdo, monkeypatch, n, path):
+    """The two-trip large-frame path (psd_large.hip: 65536 points and up; 32768 with SUAMD_PSD_LARGE=twotrip) sends its
+    frames through in batches; where a batch ends -- inside an output, inside a chunk of an output's sum, on its last
+    frame, several outputs later -- must not show in the result.  (32768 points by default take ONE trip -- two
+    workgroups per output on the 16384-point kernel, psd.hip HALVES -- and know no batches: the knob must change nothing.)"""
+    if path:
+        monkeypatch.setenv("SUAMD_PSD_LARGE", path)
+    nframes, navg = 40, 13
     x = synth.tone_noise(n * nframes, f_rel=-0.1203, sigma2=1e-2, seed=5)
     psd = engine.PSD(ctx, n, engine.WINDOW_BLACKMANN_HARRIS)
     whole = host(psd.feed(dev(x), nframes=nframes, navg=navg, scale=1.0 / n))              # one batch of 39 frames
