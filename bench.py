@@ -414,7 +414,7 @@ def run_c5(args, dev, ctx, log2_file=30, N=8192, tile=256):
                              "algorithmic_bytes_per_launch": psd_bytes}}
 
 
-def run_live_sharded(n_gpus, inspectors_per_gpu=64, nblocks=40, timeout_s=240):
+def run_live_sharded(n_gpus, inspectors_per_gpu=64, nblocks=40, timeout_s=150):
     """The drop-in itself on N GPUs: ONE process, the suscan_analyzer_* ABI with SUAMD_DEVICES=0..N-1 (csrc/analyzer.cpp:
     one worker thread per GPU, inspector handle h on GPU h mod N, the block to every shard by ncclBroadcast over xGMI,
     one message queue) and 64 heterogeneous PSK inspectors per GPU.  Run in a child process with a deadline: a secondary
