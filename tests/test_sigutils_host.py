@@ -195,3 +195,52 @@ def test_blackmann_harris_window_matches_the_oracle(L, sdo):
     L.su_taps_apply_blackmann_harris_complex(got.ctypes.data_as(C.c_void_p), got.size)
     ref = x * sdo.window(4, x.size)
     assert np.array_equal(_bits(got), _bits(ref.astype(np.complex64)))
+
+
+
+class Iir(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("h", C.POINTER(C.c_float)), ("d", C.c_void_p)]
+
+
+def test_matched_filter_and_nco_retune(L, sdo):
+    """su_iir_rrc_init / su_iir_filt_feed (WaveSampler's optional matched filter): the taps are suamd_rrc_design's, the
+    output the k-ascending fma chain of SPEC.md I; su_ncqo_set_freq keeps the phase running"""
+    for name, res, args in [("su_iir_rrc_init", C.c_int, [C.POINTER(Iir), C.c_uint64, C.c_float, C.c_float]),
+                            ("su_iir_filt_feed", CF, [C.POINTER(Iir), CF]), ("su_iir_filt_finalize", None, [C.POINTER(Iir)]),
+                            ("su_ncqo_set_freq", None, [C.POINTER(Ncqo), C.c_float]),
+                            ("suamd_rrc_design", None, [C.POINTER(C.c_float), C.c_uint, C.c_double, C.c_double])]:
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    f = Iir()
+    assert L.su_iir_rrc_init(C.byref(f), 6, 8.0, 0.35)
+    n = int(f.n)
+    assert n == 49                                                   # 6 symbol periods of 8 samples + 1
+    taps = np.array([f.h[i] for i in range(n)], dtype=np.float32)
+    want = (C.c_float * n)()
+    L.suamd_rrc_design(want, n, 8.0, float(np.float32(0.35)))       # SUFLOAT beta, widened
+    assert np.array_equal(taps, np.frombuffer(want, dtype=np.float32))
+    assert abs(float(taps.sum()) - 1.0) < 1e-6
+    x = cnoise(300, 21)
+    got = _per_sample(L.su_iir_filt_feed, f, x)
+    ref = np.zeros(x.size, np.complex64)
+    xp = np.concatenate([np.zeros(n - 1, np.complex64), x])
+    for m in range(x.size):
+        yr = yi = np.float32(0)
+        for k in range(n):
+            v = xp[m + n - 1 - k]
+            yr = np.float32(np.float64(taps[k]) * np.float64(v.real) + np.float64(yr))     # fma of binary32 operands: exact product, one rounding
+            yi = np.float32(np.float64(taps[k]) * np.float64(v.imag) + np.float64(yi))
+        ref[m] = yr + 1j * yi
+    assert np.array_equal(_bits(got), _bits(ref))
+    L.su_iir_filt_finalize(C.byref(f))
+    assert not L.su_iir_rrc_init(C.byref(f), 0, 8.0, 0.35)
+    # NCO: 1000 reads at one frequency, then a retune: the phase continues from where it was
+    o = Ncqo()
+    L.su_ncqo_init(C.byref(o), 0.01)
+    a = [L.su_ncqo_read(C.byref(o)) for _ in range(1000)]
+    L.su_ncqo_set_freq(C.byref(o), -0.02)
+    b = L.su_ncqo_read(C.byref(o))
+    dp = sdo.fnor_to_dphase(np.float32(0.01))
+    want_phase = (1000 * dp) & 0xFFFFFFFF
+    p = sdo.xlate_bulk(np.ones(1, np.complex64), want_phase, 0)
+    assert np.complex64(complex(b.re, b.im)) == p[0] and o.n == 1 and o.dphase == sdo.fnor_to_dphase(np.float32(-0.02))
