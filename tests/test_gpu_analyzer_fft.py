@@ -561,3 +561,44 @@ def test_watermark_sets_the_batch_size_and_the_stream_stays_the_same(tmp_path, s
     b = nblocks - (got.size // (W // D // 2) + 1) * H // L
     ref = sdo.specttuner_run_f32(x[b * L:], f0, bwa, guard)
     assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [32768, 65536])
+def test_main_spectrum_of_large_frames_through_the_analyzer(tmp_path, sdo, n):
+    """detector_params.window_size beyond the LDS -- the scanner's nextPow2(fs / 1 kHz) (Panoramic/Scanner.cpp:323): 32768
+    points take one trip through HBM (psd.hip HALVES), 65536 two (psd_large.hip) -- as PSD messages of a live analyzer"""
+    navg, nblocks = 4, 3
+    Lb_ = n * navg
+    x = synth.psk_carriers(Lb_ * nblocks + 777, [0.31, -0.12], sps=16, seed=n % 1000, snr_db=20)
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    Lb = suscan.load()
+    mq = suscan.MQ()
+    assert Lb.suscan_mq_init(C.byref(mq))
+    cfg = Lb.suscan_source_config_new(b"file", 1)
+    Lb.suscan_source_config_set_samp_rate(cfg, FS)
+    assert Lb.suscan_source_config_set_path(cfg, str(path).encode())
+    p = suscan.AnalyzerParams.default()
+    p.detector_params.window_size = n
+    p.detector_params.window = 4
+    p.psd_update_int = Lb_ / FS
+    an = Lb.suscan_analyzer_new(C.byref(p), cfg, C.byref(mq))
+    assert an
+    Lb.suscan_source_config_destroy(cfg)
+    frames = []
+    while True:
+        t, ptr = suscan.read_message(Lb, mq, 60.0)
+        if t == suscan.MSG_HALT:
+            break
+        if t == suscan.MSG_PSD:
+            m = C.cast(ptr, C.POINTER(suscan.PSDMsg)).contents
+            assert m.psd_size == n
+            frames.append(np.ctypeslib.as_array(m.psd_data, shape=(n,)).copy())
+        Lb.suscan_analyzer_dispose_message(t, ptr)
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+    assert len(frames) == nblocks                                  # (the 777-sample tail holds no whole frame)
+    ref = sdo.psd_frames(x, nblocks * navg, n, n, sdo.window(4, n), navg=navg, scale=1.0 / n)
+    got = np.stack(frames)
+    err = np.max(np.abs(got - ref), axis=1) / np.max(ref, axis=1)
+    assert np.all(err < 1e-5), err
