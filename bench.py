@@ -277,11 +277,22 @@ def run_workload(name, args, rank, world, dev, ctx, dist):
         one_step(k, False)
     fence()
     pipe.reset_events()
+    # the roofline leg: the channeliser's and the PSD's launches carry an event pair bound to the dispatch itself
+    # (suamd_kernel_timing) -- the kernel's own duration, what rocprofv3 --kernel-trace reports for it
+    engine.kernel_timing_read()
+    engine.kernel_timing(True)
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(k, True)
     fence()
     dt = time.perf_counter() - t0
+    engine.kernel_timing(False)
+    pipe.kernel_ms = {}
+    for kname in ("stw_kernel", "st_kernel", "chan_fir_kernel", "psd_kernel", "psd_reduce_kernel"):
+        r = engine.kernel_timing_read(kname)
+        if r["launches"]:
+            pipe.kernel_ms[kname] = {"avg": r["sum_ms"] / r["launches"], "min": r["min_ms"], "max": r["max_ms"], "launches": r["launches"],
+                                     "per_step": r["sum_ms"] / args.steps}
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -512,8 +523,13 @@ def main():
         fir_bytes = 8.0 * L + 8.0 * C * m_out
         fir_flops_built = float(C) * m_out * T * 8.0 + 14.0 * C * m_out      # direct form as built: 4 fma / tap + de-rotation
         fir_flops_survey = float(C) * L * (6.0 + 4.0 * T / D)                # translate + real taps
-        fir_ms = stages.get("fir")
-        psd_ms = stages.get("psd")
+        # per-launch durations: the dispatch-bound event pairs (pipe.kernel_ms) where the library provides them; the
+        # stream-event pairs around each stage (stage_ms: they include the queue's gaps) are reported beside them
+        kms = getattr(pipe, "kernel_ms", {})
+        chan_k = next((k for k in ("stw_kernel", "st_kernel", "chan_fir_kernel") if k in kms), None)
+        fir_ms = kms[chan_k]["per_step"] if chan_k else stages.get("fir")
+        psd_ms = (sum(kms[k]["per_step"] for k in ("psd_kernel", "psd_reduce_kernel") if k in kms)
+                  if "psd_kernel" in kms else stages.get("psd"))
         psd_bytes = 8.0 * L + 4.0 * cfg["psd"] * (L // cfg["psd"] // pipe.navg)
         kname = "stw_kernel" if fft_bank else "chan_fir_kernel"
         roof = {
@@ -531,6 +547,9 @@ def main():
                            "frac": round(psd_bytes / (psd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if psd_ms else None,
                            "kernel_ms": round(psd_ms, 4) if psd_ms else None,
                            "algorithmic_bytes_per_launch": psd_bytes},
+            "timing": ("dispatch-bound event pairs (hipExtLaunchKernelGGL start/stop events through suamd_kernel_timing): the "
+                       "kernel's own duration, averaged over every launch of the timed region") if chan_k else "stream events around the stage",
+            "kernel_launches_ms": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kms.items()},
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},
             "stalled_samples_dropped": dict(getattr(pipe, "stalled_samples", {})),
             "stage_ms_unfiltered": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}

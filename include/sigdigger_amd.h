@@ -63,6 +63,13 @@ typedef struct suamd_agc_bank    suamd_agc_bank_t;
 /* ------------------------------------------------------------------------------------ */
 SUAMD_API const char *suamd_last_error(void);
 SUAMD_API const char *suamd_version(void);
+/* Measurement aid (bench.py's roofline leg; no counterpart in the reference).  While enabled, every launch of the
+ * channeliser and PSD kernels ("stw_kernel", "st_kernel", "chan_fir_kernel", "psd_kernel", "psd_reduce_kernel") carries
+ * an event pair bound to the dispatch itself; suamd_kernel_timing_read waits for the launches of `kernel` (NULL: all of
+ * them) recorded since the last read and returns the sum / min / max of their own durations in milliseconds -- the figure
+ * rocprofv3 --kernel-trace reports, without the queue gaps two stream events around a launch would add.  Process-wide. */
+SUAMD_API void   suamd_kernel_timing(SUBOOL enable);
+SUAMD_API SUBOOL suamd_kernel_timing_read(const char *kernel, double *sum_ms, double *min_ms, double *max_ms, unsigned *launches);
 /* Replaces suscan_sigutils_init + su_lib_gen_wisdom for this path (Suscan/Library.cpp:97,
  * App/Loader.cpp:46): binds a GPU and builds the shared tables. */
 SUAMD_API suamd_ctx_t *suamd_ctx_new(int device_ordinal);

@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <deque>
@@ -303,7 +305,57 @@ static SUBOOL gang_tm(suamd_ctx *ctx, const std::vector<Item> &part, const std::
   return SU_TRUE;
 }
 
+// ---- kernel timer -------------------------------------------------------------------------------------------------
+namespace {
+struct TimedLaunch { const char *name; hipEvent_t e0, e1; };
+std::mutex g_timing_mu;
+std::vector<TimedLaunch> g_timed;                              // pairs in flight, in launch order
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_timing_pool;  // recycled pairs
+std::atomic<bool> g_timing{false};
+}  // namespace
+namespace sdk {
+bool timing_on() { return g_timing.load(std::memory_order_relaxed); }
+void timing_pair(const char *name, hipEvent_t *start, hipEvent_t *stop)
+{
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  if (!g_timing_pool.empty()) { *start = g_timing_pool.back().first; *stop = g_timing_pool.back().second; g_timing_pool.pop_back(); }
+  else { (void)hipEventCreate(start); (void)hipEventCreate(stop); }
+  g_timed.push_back({name, *start, *stop});
+}
+}  // namespace sdk
+
 extern "C" {
+
+void suamd_kernel_timing(SUBOOL enable) { g_timing.store(enable != SU_FALSE); }
+
+SUBOOL suamd_kernel_timing_read(const char *kernel, double *sum_ms, double *min_ms, double *max_ms, unsigned *launches)
+{
+  std::vector<TimedLaunch> mine;
+  {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    size_t k = 0;
+    for (const TimedLaunch &t : g_timed) {
+      if (!kernel || std::strcmp(kernel, t.name) == 0) mine.push_back(t); else g_timed[k++] = t;
+    }
+    g_timed.resize(k);
+  }
+  double sum = 0, lo = 0, hi = 0; unsigned n = 0; bool ok = true;
+  for (const TimedLaunch &t : mine) {
+    float ms = 0;
+    if (hipEventSynchronize(t.e1) != hipSuccess || hipEventElapsedTime(&ms, t.e0, t.e1) != hipSuccess) { ok = false; continue; }
+    sum += ms; lo = n ? std::min(lo, (double)ms) : ms; hi = n ? std::max(hi, (double)ms) : ms; ++n;
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    for (const TimedLaunch &t : mine) g_timing_pool.push_back({t.e0, t.e1});
+  }
+  if (sum_ms) *sum_ms = sum;
+  if (min_ms) *min_ms = lo;
+  if (max_ms) *max_ms = hi;
+  if (launches) *launches = n;
+  if (!ok) { set_err("kernel timer: an event pair could not be read"); return SU_FALSE; }
+  return SU_TRUE;
+}
 
 const char *suamd_last_error(void) { return g_err.c_str(); }
 const char *suamd_version(void) { return "sigdigger_amd 0.1 (gfx950)"; }

@@ -487,7 +487,7 @@ hipError_t launch_fir(const sdk::ChanFeedArgs &a, const FirGeom &ge, size_t lds,
     if (e != hipSuccess) return e;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL(kern, dim3(ntiles), dim3(FIR_THREADS), lds, st,
+  sdk::launch_timed("chan_fir_kernel", kern, dim3(ntiles), dim3(FIR_THREADS), lds, st,
                      reinterpret_cast<const float2 *>(a.x), reinterpret_cast<const float2 *>(a.hist),
                      reinterpret_cast<float2 *>(a.hist_next), a.len, a.n0,
                      reinterpret_cast<const float4 *>(a.g), a.dphase, a.phase0, ge, a.m_first, a.n_out,

@@ -2,9 +2,26 @@
 // gfx950 kernels.  Not installed; the public boundary is include/sigdigger_amd.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace sdk {
+
+// ---- kernel timer (capi.hip): measurement aid behind suamd_kernel_timing() --------------------------------------
+// While it is on, the launches that go through launch_timed() carry a start / stop event pair bound to the dispatch
+// itself (hipExtLaunchKernelGGL): the elapsed time of the pair is the kernel's own duration, as rocprofv3 reports it,
+// not the distance of two stream events around the launch (which adds the queue's gaps, 3-6 us per launch).
+bool timing_on();
+void timing_pair(const char *name, hipEvent_t *start, hipEvent_t *stop);
+template <class K, class... A>
+inline void launch_timed(const char *name, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args)
+{
+  if (timing_on()) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    timing_pair(name, &e0, &e1);
+    hipExtLaunchKernelGGL(kern, grid, block, lds, st, e0, e1, 0, args...);
+  } else hipLaunchKernelGGL(kern, grid, block, lds, st, args...);
+}
 
 // A batch of nchan sample rows: element (c, m) lives at base[c*cs + m*ms] (units: complex samples).
 //   channel-major  [c][m]: cs = row pitch, ms = 1   (what consumers of sample batches want)

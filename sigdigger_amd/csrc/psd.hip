@@ -277,11 +277,11 @@ hipError_t launch_psd_p(const void *x, long long hop, int navg, const float *win
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(HALVES ? 2 * nout : nout), (unsigned)S), dim3(THREADS), lds, st,
+  sdk::launch_timed("psd_kernel", kern, dim3((unsigned)(HALVES ? 2 * nout : nout), (unsigned)S), dim3(THREADS), lds, st,
                      reinterpret_cast<const cf *>(x), hop, navg, window, reinterpret_cast<const cf *>(tw),
                      scale, mode, out, partial, reinterpret_cast<const cf *>(tw2));
   if (S > 1) {
-    hipLaunchKernelGGL(psd_reduce_kernel, dim3((NT + 63) / 64, (unsigned)nout), dim3(256), 0, st,
+    sdk::launch_timed("psd_reduce_kernel", psd_reduce_kernel, dim3((NT + 63) / 64, (unsigned)nout), dim3(256), 0, st,
                        partial, S, NT, scale / (float)navg, mode, out);
   }
   return hipGetLastError();

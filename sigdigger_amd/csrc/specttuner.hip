@@ -222,7 +222,7 @@ hipError_t launch_st_v(const sdk::StArgs &a, hipStream_t st)
   }
   const unsigned nruns = (unsigned)((a.nwin + a.run - 1) / a.run);
   const unsigned ny = (unsigned)((a.nchan + G::CPP - 1) / G::CPP);
-  hipLaunchKernelGGL(kern, dim3(nruns, ny), dim3(ST_THREADS), lds, st, a);
+  sdk::launch_timed("st_kernel", kern, dim3(nruns, ny), dim3(ST_THREADS), lds, st, a);
   return hipGetLastError();
 }
 

@@ -69,6 +69,9 @@ constexpr int WV_LDS = (WV_HK + 64) * 8;
 #else
 #define TS(n) do { } while (0)
 #endif
+#ifndef STW_WPB
+#define STW_WPB 1
+#endif
 #ifndef STW_EARLY_LDS
 #define STW_EARLY_LDS 1
 #endif
@@ -77,7 +80,7 @@ constexpr int AUX_NT = 2;                                      // nt: the output
 constexpr int AUX_SC1 = 16;                                    // cache-policy bit of the raw buffer builtins: sc1 (agent scope)
 
 template <int LOG2S, bool UNIFORM, bool Y32>
-__global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
+__global__ __launch_bounds__(WAVE * STW_WPB, 1) void stw_kernel(sdk::StArgs a)
 {
 #ifdef STW_TSTAMP
   const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
@@ -86,14 +89,18 @@ __global__ __launch_bounds__(WAVE, 1) void stw_kernel(sdk::StArgs a)
   constexpr int W = WV_W, H = WV_H, S = 1 << LOG2S, HS = S / 2, NG = WAVE / S;
   static_assert(HS <= WV_REP && S >= 4, "size out of range for the wavefront kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  cf *buf = reinterpret_cast<cf *>(smem);
-  const int t = threadIdx.x;
+  // STW_WPB independent wavefronts per workgroup (nothing is shared, no barrier): fewer, fatter workgroups to dispatch
+  const int wv = STW_WPB > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
+  const long long bx = (long long)blockIdx.x * STW_WPB + wv;
+  if (STW_WPB > 1 && bx * a.run >= a.nwin) return;
+  cf *buf = reinterpret_cast<cf *>(smem + wv * WV_LDS);
+  const int t = threadIdx.x & (WAVE - 1);
 
-  const long long w_begin = (long long)blockIdx.x * a.run, w_end = (w_begin + a.run < a.nwin) ? w_begin + a.run : a.nwin;
+  const long long w_begin = bx * a.run, w_end = (w_begin + a.run < a.nwin) ? w_begin + a.run : a.nwin;
   const cf *x = reinterpret_cast<const cf *>(a.x), *hist = reinterpret_cast<const cf *>(a.hist);
   const long long off = a.have_hist ? H : 0;                   // virtual stream = hist (H samples) ++ x
   const int kbase = blockIdx.y * (NG * WAVE) + t;              // this lane's channel in group g: kbase + 64 g
-  const long long slot = (long long)blockIdx.x * gridDim.y + blockIdx.y;          // this run's hand-off slot
+  const long long slot = bx * gridDim.y + blockIdx.y;          // this run's hand-off slot
   cf *const ho = reinterpret_cast<cf *>(a.handoff);
   constexpr long long HO = (long long)NG * HS * WAVE;          // elements per slot
 
@@ -495,7 +502,11 @@ hipError_t launch_stw_u(const sdk::StArgs &a, hipStream_t st)
   auto kern = stw_kernel<LOG2S, UNIFORM, Y32>;
   const unsigned nruns = (unsigned)((a.nwin + a.run - 1) / a.run);
   const unsigned ny = (unsigned)((a.nchan + NG * WAVE - 1) / (NG * WAVE));
-  hipLaunchKernelGGL(kern, dim3(nruns, ny), dim3(WAVE), WV_LDS, st, a);
+  if constexpr (WV_LDS * STW_WPB > 65536) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WV_LDS * STW_WPB);
+    if (attr != hipSuccess) return attr;
+  }
+  sdk::launch_timed("stw_kernel", kern, dim3((nruns + STW_WPB - 1) / STW_WPB, ny), dim3(WAVE * STW_WPB), WV_LDS * STW_WPB, st, a);
   return hipGetLastError();
 }
 

@@ -45,6 +45,20 @@ def _view(t):
     return _l.View(t.stride(0), t.stride(1))
 
 
+def kernel_timing(enable):
+    """Switches the library's kernel timer (suamd_kernel_timing): launches of the channeliser / PSD kernels carry an
+    event pair bound to the dispatch itself."""
+    _l.load().suamd_kernel_timing(1 if enable else 0)
+
+
+def kernel_timing_read(kernel=None):
+    """{sum_ms, min_ms, max_ms, launches} of `kernel`'s launches since the last read (waits for them)."""
+    s, lo, hi, n = C.c_double(), C.c_double(), C.c_double(), C.c_uint()
+    check(_l.load().suamd_kernel_timing_read(kernel.encode() if kernel else None, C.byref(s), C.byref(lo), C.byref(hi), C.byref(n)),
+               "suamd_kernel_timing_read")
+    return {"sum_ms": s.value, "min_ms": lo.value, "max_ms": hi.value, "launches": n.value}
+
+
 def time_major(nchan, length, device, dtype=torch.complex64):
     """[channels, time] tensor stored time-major ([time][channel] in memory): the layout the
     one-lane-per-channel kernels stream with one contiguous access per wavefront."""

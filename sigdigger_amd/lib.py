@@ -41,6 +41,8 @@ class AgcParams(C.Structure):
 PROTOTYPES = {
     "suamd_last_error": (C.c_char_p, []),
     "suamd_version": (C.c_char_p, []),
+    "suamd_kernel_timing": (None, [C.c_int]),
+    "suamd_kernel_timing_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint)]),
     "suamd_ctx_new": (VP, [INT]),
     "suamd_ctx_destroy": (None, [VP]),
     "suamd_ctx_device": (INT, [VP]),

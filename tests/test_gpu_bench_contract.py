@@ -69,3 +69,45 @@ def test_live_mode_times_the_sharded_analyzer_itself():
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 1 and d["unit"] == "MS/s" and d["live"]["devices"] == "0" and "error" not in d["live"]
     assert d["value"] > 50.0 and d["config"]["inspectors_total"] == 64
+
+
+def test_kernel_timer_reports_the_kernels_own_duration():
+    """suamd_kernel_timing: dispatch-bound event pairs around the channeliser / PSD launches -- what bench.py's roofline
+    leg divides the algorithmic bytes by.  The pair's time is never longer than two stream events around the launch."""
+    import numpy as np
+    import torch
+    from sigdigger_amd import engine
+    ctx = engine.Context(0)
+    L = 1 << 20
+    x = torch.empty(L, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(x).normal_()
+    st = engine.SpectTuner(ctx, 4096)
+    for k in range(8):
+        st.open_channel(0.3 + 0.5 * k, 2 * np.pi * 0.75 / 64)
+    out = engine.time_major(8, L // 64 + 64, "cuda")
+    psd = engine.PSD(ctx, 8192)
+    st.feed(x, out=out)
+    po = psd.feed(x, nframes=L // 8192, navg=16)
+    torch.cuda.synchronize()
+    assert engine.kernel_timing_read()["launches"] == 0          # off: nothing is recorded
+    engine.kernel_timing(True)
+    try:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            st.feed(x, out=out)
+        e1.record()
+        for _ in range(3):
+            psd.feed(x, nframes=L // 8192, navg=16, out=po)
+        torch.cuda.synchronize()
+    finally:
+        engine.kernel_timing(False)
+    r = engine.kernel_timing_read("stw_kernel")
+    assert r["launches"] == 5
+    assert 1e-3 < r["min_ms"] <= r["sum_ms"] / 5 <= r["max_ms"] < 1.0
+    assert r["sum_ms"] <= e0.elapsed_time(e1) * 1.02
+    p = engine.kernel_timing_read("psd_kernel")
+    assert p["launches"] == 3 and p["min_ms"] > 1e-3
+    assert engine.kernel_timing_read()["launches"] in (0, 3)     # the rest: psd_reduce_kernel if the plan split the frames
+    assert engine.kernel_timing_read()["launches"] == 0
+    st.close()
