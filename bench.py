@@ -288,7 +288,7 @@ def run_workload(name, args, rank, world, dev, ctx, dist):
     dt = time.perf_counter() - t0
     engine.kernel_timing(False)
     pipe.kernel_ms = {}
-    for kname in ("stw_kernel", "st_kernel", "chan_fir_kernel", "psd_kernel", "psd_reduce_kernel"):
+    for kname in ("stp_kernel", "stw_kernel", "st_kernel", "chan_fir_kernel", "psd_kernel", "psd_reduce_kernel"):
         r = engine.kernel_timing_read(kname)
         if r["launches"]:
             pipe.kernel_ms[kname] = {"avg": r["sum_ms"] / r["launches"], "min": r["min_ms"], "max": r["max_ms"], "launches": r["launches"],
@@ -371,7 +371,7 @@ def run_fir_stage_large_block(cfg, dev, ctx, fn_rank, log2_block=24):
     nbytes = 8.0 * Lb + 8.0 * len(fn_rank) * Lb / D
     return {"block_samples": Lb, "kernel_ms": round(ms, 4), "algorithmic_bytes_per_launch": nbytes,
             "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "what": "stw_kernel alone on a 16 Mi-sample block, back-to-back launches (includes the history copy of a feed)"}
+            "what": "the channeliser kernel alone on a 16 Mi-sample block, back-to-back launches (includes the history copy of a feed)"}
 
 
 def run_c5(args, dev, ctx, log2_file=30, N=8192, tile=256):
@@ -526,17 +526,23 @@ def main():
         # per-launch durations: the dispatch-bound event pairs (pipe.kernel_ms) where the library provides them; the
         # stream-event pairs around each stage (stage_ms: they include the queue's gaps) are reported beside them
         kms = getattr(pipe, "kernel_ms", {})
-        chan_k = next((k for k in ("stw_kernel", "st_kernel", "chan_fir_kernel") if k in kms), None)
+        chan_k = next((k for k in ("stp_kernel", "stw_kernel", "st_kernel", "chan_fir_kernel") if k in kms), None)
         fir_ms = kms[chan_k]["per_step"] if chan_k else stages.get("fir")
         psd_ms = (sum(kms[k]["per_step"] for k in ("psd_kernel", "psd_reduce_kernel") if k in kms)
                   if "psd_kernel" in kms else stages.get("psd"))
         psd_bytes = 8.0 * L + 4.0 * cfg["psd"] * (L // cfg["psd"] // pipe.navg)
-        kname = "stw_kernel" if fft_bank else "chan_fir_kernel"
+        kname = (chan_k or "stp_kernel") if fft_bank else "chan_fir_kernel"
+        KERNELS = {
+            "stp_kernel": "stp_kernel (FFT channeliser, two wavefronts per window: 4096-pt forward FFT as two 64-pt DFTs on registers "
+                          "around an LDS transposition, each DFT split between the wavefronts with one swap through LDS; lane = "
+                          "channel: bin pick x response, 64-pt inverse FFT, cross-fade)",
+            "stw_kernel": "stw_kernel (FFT channeliser, one wavefront per window: 4096-pt forward FFT as two register DFT64 "
+                          "around an LDS transposition, shared by all channels; lane = channel: bin pick x response, 64-pt "
+                          "inverse FFT, cross-fade)",
+            "st_kernel": "st_kernel (FFT channeliser, one workgroup per run of windows: radix-16 passes through LDS)",
+            "chan_fir_kernel": "chan_fir_kernel (translate + 255-tap polyphase decimating FIR bank)"}
         roof = {
-            "kernel": ("stw_kernel (FFT channeliser, one wavefront per window: 4096-pt forward FFT as two register DFT64 "
-                       "around an LDS transposition, shared by all channels; lane = channel: bin pick x response, 64-pt "
-                       "inverse FFT, cross-fade)") if fft_bank else
-                      "chan_fir_kernel (translate + 255-tap polyphase decimating FIR bank)",
+            "kernel": KERNELS[kname],
             "bound": "hbm", "achieved": round(fir_bytes / (fir_ms * 1e-3) / 1e9, 2) if fir_ms else None,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(fir_bytes / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if fir_ms else None,

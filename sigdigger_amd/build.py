@@ -27,6 +27,7 @@ SOURCES = {
     "psd_large.hip": ["-ffp-contract=fast"],
     "specttuner.hip": ["-ffp-contract=off"],
     "specttuner_wave.hip": ["-ffp-contract=off"],
+    "specttuner_pair.hip": ["-ffp-contract=off"],
     "specttuner_host.cpp": ["-ffp-contract=off"],
     "chandet.hip": ["-ffp-contract=off"],
     "audio.hip": ["-ffp-contract=off"],

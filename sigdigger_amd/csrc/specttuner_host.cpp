@@ -173,6 +173,7 @@ struct suamd_specttuner {
   unsigned run_wave = 0;               // wavefront kernel: windows per wavefront (0: one round of 4 wavefronts per CU)
   int seam_polls = 256;                // wavefront kernel: bounded wait for a run's successor (SUAMD_ST_SEAM_POLLS; 0: never wait)
   bool use_wave = true;                // sizes 8..64 go to specttuner_wave.hip (SUAMD_ST_KERNEL=wg keeps them on specttuner.hip)
+  bool use_pair = true;                // 64-bin channels with one response: two wavefronts per window (specttuner_pair.hip; SUAMD_ST_KERNEL=wave keeps them on specttuner_wave.hip)
   c32 *d_tw_w = nullptr;
   c32 *d_hist[2] = {nullptr, nullptr};
   int hist_cur = 0;
@@ -358,7 +359,7 @@ suamd_specttuner_t *suamd_specttuner_new(suamd_ctx_t *ctx, unsigned window_size)
   if (!st) { suamd_set_error("out of memory"); return nullptr; }
   st->ctx = ctx; st->W = window_size; st->H = window_size / 2; st->log2w = 12;
   if (const char *e = std::getenv("SUAMD_ST_RUN")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) st->run = st->run_wave = (unsigned)v; }   // tuning knob
-  if (const char *e = std::getenv("SUAMD_ST_KERNEL")) st->use_wave = std::strcmp(e, "wg") != 0;
+  if (const char *e = std::getenv("SUAMD_ST_KERNEL")) { st->use_wave = std::strcmp(e, "wg") != 0; st->use_pair = std::strcmp(e, "wave") != 0 && st->use_wave; }
   if (const char *e = std::getenv("SUAMD_ST_SEAM_POLLS")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 20)) st->seam_polls = v; }
   st->d_tw_w = dev_upload_new(twiddles(st->W));
   bool ok = st->d_tw_w != nullptr;
@@ -517,7 +518,8 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
           // 32-bit buffer addressing of the outputs when the whole view of this feed lies below 2 GiB
           const long long hs = (1ll << g.log2s) / 2;
           const long long last = ((long long)st->ch.size() * (long long)view.chan_stride + (nwin * hs + hs) * (long long)view.time_stride) * 8;
-          a.y32 = (!d_rows && last < (1ll << 31)) ? 1 : 0;
+          static const bool no_y32 = [] { const char *e = std::getenv("SUAMD_ST_Y32"); return e && e[0] == '0'; }();   // debug: 64-bit addressing everywhere
+          a.y32 = (!d_rows && last < (1ll << 31) && !no_y32) ? 1 : 0;
         }
         if (st->run_wave) a.run = (int)st->run_wave;
         else {
@@ -553,7 +555,8 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
         (void)hipMemsetAsync(d_ts, 0, nts * sizeof(unsigned long long), s);
         a.tstamp = d_ts;
 #endif
-        e = sdk::specttuner_feed_wave(g.log2s, a, s);
+        const bool pair = st->use_pair && g.log2s == 6 && a.hk_uniform && a.run >= 2;
+        e = pair ? sdk::specttuner_feed_pair(a, s) : sdk::specttuner_feed_wave(g.log2s, a, s);
 #ifdef STW_TSTAMP
         if (std::getenv("SUAMD_STW_TSTAMP")) {
           (void)hipStreamSynchronize(s);

@@ -1,0 +1,448 @@
+// specttuner_pair.hip -- the FFT channeliser for 64-bin channels with one response, TWO wavefronts per window
+// (SPEC.md section C2; rows T2 / N2).  Same arithmetic, operation for operation, as specttuner_wave.hip (the oracle's
+// binary32 statement: both kernels equal it bit for bit); what changes is who holds what.
+//
+// specttuner_wave.hip keeps a whole 4096-point window in ONE wavefront's registers (64 points per lane, 512 registers): one
+// wavefront per SIMD, and a lone wavefront issues an instruction every ~6 cycles at best (no second wavefront to fill
+// the slots its scalar / LDS / memory instructions and their waits leave).  Here a window belongs to a workgroup of two
+// wavefronts with 32 points per lane each (<= 256 registers: two wavefronts per SIMD, eight per CU -- the LDS still
+// holds four windows per CU).  Every 64-point DFT of the window (8 x 8 on registers) is split down the middle:
+//   wavefront p runs the first-stage sub-transforms n1 = 4p .. 4p+3 (inputs n1 + 8 n2),
+//   the halves swap 16 values per lane through LDS,
+//   wavefront p runs the second-stage sub-transforms k2 = 4p .. 4p+3 (outputs k2 + 8 k1).
+// Each wavefront runs its own specialisation of the code (p is a template parameter), so the W_64 twiddles stay the
+// compile-time constants they are in the one-wavefront kernel.  Loads, transposition, spectrum, bin gather and stores
+// can hand any lane any element, so only the three mid-DFT swaps are new traffic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <type_traits>
+#include "kernels.hpp"
+#include "fft_core.hpp"
+#include "fft_reg.hpp"
+#include "sd_math.hpp"
+
+namespace {
+using namespace fftcore;
+
+// sin^2(pi i / 64): the cross-fade window of a 64-point block
+__device__ constexpr float kWinP[64] = {
+    0.000000000e+00f, 2.407636726e-03f, 9.607359767e-03f, 2.152983285e-02f, 3.806023300e-02f, 5.903936923e-02f, 8.426519483e-02f, 1.134947762e-01f, 1.464466155e-01f, 1.828033626e-01f, 2.222148776e-01f, 2.643016279e-01f, 3.086582720e-01f, 3.548576534e-01f, 4.024548531e-01f, 4.509914219e-01f, 5.000000000e-01f, 5.490085483e-01f, 5.975451469e-01f, 6.451423168e-01f, 6.913416982e-01f, 7.356983423e-01f, 7.777851224e-01f, 8.171966672e-01f, 8.535534143e-01f, 8.865052462e-01f, 9.157348275e-01f, 9.409606457e-01f, 9.619397521e-01f, 9.784701467e-01f, 9.903926253e-01f, 9.975923896e-01f, 1.000000000e+00f, 9.975923896e-01f, 9.903926253e-01f, 9.784701467e-01f, 9.619397521e-01f, 9.409606457e-01f, 9.157348275e-01f, 8.865052462e-01f, 8.535534143e-01f, 8.171966672e-01f, 7.777851224e-01f, 7.356983423e-01f, 6.913416982e-01f, 6.451423168e-01f, 5.975451469e-01f, 5.490085483e-01f, 5.000000000e-01f, 4.509914219e-01f, 4.024548531e-01f, 3.548576534e-01f, 3.086582720e-01f, 2.643016279e-01f, 2.222148776e-01f, 1.828033626e-01f, 1.464466155e-01f, 1.134947762e-01f, 8.426519483e-02f, 5.903936923e-02f, 3.806023300e-02f, 2.152983285e-02f, 9.607359767e-03f, 2.407636726e-03f};
+
+// al cur + be prv, the rounding pattern of specttuner_wave.hip's xfade
+__device__ __forceinline__ cf xfade_p(float al, cf cur, float be, cf prv)
+{
+  const cf t = cur * al;
+  return __builtin_elementwise_fma(cf{be, be}, prv, t);
+}
+
+typedef __attribute__((address_space(1))) cf gcf;
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+constexpr int WAVE = 64;
+constexpr int PW_W = 4096, PW_H = 2048, PW_S = 64, PW_HS = 32;
+constexpr int PW_PITCH = 65;                                   // transposition pitch (elements)
+constexpr int PW_REP = 32;                                     // spectrum bins repeated after the end
+constexpr int PW_HK = WAVE * PW_PITCH;                         // the response: 64 elements behind the transposition buffer
+constexpr int PW_FLAG = PW_HK + 64;                            // one word the wavefronts of a pair share (seam decision)
+constexpr int PW_LDS = (PW_FLAG + 2) * 8;
+constexpr int PW_EX = 1024;                                    // elements of one direction of a mid-DFT swap (16 x 64)
+constexpr int AUX_NT = 2;
+constexpr int AUX_SC1 = 16;
+
+#ifdef STW_TSTAMP
+#define TS(n) do { __builtin_amdgcn_sched_barrier(0); ts[n] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TS(n) do { } while (0)
+#endif
+
+// LDS operations of the two wavefronts are only ordered by a barrier; the prefetch (vmcnt) stays in flight across it
+// (barriers that only keep a swap area from being overwritten early: STP_UNSAFE_NO_ALIAS_BARRIERS drops them -- a timing
+// experiment, results are wrong)
+__device__ __forceinline__ void alias_barrier();
+__device__ __forceinline__ void pair_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ void alias_barrier()
+{
+#ifndef STP_UNSAFE_NO_ALIAS_BARRIERS
+  pair_barrier();
+#endif
+}
+
+// One 64-point DFT, split between the wavefronts of the pair.  in[a * 8 + n2] = x[(4P + a) + 8 n2]; on return
+// out[b * 8 + k1] = X[(4P + b) + 8 k1].  `ex`: 2 x PW_EX elements of LDS nobody else touches between the barrier
+// inside and the caller's next barrier.  hook(step) runs after each of the eight sub-transforms.
+template <int P, class Hook>
+__device__ __forceinline__ void dft64_pair(const cf *in, cf *out, cf *ex, int t, Hook hook)
+{
+  constexpr int Q = 1 - P;
+  cf keep[16];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    cf a8[8];
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) a8[n2] = in[a * 8 + n2];
+    dftR<8>(a8);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const cf m = mul_w64(a8[k2], (4 * P + a) * k2);
+      if (k2 / 4 == P) keep[a * 4 + (k2 & 3)] = m;
+      else ex[(P * 16 + a * 4 + (k2 & 3)) * WAVE + t] = m;
+    }
+    hook(a);
+  }
+  pair_barrier();
+  // the partner's sixteen values, requested in one go (left alone the compiler alternates read / wait / use and a lone
+  // wavefront pays the LDS latency every time)
+  cf recv[16];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int aq = 0; aq < 4; ++aq) recv[b * 4 + aq] = ex[(Q * 16 + aq * 4 + b) * WAVE + t];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    cf b8[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) b8[n1] = (n1 / 4 == P) ? keep[(n1 & 3) * 4 + b] : recv[b * 4 + (n1 & 3)];
+    dftR<8>(b8);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) out[b * 8 + k1] = b8[k1];
+    hook(4 + b);
+  }
+}
+
+template <int P, bool Y32>
+__device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const int t)
+{
+  constexpr int W = PW_W, H = PW_H, HS = PW_HS;
+#ifdef STW_TSTAMP
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
+  const long long w_begin = (long long)blockIdx.x * a.run, w_end = (w_begin + a.run < a.nwin) ? w_begin + a.run : a.nwin;
+  const cf *x = reinterpret_cast<const cf *>(a.x), *hist = reinterpret_cast<const cf *>(a.hist);
+  const long long off = a.have_hist ? H : 0;                   // virtual stream = hist (H samples) ++ x
+  const int k = blockIdx.y * WAVE + t;                         // this lane's channel
+  const long long slot = (long long)blockIdx.x * gridDim.y + blockIdx.y;
+  cf *const ho = reinterpret_cast<cf *>(a.handoff);
+  constexpr long long HO = (long long)HS * WAVE;               // elements per hand-off slot
+  unsigned *const shared_flag = reinterpret_cast<unsigned *>(buf + PW_FLAG);
+
+  // Register (a, n2) of the request holds sample t + 64 r, r = 4P + a + 8 n2: rows r < 32 come through descriptor `ra`
+  // (first half window, or the seam payload, or nothing), the others through `rb`
+  cf nxt[32];
+  __amdgpu_buffer_rsrc_t ra, rb;
+  auto aim = [&](const cf *pa, unsigned na, const cf *pb, unsigned nb) {
+    ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(pa), 0, na, 0x00020000);
+    rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(pb), 0, nb, 0x00020000);
+  };
+  auto load_one = [&](int q) {                                 // q = a * 8 + n2
+    const int r = 4 * P + (q >> 3) + 8 * (q & 7);
+    if (r < WAVE / 2) nxt[q] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(ra, t * 8, r * WAVE * 8, AUX_SC1));
+    else nxt[q] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(rb, t * 8, (r - WAVE / 2) * WAVE * 8, 0));
+  };
+  auto aim_window = [&](long long w) { aim((w == 0 && a.have_hist) ? hist : x + (w * H - off), H * 8, x + (w * H + H - off), H * 8); };
+  const bool final_run = w_end == a.nwin;
+  const long long nslot = slot + gridDim.y;
+  const unsigned epoch = a.epoch;
+  long long w_stop = w_end;
+  bool self_seam = false;
+  auto seam_ready = [&]() -> bool {
+    for (int n = 0; n < a.seam_polls; ++n) {
+      const unsigned f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.flags + nslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (f == epoch) return true;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    return false;
+  };
+  auto aim_next = [&](long long w) {
+    const bool more = w + 1 < w_stop, pay = !more && !final_run && !self_seam;
+    const long long wn = more ? w + 1 : w;
+    const cf *pa = pay ? ho + nslot * HO : ((wn == 0 && a.have_hist) ? hist : x + (wn * H - off));
+    aim(pa, more ? H * 8 : (pay ? (unsigned)HO * 8 : 0u), x + (wn * H + H - off), more ? H * 8 : 0u);
+  };
+
+  aim_window(w_begin);
+#pragma unroll
+  for (int q = 0; q < 32; ++q) load_one(q);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // W_4096^(t 2^j)
+  cf wb[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) wb[j] = reinterpret_cast<const cf *>(a.tw_w)[t << j];
+
+  // Output i of a block needs F[(64 - i) & 63] and F[32 - i]: both in second-stage sub-transform k2 = (-i) mod 8, so this
+  // wavefront owns the outputs i(b, m) = ((8 - (4P + b)) & 7) + 8 m and their cross-fade partners
+  auto out_index = [](int b, int m) { return ((8 - (4 * P + b)) & 7) + 8 * m; };
+  cf prev[16];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      prev[b * 4 + m] = (w_begin == 0 && k < a.nchan) ? reinterpret_cast<const cf *>(a.prev_in)[(long long)k * HS + out_index(b, m)] : cf{0.f, 0.f};
+
+  // (the channel record is read where it is used: the residual-NCO fields only on the path that rotates -- held across the
+  // window loop they would be spilled)
+  const sdk::StChan *const cdp = a.chans + (k < a.nchan ? k : 0);
+  const int center = cdp->center;
+  const int row = cdp->row;
+  cf *const ybase = a.rows ? static_cast<cf *>(const_cast<void *>(a.rows[row])) : reinterpret_cast<cf *>(a.y) + (long long)row * a.yv.cs;
+  const unsigned yvoff = k < a.nchan ? (unsigned)((long long)row * a.yv.cs * 8) : 0x80000000u;
+  const long long yms = a.rows ? 1 : a.yv.ms;
+  const unsigned yms8 = (unsigned)(yms * 8);
+  const bool any_precise = __builtin_amdgcn_ballot_w64(cdp->precise != 0) != 0;
+
+  auto emit_one = [&](auto rot, long long wo, int i, cf o) {
+    if constexpr (decltype(rot)::value) {
+      const uint32_t m = (uint32_t)((unsigned long long)wo * HS + i);
+      const bool precise = cdp->precise != 0;
+      const uint32_t dphase = cdp->dphase, phase0 = (uint32_t)(a.n0 - cdp->n_open);
+      float c, s;
+      sd::phasor_u32((phase0 + m) * dphase, c, s);
+      c = precise ? c : 1.0f;
+      s = precise ? s : 0.0f;
+      o = cf{__builtin_fmaf(o.x, c, -(o.y * s)), __builtin_fmaf(o.x, s, o.y * c)};
+    }
+    if constexpr (Y32) {
+      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<cf *>(a.y) + (long long)((unsigned long long)wo * HS) * yms, 0, 0x7fffffff, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), ry, yvoff, (unsigned)i * yms8, AUX_NT);
+    } else if (k < a.nchan) {
+      *(gcf *)(ybase + ((long long)((unsigned long long)wo * HS) + i) * yms) = o;
+    }
+  };
+
+  if (P == 0 && t < PW_S) buf[PW_HK + t] = reinterpret_cast<const cf *>(a.hk)[t];     // the launch's one response
+  bool publish = false;
+  for (long long w = w_begin; w < w_stop; ++w) {
+    cf v[32], A[32];
+#ifdef STW_TSTAMP
+    unsigned long long ts[16] = {0};
+#endif
+    TS(0);
+    if (publish) {
+      // the wait for this window's samples (needed here anyway) also drains the seam stores issued before them; the flag
+      // goes out once BOTH wavefronts are there -- and before this run asks for its successor's (no chain of runs waiting
+      // for each other)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pair_barrier();
+      if (P == 0 && t == 0) __hip_atomic_store(a.flags + slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      publish = false;
+    }
+    if (final_run && w + 1 == w_end && a.hist_out != nullptr && blockIdx.y == 0) {
+      const __amdgpu_buffer_rsrc_t rhs = __builtin_amdgcn_make_buffer_rsrc(a.hist_out, 0, H * 8, 0x00020000);
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int r = 4 * P + (q >> 3) + 8 * (q & 7);
+        if (r >= WAVE / 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, nxt[q]), rhs, t * 8, (r - WAVE / 2) * WAVE * 8, 0);
+      }
+    }
+    const bool last_of_run = w + 1 == w_end && !final_run;
+    if (P == 0 && last_of_run) {
+      // has the next run published the seam block's first half?  (bounded wait; otherwise this run transforms the seam
+      // window itself.)  One wavefront asks, both act on the answer.
+      const bool ok = seam_ready();
+      if (t == 0) *shared_flag = ok ? 1u : 0u;
+    }
+    // ---- forward transform, columns ----
+    // (the swap area is the first 16 KiB of the buffer: the previous window's spectrum, which both wavefronts have left)
+    dft64_pair<P>(nxt, A, buf, t, [](int) {});
+    TS(1);
+    if (last_of_run) {
+      if (*shared_flag == 0u) { self_seam = true; w_stop = w_end + 1; }
+      asm volatile("" ::: "memory");
+    }
+    aim_next(w);
+    {
+      // W_4096^(t kk), kk = 8 h + l: hi[h] lo[l]; this wavefront's l = 4P + b
+      cf lo[8], hi[8];
+      lo[1] = opaque(wb[0]); lo[2] = opaque(wb[1]); lo[4] = opaque(wb[2]);
+      lo[3] = cmul(lo[1], lo[2]); lo[5] = cmul(lo[1], lo[4]); lo[6] = cmul(lo[2], lo[4]); lo[7] = cmul(lo[3], lo[4]);
+      hi[1] = opaque(wb[3]); hi[2] = opaque(wb[4]); hi[4] = opaque(wb[5]);
+      hi[3] = cmul(hi[1], hi[2]); hi[5] = cmul(hi[1], hi[4]); hi[6] = cmul(hi[2], hi[4]); hi[7] = cmul(hi[3], hi[4]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int l = 4 * P + b;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+          cf &e = A[b * 8 + h];
+          if (h == 0 && l == 0) continue;
+          if (h == 0) e = cmul1(e, lo[l]);
+          else if (l == 0) e = cmul1(e, hi[h]);
+          else e = cmul3(e, hi[h], lo[l]);
+        }
+      }
+    }
+    TS(2);
+    alias_barrier();                                           // the partner has taken its half of the swap
+    {
+      cf *wr = buf + t * PW_PITCH;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int h = 0; h < 8; ++h) wr[4 * P + b + 8 * h] = A[b * 8 + h];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) load_one(q);
+    pair_barrier();
+    {
+      const cf *rd = buf + t;
+#pragma unroll
+      for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) v[aa * 8 + n2] = rd[(4 * P + aa + 8 * n2) * PW_PITCH];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    TS(3);
+    alias_barrier();                                           // both have read the transposition buffer: the swap may overwrite it
+    TS(4);
+    // ---- forward transform, rows: A[b * 8 + k1] = X[t + 64 (4P + b + 8 k1)] ----
+    dft64_pair<P>(v, A, buf, t, [&](int step) {
+      if (step < 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) load_one(16 + 4 * step + r);
+      }
+    });
+    TS(5);
+    alias_barrier();                                           // swap consumed
+    {
+      cf *sp = buf + t;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) sp[(4 * P + b + 8 * k1) * WAVE] = A[b * 8 + k1];
+      if (P == 0 && t < PW_REP) buf[W + t] = A[0];
+    }
+    pair_barrier();
+    TS(6);
+    // ---- channel stage: lane = channel; this wavefront's bins i = 4P + a + 8 n2 ----
+    const bool seam = w == w_begin && w_begin > 0;
+    {
+      const int c0 = center, c1 = (center - HS) & (W - 1);
+      cf u[32];
+      // all sixteen bin pairs first, then the response in chunks of four pairs, each requested one chunk ahead
+      float4 X2[16], Hq[2][4];
+      auto pair_index = [](int j) { return 4 * P + 2 * (j >> 3) + 8 * (j & 7); };   // j = (aa / 2) * 8 + n2 -> bin i (even)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int i = pair_index(j);
+        X2[j] = *reinterpret_cast<const float4 *>(buf + (i < HS ? c0 + i : c1 + (i - HS)));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Hq[0][j] = *reinterpret_cast<const float4 *>(buf + PW_HK + pair_index(j));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c + 1 < 4) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Hq[(c + 1) & 1][j] = *reinterpret_cast<const float4 *>(buf + PW_HK + pair_index(4 * (c + 1) + j));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int jj = 4 * c + j, aa = 2 * (jj >> 3), n2 = jj & 7;
+          const float4 X = X2[jj], Hh = Hq[c & 1][j];
+          cmul1x2(cf{X.x, X.y}, cf{Hh.x, Hh.y}, cf{X.z, X.w}, cf{Hh.z, Hh.w}, u[aa * 8 + n2], u[(aa + 1) * 8 + n2]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      TS(7);
+      alias_barrier();                                         // both have their bins: the swap may overwrite the spectrum
+      cf F[32];
+      // (the swap of the inverse transform lives in the SECOND 16 KiB: the next window's first swap must not run into it)
+      dft64_pair<P>(u, F, buf + 2 * PW_EX, t, [](int) {});
+      TS(8);
+      // F[b * 8 + k1] = F_nat[(4P + b) + 8 k1];  output i: cur = F_nat[(64 - i) & 63], next block's partner = F_nat[32 - i]
+      auto chan_out = [&](auto seam_tag, auto rot) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int i = out_index(b, m);
+            const int fc = (64 - i) & 63, fn = 32 - i;
+            const cf cur = F[b * 8 + (fc - (4 * P + b)) / 8], nx = F[b * 8 + (fn - (4 * P + b)) / 8];
+            if constexpr (decltype(seam_tag)::value) {
+              // the payload sits where the consumer's request registers expect it: row 4P + b + 8 m of its first half
+              const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ho + slot * HO, 0, (int)HO * 8, 0x00020000);
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, cur), rs, t * 8, (4 * P + b + 8 * m) * WAVE * 8, AUX_SC1);
+            } else {
+              emit_one(rot, w, i, xfade_p(kWinP[i], cur, kWinP[i + HS], prev[b * 4 + m]));
+            }
+            prev[b * 4 + m] = nx;
+          }
+      };
+      if (seam) chan_out(std::true_type{}, std::false_type{});
+      else if (any_precise) chan_out(std::false_type{}, std::true_type{});
+      else chan_out(std::false_type{}, std::false_type{});
+    }
+    if (seam) publish = true;
+    TS(9);
+#ifdef STW_TSTAMP
+    if (a.tstamp && t == 0 && P == 0) {
+      unsigned long long *tp = a.tstamp + ((long long)slot * a.run + (w - w_begin)) * 16;
+      for (int n = 0; n < 10; ++n) tp[n] = ts[n];
+    }
+#endif
+    // (no barrier here: the next window's first swap writes the first 16 KiB, this window's last swap was read from the second)
+  }
+  if (publish) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (P == 0 && t == 0) __hip_atomic_store(a.flags + slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (final_run) {
+    if (k < a.nchan) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) reinterpret_cast<cf *>(a.prev_out)[(long long)k * HS + out_index(b, m)] = prev[b * 4 + m];
+    }
+  } else if (!self_seam) {
+    // the seam block: request register (a, n2 < 4) holds the next run's first-half output i(a, n2)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int i = out_index(b, m);
+        const cf o = xfade_p(kWinP[i], nxt[b * 8 + m], kWinP[i + HS], prev[b * 4 + m]);
+        if (any_precise) emit_one(std::true_type{}, w_end, i, o);
+        else emit_one(std::false_type{}, w_end, i, o);
+      }
+  }
+#ifdef STW_TSTAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (a.tstamp && t == 0 && P == 0) { unsigned long long *tp = a.tstamp + ((long long)slot * a.run) * 16; tp[10] = t_entry; tp[11] = __builtin_amdgcn_s_memtime(); }
+#endif
+}
+
+template <bool Y32>
+__global__ __launch_bounds__(2 * WAVE, 2) void stp_kernel(sdk::StArgs a)
+{
+  __builtin_amdgcn_s_setprio(3);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cf *buf = reinterpret_cast<cf *>(smem);
+  const int t = threadIdx.x & (WAVE - 1);
+  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0) stp_body<0, Y32>(a, buf, t);
+  else stp_body<1, Y32>(a, buf, t);
+}
+
+}  // namespace
+
+namespace sdk {
+
+// 64-bin channels, one response for the whole launch, runs of at least two windows
+hipError_t specttuner_feed_pair(const StArgs &a, hipStream_t st)
+{
+  if (a.nwin <= 0 || a.nchan <= 0) return hipSuccess;
+  if (!a.hk_uniform || a.run < 2) return hipErrorInvalidValue;
+  const unsigned nruns = (unsigned)((a.nwin + a.run - 1) / a.run);
+  const unsigned ny = (unsigned)((a.nchan + WAVE - 1) / WAVE);
+  if (a.y32) sdk::launch_timed("stp_kernel", stp_kernel<true>, dim3(nruns, ny), dim3(2 * WAVE), PW_LDS, st, a);
+  else sdk::launch_timed("stp_kernel", stp_kernel<false>, dim3(nruns, ny), dim3(2 * WAVE), PW_LDS, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace sdk

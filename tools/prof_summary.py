@@ -14,7 +14,7 @@ def short(name):
     return re.sub(r"\(.*$", "", name)
 
 
-OURS = re.compile(r"^(st_kernel|stw_kernel|chandet_|audio_|psd_|psdl_|chan_fir|costas_|clock_|agc_|pll_|quad_|xlate_|modulate_|update_hist|interpolate_|sweep_linear|"
+OURS = re.compile(r"^(st_kernel|stw_kernel|stp_kernel|chandet_|audio_|psd_|psdl_|chan_fir|costas_|clock_|agc_|pll_|quad_|xlate_|modulate_|update_hist|interpolate_|sweep_linear|"
                   r"feed_|fft_pass|frame_|window_pad|power_argmax|centroid|ingest|rows_|cma_|zc_|conj_prev|fac_|"
                   r"histogram_|delayed_|sample_manual|averager_|insp_spectrum|psd_shift)")
 stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
