@@ -186,6 +186,12 @@ SUAMD_API SUBOOL suamd_specttuner_feed_rows(suamd_specttuner_t *st, const suamd_
                                             suamd_complex *const *d_rows, SUSCOUNT *counts, void *stream);
 /* windows per workgroup run (default 3): a run re-transforms the window before it */
 SUAMD_API SUBOOL suamd_specttuner_set_run(suamd_specttuner_t *st, unsigned run);
+/* How many of the chip's 1024 window slots (4 windows per CU: the LDS) a launch of the narrow-channel kernels may plan
+ * for; the run length of a feed is ceil(windows / slots).  Default 768 (0 restores it): a launch must fit ONE round, and
+ * kernels of other streams (the recurrences of earlier blocks) hold a few slots for milliseconds -- a workgroup that
+ * finds none waits for a whole run of another.  1024 is for a tuner that has the device to itself (an offline
+ * LPFTask-style pass): 78 instead of 88 us per 16 Mi x 64 block. */
+SUAMD_API SUBOOL suamd_specttuner_set_slots(suamd_specttuner_t *st, unsigned slots);
 /* Entries a `counts` array passed to suamd_specttuner_feed / _feed_rows must hold: one per slot of the tuner's channel
  * table (slots of closed channels are reused but the table never shrinks), i.e. the highest index ever returned by
  * _open_channel plus one.  A feed zeroes every entry and fills those of the open channels. */

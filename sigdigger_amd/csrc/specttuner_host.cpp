@@ -171,6 +171,7 @@ struct suamd_specttuner {
   int log2w = 12;
   unsigned run = 3;                    // windows per workgroup: 683 workgroups per 4 Mi-sample block, a third re-transformed
   unsigned run_wave = 0;               // wavefront kernel: windows per wavefront (0: one round of 4 wavefronts per CU)
+  unsigned slots = 0;                  // wavefront kernels: the launch's budget of the chip's 1024 window slots (0: SUAMD_ST_SLOTS, else 768)
   int seam_polls = 256;                // wavefront kernel: bounded wait for a run's successor (SUAMD_ST_SEAM_POLLS; 0: never wait)
   bool use_wave = true;                // sizes 8..64 go to specttuner_wave.hip (SUAMD_ST_KERNEL=wg keeps them on specttuner.hip)
   bool use_pair = true;                // 64-bin channels with one response: two wavefronts per window (specttuner_pair.hip; SUAMD_ST_KERNEL=wave keeps them on specttuner_wave.hip)
@@ -450,6 +451,13 @@ SUBOOL suamd_specttuner_design(unsigned window_size, double f0, double bw, doubl
   return SU_TRUE;
 }
 
+SUBOOL suamd_specttuner_set_slots(suamd_specttuner_t *st, unsigned slots)
+{
+  if (!st || (slots != 0 && (slots < 64 || slots > 4096))) { suamd_set_error("slots out of range (0, or 64 .. 4096)"); return SU_FALSE; }
+  st->slots = slots;
+  return SU_TRUE;
+}
+
 SUBOOL suamd_specttuner_set_run(suamd_specttuner_t *st, unsigned run)
 {
   if (!st || run < 1 || run > 4096) { suamd_set_error("run out of range"); return SU_FALSE; }
@@ -527,7 +535,7 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
           // (SUAMD_ST_SLOTS: the wavefront budget of a launch, default 768; a long block rounds up to whole windows per
           // wavefront far below the budget anyway, and there a larger budget is pure gain)
           static const long long slots = [] { const char *e = std::getenv("SUAMD_ST_SLOTS"); const long long v = e ? std::atoll(e) : 0; return v >= 64 && v <= 4096 ? v : 0; }();
-          const long long budget = slots ? slots : 768;
+          const long long budget = st->slots ? st->slots : (slots ? slots : 768);
           a.run = (int)std::max<long long>(1, (nwin * ny + budget - 1) / budget);
         }
         {

@@ -462,6 +462,10 @@ class SpectTuner:
     def set_run(self, run):
         check(self.ctx.lib.suamd_specttuner_set_run(self.h, int(run)), "suamd_specttuner_set_run")
 
+    def set_slots(self, slots):
+        """window slots a launch may plan for (768; 1024 when nothing else runs on the device)"""
+        check(self.ctx.lib.suamd_specttuner_set_slots(self.h, int(slots)), "suamd_specttuner_set_slots")
+
     def capacity(self):
         """entries a counts array must hold (suamd_specttuner_channel_capacity)"""
         return int(self.ctx.lib.suamd_specttuner_channel_capacity(self.h))

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "suamd_specttuner_feed": (INT, [VP, VP, U64, VP, View, C.POINTER(U64), VP]),
     "suamd_specttuner_feed_rows": (INT, [VP, VP, U64, VP, C.POINTER(U64), VP]),
     "suamd_specttuner_set_run": (INT, [VP, UINT]),
+    "suamd_specttuner_set_slots": (INT, [VP, UINT]),
     "suamd_specttuner_channel_capacity": (UINT, [VP]),
     "suamd_specttuner_reset": (INT, [VP, VP]),
     "suamd_specttuner_design": (INT, [UINT, F64, F64, F64, C.POINTER(U32), VP]),

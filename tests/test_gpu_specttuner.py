@@ -337,3 +337,41 @@ def test_reset_forgets_the_stream_position_and_closing_the_higher_channel_is_saf
     t.feed(x[H * 4:H * 8])
     assert t.samples(k0).size == 7 * 32
     t.close()
+
+
+def test_two_wavefronts_per_window_equal_one_bit_for_bit(ctx, monkeypatch):
+    """64-bin channels with one response run on specttuner_pair.hip (two wavefronts per window, every 64-point DFT split
+    between them); SUAMD_ST_KERNEL=wave keeps them on the one-wavefront kernel.  Same samples bit for bit -- runs of two
+    and three windows, the seam hand-off, a residual NCO, more channels than one workgroup serves, 64-bit row
+    addressing, and whatever slot budget plans the launch."""
+    x = cnoise(H * 96, 77)
+    chans = [(0.2 + 0.085 * c, 2 * np.pi / 64 * 0.75, 1.0, bool(c % 5 == 0)) for c in range(70)]
+    monkeypatch.setenv("SUAMD_ST_KERNEL", "wave")
+    ref = run_gpu(ctx, x, chans, splits=[H * 40], run=3)
+    monkeypatch.delenv("SUAMD_ST_KERNEL")
+    for run, tm in ((2, False), (3, True), (7, False)):
+        got = run_gpu(ctx, x, chans, splits=[H * 40], run=run, time_major=tm)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (run, tm)
+    monkeypatch.setenv("SUAMD_ST_Y32", "0")
+    got = run_gpu(ctx, x, chans, splits=[H * 40], run=2)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    monkeypatch.delenv("SUAMD_ST_Y32")
+    # slot budgets: 64 slots -> runs of two windows on a 96-window stream, 1024 -> runs of one (the one-wavefront kernel)
+    for slots in (64, 1024, 0):
+        st = engine.SpectTuner(ctx, W)
+        st.set_slots(slots)
+        ids = [st.open_channel(*c) for c in chans]
+        out, counts = st.feed(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        one = run_gpu(ctx, x, chans)
+        for k, c in enumerate(ids):
+            assert np.array_equal(out[c, :counts[c]].cpu().numpy().view(np.uint32), one[k].view(np.uint32)), slots
+        st.close()
+    with pytest.raises(engine.SigDiggerAmdError):
+        st2 = engine.SpectTuner(ctx, W)
+        try:
+            st2.set_slots(5)
+        finally:
+            st2.close()
