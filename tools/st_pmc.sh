@@ -13,7 +13,7 @@ for d in ("st_pmc", "st_pmc2", "st_pmc3", "st_pmc4"):
     acc = collections.defaultdict(list)
     for fn in glob.glob(f"gpurun_out/{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(fn)):
-            if "st_kernel" in r["Kernel_Name"] or "stw_kernel" in r["Kernel_Name"]:
+            if any(k in r["Kernel_Name"] for k in ("st_kernel", "stw_kernel", "stp_kernel")):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in sorted(acc.items()):
         print(f"{k:28s} launches {len(v):3d}  mean {sum(v)/len(v):16.1f}")
