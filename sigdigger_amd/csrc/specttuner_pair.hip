@@ -79,6 +79,9 @@ __device__ __forceinline__ void dft64_pair(const cf *in, cf *out, cf *ex, int t,
 {
   constexpr int Q = 1 - P;
   cf keep[16];
+#ifdef STP_UNSAFE_NO_EXCHANGE
+  cf unsafe[16];
+#endif
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     cf a8[8];
@@ -89,18 +92,29 @@ __device__ __forceinline__ void dft64_pair(const cf *in, cf *out, cf *ex, int t,
     for (int k2 = 0; k2 < 8; ++k2) {
       const cf m = mul_w64(a8[k2], (4 * P + a) * k2);
       if (k2 / 4 == P) keep[a * 4 + (k2 & 3)] = m;
+#ifdef STP_UNSAFE_NO_EXCHANGE
+      else unsafe[a * 4 + (k2 & 3)] = m;                       // timing experiment: the partner's half never travels (results wrong)
+#else
       else ex[(P * 16 + a * 4 + (k2 & 3)) * WAVE + t] = m;
+#endif
     }
     hook(a);
   }
+#ifndef STP_UNSAFE_NO_EXCHANGE
   pair_barrier();
+#endif
   // the partner's sixteen values, requested in one go (left alone the compiler alternates read / wait / use and a lone
   // wavefront pays the LDS latency every time)
   cf recv[16];
 #pragma unroll
   for (int b = 0; b < 4; ++b)
 #pragma unroll
-    for (int aq = 0; aq < 4; ++aq) recv[b * 4 + aq] = ex[(Q * 16 + aq * 4 + b) * WAVE + t];
+    for (int aq = 0; aq < 4; ++aq)
+#ifdef STP_UNSAFE_NO_EXCHANGE
+      recv[b * 4 + aq] = unsafe[aq * 4 + b];
+#else
+      recv[b * 4 + aq] = ex[(Q * 16 + aq * 4 + b) * WAVE + t];
+#endif
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
