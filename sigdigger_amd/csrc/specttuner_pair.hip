@@ -45,7 +45,9 @@ constexpr int PW_PITCH = 65;                                   // transposition 
 constexpr int PW_REP = 32;                                     // spectrum bins repeated after the end
 constexpr int PW_HK = WAVE * PW_PITCH;                         // the response: 64 elements behind the transposition buffer
 constexpr int PW_FLAG = PW_HK + 64;                            // one word the wavefronts of a pair share (seam decision)
-constexpr int PW_LDS = (PW_FLAG + 2) * 8;
+constexpr int PW_TOTAL = PW_FLAG + 2;                          // elements
+constexpr int PW_LDS = PW_TOTAL * 8;
+constexpr int PW_LDS_SEP = (PW_TOTAL + 2 * 1024) * 8;          // with a separate swap area
 constexpr int PW_EX = 1024;                                    // elements of one direction of a mid-DFT swap (16 x 64)
 constexpr int AUX_NT = 2;
 constexpr int AUX_SC1 = 16;
@@ -128,9 +130,12 @@ __device__ __forceinline__ void dft64_pair(const cf *in, cf *out, cf *ex, int t,
   }
 }
 
-template <int P, bool Y32>
+// SEP: the forward swaps have 16 KiB of their own behind the buffer (a launch of at most three workgroups per CU can
+// afford 50 KB each): the three barriers that only keep them off the transposition data go away
+template <int P, bool Y32, bool SEP>
 __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const int t)
 {
+  cf *const exf = SEP ? buf + PW_TOTAL : buf;                  // swap area of the two forward DFTs
   constexpr int W = PW_W, H = PW_H, HS = PW_HS;
 #ifdef STW_TSTAMP
   const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
@@ -263,7 +268,7 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
     }
     // ---- forward transform, columns ----
     // (the swap area is the first 16 KiB of the buffer: the previous window's spectrum, which both wavefronts have left)
-    dft64_pair<P>(nxt, A, buf, t, [](int) {});
+    dft64_pair<P>(nxt, A, exf, t, [](int) {});
     TS(1);
     if (last_of_run) {
       if (*shared_flag == 0u) { self_seam = true; w_stop = w_end + 1; }
@@ -291,7 +296,7 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
       }
     }
     TS(2);
-    alias_barrier();                                           // the partner has taken its half of the swap
+    if constexpr (!SEP) alias_barrier();                       // the partner has taken its half of the swap
     {
       cf *wr = buf + t * PW_PITCH;
 #pragma unroll
@@ -311,17 +316,17 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
       __builtin_amdgcn_sched_barrier(0);
     }
     TS(3);
-    alias_barrier();                                           // both have read the transposition buffer: the swap may overwrite it
+    if constexpr (!SEP) alias_barrier();                       // both have read the transposition buffer: the swap may overwrite it
     TS(4);
     // ---- forward transform, rows: A[b * 8 + k1] = X[t + 64 (4P + b + 8 k1)] ----
-    dft64_pair<P>(v, A, buf, t, [&](int step) {
+    dft64_pair<P>(v, A, exf, t, [&](int step) {
       if (step < 4) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) load_one(16 + 4 * step + r);
       }
     });
     TS(5);
-    alias_barrier();                                           // swap consumed
+    if constexpr (!SEP) alias_barrier();                       // swap consumed
     {
       cf *sp = buf + t;
 #pragma unroll
@@ -432,15 +437,15 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
 #endif
 }
 
-template <bool Y32>
+template <bool Y32, bool SEP>
 __global__ __launch_bounds__(2 * WAVE, 2) void stp_kernel(sdk::StArgs a)
 {
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf *buf = reinterpret_cast<cf *>(smem);
   const int t = threadIdx.x & (WAVE - 1);
-  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0) stp_body<0, Y32>(a, buf, t);
-  else stp_body<1, Y32>(a, buf, t);
+  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0) stp_body<0, Y32, SEP>(a, buf, t);
+  else stp_body<1, Y32, SEP>(a, buf, t);
 }
 
 }  // namespace
@@ -454,8 +459,14 @@ hipError_t specttuner_feed_pair(const StArgs &a, hipStream_t st)
   if (!a.hk_uniform || a.run < 2) return hipErrorInvalidValue;
   const unsigned nruns = (unsigned)((a.nwin + a.run - 1) / a.run);
   const unsigned ny = (unsigned)((a.nchan + WAVE - 1) / WAVE);
-  if (a.y32) sdk::launch_timed("stp_kernel", stp_kernel<true>, dim3(nruns, ny), dim3(2 * WAVE), PW_LDS, st, a);
-  else sdk::launch_timed("stp_kernel", stp_kernel<false>, dim3(nruns, ny), dim3(2 * WAVE), PW_LDS, st, a);
+  // at most three workgroups per CU anyway (768 of the 1024 window slots): each can have 50 KB of LDS
+  static const bool no_sep = [] { const char *e = getenv("SUAMD_ST_PAIR_SEP"); return e && e[0] == '0'; }();
+  const bool sep = (unsigned long long)nruns * ny <= 768 && !no_sep;
+  auto go = [&](auto kern, int lds) {
+    sdk::launch_timed("stp_kernel", kern, dim3(nruns, ny), dim3(2 * WAVE), (size_t)lds, st, a);
+  };
+  if (sep) { if (a.y32) go(stp_kernel<true, true>, PW_LDS_SEP); else go(stp_kernel<false, true>, PW_LDS_SEP); }
+  else { if (a.y32) go(stp_kernel<true, false>, PW_LDS); else go(stp_kernel<false, false>, PW_LDS); }
   return hipGetLastError();
 }
 
