@@ -157,11 +157,16 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
     ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(pa), 0, na, 0x00020000);
     rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(pb), 0, nb, 0x00020000);
   };
-  auto load_one = [&](int q) {                                 // q = a * 8 + n2
+  // (`pay`: the first-half request fetches a seam payload another workgroup -- another XCD -- has just written: agent scope.
+  // Samples are requested with the default policy: the half window this run's previous window already fetched is then
+  // found in the L2.  One policy for both would have to be sc1 -- and was, in the one-wavefront kernel: every first half
+  // came past the L2.)
+  auto load_one = [&](auto pay, int q) {                       // q = a * 8 + n2
     const int r = 4 * P + (q >> 3) + 8 * (q & 7);
-    if (r < WAVE / 2) nxt[q] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(ra, t * 8, r * WAVE * 8, AUX_SC1));
+    if (r < WAVE / 2) nxt[q] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(ra, t * 8, r * WAVE * 8, decltype(pay)::value ? AUX_SC1 : 0));
     else nxt[q] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(rb, t * 8, (r - WAVE / 2) * WAVE * 8, 0));
   };
+  bool pay_now = false;                                        // what the request in progress fetches through `ra`
   auto aim_window = [&](long long w) { aim((w == 0 && a.have_hist) ? hist : x + (w * H - off), H * 8, x + (w * H + H - off), H * 8); };
   const bool final_run = w_end == a.nwin;
   const long long nslot = slot + gridDim.y;
@@ -178,6 +183,7 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
   };
   auto aim_next = [&](long long w) {
     const bool more = w + 1 < w_stop, pay = !more && !final_run && !self_seam;
+    pay_now = pay;
     const long long wn = more ? w + 1 : w;
     const cf *pa = pay ? ho + nslot * HO : ((wn == 0 && a.have_hist) ? hist : x + (wn * H - off));
     aim(pa, more ? H * 8 : (pay ? (unsigned)HO * 8 : 0u), x + (wn * H + H - off), more ? H * 8 : 0u);
@@ -185,7 +191,7 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
 
   aim_window(w_begin);
 #pragma unroll
-  for (int q = 0; q < 32; ++q) load_one(q);
+  for (int q = 0; q < 32; ++q) load_one(std::false_type{}, q);
   __builtin_amdgcn_sched_barrier(0);
 
   // W_4096^(t 2^j)
@@ -304,8 +310,13 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
 #pragma unroll
         for (int h = 0; h < 8; ++h) wr[4 * P + b + 8 * h] = A[b * 8 + h];
     }
+    if (pay_now) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) load_one(q);
+      for (int q = 0; q < 16; ++q) load_one(std::true_type{}, q);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) load_one(std::false_type{}, q);
+    }
     pair_barrier();
     {
       const cf *rd = buf + t;
@@ -321,8 +332,13 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
     // ---- forward transform, rows: A[b * 8 + k1] = X[t + 64 (4P + b + 8 k1)] ----
     dft64_pair<P>(v, A, exf, t, [&](int step) {
       if (step < 4) {
+        if (pay_now) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) load_one(16 + 4 * step + r);
+          for (int r = 0; r < 4; ++r) load_one(std::true_type{}, 16 + 4 * step + r);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) load_one(std::false_type{}, 16 + 4 * step + r);
+        }
       }
     });
     TS(5);
