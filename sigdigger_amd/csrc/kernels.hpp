@@ -116,8 +116,8 @@ hipError_t specttuner_feed(int log2w, int log2s, const StArgs &a, hipStream_t st
 // specttuner_wave.hip: one wavefront per window, sizes 8..64 (W = 4096); channels one wavefront serves
 int stw_channels_per_wave(int log2s);
 hipError_t specttuner_feed_wave(int log2s, const StArgs &a, hipStream_t st);
-// specttuner_pair.hip: two wavefronts per window; 64-bin channels, a.hk_uniform, a.run >= 2 (same results bit for bit)
-hipError_t specttuner_feed_pair(const StArgs &a, hipStream_t st);
+// specttuner_pair.hip: two wavefronts per window; channels of 8 .. 64 bins, a.hk_uniform, a.run >= 2 (same results bit for bit)
+hipError_t specttuner_feed_pair(int log2s, const StArgs &a, hipStream_t st);
 
 // ---- chandet.hip: su_channel_detector (SPEC.md section O) ----
 struct ChanDetRecord { int first, last, width; float peak; double sum, wsum; };   // bins in frequency order (0 = -fs/2)

@@ -1,4 +1,4 @@
-// specttuner_pair.hip -- the FFT channeliser for 64-bin channels with one response, TWO wavefronts per window
+// specttuner_pair.hip -- the FFT channeliser for banks of narrow channels (8 .. 64 bins) with one response, TWO wavefronts per window
 // (SPEC.md section C2; rows T2 / N2).  Same arithmetic, operation for operation, as specttuner_wave.hip (the oracle's
 // binary32 statement: both kernels equal it bit for bit); what changes is who holds what.
 //
@@ -132,21 +132,26 @@ __device__ __forceinline__ void dft64_pair(const cf *in, cf *out, cf *ex, int t,
 
 // SEP: the forward swaps have 16 KiB of their own behind the buffer (a launch of at most three workgroups per CU can
 // afford 50 KB each): the three barriers that only keep them off the transposition data go away
-template <int P, bool Y32, bool SEP>
+// Channels of S = 2^LOG2S bins.  S = 64: a lane's channel is split between the wavefronts like the forward DFTs (third
+// swap).  S < 64: a lane serves 64 / S channels, wavefront p takes half of them whole -- their inverse transforms are
+// lane-local, no third swap.  Either way a wavefront owns 16 outputs per lane and block (`slot` o = 0..15 below).
+template <int P, int LOG2S, bool Y32, bool SEP>
 __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const int t)
 {
   cf *const exf = SEP ? buf + PW_TOTAL : buf;                  // swap area of the two forward DFTs
-  constexpr int W = PW_W, H = PW_H, HS = PW_HS;
+  constexpr int W = PW_W, H = PW_H;
+  constexpr int S = 1 << LOG2S, HS = S / 2, NG = WAVE / S, NGW = LOG2S == 6 ? 1 : NG / 2, WS = 64 / S;
+  static_assert(LOG2S >= 3 && LOG2S <= 6, "channel size out of range for the two-wavefront kernel");
 #ifdef STW_TSTAMP
   const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
   const long long w_begin = (long long)blockIdx.x * a.run, w_end = (w_begin + a.run < a.nwin) ? w_begin + a.run : a.nwin;
   const cf *x = reinterpret_cast<const cf *>(a.x), *hist = reinterpret_cast<const cf *>(a.hist);
   const long long off = a.have_hist ? H : 0;                   // virtual stream = hist (H samples) ++ x
-  const int k = blockIdx.y * WAVE + t;                         // this lane's channel
+  const int kbase = blockIdx.y * (NG * WAVE) + t;              // this lane's channel in group g: kbase + 64 g
   const long long slot = (long long)blockIdx.x * gridDim.y + blockIdx.y;
   cf *const ho = reinterpret_cast<cf *>(a.handoff);
-  constexpr long long HO = (long long)HS * WAVE;               // elements per hand-off slot
+  constexpr long long HO = 32ll * WAVE;                        // elements per hand-off slot: 16 rows per wavefront
   unsigned *const shared_flag = reinterpret_cast<unsigned *>(buf + PW_FLAG);
 
   // Register (a, n2) of the request holds sample t + 64 r, r = 4P + a + 8 n2: rows r < 32 come through descriptor `ra`
@@ -199,32 +204,51 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
 #pragma unroll
   for (int j = 0; j < 6; ++j) wb[j] = reinterpret_cast<const cf *>(a.tw_w)[t << j];
 
-  // Output i of a block needs F[(64 - i) & 63] and F[32 - i]: both in second-stage sub-transform k2 = (-i) mod 8, so this
-  // wavefront owns the outputs i(b, m) = ((8 - (4P + b)) & 7) + 8 m and their cross-fade partners
+  // The 16 outputs per lane and block this wavefront owns, slot o = 0..15:
+  //   S = 64: output i needs F[(64 - i) & 63] and F[32 - i], both of second-stage sub-transform k2 = (-i) mod 8, so the
+  //           wavefront owns i(b, m) = ((8 - (4P + b)) & 7) + 8 m, o = 4 b + m;
+  //   S < 64: outputs 0 .. S/2 - 1 of its NGW channels, o = gl S/2 + i.
+  // Slot o's seam payload travels in row 4P + (o >> 2) + 8 (o & 3) of the hand-off slot, i.e. in request register
+  // (a, n2) = (o >> 2, o & 3) of the consumer.
   auto out_index = [](int b, int m) { return ((8 - (4 * P + b)) & 7) + 8 * m; };
+  auto slot_group = [](int o) { return LOG2S == 6 ? 0 : o / HS; };                  // local group gl
+  auto slot_out = [&](int o) { return LOG2S == 6 ? out_index(o >> 2, o & 3) : o % HS; };
+  auto slot_q = [](int o) { return (o >> 2) * 8 + (o & 3); };
+  auto slot_row = [](int o) { return 4 * P + (o >> 2) + 8 * (o & 3); };
+  auto group_of = [](int gl) { return LOG2S == 6 ? 0 : P * NGW + gl; };
   cf prev[16];
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-      prev[b * 4 + m] = (w_begin == 0 && k < a.nchan) ? reinterpret_cast<const cf *>(a.prev_in)[(long long)k * HS + out_index(b, m)] : cf{0.f, 0.f};
+  for (int o = 0; o < 16; ++o) {
+    const int kk = kbase + group_of(slot_group(o)) * WAVE;
+    prev[o] = (w_begin == 0 && kk < a.nchan) ? reinterpret_cast<const cf *>(a.prev_in)[(long long)kk * HS + slot_out(o)] : cf{0.f, 0.f};
+  }
 
   // (the channel record is read where it is used: the residual-NCO fields only on the path that rotates -- held across the
   // window loop they would be spilled)
-  const sdk::StChan *const cdp = a.chans + (k < a.nchan ? k : 0);
-  const int center = cdp->center;
-  const int row = cdp->row;
-  cf *const ybase = a.rows ? static_cast<cf *>(const_cast<void *>(a.rows[row])) : reinterpret_cast<cf *>(a.y) + (long long)row * a.yv.cs;
-  const unsigned yvoff = k < a.nchan ? (unsigned)((long long)row * a.yv.cs * 8) : 0x80000000u;
+  const sdk::StChan *cdp[NGW];
+  int center[NGW];
+  cf *ybase[NGW];
+  unsigned yvoff[NGW];
+  bool any_precise = false;
+#pragma unroll
+  for (int gl = 0; gl < NGW; ++gl) {
+    const int kk = kbase + group_of(gl) * WAVE;
+    cdp[gl] = a.chans + (kk < a.nchan ? kk : 0);
+    center[gl] = cdp[gl]->center;
+    const int row = cdp[gl]->row;
+    ybase[gl] = a.rows ? static_cast<cf *>(const_cast<void *>(a.rows[row])) : reinterpret_cast<cf *>(a.y) + (long long)row * a.yv.cs;
+    yvoff[gl] = kk < a.nchan ? (unsigned)((long long)row * a.yv.cs * 8) : 0x80000000u;
+    any_precise |= __builtin_amdgcn_ballot_w64(cdp[gl]->precise != 0) != 0;
+  }
   const long long yms = a.rows ? 1 : a.yv.ms;
   const unsigned yms8 = (unsigned)(yms * 8);
-  const bool any_precise = __builtin_amdgcn_ballot_w64(cdp->precise != 0) != 0;
+  // (S < 64: the wavefronts serve different channels and may differ in `any_precise` -- their channel stages have no barrier)
 
-  auto emit_one = [&](auto rot, long long wo, int i, cf o) {
+  auto emit_one = [&](auto rot, int gl, long long wo, int i, cf o) {
     if constexpr (decltype(rot)::value) {
       const uint32_t m = (uint32_t)((unsigned long long)wo * HS + i);
-      const bool precise = cdp->precise != 0;
-      const uint32_t dphase = cdp->dphase, phase0 = (uint32_t)(a.n0 - cdp->n_open);
+      const bool precise = cdp[gl]->precise != 0;
+      const uint32_t dphase = cdp[gl]->dphase, phase0 = (uint32_t)(a.n0 - cdp[gl]->n_open);
       float c, s;
       sd::phasor_u32((phase0 + m) * dphase, c, s);
       c = precise ? c : 1.0f;
@@ -234,13 +258,13 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
     if constexpr (Y32) {
       const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
           reinterpret_cast<cf *>(a.y) + (long long)((unsigned long long)wo * HS) * yms, 0, 0x7fffffff, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), ry, yvoff, (unsigned)i * yms8, AUX_NT);
-    } else if (k < a.nchan) {
-      *(gcf *)(ybase + ((long long)((unsigned long long)wo * HS) + i) * yms) = o;
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), ry, yvoff[gl], (unsigned)i * yms8, AUX_NT);
+    } else if (kbase + group_of(gl) * WAVE < a.nchan) {
+      *(gcf *)(ybase[gl] + ((long long)((unsigned long long)wo * HS) + i) * yms) = o;
     }
   };
 
-  if (P == 0 && t < PW_S) buf[PW_HK + t] = reinterpret_cast<const cf *>(a.hk)[t];     // the launch's one response
+  if (P == 0 && t < S) buf[PW_HK + t] = reinterpret_cast<const cf *>(a.hk)[t];        // the launch's one response
   bool publish = false;
   for (long long w = w_begin; w < w_stop; ++w) {
     cf v[32], A[32];
@@ -353,10 +377,23 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
     }
     pair_barrier();
     TS(6);
-    // ---- channel stage: lane = channel; this wavefront's bins i = 4P + a + 8 n2 ----
+    // ---- channel stage: lane = channel ----
     const bool seam = w == w_begin && w_begin > 0;
-    {
-      const int c0 = center, c1 = (center - HS) & (W - 1);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ho + slot * HO, 0, (int)HO * 8, 0x00020000);
+    // slot o: this block's sample `cur` and the next block's partner `nx`
+    auto slot_done = [&](auto seam_tag, auto rot, int o, cf cur, cf nx) {
+      const int i = slot_out(o);
+      if constexpr (decltype(seam_tag)::value) {
+        // the payload sits where the consumer's request registers expect it
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, cur), rs, t * 8, slot_row(o) * WAVE * 8, AUX_SC1);
+      } else {
+        emit_one(rot, slot_group(o), w, i, xfade_p(kWinP[i * WS], cur, kWinP[(i + HS) * WS], prev[o]));
+      }
+      prev[o] = nx;
+    };
+    if constexpr (LOG2S == 6) {
+      // this wavefront's bins i = 4P + a + 8 n2 of the lane's one channel
+      const int c0 = center[0], c1 = (center[0] - HS) & (W - 1);
       cf u[32];
       // all sixteen bin pairs first, then the response in chunks of four pairs, each requested one chunk ahead
       float4 X2[16], Hq[2][4];
@@ -393,25 +430,56 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
       // F[b * 8 + k1] = F_nat[(4P + b) + 8 k1];  output i: cur = F_nat[(64 - i) & 63], next block's partner = F_nat[32 - i]
       auto chan_out = [&](auto seam_tag, auto rot) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const int i = out_index(b, m);
-            const int fc = (64 - i) & 63, fn = 32 - i;
-            const cf cur = F[b * 8 + (fc - (4 * P + b)) / 8], nx = F[b * 8 + (fn - (4 * P + b)) / 8];
-            if constexpr (decltype(seam_tag)::value) {
-              // the payload sits where the consumer's request registers expect it: row 4P + b + 8 m of its first half
-              const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ho + slot * HO, 0, (int)HO * 8, 0x00020000);
-              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, cur), rs, t * 8, (4 * P + b + 8 * m) * WAVE * 8, AUX_SC1);
-            } else {
-              emit_one(rot, w, i, xfade_p(kWinP[i], cur, kWinP[i + HS], prev[b * 4 + m]));
-            }
-            prev[b * 4 + m] = nx;
-          }
+        for (int o = 0; o < 16; ++o) {
+          const int b = o >> 2, i = slot_out(o);
+          const int fc = (64 - i) & 63, fn = 32 - i;
+          slot_done(seam_tag, rot, o, F[b * 8 + (fc - (4 * P + b)) / 8], F[b * 8 + (fn - (4 * P + b)) / 8]);
+        }
       };
       if (seam) chan_out(std::true_type{}, std::false_type{});
       else if (any_precise) chan_out(std::false_type{}, std::true_type{});
       else chan_out(std::false_type{}, std::false_type{});
+    } else {
+      // this wavefront's NGW channels per lane, whole: bins, response, inverse transform on the lane's own registers
+      auto chan_out = [&](auto seam_tag, auto rot) {
+#pragma unroll
+        for (int gl = 0; gl < NGW; ++gl) {
+          const int c0 = center[gl], c1 = (center[gl] - HS) & (W - 1);
+          cf u[S], F[S];
+          // all the bin pairs first, then the response in chunks of four pairs, each requested one chunk ahead of its products
+          constexpr int CH = S / 2 < 4 ? S / 2 : 4, NCH = (S / 2) / CH;
+          float4 X2[S / 2], Hq[2][CH];
+#pragma unroll
+          for (int i = 0; i < S; i += 2) X2[i / 2] = *reinterpret_cast<const float4 *>(buf + (i < HS ? c0 + i : c1 + (i - HS)));
+#pragma unroll
+          for (int j = 0; j < CH; ++j) Hq[0][j] = *reinterpret_cast<const float4 *>(buf + PW_HK + 2 * j);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH) {
+#pragma unroll
+              for (int j = 0; j < CH; ++j) Hq[(c + 1) & 1][j] = *reinterpret_cast<const float4 *>(buf + PW_HK + 2 * ((c + 1) * CH + j));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+              const float4 X = X2[c * CH + j], Hh = Hq[c & 1][j];
+              cmul1x2(cf{X.x, X.y}, cf{Hh.x, Hh.y}, cf{X.z, X.w}, cf{Hh.z, Hh.w}, u[2 * (c * CH + j)], u[2 * (c * CH + j) + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          dft_reg<LOG2S>(u, F);                                // y[n] = F[(S - n) mod S]
+#pragma unroll
+          for (int i = 0; i < HS; ++i) slot_done(seam_tag, rot, gl * HS + i, F[(S - i) & (S - 1)], F[HS - i]);
+          __builtin_amdgcn_sched_barrier(0);                   // one channel after the other: their operands would not fit side by side
+        }
+      };
+      if (seam) chan_out(std::true_type{}, std::false_type{});
+      else if (any_precise) chan_out(std::false_type{}, std::true_type{});
+      else chan_out(std::false_type{}, std::false_type{});
+      // both wavefronts are through with the spectrum before the next window's first swap lands in it
+      if constexpr (!SEP) alias_barrier();
+      TS(8);
     }
     if (seam) publish = true;
     TS(9);
@@ -429,23 +497,20 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
     if (P == 0 && t == 0) __hip_atomic_store(a.flags + slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (final_run) {
-    if (k < a.nchan) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) reinterpret_cast<cf *>(a.prev_out)[(long long)k * HS + out_index(b, m)] = prev[b * 4 + m];
+    for (int o = 0; o < 16; ++o) {
+      const int kk = kbase + group_of(slot_group(o)) * WAVE;
+      if (kk < a.nchan) reinterpret_cast<cf *>(a.prev_out)[(long long)kk * HS + slot_out(o)] = prev[o];
     }
   } else if (!self_seam) {
-    // the seam block: request register (a, n2 < 4) holds the next run's first-half output i(a, n2)
+    // the seam block: request register slot_q(o) holds the next run's unweighted sample of slot o
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int i = out_index(b, m);
-        const cf o = xfade_p(kWinP[i], nxt[b * 8 + m], kWinP[i + HS], prev[b * 4 + m]);
-        if (any_precise) emit_one(std::true_type{}, w_end, i, o);
-        else emit_one(std::false_type{}, w_end, i, o);
-      }
+    for (int o = 0; o < 16; ++o) {
+      const int i = slot_out(o);
+      const cf v = xfade_p(kWinP[i * WS], nxt[slot_q(o)], kWinP[(i + HS) * WS], prev[o]);
+      if (any_precise) emit_one(std::true_type{}, slot_group(o), w_end, i, v);
+      else emit_one(std::false_type{}, slot_group(o), w_end, i, v);
+    }
   }
 #ifdef STW_TSTAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -453,37 +518,50 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
 #endif
 }
 
-template <bool Y32, bool SEP>
+template <int LOG2S, bool Y32, bool SEP>
 __global__ __launch_bounds__(2 * WAVE, 2) void stp_kernel(sdk::StArgs a)
 {
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf *buf = reinterpret_cast<cf *>(smem);
   const int t = threadIdx.x & (WAVE - 1);
-  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0) stp_body<0, Y32, SEP>(a, buf, t);
-  else stp_body<1, Y32, SEP>(a, buf, t);
+  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0) stp_body<0, LOG2S, Y32, SEP>(a, buf, t);
+  else stp_body<1, LOG2S, Y32, SEP>(a, buf, t);
 }
 
-}  // namespace
-
-namespace sdk {
-
-// 64-bin channels, one response for the whole launch, runs of at least two windows
-hipError_t specttuner_feed_pair(const StArgs &a, hipStream_t st)
+template <int LOG2S>
+hipError_t launch_stp(const sdk::StArgs &a, hipStream_t st)
 {
-  if (a.nwin <= 0 || a.nchan <= 0) return hipSuccess;
-  if (!a.hk_uniform || a.run < 2) return hipErrorInvalidValue;
+  constexpr int NG = WAVE >> LOG2S;
   const unsigned nruns = (unsigned)((a.nwin + a.run - 1) / a.run);
-  const unsigned ny = (unsigned)((a.nchan + WAVE - 1) / WAVE);
+  const unsigned ny = (unsigned)((a.nchan + NG * WAVE - 1) / (NG * WAVE));
   // at most three workgroups per CU anyway (768 of the 1024 window slots): each can have 50 KB of LDS
   static const bool no_sep = [] { const char *e = getenv("SUAMD_ST_PAIR_SEP"); return e && e[0] == '0'; }();
   const bool sep = (unsigned long long)nruns * ny <= 768 && !no_sep;
   auto go = [&](auto kern, int lds) {
     sdk::launch_timed("stp_kernel", kern, dim3(nruns, ny), dim3(2 * WAVE), (size_t)lds, st, a);
   };
-  if (sep) { if (a.y32) go(stp_kernel<true, true>, PW_LDS_SEP); else go(stp_kernel<false, true>, PW_LDS_SEP); }
-  else { if (a.y32) go(stp_kernel<true, false>, PW_LDS); else go(stp_kernel<false, false>, PW_LDS); }
+  if (sep) { if (a.y32) go(stp_kernel<LOG2S, true, true>, PW_LDS_SEP); else go(stp_kernel<LOG2S, false, true>, PW_LDS_SEP); }
+  else { if (a.y32) go(stp_kernel<LOG2S, true, false>, PW_LDS); else go(stp_kernel<LOG2S, false, false>, PW_LDS); }
   return hipGetLastError();
+}
+
+}  // namespace
+
+namespace sdk {
+
+// channels of 8 .. 64 bins, one response for the whole launch, runs of at least two windows
+hipError_t specttuner_feed_pair(int log2s, const StArgs &a, hipStream_t st)
+{
+  if (a.nwin <= 0 || a.nchan <= 0) return hipSuccess;
+  if (!a.hk_uniform || a.run < 2) return hipErrorInvalidValue;
+  switch (log2s) {
+    case 3: return launch_stp<3>(a, st);
+    case 4: return launch_stp<4>(a, st);
+    case 5: return launch_stp<5>(a, st);
+    case 6: return launch_stp<6>(a, st);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 }  // namespace sdk

@@ -377,7 +377,7 @@ def test_two_wavefronts_per_window_equal_one_bit_for_bit(ctx, monkeypatch):
             st2.close()
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(10))
 def test_random_banks_and_splits_two_wavefront_kernel_against_one(ctx, monkeypatch, seed):
     """Seeded fuzz of the kernel choice: random channel counts (partial last workgroup, several workgroups), run lengths,
     feed boundaries and residual NCOs -- the two-wavefront kernel and the one-wavefront kernel must agree on every bit,
@@ -386,7 +386,9 @@ def test_random_banks_and_splits_two_wavefront_kernel_against_one(ctx, monkeypat
     nch = int(r.integers(1, 150))
     nwin = int(r.integers(20, 120))
     x = cnoise(H * nwin, 500 + seed)
-    chans = [(float(r.uniform(0, 2 * np.pi)), 2 * np.pi / 64 * 0.75, 1.0, bool(r.integers(0, 4) == 0)) for _ in range(nch)]
+    dec = int(r.choice([64, 128, 256, 512]))                     # channels of 64 / 32 / 16 / 8 bins
+    nch = nch * (dec // 64)                                      # a lane serves dec / 64 channels: fill a few workgroups at every size
+    chans = [(float(r.uniform(0, 2 * np.pi)), 2 * np.pi / dec * 0.75, 1.0, bool(r.integers(0, 4) == 0)) for _ in range(nch)]
     cuts = sorted(set(int(c) * H for c in r.integers(1, nwin, size=int(r.integers(0, 4)))))
     monkeypatch.setenv("SUAMD_ST_KERNEL", "wave")
     ref = run_gpu(ctx, x, chans, splits=cuts, run=int(r.integers(1, 6)))
@@ -395,4 +397,4 @@ def test_random_banks_and_splits_two_wavefront_kernel_against_one(ctx, monkeypat
         run = int(r.integers(2, 9))
         got = run_gpu(ctx, x, chans, splits=cuts, run=run, time_major=bool(r.integers(0, 2)))
         for a, b in zip(ref, got):
-            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (seed, nch, nwin, cuts, run)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (seed, dec, nch, nwin, cuts, run)
