@@ -100,6 +100,7 @@ struct StArgs {
   unsigned long long *tstamp;   // STW_TSTAMP builds only: [run][window of the run][16] s_memtime stamps
   int y32;                      // wavefront kernel: every byte offset (row * cs + time * ms) * 8 of this feed's outputs is below 2^31
   int hk_uniform;               // every channel of the launch has hsel == chans[0].hsel (wavefront kernel: response kept in LDS)
+  int nsel;                     // response tables in hk (distinct pass-band widths of the launch's channels)
   int seam_polls;               // wavefront kernel: polls (~0.25 us each) a run waits for its successor's payload before it transforms the seam window itself
   unsigned epoch;               // wavefront kernel: the flag value of this launch (a host counter per size group, never 0)
   void *handoff; unsigned *flags;   // wavefront kernel: [runs * blocks][16 KiB] seam payload, one flag per run (holds the epoch of the launch that published it)
@@ -116,7 +117,9 @@ hipError_t specttuner_feed(int log2w, int log2s, const StArgs &a, hipStream_t st
 // specttuner_wave.hip: one wavefront per window, sizes 8..64 (W = 4096); channels one wavefront serves
 int stw_channels_per_wave(int log2s);
 hipError_t specttuner_feed_wave(int log2s, const StArgs &a, hipStream_t st);
-// specttuner_pair.hip: two wavefronts per window; channels of 8 .. 64 bins, a.hk_uniform, a.run >= 2 (same results bit for bit)
+// specttuner_pair.hip: two wavefronts per window; channels of 8 .. 64 bins, a.nsel <= stp_max_responses() (the tables live
+// in LDS), a.run >= 2 (same results bit for bit)
+int stp_max_responses();
 hipError_t specttuner_feed_pair(int log2s, const StArgs &a, hipStream_t st);
 
 // ---- chandet.hip: su_channel_detector (SPEC.md section O) ----

@@ -147,6 +147,7 @@ struct SizeGroup {
   size_t ho_slots = 0;
   unsigned epoch = 0;                  // flag value of the next launch
   bool hk_uniform = false;             // one response for all members
+  int nsel = 0;                        // distinct responses of the members (tables in d_hk)
   float *d_win = nullptr;
   c32 *d_prev[2] = {nullptr, nullptr};
   int prev_cur = 0;
@@ -297,6 +298,7 @@ bool rebuild_group(suamd_specttuner *st, SizeGroup &g, const std::vector<int> &o
   std::vector<c32> hk;
   for (unsigned hw : halfws) { std::vector<c32> h = design_response(st->W, S, hw); hk.insert(hk.end(), h.begin(), h.end()); }
   g.hk_uniform = halfws.size() == 1;
+  g.nsel = (int)halfws.size();
   if (g.d_chans) (void)hipFree(g.d_chans);
   if (g.d_hk) (void)hipFree(g.d_hk);
   if (g.d_hkt) (void)hipFree(g.d_hkt);
@@ -522,6 +524,7 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
         // 4 Mi-sample block.
         a.hkt = g.d_hkt;
         a.hk_uniform = g.hk_uniform ? 1 : 0;
+        a.nsel = g.nsel;
         {
           // 32-bit buffer addressing of the outputs when the whole view of this feed lies below 2 GiB
           const long long hs = (1ll << g.log2s) / 2;
@@ -565,7 +568,7 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
 #endif
         // (16-bin channels stay on the one-wavefront kernel: the two-wavefront one spills registers at that size and measured
         // 33 against 29 us; 8, 32 and 64 bins measured 26 / 29 / 29 against 30 / 30 / 32 us per 4 Mi-sample block)
-        const bool pair = st->use_pair && a.hk_uniform && a.run >= 2 && g.log2s != 4;
+        const bool pair = st->use_pair && a.nsel >= 1 && a.nsel <= sdk::stp_max_responses() && a.run >= 2 && g.log2s != 4;
         e = pair ? sdk::specttuner_feed_pair(g.log2s, a, s) : sdk::specttuner_feed_wave(g.log2s, a, s);
 #ifdef STW_TSTAMP
         if (std::getenv("SUAMD_STW_TSTAMP")) {

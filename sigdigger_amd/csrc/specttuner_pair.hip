@@ -43,11 +43,11 @@ constexpr int WAVE = 64;
 constexpr int PW_W = 4096, PW_H = 2048, PW_S = 64, PW_HS = 32;
 constexpr int PW_PITCH = 65;                                   // transposition pitch (elements)
 constexpr int PW_REP = 32;                                     // spectrum bins repeated after the end
-constexpr int PW_HK = WAVE * PW_PITCH;                         // the response: 64 elements behind the transposition buffer
-constexpr int PW_FLAG = PW_HK + 64;                            // one word the wavefronts of a pair share (seam decision)
-constexpr int PW_TOTAL = PW_FLAG + 2;                          // elements
-constexpr int PW_LDS = PW_TOTAL * 8;
-constexpr int PW_LDS_SEP = (PW_TOTAL + 2 * 1024) * 8;          // with a separate swap area
+constexpr int PW_FLAG = WAVE * PW_PITCH;                       // one word the wavefronts of a pair share (seam decision), behind the transposition buffer
+constexpr int PW_TAB = PW_FLAG + 2;                            // the launch's response tables: nsel x (S + 2) elements (the pad
+                                                               // shifts each table by four banks: lanes with different responses
+                                                               // reading the same bin do not meet in a bank)
+constexpr int PW_MAXSEL = 12;                                  // 64-bin tables that still leave four workgroups per CU (39 KB: the LDS is handed out in blocks)
 constexpr int PW_EX = 1024;                                    // elements of one direction of a mid-DFT swap (16 x 64)
 constexpr int AUX_NT = 2;
 constexpr int AUX_SC1 = 16;
@@ -138,7 +138,9 @@ __device__ __forceinline__ void dft64_pair(const cf *in, cf *out, cf *ex, int t,
 template <int P, int LOG2S, bool Y32, bool SEP>
 __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const int t)
 {
-  cf *const exf = SEP ? buf + PW_TOTAL : buf;                  // swap area of the two forward DFTs
+  constexpr int TP = (1 << LOG2S) + 2;                         // pitch of a response table
+  cf *const tab = buf + PW_TAB;
+  cf *const exf = SEP ? tab + a.nsel * TP : buf;               // swap area of the two forward DFTs
   constexpr int W = PW_W, H = PW_H;
   constexpr int S = 1 << LOG2S, HS = S / 2, NG = WAVE / S, NGW = LOG2S == 6 ? 1 : NG / 2, WS = 64 / S;
   static_assert(LOG2S >= 3 && LOG2S <= 6, "channel size out of range for the two-wavefront kernel");
@@ -264,7 +266,11 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
     }
   };
 
-  if (P == 0 && t < S) buf[PW_HK + t] = reinterpret_cast<const cf *>(a.hk)[t];        // the launch's one response
+  // the launch's responses (one per distinct pass-band width: a.nsel <= PW_MAXSEL), each lane's table by its channel's selector
+  for (int e = P * WAVE + t; e < a.nsel * S; e += 2 * WAVE) tab[(e / S) * TP + (e % S)] = reinterpret_cast<const cf *>(a.hk)[e];
+  const cf *htab[NGW];
+#pragma unroll
+  for (int gl = 0; gl < NGW; ++gl) htab[gl] = tab + cdp[gl]->hsel * TP;
   bool publish = false;
   for (long long w = w_begin; w < w_stop; ++w) {
     cf v[32], A[32];
@@ -404,13 +410,13 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
         X2[j] = *reinterpret_cast<const float4 *>(buf + (i < HS ? c0 + i : c1 + (i - HS)));
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Hq[0][j] = *reinterpret_cast<const float4 *>(buf + PW_HK + pair_index(j));
+      for (int j = 0; j < 4; ++j) Hq[0][j] = *reinterpret_cast<const float4 *>(htab[0] + pair_index(j));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (c + 1 < 4) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) Hq[(c + 1) & 1][j] = *reinterpret_cast<const float4 *>(buf + PW_HK + pair_index(4 * (c + 1) + j));
+          for (int j = 0; j < 4; ++j) Hq[(c + 1) & 1][j] = *reinterpret_cast<const float4 *>(htab[0] + pair_index(4 * (c + 1) + j));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -452,13 +458,13 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
 #pragma unroll
           for (int i = 0; i < S; i += 2) X2[i / 2] = *reinterpret_cast<const float4 *>(buf + (i < HS ? c0 + i : c1 + (i - HS)));
 #pragma unroll
-          for (int j = 0; j < CH; ++j) Hq[0][j] = *reinterpret_cast<const float4 *>(buf + PW_HK + 2 * j);
+          for (int j = 0; j < CH; ++j) Hq[0][j] = *reinterpret_cast<const float4 *>(htab[gl] + 2 * j);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
             if (c + 1 < NCH) {
 #pragma unroll
-              for (int j = 0; j < CH; ++j) Hq[(c + 1) & 1][j] = *reinterpret_cast<const float4 *>(buf + PW_HK + 2 * ((c + 1) * CH + j));
+              for (int j = 0; j < CH; ++j) Hq[(c + 1) & 1][j] = *reinterpret_cast<const float4 *>(htab[gl] + 2 * ((c + 1) * CH + j));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -535,14 +541,18 @@ hipError_t launch_stp(const sdk::StArgs &a, hipStream_t st)
   constexpr int NG = WAVE >> LOG2S;
   const unsigned nruns = (unsigned)((a.nwin + a.run - 1) / a.run);
   const unsigned ny = (unsigned)((a.nchan + NG * WAVE - 1) / (NG * WAVE));
-  // at most three workgroups per CU anyway (768 of the 1024 window slots): each can have 50 KB of LDS
+  // LDS: transposition / spectrum buffer, flag word, response tables -- and, when the launch has at most three
+  // workgroups per CU anyway (768 of the 1024 window slots) and a third of the LDS holds it, the forward swaps' own 16 KiB
   static const bool no_sep = [] { const char *e = getenv("SUAMD_ST_PAIR_SEP"); return e && e[0] == '0'; }();
-  const bool sep = (unsigned long long)nruns * ny <= 768 && !no_sep;
-  auto go = [&](auto kern, int lds) {
+  const int base = PW_TAB + a.nsel * ((1 << LOG2S) + 2);
+  // (52 KB, not 160 / 3 = 53.3: the LDS is handed out in blocks, and a workgroup of 53.2 KB measured TWO per CU)
+  const bool sep = (unsigned long long)nruns * ny <= 768 && !no_sep && (base + 2 * PW_EX) * 8 <= 52 * 1024;
+  const int lds = (base + (sep ? 2 * PW_EX : 0)) * 8;
+  auto go = [&](auto kern) {
     sdk::launch_timed("stp_kernel", kern, dim3(nruns, ny), dim3(2 * WAVE), (size_t)lds, st, a);
   };
-  if (sep) { if (a.y32) go(stp_kernel<LOG2S, true, true>, PW_LDS_SEP); else go(stp_kernel<LOG2S, false, true>, PW_LDS_SEP); }
-  else { if (a.y32) go(stp_kernel<LOG2S, true, false>, PW_LDS); else go(stp_kernel<LOG2S, false, false>, PW_LDS); }
+  if (sep) { if (a.y32) go(stp_kernel<LOG2S, true, true>); else go(stp_kernel<LOG2S, false, true>); }
+  else { if (a.y32) go(stp_kernel<LOG2S, true, false>); else go(stp_kernel<LOG2S, false, false>); }
   return hipGetLastError();
 }
 
@@ -550,11 +560,13 @@ hipError_t launch_stp(const sdk::StArgs &a, hipStream_t st)
 
 namespace sdk {
 
-// channels of 8 .. 64 bins, one response for the whole launch, runs of at least two windows
+int stp_max_responses() { return PW_MAXSEL; }
+
+// channels of 8 .. 64 bins, at most stp_max_responses() distinct responses in the launch, runs of at least two windows
 hipError_t specttuner_feed_pair(int log2s, const StArgs &a, hipStream_t st)
 {
   if (a.nwin <= 0 || a.nchan <= 0) return hipSuccess;
-  if (!a.hk_uniform || a.run < 2) return hipErrorInvalidValue;
+  if (a.nsel < 1 || a.nsel > PW_MAXSEL || a.run < 2) return hipErrorInvalidValue;
   switch (log2s) {
     case 3: return launch_stp<3>(a, st);
     case 4: return launch_stp<4>(a, st);

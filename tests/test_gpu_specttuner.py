@@ -377,7 +377,7 @@ def test_two_wavefronts_per_window_equal_one_bit_for_bit(ctx, monkeypatch):
             st2.close()
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(16))
 def test_random_banks_and_splits_two_wavefront_kernel_against_one(ctx, monkeypatch, seed):
     """Seeded fuzz of the kernel choice: random channel counts (partial last workgroup, several workgroups), run lengths,
     feed boundaries and residual NCOs -- the two-wavefront kernel and the one-wavefront kernel must agree on every bit,
@@ -388,7 +388,10 @@ def test_random_banks_and_splits_two_wavefront_kernel_against_one(ctx, monkeypat
     x = cnoise(H * nwin, 500 + seed)
     dec = int(r.choice([64, 128, 256, 512]))                     # channels of 64 / 32 / 16 / 8 bins
     nch = nch * (dec // 64)                                      # a lane serves dec / 64 channels: fill a few workgroups at every size
-    chans = [(float(r.uniform(0, 2 * np.pi)), 2 * np.pi / dec * 0.75, 1.0, bool(r.integers(0, 4) == 0)) for _ in range(nch)]
+    # pass-band widths: one for the whole bank, a handful (their response tables live in LDS), or one per channel (more
+    # tables than the two-wavefront kernel holds: the bank falls back to the one-wavefront kernel)
+    widths = [[0.75], [0.75, 0.6, 0.5, 0.9, 0.4], list(np.linspace(0.3, 0.95, 40))][int(r.integers(0, 3))]
+    chans = [(float(r.uniform(0, 2 * np.pi)), 2 * np.pi / dec * float(r.choice(widths)), 1.0, bool(r.integers(0, 4) == 0)) for _ in range(nch)]
     cuts = sorted(set(int(c) * H for c in r.integers(1, nwin, size=int(r.integers(0, 4)))))
     monkeypatch.setenv("SUAMD_ST_KERNEL", "wave")
     ref = run_gpu(ctx, x, chans, splits=cuts, run=int(r.integers(1, 6)))
