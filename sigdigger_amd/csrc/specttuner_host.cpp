@@ -566,9 +566,9 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
         (void)hipMemsetAsync(d_ts, 0, nts * sizeof(unsigned long long), s);
         a.tstamp = d_ts;
 #endif
-        // (16-bin channels stay on the one-wavefront kernel: the two-wavefront one spills registers at that size and measured
-        // 33 against 29 us; 8, 32 and 64 bins measured 26 / 29 / 29 against 30 / 30 / 32 us per 4 Mi-sample block)
-        const bool pair = st->use_pair && a.nsel >= 1 && a.nsel <= sdk::stp_max_responses() && a.run >= 2 && g.log2s != 4;
+        // (with 64-bit output addressing -- row pointers, views beyond 2 GiB -- the 8- and 16-bin instantiations of the
+        // two-wavefront kernel spill registers and measured 36-37 against 35 us per 4 Mi-sample block: those stay)
+        const bool pair = st->use_pair && a.nsel >= 1 && a.nsel <= sdk::stp_max_responses() && a.run >= 2 && (a.y32 || g.log2s >= 5);
         e = pair ? sdk::specttuner_feed_pair(g.log2s, a, s) : sdk::specttuner_feed_wave(g.log2s, a, s);
 #ifdef STW_TSTAMP
         if (std::getenv("SUAMD_STW_TSTAMP")) {

@@ -453,7 +453,7 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
           const int c0 = center[gl], c1 = (center[gl] - HS) & (W - 1);
           cf u[S], F[S];
           // all the bin pairs first, then the response in chunks of four pairs, each requested one chunk ahead of its products
-          constexpr int CH = S / 2 < 4 ? S / 2 : 4, NCH = (S / 2) / CH;
+          constexpr int CH = LOG2S == 4 ? 2 : (S / 2 < 4 ? S / 2 : 4), NCH = (S / 2) / CH;   // (16 bins: two pairs at a time -- that instantiation has no register to spare)
           float4 X2[S / 2], Hq[2][CH];
 #pragma unroll
           for (int i = 0; i < S; i += 2) X2[i / 2] = *reinterpret_cast<const float4 *>(buf + (i < HS ? c0 + i : c1 + (i - HS)));
