@@ -480,7 +480,10 @@ template <int NCH, int NOUT, int TC, bool LDS_TAPS, bool DB>
 hipError_t launch_fir(const sdk::ChanFeedArgs &a, const FirGeom &ge, size_t lds, unsigned ntiles, hipStream_t st)
 {
   auto kern = chan_fir_kernel<NCH, NOUT, TC, LDS_TAPS, DB>;
-  static size_t attr_lds = 0;
+  static size_t attr_lds_dev[64] = {};                       // a function attribute belongs to a device (sharded analyzer: one per GPU)
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  size_t &attr_lds = attr_lds_dev[dev_ & 63];
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -620,7 +623,10 @@ hipError_t chan_gang_plan(const ChanFeedArgs &a, ChanGangItem *item)
 hipError_t chan_gang_feed(const ChanGangItem *d_items, int n, unsigned max_tiles, unsigned max_lds, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
-  static size_t attr_lds = 0;
+  static size_t attr_lds_dev[64] = {};                       // a function attribute belongs to a device
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  size_t &attr_lds = attr_lds_dev[dev_ & 63];
   if (max_lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chan_fir_gang_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
