@@ -87,11 +87,16 @@ def test_raw_inspectors_share_one_forward_fft_and_match_the_oracle(tmp_path, sdo
     for k, (fc, bw) in enumerate(chans):
         ch = suscan.Channel(fc=fc, f_lo=fc - bw / 2, f_hi=fc + bw / 2, bw=bw, ft=433.92e6)
         assert Lb.suscan_analyzer_open_ex_async(an, b"raw", C.byref(ch), int(k % 2 == 0), -1, 100 + k)
-    st = {"psd": 0, "open_at": {}, "id": {}, "samples": {}, "efs": {}, "handles": {}}
+    st = {"psd": 0, "open_at": {}, "id": {}, "samples": {}, "efs": {}, "handles": {}, "status": []}
 
     def on_msg(t, ptr):
         if t == suscan.MSG_PSD:
             st["psd"] += 1
+        elif t in (suscan.MSG_INTERNAL, suscan.MSG_READ_ERROR, suscan.MSG_SOURCE_INIT) and ptr:
+            # what the shards say about themselves (a GPU that could not be initialised, RCCL falling back to copies ...):
+            # shown with every assertion below, so that a failure on a box this was never run on explains itself
+            m = C.cast(ptr, C.POINTER(suscan.StatusMsg)).contents
+            st["status"].append((t, m.code, (m.err_msg or b"").decode("utf-8", "replace")))
         elif t == suscan.MSG_INSPECTOR:
             m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
             if m.kind == suscan.KIND_OPEN:
@@ -108,13 +113,13 @@ def test_raw_inspectors_share_one_forward_fft_and_match_the_oracle(tmp_path, sdo
     _pump(Lb, an, on_msg)
     Lb.suscan_analyzer_destroy(an)
     Lb.suscan_mq_finalize(C.byref(mq))
-    assert len(st["open_at"]) == len(chans) and st["psd"] == nblocks            # one PSD stream whatever the shard count
+    assert len(st["open_at"]) == len(chans) and st["psd"] == nblocks, (st["open_at"], st["psd"], st["status"])   # one PSD stream whatever the shard count
     if standin is not None:
         # every block went out as ONE broadcast of the block's bytes, rooted at shard 0
         assert standin.standin_broadcasts() == nblocks and standin.standin_bytes() == nblocks * L * 8
     G = len(devices.split(",")) if devices else 1
-    assert len(set(st["handles"].values())) == len(chans)
-    assert sorted(h % G for h in st["handles"].values()) == sorted(k % G for k in range(len(chans)))   # dealt round the shards
+    assert len(set(st["handles"].values())) == len(chans), st["status"]
+    assert sorted(h % G for h in st["handles"].values()) == sorted(k % G for k in range(len(chans))), st["status"]   # dealt round the shards
     if G == 1:
         b0 = st["open_at"][0]
         assert all(b == b0 for b in st["open_at"].values()), "the five requests were posted together"
