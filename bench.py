@@ -476,7 +476,8 @@ def main():
                          "channels); fir: translate + 255-tap direct-form low-pass + decimate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (c2, c3, c5)")
-    ap.add_argument("--cpu-samples", type=int, default=1 << 23)
+    # 64 Mi samples: ~5 s of one core + ~0.6 s of all of them on the box's EPYC (the bounded sample of the CPU leg)
+    ap.add_argument("--cpu-samples", type=int, default=1 << 26)
     ap.add_argument("--live", action="store_true",
                     help="time the sharded live analyzer instead (one process, SUAMD_DEVICES=0..N-1; run WITHOUT torchrun): "
                          "the drop-in boundary itself on N GPUs")
