@@ -468,7 +468,7 @@ SUBOOL suamd_specttuner_set_run(suamd_specttuner_t *st, unsigned run)
 }
 
 static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_y, suamd_view view,
-                      suamd_complex *const *d_rows, SUSCOUNT *counts, void *stream);
+                      suamd_complex *const *d_rows, SUSCOUNT *counts, void *stream, size_t rows_span = 0);
 
 SUBOOL suamd_specttuner_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_y, suamd_view view,
                              SUSCOUNT *counts, void *stream)
@@ -483,8 +483,18 @@ SUBOOL suamd_specttuner_feed_rows(suamd_specttuner_t *st, const suamd_complex *d
   return st_feed(st, d_x, len, nullptr, suamd_view{0, 1}, d_rows, counts, stream);
 }
 
+SUBOOL suamd_specttuner_feed_rows_near(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *const *d_rows,
+                                       const void *d_base, size_t span_bytes, SUSCOUNT *counts, void *stream)
+{
+  if (!d_rows) { suamd_set_error("null row table"); return SU_FALSE; }
+  if (!d_base || span_bytes == 0 || span_bytes >= ((size_t)1 << 31))
+    return st_feed(st, d_x, len, nullptr, suamd_view{0, 1}, d_rows, counts, stream);          // no usable promise: 64-bit addressing
+  // (d_y carries the base: with a row table the kernels take row starts from it and, rows_span set, offsets from d_y)
+  return st_feed(st, d_x, len, static_cast<suamd_complex *>(const_cast<void *>(d_base)), suamd_view{0, 1}, d_rows, counts, stream, span_bytes);
+}
+
 static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_y, suamd_view view,
-                      suamd_complex *const *d_rows, SUSCOUNT *counts, void *stream)
+                      suamd_complex *const *d_rows, SUSCOUNT *counts, void *stream, size_t rows_span)
 {
   if (!st || (len && !d_x)) { suamd_set_error("null argument"); return SU_FALSE; }
   if (len % st->H) { suamd_set_error("len must be a multiple of half a window (%u)", st->H); return SU_FALSE; }
@@ -531,6 +541,8 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
           const long long last = ((long long)st->ch.size() * (long long)view.chan_stride + (nwin * hs + hs) * (long long)view.time_stride) * 8;
           static const bool no_y32 = [] { const char *e = std::getenv("SUAMD_ST_Y32"); return e && e[0] == '0'; }();   // debug: 64-bit addressing everywhere
           a.y32 = (!d_rows && last < (1ll << 31) && !no_y32) ? 1 : 0;
+          // rows promised to start within rows_span bytes of d_y: offsets from there, if the feed's own extent fits too
+          if (d_rows && rows_span && !no_y32 && (long long)rows_span + (nwin * hs + hs) * 8 < (1ll << 31)) a.y32 = 1;
         }
         if (st->run_wave) a.run = (int)st->run_wave;
         else {

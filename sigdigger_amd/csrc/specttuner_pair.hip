@@ -239,7 +239,9 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
     center[gl] = cdp[gl]->center;
     const int row = cdp[gl]->row;
     ybase[gl] = a.rows ? static_cast<cf *>(const_cast<void *>(a.rows[row])) : reinterpret_cast<cf *>(a.y) + (long long)row * a.yv.cs;
-    yvoff[gl] = kk < a.nchan ? (unsigned)((long long)row * a.yv.cs * 8) : 0x80000000u;
+    // (Y32 with a row table: the caller has promised every row within 2 GiB of a.y -- offsets from there)
+    yvoff[gl] = kk >= a.nchan ? 0x80000000u : a.rows ? (unsigned)(reinterpret_cast<const char *>(a.rows[row]) - reinterpret_cast<const char *>(a.y))
+                                                      : (unsigned)((long long)row * a.yv.cs * 8);
     any_precise |= __builtin_amdgcn_ballot_w64(cdp[gl]->precise != 0) != 0;
   }
   const long long yms = a.rows ? 1 : a.yv.ms;

@@ -190,7 +190,9 @@ __global__ __launch_bounds__(WAVE * STW_WPB, 1) void stw_kernel(sdk::StArgs a)
     dphase[g] = cd.dphase;
     phase0[g] = (uint32_t)(a.n0 - cd.n_open);
     ybase[g] = a.rows ? static_cast<cf *>(const_cast<void *>(a.rows[cd.row])) : reinterpret_cast<cf *>(a.y) + (long long)cd.row * a.yv.cs;
-    yvoff[g] = k < a.nchan ? (unsigned)((long long)cd.row * a.yv.cs * 8) : 0x80000000u;
+    // (Y32 with a row table: the caller has promised every row within 2 GiB of a.y -- offsets from there)
+    yvoff[g] = k >= a.nchan ? 0x80000000u : a.rows ? (unsigned)(reinterpret_cast<const char *>(a.rows[cd.row]) - reinterpret_cast<const char *>(a.y))
+                                                   : (unsigned)((long long)cd.row * a.yv.cs * 8);
   }
   const long long yms = a.rows ? 1 : a.yv.ms;
   const unsigned yms8 = (unsigned)(yms * 8);

@@ -485,6 +485,24 @@ class SpectTuner:
               "suamd_specttuner_feed")
         return out, [int(v) for v in counts]
 
+    def feed_rows(self, x, rows, near=False, stream=None):
+        """The same with one row tensor per channel index (suamd_specttuner_feed_rows): rows[c] receives channel c's
+        samples.  near=True: suamd_specttuner_feed_rows_near -- the caller vouches that the rows start within 2 GiB of the
+        lowest one (rows carved from one arena): 32-bit output addressing.  Returns counts."""
+        _chk_c64(x, "x")
+        ptrs = [0 if r is None else int(r.data_ptr()) for r in rows]
+        table = torch.tensor(ptrs, dtype=torch.int64, device=x.device)
+        counts = (C.c_uint64 * max(self.capacity(), 1))()
+        if near:
+            live = [p for p in ptrs if p]
+            check(self.ctx.lib.suamd_specttuner_feed_rows_near(self.h, _ptr(x), x.numel(), table.data_ptr(), min(live), max(live) - min(live) + 8,
+                                                               counts, _stream(stream)), "suamd_specttuner_feed_rows_near")
+        else:
+            check(self.ctx.lib.suamd_specttuner_feed_rows(self.h, _ptr(x), x.numel(), table.data_ptr(), counts, _stream(stream)),
+                  "suamd_specttuner_feed_rows")
+        torch.cuda.current_stream(x.device).synchronize() if stream is None else None     # the table must outlive the launch
+        return [int(v) for v in counts]
+
 
 class _LoopBank:
     _destroy = None

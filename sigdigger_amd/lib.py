@@ -72,6 +72,7 @@ PROTOTYPES = {
     "suamd_specttuner_channel_decimation": (UINT, [VP, INT]),
     "suamd_specttuner_feed": (INT, [VP, VP, U64, VP, View, C.POINTER(U64), VP]),
     "suamd_specttuner_feed_rows": (INT, [VP, VP, U64, VP, C.POINTER(U64), VP]),
+    "suamd_specttuner_feed_rows_near": (INT, [VP, VP, U64, VP, VP, C.c_size_t, C.POINTER(U64), VP]),
     "suamd_specttuner_set_run": (INT, [VP, UINT]),
     "suamd_specttuner_set_slots": (INT, [VP, UINT]),
     "suamd_specttuner_channel_capacity": (UINT, [VP]),

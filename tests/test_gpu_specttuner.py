@@ -401,3 +401,43 @@ def test_random_banks_and_splits_two_wavefront_kernel_against_one(ctx, monkeypat
         got = run_gpu(ctx, x, chans, splits=cuts, run=run, time_major=bool(r.integers(0, 2)))
         for a, b in zip(ref, got):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (seed, dec, nch, nwin, cuts, run)
+
+
+@pytest.mark.parametrize("dec", [64, 128, 256, 512])
+def test_row_tables_with_32_bit_offsets_give_the_same_samples(ctx, dec):
+    """suamd_specttuner_feed_rows_near: one row per channel, all of one arena -- the kernels address them with 32-bit offsets
+    from the lowest row (and every narrow size runs on the two-wavefront kernel).  Same samples as the view and as the
+    plain row table, bit for bit; rows in scrambled order, a hole in the channel table (a closed channel), two feeds."""
+    x = cnoise(H * 64, 900 + dec)
+    dx = torch.from_numpy(x).cuda()
+    nch = 70 * (dec // 64) + 3
+    chans = [(0.1 + 6.0 * c / nch, 2 * np.pi / dec * (0.75 if c % 3 else 0.6), 1.0, bool(c % 7 == 0)) for c in range(nch)]
+    cap = x.size // dec + 64
+    outs = {}
+    for mode in ("view", "rows", "near"):
+        st = engine.SpectTuner(ctx, W)
+        st.set_run(3)
+        ids = [st.open_channel(*c) for c in chans]
+        st.close_channel(ids[5])
+        arena = torch.zeros((nch, cap), dtype=torch.complex64, device="cuda")
+        order = np.random.default_rng(3).permutation(nch)                    # channel c's row is arena[order[c]]
+        got = [[] for _ in ids]
+        for lo, hi in ((0, H * 24), (H * 24, x.size)):
+            if mode == "view":
+                out, counts = st.feed(dx[lo:hi])
+                rows = [out[c] for c in ids]
+            else:
+                rows = [arena[order[c]] for c in ids]
+                counts = st.feed_rows(dx[lo:hi], [None if c == ids[5] else rows[c] for c in ids], near=(mode == "near"))
+            torch.cuda.synchronize()
+            for c in ids:
+                if c != ids[5]:
+                    got[c].append(rows[c][:counts[c]].cpu().numpy())
+        outs[mode] = [np.concatenate(g) if g else None for g in got]
+        st.close()
+    for c in range(nch):
+        if c == 5:
+            continue
+        assert outs["view"][c].size == x.size // dec - (W // dec) // 2, c
+        assert np.array_equal(outs["view"][c].view(np.uint32), outs["rows"][c].view(np.uint32)), (dec, c)
+        assert np.array_equal(outs["view"][c].view(np.uint32), outs["near"][c].view(np.uint32)), (dec, c)
