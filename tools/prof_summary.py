@@ -61,7 +61,7 @@ with open(os.path.join(prof, f"{tag}_kernel_stats_summary.md"), "w") as f:
     if stats_all:
         f.write("\n## with the secondary workloads (C2, C3, C5 and the live analyzer with 64 inspectors after the default one)\n\n"
                 "Same command without `--no-extra`; kernels shared by several workloads aggregate all of them "
-                "(psd_kernel<13, 256, true> is C5's 8.6 GB launch, stw_kernel<6, true, true> includes the bench's 16 Mi-block launches, the recurrence kernels C2's 16x longer rows).\n\n")
+                "(psd_kernel<13, 256, true> is C5's 8.6 GB launch, stp_kernel<6, true, .> includes the bench's 16 Mi-block launches, the recurrence kernels C2's 16x longer rows).\n\n")
         table(list(csv.DictReader(open(stats_all[0]))))
 
 # PMC traffic: per kernel, average FETCH_SIZE / WRITE_SIZE (KiB) over launches
