@@ -907,11 +907,12 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
       // one count per slot of the tuner's channel table: it never shrinks, so after a close (or a retune, which closes
       // and reopens) it can be longer than the highest live channel
       std::vector<SUSCOUNT> counts(std::max(nrows, (size_t)suamd_specttuner_channel_capacity(a->st)), 0);
-      // the inspectors' rows are separate allocations, but of one arena in practice: when they all start within 1 GiB the
+      // the inspectors' rows are separate allocations, but of one arena in practice: when they all start within ~1.75 GiB the
       // narrow-channel kernels address them with 32-bit offsets from the lowest (suamd_specttuner_feed_rows_near)
       uintptr_t lo = ~(uintptr_t)0, hi = 0;
       for (Inspector *pi : live) { const uintptr_t p = reinterpret_cast<uintptr_t>(pi->d_y); lo = std::min(lo, p); hi = std::max(hi, p); }
-      const bool near = !live.empty() && hi - lo < ((uintptr_t)1 << 30);
+      const bool near = !live.empty() && hi - lo < ((uintptr_t)1 << 31) - ((uintptr_t)1 << 28);   // the library checks the feed's own extent on top
+      if (std::getenv("SUAMD_ANALYZER_DEBUG")) { static int once = 0; if (!once++) std::fprintf(stderr, "[worker] inspector rows span %.1f MiB over %zu inspectors: %s\n", (double)(hi - lo) / 1048576.0, live.size(), near ? "near" : "64-bit"); }
       if (!(near ? suamd_specttuner_feed_rows_near(a->st, a->d_x, len, a->d_rowptr[slot], reinterpret_cast<const void *>(lo), (size_t)(hi - lo) + 8, counts.data(), sF)
                  : suamd_specttuner_feed_rows(a->st, a->d_x, len, a->d_rowptr[slot], counts.data(), sF))) { fail("channeliser"); return; }
       for (size_t i = 0; i < live.size(); ++i) fm[i] = counts[live[i]->st_chan];
