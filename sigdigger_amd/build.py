@@ -4,6 +4,7 @@
 
 The .so is git-ignored but travels to the GPU box with the gpurun snapshot.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -43,11 +44,32 @@ HEADERS = ["kernels.hpp", "sd_math.hpp", "design.hpp", "fft_core.hpp", "fft_reg.
            os.path.join("..", "..", "include", "suscan_amd.h")]
 
 
-def _stale(target, deps):
+def _digest(cmd, deps):
+    """sha256 over the compile command and the bytes of every input: what an object or the library was built FROM.
+    (mtimes do not survive a checkout or the gpurun snapshot; a stale object shipped beside a newer source must rebuild.)"""
+    h = hashlib.sha256()
+    h.update("\0".join(cmd).encode())
+    for d in deps:
+        h.update(b"\0" + os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(target, stamp):
+    """True unless `target` exists and its side file `<target>.sha256` holds `stamp`."""
     if not os.path.exists(target):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        with open(target + ".sha256") as f:
+            return f.read().strip() != stamp
+    except OSError:
+        return True
+
+
+def _mark(target, stamp):
+    with open(target + ".sha256", "w") as f:
+        f.write(stamp + "\n")
 
 
 def build(force=False, verbose=False):
@@ -57,20 +79,30 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC] + COMMON + flags + ["-c", s, "-o", o])
+        cmd = [HIPCC] + COMMON + flags + ["-c", s, "-o", o]
+        stamp = _digest(cmd, [s] + hdrs)
+        if force or _stale(o, stamp):
+            jobs.append((cmd, o, stamp))
 
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
 
+    def compile_one(job):
+        cmd, o, stamp = job
+        run(cmd)
+        _mark(o, stamp)
+
     if jobs:
-        with ThreadPoolExecutor(max_workers=4) as ex:
-            list(ex.map(run, jobs))
-    if force or jobs or _stale(OUT, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs +
-            ["-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-ldl"])
+        with ThreadPoolExecutor(max_workers=int(os.environ.get("SUAMD_BUILD_JOBS", "6"))) as ex:
+            list(ex.map(compile_one, jobs))
+    link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-ldl"]
+    # the library's stamp covers the objects' stamps, i.e. every source byte and flag
+    lstamp = hashlib.sha256(("\0".join(link) + "".join(open(o + ".sha256").read() for o in objs)).encode()).hexdigest()
+    if force or jobs or _stale(OUT, lstamp):
+        run(link)
+        _mark(OUT, lstamp)
     return OUT
 
 
