@@ -497,16 +497,31 @@ def main():
                           "live": d}), flush=True)
         return
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ       # under torch.distributed.run
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dist = None
     # test hook: SUAMD_BENCH_SHARE_GPU=1 puts every rank on GPU 0 with the gloo backend, so that the
     # N > 1 control flow (sharding, block broadcast, barriers, max-over-ranks) can be exercised on a
     # one-GPU box; RCCL itself refuses two ranks on one device
     share = os.environ.get("SUAMD_BENCH_SHARE_GPU") == "1"
+    if args.gpus > 1 and not launched:
+        # a bare `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU under torch.distributed.run,
+        # exactly the command the contract names) instead of timing one GPU and calling it N
+        ndev = torch.cuda.device_count()
+        if not share and ndev < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible")
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        sys.stdout.flush()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if not share and torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
+    dist = None
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -666,6 +681,7 @@ def main():
             ref = reference_loops()
             if ref is not None:
                 out["cpu_baseline"]["reference_loops"] = ref
+        assert out["n_gpus"] == args.gpus == world, (out["n_gpus"], args.gpus, world)
         print(json.dumps(out), flush=True)
 
     if dist is not None:

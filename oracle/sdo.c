@@ -1191,6 +1191,14 @@ void sdo_blackmann_harris_complex(sdo_c32 *h, size_t n)
   }
 }
 
+/* Re(x conj(x)) as the reference's `x *= conj(x)` computes it: fl(fl(a a) + fl(b b)).  volatile: no contraction whatever
+ * flags this file is built with (the -O3 -march=native build of the CPU baseline has fma instructions at hand) */
+static inline float sdo_norm2_unfused(float a, float b)
+{
+  volatile float aa = a * a, bb = b * b;
+  return aa + bb;
+}
+
 float sdo_carrier_detect(const sdo_c32 *data, size_t len, float avgRelBw, float dcNotchRelBw)
 {
   size_t alloc = 1, k;
@@ -1208,9 +1216,10 @@ float sdo_carrier_detect(const sdo_c32 *data, size_t len, float avgRelBw, float 
   int delta = (bins - 1) / 2, start;
   int skipLen = (int)(.5 * (double)dcNotchRelBw * (double)alloc);
   float maxVal = 0, psd;
-  double accr = 0, acci = 0;
+  float accr = 0, acci = 0;                              /* SUCOMPLEX acc: binary32, summed in bin order (:109, :130) */
   for (i = skipLen; i < (int)alloc - skipLen; ++i) {
-    buf[i].re = fmaf(buf[i].re, buf[i].re, buf[i].im * buf[i].im);
+    /* asSuComplex[i] *= conj(asSuComplex[i]) (:113): a complex product -- two rounded squares, one rounded sum, no fma */
+    buf[i].re = sdo_norm2_unfused(buf[i].re, buf[i].im);
     buf[i].im = 0;
     psd = buf[i].re;
     if (psd > maxVal) { maxVal = psd; maxNdx = i; }
@@ -1218,15 +1227,16 @@ float sdo_carrier_detect(const sdo_c32 *data, size_t len, float avgRelBw, float 
   start = maxNdx - delta;
   for (i = 0; i < bins; ++i) {
     int j = i + start;
+    float cs, sn;
     if (j < 0) j += (int)alloc;
     j %= (int)alloc;
     psd = buf[j].re;
     float nFreq = 2.f * (float)j / (float)alloc;
-    double ang = (double)((float)SDO_PI * nFreq);
-    accr += (double)psd * cos(ang);
-    acci += (double)psd * sin(ang);
+    sincosf((float)SDO_PI * nFreq, &sn, &cs);            /* SU_C_EXP(SU_I * pi * nFreq) = cexpf(0 + i theta) (:130) */
+    accr += psd * cs;
+    acci += psd * sn;
   }
-  float peak = (float)atan2(acci, accr);
+  float peak = atan2f(acci, accr);                       /* SU_C_ARG (:134) */
   free(buf); free(re); free(im);
   return peak;
 }
@@ -1414,34 +1424,43 @@ void sdo_doppler_calc(const sdo_c32 *data, size_t len, float fs, double f0, floa
 
   int i, maxNdx = 0, bins = (int)alloc, delta = bins / 2, start;
   float maxVal = 0, psd, peak, lambda = (float)(299792458. / f0);
-  double accr = 0, acci = 0;
+  float accr = 0, acci = 0;                              /* SUCOMPLEX acc (:112): binary32, bin order */
   float dispAcc = 0, totalEnergy = 0, err = 0, t, y;
+  /* every sum below is built in the reference's type AND order: a binary32 running sum over 2^15 .. 2^24 bins carries a
+   * rounding error of the order of sqrt(bins) ulp, so "the same number" means the same sequence of roundings */
   for (i = 0; i < bins; ++i) {
-    buf[i].re = fmaf(buf[i].re, buf[i].re, buf[i].im * buf[i].im);
+    buf[i].re = sdo_norm2_unfused(buf[i].re, buf[i].im); /* x *= conj(x) (:120) */
     buf[i].im = 0;
     psd = buf[i].re;
     if (psd > maxVal) { maxVal = psd; maxNdx = i; }
     if (spectrum) spectrum[((size_t)(bins - i) + (size_t)delta) % (size_t)bins] = psd;
-    y = psd - err;                                       /* Kahan, :131-134 */
-    t = totalEnergy + y;
-    err = (t - totalEnergy) - y;
-    totalEnergy = t;
+    {
+      volatile float vy, vt;                             /* Kahan, :131-134; volatile: must survive any optimiser */
+      vy = psd - err; y = vy;
+      vt = totalEnergy + y; t = vt;
+      err = (t - totalEnergy) - y;
+      totalEnergy = t;
+    }
   }
   start = maxNdx - delta;
+  /* (:157) the reference divides by the int product delta * delta, which overflows from 2^17 bins on (undefined; the
+   * build here yields 0 -> sigma = inf).  The restatement keeps the meaning: delta^2 as a binary32 (exact: a power of two) */
+  const float d2 = (float)delta * (float)delta;
   for (i = 0; i < bins; ++i) {
     long long j = i + start;
+    float cs, sn;
     if (j < 0) j += (long long)alloc;
     j %= (long long)alloc;
     psd = buf[j].re;
     float nFreq = 2.f * (float)j / (float)alloc;
-    double ang = (double)((float)SDO_PI * nFreq);
-    accr += (double)psd * cos(ang);
-    acci += (double)psd * sin(ang);
+    sincosf((float)SDO_PI * nFreq, &sn, &cs);
+    accr += psd * cs;
+    acci += psd * sn;
     j = i;
     if (j >= delta) j -= bins;
-    dispAcc += ((float)j * (float)j * psd / totalEnergy) / ((float)delta * (float)delta);
+    dispAcc += ((float)(j * j) * psd / totalEnergy) / d2;  /* j * j is an int64 product converted once (:157) */
   }
-  peak = (float)atan2(acci, accr);
+  peak = atan2f(acci, accr);
   if (peak > (float)SDO_PI) peak -= (float)(2 * SDO_PI);
   peak = fs * (peak / (float)SDO_PI) * .5f;
   res[0] = -lambda * peak;

@@ -307,20 +307,26 @@ static SUBOOL gang_tm(suamd_ctx *ctx, const std::vector<Item> &part, const std::
 
 // ---- kernel timer -------------------------------------------------------------------------------------------------
 namespace {
-struct TimedLaunch { const char *name; hipEvent_t e0, e1; };
+struct TimedLaunch { const char *name; hipEvent_t e0, e1; int dev; };
 std::mutex g_timing_mu;
 std::vector<TimedLaunch> g_timed;                              // pairs in flight, in launch order
-std::vector<std::pair<hipEvent_t, hipEvent_t>> g_timing_pool;  // recycled pairs
+// recycled pairs, per device: a HIP event belongs to the device that was current when it was created, and the sharded
+// analyzer launches from one worker thread per GPU (a process-wide pool handed GPU 0's events to GPU 1's launches)
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_timing_pool[64];
 std::atomic<bool> g_timing{false};
 }  // namespace
 namespace sdk {
 bool timing_on() { return g_timing.load(std::memory_order_relaxed); }
 void timing_pair(const char *name, hipEvent_t *start, hipEvent_t *stop)
 {
+  int dev = 0;
+  (void)hipGetDevice(&dev);                                    // the launching thread's device: the launch follows on it
+  dev &= 63;
   std::lock_guard<std::mutex> lk(g_timing_mu);
-  if (!g_timing_pool.empty()) { *start = g_timing_pool.back().first; *stop = g_timing_pool.back().second; g_timing_pool.pop_back(); }
+  auto &pool = g_timing_pool[dev];
+  if (!pool.empty()) { *start = pool.back().first; *stop = pool.back().second; pool.pop_back(); }
   else { (void)hipEventCreate(start); (void)hipEventCreate(stop); }
-  g_timed.push_back({name, *start, *stop});
+  g_timed.push_back({name, *start, *stop, dev});
 }
 }  // namespace sdk
 
@@ -347,7 +353,7 @@ SUBOOL suamd_kernel_timing_read(const char *kernel, double *sum_ms, double *min_
   }
   {
     std::lock_guard<std::mutex> lk(g_timing_mu);
-    for (const TimedLaunch &t : mine) g_timing_pool.push_back({t.e0, t.e1});
+    for (const TimedLaunch &t : mine) g_timing_pool[t.dev].push_back({t.e0, t.e1});
   }
   if (sum_ms) *sum_ms = sum;
   if (min_ms) *min_ms = lo;
@@ -493,7 +499,13 @@ SUBOOL suamd_psd_feed(suamd_psd_t *p, const suamd_complex *d_x, SUSCOUNT nframes
       if (const char *e = getenv("SUAMD_PSD_LARGE_BATCH")) { const long long v = atoll(e); if (v >= 1 && v < batch) batch = v; }   // tests: awkward batch boundaries
       if (batch < 1) batch = 1;
       const int ch = sdk::psd_large_chunk((int)navg), cpo = ((int)navg + ch - 1) / ch;
-      const int pring = (int)(batch / ch) + 2 * cpo + 4;        // the chunks a batch touches + an output still open
+      // ring of chunk sums: everything between the first chunk of the batch's first (possibly still open) output and the
+      // batch's last chunk is live at once.  A batch of `batch` frames touches at most (batch + navg - 2) / navg + 1 outputs of
+      // cpo = ceil(navg / ch) chunks each -- NOT batch / ch chunks: with navg no multiple of ch every output's last chunk is
+      // short (round 3 sized the ring by batch / ch and let chunks of one batch share slots: ADVICE r3)
+      const long long pring_ll = ((batch + (long long)navg - 2) / (long long)navg + 1) * cpo + 2;
+      if (pring_ll > 0x7fffffff) { set_err("navg too small for this batch"); return SU_FALSE; }
+      const int pring = (int)pring_ll;
       const size_t ab = sizeof(suamd_complex) * (size_t)p->n * (size_t)batch;
       if (!p->partial.reserve(ab + sizeof(float) * (size_t)p->n * (size_t)pring)) { set_err("scratch allocation failed"); return SU_FALSE; }
       char *base = static_cast<char *>(p->partial.p);
@@ -1715,7 +1727,7 @@ SUBOOL suamd_fac_get_range(suamd_fac_t *f, SUFLOAT *min, SUFLOAT *max, void *str
 namespace {
 struct CaptureFft {                      // scratch of one whole-capture task
   void *a = nullptr, *b = nullptr, *res = nullptr;
-  float *blk_max = nullptr; long long *blk_idx = nullptr; double *blk_sum = nullptr, *d_res = nullptr;
+  float *blk_max = nullptr; long long *blk_idx = nullptr; double *d_res = nullptr;
   long long alloc = 1; int log2n = 0;
   static constexpr int NBLK = 512;
   bool init(SUSCOUNT len)
@@ -1726,12 +1738,11 @@ struct CaptureFft {                      // scratch of one whole-capture task
     return hipMalloc(&a, bytes) == hipSuccess && hipMalloc(&b, bytes) == hipSuccess &&
            hipMalloc((void **)&blk_max, NBLK * sizeof(float)) == hipSuccess &&
            hipMalloc((void **)&blk_idx, NBLK * sizeof(long long)) == hipSuccess &&
-           hipMalloc((void **)&blk_sum, NBLK * sizeof(double)) == hipSuccess &&
            hipMalloc((void **)&d_res, 8 * sizeof(double)) == hipSuccess;
   }
   ~CaptureFft()
   {
-    for (void *p : {a, b, (void *)blk_max, (void *)blk_idx, (void *)blk_sum, (void *)d_res}) if (p) (void)hipFree(p);
+    for (void *p : {a, b, (void *)blk_max, (void *)blk_idx, (void *)d_res}) if (p) (void)hipFree(p);
   }
 };
 }  // namespace
@@ -1879,11 +1890,11 @@ SUBOOL suamd_carrier_detect(suamd_ctx_t *ctx, const suamd_complex *d_data, SUSCO
   const int delta = (bins - 1) / 2;
   const int skipLen = static_cast<int>(.5 * (double)dcNotchRelBw * (double)w.alloc);
   HIP_TRY(sdk::spectrum_centroid(w.res, w.alloc, skipLen, w.alloc - skipLen, nullptr, bins, delta, 0, w.blk_max,
-                                 w.blk_idx, w.blk_sum, CaptureFft::NBLK, w.d_res, st), SU_FALSE);
-  double res[5];
+                                 w.blk_idx, CaptureFft::NBLK, reinterpret_cast<float *>(w.d_res), st), SU_FALSE);
+  float res[5];                                                        // binary32, as the reference's SUCOMPLEX acc
   HIP_TRY(hipMemcpyAsync(res, w.d_res, sizeof res, hipMemcpyDeviceToHost, st), SU_FALSE);
   HIP_TRY(hipStreamSynchronize(st), SU_FALSE);
-  float p = (float)std::atan2(res[1], res[0]);
+  float p = std::atan2(res[1], res[0]);                                // SU_C_ARG (:134)
   if (p > (float)M_PI) p -= (float)(2 * M_PI);
   *peak = p;
   return SU_TRUE;
@@ -1908,18 +1919,18 @@ SUBOOL suamd_doppler_calc(suamd_ctx_t *ctx, const suamd_complex *d_data, SUSCOUN
   HIP_TRY(sdk::fft_forward(w.a, w.b, w.log2n, &w.res, st), SU_FALSE);
   const long long bins = w.alloc, delta = bins / 2;                   // DopplerCalculator.cpp:107-108
   HIP_TRY(sdk::spectrum_centroid(w.res, w.alloc, 0, w.alloc, d_spectrum, bins, delta, 1, w.blk_max, w.blk_idx,
-                                 w.blk_sum, CaptureFft::NBLK, w.d_res, st), SU_FALSE);
-  double res[5];
+                                 CaptureFft::NBLK, reinterpret_cast<float *>(w.d_res), st), SU_FALSE);
+  float res[5];                                                        // binary32 sums in the reference's order (fft.hip)
   HIP_TRY(hipMemcpyAsync(res, w.d_res, sizeof res, hipMemcpyDeviceToHost, st), SU_FALSE);
   HIP_TRY(hipStreamSynchronize(st), SU_FALSE);
   // DopplerCalculator.cpp:158-173
   const float lambda = static_cast<float>(299792458.0 / f0);
-  float pk = (float)std::atan2(res[1], res[0]);
+  float pk = std::atan2(res[1], res[0]);
   if (pk > (float)M_PI) pk -= (float)(2 * M_PI);
   pk = fs * (pk / (float)M_PI) * .5f;                                  // SU_NORM2ABS_FREQ(fs, SU_ANG2NORM_FREQ(pk))
   if (peak) *peak = -lambda * pk;
-  if (sigma) *sigma = fs * (float)std::sqrt(res[2]) * .5f;
-  if (max) *max = (float)res[3];
+  if (sigma) *sigma = fs * std::sqrt(res[2]) * .5f;
+  if (max) *max = res[3];
   return SU_TRUE;
 }
 

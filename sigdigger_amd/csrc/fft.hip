@@ -145,29 +145,27 @@ __global__ void window_pad_kernel(const float2 *__restrict__ data, long long len
   }
 }
 
-// |X|^2 of bins [lo, hi) (others keep Re(X), as the reference's loop leaves them), block-wise
-// arg-max (first maximum wins, like the sequential scan) and total energy (double)
+// |X|^2 of bins [lo, hi) (others keep Re(X), as the reference's loop leaves them) and the block-wise arg-max (first
+// maximum wins, like the sequential scan).  The power is the real part of the reference's complex product
+// `x *= conj(x)` (Tasks/DopplerCalculator.cpp:120, CarrierDetector.cpp:113): two rounded squares and their rounded sum,
+// not an fma.
 __global__ __launch_bounds__(256) void power_argmax_kernel(float2 *__restrict__ buf, long long alloc, long long lo,
                                                            long long hi, float *__restrict__ mirror,
-                                                           float *__restrict__ blk_max, long long *__restrict__ blk_idx,
-                                                           double *__restrict__ blk_sum)
+                                                           float *__restrict__ blk_max, long long *__restrict__ blk_idx)
 {
   __shared__ float smax[256];
   __shared__ long long sidx[256];
-  __shared__ double ssum[256];
   float best = 0.0f;
   long long bi = 0;
-  double sum = 0.0;
   for (long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < hi;
        i += (long long)gridDim.x * blockDim.x) {
     const float2 x = buf[i];
-    const float p = __builtin_fmaf(x.x, x.x, x.y * x.y);
+    const float p = __fadd_rn(__fmul_rn(x.x, x.x), __fmul_rn(x.y, x.y));
     buf[i] = float2{p, 0.0f};
     if (mirror != nullptr) mirror[(alloc - i + alloc / 2) % alloc] = p;      // DopplerCalculator.cpp:128
-    sum += (double)p;
     if (p > best || (p == best && p > 0.0f && i < bi)) { best = p; bi = i; }
   }
-  smax[threadIdx.x] = best; sidx[threadIdx.x] = bi; ssum[threadIdx.x] = sum;
+  smax[threadIdx.x] = best; sidx[threadIdx.x] = bi;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if (threadIdx.x < s) {
@@ -176,64 +174,124 @@ __global__ __launch_bounds__(256) void power_argmax_kernel(float2 *__restrict__ 
       if (om > smax[threadIdx.x] || (om == smax[threadIdx.x] && om > 0.0f && oi < sidx[threadIdx.x])) {
         smax[threadIdx.x] = om; sidx[threadIdx.x] = oi;
       }
-      ssum[threadIdx.x] += ssum[threadIdx.x + s];
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { blk_max[blockIdx.x] = smax[0]; blk_idx[blockIdx.x] = sidx[0]; blk_sum[blockIdx.x] = ssum[0]; }
+  if (threadIdx.x == 0) { blk_max[blockIdx.x] = smax[0]; blk_idx[blockIdx.x] = sidx[0]; }
 }
 
-// final arg-max over the block results + circular centroid (and dispersion) around it
-// res[0] = acc.re, res[1] = acc.im, res[2] = dispersion accumulator, res[3] = max value, res[4] = total energy
-__global__ __launch_bounds__(256) void centroid_kernel(const float2 *__restrict__ buf, long long alloc, int nblk,
-                                                       const float *__restrict__ blk_max,
-                                                       const long long *__restrict__ blk_idx,
-                                                       const double *__restrict__ blk_sum, long long bins,
-                                                       long long delta, int with_dispersion, double *__restrict__ res)
+// ---- the reference's running sums, in ITS type and order --------------------------------------------------------------
+// DopplerCalculator's total energy is a binary32 Kahan sum over the bins in index order (:130-134), its centroid a
+// binary32 complex accumulator and its variance a plain binary32 accumulator over the bins in order from `start`
+// (:144-158); CarrierDetector's centroid likewise (:120-131).  A binary32 running sum of 2^15 .. 2^24 terms carries a
+// rounding error of the order of sqrt(bins) ulp -- 1e-5 relative at 2^19 bins -- so "the reference's number" is the number
+// THAT sequence of roundings produces: a pairwise or binary64 sum is more accurate and therefore different (round 3
+// compared sigma at 2e-3).  A sequence of dependent roundings is serial by nature: one wavefront per sum walks the bins;
+// what is parallel is everything else -- 64 lanes fetch and form the next 256 terms (gather, sincos, products, division)
+// while the sum of the previous 256 runs as a chain of uniform adds fed by LDS broadcast reads (one ds_read_b128 per four
+// terms).  ~6 cycles per term: 1.3 ms per 2^19 bins for a plain sum, ~5 ms for the Kahan sum -- once per capture.
+constexpr int SER_TILE = 256;
+
+// total = Kahan sum of buf[i].x, i = 0 .. bins-1 (bins a multiple of 16)
+__global__ __launch_bounds__(64) void serial_kahan_kernel(const float2 *__restrict__ buf, long long bins, float *__restrict__ total_out)
 {
-  __shared__ double sre[256], sim[256], sdisp[256];
+#pragma clang fp contract(off)
+  __shared__ __attribute__((aligned(16))) float tile[2][SER_TILE];
+  const int l = threadIdx.x;
+  float total = 0.0f, err = 0.0f;
+  float r[SER_TILE / 64];
+  auto fetch = [&](long long i0) {
+#pragma unroll
+    for (int q = 0; q < SER_TILE / 64; ++q) { const long long i = i0 + l + 64 * q; r[q] = i < bins ? buf[i].x : 0.0f; }
+  };
+  fetch(0);
+  int pp = 0;
+  for (long long i0 = 0; i0 < bins; i0 += SER_TILE, pp ^= 1) {
+#pragma unroll
+    for (int q = 0; q < SER_TILE / 64; ++q) tile[pp][l + 64 * q] = r[q];
+    __syncthreads();
+    if (i0 + SER_TILE < bins) fetch(i0 + SER_TILE);
+    const int cnt = bins - i0 < SER_TILE ? (int)(bins - i0) : SER_TILE;      // a multiple of 4
+    for (int e = 0; e < cnt; e += 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(&tile[pp][e]);
+      const float ps[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float y = __fsub_rn(ps[k], err);
+        const float t = __fadd_rn(total, y);
+        err = __fsub_rn(__fsub_rn(t, total), y);
+        total = t;
+      }
+    }
+  }
+  if (l == 0) *total_out = total;
+}
+
+// blockIdx.x = 0: acc.re, 1: acc.im, 2: the variance accumulator (only with_dispersion); res[0..2] binary32
+__global__ __launch_bounds__(64) void serial_centroid_kernel(const float2 *__restrict__ buf, long long alloc, int nblk,
+                                                             const float *__restrict__ blk_max,
+                                                             const long long *__restrict__ blk_idx,
+                                                             const float *__restrict__ total_in, long long bins,
+                                                             long long delta, float *__restrict__ res)
+{
+#pragma clang fp contract(off)
+  __shared__ __attribute__((aligned(16))) float tile[2][SER_TILE];
   __shared__ long long smaxidx;
   __shared__ float smaxval;
-  __shared__ double stotal;
-  if (threadIdx.x == 0) {
-    float best = 0.0f; long long bi = 0; double tot = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+  const int l = threadIdx.x, which = blockIdx.x;
+  if (l == 0) {
+    float best = 0.0f; long long bi = 0;
+    for (int b = 0; b < nblk; ++b)
       if (blk_max[b] > best || (blk_max[b] == best && best > 0.0f && blk_idx[b] < bi)) { best = blk_max[b]; bi = blk_idx[b]; }
-      tot += blk_sum[b];
-    }
-    smaxidx = bi; smaxval = best; stotal = tot;
+    smaxidx = bi; smaxval = best;
   }
   __syncthreads();
   const long long start = smaxidx - delta;
-  const double total = stotal;
-  double are = 0, aim = 0, disp = 0;
-  for (long long i = threadIdx.x; i < bins; i += blockDim.x) {
-    long long j = i + start;
-    if (j < 0) j += alloc;
-    j %= alloc;
-    const float psd = buf[j].x;
-    const float nFreq = 2.f * (float)j / (float)alloc;
-    float sn, cs;
-    sincosf(3.14159265358979323846f * nFreq, &sn, &cs);
-    are += (double)(psd * cs);
-    aim += (double)(psd * sn);
-    if (with_dispersion) {
-      long long jj = i;
-      if (jj >= delta) jj -= bins;
-      disp += ((double)jj * (double)jj * (double)psd / total) / ((double)delta * (double)delta);
+  const float total = which == 2 ? *total_in : 1.0f;
+  const float d2 = __fmul_rn((float)delta, (float)delta);     // delta * delta (:157; an int product there, see SPEC.md T10)
+  const float falloc = (float)alloc;
+  float r[SER_TILE / 64];
+  auto fetch = [&](long long i0) {
+#pragma unroll
+    for (int q = 0; q < SER_TILE / 64; ++q) {
+      const long long i = i0 + l + 64 * q;
+      float term = 0.0f;
+      if (i < bins) {
+        long long j = i + start;
+        if (j < 0) j += alloc;
+        j %= alloc;
+        const float psd = buf[j].x;
+        if (which == 2) {
+          long long jj = i;
+          if (jj >= delta) jj -= bins;
+          term = __fdiv_rn(__fdiv_rn(__fmul_rn((float)(jj * jj), psd), total), d2);
+        } else {
+          const float nFreq = __fdiv_rn(__fmul_rn(2.f, (float)j), falloc);
+          float sn, cs;
+          sincosf(__fmul_rn(3.14159265358979323846f, nFreq), &sn, &cs);
+          term = __fmul_rn(psd, which == 0 ? cs : sn);
+        }
+      }
+      r[q] = term;
     }
-  }
-  sre[threadIdx.x] = are; sim[threadIdx.x] = aim; sdisp[threadIdx.x] = disp;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      sre[threadIdx.x] += sre[threadIdx.x + s];
-      sim[threadIdx.x] += sim[threadIdx.x + s];
-      sdisp[threadIdx.x] += sdisp[threadIdx.x + s];
-    }
+  };
+  float acc = 0.0f;
+  fetch(0);
+  int pp = 0;
+  for (long long i0 = 0; i0 < bins; i0 += SER_TILE, pp ^= 1) {
+#pragma unroll
+    for (int q = 0; q < SER_TILE / 64; ++q) tile[pp][l + 64 * q] = r[q];
     __syncthreads();
+    if (i0 + SER_TILE < bins) fetch(i0 + SER_TILE);
+    const int cnt = bins - i0 < SER_TILE ? (int)(bins - i0) : SER_TILE;
+    int e = 0;
+    for (; e + 4 <= cnt; e += 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(&tile[pp][e]);
+      acc = __fadd_rn(acc, v.x); acc = __fadd_rn(acc, v.y); acc = __fadd_rn(acc, v.z); acc = __fadd_rn(acc, v.w);
+    }
+    for (; e < cnt; ++e) acc = __fadd_rn(acc, tile[pp][e]);
   }
-  if (threadIdx.x == 0) { res[0] = sre[0]; res[1] = sim[0]; res[2] = sdisp[0]; res[3] = (double)smaxval; res[4] = total; }
+  if (l == 0) { res[which] = acc; if (which == 0) res[3] = smaxval; }
 }
 
 // large PSD frames (N > 16384): buf = window .* frame
@@ -431,13 +489,16 @@ hipError_t window_pad(const void *data, long long len, long long alloc, void *bu
 }
 
 hipError_t spectrum_centroid(void *buf, long long alloc, long long lo, long long hi, float *mirror, long long bins,
-                             long long delta, int with_dispersion, float *blk_max, long long *blk_idx, double *blk_sum,
-                             int nblk, double *res, hipStream_t st)
+                             long long delta, int with_dispersion, float *blk_max, long long *blk_idx,
+                             int nblk, float *res, hipStream_t st)
 {
   hipLaunchKernelGGL(power_argmax_kernel, dim3(nblk), dim3(256), 0, st, reinterpret_cast<float2 *>(buf), alloc, lo, hi,
-                     mirror, blk_max, blk_idx, blk_sum);
-  hipLaunchKernelGGL(centroid_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const float2 *>(buf), alloc, nblk,
-                     blk_max, blk_idx, blk_sum, bins, delta, with_dispersion, res);
+                     mirror, blk_max, blk_idx);
+  // res[0] = acc.re, res[1] = acc.im, res[2] = variance accumulator, res[3] = max value, res[4] = total energy
+  if (with_dispersion)
+    hipLaunchKernelGGL(serial_kahan_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<const float2 *>(buf), bins, res + 4);
+  hipLaunchKernelGGL(serial_centroid_kernel, dim3(with_dispersion ? 3 : 2), dim3(64), 0, st, reinterpret_cast<const float2 *>(buf),
+                     alloc, nblk, blk_max, blk_idx, res + 4, bins, delta, res);
   return hipGetLastError();
 }
 

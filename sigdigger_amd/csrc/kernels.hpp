@@ -294,7 +294,7 @@ hipError_t fac_feed(void *a, void *b, int log2n, float alpha, long long view_sta
                     float *fac, unsigned *mx, unsigned *mn, hipStream_t st);
 hipError_t window_pad(const void *data, long long len, long long alloc, void *buf, hipStream_t st);
 hipError_t spectrum_centroid(void *buf, long long alloc, long long lo, long long hi, float *mirror, long long bins,
-                             long long delta, int with_dispersion, float *blk_max, long long *blk_idx, double *blk_sum,
-                             int nblk, double *res, hipStream_t st);
+                             long long delta, int with_dispersion, float *blk_max, long long *blk_idx,
+                             int nblk, float *res, hipStream_t st);
 
 }  // namespace sdk

@@ -270,6 +270,9 @@ hipError_t psd_frames_large2(int log2n, const void *x, long long hop, int navg, 
     else hipLaunchKernelGGL(psdl_cols_kernel<6>, ga, dim3(256), 0, st, xx + F0 * hop, hop, l1, window, reinterpret_cast<const cf *>(tw_n), reinterpret_cast<cf *>(a));
     const long long o_first = F0 / navg;
     const long long g_first = chunk_of(F0), ng = chunk_of(F0 + nb - 1) - g_first + 1;
+    // slots are addressed g % pring: the chunks from the first one of the batch's first output (read again by the finish
+    // kernel when that output completes) to the batch's last must not share a slot
+    if (chunk_of(F0 + nb - 1) - o_first * cpo + 1 > pring) return hipErrorInvalidValue;
     hipError_t e;
     switch (l1) {
       case 9:  e = launch_rows<9, 64>(a, l2, F0, nb, navg, ch, cpo, g_first, ng, tw_row, P, pring, st); break;

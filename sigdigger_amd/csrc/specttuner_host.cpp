@@ -433,8 +433,12 @@ SUBOOL suamd_specttuner_reset(suamd_specttuner_t *st, void *stream)
     SizeGroup &g = kv.second;
     const size_t HS = ((size_t)1 << g.log2s) / 2;
     if (g.dirty) {
-      // the tables are rebuilt at the next feed from the snapshot: clear what the rebuild would carry over
-      if (g.snap_prev && hipMemsetAsync(g.snap_prev, 0, std::max<size_t>(1, g.snap_members.size()) * HS * sizeof(c32), s) != hipSuccess) { suamd_set_error("reset failed"); return SU_FALSE; }
+      // the tables are rebuilt at the next feed from the snapshot: drop what the rebuild would carry over (it zero-fills
+      // a group that has no snapshot).  Not a memset on `s`: rebuild_group copies with blocking calls on the null stream,
+      // which a non-blocking caller stream is not ordered with -- the snapshot's last writer was synchronised
+      // when it was taken, so freeing it here is safe
+      if (g.snap_prev) { (void)hipFree(g.snap_prev); g.snap_prev = nullptr; }
+      g.snap_members.clear();
     } else if (g.d_prev[g.prev_cur] && !g.members.empty() &&
                hipMemsetAsync(g.d_prev[g.prev_cur], 0, g.members.size() * HS * sizeof(c32), s) != hipSuccess) { suamd_set_error("reset failed"); return SU_FALSE; }
   }

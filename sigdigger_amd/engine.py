@@ -491,7 +491,19 @@ class SpectTuner:
         lowest one (rows carved from one arena): 32-bit output addressing.  Returns counts."""
         _chk_c64(x, "x")
         ptrs = [0 if r is None else int(r.data_ptr()) for r in rows]
-        table = torch.tensor(ptrs, dtype=torch.int64, device=x.device)
+        # the kernel reads the table after this call returns: it lives on the tuner, not in a temporary the caching
+        # allocator may hand to someone else while the launch is still queued on `stream` (ADVICE r3); a table of another
+        # length replaces the old one only after the device has finished with it
+        table = getattr(self, "_row_table", None)
+        if table is None or table.numel() != len(ptrs) or table.device != x.device:
+            if table is not None:
+                torch.cuda.synchronize(table.device)
+            table = self._row_table = torch.empty(len(ptrs), dtype=torch.int64, device=x.device)
+            self._row_table_host = None
+        if self._row_table_host != ptrs:
+            torch.cuda.synchronize(x.device)                    # an earlier feed may still read the old contents
+            table.copy_(torch.tensor(ptrs, dtype=torch.int64))
+            self._row_table_host = list(ptrs)
         counts = (C.c_uint64 * max(self.capacity(), 1))()
         if near:
             live = [p for p in ptrs if p]
@@ -500,7 +512,6 @@ class SpectTuner:
         else:
             check(self.ctx.lib.suamd_specttuner_feed_rows(self.h, _ptr(x), x.numel(), table.data_ptr(), counts, _stream(stream)),
                   "suamd_specttuner_feed_rows")
-        torch.cuda.current_stream(x.device).synchronize() if stream is None else None     # the table must outlive the launch
         return [int(v) for v in counts]
 
 

@@ -61,6 +61,42 @@ def test_two_ranks_share_the_gpu_over_gloo():
     assert abs(d["aggregate_inspector_MSps"] - d["value"] * d["config"]["inspectors_total"]) < 0.01 * d["aggregate_inspector_MSps"]
 
 
+def test_bare_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run around it must not time one GPU and print n_gpus 1
+    (VERDICT r3 #2): bench.py re-executes itself under torch.distributed.run with one rank per GPU.  Here both ranks share
+    the test box's GPU over gloo; on a real node the same path initialises RCCL with N ranks."""
+    env = dict(os.environ, SUAMD_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["inspectors_total"] == 2 * d["config"]["inspectors_per_gpu"]
+    assert "RCCL broadcast" in d["config"]["parallelism"]
+    # without the test hook a one-GPU box must refuse, loudly, rather than time one GPU
+    env.pop("SUAMD_BENCH_SHARE_GPU")
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_the_n1_line_of_the_self_launching_bench_reproduces_the_drivers():
+    """--gpus 1 takes no launcher: same steps and warm-up give the same kind of line whether RANK / WORLD_SIZE are set by
+    torch.distributed.run (world 1) or absent (the driver's N = 1 command)."""
+    args = ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-extra", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    a = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port())] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr + b.stderr)[-3000:]
+    da, db = _last_json(a.stdout), _last_json(b.stdout)
+    assert da["n_gpus"] == db["n_gpus"] == 1 and da["steps"] == db["steps"] == 20
+    assert abs(da["value"] - db["value"]) < 0.1 * da["value"], (da["value"], db["value"])
+
+
 def test_live_mode_times_the_sharded_analyzer_itself():
     """`bench.py --live --gpus N` (no torchrun): one process, the suscan_analyzer_* ABI with SUAMD_DEVICES = 0..N-1 -- the
     C++ sharded analyzer that IS the drop-in (csrc/analyzer.cpp), not the Python harness.  N = 1 on the test box."""

@@ -185,7 +185,7 @@ def test_carrier_detector(n):
     ref = sdref.carrier_detector(x, 0.05, 0.01)
     ora = sdo.carrier_detect(x, 0.05, 0.01)
     assert abs(ref - 0.37) < 1e-2
-    assert abs(ref - ora) <= 1e-5 * abs(ora) + 1e-6
+    assert abs(ref - ora) <= 1e-6 * abs(ora)               # same FFT, same binary32 sums in the same order: a libm ulp at most
 
 
 def test_doppler_calculator():
@@ -194,11 +194,12 @@ def test_doppler_calculator():
     x = (np.exp(1j * 0.21 * t) + 0.2 * cnoise(n, 14)).astype(np.complex64)
     peak, sigma, spec = sdref.doppler(x, 48000.0, 1.42e9)
     opeak, osigma, _omax, ospec = sdo.doppler_calc(x, 48000.0, 1.42e9)
-    assert abs(peak - opeak) <= 1e-5 * abs(opeak)
-    assert abs(sigma - osigma) <= 1e-4 * abs(osigma)
+    # energy (Kahan), centroid and variance are binary32 running sums in bin order on both sides
+    assert abs(peak - opeak) <= 1e-6 * abs(opeak)
+    assert abs(sigma - osigma) <= 1e-6 * abs(osigma)
     assert spec.size == ospec.size
     assert np.all(spec.imag == 0)
-    assert relerr(spec.real, ospec) <= 1e-5
+    assert np.array_equal(spec.real, ospec)                # x *= conj(x): two rounded squares and their rounded sum
 
 
 # ---- P2 / P3: SpectrumView (Panoramic/Scanner.cpp:27-293) --------------------------------------------------------------
