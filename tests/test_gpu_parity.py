@@ -1265,4 +1265,6 @@ def test_doppler_calc_matches_oracle(ctx, sdo):
     assert abs(gp - rp) <= 1e-5 * abs(rp)                                # m/s
     assert abs(gs - rs) <= 1e-5 * abs(rs)
     # first principles: +0.02 cycles/sample at 250 kS/s = +5 kHz  ->  v = -lambda * f
-    assert abs(gp - (-(299792458.0 / f0) * 5e3)) < 0.5
+    # (the reference's binary32 centroid over 2^19 bins -- signal bins + 5e5 noise bins summed in bin order -- sits 0.25 %
+    # off the line here; the binary64 centroid of rounds 1-3 was within 0.5 m/s of it, and was not the reference's number)
+    assert abs(gp - (-(299792458.0 / f0) * 5e3)) < 0.005 * (299792458.0 / f0) * 5e3
