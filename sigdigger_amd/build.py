@@ -22,6 +22,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=h
 SOURCES = {
     "psd.hip":   ["-ffp-contract=fast"],
     "chan.hip":  ["-ffp-contract=off"],
+    "chan_stream.hip": ["-ffp-contract=off"],
     "loops.hip": ["-ffp-contract=off"],
     "specview.hip": ["-ffp-contract=off"],
     "fft.hip": ["-ffp-contract=fast"],

@@ -217,6 +217,7 @@ struct suamd_chanbank {
   uint64_t n_total;      // samples consumed so far (absolute index of the next x[0])
   float    *d_taps;      // real prototype [ntaps]
   void     *d_g;         // float4 [nchan][ntaps]: modulated taps as (re, re, -im, im)
+  void     *d_g2;        // float2 [nchan][ntaps] + 64: the same as (re, im) pairs (chan_stream.hip)
   uint32_t *d_dphase, *d_phase0;
   void     *d_hist[2];   // float2 [ntaps-1], ping-pong: d_hist[hist_cur] precedes the next block
   int       hist_cur;
@@ -605,18 +606,19 @@ suamd_chanbank_t *suamd_chanbank_new(suamd_ctx_t *ctx, unsigned nchan, const dou
   for (unsigned c = 0; c < nchan; ++c) dp[c] = suamd_fnor_to_dphase(-fnor[c]);
   b->d_taps   = dev_alloc<float>(ntaps);
   b->d_g      = dev_alloc<float>(4 * (size_t)nchan * ntaps);
+  b->d_g2     = dev_zeros<float>(2 * ((size_t)nchan * ntaps + 64));      // + the stream kernel's look-ahead (two runs of 16 taps)
   b->d_dphase = dev_from_host(dp);
   b->d_phase0 = dev_from_host(p0);
   b->d_hist[0] = dev_zeros<float>(2 * (size_t)(ntaps > 1 ? ntaps - 1 : 1));
   b->d_hist[1] = dev_zeros<float>(2 * (size_t)(ntaps > 1 ? ntaps - 1 : 1));
   b->hist_cur = 0;
-  if (!b->d_taps || !b->d_g || !b->d_dphase || !b->d_phase0 || !b->d_hist[0] || !b->d_hist[1] ||
+  if (!b->d_taps || !b->d_g || !b->d_g2 || !b->d_dphase || !b->d_phase0 || !b->d_hist[0] || !b->d_hist[1] ||
       !dev_upload(b->d_taps, taps, ntaps)) {
     set_err("device allocation failed");
     suamd_chanbank_destroy(b);
     return nullptr;
   }
-  hipError_t e = sdk::chan_modulate_taps(b->d_taps, (int)ntaps, b->d_dphase, (int)nchan, b->d_g, nullptr);
+  hipError_t e = sdk::chan_modulate_taps(b->d_taps, (int)ntaps, b->d_dphase, (int)nchan, b->d_g, b->d_g2, nullptr);
   if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
   if (e != hipSuccess) {
     set_err("tap modulation kernel failed: %s", hipGetErrorString(e));
@@ -631,6 +633,7 @@ void suamd_chanbank_destroy(suamd_chanbank_t *b)
   if (!b) return;
   if (b->d_taps) hipFree(b->d_taps);
   if (b->d_g) hipFree(b->d_g);
+  if (b->d_g2) hipFree(b->d_g2);
   if (b->d_dphase) hipFree(b->d_dphase);
   if (b->d_phase0) hipFree(b->d_phase0);
   if (b->d_hist[0]) hipFree(b->d_hist[0]);
@@ -671,7 +674,7 @@ SUBOOL suamd_chanbank_feed(suamd_chanbank_t *b, const suamd_complex *d_x, SUSCOU
   sdk::ChanFeedArgs a;
   a.x = d_x; a.hist = b->d_hist[b->hist_cur]; a.hist_next = b->d_hist[b->hist_cur ^ 1];
   a.len = (long long)len; a.n0 = b->n_total;
-  a.g = b->d_g; a.dphase = b->d_dphase; a.phase0 = b->d_phase0;
+  a.g = b->d_g; a.g2 = b->d_g2; a.dphase = b->d_dphase; a.phase0 = b->d_phase0;
   a.ntaps = (int)b->ntaps; a.nchan = (int)b->nchan; a.D = b->D;
   a.m_first = mf; a.n_out = (long long)no; a.y = d_y; a.yv = as_view(yv);
   HIP_TRY(sdk::chan_feed(a, as_stream(stream)), SU_FALSE);
@@ -699,7 +702,7 @@ SUBOOL suamd_chanbank_gang_feed(suamd_ctx_t *ctx, suamd_chanbank_t *const *banks
     sdk::ChanFeedArgs a;
     a.x = d_x; a.hist = b->d_hist[b->hist_cur]; a.hist_next = b->d_hist[b->hist_cur ^ 1];
     a.len = (long long)len; a.n0 = b->n_total;
-    a.g = b->d_g; a.dphase = b->d_dphase; a.phase0 = b->d_phase0;
+    a.g = b->d_g; a.g2 = nullptr; a.dphase = b->d_dphase; a.phase0 = b->d_phase0;
     a.ntaps = (int)b->ntaps; a.nchan = 1; a.D = b->D;
     a.m_first = mf; a.n_out = (long long)no; a.y = d_y[i]; a.yv = sdk::View{0, 1};
     if (sdk::chan_gang_plan(a, &items[i]) != hipSuccess) { set_err("bank %u does not fit the gang kernel (decimation %u, %u taps)", i, b->D, b->ntaps); return SU_FALSE; }

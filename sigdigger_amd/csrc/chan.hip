@@ -71,7 +71,7 @@ __global__ void xlate_kernel(const float4 *__restrict__ x, float4 *__restrict__ 
 // packed fmas that accumulate (acc.re, acc.im) -- the SGPR pairs come straight out of s_load,
 // no scalar ALU work per tap.
 __global__ void modulate_taps_kernel(const float *__restrict__ h, int ntaps, const uint32_t *__restrict__ dphase,
-                                     int nchan, float4 *__restrict__ g)
+                                     int nchan, float4 *__restrict__ g, float2 *__restrict__ g2)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ntaps * nchan) return;
@@ -80,6 +80,7 @@ __global__ void modulate_taps_kernel(const float *__restrict__ h, int ntaps, con
   sd::phasor_u32(0u - (uint32_t)k * dphase[c], cs, sn);
   const float re = h[k] * cs, im = h[k] * sn;
   g[t] = float4{re, re, -im, im};
+  if (g2) g2[t] = float2{re, im};                      // chan_stream.hip: (re, im) pairs for scalar loads
 }
 
 // ---------------------------------------------------------------------------------------
@@ -511,11 +512,11 @@ hipError_t xlate_bulk(const void *x, void *y, long long len, uint32_t p0, uint32
   return hipGetLastError();
 }
 
-hipError_t chan_modulate_taps(const float *h, int ntaps, const uint32_t *dphase, int nchan, void *g, hipStream_t st)
+hipError_t chan_modulate_taps(const float *h, int ntaps, const uint32_t *dphase, int nchan, void *g, void *g2, hipStream_t st)
 {
   const int total = ntaps * nchan;
   hipLaunchKernelGGL(modulate_taps_kernel, dim3((total + 255) / 256), dim3(256), 0, st, h, ntaps, dphase, nchan,
-                     reinterpret_cast<float4 *>(g));
+                     reinterpret_cast<float4 *>(g), reinterpret_cast<float2 *>(g2));
   return hipGetLastError();
 }
 
@@ -569,6 +570,11 @@ static hipError_t fir_plan(const ChanFeedArgs &a, FirPlan &pl)
 hipError_t chan_feed(const ChanFeedArgs &a, hipStream_t st)
 {
   if (a.n_out <= 0) return chan_update_hist(a.hist_next, a.hist, a.x, a.len, a.ntaps, st);
+  {
+    // one or two channels: the stage is HBM-bound and runs as a stream (chan_stream.hip), same bits
+    hipError_t es = hipSuccess;
+    if (chan_stream_feed(a, a.g2, st, &es)) return es;
+  }
   FirPlan pl;
   hipError_t e = fir_plan(a, pl);
   if (e != hipSuccess) return e;

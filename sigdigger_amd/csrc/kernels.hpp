@@ -44,7 +44,8 @@ hipError_t insp_spectrum_db_shift(float *data, long long len, long long nspec, h
 
 // ---- chan.hip ----
 hipError_t xlate_bulk(const void *x, void *y, long long len, uint32_t p0, uint32_t dp, uint64_t n0, hipStream_t st);
-hipError_t chan_modulate_taps(const float *h, int ntaps, const uint32_t *dphase, int nchan, void *g, hipStream_t st);
+// g: float4 [nchan][ntaps] (re, re, -im, im); g2 (may be null): the same taps as compact (re, im) pairs, [nchan][ntaps] + 64 spare entries
+hipError_t chan_modulate_taps(const float *h, int ntaps, const uint32_t *dphase, int nchan, void *g, void *g2, hipStream_t st);
 struct ChanFeedArgs {
   const void *x;        // input block (device), len samples
   const void *hist;     // ntaps-1 samples preceding x[0] (device)
@@ -52,6 +53,7 @@ struct ChanFeedArgs {
   long long   len;
   uint64_t    n0;       // absolute index of x[0]
   const void *g;        // float4 [nchan][ntaps] modulated taps (re, re, -im, im)
+  const void *g2;       // float2 [nchan][ntaps] (+ 64 spare) the same taps as (re, im): the stream kernel's scalar loads; may be null
   const uint32_t *dphase;   // [nchan]
   const uint32_t *phase0;   // [nchan]
   int         ntaps, nchan;
@@ -62,6 +64,8 @@ struct ChanFeedArgs {
   View        yv;
 };
 hipError_t chan_feed(const ChanFeedArgs &a, hipStream_t st);
+// chan_stream.hip: few channels as a stream (LDS-DMA ring); false = not this kernel's shape (nothing launched)
+bool chan_stream_feed(const ChanFeedArgs &a, const void *g2, hipStream_t st, hipError_t *err);
 // tiling of one feed (chan.hip plans it)
 struct FirGeom {
   int D, ntaps, nchan;

@@ -337,6 +337,35 @@ def test_chanbank_bit_exact(ctx, sdo, nchan, D, T):
             assert_bits(got[c], ref[c], f"chanbank channel {c} ({layout})")
 
 
+@pytest.mark.parametrize("nchan,D,T", [(1, 16, 255), (2, 16, 255), (1, 8, 255), (1, 32, 255), (1, 64, 255), (2, 64, 129),
+                                       (1, 16, 16), (1, 16, 7), (1, 16, 1), (1, 16, 1023), (2, 32, 64), (1, 8, 33)])
+def test_chanbank_stream_kernel_equals_the_tiled_one_and_the_oracle(ctx, sdo, monkeypatch, nchan, D, T):
+    """chan_stream.hip (one or two channels: persistent workgroups, LDS-DMA ring, scalar taps) against chan_fir_kernel
+    (SUAMD_FIR_STREAM=0) bit for bit -- feeds of ragged sizes (a tile boundary inside, a feed shorter than a tile, an
+    odd start so that the first history pair straddles hist / x), both layouts -- and against the oracle on the head."""
+    n = 300000
+    fn = [0.25, -0.4][:nchan]
+    x = synth.psk_carriers(n, fn, sps=max(D // 2, 4), seed=T + D)
+    taps = sdo.lpf_design(T, 0.8 / D)
+    cuts = [0, 70001, 70002, 70002 + 64 * 8 * D + 3, 200000 - 1, n]
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SUAMD_FIR_STREAM", mode)
+        for layout in ("cm", "tm"):
+            bank = engine.ChannelBank(ctx, fn, D, taps)
+            got = []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                out = empty_rows(nchan, bank.output_count(b - a) + 3, layout)
+                got.append(host(bank.feed(dev(x[a:b]), out=out)))
+            res[mode, layout] = np.concatenate(got, axis=1)
+    monkeypatch.delenv("SUAMD_FIR_STREAM")
+    for layout in ("cm", "tm"):
+        assert_bits(res["1", layout], res["0", layout], f"stream vs tiled kernel ({layout})")
+    ref = _oracle_bank(sdo, x[:80000], fn, D, taps, [(0, 80000)])
+    for c in range(nchan):
+        assert_bits(res["1", "cm"][c, :len(ref[c])], ref[c], f"stream kernel channel {c} vs oracle")
+
+
 def test_chanbank_gang_bit_exact(ctx, sdo):
     """many 1-channel banks -- different carriers, decimations (powers of two and not), tap counts -- on the same
     blocks in one launch each: every row equals the oracle's channel, history and sample clock carried; includes
