@@ -217,7 +217,8 @@ struct suamd_chanbank {
   uint64_t n_total;      // samples consumed so far (absolute index of the next x[0])
   float    *d_taps;      // real prototype [ntaps]
   void     *d_g;         // float4 [nchan][ntaps]: modulated taps as (re, re, -im, im)
-  void     *d_g2;        // float2 [nchan][ntaps] + 64: the same as (re, im) pairs (chan_stream.hip)
+  void     *d_g2;        // float2 [nchan][ntaps]: the same as (re, im) pairs (chan_stream.hip); 64 spare entries on either side
+  void     *d_g2_base;   // the allocation behind d_g2
   uint32_t *d_dphase, *d_phase0;
   void     *d_hist[2];   // float2 [ntaps-1], ping-pong: d_hist[hist_cur] precedes the next block
   int       hist_cur;
@@ -606,7 +607,8 @@ suamd_chanbank_t *suamd_chanbank_new(suamd_ctx_t *ctx, unsigned nchan, const dou
   for (unsigned c = 0; c < nchan; ++c) dp[c] = suamd_fnor_to_dphase(-fnor[c]);
   b->d_taps   = dev_alloc<float>(ntaps);
   b->d_g      = dev_alloc<float>(4 * (size_t)nchan * ntaps);
-  b->d_g2     = dev_zeros<float>(2 * ((size_t)nchan * ntaps + 64));      // + the stream kernel's look-ahead (two runs of 16 taps)
+  b->d_g2_base = dev_zeros<float>(2 * ((size_t)nchan * ntaps + 128));   // the stream kernels read up to D taps in front of a row and two runs behind it
+  b->d_g2     = b->d_g2_base ? static_cast<float *>(b->d_g2_base) + 2 * 64 : nullptr;
   b->d_dphase = dev_from_host(dp);
   b->d_phase0 = dev_from_host(p0);
   b->d_hist[0] = dev_zeros<float>(2 * (size_t)(ntaps > 1 ? ntaps - 1 : 1));
@@ -633,7 +635,7 @@ void suamd_chanbank_destroy(suamd_chanbank_t *b)
   if (!b) return;
   if (b->d_taps) hipFree(b->d_taps);
   if (b->d_g) hipFree(b->d_g);
-  if (b->d_g2) hipFree(b->d_g2);
+  if (b->d_g2_base) hipFree(b->d_g2_base);
   if (b->d_dphase) hipFree(b->d_dphase);
   if (b->d_phase0) hipFree(b->d_phase0);
   if (b->d_hist[0]) hipFree(b->d_hist[0]);
