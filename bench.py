@@ -225,8 +225,79 @@ def pmc_traffic(kernel, workload, block):
             continue
         w = d.get("workload", {})
         if w.get("name") == workload and w.get("block_samples") == block and kernel in d.get("kernels", {}):
-            best = d["kernels"][kernel].get("hbm_bytes_per_launch")
-    return best
+            best = (d["kernels"][kernel].get("hbm_bytes_per_launch"),
+                    f"profiles/{os.path.basename(f)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this "
+                    f"workload (2 x FETCH + WRITE, gfx950 half-count of streamed reads), not measured in this run")
+    return best if best else (None, None)
+
+
+CHANNELISER_KERNELS = ("stx_kernel", "stp_kernel", "stw_kernel", "st_kernel", "chan_pair_kernel", "chan_fir_kernel")
+KERNELS = {
+    "stx_kernel": "stx_kernel (FFT channeliser for channels of 128 bins and more: the narrow kernels' 4096-pt forward transform -- two "
+                  "64-pt DFTs on registers around an LDS transposition, once per window for all channels --, inverse transform of a "
+                  "channel as 64-pt register DFTs in size / 64 lanes around one LDS exchange)",
+    "stp_kernel": "stp_kernel (FFT channeliser, two wavefronts per window: 4096-pt forward FFT as two 64-pt DFTs on registers "
+                  "around an LDS transposition, each DFT split between the wavefronts with one swap through LDS; lane = "
+                  "channel: bin pick x response, 64-pt inverse FFT, cross-fade)",
+    "stw_kernel": "stw_kernel (FFT channeliser, one wavefront per window: 4096-pt forward FFT as two register DFT64 "
+                  "around an LDS transposition, shared by all channels; lane = channel: bin pick x response, 64-pt "
+                  "inverse FFT, cross-fade)",
+    "st_kernel": "st_kernel (FFT channeliser, one workgroup per run of windows: radix-16 passes through LDS)",
+    "chan_pair_kernel": "chan_pair_kernel (translate + polyphase decimating FIR for one or two channels as a stream: persistent "
+                        "workgroups, lane = two adjacent outputs sharing their samples in LDS, next tile staged through registers, "
+                        "taps from scalar loads; the SPEC's fma chain per output)",
+    "chan_fir_kernel": "chan_fir_kernel (translate + 255-tap polyphase decimating FIR bank)"}
+
+
+def fir_stage_roofline(C, D, L, kernel_ms, kname, workload, timing):
+    """roofline object of the north star's "FIR stage" (the channeliser): algorithmic (compulsory) bytes per launch
+    (the shared input once + every channel's decimated output) over the kernel's own duration"""
+    nbytes = 8.0 * L + 8.0 * C * (L // D)
+    traffic, tsrc = pmc_traffic(kname, workload, L)
+    return {"kernel": KERNELS.get(kname, kname), "bound": "hbm",
+            "achieved": round(nbytes / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(nbytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kernel_ms else None,
+            "traffic": traffic, "traffic_source": tsrc,
+            "algorithmic_bytes_per_launch": nbytes, "kernel_ms": round(kernel_ms, 4) if kernel_ms else None, "timing": timing}
+
+
+def channeliser_alone(ctx, dev, fn, D, T, channeliser, log2_block, slots=None, reps=10):
+    """the channeliser kernel alone on a resident block (dispatch-bound event pairs): ms per launch and the kernel's name"""
+    Lb = 1 << log2_block
+    x = torch.empty(Lb, dtype=torch.complex64, device=dev)
+    torch.view_as_real(x).normal_()
+    C = len(fn)
+    if channeliser == "fft":
+        st = engine.SpectTuner(ctx, 4096)
+        if slots:
+            st.set_slots(slots)
+        for f in fn:
+            st.open_channel(np.pi * f % (2 * np.pi), 2 * np.pi * 0.75 / D)
+        out = engine.time_major(C, Lb // D + 64, dev)
+        feed = lambda: st.feed(x, out=out)
+    else:
+        bank = engine.ChannelBank(ctx, fn, D, ctx.lpf_design(T, 0.75 / D))
+        out = engine.time_major(C, Lb // D + 8, dev)
+        feed = lambda: bank.feed(x, out=out)
+    feed()
+    torch.cuda.synchronize(dev)
+    engine.kernel_timing_read()
+    engine.kernel_timing(True)
+    for _ in range(reps):
+        feed()
+    torch.cuda.synchronize(dev)
+    engine.kernel_timing(False)
+    best = None
+    for k in CHANNELISER_KERNELS:
+        r = engine.kernel_timing_read(k)
+        if r["launches"] and (best is None or r["sum_ms"] > best[1]["sum_ms"]):
+            best = (k, r)
+    engine.kernel_timing_read()
+    if channeliser == "fft":
+        st.close()
+    if best is None:
+        return None, None
+    return best[1]["sum_ms"] / reps, best[0]        # (a bank of several sizes launches once per size: the sum per feed)
 
 
 def _cpu_model():
@@ -288,7 +359,7 @@ def run_workload(name, args, rank, world, dev, ctx, dist):
     dt = time.perf_counter() - t0
     engine.kernel_timing(False)
     pipe.kernel_ms = {}
-    for kname in ("stp_kernel", "stw_kernel", "st_kernel", "chan_fir_kernel", "psd_kernel", "psd_reduce_kernel"):
+    for kname in CHANNELISER_KERNELS + ("psd_kernel", "psd_reduce_kernel"):
         r = engine.kernel_timing_read(kname)
         if r["launches"]:
             pipe.kernel_ms[kname] = {"avg": r["sum_ms"] / r["launches"], "min": r["min_ms"], "max": r["max_ms"], "launches": r["launches"],
@@ -551,35 +622,20 @@ def main():
         # per-launch durations: the dispatch-bound event pairs (pipe.kernel_ms) where the library provides them; the
         # stream-event pairs around each stage (stage_ms: they include the queue's gaps) are reported beside them
         kms = getattr(pipe, "kernel_ms", {})
-        chan_k = next((k for k in ("stp_kernel", "stw_kernel", "st_kernel", "chan_fir_kernel") if k in kms), None)
+        chan_k = next((k for k in CHANNELISER_KERNELS if k in kms), None)
         fir_ms = kms[chan_k]["per_step"] if chan_k else stages.get("fir")
         psd_ms = (sum(kms[k]["per_step"] for k in ("psd_kernel", "psd_reduce_kernel") if k in kms)
                   if "psd_kernel" in kms else stages.get("psd"))
         psd_bytes = 8.0 * L + 4.0 * cfg["psd"] * (L // cfg["psd"] // pipe.navg)
-        kname = (chan_k or "stp_kernel") if fft_bank else "chan_fir_kernel"
-        KERNELS = {
-            "stp_kernel": "stp_kernel (FFT channeliser, two wavefronts per window: 4096-pt forward FFT as two 64-pt DFTs on registers "
-                          "around an LDS transposition, each DFT split between the wavefronts with one swap through LDS; lane = "
-                          "channel: bin pick x response, 64-pt inverse FFT, cross-fade)",
-            "stw_kernel": "stw_kernel (FFT channeliser, one wavefront per window: 4096-pt forward FFT as two register DFT64 "
-                          "around an LDS transposition, shared by all channels; lane = channel: bin pick x response, 64-pt "
-                          "inverse FFT, cross-fade)",
-            "st_kernel": "st_kernel (FFT channeliser, one workgroup per run of windows: radix-16 passes through LDS)",
-            "chan_fir_kernel": "chan_fir_kernel (translate + 255-tap polyphase decimating FIR bank)"}
-        roof = {
-            "kernel": KERNELS[kname],
-            "bound": "hbm", "achieved": round(fir_bytes / (fir_ms * 1e-3) / 1e9, 2) if fir_ms else None,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(fir_bytes / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if fir_ms else None,
-            "traffic": pmc_traffic(kname, args.workload, L),
-            "algorithmic_bytes_per_launch": fir_bytes,
-            "kernel_ms": round(fir_ms, 4) if fir_ms else None,
+        kname = chan_k or ("stp_kernel" if fft_bank else "chan_fir_kernel")
+        TIMING = ("dispatch-bound event pairs (hipExtLaunchKernelGGL start/stop events through suamd_kernel_timing): the "
+                  "kernel's own duration, averaged over every launch of the timed region")
+        roof = fir_stage_roofline(C, D, L, fir_ms, kname, args.workload, TIMING if chan_k else "stream events around the stage")
+        roof.update({
             "psd_kernel": {"achieved": round(psd_bytes / (psd_ms * 1e-3) / 1e9, 2) if psd_ms else None,
                            "frac": round(psd_bytes / (psd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if psd_ms else None,
                            "kernel_ms": round(psd_ms, 4) if psd_ms else None,
                            "algorithmic_bytes_per_launch": psd_bytes},
-            "timing": ("dispatch-bound event pairs (hipExtLaunchKernelGGL start/stop events through suamd_kernel_timing): the "
-                       "kernel's own duration, averaged over every launch of the timed region") if chan_k else "stream events around the stage",
             "kernel_launches_ms": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kms.items()},
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},
             "stalled_samples_dropped": dict(getattr(pipe, "stalled_samples", {})),
@@ -587,7 +643,7 @@ def main():
                                     for k, v in getattr(pipe, "stage_raw", {}).items()},
             "note": "recurrence stages (AGC/Costas/Gardner) are one-lane-per-channel and latency-bound; "
                     "they are reported in stage_ms, not against a roofline (SURVEY.md section 8d)",
-        }
+        })
         if not fft_bank and fir_ms:
             roof["fp32_vector"] = {"peak_tflops": FP32_PEAK_TFLOPS,
                                    "flops_as_built": fir_flops_built, "frac_as_built": round(fir_flops_built / (fir_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
@@ -653,12 +709,35 @@ def main():
             for w in ("c2", "c3"):
                 if w == args.workload:
                     continue
-                a2 = argparse.Namespace(**vars(args))
-                a2.steps, a2.warmup = max(5, min(25, args.steps // 4)), 2
-                c2, L2, dt2, st2, _, _ = run_workload(w, a2, 0, 1, dev, ctx, None)
-                extra[w] = {"workload": describe(c2, args.channeliser), "value_MSps": round(L2 * a2.steps / dt2 / 1e6, 3),
-                            "ms_per_step": round(dt2 / a2.steps * 1e3, 4),
-                            "stage_ms": {k: round(v, 4) for k, v in st2.items()}}
+                # C2 as BASELINE.json states it -- "1 PSK inspector, 255-tap LPF": the translate + 255-tap polyphase FIR --
+                # AND behind the FFT filter bank (what the live analyzer puts in front of an inspector); C3 on the default
+                variants = (("fir", "255-tap LPF (BASELINE.json configs[1])"), ("fft", "FFT filter bank")) if w == "c2" else ((args.channeliser, None),)
+                for chn, label in variants:
+                    a2 = argparse.Namespace(**vars(args))
+                    a2.steps, a2.warmup, a2.channeliser = max(5, min(40, args.steps // 4)), 4, chn
+                    c2, L2, dt2, st2, fn2, pipe2 = run_workload(w, a2, 0, 1, dev, ctx, None)
+                    k2 = getattr(pipe2, "kernel_ms", {})
+                    ck = next((k for k in CHANNELISER_KERNELS if k in k2), None)
+                    entry = {"workload": describe(c2, chn), "value_MSps": round(L2 * a2.steps / dt2 / 1e6, 3),
+                             "ms_per_step": round(dt2 / a2.steps * 1e3, 4),
+                             "stage_ms": {k: round(v, 4) for k, v in st2.items()},
+                             "config": {"channeliser": chn, "taps": c2["T"] if chn == "fir" else None,
+                                        "channel_bins": 4096 // c2["D"] if chn == "fft" else None, "decimation": c2["D"],
+                                        "inspectors": len(fn2), "block_samples": L2, "psd_size": c2["psd"]}}
+                    if ck:
+                        entry["roofline"] = fir_stage_roofline(len(fn2), c2["D"], L2, k2[ck]["per_step"], ck, w, TIMING + " (in the pipeline)")
+                        entry["roofline"]["kernel_launches_ms"] = {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in k2.items()}
+                        try:                                  # the same kernel alone: this block size, and a 16 Mi-sample block
+                            for key, lg in (("fir_stage_alone", int(np.log2(L2))), ("fir_stage_16Mi_block", 24)):
+                                msa, ka = channeliser_alone(ctx, dev, fn2, c2["D"], c2["T"], chn, lg)
+                                if msa:
+                                    entry["roofline"][key] = fir_stage_roofline(len(fn2), c2["D"], 1 << lg, msa, ka, w, TIMING + " (the kernel alone, re-feeding one resident block)")
+                        except Exception as e:
+                            entry["roofline"]["fir_stage_16Mi_block"] = {"error": repr(e)}
+                    if label:
+                        extra.setdefault(w, {})[chn] = dict(entry, variant=label)
+                    else:
+                        extra[w] = entry
             extra["c5"] = run_c5(args, dev, ctx)
             try:                                              # the drop-in boundary itself, end to end (host thread, file source)
                 from sigdigger_amd.livebench import live_rate

@@ -497,6 +497,7 @@ bool chan_stream_feed(const ChanFeedArgs &a, const void *g2, hipStream_t st, hip
   const int TO = 128 * nw;
   sa.ntiles = (int)((a.n_out + TO - 1) / TO);
   sa.tiles_per_wg = (sa.ntiles + ncu - 1) / ncu;
+  if (const char *e = getenv("SUAMD_FIR_PAIR_TPW")) { const int v = atoi(e); if (v >= 1) sa.tiles_per_wg = v; }
   const unsigned grid = (unsigned)((sa.ntiles + sa.tiles_per_wg - 1) / sa.tiles_per_wg);
   sa.ts = (size_t)grid * sa.tiles_per_wg <= 4096 * 64 ? ts_buffer() : nullptr;
   const size_t lds = pbytes(nw);
