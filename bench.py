@@ -231,11 +231,8 @@ def pmc_traffic(kernel, workload, block):
     return best if best else (None, None)
 
 
-CHANNELISER_KERNELS = ("stx_kernel", "stp_kernel", "stw_kernel", "st_kernel", "chan_pair_kernel", "chan_fir_kernel")
+CHANNELISER_KERNELS = ("stp_kernel", "stw_kernel", "st_kernel", "chan_pair_kernel", "chan_fir_kernel")
 KERNELS = {
-    "stx_kernel": "stx_kernel (FFT channeliser for channels of 128 bins and more: the narrow kernels' 4096-pt forward transform -- two "
-                  "64-pt DFTs on registers around an LDS transposition, once per window for all channels --, inverse transform of a "
-                  "channel as 64-pt register DFTs in size / 64 lanes around one LDS exchange)",
     "stp_kernel": "stp_kernel (FFT channeliser, two wavefronts per window: 4096-pt forward FFT as two 64-pt DFTs on registers "
                   "around an LDS transposition, each DFT split between the wavefronts with one swap through LDS; lane = "
                   "channel: bin pick x response, 64-pt inverse FFT, cross-fade)",

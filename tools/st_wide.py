@@ -7,7 +7,7 @@ from sigdigger_amd import engine, synth
 ctx = engine.Context(0)
 L = 1 << 22
 x = torch.empty(L, dtype=torch.complex64, device="cuda"); torch.view_as_real(x).normal_()
-for C, D in ((1, 16), (16, 16), (64, 16), (1, 32), (32, 32), (1, 1), (1, 4)):
+for C, D in ((1, 16), (16, 16), (64, 16), (1, 32), (32, 32), (64, 32), (1, 1), (1, 4)):
     st = engine.SpectTuner(ctx, 4096)
     for f in synth.raster(C, 1.8 / max(C, 2)):
         st.open_channel(np.pi * f % (2 * np.pi), 2 * np.pi * 0.75 / D)
@@ -18,6 +18,7 @@ for C, D in ((1, 16), (16, 16), (64, 16), (1, 32), (32, 32), (1, 1), (1, 4)):
         st.feed(x, out=out)
     torch.cuda.synchronize(); engine.kernel_timing(False)
     r = engine.kernel_timing_read()
-    us = r["sum_ms"] / max(r["launches"], 1) * 1e3
-    print(f"C={C:3d} D={D:3d} ({4096 // D:4d} bins): {us:7.1f} us ({r['launches']} launches)")
+    us = r["sum_ms"] / 10 * 1e3
+    alg = 8 * L + 8 * C * L / D
+    print(f"C={C:3d} D={D:3d} ({4096 // D:4d} bins): {us:7.1f} us per feed ({r['launches']} launches)  {alg / us / 1e3:7.1f} GB/s = {alg / us / 8e6:.3f} of HBM peak")
     st.close()
