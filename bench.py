@@ -231,6 +231,14 @@ def pmc_traffic(kernel, workload, block):
     return best if best else (None, None)
 
 
+# The benched block: 16 Mi samples (0.34 s of a 50 MS/s stream) since round 4.  The sustained rate does not depend on it
+# (the step is the Costas recurrence: 809 / 813 / 815 MS/s at 4 / 8 / 16 Mi), the channeliser's and the PSD's launches
+# do: a 4 Mi block gives a workgroup three windows, so a launch's start (every workgroup's first 32 KiB at once), seam
+# hand-off and drain are a third of it; measured INSIDE the pipeline, same box, back to back (tools/block_sweep.sh,
+# profiles/r04_block_sweep.txt): channeliser 0.277 / 0.307 / 0.347 of the HBM peak, PSD 0.203 / 0.235 / 0.284.
+# `--block 22` is round 1-3's line; `roofline.fir_stage_alone` reports both sizes with the kernel alone.
+DEFAULT_LOG2_BLOCK = 24
+
 CHANNELISER_KERNELS = ("stp_kernel", "stw_kernel", "st_kernel", "chan_pair_kernel", "chan_fir_kernel")
 KERNELS = {
     "stp_kernel": "stp_kernel (FFT channeliser, two wavefronts per window: 4096-pt forward FFT as two 64-pt DFTs on registers "
@@ -413,11 +421,11 @@ def run_host_fed(name, args, dev, ctx):
             "pcie_GBps": round(8.0 * L * steps / dt / 1e9, 2)}
 
 
-def run_fir_stage_large_block(cfg, dev, ctx, fn_rank, log2_block=24):
-    """The FFT channeliser of the default workload on a 16 Mi-sample block (same 64 channels, same kernel): the 4 Mi block
-    of the headline gives a wavefront three windows, so its start (the first 32 KiB of every wavefront at once) and the
-    2-or-3-windows quantisation weigh a third of the launch; on a longer block they amortise.  Reported beside the
-    headline's `roofline`, never instead of it."""
+def run_fir_stage_alone(cfg, dev, ctx, fn_rank, log2_block):
+    """The FFT channeliser of the default workload alone (same 64 channels, same kernel, one resident block re-fed) on a
+    block of 2^log2_block samples.  A 4 Mi block gives a workgroup three windows, so its start (the first 32 KiB of every
+    workgroup at once) and the 2-or-3-windows quantisation weigh a third of the launch; on a longer block they amortise.
+    Reported beside the headline's `roofline` (the kernel inside the pipeline), never instead of it."""
     Lb, D = 1 << log2_block, cfg["D"]
     x = torch.empty(Lb, dtype=torch.complex64, device=dev)
     torch.view_as_real(x).normal_()
@@ -444,11 +452,12 @@ def run_fir_stage_large_block(cfg, dev, ctx, fn_rank, log2_block=24):
         nbytes = 8.0 * Lb + 8.0 * len(fn_rank) * Lb / D
         res[f"slots_{slots}"] = {"kernel_ms": round(ms, 4), "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1),
                                  "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-    best = res["slots_1024"]
+    best = res["slots_768"]
     return {"block_samples": Lb, "kernel_ms": best["kernel_ms"], "algorithmic_bytes_per_launch": nbytes,
             "achieved": best["achieved"], "unit": "GB/s", "frac": best["frac"], "plans": res,
-            "what": "the channeliser kernel alone on a 16 Mi-sample block (dispatch-bound event pairs); headline fields: the "
-                    "1024-slot plan (suamd_specttuner_set_slots, a tuner with the device to itself); `plans` also has the default 768"}
+            "what": "the channeliser kernel alone, one resident block re-fed (dispatch-bound event pairs); headline fields: the "
+                    "default 768-slot plan (what the pipeline runs); `plans` also has the 1024-slot plan of a tuner that has "
+                    "the device to itself (suamd_specttuner_set_slots)"}
 
 
 def run_c5(args, dev, ctx, log2_file=30, N=8192, tile=256):
@@ -531,14 +540,14 @@ def run_live_sharded(n_gpus, inspectors_per_gpu=64, nblocks=40, timeout_s=150):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # 600 steps (3 s timed): the three serial stages run as a pipeline over consecutive blocks, and the timed region pays
-    # its fill and drain once (~7 ms against 5.2 ms per step); and the chip needs seconds of load to settle its clocks
-    # (the slowest kernel alone goes 5.30 -> 5.19 -> 5.16 -> 5.14 ms per block over 100 / 300 / 600 / 1000 steps:
-    # 775 / 800 / 806 / 811 MS/s) -- a sustained-rate metric wants both amortised
-    ap.add_argument("--steps", type=int, default=600)
+    # 150 steps (3 s timed): the three serial stages run as a pipeline over consecutive blocks, and the timed region pays
+    # its fill and drain once (~1.3 steps); and the chip needs seconds of load to settle its clocks (4 Mi blocks: the
+    # slowest kernel alone goes 5.30 -> 5.19 -> 5.16 -> 5.14 ms per block over 0.5 / 1.5 / 3 / 5 s) -- a sustained-rate
+    # metric wants both amortised
+    ap.add_argument("--steps", type=int, default=150)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
-    ap.add_argument("--block", type=int, default=22, help="log2 of the IQ block length (samples)")
+    ap.add_argument("--block", type=int, default=DEFAULT_LOG2_BLOCK, help="log2 of the IQ block length (samples)")
     ap.add_argument("--channeliser", default="fft", choices=("fft", "fir"),
                     help="fft: the FFT filter bank with su_specttuner's semantics (what the reference runs behind its "
                          "channels); fir: translate + 255-tap direct-form low-pass + decimate")
@@ -711,7 +720,7 @@ def main():
                 variants = (("fir", "255-tap LPF (BASELINE.json configs[1])"), ("fft", "FFT filter bank")) if w == "c2" else ((args.channeliser, None),)
                 for chn, label in variants:
                     a2 = argparse.Namespace(**vars(args))
-                    a2.steps, a2.warmup, a2.channeliser = max(5, min(40, args.steps // 4)), 4, chn
+                    a2.steps, a2.warmup, a2.channeliser = max(5, min(20, args.steps // 4)), 3, chn
                     c2, L2, dt2, st2, fn2, pipe2 = run_workload(w, a2, 0, 1, dev, ctx, None)
                     k2 = getattr(pipe2, "kernel_ms", {})
                     ck = next((k for k in CHANNELISER_KERNELS if k in k2), None)
@@ -725,12 +734,15 @@ def main():
                         entry["roofline"] = fir_stage_roofline(len(fn2), c2["D"], L2, k2[ck]["per_step"], ck, w, TIMING + " (in the pipeline)")
                         entry["roofline"]["kernel_launches_ms"] = {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in k2.items()}
                         try:                                  # the same kernel alone: this block size, and a 16 Mi-sample block
-                            for key, lg in (("fir_stage_alone", int(np.log2(L2))), ("fir_stage_16Mi_block", 24)):
+                            lgs = sorted({int(np.log2(L2)), 22, 24})
+                            entry["roofline"]["fir_stage_alone"] = {}
+                            for lg in lgs:
                                 msa, ka = channeliser_alone(ctx, dev, fn2, c2["D"], c2["T"], chn, lg)
                                 if msa:
-                                    entry["roofline"][key] = fir_stage_roofline(len(fn2), c2["D"], 1 << lg, msa, ka, w, TIMING + " (the kernel alone, re-feeding one resident block)")
+                                    entry["roofline"]["fir_stage_alone"][f"{(1 << lg) >> 20}Mi"] = fir_stage_roofline(
+                                        len(fn2), c2["D"], 1 << lg, msa, ka, w, TIMING + " (the kernel alone, re-feeding one resident block)")
                         except Exception as e:
-                            entry["roofline"]["fir_stage_16Mi_block"] = {"error": repr(e)}
+                            entry["roofline"]["fir_stage_alone"] = {"error": repr(e)}
                     if label:
                         extra.setdefault(w, {})[chn] = dict(entry, variant=label)
                     else:
@@ -744,9 +756,10 @@ def main():
             out["host_fed"] = run_host_fed(args.workload, args, dev, ctx)
             if args.channeliser == "fft" and cfg["kind"] == "psk":
                 try:
-                    out["roofline"]["fir_stage_16Mi_block"] = run_fir_stage_large_block(cfg, dev, ctx, fn_rank)
+                    out["roofline"]["fir_stage_alone"] = {f"{(1 << lg) >> 20}Mi": run_fir_stage_alone(cfg, dev, ctx, fn_rank, lg)
+                                                          for lg in sorted({args.block, 22, 24})}
                 except Exception as e:
-                    out["roofline"]["fir_stage_16Mi_block"] = {"error": repr(e)}
+                    out["roofline"]["fir_stage_alone"] = {"error": repr(e)}
             out["other_workloads"] = extra
         if world > 1 and os.environ.get("SUAMD_BENCH_LIVE_SHARDED", "1") != "0" and not share:
             # the curve of the drop-in itself: the C++ analyzer sharded over the same N GPUs (the other ranks idle at the

@@ -482,12 +482,18 @@ bool chan_stream_feed(const ChanFeedArgs &a, const void *g2, hipStream_t st, hip
   static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   const int PP = 2 * D + pad_for(2 * D), HBP = hbp_for(D, a.ntaps);
   auto pbytes = [&](int w) { return (size_t)2 * PP * 8 + (size_t)(HBP + 64 * w) * PP * 8; };   // w wavefronts
-  // 8 wavefronts (1024 outputs per tile), fewer for short feeds or long filters.  Measured and NOT taken
-  // (profiles/r04_fir_stream_phases.txt): tiles of 512 outputs, two per CU on a 4 Mi-sample block so that the second one's
-  // read overlaps the first one's arithmetic -- 22 against 16 us; one wavefront per SIMD with two pair-blocks per lane
-  // (four fma chains on the same taps) -- 35 k against 20 k ticks per 1024 outputs, the compiler's SGPR spill code in its loop.
-  int nw = 8;
-  if (const char *e = getenv("SUAMD_FIR_PAIR_NW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) nw = v; }
+  // Long feeds (two or more 1024-output tiles per CU): 8 wavefronts, one persistent workgroup per CU streaming its run of
+  // tiles (the next tile's loads fly under the current tile's arithmetic).  Shorter feeds have nothing to stream -- a CU's
+  // share is a tile or two -- so they go out as independent tiles of 256 outputs (2 wavefronts, four workgroups per CU):
+  // the dispatcher overlaps one workgroup's loads with another's arithmetic, and a CU that is partly taken by other
+  // kernels (the recurrence stages of the previous blocks hold three for the whole step) costs a quarter tile, not a
+  // whole one.  C = 1, D = 16, T = 255, alone / behind the pipeline's other streams, 4 Mi samples: 19.9 / 31.0 us against
+  // 20.9 / 38.3 for the persistent shape; 8 Mi alone 45 against 40.5, 16 Mi 72 against 69 (profiles/r04_fir_stream_phases.txt).
+  // Measured and NOT taken: one wavefront per SIMD with two pair-blocks per lane (four fma chains on the same taps) --
+  // 35 k against 20 k ticks per 1024 outputs, the compiler's SGPR spill code in its loop.
+  int nw = 8, tpw = 0;
+  if (a.n_out < 2ll * 1024 * ncu) { nw = 2; tpw = 1; }
+  if (const char *e = getenv("SUAMD_FIR_PAIR_NW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) { nw = v; tpw = 0; } }
   while (nw > 1 && a.n_out < 128ll * nw) nw >>= 1;
   while (nw > 1 && pbytes(nw) > 160 * 1024) nw >>= 1;
   if (pbytes(nw) > 160 * 1024 || HBP > 64 || HBP > 64 * nw || a.n_out < 128 * nw) return false;
@@ -496,7 +502,8 @@ bool chan_stream_feed(const ChanFeedArgs &a, const void *g2, hipStream_t st, hip
   { const char *e = getenv("SUAMD_FIR_STREAM_DBG"); sa.dbg = e ? atoi(e) : 0; }
   const int TO = 128 * nw;
   sa.ntiles = (int)((a.n_out + TO - 1) / TO);
-  sa.tiles_per_wg = (sa.ntiles + ncu - 1) / ncu;
+  const int slots = ncu * (8 / nw);                              // resident workgroups: 8 wavefronts and the LDS of one CU
+  sa.tiles_per_wg = tpw ? tpw : (sa.ntiles + slots - 1) / slots;
   if (const char *e = getenv("SUAMD_FIR_PAIR_TPW")) { const int v = atoi(e); if (v >= 1) sa.tiles_per_wg = v; }
   const unsigned grid = (unsigned)((sa.ntiles + sa.tiles_per_wg - 1) / sa.tiles_per_wg);
   sa.ts = (size_t)grid * sa.tiles_per_wg <= 4096 * 64 ? ts_buffer() : nullptr;

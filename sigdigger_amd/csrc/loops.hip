@@ -529,15 +529,15 @@ __global__ __launch_bounds__(256) void agc_peak1_kernel(const float *__restrict_
                                                         long long len, int H, float *__restrict__ peak)
 {
   __builtin_amdgcn_s_setprio(3);
-  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (m >= len) return;
-  float pk = db[m];
-  for (int i = 1; i < H; ++i) {
-    const long long q = m - i;
-    const float v = q >= 0 ? db[q] : hist[q + (H - 1)];
-    pk = pk > v ? pk : v;
+  for (long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x; m < len; m += (long long)gridDim.x * blockDim.x) {
+    float pk = db[m];
+    for (int i = 1; i < H; ++i) {
+      const long long q = m - i;
+      const float v = q >= 0 ? db[q] : hist[q + (H - 1)];
+      pk = pk > v ? pk : v;
+    }
+    peak[m] = pk;
   }
-  peak[m] = pk;
 }
 
 // (1)+(2) for the items of a gang: a workgroup takes tiles of 256 outputs of its item, stages the 256 + H - 1

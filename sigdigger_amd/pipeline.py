@@ -12,6 +12,9 @@ import torch
 from . import engine
 
 
+_STAGE_STREAMS = {}
+
+
 class InspectorBankConfig:
     """Parameters shared by the inspectors of one bank (one decimation)."""
 
@@ -101,9 +104,13 @@ class AnalyzerPipeline:
             self.clock = engine.ClockBank(ctx, self.nchan, bank.clock_gain, 1.0 / bank.sps)
         self.host_sym = None
         if overlap:
-            self.s_agc = torch.cuda.Stream(self.dev)
-            self.s_dem = torch.cuda.Stream(self.dev)      # Costas / quad demod
-            self.s_clk = torch.cuda.Stream(self.dev)
+            # one set of stage streams per device, shared by every pipeline of the process: HIP spreads its streams over
+            # four hardware queues, and a second pipeline with streams of its own would have two of its stages behind
+            # one queue (bench.py builds C2 / C3 after the default workload: their kernels ran 2-3 x slower for it)
+            key = str(self.dev)
+            if key not in _STAGE_STREAMS:
+                _STAGE_STREAMS[key] = tuple(torch.cuda.Stream(self.dev) for _ in range(3))
+            self.s_agc, self.s_dem, self.s_clk = _STAGE_STREAMS[key]      # AGC; Costas / quad demod; clock recovery
         self.done = {}                         # (stage, block index) -> event
         self.ev = {}                           # per-stage timing events
 

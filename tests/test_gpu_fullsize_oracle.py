@@ -150,7 +150,7 @@ def test_two_rank_shards_on_one_gpu_equal_the_single_rank_pipeline(ctx, channeli
 @pytest.mark.parametrize("workload", ["c4", "c3", "c2"])
 def test_the_pipeline_as_bench_py_builds_it_is_exact_end_to_end(ctx, sdo, workload):
     """VERDICT r2 #1.  The bench's DEFAULT path -- pipeline.AnalyzerPipeline with channeliser="fft", constructed with
-    bench.py's own WORKLOADS table, block generator and block length (4 Mi samples) -- over two consecutive blocks
+    bench.py's own WORKLOADS table, block generator and default block length (16 Mi samples since round 4) -- over two consecutive blocks
     (the second one starts from carried state: history, cross-fade partners, every loop):
       * every channel row out of the FFT channeliser equals the oracle's binary32 statement BIT FOR BIT (64 of 64 rows);
       * the oracle's AGC -> Costas -> Gardner (quad demod -> Gardner for c3) on those rows equals the recovered
@@ -159,7 +159,7 @@ def test_the_pipeline_as_bench_py_builds_it_is_exact_end_to_end(ctx, sdo, worklo
     import os
     import bench
     cfg = bench.WORKLOADS[workload]
-    Lb = 1 << 22
+    Lb = 1 << bench.DEFAULT_LOG2_BLOCK
     fn = synth.raster(cfg["per_gpu"], cfg["spacing"])
     Dd, sps = cfg["D"], cfg["sps_in"] / cfg["D"]
     bank = pipeline.InspectorBankConfig(kind=cfg["kind"], fnor=fn, decimation=Dd, ntaps=cfg["T"], sps=sps, channeliser="fft")
@@ -199,3 +199,39 @@ def test_the_pipeline_as_bench_py_builds_it_is_exact_end_to_end(ctx, sdo, worklo
             # ... and what reached pinned host memory inside the bench's timed region is that
             n = min(int(hcnt[c]), hsym.shape[1])
             assert int(hcnt[c]) == rs.size and np.array_equal(bits(hsym[c, :n].numpy()), bits(rs[:n]))
+
+
+@pytest.mark.parametrize("nchan", [1, 2])
+def test_c2_fir_stage_at_the_benched_block_size_equals_the_oracle(ctx, sdo, monkeypatch, nchan):
+    """BASELINE configs[1] as written -- translate + 255-tap low-pass, D = 16 -- on bench.py's block (16 Mi samples) and the
+    next, ragged one: long feeds take the persistent shape of chan_pair_kernel (runs of 1024-output tiles per workgroup,
+    history handed on inside the LDS), which the small parity cases only reach through SUAMD_FIR_PAIR_NW.  Every output of
+    both feeds against the oracle's fma chain, bit for bit, and against chan_fir_kernel (SUAMD_FIR_STREAM=0)."""
+    import bench
+    from sigdigger_amd import engine
+    D, T, Lb = 16, 255, 1 << bench.DEFAULT_LOG2_BLOCK
+    cuts = [0, Lb, Lb + (1 << 21) + 12345]
+    rng = np.random.default_rng(77)
+    x = np.empty(cuts[-1], dtype=np.complex64)
+    x.real = rng.standard_normal(cuts[-1], dtype=np.float32)
+    x.imag = rng.standard_normal(cuts[-1], dtype=np.float32)
+    fn = [0.25, -0.4][:nchan]
+    taps = sdo.lpf_design(T, 0.75 / D)
+    xd = torch.from_numpy(x).cuda()
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SUAMD_FIR_STREAM", mode)
+        bank = engine.ChannelBank(ctx, fn, D, taps)
+        got = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            out = torch.empty((nchan, bank.output_count(b - a) + 3), dtype=torch.complex64, device="cuda")
+            got.append(bank.feed(xd[a:b], out=out).cpu().numpy())
+        res[mode] = np.concatenate(got, axis=1)
+    monkeypatch.delenv("SUAMD_FIR_STREAM")
+    assert np.array_equal(bits(res["1"]), bits(res["0"])), "stream kernel vs tiled kernel"
+    for c, f in enumerate(fn):
+        dp = sdo.fnor_to_dphase(-f)
+        g = sdo.chan_modulate_taps(taps, dp)
+        ref = sdo.chan_feed(np.zeros(T - 1, dtype=np.complex64), x, 0, g, D, 0, dp)
+        assert ref.size == res["1"].shape[1] == (cuts[-1] + D - 1) // D
+        assert np.array_equal(bits(res["1"][c]), bits(ref)), f"channel {c} vs the oracle"

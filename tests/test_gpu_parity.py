@@ -340,30 +340,39 @@ def test_chanbank_bit_exact(ctx, sdo, nchan, D, T):
 @pytest.mark.parametrize("nchan,D,T", [(1, 16, 255), (2, 16, 255), (1, 8, 255), (1, 32, 255), (1, 64, 255), (2, 64, 129),
                                        (1, 16, 16), (1, 16, 7), (1, 16, 1), (1, 16, 1023), (2, 32, 64), (1, 8, 33)])
 def test_chanbank_stream_kernel_equals_the_tiled_one_and_the_oracle(ctx, sdo, monkeypatch, nchan, D, T):
-    """chan_stream.hip (one or two channels: persistent workgroups, LDS-DMA ring, scalar taps) against chan_fir_kernel
+    """chan_stream.hip (one or two channels, lane = two adjacent outputs, scalar taps) against chan_fir_kernel
     (SUAMD_FIR_STREAM=0) bit for bit -- feeds of ragged sizes (a tile boundary inside, a feed shorter than a tile, an
-    odd start so that the first history pair straddles hist / x), both layouts -- and against the oracle on the head."""
+    odd start so that the first history pair straddles hist / x), both layouts, and each tile shape the dispatch can pick:
+    its own choice for these lengths (independent 256-output tiles), the persistent 1024-output stream of long feeds
+    (SUAMD_FIR_PAIR_NW=8: runs of tiles with the history handed on inside the LDS) and the 512-output one -- and against
+    the oracle on the head."""
     n = 300000
     fn = [0.25, -0.4][:nchan]
     x = synth.psk_carriers(n, fn, sps=max(D // 2, 4), seed=T + D)
     taps = sdo.lpf_design(T, 0.8 / D)
     cuts = [0, 70001, 70002, 70002 + 64 * 8 * D + 3, 200000 - 1, n]
     res = {}
-    for mode in ("1", "0"):
+    for mode, nw in (("1", None), ("1", "8"), ("1", "4"), ("0", None)):
         monkeypatch.setenv("SUAMD_FIR_STREAM", mode)
+        if nw:
+            monkeypatch.setenv("SUAMD_FIR_PAIR_NW", nw)
+        else:
+            monkeypatch.delenv("SUAMD_FIR_PAIR_NW", raising=False)
         for layout in ("cm", "tm"):
             bank = engine.ChannelBank(ctx, fn, D, taps)
             got = []
             for a, b in zip(cuts[:-1], cuts[1:]):
                 out = empty_rows(nchan, bank.output_count(b - a) + 3, layout)
                 got.append(host(bank.feed(dev(x[a:b]), out=out)))
-            res[mode, layout] = np.concatenate(got, axis=1)
+            res[mode, nw, layout] = np.concatenate(got, axis=1)
     monkeypatch.delenv("SUAMD_FIR_STREAM")
+    monkeypatch.delenv("SUAMD_FIR_PAIR_NW", raising=False)
     for layout in ("cm", "tm"):
-        assert_bits(res["1", layout], res["0", layout], f"stream vs tiled kernel ({layout})")
+        for nw in (None, "8", "4"):
+            assert_bits(res["1", nw, layout], res["0", None, layout], f"stream (NW = {nw or 'auto'}) vs tiled kernel ({layout})")
     ref = _oracle_bank(sdo, x[:80000], fn, D, taps, [(0, 80000)])
     for c in range(nchan):
-        assert_bits(res["1", "cm"][c, :len(ref[c])], ref[c], f"stream kernel channel {c} vs oracle")
+        assert_bits(res["1", None, "cm"][c, :len(ref[c])], ref[c], f"stream kernel channel {c} vs oracle")
 
 
 def test_chanbank_gang_bit_exact(ctx, sdo):
@@ -547,6 +556,21 @@ def test_agc_bank_bit_exact(ctx, sdo, layout):
     for c in range(nchan):
         st = sdo.agc_new(sdo.agc_params_from_tau(16.0))
         assert_bits(got[c], sdo.agc_feed_bulk(st, x[c]), f"agc ch {c}")
+
+
+@pytest.mark.parametrize("nchan", [1, 2])
+def test_agc_rows_longer_than_the_launch_grid(ctx, sdo, nchan):
+    """rows of 2^20 + 3 samples: more than grid_for()'s 2048 workgroups x 256 threads cover in one pass, so every AGC
+    kernel must stride (the single-channel peak kernel of rounds 1-3 did not: rows beyond 524288 samples kept stale
+    peaks -- found by running C2 on the bench's 16 Mi-sample block)"""
+    n = (1 << 20) + 3
+    rng = np.random.default_rng(11)
+    x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * np.repeat(np.array([0.02, 1.0, 0.2, 3.0]), n // 4 + 1)[:n]).astype(np.complex64)
+    xx = np.stack([x * (1 + c) for c in range(nchan)]).astype(np.complex64)
+    bank = engine.AGCBank(ctx, nchan, tau=5.0)
+    got = host(bank.feed(dev_rows(xx, "tm"), out=empty_rows(nchan, n, "tm")))
+    for c in range(nchan):
+        assert_bits(got[c], sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(5.0)), xx[c]), f"agc ch {c} of {nchan}")
 
 
 def test_psk_inspector_chain_end_to_end(ctx, sdo):

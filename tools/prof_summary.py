@@ -14,7 +14,7 @@ def short(name):
     return re.sub(r"\(.*$", "", name)
 
 
-OURS = re.compile(r"^(st_kernel|stw_kernel|stp_kernel|chandet_|audio_|psd_|psdl_|chan_fir|costas_|clock_|agc_|pll_|quad_|xlate_|modulate_|update_hist|interpolate_|sweep_linear|"
+OURS = re.compile(r"^(st_kernel|stw_kernel|stp_kernel|chandet_|audio_|psd_|psdl_|chan_fir|chan_pair|costas_|clock_|agc_|pll_|quad_|xlate_|modulate_|update_hist|interpolate_|sweep_linear|"
                   r"feed_|fft_pass|frame_|window_pad|power_argmax|centroid|ingest|rows_|cma_|zc_|conj_prev|fac_|"
                   r"histogram_|delayed_|sample_manual|averager_|insp_spectrum|psd_shift)")
 stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
@@ -29,15 +29,8 @@ try:
     bj = json.loads(bench_line)
 except Exception:
     bj = None
+block = bj["config"]["block_samples"] if bj else None
 with open(os.path.join(prof, f"{tag}_kernel_stats_summary.md"), "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats, {tag} (MI355X)\n\n")
-    f.write("`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-extra --no-cpu-baseline` "
-            "(tools/profile_round.sh): the default workload (C4 slice: 8192-pt PSD + 64 QPSK inspectors, 4 Mi-sample blocks, "
-            "20 steps + 3 warm-up). Our kernels only; the full table (with torch's synthetic-data kernels) is "
-            f"`{tag}_kernel_stats.csv`.\n\n")
-    if bj:
-        f.write(f"Bench line under the profiler: value = {bj['value']} MS/s, stage_ms = {bj['roofline']['stage_ms']}.\n\n")
-    f.write("| kernel | calls | avg us | min us | max us | % of GPU time |\n|---|---|---|---|---|---|\n")
     def table(rws):
         f.write("| kernel | calls | avg us | min us | max us | % of GPU time |\n|---|---|---|---|---|---|\n")
         for r in rws:
@@ -46,12 +39,11 @@ with open(os.path.join(prof, f"{tag}_kernel_stats_summary.md"), "w") as f:
                 continue
             f.write(f"| {n} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
                     f"{float(r['MaxNs'])/1e3:.1f} | {r['Percentage']} |\n")
-    f.seek(0); f.truncate()
     f.write(f"# rocprofv3 --kernel-trace --stats, {tag} (MI355X)\n\n")
-    f.write("`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-extra --no-cpu-baseline` "
-            "(tools/profile_round.sh): the default workload (C4 slice: 8192-pt PSD + 64 QPSK inspectors, 4 Mi-sample blocks, "
-            "20 steps + 3 warm-up). Our kernels only; the full table (with torch's synthetic-data kernels) is "
-            f"`{tag}_kernel_stats.csv`.\n\n")
+    f.write("`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-extra --no-cpu-baseline`\n"
+            "(tools/profile_round.sh): the default workload (C4 slice: 8192-pt PSD + 64 QPSK inspectors; "
+            f"{block} samples per block, {bj['steps'] if bj else '?'} steps + {bj['warmup'] if bj else '?'} warm-up).\n"
+            f"Our kernels only; the full table (with torch's synthetic-data kernels) is `{tag}_kernel_stats.csv`.\n\n")
     if bj:
         f.write(f"Bench line under the profiler: value = {bj['value']} MS/s, stage_ms = {bj['roofline']['stage_ms']}.\n\n")
     table(rows)
@@ -60,8 +52,9 @@ with open(os.path.join(prof, f"{tag}_kernel_stats_summary.md"), "w") as f:
     stats_all = glob.glob(os.path.join(out, "trace_all", "**", "*kernel_stats.csv"), recursive=True)
     if stats_all:
         f.write("\n## with the secondary workloads (C2, C3, C5 and the live analyzer with 64 inspectors after the default one)\n\n"
-                "Same command without `--no-extra`; kernels shared by several workloads aggregate all of them "
-                "(psd_kernel<13, 256, true> is C5's 8.6 GB launch, stp_kernel<6, true, .> includes the bench's 16 Mi-block launches, the recurrence kernels C2's 16x longer rows).\n\n")
+                "Same command without `--no-extra`; kernels shared by several workloads aggregate all of them\n"
+                "(psd_kernel<13, 256, true> is C5's 8.6 GB launch, stp_kernel<6, true, .> includes the bench's launches of the\n"
+                "kernel alone on 4 Mi and 16 Mi blocks, the recurrence kernels C2's 16x longer rows).\n\n")
         table(list(csv.DictReader(open(stats_all[0]))))
 
 # PMC traffic: per kernel, average FETCH_SIZE / WRITE_SIZE (KiB) over launches
@@ -111,7 +104,7 @@ doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
        "units": "counter values are KiB; per-launch averages; HBM bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 "
                 "(FETCH_SIZE counts half of the streamed bytes on gfx950, see calibration)",
        "calibration": old.get("calibration") or _prev_calibration(),
-       "workload": {"name": "c4", "block_samples": 4194304},
+       "workload": {"name": "c4", "block_samples": block},
        "kernels_by_grid": res}
 doc["kernels"] = best
 json.dump(doc, open(p_old, "w"), indent=1)

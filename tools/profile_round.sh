@@ -20,6 +20,9 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err
 python bench.py --no-extra --no-cpu-baseline --isolated > $OUT/bench_isolated.json 2>> $OUT/bench.err
 python tools/st_bench.py > $OUT/kernel_microbench.txt 2>&1
 python tools/fir_bench.py >> $OUT/kernel_microbench.txt 2>&1
+python tools/fir_c1.py >> $OUT/kernel_microbench.txt 2>&1
+SUAMD_FIR_STREAM=0 python tools/fir_c1.py >> $OUT/kernel_microbench.txt 2>&1
+python tools/st_wide.py >> $OUT/kernel_microbench.txt 2>&1
 python tools/psd_bench.py >> $OUT/kernel_microbench.txt 2>&1
 bash tools/st_pmc.sh > $OUT/st_sq_counters.txt 2>&1
 python tools/psd_large.py > $OUT/psd_large_frames.txt 2>&1
