@@ -142,6 +142,7 @@ struct SizeGroup {
   sdk::StChan *d_chans = nullptr;
   c32 *d_hk = nullptr, *d_tw = nullptr;
   c32 *d_hkt = nullptr;                // per-channel responses, [block of 64 channels][bin][lane] (wavefront kernel)
+  size_t hkt_blocks = 0;               // blocks in d_hkt (whole wavefronts' worth)
   c32 *d_handoff = nullptr;            // wavefront kernel: seam payload between consecutive runs, 16 KiB per run and block
   unsigned *d_flags = nullptr;         // one flag per run and block: the epoch of the launch that published it
   size_t ho_slots = 0;
@@ -306,8 +307,15 @@ bool rebuild_group(suamd_specttuner *st, SizeGroup &g, const std::vector<int> &o
   g.d_chans = dev_upload_new(tab);
   g.d_hk = dev_upload_new(hk);
   if (wave) {
-    const size_t nblk = (n + 63) / 64;
-    std::vector<c32> hkt(std::max<size_t>(1, nblk) * S * 64, c32{0.f, 0.f});
+    // stw_kernel reads one [bin][lane] block per lane group: a wavefront of channels below 64 bins serves 64 / S groups of 64
+    // channels, and EVERY group's block is loaded whether or not its channels exist (the buffer descriptor bounds one block,
+    // not the table) -- so the table holds whole wavefronts' worth.  Rounds 2-3 sized it ceil(n / 64): a bank of fewer than
+    // 64 * 64 / S narrow channels with per-channel responses was read up to 28 KiB beyond its end, a fault whenever the
+    // table happened to end a mapped region (found with eight analyzer shards on one device, tools/live_fault_repro.py).
+    const size_t per_wave = sdk::stw_channels_per_wave(g.log2s) / 64;
+    const size_t nblk = std::max<size_t>(1, (n + 64 * per_wave - 1) / (64 * per_wave)) * per_wave;
+    g.hkt_blocks = nblk;
+    std::vector<c32> hkt(nblk * S * 64, c32{0.f, 0.f});
     for (size_t k = 0; k < n; ++k)
       for (unsigned i = 0; i < S; ++i) hkt[((k >> 6) * S + i) * 64 + (k & 63)] = hk[(size_t)tab[k].hsel * S + i];
     g.d_hkt = dev_upload_new(hkt);
@@ -537,6 +545,10 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
         // 32 us on an idle chip and 56 us inside the pipeline.  3/4 of the slots: 683 wavefronts of 3 windows for a
         // 4 Mi-sample block.
         a.hkt = g.d_hkt;
+        {
+          const size_t cpw = (size_t)sdk::stw_channels_per_wave(g.log2s);
+          if (g.hkt_blocks < (g.members.size() + cpw - 1) / cpw * (cpw / 64)) { suamd_set_error("internal: response table smaller than the launch"); return SU_FALSE; }
+        }
         a.hk_uniform = g.hk_uniform ? 1 : 0;
         a.nsel = g.nsel;
         {

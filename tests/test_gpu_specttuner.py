@@ -441,3 +441,24 @@ def test_row_tables_with_32_bit_offsets_give_the_same_samples(ctx, dec):
         assert outs["view"][c].size == x.size // dec - (W // dec) // 2, c
         assert np.array_equal(outs["view"][c].view(np.uint32), outs["rows"][c].view(np.uint32)), (dec, c)
         assert np.array_equal(outs["view"][c].view(np.uint32), outs["near"][c].view(np.uint32)), (dec, c)
+
+
+@pytest.mark.parametrize("dec,nch", [(512, 5), (512, 64), (256, 70), (128, 3)])
+def test_few_narrow_channels_with_their_own_responses_on_the_one_wavefront_kernel(ctx, monkeypatch, dec, nch):
+    """A bank far smaller than one wavefront serves (64 lanes x dec / 64 channels) with a pass-band width per channel, kept on
+    the one-wavefront kernel: it loads a response block for EVERY lane group, present or not, so the [block][bin][lane]
+    table must hold whole wavefronts' worth.  Rounds 2-3 sized it by the channel count -- an over-read of up to 28 KiB that
+    faulted when the table ended a mapped region (eight analyzer shards on one device).  suamd_specttuner_feed now checks
+    the table against the launch; the samples equal the two-wavefront kernel's (tables in LDS) bit for bit."""
+    x = cnoise(H * 40, 4242)
+    widths = np.linspace(0.35, 0.9, 7)
+    chans = [(0.1 + 6.0 * c / nch, 2 * np.pi / dec * float(widths[c % 7]), 1.0, bool(c % 3 == 0)) for c in range(nch)]
+    monkeypatch.setenv("SUAMD_ST_KERNEL", "wave")
+    one = run_gpu(ctx, x, chans, splits=[H * 13])
+    monkeypatch.setenv("SUAMD_ST_Y32", "0")
+    one64 = run_gpu(ctx, x, chans, splits=[H * 13])
+    monkeypatch.delenv("SUAMD_ST_Y32")
+    monkeypatch.delenv("SUAMD_ST_KERNEL")
+    two = run_gpu(ctx, x, chans, splits=[H * 13])
+    for a, b, c in zip(one, one64, two):
+        assert a.size > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(a.view(np.uint32), c.view(np.uint32))
