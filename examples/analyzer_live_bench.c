@@ -1,20 +1,22 @@
 /* examples/analyzer_live_bench.c -- throughput of the live path from plain C: what sigdigger_amd/livebench.py measures
  * through ctypes, with a C consumer thread instead of a Python one, so that the figure describes the LIBRARY (the sharded
  * analyzer behind suscan_analyzer_*: SUAMD_DEVICES=0,1,...) and not the interpreter that reads its queue.  N heterogeneous
- * PSK inspectors (own carrier / bandwidth / baud / Costas order / loop bandwidth: Default/GenericInspector/InspectorCtl/*.cpp
+ * PSK inspectors (own carrier / bandwidth / baud / Costas order / loop bandwidth: Default/GenericInspector/InspectorCtl/ sources
  * vocabulary), a looping capture in the page cache, unthrottled; one message per inspector and block is read, counted and
  * disposed (Suscan/Analyzer.cpp:63-103).
  *
  *   gcc -O2 -std=c99 examples/analyzer_live_bench.c -Iinclude -Lsigdigger_amd -lsigdigger_amd \
  *       -Wl,-rpath,$PWD/sigdigger_amd -lm -o analyzer_live_bench
- *   SUAMD_DEVICES=0,1,2,3,4,5,6,7 SUAMD_ANALYZER_BCAST=rccl ./analyzer_live_bench capture.raw 512 60
- * prints one JSON line. */
+ *   SUAMD_DEVICES=0,1,2,3,4,5,6,7 SUAMD_ANALYZER_BCAST=rccl ./analyzer_live_bench capture.raw 512 60 [class]
+ * prints one JSON line.  class: psk (default) or raw -- channel samples without a demodulator chain behind them, i.e. next to no
+ * GPU work per message: what the source thread, the queue and this consumer sustain by themselves. */
 #define _POSIX_C_SOURCE 200809L
 #include <suscan_amd.h>
 
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <time.h>
 
 static double now_s(void)
@@ -37,7 +39,10 @@ int main(int argc, char **argv)
   double t0 = 0, spacing, dt = 0, worker = 0;
   int running = 1, measuring = 0, done = 0;
 
-  if (argc < 4) { fprintf(stderr, "usage: %s capture.raw inspectors blocks\n", argv[0]); return 2; }
+  const char *cls = argc > 4 ? argv[4] : "psk";
+  const int psk = strcmp(cls, "psk") == 0;
+
+  if (argc < 4) { fprintf(stderr, "usage: %s capture.raw inspectors blocks [psk|raw]\n", argv[0]); return 2; }
   n_insp = (unsigned)atoi(argv[2]);
   nblocks = (unsigned)atoi(argv[3]);
   if (!suscan_mq_init(&mq)) return 1;
@@ -58,7 +63,7 @@ int main(int argc, char **argv)
     const double fc = ((double)k - 0.5 * (double)n_insp + 0.5) * spacing;
     const double bw = (100e3 + 10e3 * (double)(k % 7)) * spacing / 300e3;
     ch.fc = fc; ch.f_lo = fc - bw / 2; ch.f_hi = fc + bw / 2; ch.bw = (SUFLOAT)bw; ch.ft = 100e6;
-    if (!suscan_analyzer_open_ex_async(an, "psk", &ch, SU_TRUE, -1, 1000 + k)) return 1;
+    if (!suscan_analyzer_open_ex_async(an, cls, &ch, SU_TRUE, -1, 1000 + k)) return 1;
   }
   while (running) {
     uint32_t type = 0;
@@ -71,7 +76,9 @@ int main(int argc, char **argv)
         struct suscan_analyzer_inspector_msg *m = msg;
         if (m->kind == SUSCAN_ANALYZER_INSPECTOR_MSGKIND_OPEN) {
           const unsigned i = m->req_id - 1000;
-          suscan_config_t *c2 = suscan_config_dup(m->config);
+          suscan_config_t *c2;
+          if (!psk) { ++configured; break; }
+          c2 = suscan_config_dup(m->config);
           suscan_config_set_integer(c2, "afc.costas-order", 1 + i % 3);
           suscan_config_set_float(c2, "afc.loop-bw", (SUFLOAT)(50.0 + 5.0 * (double)(i % 11)));
           suscan_config_set_integer(c2, "clock.type", 1);
@@ -105,9 +112,9 @@ int main(int argc, char **argv)
   suscan_analyzer_destroy(an);
   suscan_mq_finalize(&mq);
   if (!done) { printf("{\"error\": \"halted before the measurement finished (%u of %u inspectors configured)\"}\n", configured, n_insp); return 1; }
-  printf("{\"consumer\": \"C (examples/analyzer_live_bench.c)\", \"inspectors\": %u, \"blocks\": %u, \"block_samples\": %lu, "
+  printf("{\"consumer\": \"C (examples/analyzer_live_bench.c)\", \"class\": \"%s\", \"inspectors\": %u, \"blocks\": %u, \"block_samples\": %lu, "
          "\"value_MSps\": %.3f, \"ms_per_block\": %.4f, \"worker_MSps\": %.3f, \"symbols_Msps\": %.3f, \"sample_messages_per_s\": %.0f}\n",
-         n_insp, nblocks, block, (double)nblocks * (double)block / dt / 1e6, dt / nblocks * 1e3, worker / 1e6,
+         cls, n_insp, nblocks, block, (double)nblocks * (double)block / dt / 1e6, dt / nblocks * 1e3, worker / 1e6,
          (double)symbols / dt / 1e6, (double)samples_msgs / dt);
   return 0;
 }

@@ -333,8 +333,42 @@ struct Source {
   ~Source() { if (fp) std::fclose(fp); }
 };
 
+// The inspectors' sample rows (channel samples, gain-controlled, carrier-corrected, symbols: four per slot and inspector) come
+// out of slabs of one allocation each, per shard: the narrow-channel kernels address every row of a launch with 32-bit offsets
+// from the lowest one when they all start within ~1.75 GiB (suamd_specttuner_feed_rows_near), and rows that are hipMalloc'ed
+// one by one are only that close while nothing else allocates on the device (bench.py's live64 line behind 16 Mi-sample
+// pipelines, eight shards on one device: spans beyond 2 GiB, the 64-bit kernels, 2.9 instead of 2.0 ms per block).  Freed rows
+// go to a free list by size (an analyzer's inspectors use a handful of sizes); slabs go back to the device with the shard.
+struct RowArena {
+  struct Slab { char *base; size_t size, head; };
+  std::vector<Slab> slabs;
+  std::map<size_t, std::vector<void *>> spare;
+  static size_t rounded(size_t bytes) { return (bytes + 4095) & ~(size_t)4095; }
+  void *take(size_t bytes)
+  {
+    bytes = rounded(bytes);
+    auto it = spare.find(bytes);
+    if (it != spare.end() && !it->second.empty()) { void *p = it->second.back(); it->second.pop_back(); return p; }
+    for (Slab &sl : slabs)
+      if (sl.head + bytes <= sl.size) { void *p = sl.base + sl.head; sl.head += bytes; return p; }
+    const size_t want = std::max<size_t>((size_t)256 << 20, 4 * bytes);
+    char *base = nullptr;
+    if (hipMalloc((void **)&base, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    slabs.push_back(Slab{base, want, bytes});
+    return base;
+  }
+  // (the caller has made sure nothing in flight still touches the row: free_rows synchronises, as hipFree did)
+  void give(void *p, size_t bytes) { if (p) spare[rounded(bytes)].push_back(p); }
+  void release()
+  {
+    for (Slab &sl : slabs) (void)hipFree(sl.base);
+    slabs.clear(); spare.clear();
+  }
+};
+
 struct Inspector {
   SUHANDLE handle;
+  RowArena *arena = nullptr;                  // the shard's row slabs (null: plain allocations)
   uint32_t inspector_id = 0;
   std::string cls;
   struct sigutils_channel channel;
@@ -449,8 +483,13 @@ struct Inspector {
   }
   void free_rows()
   {
+    if (arena && cap) (void)hipDeviceSynchronize();            // launches still in flight read and write these rows
     for (Slot &s : slot) {
-      for (void *p : {(void *)s.d_y, (void *)s.d_a, (void *)s.d_z, (void *)s.d_sym, (void *)s.d_count}) if (p) (void)hipFree(p);
+      for (void *p : {(void *)s.d_y, (void *)s.d_a, (void *)s.d_z, (void *)s.d_sym}) {
+        if (!p) continue;
+        if (arena) arena->give(p, cap * 8); else (void)hipFree(p);
+      }
+      if (s.d_count) (void)hipFree(s.d_count);
       if (s.h_out) (void)hipHostFree(s.h_out);
       s.d_y = s.d_a = s.d_z = s.d_sym = s.h_out = nullptr; s.d_count = nullptr;
     }
@@ -563,6 +602,7 @@ struct suscan_analyzer {
   suamd_complex **d_rowptr[2] = {nullptr, nullptr};   // per slot: where each FFT channel's row starts (device table)
   suamd_complex **h_rowptr[2] = {nullptr, nullptr};   // pinned staging, and what the device table holds
   size_t rowptr_cap = 0;
+  RowArena rows;                              // the inspectors' sample rows (one slab: rows near each other)
   std::map<SUHANDLE, std::unique_ptr<Inspector>> inspectors;
   hipStream_t stream = nullptr;
   static constexpr int NISTREAMS = 4;          // gain control / carrier control / clock recovery / channeliser (+ spectra, estimators)
@@ -661,14 +701,20 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
   if (need > in.cap) {
     in.free_rows();
     bool ok = true;
+    in.arena = &a->rows;
+    in.cap = need;                                       // (free_rows hands rows back by this size)
+    static const bool poison = std::getenv("SUAMD_ANALYZER_POISON_ROWS") != nullptr;   // debug: rows start as NaNs, not as whatever was there
+    auto row = [&](suamd_complex **p) {
+      *p = static_cast<suamd_complex *>(a->rows.take(need * 8));
+      if (*p && poison) (void)hipMemset(*p, 0xff, need * 8);
+      return *p != nullptr;
+    };
     for (Inspector::Slot &sl : in.slot)
-      ok = ok && hipMalloc((void **)&sl.d_y, need * 8) == hipSuccess && hipMalloc((void **)&sl.d_a, need * 8) == hipSuccess &&
-           hipMalloc((void **)&sl.d_z, need * 8) == hipSuccess && hipMalloc((void **)&sl.d_sym, need * 8) == hipSuccess &&
+      ok = ok && row(&sl.d_y) && row(&sl.d_a) && row(&sl.d_z) && row(&sl.d_sym) &&
            hipMalloc((void **)&sl.d_count, 4) == hipSuccess &&
            hipHostMalloc((void **)&sl.h_out, need * 8, hipHostMallocMapped) == hipSuccess;
     if (ok && !in.d_prev) ok = hipMalloc((void **)&in.d_prev, 8) == hipSuccess;
-    if (!ok) { err = "device allocation failed"; return false; }
-    in.cap = need;
+    if (!ok) { in.free_rows(); err = "device allocation failed"; return false; }
   }
   if (!in.stream) in.stream = a->istream[0];
   for (Inspector::Slot &sl : in.slot)
@@ -1451,6 +1497,7 @@ void free_device(suscan_analyzer *a)
   (void)hipDeviceSynchronize();
   for (auto &kv : a->inspectors) kv.second->free_all();
   a->inspectors.clear();
+  a->rows.release();
   if (a->st) suamd_specttuner_destroy(a->st);
   a->st = nullptr;
   if (a->chandet) suamd_chandet_destroy(a->chandet);
@@ -1497,8 +1544,22 @@ bool init_device(suscan_analyzer *a, std::string &err)
   bool ok = a->ctx != nullptr;
   if (!ok) err = suamd_last_error();
   if (ok && hipStreamCreate(&a->stream) != hipSuccess) { ok = false; err = "hipStreamCreate failed"; }
-  for (int k = 0; ok && k < suscan_analyzer::NISTREAMS; ++k)
-    if (hipStreamCreateWithFlags(&a->istream[k], hipStreamNonBlocking) != hipSuccess) { ok = false; err = "hipStreamCreate failed"; }
+  // The three recurrence stages (gain control, carrier control, clock recovery) run concurrently on streams of their own, and
+  // that only holds while their streams sit on different hardware queues: HIP deals a process's streams of one priority over
+  // four queues by head count, so with streams of the host application (or of torch, in bench.py) already there two stages
+  // could end up behind one queue -- measured 3.8-4.4 instead of 2.0 ms per block, depending on nothing but how many streams
+  // the process had created before (tools/live_queue_probe.py).  Streams of another priority come out of another set of
+  // queues: the three stage streams ask for SUAMD_ANALYZER_STAGE_PRIORITY (default: the highest), which nobody else uses.
+  int prio_lo = 0, prio_hi = 0, prio = 0;
+  bool prio_ok = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_lo != prio_hi;
+  if (!prio_ok) (void)hipGetLastError();
+  prio = prio_hi;
+  if (const char *e = std::getenv("SUAMD_ANALYZER_STAGE_PRIORITY")) { if (!strcasecmp(e, "off")) prio_ok = false; else prio = std::atoi(e); }
+  for (int k = 0; ok && k < suscan_analyzer::NISTREAMS; ++k) {
+    hipError_t e = (prio_ok && k < 3) ? hipStreamCreateWithPriority(&a->istream[k], hipStreamNonBlocking, prio)
+                                      : hipStreamCreateWithFlags(&a->istream[k], hipStreamNonBlocking);
+    if (e != hipSuccess) { ok = false; err = "hipStreamCreate failed"; }
+  }
   if (ok && hipEventCreateWithFlags(&a->ev_input, hipEventDisableTiming) != hipSuccess) { ok = false; err = "hipEventCreate failed"; }
   a->trace = std::getenv("SUAMD_ANALYZER_TRACE") != nullptr;
   if (const char *e = std::getenv("SUAMD_ANALYZER_SUBRANGES")) {           // tuning knob: 1 = whole block per stage

@@ -121,7 +121,9 @@ suamd_audio_t *suamd_audio_new(suamd_ctx_t *ctx, SUFLOAT equiv_fs, SUFLOAT bandw
   if (!au) return nullptr;
   au->ctx = ctx; au->efs = equiv_fs; au->bw = bandwidth; au->fa = equiv_fs < 44100 ? equiv_fs : 44100; au->cutoff = 0.45 * au->fa;
   if (hipMalloc((void **)&au->d_xprev, sizeof(cf)) != hipSuccess || hipMalloc((void **)&au->d_power, sizeof(float)) != hipSuccess ||
-      hipMemset(au->d_xprev, 0, sizeof(cf)) != hipSuccess) { suamd_set_error("allocation failed"); suamd_audio_destroy(au); return nullptr; }
+      hipMemset(au->d_xprev, 0, sizeof(cf)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+    suamd_set_error("allocation failed"); suamd_audio_destroy(au); return nullptr;      // (the fill is over before a feed on another stream)
+  }
   return au;
 }
 
@@ -178,8 +180,8 @@ SUBOOL suamd_audio_feed(suamd_audio_t *au, const suamd_complex *d_x, SUSCOUNT le
     const size_t cap = (size_t)len + 2 * HIST + 1024;
     if (hipMalloc((void **)&na, cap * sizeof(cf)) != hipSuccess) { suamd_set_error("allocation failed"); return SU_FALSE; }
     (void)hipStreamSynchronize(s);
-    if (au->d_a) { (void)hipMemcpy(na, au->d_a, HIST * sizeof(cf), hipMemcpyDeviceToDevice); (void)hipFree(au->d_a); }
-    else (void)hipMemset(na, 0, HIST * sizeof(cf));
+    if (au->d_a) { (void)hipMemcpy(na, au->d_a, HIST * sizeof(cf), hipMemcpyDeviceToDevice); (void)hipStreamSynchronize(nullptr); (void)hipFree(au->d_a); }
+    else { (void)hipMemset(na, 0, HIST * sizeof(cf)); (void)hipStreamSynchronize(nullptr); }
     au->d_a = na; au->cap = cap;
   }
   float fc; int M; double ratio;

@@ -82,7 +82,9 @@ template <typename T> T *dev_from_host(const std::vector<T> &v)
 template <typename T> T *dev_zeros(size_t n)
 {
   T *p = dev_alloc<T>(n);
-  if (p && hipMemset(p, 0, (n ? n : 1) * sizeof(T)) != hipSuccess) { hipFree(p); return nullptr; }
+  // (hipMemset on device memory may return before the fill has run, and the callers' launches go to non-blocking streams,
+  // which do not wait for the null stream: the fill must be over before the object is handed out)
+  if (p && (hipMemset(p, 0, (n ? n : 1) * sizeof(T)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)) { hipFree(p); return nullptr; }
   return p;
 }
 
@@ -1762,7 +1764,8 @@ suamd_power_bank_t *suamd_power_bank_new(suamd_ctx_t *ctx, SUSCOUNT integrate_sa
   auto *b = new (std::nothrow) suamd_power_bank;
   if (!b) { set_err("out of memory"); return nullptr; }
   b->ctx = ctx; b->N = integrate_samples; b->cnt = 0;
-  if (hipMalloc((void **)&b->d_acc, 2 * sizeof(double)) != hipSuccess || hipMemset(b->d_acc, 0, 2 * sizeof(double)) != hipSuccess) {
+  if (hipMalloc((void **)&b->d_acc, 2 * sizeof(double)) != hipSuccess || hipMemset(b->d_acc, 0, 2 * sizeof(double)) != hipSuccess ||
+      hipStreamSynchronize(nullptr) != hipSuccess) {
     set_err("device allocation failed"); suamd_power_bank_destroy(b); return nullptr;
   }
   return b;

@@ -340,6 +340,11 @@ bool rebuild_group(suamd_specttuner *st, SizeGroup &g, const std::vector<int> &o
       if (hipMemcpy(np[0] + k * HS, old_prev + ok * HS, HS * sizeof(c32), hipMemcpyDeviceToDevice) != hipSuccess) return false;
     }
   }
+  // the fills and copies above went to the null stream and may still be on their way; the feeds run on the caller's
+  // stream, which need not wait for it (a non-blocking stream does not): a cross-fade state zeroed AFTER the first
+  // windows had written it showed up as one wrong half window per rebuild, once in a few dozen runs with several
+  // analyzer shards on one device
+  if (hipStreamSynchronize(nullptr) != hipSuccess) return false;
   for (int p = 0; p < 2; ++p) { if (g.d_prev[p]) (void)hipFree(g.d_prev[p]); g.d_prev[p] = np[p]; }
   g.prev_cur = 0;
   g.dirty = false;
@@ -579,7 +584,7 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
             g.d_handoff = nullptr; g.d_flags = nullptr; g.ho_slots = 0;
             if (hipMalloc((void **)&g.d_handoff, slots * 2048 * sizeof(c32)) != hipSuccess ||
                 hipMalloc((void **)&g.d_flags, slots * sizeof(unsigned)) != hipSuccess ||
-                hipMemset(g.d_flags, 0, slots * sizeof(unsigned)) != hipSuccess) { suamd_set_error("device allocation failed"); return SU_FALSE; }
+                hipMemset(g.d_flags, 0, slots * sizeof(unsigned)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { suamd_set_error("device allocation failed"); return SU_FALSE; }
             g.ho_slots = slots;
           }
           a.handoff = g.d_handoff; a.flags = g.d_flags;

@@ -6,6 +6,8 @@ libsigdigger_amd.so; this module only sequences the C-ABI calls on HIP streams a
 several GPUs, shards the inspector channels across ranks (channel c -> rank c mod G) and
 broadcasts the IQ block with RCCL (torch.distributed backend "nccl").
 """
+import os
+
 import numpy as np
 import torch
 
@@ -109,7 +111,11 @@ class AnalyzerPipeline:
             # one queue (bench.py builds C2 / C3 after the default workload: their kernels ran 2-3 x slower for it)
             key = str(self.dev)
             if key not in _STAGE_STREAMS:
-                _STAGE_STREAMS[key] = tuple(torch.cuda.Stream(self.dev) for _ in range(3))
+                # ... and of a priority of their own (SUAMD_PIPELINE_STAGE_PRIORITY, default -1 = high): streams of
+                # another priority come out of another set of hardware queues, so the three never share one with each
+                # other or with whatever streams the process made before (csrc/analyzer.cpp init_device: same reason)
+                prio = int(os.environ.get("SUAMD_PIPELINE_STAGE_PRIORITY", "-1"))
+                _STAGE_STREAMS[key] = tuple(torch.cuda.Stream(self.dev, priority=prio) for _ in range(3))
             self.s_agc, self.s_dem, self.s_clk = _STAGE_STREAMS[key]      # AGC; Costas / quad demod; clock recovery
         self.done = {}                         # (stage, block index) -> event
         self.ev = {}                           # per-stage timing events

@@ -47,13 +47,17 @@ def main():
             r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("LIVE ")]
             p = json.loads(line[-1][5:]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+            r = subprocess.run([exe, cap, str(n), str(blocks * 4), "raw"], env=env, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            raw = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
             print(f"shards {g} ({n:3d} inspectors, block exchange: {'ncclBroadcast (stand-in, one device)' if g > 1 else 'none'}):")
-            for name, x in (("C consumer     ", c), ("Python consumer", p)):
+            for name, x in (("C consumer     ", c), ("Python consumer", p), ("C consumer, \"raw\" inspectors (channel samples only: the host side's own ceiling)", raw)):
                 if "error" in x:
                     print(f"    {name}: {x['error']}")
                 else:
                     print(f"    {name}: {x['value_MSps']:8.1f} MS/s at the consumer ({x['ms_per_block']:.2f} ms per 2 Mi-sample block), "
-                          f"worker {x['worker_MSps']:8.1f} MS/s, {x['symbols_Msps']:.1f} Msym/s delivered")
+                          f"worker {x['worker_MSps']:8.1f} MS/s, {x['symbols_Msps']:.1f} Msym/s delivered"
+                          + (f", {x['sample_messages_per_s']:.0f} messages/s" if "sample_messages_per_s" in x else ""))
             sys.stdout.flush()
     finally:
         shutil.rmtree(d, ignore_errors=True)
