@@ -248,9 +248,9 @@ KERNELS = {
                   "around an LDS transposition, shared by all channels; lane = channel: bin pick x response, 64-pt "
                   "inverse FFT, cross-fade)",
     "st_kernel": "st_kernel (FFT channeliser, one workgroup per run of windows: radix-16 passes through LDS)",
-    "chan_pair_kernel": "chan_pair_kernel (translate + polyphase decimating FIR for one or two channels as a stream: persistent "
-                        "workgroups, lane = two adjacent outputs sharing their samples in LDS, next tile staged through registers, "
-                        "taps from scalar loads; the SPEC's fma chain per output)",
+    "chan_pair_kernel": "chan_pair_kernel (translate + polyphase decimating FIR for one or two channels: tiles of 256 outputs, "
+                        "lane = two adjacent outputs sharing their samples in LDS, taps from scalar loads, the SPEC's fma chain "
+                        "per output in asm; SUAMD_FIR_PAIR_NW=8: persistent workgroups streaming runs of 1024-output tiles)",
     "chan_fir_kernel": "chan_fir_kernel (translate + 255-tap polyphase decimating FIR bank)"}
 
 

@@ -482,17 +482,18 @@ bool chan_stream_feed(const ChanFeedArgs &a, const void *g2, hipStream_t st, hip
   static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   const int PP = 2 * D + pad_for(2 * D), HBP = hbp_for(D, a.ntaps);
   auto pbytes = [&](int w) { return (size_t)2 * PP * 8 + (size_t)(HBP + 64 * w) * PP * 8; };   // w wavefronts
-  // Long feeds (two or more 1024-output tiles per CU): 8 wavefronts, one persistent workgroup per CU streaming its run of
-  // tiles (the next tile's loads fly under the current tile's arithmetic).  Shorter feeds have nothing to stream -- a CU's
-  // share is a tile or two -- so they go out as independent tiles of 256 outputs (2 wavefronts, four workgroups per CU):
-  // the dispatcher overlaps one workgroup's loads with another's arithmetic, and a CU that is partly taken by other
-  // kernels (the recurrence stages of the previous blocks hold three for the whole step) costs a quarter tile, not a
-  // whole one.  C = 1, D = 16, T = 255, alone / behind the pipeline's other streams, 4 Mi samples: 19.9 / 31.0 us against
-  // 20.9 / 38.3 for the persistent shape; 8 Mi alone 45 against 40.5, 16 Mi 72 against 69 (profiles/r04_fir_stream_phases.txt).
+  // Default shape: independent tiles of 256 outputs (2 wavefronts per workgroup, four workgroups per CU, one tile each).
+  // The dispatcher overlaps one workgroup's loads with another's arithmetic, and a CU that is partly taken by other
+  // kernels costs a quarter tile, not a run of whole ones.  The persistent shape (SUAMD_FIR_PAIR_NW=8: one workgroup of 8
+  // wavefronts per CU streaming its run of 1024-output tiles, the next tile's loads under the current tile's arithmetic)
+  // is 3-12 % faster on an idle chip at 8-16 Mi samples and up to 1.6 x slower inside the analyzer pipeline, where the
+  // recurrence wavefronts of earlier blocks hold three CUs for the whole step: it needs a CU's whole LDS and register
+  // file, so its last three workgroups start when the first ones finish.  C = 1, D = 16, T = 255, alone / in the
+  // pipeline: 4 Mi 19.9 / 31.0 us against 20.9 / 38.3; 8 Mi alone 46 against 41; 16 Mi 72 / 75 against 70 / 122
+  // (profiles/r04_fir_tile_shapes.txt).
   // Measured and NOT taken: one wavefront per SIMD with two pair-blocks per lane (four fma chains on the same taps) --
   // 35 k against 20 k ticks per 1024 outputs, the compiler's SGPR spill code in its loop.
-  int nw = 8, tpw = 0;
-  if (a.n_out < 2ll * 1024 * ncu) { nw = 2; tpw = 1; }
+  int nw = 2, tpw = 1;
   if (const char *e = getenv("SUAMD_FIR_PAIR_NW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) { nw = v; tpw = 0; } }
   while (nw > 1 && a.n_out < 128ll * nw) nw >>= 1;
   while (nw > 1 && pbytes(nw) > 160 * 1024) nw >>= 1;

@@ -204,9 +204,10 @@ def test_the_pipeline_as_bench_py_builds_it_is_exact_end_to_end(ctx, sdo, worklo
 @pytest.mark.parametrize("nchan", [1, 2])
 def test_c2_fir_stage_at_the_benched_block_size_equals_the_oracle(ctx, sdo, monkeypatch, nchan):
     """BASELINE configs[1] as written -- translate + 255-tap low-pass, D = 16 -- on bench.py's block (16 Mi samples) and the
-    next, ragged one: long feeds take the persistent shape of chan_pair_kernel (runs of 1024-output tiles per workgroup,
-    history handed on inside the LDS), which the small parity cases only reach through SUAMD_FIR_PAIR_NW.  Every output of
-    both feeds against the oracle's fma chain, bit for bit, and against chan_fir_kernel (SUAMD_FIR_STREAM=0)."""
+    next, ragged one, in both shapes of chan_pair_kernel: independent 256-output tiles (the default) and the persistent
+    one (SUAMD_FIR_PAIR_NW=8: runs of four 1024-output tiles per workgroup at this size, the history handed on inside the
+    LDS -- the small parity cases only reach runs of one or two).  Every output of both feeds against the oracle's fma
+    chain, bit for bit, and against chan_fir_kernel (SUAMD_FIR_STREAM=0)."""
     import bench
     from sigdigger_amd import engine
     D, T, Lb = 16, 255, 1 << bench.DEFAULT_LOG2_BLOCK
@@ -219,16 +220,22 @@ def test_c2_fir_stage_at_the_benched_block_size_equals_the_oracle(ctx, sdo, monk
     taps = sdo.lpf_design(T, 0.75 / D)
     xd = torch.from_numpy(x).cuda()
     res = {}
-    for mode in ("1", "0"):
+    for mode, nw in (("1", None), ("1", "8"), ("0", None)):
         monkeypatch.setenv("SUAMD_FIR_STREAM", mode)
+        if nw:
+            monkeypatch.setenv("SUAMD_FIR_PAIR_NW", nw)
+        else:
+            monkeypatch.delenv("SUAMD_FIR_PAIR_NW", raising=False)
         bank = engine.ChannelBank(ctx, fn, D, taps)
         got = []
         for a, b in zip(cuts[:-1], cuts[1:]):
             out = torch.empty((nchan, bank.output_count(b - a) + 3), dtype=torch.complex64, device="cuda")
             got.append(bank.feed(xd[a:b], out=out).cpu().numpy())
-        res[mode] = np.concatenate(got, axis=1)
+        res[mode + (nw or "")] = np.concatenate(got, axis=1)
     monkeypatch.delenv("SUAMD_FIR_STREAM")
-    assert np.array_equal(bits(res["1"]), bits(res["0"])), "stream kernel vs tiled kernel"
+    monkeypatch.delenv("SUAMD_FIR_PAIR_NW", raising=False)
+    assert np.array_equal(bits(res["1"]), bits(res["0"])), "pair kernel (independent tiles) vs chan_fir_kernel"
+    assert np.array_equal(bits(res["18"]), bits(res["0"])), "pair kernel (persistent stream) vs chan_fir_kernel"
     for c, f in enumerate(fn):
         dp = sdo.fnor_to_dphase(-f)
         g = sdo.chan_modulate_taps(taps, dp)

@@ -343,8 +343,8 @@ def test_chanbank_stream_kernel_equals_the_tiled_one_and_the_oracle(ctx, sdo, mo
     """chan_stream.hip (one or two channels, lane = two adjacent outputs, scalar taps) against chan_fir_kernel
     (SUAMD_FIR_STREAM=0) bit for bit -- feeds of ragged sizes (a tile boundary inside, a feed shorter than a tile, an
     odd start so that the first history pair straddles hist / x), both layouts, and each tile shape the dispatch can pick:
-    its own choice for these lengths (independent 256-output tiles), the persistent 1024-output stream of long feeds
-    (SUAMD_FIR_PAIR_NW=8: runs of tiles with the history handed on inside the LDS) and the 512-output one -- and against
+    the default (independent 256-output tiles), the persistent 1024-output stream (SUAMD_FIR_PAIR_NW=8: runs of tiles
+    with the history handed on inside the LDS) and the 512-output one -- and against
     the oracle on the head."""
     n = 300000
     fn = [0.25, -0.4][:nchan]
