@@ -17,10 +17,16 @@
 //      k h[i], inverse transform (conjugate, forward passes on the group's own LDS scratch, conjugate), cross-fade with
 //      the previous window's half (kept in registers: in the last pass's geometry a thread holds y[i] and y[i + size/2]
 //      for the same i), optional residual NCO ("precise"), store through the view.
+//   Banks with more channels than fit side by side (NGL > 1, round 4): the workgroup keeps the window's spectrum in the
+//   registers that hold the last forward pass's output and runs step 2 for up to NGL channel groups in turn, rewriting
+//   the LDS spectrum from those registers before each -- ONE forward transform per window for NGL x 256 / TPI channels
+//   instead of one per group (NGL = 2: 64 channels of 256 bins 164 -> 142 us per 4 Mi samples).  Every channel's
+//   operation sequence is unchanged, so are the bits.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "kernels.hpp"
 #include "fft_core.hpp"
 #include "sd_math.hpp"
@@ -29,6 +35,12 @@ namespace {
 using namespace fftcore;
 
 constexpr int ST_THREADS = 256;
+
+// compile-time loop over the turns (the per-turn arrays must be indexed by constants to stay in registers)
+template <int N, int I = 0, typename F> __device__ __forceinline__ void static_for_g(F &&f)
+{
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for_g<N, I + 1>(f); }
+}
 
 template <int LOG2S> struct StGeomT {
   static constexpr int S    = 1 << LOG2S;
@@ -40,7 +52,7 @@ template <int LOG2S> struct StGeomT {
 
 // OCC: workgroups per CU the register budget is cut for (the LDS of one workgroup is ~35 KB: up to 4 fit);
 // PREFETCH: request the next window's samples right after pass 0 of this one (32 VGPRs)
-template <int LOG2W, int LOG2S, int OCC, bool PREFETCH>
+template <int LOG2W, int LOG2S, int OCC, bool PREFETCH, int NGL>
 __global__ __launch_bounds__(ST_THREADS, OCC) void st_kernel(sdk::StArgs a)
 {
   __builtin_amdgcn_s_setprio(3);   // ahead of the resident recurrence wavefronts (see chan_fir_kernel)
@@ -59,9 +71,18 @@ __global__ __launch_bounds__(ST_THREADS, OCC) void st_kernel(sdk::StArgs a)
   cf *scratch = spec;                                          // then (once every group holds its bins) the groups' scratch
   const int tid0 = threadIdx.x;
   const int grp = tid0 / G::TPI, tl0 = tid0 % G::TPI;
-  const int ch = blockIdx.y * G::CPP + grp;                    // channel of this thread's group (in the size group)
-  const bool live = ch < a.nchan;
-  const sdk::StChan cd = a.chans[live ? ch : 0];
+  // this workgroup's channel groups: (blockIdx.y * NGL + g) * CPP + grp is the channel of this thread's group in turn g
+  const int gbase = blockIdx.y * NGL;
+  const int ngl = min(NGL, (a.nchan - gbase * G::CPP + G::CPP - 1) / G::CPP);     // turns that have a channel at all (uniform)
+  int chv[NGL];
+  bool livev[NGL];
+  sdk::StChan cdv[NGL];
+#pragma unroll
+  for (int g = 0; g < NGL; ++g) {
+    chv[g] = (gbase + g) * G::CPP + grp;
+    livev[g] = chv[g] < a.nchan;
+    cdv[g] = a.chans[livev[g] ? chv[g] : 0];
+  }
   cf *gscr = scratch + grp * G::PADS;
 
   TwBase tbw, tbs;
@@ -74,14 +95,16 @@ __global__ __launch_bounds__(ST_THREADS, OCC) void st_kernel(sdk::StArgs a)
   const cf *x = reinterpret_cast<const cf *>(a.x), *hist = reinterpret_cast<const cf *>(a.hist);
   const long long off = a.have_hist ? H : 0;                   // virtual stream = hist (H samples) ++ x
 
-  cf prev[NBLS][RLS / 2];                                      // y_{w-1}[i + S/2] for this thread's i
+  cf prev[NGL][NBLS][RLS / 2];                                 // y_{w-1}[i + S/2] for this thread's i, per turn
 #pragma unroll
-  for (int b = 0; b < NBLS; ++b)
+  for (int g = 0; g < NGL; ++g)
 #pragma unroll
-    for (int q = 0; q < RLS / 2; ++q) {
-      const int i = tl0 + b * G::TPI + q * (S / RLS);
-      prev[b][q] = (w_begin == 0 && live) ? reinterpret_cast<const cf *>(a.prev_in)[(long long)ch * HS + i] : cf{0.f, 0.f};
-    }
+    for (int b = 0; b < NBLS; ++b)
+#pragma unroll
+      for (int q = 0; q < RLS / 2; ++q) {
+        const int i = tl0 + b * G::TPI + q * (S / RLS);
+        prev[g][b][q] = (w_begin == 0 && livev[g]) ? reinterpret_cast<const cf *>(a.prev_in)[(long long)chv[g] * HS + i] : cf{0.f, 0.f};
+      }
 
   cf nxt[EW];
   auto request = [&](long long w) {
@@ -110,6 +133,12 @@ __global__ __launch_bounds__(ST_THREADS, OCC) void st_kernel(sdk::StArgs a)
     if (PREFETCH && w + 1 < w_end) request(w + 1);
     PassRunner<LOG2W, ST_THREADS, 1, 1>::run(v, spec, tbw, tid, nullptr);
     // v[b*RL + q] = X[j + q*W/RL]; the last pass's gather was followed by a barrier: spec may take the spectrum
+    static_for_g<NGL>([&](auto gc) {
+    constexpr int g = decltype(gc)::value;
+    if (g >= ngl) return;                                      // (uniform: every thread of the workgroup skips the turn)
+    const sdk::StChan &cd = cdv[g];
+    const bool live = livev[g];
+    // (turn g > 0: the previous turn ended with a barrier behind its last LDS reads; the spectrum comes back from v)
 #pragma unroll
     for (int b = 0; b < NBLW; ++b) {
       cf *sp = spec + lpad(tid + b * ST_THREADS);
@@ -158,7 +187,7 @@ __global__ __launch_bounds__(ST_THREADS, OCC) void st_kernel(sdk::StArgs a)
         const cf nx = cf{u[b * RLS + q + RLS / 2].x, -u[b * RLS + q + RLS / 2].y};
         if (emit && live) {
           const float al = win[i], be = win[i + HS];
-          float orr = al * cur.x + be * prev[b][q].x, oi = al * cur.y + be * prev[b][q].y;
+          float orr = al * cur.x + be * prev[g][b][q].x, oi = al * cur.y + be * prev[g][b][q].y;
           const unsigned long long m = (unsigned long long)w * HS + i;      // output index within this feed
           if (cd.precise) {
             float c, s;
@@ -169,14 +198,14 @@ __global__ __launch_bounds__(ST_THREADS, OCC) void st_kernel(sdk::StArgs a)
           if (tile) spec[i * TP + grp] = cf{orr, oi};
           else ybase[(long long)m * yms] = cf{orr, oi};
         }
-        prev[b][q] = nx;
+        prev[g][b][q] = nx;
       }
     }
     if (tile) {
       __syncthreads();
       if (emit) {
         const int col = tid % G::CPP, r0 = tid / G::CPP;
-        const int cch = blockIdx.y * G::CPP + col;
+        const int cch = (gbase + g) * G::CPP + col;
         if (cch < a.nchan) {
           const long long orow = a.chans[cch].row;
           cf *yb = reinterpret_cast<cf *>(a.y) + orow * a.yv.cs + (long long)((unsigned long long)w * HS) * a.yv.ms;
@@ -188,29 +217,34 @@ __global__ __launch_bounds__(ST_THREADS, OCC) void st_kernel(sdk::StArgs a)
         }
       }
     }
-    // the group scratch and the spectrum are rewritten by the next window's passes: its pass 0 ends with a barrier
-    // only after writing spec -- order this window's spectrum reads before that
+    // the group scratch and the spectrum are rewritten by the next turn / the next window's passes (its pass 0 ends with
+    // a barrier only after writing spec): order this turn's LDS reads before that
     __syncthreads();
+    });
   }
   // carry the last window's second half to the next feed
-  if (w_end == a.nwin && live) {
+  if (w_end == a.nwin) {
 #pragma unroll
-    for (int b = 0; b < NBLS; ++b)
+    for (int g = 0; g < NGL; ++g)
+      if (livev[g]) {
 #pragma unroll
-      for (int q = 0; q < RLS / 2; ++q) {
-        const int i = tl0 + b * G::TPI + q * (S / RLS);
-        reinterpret_cast<cf *>(a.prev_out)[(long long)ch * HS + i] = prev[b][q];
+        for (int b = 0; b < NBLS; ++b)
+#pragma unroll
+          for (int q = 0; q < RLS / 2; ++q) {
+            const int i = tl0 + b * G::TPI + q * (S / RLS);
+            reinterpret_cast<cf *>(a.prev_out)[(long long)chv[g] * HS + i] = prev[g][b][q];
+          }
       }
   }
 }
 
-template <int LOG2W, int LOG2S, int OCC, bool PREFETCH>
+template <int LOG2W, int LOG2S, int OCC, bool PREFETCH, int NGL>
 hipError_t launch_st_v(const sdk::StArgs &a, hipStream_t st)
 {
   using G = StGeomT<LOG2S>;
   constexpr int W = 1 << LOG2W;
   const size_t lds = sizeof(cf) * std::max((size_t)(W + W / 16 + 1), (size_t)G::CPP * G::PADS);
-  auto kern = st_kernel<LOG2W, LOG2S, OCC, PREFETCH>;
+  auto kern = st_kernel<LOG2W, LOG2S, OCC, PREFETCH, NGL>;
   static bool attr_done_dev[64] = {};                        // a function attribute belongs to a device
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
@@ -221,21 +255,33 @@ hipError_t launch_st_v(const sdk::StArgs &a, hipStream_t st)
     attr_done = true;
   }
   const unsigned nruns = (unsigned)((a.nwin + a.run - 1) / a.run);
-  const unsigned ny = (unsigned)((a.nchan + G::CPP - 1) / G::CPP);
-  sdk::launch_timed("st_kernel", kern, dim3(nruns, ny), dim3(ST_THREADS), lds, st, a);
+  const unsigned ngroups = (unsigned)((a.nchan + G::CPP - 1) / G::CPP);
+  sdk::launch_timed("st_kernel", kern, dim3(nruns, (ngroups + NGL - 1) / NGL), dim3(ST_THREADS), lds, st, a);
   return hipGetLastError();
 }
 
 template <int LOG2W, int LOG2S>
 hipError_t launch_st(const sdk::StArgs &a, hipStream_t st)
 {
+  using G = StGeomT<LOG2S>;
   static const int variant = [] { const char *e = getenv("SUAMD_ST_VARIANT"); return e ? atoi(e) : 0; }();
   switch (variant) {
-    case 1:  return launch_st_v<LOG2W, LOG2S, 2, true>(a, st);
-    case 2:  return launch_st_v<LOG2W, LOG2S, 4, false>(a, st);
-    case 3:  return launch_st_v<LOG2W, LOG2S, 3, false>(a, st);
-    default: return launch_st_v<LOG2W, LOG2S, 3, true>(a, st);
+    case 1:  return launch_st_v<LOG2W, LOG2S, 2, true, 1>(a, st);
+    case 2:  return launch_st_v<LOG2W, LOG2S, 4, false, 1>(a, st);
+    case 3:  return launch_st_v<LOG2W, LOG2S, 3, false, 1>(a, st);
+    default: break;
   }
+  // two channel groups per workgroup, in turn, on ONE forward transform (SUAMD_ST_NGL=1: a workgroup per group, rounds 2-3).
+  // Measured per 4 Mi-sample block (tools/st_wide.py, same box, back to back): 64 x 256 bins 163.5 -> 142.4 us, 128 x 256
+  // 333 -> 275, 64 x 128 84.1 -> 77.7, 128 x 128 148.8 -> 140.9; compiled for two workgroups per CU -- with three the
+  // second turn's cross-fade state spills to scratch memory and the gain turns into a loss (246 us), and four turns per
+  // workgroup lose to two even without spills (190 us): the channel stage, not the forward transform, is most of a window.
+  if constexpr (LOG2S >= 7 && LOG2S <= 11) {
+    static const int ngl_env = [] { const char *e = getenv("SUAMD_ST_NGL"); return e ? atoi(e) : 0; }();
+    const int ngroups = (a.nchan + G::CPP - 1) / G::CPP;
+    if ((ngl_env ? ngl_env : (ngroups >= 2 ? 2 : 1)) >= 2) return launch_st_v<LOG2W, LOG2S, 2, true, 2>(a, st);
+  }
+  return launch_st_v<LOG2W, LOG2S, 3, true, 1>(a, st);
 }
 
 }  // namespace

@@ -7,7 +7,7 @@ from sigdigger_amd import engine, synth
 ctx = engine.Context(0)
 L = 1 << 22
 x = torch.empty(L, dtype=torch.complex64, device="cuda"); torch.view_as_real(x).normal_()
-for C, D in ((1, 16), (16, 16), (64, 16), (1, 32), (32, 32), (64, 32), (1, 1), (1, 4)):
+for C, D in ((1, 16), (16, 16), (32, 16), (64, 16), (128, 16), (1, 32), (32, 32), (64, 32), (128, 32), (16, 8), (1, 1), (1, 4)):
     st = engine.SpectTuner(ctx, 4096)
     for f in synth.raster(C, 1.8 / max(C, 2)):
         st.open_channel(np.pi * f % (2 * np.pi), 2 * np.pi * 0.75 / D)
