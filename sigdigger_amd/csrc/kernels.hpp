@@ -117,6 +117,7 @@ struct StArgs {
 };
 // channels one workgroup serves side by side for inverse transforms of 2^log2s points
 int st_channels_per_group(int log2s);
+int st_plan_run(int log2s, int nchan, long long nwin);      // windows per workgroup that fill one round of the chip
 hipError_t specttuner_feed(int log2w, int log2s, const StArgs &a, hipStream_t st);
 // specttuner_wave.hip: one wavefront per window, sizes 8..64 (W = 4096); channels one wavefront serves
 int stw_channels_per_wave(int log2s);

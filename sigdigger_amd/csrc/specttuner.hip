@@ -31,6 +31,8 @@
 #include "fft_core.hpp"
 #include "sd_math.hpp"
 
+namespace sdk { bool st_two_turns(int log2s, int nchan); }
+
 namespace {
 using namespace fftcore;
 
@@ -277,9 +279,7 @@ hipError_t launch_st(const sdk::StArgs &a, hipStream_t st)
   // second turn's cross-fade state spills to scratch memory and the gain turns into a loss (246 us), and four turns per
   // workgroup lose to two even without spills (190 us): the channel stage, not the forward transform, is most of a window.
   if constexpr (LOG2S >= 7 && LOG2S <= 11) {
-    static const int ngl_env = [] { const char *e = getenv("SUAMD_ST_NGL"); return e ? atoi(e) : 0; }();
-    const int ngroups = (a.nchan + G::CPP - 1) / G::CPP;
-    if ((ngl_env ? ngl_env : (ngroups >= 2 ? 2 : 1)) >= 2) return launch_st_v<LOG2W, LOG2S, 2, true, 2>(a, st);
+    if (sdk::st_two_turns(LOG2S, a.nchan)) return launch_st_v<LOG2W, LOG2S, 2, true, 2>(a, st);
   }
   return launch_st_v<LOG2W, LOG2S, 3, true, 1>(a, st);
 }
@@ -289,6 +289,30 @@ hipError_t launch_st(const sdk::StArgs &a, hipStream_t st)
 namespace sdk {
 
 int st_channels_per_group(int log2s) { return log2s == 5 ? 64 : (log2s < 4 ? 256 : (256 * 16) >> log2s); }
+
+bool st_two_turns(int log2s, int nchan)
+{
+  static const int ngl_env = [] { const char *e = getenv("SUAMD_ST_NGL"); return e ? atoi(e) : 0; }();
+  const int cpp = st_channels_per_group(log2s);
+  const int ngroups = (nchan + cpp - 1) / cpp;
+  return log2s >= 7 && log2s <= 11 && (ngl_env ? ngl_env : (ngroups >= 2 ? 2 : 1)) >= 2;
+}
+
+// windows per workgroup of the workgroup kernel: the launch fills ONE round of the chip's resident workgroups (three per CU,
+// two for the two-turn instantiation), a tenth of them left to whatever else is running -- a launch of 2.7 rounds runs as
+// long as one of 3, and a workgroup that finds no slot waits for a whole run of another.  At least 3 (a run re-transforms
+// the window before its first).  Measured per 4 Mi-sample block (tools/st_wide.py): 64 x 256 bins 144 us at 3 windows per
+// workgroup (1366 workgroups on 512 slots), 129 at 4, 121 at 8 (512 workgroups); one channel: 46 at 3, 45 at 4, 56 at 6.
+int st_plan_run(int log2s, int nchan, long long nwin)
+{
+  const int cpp = st_channels_per_group(log2s);
+  const int ngroups = (nchan + cpp - 1) / cpp;
+  const bool two = st_two_turns(log2s, nchan);
+  const long long ny = two ? (ngroups + 1) / 2 : ngroups;
+  const long long slots = (two ? 2 : 3) * 256 * 9 / 10;
+  const long long run = (nwin * ny + slots - 1) / slots;
+  return (int)std::min<long long>(64, std::max<long long>(3, run));
+}
 
 hipError_t specttuner_feed(int log2w, int log2s, const StArgs &a, hipStream_t st)
 {

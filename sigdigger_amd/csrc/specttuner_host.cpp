@@ -171,7 +171,7 @@ struct suamd_specttuner {
   suamd_ctx_t *ctx = nullptr;
   unsigned W = 4096, H = 2048;
   int log2w = 12;
-  unsigned run = 3;                    // windows per workgroup: 683 workgroups per 4 Mi-sample block, a third re-transformed
+  unsigned run = 0;                    // windows per workgroup of the workgroup kernel (0: planned per launch, sdk::st_plan_run)
   unsigned run_wave = 0;               // wavefront kernel: windows per wavefront (0: one round of 4 wavefronts per CU)
   unsigned slots = 0;                  // wavefront kernels: the launch's budget of the chip's 1024 window slots (0: SUAMD_ST_SLOTS, else 768)
   int seam_polls = 256;                // wavefront kernel: bounded wait for a run's successor (SUAMD_ST_SEAM_POLLS; 0: never wait)
@@ -533,7 +533,7 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
       if (!d_y && !d_rows) { suamd_set_error("null output"); return SU_FALSE; }
       sdk::StArgs a{};
       a.x = d_x; a.hist = st->d_hist[st->hist_cur]; a.have_hist = st->have_hist ? 1 : 0;
-      a.nwin = nwin; a.run = (int)st->run;
+      a.nwin = nwin; a.run = st->run ? (int)st->run : 3;
       a.tw_w = st->d_tw_w; a.tw_s = g.d_tw;
       a.chans = g.d_chans; a.nchan = (int)g.members.size();
       a.hk = g.d_hk; a.win = g.d_win;
@@ -634,7 +634,10 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
           }
         }
 #endif
-      } else e = sdk::specttuner_feed(st->log2w, g.log2s, a, s);
+      } else {
+        if (!st->run) a.run = sdk::st_plan_run(g.log2s, a.nchan, nwin);
+        e = sdk::specttuner_feed(st->log2w, g.log2s, a, s);
+      }
       if (e != hipSuccess) { suamd_set_error("specttuner launch failed: %s", hipGetErrorString(e)); return SU_FALSE; }
       g.prev_cur ^= 1;
       const unsigned HS = (1u << g.log2s) / 2;
