@@ -386,7 +386,14 @@ int psd_split(long long nout, int navg, int log2n)
     minf = e ? atoi(e) : 2;
     if (minf < 1) minf = 1;
   }
-  const int target = target_env > 0 ? target_env : (log2n <= 12 ? 1024 : 512);
+  // (round 4: 8192 points 512 -> 256 and 16384 points 512 -> 256 workgroups.  16384 points fit ONE workgroup per CU, so 512
+  // was two rounds: 48.5 -> 42.1 us per 16 Mi samples.  8192 points fit two per CU, and 512 workgroups of 4 frames for
+  // exactly 512 slots is what the analyzer pipeline cannot give: its three recurrence wavefronts take a slot each, the
+  // displaced workgroups start when the first ones end -- 55.9 + 5.1 us inside the pipeline against 34.2 + 6.5 alone; 256
+  // workgroups of 8 frames: 49.6 + 4.8 inside, 38.2 + 5.3 alone, and half the partial sums (1.125 x instead of 1.25 x the
+  // algorithmic bytes).  Blocks of 4 Mi samples and captures are not affected: the first is bounded by `minf`, the second
+  // never splits.  tools/psd_block.py, tools/inpipe_sweep.sh, profiles/r04_inpipe_penalty.txt)
+  const int target = target_env > 0 ? target_env : (log2n <= 12 ? 1024 : 256);
   if (nout <= 0 || navg < 2 * minf || nout >= target) return 1;
   long long s = (target + nout - 1) / nout;
   if (s > navg / minf) s = navg / minf;
