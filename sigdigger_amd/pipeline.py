@@ -50,6 +50,7 @@ class AnalyzerPipeline:
     """
 
     NBUF = 3                                   # ring depth of every inter-stage buffer
+    SUB = max(1, int(os.environ.get("SUAMD_PIPELINE_SUB", "4")))   # sub-ranges a block takes through the serial stages of a PSK chain
 
     def __init__(self, ctx, block_len, psd_size=8192, psd_window=engine.WINDOW_BLACKMANN_HARRIS,
                  psd_navg=None, bank=None, do_psd=True, overlap=True):
@@ -118,6 +119,7 @@ class AnalyzerPipeline:
                 _STAGE_STREAMS[key] = tuple(torch.cuda.Stream(self.dev, priority=prio) for _ in range(3))
             self.s_agc, self.s_dem, self.s_clk = _STAGE_STREAMS[key]      # AGC; Costas / quad demod; clock recovery
         self.done = {}                         # (stage, block index) -> event
+        self.marks_per_step = 1                # timing marks per step of a serial stage (step() with sub-ranges: SUB)
         self.ev = {}                           # per-stage timing events
 
     # ---- helpers ---------------------------------------------------------------------------
@@ -174,37 +176,67 @@ class AnalyzerPipeline:
         self._signal("fir", k, st)
         m = y.shape[1]
         src = y
+        # The three serial stages take the block in SUB sub-ranges (PSK chains): sub-range j of the Costas stage only waits for
+        # sub-range j of the AGC, the Gardner stage for sub-range j of Costas -- a block's way through the stages (and with it
+        # the pipeline's fill and drain: 1.3 steps per timed region with whole blocks) shrinks to the slowest stage plus a
+        # quarter of the others.  The banks are stream processors (state carried from call to call), so the sub-ranges give
+        # the same samples as the whole block, bit for bit (csrc/analyzer.cpp pushes its inspectors through the same way).
+        nsub = self.SUB if psk else 1
+        cuts = [m * j // nsub for j in range(nsub + 1)]
         # ---- AGC ----
         if psk and self.agc is not None:
             self._wait(self.s_agc, "fir", k)
             self._wait(self.s_agc, "dem", k - nb)                                    # a[i] free again
-            self._mark("agc0", self.s_agc, timed)
-            src = self.agc.feed(y, out=self.a[i][:, :m], stream=self.s_agc)
-            self._mark("agc1", self.s_agc, timed)
+            for j in range(nsub):
+                lo, hi = cuts[j], cuts[j + 1]
+                self._mark("agc0", self.s_agc, timed)
+                if hi > lo:
+                    self.agc.feed(y[:, lo:hi], out=self.a[i][:, lo:hi], stream=self.s_agc)
+                self._mark("agc1", self.s_agc, timed)
+                self._signal(("agc", j), k, self.s_agc)
+            src = self.a[i][:, :m]
             self._signal("agc", k, self.s_agc)
         # ---- carrier recovery / quadrature demod ----
-        self._wait(self.s_dem, "agc" if (psk and self.agc is not None) else "fir", k)
         self._wait(self.s_dem, "clk", k - nb)                                        # z[i] free again
-        self._mark("dem0", self.s_dem, timed)
         if psk:
-            z = self.costas.feed(src, out=self.z[i][:, :m], stream=self.s_dem)
+            if self.agc is None:
+                self._wait(self.s_dem, "fir", k)
+            for j in range(nsub):
+                lo, hi = cuts[j], cuts[j + 1]
+                if self.agc is not None:
+                    self._wait(self.s_dem, ("agc", j), k)
+                self._mark("dem0", self.s_dem, timed)              # (behind the wait: the stage's own time, per sub-range)
+                if hi > lo:
+                    self.costas.feed(src[:, lo:hi], out=self.z[i][:, lo:hi], stream=self.s_dem)
+                self._mark("dem1", self.s_dem, timed)
+                self._signal(("dem", j), k, self.s_dem)
+            z = self.z[i][:, :m]
         else:
+            self._wait(self.s_dem, "fir", k)
+            self._mark("dem0", self.s_dem, timed)
             z = self.ctx.quad_demod(y, prev=self.qprev[k & 1], first=self.first, out=self.z[i][:, :m],
                                     prev_out=self.qprev[(k + 1) & 1], stream=self.s_dem)
             self.first = False
-        self._mark("dem1", self.s_dem, timed)
+            self._mark("dem1", self.s_dem, timed)
+            self._signal(("dem", 0), k, self.s_dem)
         self._signal("dem", k, self.s_dem)
-        # ---- clock recovery ----
-        self._wait(self.s_clk, "dem", k)
+        # ---- clock recovery (appends to the block's symbol rows: one count per channel, cleared once per block) ----
+        self._wait(self.s_clk, ("dem", 0), k)
         with torch.cuda.stream(self.s_clk):
             self.count[i].zero_()
-        self._mark("clk0", self.s_clk, timed)
-        self.clock.feed(z, self.sym[i], self.count[i], stream=self.s_clk)
-        self._mark("clk1", self.s_clk, timed)
+        for j in range(nsub):
+            lo, hi = cuts[j], cuts[j + 1]
+            self._wait(self.s_clk, ("dem", j), k)
+            self._mark("clk0", self.s_clk, timed)
+            if hi > lo:
+                self.clock.feed(z[:, lo:hi], self.sym[i], self.count[i], stream=self.s_clk)
+            self._mark("clk1", self.s_clk, timed)
         self._signal("clk", k, self.s_clk)
+        self.marks_per_step = nsub
         return self.psd_out if self.do_psd else None
 
     def _step_serial(self, x, timed, st):
+        self.marks_per_step = 1
         if self.do_psd:
             self._mark("psd0", st, timed)
             self.psd.feed(x, nframes=self.nframes, navg=self.navg, scale=1.0 / self.psd_size,
@@ -281,6 +313,9 @@ class AnalyzerPipeline:
             # counted in self.stalled_samples, so the figure is the kernel's launch duration, as rocprofv3 reports it.
             if a in ev and b in ev:
                 t = np.array([s.elapsed_time(e) for s, e in zip(ev[a], ev[b])])
+                n = getattr(self, "marks_per_step", 1)          # the serial stages of a PSK chain mark every sub-range: per step = their sum
+                if a[:3] in ("agc", "dem", "clk") and n > 1 and t.size % n == 0:
+                    t = t.reshape(-1, n).sum(axis=1)
                 keep = t <= 5.0 * np.median(t)
                 self.stage_raw[a[:-1]] = {"mean": float(t.mean()), "median": float(np.median(t)), "max": float(t.max()), "n": int(t.size)}
                 if not keep.all():
