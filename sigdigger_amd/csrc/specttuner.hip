@@ -52,6 +52,21 @@ template <int LOG2S> struct StGeomT {
   static constexpr int PADS = S + S / 16 + 1;                  // a group's LDS scratch (elements)
 };
 
+// One output sample: sin^2 / cos^2 cross-fade of this window's first half with the previous window's second half, then
+// the channel's residual NCO ("precise").  One function for st_kernel and st_seam_kernel: the same expression, the same
+// instruction selection, the same bits.
+__device__ __forceinline__ cf st_emit(float al, float be, cf cur, cf prev, const sdk::StChan &cd, unsigned long long n0, unsigned long long m)
+{
+  float orr = al * cur.x + be * prev.x, oi = al * cur.y + be * prev.y;
+  if (cd.precise) {
+    float c, s;
+    sd::phasor_u32((uint32_t)(n0 - cd.n_open + m) * cd.dphase, c, s);
+    const float tr = orr * c - oi * s, ti = orr * s + oi * c;
+    orr = tr; oi = ti;
+  }
+  return cf{orr, oi};
+}
+
 // OCC: workgroups per CU the register budget is cut for (the LDS of one workgroup is ~35 KB: up to 4 fit);
 // PREFETCH: request the next window's samples right after pass 0 of this one (32 VGPRs)
 template <int LOG2W, int LOG2S, int OCC, bool PREFETCH, int NGL>
@@ -93,7 +108,11 @@ __global__ __launch_bounds__(ST_THREADS, OCC) void st_kernel(sdk::StArgs a)
 
   // run of windows [w_begin, w_end); w_begin - 1 is the warm-up window (none for the first run: carried state)
   const long long w_begin = (long long)blockIdx.x * a.run, w_end = (w_begin + a.run < a.nwin) ? w_begin + a.run : a.nwin;
-  const long long w_first = w_begin > 0 ? w_begin - 1 : 0;
+  // a.handoff set (round 4): no warm-up window.  A run writes the raw first half of its first block and leaves its last
+  // window's second half in a.handoff[run][channel][size/2]; st_seam_kernel completes the first block of every later run
+  // from its predecessor's entry.  A third of the transforms of a 3-window run were warm-up.
+  const bool seam = a.handoff != nullptr;
+  const long long w_first = (seam || w_begin == 0) ? w_begin : w_begin - 1;
   const cf *x = reinterpret_cast<const cf *>(a.x), *hist = reinterpret_cast<const cf *>(a.hist);
   const long long off = a.have_hist ? H : 0;                   // virtual stream = hist (H samples) ++ x
 
@@ -170,6 +189,7 @@ __global__ __launch_bounds__(ST_THREADS, OCC) void st_kernel(sdk::StArgs a)
     PassRunner<LOG2S, G::TPI, 0, 1>::run(u, gscr, tbs, tl, nullptr);
     // u[b*RL + q] = conj(y[j + q*S/RL]), j = tl + b*TPI: q < RL/2 is the first half of the block, q + RL/2 its partner
     const bool emit = w >= w_begin;
+    const bool raw = seam && w == w_begin && w_begin > 0;
     const float *win = a.win;
     // time-major output ([m][channel] in memory, what the one-lane-per-channel loops stream): the block goes through an
     // LDS tile [i][channel] so that a wavefront stores 64 channels of one instant = 512 contiguous bytes; otherwise
@@ -188,17 +208,11 @@ __global__ __launch_bounds__(ST_THREADS, OCC) void st_kernel(sdk::StArgs a)
         const cf cur = cf{u[b * RLS + q].x, -u[b * RLS + q].y};
         const cf nx = cf{u[b * RLS + q + RLS / 2].x, -u[b * RLS + q + RLS / 2].y};
         if (emit && live) {
-          const float al = win[i], be = win[i + HS];
-          float orr = al * cur.x + be * prev[g][b][q].x, oi = al * cur.y + be * prev[g][b][q].y;
           const unsigned long long m = (unsigned long long)w * HS + i;      // output index within this feed
-          if (cd.precise) {
-            float c, s;
-            sd::phasor_u32((uint32_t)(a.n0 - cd.n_open + m) * cd.dphase, c, s);
-            const float tr = orr * c - oi * s, ti = orr * s + oi * c;
-            orr = tr; oi = ti;
-          }
-          if (tile) spec[i * TP + grp] = cf{orr, oi};
-          else ybase[(long long)m * yms] = cf{orr, oi};
+          // (raw: the first block of a later run -- its previous half is the run before's: st_seam_kernel)
+          const cf o = raw ? cur : st_emit(win[i], win[i + HS], cur, prev[g][b][q], cd, a.n0, m);
+          if (tile) spec[i * TP + grp] = o;
+          else ybase[(long long)m * yms] = o;
         }
         prev[g][b][q] = nx;
       }
@@ -224,7 +238,19 @@ __global__ __launch_bounds__(ST_THREADS, OCC) void st_kernel(sdk::StArgs a)
     __syncthreads();
     });
   }
-  // carry the last window's second half to the next feed
+  // the last window's second half: to the next run (seam) ...
+  if (seam && w_end != a.nwin) {
+#pragma unroll
+    for (int g = 0; g < NGL; ++g)
+      if (livev[g]) {
+        cf *sp = reinterpret_cast<cf *>(a.handoff) + ((long long)blockIdx.x * a.nchan + chv[g]) * HS;
+#pragma unroll
+        for (int b = 0; b < NBLS; ++b)
+#pragma unroll
+          for (int q = 0; q < RLS / 2; ++q) sp[tl0 + b * G::TPI + q * (S / RLS)] = prev[g][b][q];
+      }
+  }
+  // ... or to the next feed
   if (w_end == a.nwin) {
 #pragma unroll
     for (int g = 0; g < NGL; ++g)
@@ -237,6 +263,26 @@ __global__ __launch_bounds__(ST_THREADS, OCC) void st_kernel(sdk::StArgs a)
             reinterpret_cast<cf *>(a.prev_out)[(long long)chv[g] * HS + i] = prev[g][b][q];
           }
       }
+  }
+}
+
+// completes the first block of the runs 1 .. nruns-1 of an st_kernel launch with a.handoff: raw first half (where the run left
+// it) x sin^2 + the previous run's last second half x cos^2, residual NCO -- st_emit, as inside the run.  grid.y = run - 1.
+__global__ __launch_bounds__(256) void st_seam_kernel(sdk::StArgs a, int log2s)
+{
+  const int HS = (1 << log2s) / 2;
+  const long long r = (long long)blockIdx.y + 1, w = r * a.run;
+  const cf *seam = reinterpret_cast<const cf *>(a.handoff) + (r - 1) * (long long)a.nchan * HS;
+  const long long total = (long long)a.nchan * HS;
+  // neighbouring threads along the output's unit stride: channels for time-major views, time for rows / channel-major ones
+  const bool tm = !a.rows && a.yv.cs == 1 && a.yv.ms != 1;
+  for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int c = tm ? (int)(t % a.nchan) : (int)(t / HS), i = tm ? (int)(t / a.nchan) : (int)(t - (long long)c * HS);
+    const sdk::StChan cd = a.chans[c];
+    const unsigned long long m = (unsigned long long)w * HS + i;
+    cf *yp = a.rows ? static_cast<cf *>(const_cast<void *>(a.rows[cd.row])) + m
+                    : reinterpret_cast<cf *>(a.y) + (long long)cd.row * a.yv.cs + (long long)m * a.yv.ms;
+    *yp = st_emit(a.win[i], a.win[i + HS], *yp, seam[(long long)c * HS + i], cd, a.n0, m);
   }
 }
 
@@ -259,6 +305,10 @@ hipError_t launch_st_v(const sdk::StArgs &a, hipStream_t st)
   const unsigned nruns = (unsigned)((a.nwin + a.run - 1) / a.run);
   const unsigned ngroups = (unsigned)((a.nchan + G::CPP - 1) / G::CPP);
   sdk::launch_timed("st_kernel", kern, dim3(nruns, (ngroups + NGL - 1) / NGL), dim3(ST_THREADS), lds, st, a);
+  if (a.handoff && nruns > 1) {
+    const long long total = (long long)a.nchan * (1 << (LOG2S - 1));
+    sdk::launch_timed("st_seam_kernel", st_seam_kernel, dim3((unsigned)std::min<long long>(64, (total + 255) / 256), nruns - 1), dim3(256), 0, st, a, LOG2S);
+  }
   return hipGetLastError();
 }
 

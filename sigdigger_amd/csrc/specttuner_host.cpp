@@ -146,6 +146,8 @@ struct SizeGroup {
   c32 *d_handoff = nullptr;            // wavefront kernel: seam payload between consecutive runs, 16 KiB per run and block
   unsigned *d_flags = nullptr;         // one flag per run and block: the epoch of the launch that published it
   size_t ho_slots = 0;
+  c32 *d_seam = nullptr;               // workgroup kernel: a run's last second half for its successor, [run][channel][size / 2]
+  size_t seam_elems = 0;
   unsigned epoch = 0;                  // flag value of the next launch
   bool hk_uniform = false;             // one response for all members
   int nsel = 0;                        // distinct responses of the members (tables in d_hk)
@@ -160,8 +162,8 @@ struct SizeGroup {
   c32 *snap_prev = nullptr;
   void release()
   {
-    for (void *p : {(void *)d_handoff, (void *)d_flags, (void *)d_chans, (void *)d_hk, (void *)d_hkt, (void *)d_tw, (void *)d_win, (void *)d_prev[0], (void *)d_prev[1], (void *)snap_prev}) if (p) (void)hipFree(p);
-    d_chans = nullptr; d_hk = d_tw = d_hkt = d_handoff = nullptr; d_flags = nullptr; ho_slots = 0; d_win = nullptr; d_prev[0] = d_prev[1] = nullptr; snap_prev = nullptr;
+    for (void *p : {(void *)d_handoff, (void *)d_seam, (void *)d_flags, (void *)d_chans, (void *)d_hk, (void *)d_hkt, (void *)d_tw, (void *)d_win, (void *)d_prev[0], (void *)d_prev[1], (void *)snap_prev}) if (p) (void)hipFree(p);
+    d_chans = nullptr; d_hk = d_tw = d_hkt = d_handoff = d_seam = nullptr; d_flags = nullptr; ho_slots = 0; seam_elems = 0; d_win = nullptr; d_prev[0] = d_prev[1] = nullptr; snap_prev = nullptr;
   }
 };
 
@@ -636,6 +638,26 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
 #endif
       } else {
         if (!st->run) a.run = sdk::st_plan_run(g.log2s, a.nchan, nwin);
+        {
+          // seam buffer of the runs: no warm-up window, the first block of every later run completed by st_seam_kernel.
+          // Banks that fit one workgroup side by side only (measured per 4 Mi samples, tools/st_wide.py: one channel of 256
+          // bins 49.1 -> 44.7 us, of 128 bins 46.6 -> 40.3; 64 x 256 bins 136 -> 143, 128 x 256 267 -> 284: there a run is
+          // long and the warm-up window a ninth of it, less than the second launch costs).  SUAMD_ST_SEAM=0 / 1: never / always.
+          static const int seam_env = [] { const char *e2 = std::getenv("SUAMD_ST_SEAM"); return e2 ? (e2[0] == '0' ? 0 : 1) : -1; }();
+          const bool seam_off = seam_env == 0 || (seam_env < 0 && a.nchan > sdk::st_channels_per_group(g.log2s));
+          const size_t nruns = (size_t)((nwin + a.run - 1) / a.run);
+          const size_t need = nruns > 1 ? (nruns - 1) * (size_t)a.nchan * ((size_t)1 << (g.log2s - 1)) : 0;
+          a.handoff = nullptr;
+          if (!seam_off && need && g.log2s >= 1 && need * sizeof(c32) <= ((size_t)256 << 20)) {
+            if (need > g.seam_elems) {
+              if (g.d_seam) (void)hipFree(g.d_seam);
+              g.d_seam = nullptr; g.seam_elems = 0;
+              if (hipMalloc((void **)&g.d_seam, need * sizeof(c32)) == hipSuccess) g.seam_elems = need;
+              else (void)hipGetLastError();
+            }
+            a.handoff = g.d_seam;                                 // (null: the launch falls back to warm-up windows)
+          }
+        }
         e = sdk::specttuner_feed(st->log2w, g.log2s, a, s);
       }
       if (e != hipSuccess) { suamd_set_error("specttuner launch failed: %s", hipGetErrorString(e)); return SU_FALSE; }

@@ -462,3 +462,24 @@ def test_few_narrow_channels_with_their_own_responses_on_the_one_wavefront_kerne
     two = run_gpu(ctx, x, chans, splits=[H * 13])
     for a, b, c in zip(one, one64, two):
         assert a.size > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(a.view(np.uint32), c.view(np.uint32))
+
+
+@pytest.mark.parametrize("dec,nch", [(16, 1), (16, 5), (16, 40), (32, 70), (8, 3), (1, 1), (4, 2)])
+def test_wide_channels_without_the_warm_up_window(ctx, monkeypatch, dec, nch):
+    """The workgroup kernel's two ways over the seam of consecutive runs: a warm-up window per run (SUAMD_ST_SEAM=0: the
+    window before the run is transformed again for its second half) and the hand-off (SUAMD_ST_SEAM=1: the run leaves its
+    last second half in a buffer, st_seam_kernel completes the next run's first block) -- the same samples bit for bit,
+    with and without a residual NCO, channel-major and time-major output, runs of 1, 2 and 5 windows, feeds cut at
+    arbitrary half windows, one or two channel groups per workgroup."""
+    x = cnoise(H * 47, 900 + dec + nch)
+    bw = 2 * np.pi * 0.75 / dec
+    chans = [(0.3 + 6.0 * c / max(nch, 2), bw * (0.6 + 0.4 * (c % 3) / 2), 1.0, bool(c % 2)) for c in range(nch)]
+    for run in (1, 2, 5, None):
+        for tm in (False, True):
+            monkeypatch.setenv("SUAMD_ST_SEAM", "0")
+            ref = run_gpu(ctx, x, chans, splits=[H * 9, H * 10, H * 31], run=run, time_major=tm)
+            monkeypatch.setenv("SUAMD_ST_SEAM", "1")
+            got = run_gpu(ctx, x, chans, splits=[H * 9, H * 10, H * 31], run=run, time_major=tm)
+            monkeypatch.delenv("SUAMD_ST_SEAM")
+            for a, b in zip(ref, got):
+                assert a.size == b.size > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (run, tm)
