@@ -315,7 +315,6 @@ hipError_t launch_st_v(const sdk::StArgs &a, hipStream_t st)
 template <int LOG2W, int LOG2S>
 hipError_t launch_st(const sdk::StArgs &a, hipStream_t st)
 {
-  using G = StGeomT<LOG2S>;
   static const int variant = [] { const char *e = getenv("SUAMD_ST_VARIANT"); return e ? atoi(e) : 0; }();
   switch (variant) {
     case 1:  return launch_st_v<LOG2W, LOG2S, 2, true, 1>(a, st);

@@ -40,7 +40,7 @@ __device__ __forceinline__ cf xfade_p(float al, cf cur, float be, cf prv)
 typedef __attribute__((address_space(1))) cf gcf;
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 constexpr int WAVE = 64;
-constexpr int PW_W = 4096, PW_H = 2048, PW_S = 64, PW_HS = 32;
+constexpr int PW_W = 4096, PW_H = 2048;
 constexpr int PW_PITCH = 65;                                   // transposition pitch (elements)
 constexpr int PW_REP = 32;                                     // spectrum bins repeated after the end
 constexpr int PW_FLAG = WAVE * PW_PITCH;                       // one word the wavefronts of a pair share (seam decision), behind the transposition buffer
