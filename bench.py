@@ -367,8 +367,16 @@ def run_workload(name, args, rank, world, dev, ctx, dist):
     for kname in CHANNELISER_KERNELS + ("psd_kernel", "psd_reduce_kernel"):
         r = engine.kernel_timing_read(kname)
         if r["launches"]:
-            pipe.kernel_ms[kname] = {"avg": r["sum_ms"] / r["launches"], "min": r["min_ms"], "max": r["max_ms"], "launches": r["launches"],
-                                     "per_step": r["sum_ms"] / args.steps}
+            n, tot = r["launches"], r["sum_ms"]
+            entry = {"avg": tot / n, "min": r["min_ms"], "max": r["max_ms"], "launches": n}
+            # One sample far beyond the rest is not a launch: now and then an event pair of a 50-100 us kernel reads 1-2 ms
+            # (the queue stalls between the two events; rocprofv3's trace of the same runs never shows such a kernel, and
+            # pipeline.stage_times_ms drops the same samples from stage_ms).  The single worst sample is dropped when it is
+            # more than five times the shortest one, and said so.
+            if n >= 8 and r["max_ms"] > 5.0 * r["min_ms"]:
+                entry.update({"avg": (tot - r["max_ms"]) / (n - 1), "avg_all_samples": tot / n, "dropped_stalled_sample_ms": r["max_ms"]})
+            entry["per_step"] = entry["avg"] * n / args.steps
+            pipe.kernel_ms[kname] = entry
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -340,6 +340,19 @@ __device__ __forceinline__ float2 costas_step(const sdk::CostasParams &p, Costas
   return float2{z.re, z.im};
 }
 
+// Where a recurrence kernel's one wavefront sits: workgroups are dealt round the chip's eight XCDs in launch order, so the
+// only workgroup of a 64-channel launch always lands on XCD 0 -- and so do the other two recurrence stages', each taking a
+// workgroup slot (registers, the clock kernel's 32 KB of LDS) away from the SAME 32 CUs.  A transform launch planned for
+// one round of the chip (the channeliser: 745 workgroups, 93-94 per XCD for 96 slots) then finds XCD 0 two or three
+// short and runs a second round there: 131 instead of 87 us whenever clock and Costas wavefronts were both resident
+// (rocprofv3 kernel trace, profiles/r04_inpipe_penalty.txt).  With `xcd` >= 0 the launch has eight workgroups per block
+// of channels and only number `xcd` of each eight does the work: the stages sit on different XCDs.
+__device__ __forceinline__ int serial_block(int xcd, bool &mine)
+{
+  mine = xcd < 0 || (int)(blockIdx.x & 7) == xcd;
+  return xcd < 0 ? (int)blockIdx.x : (int)(blockIdx.x >> 3);
+}
+
 // A single wavefront issues roughly one instruction every 4-5 cycles, so the cost of a serial
 // recurrence is its dynamic instruction count per sample: the loop kind is a template
 // parameter (no per-sample scalar branching), full chunks run without bounds checks and only
@@ -347,10 +360,11 @@ __device__ __forceinline__ float2 costas_step(const sdk::CostasParams &p, Costas
 template <int KIND, int ORDER, bool GAIN1>
 __global__ __launch_bounds__(64) void costas_kernel(sdk::CostasParams p, sdk::CostasState s, int nchan,
                                                     const float2 *__restrict__ x, sdk::View xv,
-                                                    float2 *__restrict__ y, sdk::View yv, long long len)
+                                                    float2 *__restrict__ y, sdk::View yv, long long len, int xcd)
 {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= nchan) return;
+  bool mine;
+  const int c = serial_block(xcd, mine) * 64 + threadIdx.x;
+  if (!mine || c >= nchan) return;
   CostasRegs<ORDER> r;
   r.phase = s.phase[c];
   r.omega = s.omega[c];
@@ -593,10 +607,11 @@ __global__ __launch_bounds__(64) void agc_state_items_kernel(const sdk::AgcState
 }
 
 __global__ __launch_bounds__(64) void agc_level_kernel(sdk::AgcParams p, sdk::AgcState s, int nchan,
-                                                       long long len, float *__restrict__ peak)
+                                                       long long len, float *__restrict__ peak, int xcd)
 {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= nchan) return;
+  bool mine;
+  const int c = serial_block(xcd, mine) * 64 + threadIdx.x;
+  if (!mine || c >= nchan) return;
   unsigned hang_n = s.hang_n[c];
   float fast = s.fast_level[c], slow = s.slow_level[c];
   const uint32_t lo = (uint32_t)c * 4u;
@@ -1083,9 +1098,11 @@ __device__ __forceinline__ void clock_stream_tm(const float2 *base, const long l
 __global__ __launch_bounds__(64) void clock_kernel(sdk::ClockParams p, sdk::ClockState s, int nchan,
                                                    const float2 *__restrict__ x, sdk::View xv, long long len,
                                                    float2 *__restrict__ sym, long long sym_stride,
-                                                   uint32_t *__restrict__ count, int mode)
+                                                   uint32_t *__restrict__ count, int mode, int xcd)
 {
-  const int cc = blockIdx.x * 64 + threadIdx.x;
+  bool mine;
+  const int cc = serial_block(xcd, mine) * 64 + threadIdx.x;
+  if (!mine) return;
   const bool live = cc < nchan;                               // idle lanes take part in the wave-wide steps with length 0
   const int c = live ? cc : 0;
   ClockRegs r;
@@ -1254,17 +1271,29 @@ hipError_t sample_manual_bulk(const void *data, long long length, double symbol_
   return hipGetLastError();
 }
 
+// grid of a recurrence launch and the XCD its wavefronts go to (SUAMD_SERIAL_XCD=0: one workgroup per block of channels on
+// whatever XCD the dispatcher's round robin gives it -- XCD 0 for a single block)
+static int serial_xcd(int stage, dim3 &grid)
+{
+  static const bool off = [] { const char *e = getenv("SUAMD_SERIAL_XCD"); return e && e[0] == '0'; }();
+  if (off || grid.x > 64) return -1;
+  grid.x *= 8;
+  return stage;                                                // AGC 3, Costas 1, clock 2: three different XCDs
+}
+
 hipError_t costas_feed(const CostasParams &p, const CostasState &s, int nchan, const void *x, View xs,
                        void *y, View ys, long long len, hipStream_t st)
 {
   if (len <= 0 || nchan <= 0) return hipSuccess;
-  const dim3 grid((nchan + 63) / 64), block(64);
+  dim3 grid((nchan + 63) / 64);
+  const dim3 block(64);
+  const int xcd = serial_xcd(1, grid);
   const float2 *xx = reinterpret_cast<const float2 *>(x);
   float2 *yy = reinterpret_cast<float2 *>(y);
 #define SD_COSTAS_CASE(K, O) \
   case (K) * 8 + (O): \
-    if (p.gain == 1.0f) hipLaunchKernelGGL((costas_kernel<K, O, true>), grid, block, 0, st, p, s, nchan, xx, xs, yy, ys, len); \
-    else hipLaunchKernelGGL((costas_kernel<K, O, false>), grid, block, 0, st, p, s, nchan, xx, xs, yy, ys, len); \
+    if (p.gain == 1.0f) hipLaunchKernelGGL((costas_kernel<K, O, true>), grid, block, 0, st, p, s, nchan, xx, xs, yy, ys, len, xcd); \
+    else hipLaunchKernelGGL((costas_kernel<K, O, false>), grid, block, 0, st, p, s, nchan, xx, xs, yy, ys, len, xcd); \
     break;
   if (p.order < 0 || p.order > 4 || p.kind < 1 || p.kind > 3) return hipErrorInvalidValue;
   switch (p.kind * 8 + p.order) {
@@ -1291,8 +1320,10 @@ hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, cons
 {
   if (len <= 0 || nchan <= 0) return hipSuccess;
   static const int mode = getenv("SUAMD_CLOCK_MODE") ? atoi(getenv("SUAMD_CLOCK_MODE")) : 0;   // tuning knob: 1 = crossing by crossing
-  hipLaunchKernelGGL(clock_kernel, dim3((nchan + 63) / 64), dim3(64), 0, st, p, s, nchan,
-                     reinterpret_cast<const float2 *>(x), xs, len, reinterpret_cast<float2 *>(sym), sym_stride, count, mode);
+  dim3 grid((nchan + 63) / 64);
+  const int xcd = serial_xcd(2, grid);
+  hipLaunchKernelGGL(clock_kernel, grid, dim3(64), 0, st, p, s, nchan,
+                     reinterpret_cast<const float2 *>(x), xs, len, reinterpret_cast<float2 *>(sym), sym_stride, count, mode, xcd);
   return hipGetLastError();
 }
 
@@ -1334,7 +1365,9 @@ hipError_t agc_feed(const AgcParams &p, const AgcState &s, int nchan, const void
   if (len <= 0 || nchan <= 0) return hipSuccess;
   hipError_t e = agc_feed_pre(p, s, nchan, x, xv, len, scratch, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(agc_level_kernel, dim3((nchan + 63) / 64), dim3(64), 0, st, p, s, nchan, len, scratch + len * nchan);
+  dim3 grid((nchan + 63) / 64);
+  const int xcd = serial_xcd(3, grid);
+  hipLaunchKernelGGL(agc_level_kernel, grid, dim3(64), 0, st, p, s, nchan, len, scratch + len * nchan, xcd);
   return agc_feed_post(p, s, nchan, x, xv, y, yv, len, scratch, st);
 }
 
