@@ -343,26 +343,30 @@ def run_workload(name, args, rank, world, dev, ctx, dist):
             work.wait()
 
     def fence():
+        pipe.flush()                  # (a transform window holds the last block's tail back until the next block comes)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if dist is not None:
-        pipeline.broadcast_block(bufs[0], dist, async_op=False)
-    for k in range(args.warmup):
-        one_step(k, False)
-    fence()
-    pipe.reset_events()
-    # the roofline leg: the channeliser's and the PSD's launches carry an event pair bound to the dispatch itself
-    # (suamd_kernel_timing) -- the kernel's own duration, what rocprofv3 --kernel-trace reports for it
-    engine.kernel_timing_read()
-    engine.kernel_timing(True)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(k, True)
-    fence()
-    dt = time.perf_counter() - t0
-    engine.kernel_timing(False)
+    # the steps are enqueued with the pipeline's transform stream current (CU-partitioned device: the masked stream the PSD
+    # and the channeliser run on), so the block broadcast orders itself against that stream and a step costs no extra events
+    with torch.cuda.stream(pipe.main_stream()):
+        if dist is not None:
+            pipeline.broadcast_block(bufs[0], dist, async_op=False)
+        for k in range(args.warmup):
+            one_step(k, False)
+        fence()
+        pipe.reset_events()
+        # the roofline leg: the channeliser's and the PSD's launches carry an event pair bound to the dispatch itself
+        # (suamd_kernel_timing) -- the kernel's own duration, what rocprofv3 --kernel-trace reports for it
+        engine.kernel_timing_read()
+        engine.kernel_timing(True)
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            one_step(k, True)
+        fence()
+        dt = time.perf_counter() - t0
+        engine.kernel_timing(False)
     pipe.kernel_ms = {}
     for kname in CHANNELISER_KERNELS + ("psd_kernel", "psd_reduce_kernel"):
         r = engine.kernel_timing_read(kname)

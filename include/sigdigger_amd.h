@@ -75,6 +75,19 @@ SUAMD_API SUBOOL suamd_kernel_timing_read(const char *kernel, double *sum_ms, do
 SUAMD_API suamd_ctx_t *suamd_ctx_new(int device_ordinal);
 SUAMD_API void         suamd_ctx_destroy(suamd_ctx_t *ctx);
 SUAMD_API int          suamd_ctx_device(const suamd_ctx_t *ctx);
+/* Streams confined to a set of compute units (no counterpart in the reference; the live path and bench.py use it to keep
+ * the one-wavefront recurrences -- su_costas / su_clock_detector / su_agc level trackers, milliseconds per launch -- off
+ * the CUs the transform kernels plan their single round of workgroups for).  `cu_mask` has `nwords` 32-bit words, bit i
+ * of the whole = compute unit i in the driver's numbering, which deals consecutive bits to consecutive XCDs (bit i is
+ * on XCD i mod 8 of an MI355X: suamd_probe_placement shows it); at least one bit must be set.  The stream is
+ * non-blocking, gets a hardware queue of its own and is destroyed with suamd_stream_destroy.  NULL on failure. */
+SUAMD_API unsigned suamd_ctx_cu_count(const suamd_ctx_t *ctx);
+SUAMD_API void    *suamd_stream_new_cu_mask(suamd_ctx_t *ctx, const uint32_t *cu_mask, unsigned nwords);
+SUAMD_API SUBOOL   suamd_stream_destroy(suamd_ctx_t *ctx, void *stream);
+/* Where `nblocks` one-wavefront workgroups launched on `stream` ran: h_where[b] = xcc_id << 16 | se_id << 8 | cu_id of
+ * workgroup b (host array; the call synchronises the stream).  Every workgroup spins for `spin_ticks` of the shader clock
+ * so that a launch larger than the stream's CUs really spreads over all of them. */
+SUAMD_API SUBOOL   suamd_probe_placement(suamd_ctx_t *ctx, void *stream, unsigned nblocks, unsigned spin_ticks, uint32_t *h_where);
 
 /* ------------------------------------------------------------------------------------ */
 /* A2-A4, A9: main-spectrum PSD                                                          */
@@ -95,6 +108,12 @@ enum suamd_psd_mode {
  * up to 16384 the frame stays in LDS, larger frames go pass by pass through HBM. */
 SUAMD_API suamd_psd_t *suamd_psd_new(suamd_ctx_t *ctx, unsigned window_size, int window_type);
 SUAMD_API void         suamd_psd_destroy(suamd_psd_t *psd);
+/* Launch plan of the in-LDS sizes (512 .. 16384 points): when a feed has fewer outputs than workgroups the chip holds,
+ * the navg frames of an output are split over several workgroups (partial sums, one more short launch) -- aiming at
+ * `workgroups` per launch.  0 restores the default: 1024 up to 4096 points, 256 above (one workgroup per CU: what a launch
+ * that shares the chip with other streams' long-running kernels can count on).  512 is for 8192-point frames on a chip the
+ * launch has to itself (two workgroups per CU fit).  The result does not depend on it beyond the summation order. */
+SUAMD_API SUBOOL       suamd_psd_set_split_target(suamd_psd_t *psd, unsigned workgroups);
 /* For o < nframes/navg:
  *   d_out[o*N + i] = scale/navg * sum_{f<navg} |FFT_N(window .* d_x[(o*navg+f)*hop ...])[i]|^2
  * (mode LINEAR), or its fftshift + 10*log10(. + 1e-8) (mode DB_SHIFTED). */
@@ -507,6 +526,13 @@ SUAMD_API void   suamd_agc_bank_destroy(suamd_agc_bank_t *b);
 /* `dest[p] = su_agc_feed(&agc, origin[p])` loop (Tasks/AGCTask.cpp:70-73) */
 SUAMD_API SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d_x, suamd_view xv,
                                      suamd_complex *d_y, suamd_view yv, SUSCOUNT len, void *stream);
+/* The same on two streams: the level trackers (the AGC's one recurrence: one wavefront per 64 channels, milliseconds per
+ * launch) on `stream_level`, its feed-forward kernels (|x|^2 in dB, sliding maximum, gain on the delayed input, state carry:
+ * many workgroups, microseconds) on `stream_wide`, ordered by device-side event waits.  For callers that confine their
+ * recurrence streams to a few compute units (suamd_stream_new_cu_mask): the feed-forward kernels must not be confined
+ * with them.  The input is read and the output complete on `stream_wide`.  Same samples bit for bit. */
+SUAMD_API SUBOOL suamd_agc_bank_feed_split(suamd_agc_bank_t *b, const suamd_complex *d_x, suamd_view xv,
+                                           suamd_complex *d_y, suamd_view yv, SUSCOUNT len, void *stream_level, void *stream_wide);
 
 /* ------------------------------------------------------------------------------------ */
 /* T9 / T10: whole-capture FFT tasks                                                     */

@@ -211,6 +211,7 @@ struct suamd_psd {
   void  *d_tw_row = nullptr;   // frames beyond the LDS (psd_large.hip): W_N1 table of the row transforms, float2[N1]
   void  *d_tw_half = nullptr;  // 32768-point frames in one trip (psd_kernel HALVES): W_16384 table
   Scratch partial;       // split-frame partial sums
+  int split_target = 0;  // suamd_psd_set_split_target (0: the kernel family's default)
 };
 
 struct suamd_chanbank {
@@ -254,6 +255,7 @@ struct suamd_agc_bank {
   sdk::AgcParams p;
   sdk::AgcState  s;
   Scratch scratch;       // 2 x [len][nchan] floats: magnitudes in dB; their sliding maximum, then levels
+  hipEvent_t ev[2] = {nullptr, nullptr};   // suamd_agc_bank_feed_split: the two hops between its streams
 };
 
 template <typename Item>
@@ -399,6 +401,71 @@ suamd_ctx_t *suamd_ctx_new(int device_ordinal)
 void suamd_ctx_destroy(suamd_ctx_t *ctx) { delete ctx; }
 int  suamd_ctx_device(const suamd_ctx_t *ctx) { return ctx ? ctx->device : -1; }
 
+SUBOOL suamd_psd_set_split_target(suamd_psd_t *psd, unsigned workgroups)
+{
+  if (!psd || workgroups > 65536) { set_err("bad argument"); return SU_FALSE; }
+  psd->split_target = (int)workgroups;
+  return SU_TRUE;
+}
+
+// ---- CU-masked streams ---------------------------------------------------------------------
+unsigned suamd_ctx_cu_count(const suamd_ctx_t *ctx)
+{
+  if (!ctx) return 0;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) return 0;
+  return n > 0 ? (unsigned)n : 0;
+}
+
+void *suamd_stream_new_cu_mask(suamd_ctx_t *ctx, const uint32_t *cu_mask, unsigned nwords)
+{
+  if (!ctx || !cu_mask || !nwords) { set_err("null context or empty CU mask"); return nullptr; }
+  uint32_t any = 0;
+  for (unsigned i = 0; i < nwords; ++i) any |= cu_mask[i];
+  if (!any) { set_err("a CU mask without a compute unit"); return nullptr; }
+  HIP_TRY(hipSetDevice(ctx->device), nullptr);
+  hipStream_t st = nullptr;
+  HIP_TRY(hipExtStreamCreateWithCUMask(&st, nwords, cu_mask), nullptr);
+  return st;
+}
+
+SUBOOL suamd_stream_destroy(suamd_ctx_t *ctx, void *stream)
+{
+  if (!ctx || !stream) { set_err("null context or stream"); return SU_FALSE; }
+  HIP_TRY(hipSetDevice(ctx->device), SU_FALSE);
+  HIP_TRY(hipStreamDestroy((hipStream_t)stream), SU_FALSE);
+  return SU_TRUE;
+}
+
+namespace {
+__global__ void __launch_bounds__(64) placement_kernel(uint32_t *where, unsigned spin)
+{
+  unsigned hw, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  while (__builtin_readcyclecounter() - t0 < spin) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0)                                        // HW_ID: CU_ID [11:8], SH_ID [12], SE_ID [15:13]
+    where[blockIdx.x] = (xcc & 0xf) << 16 | ((hw >> 12) & 0xf) << 8 | ((hw >> 8) & 0xf);
+}
+}
+
+SUBOOL suamd_probe_placement(suamd_ctx_t *ctx, void *stream, unsigned nblocks, unsigned spin_ticks, uint32_t *h_where)
+{
+  if (!ctx || !h_where || !nblocks) { set_err("null argument"); return SU_FALSE; }
+  HIP_TRY(hipSetDevice(ctx->device), SU_FALSE);
+  uint32_t *d = nullptr;
+  HIP_TRY(hipMalloc(&d, sizeof(uint32_t) * nblocks), SU_FALSE);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(placement_kernel, dim3(nblocks), dim3(64), 0, st, d, spin_ticks);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(h_where, d, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d);
+  if (e != hipSuccess) { set_err("placement probe: %s", hipGetErrorString(e)); return SU_FALSE; }
+  return SU_TRUE;
+}
+
 // ---- PSD -----------------------------------------------------------------------------------
 suamd_psd_t *suamd_psd_new(suamd_ctx_t *ctx, unsigned n, int window_type)
 {
@@ -528,6 +595,7 @@ SUBOOL suamd_psd_feed(suamd_psd_t *p, const suamd_complex *d_x, SUSCOUNT nframes
                                   base, base + cb, reinterpret_cast<float *>(base + 2 * cb), (int)batch, as_stream(stream)), SU_FALSE);
     return SU_TRUE;
   }
+  struct Plan { Plan(int t) { sdk::psd_split_target(t); } ~Plan() { sdk::psd_split_target(0); } } plan(p->split_target);
   const int S = sdk::psd_split(nout, (int)navg, (int)p->log2n);
   float *partial = nullptr;
   if (S > 1) {
@@ -1382,6 +1450,7 @@ void suamd_agc_bank_destroy(suamd_agc_bank_t *b)
   if (b->s.fast_level) hipFree(b->s.fast_level);
   if (b->s.slow_level) hipFree(b->s.slow_level);
   b->scratch.release();
+  for (hipEvent_t e : b->ev) if (e) (void)hipEventDestroy(e);
   delete b;
 }
 
@@ -1396,6 +1465,32 @@ SUBOOL suamd_agc_bank_feed(suamd_agc_bank_t *b, const suamd_complex *d_x, suamd_
   if (!b->scratch.reserve(2 * sizeof(float) * (size_t)len * b->nchan)) { set_err("scratch allocation failed"); return SU_FALSE; }
   HIP_TRY(sdk::agc_feed(b->p, b->s, (int)b->nchan, d_x, as_view(xv), d_y, as_view(yv), (long long)len,
                         static_cast<float *>(b->scratch.p), as_stream(stream)), SU_FALSE);
+  b->n_fed += len;
+  return SU_TRUE;
+}
+
+SUBOOL suamd_agc_bank_feed_split(suamd_agc_bank_t *b, const suamd_complex *d_x, suamd_view xv, suamd_complex *d_y,
+                                 suamd_view yv, SUSCOUNT len, void *stream_level, void *stream_wide)
+{
+  if (!b) { set_err("null argument"); return SU_FALSE; }
+  if (len == 0) return SU_TRUE;
+  if (!d_x || !d_y) { set_err("null argument"); return SU_FALSE; }
+  if (d_x == d_y) { set_err("the AGC bank cannot run in place (the output is the input delayed)"); return SU_FALSE; }
+  hipStream_t sl = as_stream(stream_level), sw = as_stream(stream_wide);
+  if (sl == sw) return suamd_agc_bank_feed(b, d_x, xv, d_y, yv, len, stream_wide);
+  if (!b->scratch.reserve(2 * sizeof(float) * (size_t)len * b->nchan)) { set_err("scratch allocation failed"); return SU_FALSE; }
+  for (hipEvent_t &e : b->ev)
+    if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming), SU_FALSE);
+  float *scratch = static_cast<float *>(b->scratch.p);
+  // wide: magnitudes + sliding maximum -> level: the trackers -> wide: gain on the delayed input, state carry.  Both hops
+  // are device-side waits; the scratch needs no more: the next call's first step sits behind this call's last on `wide`
+  HIP_TRY(sdk::agc_feed_pre(b->p, b->s, (int)b->nchan, d_x, as_view(xv), (long long)len, scratch, sw), SU_FALSE);
+  HIP_TRY(hipEventRecord(b->ev[0], sw), SU_FALSE);
+  HIP_TRY(hipStreamWaitEvent(sl, b->ev[0], 0), SU_FALSE);
+  HIP_TRY(sdk::agc_feed_level(b->p, b->s, (int)b->nchan, (long long)len, scratch, sl), SU_FALSE);
+  HIP_TRY(hipEventRecord(b->ev[1], sl), SU_FALSE);
+  HIP_TRY(hipStreamWaitEvent(sw, b->ev[1], 0), SU_FALSE);
+  HIP_TRY(sdk::agc_feed_post(b->p, b->s, (int)b->nchan, d_x, as_view(xv), d_y, as_view(yv), (long long)len, scratch, sw), SU_FALSE);
   b->n_fed += len;
   return SU_TRUE;
 }

@@ -33,6 +33,7 @@ struct View { long long cs, ms; };
 // partial: scratch for split-frame accumulation, >= nout * psd_split(nout, navg, log2n) * N floats (may be
 // nullptr when psd_split() == 1)
 int        psd_split(long long nout, int navg, int log2n);
+void       psd_split_target(int target);      // this thread's next psd_split() calls aim at `target` workgroups (0: the defaults)
 hipError_t psd_frames(int log2n, const void *x, long long hop, int navg, const float *window,
                       const void *tw, float scale, int mode, float *out, long long nout, float *partial,
                       hipStream_t st);
@@ -214,6 +215,8 @@ hipError_t agc_feed_pre(const AgcParams &p, const AgcState &s, int nchan, const 
                         float *scratch, hipStream_t st);
 hipError_t agc_feed_post(const AgcParams &p, const AgcState &s, int nchan, const void *x, View xv, void *y, View yv,
                          long long len, float *scratch, hipStream_t st);
+// the level trackers between the two (the one recurrence of the AGC: one lane per channel)
+hipError_t agc_feed_level(const AgcParams &p, const AgcState &s, int nchan, long long len, float *scratch, hipStream_t st);
 struct AgcGangItem { AgcParams p; AgcState s; float *peak; long long len; };
 // gain on the delayed input for outputs [m0, m1) of many 1-channel banks (rows contiguous): one launch, grid.y = item
 struct AgcApplyItem { AgcParams p; const float *delay_line; const void *x; void *y; const float *lvl; long long m0, m1; };

@@ -1365,10 +1365,18 @@ hipError_t agc_feed(const AgcParams &p, const AgcState &s, int nchan, const void
   if (len <= 0 || nchan <= 0) return hipSuccess;
   hipError_t e = agc_feed_pre(p, s, nchan, x, xv, len, scratch, st);
   if (e != hipSuccess) return e;
+  e = agc_feed_level(p, s, nchan, len, scratch, st);
+  if (e != hipSuccess) return e;
+  return agc_feed_post(p, s, nchan, x, xv, y, yv, len, scratch, st);
+}
+
+hipError_t agc_feed_level(const AgcParams &p, const AgcState &s, int nchan, long long len, float *scratch, hipStream_t st)
+{
+  if (len <= 0 || nchan <= 0) return hipSuccess;
   dim3 grid((nchan + 63) / 64);
   const int xcd = serial_xcd(3, grid);
   hipLaunchKernelGGL(agc_level_kernel, grid, dim3(64), 0, st, p, s, nchan, len, scratch + len * nchan, xcd);
-  return agc_feed_post(p, s, nchan, x, xv, y, yv, len, scratch, st);
+  return hipGetLastError();
 }
 
 hipError_t agc_apply_items(const AgcApplyItem *d_items, int n, long long max_span, hipStream_t st)

@@ -370,6 +370,10 @@ namespace sdk {
 
 // how many workgroups share the navg frames of one output: enough to fill the chip's resident-workgroup slots for
 // that frame size, at least `minf` frames each
+// a caller's plan for the launches of this thread (suamd_psd_set_split_target): 0 = the defaults below
+static thread_local int t_split_target = 0;
+void psd_split_target(int target) { t_split_target = target > 0 ? target : 0; }
+
 int psd_split(long long nout, int navg, int log2n)
 {
   // Resident workgroups on the chip (256 CUs): 4 per CU for N <= 4096, 2 for 8192, 1 for 16384 (LDS).  At least `minf`
@@ -393,7 +397,7 @@ int psd_split(long long nout, int navg, int log2n)
   // workgroups of 8 frames: 49.6 + 4.8 inside, 38.2 + 5.3 alone, and half the partial sums (1.125 x instead of 1.25 x the
   // algorithmic bytes).  Blocks of 4 Mi samples and captures are not affected: the first is bounded by `minf`, the second
   // never splits.  tools/psd_block.py, tools/inpipe_sweep.sh, profiles/r04_inpipe_penalty.txt)
-  const int target = target_env > 0 ? target_env : (log2n <= 12 ? 1024 : 256);
+  const int target = t_split_target > 0 ? t_split_target : target_env > 0 ? target_env : (log2n <= 12 ? 1024 : 256);
   if (nout <= 0 || navg < 2 * minf || nout >= target) return 1;
   long long s = (target + nout - 1) / nout;
   if (s > navg / minf) s = navg / minf;

@@ -86,6 +86,31 @@ class Context:
         except Exception:
             pass
 
+    # ---- streams confined to a set of compute units ---------------------------------------
+    def cu_count(self):
+        return int(self.lib.suamd_ctx_cu_count(self.h))
+
+    def masked_stream(self, cus):
+        """A non-blocking HIP stream whose kernels only run on the compute units in `cus` (driver numbering: consecutive
+        indices sit on consecutive XCDs), wrapped for torch (an ExternalStream does not own it: destroy_stream)."""
+        n = max(self.cu_count(), max(cus) + 1)
+        words = (C.c_uint32 * ((n + 31) // 32))()
+        for c in cus:
+            words[c >> 5] |= 1 << (c & 31)
+        h = self.lib.suamd_stream_new_cu_mask(self.h, words, len(words))
+        if not h:
+            raise SigDiggerAmdError("suamd_stream_new_cu_mask: " + _l.last_error())
+        return torch.cuda.ExternalStream(h, device=torch.device("cuda", self.device))
+
+    def destroy_stream(self, stream):
+        check(self.lib.suamd_stream_destroy(self.h, C.c_void_p(stream.cuda_stream)), "suamd_stream_destroy")
+
+    def probe_placement(self, stream, nblocks=2048, spin_ticks=20000):
+        """(xcc, se, cu) of every workgroup of a probe launch on `stream` (suamd_probe_placement)."""
+        out = (C.c_uint32 * nblocks)()
+        check(self.lib.suamd_probe_placement(self.h, _stream(stream), nblocks, spin_ticks, out), "suamd_probe_placement")
+        return [((w >> 16) & 0xf, (w >> 8) & 0xf, w & 0xf) for w in out]
+
     # ---- element-wise entry points -------------------------------------------------------
     def psd_shift_db(self, psd, stream=None):
         """PSDMessage ctor loop, in place on [frames, n] (or [n])."""
@@ -291,6 +316,10 @@ class PSD:
             self.close()
         except Exception:
             pass
+
+    def set_split_target(self, workgroups):
+        """workgroups a launch with few outputs is split into (suamd_psd_set_split_target; 0: the default)"""
+        check(self.ctx.lib.suamd_psd_set_split_target(self.h, int(workgroups)), "suamd_psd_set_split_target")
 
     def feed(self, x, nframes=None, hop=None, navg=1, scale=1.0, mode=PSD_LINEAR, out=None, stream=None):
         _chk_c64(x, "x")
@@ -901,8 +930,14 @@ class AGCBank(_LoopBank):
         if not self.h:
             raise SigDiggerAmdError("suamd_agc_bank_new: " + _l.last_error())
 
-    def feed(self, x, out=None, stream=None):
+    def feed(self, x, out=None, stream=None, wide=None):
+        """`wide`: a second stream for the AGC's feed-forward kernels (suamd_agc_bank_feed_split); `stream` then only
+        carries the level trackers, and x is read / out complete on `wide`."""
         out = self._rows(x, out)
+        if wide is not None:
+            check(self.ctx.lib.suamd_agc_bank_feed_split(self.h, _ptr(x), _view(x), _ptr(out), _view(out),
+                                                         x.shape[1], _stream(stream), _stream(wide)), "suamd_agc_bank_feed_split")
+            return out
         check(self.ctx.lib.suamd_agc_bank_feed(self.h, _ptr(x), _view(x), _ptr(out), _view(out),
                                                x.shape[1], _stream(stream)), "suamd_agc_bank_feed")
         return out

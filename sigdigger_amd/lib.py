@@ -46,8 +46,13 @@ PROTOTYPES = {
     "suamd_ctx_new": (VP, [INT]),
     "suamd_ctx_destroy": (None, [VP]),
     "suamd_ctx_device": (INT, [VP]),
+    "suamd_ctx_cu_count": (UINT, [VP]),
+    "suamd_stream_new_cu_mask": (VP, [VP, C.POINTER(U32), UINT]),
+    "suamd_stream_destroy": (INT, [VP, VP]),
+    "suamd_probe_placement": (INT, [VP, VP, UINT, UINT, C.POINTER(U32)]),
     "suamd_psd_new": (VP, [VP, UINT, INT]),
     "suamd_psd_destroy": (None, [VP]),
+    "suamd_psd_set_split_target": (INT, [VP, UINT]),
     "suamd_psd_feed": (INT, [VP, VP, U64, U64, UINT, F32, INT, VP, VP]),
     "suamd_psd_shift_db": (INT, [VP, VP, U64, U64, VP]),
     "suamd_averager_feed": (INT, [VP, VP, VP, U64, F32, INT, VP]),
@@ -170,6 +175,7 @@ PROTOTYPES = {
     "suamd_agc_bank_new": (VP, [VP, UINT, C.POINTER(AgcParams)]),
     "suamd_agc_bank_destroy": (None, [VP]),
     "suamd_agc_bank_feed": (INT, [VP, VP, View, VP, View, U64, VP]),
+    "suamd_agc_bank_feed_split": (INT, [VP, VP, View, VP, View, U64, VP, VP]),
     "suamd_fft_forward_bulk": (INT, [VP, VP, VP, VP, UINT, VP]),
     "suamd_carrier_detect": (INT, [VP, VP, U64, F32, F32, C.POINTER(F32), VP]),
     "suamd_doppler_alloc_size": (U64, [U64]),

@@ -17,6 +17,45 @@ from . import engine
 _STAGE_STREAMS = {}
 
 
+def cu_partition(ncus, reserved_per_xcd, nxcd=8):
+    """(reserved, transform) compute-unit index lists.  The driver deals consecutive mask bits to consecutive XCDs (bit i
+    -> XCD i mod 8; suamd_probe_placement / tests/test_gpu_cu_mask.py check it), and the dispatcher deals the workgroups of
+    a launch to the XCDs in turn whatever their enabled CUs -- so the reserved set takes the SAME number of CUs from every
+    XCD: a transform launch planned for one round then has the same slots on each."""
+    r = max(0, min(int(reserved_per_xcd), ncus // nxcd - 1))
+    reserved = list(range(r * nxcd))
+    return reserved, list(range(r * nxcd, ncus))
+
+
+def _make_stage_streams(ctx, dev):
+    """The three recurrence stage streams, and the stream + CU count the transform kernels get.
+
+    SUAMD_PIPELINE_CU_PARTITION=1 (the number = reserved CUs per XCD; default 0 = off, the transform window of
+    AnalyzerPipeline does better): the recurrences -- one wavefront per 64
+    inspectors holding ~200 registers of a SIMD (the clock kernel also 32 KB of LDS) for milliseconds -- run on streams
+    confined to 8 reserved CUs (hipExtStreamCreateWithCUMask), the transform kernels on a stream confined to the other
+    248.  Before (round 4) a recurrence wavefront sat wherever the dispatcher put it and took a slot from a transform
+    launch planned for exactly one round of workgroups (profiles/r04_inpipe_penalty.txt: stp_kernel 85 -> 96 us, and a launch
+    could not be planned for more than 3/4 of the chip).  Measured (round 5, 16 Mi block): stp_kernel 96 -> 89-90 us, no launch
+    above 112 us any more -- but 248 CUs hold 992 window slots, so a 16 Mi block (8192 windows) takes 9 windows per
+    workgroup where the whole chip takes 8: the transform window (idle chip, 1024 slots) reaches 76 us.
+    SUAMD_PIPELINE_CU_PARTITION=0: streams of a priority of their own, as in round 4."""
+    part = int(os.environ.get("SUAMD_PIPELINE_CU_PARTITION", "0"))
+    ncus = ctx.cu_count()
+    if part > 0 and ncus >= 16:
+        reserved, transform = cu_partition(ncus, part)
+        # every stage gets the whole reserved set; loops.hip's serial_xcd() puts AGC / Costas / clock on three XCDs of it
+        stages = tuple(ctx.masked_stream(reserved) for _ in range(3))
+        # two streams on the other CUs: the transforms' (PSD, channeliser) and one for the feed-forward kernels of the
+        # serial stages (the AGC's magnitudes / sliding maximum / gain: many workgroups, microseconds each)
+        return stages + (ctx.masked_stream(transform), len(transform), ctx.masked_stream(transform))
+    # streams of a priority of their own (SUAMD_PIPELINE_STAGE_PRIORITY, default -1 = high): streams of another priority
+    # come out of another set of hardware queues, so the three never share one with each other or with whatever streams
+    # the process made before (csrc/analyzer.cpp init_device: same reason)
+    prio = int(os.environ.get("SUAMD_PIPELINE_STAGE_PRIORITY", "-1"))
+    return tuple(torch.cuda.Stream(dev, priority=prio) for _ in range(3)) + (None, ncus, None)
+
+
 class InspectorBankConfig:
     """Parameters shared by the inspectors of one bank (one decimation)."""
 
@@ -53,7 +92,7 @@ class AnalyzerPipeline:
     SUB = max(1, int(os.environ.get("SUAMD_PIPELINE_SUB", "4")))   # sub-ranges a block takes through the serial stages of a PSK chain
 
     def __init__(self, ctx, block_len, psd_size=8192, psd_window=engine.WINDOW_BLACKMANN_HARRIS,
-                 psd_navg=None, bank=None, do_psd=True, overlap=True):
+                 psd_navg=None, bank=None, do_psd=True, overlap=True, window=None):
         self.ctx = ctx
         self.block_len = int(block_len)
         self.dev = torch.device("cuda", ctx.device)
@@ -106,23 +145,44 @@ class AnalyzerPipeline:
                 self.first = True
             self.clock = engine.ClockBank(ctx, self.nchan, bank.clock_gain, 1.0 / bank.sps)
         self.host_sym = None
+        self._pending = []                     # transform window: closures of the last block's held-back tail
+        # Transform window (default on; SUAMD_PIPELINE_WINDOW=0 or window=False: round 4's free-running streams).  Once per
+        # block the recurrence streams pause at a skewed cut (AGC done, Costas one sub-range from its end, Gardner two) and
+        # the block's PSD + channeliser run on an otherwise idle chip: the channeliser plans all 1024 window slots (8 windows
+        # per workgroup on a 16 Mi block instead of 11 on 3/4 of them) and nothing displaces a workgroup of its one round.
+        # Measured (16 Mi block, 64 inspectors, same box, alternating): stp_kernel 96.4 us (max 130) -> 76.1 (max 77),
+        # psd_kernel + reduce 50 -> 44 us; the slowest stream pauses ~0.15 ms per 21 ms step (795 -> 789 MS/s).
+        if window is None:
+            window = os.environ.get("SUAMD_PIPELINE_WINDOW", "1") != "0"
+        self.window = bool(overlap and window)
+        if self.window and do_psd and self.psd_size == 8192 and os.environ.get("SUAMD_PSD_SPLIT_TARGET") is None:
+            self.psd.set_split_target(512)     # two 8192-point workgroups per CU, and the chip is the PSD's own in the window
         if overlap:
             # one set of stage streams per device, shared by every pipeline of the process: HIP spreads its streams over
             # four hardware queues, and a second pipeline with streams of its own would have two of its stages behind
             # one queue (bench.py builds C2 / C3 after the default workload: their kernels ran 2-3 x slower for it)
             key = str(self.dev)
             if key not in _STAGE_STREAMS:
-                # ... and of a priority of their own (SUAMD_PIPELINE_STAGE_PRIORITY, default -1 = high): streams of
-                # another priority come out of another set of hardware queues, so the three never share one with each
-                # other or with whatever streams the process made before (csrc/analyzer.cpp init_device: same reason)
-                prio = int(os.environ.get("SUAMD_PIPELINE_STAGE_PRIORITY", "-1"))
-                _STAGE_STREAMS[key] = tuple(torch.cuda.Stream(self.dev, priority=prio) for _ in range(3))
-            self.s_agc, self.s_dem, self.s_clk = _STAGE_STREAMS[key]      # AGC; Costas / quad demod; clock recovery
+                _STAGE_STREAMS[key] = _make_stage_streams(ctx, self.dev)
+            self.s_agc, self.s_dem, self.s_clk, self.s_main, self.transform_cus, self.s_wide = _STAGE_STREAMS[key]      # AGC; Costas / quad demod; clock recovery
+            self.s_crit = self.s_dem if (bank is None or bank.kind == "psk") else self.s_clk
+            if (self.s_main is not None or self.window) and self.nchan and self.chan is None and not os.environ.get("SUAMD_PIPE_KEEP_SLOTS"):
+                # the transform kernels have `transform_cus` compute units to themselves (a CU partition, or the whole chip
+                # inside a transform window): the channeliser plans its ONE round of workgroups for all their window
+                # slots (4 per CU) instead of 3/4 of the chip's
+                self.st.set_slots(4 * self.transform_cus)
         self.done = {}                         # (stage, block index) -> event
         self.marks_per_step = 1                # timing marks per step of a serial stage (step() with sub-ranges: SUB)
         self.ev = {}                           # per-stage timing events
 
     # ---- helpers ---------------------------------------------------------------------------
+    def main_stream(self):
+        """the stream the PSD and the channeliser run on: the CU-masked transform stream when the device is partitioned
+        (callers that order other work against a step -- the block broadcast, uploads -- make it current), else the
+        caller's current stream"""
+        s = getattr(self, "s_main", None) if self.overlap else None
+        return s if s is not None else torch.cuda.current_stream(self.dev)
+
     def _mark(self, name, stream, timed):
         if not timed:
             return
@@ -149,31 +209,64 @@ class AnalyzerPipeline:
 
     def step(self, x, timed=False, stream=None):
         """One pass of the hot path over one resident IQ block x (complex64 [block_len])."""
-        st = stream or torch.cuda.current_stream(self.dev)
+        if not self.overlap:
+            self.k += 1
+            return self._step_serial(x, timed, stream or torch.cuda.current_stream(self.dev))
+        caller = torch.cuda.current_stream(self.dev)
+        # Transform window: the PSD and the channeliser go onto the slowest stage's stream (carrier recovery; the clock stage
+        # of an FSK chain) -- the one whose pause is the cost of the window: between its launches there is then no cross-queue hop (measured with the
+        # transforms on a stream of their own: 37 us from the last Costas launch to the PSD, 43 us from the channeliser to the
+        # next Costas launch, on top of the kernels' 120 us)
+        st = stream or (self.s_crit if self.window else self.main_stream())
+        if stream is None and st != caller:
+            # ... on a stream of the pipeline's, but with the caller's stream semantics: the transforms start behind what
+            # the caller has enqueued (its x) and the caller's stream continues behind them (psd_out, its reuse of x)
+            st.wait_stream(caller)
+            try:
+                return self._step_overlapped(x, timed, st)
+            finally:
+                caller.wait_event(self.done[("fir", self.k - 1)] if self.nchan else self._psd_done)
+        return self._step_overlapped(x, timed, st)
+
+    def _step_overlapped(self, x, timed, st):
         k = self.k
         self.k += 1
-        if not self.overlap:
-            return self._step_serial(x, timed, st)
         nb = self.NBUF
         i = k % nb
-        # ---- main spectrum on its own stream (reads x only) ----
-        # (on the caller's stream: four streams = the four HIP hardware queues, so the three
-        #  serial stages never share a queue and really run concurrently)
+        stage_streams = [q for q in (self.s_agc, self.s_wide, self.s_dem, self.s_clk) if q is not None]
+        pend, self._pending = self._pending, []
+        if pend:
+            # transform window (see _make_stage_streams): the PSD and the channeliser of this block start when the recurrence
+            # launches enqueued so far -- block k-1 up to its skewed cut -- have drained ...
+            for q in stage_streams:
+                if q != st:
+                    st.wait_stream(q)
+        # ---- main spectrum (reads x only) ----
         if self.do_psd:
             self._mark("psd0", st, timed)
             self.psd.feed(x, nframes=self.nframes, navg=self.navg, scale=1.0 / self.psd_size,
                           out=self.psd_out, stream=st)
             self._mark("psd1", st, timed)
         if not self.nchan:
+            self._psd_done = torch.cuda.Event()
+            self._psd_done.record(st)
             return self.psd_out if self.do_psd else None
         cfg = self.bank_cfg
         psk = cfg.kind == "psk"
-        # ---- channel bank: many workgroups, on the caller's stream ----
+        # ---- channel bank: many workgroups, on the transform stream ----
         self._wait(st, "agc" if (psk and self.agc is not None) else "dem", k - nb)   # y[i] free again
         self._mark("fir0", st, timed)
         y = self._channelise(x, self.y[i], st)
         self._mark("fir1", st, timed)
         self._signal("fir", k, st)
+        if pend:
+            # ... and the rest of block k-1 (and everything after it) runs behind them: the transforms have the chip to
+            # themselves for their ~130 us, the slowest recurrence stream pauses for exactly that long
+            for q in stage_streams:
+                if q != st:
+                    q.wait_event(self.done[("fir", k)])
+            for f in pend:
+                f()
         m = y.shape[1]
         src = y
         # The three serial stages take the block in SUB sub-ranges (PSK chains): sub-range j of the Costas stage only waits for
@@ -181,28 +274,38 @@ class AnalyzerPipeline:
         # the pipeline's fill and drain: 1.3 steps per timed region with whole blocks) shrinks to the slowest stage plus a
         # quarter of the others.  The banks are stream processors (state carried from call to call), so the sub-ranges give
         # the same samples as the whole block, bit for bit (csrc/analyzer.cpp pushes its inspectors through the same way).
-        nsub = self.SUB if psk else 1
+        nsub = self.SUB if (psk or self.window) else 1       # (FSK chains: only the clock stage, and only for the window's cut)
         cuts = [m * j // nsub for j in range(nsub + 1)]
+        ops = {"agc": [], "dem": [], "clk": []}            # per stage: one closure per sub-range, enqueued in order
         # ---- AGC ----
         if psk and self.agc is not None:
-            self._wait(self.s_agc, "fir", k)
-            self._wait(self.s_agc, "dem", k - nb)                                    # a[i] free again
-            for j in range(nsub):
+            # CU-partitioned device: only the level trackers run on the (confined) AGC stream; the feed-forward kernels,
+            # the stage's dependencies and its completion live on the wide stream
+            sa = self.s_wide if self.s_wide is not None else self.s_agc
+
+            def agc_op(j):
                 lo, hi = cuts[j], cuts[j + 1]
-                self._mark("agc0", self.s_agc, timed)
+                if j == 0:
+                    self._wait(sa, "fir", k)
+                    self._wait(sa, "dem", k - nb)                                    # a[i] free again
+                self._mark("agc0", sa, timed)
                 if hi > lo:
-                    self.agc.feed(y[:, lo:hi], out=self.a[i][:, lo:hi], stream=self.s_agc)
-                self._mark("agc1", self.s_agc, timed)
-                self._signal(("agc", j), k, self.s_agc)
+                    self.agc.feed(y[:, lo:hi], out=self.a[i][:, lo:hi], stream=self.s_agc, wide=self.s_wide)
+                self._mark("agc1", sa, timed)
+                self._signal(("agc", j), k, sa)
+                if j == nsub - 1:
+                    self._signal("agc", k, sa)
+            ops["agc"] = [(lambda j=j: agc_op(j)) for j in range(nsub)]
             src = self.a[i][:, :m]
-            self._signal("agc", k, self.s_agc)
         # ---- carrier recovery / quadrature demod ----
-        self._wait(self.s_dem, "clk", k - nb)                                        # z[i] free again
+        z = self.z[i][:, :m]
         if psk:
-            if self.agc is None:
-                self._wait(self.s_dem, "fir", k)
-            for j in range(nsub):
+            def dem_op(j):
                 lo, hi = cuts[j], cuts[j + 1]
+                if j == 0:
+                    self._wait(self.s_dem, "clk", k - nb)                            # z[i] free again
+                    if self.agc is None:
+                        self._wait(self.s_dem, "fir", k)
                 if self.agc is not None:
                     self._wait(self.s_dem, ("agc", j), k)
                 self._mark("dem0", self.s_dem, timed)              # (behind the wait: the stage's own time, per sub-range)
@@ -210,30 +313,58 @@ class AnalyzerPipeline:
                     self.costas.feed(src[:, lo:hi], out=self.z[i][:, lo:hi], stream=self.s_dem)
                 self._mark("dem1", self.s_dem, timed)
                 self._signal(("dem", j), k, self.s_dem)
-            z = self.z[i][:, :m]
+                if j == nsub - 1:
+                    self._signal("dem", k, self.s_dem)
+            ops["dem"] = [(lambda j=j: dem_op(j)) for j in range(nsub)]
         else:
-            self._wait(self.s_dem, "fir", k)
-            self._mark("dem0", self.s_dem, timed)
-            z = self.ctx.quad_demod(y, prev=self.qprev[k & 1], first=self.first, out=self.z[i][:, :m],
+            def quad_op():
+                self._wait(self.s_dem, "clk", k - nb)
+                self._wait(self.s_dem, "fir", k)
+                self._mark("dem0", self.s_dem, timed)
+                self.ctx.quad_demod(y, prev=self.qprev[k & 1], first=self.first, out=self.z[i][:, :m],
                                     prev_out=self.qprev[(k + 1) & 1], stream=self.s_dem)
-            self.first = False
-            self._mark("dem1", self.s_dem, timed)
-            self._signal(("dem", 0), k, self.s_dem)
-        self._signal("dem", k, self.s_dem)
+                self.first = False
+                self._mark("dem1", self.s_dem, timed)
+                self._signal(("dem", 0), k, self.s_dem)
+                self._signal("dem", k, self.s_dem)
+            ops["dem"] = [quad_op]
+
         # ---- clock recovery (appends to the block's symbol rows: one count per channel, cleared once per block) ----
-        self._wait(self.s_clk, ("dem", 0), k)
-        with torch.cuda.stream(self.s_clk):
-            self.count[i].zero_()
-        for j in range(nsub):
+        def clk_op(j):
             lo, hi = cuts[j], cuts[j + 1]
+            if j == 0:
+                self._wait(self.s_clk, ("dem", 0), k)
+                with torch.cuda.stream(self.s_clk):
+                    self.count[i].zero_()
             self._wait(self.s_clk, ("dem", j), k)
             self._mark("clk0", self.s_clk, timed)
             if hi > lo:
                 self.clock.feed(z[:, lo:hi], self.sym[i], self.count[i], stream=self.s_clk)
             self._mark("clk1", self.s_clk, timed)
-        self._signal("clk", k, self.s_clk)
+            if j == nsub - 1:
+                self._signal("clk", k, self.s_clk)
+        ops["clk"] = [(lambda j=j: clk_op(j)) for j in range(nsub)]
+        # Transform window: the tail of the block -- the last sub-range of the carrier stage, the last two of the clock stage --
+        # is held back until the NEXT block's transforms are enqueued.  The stages run skewed by one sub-range (AGC ahead of
+        # Costas ahead of Gardner), so AGC j+2 / Costas j+1 / clock j end together: cutting there pauses the slowest stream
+        # for the transforms' own duration and the others inside their slack.
+        hold = {"agc": 0, "dem": 0, "clk": 0}
+        if self.window and nsub >= 3:
+            hold = {"agc": 0, "dem": 1, "clk": 2} if psk else {"agc": 0, "dem": 0, "clk": 1}
+        for name in ("agc", "dem", "clk"):
+            n = len(ops[name]) - hold[name]
+            for f in ops[name][:n]:
+                f()
+            self._pending.extend(ops[name][n:])
         self.marks_per_step = nsub
+        self.marks_per_stage = {name: len(ops[name]) for name in ops}
         return self.psd_out if self.do_psd else None
+
+    def flush(self):
+        """enqueues what a transform window holds back (the last block's tail): call before waiting for results"""
+        pend, self._pending = self._pending, []
+        for f in pend:
+            f()
 
     def _step_serial(self, x, timed, st):
         self.marks_per_step = 1
@@ -284,19 +415,27 @@ class AnalyzerPipeline:
         """Enqueues the device -> host copy of the block just fed; returns (host symbols, host counts) of that slot --
         valid once the clock stream has passed (latest_symbols() / sync())."""
         i = (self.k - 1) % self.NBUF
-        with torch.cuda.stream(self.s_clk):
-            self.host_sym[i].copy_(self.sym[i][:, :self.sym_cap], non_blocking=True)
-            self.host_count[i].copy_(self.count[i], non_blocking=True)
+
+        def copy():
+            with torch.cuda.stream(self.s_clk):
+                self.host_sym[i].copy_(self.sym[i][:, :self.sym_cap], non_blocking=True)
+                self.host_count[i].copy_(self.count[i], non_blocking=True)
+        if self._pending:
+            self._pending.append(copy)         # behind the held-back clock sub-ranges (transform window)
+        else:
+            copy()
         return self.host_sym[i], self.host_count[i]
 
     def latest_symbols(self):
         """(sym, count) of the most recently fed block (synchronises the clock stage)."""
         i = (self.k - 1) % (self.NBUF if self.overlap else 1)
         if self.overlap:
+            self.flush()
             self.s_clk.synchronize()
         return self.sym[i], self.count[i]
 
     def sync(self):
+        self.flush()
         torch.cuda.synchronize(self.dev)
 
     def stage_times_ms(self):
@@ -313,7 +452,7 @@ class AnalyzerPipeline:
             # counted in self.stalled_samples, so the figure is the kernel's launch duration, as rocprofv3 reports it.
             if a in ev and b in ev:
                 t = np.array([s.elapsed_time(e) for s, e in zip(ev[a], ev[b])])
-                n = getattr(self, "marks_per_step", 1)          # the serial stages of a PSK chain mark every sub-range: per step = their sum
+                n = getattr(self, "marks_per_stage", {}).get(a[:3], 1) if self.overlap else 1   # a serial stage marks every sub-range: per step = their sum
                 if a[:3] in ("agc", "dem", "clk") and n > 1 and t.size % n == 0:
                     t = t.reshape(-1, n).sum(axis=1)
                 keep = t <= 5.0 * np.median(t)

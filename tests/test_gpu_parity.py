@@ -653,6 +653,42 @@ def test_pipeline_overlap_equals_serial_and_oracle(ctx, sdo, kind):
         assert_bits(s_ov[ch], ref, f"symbols ch {ch} vs oracle")
 
 
+@pytest.mark.parametrize("kind", ["psk", "fsk"])
+def test_transform_window_holds_a_blocks_tail_back_and_delivers_the_same_symbols(ctx, kind):
+    """The pipeline's transform window (round 5): the tail of block k's serial stages is enqueued behind block k+1's PSD and
+    channeliser, which wait for the rest of block k.  Blocks are pushed back to back as bench.py does -- no flush in
+    between -- and what reaches pinned host memory must be, bit for bit, what the free-running streams deliver."""
+    from sigdigger_amd import pipeline
+    L, D, nchan, nblocks = 1 << 16, 16, 6, 3                   # (the ring of host landing zones is three deep)
+    fn = synth.raster(nchan, 0.11)
+    sps_in = 128
+    xs = (synth.psk_carriers(L * nblocks, fn, sps=sps_in, order=4, seed=17, snr_db=22) if kind == "psk"
+          else synth.fsk_carriers(L * nblocks, fn, sps=sps_in, seed=18))
+    dx = dev(xs)
+
+    def run(window):
+        bank = pipeline.InspectorBankConfig(kind=kind, fnor=fn, decimation=D, ntaps=255, sps=sps_in / D, channeliser="fft")
+        pipe = pipeline.AnalyzerPipeline(ctx, L, psd_size=4096, psd_navg=4, bank=bank, window=window)
+        pipe.enable_delivery()
+        got, held = [], 0
+        for b in range(nblocks):
+            pipe.step(dx[b * L:(b + 1) * L])
+            got.append(pipe.deliver())
+            held += len(pipe._pending)
+        pipe.sync()
+        return [(hs.numpy().copy(), hc.numpy().copy()) for hs, hc in got], held, host(pipe.psd_out).copy()
+    win, held, psd_w = run(True)
+    free, none, psd_f = run(False)
+    assert held > 0 and none == 0, "the window did not hold anything back"
+    assert_bits(psd_w, psd_f, "psd")
+    for b in range(nblocks):
+        assert np.array_equal(win[b][1], free[b][1]), f"block {b}: symbol counts"
+        assert win[b][1].min() > 50
+        for c in range(nchan):
+            n = min(int(win[b][1][c]), win[b][0].shape[1])
+            assert_bits(win[b][0][c, :n], free[b][0][c, :n], f"block {b} ch {c}")
+
+
 # ------------------------------------------------------------------------------------------
 # P2/P3: panoramic SpectrumView (config C5 shape) -- bit exact
 # ------------------------------------------------------------------------------------------
