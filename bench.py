@@ -35,20 +35,26 @@ FP32_PEAK_TFLOPS = 157.3     # vector FP32 spec peak
 
 WORKLOADS = {
     # C4 / north-star target line: 50 MS/s-class IQ, 8192-pt PSD + 64 QPSK inspectors per GPU
-    "c4": dict(what="C4 slice / north-star target: 8192-pt PSD + 64 QPSK inspectors per GPU (AGC+Costas+Gardner)",
+    "c4": dict(what="C4 slice: 8192-pt PSD + 64 QPSK inspectors per GPU",
                rate="D=64, 50 kBd @ 50 MS/s (15.6 sps)",
                psd=8192, per_gpu=64, D=64, T=255, sps_in=1000, kind="psk", spacing=2 * 90e3 / 50e6),
     # C2: 20 MS/s, 8192-pt PSD + 1 PSK inspector
-    "c2": dict(what="C2: 8192-pt PSD + 1 QPSK inspector (AGC+Costas+Gardner)", rate="D=16, 250 kBd @ 20 MS/s (5 sps)",
+    "c2": dict(what="C2: 8192-pt PSD + 1 QPSK inspector", rate="D=16, 250 kBd @ 20 MS/s (5 sps)",
                psd=8192, per_gpu=1, D=16, T=255, sps_in=80, kind="psk", spacing=0.25),
     # C3: 50 MS/s, 16384-pt PSD + 64 FSK inspectors (quad-demod path)
-    "c3": dict(what="C3: 16384-pt PSD + 64 2-FSK inspectors (quad demod + Gardner)", rate="D=64, 100 kBd @ 50 MS/s (7.8 sps)",
+    "c3": dict(what="C3: 16384-pt PSD + 64 2-FSK inspectors", rate="D=64, 100 kBd @ 50 MS/s (7.8 sps)",
                psd=16384, per_gpu=64, D=64, T=255, sps_in=500, kind="fsk", spacing=2 * 700e3 / 50e6),
 }
 
 
 def describe(cfg, channeliser):
-    """what ran, channeliser included: the bench line must not say "255-tap LPF" over a kernel that has no taps"""
+    """what ran, channeliser included, in a few words (the long form goes to the END of the line, `notes`: the driver's
+    parsed copy of the line is cut after a few kB)"""
+    ch = f"FFT filter bank, {4096 // cfg['D']}-bin channels" if channeliser == "fft" else f"translate + {cfg['T']}-tap polyphase FIR"
+    return f"{cfg['what']}; {ch}; {cfg['rate']}"
+
+
+def describe_long(cfg, channeliser):
     if channeliser == "fft":
         ch = (f"behind the FFT filter bank (su_specttuner semantics: one 4096-pt forward FFT per half window for all channels, "
               f"{4096 // cfg['D']}-bin channels, inverse FFT + cross-fade per channel)")
@@ -80,6 +86,50 @@ def make_block(n, fnor, sps_in, kind, device, seed=1234):
     return x
 
 
+_FAST_BUILT = False
+
+
+def _build_fast_once(sdo):
+    global _FAST_BUILT
+    if not _FAST_BUILT:
+        sdo.build_fast(force=True)
+        _FAST_BUILT = True
+
+
+def cpu_psd_baseline(N, nsamples, ncores):
+    """PSD only (BASELINE.json configs[0]'s CPU leg): the oracle's windowed FFT power + averaging over every window of a
+    bounded sample, -O3 -march=native build, one thread and all of them (frame ranges)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import sdo
+    _build_fast_once(sdo)
+    sdo.use_fast(True)
+    try:
+        rng = np.random.default_rng(9)
+        x = (rng.standard_normal(nsamples) + 1j * rng.standard_normal(nsamples)).astype(np.complex64) * 0.3
+        win = sdo.window(4, N)
+        nfr = nsamples // N
+
+        def rng_(fr):
+            return sdo.psd_frames(x[fr[0] * N:fr[1] * N], fr[1] - fr[0], N, N, win, navg=fr[1] - fr[0], scale=1.0 / N)
+        t0 = time.perf_counter()
+        rng_((0, nfr))
+        t1 = time.perf_counter() - t0
+        tn = t1
+        if ncores > 1:
+            edges = [nfr * k // ncores for k in range(ncores + 1)]
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(ncores) as ex:
+                list(ex.map(rng_, [(edges[k], edges[k + 1]) for k in range(ncores) if edges[k + 1] > edges[k]]))
+            tn = time.perf_counter() - t0
+        return {"value": round(nsamples / tn / 1e6, 3), "unit": "MS/s", "cores": ncores, "kind": "port",
+                "value_1thread": round(nsamples / t1 / 1e6, 3), "frames_per_s_1thread": round(nfr / t1, 1),
+                "sample": f"{nsamples} complex samples: {N}-pt Blackman-Harris windowed FFT power over every window, averaged "
+                          f"(oracle/sdo.c sdo_psd_frames, -O3 -march=native; a restatement, not upstream sigutils)",
+                "cpu_model": _cpu_model()}
+    finally:
+        sdo.use_fast(False)
+
+
 def cpu_baseline(cfg, nsamples, fnor_rank, ncores, channeliser):
     """Times the CPU oracle (oracle/sdo.c, a restatement -- NOT upstream sigutils) on a bounded sample of the SAME
     pipeline the GPU leg ran -- same channeliser algorithm, same chains -- on this box's host cores, from the
@@ -88,7 +138,7 @@ def cpu_baseline(cfg, nsamples, fnor_rank, ncores, channeliser):
     GPU), then the serial chains one channel per task."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import sdo
-    sdo.build_fast(force=True)                                # -march=native: always built on the box that times it
+    _build_fast_once(sdo)                                     # -march=native: always built on the box that times it
     sdo.use_fast(True)
     try:
         rng = np.random.default_rng(7)
@@ -225,9 +275,12 @@ def pmc_traffic(kernel, workload, block):
             continue
         w = d.get("workload", {})
         if w.get("name") == workload and w.get("block_samples") == block and kernel in d.get("kernels", {}):
+            import hashlib
+            raw = open(f, "rb").read()
+            blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()[:12]
             best = (d["kernels"][kernel].get("hbm_bytes_per_launch"),
-                    f"profiles/{os.path.basename(f)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this "
-                    f"workload (2 x FETCH + WRITE, gfx950 half-count of streamed reads), not measured in this run")
+                    f"profiles/{os.path.basename(f)} (git blob {blob}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an EARLIER run "
+                    f"of this workload (2 x FETCH + WRITE), not measured in this run")
     return best if best else (None, None)
 
 
@@ -254,16 +307,58 @@ KERNELS = {
     "chan_fir_kernel": "chan_fir_kernel (translate + 255-tap polyphase decimating FIR bank)"}
 
 
-def fir_stage_roofline(C, D, L, kernel_ms, kname, workload, timing):
+def fir_stage_roofline(C, D, L, kernel_ms, kname, workload, timing, traffic=None):
     """roofline object of the north star's "FIR stage" (the channeliser): algorithmic (compulsory) bytes per launch
-    (the shared input once + every channel's decimated output) over the kernel's own duration"""
+    (the shared input once + every channel's decimated output) over the kernel's own duration.
+    `traffic`: (bytes per launch, source) measured by this run's own PMC passes; else the committed profile's figure."""
     nbytes = 8.0 * L + 8.0 * C * (L // D)
-    traffic, tsrc = pmc_traffic(kname, workload, L)
-    return {"kernel": KERNELS.get(kname, kname), "bound": "hbm",
+    tr, tsrc = traffic if traffic and traffic[0] else pmc_traffic(kname, workload, L)
+    return {"kernel": kname, "bound": "hbm",
             "achieved": round(nbytes / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(nbytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kernel_ms else None,
-            "traffic": traffic, "traffic_source": tsrc,
+            "traffic": tr, "traffic_over_algorithmic": round(tr / nbytes, 4) if tr else None, "traffic_source": tsrc,
             "algorithmic_bytes_per_launch": nbytes, "kernel_ms": round(kernel_ms, 4) if kernel_ms else None, "timing": timing}
+
+
+def pmc_traffic_in_run(args, kernels):
+    """HBM bytes per launch of `kernels`, COUNTED IN THIS RUN: two child runs of this script's default workload under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, nothing else traced -- MI355X_MICROARCH.md's
+    recipe), 4 steps each; bytes = 2 x FETCH_SIZE + WRITE_SIZE KiB (gfx950 counts half of the streamed reads: calibrated in
+    profiles/r01_pmc_traffic.json with a copy kernel).  {} when rocprofv3 is not on the box or a pass fails."""
+    import csv, glob, shutil, subprocess, tempfile
+    if os.environ.get("SUAMD_BENCH_CHILD") or not shutil.which("rocprofv3"):
+        return {}
+    acc = {}
+    tmp = tempfile.mkdtemp(prefix="suamd_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "4", "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--block", str(args.block),
+                   "--workload", args.workload, "--channeliser", args.channeliser]
+            env = dict(os.environ, SUAMD_BENCH_CHILD="1", TMPDIR="/tmp")
+            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != ctr:
+                        continue
+                    k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+                    if k in kernels:
+                        acc.setdefault(k, {}).setdefault(ctr, []).append(float(row["Counter_Value"]))
+    except Exception:
+        return {}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for k, v in acc.items():
+        if v.get("FETCH_SIZE") and v.get("WRITE_SIZE"):
+            f, w = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+            res[k] = {"hbm_bytes_per_launch": int(2048 * f + 1024 * w), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
+                      "launches": len(v["FETCH_SIZE"])}
+    return res
 
 
 def channeliser_alone(ctx, dev, fn, D, T, channeliser, log2_block, slots=None, reps=10):
@@ -372,13 +467,13 @@ def run_workload(name, args, rank, world, dev, ctx, dist):
         r = engine.kernel_timing_read(kname)
         if r["launches"]:
             n, tot = r["launches"], r["sum_ms"]
+            # `avg` and `per_step` -- what roofline.frac is computed from -- are over ALL launches of the timed region.  Now
+            # and then an event pair of a 50-100 us kernel reads 1-2 ms (the queue stalls between the two events; rocprofv3's
+            # trace of the same runs never shows such a kernel): the mean without the single worst sample is reported BESIDE
+            # it (`avg_without_worst`) when that sample is more than five times the shortest, never instead of it.
             entry = {"avg": tot / n, "min": r["min_ms"], "max": r["max_ms"], "launches": n}
-            # One sample far beyond the rest is not a launch: now and then an event pair of a 50-100 us kernel reads 1-2 ms
-            # (the queue stalls between the two events; rocprofv3's trace of the same runs never shows such a kernel, and
-            # pipeline.stage_times_ms drops the same samples from stage_ms).  The single worst sample is dropped when it is
-            # more than five times the shortest one, and said so.
             if n >= 8 and r["max_ms"] > 5.0 * r["min_ms"]:
-                entry.update({"avg": (tot - r["max_ms"]) / (n - 1), "avg_all_samples": tot / n, "dropped_stalled_sample_ms": r["max_ms"]})
+                entry.update({"avg_without_worst": (tot - r["max_ms"]) / (n - 1), "worst_sample_ms": r["max_ms"]})
             entry["per_step"] = entry["avg"] * n / args.steps
             pipe.kernel_ms[kname] = entry
     if dist is not None:
@@ -523,6 +618,128 @@ def run_c5(args, dev, ctx, log2_file=30, N=8192, tile=256):
                              "algorithmic_bytes_per_launch": psd_bytes}}
 
 
+def run_c1(args):
+    """BASELINE.json configs[0]: "CPU reference: suscan file source, 2.4 MS/s synthetic IQ, 8192-pt PSD only, 1 inspector off
+    (Averager + FFT plumbing)" -- through the drop-in boundary (the live analyzer, unthrottled) at three operating points, with
+    the CPU leg (the oracle's PSD on this box's cores; the reference's own PSDMessage + Averager loop is
+    cpu_baseline.reference_loops.psd_message_plus_averager) beside it."""
+    from sigdigger_amd.livebench import live_psd_only
+    out = {"workload": "C1 (BASELINE.json configs[0]): file source, 2.4 MS/s, 8192-pt PSD only, no inspector, unthrottled"}
+    for key, a in (("live_25fps", (2_400_000, 8192, 0.04, 500)),                       # 12 frames per message: the GUI's refresh rate
+                   ("live_reference_defaults", (3_000_000, 4096, 0.04, 500)),           # include/AppConfig.h:35-38: 4096 bins, 25 fps
+                   ("live_2Mi_blocks", (2_400_000, 8192, (1 << 21) / 2.4e6, 60))):     # 256 frames per message: the stream rate
+        try:
+            out[key] = live_psd_only(*a)
+        except Exception as e:                                # a secondary figure must not take the bench line down
+            out[key] = {"error": repr(e)}
+    if not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_psd_baseline(8192, 1 << 25, os.cpu_count() or 1)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
+def run_capacity(args, dev, ctx):
+    """How many PSK inspectors (D = 64: C4's kind) one MI355X carries: the default workload with 64 ... 4096 inspectors on one
+    GPU -- the stream rate, the slowest stage and the channeliser's time per step for each.  Same pipeline, same kernels, the
+    headline's block (64 QPSK carriers); inspector c sits on carrier c mod 64 (independent opens of the same channels, as
+    Suscan/Analyzer.cpp:411-432 allows), so every chain locks as in the headline -- a Gardner wavefront's time depends on how
+    its lanes' symbol clocks relate (design/recurrences.md), noise-only channels would run it twice as long.  16 Mi samples up to
+    1024 inspectors, 4 Mi beyond (the inter-stage rings of 4096 inspectors at 16 Mi samples would take 77 GB)."""
+    cfg = WORKLOADS["c4"]
+    rows = []
+    blocks = {}
+    for n, lg in ((64, args.block), (128, args.block), (256, args.block), (512, args.block), (1024, args.block), (2048, 22), (4096, 22)):
+        L = 1 << lg
+        try:
+            if lg not in blocks:
+                blocks[lg] = make_block(L, synth.raster(64, cfg["spacing"]), cfg["sps_in"], "psk", dev, seed=4321)
+            x = blocks[lg]
+            fn = np.tile(synth.raster(64, cfg["spacing"]), n // 64)
+            bank = pipeline.InspectorBankConfig(kind="psk", fnor=fn, decimation=cfg["D"], ntaps=cfg["T"], sps=cfg["sps_in"] / cfg["D"],
+                                                channeliser="fft")
+            pipe = pipeline.AnalyzerPipeline(ctx, L, psd_size=cfg["psd"], psd_navg=min(256, L // cfg["psd"]), bank=bank, do_psd=True)
+            pipe.enable_delivery()
+            steps = 6 if lg >= 24 else 12
+            with torch.cuda.stream(pipe.main_stream()):
+                for _ in range(2):
+                    pipe.step(x)
+                    pipe.deliver()
+                pipe.sync()
+                pipe.reset_events()
+                engine.kernel_timing_read()
+                engine.kernel_timing(True)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    pipe.step(x, timed=True)
+                    pipe.deliver()
+                pipe.sync()
+                dt = time.perf_counter() - t0
+                engine.kernel_timing(False)
+            kt = {k: engine.kernel_timing_read(k) for k in CHANNELISER_KERNELS}
+            ck = max(kt, key=lambda k: kt[k]["sum_ms"])
+            engine.kernel_timing_read()
+            st = pipe.stage_times_ms()
+            slow = max(st, key=st.get)
+            rows.append({"inspectors": n, "block_samples": L, "value_MSps": round(L * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+                         "slowest_stage": slow, "stage_ms": {k: round(v, 3) for k, v in st.items()},
+                         "channeliser_kernel": ck, "channeliser_ms_per_step": round(kt[ck]["sum_ms"] / steps, 4),
+                         "channeliser_launches_per_step": round(kt[ck]["launches"] / steps, 2),
+                         "realtime_factor_at_50MSps": round(L * steps / dt / 50e6, 1)})
+            del pipe
+            torch.cuda.empty_cache()
+        except Exception as e:
+            rows.append({"inspectors": n, "error": repr(e)[:300]})
+            break
+    ok = [r for r in rows if "value_MSps" in r]
+    best = max((r["inspectors"] for r in ok if r["value_MSps"] >= 50.0), default=None)
+    out = {"what": run_capacity.__doc__.split("\n\n")[0].replace("\n    ", " "), "rows": rows,
+           "max_inspectors_measured_at_ge_50MSps": best}
+    if ok:
+        last = ok[-1]
+        # beyond the last measured row the step grows in proportion to the inspectors (its slowest stage is throughput-bound
+        # by then), so the count at which the rate falls to 50 MS/s follows from that row
+        out["extrapolated_inspectors_at_50MSps"] = int(last["inspectors"] * last["value_MSps"] / 50.0)
+        out["note"] = (f"every measured count sustains >= 50 MS/s; the last row ({last['inspectors']} inspectors) runs at "
+                       f"{last['value_MSps']} MS/s with `{last['slowest_stage']}` as its step, and from there the step grows with the count: "
+                       f"~{out['extrapolated_inspectors_at_50MSps']} inspectors at 50 MS/s (extrapolated, not measured)") if best == last["inspectors"] else None
+    return out
+
+
+def multi_gpu_diagnostics(dist, rank, world, local_rank, dev_index, dev, L, share):
+    """Before the timed region of an N > 1 run: who is here (one rank per GPU, distinct devices) and what one block costs to
+    broadcast.  Fails loudly instead of timing a job that is not the one asked for."""
+    props = torch.cuda.get_device_properties(dev_index)
+    me = {"rank": rank, "local_rank": local_rank, "device": dev_index, "pid": os.getpid(), "name": props.name,
+          "uuid": str(getattr(props, "uuid", "")), "pci": f"{getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', 0):02x}:{getattr(props, 'pci_device_id', 0):02x}"}
+    seen = [None] * world
+    dist.all_gather_object(seen, me)
+    ids = {(g["uuid"], g["pci"]) for g in seen}
+    if len(seen) != world or any(g is None for g in seen):
+        raise SystemExit(f"bench.py: {sum(g is not None for g in seen)} ranks answered, {world} expected")
+    if not share and len(ids) != world:
+        raise SystemExit(f"bench.py: {world} ranks on {len(ids)} distinct GPU(s): {sorted(ids)}")
+    buf = torch.empty(2 * L, dtype=torch.float32, device=dev)
+    buf.normal_()
+    dist.broadcast(buf, src=0)                                # (communicator set-up and the first transfer's channel set-up)
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.broadcast(buf, src=0)
+    torch.cuda.synchronize(dev)
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    nbytes = buf.numel() * 4
+    del buf
+    return {"rccl_ranks_seen": len(seen), "backend": dist.get_backend(), "distinct_devices": len(ids), "ranks": seen,
+            "bcast_block_bytes": nbytes, "bcast_ms": round(float(dt.item()) / reps * 1e3, 4),
+            "bcast_GBps": round(nbytes * reps / float(dt.item()) / 1e9, 2),
+            "what": "one IQ block broadcast from rank 0 to every rank (max over ranks), back to back, before the timed region"}
+
+
 def run_live_sharded(n_gpus, inspectors_per_gpu=64, nblocks=40, timeout_s=150):
     """The drop-in itself on N GPUs: ONE process, the suscan_analyzer_* ABI with SUAMD_DEVICES=0..N-1 (csrc/analyzer.cpp:
     one worker thread per GPU, inspector handle h on GPU h mod N, the block to every shard by ncclBroadcast over xGMI,
@@ -564,7 +781,9 @@ def main():
                     help="fft: the FFT filter bank with su_specttuner's semantics (what the reference runs behind its "
                          "channels); fir: translate + 255-tap direct-form low-pass + decimate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (c2, c3, c5)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (c1, c2, c3, c5, capacity, live)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not count HBM traffic in child runs under rocprofv3 --pmc")
+    ap.add_argument("--pmc", action="store_true", help="count it even with --no-extra (the default run counts it)")
     # 64 Mi samples: ~5 s of one core + ~0.6 s of all of them on the box's EPYC (the bounded sample of the CPU leg)
     ap.add_argument("--cpu-samples", type=int, default=1 << 26)
     ap.add_argument("--live", action="store_true",
@@ -620,6 +839,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo" if share else "nccl", rank=rank, world_size=world)
     ctx = engine.Context(dev_index)
+    mg = multi_gpu_diagnostics(dist, rank, world, local_rank, dev_index, dev, 1 << args.block, share) if dist is not None else None
 
     cfg, L, dt, stages, fn_rank, pipe = run_workload(args.workload, args, rank, world, dev, ctx, dist)
 
@@ -648,12 +868,21 @@ def main():
         kname = chan_k or ("stp_kernel" if fft_bank else "chan_fir_kernel")
         TIMING = ("dispatch-bound event pairs (hipExtLaunchKernelGGL start/stop events through suamd_kernel_timing): the "
                   "kernel's own duration, averaged over every launch of the timed region")
-        roof = fir_stage_roofline(C, D, L, fir_ms, kname, args.workload, TIMING if chan_k else "stream events around the stage")
+        # HBM traffic of the two transform kernels, counted by this run's own PMC passes (N = 1 only; the committed profile's
+        # figure, labelled as such, when rocprofv3 is not on the box)
+        pmc = pmc_traffic_in_run(args, (kname, "psd_kernel", "psd_reduce_kernel")) if (world == 1 and not args.no_pmc and (args.pmc or not args.no_extra)) else {}
+        src_now = ("counted in this run: child runs of this command line under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                   "(separate passes, 4 steps), 2 x FETCH + WRITE per launch")
+        roof = fir_stage_roofline(C, D, L, fir_ms, kname, args.workload, TIMING if chan_k else "stream events around the stage",
+                                  traffic=(pmc[kname]["hbm_bytes_per_launch"], src_now) if kname in pmc else None)
+        psd_tr = (pmc["psd_kernel"]["hbm_bytes_per_launch"] + pmc.get("psd_reduce_kernel", {}).get("hbm_bytes_per_launch", 0)) if "psd_kernel" in pmc else None
         roof.update({
             "psd_kernel": {"achieved": round(psd_bytes / (psd_ms * 1e-3) / 1e9, 2) if psd_ms else None,
                            "frac": round(psd_bytes / (psd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if psd_ms else None,
                            "kernel_ms": round(psd_ms, 4) if psd_ms else None,
-                           "algorithmic_bytes_per_launch": psd_bytes},
+                           "algorithmic_bytes_per_launch": psd_bytes,
+                           "traffic": psd_tr, "traffic_over_algorithmic": round(psd_tr / psd_bytes, 4) if psd_tr else None},
+            "pmc_counters": pmc or None,
             "kernel_launches_ms": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kms.items()},
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},
             "stalled_samples_dropped": dict(getattr(pipe, "stalled_samples", {})),
@@ -670,6 +899,7 @@ def main():
             "metric": "MS/s complex IQ sustained (PSD + N inspectors)", "value": round(value, 3), "unit": "MS/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "block_log2": args.block,
             "config": {"workload": describe(cfg, args.channeliser), "block_samples": L, "psd_size": cfg["psd"],
                        "inspectors_per_gpu": cfg["per_gpu"], "inspectors_total": cfg["per_gpu"] * world,
                        "decimation": D, "taps": None if fft_bank else T,
@@ -677,11 +907,7 @@ def main():
                        "parallelism": f"channel-sharded x{world}, RCCL broadcast of the IQ block" if world > 1
                        else "single GPU",
                        "channeliser": args.channeliser,
-                       "value_definition": "rate of the IQ stream: every rank consumes the same broadcast block and runs "
-                                           "its shard of the inspectors on it; symbols are copied to pinned host memory "
-                                           "inside the timed region.  (Round 1 multiplied by the GPU count; since round 2 it "
-                                           "does not -- N GPUs carry N x the inspectors at the same stream rate; "
-                                           "aggregate_inspector_MSps is the product.)"},
+                       "schedule": "transform window" if pipe.window else "free-running streams"},
             "aggregate_inspector_MSps": round(value * cfg["per_gpu"] * world, 1),
             "roofline": roof,
         }
@@ -755,10 +981,17 @@ def main():
                                         len(fn2), c2["D"], 1 << lg, msa, ka, w, TIMING + " (the kernel alone, re-feeding one resident block)")
                         except Exception as e:
                             entry["roofline"]["fir_stage_alone"] = {"error": repr(e)}
+                    if not args.no_cpu_baseline:              # the same workload on this box's host cores (bounded sample)
+                        try:
+                            entry["cpu_baseline"] = cpu_baseline(c2, (1 << 23) if w == "c2" else (1 << 25), fn2, os.cpu_count() or 1, chn)
+                        except Exception as e:
+                            entry["cpu_baseline"] = {"error": repr(e)}
                     if label:
                         extra.setdefault(w, {})[chn] = dict(entry, variant=label)
                     else:
                         extra[w] = entry
+            extra["c1"] = run_c1(args)
+            extra["capacity"] = run_capacity(args, dev, ctx)
             extra["c5"] = run_c5(args, dev, ctx)
             try:                                              # the drop-in boundary itself, end to end (host thread, file source)
                 from sigdigger_amd.livebench import live_rate
@@ -773,6 +1006,8 @@ def main():
                 except Exception as e:
                     out["roofline"]["fir_stage_alone"] = {"error": repr(e)}
             out["other_workloads"] = extra
+        if mg is not None:
+            out["multi_gpu"] = mg
         if world > 1 and os.environ.get("SUAMD_BENCH_LIVE_SHARDED", "1") != "0" and not share:
             # the curve of the drop-in itself: the C++ analyzer sharded over the same N GPUs (the other ranks idle at the
             # barrier below; their GPUs are free)
@@ -782,6 +1017,17 @@ def main():
             ref = reference_loops()
             if ref is not None:
                 out["cpu_baseline"]["reference_loops"] = ref
+        # the long descriptions last: the driver's parsed copy of the line is cut after a few kB
+        out["notes"] = {
+            "workload": describe_long(cfg, args.channeliser), "kernel": KERNELS.get(kname, kname),
+            "value_definition": "rate of the IQ stream: every rank consumes the same broadcast block and runs its shard of the "
+                                "inspectors on it; symbols are copied to pinned host memory inside the timed region.  (Round 1 "
+                                "multiplied by the GPU count; since round 2 it does not -- N GPUs carry N x the inspectors at the "
+                                "same stream rate; aggregate_inspector_MSps is the product.)",
+            "schedule": "transform window (round 5): once per block the three recurrence streams pause at a skewed cut (AGC done, "
+                        "Costas one sub-range from its end, Gardner two) and the block's PSD + channeliser run on the idle chip, on "
+                        "the slowest stage's stream; SUAMD_PIPELINE_WINDOW=0 restores round 4's free-running streams" if pipe.window else
+                        "free-running streams (round 4)"}
         assert out["n_gpus"] == args.gpus == world, (out["n_gpus"], args.gpus, world)
         print(json.dumps(out), flush=True)
 

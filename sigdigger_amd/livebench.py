@@ -33,7 +33,7 @@ def live_rate(n_inspectors=64, nblocks=40, fs=50_000_000, nfft=8192, block=1 << 
         assert an
         Lb.suscan_source_config_destroy(cfg)
         Lb.suscan_analyzer_set_throttle_async(an, 0, 0)
-        spacing = min(300e3, 0.9 * fs / n_inspectors)                                       # every channel inside +-fs/2
+        spacing = min(300e3, 0.9 * fs / max(n_inspectors, 1))                               # every channel inside +-fs/2
         for k in range(n_inspectors):
             fc = (k - n_inspectors / 2 + 0.5) * spacing
             bw = (100e3 + 10e3 * (k % 7)) * spacing / 300e3
@@ -74,7 +74,7 @@ def live_rate(n_inspectors=64, nblocks=40, fs=50_000_000, nfft=8192, block=1 << 
                                                 f"{block}-sample blocks at {fs / 1e6:g} MS/s",
                                     "value_MSps": round(nblocks * block / dt / 1e6, 3), "ms_per_block": round(dt / nblocks * 1e3, 4),
                                     "symbols_Msps": round(st["sym"] / dt / 1e6, 3), "inspectors": n_inspectors, "blocks": nblocks,
-                                    "worker_MSps": round(worker / 1e6, 3),
+                                    "worker_MSps": round(worker / 1e6, 3), "psd_frames_per_s": round(nblocks / dt, 1),
                                     "note": "value_MSps is timed at this Python consumer (one message per inspector and block: it "
                                             "becomes the limit beyond ~100 inspectors); worker_MSps is suscan_analyzer_get_measured_samp_rate"}
                     Lb.suscan_analyzer_req_halt(an)
@@ -92,3 +92,20 @@ def live_rate(n_inspectors=64, nblocks=40, fs=50_000_000, nfft=8192, block=1 << 
         return st["result"] or {"error": "analyzer halted before the measurement finished"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def live_psd_only(fs=2_400_000, nfft=8192, interval_s=0.04, nblocks=400, timeout_s=60.0):
+    """BASELINE.json configs[0] through the drop-in boundary: file source, PSD only, no inspector, unthrottled.  The block is
+    what the analyzer derives from psd_update_int (csrc/analyzer.cpp setup_psd: nfft x round(fs x interval / nfft) samples ->
+    one PSD message per block), i.e. the reference's operating point (include/AppConfig.h:35-38: 25 fps) when interval_s = 0.04."""
+    frames = max(1, int(fs * interval_s / nfft + 0.5))
+    block = nfft * frames
+    # the capture: a whole number of blocks, at least 4 (looped), in the page cache
+    d = live_rate(0, nblocks, fs=fs, nfft=nfft, block=block, timeout_s=timeout_s)
+    if "error" not in d:
+        d["workload"] = (f"live analyzer through the suscan ABI: file source (f32 IQ, page cache, looped), {nfft}-pt PSD only, no inspector, "
+                         f"unthrottled; {frames} frames averaged per PSD message ({block}-sample blocks = {interval_s * 1e3:g} ms at {fs / 1e6:g} MS/s)")
+        d["realtime_factor"] = round(d["value_MSps"] * 1e6 / fs, 1)
+        d.pop("symbols_Msps", None)
+        d.pop("note", None)
+    return d

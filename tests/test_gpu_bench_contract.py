@@ -55,6 +55,10 @@ def test_two_ranks_share_the_gpu_over_gloo():
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["inspectors_total"] == 2 * d["config"]["inspectors_per_gpu"]
     assert "cpu_baseline" not in d and "other_workloads" not in d                  # N = 1 only
+    # the run says who took part and what a block costs to broadcast, before it times anything
+    mg = d["multi_gpu"]
+    assert mg["rccl_ranks_seen"] == 2 and [g["rank"] for g in mg["ranks"]] == [0, 1] and mg["bcast_GBps"] > 0
+    assert mg["bcast_block_bytes"] == 8 * d["config"]["block_samples"]
     # `value` is the rate of the IQ stream: both ranks consume the same broadcast block (each runs its own shard of the
     # inspectors on it); the aggregate channel rate is reported beside it
     assert abs(d["value"] - d["config"]["block_samples"] / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
