@@ -343,7 +343,12 @@ struct RowArena {
   struct Slab { char *base; size_t size, head; };
   std::vector<Slab> slabs;
   std::map<size_t, std::vector<void *>> spare;
-  static size_t rounded(size_t bytes) { return (bytes + 4095) & ~(size_t)4095; }
+  // Rows come in power-of-two size classes (>= 4 KiB): a freed row serves any later request of its class, so an inspector
+  // that is resized back and forth (set_bandwidth: another decimation, another row length) reuses what it gave back instead
+  // of carving the slabs further.  The first slab is sized from the first request (32 MiB or 8 rows), later ones grow
+  // geometrically up to 256 MiB: one raw inspector on a small block does not reserve 256 MiB per shard any more.
+  // Memory floor: slabs are only returned when the analyzer is destroyed (release()).
+  static size_t rounded(size_t bytes) { size_t c = 4096; while (c < bytes) c <<= 1; return c; }
   void *take(size_t bytes)
   {
     bytes = rounded(bytes);
@@ -351,7 +356,8 @@ struct RowArena {
     if (it != spare.end() && !it->second.empty()) { void *p = it->second.back(); it->second.pop_back(); return p; }
     for (Slab &sl : slabs)
       if (sl.head + bytes <= sl.size) { void *p = sl.base + sl.head; sl.head += bytes; return p; }
-    const size_t want = std::max<size_t>((size_t)256 << 20, 4 * bytes);
+    const size_t grow = slabs.empty() ? ((size_t)32 << 20) : std::min<size_t>((size_t)256 << 20, 2 * slabs.back().size);
+    const size_t want = std::max<size_t>(grow, slabs.empty() ? 8 * bytes : 4 * bytes);
     char *base = nullptr;
     if (hipMalloc((void **)&base, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     slabs.push_back(Slab{base, want, bytes});
@@ -547,6 +553,9 @@ struct BlockBus {
   std::vector<void *> comm;
   int (*bcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
   int (*comm_destroy)(void *) = nullptr;
+  int (*comm_abort)(void *) = nullptr;          // ncclCommAbort: releases a collective whose peer never came
+  int bcast_timeout_ms = 2000;                  // SUAMD_ANALYZER_BCAST_TIMEOUT_MS: how long a broadcast may sit on a stream
+  std::vector<bool> lost_reported;              // per subscriber: its loss has been posted as READ_ERROR
   bool bcast_off = false;                       // a broadcast failed, or a shard gave up: per-GPU host copies from here on
   uint64_t bcast_blocks = 0;                    // blocks that went out through ncclBroadcast (diagnostic, SOURCE_INFO-independent)
 };
@@ -554,6 +563,7 @@ struct BlockBus {
 struct suscan_analyzer {
   int device = 0;                               // the GPU this shard is bound to
   int shard = 0, nshards = 1;
+  int fault_shard = -1; long long fault_block = -1;   // SUAMD_ANALYZER_FAULT=shard_dies:<shard>:<block> (tests): that shard stops at that block
   suscan_analyzer *primary = nullptr;           // shard 0 (itself for shard 0)
   std::vector<suscan_analyzer *> secondaries;   // shard 0 only: shards 1 .. G-1
   std::shared_ptr<BlockBus> bus;
@@ -1621,6 +1631,47 @@ bool bus_publish(suscan_analyzer *a, const void *host, size_t samples, size_t va
   return b.e[(b.seq - 1) & 1].via_bcast;                     // (only the publisher writes the entries)
 }
 
+// A collective needs every rank.  A shard that dies between the publisher's decision ("this block goes out by broadcast")
+// and its own ncclBroadcast call leaves the other ranks' calls on their streams with a peer that never comes: librccl's
+// kernel spins for ever and every later synchronisation of that stream hangs with it.  So the stream is never waited for
+// blindly behind a broadcast: the event recorded after the call is polled with a deadline, and when it runs out the rank
+// aborts its communicator (ncclCommAbort releases the kernel), the bus switches to per-GPU host copies for good, and the
+// dead shard is reported.  Returns false when the deadline passed.
+bool wait_event_deadline(hipEvent_t ev, int timeout_ms)
+{
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+  for (int spins = 0;; ++spins) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q == hipSuccess) return true;
+    if (q != hipErrorNotReady) { (void)hipGetLastError(); return true; }   // a broken event is not a hung broadcast
+    if (std::chrono::steady_clock::now() >= t_end) return false;
+    if (spins < 2000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100));
+  }
+}
+
+// this rank's broadcast did not complete: release its stream, stop broadcasting, say which shard is gone
+void bus_broadcast_stuck(suscan_analyzer *a, hipEvent_t ev)
+{
+  BlockBus &b = *a->bus;
+  void *comm = nullptr;
+  std::vector<int> lost;
+  {
+    std::lock_guard<std::mutex> lk(b.m);
+    b.bcast_off = true;
+    if ((size_t)a->shard < b.comm.size()) { comm = b.comm[a->shard]; b.comm[a->shard] = nullptr; }
+    if (b.lost_reported.size() < b.done.size()) b.lost_reported.resize(b.done.size(), false);
+    for (size_t i = 0; i < b.done.size(); ++i)
+      if (b.done[i] == ~0ull && !b.lost_reported[i]) { b.lost_reported[i] = true; lost.push_back((int)i + 1); }
+  }
+  if (comm && b.comm_abort) (void)b.comm_abort(comm);         // (the communicator is gone with it: never destroyed twice)
+  if (!wait_event_deadline(ev, 20000))                         // without ncclCommAbort (an old library) the kernel cannot be released
+    push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, "GPU shard " + std::to_string(a->shard) + ": a stuck ncclBroadcast could not be aborted");
+  push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, 0, "GPU shard " + std::to_string(a->shard) + ": ncclBroadcast did not complete within " +
+              std::to_string(b.bcast_timeout_ms) + " ms (a rank is missing): aborted, per-GPU host copies from here on");
+  for (int sh : lost)
+    push_status(a->primary ? a->primary : a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, "GPU shard " + std::to_string(sh) + " is gone: its inspectors deliver nothing any more");
+}
+
 void bus_close(suscan_analyzer *a)
 {
   if (!a->bus) return;
@@ -1693,14 +1744,26 @@ void secondary_main(suscan_analyzer *a)
       if (fft != a->use_fft && !fft && a->st) { suamd_specttuner_destroy(a->st); a->st = nullptr; }
       a->use_fft = fft;
     }
+    if (a->fault_shard == a->shard && a->fault_block == (long long)k) {   // SUAMD_ANALYZER_FAULT (tests): this shard dies here,
+      push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, "GPU shard " + std::to_string(a->shard) + ": fault injection at block " + std::to_string(k));
+      failed = true;                                                       // after the publisher has counted on it for block k
+      break;
+    }
     if (a->xfree_set) (void)hipStreamWaitEvent(a->stream, a->ev_xfree, 0);
     const bool compact = e.bytes_per_sample != sizeof(suamd_complex);
     void *dst = compact ? a->d_raw : (void *)a->d_x;
     const size_t bytes = e.valid * e.bytes_per_sample;
     bool sent = false;
     if (e.via_bcast) {
-      sent = bus.bcast(nullptr, dst, bytes, 0 /* ncclInt8 */, 0, bus.comm[a->shard], a->stream) == 0;
+      void *comm = nullptr;
+      { std::lock_guard<std::mutex> lk(bus.m); comm = bus.comm[a->shard]; }
+      sent = comm && bus.bcast(nullptr, dst, bytes, 0 /* ncclInt8 */, 0, comm, a->stream) == 0;
       if (!sent) { std::lock_guard<std::mutex> lk(bus.m); bus.bcast_off = true; }
+      else {
+        // nothing that reads the block is enqueued before the broadcast is known to have completed (see wait_event_deadline)
+        (void)hipEventRecord(a->ev_h2d[0], a->stream);
+        if (!wait_event_deadline(a->ev_h2d[0], bus.bcast_timeout_ms)) { bus_broadcast_stuck(a, a->ev_h2d[0]); sent = false; }
+      }
     }
     if (!sent) (void)hipMemcpyAsync(dst, e.host, bytes, hipMemcpyHostToDevice, a->stream);
     (void)hipEventRecord(a->ev_h2d[0], a->stream);
@@ -1770,6 +1833,8 @@ void setup_rccl(suscan_analyzer *a)
   std::lock_guard<std::mutex> lk(a->bus->m);
   a->bus->rccl_lib = lib; a->bus->comm = comm; a->bus->bcast = bcast;
   a->bus->comm_destroy = reinterpret_cast<int (*)(void *)>(dlsym(lib, "ncclCommDestroy"));
+  a->bus->comm_abort = reinterpret_cast<int (*)(void *)>(dlsym(lib, "ncclCommAbort"));
+  if (const char *t = std::getenv("SUAMD_ANALYZER_BCAST_TIMEOUT_MS")) { const int v = std::atoi(t); if (v >= 10 && v <= 600000) a->bus->bcast_timeout_ms = v; }
 }
 
 void worker_main(suscan_analyzer *a)
@@ -1947,9 +2012,16 @@ void worker_main(suscan_analyzer *a)
     if (via_bcast) {                                         // SUAMD_ANALYZER_BCAST=rccl: GPU 0 is the root of one broadcast per block
       void *root = src.bytes_per_sample() == sizeof(suamd_complex) || h_flt ? (void *)a->d_x : a->d_raw;
       const size_t bytes = blen * (h_flt ? sizeof(suamd_complex) : src.bytes_per_sample());
-      if (a->bus->bcast(root, root, bytes, 0, 0, a->bus->comm[0], a->stream) != 0) {
+      void *comm = nullptr;
+      { std::lock_guard<std::mutex> lk(a->bus->m); comm = a->bus->comm[0]; }
+      if (!comm || a->bus->bcast(root, root, bytes, 0, 0, comm, a->stream) != 0) {
         std::lock_guard<std::mutex> lk(a->bus->m);
         a->bus->bcast_off = true;                              // (the shards that could not take part fall back to their host copy themselves)
+      } else {
+        // the root's stream is never waited for blindly behind a collective (wait_event_deadline): a shard that died after
+        // this block was published would otherwise hang the analyzer
+        (void)hipEventRecord(a->ev_h2d[cur], a->stream);
+        if (!wait_event_deadline(a->ev_h2d[cur], a->bus->bcast_timeout_ms)) bus_broadcast_stuck(a, a->ev_h2d[cur]);
       }
     }
     (void)hipEventRecord(a->ev_h2d[cur], a->stream);
@@ -2436,6 +2508,10 @@ suscan_analyzer_t *suscan_analyzer_new(const struct suscan_analyzer_params *para
         s->params = *params; s->source_cfg = *config; s->mq = mq;
         s->device = devs[i]; s->shard = (int)i; s->nshards = a->nshards; s->primary = a; s->bus = a->bus;
         s->next_handle = (SUHANDLE)i;
+        if (const char *f = std::getenv("SUAMD_ANALYZER_FAULT")) {
+          int fs = -1; long long fb = -1;
+          if (std::sscanf(f, "shard_dies:%d:%lld", &fs, &fb) == 2) { s->fault_shard = fs; s->fault_block = fb; }
+        }
         a->secondaries.push_back(s);
       }
       if (a->secondaries.size() != devs.size() - 1) {          // out of memory: one GPU then

@@ -305,6 +305,7 @@ hipError_t launch_st_v(const sdk::StArgs &a, hipStream_t st)
   const unsigned nruns = (unsigned)((a.nwin + a.run - 1) / a.run);
   const unsigned ngroups = (unsigned)((a.nchan + G::CPP - 1) / G::CPP);
   sdk::launch_timed("st_kernel", kern, dim3(nruns, (ngroups + NGL - 1) / NGL), dim3(ST_THREADS), lds, st, a);
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   if (a.handoff && nruns > 1) {
     const long long total = (long long)a.nchan * (1 << (LOG2S - 1));
     sdk::launch_timed("st_seam_kernel", st_seam_kernel, dim3((unsigned)std::min<long long>(64, (total + 255) / 256), nruns - 1), dim3(256), 0, st, a, LOG2S);
@@ -341,7 +342,8 @@ int st_channels_per_group(int log2s) { return log2s == 5 ? 64 : (log2s < 4 ? 256
 
 bool st_two_turns(int log2s, int nchan)
 {
-  static const int ngl_env = [] { const char *e = getenv("SUAMD_ST_NGL"); return e ? atoi(e) : 0; }();
+  const char *engl = getenv("SUAMD_ST_NGL");                    // (read on every launch: A / B tests switch it in-process)
+  const int ngl_env = engl ? atoi(engl) : 0;
   const int cpp = st_channels_per_group(log2s);
   const int ngroups = (nchan + cpp - 1) / cpp;
   return log2s >= 7 && log2s <= 11 && (ngl_env ? ngl_env : (ngroups >= 2 ? 2 : 1)) >= 2;

@@ -562,7 +562,8 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
           // 32-bit buffer addressing of the outputs when the whole view of this feed lies below 2 GiB
           const long long hs = (1ll << g.log2s) / 2;
           const long long last = ((long long)st->ch.size() * (long long)view.chan_stride + (nwin * hs + hs) * (long long)view.time_stride) * 8;
-          static const bool no_y32 = [] { const char *e = std::getenv("SUAMD_ST_Y32"); return e && e[0] == '0'; }();   // debug: 64-bit addressing everywhere
+          const char *ey = std::getenv("SUAMD_ST_Y32");          // debug: 64-bit addressing everywhere (read on every feed)
+          const bool no_y32 = ey && ey[0] == '0';
           a.y32 = (!d_rows && last < (1ll << 31) && !no_y32) ? 1 : 0;
           // rows promised to start within rows_span bytes of d_y: offsets from there, if the feed's own extent fits too
           if (d_rows && rows_span && !no_y32 && (long long)rows_span + (nwin * hs + hs) * 8 < (1ll << 31)) a.y32 = 1;
@@ -643,9 +644,13 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
           // Banks that fit one workgroup side by side only (measured per 4 Mi samples, tools/st_wide.py: one channel of 256
           // bins 49.1 -> 44.7 us, of 128 bins 46.6 -> 40.3; 64 x 256 bins 136 -> 143, 128 x 256 267 -> 284: there a run is
           // long and the warm-up window a ninth of it, less than the second launch costs).  SUAMD_ST_SEAM=0 / 1: never / always.
-          static const int seam_env = [] { const char *e2 = std::getenv("SUAMD_ST_SEAM"); return e2 ? (e2[0] == '0' ? 0 : 1) : -1; }();
-          const bool seam_off = seam_env == 0 || (seam_env < 0 && a.nchan > sdk::st_channels_per_group(g.log2s));
+          // (read on every feed, like SUAMD_FIR_STREAM: a test that flips it inside one process must get the other path)
+          const char *e2 = std::getenv("SUAMD_ST_SEAM");
+          const int seam_env = e2 ? (e2[0] == '0' ? 0 : 1) : -1;
           const size_t nruns = (size_t)((nwin + a.run - 1) / a.run);
+          // st_seam_kernel takes the runs in grid.y: beyond 65535 of them (one-window runs of a narrow size on a very long
+          // feed) the launch keeps its warm-up windows instead
+          const bool seam_off = seam_env == 0 || (seam_env < 0 && a.nchan > sdk::st_channels_per_group(g.log2s)) || nruns - 1 > 65535;
           const size_t need = nruns > 1 ? (nruns - 1) * (size_t)a.nchan * ((size_t)1 << (g.log2s - 1)) : 0;
           a.handoff = nullptr;
           if (!seam_off && need && g.log2s >= 1 && need * sizeof(c32) <= ((size_t)256 << 20)) {

@@ -6,10 +6,19 @@
 // root's bytes, and the root's stream does not pass its call before every rank has them (so the root may overwrite its
 // buffer afterwards, as it does with the next block).  Same device: the "transfer" is a device-to-device copy.
 //
+// A MISSING rank (round 5).  With librccl a call returns at once and the collective lives on the stream: if a rank never
+// calls, the root's stream sits in a kernel that waits for it -- for ever, or until ncclCommAbort.  Ranks that share one
+// device cannot wait for each other on the device (their streams share hardware queues: the waiting kernel would sit in
+// front of the work it waits for), so the stand-in waits for the other ranks on the HOST for a grace period
+// (STANDIN_GRACE_MS, default 1000) and only when a rank has not shown up by then puts a kernel on the root's stream that
+// spins until ncclCommAbort(root's communicator) releases it (or STANDIN_SPIN_LIMIT_S, default 20 s, have passed: a test
+// must fail, not hang the box) -- what csrc/analyzer.cpp's broadcast watchdog is there for.
+//
 // Built by tests/test_gpu_analyzer_fft.py with hipcc into a temporary directory and handed to the analyzer through
 // SUAMD_RCCL_LIB together with SUAMD_RCCL_ALLOW_SAME_DEVICE=1.  Nothing under sigdigger_amd/ refers to it.
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <cstdlib>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -24,10 +33,33 @@ struct Group {
   std::condition_variable cv;
   std::map<unsigned long long, Call> calls;                    // by call index (every rank issues its broadcasts in the same order)
 };
-struct Comm { Group *g; int rank; unsigned long long seq = 0; };
-unsigned long long g_broadcasts = 0, g_bytes = 0;
+struct Comm { Group *g; int rank; unsigned long long seq = 0; unsigned *abort_flag = nullptr; };   // abort_flag: pinned host memory
+unsigned long long g_broadcasts = 0, g_bytes = 0, g_aborts = 0, g_orphans = 0;
 std::mutex g_m;
 constexpr auto kWait = std::chrono::seconds(20);               // a test must fail, not hang
+
+std::chrono::milliseconds grace()
+{
+  const char *e = std::getenv("STANDIN_GRACE_MS");
+  const long v = e ? std::atol(e) : 1000;
+  return std::chrono::milliseconds(v > 0 ? v : 1000);
+}
+
+unsigned long long spin_limit_ticks()
+{
+  const char *e = std::getenv("STANDIN_SPIN_LIMIT_S");
+  const double s = e ? std::atof(e) : 20.0;
+  return (unsigned long long)((s > 0 ? s : 20.0) * 1e8);       // wall_clock64(): 100 MHz
+}
+
+// the root's stream with a rank missing: nothing gets past this before ncclCommAbort (or the limit)
+__global__ void orphan_kernel(const unsigned *abort_flag, unsigned long long limit)
+{
+  if (threadIdx.x) return;
+  const unsigned long long t0 = wall_clock64();
+  while (!__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) && wall_clock64() - t0 < limit)
+    __builtin_amdgcn_s_sleep(64);
+}
 
 size_t type_size(int t) { static const size_t sz[] = {1, 1, 4, 4, 8, 8, 2, 4, 8, 2}; return t >= 0 && t < 10 ? sz[t] : 0; }
 
@@ -40,7 +72,28 @@ __attribute__((visibility("default"))) int ncclCommInitAll(void **comms, int nde
   if (!comms || ndev < 1) return 4;                            // ncclInvalidArgument
   Group *g = new Group;
   g->n = ndev;
-  for (int r = 0; r < ndev; ++r) comms[r] = new Comm{g, r};
+  for (int r = 0; r < ndev; ++r) {
+    Comm *c = new Comm{g, r};
+    if (hipHostMalloc((void **)&c->abort_flag, sizeof(unsigned), hipHostMallocDefault) != hipSuccess) return 1;
+    *c->abort_flag = 0;
+    comms[r] = c;
+  }
+  return 0;
+}
+
+// releases what this rank's stream is stuck in and retires the communicator (as ncclCommAbort does; the flag's page stays:
+// the kernel it releases is still reading it)
+__attribute__((visibility("default"))) int ncclCommAbort(void *c)
+{
+  Comm *cm = static_cast<Comm *>(c);
+  if (!cm) return 4;
+  __atomic_store_n(cm->abort_flag, 1u, __ATOMIC_RELEASE);
+  { std::lock_guard<std::mutex> gl(g_m); ++g_aborts; }
+  Group *g = cm->g;
+  bool last;
+  { std::lock_guard<std::mutex> lk(g->m); last = --g->n == 0; }
+  delete cm;
+  if (last) delete g;
   return 0;
 }
 
@@ -71,7 +124,15 @@ __attribute__((visibility("default"))) int ncclBroadcast(const void *send, void 
     g->cv.notify_all();
     if (recv != send && hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
     // the root's stream passes this call once every other rank has its copy
-    if (!g->cv.wait_for(lk, kWait, [&] { return (int)g->calls[k].got.size() == g->n - 1; })) return 6;   // ncclRemoteError-like
+    const int peers = g->n - 1;
+    if (!g->cv.wait_for(lk, grace(), [&] { return (int)g->calls[k].got.size() >= peers; })) {
+      // a rank is missing: the call itself succeeds (it only enqueues), the stream is what hangs
+      static const unsigned long long limit = spin_limit_ticks();
+      hipLaunchKernelGGL(orphan_kernel, dim3(1), dim3(64), 0, st, cm->abort_flag, limit);
+      std::lock_guard<std::mutex> gl(g_m);
+      ++g_orphans;
+      return hipGetLastError() == hipSuccess ? 0 : 1;
+    }
     for (hipEvent_t e : g->calls[k].got) { (void)hipStreamWaitEvent(st, e, 0); }
     // (the events are released with the call record; the stream wait has captured them)
     for (hipEvent_t e : g->calls[k].got) (void)hipEventDestroy(e);
@@ -94,5 +155,7 @@ __attribute__((visibility("default"))) int ncclBroadcast(const void *send, void 
 // what the test reads: how many broadcasts completed through this library, and their payload
 __attribute__((visibility("default"))) unsigned long long standin_broadcasts(void) { std::lock_guard<std::mutex> gl(g_m); return g_broadcasts; }
 __attribute__((visibility("default"))) unsigned long long standin_bytes(void) { std::lock_guard<std::mutex> gl(g_m); return g_bytes; }
+__attribute__((visibility("default"))) unsigned long long standin_aborts(void) { std::lock_guard<std::mutex> gl(g_m); return g_aborts; }
+__attribute__((visibility("default"))) unsigned long long standin_orphans(void) { std::lock_guard<std::mutex> gl(g_m); return g_orphans; }
 
 }  // extern "C"

@@ -474,12 +474,28 @@ def test_wide_channels_without_the_warm_up_window(ctx, monkeypatch, dec, nch):
     x = cnoise(H * 47, 900 + dec + nch)
     bw = 2 * np.pi * 0.75 / dec
     chans = [(0.3 + 6.0 * c / max(nch, 2), bw * (0.6 + 0.4 * (c % 3) / 2), 1.0, bool(c % 2)) for c in range(nch)]
+    def seam_launches(fn):
+        """fn() with the library's kernel timer on: its result and how many st_seam_kernel launches it made"""
+        engine.kernel_timing_read()
+        engine.kernel_timing(True)
+        try:
+            out = fn()
+            torch.cuda.synchronize()
+        finally:
+            engine.kernel_timing(False)
+        n = engine.kernel_timing_read("st_seam_kernel")["launches"]
+        engine.kernel_timing_read()
+        return out, n
     for run in (1, 2, 5, None):
         for tm in (False, True):
+            # (the knob is read on every feed -- ADVICE r4: cached in a function-local static it compared a mode with itself)
             monkeypatch.setenv("SUAMD_ST_SEAM", "0")
-            ref = run_gpu(ctx, x, chans, splits=[H * 9, H * 10, H * 31], run=run, time_major=tm)
+            ref, n0 = seam_launches(lambda: run_gpu(ctx, x, chans, splits=[H * 9, H * 10, H * 31], run=run, time_major=tm))
             monkeypatch.setenv("SUAMD_ST_SEAM", "1")
-            got = run_gpu(ctx, x, chans, splits=[H * 9, H * 10, H * 31], run=run, time_major=tm)
+            got, n1 = seam_launches(lambda: run_gpu(ctx, x, chans, splits=[H * 9, H * 10, H * 31], run=run, time_major=tm))
             monkeypatch.delenv("SUAMD_ST_SEAM")
+            assert n0 == 0, "SUAMD_ST_SEAM=0 still launched the seam kernel"
+            if run in (1, 2, 5):
+                assert n1 > 0, "SUAMD_ST_SEAM=1 never launched the seam kernel: the two runs took the same path"
             for a, b in zip(ref, got):
                 assert a.size == b.size > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (run, tm)
