@@ -915,6 +915,7 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
     in.stream = sA;
     if (in.dirty) {
       std::string err;
+      flush_watermark(a, in);                                 // (a rebuild for any other reason -- the block size changed -- as well)
       if (!build_chain(a, in, err)) {
         // the inspector sits this block out; its channel must not stay a member of the filter bank, whose kernel would
         // store that channel's samples through a row pointer nobody maintains
@@ -1271,6 +1272,10 @@ void handle_request(suscan_analyzer *a, Request &r)
     }
     case Request::SET_CONFIG: {
       Inspector &in = *it->second;
+      // the chain behind the channel is rebuilt at the next block: what the old one has not delivered yet (a watermark's
+      // unfilled batch) goes out BEFORE the acknowledgement -- a SAMPLES batch never mixes two configurations (found by
+      // tests/test_gpu_analyzer_fuzz.py: the remainder used to surface inside the new chain's first batch)
+      flush_watermark(a, in);
       // copy the values of every field the inspector knows
       for (unsigned i = 0; r.config && i < r.config->desc->field_count; ++i) {
         const suscan_field_value *v = r.config->values[i];
@@ -1303,8 +1308,8 @@ void handle_request(suscan_analyzer *a, Request &r)
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);   // acknowledgement: no spectrum_data yet
       break;
     }
-    case Request::SET_FREQ: it->second->channel.fc = r.fvalue; it->second->dirty = true; break;
-    case Request::SET_BW:   it->second->channel.bw = (SUFLOAT)r.fvalue; it->second->dirty = true; break;
+    case Request::SET_FREQ: flush_watermark(a, *it->second); it->second->channel.fc = r.fvalue; it->second->dirty = true; break;
+    case Request::SET_BW:   flush_watermark(a, *it->second); it->second->channel.bw = (SUFLOAT)r.fvalue; it->second->dirty = true; break;   // (another sample rate: see SET_CONFIG)
     case Request::SET_PARAMS: {
       // only the PSD parameters matter on this path; applied at the next block boundary by the worker
       a->params = r.params;

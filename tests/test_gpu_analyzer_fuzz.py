@@ -1,0 +1,468 @@
+"""Seeded fuzz of the live analyzer's request handling.
+
+csrc/analyzer.cpp is threaded host code -- a worker per GPU shard, two blocks in flight, requests that take effect at
+block boundaries -- and until round 5 it was only exercised by scripted scenarios.  Here a seeded random schedule of
+requests (open raw / psk inspectors, close, set_config, set_watermark, set_freq, set_bandwidth, set_params, seek) is
+posted from the consumer thread against an UNTHROTTLED looping source, i.e. while blocks are in flight, on one and on three
+shards (SUAMD_DEVICES=0,0,0) and on both channelisers.  Every SAMPLES stream that comes back is then replayed by the
+oracle: the consumer sees every reply in queue order with the PSD and SAMPLES messages, so it knows (to within the skew
+between shards, which the comparison searches) at which block boundary each request took effect, and the samples between
+two boundaries must be the oracle's for that configuration from that block on, BIT FOR BIT.
+
+What the replay relies on (csrc/analyzer.cpp, tests/test_gpu_analyzer*.py pin each of these on its own):
+  * a request is handled between two blocks; its reply is queued before any message of the first block it affects;
+  * FIR channeliser: an inspector's bank starts fresh (zero history, sample clock 0) with the block it is (re)built at --
+    open, set_config, set_freq, set_bandwidth all rebuild it;
+  * FFT channeliser: one tuner per shard; a channel opened while the tuner runs starts on the window that straddles the
+    block boundary with a zero cross-fade partner (= the oracle started half a window earlier); set_config rebuilds the
+    stages BEHIND the channel and leaves the channel alone; set_freq / set_bandwidth re-open the channel;
+  * watermarks change the batching, never the stream; set_params that keeps the block size leaves the inspectors alone.
+A seek has no reply and moves every stream at once: it is posted near the end of a schedule and what follows it is only
+checked for liveness (every reply arrives, every sample is finite, the analyzer halts)."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+from sigdigger_amd import suscan, synth
+from tests.test_gpu_analyzer import FS, L, _pump, _start
+
+pytestmark = pytest.mark.gpu
+W, H = 4096, 2048
+NLOOP = 8                                  # blocks in the looping capture
+K_START, K_SEEK, K_END = 3, 40, 48         # PSD messages: schedule starts / the seek goes out / halt
+CARRIERS = [-300e3, -180e3, -60e3, 70e3, 190e3, 310e3]
+BAUD = 15625.0
+COMBOS = [("fft", None), ("fft", "0,0,0"), ("fir", None), ("fir", "0,0,0")]
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _pow2floor_D(bw):
+    D = 1
+    while D * 2 <= FS / (2 * bw) and D < 4096:
+        D *= 2
+    return D
+
+
+class Insp:
+    """what the consumer knows about one inspector: its requests, and its messages in queue order"""
+
+    def __init__(self, req, cls, fc, bw, precise, anchor=False):
+        self.req, self.cls, self.fc, self.bw, self.precise, self.anchor = req, cls, fc, bw, precise, anchor
+        self.handle = None
+        self.iid = 7000 + req
+        self.items = []                    # ("s", samples) | ("ev", kind, psd_count, payload)   in queue order
+        self.state = "opening"             # opening -> idset -> live -> closing -> closed
+        self.cfg = None                    # psk: (order, loop_bw, gain) of the last set_config posted
+        self.pending_cfg = 0
+        self.pending = []                  # configurations posted, not yet acknowledged
+        self.last_touch = 0
+
+
+class Fuzz:
+    def __init__(self, Lb, an, rng, G):
+        self.Lb, self.an, self.rng, self.G = Lb, an, rng, G
+        self.psd = 0
+        self.by_req, self.by_handle, self.by_iid = {}, {}, {}
+        self.next_req = 100
+        self.replies_expected = 0
+        self.replies = 0
+        self.seek_at = None
+        self.seek_marked = False
+        self.params_toggles = 0
+        self.window = 4
+        self.finite = True
+        self.halted = False
+
+    # ---- requests ----------------------------------------------------------------------------------------------
+    def chan(self, fc, bw):
+        return suscan.Channel(fc=float(fc), f_lo=float(fc - bw / 2), f_hi=float(fc + bw / 2), bw=float(bw), ft=433.92e6)
+
+    def open(self, cls, fc, bw, precise, anchor=False):
+        self.next_req += 1
+        i = Insp(self.next_req, cls, fc, bw, precise, anchor)
+        self.by_req[i.req] = i
+        assert self.Lb.suscan_analyzer_open_ex_async(self.an, cls.encode(), C.byref(self.chan(fc, bw)), int(precise), -1, i.req)
+        self.replies_expected += 1
+        return i
+
+    def configure(self, i):
+        order = int(self.rng.integers(1, 4))
+        loop_bw = float(self.rng.choice([20.0, 40.0, 60.0]))
+        gain = float(self.rng.choice([0.1, 0.2]))
+        desc = self.Lb.suscan_inspector_config_desc(b"psk")
+        cfg = self.Lb.suscan_config_new(desc)
+        self.Lb.suscan_config_set_integer(cfg, b"afc.costas-order", order)
+        self.Lb.suscan_config_set_float(cfg, b"afc.loop-bw", loop_bw)
+        self.Lb.suscan_config_set_integer(cfg, b"clock.type", 1)
+        self.Lb.suscan_config_set_float(cfg, b"clock.baud", BAUD)
+        self.Lb.suscan_config_set_float(cfg, b"clock.gain", gain)
+        self.next_req += 1
+        assert self.Lb.suscan_analyzer_set_inspector_config_async(self.an, i.handle, cfg, self.next_req)
+        self.Lb.suscan_config_destroy(cfg)
+        i.pending.append((order, loop_bw, gain))
+        i.pending_cfg += 1
+        self.replies_expected += 1
+
+    def marker(self, i, what):
+        """a request with a reply behind one without (set_freq, set_bandwidth, seek): the reply's place in the queue bounds
+        the boundary the silent request took effect at"""
+        self.next_req += 1
+        i.markers = getattr(i, "markers", {})
+        i.markers[self.next_req] = what
+        assert self.Lb.suscan_analyzer_set_inspector_id_async(self.an, i.handle, i.iid, self.next_req)
+        self.replies_expected += 1
+
+    def live(self, cls=None, anchors=False):
+        return [i for i in self.by_handle.values() if i.state == "live" and (cls is None or i.cls == cls) and (anchors or not i.anchor)
+                and self.psd - i.last_touch >= 2]
+
+    def schedule(self):
+        """called at every PSD message: this step's requests"""
+        k, rng = self.psd, self.rng
+        if k < K_START or self.seek_at is not None:
+            return
+        if k == K_SEEK:
+            # a seek back to the start of the capture; the marker goes to shard 0's anchor (same request queue as the seek)
+            tv = suscan.Timeval(0, 0)
+            assert self.Lb.suscan_analyzer_seek(self.an, C.byref(tv))
+            self.seek_at = k
+            a0 = next(i for i in self.by_handle.values() if i.anchor and i.handle % self.G == 0)
+            self.marker(a0, ("seek",))
+            return
+        n_live = len([i for i in self.by_handle.values() if i.state in ("opening", "idset", "live")])
+        for _ in range(int(rng.integers(1, 4))):
+            op = rng.choice(["open", "open", "close", "config", "watermark", "freq", "bw", "params"])
+            if op == "open" and n_live < 9:
+                cls = "psk" if rng.random() < 0.5 else "raw"
+                fc = float(rng.choice(CARRIERS)) + float(rng.integers(-3, 4)) * 1e3
+                bw = float(rng.choice([30e3, 40e3, 15e3, 9e3])) if cls == "raw" else float(rng.choice([30e3, 40e3]))
+                self.open(cls, fc, bw, precise=bool(rng.integers(0, 2)))
+                n_live += 1
+            elif op == "close":
+                c = [i for i in self.live() if self.psd - i.opened_at >= 4]
+                if c:
+                    i = c[int(rng.integers(len(c)))]
+                    self.next_req += 1
+                    assert self.Lb.suscan_analyzer_close_async(self.an, i.handle, self.next_req)
+                    i.state = "closing"
+                    self.replies_expected += 1
+            elif op == "config":
+                c = [i for i in self.live("psk") if i.pending_cfg == 0]
+                if c:
+                    i = c[int(rng.integers(len(c)))]
+                    self.configure(i)
+                    i.last_touch = self.psd
+            elif op == "watermark":
+                c = self.live(anchors=True)
+                if c:
+                    i = c[int(rng.integers(len(c)))]
+                    self.next_req += 1
+                    assert self.Lb.suscan_analyzer_set_inspector_watermark_async(self.an, i.handle, int(rng.choice([0, 500, 1000, 4096])), self.next_req)
+                    self.replies_expected += 1
+            elif op in ("freq", "bw"):
+                c = [i for i in self.live("raw") if not getattr(i, "retune_pending", False)]
+                if c:
+                    i = c[int(rng.integers(len(c)))]
+                    if op == "freq":
+                        fc = float(rng.choice(CARRIERS)) + float(rng.integers(-3, 4)) * 1e3
+                        assert self.Lb.suscan_analyzer_set_inspector_freq_overridable(self.an, i.handle, fc)
+                        self.marker(i, ("freq", fc))
+                    else:
+                        bw = float(rng.choice([30e3, 40e3, 15e3, 9e3]))
+                        assert self.Lb.suscan_analyzer_set_inspector_bandwidth_overridable(self.an, i.handle, bw)
+                        self.marker(i, ("bw", bw))
+                    i.retune_pending = True
+                    i.last_touch = self.psd
+            elif op == "params" and self.params_toggles < 4:
+                p = suscan.AnalyzerParams.default()
+                p.detector_params.window_size = 4096
+                self.window = 3 if self.window == 4 else 4
+                p.detector_params.window = self.window
+                p.psd_update_int = L / FS                     # the block size stays: the inspectors must not notice
+                self.next_req += 1
+                assert self.Lb.suscan_analyzer_set_params_async(self.an, C.byref(p), self.next_req)
+                self.params_toggles += 1
+
+    # ---- messages ----------------------------------------------------------------------------------------------
+    def on_msg(self, t, ptr):
+        if t == suscan.MSG_PSD:
+            self.psd += 1
+            if self.psd >= K_END and not self.halted and self.replies >= self.replies_expected:
+                self.Lb.suscan_analyzer_req_halt(self.an)
+                self.halted = True
+            elif self.psd >= K_END + 40 and not self.halted:                 # replies missing: stop anyway, the test says which
+                self.Lb.suscan_analyzer_req_halt(self.an)
+                self.halted = True
+            else:
+                self.schedule()
+        elif t == suscan.MSG_INSPECTOR:
+            m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
+            self.replies += 1
+            if m.kind == suscan.KIND_OPEN:
+                i = self.by_req[m.req_id]
+                i.handle, i.opened_at, i.equiv_fs = m.handle, self.psd, m.equiv_fs
+                self.by_handle[m.handle] = i
+                self.by_iid[i.iid] = i
+                i.items.append(("ev", "open", self.psd, None))
+                i.state = "idset"
+                self.next_req += 1
+                assert self.Lb.suscan_analyzer_set_inspector_id_async(self.an, m.handle, i.iid, self.next_req)
+                self.replies_expected += 1
+                return
+            i = self.by_handle.get(m.handle)
+            assert i is not None, f"a reply of kind {m.kind} for an unknown handle {m.handle}"
+            if m.kind == suscan.KIND_SET_ID:
+                what = getattr(i, "markers", {}).pop(m.req_id, None)
+                if what is None:                                              # the id hand-shake after OPEN
+                    i.items.append(("ev", "id", self.psd, None))
+                    if i.cls == "psk":
+                        self.configure(i)
+                    i.state = "live"
+                    i.last_touch = self.psd
+                elif what[0] == "seek":
+                    self.seek_marked = True
+                    for j in self.by_handle.values():
+                        j.items.append(("ev", "seek", self.psd, None))
+                else:
+                    i.items.append(("ev", what[0], self.psd, what[1]))
+                    i.retune_pending = False
+            elif m.kind == suscan.KIND_SET_CONFIG:
+                i.pending_cfg -= 1
+                i.items.append(("ev", "config", self.psd, i.pending.pop(0)))
+            elif m.kind == suscan.KIND_CLOSE:
+                i.items.append(("ev", "close", self.psd, None))
+                i.state = "closed"
+            elif m.kind == suscan.KIND_SET_WATERMARK:
+                pass
+            else:
+                raise AssertionError(f"unexpected reply kind {m.kind} (req {m.req_id})")
+        elif t == suscan.MSG_SAMPLES:
+            m = C.cast(ptr, C.POINTER(suscan.SampleBatchMsg)).contents
+            v = np.ctypeslib.as_array(m.samples, shape=(m.sample_count * 2,)).copy()
+            if not np.all(np.isfinite(v)):
+                self.finite = False
+            i = self.by_iid.get(m.inspector_id)
+            if i is not None:
+                i.items.append(("s", v.view(np.complex64)))
+
+
+# ---- the oracle's replay ----------------------------------------------------------------------------------------------
+class Replay:
+    def __init__(self, sdo, x, channeliser):
+        self.sdo, self.x, self.channeliser = sdo, x, channeliser
+        self.cache = {}
+
+    def xin(self, p, nblocks, lead=0):
+        """the looping capture from block p on (`lead` samples before it), nblocks long"""
+        idx = (np.arange(-lead, nblocks * L) + (p % NLOOP) * L) % (NLOOP * L)
+        return self.x[idx]
+
+    def channel(self, p, fc, bw, precise, nblocks):
+        """the channel's sample stream when it is (re)built at block p"""
+        key = (p % NLOOP, fc, bw, precise, nblocks)
+        if key in self.cache:
+            return self.cache[key]
+        sdo = self.sdo
+        D = _pow2floor_D(bw)
+        if self.channeliser == "fir":
+            dp = sdo.fnor_to_dphase(-2 * fc / FS)
+            y = sdo.chan_feed(np.zeros(254, np.complex64), self.xin(p, nblocks), 0, sdo.chan_modulate_taps(sdo.lpf_design(255, bw / FS), dp), D, 0, dp)
+        else:
+            f0 = (2 * np.pi * fc / FS) % (2 * np.pi)
+            # a channel opened on a running tuner: the first window straddles the boundary, its partner is zero
+            y = sdo.specttuner_run_f32(self.xin(p, nblocks, lead=H), f0, 2 * np.pi * bw / FS, FS / (D * bw), precise=precise)
+        self.cache[key] = y
+        return y
+
+    def symbols(self, y, D, cfg):
+        sdo = self.sdo
+        order, loop_bw, gain = cfg
+        efs = FS / D
+        sps = efs / BAUD
+        a = sdo.agc_feed_bulk(sdo.agc_new(sdo.agc_params_from_tau(sps)), y)
+        z = sdo.costas_feed_bulk(sdo.costas_new(order, 0.0, min(2.0 / sps, 0.95), 3, 2 * loop_bw / efs), a)
+        return sdo.clock_feed_bulk(sdo.clock_new(gain, BAUD / efs), z)
+
+
+def _match(got, exp, blk, max_skip, tail_slack=0):
+    """got[: n - tail_slack] == exp[j * blk :][: ...] for some j <= max_skip (whole blocks that went out before the id was set)"""
+    n = got.size - tail_slack
+    if n <= 0:
+        return True
+    for j in range(max_skip + 1):
+        e = exp[j * blk: j * blk + n]
+        if e.size == n and np.array_equal(_bits(got[:n]), _bits(e)):
+            return True
+    return False
+
+
+def _diagnose(got, exp, blk):
+    """where a replay that should have matched stops matching: for the shifts tried, the first differing sample and how many
+    of the samples agree to 1e-5 (a wrong boundary agrees nowhere, a wrong start state agrees after a while)"""
+    out = []
+    for j in range(6):
+        e = exp[j * blk: j * blk + got.size]
+        n = min(e.size, got.size)
+        if n == 0:
+            continue
+        same = _bits(got[:n]) == _bits(e[:n])
+        close = np.abs(got[:n] - e[:n]) <= 1e-5 * max(float(np.max(np.abs(e[:n]))), 1e-30)
+        first = int(np.argmin(same)) if not same.all() else n
+        out.append(f"shift {j}: first bit difference at {first}/{n}, {100.0 * close.mean():.1f}% within 1e-5, last 100 close: {bool(close[-100:].all())}")
+    return "; ".join(out)
+
+
+def _verify(i, rp, G, fresh_anchor):
+    """every segment of inspector i's stream against the oracle; returns the number of samples compared"""
+    items = i.items
+    checked = 0
+    fc, bw = i.fc, i.bw
+    k = 0
+    # cut the item list at the seek marker (and forget the two blocks before it: the seek may have taken effect a boundary
+    # earlier than its marker, on this shard or another)
+    cut = next((n for n, it in enumerate(items) if it[0] == "ev" and it[1] == "seek"), None)
+    post_seek = cut is not None
+    if post_seek:
+        items = items[:cut]
+    segs = []                              # (start event, samples, end event)
+    cur_ev, cur = None, []
+    for it in items:
+        if it[0] == "s":
+            cur.append(it[1])
+        else:
+            if cur_ev is not None:
+                segs.append((cur_ev, cur, it))
+            cur_ev, cur = it, []
+    if cur_ev is not None:
+        segs.append((cur_ev, cur, None))
+    p_open = None
+    cfg = None
+    for ev, chunks, end in segs:
+        kind, at, payload = ev[1], ev[2], ev[3]
+        got = np.concatenate(chunks) if chunks else np.zeros(0, np.complex64)
+        D = _pow2floor_D(bw)
+        blk = L // D
+        if kind == "open":
+            p_open = at
+            continue                       # samples before the id is set carry id 0: not attributed
+        # (FFT channeliser: a set_freq / set_bandwidth that changes nothing leaves the channel open -- its stream, and a precise
+        # channel's residual NCO, run on from the block it was opened at; the FIR bank is rebuilt by any request)
+        extra_skip = 0
+        if kind in ("freq", "bw"):
+            same = (payload == fc) if kind == "freq" else (_pow2floor_D(payload) == D and payload == bw)
+            if same and rp.channeliser == "fft":
+                extra_skip = at - p_open + 2
+            else:
+                p_open = at
+            if kind == "freq":
+                fc = payload
+            else:
+                bw = payload
+                D = _pow2floor_D(bw)
+                blk = L // D
+        elif kind == "config":
+            cfg = payload
+        if kind == "close" or got.size == 0:
+            continue
+        # the tail of a segment that a silent request (freq / bw / seek) ends may already belong to what follows
+        # (two blocks of the widest channel -- the next configuration's samples that came before its marker -- and a
+        # watermark's flushed remainder)
+        slack_blocks = 2 if (end is None and post_seek) or (end is not None and end[1] in ("freq", "bw")) else 0
+        slack_samples = (2 * (L // 8) + 4096) if slack_blocks else 0
+        nblocks = got.size // blk + 8
+        ok = False
+        if i.cls == "raw":
+            if kind == "config":
+                continue
+            # (re)built at a boundary within the shard skew of where its reply was seen; up to three blocks gone under id 0
+            back = 3 if kind == "id" else 1
+            for p in range(p_open + 2, p_open - 4, -1):
+                if p < 0:
+                    continue
+                if fresh_anchor and i.anchor and rp.channeliser == "fft" and kind == "id":
+                    # the first inspector of its shard starts the tuner: no straddling window, half a channel block less
+                    f0 = (2 * np.pi * fc / FS) % (2 * np.pi)
+                    exp = rp.sdo.specttuner_run_f32(rp.xin(p, nblocks), f0, 2 * np.pi * bw / FS, FS / (D * bw), precise=i.precise)
+                    hb = W // D // 2
+                    cands = [exp[max(0, j * blk - hb):] for j in range(back + 1)]
+                    n_cmp = max(0, got.size - slack_samples)
+                    ok = any(c.size >= n_cmp and np.array_equal(_bits(got[:n_cmp]), _bits(c[:n_cmp])) for c in cands)
+                else:
+                    ok = _match(got, rp.channel(p, fc, bw, i.precise, nblocks + 4 + extra_skip), blk, back + 2 + extra_skip, slack_samples)
+                if ok:
+                    break
+            assert ok, (f"inspector {i.req} ({i.cls}, fc {fc}, bw {bw}, precise {i.precise}, shard {i.handle % G}): segment after `{kind}` at block ~{at} "
+                        f"({got.size} samples, ended by {end[1] if end else None}) matches no replay; events {[it[1:] for it in i.items if it[0] == 'ev']}; "
+                        f"against the replay from block {p_open}: {_diagnose(got, rp.channel(p_open, fc, bw, i.precise, nblocks + 4), blk)}")
+            checked += got.size
+        else:
+            if kind != "config" or cfg is None:
+                continue                   # a psk chain before its first configuration runs the library's defaults: not replayed
+            sps = FS / D / BAUD
+            nb = min(int(got.size * sps / blk) + 5, 70)         # symbols -> channel blocks, with room
+            if slack_blocks:
+                got = got[:max(0, got.size - int(slack_blocks * blk / sps) - 16)]
+            for p_cfg in range(at + 2, at - 4, -1):
+                if p_cfg < 0:
+                    continue
+                if rp.channeliser == "fir":
+                    exp = rp.symbols(rp.channel(p_cfg, fc, bw, i.precise, nb), D, cfg)
+                    ok = exp.size >= got.size and np.array_equal(_bits(got), _bits(exp[:got.size]))
+                else:
+                    for po in range(p_open + 2, p_open - 4, -1):
+                        if po < 0 or po > p_cfg:
+                            continue
+                        y = rp.channel(po, fc, bw, i.precise, nb + (p_cfg - po))[(p_cfg - po) * blk:]
+                        exp = rp.symbols(y, D, cfg)
+                        ok = exp.size >= got.size and np.array_equal(_bits(got), _bits(exp[:got.size]))
+                        if ok:
+                            break
+                if ok:
+                    break
+            assert ok, f"inspector {i.req} (psk, fc {fc}, bw {bw}, precise {i.precise}, cfg {cfg}, shard {i.handle % G}): {got.size} symbols after set_config at block ~{at} (open ~{p_open}) match no replay"
+            checked += got.size
+    return checked
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_request_schedules_replayed_by_the_oracle(tmp_path, sdo, monkeypatch, seed):
+    channeliser, devices = COMBOS[seed % 4]
+    monkeypatch.setenv("SUAMD_ANALYZER_CHANNELISER", channeliser)
+    if devices:
+        monkeypatch.setenv("SUAMD_DEVICES", devices)
+    G = len(devices.split(",")) if devices else 1
+    rng = np.random.default_rng(1000 + seed)
+    x = synth.psk_carriers(L * NLOOP, [2 * f / FS for f in CARRIERS], sps=int(FS / BAUD), order=4, seed=50 + seed, snr_db=25)
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    Lb, mq, an = _start(path, L, loop=True)
+    Lb.suscan_analyzer_set_throttle_async(an, 0, 0)            # full speed: requests land while blocks are in flight
+    fz = Fuzz(Lb, an, rng, G)
+    # one anchor per shard, opened before anything else: a raw, non-precise inspector that is never closed (it keeps its
+    # shard's tuner running, so every later channel of that shard opens on a running tuner)
+    for s in range(G):
+        fz.open("raw", CARRIERS[s] + 500.0 * s, 40e3, precise=False, anchor=True)
+    t0 = time.time()
+    seen = _pump(Lb, an, fz.on_msg, limit=400000)
+    took = time.time() - t0
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+    assert seen[-1] == suscan.MSG_HALT and took < 120, (seen[-3:], took)
+    assert fz.replies == fz.replies_expected, f"{fz.replies} replies for {fz.replies_expected} requests that have one"
+    assert fz.finite, "non-finite samples"
+    assert fz.seek_at is not None and fz.seek_marked
+    # the anchors sit on shards 0 .. G-1 (handles are dealt round the shards in request order)
+    assert sorted(i.handle % G for i in fz.by_handle.values() if i.anchor) == list(range(G))
+    rp = Replay(sdo, x, channeliser)
+    total, ninsp, ncfg = 0, 0, 0
+    for i in fz.by_handle.values():
+        n = _verify(i, rp, G, fresh_anchor=True)
+        total += n
+        ninsp += n > 0
+        ncfg += sum(1 for it in i.items if it[0] == "ev" and it[1] == "config")
+    assert ninsp >= 4 and total > 50000, (ninsp, total)        # the schedule really exercised something
