@@ -262,6 +262,11 @@ SUAMD_API SUSCOUNT suamd_chanbank_output_count(const suamd_chanbank_t *bank, SUS
 SUAMD_API SUBOOL suamd_chanbank_feed(suamd_chanbank_t *bank, const suamd_complex *d_x, SUSCOUNT len,
                                      suamd_complex *d_y, suamd_view yv, SUSCOUNT *n_out, void *stream);
 SUAMD_API SUBOOL suamd_chanbank_reset(suamd_chanbank_t *bank, void *stream);
+/* Launch plan only (same samples): the caller promises that nothing else runs on the device while this bank's feeds do
+ * (an offline pass; the stream pipeline's transform window).  Long feeds of the one- / two-channel stream kernel then run
+ * as one persistent workgroup per CU, which needs every CU's whole LDS and register file -- beside long-running kernels of
+ * other streams that shape takes up to 1.6 x longer, which is why it is not the default. */
+SUAMD_API SUBOOL suamd_chanbank_set_exclusive(suamd_chanbank_t *bank, SUBOOL exclusive);
 /* Many 1-channel banks (each its own centre frequency, decimation, taps and stream position) fed the SAME wideband
  * block in one launch -- the analyzer's inspectors, which all channelise the block the source just delivered
  * (suscan's inspector scheduler, Suscan/Analyzer.h:137-168).  d_y[i]: contiguous output row of bank i, n_out[i]

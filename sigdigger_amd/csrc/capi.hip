@@ -225,6 +225,7 @@ struct suamd_chanbank {
   uint32_t *d_dphase, *d_phase0;
   void     *d_hist[2];   // float2 [ntaps-1], ping-pong: d_hist[hist_cur] precedes the next block
   int       hist_cur;
+  int       exclusive = 0;   // suamd_chanbank_set_exclusive
 };
 
 struct suamd_costas_bank {
@@ -400,6 +401,13 @@ suamd_ctx_t *suamd_ctx_new(int device_ordinal)
 
 void suamd_ctx_destroy(suamd_ctx_t *ctx) { delete ctx; }
 int  suamd_ctx_device(const suamd_ctx_t *ctx) { return ctx ? ctx->device : -1; }
+
+SUBOOL suamd_chanbank_set_exclusive(suamd_chanbank_t *bank, SUBOOL exclusive)
+{
+  if (!bank) { set_err("null argument"); return SU_FALSE; }
+  bank->exclusive = exclusive ? 1 : 0;
+  return SU_TRUE;
+}
 
 SUBOOL suamd_psd_set_split_target(suamd_psd_t *psd, unsigned workgroups)
 {
@@ -749,6 +757,7 @@ SUBOOL suamd_chanbank_feed(suamd_chanbank_t *b, const suamd_complex *d_x, SUSCOU
   a.g = b->d_g; a.g2 = b->d_g2; a.dphase = b->d_dphase; a.phase0 = b->d_phase0;
   a.ntaps = (int)b->ntaps; a.nchan = (int)b->nchan; a.D = b->D;
   a.m_first = mf; a.n_out = (long long)no; a.y = d_y; a.yv = as_view(yv);
+  a.exclusive = b->exclusive;
   HIP_TRY(sdk::chan_feed(a, as_stream(stream)), SU_FALSE);
   b->hist_cur ^= 1;
   b->n_total += len;

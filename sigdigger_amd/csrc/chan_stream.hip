@@ -497,7 +497,11 @@ bool chan_stream_feed(const ChanFeedArgs &a, const void *g2, hipStream_t st, hip
   // (profiles/r04_fir_tile_shapes.txt).
   // Measured and NOT taken: one wavefront per SIMD with two pair-blocks per lane (four fma chains on the same taps) --
   // 35 k against 20 k ticks per 1024 outputs, the compiler's SGPR spill code in its loop.
+  // Round 5: a caller that HAS the chip to itself while the feed runs (suamd_chanbank_set_exclusive: the stream pipeline's
+  // transform window, an offline pass) gets the persistent shape for long feeds -- 16 Mi samples inside the window: 71.1
+  // against 75.0 us, 4 Mi: 25.6 against 22.1 (the independent tiles keep the short feeds).
   int nw = 2, tpw = 1;
+  if (a.exclusive && a.n_out >= (1ll << 19)) { nw = 8; tpw = 0; }
   if (const char *e = getenv("SUAMD_FIR_PAIR_NW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) { nw = v; tpw = 0; } }
   while (nw > 1 && a.n_out < 128ll * nw) nw >>= 1;
   while (nw > 1 && pbytes(nw) > 160 * 1024) nw >>= 1;

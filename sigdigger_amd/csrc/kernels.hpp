@@ -63,6 +63,7 @@ struct ChanFeedArgs {
   long long   n_out;
   void       *y;        // element (c, m) at y[c*yv.cs + m*yv.ms]
   View        yv;
+  int         exclusive = 0;   // the caller has the device to itself while this feed runs (suamd_chanbank_set_exclusive)
 };
 hipError_t chan_feed(const ChanFeedArgs &a, hipStream_t st);
 // chan_stream.hip: few channels as a stream (LDS-DMA ring); false = not this kernel's shape (nothing launched)

@@ -360,6 +360,10 @@ class ChannelBank:
         except Exception:
             pass
 
+    def set_exclusive(self, on=True):
+        """launch plan for a bank that has the device to itself while it is fed (suamd_chanbank_set_exclusive)"""
+        check(self.ctx.lib.suamd_chanbank_set_exclusive(self.h, 1 if on else 0), "suamd_chanbank_set_exclusive")
+
     def output_count(self, length):
         return int(self.ctx.lib.suamd_chanbank_output_count(self.h, int(length)))
 

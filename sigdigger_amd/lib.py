@@ -91,6 +91,7 @@ PROTOTYPES = {
     "suamd_chanbank_output_count": (U64, [VP, U64]),
     "suamd_chanbank_feed": (INT, [VP, VP, U64, VP, View, C.POINTER(U64), VP]),
     "suamd_chanbank_reset": (INT, [VP, VP]),
+    "suamd_chanbank_set_exclusive": (INT, [VP, INT]),
     "suamd_quad_demod_batch": (INT, [VP, VP, View, VP, View, UINT, U64, VP, INT, VP, VP]),
     "suamd_delayed_conj_bulk": (INT, [VP, VP, VP, U64, U64, VP]),
     "suamd_histogram_feed_bulk": (INT, [VP, VP, U64, INT, VP, VP]),

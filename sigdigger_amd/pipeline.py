@@ -171,6 +171,8 @@ class AnalyzerPipeline:
                 # inside a transform window): the channeliser plans its ONE round of workgroups for all their window
                 # slots (4 per CU) instead of 3/4 of the chip's
                 self.st.set_slots(4 * self.transform_cus)
+            if self.window and self.nchan and self.chan is not None:
+                self.chan.set_exclusive(True)      # inside the window the FIR bank's feed is alone on the chip too
         self.done = {}                         # (stage, block index) -> event
         self.marks_per_step = 1                # timing marks per step of a serial stage (step() with sub-ranges: SUB)
         self.ev = {}                           # per-stage timing events
