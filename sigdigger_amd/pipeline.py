@@ -179,9 +179,12 @@ class AnalyzerPipeline:
 
     # ---- helpers ---------------------------------------------------------------------------
     def main_stream(self):
-        """the stream the PSD and the channeliser run on: the CU-masked transform stream when the device is partitioned
-        (callers that order other work against a step -- the block broadcast, uploads -- make it current), else the
-        caller's current stream"""
+        """the stream the PSD and the channeliser run on: the slowest stage's stream inside a transform window, the CU-masked
+        transform stream when the device is partitioned, else the caller's current stream.  Callers that order other work
+        against a step -- the block broadcast, uploads -- make it current: a step then costs no cross-stream hop to and from
+        the caller's stream."""
+        if self.overlap and self.window and self.nchan:
+            return self.s_crit                 # transform window: the slowest stage's stream carries the transforms
         s = getattr(self, "s_main", None) if self.overlap else None
         return s if s is not None else torch.cuda.current_stream(self.dev)
 
