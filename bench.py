@@ -430,12 +430,13 @@ def run_workload(name, args, rank, world, dev, ctx, dist):
 
     def one_step(k, timed):
         cur = bufs[k & 1]
-        # rank 0's next block -> every GPU over xGMI, overlapped with this step's compute
-        work = pipeline.broadcast_block(bufs[(k + 1) & 1], dist)
-        pipe.step(cur, timed=timed)
+        # rank 0's next block -> every GPU over xGMI: started right BEHIND this block's PSD + channeliser (it must not take CUs
+        # from their one round of workgroups) and overlapped with the serial stages
+        work = []
+        pipe.step(cur, timed=timed, after_transforms=lambda: work.append(pipeline.broadcast_block(bufs[(k + 1) & 1], dist)))
         pipe.deliver()
-        if work is not None:
-            work.wait()
+        if work and work[0] is not None:
+            work[0].wait()
 
     def fence():
         pipe.flush()                  # (a transform window holds the last block's tail back until the next block comes)

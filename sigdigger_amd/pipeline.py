@@ -212,11 +212,19 @@ class AnalyzerPipeline:
         y, counts = self.st.feed(x, out=out, stream=st)           # the first block is one half window short
         return y[:, :counts[0]]
 
-    def step(self, x, timed=False, stream=None):
-        """One pass of the hot path over one resident IQ block x (complex64 [block_len])."""
+    def step(self, x, timed=False, stream=None, after_transforms=None):
+        """One pass of the hot path over one resident IQ block x (complex64 [block_len]).
+
+        after_transforms: called (no arguments) right behind the enqueue of the block's PSD + channeliser, with their stream
+        current -- the place to start work that must not run beside them and may run beside the recurrences (the broadcast of
+        the NEXT block to the other GPUs: ordered behind this block's transforms, it overlaps the serial stages)."""
         if not self.overlap:
             self.k += 1
-            return self._step_serial(x, timed, stream or torch.cuda.current_stream(self.dev))
+            out = self._step_serial(x, timed, stream or torch.cuda.current_stream(self.dev))
+            if after_transforms is not None:
+                after_transforms()
+            return out
+        self._after_transforms = after_transforms
         caller = torch.cuda.current_stream(self.dev)
         # Transform window: the PSD and the channeliser go onto the slowest stage's stream (carrier recovery; the clock stage
         # of an FSK chain) -- the one whose pause is the cost of the window: between its launches there is then no cross-queue hop (measured with the
@@ -255,6 +263,10 @@ class AnalyzerPipeline:
         if not self.nchan:
             self._psd_done = torch.cuda.Event()
             self._psd_done.record(st)
+            hook, self._after_transforms = getattr(self, "_after_transforms", None), None
+            if hook is not None:
+                with torch.cuda.stream(st):
+                    hook()
             return self.psd_out if self.do_psd else None
         cfg = self.bank_cfg
         psk = cfg.kind == "psk"
@@ -264,6 +276,10 @@ class AnalyzerPipeline:
         y = self._channelise(x, self.y[i], st)
         self._mark("fir1", st, timed)
         self._signal("fir", k, st)
+        hook, self._after_transforms = getattr(self, "_after_transforms", None), None
+        if hook is not None:
+            with torch.cuda.stream(st):
+                hook()
         if pend:
             # ... and the rest of block k-1 (and everything after it) runs behind them: the transforms have the chip to
             # themselves for their ~130 us, the slowest recurrence stream pauses for exactly that long
