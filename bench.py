@@ -997,6 +997,20 @@ def main():
                         extra.setdefault(w, {})[chn] = dict(entry, variant=label)
                     else:
                         extra[w] = entry
+            if args.block != 22 and args.workload == "c4":
+                # rounds 1-3 benched 4 Mi-sample blocks: the same workload at that block, so that the rounds stay comparable
+                try:
+                    a4 = argparse.Namespace(**vars(args))
+                    a4.block, a4.steps, a4.warmup = 22, max(20, min(80, args.steps)), 5
+                    c4_, L4, dt4, st4, fn4, pipe4 = run_workload("c4", a4, 0, 1, dev, ctx, None)
+                    k4 = getattr(pipe4, "kernel_ms", {})
+                    ck4 = next((k for k in CHANNELISER_KERNELS if k in k4), None)
+                    extra["c4_block_4Mi"] = {"block_samples": L4, "value_MSps": round(L4 * a4.steps / dt4 / 1e6, 3), "ms_per_step": round(dt4 / a4.steps * 1e3, 4),
+                                             "stage_ms": {k: round(v, 4) for k, v in st4.items()},
+                                             "roofline": fir_stage_roofline(len(fn4), c4_["D"], L4, k4[ck4]["per_step"], ck4, "c4", TIMING + " (in the pipeline)") if ck4 else None}
+                    del pipe4
+                except Exception as e:
+                    extra["c4_block_4Mi"] = {"error": repr(e)}
             extra["c1"] = run_c1(args)
             extra["capacity"] = run_capacity(args, dev, ctx)
             extra["c5"] = run_c5(args, dev, ctx)
