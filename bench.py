@@ -840,7 +840,14 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo" if share else "nccl", rank=rank, world_size=world)
     ctx = engine.Context(dev_index)
-    mg = multi_gpu_diagnostics(dist, rank, world, local_rank, dev_index, dev, 1 << args.block, share) if dist is not None else None
+    mg = None
+    if dist is not None:
+        try:
+            mg = multi_gpu_diagnostics(dist, rank, world, local_rank, dev_index, dev, 1 << args.block, share)
+        except SystemExit:
+            raise                                             # fewer ranks / GPUs than asked for: no line at all
+        except Exception as e:                                # a diagnostic that fails must not take the timed run with it
+            mg = {"error": repr(e)}
 
     cfg, L, dt, stages, fn_rank, pipe = run_workload(args.workload, args, rank, world, dev, ctx, dist)
 
