@@ -86,6 +86,11 @@ class AnalyzerPipeline:
     for buffer reuse, for the consumer of the buffer it overwrites), so consecutive blocks flow
     through the stages like a pipeline: steady-state cost per block = the slowest stage, not the
     sum.  The rest of the chip stays free for the PSD and FIR kernels of the next blocks.
+
+    Transform window (round 5, default): the TAIL of a block's serial stages -- the last carrier sub-range, the last two
+    clock sub-ranges, the hand-off copy of deliver() -- is only enqueued by the NEXT step(), behind that block's PSD and
+    channeliser, which get the idle chip.  A caller that wants the results of the last block it fed calls flush() (or
+    latest_symbols() / sync(), which do) before it waits for them.
     """
 
     NBUF = 3                                   # ring depth of every inter-stage buffer
