@@ -343,12 +343,20 @@ struct RowArena {
   struct Slab { char *base; size_t size, head; };
   std::vector<Slab> slabs;
   std::map<size_t, std::vector<void *>> spare;
-  // Rows come in power-of-two size classes (>= 4 KiB): a freed row serves any later request of its class, so an inspector
-  // that is resized back and forth (set_bandwidth: another decimation, another row length) reuses what it gave back instead
-  // of carving the slabs further.  The first slab is sized from the first request (32 MiB or 8 rows), later ones grow
+  // Rows come in size classes -- eight per octave (>= 4 KiB; at most 12.5 % over the request: the rows of hundreds of
+  // inspectors must stay within the 1.75 GiB span of suamd_specttuner_feed_rows_near) --: a freed row serves any later request
+  // of its class, so an inspector that is resized back and forth (set_bandwidth: another decimation, another row length)
+  // reuses what it gave back instead of carving the slabs further.  The first slab is sized from the first request (32 MiB or 8 rows), later ones grow
   // geometrically up to 256 MiB: one raw inspector on a small block does not reserve 256 MiB per shard any more.
   // Memory floor: slabs are only returned when the analyzer is destroyed (release()).
-  static size_t rounded(size_t bytes) { size_t c = 4096; while (c < bytes) c <<= 1; return c; }
+  static size_t rounded(size_t bytes)
+  {
+    if (bytes <= 4096) return 4096;
+    size_t p = 4096;
+    while ((p << 1) <= bytes) p <<= 1;                        // p <= bytes < 2 p
+    const size_t g = p >> 3;
+    return (bytes + g - 1) / g * g;
+  }
   void *take(size_t bytes)
   {
     bytes = rounded(bytes);
