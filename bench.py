@@ -63,21 +63,29 @@ def describe_long(cfg, channeliser):
     return f"{cfg['what']} {ch}, {cfg['rate']}"
 
 
-def make_block(n, fnor, sps_in, kind, device, seed=1234):
-    """Synthetic IQ block generated on the device: sum of rect-pulse QPSK / 2-FSK carriers + noise."""
+def make_block(n, fnor, sps_in, kind, device, seed=1234, stagger=True, ppm=100.0):
+    """Synthetic IQ block generated on the device: sum of rect-pulse QPSK / 2-FSK carriers + noise.
+
+    stagger (default): the band as it is -- every carrier has its own symbol timing (offset uniform in one symbol) and its own
+    baud (+- `ppm` parts per million around the nominal one), so the 64 Gardner detectors of a wavefront cross their half
+    cycles at unrelated instants.  stagger=False is rounds 1-5's block: every carrier's symbol boundaries at
+    the same samples -- the best case of the lock-step clock kernel -- kept as `value_aligned_clocks` beside the headline."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     t = torch.arange(n, device=device, dtype=torch.float64)
     x = torch.zeros(n, dtype=torch.complex64, device=device)
-    nsym = n // sps_in + 2
-    idx = (torch.arange(n, device=device) // sps_in)
+    nsym = n // sps_in + 4
+    rng = np.random.default_rng(seed + 77)
+    offs = rng.random(len(fnor)) * sps_in if stagger else np.zeros(len(fnor))
+    spss = sps_in * (1.0 + (2.0 * rng.random(len(fnor)) - 1.0) * ppm * 1e-6) if stagger else np.full(len(fnor), float(sps_in))
     for c, f in enumerate(fnor):
+        idx = torch.floor((t + float(offs[c])) / float(spss[c])).to(torch.int64)
         if kind == "psk":
             sym = torch.randint(0, 4, (nsym,), generator=g, device=device)
             ph = (np.pi / 2) * sym[idx].to(torch.float64) + np.pi / 4
         else:
             bits = torch.randint(0, 2, (nsym,), generator=g, device=device).to(torch.float64) * 2 - 1
-            ph = torch.cumsum(bits[idx] * (np.pi / sps_in), 0)
+            ph = torch.cumsum(bits[idx] * (np.pi / float(spss[c])), 0)
         ph = ph + (np.pi * float(f)) * t + 0.37 * c
         x += torch.polar(torch.ones_like(ph), ph).to(torch.complex64)
     noise = torch.randn(n, 2, generator=g, device=device, dtype=torch.float32) * 0.05
@@ -334,8 +342,8 @@ def pmc_traffic_in_run(args, kernels):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
             cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "4", "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--block", str(args.block),
-                   "--workload", args.workload, "--channeliser", args.channeliser]
+                   "--steps", "4", "--warmup", "1", "--lean", "--block", str(args.block),
+                   "--workload", args.workload, "--channeliser", args.channeliser] + (["--aligned"] if args.aligned else [])
             env = dict(os.environ, SUAMD_BENCH_CHILD="1", TMPDIR="/tmp")
             r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=240)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
@@ -410,7 +418,7 @@ def _cpu_model():
     return "unknown"
 
 
-def run_workload(name, args, rank, world, dev, ctx, dist):
+def run_workload(name, args, rank, world, dev, ctx, dist, stagger=True):
     cfg = WORKLOADS[name]
     L = 1 << args.block
     nch_total = cfg["per_gpu"] * world
@@ -423,7 +431,7 @@ def run_workload(name, args, rank, world, dev, ctx, dist):
     pipe = pipeline.AnalyzerPipeline(ctx, L, psd_size=cfg["psd"], psd_navg=navg, bank=bank, do_psd=(rank == 0))
     pipe.enable_delivery()       # the recovered symbols reach (pinned) host memory inside the timed region
 
-    bufs = [make_block(L, fn_all, cfg["sps_in"], cfg["kind"], dev, seed=1234),
+    bufs = [make_block(L, fn_all, cfg["sps_in"], cfg["kind"], dev, seed=1234, stagger=stagger),
             torch.empty(L, dtype=torch.complex64, device=dev)]
     bufs[1].copy_(bufs[0])
     torch.cuda.synchronize(dev)
@@ -568,26 +576,34 @@ def run_fir_stage_alone(cfg, dev, ctx, fn_rank, log2_block):
                     "the device to itself (suamd_specttuner_set_slots)"}
 
 
-def run_c5(args, dev, ctx, log2_file=30, N=8192, tile=256):
+def run_c5(args, dev, ctx, log2_file=30, N=8192, tile=256, rank=0, world=1, dist=None, steps=None, warm=1):
     """C5: panoramic-scanner sweep over a captured file resident in HBM -- every dwell is `tile` frames of
     N points averaged into one shifted-dB PSD message (PSDMessage.cpp:26-39 fused), fed to the SpectrumView
-    at the dwell's centre frequency (Panoramic/Scanner.cpp:239-293).  One step = one pass over the file."""
+    at the dwell's centre frequency (Panoramic/Scanner.cpp:239-293).  One step = one pass over the file.
+
+    world > 1: the dwells (frames of the sweep) are independent (Panoramic/Scanner.cpp:503-523 feeds them one by one into
+    bins that only they cover), so rank r takes the dwells d = r (mod world) -- its share of the capture resident in its
+    own HBM, its own SpectrumView over the whole range -- and NOTHING is exchanged ("C5 shards by frame").
+    The capture is fixed (2^log2_file samples over all ranks): strong scaling."""
     total = 1 << log2_file
-    x = torch.empty(total, dtype=torch.complex64, device=dev)
+    dwells_all = total // (N * tile)
+    mine = np.arange(rank, dwells_all, world)
+    dwells = len(mine)
+    share = dwells * N * tile
+    x = torch.empty(share, dtype=torch.complex64, device=dev)
     xr = torch.view_as_real(x)
     chunk = 1 << 26
-    g = torch.Generator(device=dev); g.manual_seed(5)
-    for o in range(0, total, chunk):
+    g = torch.Generator(device=dev); g.manual_seed(5 + rank)
+    for o in range(0, share, chunk):
         xr[o:o + chunk].normal_(generator=g)
-    dwells = total // (N * tile)
     psd = engine.PSD(ctx, N)                     # Blackman-Harris (the analyzer default)
     frames = torch.empty((dwells, N), dtype=torch.float32, device=dev)
     fs, rel = 20e6, 0.5
     view = engine.SpectrumView(ctx)
     f0 = 100e6
-    view.set_range(f0, f0 + dwells * fs * rel)
+    view.set_range(f0, f0 + dwells_all * fs * rel)
     view.set_fft(fs, rel)
-    centers = f0 + (np.arange(dwells) + 0.5) * fs * rel
+    centers = f0 + (mine + 0.5) * fs * rel
 
     def step(ev=None):
         if ev: ev[0].record()
@@ -596,27 +612,45 @@ def run_c5(args, dev, ctx, log2_file=30, N=8192, tile=256):
         view.feed_sweep(frames, centers)
         if ev: ev[2].record()
 
-    steps, warm = max(3, min(10, args.steps // 4)), 1
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    steps = steps or max(3, min(10, args.steps // 4))
     for _ in range(warm):
         step()
-    torch.cuda.synchronize(dev)
+    fence()
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    engine.kernel_timing_read()
+    engine.kernel_timing(True)
     t0 = time.perf_counter()
     for k in range(steps):
         step(evs[k])
-    torch.cuda.synchronize(dev)
+    fence()
     dt = time.perf_counter() - t0
+    engine.kernel_timing(False)
+    kt = engine.kernel_timing_read("psd_kernel")
+    engine.kernel_timing_read()
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
     psd_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
     view_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / steps
-    psd_bytes = 8.0 * total + 4.0 * N * dwells
+    k_ms = kt["sum_ms"] / kt["launches"] if kt["launches"] else psd_ms
+    psd_bytes = 8.0 * share + 4.0 * N * dwells
     del x
-    return {"workload": f"C5: panoramic sweep over a {total / 1e9:.2f} GS capture in HBM, {dwells} dwells x {tile} x "
-                        f"{N}-pt frames (Blackman-Harris, averaged, shift+dB fused) -> SpectrumView",
-            "value_MSps": round(total * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+    return {"workload": f"C5: panoramic sweep over a {total / 1e9:.2f} GS capture in HBM, {dwells_all} dwells x {tile} x "
+                        f"{N}-pt frames (Blackman-Harris, averaged, shift+dB fused) -> SpectrumView"
+                        + (f"; dwells sharded d mod {world}, no exchange" if world > 1 else ""),
+            "value_MSps": round(total * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "dwells_per_rank": dwells, "capture_samples": total,
             "stage_ms": {"psd": round(psd_ms, 4), "specview": round(view_ms, 4)},
-            "psd_roofline": {"bound": "hbm", "achieved": round(psd_bytes / (psd_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": round(psd_bytes / (psd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                             "algorithmic_bytes_per_launch": psd_bytes}}
+            "psd_roofline": {"kernel": "psd_kernel", "bound": "hbm", "achieved": round(psd_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(psd_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms": round(k_ms, 4),
+                             "algorithmic_bytes_per_launch": psd_bytes, "traffic": None,
+                             "timing": "kernel's own duration (dispatch-bound event pairs) on this rank"}}
 
 
 def run_c1(args):
@@ -767,6 +801,131 @@ def run_live_sharded(n_gpus, inspectors_per_gpu=64, nblocks=40, timeout_s=150):
         return {"error": repr(e)}
 
 
+def run_extra(args, dev, ctx, cfg, fn_rank, TIMING):
+    """The secondary workloads (`--extra`; detail file only): C2 both ways, C3, the default workload at rounds 1-3's 4 Mi block,
+    C1 through the live analyzer, the one-GPU capacity sweep, C5, the 64-heterogeneous-inspector live rate, the FIR stage alone."""
+    extra = {}
+    for w in ("c2", "c3"):
+        if w == args.workload:
+            continue
+        # C2 as BASELINE.json states it -- "1 PSK inspector, 255-tap LPF": the translate + 255-tap polyphase FIR --
+        # AND behind the FFT filter bank (what the live analyzer puts in front of an inspector); C3 on the default
+        variants = (("fir", "255-tap LPF (BASELINE.json configs[1])"), ("fft", "FFT filter bank")) if w == "c2" else ((args.channeliser, None),)
+        for chn, label in variants:
+            a2 = argparse.Namespace(**vars(args))
+            a2.steps, a2.warmup, a2.channeliser = max(5, min(20, args.steps // 4)), 3, chn
+            c2, L2, dt2, st2, fn2, pipe2 = run_workload(w, a2, 0, 1, dev, ctx, None)
+            k2 = getattr(pipe2, "kernel_ms", {})
+            ck = next((k for k in CHANNELISER_KERNELS if k in k2), None)
+            entry = {"workload": describe(c2, chn), "value_MSps": round(L2 * a2.steps / dt2 / 1e6, 3),
+                     "ms_per_step": round(dt2 / a2.steps * 1e3, 4),
+                     "stage_ms": {k: round(v, 4) for k, v in st2.items()},
+                     "config": {"channeliser": chn, "taps": c2["T"] if chn == "fir" else None,
+                                "channel_bins": 4096 // c2["D"] if chn == "fft" else None, "decimation": c2["D"],
+                                "inspectors": len(fn2), "block_samples": L2, "psd_size": c2["psd"]}}
+            if ck:
+                entry["roofline"] = fir_stage_roofline(len(fn2), c2["D"], L2, k2[ck]["per_step"], ck, w, TIMING + " (in the pipeline)")
+                entry["roofline"]["kernel_launches_ms"] = {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in k2.items()}
+                if "psd_kernel" in k2:
+                    pms = sum(k2[k]["per_step"] for k in ("psd_kernel", "psd_reduce_kernel") if k in k2)
+                    pb = 8.0 * L2 + 4.0 * c2["psd"] * (L2 // c2["psd"] // pipe2.navg)
+                    entry["psd_roofline"] = {"kernel_ms": round(pms, 4), "frac": round(pb / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": pb,
+                                             "psd_size": c2["psd"]}
+                try:                                  # the same kernel alone: this block size, and a 16 Mi-sample block
+                    lgs = sorted({int(np.log2(L2)), 22, 24})
+                    entry["roofline"]["fir_stage_alone"] = {}
+                    for lg in lgs:
+                        msa, ka = channeliser_alone(ctx, dev, fn2, c2["D"], c2["T"], chn, lg)
+                        if msa:
+                            entry["roofline"]["fir_stage_alone"][f"{(1 << lg) >> 20}Mi"] = fir_stage_roofline(
+                                len(fn2), c2["D"], 1 << lg, msa, ka, w, TIMING + " (the kernel alone, re-feeding one resident block)")
+                except Exception as e:
+                    entry["roofline"]["fir_stage_alone"] = {"error": repr(e)}
+            if not args.no_cpu_baseline:              # the same workload on this box's host cores (bounded sample)
+                try:
+                    entry["cpu_baseline"] = cpu_baseline(c2, (1 << 23) if w == "c2" else (1 << 25), fn2, os.cpu_count() or 1, chn)
+                except Exception as e:
+                    entry["cpu_baseline"] = {"error": repr(e)}
+            if label:
+                extra.setdefault(w, {})[chn] = dict(entry, variant=label)
+            else:
+                extra[w] = entry
+            del pipe2
+    if args.block != 22 and args.workload == "c4":
+        # rounds 1-3 benched 4 Mi-sample blocks: the same workload at that block, so that the rounds stay comparable
+        try:
+            a4 = argparse.Namespace(**vars(args))
+            a4.block, a4.steps, a4.warmup = 22, max(20, min(80, args.steps)), 5
+            c4_, L4, dt4, st4, fn4, pipe4 = run_workload("c4", a4, 0, 1, dev, ctx, None)
+            k4 = getattr(pipe4, "kernel_ms", {})
+            ck4 = next((k for k in CHANNELISER_KERNELS if k in k4), None)
+            extra["c4_block_4Mi"] = {"block_samples": L4, "value_MSps": round(L4 * a4.steps / dt4 / 1e6, 3), "ms_per_step": round(dt4 / a4.steps * 1e3, 4),
+                                     "stage_ms": {k: round(v, 4) for k, v in st4.items()},
+                                     "roofline": fir_stage_roofline(len(fn4), c4_["D"], L4, k4[ck4]["per_step"], ck4, "c4", TIMING + " (in the pipeline)") if ck4 else None}
+            del pipe4
+        except Exception as e:
+            extra["c4_block_4Mi"] = {"error": repr(e)}
+    extra["c1"] = run_c1(args)
+    extra["capacity"] = run_capacity(args, dev, ctx)
+    extra["c5"] = run_c5(args, dev, ctx)
+    try:                                              # the drop-in boundary itself, end to end (host thread, file source)
+        from sigdigger_amd.livebench import live_rate
+        extra["live64"] = live_rate(64, 60)
+    except Exception as e:                            # a secondary figure must not take the bench line down
+        extra["live64"] = {"error": repr(e)}
+    if args.channeliser == "fft" and cfg["kind"] == "psk":
+        try:
+            extra["fir_stage_alone"] = {f"{(1 << lg) >> 20}Mi": run_fir_stage_alone(cfg, dev, ctx, fn_rank, lg) for lg in sorted({args.block, 22, 24})}
+        except Exception as e:
+            extra["fir_stage_alone"] = {"error": repr(e)}
+    return extra
+
+
+def run_live_roofline(dev, log2_blocks=(21, 22), nblocks=24):
+    """The roofline of the FIR stage and of the PSD ON THE BOUNDARY: BASELINE.json configs[3]'s per-GPU slice -- 8192-pt PSD + 64
+    QPSK inspectors (Costas + Gardner) at 50 MS/s, decimation 64 -- through the suscan_analyzer_* C ABI (csrc/analyzer.cpp's own
+    worker thread, file source looping over a capture of staggered carriers), at the blocks a GUI lives with (25 fps x 50 MS/s =
+    2 Mi samples, include/AppConfig.h:35-36) and twice that.  Kernel durations: the library's dispatch-bound event pairs
+    (suamd_kernel_timing is process-global, so the worker thread's launches are timed like the harness's)."""
+    from sigdigger_amd.livebench import live_rate
+    cfg = WORKLOADS["c4"]
+    fs = 50e6
+    spacing = 700e3
+    out = {}
+    for lg in log2_blocks:
+        L = 1 << lg
+        try:
+            fn = (np.arange(64) - 32 + 0.5) * spacing * 2.0 / fs
+            cap = make_block(4 * L, fn, cfg["sps_in"], "psk", dev, seed=2468).cpu().numpy()
+            d = live_rate(64, nblocks, fs=int(fs), nfft=8192, block=L, uniform=dict(spacing=spacing, bw=300e3, baud=fs / cfg["sps_in"], costas_order=2),
+                          ktimer=True, capture=cap)
+            del cap
+            if "error" in d:
+                out[f"{L >> 20}Mi"] = d
+                continue
+            kern = d.get("kernels") or {}
+            ck = max((k for k in kern if k in CHANNELISER_KERNELS or k == "chan_fir_gang_kernel"), key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"], default=None)
+            e = {"block_samples": L, "value_MSps": d["value_MSps"], "worker_MSps": d["worker_MSps"], "ms_per_block": d["ms_per_block"]}
+            if ck:
+                per_block = kern[ck]["avg_ms"] * kern[ck]["launches"] / nblocks
+                nbytes = 8.0 * L + 8.0 * 64 * (L // 64)
+                e.update({"kernel": ck, "kernel_ms": round(per_block, 5), "launches_per_block": round(kern[ck]["launches"] / nblocks, 2),
+                          "algorithmic_bytes_per_launch": nbytes, "achieved": round(nbytes / (per_block * 1e-3) / 1e9, 1),
+                          "frac": round(nbytes / (per_block * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+            if "psd_kernel" in kern:
+                pms = sum(kern[k]["avg_ms"] * kern[k]["launches"] for k in ("psd_kernel", "psd_reduce_kernel") if k in kern) / nblocks
+                pb = 8.0 * L + 4.0 * 8192
+                e["psd"] = {"kernel_ms": round(pms, 5), "frac": round(pb / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": pb}
+            out[f"{L >> 20}Mi"] = e
+        except Exception as ex:                               # a secondary figure must not take the bench line down
+            out[f"{L >> 20}Mi"] = {"error": repr(ex)[:200]}
+    return out
+
+
+def _r(v, n=4):
+    return round(v, n) if isinstance(v, float) else v
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -776,23 +935,32 @@ def main():
     # metric wants both amortised
     ap.add_argument("--steps", type=int, default=150)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS) + ["c5"])
     ap.add_argument("--block", type=int, default=DEFAULT_LOG2_BLOCK, help="log2 of the IQ block length (samples)")
     ap.add_argument("--channeliser", default="fft", choices=("fft", "fir"),
                     help="fft: the FFT filter bank with su_specttuner's semantics (what the reference runs behind its "
                          "channels); fir: translate + 255-tap direct-form low-pass + decimate")
+    ap.add_argument("--aligned", action="store_true", help="rounds 1-5's input: every carrier's symbol boundaries at the same samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (c1, c2, c3, c5, capacity, live)")
+    ap.add_argument("--extra", action="store_true",
+                    help="also run the secondary workloads (c1, c2, c3, c5, capacity sweep, host-fed, FIR stage alone): their results go "
+                         "to the detail file only")
+    ap.add_argument("--no-extra", action="store_true", help="(the default since round 6; accepted for old command lines)")
     ap.add_argument("--no-pmc", action="store_true", help="do not count HBM traffic in child runs under rocprofv3 --pmc")
-    ap.add_argument("--pmc", action="store_true", help="count it even with --no-extra (the default run counts it)")
-    # 64 Mi samples: ~5 s of one core + ~0.6 s of all of them on the box's EPYC (the bounded sample of the CPU leg)
-    ap.add_argument("--cpu-samples", type=int, default=1 << 26)
+    ap.add_argument("--no-live", action="store_true", help="skip the live-analyzer roofline leg (the C++ boundary at 2 Mi / 4 Mi blocks)")
+    ap.add_argument("--lean", action="store_true", help="the headline workload only: no PMC children, live leg, aligned run, CPU baseline")
+    ap.add_argument("--detail", default=os.environ.get("SUAMD_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json")),
+                    help="where the long form goes (everything that is not in the one compact line)")
+    # 32 Mi samples: ~2.5 s of one core + ~0.3 s of all of them on the box's EPYC (the bounded sample of the CPU leg)
+    ap.add_argument("--cpu-samples", type=int, default=1 << 25)
     ap.add_argument("--live", action="store_true",
                     help="time the sharded live analyzer instead (one process, SUAMD_DEVICES=0..N-1; run WITHOUT torchrun): "
                          "the drop-in boundary itself on N GPUs")
     ap.add_argument("--isolated", action="store_true",
                     help="after the timed region also time the FIR and PSD kernels alone on an idle GPU")
     args = ap.parse_args()
+    if args.lean:
+        args.no_pmc = args.no_live = args.no_cpu_baseline = True
 
     if args.live:
         d = run_live_sharded(args.gpus, nblocks=max(20, min(200, args.steps)))
@@ -849,7 +1017,25 @@ def main():
         except Exception as e:                                # a diagnostic that fails must not take the timed run with it
             mg = {"error": repr(e)}
 
-    cfg, L, dt, stages, fn_rank, pipe = run_workload(args.workload, args, rank, world, dev, ctx, dist)
+    t_start = time.perf_counter()
+    if args.workload == "c5":
+        # BASELINE.json configs[4], sharded by frame (dwell d on rank d mod N; no exchange): a line of its own
+        d = run_c5(args, dev, ctx, rank=rank, world=world, dist=dist, steps=args.steps, warm=max(1, args.warmup))
+        if rank == 0:
+            out = {"metric": "MS/s complex IQ sustained (PSD + N inspectors)", "value": d["value_MSps"], "unit": "MS/s", "n_gpus": world,
+                   "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": d["ms_per_step"], "higher_is_better": True,
+                   "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "config": {"workload": d["workload"], "psd_size": 8192, "tile_frames": 256, "capture_samples": d["capture_samples"],
+                              "dwells_per_rank": d["dwells_per_rank"], "parallelism": f"dwells sharded d mod {world}, no exchange" if world > 1 else "single GPU"},
+                   "stage_ms": d["stage_ms"], "roofline": d["psd_roofline"]}
+            if mg is not None and "error" not in mg:
+                out["multi_gpu"] = {k: mg[k] for k in ("rccl_ranks_seen", "backend", "distinct_devices")}
+            print(json.dumps(out, separators=(",", ":")), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    cfg, L, dt, stages, fn_rank, pipe = run_workload(args.workload, args, rank, world, dev, ctx, dist, stagger=not args.aligned)
 
     if rank == 0:
         K = args.steps
@@ -876,39 +1062,70 @@ def main():
         kname = chan_k or ("stp_kernel" if fft_bank else "chan_fir_kernel")
         TIMING = ("dispatch-bound event pairs (hipExtLaunchKernelGGL start/stop events through suamd_kernel_timing): the "
                   "kernel's own duration, averaged over every launch of the timed region")
-        # HBM traffic of the two transform kernels, counted by this run's own PMC passes (N = 1 only; the committed profile's
-        # figure, labelled as such, when rocprofv3 is not on the box)
-        pmc = pmc_traffic_in_run(args, (kname, "psd_kernel", "psd_reduce_kernel")) if (world == 1 and not args.no_pmc and (args.pmc or not args.no_extra)) else {}
-        src_now = ("counted in this run: child runs of this command line under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
-                   "(separate passes, 4 steps), 2 x FETCH + WRITE per launch")
+        detail = {"argv": sys.argv[1:], "kernel_launches_ms": {k: {kk: _r(vv, 5) for kk, vv in v.items()} for k, v in kms.items()},
+                  "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+                  "stalled_samples_dropped": dict(getattr(pipe, "stalled_samples", {})),
+                  "stage_ms_unfiltered": {k: {kk: _r(vv) for kk, vv in v.items()} for k, v in getattr(pipe, "stage_raw", {}).items()},
+                  "timing": TIMING}
+
+        # ---- the legs beside the headline (N = 1 only) ----
+        aligned = None
+        if world == 1 and not args.lean and not args.aligned:
+            # rounds 1-5's input (every symbol clock aligned): the lock-step clock kernel's best case, beside the headline
+            try:
+                a2 = argparse.Namespace(**vars(args))
+                a2.steps, a2.warmup = max(4, min(10, args.steps)), 3
+                _, L2, dt2, st2, _, pipe2 = run_workload(args.workload, a2, 0, 1, dev, ctx, None, stagger=False)
+                aligned = {"value_MSps": round(L2 * a2.steps / dt2 / 1e6, 1), "steps": a2.steps, "stage_ms": {k: round(v, 3) for k, v in st2.items()}}
+                del pipe2
+            except Exception as e:
+                aligned = {"error": repr(e)[:200]}
+        live = None
+        if world == 1 and not args.no_live:
+            live = run_live_roofline(dev)
+            detail["live_roofline"] = live
+        # HBM traffic of the two transform kernels, counted by this run's own PMC passes (child runs of this command line;
+        # they run while this process times the CPU leg -- its GPU is idle then)
+        pmc = {}
+        pmc_thread = None
+        if world == 1 and not args.no_pmc:
+            import threading
+            box = {}
+            pmc_thread = threading.Thread(target=lambda: box.update(r=pmc_traffic_in_run(args, (kname, "psd_kernel", "psd_reduce_kernel"))))
+            pmc_thread.start()
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (rank 0's host cores)
+            cpu = cpu_baseline(cfg, args.cpu_samples, fn_rank, os.cpu_count() or 1, args.channeliser)
+            detail["cpu_baseline"] = dict(cpu)
+            ref = reference_loops()
+            if ref is not None:
+                detail["cpu_baseline"]["reference_loops"] = ref
+        if pmc_thread is not None:
+            pmc_thread.join()
+            pmc = box.get("r") or {}
+        detail["pmc_counters"] = pmc or None
+        src_now = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (4 steps), 2 x FETCH + WRITE"
         roof = fir_stage_roofline(C, D, L, fir_ms, kname, args.workload, TIMING if chan_k else "stream events around the stage",
                                   traffic=(pmc[kname]["hbm_bytes_per_launch"], src_now) if kname in pmc else None)
+        detail["roofline_long"] = dict(roof, kernel_description=KERNELS.get(kname, kname))
         psd_tr = (pmc["psd_kernel"]["hbm_bytes_per_launch"] + pmc.get("psd_reduce_kernel", {}).get("hbm_bytes_per_launch", 0)) if "psd_kernel" in pmc else None
-        if chan_k and "avg_without_worst" in kms[chan_k]:
-            # (an event pair now and then reads a millisecond on a 76 us kernel -- rocprofv3's trace of the same runs never shows
-            # such a launch; `frac` keeps it, this is the same figure without that one sample)
-            ww = kms[chan_k]["avg_without_worst"] * kms[chan_k]["launches"] / K
-            roof["frac_without_worst_sample"] = round(fir_bytes / (ww * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-            roof["worst_sample_ms"] = round(kms[chan_k]["worst_sample_ms"], 4)
-        roof.update({
-            "psd_kernel": {"achieved": round(psd_bytes / (psd_ms * 1e-3) / 1e9, 2) if psd_ms else None,
-                           "frac": round(psd_bytes / (psd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if psd_ms else None,
-                           "kernel_ms": round(psd_ms, 4) if psd_ms else None,
-                           "algorithmic_bytes_per_launch": psd_bytes,
-                           "traffic": psd_tr, "traffic_over_algorithmic": round(psd_tr / psd_bytes, 4) if psd_tr else None},
-            "pmc_counters": pmc or None,
-            "kernel_launches_ms": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kms.items()},
-            "stage_ms": {k: round(v, 4) for k, v in stages.items()},
-            "stalled_samples_dropped": dict(getattr(pipe, "stalled_samples", {})),
-            "stage_ms_unfiltered": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
-                                    for k, v in getattr(pipe, "stage_raw", {}).items()},
-            "note": "recurrence stages (AGC/Costas/Gardner) are one-lane-per-channel and latency-bound; "
-                    "they are reported in stage_ms, not against a roofline (SURVEY.md section 8d)",
-        })
+        roof_c = {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "kernel_ms", "algorithmic_bytes_per_launch",
+                                        "traffic", "traffic_over_algorithmic")}
+        roof_c["traffic_source"] = (roof.get("traffic_source") or "")[:110] or None
+        roof_c["timing"] = "kernel's own duration (dispatch-bound event pairs), mean over every launch of the timed region"
+        if chan_k:
+            roof_c["kernel_ms_min_max"] = [round(kms[chan_k]["min"], 4), round(kms[chan_k]["max"], 4)]
+        roof_c["psd"] = {"kernel": "psd_kernel" + ("+psd_reduce_kernel" if "psd_reduce_kernel" in kms else ""),
+                         "frac": round(psd_bytes / (psd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if psd_ms else None,
+                         "kernel_ms": round(psd_ms, 4) if psd_ms else None, "algorithmic_bytes_per_launch": psd_bytes,
+                         "traffic_over_algorithmic": round(psd_tr / psd_bytes, 4) if psd_tr else None}
+        if live:
+            # the same two kernels inside the C++ live analyzer (the drop-in boundary), at a GUI's block lengths
+            roof_c["live_analyzer"] = {k: ({kk: v.get(kk) for kk in ("kernel", "frac", "kernel_ms", "value_MSps")} | ({"psd_frac": v["psd"]["frac"]} if "psd" in v else {}))
+                                       if "error" not in v else {"error": v["error"][:80]} for k, v in live.items()}
         if not fft_bank and fir_ms:
-            roof["fp32_vector"] = {"peak_tflops": FP32_PEAK_TFLOPS,
-                                   "flops_as_built": fir_flops_built, "frac_as_built": round(fir_flops_built / (fir_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
-                                   "flops_survey_8d": fir_flops_survey, "frac_survey_8d": round(fir_flops_survey / (fir_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
+            roof_c["fp32_vector"] = {"peak_tflops": FP32_PEAK_TFLOPS, "frac_as_built": round(fir_flops_built / (fir_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                                     "frac_survey_8d": round(fir_flops_survey / (fir_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
         out = {
             "metric": "MS/s complex IQ sustained (PSD + N inspectors)", "value": round(value, 3), "unit": "MS/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 4),
@@ -921,10 +1138,15 @@ def main():
                        "parallelism": f"channel-sharded x{world}, RCCL broadcast of the IQ block" if world > 1
                        else "single GPU",
                        "channeliser": args.channeliser,
-                       "schedule": "transform window" if pipe.window else "free-running streams"},
+                       "schedule": "transform window" if pipe.window else "free-running streams",
+                       "symbol_clocks": "aligned (rounds 1-5's input)" if args.aligned else "staggered: per-carrier timing offset, +-100 ppm baud"},
             "aggregate_inspector_MSps": round(value * cfg["per_gpu"] * world, 1),
-            "roofline": roof,
+            "stage_ms": {k: round(v, 3) for k, v in stages.items()},
+            "roofline": roof_c,
         }
+        if aligned is not None:
+            out["value_aligned_clocks"] = aligned.get("value_MSps")
+            detail["aligned_clocks"] = aligned
         if args.isolated:
             # the same launches on an otherwise idle chip (in the pipeline they share the GPU with the
             # AGC / Costas / Gardner kernels of neighbouring blocks)
@@ -946,107 +1168,33 @@ def main():
                 torch.cuda.synchronize(dev)
                 iso[name + "_ms"] = round(e0.elapsed_time(e1) / 10, 4)
             iso["fir_hbm_frac"] = round(fir_bytes / (iso["fir_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-            if fft_bank:                                       # the direct-form bank on the same block, for comparison
-                taps = ctx.lpf_design(T, 0.75 / D)
-                direct = engine.ChannelBank(ctx, fn_rank, D, taps)
-                direct.feed(x, out=pipe.y[1])
-                torch.cuda.synchronize(dev)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(10):
-                    direct.feed(x, out=pipe.y[1])
-                e1.record()
-                torch.cuda.synchronize(dev)
-                iso["direct_fir_ms"] = round(e0.elapsed_time(e1) / 10, 4)
-                iso["direct_fir_hbm_frac"] = round(fir_bytes / (iso["direct_fir_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             if "psd_ms" in iso:
                 iso["psd_hbm_frac"] = round(psd_bytes / (iso["psd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-            roof["isolated"] = iso
-        if world == 1 and not args.no_extra:
-            extra = {}
-            for w in ("c2", "c3"):
-                if w == args.workload:
-                    continue
-                # C2 as BASELINE.json states it -- "1 PSK inspector, 255-tap LPF": the translate + 255-tap polyphase FIR --
-                # AND behind the FFT filter bank (what the live analyzer puts in front of an inspector); C3 on the default
-                variants = (("fir", "255-tap LPF (BASELINE.json configs[1])"), ("fft", "FFT filter bank")) if w == "c2" else ((args.channeliser, None),)
-                for chn, label in variants:
-                    a2 = argparse.Namespace(**vars(args))
-                    a2.steps, a2.warmup, a2.channeliser = max(5, min(20, args.steps // 4)), 3, chn
-                    c2, L2, dt2, st2, fn2, pipe2 = run_workload(w, a2, 0, 1, dev, ctx, None)
-                    k2 = getattr(pipe2, "kernel_ms", {})
-                    ck = next((k for k in CHANNELISER_KERNELS if k in k2), None)
-                    entry = {"workload": describe(c2, chn), "value_MSps": round(L2 * a2.steps / dt2 / 1e6, 3),
-                             "ms_per_step": round(dt2 / a2.steps * 1e3, 4),
-                             "stage_ms": {k: round(v, 4) for k, v in st2.items()},
-                             "config": {"channeliser": chn, "taps": c2["T"] if chn == "fir" else None,
-                                        "channel_bins": 4096 // c2["D"] if chn == "fft" else None, "decimation": c2["D"],
-                                        "inspectors": len(fn2), "block_samples": L2, "psd_size": c2["psd"]}}
-                    if ck:
-                        entry["roofline"] = fir_stage_roofline(len(fn2), c2["D"], L2, k2[ck]["per_step"], ck, w, TIMING + " (in the pipeline)")
-                        entry["roofline"]["kernel_launches_ms"] = {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in k2.items()}
-                        try:                                  # the same kernel alone: this block size, and a 16 Mi-sample block
-                            lgs = sorted({int(np.log2(L2)), 22, 24})
-                            entry["roofline"]["fir_stage_alone"] = {}
-                            for lg in lgs:
-                                msa, ka = channeliser_alone(ctx, dev, fn2, c2["D"], c2["T"], chn, lg)
-                                if msa:
-                                    entry["roofline"]["fir_stage_alone"][f"{(1 << lg) >> 20}Mi"] = fir_stage_roofline(
-                                        len(fn2), c2["D"], 1 << lg, msa, ka, w, TIMING + " (the kernel alone, re-feeding one resident block)")
-                        except Exception as e:
-                            entry["roofline"]["fir_stage_alone"] = {"error": repr(e)}
-                    if not args.no_cpu_baseline:              # the same workload on this box's host cores (bounded sample)
-                        try:
-                            entry["cpu_baseline"] = cpu_baseline(c2, (1 << 23) if w == "c2" else (1 << 25), fn2, os.cpu_count() or 1, chn)
-                        except Exception as e:
-                            entry["cpu_baseline"] = {"error": repr(e)}
-                    if label:
-                        extra.setdefault(w, {})[chn] = dict(entry, variant=label)
-                    else:
-                        extra[w] = entry
-            if args.block != 22 and args.workload == "c4":
-                # rounds 1-3 benched 4 Mi-sample blocks: the same workload at that block, so that the rounds stay comparable
-                try:
-                    a4 = argparse.Namespace(**vars(args))
-                    a4.block, a4.steps, a4.warmup = 22, max(20, min(80, args.steps)), 5
-                    c4_, L4, dt4, st4, fn4, pipe4 = run_workload("c4", a4, 0, 1, dev, ctx, None)
-                    k4 = getattr(pipe4, "kernel_ms", {})
-                    ck4 = next((k for k in CHANNELISER_KERNELS if k in k4), None)
-                    extra["c4_block_4Mi"] = {"block_samples": L4, "value_MSps": round(L4 * a4.steps / dt4 / 1e6, 3), "ms_per_step": round(dt4 / a4.steps * 1e3, 4),
-                                             "stage_ms": {k: round(v, 4) for k, v in st4.items()},
-                                             "roofline": fir_stage_roofline(len(fn4), c4_["D"], L4, k4[ck4]["per_step"], ck4, "c4", TIMING + " (in the pipeline)") if ck4 else None}
-                    del pipe4
-                except Exception as e:
-                    extra["c4_block_4Mi"] = {"error": repr(e)}
-            extra["c1"] = run_c1(args)
-            extra["capacity"] = run_capacity(args, dev, ctx)
-            extra["c5"] = run_c5(args, dev, ctx)
-            try:                                              # the drop-in boundary itself, end to end (host thread, file source)
-                from sigdigger_amd.livebench import live_rate
-                extra["live64"] = live_rate(64, 60)
-            except Exception as e:                            # a secondary figure must not take the bench line down
-                extra["live64"] = {"error": repr(e)}
-            out["host_fed"] = run_host_fed(args.workload, args, dev, ctx)
-            if args.channeliser == "fft" and cfg["kind"] == "psk":
-                try:
-                    out["roofline"]["fir_stage_alone"] = {f"{(1 << lg) >> 20}Mi": run_fir_stage_alone(cfg, dev, ctx, fn_rank, lg)
-                                                          for lg in sorted({args.block, 22, 24})}
-                except Exception as e:
-                    out["roofline"]["fir_stage_alone"] = {"error": repr(e)}
-            out["other_workloads"] = extra
+            detail["isolated"] = iso
+        if world == 1 and args.extra:
+            detail["other_workloads"] = run_extra(args, dev, ctx, cfg, fn_rank, TIMING)
+            detail["host_fed"] = run_host_fed(args.workload, args, dev, ctx)
+            ow = detail["other_workloads"]
+            out["other_workloads"] = {k: (v.get("value_MSps") if "value_MSps" in v else {kk: vv.get("value_MSps") for kk, vv in v.items() if isinstance(vv, dict) and "value_MSps" in vv})
+                                      for k, v in ow.items() if isinstance(v, dict) and k in ("c2", "c3", "c5", "c4_block_4Mi")}
         if mg is not None:
-            out["multi_gpu"] = mg
+            detail["multi_gpu"] = mg
+            out["multi_gpu"] = mg if "error" in mg else {
+                "rccl_ranks_seen": mg["rccl_ranks_seen"], "backend": mg["backend"], "distinct_devices": mg["distinct_devices"],
+                "bcast_block_bytes": mg["bcast_block_bytes"], "bcast_ms": mg["bcast_ms"], "bcast_GBps": mg["bcast_GBps"],
+                "ranks": [{"rank": g["rank"], "device": g["device"], "pci": g["pci"]} for g in mg["ranks"]]}
         if world > 1 and os.environ.get("SUAMD_BENCH_LIVE_SHARDED", "1") != "0" and not share:
             # the curve of the drop-in itself: the C++ analyzer sharded over the same N GPUs (the other ranks idle at the
             # barrier below; their GPUs are free)
-            out["live_sharded_analyzer"] = run_live_sharded(world)
-        if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (rank 0's host cores)
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_samples, fn_rank, os.cpu_count() or 1, args.channeliser)
-            ref = reference_loops()
-            if ref is not None:
-                out["cpu_baseline"]["reference_loops"] = ref
-        # the long descriptions last: the driver's parsed copy of the line is cut after a few kB
-        out["notes"] = {
+            ls = run_live_sharded(world)
+            detail["live_sharded_analyzer"] = ls
+            out["live_sharded_analyzer"] = {k: ls.get(k) for k in ("value_MSps", "worker_MSps", "inspectors", "devices", "block_exchange", "error") if k in ls}
+        if cpu is not None:
+            out["cpu_baseline"] = {"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
+                                   "value_1thread": cpu["value_1thread"], "cpu_model": cpu["cpu_model"],
+                                   "sample": f"{args.cpu_samples} complex samples of the same pipeline (PSD + {'FFT filter bank' if fft_bank else 'FIR bank'} + "
+                                             f"{C} chains) through oracle/sdo.c -O3 -march=native (a restatement, not upstream sigutils)"}
+        detail["notes"] = {
             "workload": describe_long(cfg, args.channeliser), "kernel": KERNELS.get(kname, kname),
             "value_definition": "rate of the IQ stream: every rank consumes the same broadcast block and runs its shard of the "
                                 "inspectors on it; symbols are copied to pinned host memory inside the timed region.  (Round 1 "
@@ -1056,8 +1204,19 @@ def main():
                         "Costas one sub-range from its end, Gardner two) and the block's PSD + channeliser run on the idle chip, on "
                         "the slowest stage's stream; SUAMD_PIPELINE_WINDOW=0 restores round 4's free-running streams" if pipe.window else
                         "free-running streams (round 4)"}
+        out["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
+        try:
+            with open(args.detail, "w") as f:
+                json.dump(dict(out, detail=detail), f, indent=1)
+            out["detail_file"] = os.path.relpath(args.detail, ROOT)
+        except OSError as e:
+            out["detail_file"] = None
+            print(f"# bench.py: detail file not written: {e}", file=sys.stderr)
         assert out["n_gpus"] == args.gpus == world, (out["n_gpus"], args.gpus, world)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out, separators=(",", ":"))
+        # ONE compact line (the driver parses the last line that starts with "{"; round 5's 23 KB line was not parsed)
+        assert len(line) < 4096, len(line)
+        print(line, flush=True)
 
     if dist is not None:
         dist.barrier()

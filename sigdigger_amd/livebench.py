@@ -12,13 +12,27 @@ import numpy as np
 from . import suscan
 
 
-def live_rate(n_inspectors=64, nblocks=40, fs=50_000_000, nfft=8192, block=1 << 21, timeout_s=60.0, cls=b"psk"):
+LIVE_KERNELS = ("stp_kernel", "stw_kernel", "st_kernel", "chan_fir_gang_kernel", "psd_kernel", "psd_reduce_kernel")
+
+
+def live_rate(n_inspectors=64, nblocks=40, fs=50_000_000, nfft=8192, block=1 << 21, timeout_s=60.0, cls=b"psk", uniform=None,
+              ktimer=False, capture=None):
+    """uniform: None = 64 inspectors that share nothing (below); dict(spacing=Hz, bw=Hz, baud=Hz, costas_order=n) = every
+    inspector the same kind on its own carrier -- BASELINE.json configs[3]'s per-GPU slice through the boundary (bw 300 kHz at
+    50 MS/s: decimation 64, 64-bin channels of the FFT filter bank).  ktimer: the library's kernel timer
+    (suamd_kernel_timing, process-global) runs over the timed blocks and the result carries `kernels` = {name: {launches,
+    avg_ms, min_ms, max_ms}} for the channeliser and PSD kernels the analyzer's worker launched.  capture: the IQ the file
+    source loops over (default: four blocks of noise)."""
     Lb = suscan.load()
     d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     path = os.path.join(d, "cap.raw")
     try:
         rng = np.random.default_rng(1)
-        (0.1 * rng.standard_normal(2 * block * 4).astype(np.float32)).tofile(path)          # 4 blocks, looped
+        if capture is not None:                                   # the caller's IQ (complex64, a whole number of blocks), looped
+            assert capture.dtype == np.complex64 and capture.size % block == 0
+            capture.tofile(path)
+        else:
+            (0.1 * rng.standard_normal(2 * block * 4).astype(np.float32)).tofile(path)      # 4 blocks of noise, looped
         mq = suscan.MQ()
         assert Lb.suscan_mq_init(C.byref(mq))
         cfg = Lb.suscan_source_config_new(b"file", 1)
@@ -34,9 +48,13 @@ def live_rate(n_inspectors=64, nblocks=40, fs=50_000_000, nfft=8192, block=1 << 
         Lb.suscan_source_config_destroy(cfg)
         Lb.suscan_analyzer_set_throttle_async(an, 0, 0)
         spacing = min(300e3, 0.9 * fs / max(n_inspectors, 1))                               # every channel inside +-fs/2
+        if uniform:
+            spacing = float(uniform["spacing"])
         for k in range(n_inspectors):
             fc = (k - n_inspectors / 2 + 0.5) * spacing
             bw = (100e3 + 10e3 * (k % 7)) * spacing / 300e3
+            if uniform:
+                bw = float(uniform["bw"])
             ch = suscan.Channel(fc=float(fc), f_lo=float(fc - bw / 2), f_hi=float(fc + bw / 2), bw=float(bw), ft=100e6)
             assert Lb.suscan_analyzer_open_ex_async(an, cls, C.byref(ch), 1, -1, 1000 + k)
         st = {"psd": 0, "sym": 0, "t0": None, "cfg": 0, "result": None}
@@ -54,27 +72,50 @@ def live_rate(n_inspectors=64, nblocks=40, fs=50_000_000, nfft=8192, block=1 << 
                 if m.kind == suscan.KIND_OPEN:
                     k = m.req_id - 1000
                     c2 = Lb.suscan_config_dup(m.config)
-                    Lb.suscan_config_set_integer(c2, b"afc.costas-order", 1 + k % 3)
-                    Lb.suscan_config_set_float(c2, b"afc.loop-bw", 50.0 + 5 * (k % 11))
-                    Lb.suscan_config_set_integer(c2, b"clock.type", 1)
-                    Lb.suscan_config_set_float(c2, b"clock.baud", (20e3 + 1e3 * (k % 13)) * spacing / 300e3)
+                    if uniform:
+                        Lb.suscan_config_set_integer(c2, b"afc.costas-order", int(uniform.get("costas_order", 2)))
+                        Lb.suscan_config_set_float(c2, b"afc.loop-bw", float(uniform.get("loop_bw", 100.0)))
+                        Lb.suscan_config_set_integer(c2, b"clock.type", 1)
+                        Lb.suscan_config_set_float(c2, b"clock.baud", float(uniform["baud"]))
+                    else:
+                        Lb.suscan_config_set_integer(c2, b"afc.costas-order", 1 + k % 3)
+                        Lb.suscan_config_set_float(c2, b"afc.loop-bw", 50.0 + 5 * (k % 11))
+                        Lb.suscan_config_set_integer(c2, b"clock.type", 1)
+                        Lb.suscan_config_set_float(c2, b"clock.baud", (20e3 + 1e3 * (k % 13)) * spacing / 300e3)
                     Lb.suscan_analyzer_set_inspector_config_async(an, m.handle, c2, 2000 + k)
                     Lb.suscan_config_destroy(c2)
                 elif m.kind == suscan.KIND_SET_CONFIG:
                     st["cfg"] += 1
             elif t.value == suscan.MSG_PSD:
                 if st["cfg"] == n_inspectors and st["t0"] is None:
+                    st["warm"] = st.get("warm", 0) + 1
+                    if st["warm"] < 4:                            # the first blocks behind the last SET_CONFIG build chains
+                        Lb.suscan_analyzer_dispose_message(t.value, ptr)
+                        continue
                     st["t0"], st["psd"] = time.time(), 0
+                    if ktimer:
+                        _ktimer_read(None)
+                        suscan._l.load().suamd_kernel_timing(1)
                 st["psd"] += 1
                 if st["t0"] is not None and st["psd"] == nblocks and st["result"] is None:
                     dt = time.time() - st["t0"]
                     worker = float(Lb.suscan_analyzer_get_measured_samp_rate(an))   # the worker's own rate (EMA over blocks): this
+                    kern = None
+                    if ktimer:
+                        suscan._l.load().suamd_kernel_timing(0)
+                        kern = {}
+                        for kn in LIVE_KERNELS:
+                            r = _ktimer_read(kn)
+                            if r["launches"]:
+                                kern[kn] = {"launches": r["launches"], "avg_ms": r["sum_ms"] / r["launches"], "min_ms": r["min_ms"], "max_ms": r["max_ms"]}
+                        _ktimer_read(None)
                     st["result"] = {"workload": f"live analyzer through the suscan ABI: {nfft}-pt PSD + {n_inspectors} heterogeneous PSK "
                                                 f"inspectors (own carrier / bandwidth / baud / Costas order / loop bandwidth), file source, "
                                                 f"{block}-sample blocks at {fs / 1e6:g} MS/s",
                                     "value_MSps": round(nblocks * block / dt / 1e6, 3), "ms_per_block": round(dt / nblocks * 1e3, 4),
                                     "symbols_Msps": round(st["sym"] / dt / 1e6, 3), "inspectors": n_inspectors, "blocks": nblocks,
                                     "worker_MSps": round(worker / 1e6, 3), "psd_frames_per_s": round(nblocks / dt, 1),
+                                    "block_samples": block, "kernels": kern,
                                     "note": "value_MSps is timed at this Python consumer (one message per inspector and block: it "
                                             "becomes the limit beyond ~100 inspectors); worker_MSps is suscan_analyzer_get_measured_samp_rate"}
                     Lb.suscan_analyzer_req_halt(an)
@@ -92,6 +133,12 @@ def live_rate(n_inspectors=64, nblocks=40, fs=50_000_000, nfft=8192, block=1 << 
         return st["result"] or {"error": "analyzer halted before the measurement finished"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def _ktimer_read(kernel):
+    s, lo, hi, n = C.c_double(), C.c_double(), C.c_double(), C.c_uint()
+    suscan._l.load().suamd_kernel_timing_read(kernel.encode() if kernel else None, C.byref(s), C.byref(lo), C.byref(hi), C.byref(n))
+    return {"sum_ms": s.value, "min_ms": lo.value, "max_ms": hi.value, "launches": n.value}
 
 
 def live_psd_only(fs=2_400_000, nfft=8192, interval_s=0.04, nblocks=400, timeout_s=60.0):

@@ -30,7 +30,7 @@ def _last_json(out):
 
 
 def test_single_gpu_line():
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--no-extra", "--cpu-samples", "65536"],
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--no-pmc", "--no-live", "--cpu-samples", "65536"],
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
@@ -44,6 +44,58 @@ def test_single_gpu_line():
     assert abs(d["value"] - d["config"]["block_samples"] * 4 / (d["ms_per_step"] * 4e-3) / 1e6) < 0.01 * d["value"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+def test_the_drivers_exact_command_prints_one_compact_parseable_line(tmp_path):
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` -- the command the driver runs at round end, nothing added: exactly
+    one line starting with "{", under 4 KB (round 5's 23 KB line was not parsed: BENCH_r05.json parsed == null), carrying the
+    contract's keys plus `roofline` (with PMC traffic counted in the run and the live analyzer's own figures) and `cpu_baseline`;
+    the long form goes to the detail file the line names."""
+    env = dict(os.environ, SUAMD_BENCH_DETAIL=str(tmp_path / "detail.json"))
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and r.stdout.rstrip().endswith(lines[0]), r.stdout[-1000:]
+    assert len(lines[0]) < 4096, len(lines[0])
+    d = json.loads(lines[0])
+    assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5
+    roof = d["roofline"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "kernel_ms", "algorithmic_bytes_per_launch", "traffic", "traffic_over_algorithmic"):
+        assert k in roof, k
+    assert roof["bound"] == "hbm" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
+    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["kernel_ms"] * 1e-3) / 1e9) < 0.01 * roof["achieved"]
+    # the kernel's duration fits the step it is part of, and the step fits the run
+    assert roof["kernel_ms"] < d["ms_per_step"] and d["ms_per_step"] * 20e-3 < d["bench_wall_s"]
+    assert "psd" in roof and roof["psd"]["frac"] > 0.05
+    live = roof["live_analyzer"]                                 # the same kernels inside the C++ analyzer, at a GUI's blocks
+    assert set(live) == {"2Mi", "4Mi"} and all("error" not in v and v["frac"] > 0.02 and v["value_MSps"] > 50.0 for v in live.values()), live
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["value_1thread"] > 0 and "sample" in cb
+    assert d["config"]["symbol_clocks"].startswith("staggered") and d["value_aligned_clocks"] > 50.0 and d["value"] > 50.0
+    det = json.load(open(tmp_path / "detail.json"))
+    assert det["value"] == d["value"] and "kernel_launches_ms" in det["detail"] and "notes" in det["detail"]
+    import shutil
+    if shutil.which("rocprofv3"):
+        assert roof["traffic"] and 0.9 < roof["traffic_over_algorithmic"] < 2.0, roof
+
+
+def test_c5_shards_by_frame_over_two_ranks_without_an_exchange():
+    """BASELINE.json configs[4] as a workload of its own: dwell d on rank d mod N (Panoramic/Scanner.cpp:503-523: independent
+    frames), each rank's share of the capture resident in its own HBM, nothing exchanged; two ranks sharing the test GPU."""
+    env = dict(os.environ, SUAMD_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, "bench.py", "--workload", "c5", "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    two = subprocess.run([sys.executable, "bench.py", "--workload", "c5", "--gpus", "2", "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0 and two.returncode == 0, (one.stderr + two.stderr)[-3000:]
+    d1, d2 = _last_json(one.stdout), _last_json(two.stdout)
+    assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d1["scaling"] == d2["scaling"] == "strong"
+    assert d1["config"]["dwells_per_rank"] == 2 * d2["config"]["dwells_per_rank"] == 512
+    assert d1["config"]["capture_samples"] == d2["config"]["capture_samples"] == 1 << 30
+    for d in (d1, d2):
+        assert d["value"] > 1000.0 and d["roofline"]["bound"] == "hbm" and 0.05 < d["roofline"]["frac"] < 1.0
 
 
 def test_two_ranks_share_the_gpu_over_gloo():

@@ -10,14 +10,14 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { ( cd $REPO && "$@" ); }
 cd $REPO
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py --no-extra --no-cpu-baseline --no-pmc > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_all -o t -- python bench.py --no-cpu-baseline --no-pmc > $OUT/bench_all_under_rocprof.json 2> $OUT/trace_all.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py --lean > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_all -o t -- python bench.py --extra --no-pmc --no-cpu-baseline > $OUT/bench_all_under_rocprof.json 2> $OUT/trace_all.err
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python bench.py --steps 4 --warmup 1 --no-extra --no-cpu-baseline --no-pmc > /dev/null 2> $OUT/pmc_$c.err
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmcall_$c -o p -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-pmc > /dev/null 2> $OUT/pmcall_$c.err
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python bench.py --steps 4 --warmup 1 --lean > /dev/null 2> $OUT/pmc_$c.err
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmcall_$c -o p -- python bench.py --steps 4 --warmup 1 --extra --no-pmc --no-cpu-baseline > /dev/null 2> $OUT/pmcall_$c.err
 done
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-python bench.py --no-extra --no-cpu-baseline --isolated --no-pmc > $OUT/bench_isolated.json 2>> $OUT/bench.err
+python bench.py --lean --isolated --no-pmc > $OUT/bench_isolated.json 2>> $OUT/bench.err
 python tools/st_bench.py > $OUT/kernel_microbench.txt 2>&1
 python tools/fir_bench.py >> $OUT/kernel_microbench.txt 2>&1
 python tools/fir_c1.py >> $OUT/kernel_microbench.txt 2>&1
