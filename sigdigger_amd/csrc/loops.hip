@@ -1034,9 +1034,8 @@ constexpr int CT = 64;          // samples per LDS tile
 // loads are bounded.  Sample m of the lane sits at base[m * pitch] + lo bytes.
 template <bool SLACK>
 __device__ __forceinline__ void clock_stream_tm(const float2 *base, const long long pitch, const uint32_t lo, long long len,
-                                                const sdk::ClockParams &p, ClockRegs &r, float2 *__restrict__ out)
+                                                const sdk::ClockParams &p, ClockRegs &r, float2 *__restrict__ out, float2 *tile)
 {
-  __shared__ float2 tile[CT * 64];
   const int lane = threadIdx.x;
   const long long maxlen = uniform64(wave_max(len));
   if (maxlen <= 0) return;
@@ -1095,11 +1094,129 @@ __device__ __forceinline__ void clock_stream_tm(const float2 *base, const long l
   }
 }
 
+// Gardner detectors of a BANK (uniform parameters, one length), round by round: every lane gets to its own next half-cycle
+// crossing in the same round, wherever that is -- symbol clocks that are not aligned cost nothing.  What the two schedules
+// above pay for: the lock-step form runs the ~45-instruction crossing code whenever ANY lane crosses (every sample, with 64
+// unrelated clocks: 150 ns per sample against 57 aligned); clock_stream_tm's divergent advance loop costs a v_cmp -> SALU ->
+// branch chain per sample (~95 ns).  Here a round is branch-free:
+//   advance   U steps for every lane, no exit test: p += b; t = p - 0.5; the first t >= 0 is the crossing's (phi - 0.5) --
+//             picked by an UNSIGNED minimum (a negative float is a large unsigned) --, the steps before it are counted in a
+//             bit string (v_alignbit of t's sign).  4 instructions per step, one dependent add.  A lane that has not crossed
+//             after U steps (U = ceil(0.5 / bhint) + 1) just carries p_U into the next round.
+//   crossing  for all lanes at once, the symbol / half-cycle split as selects (with unrelated clocks both occur in every
+//             round anyway), the symbol store under its mask.
+// Samples sit in an LDS ring of two 64-row tiles in "y" coordinates (y[0] = the sample before the block, y[i + 1] = x[i]); a
+// tile is replaced when every lane has left it, its successor waits in registers meanwhile.  Lanes are never bounded inside
+// a round: the rounds stop U samples before the end and a plain per-sample loop (clock_step on per-lane indices) finishes
+// the block -- <= 2 U samples per call.  Per lane the operations and their order are clock_step's: same bits.
+constexpr int RT = 64, RING = 2 * RT;
+__device__ __forceinline__ void clock_ring(const float2 *base, const long long pitch, const uint32_t lo, const long long len, const bool live,
+                                           const int U, const sdk::ClockParams &p, ClockRegs &r, float2 *__restrict__ out, float2 *ring)
+{
+  const int lane = threadIdx.x;
+  // y index of the next sample a lane consumes (idle lanes: beyond everything)
+  long long ny = live ? 1 : (1ll << 40);
+  if (len >= 4 * (long long)U + 2 * RT) {
+    const int ylen = (int)(len < (1ll << 30) ? len : (1ll << 30));   // y indices as 32-bit numbers inside a call
+    // tile T holds y[T * RT .. T * RT + RT); request(T) loads it into registers
+    float2 pre[RT];
+    auto request = [&](int T) {
+      const long long y0 = (long long)T * RT;                        // x index: y index - 1
+      if (y0 >= 1 && y0 + RT - 1 <= len) {
+#pragma unroll
+        for (int j = 0; j < RT; ++j) pre[j] = ld_elem(base, (y0 + j - 1) * pitch, lo);
+      } else {
+#pragma unroll
+        for (int j = 0; j < RT; ++j) pre[j] = (y0 + j >= 1 && y0 + j <= len) ? ld_elem(base, (y0 + j - 1) * pitch, lo) : float2{0.0f, 0.0f};
+      }
+    };
+    auto commit = [&](int T) {
+      float2 *dst = ring + (size_t)((T & 1) * RT) * 64 + lane;
+#pragma unroll
+      for (int j = 0; j < RT; ++j) dst[j * 64] = pre[j];
+    };
+    request(0); commit(0);
+    ring[lane] = r.prev;                                             // y[0]
+    request(1); commit(1);
+    int wlo = 0;                                                     // the ring holds y[wlo, wlo + RING)
+    request(2);
+    int n = live ? 1 : (1 << 30);                                    // ny as an int
+    float phi = r.phi, bnor = r.bnor;
+    int hc = r.halfcycle;
+    float2 x0 = r.x0, x1 = r.x1, x2 = r.x2;
+    uint32_t cnt = r.n;
+    const int stop = ylen + 1 - U;                                   // a round needs n + U <= ylen + 1
+    for (;;) {
+      // every lane has left the ring's older tile: replace it by the tile that waits in registers, request the next one
+      if (__all(n > wlo + RT)) {
+        commit(wlo / RT + 2);
+        wlo += RT;
+        request(wlo / RT + 2);
+      }
+      if (__any(live && n > stop)) break;                            // the end of the block: finished below
+      const bool act = n + U <= wlo + RING;                          // (a lane far ahead of the others waits for the ring)
+      float pp = phi;
+      uint32_t sel = 0xffffffffu, bits = 0;
+      for (int g = 0; g < U; g += 3) {                               // (U is a multiple of three: the loop counter is scalar work)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          pp = pp + bnor;
+          const float t = pp - 0.5f;
+          const uint32_t tu = __float_as_uint(t);
+          sel = tu < sel ? tu : sel;
+          bits = __builtin_amdgcn_alignbit(bits, tu, 31);
+        }
+      }
+      const float ts = __uint_as_float(sel);
+      const bool crossed = act && ts >= 0.0f;                        // (a NaN phase never crosses, as in clock_step)
+      int used = __builtin_popcount(bits) + 1;
+      used = used < U ? used : U;
+      used = act ? used : 0;
+      const int c = n + used - 1;                                    // y index of the crossing sample
+      const float2 v = ring[(c & (RING - 1)) * 64 + lane];
+      const float2 pv = ring[((c - 1) & (RING - 1)) * 64 + lane];
+      const float mu = ts / bnor;
+      float2 q;
+      q.x = sd::fma_(mu, pv.x - v.x, v.x);
+      q.y = sd::fma_(mu, pv.y - v.y, v.y);
+      const int hn = hc ^ 1;
+      const bool sym = crossed && hn == 0, half = crossed && hn != 0;
+      const float dr = q.x - x0.x, di = q.y - x0.y;
+      const float e = p.gain * sd::fma_(x1.y, di, x1.x * dr);
+      const float phis = sd::fma_(p.alpha, e, ts);
+      float b = sd::fma_(p.beta, e, bnor);
+      if (b < p.bmin) b = p.bmin;
+      if (b > p.bmax) b = p.bmax;
+      if (sym) out[cnt] = q;
+      cnt += sym ? 1u : 0u;
+      x2 = sym ? x0 : x2;
+      x0 = sym ? q : x0;
+      x1 = half ? q : x1;
+      phi = crossed ? (sym ? phis : ts) : (act ? pp : phi);
+      bnor = sym ? b : bnor;
+      hc = crossed ? hn : hc;
+      n += used;
+    }
+    if (live) {
+      r.phi = phi; r.bnor = bnor; r.halfcycle = hc; r.x0 = x0; r.x1 = x1; r.x2 = x2; r.n = cnt;
+      ny = n;
+      if (n >= 2) r.prev = ld_elem(base, (long long)(n - 2) * pitch, lo);
+    }
+  }
+  // the rest of the block, sample by sample, every lane from where it is
+  const long long left = live ? len + 1 - ny : 0;
+  const long long most = uniform64(wave_max(left));
+  for (long long i = 0; i < most; ++i) {
+    if (i < left) clock_step(p, r, ld_elem(base, (ny - 1 + i) * pitch, lo), out);
+  }
+}
+
 __global__ __launch_bounds__(64) void clock_kernel(sdk::ClockParams p, sdk::ClockState s, int nchan,
                                                    const float2 *__restrict__ x, sdk::View xv, long long len,
                                                    float2 *__restrict__ sym, long long sym_stride,
-                                                   uint32_t *__restrict__ count, int mode, int xcd)
+                                                   uint32_t *__restrict__ count, int mode, int xcd, int ring_steps)
 {
+  __shared__ float2 lds[RING * 64];                           // clock_ring's two tiles; clock_stream_tm uses the first
   bool mine;
   const int cc = serial_block(xcd, mine) * 64 + threadIdx.x;
   if (!mine) return;
@@ -1116,10 +1233,14 @@ __global__ __launch_bounds__(64) void clock_kernel(sdk::ClockParams p, sdk::Cloc
   const uint32_t xo = (uint32_t)((long long)c * xv.cs * 8);
   float2 *out = sym + (long long)c * sym_stride;
   const long long mylen = live ? len : 0;
-  if (mode == 1) {
-    if (xv.ms == 64) clock_stream_tm<false>(x, 64, xo, mylen, p, r, out);
-    else if (xv.ms == 1) clock_stream_tm<false>(x, 1, xo, mylen, p, r, out);
-    else clock_stream_tm<false>(x, xv.ms, xo, mylen, p, r, out);
+  if (mode == 2) {
+    if (xv.ms == 64) clock_ring(x, 64, xo, len, live, ring_steps, p, r, out, lds);
+    else if (xv.ms == 1) clock_ring(x, 1, xo, len, live, ring_steps, p, r, out, lds);
+    else clock_ring(x, xv.ms, xo, len, live, ring_steps, p, r, out, lds);
+  } else if (mode == 1) {
+    if (xv.ms == 64) clock_stream_tm<false>(x, 64, xo, mylen, p, r, out, lds);
+    else if (xv.ms == 1) clock_stream_tm<false>(x, 1, xo, mylen, p, r, out, lds);
+    else clock_stream_tm<false>(x, xv.ms, xo, mylen, p, r, out, lds);
   } else {
     if (xv.ms == 64) stream_row(x, 64, xo, mylen, [&](long long, float2 v) { clock_step(p, r, v, out); });
     else if (xv.ms == 1) stream_row(x, 1, xo, mylen, [&](long long, float2 v) { clock_step(p, r, v, out); });
@@ -1151,7 +1272,8 @@ __global__ __launch_bounds__(64) void clock_gang_kernel(const sdk::ClockGangItem
   r.n = it.count[0];
   const long long len = live ? it.len : 0;
   float2 *out = reinterpret_cast<float2 *>(it.sym);
-  clock_stream_tm<true>(tm + (size_t)blockIdx.x * slab, 64, threadIdx.x * 8u, len, p, r, out);
+  __shared__ float2 tile[CT * 64];
+  clock_stream_tm<true>(tm + (size_t)blockIdx.x * slab, 64, threadIdx.x * 8u, len, p, r, out, tile);
   if (!live) return;
   s.phi[0] = r.phi; s.bnor[0] = r.bnor; s.halfcycle[0] = r.halfcycle;
   s.prev[0] = r.prev.x; s.prev[1] = r.prev.y;
@@ -1319,11 +1441,19 @@ hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, cons
                       long long len, void *sym, long long sym_stride, uint32_t *count, hipStream_t st)
 {
   if (len <= 0 || nchan <= 0) return hipSuccess;
-  static const int mode = getenv("SUAMD_CLOCK_MODE") ? atoi(getenv("SUAMD_CLOCK_MODE")) : 0;   // tuning knob: 1 = crossing by crossing
+  // the schedule: 2 = round by round (clock_ring), whenever a half cycle is at most 24 samples (beyond that crossings are rare
+  // and the lock-step form's three instructions per sample win); 0 = lock step; 1 = clock_stream_tm.  SUAMD_CLOCK_MODE pins it (A / B).
+  static const int forced = getenv("SUAMD_CLOCK_MODE") ? atoi(getenv("SUAMD_CLOCK_MODE")) : -1;
+  const float bhint = 2.0f * p.bmin;
+  int steps = (int)ceilf(0.5f / bhint) + 1;
+  const int mode = forced >= 0 ? forced : (steps <= 25 ? 2 : 0);
+  steps = 3 * ((steps + 2) / 3);                               // (clock_ring advances in groups of three)
+  if (steps > 30) steps = 30;
+  if (steps < 3) steps = 3;
   dim3 grid((nchan + 63) / 64);
   const int xcd = serial_xcd(2, grid);
   hipLaunchKernelGGL(clock_kernel, grid, dim3(64), 0, st, p, s, nchan,
-                     reinterpret_cast<const float2 *>(x), xs, len, reinterpret_cast<float2 *>(sym), sym_stride, count, mode, xcd);
+                     reinterpret_cast<const float2 *>(x), xs, len, reinterpret_cast<float2 *>(sym), sym_stride, count, mode, xcd, steps);
   return hipGetLastError();
 }
 

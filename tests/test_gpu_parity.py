@@ -542,6 +542,57 @@ def test_clock_bank_bit_exact_symbol_counts(ctx, sdo, layout):
         assert_bits(syms[c, :counts[c]], ref, f"clock ch {c}")
 
 
+def _staggered_rows(nchan, n, sps, seed=40, ppm=300.0):
+    """PSK rows whose symbol clocks share nothing: per-channel timing offset (uniform in one symbol) and baud (+- ppm)"""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    x = np.empty((nchan, n), np.complex64)
+    for c in range(nchan):
+        off, s = rng.random() * sps, sps * (1 + (2 * rng.random() - 1) * ppm * 1e-6)
+        sym = rng.integers(0, 4, int(n / sps * 1.001) + 8)
+        x[c] = np.exp(1j * (np.pi / 2 * sym[np.floor((t + off) / s).astype(np.int64)] + np.pi / 4 + 0.01 * c))
+    x += (0.08 * (rng.standard_normal((nchan, n)) + 1j * rng.standard_normal((nchan, n)))).astype(np.complex64)
+    return x
+
+
+@pytest.mark.parametrize("layout", ["cm", "tm"])
+@pytest.mark.parametrize("sps,gain", [(15.625, 0.2), (7.8, 1.0), (2.0, 0.2), (23.0, 0.2), (80.0, 0.2)])
+def test_clock_bank_with_staggered_symbol_clocks_bit_exact(ctx, sdo, layout, sps, gain):
+    """The band as it is: 64+ Gardner detectors whose half-cycle crossings fall at unrelated instants.  The
+    bank's round-by-round schedule (clock_ring: every lane to its own next crossing per round; sps <= 48) and the lock-step
+    schedule beyond it give, lane for lane, the oracle's symbols bit for bit -- over ragged splits of the stream (pieces shorter
+    than a round, than the LDS ring, and long ones), with an idle tail of lanes in the second wavefront and one lane whose
+    input turns to NaN half way (a NaN phase never crosses again: SPEC.md section G's `phi >= 0.5`)."""
+    nchan, n = 70, 30000
+    x = _staggered_rows(nchan, n, sps)
+    x[5, n // 2:] = np.nan
+    bank = engine.ClockBank(ctx, nchan, gain, 1.0 / sps)
+    sym = torch.zeros((nchan, n), dtype=torch.complex64, device="cuda")
+    cnt = torch.zeros(nchan, dtype=torch.int32, device="cuda")
+    dx = dev_rows(x, layout)
+    cuts = (0, 2, 40, 333, 700, 1100, 9000, 9001, 21000, n)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        bank.feed(dx[:, a:b], sym, cnt)
+    counts, syms = host(cnt), host(sym)
+    bn, ph = bank.state()
+    for c in range(nchan):
+        st = sdo.clock_new(gain, 1.0 / sps)
+        with np.errstate(all="ignore"):
+            ref = sdo.clock_feed_bulk(st, x[c])
+        assert counts[c] == len(ref), f"symbol count ch {c}: {counts[c]} vs {len(ref)}"
+        got = syms[c, :counts[c]]
+        if c == 5:
+            # the poisoned lane: the same symbols, the same NaNs at the same places and none after (x86's subss keeps a NaN
+            # operand's sign, v_pk_add_f32's neg modifier flips it: a NaN's sign bit is not part of the contract)
+            fr, fg = ref.view(np.float32), got.view(np.float32)
+            assert np.array_equal(np.isnan(fr), np.isnan(fg)) and np.isnan(fr).any()
+            assert_bits(np.nan_to_num(fg, nan=7.0), np.nan_to_num(fr, nan=7.0), "clock, NaN lane")
+            assert np.isnan(bn[c]) == np.isnan(np.float32(st.bnor)) and np.isnan(ph[c]) == np.isnan(np.float32(st.phi))
+            continue
+        assert_bits(got, ref, f"clock ch {c}")
+        assert np.float32(st.bnor).view(np.uint32) == bn[c].view(np.uint32) and np.float32(st.phi).view(np.uint32) == ph[c].view(np.uint32), c
+
+
 @pytest.mark.parametrize("layout", ["cm", "tm"])
 def test_agc_bank_bit_exact(ctx, sdo, layout):
     nchan, n = 65, 6000
