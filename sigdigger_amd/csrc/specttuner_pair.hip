@@ -51,6 +51,12 @@ constexpr int PW_MAXSEL = 12;                                  // 64-bin tables 
 constexpr int PW_EX = 1024;                                    // elements of one direction of a mid-DFT swap (16 x 64)
 constexpr int AUX_NT = 2;
 constexpr int AUX_SC1 = 16;
+// The first half of a window is the half the run's previous window requested as its second: its last use.  Marked
+// non-temporal, a hit does not renew the line -- the L2 (4 MiB per XCD, about what an XCD's 128 workgroups stream per
+// window) keeps the second halves, which ARE used again, one window longer.
+#ifndef STP_FIRST_HALF_AUX
+#define STP_FIRST_HALF_AUX AUX_NT
+#endif
 
 #ifdef STW_TSTAMP
 #define TS(n) do { __builtin_amdgcn_sched_barrier(0); ts[n] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -170,7 +176,7 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
   // came past the L2.)
   auto load_one = [&](auto pay, int q) {                       // q = a * 8 + n2
     const int r = 4 * P + (q >> 3) + 8 * (q & 7);
-    if (r < WAVE / 2) nxt[q] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(ra, t * 8, r * WAVE * 8, decltype(pay)::value ? AUX_SC1 : 0));
+    if (r < WAVE / 2) nxt[q] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(ra, t * 8, r * WAVE * 8, decltype(pay)::value ? AUX_SC1 : STP_FIRST_HALF_AUX));
     else nxt[q] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(rb, t * 8, (r - WAVE / 2) * WAVE * 8, 0));
   };
   bool pay_now = false;                                        // what the request in progress fetches through `ra`

@@ -3,7 +3,7 @@ sample.  SUAMD_CLOCK_MODE picks the kernel's schedule (read once per process).""
 import os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from sigdigger_amd import engine
 
 ctx = engine.Context(0)

@@ -2,7 +2,7 @@
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from sigdigger_amd import engine, synth
 
 L = 1 << int(__import__('os').environ.get('ST_LOG2L', 22))
