@@ -562,7 +562,8 @@ struct BlockBus {
   int (*bcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
   int (*comm_destroy)(void *) = nullptr;
   int (*comm_abort)(void *) = nullptr;          // ncclCommAbort: releases a collective whose peer never came
-  int bcast_timeout_ms = 2000;                  // SUAMD_ANALYZER_BCAST_TIMEOUT_MS: how long a broadcast may sit on a stream
+  int bcast_timeout_ms = 2000;                  // SUAMD_ANALYZER_BCAST_TIMEOUT_MS: how long a broadcast may sit on a stream ONCE A SHARD IS KNOWN TO BE GONE
+  int bcast_ceiling_ms = 120000;                // ... and with every shard alive as far as anyone knows (a wedged peer that never said so)
   std::vector<bool> lost_reported;              // per subscriber: its loss has been posted as READ_ERROR
   bool bcast_off = false;                       // a broadcast failed, or a shard gave up: per-GPU host copies from here on
   uint64_t bcast_blocks = 0;                    // blocks that went out through ncclBroadcast (diagnostic, SOURCE_INFO-independent)
@@ -641,6 +642,8 @@ struct suscan_analyzer {
   hipEvent_t ev_psd[2] = {};                  // the PSD of the block in slot p is in h_psd[p]
   float *h_psd[2] = {nullptr, nullptr};       // pinned landing zones of the PSD frames
   hipEvent_t ev_h2d[2] = {};                  // the host half h has been copied out: it may take the next read
+  hipEvent_t ev_bcast = nullptr;              // shard 0 (the root): behind its latest ncclBroadcast; settled lazily (bcast_settle)
+  bool bcast_pending = false;
   bool h2d_set[2] = {false, false};
   bool pipelined = true;                      // two blocks in flight (SUAMD_ANALYZER_PIPELINE=0 or the trace knob: one)
   suamd_complex *h_x = nullptr, *d_x = nullptr;
@@ -1537,6 +1540,7 @@ void free_device(suscan_analyzer *a)
     a->h_psd[p] = nullptr;
     if (a->ev_psd[p]) (void)hipEventDestroy(a->ev_psd[p]);
     if (a->ev_h2d[p]) (void)hipEventDestroy(a->ev_h2d[p]);
+    if (p == 0 && a->ev_bcast) { (void)hipEventDestroy(a->ev_bcast); a->ev_bcast = nullptr; }
     a->ev_psd[p] = a->ev_h2d[p] = nullptr;
     for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) { if (a->ev_done[p][k]) (void)hipEventDestroy(a->ev_done[p][k]); a->ev_done[p][k] = nullptr; }
   }
@@ -1593,7 +1597,8 @@ bool init_device(suscan_analyzer *a, std::string &err)
     for (int j = 0; ok && j < suscan_analyzer::NSUB; ++j)
       if (hipEventCreateWithFlags(&a->ev_stage[g][j], hipEventDisableTiming) != hipSuccess) { ok = false; err = "hipEventCreate failed"; }
   if (ok) {
-    bool e = hipEventCreateWithFlags(&a->ev_xfree, hipEventDisableTiming) == hipSuccess &&
+    bool e = hipEventCreateWithFlags(&a->ev_bcast, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&a->ev_xfree, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&a->ev_fir, hipEventDisableTiming) == hipSuccess;
     for (int p = 0; p < 2; ++p) {
       e = e && hipEventCreateWithFlags(&a->ev_psd[p], hipEventDisableTiming) == hipSuccess &&
@@ -1646,10 +1651,14 @@ bool bus_publish(suscan_analyzer *a, const void *host, size_t samples, size_t va
 
 // A collective needs every rank.  A shard that dies between the publisher's decision ("this block goes out by broadcast")
 // and its own ncclBroadcast call leaves the other ranks' calls on their streams with a peer that never comes: librccl's
-// kernel spins for ever and every later synchronisation of that stream hangs with it.  So the stream is never waited for
-// blindly behind a broadcast: the event recorded after the call is polled with a deadline, and when it runs out the rank
-// aborts its communicator (ncclCommAbort releases the kernel), the bus switches to per-GPU host copies for good, and the
-// dead shard is reported.  Returns false when the deadline passed.
+// kernel spins for ever and every later synchronisation of that stream hangs with it.  So a stream is never waited for
+// blindly behind a broadcast: the event recorded after the call is polled, and a DEADLINE RUNS ONLY WHILE A SHARD IS KNOWN TO
+// BE GONE (its `done` pinned at ~0, or the bus closed): a peer that is merely slow -- building the chains of hundreds of
+// inspectors on its first block, loading HIP modules, RCCL setting its channels up on the first collective -- is waited
+// for as long as it takes (round 5 gave every block 2 s whatever the reason and declared a slow peer dead: ADVICE r5).
+// `bcast_ceiling_ms` bounds the wait when nobody has reported anything (a peer wedged without saying so).  When the
+// deadline runs out the rank aborts its communicator (ncclCommAbort releases the kernel), the bus switches to per-GPU host
+// copies for good, and the dead shard is reported.  Returns false when the deadline passed.
 bool wait_event_deadline(hipEvent_t ev, int timeout_ms)
 {
   const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
@@ -1658,6 +1667,32 @@ bool wait_event_deadline(hipEvent_t ev, int timeout_ms)
     if (q == hipSuccess) return true;
     if (q != hipErrorNotReady) { (void)hipGetLastError(); return true; }   // a broken event is not a hung broadcast
     if (std::chrono::steady_clock::now() >= t_end) return false;
+    if (spins < 2000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100));
+  }
+}
+
+bool bcast_wait(suscan_analyzer *a, hipEvent_t ev)
+{
+  BlockBus &b = *a->bus;
+  const auto t0 = std::chrono::steady_clock::now();
+  bool armed = false;
+  std::chrono::steady_clock::time_point t_armed;
+  for (int spins = 0;; ++spins) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q == hipSuccess) return true;
+    if (q != hipErrorNotReady) { (void)hipGetLastError(); return true; }
+    const auto now = std::chrono::steady_clock::now();
+    if ((spins & 63) == 63 || spins < 4) {                      // (the mutex every 64th poll: ~6 ms once the polls sleep)
+      bool lost = false;
+      {
+        std::lock_guard<std::mutex> lk(b.m);
+        lost = b.closed;
+        for (uint64_t d : b.done) lost = lost || d == ~0ull;
+      }
+      if (lost && !armed) { armed = true; t_armed = now; }
+    }
+    if (armed && now - t_armed >= std::chrono::milliseconds(b.bcast_timeout_ms)) return false;
+    if (now - t0 >= std::chrono::milliseconds(b.bcast_ceiling_ms)) return false;
     if (spins < 2000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100));
   }
 }
@@ -1679,8 +1714,14 @@ void bus_broadcast_stuck(suscan_analyzer *a, hipEvent_t ev)
   if (comm && b.comm_abort) (void)b.comm_abort(comm);         // (the communicator is gone with it: never destroyed twice)
   if (!wait_event_deadline(ev, 20000))                         // without ncclCommAbort (an old library) the kernel cannot be released
     push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, "GPU shard " + std::to_string(a->shard) + ": a stuck ncclBroadcast could not be aborted");
-  push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, 0, "GPU shard " + std::to_string(a->shard) + ": ncclBroadcast did not complete within " +
-              std::to_string(b.bcast_timeout_ms) + " ms (a rank is missing): aborted, per-GPU host copies from here on");
+  bool any_gone = false;
+  { std::lock_guard<std::mutex> lk(b.m); for (uint64_t d : b.done) any_gone = any_gone || d == ~0ull; }
+  if (any_gone)
+    push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, 0, "GPU shard " + std::to_string(a->shard) + ": ncclBroadcast did not complete within " +
+                std::to_string(b.bcast_timeout_ms) + " ms of a shard going away (a rank is missing): aborted, per-GPU host copies from here on");
+  else
+    push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, 0, "GPU shard " + std::to_string(a->shard) + ": ncclBroadcast did not complete within " +
+                std::to_string(b.bcast_ceiling_ms) + " ms although no shard has reported a failure: broadcast disabled, per-GPU host copies from here on");
   for (int sh : lost)
     push_status(a->primary ? a->primary : a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, "GPU shard " + std::to_string(sh) + " is gone: its inspectors deliver nothing any more");
 }
@@ -1775,7 +1816,7 @@ void secondary_main(suscan_analyzer *a)
       else {
         // nothing that reads the block is enqueued before the broadcast is known to have completed (see wait_event_deadline)
         (void)hipEventRecord(a->ev_h2d[0], a->stream);
-        if (!wait_event_deadline(a->ev_h2d[0], bus.bcast_timeout_ms)) { bus_broadcast_stuck(a, a->ev_h2d[0]); sent = false; }
+        if (!bcast_wait(a, a->ev_h2d[0])) { bus_broadcast_stuck(a, a->ev_h2d[0]); sent = false; }
       }
     }
     if (!sent) (void)hipMemcpyAsync(dst, e.host, bytes, hipMemcpyHostToDevice, a->stream);
@@ -1848,6 +1889,7 @@ void setup_rccl(suscan_analyzer *a)
   a->bus->comm_destroy = reinterpret_cast<int (*)(void *)>(dlsym(lib, "ncclCommDestroy"));
   a->bus->comm_abort = reinterpret_cast<int (*)(void *)>(dlsym(lib, "ncclCommAbort"));
   if (const char *t = std::getenv("SUAMD_ANALYZER_BCAST_TIMEOUT_MS")) { const int v = std::atoi(t); if (v >= 10 && v <= 600000) a->bus->bcast_timeout_ms = v; }
+  if (const char *t = std::getenv("SUAMD_ANALYZER_BCAST_CEILING_MS")) { const int v = std::atoi(t); if (v >= 10 && v <= 3600000) a->bus->bcast_ceiling_ms = v; }
 }
 
 void worker_main(suscan_analyzer *a)
@@ -1889,7 +1931,14 @@ void worker_main(suscan_analyzer *a)
   double tmark[8] = {};
   static const bool dbg = std::getenv("SUAMD_ANALYZER_DEBUG") != nullptr;
 #define DBG(...) do { if (dbg) { std::fprintf(stderr, "[worker] " __VA_ARGS__); std::fputc('\n', stderr); std::fflush(stderr); } } while (0)
+  // before the worker blocks on the device: the latest broadcast has completed, or its communicator is aborted (bcast_wait)
+  auto bcast_settle = [&] {
+    if (!a->bcast_pending) return;
+    a->bcast_pending = false;
+    if (!bcast_wait(a, a->ev_bcast)) bus_broadcast_stuck(a, a->ev_bcast);
+  };
   auto finish = [&](InFlight &f) {                          // PSD message first, then the inspectors' messages, as ever
+    bcast_settle();
     if (!f.on) return;
     DBG("finish slot %d: wait psd", f.slot);
     (void)hipEventSynchronize(a->ev_psd[f.slot]);
@@ -1954,6 +2003,7 @@ void worker_main(suscan_analyzer *a)
     suamd_complex *h_cur = a->h_x + (size_t)cur * a->block;
     if (!have_next) {
       looped = false; src.mark();
+      bcast_settle();
       if (a->h2d_set[cur]) (void)hipEventSynchronize(a->ev_h2d[cur]);
       got_next = src.read(h_cur, a->block, &looped);
     }
@@ -1975,6 +2025,7 @@ void worker_main(suscan_analyzer *a)
       // the block after this one starts coming off the source now, on the helper thread
       src.mark();
       DBG("block at %llu: wait h2d of the other half", (unsigned long long)consumed);
+      bcast_settle();
       if (a->h2d_set[cur ^ 1]) (void)hipEventSynchronize(a->ev_h2d[cur ^ 1]);   // that half's copy (the previous block) is out
       reader.start(a->h_x + (size_t)(cur ^ 1) * a->block, a->block);
       DBG("read-ahead started");
@@ -2015,7 +2066,7 @@ void worker_main(suscan_analyzer *a)
     if (a->xfree_set) (void)hipStreamWaitEvent(a->stream, a->ev_xfree, 0);
     if (h_flt) {
       (void)hipMemcpyAsync(a->d_x, h_flt, blen * sizeof(suamd_complex), hipMemcpyHostToDevice, a->stream);
-      if (h_flt == a->h_flt) (void)hipStreamSynchronize(a->stream);   // one expansion buffer: the copy must be out before the next block
+      if (h_flt == a->h_flt) { bcast_settle(); (void)hipStreamSynchronize(a->stream); }   // one expansion buffer: the copy must be out before the next block
     } else if (src.bytes_per_sample() == sizeof(suamd_complex)) {
       (void)hipMemcpyAsync(a->d_x, h_cur, blen * sizeof(suamd_complex), hipMemcpyHostToDevice, a->stream);
     } else {                                               // 2-4 B/sample over PCIe, expanded on the GPU
@@ -2031,10 +2082,12 @@ void worker_main(suscan_analyzer *a)
         std::lock_guard<std::mutex> lk(a->bus->m);
         a->bus->bcast_off = true;                              // (the shards that could not take part fall back to their host copy themselves)
       } else {
-        // the root's stream is never waited for blindly behind a collective (wait_event_deadline): a shard that died after
-        // this block was published would otherwise hang the analyzer
-        (void)hipEventRecord(a->ev_h2d[cur], a->stream);
-        if (!wait_event_deadline(a->ev_h2d[cur], a->bus->bcast_timeout_ms)) bus_broadcast_stuck(a, a->ev_h2d[cur]);
+        // The root's stream is never waited for blindly behind a collective: a shard that died after this block was
+        // published would otherwise hang the analyzer.  But the root only SENDS -- its own copy of the block is whole
+        // whatever becomes of the broadcast -- so it does not stop here: the event is settled (bcast_settle) right before
+        // the worker next blocks on the device, after this block's own work has been enqueued behind the collective.
+        (void)hipEventRecord(a->ev_bcast, a->stream);
+        a->bcast_pending = true;
       }
     }
     (void)hipEventRecord(a->ev_h2d[cur], a->stream);
@@ -2064,6 +2117,7 @@ void worker_main(suscan_analyzer *a)
     if (navg && !suamd_psd_feed(a->psd, a->d_x, navg, n, navg, 1.0f / (float)n, SUAMD_PSD_LINEAR, a->d_psd, a->stream)) {
       fatal = suamd_last_error();
       (void)reader.wait(&looped_next);                        // the helper thread is off the pinned buffer before it is freed
+      bcast_settle();
       for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) (void)hipStreamSynchronize(a->istream[k]);
       finish(flight);
       push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_READ_ERROR, -1, fatal);

@@ -26,8 +26,9 @@ def test_a_cu_mask_confines_a_stream_and_consecutive_bits_sit_on_consecutive_xcd
     try:
         w_res = ctx.probe_placement(s_res, 512, 20000)
         w_tr = ctx.probe_placement(s_tr, 8192, 20000)
-        # one CU per XCD, the same (se, cu) on each: bit i -> XCD i mod 8
-        assert sorted(set(w_res)) == [(x, 0, 0) for x in range(8)]
+        # one CU per XCD: bit i -> XCD i mod 8 (WHICH physical (se, cu) an XCD's first enabled CU is depends on the die's
+        # harvesting: most boxes of the pool read (x, 0, 0) for every x, one read (1, 0, 1))
+        assert len(set(w_res)) == 8 and sorted(x for x, _, _ in set(w_res)) == list(range(8)), sorted(set(w_res))
         assert len(set(w_tr)) == 248 and not (set(w_tr) & set(w_res))
         # the dispatcher deals the workgroups of a launch to the XCDs in turn whatever CUs they have enabled
         per_xcd = np.bincount([x for x, _, _ in w_tr], minlength=8)
