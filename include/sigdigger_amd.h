@@ -70,6 +70,17 @@ SUAMD_API const char *suamd_version(void);
  * rocprofv3 --kernel-trace reports, without the queue gaps two stream events around a launch would add.  Process-wide. */
 SUAMD_API void   suamd_kernel_timing(SUBOOL enable);
 SUAMD_API SUBOOL suamd_kernel_timing_read(const char *kernel, double *sum_ms, double *min_ms, double *max_ms, unsigned *launches);
+/* Tuning (no counterpart in the reference): every knob that changes HOW the library computes -- launch plans, kernel
+ * choices, schedules; never the result -- lives in one struct (csrc/tuning.hpp lists the fields with their environment
+ * names, ranges and meaning).  The SUAMD_* environment is read ONCE, at first use; these calls change a field afterwards
+ * (what the A / B parity tests do).  `name` is the field's name or its environment variable's.  suamd_tuning_set returns
+ * SU_FALSE for an unknown name or a value outside the field's range; suamd_tuning_describe walks the table (SU_FALSE past
+ * its end); suamd_tuning_reset goes back to defaults + environment.  Process-wide; objects made under a plan keep it where
+ * the field says so. */
+SUAMD_API SUBOOL suamd_tuning_set(const char *name, long long value);
+SUAMD_API SUBOOL suamd_tuning_get(const char *name, long long *value);
+SUAMD_API SUBOOL suamd_tuning_describe(unsigned index, const char **name, const char **env, long long *def, long long *lo, long long *hi, const char **doc);
+SUAMD_API void   suamd_tuning_reset(void);
 /* Replaces suscan_sigutils_init + su_lib_gen_wisdom for this path (Suscan/Library.cpp:97,
  * App/Loader.cpp:46): binds a GPU and builds the shared tables. */
 SUAMD_API suamd_ctx_t *suamd_ctx_new(int device_ordinal);

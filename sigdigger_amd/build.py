@@ -39,9 +39,10 @@ SOURCES = {
     "capi.hip":  ["-ffp-contract=off"],
     "analyzer.cpp": ["-ffp-contract=off"],
     "export.cpp": ["-ffp-contract=off"],
+    "tuning.cpp": ["-ffp-contract=off"],
     "sigutils_host.cpp": ["-ffp-contract=off", "-Wno-return-type-c-linkage"],   # std::complex<float> == float _Complex in the x86-64 ABI
 }
-HEADERS = ["kernels.hpp", "sd_math.hpp", "design.hpp", "fft_core.hpp", "fft_reg.hpp", os.path.join("..", "..", "include", "sigdigger_amd.h"),
+HEADERS = ["kernels.hpp", "sd_math.hpp", "design.hpp", "fft_core.hpp", "fft_reg.hpp", "tuning.hpp", os.path.join("..", "..", "include", "sigdigger_amd.h"),
            os.path.join("..", "..", "include", "suscan_amd.h")]
 
 

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/suscan_amd.h"
+#include "tuning.hpp"
 
 namespace {
 
@@ -724,7 +725,7 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
     bool ok = true;
     in.arena = &a->rows;
     in.cap = need;                                       // (free_rows hands rows back by this size)
-    static const bool poison = std::getenv("SUAMD_ANALYZER_POISON_ROWS") != nullptr;   // debug: rows start as NaNs, not as whatever was there
+    const bool poison = sdk::tuning().analyzer_poison_rows != 0;   // debug: rows start as NaNs, not as whatever was there
     auto row = [&](suamd_complex **p) {
       *p = static_cast<suamd_complex *>(a->rows.take(need * 8));
       if (*p && poison) (void)hipMemset(*p, 0xff, need * 8);
@@ -980,7 +981,7 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
       uintptr_t lo = ~(uintptr_t)0, hi = 0;
       for (Inspector *pi : live) { const uintptr_t p = reinterpret_cast<uintptr_t>(pi->d_y); lo = std::min(lo, p); hi = std::max(hi, p); }
       const bool near = !live.empty() && hi - lo < ((uintptr_t)1 << 31) - ((uintptr_t)1 << 28);   // the library checks the feed's own extent on top
-      if (std::getenv("SUAMD_ANALYZER_DEBUG")) { static int once = 0; if (!once++) std::fprintf(stderr, "[worker] inspector rows span %.1f MiB over %zu inspectors: %s\n", (double)(hi - lo) / 1048576.0, live.size(), near ? "near" : "64-bit"); }
+      if (sdk::tuning().analyzer_debug) { static int once = 0; if (!once++) std::fprintf(stderr, "[worker] inspector rows span %.1f MiB over %zu inspectors: %s\n", (double)(hi - lo) / 1048576.0, live.size(), near ? "near" : "64-bit"); }
       if (!(near ? suamd_specttuner_feed_rows_near(a->st, a->d_x, len, a->d_rowptr[slot], reinterpret_cast<const void *>(lo), (size_t)(hi - lo) + 8, counts.data(), sF)
                  : suamd_specttuner_feed_rows(a->st, a->d_x, len, a->d_rowptr[slot], counts.data(), sF))) { fail("channeliser"); return; }
       for (size_t i = 0; i < live.size(); ++i) fm[i] = counts[live[i]->st_chan];
@@ -1581,18 +1582,15 @@ bool init_device(suscan_analyzer *a, std::string &err)
   bool prio_ok = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_lo != prio_hi;
   if (!prio_ok) (void)hipGetLastError();
   prio = prio_hi;
-  if (const char *e = std::getenv("SUAMD_ANALYZER_STAGE_PRIORITY")) { if (!strcasecmp(e, "off")) prio_ok = false; else prio = std::atoi(e); }
+  if (const long long v = sdk::tuning().analyzer_stage_priority; v == -2) prio_ok = false; else if (v != 99) prio = (int)v;
   for (int k = 0; ok && k < suscan_analyzer::NISTREAMS; ++k) {
     hipError_t e = (prio_ok && k < 3) ? hipStreamCreateWithPriority(&a->istream[k], hipStreamNonBlocking, prio)
                                       : hipStreamCreateWithFlags(&a->istream[k], hipStreamNonBlocking);
     if (e != hipSuccess) { ok = false; err = "hipStreamCreate failed"; }
   }
   if (ok && hipEventCreateWithFlags(&a->ev_input, hipEventDisableTiming) != hipSuccess) { ok = false; err = "hipEventCreate failed"; }
-  a->trace = std::getenv("SUAMD_ANALYZER_TRACE") != nullptr;
-  if (const char *e = std::getenv("SUAMD_ANALYZER_SUBRANGES")) {           // tuning knob: 1 = whole block per stage
-    const int v = std::atoi(e);
-    if (v >= 1 && v <= suscan_analyzer::NSUB) a->nsub = a->nsub_env = v;
-  }
+  a->trace = sdk::tuning().analyzer_trace != 0;
+  if (const int v = (int)sdk::tuning().analyzer_subranges; v >= 1 && v <= suscan_analyzer::NSUB) a->nsub = a->nsub_env = v;   // 1 = whole block per stage
   for (int g = 0; ok && g < 3; ++g)
     for (int j = 0; ok && j < suscan_analyzer::NSUB; ++j)
       if (hipEventCreateWithFlags(&a->ev_stage[g][j], hipEventDisableTiming) != hipSuccess) { ok = false; err = "hipEventCreate failed"; }
@@ -1608,8 +1606,7 @@ bool init_device(suscan_analyzer *a, std::string &err)
     if (!e) { ok = false; err = "hipEventCreate failed"; }
     const char *ce = std::getenv("SUAMD_ANALYZER_CHANNELISER");
     a->want_fft = !(ce && !strcasecmp(ce, "fir"));
-    const char *pe = std::getenv("SUAMD_ANALYZER_PIPELINE");
-    a->pipelined = !a->trace && !(pe && std::atoi(pe) == 0);
+    a->pipelined = !a->trace && sdk::tuning().analyzer_pipeline != 0;
   }
   if (ok && a->trace) {
     (void)hipEventCreate(&a->ev_t0); (void)hipEventCreate(&a->ev_tfir); (void)hipEventCreate(&a->ev_tpre); (void)hipEventCreate(&a->ev_tdone);
@@ -1929,7 +1926,7 @@ void worker_main(suscan_analyzer *a)
   struct InFlight { bool on = false; int slot = 0; suscan_analyzer_psd_msg *msg = nullptr; unsigned n = 0; bool chan = false; } flight;
   int slot = 0;
   double tmark[8] = {};
-  static const bool dbg = std::getenv("SUAMD_ANALYZER_DEBUG") != nullptr;
+  const bool dbg = sdk::tuning().analyzer_debug != 0;
 #define DBG(...) do { if (dbg) { std::fprintf(stderr, "[worker] " __VA_ARGS__); std::fputc('\n', stderr); std::fflush(stderr); } } while (0)
   // before the worker blocks on the device: the latest broadcast has completed, or its communicator is aborted (bcast_wait)
   auto bcast_settle = [&] {
@@ -2575,7 +2572,10 @@ suscan_analyzer_t *suscan_analyzer_new(const struct suscan_analyzer_params *para
         s->params = *params; s->source_cfg = *config; s->mq = mq;
         s->device = devs[i]; s->shard = (int)i; s->nshards = a->nshards; s->primary = a; s->bus = a->bus;
         s->next_handle = (SUHANDLE)i;
-        if (const char *f = std::getenv("SUAMD_ANALYZER_FAULT")) {
+        // test hook (tests/test_gpu_analyzer_fft.py: a shard that dies mid-broadcast), honoured only beside SUAMD_TEST_HOOKS=1:
+        // nothing a deployment sets by accident.  INTEGRATION.md section 3.1.
+        const char *hooks = std::getenv("SUAMD_TEST_HOOKS");
+        if (const char *f = (hooks && std::atoi(hooks) == 1) ? std::getenv("SUAMD_ANALYZER_FAULT") : nullptr) {
           int fs = -1; long long fb = -1;
           if (std::sscanf(f, "shard_dies:%d:%lld", &fs, &fb) == 2) { s->fault_shard = fs; s->fault_block = fb; }
         }

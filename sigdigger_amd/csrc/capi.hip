@@ -18,6 +18,7 @@
 
 #include "../../include/sigdigger_amd.h"
 #include "kernels.hpp"
+#include "tuning.hpp"
 #include "design.hpp"
 
 namespace {
@@ -341,6 +342,28 @@ extern "C" {
 
 void suamd_kernel_timing(SUBOOL enable) { g_timing.store(enable != SU_FALSE); }
 
+SUBOOL suamd_tuning_set(const char *name, long long value)
+{
+  if (sdk::tuning_set(name, value)) return SU_TRUE;
+  set_err("suamd_tuning_set: no field '%s', or %lld outside its range", name ? name : "(null)", value);
+  return SU_FALSE;
+}
+SUBOOL suamd_tuning_get(const char *name, long long *value) { return sdk::tuning_get(name, value) ? SU_TRUE : SU_FALSE; }
+SUBOOL suamd_tuning_describe(unsigned index, const char **name, const char **env, long long *def, long long *lo, long long *hi, const char **doc)
+{
+  unsigned n = 0;
+  const sdk::TuningField *f = sdk::tuning_fields(&n);
+  if (index >= n) return SU_FALSE;
+  if (name) *name = f[index].name;
+  if (env) *env = f[index].env;
+  if (def) *def = f[index].def;
+  if (lo) *lo = f[index].lo;
+  if (hi) *hi = f[index].hi;
+  if (doc) *doc = f[index].doc;
+  return SU_TRUE;
+}
+void suamd_tuning_reset(void) { sdk::tuning_reset(); }
+
 SUBOOL suamd_kernel_timing_read(const char *kernel, double *sum_ms, double *min_ms, double *max_ms, unsigned *launches)
 {
   std::vector<TimedLaunch> mine;
@@ -554,8 +577,7 @@ SUBOOL suamd_psd_feed(suamd_psd_t *p, const suamd_complex *d_x, SUSCOUNT nframes
     // (batches of up to 16 Mi points = 128 MiB per ping-pong buffer, the whole job if it is smaller)
     // SUAMD_PSD_LARGE (read per call: the tests switch it): "passes" = round 2's radix-16 passes through HBM, "twotrip" =
     // psd_large.hip for 32768 points too
-    const char *mode_env = getenv("SUAMD_PSD_LARGE");
-    const bool passes = mode_env && !strcmp(mode_env, "passes"), two_trip = mode_env && !strcmp(mode_env, "twotrip");
+    const bool passes = sdk::tuning().psd_large == 0, two_trip = sdk::tuning().psd_large == 1;
     if (p->log2n == 15 && !passes && !two_trip && p->d_tw_half) {
       // 32768 points (the scanner at 20 MS/s): ONE trip through HBM -- two workgroups per output on the 16384-point kernel,
       // each forms one of the two interleaved half spectra's operands from the whole frame on the way in (psd.hip, HALVES)
@@ -571,11 +593,11 @@ SUBOOL suamd_psd_feed(suamd_psd_t *p, const suamd_complex *d_x, SUSCOUNT nframes
     }
     if (!passes) {
       // psd_large.hip: two trips through HBM (column transforms on registers, row transforms in LDS)
-      static const long long batch_points = [] { const char *e = getenv("SUAMD_PSD_LARGE_POINTS"); const long long v = e ? atoll(e) : 0; return v >= 15 && v <= 30 ? 1ll << v : 1ll << 27; }();
+      const long long batch_points = 1ll << sdk::tuning().psd_large_points;
       long long batch = batch_points / (long long)p->n;         // 128 Mi points = 1 GiB of intermediate (measured: small batches that would fit the last-level cache lose more to launch tails than they gain)
       if (batch > 32768) batch = 32768;                         // grid.y of the column pass
       if (batch > nout * (long long)navg) batch = nout * (long long)navg;
-      if (const char *e = getenv("SUAMD_PSD_LARGE_BATCH")) { const long long v = atoll(e); if (v >= 1 && v < batch) batch = v; }   // tests: awkward batch boundaries
+      if (const long long v = sdk::tuning().psd_large_batch; v >= 1 && v < batch) batch = v;   // tests: awkward batch boundaries
       if (batch < 1) batch = 1;
       const int ch = sdk::psd_large_chunk((int)navg), cpo = ((int)navg + ch - 1) / ch;
       // ring of chunk sums: everything between the first chunk of the batch's first (possibly still open) output and the
@@ -594,7 +616,7 @@ SUBOOL suamd_psd_feed(suamd_psd_t *p, const suamd_complex *d_x, SUSCOUNT nframes
     }
     long long batch = (1ll << 24) / (long long)p->n;
     if (batch > nout * (long long)navg) batch = nout * (long long)navg;
-    if (const char *e = getenv("SUAMD_PSD_LARGE_BATCH")) { const long long v = atoll(e); if (v >= 1 && v < batch) batch = v; }   // tests: awkward batch boundaries
+    if (const long long v = sdk::tuning().psd_large_batch; v >= 1 && v < batch) batch = v;   // tests: awkward batch boundaries
     if (batch < 1) batch = 1;
     const size_t cb = sizeof(suamd_complex) * (size_t)p->n * (size_t)batch;
     if (!p->partial.reserve(2 * cb + sizeof(float) * (size_t)p->n)) { set_err("scratch allocation failed"); return SU_FALSE; }

@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "kernels.hpp"
+#include "tuning.hpp"
 #include "sd_math.hpp"
 
 namespace {
@@ -530,8 +531,7 @@ static hipError_t fir_plan(const ChanFeedArgs &a, FirPlan &pl)
   ge.D = (int)a.D; ge.ntaps = a.ntaps; ge.nchan = a.nchan;
   ge.KD = ((a.ntaps - 1 + ge.D - 1) / ge.D) * ge.D;
   ge.PAD = (ge.D & 1) ? 0 : 1;                                      // D + PAD odd
-  static const int force_smem = getenv("SUAMD_FIR_SMEM_TAPS") ? atoi(getenv("SUAMD_FIR_SMEM_TAPS")) : 0;   // tuning knobs
-  static const int force_nout = getenv("SUAMD_FIR_NOUT") ? atoi(getenv("SUAMD_FIR_NOUT")) : 0;
+  const int force_smem = (int)sdk::tuning().fir_smem_taps, force_nout = (int)sdk::tuning().fir_nout;   // tuning knobs
   const bool lds_taps = !force_smem && (size_t)a.nchan * a.ntaps * sizeof(float4) <= 16 * 1024;
   // (measured alternative at C = D = 64: 8 channels per lane 124 us -- 61 SGPRs spill)
   const int nch = a.nchan >= 4 ? 4 : (a.nchan >= 2 ? 2 : 1);
@@ -598,7 +598,7 @@ hipError_t chan_feed(const ChanFeedArgs &a, hipStream_t st)
   // taps from scalar loads: 4 channels x 4 taps = 64 SGPRs per chunk, so no second chunk in flight
   // 4 channels x 2 taps = 32 SGPRs per chunk, two chunks in flight (ping-pong): 114.7 -> 109.1 us at C = D = 64,
   // 51.7 -> 42.2 us at C = 16 against single chunks of 4 taps
-  static const int tc4 = getenv("SUAMD_FIR_TC4") ? atoi(getenv("SUAMD_FIR_TC4")) : 0;
+  const int tc4 = (int)sdk::tuning().fir_tc4;
   if (!tc4 && nch == 4) { if (nout == 2) SD_FIR(4, 2, 2, false, true); SD_FIR(4, 1, 2, false, true); }
   if (nout == 2) { if (nch == 4) SD_FIR(4, 2, 4, false, false); if (nch == 2) SD_FIR(2, 2, 4, false, true); SD_FIR(1, 2, 8, false, true); }
   if (nch == 4) SD_FIR(4, 1, 4, false, false); if (nch == 2) SD_FIR(2, 1, 4, false, true); SD_FIR(1, 1, 8, false, true);

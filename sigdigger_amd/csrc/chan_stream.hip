@@ -32,6 +32,7 @@
 #include <vector>
 #include <stdio.h>
 #include "kernels.hpp"
+#include "tuning.hpp"
 #include "sd_math.hpp"
 
 namespace {
@@ -48,13 +49,21 @@ struct StreamArgs {
   sdk::ChanFeedArgs a;
   const float2 *g2;      // [nchan][ntaps] (re, im), 64 spare entries on either side
   int ntiles, tiles_per_wg;
-  unsigned long long *ts; // phase clocks (SUAMD_FIR_STREAM_TS=1; measurement aid)
-  int shape;             // 0 in every launch.  The tile loop tests two bits of it (skip the next tile's loads / the runs): left over
-                         // from round 4's timing experiments and kept, with no way to set it, because of what the optimiser does once it
-                         // knows both are never taken -- it folds the prefetch branches into the tile loop's own and the kernel takes 33
-                         // instead of 20 us per 4 Mi samples (measured three ways: the tests removed, replaced by other opaque
-                         // arguments, and as they are)
+#ifdef SUAMD_INSTRUMENT
+  unsigned long long *ts; // phase clocks (instrumented build + SUAMD_FIR_STREAM_TS=1)
+#endif
 };
+
+// The tile loop's two structural branches ("prefetch the next tile in the run loop", "run the runs at all") must stay
+// branches: once the optimiser knows both are always taken it folds the prefetch branches into the tile loop's own and the
+// kernel takes 33 instead of 20 us per 4 Mi samples (round 4, measured three ways).  Rounds 4-5 kept a dead kernel
+// argument for that; this is the same thing said to the compiler directly: a zero it cannot see through.
+__device__ __forceinline__ int opaque_zero()
+{
+  int z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  return z;
+}
 
 // One tap against one sample as two v_pk_fma_f32, the tap straight from its SGPR pair: op_sel picks re for both halves,
 // then im against the swapped sample with the real part's product negated -- the SPEC's operation pair
@@ -190,8 +199,13 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? NW / 4 : 1) void chan_pair_kerne
   const int t_begin = blockIdx.x * sa.tiles_per_wg;
   const int t_end = t_begin + sa.tiles_per_wg < sa.ntiles ? t_begin + sa.tiles_per_wg : sa.ntiles;
   if (t_begin >= t_end) return;
+#ifdef SUAMD_INSTRUMENT
   unsigned long long tsv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define SD_TS(i) do { if (sa.ts) { __builtin_amdgcn_sched_barrier(0); tsv[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define SD_TS(i) do { } while (0)
+#endif
+  const int shape = opaque_zero();
 
   // pair-block p of tile t ends at sample (m_first + t TO + 2 p + 1) D; its first new sample:
   auto tile_n1 = [&](int t) { return ((long long)a.m_first + (long long)t * TO - 1) * D + 1; };
@@ -272,15 +286,17 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? NW / 4 : 1) void chan_pair_kerne
   // loads per thread go out one per run in the first D runs (statically unrolled groups: pf[] keeps constant indices):
   // issued in one burst they hold every wavefront in the issue stage for 3000 ticks at the same time.
   constexpr int G = PB / 8;
-  const int RR = (sa.shape & 2) ? 0 : (T + D + 7) / 8;             // runs
+  const int RR = (shape & 2) ? 0 : (T + D + 7) / 8;                // runs
   const int NG = (RR + G - 1) / G;                               // groups
   const int g_lo = (D / 8 + G - 1) / G, g_hi = (T / 8) / G;      // groups g_lo .. g_hi - 1 are whole
   for (int t = t_begin; t < t_end; ++t) {
+#ifdef SUAMD_INSTRUMENT
     tsv[3] = tsv[5] = tsv[6] = 0;
+#endif
     SD_TS(0);
     flush();                                                     // the previous tile's outputs
     const bool more = t + 1 < t_end;
-    const bool pre = more && !(sa.shape & 1);
+    const bool pre = more && !(shape & 1);
     const long long N1n = tile_n1(t + 1);
     const bool pre_whole = N1n >= n0 && N1n + (long long)NP * PB <= n0 + len;   // the next tile lies inside x
     const float2 *const psrc = x + (N1n - n0) + 2 * tid;
@@ -391,6 +407,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? NW / 4 : 1) void chan_pair_kerne
       __syncthreads();
     }
     SD_TS(4);
+#ifdef SUAMD_INSTRUMENT
     if (sa.ts && tid == 0) {
       unsigned long long *tp2 = sa.ts + ((size_t)blockIdx.x * sa.tiles_per_wg + (t - t_begin)) * 8;
 #pragma unroll
@@ -401,6 +418,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? NW / 4 : 1) void chan_pair_kerne
 #pragma unroll
       for (int i = 0; i < 7; ++i) tp3[i] = tsv[i];
     }
+#endif
   }
 #undef SD_TS
   flush();
@@ -437,6 +455,7 @@ hipError_t launch_pair_nw(int nw, const StreamArgs &sa, size_t lds, unsigned gri
 
 namespace sdk {
 
+#ifdef SUAMD_INSTRUMENT
 static unsigned long long *ts_buffer()
 {
   static unsigned long long *d_ts = nullptr;
@@ -474,13 +493,15 @@ static void ts_report(const StreamArgs &sa, unsigned grid, int nw, hipStream_t s
   }
 }
 
+#endif  // SUAMD_INSTRUMENT
+
 // true if this feed is taken (launched); false if the shape is not this kernel's (the caller goes on to chan_fir_kernel):
 // one or two channels, D = 8 or 16, at least 128 outputs, a tile (with its history pair-blocks) within the LDS.
 bool chan_stream_feed(const ChanFeedArgs &a, const void *g2, hipStream_t st, hipError_t *err)
 {
   *err = hipSuccess;
-  const char *mode_env = getenv("SUAMD_FIR_STREAM");          // 0: off (read per call: the tests compare the two kernels)
-  if ((mode_env && atoi(mode_env) == 0) || !g2 || a.nchan < 1 || a.nchan > 2 || a.n_out <= 0 || a.ntaps < 1) return false;
+  const sdk::Tuning &tn = sdk::tuning();                      // (fir_stream = 0: off -- read per call: the tests compare the two kernels)
+  if (tn.fir_stream == 0 || !g2 || a.nchan < 1 || a.nchan > 2 || a.n_out <= 0 || a.ntaps < 1) return false;
   const int D = (int)a.D;
   if (D != 8 && D != 16) return false;
   static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
@@ -502,24 +523,27 @@ bool chan_stream_feed(const ChanFeedArgs &a, const void *g2, hipStream_t st, hip
   // against 75.0 us, 4 Mi: 25.6 against 22.1 (the independent tiles keep the short feeds).
   int nw = 2, tpw = 1;
   if (a.exclusive && a.n_out >= (1ll << 19)) { nw = 8; tpw = 0; }
-  if (const char *e = getenv("SUAMD_FIR_PAIR_NW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) { nw = v; tpw = 0; } }
+  if (const int v = (int)tn.fir_pair_nw; v == 1 || v == 2 || v == 4 || v == 8) { nw = v; tpw = 0; }
   while (nw > 1 && a.n_out < 128ll * nw) nw >>= 1;
   while (nw > 1 && pbytes(nw) > 160 * 1024) nw >>= 1;
   if (pbytes(nw) > 160 * 1024 || HBP > 64 || HBP > 64 * nw || a.n_out < 128 * nw) return false;
   StreamArgs sa;
   sa.a = a; sa.g2 = reinterpret_cast<const float2 *>(g2);
-  sa.shape = 0;
   const int TO = 128 * nw;
   sa.ntiles = (int)((a.n_out + TO - 1) / TO);
   const int slots = ncu * (8 / nw);                              // resident workgroups: 8 wavefronts and the LDS of one CU
   sa.tiles_per_wg = tpw ? tpw : (sa.ntiles + slots - 1) / slots;
-  if (const char *e = getenv("SUAMD_FIR_PAIR_TPW")) { const int v = atoi(e); if (v >= 1) sa.tiles_per_wg = v; }
+  if (tn.fir_pair_tpw >= 1) sa.tiles_per_wg = (int)tn.fir_pair_tpw;
   const unsigned grid = (unsigned)((sa.ntiles + sa.tiles_per_wg - 1) / sa.tiles_per_wg);
+#ifdef SUAMD_INSTRUMENT
   sa.ts = (size_t)grid * sa.tiles_per_wg <= 4096 * 64 ? ts_buffer() : nullptr;
+#endif
   const size_t lds = pbytes(nw);
   if (D == 8) *err = a.nchan == 1 ? launch_pair_nw<8, 1>(nw, sa, lds, grid, st) : launch_pair_nw<8, 2>(nw, sa, lds, grid, st);
   else *err = a.nchan == 1 ? launch_pair_nw<16, 1>(nw, sa, lds, grid, st) : launch_pair_nw<16, 2>(nw, sa, lds, grid, st);
+#ifdef SUAMD_INSTRUMENT
   if (sa.ts && *err == hipSuccess) ts_report(sa, grid, nw, st);
+#endif
   return true;
 }
 

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.hpp"
+#include "tuning.hpp"
 #include "sd_math.hpp"
 
 namespace {
@@ -1397,7 +1398,7 @@ hipError_t sample_manual_bulk(const void *data, long long length, double symbol_
 // whatever XCD the dispatcher's round robin gives it -- XCD 0 for a single block)
 static int serial_xcd(int stage, dim3 &grid)
 {
-  static const bool off = [] { const char *e = getenv("SUAMD_SERIAL_XCD"); return e && e[0] == '0'; }();
+  const bool off = sdk::tuning().serial_xcd == 0;
   if (off || grid.x > 64) return -1;
   grid.x *= 8;
   return stage;                                                // AGC 3, Costas 1, clock 2: three different XCDs
@@ -1442,8 +1443,8 @@ hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, cons
 {
   if (len <= 0 || nchan <= 0) return hipSuccess;
   // the schedule: 2 = round by round (clock_ring), whenever a half cycle is at most 24 samples (beyond that crossings are rare
-  // and the lock-step form's three instructions per sample win); 0 = lock step; 1 = clock_stream_tm.  SUAMD_CLOCK_MODE pins it (A / B).
-  static const int forced = getenv("SUAMD_CLOCK_MODE") ? atoi(getenv("SUAMD_CLOCK_MODE")) : -1;
+  // and the lock-step form's three instructions per sample win); 0 = lock step; 1 = clock_stream_tm.  sdk::tuning().clock_mode pins it (A / B).
+  const int forced = (int)sdk::tuning().clock_mode;
   const float bhint = 2.0f * p.bmin;
   int steps = (int)ceilf(0.5f / bhint) + 1;
   const int mode = forced >= 0 ? forced : (steps <= 25 ? 2 : 0);

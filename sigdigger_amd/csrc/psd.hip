@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "kernels.hpp"
+#include "tuning.hpp"
 
 #include "fft_core.hpp"
 
@@ -359,8 +360,7 @@ template <int LOG2N, int THREADS>
 hipError_t launch_psd(const void *x, long long hop, int navg, const float *window, const void *tw,
                       float scale, int mode, float *out, long long nout, float *partial, int S, hipStream_t st)
 {
-  static int force = -2;                                     // SUAMD_PSD_STREAM=0/1 pins the policy (measurements)
-  if (force == -2) { const char *e = getenv("SUAMD_PSD_STREAM"); force = e ? atoi(e) : -1; }
+  const int force = (int)sdk::tuning().psd_stream;           // 0 / 1 pins the policy (measurements)
   const bool stream = force >= 0 ? force != 0 : nout * navg * hop * 8 > PSD_STREAM_BYTES;
   return stream ? launch_psd_p<LOG2N, THREADS, true>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st)
                 : launch_psd_p<LOG2N, THREADS, false>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st);
@@ -382,14 +382,8 @@ int psd_split(long long nout, int navg, int log2n)
   // outputs: 4096-pt 463 us split over 512 workgroups, 407 us over 1024; 8192-pt 540-585 / 565 / 543 us over 512 /
   // 1024 / 2048; 16384-pt 570 / 586 / 605 us.  On a 4 Mi analyzer block minf decides (8192-pt 25.6 us at minf = 2,
   // 30.6 us at 4; 16384-pt 28.8 vs 44.8 us).  An input with nout >= target never splits.
-  static int target_env = 0, minf = 0;
-  if (minf == 0) {
-    const char *e = getenv("SUAMD_PSD_SPLIT_TARGET");
-    target_env = e ? atoi(e) : -1;
-    e = getenv("SUAMD_PSD_MIN_FRAMES");
-    minf = e ? atoi(e) : 2;
-    if (minf < 1) minf = 1;
-  }
+  const int target_env = sdk::tuning().psd_split_target > 0 ? (int)sdk::tuning().psd_split_target : -1;
+  const int minf = sdk::tuning().psd_min_frames > 0 ? (int)sdk::tuning().psd_min_frames : 2;
   // (round 4: 8192 points 512 -> 256 and 16384 points 512 -> 256 workgroups.  16384 points fit ONE workgroup per CU, so 512
   // was two rounds: 48.5 -> 42.1 us per 16 Mi samples.  8192 points fit two per CU, and 512 workgroups of 4 frames for
   // exactly 512 slots is what the analyzer pipeline cannot give: its three recurrence wavefronts take a slot each, the
@@ -431,8 +425,7 @@ hipError_t psd_frames_32k(const void *x, long long hop, int navg, const float *w
 {
   if (nout <= 0) return hipSuccess;
   const int S = partial ? psd_split(2 * nout, navg, 14) : 1;
-  static int force = -2;
-  if (force == -2) { const char *e = getenv("SUAMD_PSD_STREAM"); force = e ? atoi(e) : -1; }
+  const int force = (int)sdk::tuning().psd_stream;
   const bool stream = force >= 0 ? force != 0 : nout * navg * hop * 8 > PSD_STREAM_BYTES;
   return stream ? launch_psd_p<14, 512, true, true>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st, tw2)
                 : launch_psd_p<14, 512, false, true>(x, hop, navg, window, tw, scale, mode, out, nout, partial, S, st, tw2);

@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "kernels.hpp"
+#include "tuning.hpp"
 #include "fft_core.hpp"
 #include "fft_reg.hpp"
 
@@ -242,7 +243,7 @@ namespace sdk {
 // how N = 2^log2n splits: pass A transforms 2^log2n2 points per thread on registers, pass B rows of 2^(log2n - log2n2)
 int psd_large_log2n2(int log2n)
 {
-  static const int force = [] { const char *e = getenv("SUAMD_PSD_LARGE_N2"); return e ? atoi(e) : 0; }();   // measurements
+  const int force = (int)sdk::tuning().psd_large_n2;           // measurements
   if ((force == 5 && log2n <= 19) || force == 6) return force;
   return log2n <= 17 ? 5 : 6;
 }

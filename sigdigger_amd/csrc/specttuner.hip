@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <type_traits>
 #include "kernels.hpp"
+#include "tuning.hpp"
 #include "fft_core.hpp"
 #include "sd_math.hpp"
 
@@ -316,7 +317,7 @@ hipError_t launch_st_v(const sdk::StArgs &a, hipStream_t st)
 template <int LOG2W, int LOG2S>
 hipError_t launch_st(const sdk::StArgs &a, hipStream_t st)
 {
-  static const int variant = [] { const char *e = getenv("SUAMD_ST_VARIANT"); return e ? atoi(e) : 0; }();
+  const int variant = (int)sdk::tuning().st_variant;
   switch (variant) {
     case 1:  return launch_st_v<LOG2W, LOG2S, 2, true, 1>(a, st);
     case 2:  return launch_st_v<LOG2W, LOG2S, 4, false, 1>(a, st);
@@ -342,8 +343,7 @@ int st_channels_per_group(int log2s) { return log2s == 5 ? 64 : (log2s < 4 ? 256
 
 bool st_two_turns(int log2s, int nchan)
 {
-  const char *engl = getenv("SUAMD_ST_NGL");                    // (read on every launch: A / B tests switch it in-process)
-  const int ngl_env = engl ? atoi(engl) : 0;
+  const int ngl_env = (int)sdk::tuning().st_ngl;               // (read on every launch: A / B tests switch it in-process)
   const int cpp = st_channels_per_group(log2s);
   const int ngroups = (nchan + cpp - 1) / cpp;
   return log2s >= 7 && log2s <= 11 && (ngl_env ? ngl_env : (ngroups >= 2 ? 2 : 1)) >= 2;

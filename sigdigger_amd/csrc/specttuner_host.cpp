@@ -4,6 +4,12 @@
 //                        Tasks/LPFTask.cpp:52-69,83-87,104-107,123 is written against -- it links unchanged.
 // Channel geometry and the frequency response are designed here in double precision (not on the hot path); there is
 // no CPU implementation of the channeliser itself: without a gfx950 device the constructors fail.
+// phase clocks (STW_TSTAMP) and the wrong-result timing experiments (STP_UNSAFE_*) exist in the instrumented build only
+#ifndef SUAMD_INSTRUMENT
+#undef STW_TSTAMP
+#undef STP_UNSAFE_NO_EXCHANGE
+#undef STP_UNSAFE_NO_ALIAS_BARRIERS
+#endif
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -17,6 +23,7 @@
 
 #include "../../include/sigdigger_amd.h"
 #include "kernels.hpp"
+#include "tuning.hpp"
 
 void suamd_set_error(const char *fmt, ...);                // capi.hip
 
@@ -376,9 +383,13 @@ suamd_specttuner_t *suamd_specttuner_new(suamd_ctx_t *ctx, unsigned window_size)
   auto *st = new (std::nothrow) suamd_specttuner();
   if (!st) { suamd_set_error("out of memory"); return nullptr; }
   st->ctx = ctx; st->W = window_size; st->H = window_size / 2; st->log2w = 12;
-  if (const char *e = std::getenv("SUAMD_ST_RUN")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) st->run = st->run_wave = (unsigned)v; }   // tuning knob
-  if (const char *e = std::getenv("SUAMD_ST_KERNEL")) { st->use_wave = std::strcmp(e, "wg") != 0; st->use_pair = std::strcmp(e, "wave") != 0 && st->use_wave; }
-  if (const char *e = std::getenv("SUAMD_ST_SEAM_POLLS")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 20)) st->seam_polls = v; }
+  {
+    const sdk::Tuning &tn = sdk::tuning();                    // (a tuner keeps the plan it was made under)
+    if (tn.st_run >= 1) st->run = st->run_wave = (unsigned)tn.st_run;
+    st->use_wave = tn.st_kernel != 2;
+    st->use_pair = tn.st_kernel == 0;
+    if (tn.st_seam_polls >= 0) st->seam_polls = (int)tn.st_seam_polls;
+  }
   st->d_tw_w = dev_upload_new(twiddles(st->W));
   bool ok = st->d_tw_w != nullptr;
   for (int p = 0; p < 2 && ok; ++p) ok = hipMalloc((void **)&st->d_hist[p], st->H * sizeof(c32)) == hipSuccess;
@@ -562,8 +573,7 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
           // 32-bit buffer addressing of the outputs when the whole view of this feed lies below 2 GiB
           const long long hs = (1ll << g.log2s) / 2;
           const long long last = ((long long)st->ch.size() * (long long)view.chan_stride + (nwin * hs + hs) * (long long)view.time_stride) * 8;
-          const char *ey = std::getenv("SUAMD_ST_Y32");          // debug: 64-bit addressing everywhere (read on every feed)
-          const bool no_y32 = ey && ey[0] == '0';
+          const bool no_y32 = sdk::tuning().st_y32 == 0;          // debug: 64-bit addressing everywhere
           a.y32 = (!d_rows && last < (1ll << 31) && !no_y32) ? 1 : 0;
           // rows promised to start within rows_span bytes of d_y: offsets from there, if the feed's own extent fits too
           if (d_rows && rows_span && !no_y32 && (long long)rows_span + (nwin * hs + hs) * 8 < (1ll << 31)) a.y32 = 1;
@@ -573,7 +583,7 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
           const long long ny = ((long long)g.members.size() + sdk::stw_channels_per_wave(g.log2s) - 1) / sdk::stw_channels_per_wave(g.log2s);
           // (SUAMD_ST_SLOTS: the wavefront budget of a launch, default 768; a long block rounds up to whole windows per
           // wavefront far below the budget anyway, and there a larger budget is pure gain)
-          static const long long slots = [] { const char *e = std::getenv("SUAMD_ST_SLOTS"); const long long v = e ? std::atoll(e) : 0; return v >= 64 && v <= 4096 ? v : 0; }();
+          const long long slots = sdk::tuning().st_slots >= 64 ? sdk::tuning().st_slots : 0;
           const long long budget = st->slots ? st->slots : (slots ? slots : 768);
           a.run = (int)std::max<long long>(1, (nwin * ny + budget - 1) / budget);
         }
@@ -607,7 +617,7 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
         const bool pair = st->use_pair && a.nsel >= 1 && a.nsel <= sdk::stp_max_responses() && a.run >= 2 && (a.y32 || g.log2s >= 5);
         e = pair ? sdk::specttuner_feed_pair(g.log2s, a, s) : sdk::specttuner_feed_wave(g.log2s, a, s);
 #ifdef STW_TSTAMP
-        if (std::getenv("SUAMD_STW_TSTAMP")) {
+        {
           (void)hipStreamSynchronize(s);
           std::vector<unsigned long long> ts(nts);
           (void)hipMemcpy(ts.data(), d_ts, nts * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -644,9 +654,8 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
           // Banks that fit one workgroup side by side only (measured per 4 Mi samples, tools/st_wide.py: one channel of 256
           // bins 49.1 -> 44.7 us, of 128 bins 46.6 -> 40.3; 64 x 256 bins 136 -> 143, 128 x 256 267 -> 284: there a run is
           // long and the warm-up window a ninth of it, less than the second launch costs).  SUAMD_ST_SEAM=0 / 1: never / always.
-          // (read on every feed, like SUAMD_FIR_STREAM: a test that flips it inside one process must get the other path)
-          const char *e2 = std::getenv("SUAMD_ST_SEAM");
-          const int seam_env = e2 ? (e2[0] == '0' ? 0 : 1) : -1;
+          // (sdk::tuning().st_seam, read on every feed: a test that flips it inside one process gets the other path)
+          const int seam_env = (int)sdk::tuning().st_seam;
           const size_t nruns = (size_t)((nwin + a.run - 1) / a.run);
           // st_seam_kernel takes the runs in grid.y: beyond 65535 of them (one-window runs of a narrow size on a very long
           // feed) the launch keeps its warm-up windows instead

@@ -13,12 +13,19 @@
 // Each wavefront runs its own specialisation of the code (p is a template parameter), so the W_64 twiddles stay the
 // compile-time constants they are in the one-wavefront kernel.  Loads, transposition, spectrum, bin gather and stores
 // can hand any lane any element, so only the three mid-DFT swaps are new traffic.
+// phase clocks (STW_TSTAMP) and the wrong-result timing experiments (STP_UNSAFE_*) exist in the instrumented build only
+#ifndef SUAMD_INSTRUMENT
+#undef STW_TSTAMP
+#undef STP_UNSAFE_NO_EXCHANGE
+#undef STP_UNSAFE_NO_ALIAS_BARRIERS
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
 #include "kernels.hpp"
+#include "tuning.hpp"
 #include "fft_core.hpp"
 #include "fft_reg.hpp"
 #include "sd_math.hpp"
@@ -551,7 +558,7 @@ hipError_t launch_stp(const sdk::StArgs &a, hipStream_t st)
   const unsigned ny = (unsigned)((a.nchan + NG * WAVE - 1) / (NG * WAVE));
   // LDS: transposition / spectrum buffer, flag word, response tables -- and, when the launch has at most three
   // workgroups per CU anyway (768 of the 1024 window slots) and a third of the LDS holds it, the forward swaps' own 16 KiB
-  static const bool no_sep = [] { const char *e = getenv("SUAMD_ST_PAIR_SEP"); return e && e[0] == '0'; }();
+  const bool no_sep = sdk::tuning().st_pair_sep == 0;
   const int base = PW_TAB + a.nsel * ((1 << LOG2S) + 2);
   // (52 KB, not 160 / 3 = 53.3: the LDS is handed out in blocks, and a workgroup of 53.2 KB measured TWO per CU)
   const bool sep = (unsigned long long)nruns * ny <= 768 && !no_sep && (base + 2 * PW_EX) * 8 <= 52 * 1024;

@@ -19,6 +19,12 @@
 // A workgroup (= one wavefront) owns a run of consecutive windows; the cross-fade partner at the seam between two runs is
 // handed over through global memory (see handoff_store); 4 workgroups fit a CU (33 KB of LDS each), one per SIMD, each with the full 512-register file:
 // the instruction-level parallelism of 64 independent points per lane is what keeps the SIMD busy.
+// phase clocks (STW_TSTAMP) and the wrong-result timing experiments (STP_UNSAFE_*) exist in the instrumented build only
+#ifndef SUAMD_INSTRUMENT
+#undef STW_TSTAMP
+#undef STP_UNSAFE_NO_EXCHANGE
+#undef STP_UNSAFE_NO_ALIAS_BARRIERS
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

@@ -59,6 +59,47 @@ def kernel_timing_read(kernel=None):
     return {"sum_ms": s.value, "min_ms": lo.value, "max_ms": hi.value, "launches": n.value}
 
 
+def tuning_set(name, value):
+    """suamd_tuning_set: one field of the library's tuning struct (csrc/tuning.hpp) by its name or its SUAMD_* environment
+    name -- how the A / B tests pick a kernel or a plan inside one process (the environment itself is read once)."""
+    check(_l.load().suamd_tuning_set(name.encode(), int(value)), "suamd_tuning_set")
+
+
+def tuning_get(name):
+    v = C.c_longlong()
+    check(_l.load().suamd_tuning_get(name.encode(), C.byref(v)), "suamd_tuning_get")
+    return v.value
+
+
+def tuning_fields():
+    """[(name, env, default, lo, hi, doc)] of every tuning field"""
+    out, i = [], 0
+    n, e, d = C.c_char_p(), C.c_char_p(), C.c_char_p()
+    df, lo, hi = C.c_longlong(), C.c_longlong(), C.c_longlong()
+    while _l.load().suamd_tuning_describe(i, C.byref(n), C.byref(e), C.byref(df), C.byref(lo), C.byref(hi), C.byref(d)):
+        out.append((n.value.decode(), e.value.decode(), df.value, lo.value, hi.value, d.value.decode()))
+        i += 1
+    return out
+
+
+class tuned:
+    """with engine.tuned(SUAMD_ST_SEAM=0, clock_mode=1): ... -- fields set for the block, restored after"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: tuning_get(k) for k in self.kw}
+        for k, v in self.kw.items():
+            tuning_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            tuning_set(k, v)
+        return False
+
+
 def time_major(nchan, length, device, dtype=torch.complex64):
     """[channels, time] tensor stored time-major ([time][channel] in memory): the layout the
     one-lane-per-channel kernels stream with one contiguous access per wavefront."""

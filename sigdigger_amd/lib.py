@@ -42,6 +42,11 @@ PROTOTYPES = {
     "suamd_last_error": (C.c_char_p, []),
     "suamd_version": (C.c_char_p, []),
     "suamd_kernel_timing": (None, [C.c_int]),
+    "suamd_tuning_set": (C.c_int, [C.c_char_p, C.c_longlong]),
+    "suamd_tuning_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_longlong)]),
+    "suamd_tuning_describe": (C.c_int, [C.c_uint, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                        C.POINTER(C.c_longlong), C.POINTER(C.c_char_p)]),
+    "suamd_tuning_reset": (None, []),
     "suamd_kernel_timing_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint)]),
     "suamd_ctx_new": (VP, [INT]),
     "suamd_ctx_destroy": (None, [VP]),

@@ -43,3 +43,35 @@ def ctx():
     c = engine.Context(0)
     yield c
     c.close()
+
+
+class _Tune:
+    """The library's tuning struct (csrc/tuning.hpp) through the C ABI, with monkeypatch's verbs: the SUAMD_* environment is
+    read once per process, so an A / B test sets the FIELD (by its environment name, words as the environment takes them)
+    and the fixture puts every touched field back."""
+    WORDS = {"SUAMD_ST_KERNEL": {"pair": 0, "wave": 1, "wg": 2}, "SUAMD_PSD_LARGE": {"passes": 0, "twotrip": 1}}
+
+    def __init__(self):
+        from sigdigger_amd import engine
+        self.engine, self.touched = engine, {}
+
+    def setenv(self, name, value):
+        if name not in self.touched:
+            self.touched[name] = self.engine.tuning_get(name)
+        v = self.WORDS.get(name, {}).get(str(value))
+        self.engine.tuning_set(name, int(value) if v is None else v)
+
+    def delenv(self, name, raising=True):
+        if name in self.touched:
+            self.engine.tuning_set(name, self.touched[name])
+
+    def restore(self):
+        for k, v in self.touched.items():
+            self.engine.tuning_set(k, v)
+
+
+@pytest.fixture
+def tune():
+    t = _Tune()
+    yield t
+    t.restore()

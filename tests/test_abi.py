@@ -252,3 +252,38 @@ def test_source_config_round_trips_what_source_cpp_reads():
     assert L.suscan_source_info_init_copy(C.byref(b), C.byref(a)) and b.frequency == 1e9 and b.history_length == 77
     L.suscan_source_info_finalize(C.byref(b))
     L.suscan_source_info_finalize(C.byref(a))
+
+
+def test_tuning_struct_through_the_abi():
+    """csrc/tuning.hpp: one documented struct for every knob that changes HOW the library computes; the SUAMD_* environment
+    is read once, suamd_tuning_set / _get / _describe / _reset do the rest (no GPU involved)."""
+    from sigdigger_amd import engine
+    fields = engine.tuning_fields()
+    names = {f[0] for f in fields}
+    assert len(fields) >= 25 and {"st_slots", "st_seam", "fir_stream", "psd_large_batch", "clock_mode", "analyzer_subranges"} <= names
+    for name, env, dflt, lo, hi, doc in fields:
+        assert env.startswith("SUAMD_") and lo <= dflt <= hi and len(doc) > 10, name
+        assert engine.tuning_get(name) == engine.tuning_get(env)
+    old = engine.tuning_get("clock_mode")
+    try:
+        engine.tuning_set("SUAMD_CLOCK_MODE", 1)
+        assert engine.tuning_get("clock_mode") == 1
+        with engine.tuned(clock_mode=0, st_slots=1024):
+            assert engine.tuning_get("clock_mode") == 0 and engine.tuning_get("SUAMD_ST_SLOTS") == 1024
+        assert engine.tuning_get("clock_mode") == 1
+        import pytest
+        with pytest.raises(Exception):
+            engine.tuning_set("clock_mode", 7)                   # outside the field's range
+        with pytest.raises(Exception):
+            engine.tuning_set("no_such_field", 1)
+    finally:
+        engine.tuning_set("clock_mode", old)
+    # no translation unit of the product reads a tuning variable behind the struct's back
+    import glob, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    envs = {f[1] for f in fields}
+    for path in glob.glob(os.path.join(root, "sigdigger_amd", "csrc", "*")):
+        if path.endswith(("tuning.cpp", "tuning.hpp", ".o", ".sha256")):
+            continue
+        for m in re.finditer(r'getenv\("(SUAMD_[A-Z0-9_]+)"\)', open(path, errors="ignore").read()):
+            assert m.group(1) not in envs, (os.path.basename(path), m.group(1))

@@ -164,6 +164,7 @@ def test_a_shard_that_dies_mid_broadcast_does_not_hang_the_analyzer(tmp_path, sd
     monkeypatch.setenv("SUAMD_ANALYZER_BCAST_TIMEOUT_MS", "300")
     monkeypatch.setenv("STANDIN_GRACE_MS", "150")
     monkeypatch.setenv("SUAMD_DEVICES", "0,0,0")
+    monkeypatch.setenv("SUAMD_TEST_HOOKS", "1")
     monkeypatch.setenv("SUAMD_ANALYZER_FAULT", "shard_dies:1:6")
     nblocks, dies_at = 14, 6
     chans = [(125e3, 40e3), (-200e3, 40e3), (310e3, 9e3), (0.0, 300e3), (-50e3, 2.5e3), (220e3, 40e3)]

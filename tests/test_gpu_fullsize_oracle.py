@@ -202,7 +202,7 @@ def test_the_pipeline_as_bench_py_builds_it_is_exact_end_to_end(ctx, sdo, worklo
 
 
 @pytest.mark.parametrize("nchan", [1, 2])
-def test_c2_fir_stage_at_the_benched_block_size_equals_the_oracle(ctx, sdo, monkeypatch, nchan):
+def test_c2_fir_stage_at_the_benched_block_size_equals_the_oracle(ctx, sdo, tune, nchan):
     """BASELINE configs[1] as written -- translate + 255-tap low-pass, D = 16 -- on bench.py's block (16 Mi samples) and the
     next, ragged one, in both shapes of chan_pair_kernel: independent 256-output tiles (the default) and the persistent
     one (SUAMD_FIR_PAIR_NW=8: runs of four 1024-output tiles per workgroup at this size, the history handed on inside the
@@ -221,19 +221,19 @@ def test_c2_fir_stage_at_the_benched_block_size_equals_the_oracle(ctx, sdo, monk
     xd = torch.from_numpy(x).cuda()
     res = {}
     for mode, nw in (("1", None), ("1", "8"), ("0", None)):
-        monkeypatch.setenv("SUAMD_FIR_STREAM", mode)
+        tune.setenv("SUAMD_FIR_STREAM", mode)
         if nw:
-            monkeypatch.setenv("SUAMD_FIR_PAIR_NW", nw)
+            tune.setenv("SUAMD_FIR_PAIR_NW", nw)
         else:
-            monkeypatch.delenv("SUAMD_FIR_PAIR_NW", raising=False)
+            tune.delenv("SUAMD_FIR_PAIR_NW", raising=False)
         bank = engine.ChannelBank(ctx, fn, D, taps)
         got = []
         for a, b in zip(cuts[:-1], cuts[1:]):
             out = torch.empty((nchan, bank.output_count(b - a) + 3), dtype=torch.complex64, device="cuda")
             got.append(bank.feed(xd[a:b], out=out).cpu().numpy())
         res[mode + (nw or "")] = np.concatenate(got, axis=1)
-    monkeypatch.delenv("SUAMD_FIR_STREAM")
-    monkeypatch.delenv("SUAMD_FIR_PAIR_NW", raising=False)
+    tune.delenv("SUAMD_FIR_STREAM")
+    tune.delenv("SUAMD_FIR_PAIR_NW", raising=False)
     assert np.array_equal(bits(res["1"]), bits(res["0"])), "pair kernel (independent tiles) vs chan_fir_kernel"
     assert np.array_equal(bits(res["18"]), bits(res["0"])), "pair kernel (persistent stream) vs chan_fir_kernel"
     for c, f in enumerate(fn):

@@ -124,30 +124,30 @@ def test_psd_large_frames(ctx, sdo, n, nframes, navg):
 
 
 @pytest.mark.parametrize("n,path", [(65536, None), (32768, "twotrip"), (32768, None)])
-def test_psd_large_frames_batches_do_not_change_the_bits(ctx, sdo, monkeypatch, n, path):
+def test_psd_large_frames_batches_do_not_change_the_bits(ctx, sdo, tune, n, path):
     """The two-trip large-frame path (psd_large.hip: 65536 points and up; 32768 with SUAMD_PSD_LARGE=twotrip) sends its
     frames through in batches; where a batch ends -- inside an output, inside a chunk of an output's sum, on its last
     frame, several outputs later -- must not show in the result.  (32768 points by default take ONE trip -- two
     workgroups per output on the 16384-point kernel, psd.hip HALVES -- and know no batches: the knob must change nothing.)"""
     if path:
-        monkeypatch.setenv("SUAMD_PSD_LARGE", path)
+        tune.setenv("SUAMD_PSD_LARGE", path)
     nframes, navg = 40, 13
     x = synth.tone_noise(n * nframes, f_rel=-0.1203, sigma2=1e-2, seed=5)
     psd = engine.PSD(ctx, n, engine.WINDOW_BLACKMANN_HARRIS)
     whole = host(psd.feed(dev(x), nframes=nframes, navg=navg, scale=1.0 / n))              # one batch of 39 frames
     assert whole.shape == (3, n)
     for b in ("1", "7", "13", "20"):
-        monkeypatch.setenv("SUAMD_PSD_LARGE_BATCH", b)
+        tune.setenv("SUAMD_PSD_LARGE_BATCH", b)
         part = host(psd.feed(dev(x), nframes=nframes, navg=navg, scale=1.0 / n))
         assert np.array_equal(part.view(np.uint32), whole.view(np.uint32)), b
-    monkeypatch.delenv("SUAMD_PSD_LARGE_BATCH")
+    tune.delenv("SUAMD_PSD_LARGE_BATCH")
     ref = sdo.psd_frames(x, nframes, n, n, sdo.window(4, n), navg=navg, scale=1.0 / n)
     err = np.max(np.abs(whole - ref), axis=1) / np.max(ref, axis=1)
     assert np.all(err < PSD_TOL), err
 
 
 @pytest.mark.parametrize("n,navg", [(65536, 5), (65536, 13), (1 << 17, 3)])
-def test_psd_large_frames_many_outputs_of_ragged_chunks(ctx, sdo, monkeypatch, n, navg):
+def test_psd_large_frames_many_outputs_of_ragged_chunks(ctx, sdo, tune, n, navg):
     """Many outputs in ONE batch with navg no multiple of the chunk length (the ring of chunk sums was sized by
     batch / chunk, but an output takes ceil(navg / chunk) chunks, so chunks of one batch shared slots and the outputs came
     out silently wrong from 64 outputs on).  Overlapping frames keep the input small; one batch against frame-by-frame
@@ -158,11 +158,11 @@ def test_psd_large_frames_many_outputs_of_ragged_chunks(ctx, sdo, monkeypatch, n
     psd = engine.PSD(ctx, n, engine.WINDOW_HANN)
     whole = host(psd.feed(dev(x), nframes=nframes, hop=hop, navg=navg, scale=1.0 / n))
     assert whole.shape == (nout, n)
-    monkeypatch.setenv("SUAMD_PSD_LARGE_BATCH", "1")
+    tune.setenv("SUAMD_PSD_LARGE_BATCH", "1")
     single = host(psd.feed(dev(x), nframes=nframes, hop=hop, navg=navg, scale=1.0 / n))
-    monkeypatch.setenv("SUAMD_PSD_LARGE_BATCH", str(3 * navg + 1))
+    tune.setenv("SUAMD_PSD_LARGE_BATCH", str(3 * navg + 1))
     some = host(psd.feed(dev(x), nframes=nframes, hop=hop, navg=navg, scale=1.0 / n))
-    monkeypatch.delenv("SUAMD_PSD_LARGE_BATCH")
+    tune.delenv("SUAMD_PSD_LARGE_BATCH")
     assert np.array_equal(whole.view(np.uint32), single.view(np.uint32))
     assert np.array_equal(whole.view(np.uint32), some.view(np.uint32))
     ref = sdo.psd_frames(x, nframes, n, hop, sdo.window(2, n), navg=navg, scale=1.0 / n)
@@ -339,7 +339,7 @@ def test_chanbank_bit_exact(ctx, sdo, nchan, D, T):
 
 @pytest.mark.parametrize("nchan,D,T", [(1, 16, 255), (2, 16, 255), (1, 8, 255), (1, 32, 255), (1, 64, 255), (2, 64, 129),
                                        (1, 16, 16), (1, 16, 7), (1, 16, 1), (1, 16, 1023), (2, 32, 64), (1, 8, 33)])
-def test_chanbank_stream_kernel_equals_the_tiled_one_and_the_oracle(ctx, sdo, monkeypatch, nchan, D, T):
+def test_chanbank_stream_kernel_equals_the_tiled_one_and_the_oracle(ctx, sdo, tune, nchan, D, T):
     """chan_stream.hip (one or two channels, lane = two adjacent outputs, scalar taps) against chan_fir_kernel
     (SUAMD_FIR_STREAM=0) bit for bit -- feeds of ragged sizes (a tile boundary inside, a feed shorter than a tile, an
     odd start so that the first history pair straddles hist / x), both layouts, and each tile shape the dispatch can pick:
@@ -353,11 +353,11 @@ def test_chanbank_stream_kernel_equals_the_tiled_one_and_the_oracle(ctx, sdo, mo
     cuts = [0, 70001, 70002, 70002 + 64 * 8 * D + 3, 200000 - 1, n]
     res = {}
     for mode, nw in (("1", None), ("1", "8"), ("1", "4"), ("0", None)):
-        monkeypatch.setenv("SUAMD_FIR_STREAM", mode)
+        tune.setenv("SUAMD_FIR_STREAM", mode)
         if nw:
-            monkeypatch.setenv("SUAMD_FIR_PAIR_NW", nw)
+            tune.setenv("SUAMD_FIR_PAIR_NW", nw)
         else:
-            monkeypatch.delenv("SUAMD_FIR_PAIR_NW", raising=False)
+            tune.delenv("SUAMD_FIR_PAIR_NW", raising=False)
         for layout in ("cm", "tm"):
             bank = engine.ChannelBank(ctx, fn, D, taps)
             got = []
@@ -365,8 +365,8 @@ def test_chanbank_stream_kernel_equals_the_tiled_one_and_the_oracle(ctx, sdo, mo
                 out = empty_rows(nchan, bank.output_count(b - a) + 3, layout)
                 got.append(host(bank.feed(dev(x[a:b]), out=out)))
             res[mode, nw, layout] = np.concatenate(got, axis=1)
-    monkeypatch.delenv("SUAMD_FIR_STREAM")
-    monkeypatch.delenv("SUAMD_FIR_PAIR_NW", raising=False)
+    tune.delenv("SUAMD_FIR_STREAM")
+    tune.delenv("SUAMD_FIR_PAIR_NW", raising=False)
     for layout in ("cm", "tm"):
         for nw in (None, "8", "4"):
             assert_bits(res["1", nw, layout], res["0", None, layout], f"stream (NW = {nw or 'auto'}) vs tiled kernel ({layout})")

@@ -89,7 +89,7 @@ def test_any_split_of_the_stream_gives_the_same_samples(ctx):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (splits, run)
 
 
-def test_a_run_that_cannot_get_its_seam_payload_transforms_the_seam_window_itself(ctx, monkeypatch):
+def test_a_run_that_cannot_get_its_seam_payload_transforms_the_seam_window_itself(ctx, tune):
     """The wavefront kernel hands the block at the seam of two runs over through global memory; a run whose successor has
     not published in time (not resident: the device full of something else) computes that block itself.  Forced here with
     a zero wait budget: every run takes the fallback, and the samples are those of the normal path bit for bit."""
@@ -97,7 +97,7 @@ def test_a_run_that_cannot_get_its_seam_payload_transforms_the_seam_window_itsel
     chans = [(0.3 + 0.09 * c, 2 * np.pi / 64 * 0.7, 1.0, bool(c % 3 == 0)) for c in range(70)]       # two blocks of 64 lanes
     chans += [(1.1, 2 * np.pi / 16 * 0.8, 1.0, False)]
     ref = run_gpu(ctx, x, chans, splits=[H * 13], run=3)
-    monkeypatch.setenv("SUAMD_ST_SEAM_POLLS", "0")
+    tune.setenv("SUAMD_ST_SEAM_POLLS", "0")
     for run in (1, 3):
         got = run_gpu(ctx, x, chans, splits=[H * 13], run=run)
         for a, b in zip(ref, got):
@@ -339,25 +339,25 @@ def test_reset_forgets_the_stream_position_and_closing_the_higher_channel_is_saf
     t.close()
 
 
-def test_two_wavefronts_per_window_equal_one_bit_for_bit(ctx, monkeypatch):
+def test_two_wavefronts_per_window_equal_one_bit_for_bit(ctx, tune):
     """64-bin channels with one response run on specttuner_pair.hip (two wavefronts per window, every 64-point DFT split
     between them); SUAMD_ST_KERNEL=wave keeps them on the one-wavefront kernel.  Same samples bit for bit -- runs of two
     and three windows, the seam hand-off, a residual NCO, more channels than one workgroup serves, 64-bit row
     addressing, and whatever slot budget plans the launch."""
     x = cnoise(H * 96, 77)
     chans = [(0.2 + 0.085 * c, 2 * np.pi / 64 * 0.75, 1.0, bool(c % 5 == 0)) for c in range(70)]
-    monkeypatch.setenv("SUAMD_ST_KERNEL", "wave")
+    tune.setenv("SUAMD_ST_KERNEL", "wave")
     ref = run_gpu(ctx, x, chans, splits=[H * 40], run=3)
-    monkeypatch.delenv("SUAMD_ST_KERNEL")
+    tune.delenv("SUAMD_ST_KERNEL")
     for run, tm in ((2, False), (3, True), (7, False)):
         got = run_gpu(ctx, x, chans, splits=[H * 40], run=run, time_major=tm)
         for a, b in zip(ref, got):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (run, tm)
-    monkeypatch.setenv("SUAMD_ST_Y32", "0")
+    tune.setenv("SUAMD_ST_Y32", "0")
     got = run_gpu(ctx, x, chans, splits=[H * 40], run=2)
     for a, b in zip(ref, got):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-    monkeypatch.delenv("SUAMD_ST_Y32")
+    tune.delenv("SUAMD_ST_Y32")
     # slot budgets: 64 slots -> runs of two windows on a 96-window stream, 1024 -> runs of one (the one-wavefront kernel)
     for slots in (64, 1024, 0):
         st = engine.SpectTuner(ctx, W)
@@ -378,7 +378,7 @@ def test_two_wavefronts_per_window_equal_one_bit_for_bit(ctx, monkeypatch):
 
 
 @pytest.mark.parametrize("seed", range(16))
-def test_random_banks_and_splits_two_wavefront_kernel_against_one(ctx, monkeypatch, seed):
+def test_random_banks_and_splits_two_wavefront_kernel_against_one(ctx, tune, seed):
     """Seeded fuzz of the kernel choice: random channel counts (partial last workgroup, several workgroups), run lengths,
     feed boundaries and residual NCOs -- the two-wavefront kernel and the one-wavefront kernel must agree on every bit,
     whichever mixture of them the run lengths select."""
@@ -393,9 +393,9 @@ def test_random_banks_and_splits_two_wavefront_kernel_against_one(ctx, monkeypat
     widths = [[0.75], [0.75, 0.6, 0.5, 0.9, 0.4], list(np.linspace(0.3, 0.95, 40))][int(r.integers(0, 3))]
     chans = [(float(r.uniform(0, 2 * np.pi)), 2 * np.pi / dec * float(r.choice(widths)), 1.0, bool(r.integers(0, 4) == 0)) for _ in range(nch)]
     cuts = sorted(set(int(c) * H for c in r.integers(1, nwin, size=int(r.integers(0, 4)))))
-    monkeypatch.setenv("SUAMD_ST_KERNEL", "wave")
+    tune.setenv("SUAMD_ST_KERNEL", "wave")
     ref = run_gpu(ctx, x, chans, splits=cuts, run=int(r.integers(1, 6)))
-    monkeypatch.delenv("SUAMD_ST_KERNEL")
+    tune.delenv("SUAMD_ST_KERNEL")
     for _ in range(2):
         run = int(r.integers(2, 9))
         got = run_gpu(ctx, x, chans, splits=cuts, run=run, time_major=bool(r.integers(0, 2)))
@@ -444,7 +444,7 @@ def test_row_tables_with_32_bit_offsets_give_the_same_samples(ctx, dec):
 
 
 @pytest.mark.parametrize("dec,nch", [(512, 5), (512, 64), (256, 70), (128, 3)])
-def test_few_narrow_channels_with_their_own_responses_on_the_one_wavefront_kernel(ctx, monkeypatch, dec, nch):
+def test_few_narrow_channels_with_their_own_responses_on_the_one_wavefront_kernel(ctx, tune, dec, nch):
     """A bank far smaller than one wavefront serves (64 lanes x dec / 64 channels) with a pass-band width per channel, kept on
     the one-wavefront kernel: it loads a response block for EVERY lane group, present or not, so the [block][bin][lane]
     table must hold whole wavefronts' worth.  Rounds 2-3 sized it by the channel count -- an over-read of up to 28 KiB that
@@ -453,19 +453,19 @@ def test_few_narrow_channels_with_their_own_responses_on_the_one_wavefront_kerne
     x = cnoise(H * 40, 4242)
     widths = np.linspace(0.35, 0.9, 7)
     chans = [(0.1 + 6.0 * c / nch, 2 * np.pi / dec * float(widths[c % 7]), 1.0, bool(c % 3 == 0)) for c in range(nch)]
-    monkeypatch.setenv("SUAMD_ST_KERNEL", "wave")
+    tune.setenv("SUAMD_ST_KERNEL", "wave")
     one = run_gpu(ctx, x, chans, splits=[H * 13])
-    monkeypatch.setenv("SUAMD_ST_Y32", "0")
+    tune.setenv("SUAMD_ST_Y32", "0")
     one64 = run_gpu(ctx, x, chans, splits=[H * 13])
-    monkeypatch.delenv("SUAMD_ST_Y32")
-    monkeypatch.delenv("SUAMD_ST_KERNEL")
+    tune.delenv("SUAMD_ST_Y32")
+    tune.delenv("SUAMD_ST_KERNEL")
     two = run_gpu(ctx, x, chans, splits=[H * 13])
     for a, b, c in zip(one, one64, two):
         assert a.size > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(a.view(np.uint32), c.view(np.uint32))
 
 
 @pytest.mark.parametrize("dec,nch", [(16, 1), (16, 5), (16, 40), (32, 70), (8, 3), (1, 1), (4, 2)])
-def test_wide_channels_without_the_warm_up_window(ctx, monkeypatch, dec, nch):
+def test_wide_channels_without_the_warm_up_window(ctx, tune, dec, nch):
     """The workgroup kernel's two ways over the seam of consecutive runs: a warm-up window per run (SUAMD_ST_SEAM=0: the
     window before the run is transformed again for its second half) and the hand-off (SUAMD_ST_SEAM=1: the run leaves its
     last second half in a buffer, st_seam_kernel completes the next run's first block) -- the same samples bit for bit,
@@ -489,11 +489,11 @@ def test_wide_channels_without_the_warm_up_window(ctx, monkeypatch, dec, nch):
     for run in (1, 2, 5, None):
         for tm in (False, True):
             # (the knob is read on every feed -- ADVICE r4: cached in a function-local static it compared a mode with itself)
-            monkeypatch.setenv("SUAMD_ST_SEAM", "0")
+            tune.setenv("SUAMD_ST_SEAM", "0")
             ref, n0 = seam_launches(lambda: run_gpu(ctx, x, chans, splits=[H * 9, H * 10, H * 31], run=run, time_major=tm))
-            monkeypatch.setenv("SUAMD_ST_SEAM", "1")
+            tune.setenv("SUAMD_ST_SEAM", "1")
             got, n1 = seam_launches(lambda: run_gpu(ctx, x, chans, splits=[H * 9, H * 10, H * 31], run=run, time_major=tm))
-            monkeypatch.delenv("SUAMD_ST_SEAM")
+            tune.delenv("SUAMD_ST_SEAM")
             assert n0 == 0, "SUAMD_ST_SEAM=0 still launched the seam kernel"
             if run in (1, 2, 5):
                 assert n1 > 0, "SUAMD_ST_SEAM=1 never launched the seam kernel: the two runs took the same path"
