@@ -603,7 +603,11 @@ SUAMD_API SUBOOL suamd_export_capture(suamd_ctx_t *ctx, const char *path, const 
  * returns the normalised baud (symbols per sample, x equiv_fs = Hz), 0 = no estimate.  Blocks shorter than `size`
  * leave the estimate as it is. */
 typedef struct suamd_baud_estimator suamd_baud_estimator_t;
-enum suamd_baud_estimator_kind { SUAMD_BAUD_ESTIMATOR_FAC = 0, SUAMD_BAUD_ESTIMATOR_NONLINEAR = 1 };
+/* kind 2, "carrier": the channel's residual carrier offset in cycles per sample, (-1/2, 1/2] -- the reference's own
+ * CarrierDetector computation (Tasks/CarrierDetector.cpp:99-137: window, transform, strongest bin, power-weighted phasor sum
+ * around it) with avgRelBw = 1/2 and no DC notch, on the first `size` samples of a block; x equiv_fs = what afc.offset takes
+ * (SPEC.md section M).  Same object, same calls as the two baud estimators. */
+enum suamd_baud_estimator_kind { SUAMD_BAUD_ESTIMATOR_FAC = 0, SUAMD_BAUD_ESTIMATOR_NONLINEAR = 1, SUAMD_ESTIMATOR_CARRIER = 2 };
 SUAMD_API suamd_baud_estimator_t *suamd_baud_estimator_new(suamd_ctx_t *ctx, int kind, unsigned size /* 2^k, 512..2^20 */);
 SUAMD_API void     suamd_baud_estimator_destroy(suamd_baud_estimator_t *e);
 SUAMD_API unsigned suamd_baud_estimator_size(const suamd_baud_estimator_t *e);

@@ -409,9 +409,10 @@ struct Inspector {
   uint32_t spectsrc_id = 0;                   // 0 = none (Suscan/Analyzer.cpp:539-547)
   suamd_power_bank_t *power = nullptr;         // class "power"
   suamd_audio_t *audio = nullptr;              // class "audio"
-  suamd_baud_estimator_t *est[2] = {nullptr, nullptr};   // "baud-fac", "baud-nonlinear" (estimator_list of the OPEN message)
-  bool est_on[2] = {false, false}, est_fed[2] = {false, false};
-  SUFLOAT last_est[2] = {0, 0};                           // a block too short for the analysis window repeats the last estimate
+  static constexpr int NEST = 3;
+  suamd_baud_estimator_t *est[NEST] = {nullptr, nullptr, nullptr};   // "baud-fac", "baud-nonlinear", "carrier" (estimator_list of the OPEN message)
+  bool est_on[NEST] = {false, false, false}, est_fed[NEST] = {false, false, false};
+  SUFLOAT last_est[NEST] = {0, 0, 0};                           // a block too short for the analysis window repeats the last estimate
   suamd_psd_t *spect_psd = nullptr;           // spectrum of the channel samples, one frame set per block
   unsigned spect_n = 0;
   suamd_complex *d_spre = nullptr;            // transformed samples
@@ -421,7 +422,7 @@ struct Inspector {
   // all inspectors work on the analyzer's inspector stream, stage by stage (enqueue_inspectors); results
   // land in pinned memory and become messages after one synchronisation (collect_inspectors)
   hipStream_t stream = nullptr;
-  struct Pinned { uint32_t count; float est[2]; float spec[8192]; } *pin = nullptr;   // D2H landing zone
+  struct Pinned { uint32_t count; float est[NEST]; float spec[8192]; } *pin = nullptr;   // D2H landing zone
   suamd_complex *h_out = nullptr;             // samples / symbols of the block, written by the device (mapped, cap long)
   SUSCOUNT pend_m = 0;                        // channel samples of the block in flight
   bool pend_samples = false, pend_spectrum = false, pend_symbols = false;
@@ -438,7 +439,7 @@ struct Inspector {
     uint32_t *d_count = nullptr;
     Pinned *pin = nullptr;
     SUSCOUNT pend_m = 0;
-    bool pend_samples = false, pend_spectrum = false, pend_symbols = false, est_fed[2] = {false, false};
+    bool pend_samples = false, pend_spectrum = false, pend_symbols = false, est_fed[NEST] = {false, false, false};
     const suamd_complex *pend_src = nullptr;
     unsigned pend_spec_n = 0;
   } slot[2];
@@ -451,14 +452,14 @@ struct Inspector {
   {
     Slot &s = slot[p];
     s.pend_m = pend_m; s.pend_samples = pend_samples; s.pend_spectrum = pend_spectrum; s.pend_symbols = pend_symbols;
-    s.pend_src = pend_src; s.pend_spec_n = pend_spec_n; s.est_fed[0] = est_fed[0]; s.est_fed[1] = est_fed[1];
+    s.pend_src = pend_src; s.pend_spec_n = pend_spec_n; for (int k = 0; k < NEST; ++k) s.est_fed[k] = est_fed[k];
   }
   void recall(int p)
   {
     use(p);
     const Slot &s = slot[p];
     pend_m = s.pend_m; pend_samples = s.pend_samples; pend_spectrum = s.pend_spectrum; pend_symbols = s.pend_symbols;
-    pend_src = s.pend_src; pend_spec_n = s.pend_spec_n; est_fed[0] = s.est_fed[0]; est_fed[1] = s.est_fed[1];
+    pend_src = s.pend_src; pend_spec_n = s.pend_spec_n; for (int k = 0; k < NEST; ++k) est_fed[k] = s.est_fed[k];
   }
   void close_channel()
   {
@@ -923,7 +924,7 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
     Inspector &in = *kv.second;
     in.use(slot);
     in.pend_samples = in.pend_spectrum = in.pend_symbols = false;
-    in.est_fed[0] = in.est_fed[1] = false;
+    for (bool &f : in.est_fed) f = false;
     in.stream = sA;
     if (in.dirty) {
       std::string err;
@@ -1001,13 +1002,13 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
       in.stream = sF;                                         // spectra and estimators read the channel samples: beside the chain
       if (in.spectsrc_id) enqueue_spectrum(a, in, fm[i]);
       in.spect_have_prev = true; in.last_slot = slot; in.last_fir_m = fm[i];   // for the next block's "sample before"
-      for (int k = 0; k < 2; ++k) {                           // enabled estimators look at the channel samples too
+      for (int k = 0; k < Inspector::NEST; ++k) {             // enabled estimators look at the channel samples too
         if (!in.est_on[k]) continue;
         unsigned want = 512;
         while (want * 2 <= fm[i] && want < 8192) want *= 2;
         if (fm[i] < want) continue;                           // fewer than 512 channel samples per block: no estimate
         if (in.est[k] && suamd_baud_estimator_size(in.est[k]) != want) { suamd_baud_estimator_destroy(in.est[k]); in.est[k] = nullptr; }
-        if (!in.est[k]) in.est[k] = suamd_baud_estimator_new(a->ctx, k == 0 ? SUAMD_BAUD_ESTIMATOR_FAC : SUAMD_BAUD_ESTIMATOR_NONLINEAR, want);
+        if (!in.est[k]) in.est[k] = suamd_baud_estimator_new(a->ctx, k, want);   // (the estimator ids ARE the kinds: fac, nonlinear, carrier)
         if (!in.est[k] || !suamd_baud_estimator_feed_to(in.est[k], in.d_y, fm[i], &in.pin->est[k], sF)) { fail("estimator"); continue; }
         in.est_fed[k] = true;
       }
@@ -1151,7 +1152,7 @@ void collect_inspectors(suscan_analyzer *a, int slot)
   bool any = false;
   for (auto &kv : a->inspectors) {
     kv.second->recall(slot);
-    any = any || kv.second->pend_samples || kv.second->pend_spectrum || kv.second->pend_symbols || kv.second->est_on[0] || kv.second->est_on[1];
+    any = any || kv.second->pend_samples || kv.second->pend_spectrum || kv.second->pend_symbols || kv.second->est_on[0] || kv.second->est_on[1] || kv.second->est_on[2];
   }
   if (!any) return;
   for (int k = 0; k < suscan_analyzer::NISTREAMS; ++k) (void)hipEventSynchronize(a->ev_done[slot][k]);
@@ -1169,14 +1170,14 @@ void collect_inspectors(suscan_analyzer *a, int slot)
       std::memcpy(msg->spectrum_data, in.pin->spec, in.pend_spec_n * sizeof(float));
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, msg);
     }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < Inspector::NEST; ++k) {
       if (!in.est_on[k]) continue;
       auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_ESTIMATOR, 0);
       m->handle = in.handle;
       m->inspector_id = in.inspector_id;
       m->estimator_id = (uint32_t)k;
       m->enabled = SU_TRUE;
-      m->value = in.est_fed[k] ? in.pin->est[k] * (SUFLOAT)in.equiv_fs : in.last_est[k];   // Hz, what clock.baud takes
+      m->value = in.est_fed[k] ? in.pin->est[k] * (SUFLOAT)in.equiv_fs : in.last_est[k];   // Hz, what clock.baud / afc.offset take
       in.last_est[k] = m->value;
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
     }
@@ -1185,9 +1186,10 @@ void collect_inspectors(suscan_analyzer *a, int slot)
   }
 }
 
-const struct suscan_estimator_class kEstimators[2] = {
+const struct suscan_estimator_class kEstimators[3] = {
   {"baud-fac", "Fast autocorrelation baud estimator", "clock.baud"},
   {"baud-nonlinear", "Non-linear baud estimator", "clock.baud"},
+  {"carrier", "Carrier offset estimator (spectral centroid)", "afc.offset"},
 };
 
 void push_source_info(suscan_analyzer *a)
@@ -1244,10 +1246,9 @@ void handle_request(suscan_analyzer *a, Request &r)
       m->spectsrc_list = static_cast<char **>(std::calloc(m->spectsrc_count, sizeof(char *)));
       for (unsigned k = 0; k < m->spectsrc_count; ++k) m->spectsrc_list[k] = const_cast<char *>(suamd_spectsrc_name(k + 1));
       if (r.cls != "raw" && r.cls != "power" && r.cls != "audio") {   // the baud estimators (names static, like the sources')
-        m->estimator_count = 2;
-        m->estimator_list = static_cast<char **>(std::calloc(2, sizeof(char *)));
-        m->estimator_list[0] = const_cast<char *>(kEstimators[0].name);
-        m->estimator_list[1] = const_cast<char *>(kEstimators[1].name);
+        m->estimator_count = 3;
+        m->estimator_list = static_cast<char **>(std::calloc(3, sizeof(char *)));
+        for (int k = 0; k < 3; ++k) m->estimator_list[k] = const_cast<char *>(kEstimators[k].name);
       }
       a->inspectors[in->handle] = std::move(in);
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);
@@ -1333,7 +1334,7 @@ void handle_request(suscan_analyzer *a, Request &r)
     case Request::SET_THROTTLE: a->throttle = r.value; break;
     case Request::ESTIMATOR: {
       Inspector &in = *it->second;
-      if (r.value >= 2 || in.cls == "raw" || in.cls == "power") {
+      if (r.value >= Inspector::NEST || in.cls == "raw" || in.cls == "power") {
         auto *m = new_insp_msg(SUSCAN_ANALYZER_INSPECTOR_MSGKIND_WRONG_OBJECT, r.req_id);
         m->handle = r.handle;
         push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);

@@ -1943,7 +1943,7 @@ struct suamd_baud_estimator {
 suamd_baud_estimator_t *suamd_baud_estimator_new(suamd_ctx_t *ctx, int kind, unsigned size)
 {
   if (!ctx) { set_err("null context"); return nullptr; }
-  if (kind != SUAMD_BAUD_ESTIMATOR_FAC && kind != SUAMD_BAUD_ESTIMATOR_NONLINEAR) { set_err("unknown estimator kind %d", kind); return nullptr; }
+  if (kind != SUAMD_BAUD_ESTIMATOR_FAC && kind != SUAMD_BAUD_ESTIMATOR_NONLINEAR && kind != SUAMD_ESTIMATOR_CARRIER) { set_err("unknown estimator kind %d", kind); return nullptr; }
   if (size < 512 || size > (1u << 20) || (size & (size - 1))) { set_err("size %u unsupported (power of two, 512..1048576)", size); return nullptr; }
   auto *e = new (std::nothrow) suamd_baud_estimator;
   if (!e) { set_err("out of memory"); return nullptr; }
@@ -1951,6 +1951,7 @@ suamd_baud_estimator_t *suamd_baud_estimator_new(suamd_ctx_t *ctx, int kind, uns
   bool ok = hipHostMalloc((void **)&e->pin, sizeof *e->pin, hipHostMallocMapped) == hipSuccess;
   if (ok) std::memset(e->pin, 0, sizeof *e->pin);
   if (ok && kind == SUAMD_BAUD_ESTIMATOR_NONLINEAR) ok = e->w.init(size) && hipMalloc(&e->y, sizeof(suamd_complex) * (size_t)size) == hipSuccess;
+  if (ok && kind == SUAMD_ESTIMATOR_CARRIER) ok = e->w.init(size);
   if (ok && kind == SUAMD_BAUD_ESTIMATOR_FAC) {
     e->fac = suamd_fac_new(ctx, size, 0.25f);
     ok = e->fac != nullptr;
@@ -1995,6 +1996,17 @@ SUBOOL suamd_baud_estimator_feed_to(suamd_baud_estimator_t *e, const suamd_compl
     // the lowest strong line outside the DC notch (1 % of the band), power centroid over 9 bins
     const int skip = std::max(4, (int)(0.01 * (double)n));
     HIP_TRY(sdk::baud_line(e->w.res, (int)n, skip, e->w.d_res, e->d_val, st), SU_FALSE);
+    HIP_TRY(hipMemcpyAsync(h_value, e->d_val, sizeof(float), hipMemcpyDeviceToHost, st), SU_FALSE);
+  } else if (e->kind == SUAMD_ESTIMATOR_CARRIER) {
+    // Tasks/CarrierDetector.cpp:99-137 on the window's samples -- Blackman-Harris, transform, the strongest bin, the power-
+    // weighted phasor sum over the `bins` around it -- with avgRelBw = 1/2 (half the channel around the peak: a modulated
+    // carrier's whole main lobe, not the data-dependent crest inside it) and no DC notch (the channel IS the baseband)
+    HIP_TRY(sdk::window_pad(d_x, n, e->w.alloc, e->w.a, st), SU_FALSE);
+    HIP_TRY(sdk::fft_forward(e->w.a, e->w.b, e->w.log2n, &e->w.res, st), SU_FALSE);
+    const int bins = static_cast<int>((double)e->w.alloc * 0.5) + 1, delta = (bins - 1) / 2;
+    HIP_TRY(sdk::spectrum_centroid(e->w.res, e->w.alloc, 0, e->w.alloc, nullptr, bins, delta, 0, e->w.blk_max, e->w.blk_idx,
+                                   CaptureFft::NBLK, reinterpret_cast<float *>(e->w.d_res), st), SU_FALSE);
+    HIP_TRY(sdk::carrier_norm(reinterpret_cast<const float *>(e->w.d_res), e->d_val, st), SU_FALSE);
     HIP_TRY(hipMemcpyAsync(h_value, e->d_val, sizeof(float), hipMemcpyDeviceToHost, st), SU_FALSE);
   } else {
     if (!suamd_fac_feed(e->fac, d_x, 1, 0, (SUSDIFF)(n / 2), st)) return SU_FALSE;

@@ -488,6 +488,20 @@ hipError_t window_pad(const void *data, long long len, long long alloc, void *bu
   return hipGetLastError();
 }
 
+// the carrier estimator's last step on the device: res = {acc.re, acc.im, ...} of spectrum_centroid; value = SU_C_ARG(acc)
+// wrapped to (-pi, pi] (Tasks/CarrierDetector.cpp:134-137) as cycles per sample
+__global__ void carrier_norm_kernel(const float *__restrict__ res, float *__restrict__ value)
+{
+  float p = atan2f(res[1], res[0]);
+  if (p > 3.14159265358979323846f) p -= 6.28318530717958647692f;
+  value[0] = p * 0.15915494309189533577f;
+}
+hipError_t carrier_norm(const float *res, float *value, hipStream_t st)
+{
+  hipLaunchKernelGGL(carrier_norm_kernel, dim3(1), dim3(1), 0, st, res, value);
+  return hipGetLastError();
+}
+
 hipError_t spectrum_centroid(void *buf, long long alloc, long long lo, long long hi, float *mirror, long long bins,
                              long long delta, int with_dispersion, float *blk_max, long long *blk_idx,
                              int nblk, float *res, hipStream_t st)

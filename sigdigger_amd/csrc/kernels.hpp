@@ -283,6 +283,7 @@ hipError_t fac_first_valley(const float *fac, int n_half, float *out, hipStream_
 // that reaches half of the strongest one (a comb of harmonics has no strongest tooth worth trusting), then the power
 // centroid over +-4 bins.  res[0] = centroid bin (0: none), value[0] = centroid / n
 hipError_t baud_line(const void *X, int n, int skip, double *res, float *value, hipStream_t st);
+hipError_t carrier_norm(const float *res, float *value, hipStream_t st);
 // source conditioning in front of the path: I/Q swap, then removal of a tracked DC level (dc: device float[2],
 // or nullptr).  The level follows the block means: dc = first ? mean : dc + alpha (mean - dc), and the block is
 // corrected with the updated level.  partial: device scratch of 2 * 256 floats.

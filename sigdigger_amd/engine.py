@@ -715,9 +715,10 @@ class PowerBank(_LoopBank):
 
 
 class BaudEstimator(_LoopBank):
-    """suamd_baud_estimator_t: kind 0 = fast autocorrelation valley, 1 = nonlinear (|dx|^2 line); normalised baud."""
+    """suamd_baud_estimator_t: kind 0 = fast autocorrelation valley, 1 = nonlinear (|dx|^2 line): normalised baud; kind 2 =
+    carrier (the reference's CarrierDetector centroid, avgRelBw 1/2): residual carrier in cycles per sample."""
     _destroy = "suamd_baud_estimator_destroy"
-    FAC, NONLINEAR = 0, 1
+    FAC, NONLINEAR, CARRIER = 0, 1, 2
 
     def __init__(self, ctx, kind, size):
         self.ctx = ctx

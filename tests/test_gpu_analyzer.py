@@ -227,6 +227,9 @@ def test_psk_inspector_protocol_and_symbols(tmp_path, sdo):
     D = 8                                               # pow2floor(fs / (2 bw)) = pow2floor(12.5)
     assert abs(st["equiv_fs"] - FS / D) < 1e-3
     taps = sdo.lpf_design(255, bw / FS)
+    car, off = [v for _, v in st["est"][2]], [v for _, v in st["est"]["off"]]
+    assert len(car) >= st["psd"] - st["on_at"] - 1 and abs(np.median(car[2:])) < 0.1 * df, car           # on its carrier: ~ 0 Hz
+    assert len(off) >= st["psd"] - st["on2_at"] - 1 and abs(np.median(off[2:]) - df) < 0.1 * df, off      # 1.5 kHz below it
     dp = sdo.fnor_to_dphase(-2 * fc / FS)
     xs = x[b0 * L:]
     y = sdo.chan_feed(np.zeros(254, np.complex64), xs, 0, sdo.chan_modulate_taps(taps, dp), D, 0, dp)
@@ -716,7 +719,9 @@ def test_power_inspector_class(tmp_path, sdo):
 def test_seek_estimators_and_tle(tmp_path, sdo):
     """Analyzer::seek moves the file position; setInspectorEnabled switches the baud estimators of estimator_list on and
     ESTIMATOR messages carry the baud in Hz (both within a few percent of the truth, each equal to its oracle on the same
-    channel samples); Doppler correction from a TLE is refused, its removal acknowledged"""
+    channel samples) and -- estimator 2, "carrier" -> afc.offset -- the channel's residual carrier in Hz (the inspector is
+    opened 1.5 kHz beside its carrier; the estimate is the reference's CarrierDetector centroid on the channel samples);
+    Doppler correction from a TLE is refused, its removal acknowledged"""
     nblocks = 14
     baud, bw, fc = 3906.25, 30e3, 100e3                     # 16 channel samples per symbol at equiv_fs = 62.5 kS/s
     x = synth.psk_carriers(L * nblocks, [2 * fc / FS], sps=int(FS / baud), order=4, seed=9, snr_db=25)
@@ -724,11 +729,15 @@ def test_seek_estimators_and_tle(tmp_path, sdo):
     x.tofile(path)
     Lb, mq, an = _start(path, L)
     Lb.suscan_analyzer_set_throttle_async(an, 2 * FS, 0)
-    cls = [C.cast(Lb.suscan_estimator_class_lookup(n), C.POINTER(suscan.EstimatorClass)).contents for n in (b"baud-fac", b"baud-nonlinear")]
-    assert [c.field for c in cls] == [b"clock.baud", b"clock.baud"] and not Lb.suscan_estimator_class_lookup(b"nope")
+    cls = [C.cast(Lb.suscan_estimator_class_lookup(n), C.POINTER(suscan.EstimatorClass)).contents for n in (b"baud-fac", b"baud-nonlinear", b"carrier")]
+    assert [c.field for c in cls] == [b"clock.baud", b"clock.baud", b"afc.offset"] and not Lb.suscan_estimator_class_lookup(b"nope")
     ch = suscan.Channel(fc=fc, f_lo=fc - bw / 2, f_hi=fc + bw / 2, bw=bw, ft=433.92e6)
     assert Lb.suscan_analyzer_open_ex_async(an, b"psk", C.byref(ch), 1, -1, 7)
-    st = {"psd": 0, "ts": [], "est": {0: [], 1: []}, "ack": [], "kinds": [], "on_at": None, "handle": None}
+    df = 1500.0                                             # a second inspector, this far below the carrier: only estimator 2
+    fch = fc - df
+    ch2 = suscan.Channel(fc=fch, f_lo=fch - bw / 2, f_hi=fch + bw / 2, bw=bw, ft=433.92e6)
+    assert Lb.suscan_analyzer_open_ex_async(an, b"psk", C.byref(ch2), 1, -1, 8)
+    st = {"psd": 0, "ts": [], "est": {0: [], 1: [], 2: [], "off": []}, "handle2": None, "ack": [], "kinds": [], "on_at": None, "handle": None}
 
     def on_msg(t, ptr):
         if t == suscan.MSG_PSD:
@@ -741,20 +750,28 @@ def test_seek_estimators_and_tle(tmp_path, sdo):
         elif t == suscan.MSG_INSPECTOR:
             m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
             st["kinds"].append(m.kind)
-            if m.kind == suscan.KIND_OPEN:
-                assert m.estimator_count == 2
+            if m.kind == suscan.KIND_OPEN and m.req_id == 8:
+                st["handle2"] = m.handle
+                assert Lb.suscan_analyzer_inspector_estimator_cmd_async(an, m.handle, 2, 1, 70)
+            elif m.kind == suscan.KIND_OPEN:
+                assert m.estimator_count == 3
                 names = C.cast(m.estimator_list, C.POINTER(C.c_char_p))
-                assert [names[0], names[1]] == [b"baud-fac", b"baud-nonlinear"]
+                assert [names[0], names[1], names[2]] == [b"baud-fac", b"baud-nonlinear", b"carrier"]
                 st["handle"] = m.handle
-                for eid in (0, 1):
+                for eid in (0, 1, 2):
                     assert Lb.suscan_analyzer_inspector_estimator_cmd_async(an, m.handle, eid, 1, 50 + eid)
                 assert Lb.suscan_analyzer_inspector_estimator_cmd_async(an, m.handle, 5, 1, 59)      # no such estimator
                 assert Lb.suscan_analyzer_inspector_set_tle_async(an, m.handle, None, 60)            # disable: fine
                 assert Lb.suscan_analyzer_inspector_set_tle_async(an, m.handle, 1, 61)               # any orbit: refused
             elif m.kind == suscan.KIND_ESTIMATOR:
-                if m.req_id in (50, 51):
+                if m.req_id in (50, 51, 52):
                     st["ack"].append((m.req_id, m.estimator_id, m.enabled))
                     st["on_at"] = st["psd"]
+                elif m.req_id == 70:
+                    st["on2_at"] = st["psd"]
+                elif m.handle == st["handle2"]:
+                    assert m.estimator_id == 2
+                    st["est"]["off"].append((st["psd"], m.value))
                 else:
                     st["est"][m.estimator_id].append((st["psd"], m.value))
             elif m.req_id == 59:
@@ -765,7 +782,7 @@ def test_seek_estimators_and_tle(tmp_path, sdo):
                 assert m.kind == suscan.KIND_INVALID_ARGUMENT
 
     _pump(Lb, an, on_msg)
-    assert sorted(st["ack"]) == [(50, 0, 1), (51, 1, 1)]
+    assert sorted(st["ack"]) == [(50, 0, 1), (51, 1, 1), (52, 2, 1)]
     assert {suscan.KIND_WRONG_OBJECT, suscan.KIND_SET_TLE, suscan.KIND_INVALID_ARGUMENT} <= set(st["kinds"])
     # seek: 9 blocks, then the position jumps back to block 2 and the remaining 12 blocks follow
     assert st["psd"] == 9 + (nblocks - 2) or st["psd"] == 10 + (nblocks - 2)           # the request lands one block later at most
@@ -788,6 +805,11 @@ def test_seek_estimators_and_tle(tmp_path, sdo):
     nl = sdo.baud_nonlinear(blk) * efs
     got = dict(st["est"][1])[b0 + 1]                                                # messages of block b0 arrive before PSD b0 + 1
     assert abs(got - nl) / nl < 2e-3, (got, nl)
+    # the carrier estimate of that block: the reference's CarrierDetector computation (oracle pinned to the compiled
+    # Tasks/CarrierDetector.cpp, tests/test_ref_pin.py) on the same channel samples, avgRelBw 1/2, no DC notch
+    cref = sdo.carrier_detect(blk, 0.5, 0.0) / (2 * np.pi) * efs
+    cgot = dict(st["est"][2])[b0 + 1]
+    assert abs(cgot - cref) < 2e-5 * efs, (cgot, cref)
     Lb.suscan_analyzer_destroy(an)
     Lb.suscan_mq_finalize(C.byref(mq))
 

@@ -975,6 +975,31 @@ def test_source_fix_matches_oracle(ctx, sdo):
         engine.source_fix(ctx, dev(blocks[0]), False, dc_d, 1.5)                  # alpha out of range
 
 
+@pytest.mark.parametrize("f_off,sps,order", [(0.031, 8, 4), (-0.12, 16, 2), (0.0, 6, 4), (0.004, 32, 8)])
+def test_carrier_estimator_is_the_references_carrier_detector(ctx, sdo, f_off, sps, order):
+    """Estimator 2 ("carrier" -> afc.offset, SPEC.md section M): Tasks/CarrierDetector.cpp's computation (avgRelBw 1/2, no DC
+    notch) on the first n samples of a block -- against the oracle (which tests/test_ref_pin.py holds to the compiled
+    reference translation unit) and against the truth: a PSK carrier f_off cycles per sample off the channel centre, and a
+    bare tone."""
+    n = 4096
+    x = synth.psk_carriers(n * 3, [2 * f_off], sps=sps, order=order, seed=17, snr_db=20)
+    est = engine.BaudEstimator(ctx, engine.BaudEstimator.CARRIER, n)
+    assert est.get() == 0.0
+    for k in range(3):
+        blk = x[k * n:(k + 1) * n]
+        est.feed(dev(blk))
+        ref = sdo.carrier_detect(blk, 0.5, 0.0) / (2 * np.pi)
+        got = est.get()
+        assert abs(got - ref) < 1e-5, (k, got, ref)
+        assert abs(got - f_off) < 0.02 / sps + 2e-3, (k, got, f_off)                # a few percent of the symbol rate
+    tone = synth.tone_noise(n, f_rel=f_off, sigma2=1e-3, seed=2)
+    est.feed(dev(tone))
+    assert abs(est.get() - f_off) < 5e-4 and abs(est.get() - sdo.carrier_detect(tone, 0.5, 0.0) / (2 * np.pi)) < 1e-5
+    before = est.get()
+    est.feed(dev(tone[:n - 1]))                                                     # not a whole window: the estimate stands
+    assert est.get() == before
+
+
 @pytest.mark.parametrize("sps,order", [(8, 4), (16, 4), (11, 2), (4, 8)])
 def test_baud_estimators_match_oracle_and_truth(ctx, sdo, sps, order):
     """nonlinear: the |dx|^2 line through the carrier detector's search -- same estimate as the oracle (FFT tolerance) and
