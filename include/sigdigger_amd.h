@@ -90,8 +90,12 @@ SUAMD_API int          suamd_ctx_device(const suamd_ctx_t *ctx);
  * the one-wavefront recurrences -- su_costas / su_clock_detector / su_agc level trackers, milliseconds per launch -- off
  * the CUs the transform kernels plan their single round of workgroups for).  `cu_mask` has `nwords` 32-bit words, bit i
  * of the whole = compute unit i in the driver's numbering, which deals consecutive bits to consecutive XCDs (bit i is
- * on XCD i mod 8 of an MI355X: suamd_probe_placement shows it); at least one bit must be set.  The stream is
- * non-blocking, gets a hardware queue of its own and is destroyed with suamd_stream_destroy.  NULL on failure. */
+ * on XCD i mod 8 of an MI355X: suamd_probe_placement shows it); at least one bit must be set.  The stream gets a hardware
+ * queue of its own and is destroyed with suamd_stream_destroy.  hipExtStreamCreateWithCUMask takes no flags: the stream has
+ * the DEFAULT flags, i.e. it synchronises with the legacy null stream like any hipStreamCreate stream -- a caller that
+ * wants its masked streams to run beside other work must not issue that work on the null stream (PyTorch's default stream
+ * on ROCm IS the null stream: sigdigger_amd/pipeline.py keeps every kernel of a partitioned pipeline on streams of its
+ * own).  NULL on failure. */
 SUAMD_API unsigned suamd_ctx_cu_count(const suamd_ctx_t *ctx);
 SUAMD_API void    *suamd_stream_new_cu_mask(suamd_ctx_t *ctx, const uint32_t *cu_mask, unsigned nwords);
 SUAMD_API SUBOOL   suamd_stream_destroy(suamd_ctx_t *ctx, void *stream);

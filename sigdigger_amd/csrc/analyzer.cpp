@@ -393,6 +393,7 @@ struct Inspector {
   SUSCOUNT watermark = 0;                      // > 0: SAMPLES batches of exactly this many samples (Suscan/Analyzer.cpp:528-537)
   std::vector<suamd_complex> wm_buf;           // what has not filled a batch yet (flushed at EOS / close)
   bool dirty = true;                          // chain must be (re)built
+  bool keep_wm = false;                       // ... by a retune (SET_FREQ): same sample rate, the watermark's partial batch carries over
   suamd_chanbank_t *bank = nullptr;           // channeliser "fir": translate + 255-tap low-pass + decimate (SPEC.md C)
   suamd_specttuner_t *st = nullptr;           // channeliser "fft": a channel of the analyzer's su_specttuner (SPEC.md C2)
   int st_chan = -1;
@@ -928,7 +929,8 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
     in.stream = sA;
     if (in.dirty) {
       std::string err;
-      flush_watermark(a, in);                                 // (a rebuild for any other reason -- the block size changed -- as well)
+      if (!in.keep_wm) flush_watermark(a, in);                // (a rebuild for any other reason -- the block size changed -- as well)
+      in.keep_wm = false;
       if (!build_chain(a, in, err)) {
         // the inspector sits this block out; its channel must not stay a member of the filter bank, whose kernel would
         // store that channel's samples through a row pointer nobody maintains
@@ -1321,7 +1323,10 @@ void handle_request(suscan_analyzer *a, Request &r)
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);   // acknowledgement: no spectrum_data yet
       break;
     }
-    case Request::SET_FREQ: flush_watermark(a, *it->second); it->second->channel.fc = r.fvalue; it->second->dirty = true; break;
+    // a retune keeps the channel's sample rate: the stream goes on, and with a watermark its batches stay exactly w samples
+    // (Analyzer::setInspectorWatermark's contract; round 5 flushed a short batch on every drag of the frequency: ADVICE r5).
+    // Only requests that change the rate (SET_BW, SET_CONFIG) or the block flush the remainder.
+    case Request::SET_FREQ: it->second->channel.fc = r.fvalue; it->second->dirty = true; it->second->keep_wm = true; break;
     case Request::SET_BW:   flush_watermark(a, *it->second); it->second->channel.bw = (SUFLOAT)r.fvalue; it->second->dirty = true; break;   // (another sample rate: see SET_CONFIG)
     case Request::SET_PARAMS: {
       // only the PSD parameters matter on this path; applied at the next block boundary by the worker

@@ -132,8 +132,10 @@ class Context:
         return int(self.lib.suamd_ctx_cu_count(self.h))
 
     def masked_stream(self, cus):
-        """A non-blocking HIP stream whose kernels only run on the compute units in `cus` (driver numbering: consecutive
-        indices sit on consecutive XCDs), wrapped for torch (an ExternalStream does not own it: destroy_stream)."""
+        """A HIP stream whose kernels only run on the compute units in `cus` (driver numbering: consecutive indices sit on
+        consecutive XCDs), wrapped for torch (an ExternalStream does not own it: destroy_stream).  Default stream flags
+        (hipExtStreamCreateWithCUMask takes none): it synchronises with the null stream -- torch's default stream on ROCm --
+        so work that is to run beside it must be on a stream of its own."""
         n = max(self.cu_count(), max(cus) + 1)
         words = (C.c_uint32 * ((n + 31) // 32))()
         for c in cus:

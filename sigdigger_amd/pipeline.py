@@ -159,7 +159,9 @@ class AnalyzerPipeline:
         # psd_kernel + reduce 50 -> 44 us; the slowest stream pauses ~0.15 ms per 21 ms step (795 -> 789 MS/s).
         if window is None:
             window = os.environ.get("SUAMD_PIPELINE_WINDOW", "1") != "0"
-        self.window = bool(overlap and window)
+        # (a window exists only where a tail can be held back: at least three sub-ranges -- with fewer, nothing pauses and the
+        # plans below, which assume the transforms have the chip to themselves, would be applied beside running recurrences)
+        self.window = bool(overlap and window and self.SUB >= 3)
         if self.window and do_psd and self.psd_size == 8192 and os.environ.get("SUAMD_PSD_SPLIT_TARGET") is None:
             self.psd.set_split_target(512)     # two 8192-point workgroups per CU, and the chip is the PSD's own in the window
         if overlap:

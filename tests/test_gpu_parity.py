@@ -704,8 +704,8 @@ def test_pipeline_overlap_equals_serial_and_oracle(ctx, sdo, kind):
         assert_bits(s_ov[ch], ref, f"symbols ch {ch} vs oracle")
 
 
-@pytest.mark.parametrize("kind", ["psk", "fsk"])
-def test_transform_window_holds_a_blocks_tail_back_and_delivers_the_same_symbols(ctx, kind):
+@pytest.mark.parametrize("kind,psd_size", [("psk", 4096), ("fsk", 4096), ("psk", 8192)])
+def test_transform_window_holds_a_blocks_tail_back_and_delivers_the_same_symbols(ctx, kind, psd_size):
     """The pipeline's transform window (round 5): the tail of block k's serial stages is enqueued behind block k+1's PSD and
     channeliser, which wait for the rest of block k.  Blocks are pushed back to back as bench.py does -- no flush in
     between -- and what reaches pinned host memory must be, bit for bit, what the free-running streams deliver."""
@@ -719,7 +719,7 @@ def test_transform_window_holds_a_blocks_tail_back_and_delivers_the_same_symbols
 
     def run(window):
         bank = pipeline.InspectorBankConfig(kind=kind, fnor=fn, decimation=D, ntaps=255, sps=sps_in / D, channeliser="fft")
-        pipe = pipeline.AnalyzerPipeline(ctx, L, psd_size=4096, psd_navg=4, bank=bank, window=window)
+        pipe = pipeline.AnalyzerPipeline(ctx, L, psd_size=psd_size, psd_navg=4, bank=bank, window=window)
         pipe.enable_delivery()
         got, held = [], 0
         for b in range(nblocks):
@@ -731,7 +731,12 @@ def test_transform_window_holds_a_blocks_tail_back_and_delivers_the_same_symbols
     win, held, psd_w = run(True)
     free, none, psd_f = run(False)
     assert held > 0 and none == 0, "the window did not hold anything back"
-    assert_bits(psd_w, psd_f, "psd")
+    if psd_size == 8192:
+        # 8192 points: the window plans 512 split workgroups where the free-running streams plan one per CU -- another
+        # association of the frames' sum, not another spectrum (say the tolerance)
+        assert np.max(np.abs(psd_w - psd_f) / np.max(psd_f, axis=1, keepdims=True)) < 1e-6
+    else:
+        assert_bits(psd_w, psd_f, "psd")
     for b in range(nblocks):
         assert np.array_equal(win[b][1], free[b][1]), f"block {b}: symbol counts"
         assert win[b][1].min() > 50
