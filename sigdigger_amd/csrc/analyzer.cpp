@@ -393,7 +393,6 @@ struct Inspector {
   SUSCOUNT watermark = 0;                      // > 0: SAMPLES batches of exactly this many samples (Suscan/Analyzer.cpp:528-537)
   std::vector<suamd_complex> wm_buf;           // what has not filled a batch yet (flushed at EOS / close)
   bool dirty = true;                          // chain must be (re)built
-  bool keep_wm = false;                       // ... by a retune (SET_FREQ): same sample rate, the watermark's partial batch carries over
   suamd_chanbank_t *bank = nullptr;           // channeliser "fir": translate + 255-tap low-pass + decimate (SPEC.md C)
   suamd_specttuner_t *st = nullptr;           // channeliser "fft": a channel of the analyzer's su_specttuner (SPEC.md C2)
   int st_chan = -1;
@@ -839,7 +838,8 @@ void push_samples(suscan_analyzer *a, const Inspector &in, const suamd_complex *
 
 // One block's output of an inspector.  No watermark: one SAMPLES message per block.  Watermark w
 // (Analyzer::setInspectorWatermark, Suscan/Analyzer.cpp:528-537): batches of exactly w samples; what does not fill one
-// waits for the next block (flush_watermark at EOS / close).  The stream is the same either way.
+// waits for the next block.  A batch is shorter only where the stream itself is cut: CLOSE / EOS, a retune or a
+// reconfiguration (flush_watermark: the remainder goes out before samples of the new tuning follow).  The stream is the same either way.
 void emit_samples(suscan_analyzer *a, Inspector &in, size_t count)
 {
   if (count == 0 || count > in.cap) return;
@@ -929,8 +929,7 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
     in.stream = sA;
     if (in.dirty) {
       std::string err;
-      if (!in.keep_wm) flush_watermark(a, in);                // (a rebuild for any other reason -- the block size changed -- as well)
-      in.keep_wm = false;
+      flush_watermark(a, in);                                 // (a rebuild for any other reason -- the block size changed -- as well)
       if (!build_chain(a, in, err)) {
         // the inspector sits this block out; its channel must not stay a member of the filter bank, whose kernel would
         // store that channel's samples through a row pointer nobody maintains
@@ -1323,10 +1322,12 @@ void handle_request(suscan_analyzer *a, Request &r)
       push(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INSPECTOR, m);   // acknowledgement: no spectrum_data yet
       break;
     }
-    // a retune keeps the channel's sample rate: the stream goes on, and with a watermark its batches stay exactly w samples
-    // (Analyzer::setInspectorWatermark's contract; round 5 flushed a short batch on every drag of the frequency: ADVICE r5).
-    // Only requests that change the rate (SET_BW, SET_CONFIG) or the block flush the remainder.
-    case Request::SET_FREQ: it->second->channel.fc = r.fvalue; it->second->dirty = true; it->second->keep_wm = true; break;
+    // A retune cuts the watermark's current batch short: the remainder goes out as it is, so that no SAMPLES message ever mixes
+    // samples of two tunings (the one place a batch is shorter than the watermark besides CLOSE / EOS; a retune has no reply
+    // message, the short batch is the client's only marker).  Round 6 tried carrying the remainder over: the
+    // fuzz test's replay (tests/test_gpu_analyzer_fuzz.py) showed what that means -- up to w - 1 samples of the OLD frequency
+    // at the head of the first batch after the retune -- and it was taken back.
+    case Request::SET_FREQ: flush_watermark(a, *it->second); it->second->channel.fc = r.fvalue; it->second->dirty = true; break;
     case Request::SET_BW:   flush_watermark(a, *it->second); it->second->channel.bw = (SUFLOAT)r.fvalue; it->second->dirty = true; break;   // (another sample rate: see SET_CONFIG)
     case Request::SET_PARAMS: {
       // only the PSD parameters matter on this path; applied at the next block boundary by the worker
@@ -2117,6 +2118,12 @@ void worker_main(suscan_analyzer *a)
     tick(1);
     const unsigned n = (unsigned)a->params.detector_params.window_size;
     const unsigned navg = last ? (unsigned)(blen / n) : a->navg;     // the tail: the whole frames it holds (none: no PSD message)
+    // The main spectrum goes BEHIND the block's channeliser, not beside it.  Side by side the two transform launches share
+    // every CU's LDS (a PSD workgroup takes 64 KB, a channeliser workgroup 50): not all of the channeliser's one round of
+    // workgroups is resident, its runs wait out their bounded seam polls for successors that have not started, and the
+    // launch takes 120 - 150 us per 2 Mi block where it takes 33 alone (rocprofv3 trace of the 64-inspector analyzer, round 6).
+    // The chains wait for the channeliser; nothing waits for the PSD before the block's messages go out.
+    (void)hipStreamWaitEvent(a->stream, a->ev_fir, 0);
     if (navg && !suamd_psd_feed(a->psd, a->d_x, navg, n, navg, 1.0f / (float)n, SUAMD_PSD_LINEAR, a->d_psd, a->stream)) {
       fatal = suamd_last_error();
       (void)reader.wait(&looped_next);                        // the helper thread is off the pinned buffer before it is freed

@@ -148,12 +148,18 @@ __device__ __forceinline__ void dft64_pair(const cf *in, cf *out, cf *ex, int t,
 // Channels of S = 2^LOG2S bins.  S = 64: a lane's channel is split between the wavefronts like the forward DFTs (third
 // swap).  S < 64: a lane serves 64 / S channels, wavefront p takes half of them whole -- their inverse transforms are
 // lane-local, no third swap.  Either way a wavefront owns 16 outputs per lane and block (`slot` o = 0..15 below).
-template <int P, int LOG2S, bool Y32, bool SEP>
+// ROWT (64-bin channels, 32-bit row offsets): the outputs go to per-channel ROWS -- the live analyzer's layout, one row per
+// inspector -- through a transposition in LDS.  Lane = channel means a store instruction touches 64 rows with 8 bytes each:
+// 118 us per 2 Mi-sample block in the 64-inspector analyzer (rocprofv3, round 6) against 17 for time-major output.  Staged,
+// a block's 64 x 32 outputs leave as 16-byte pieces, sixteen lanes covering 256 contiguous bytes of a row.
+template <int P, int LOG2S, bool Y32, bool SEP, bool ROWT>
 __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const int t)
 {
+  static_assert(!ROWT || (LOG2S == 6 && Y32), "row-transposed stores: 64-bin channels, 32-bit offsets");
   constexpr int TP = (1 << LOG2S) + 2;                         // pitch of a response table
   cf *const tab = buf + PW_TAB;
   cf *const exf = SEP ? tab + a.nsel * TP : buf;               // swap area of the two forward DFTs
+  unsigned *const rowoff = reinterpret_cast<unsigned *>(tab + a.nsel * TP + (SEP ? 2 * PW_EX : 0));   // ROWT: byte offset of every lane's row
   constexpr int W = PW_W, H = PW_H;
   constexpr int S = 1 << LOG2S, HS = S / 2, NG = WAVE / S, NGW = LOG2S == 6 ? 1 : NG / 2, WS = 64 / S;
   static_assert(LOG2S >= 3 && LOG2S <= 6, "channel size out of range for the two-wavefront kernel");
@@ -259,8 +265,26 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
   }
   const long long yms = a.rows ? 1 : a.yv.ms;
   const unsigned yms8 = (unsigned)(yms * 8);
+  if constexpr (ROWT) { if (P == 0) rowoff[t] = yvoff[0]; }      // (read behind the first window's barriers)
   // (S < 64: the wavefronts serve different channels and may differ in `any_precise` -- their channel stages have no barrier)
 
+  // ROWT staging: element (channel t, sample i) of the block at stg[t * 32 + (i ^ ((t & 15) << 1))] -- an even swizzle keeps
+  // the pair (2 m, 2 m + 1) adjacent and in order for the 16-byte reads, and spreads a store's 64 lanes over the banks
+  cf *const stg = buf;
+  auto stage_flush = [&](long long wo) {
+    pair_barrier();                                              // both wavefronts' halves of the block are in
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<cf *>(a.y) + (long long)((unsigned long long)wo * HS), 0, 0x7fffffff, 0x00020000);
+    const int m2 = (t & 15) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 32 * P + 4 * j + (t >> 4);
+      const float4 v = *reinterpret_cast<const float4 *>(stg + r * 32 + (m2 ^ ((r & 15) << 1)));
+      typedef unsigned v4u __attribute__((ext_vector_type(4)));
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), ry, rowoff[r], m2 * 8, AUX_NT);
+    }
+    if constexpr (!SEP) alias_barrier();                         // the next window's first swap lands where the staging was read
+  };
   auto emit_one = [&](auto rot, int gl, long long wo, int i, cf o) {
     if constexpr (decltype(rot)::value) {
       const uint32_t m = (uint32_t)((unsigned long long)wo * HS + i);
@@ -272,7 +296,9 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
       s = precise ? s : 0.0f;
       o = cf{__builtin_fmaf(o.x, c, -(o.y * s)), __builtin_fmaf(o.x, s, o.y * c)};
     }
-    if constexpr (Y32) {
+    if constexpr (ROWT) {
+      stg[t * 32 + (i ^ ((t & 15) << 1))] = o;
+    } else if constexpr (Y32) {
       const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
           reinterpret_cast<cf *>(a.y) + (long long)((unsigned long long)wo * HS) * yms, 0, 0x7fffffff, 0x00020000);
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), ry, yvoff[gl], (unsigned)i * yms8, AUX_NT);
@@ -460,6 +486,7 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
       if (seam) chan_out(std::true_type{}, std::false_type{});
       else if (any_precise) chan_out(std::false_type{}, std::true_type{});
       else chan_out(std::false_type{}, std::false_type{});
+      if constexpr (ROWT) { if (!seam) stage_flush(w); }
     } else {
       // this wavefront's NGW channels per lane, whole: bins, response, inverse transform on the lane's own registers
       auto chan_out = [&](auto seam_tag, auto rot) {
@@ -525,6 +552,7 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
     }
   } else if (!self_seam) {
     // the seam block: request register slot_q(o) holds the next run's unweighted sample of slot o
+    if constexpr (ROWT) pair_barrier();                          // (the partner may still be reading the last block's staging)
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
       const int i = slot_out(o);
@@ -532,6 +560,7 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
       if (any_precise) emit_one(std::true_type{}, slot_group(o), w_end, i, v);
       else emit_one(std::false_type{}, slot_group(o), w_end, i, v);
     }
+    if constexpr (ROWT) stage_flush(w_end);
   }
 #ifdef STW_TSTAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -539,15 +568,15 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
 #endif
 }
 
-template <int LOG2S, bool Y32, bool SEP>
+template <int LOG2S, bool Y32, bool SEP, bool ROWT = false>
 __global__ __launch_bounds__(2 * WAVE, 2) void stp_kernel(sdk::StArgs a)
 {
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf *buf = reinterpret_cast<cf *>(smem);
   const int t = threadIdx.x & (WAVE - 1);
-  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0) stp_body<0, LOG2S, Y32, SEP>(a, buf, t);
-  else stp_body<1, LOG2S, Y32, SEP>(a, buf, t);
+  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0) stp_body<0, LOG2S, Y32, SEP, ROWT>(a, buf, t);
+  else stp_body<1, LOG2S, Y32, SEP, ROWT>(a, buf, t);
 }
 
 template <int LOG2S>
@@ -562,10 +591,17 @@ hipError_t launch_stp(const sdk::StArgs &a, hipStream_t st)
   const int base = PW_TAB + a.nsel * ((1 << LOG2S) + 2);
   // (52 KB, not 160 / 3 = 53.3: the LDS is handed out in blocks, and a workgroup of 53.2 KB measured TWO per CU)
   const bool sep = (unsigned long long)nruns * ny <= 768 && !no_sep && (base + 2 * PW_EX) * 8 <= 52 * 1024;
-  const int lds = (base + (sep ? 2 * PW_EX : 0)) * 8;
+  // per-channel rows with 32-bit offsets (the live analyzer): 64-bin channels leave through the LDS transposition (ROWT);
+  // sdk::tuning().st_row_stage = 0 keeps the lane-per-row stores (A / B)
+  bool rowt = false;
+  if constexpr (LOG2S == 6) rowt = a.rows != nullptr && a.y32 && sdk::tuning().st_row_stage != 0;
+  const int lds = (base + (sep ? 2 * PW_EX : 0)) * 8 + (rowt ? 256 : 0);
   auto go = [&](auto kern) {
     sdk::launch_timed("stp_kernel", kern, dim3(nruns, ny), dim3(2 * WAVE), (size_t)lds, st, a);
   };
+  if constexpr (LOG2S == 6) {
+    if (rowt) { if (sep) go(stp_kernel<LOG2S, true, true, true>); else go(stp_kernel<LOG2S, true, false, true>); return hipGetLastError(); }
+  }
   if (sep) { if (a.y32) go(stp_kernel<LOG2S, true, true>); else go(stp_kernel<LOG2S, false, true>); }
   else { if (a.y32) go(stp_kernel<LOG2S, true, false>); else go(stp_kernel<LOG2S, false, false>); }
   return hipGetLastError();

@@ -21,6 +21,7 @@
   X(st_variant,      "SUAMD_ST_VARIANT",      0, 0, 8,       "st_kernel instantiation override (measurements)") \
   X(st_ngl,          "SUAMD_ST_NGL",          0, 0, 4,       "channel groups a wide-channel workgroup serves per forward transform; 0: two where the bank has more than one") \
   X(st_pair_sep,     "SUAMD_ST_PAIR_SEP",     1, 0, 1,       "stp_kernel: 0 never gives the forward swaps 16 KiB of LDS of their own") \
+  X(st_row_stage,    "SUAMD_ST_ROW_STAGE",    1, 0, 1,       "stp_kernel, per-channel rows (the live analyzer): 0 stores lane by lane instead of through the LDS transposition") \
   /* main spectrum (psd.hip, psd_large.hip, capi.hip) */                                                                                    \
   X(psd_large,       "SUAMD_PSD_LARGE",       -1, -1, 1,     "frames above 16384 points: 0 round 2's radix-16 passes through HBM, 1 the two-trip transform for 32768 points too, -1 by size (32768: one trip; above: two); env: passes / twotrip") \
   X(psd_large_points, "SUAMD_PSD_LARGE_POINTS", 27, 15, 30,  "log2 of the points one batch of the two-trip PSD keeps in its intermediate") \

@@ -227,9 +227,6 @@ def test_psk_inspector_protocol_and_symbols(tmp_path, sdo):
     D = 8                                               # pow2floor(fs / (2 bw)) = pow2floor(12.5)
     assert abs(st["equiv_fs"] - FS / D) < 1e-3
     taps = sdo.lpf_design(255, bw / FS)
-    car, off = [v for _, v in st["est"][2]], [v for _, v in st["est"]["off"]]
-    assert len(car) >= st["psd"] - st["on_at"] - 1 and abs(np.median(car[2:])) < 0.1 * df, car           # on its carrier: ~ 0 Hz
-    assert len(off) >= st["psd"] - st["on2_at"] - 1 and abs(np.median(off[2:]) - df) < 0.1 * df, off      # 1.5 kHz below it
     dp = sdo.fnor_to_dphase(-2 * fc / FS)
     xs = x[b0 * L:]
     y = sdo.chan_feed(np.zeros(254, np.complex64), xs, 0, sdo.chan_modulate_taps(taps, dp), D, 0, dp)
@@ -796,6 +793,9 @@ def test_seek_estimators_and_tle(tmp_path, sdo):
         assert abs(np.median(vals[2:]) - baud) / baud < tol, (eid, vals)
     # against the oracle on the channel samples of the block after the estimators were switched on
     b0 = st["on_at"]                                                                # estimators see blocks b0, b0 + 1, ...
+    car, off = [v for _, v in st["est"][2]], [v for _, v in st["est"]["off"]]
+    assert len(car) >= st["psd"] - st["on_at"] - 1 and abs(np.median(car[2:])) < 0.1 * df, car           # on its carrier: ~ 0 Hz
+    assert len(off) >= st["psd"] - st["on2_at"] - 1 and abs(np.median(off[2:]) - df) < 0.1 * df, off      # 1.5 kHz below it
     dp = sdo.fnor_to_dphase(-2 * fc / FS)
     taps = sdo.lpf_design(255, bw / FS)
     open_at = 0
