@@ -323,7 +323,36 @@ std::vector<TimedLaunch> g_timed;                              // pairs in fligh
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_timing_pool[64];
 std::atomic<bool> g_timing{false};
 }  // namespace
+namespace {
+// the gate of a timed launch (kernels.hpp): one lane polls a word of pinned host memory, 20 ms at most
+__global__ void timing_gate_kernel(const volatile unsigned *flag)
+{
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();            // 100 MHz
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u &&
+         __builtin_amdgcn_s_memrealtime() - t0 < 2000000ull) __builtin_amdgcn_s_sleep(16);
+}
+constexpr unsigned kGateRing = 8192;
+unsigned *g_gate_ring = nullptr;                               // pinned, mapped; a word per timed launch, reused round the ring
+unsigned g_gate_next = 0;
+}  // namespace
 namespace sdk {
+volatile unsigned *timing_gate(hipStream_t st)
+{
+  unsigned *w = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    if (!g_gate_ring && hipHostMalloc((void **)&g_gate_ring, kGateRing * sizeof(unsigned), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+      g_gate_ring = nullptr;
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    w = g_gate_ring + (g_gate_next++ % kGateRing);
+  }
+  __atomic_store_n(w, 0u, __ATOMIC_RELEASE);
+  hipLaunchKernelGGL(timing_gate_kernel, dim3(1), dim3(1), 0, st, (const volatile unsigned *)w);
+  if (hipGetLastError() != hipSuccess) { __atomic_store_n(w, 1u, __ATOMIC_RELEASE); return nullptr; }
+  return w;
+}
 bool timing_on() { return g_timing.load(std::memory_order_relaxed); }
 void timing_pair(const char *name, hipEvent_t *start, hipEvent_t *stop)
 {

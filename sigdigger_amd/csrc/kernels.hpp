@@ -13,13 +13,23 @@ namespace sdk {
 // not the distance of two stream events around the launch (which adds the queue's gaps, 3-6 us per launch).
 bool timing_on();
 void timing_pair(const char *name, hipEvent_t *start, hipEvent_t *stop);
+// The pair's START is a marker the runtime enqueues in front of the kernel's packet, its stop is the kernel's own end: if
+// the host is held up between writing the two packets while the queue is empty (a page fault, the allocator, a descheduled
+// thread), the marker is stamped at once and the kernel starts a millisecond later -- an event pair of a 77 us kernel
+// then reads 0.94 ms (round 6: one such sample in 20 turned roofline.frac 0.44 into 0.28; rocprofv3, which reads the
+// dispatch's own timestamps, never shows such a launch).  So a timed launch is preceded by a GATE: a one-lane kernel that
+// waits (bounded: 20 ms) for a word in pinned host memory which the host sets once both packets are in the queue.
+// timing_gate() launches it on `st` and returns the word (nullptr: no gate, the launch is timed as before).
+volatile unsigned *timing_gate(hipStream_t st);
 template <class K, class... A>
 inline void launch_timed(const char *name, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args)
 {
   if (timing_on()) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     timing_pair(name, &e0, &e1);
+    volatile unsigned *gate = timing_gate(st);
     hipExtLaunchKernelGGL(kern, grid, block, lds, st, e0, e1, 0, args...);
+    if (gate) __atomic_store_n(const_cast<unsigned *>(gate), 1u, __ATOMIC_RELEASE);
   } else hipLaunchKernelGGL(kern, grid, block, lds, st, args...);
 }
 

@@ -22,26 +22,26 @@ constexpr float kCountMax = 5.0f;        // SIGDIGGER_SCANNER_COUNT_MAX
 constexpr float kCountReset = 1.0f;      // SIGDIGGER_SCANNER_COUNT_RESET
 
 __global__ void feed_linear_kernel(sdk::SpecViewLinear g, const float *__restrict__ psdData,
-                                   const float *__restrict__ countData, float *__restrict__ psdAccum,
-                                   float *__restrict__ psdCount)
+                                   const float *__restrict__ countData, float *__restrict__ acc_sum,
+                                   float *__restrict__ acc_cnt)
 {
   const int j = g.j0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= g.k) return;
-  const double freqJ = g.viewFreqMin + g.dstBinW * j;
-  const double srcBin = (freqJ - g.freqMin) / g.srcBinW;
-  int startBin = (int)srcBin;
-  int endBin = (int)(srcBin + g.delta);
+  const double f_bin = g.viewFreqMin + g.dstBinW * j;
+  const double src_pos = (f_bin - g.freqMin) / g.srcBinW;
+  int b_lo = (int)src_pos;
+  int b_hi = (int)(src_pos + g.delta);
   const int psdSize = g.psdSize;
-  startBin = startBin < 0 ? 0 : (startBin > psdSize - 1 ? psdSize - 1 : startBin);
-  endBin = endBin < startBin + 1 ? startBin + 1 : (endBin > psdSize ? psdSize : endBin);
+  b_lo = b_lo < 0 ? 0 : (b_lo > psdSize - 1 ? psdSize - 1 : b_lo);
+  b_hi = b_hi < b_lo + 1 ? b_lo + 1 : (b_hi > psdSize ? psdSize : b_hi);
   float acc = 0, cnt = 0;
-  for (int i = startBin; i < endBin; i++) {
+  for (int i = b_lo; i < b_hi; i++) {
     acc += psdData[i];
     cnt += countData != nullptr ? countData[i] : 1.0f;
   }
   if (cnt > 0) {
-    psdAccum[j] += acc / cnt;
-    psdCount[j] += 1;
+    acc_sum[j] += acc / cnt;
+    acc_cnt[j] += 1;
   }
 }
 
@@ -62,7 +62,7 @@ __global__ void feed_linear_kernel(sdk::SpecViewLinear g, const float *__restric
 __global__ __launch_bounds__(256) void sweep_linear_kernel(const sdk::SpecViewLinear *__restrict__ geom, int nframes,
                                                           const float *__restrict__ frames, long long frame_stride,
                                                           const float *__restrict__ cntBefore,
-                                                          float *__restrict__ psdAccum, float *__restrict__ psdCount, int n)
+                                                          float *__restrict__ acc_sum, float *__restrict__ acc_cnt, int n)
 {
   __shared__ int list[256];
   __shared__ int wave_cnt[4];
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void sweep_linear_kernel(const sdk::SpecViewLi
   const int J = blockIdx.x * blockDim.x;                         // bins [J, J + 255]
   const int j = J + t;
   const bool live = j < n;
-  float acc = live ? psdAccum[j] : 0.0f, cnt = live ? psdCount[j] : 0.0f;
-  bool left_valid = (live && j > 0) ? cntBefore[j - 1] > .5f : true;   // snapshot: psdCount[j-1] is being rewritten
+  float acc = live ? acc_sum[j] : 0.0f, cnt = live ? acc_cnt[j] : 0.0f;
+  bool left_valid = (live && j > 0) ? cntBefore[j - 1] > .5f : true;   // snapshot: acc_cnt[j-1] is being rewritten
   for (int f0 = 0; f0 < nframes; f0 += 256) {
     // which of the frames f0 .. f0+255 reach a bin of this workgroup (or the left neighbour of one)?
     const int f = f0 + t;
@@ -95,26 +95,26 @@ __global__ __launch_bounds__(256) void sweep_linear_kernel(const sdk::SpecViewLi
         if (j - 1 >= g.j0 && j - 1 < g.k) left_valid = true;
         if (j >= g.j0 && j < g.k) {
           const float *__restrict__ psdData = frames + (long long)fe * frame_stride;
-          const double freqJ = g.viewFreqMin + g.dstBinW * j;
-          const double srcBin = (freqJ - g.freqMin) / g.srcBinW;
-          int startBin = (int)srcBin;
-          int endBin = (int)(srcBin + g.delta);
+          const double f_bin = g.viewFreqMin + g.dstBinW * j;
+          const double src_pos = (f_bin - g.freqMin) / g.srcBinW;
+          int b_lo = (int)src_pos;
+          int b_hi = (int)(src_pos + g.delta);
           const int psdSize = g.psdSize;
-          startBin = startBin < 0 ? 0 : (startBin > psdSize - 1 ? psdSize - 1 : startBin);
-          endBin = endBin < startBin + 1 ? startBin + 1 : (endBin > psdSize ? psdSize : endBin);
+          b_lo = b_lo < 0 ? 0 : (b_lo > psdSize - 1 ? psdSize - 1 : b_lo);
+          b_hi = b_hi < b_lo + 1 ? b_lo + 1 : (b_hi > psdSize ? psdSize : b_hi);
           // the source bins are summed in ascending order, as the reference does; eight requests in flight at a time
           // (c counts them: a sum of ones, exact)
           float a = 0;
-          int i = startBin;
-          for (; i + 8 <= endBin; i += 8) {
+          int i = b_lo;
+          for (; i + 8 <= b_hi; i += 8) {
             float s8[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s8[u] = psdData[i + u];
 #pragma unroll
             for (int u = 0; u < 8; ++u) a += s8[u];
           }
-          for (; i < endBin; i++) a += psdData[i];
-          const float c = (float)(endBin - startBin);
+          for (; i < b_hi; i++) a += psdData[i];
+          const float c = (float)(b_hi - b_lo);
           if (c > 0) { acc += a / c; cnt += 1; }
         }
         if (cnt > kCountMax && left_valid) {                      // interpolate(), Scanner.cpp:87-90
@@ -127,13 +127,13 @@ __global__ __launch_bounds__(256) void sweep_linear_kernel(const sdk::SpecViewLi
     __syncthreads();                                             // the list is rebuilt in the next round
   }
   if (live) {
-    psdAccum[j] = acc;
-    psdCount[j] = cnt;
+    acc_sum[j] = acc;
+    acc_cnt[j] = cnt;
   }
 }
 
 __global__ void feed_hist_kernel(sdk::SpecViewHist g, const float *__restrict__ psdData,
-                                 float *__restrict__ psdAccum, float *__restrict__ psdCount)
+                                 float *__restrict__ acc_sum, float *__restrict__ acc_cnt)
 {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   float accum = 0;
@@ -141,15 +141,15 @@ __global__ void feed_hist_kernel(sdk::SpecViewHist g, const float *__restrict__ 
   accum *= g.inv;
   const unsigned j = g.j;
   if (g.split) {
-    psdCount[j] += 1 - g.t;
-    psdAccum[j] += (1 - g.t) * accum;
+    acc_cnt[j] += 1 - g.t;
+    acc_sum[j] += (1 - g.t) * accum;
     if (j + 1 < g.spectrumSize) {
-      psdCount[j + 1] += g.t;
-      psdAccum[j + 1] += g.t * accum;
+      acc_cnt[j + 1] += g.t;
+      acc_sum[j + 1] += g.t * accum;
     }
   } else {
-    psdCount[j] += 1;
-    psdAccum[j] += accum;
+    acc_cnt[j] += 1;
+    acc_sum[j] += accum;
   }
 }
 
@@ -164,8 +164,8 @@ __global__ void feed_hist_kernel(sdk::SpecViewHist g, const float *__restrict__ 
 // group) and interpolate_reset_kernel applies them afterwards.  The expressions are the reference's (Scanner.cpp:56-116).
 constexpr int INTERP_WGS = 16;
 
-__global__ __launch_bounds__(1024) void interpolate_kernel(float *__restrict__ psd, const float *__restrict__ psdAccum,
-                                                           const float *__restrict__ psdCount, int n,
+__global__ __launch_bounds__(1024) void interpolate_kernel(float *__restrict__ psd, const float *__restrict__ acc_sum,
+                                                           const float *__restrict__ acc_cnt, int n,
                                                            unsigned long long *__restrict__ resetMask)
 {
   __shared__ unsigned long long mask[1024];
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(1024) void interpolate_kernel(float *__restrict__ p
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
       const int i = (wv * 64 + k0 + u) * 64 + lane;
-      c[u] = i < n ? psdCount[i] : 0.0f;
+      c[u] = i < n ? acc_cnt[i] : 0.0f;
     }
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
@@ -213,8 +213,8 @@ __global__ __launch_bounds__(1024) void interpolate_kernel(float *__restrict__ p
 #pragma unroll
   for (int u = 0; u < GPW; ++u) {
     const int i = (g0 + u) * 64 + lane;
-    c[u] = i < n ? psdCount[i] : 0.0f;
-    ac[u] = i < n ? psdAccum[i] : 0.0f;
+    c[u] = i < n ? acc_cnt[i] : 0.0f;
+    ac[u] = i < n ? acc_sum[i] : 0.0f;
   }
 #pragma unroll
   for (int u = 0; u < GPW; ++u) {
@@ -239,13 +239,13 @@ __global__ __launch_bounds__(1024) void interpolate_kernel(float *__restrict__ p
         const bool first = (left < 0);
         if (R >= n) {
           // trailing zeroes: take the value on the left (default when the whole view is empty)
-          outv = first ? kDefaultBin : psdAccum[left] / psdCount[left];
+          outv = first ? kDefaultBin : acc_sum[left] / acc_cnt[left];
         } else {
-          const float rightv = psdAccum[R] / psdCount[R];
+          const float rightv = acc_sum[R] / acc_cnt[R];
           if (first) {
             outv = rightv;
           } else {
-            const float leftv = psdAccum[left] / psdCount[left];
+            const float leftv = acc_sum[left] / acc_cnt[left];
             const unsigned count = (unsigned)(R - left - 1);
             const unsigned jj = (unsigned)(i - (left + 1));
             const float tt = (float)((float)jj + .5f) / count;
@@ -261,15 +261,15 @@ __global__ __launch_bounds__(1024) void interpolate_kernel(float *__restrict__ p
 }
 
 // count > 5 -> accum = mean, count = 1 for the bins interpolate_kernel marked (Scanner.cpp:87-90; psd[i] holds the mean)
-__global__ __launch_bounds__(256) void interpolate_reset_kernel(const float *__restrict__ psd, float *__restrict__ psdAccum,
-                                                                float *__restrict__ psdCount, int n,
+__global__ __launch_bounds__(256) void interpolate_reset_kernel(const float *__restrict__ psd, float *__restrict__ acc_sum,
+                                                                float *__restrict__ acc_cnt, int n,
                                                                 const unsigned long long *__restrict__ resetMask)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if ((resetMask[i >> 6] >> (i & 63)) & 1ull) {
-    psdCount[i] = kCountReset;
-    psdAccum[i] = psd[i] * kCountReset;
+    acc_cnt[i] = kCountReset;
+    acc_sum[i] = psd[i] * kCountReset;
   }
 }
 
