@@ -587,7 +587,7 @@ def run_c5(args, dev, ctx, log2_file=30, N=8192, tile=256, rank=0, world=1, dist
     The capture is fixed (2^log2_file samples over all ranks): strong scaling."""
     total = 1 << log2_file
     dwells_all = total // (N * tile)
-    mine = np.arange(rank, dwells_all, world)
+    mine = pipeline.shard_frames(dwells_all, rank, world)
     dwells = len(mine)
     share = dwells * N * tile
     x = torch.empty(share, dtype=torch.complex64, device=dev)

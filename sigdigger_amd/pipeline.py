@@ -509,6 +509,13 @@ def channel_owner(c, world):
     return c % world, c // world
 
 
+def shard_frames(nframes, rank, world):
+    """frame (dwell) f of a panoramic sweep -> rank f mod G ("C5 shards by frame"; the frames are
+    independent -- Panoramic/Scanner.cpp:503-523 feeds them one by one into bins that only they cover): the indices this rank
+    transforms.  No exchange: every rank keeps its own SpectrumView over the whole range."""
+    return np.arange(int(rank), int(nframes), int(world))
+
+
 def broadcast_block(buf, dist, src=0, async_op=True):
     """The one exchange step of the multi-GPU path: rank `src` holds the IQ block, every rank
     needs it (RCCL broadcast over xGMI on GPUs; gloo in the CPU tests).  Returns the work handle

@@ -26,6 +26,16 @@ def test_shard_channels_is_a_partition():
             assert parts[r][i] == fn[c]
 
 
+def test_shard_frames_is_a_partition():
+    """C5 (BASELINE.json configs[4]) shards by frame: dwell f of the sweep on rank f mod G, nothing exchanged"""
+    for nframes in (512, 513, 7):
+        for world in (1, 2, 4, 8):
+            parts = [pipeline.shard_frames(nframes, r, world) for r in range(world)]
+            assert sorted(np.concatenate(parts).tolist()) == list(range(nframes))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+            assert all(np.all(p % world == r) for r, p in enumerate(parts))
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -40,19 +40,21 @@ with open(os.path.join(prof, f"{tag}_kernel_stats_summary.md"), "w") as f:
             f.write(f"| {n} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
                     f"{float(r['MaxNs'])/1e3:.1f} | {r['Percentage']} |\n")
     f.write(f"# rocprofv3 --kernel-trace --stats, {tag} (MI355X)\n\n")
-    f.write("`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-extra --no-cpu-baseline`\n"
+    f.write("`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --lean`\n"
             "(tools/profile_round.sh): the default workload (C4 slice: 8192-pt PSD + 64 QPSK inspectors; "
             f"{block} samples per block, {bj['steps'] if bj else '?'} steps + {bj['warmup'] if bj else '?'} warm-up).\n"
             f"Our kernels only; the full table (with torch's synthetic-data kernels) is `{tag}_kernel_stats.csv`.\n\n")
     if bj:
-        f.write(f"Bench line under the profiler: value = {bj['value']} MS/s, stage_ms = {bj['roofline']['stage_ms']}.\n\n")
+        f.write(f"Bench line under the profiler: value = {bj['value']} MS/s, stage_ms = {bj.get('stage_ms', bj['roofline'].get('stage_ms'))}; "
+                f"the bench's own timer for the channeliser in the same run: {bj['roofline'].get('kernel_ms')} ms "
+                f"(min / max {bj['roofline'].get('kernel_ms_min_max')}).\n\n")
     table(rows)
     f.write("\nThe serial (one-lane-per-channel) kernels run concurrently on separate streams, so their percentages add up "
             "to more than the wall time; the step time is the slowest of them.\n")
     stats_all = glob.glob(os.path.join(out, "trace_all", "**", "*kernel_stats.csv"), recursive=True)
     if stats_all:
         f.write("\n## with the secondary workloads (C2, C3, C5 and the live analyzer with 64 inspectors after the default one)\n\n"
-                "Same command without `--no-extra`; kernels shared by several workloads aggregate all of them\n"
+                "`python bench.py --extra --no-pmc --no-cpu-baseline` under the same profiler; kernels shared by several workloads aggregate all of them\n"
                 "(psd_kernel<13, 256, true> is C5's 8.6 GB launch, stp_kernel<6, true, .> includes the bench's launches of the\n"
                 "kernel alone on 4 Mi and 16 Mi blocks, the recurrence kernels C2's 16x longer rows).\n\n")
         table(list(csv.DictReader(open(stats_all[0]))))
@@ -109,6 +111,9 @@ doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
 doc["kernels"] = best
 json.dump(doc, open(p_old, "w"), indent=1)
 for a, b in (("bench.json", f"{tag}_bench.json"), ("bench_isolated.json", f"{tag}_bench_isolated.json"),
+             ("bench_driver_command.json", f"{tag}_bench_driver_command.json"), ("bench_detail.json", f"{tag}_bench_detail.json"),
+             ("bench_detail_extra.json", f"{tag}_bench_detail_extra.json"), ("clock_staggered.txt", f"{tag}_clock_staggered.txt"),
+             ("live_analyzer.txt", f"{tag}_live_analyzer.txt"), ("live_kernel_stats.csv", f"{tag}_live_kernel_stats.csv"),
              ("bench_under_rocprof.json", f"{tag}_bench_under_rocprof.json"), ("kernel_microbench.txt", f"{tag}_kernel_microbench.txt")):
     src = os.path.join(out, a)
     if os.path.exists(src) and os.path.getsize(src) > 0:

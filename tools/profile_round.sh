@@ -16,8 +16,19 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python bench.py --steps 4 --warmup 1 --lean > /dev/null 2> $OUT/pmc_$c.err
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmcall_$c -o p -- python bench.py --steps 4 --warmup 1 --extra --no-pmc --no-cpu-baseline > /dev/null 2> $OUT/pmcall_$c.err
 done
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
-python bench.py --lean --isolated --no-pmc > $OUT/bench_isolated.json 2>> $OUT/bench.err
+# the driver's exact command (its compact line + the detail file), the default command (150 steps) with the secondary workloads
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_command.json 2> $OUT/bench.err
+cp bench_detail.json $OUT/bench_detail.json
+python bench.py --extra > $OUT/bench.json 2>> $OUT/bench.err
+cp bench_detail.json $OUT/bench_detail_extra.json
+python bench.py --lean --isolated > $OUT/bench_isolated.json 2>> $OUT/bench.err
+# the bank clock recovery, aligned / staggered symbol clocks, in its three schedules
+for m in 2 1 0; do SUAMD_CLOCK_MODE=$m python tools/clock_stagger.py 2>/dev/null; done > $OUT/clock_staggered.txt
+# the boundary: BASELINE configs[3]'s per-GPU slice through the suscan ABI, and rocprofv3's view of its kernels
+for lg in 21 22; do LIVE_LOG2=$lg python tools/live_c4.py 2>/dev/null | tail -1; done > $OUT/live_analyzer.txt
+for s in 0; do SUAMD_ST_ROW_STAGE=$s LIVE_LOG2=21 python tools/live_c4.py 2>/dev/null | tail -1; done >> $OUT/live_analyzer.txt
+(cd /tmp && LIVE_LOG2=21 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_live -o t -- python $REPO/tools/live_c4.py > /dev/null 2> $OUT/trace_live.err)
+f=$(find $OUT/trace_live -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/live_kernel_stats.csv
 python tools/st_bench.py > $OUT/kernel_microbench.txt 2>&1
 python tools/fir_bench.py >> $OUT/kernel_microbench.txt 2>&1
 python tools/fir_c1.py >> $OUT/kernel_microbench.txt 2>&1
