@@ -1442,12 +1442,19 @@ hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, cons
                       long long len, void *sym, long long sym_stride, uint32_t *count, hipStream_t st)
 {
   if (len <= 0 || nchan <= 0) return hipSuccess;
-  // the schedule: 2 = round by round (clock_ring), whenever a half cycle is at most 24 samples (beyond that crossings are rare
-  // and the lock-step form's three instructions per sample win); 0 = lock step; 1 = clock_stream_tm.  sdk::tuning().clock_mode pins it (A / B).
+  // The schedule.  2 = round by round (clock_ring): a round (~105 instructions + staging) per half cycle whatever the lanes'
+  // timing; 0 = lock step: 3 instructions per sample + the ~45-instruction crossing code whenever ANY lane crosses -- with
+  // n unrelated clocks that is a fraction 1 - (1 - 1 / k)^n of the samples (k = samples per half cycle).  One or two
+  // channels (BASELINE configs[1]: ONE inspector at 5 samples per symbol) cross rarely enough for the lock step to win (125 vs
+  // ~100 ns per sample at k = 2.5), 64 staggered ones never (139 vs 56 at k = 7.8); slow symbol rates (k > 24) keep the lock
+  // step as well.  1 = clock_stream_tm.  sdk::tuning().clock_mode pins a schedule (A / B).
   const int forced = (int)sdk::tuning().clock_mode;
   const float bhint = 2.0f * p.bmin;
   int steps = (int)ceilf(0.5f / bhint) + 1;
-  const int mode = forced >= 0 ? forced : (steps <= 25 ? 2 : 0);
+  const double inv_k = fmin(1.0, 2.0 * (double)bhint);
+  const double cost_lock = 3.0 + 45.0 * (1.0 - pow(1.0 - inv_k, (double)(nchan < 64 ? nchan : 64)));
+  const double cost_ring = 107.0 * inv_k + 2.0;
+  const int mode = forced >= 0 ? forced : ((steps <= 25 && cost_ring < cost_lock) ? 2 : 0);
   steps = 3 * ((steps + 2) / 3);                               // (clock_ring advances in groups of three)
   if (steps > 30) steps = 30;
   if (steps < 3) steps = 3;
