@@ -1095,11 +1095,16 @@ def main():
             pmc_thread.start()
         cpu = None
         if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (rank 0's host cores)
-            cpu = cpu_baseline(cfg, args.cpu_samples, fn_rank, os.cpu_count() or 1, args.channeliser)
-            detail["cpu_baseline"] = dict(cpu)
-            ref = reference_loops()
-            if ref is not None:
-                detail["cpu_baseline"]["reference_loops"] = ref
+            try:
+                cpu = cpu_baseline(cfg, args.cpu_samples, fn_rank, os.cpu_count() or 1, args.channeliser)
+                detail["cpu_baseline"] = dict(cpu)
+                ref = reference_loops()
+                if ref is not None:
+                    detail["cpu_baseline"]["reference_loops"] = ref
+            except Exception as e:                            # (the line must come out even if the CPU leg cannot run)
+                cpu = None
+                detail["cpu_baseline"] = {"error": repr(e)[:300]}
+                print(f"# bench.py: cpu_baseline failed: {e!r}", file=sys.stderr)
         if pmc_thread is not None:
             pmc_thread.join()
             pmc = box.get("r") or {}
