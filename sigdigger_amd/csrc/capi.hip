@@ -1652,7 +1652,23 @@ SUBOOL suamd_clock_gang_feed(suamd_ctx_t *ctx, suamd_clock_bank_t *const *banks,
     if (!banks[i] || banks[i]->nchan != 1) { set_err("gang members must be 1-channel banks"); return SU_FALSE; }
     if (len[i] == 0) continue;
     if (!d_x[i] || !d_sym[i] || !d_count[i]) { set_err("null row"); return SU_FALSE; }
-    items.push_back(sdk::ClockGangItem{banks[i]->p, banks[i]->s, d_x[i], (long long)len[i], d_sym[i], d_count[i]});
+    items.push_back(sdk::ClockGangItem{banks[i]->p, banks[i]->s, d_x[i], (long long)len[i], d_sym[i], d_count[i], 0, 0});
+  }
+  // per group of 64 items (one wavefront): the schedule.  Round by round (loops.hip clock_ring) when there are enough lanes for
+  // their crossings to spread over the samples and every item's half cycle is short enough for one round's advance steps;
+  // sdk::tuning().clock_mode 0 / 1 keeps the crossing-by-crossing form (A / B)
+  for (size_t g0 = 0; g0 < items.size(); g0 += 64) {
+    const size_t g1 = std::min(items.size(), g0 + 64);
+    int steps = 0;
+    bool same = true;
+    for (size_t q = g0; q < g1; ++q) {
+      steps = std::max(steps, (int)std::ceil(0.5f / (2.0f * items[q].p.bmin)) + 1);
+      same = same && std::memcmp(&items[q].p, &items[g0].p, sizeof(sdk::ClockParams)) == 0;
+    }
+    const long long forced = sdk::tuning().clock_mode;
+    const bool ring = forced >= 0 ? forced == 2 : (g1 - g0 >= 3 && steps <= 25);
+    steps = std::min(30, 3 * ((steps + 2) / 3));
+    for (size_t q = g0; q < g1; ++q) { items[q].steps = ring ? steps : 0; items[q].uniform = same ? 1 : 0; }
   }
   for (size_t o = 0; o < items.size(); o += 512) {
     std::vector<sdk::ClockGangItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));

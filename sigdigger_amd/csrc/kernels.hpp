@@ -187,7 +187,9 @@ hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, cons
 // a gang runs their recurrences side by side like a bank does).  Rows are contiguous (unit time stride),
 // lengths may differ per item.  items: device array.
 struct CostasGangItem { CostasParams p; CostasState s; const void *x; void *y; long long len; };
-struct ClockGangItem { ClockParams p; ClockState s; const void *x; long long len; void *sym; uint32_t *count; };
+struct ClockGangItem { ClockParams p; ClockState s; const void *x; long long len; void *sym; uint32_t *count;
+                       int steps;      // > 0: the item's group of 64 runs round by round (clock_ring) with this many advance steps; 0: clock_stream_tm
+                       int uniform; }; // every item of the group has the same parameters
 struct PllGangItem { float alpha, beta; PllState s; const void *x; void *y; long long len; };
 // symbol rows: the length is *count when count != nullptr (the clock gang's device-side counts), else fixed_len
 struct CmaGangItem { float mu; int locked; void *w; void *dl; const void *x; void *y; const uint32_t *count; long long fixed_len; };

@@ -366,6 +366,9 @@ __global__ __launch_bounds__(64) void costas_kernel(sdk::CostasParams p, sdk::Co
   bool mine;
   const int c = serial_block(xcd, mine) * 64 + threadIdx.x;
   if (!mine || c >= nchan) return;
+  // (measured both ways, round 6: these parameters in VGPRs instead of the kernel argument's SGPRs -- 21.08 against 20.5 ms per
+  // 64 x 262144 samples; the gang's per-lane parameters made wave-uniform -- 828 against 747 us per 64 x 8192.  Each form keeps
+  // the operand kind its instruction selection was tuned with.)
   CostasRegs<ORDER> r;
   r.phase = s.phase[c];
   r.omega = s.omega[c];
@@ -915,6 +918,10 @@ __global__ __launch_bounds__(256) void rows_tm_scatter_kernel(const char *__rest
   }
 }
 
+// (Round 6 tried a UNIFORM form for groups whose items have identical parameters -- 64 inspectors opened alike --, the parameters
+// read once and kept in SGPRs like a bank's: SLOWER, 828 against 747 us per 64 x 8192 samples.  A VOP3P instruction reads one
+// SGPR operand; thirteen scalar parameters cost more v_mov than the per-lane VGPRs cost anything.  Taken back.)
+__device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 template <int KIND, int ORDER, bool GAIN1>
 __device__ __forceinline__ void costas_gang_body(const sdk::CostasGangItem *__restrict__ items, int count, float2 *tm)
 {
@@ -1111,24 +1118,31 @@ __device__ __forceinline__ void clock_stream_tm(const float2 *base, const long l
 // a round: the rounds stop U samples before the end and a plain per-sample loop (clock_step on per-lane indices) finishes
 // the block -- <= 2 U samples per call.  Per lane the operations and their order are clock_step's: same bits.
 constexpr int RT = 64, RING = 2 * RT;
+// `len` is per lane (a bank passes the same for every live lane; a gang's items have their own): a lane within U samples of its
+// end sits the rounds out ("tail") and the rounds go on while any lane is not there yet.  Rows must be readable up to the
+// longest lane's length (a bank's are that long; a gang's slab has whole tiles of slack).  `p` may be wave-uniform (a bank:
+// SGPRs) or per lane (a gang).
 __device__ __forceinline__ void clock_ring(const float2 *base, const long long pitch, const uint32_t lo, const long long len, const bool live,
                                            const int U, const sdk::ClockParams &p, ClockRegs &r, float2 *__restrict__ out, float2 *ring)
 {
   const int lane = threadIdx.x;
-  // y index of the next sample a lane consumes (idle lanes: beyond everything)
-  long long ny = live ? 1 : (1ll << 40);
-  if (len >= 4 * (long long)U + 2 * RT) {
-    const int ylen = (int)(len < (1ll << 30) ? len : (1ll << 30));   // y indices as 32-bit numbers inside a call
+  const long long mylen = live ? len : 0;
+  const long long maxlen = uniform64(wave_max(mylen));
+  // y index of the next sample a lane consumes
+  long long ny = 1;
+  if (maxlen >= 4 * (long long)U + 2 * RT) {
+    const int ylen = (int)(mylen < (1ll << 30) ? mylen : (1ll << 30));   // y indices as 32-bit numbers inside a call
+    const long long loadable = maxlen < (1ll << 30) ? maxlen : (1ll << 30);
     // tile T holds y[T * RT .. T * RT + RT); request(T) loads it into registers
     float2 pre[RT];
     auto request = [&](int T) {
       const long long y0 = (long long)T * RT;                        // x index: y index - 1
-      if (y0 >= 1 && y0 + RT - 1 <= len) {
+      if (y0 >= 1 && y0 + RT - 1 <= loadable) {
 #pragma unroll
         for (int j = 0; j < RT; ++j) pre[j] = ld_elem(base, (y0 + j - 1) * pitch, lo);
       } else {
 #pragma unroll
-        for (int j = 0; j < RT; ++j) pre[j] = (y0 + j >= 1 && y0 + j <= len) ? ld_elem(base, (y0 + j - 1) * pitch, lo) : float2{0.0f, 0.0f};
+        for (int j = 0; j < RT; ++j) pre[j] = (y0 + j >= 1 && y0 + j <= loadable) ? ld_elem(base, (y0 + j - 1) * pitch, lo) : float2{0.0f, 0.0f};
       }
     };
     auto commit = [&](int T) {
@@ -1141,21 +1155,22 @@ __device__ __forceinline__ void clock_ring(const float2 *base, const long long p
     request(1); commit(1);
     int wlo = 0;                                                     // the ring holds y[wlo, wlo + RING)
     request(2);
-    int n = live ? 1 : (1 << 30);                                    // ny as an int
+    int n = 1;
     float phi = r.phi, bnor = r.bnor;
     int hc = r.halfcycle;
     float2 x0 = r.x0, x1 = r.x1, x2 = r.x2;
     uint32_t cnt = r.n;
-    const int stop = ylen + 1 - U;                                   // a round needs n + U <= ylen + 1
+    const int stop = ylen + 1 - U;                                   // a round needs n + U <= ylen + 1 (idle and short lanes: never)
     for (;;) {
+      const bool tail = n > stop;                                    // this lane's rounds are over: the rest below, sample by sample
+      if (__all(tail)) break;
       // every lane has left the ring's older tile: replace it by the tile that waits in registers, request the next one
-      if (__all(n > wlo + RT)) {
+      if (__all(tail || n > wlo + RT)) {
         commit(wlo / RT + 2);
         wlo += RT;
         request(wlo / RT + 2);
       }
-      if (__any(live && n > stop)) break;                            // the end of the block: finished below
-      const bool act = n + U <= wlo + RING;                          // (a lane far ahead of the others waits for the ring)
+      const bool act = !tail && n + U <= wlo + RING;                 // (a lane far ahead of the others waits for the ring)
       float pp = phi;
       uint32_t sel = 0xffffffffu, bits = 0;
       for (int g = 0; g < U; g += 3) {                               // (U is a multiple of three: the loop counter is scalar work)
@@ -1205,7 +1220,7 @@ __device__ __forceinline__ void clock_ring(const float2 *base, const long long p
     }
   }
   // the rest of the block, sample by sample, every lane from where it is
-  const long long left = live ? len + 1 - ny : 0;
+  const long long left = live ? mylen + 1 - ny : 0;
   const long long most = uniform64(wave_max(left));
   for (long long i = 0; i < most; ++i) {
     if (i < left) clock_step(p, r, ld_elem(base, (ny - 1 + i) * pitch, lo), out);
@@ -1258,10 +1273,16 @@ __global__ __launch_bounds__(64) void clock_kernel(sdk::ClockParams p, sdk::Cloc
 
 __global__ __launch_bounds__(64) void clock_gang_kernel(const sdk::ClockGangItem *__restrict__ items, int n, float2 *tm, long long slab)
 {
+  __shared__ float2 lds[RING * 64];                             // clock_ring's two tiles; clock_stream_tm uses the first
   const int j = blockIdx.x * 64 + threadIdx.x;
   const bool live = j < n;
   const sdk::ClockGangItem it = items[live ? j : 0];
-  const sdk::ClockParams p = it.p;
+  sdk::ClockParams p = it.p;
+  // (the host writes one `steps` / `uniform` per group of 64 items; lane 0 of a workgroup is always live)
+  const int steps = __builtin_amdgcn_readfirstlane(it.steps);
+  if (__builtin_amdgcn_readfirstlane(it.uniform)) {
+    p.alpha = uniform_f(p.alpha); p.beta = uniform_f(p.beta); p.gain = uniform_f(p.gain); p.bmin = uniform_f(p.bmin); p.bmax = uniform_f(p.bmax);
+  }
   const sdk::ClockState s = it.s;
   ClockRegs r;
   r.phi = s.phi[0]; r.bnor = s.bnor[0];
@@ -1273,8 +1294,10 @@ __global__ __launch_bounds__(64) void clock_gang_kernel(const sdk::ClockGangItem
   r.n = it.count[0];
   const long long len = live ? it.len : 0;
   float2 *out = reinterpret_cast<float2 *>(it.sym);
-  __shared__ float2 tile[CT * 64];
-  clock_stream_tm<true>(tm + (size_t)blockIdx.x * slab, 64, threadIdx.x * 8u, len, p, r, out, tile);
+  // round by round when the group's symbol rates allow it (the banks' schedule: staggered symbol clocks cost nothing), else
+  // crossing by crossing
+  if (steps > 0) clock_ring(tm + (size_t)blockIdx.x * slab, 64, threadIdx.x * 8u, len, live, steps, p, r, out, lds);
+  else clock_stream_tm<true>(tm + (size_t)blockIdx.x * slab, 64, threadIdx.x * 8u, len, p, r, out, lds);
   if (!live) return;
   s.phi[0] = r.phi; s.bnor[0] = r.bnor; s.halfcycle[0] = r.halfcycle;
   s.prev[0] = r.prev.x; s.prev[1] = r.prev.y;

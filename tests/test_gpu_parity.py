@@ -1131,6 +1131,48 @@ def test_gangs_of_heterogeneous_banks_bit_exact(ctx, sdo):
         assert_bits(host(syms[i][:k]), ref, f"gang item {i}: symbols")
 
 
+@pytest.mark.parametrize("kind,arm,n", [(2, 3, 64), (1, 1, 70), (3, 3, 9)])
+def test_gangs_of_inspectors_opened_alike_bit_exact(ctx, sdo, kind, arm, n):
+    """BASELINE configs[3]'s case: every inspector of a gang with the SAME loop parameters (round 6: such a group's Costas
+    parameters travel in SGPRs, costas_gang_body UNIFORM) -- carriers with their own symbol timing, rows of different
+    lengths, two rounds of calls; every item equals its oracle bit for bit, state included, and so does a gang in which one
+    item differs (the per-lane path) on the same input."""
+    rng = np.random.default_rng(kind * 100 + n)
+    sps, lbw = 8, 0.01
+    lens = rng.integers(3000, 6000, n)
+    lens[:3] = [0, 1, 5999]
+    xs_h = [np.roll(synth.psk_carriers(max(int(L_), 1) + 64, [0.002 * (i % 5 - 2)], sps=sps, order=int(2 ** kind), seed=300 + i), 3 * i)[:int(L_)]
+            for i, L_ in enumerate(lens)]
+    cuts = [(0, int(L_) // 3) for L_ in lens], [(int(L_) // 3, int(L_)) for L_ in lens]
+    res = {}
+    for variant in ("alike", "one_differs"):
+        lb = [lbw] * n
+        if variant == "one_differs":
+            lb[n // 2] = 0.013
+        cos = [engine.CostasBank(ctx, 1, kind, 0.0, 2.0 / sps, arm, float(lb[i])) for i in range(n)]
+        clk = [engine.ClockBank(ctx, 1, 0.2, 1.0 / sps) for i in range(n)]
+        syms = [torch.zeros(int(L_) + 2, dtype=torch.complex64, device="cuda") for L_ in lens]
+        cnts = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(n)]
+        outs = [[] for _ in range(n)]
+        for rnd in cuts:
+            xs = [dev(xs_h[i][a:b]) if b > a else torch.empty(0, dtype=torch.complex64, device="cuda") for i, (a, b) in enumerate(rnd)]
+            yz = [torch.empty_like(x) for x in xs]
+            engine.gang_costas(ctx, cos, xs, yz)
+            engine.gang_clock(ctx, clk, yz, syms, cnts)
+            for i in range(n):
+                outs[i].append(host(yz[i]))
+        for i in range(n):
+            st = sdo.costas_new(kind, 0.0, 2.0 / sps, arm, float(lb[i]))
+            z = sdo.costas_feed_bulk(st, xs_h[i]) if lens[i] else xs_h[i]
+            assert_bits(np.concatenate(outs[i]), z, f"{variant}, item {i}: costas output")
+            om, ph = cos[i].state()
+            assert ph[0] == st.phase and np.float32(st.omega) == om[0]
+            ref = sdo.clock_feed_bulk(sdo.clock_new(0.2, 1.0 / sps), z) if lens[i] else z
+            k = int(cnts[i].cpu()[0])
+            assert k == ref.size, f"{variant}, item {i}: symbol count"
+            assert_bits(host(syms[i][:k]), ref, f"{variant}, item {i}: symbols")
+
+
 def test_gangs_larger_than_a_descriptor_slot(ctx, sdo):
     """700 inspectors' worth of items: the gangs split into several descriptor tables / launches (512 items per slot,
     448 for the Costas loops, 256 for the channeliser) and every item still equals its oracle"""

@@ -404,7 +404,7 @@ def test_random_banks_and_splits_two_wavefront_kernel_against_one(ctx, tune, see
 
 
 @pytest.mark.parametrize("dec", [64, 128, 256, 512])
-def test_row_tables_with_32_bit_offsets_give_the_same_samples(ctx, dec):
+def test_row_tables_with_32_bit_offsets_give_the_same_samples(ctx, tune, dec):
     """suamd_specttuner_feed_rows_near: one row per channel, all of one arena -- the kernels address them with 32-bit offsets
     from the lowest row (and every narrow size runs on the two-wavefront kernel).  Same samples as the view and as the
     plain row table, bit for bit; rows in scrambled order, a hole in the channel table (a closed channel), two feeds."""
@@ -414,7 +414,10 @@ def test_row_tables_with_32_bit_offsets_give_the_same_samples(ctx, dec):
     chans = [(0.1 + 6.0 * c / nch, 2 * np.pi / dec * (0.75 if c % 3 else 0.6), 1.0, bool(c % 7 == 0)) for c in range(nch)]
     cap = x.size // dec + 64
     outs = {}
-    for mode in ("view", "rows", "near"):
+    # "near": 64-bin channels leave through stp_kernel's LDS transposition (round 6, ROWT: sixteen lanes per 256 bytes of a
+    # row); "near_lane_per_row": the same rows with tuning().st_row_stage = 0 (lane = channel, 8 bytes per row and store)
+    for mode in ("view", "rows", "near", "near_lane_per_row"):
+        tune.setenv("SUAMD_ST_ROW_STAGE", 0 if mode == "near_lane_per_row" else 1)
         st = engine.SpectTuner(ctx, W)
         st.set_run(3)
         ids = [st.open_channel(*c) for c in chans]
@@ -428,7 +431,7 @@ def test_row_tables_with_32_bit_offsets_give_the_same_samples(ctx, dec):
                 rows = [out[c] for c in ids]
             else:
                 rows = [arena[order[c]] for c in ids]
-                counts = st.feed_rows(dx[lo:hi], [None if c == ids[5] else rows[c] for c in ids], near=(mode == "near"))
+                counts = st.feed_rows(dx[lo:hi], [None if c == ids[5] else rows[c] for c in ids], near=mode.startswith("near"))
             torch.cuda.synchronize()
             for c in ids:
                 if c != ids[5]:
@@ -441,6 +444,7 @@ def test_row_tables_with_32_bit_offsets_give_the_same_samples(ctx, dec):
         assert outs["view"][c].size == x.size // dec - (W // dec) // 2, c
         assert np.array_equal(outs["view"][c].view(np.uint32), outs["rows"][c].view(np.uint32)), (dec, c)
         assert np.array_equal(outs["view"][c].view(np.uint32), outs["near"][c].view(np.uint32)), (dec, c)
+        assert np.array_equal(outs["view"][c].view(np.uint32), outs["near_lane_per_row"][c].view(np.uint32)), (dec, c)
 
 
 @pytest.mark.parametrize("dec,nch", [(512, 5), (512, 64), (256, 70), (128, 3)])
