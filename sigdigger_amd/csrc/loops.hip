@@ -828,8 +828,9 @@ __device__ __forceinline__ long long uniform64(long long v)
 }
 
 template <bool HAS_OUT, typename T, typename F>
-__device__ __forceinline__ void gang_stream_tm(T *tm, long long len, F step)
+__device__ __forceinline__ void gang_stream_tm(T *tm_io, long long len, F step)
 {
+  T *tm = tm_io, *tmo = tm_io;
   const uint32_t lo = threadIdx.x * (uint32_t)sizeof(T);
   const long long maxlen = uniform64(wave_max(len));
   if (maxlen <= 0) return;
@@ -844,7 +845,7 @@ __device__ __forceinline__ void gang_stream_tm(T *tm, long long len, F step)
       if (len > 0) {
 #pragma unroll
         for (int j = 0; j < CHUNK; ++j) {
-          if constexpr (HAS_OUT) st_elem(tm, (i + j) * 64, lo, step(i + j, cur[j]));
+          if constexpr (HAS_OUT) st_elem(tmo, (i + j) * 64, lo, step(i + j, cur[j]));
           else step(i + j, cur[j]);
         }
       }
@@ -852,7 +853,7 @@ __device__ __forceinline__ void gang_stream_tm(T *tm, long long len, F step)
 #pragma unroll
       for (int j = 0; j < CHUNK; ++j) {
         if (i + j < len) {
-          if constexpr (HAS_OUT) st_elem(tm, (i + j) * 64, lo, step(i + j, cur[j]));
+          if constexpr (HAS_OUT) st_elem(tmo, (i + j) * 64, lo, step(i + j, cur[j]));
           else step(i + j, cur[j]);
         }
       }

@@ -424,7 +424,23 @@ def _verify(i, rp, G, fresh_anchor):
                             break
                 if ok:
                     break
-            assert ok, f"inspector {i.req} (psk, fc {fc}, bw {bw}, precise {i.precise}, cfg {cfg}, shard {i.handle % G}): {got.size} symbols after set_config at block ~{at} (open ~{p_open}) match no replay"
+            if not ok:
+                # diagnosis: does ANY pair of boundaries within +- 12 blocks reproduce the symbols (a skew beyond the search window),
+                # or a prefix of them (a stream that goes wrong somewhere)?
+                wide = []
+                for p_cfg in range(max(0, at - 12), at + 13):
+                    for po in ([p_cfg] if rp.channeliser == "fir" else range(max(0, p_open - 12), min(p_cfg, p_open + 12) + 1)):
+                        y = rp.channel(po, fc, bw, i.precise, nb + (p_cfg - po) + 8)[(p_cfg - po) * blk:]
+                        exp = rp.symbols(y, D, cfg)
+                        m = min(exp.size, got.size)
+                        eq = _bits(got[:m]) == _bits(exp[:m])
+                        first = int(np.argmin(eq)) if not eq.all() else m
+                        if first > 16:
+                            wide.append((p_cfg, po, first, m))
+                diag = sorted(wide, key=lambda w: -w[2])[:4]
+            assert ok, (f"inspector {i.req} (psk, fc {fc}, bw {bw}, precise {i.precise}, cfg {cfg}, shard {i.handle % G}): {got.size} symbols after set_config "
+                        f"at block ~{at} (open ~{p_open}) match no replay; events {[it[1:] for it in i.items if it[0] == 'ev']}; "
+                        f"widest agreements (cfg block, open block, equal symbols, compared): {diag}")
             checked += got.size
     return checked
 
