@@ -226,6 +226,14 @@ SUAMD_API SUBOOL suamd_specttuner_feed_rows(suamd_specttuner_t *st, const suamd_
 SUAMD_API SUBOOL suamd_specttuner_feed_rows_near(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len,
                                                  suamd_complex *const *d_rows, const void *d_base, size_t span_bytes,
                                                  SUSCOUNT *counts, void *stream);
+/* Both at once: channels of at most `view_max_size` bins (the narrow sizes, whose kernels store one channel per lane) go
+ * through the view -- a time-major slab {1, pitch} keeps those stores contiguous --, wider ones to their rows as in
+ * _feed_rows_near (d_base NULL: as in _feed_rows).  The live analyzer's feed: narrow inspectors are columns of one slab,
+ * wide ones own their rows. */
+SUAMD_API SUBOOL suamd_specttuner_feed_mixed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len,
+                                             suamd_complex *d_y, suamd_view view, unsigned view_max_size,
+                                             suamd_complex *const *d_rows, const void *d_base, size_t span_bytes,
+                                             SUSCOUNT *counts, void *stream);
 /* windows per workgroup run (default 3): a run re-transforms the window before it */
 SUAMD_API SUBOOL suamd_specttuner_set_run(suamd_specttuner_t *st, unsigned run);
 /* How many of the chip's 1024 window slots (4 windows per CU: the LDS) a launch of the narrow-channel kernels may plan
@@ -528,6 +536,50 @@ SUAMD_API SUBOOL suamd_rows_deliver(suamd_ctx_t *ctx, unsigned n, const suamd_co
 SUAMD_API SUBOOL suamd_clock_gang_feed(suamd_ctx_t *ctx, suamd_clock_bank_t *const *banks, unsigned n,
                                        const suamd_complex *const *d_x, const SUSCOUNT *len,
                                        suamd_complex *const *d_sym, uint32_t *const *d_count, void *stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Gangs on time-major slabs.  The same one-channel banks when their rows are COLUMNS of one slab per side     */
+/* already -- what suamd_specttuner_feed leaves with the view {1, pitch}: sample m of item i at               */
+/* d_x[i][m * x_pitch], the items side by side in a slab row.  Nothing is gathered or scattered: a            */
+/* recurrence wavefront streams the slab where it lies (512 contiguous bytes per time step for 64 adjacent     */
+/* columns), the feed-forward AGC steps work in tiles of 64 columns.  This is how the live analyzer serves     */
+/* the inspectors of its FFT filter bank (Suscan/Analyzer.cpp:411-484: independent handles, one shared         */
+/* baseband).  Results are bit-identical to the row forms above.  The row starts of a side must lie within     */
+/* 4 GiB of the lowest one, and a slab must be readable 64 rows beyond its longest item.                       */
+/* ------------------------------------------------------------------------------------ */
+SUAMD_API SUBOOL suamd_costas_gang_feed_slab(suamd_ctx_t *ctx, suamd_costas_bank_t *const *banks, unsigned n,
+                                             const suamd_complex *const *d_x, SUSCOUNT x_pitch,
+                                             suamd_complex *const *d_y, SUSCOUNT y_pitch, const SUSCOUNT *len, void *stream);
+SUAMD_API SUBOOL suamd_pll_gang_feed_slab(suamd_ctx_t *ctx, suamd_pll_bank_t *const *banks, unsigned n,
+                                          const suamd_complex *const *d_x, SUSCOUNT x_pitch,
+                                          suamd_complex *const *d_y, SUSCOUNT y_pitch, const SUSCOUNT *len, void *stream);
+/* (symbols still leave as contiguous rows d_sym[i], counted in *d_count[i]: they are few) */
+SUAMD_API SUBOOL suamd_clock_gang_feed_slab(suamd_ctx_t *ctx, suamd_clock_bank_t *const *banks, unsigned n,
+                                            const suamd_complex *const *d_x, SUSCOUNT x_pitch, const SUSCOUNT *len,
+                                            suamd_complex *const *d_sym, uint32_t *const *d_count, void *stream);
+/* The AGC's four steps (suamd_agc_gang_pre / _level / _apply / _finish).  Item i is column d_x[i] - d_x_slab (< x_pitch)
+ * of the input slab; its magnitudes and levels live in the same column of two work slabs the caller lends for the
+ * block: d_work holds 2 * work_rows * x_pitch floats, work_rows >= every len[i].  _apply writes column
+ * d_y[i] - d_y_slab of the output slab.  mag_history_size and delay_line_size <= 64. */
+SUAMD_API SUBOOL suamd_agc_gang_pre_slab(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n,
+                                         const suamd_complex *d_x_slab, SUSCOUNT x_pitch, const suamd_complex *const *d_x,
+                                         const SUSCOUNT *len, float *d_work, SUSCOUNT work_rows, void *stream);
+SUAMD_API SUBOOL suamd_agc_gang_level_slab(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n,
+                                           const suamd_complex *d_x_slab, SUSCOUNT x_pitch, const suamd_complex *const *d_x,
+                                           const SUSCOUNT *len, const SUSCOUNT *m0, const SUSCOUNT *m1,
+                                           float *d_work, SUSCOUNT work_rows, void *stream);
+SUAMD_API SUBOOL suamd_agc_gang_apply_slab(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n,
+                                           const suamd_complex *d_x_slab, SUSCOUNT x_pitch, const suamd_complex *const *d_x,
+                                           suamd_complex *d_y_slab, SUSCOUNT y_pitch, suamd_complex *const *d_y,
+                                           const SUSCOUNT *len, const SUSCOUNT *m0, const SUSCOUNT *m1,
+                                           float *d_work, SUSCOUNT work_rows, void *stream);
+SUAMD_API SUBOOL suamd_agc_gang_finish_slab(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks, unsigned n,
+                                            const suamd_complex *d_x_slab, SUSCOUNT x_pitch, const suamd_complex *const *d_x,
+                                            const SUSCOUNT *len, float *d_work, SUSCOUNT work_rows, void *stream);
+/* suamd_rows_deliver for sources with an element stride each (src_stride NULL: all 1): a slab column hands its batch over */
+SUAMD_API SUBOOL suamd_rows_deliver_strided(suamd_ctx_t *ctx, unsigned n, const suamd_complex *const *d_src,
+                                            const SUSCOUNT *src_stride, uint32_t *const *d_count, const SUSCOUNT *fixed_len,
+                                            suamd_complex *const *dst, uint32_t *const *count_out, void *stream);
 
 /* struct su_agc_params (Tasks/AGCTask.cpp:41-47) + su_agc_params_INITIALIZER defaults */
 struct suamd_agc_params {

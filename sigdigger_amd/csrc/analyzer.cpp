@@ -432,10 +432,19 @@ struct Inspector {
   suamd_complex *d_y = nullptr, *d_a = nullptr, *d_z = nullptr, *d_sym = nullptr, *d_prev = nullptr;
   uint32_t *d_count = nullptr;
   size_t cap = 0;
+  // The narrow channels of the FFT filter bank (<= 64 bins: the kernels that store one channel per lane) leave the
+  // channeliser as COLUMNS of the shard's time-major slab (suscan_analyzer::slab; column = lane = the channel's index in the
+  // tuner).  in_slab: the chain lives there too -- d_y / d_a / d_z are columns of the three slabs, element stride ts = the
+  // pitch, and the gangs stream them where they lie (suamd_*_gang_*_slab).  copy_out: the class needs contiguous rows
+  // throughout (audio, power): the column is copied into the inspector's own row right behind the channeliser.
+  bool in_slab = false, copy_out = false;
+  int lane = -1;
+  size_t ts = 1;                              // element stride of d_y / d_a / d_z
+  suamd_complex *d_lin = nullptr;             // in_slab: the block's channel samples as a contiguous row, when a consumer needs one (spectrum, estimators)
   // Two blocks are in flight at a time (block k+1 is enqueued before block k's results are collected), so every
   // per-block buffer and every "pending" note exists twice; the names above are the aliases of the slot in use.
   struct Slot {
-    suamd_complex *d_y = nullptr, *d_a = nullptr, *d_z = nullptr, *d_sym = nullptr, *h_out = nullptr;
+    suamd_complex *d_y = nullptr, *d_a = nullptr, *d_z = nullptr, *d_sym = nullptr, *h_out = nullptr, *d_lin = nullptr;
     uint32_t *d_count = nullptr;
     Pinned *pin = nullptr;
     SUSCOUNT pend_m = 0;
@@ -446,7 +455,7 @@ struct Inspector {
   void use(int p)
   {
     Slot &s = slot[p];
-    d_y = s.d_y; d_a = s.d_a; d_z = s.d_z; d_sym = s.d_sym; h_out = s.h_out; d_count = s.d_count; pin = s.pin;
+    d_y = s.d_y; d_a = s.d_a; d_z = s.d_z; d_sym = s.d_sym; h_out = s.h_out; d_count = s.d_count; pin = s.pin; d_lin = s.d_lin;
   }
   void stash(int p)
   {
@@ -501,15 +510,16 @@ struct Inspector {
   {
     if (arena && cap) (void)hipDeviceSynchronize();            // launches still in flight read and write these rows
     for (Slot &s : slot) {
-      for (void *p : {(void *)s.d_y, (void *)s.d_a, (void *)s.d_z, (void *)s.d_sym}) {
+      // (columns of the analyzer's slabs are not this inspector's to give back)
+      for (void *p : {in_slab ? nullptr : (void *)s.d_y, in_slab ? nullptr : (void *)s.d_a, in_slab ? nullptr : (void *)s.d_z, (void *)s.d_sym, (void *)s.d_lin}) {
         if (!p) continue;
         if (arena) arena->give(p, cap * 8); else (void)hipFree(p);
       }
       if (s.d_count) (void)hipFree(s.d_count);
       if (s.h_out) (void)hipHostFree(s.h_out);
-      s.d_y = s.d_a = s.d_z = s.d_sym = s.h_out = nullptr; s.d_count = nullptr;
+      s.d_y = s.d_a = s.d_z = s.d_sym = s.h_out = s.d_lin = nullptr; s.d_count = nullptr;
     }
-    d_y = d_a = d_z = d_sym = h_out = nullptr; d_count = nullptr; cap = 0;
+    d_y = d_a = d_z = d_sym = h_out = d_lin = nullptr; d_count = nullptr; cap = 0;
   }
   void free_all()
   {
@@ -624,6 +634,12 @@ struct suscan_analyzer {
   suamd_complex **h_rowptr[2] = {nullptr, nullptr};   // pinned staging, and what the device table holds
   size_t rowptr_cap = 0;
   RowArena rows;                              // the inspectors' sample rows (one slab: rows near each other)
+  // Time-major slabs of the narrow FFT channels, per slot: y = what the channeliser writes ([time][pitch], column = channel
+  // index), a / z = the chain's ping-pong partners, work = the AGC's magnitudes and levels (2 x rows x pitch floats).  The
+  // three complex slabs of a slot are ONE allocation (gang items of one call then lie within 4 GiB of each other).
+  struct SlabSet { suamd_complex *y = nullptr, *a = nullptr, *z = nullptr; float *work = nullptr; } slab[2];
+  size_t slab_rows = 0, slab_pitch = 0;       // rows include 128 of slack: the gang kernels look a tile ahead
+  uint32_t *d_sink = nullptr;                 // where the column -> row copies write their counts
   std::map<SUHANDLE, std::unique_ptr<Inspector>> inspectors;
   hipStream_t stream = nullptr;
   static constexpr int NISTREAMS = 4;          // gain control / carrier control / clock recovery / channeliser (+ spectra, estimators)
@@ -713,7 +729,19 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
       err = "FFT channeliser: unexpected decimation";
       return false;
     }
-  } else {
+  }
+  {
+    // narrow channels of the filter bank are columns of the shard's slab (the feed sends every channel of <= 64 bins there);
+    // classes whose stages want contiguous rows throughout copy their column out instead of living in it
+    const bool narrow = a->use_fft && sdk::tuning().analyzer_slab != 0 && suamd_specttuner_channel_size(a->st, in.st_chan) <= 64;
+    const bool lives = narrow && in.cls != "audio" && in.cls != "power";
+    if (lives != in.in_slab) in.free_rows();                 // (rows <-> columns: the other kind of buffers)
+    in.in_slab = lives;
+    in.copy_out = narrow && !lives;
+    in.lane = narrow ? in.st_chan : -1;
+    if (!lives) in.ts = 1;
+  }
+  if (!a->use_fft) {
     float taps[255];
     suamd_lpf_design(taps, 255, bw / fs);                // cut-off bw/2 in Hz = (bw/fs) of Nyquist
     const double fn = in.fnor;
@@ -733,7 +761,7 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
       return *p != nullptr;
     };
     for (Inspector::Slot &sl : in.slot)
-      ok = ok && row(&sl.d_y) && row(&sl.d_a) && row(&sl.d_z) && row(&sl.d_sym) &&
+      ok = ok && (in.in_slab || (row(&sl.d_y) && row(&sl.d_a) && row(&sl.d_z))) && row(&sl.d_sym) &&
            hipMalloc((void **)&sl.d_count, 4) == hipSuccess &&
            hipHostMalloc((void **)&sl.h_out, need * 8, hipHostMallocMapped) == hipSuccess;
     if (ok && !in.d_prev) ok = hipMalloc((void **)&in.d_prev, 8) == hipSuccess;
@@ -877,8 +905,8 @@ void enqueue_spectrum(suscan_analyzer *a, Inspector &in, SUSCOUNT m)
     }
     in.spect_n = n;
   }
-  const suamd_complex *d_before = in.spect_have_prev && in.last_fir_m ? in.slot[in.last_slot].d_y + (in.last_fir_m - 1) : nullptr;
-  if (!suamd_spectsrc_preproc_from(a->ctx, in.spectsrc_id, in.d_y, m, d_before, in.d_spre, in.stream)) return;
+  const suamd_complex *d_before = in.spect_have_prev && in.last_fir_m ? in.slot[in.last_slot].d_y + (in.last_fir_m - 1) * in.ts : nullptr;
+  if (!suamd_spectsrc_preproc_from(a->ctx, in.spectsrc_id, in.in_slab ? in.d_lin : in.d_y, m, d_before, in.d_spre, in.stream)) return;
   const unsigned frames = (unsigned)(m / n);
   if (!suamd_psd_feed(in.spect_psd, in.d_spre, frames, n, frames, 1.0f / (float)n, SUAMD_PSD_LINEAR, in.d_spec, in.stream)) return;
   (void)hipMemcpyAsync(in.pin->spec, in.d_spec, n * sizeof(float), hipMemcpyDeviceToHost, in.stream);
@@ -895,6 +923,66 @@ void enqueue_spectrum(suscan_analyzer *a, Inspector &in, SUSCOUNT m)
 // is invariant under splitting its input, which the parity tests pin).  Bit-identical to running every chain
 // on its own, whole block at once.
 void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot);
+
+// The slabs of the narrow FFT channels: pitch = the tuner's channel table rounded up to 64 columns, rows = the longest
+// narrow channel's samples per block (D = 64) + slack.  Grown when the table or the block grows (contents carried over:
+// the previous block's last samples are still looked at); every inspector's column pointers are set from here.
+bool ensure_slabs(suscan_analyzer *a)
+{
+  bool any = false;
+  for (auto &kv : a->inspectors) any = any || kv.second->in_slab || kv.second->copy_out;
+  if (!any) return true;
+  const size_t cap = a->st ? suamd_specttuner_channel_capacity(a->st) : 0;
+  const size_t pitch = std::max<size_t>(64, (cap + 63) / 64 * 64);
+  const size_t rows = a->block / 64 + 8 + 128;
+  if (pitch > a->slab_pitch || rows > a->slab_rows) {
+    (void)hipDeviceSynchronize();                            // launches in flight read and write the old slabs
+    const size_t np = std::max(pitch, a->slab_pitch), nr = std::max(rows, a->slab_rows);
+    const size_t one = nr * np;                              // elements of one complex slab
+    suscan_analyzer::SlabSet fresh[2];
+    bool ok = true;
+    for (auto &f : fresh) {
+      ok = ok && hipMalloc((void **)&f.y, 3 * one * sizeof(suamd_complex)) == hipSuccess &&
+           hipMalloc((void **)&f.work, 2 * one * sizeof(float)) == hipSuccess;
+      if (!ok) break;
+      f.a = f.y + one; f.z = f.a + one;
+      const int fill = sdk::tuning().analyzer_poison_rows != 0 ? 0xff : 0;
+      ok = hipMemset(f.y, fill, 3 * one * sizeof(suamd_complex)) == hipSuccess && hipMemset(f.work, 0, 2 * one * sizeof(float)) == hipSuccess;
+    }
+    if (ok && !a->d_sink) ok = hipMalloc((void **)&a->d_sink, 4) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      for (auto &f : fresh) { if (f.y) (void)hipFree(f.y); if (f.work) (void)hipFree(f.work); }
+      return false;
+    }
+    for (int p = 0; p < 2; ++p) {
+      suscan_analyzer::SlabSet &o = a->slab[p];
+      if (o.y) {
+        const suamd_complex *src[3] = {o.y, o.a, o.z};
+        suamd_complex *dst[3] = {fresh[p].y, fresh[p].a, fresh[p].z};
+        for (int k = 0; k < 3; ++k)
+          (void)hipMemcpy2D(dst[k], np * sizeof(suamd_complex), src[k], a->slab_pitch * sizeof(suamd_complex),
+                            a->slab_pitch * sizeof(suamd_complex), a->slab_rows, hipMemcpyDeviceToDevice);
+        (void)hipFree(o.y);
+        (void)hipFree(o.work);
+      }
+      o = fresh[p];
+    }
+    (void)hipDeviceSynchronize();
+    a->slab_pitch = np; a->slab_rows = nr;
+  }
+  for (auto &kv : a->inspectors) {
+    Inspector &in = *kv.second;
+    if (!in.in_slab) continue;
+    in.ts = a->slab_pitch;
+    for (int p = 0; p < 2; ++p) {
+      in.slot[p].d_y = a->slab[p].y + in.lane;
+      in.slot[p].d_a = a->slab[p].a + in.lane;
+      in.slot[p].d_z = a->slab[p].z + in.lane;
+    }
+  }
+  return true;
+}
 
 // Block k goes into slot k & 1 while block k-1 (the other slot) may still be on the device: every stream takes the
 // blocks in order, so the loop states carry over by themselves, and the two slots share no per-block buffer.
@@ -949,6 +1037,10 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
   }
   a->st_idle = false;
   auto fail = [&](const char *what) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, std::string(what) + ": " + suamd_last_error()); };
+  if (!ensure_slabs(a)) { push_status(a, SUSCAN_ANALYZER_MESSAGE_TYPE_INTERNAL, -1, "inspector slabs: device allocation failed"); return; }
+  for (Inspector *pi : live) pi->use(slot);                   // (the slabs may have moved)
+  const suscan_analyzer::SlabSet &sb = a->slab[slot];
+  const SUSCOUNT pitch = (SUSCOUNT)a->slab_pitch;
   {
     // every inspector channelises the same wideband block: one launch for all of them
     std::vector<suamd_chanbank_t *> fb; std::vector<suamd_complex *> fy; std::vector<SUSCOUNT> fm(live.size());
@@ -970,9 +1062,11 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
         a->rowptr_cap = cap;
         for (int p = 0; p < 2; ++p) (void)hipMemcpyAsync(a->d_rowptr[p], a->h_rowptr[p], cap * sizeof(void *), hipMemcpyHostToDevice, sF);
       }
-      bool changed = false;
-      for (Inspector *pi : live)
+      bool changed = false, any_col = false;
+      for (Inspector *pi : live) {
+        if (pi->lane >= 0) { any_col = true; continue; }      // a column of the slab: the view serves it, not the table
         if (a->h_rowptr[slot][pi->st_chan] != pi->d_y) { a->h_rowptr[slot][pi->st_chan] = pi->d_y; changed = true; }
+      }
       // (the slot's previous block has been collected by now: its table and staging are free to change)
       if (changed) (void)hipMemcpyAsync(a->d_rowptr[slot], a->h_rowptr[slot], nrows * sizeof(void *), hipMemcpyHostToDevice, sF);
       // one count per slot of the tuner's channel table: it never shrinks, so after a close (or a retune, which closes
@@ -981,12 +1075,41 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
       // the inspectors' rows are separate allocations, but of one arena in practice: when they all start within ~1.75 GiB the
       // narrow-channel kernels address them with 32-bit offsets from the lowest (suamd_specttuner_feed_rows_near)
       uintptr_t lo = ~(uintptr_t)0, hi = 0;
-      for (Inspector *pi : live) { const uintptr_t p = reinterpret_cast<uintptr_t>(pi->d_y); lo = std::min(lo, p); hi = std::max(hi, p); }
-      const bool near = !live.empty() && hi - lo < ((uintptr_t)1 << 31) - ((uintptr_t)1 << 28);   // the library checks the feed's own extent on top
-      if (sdk::tuning().analyzer_debug) { static int once = 0; if (!once++) std::fprintf(stderr, "[worker] inspector rows span %.1f MiB over %zu inspectors: %s\n", (double)(hi - lo) / 1048576.0, live.size(), near ? "near" : "64-bit"); }
-      if (!(near ? suamd_specttuner_feed_rows_near(a->st, a->d_x, len, a->d_rowptr[slot], reinterpret_cast<const void *>(lo), (size_t)(hi - lo) + 8, counts.data(), sF)
-                 : suamd_specttuner_feed_rows(a->st, a->d_x, len, a->d_rowptr[slot], counts.data(), sF))) { fail("channeliser"); return; }
+      size_t nrow = 0;
+      for (Inspector *pi : live) {
+        if (pi->lane >= 0) continue;
+        const uintptr_t p = reinterpret_cast<uintptr_t>(pi->d_y); lo = std::min(lo, p); hi = std::max(hi, p); ++nrow;
+      }
+      const bool near = nrow > 0 && hi - lo < ((uintptr_t)1 << 31) - ((uintptr_t)1 << 28);   // the library checks the feed's own extent on top
+      if (sdk::tuning().analyzer_debug) { static int once = 0; if (!once++) std::fprintf(stderr, "[worker] %zu inspectors: %zu in rows spanning %.1f MiB (%s), %zu in slab columns (pitch %zu)\n", live.size(), nrow, nrow ? (double)(hi - lo) / 1048576.0 : 0.0, near ? "near" : "64-bit", live.size() - nrow, (size_t)pitch); }
+      const void *base = near ? reinterpret_cast<const void *>(lo) : nullptr;
+      const size_t span = near ? (size_t)(hi - lo) + 8 : 0;
+      if (any_col) {
+        // narrow channels (every channel of <= 64 bins is a column) through the time-major view, wide ones to their rows
+        if (!suamd_specttuner_feed_mixed(a->st, a->d_x, len, sb.y, suamd_view{1, pitch}, 64, a->d_rowptr[slot], base, span, counts.data(), sF)) { fail("channeliser"); return; }
+      } else if (!(near ? suamd_specttuner_feed_rows_near(a->st, a->d_x, len, a->d_rowptr[slot], base, span, counts.data(), sF)
+                        : suamd_specttuner_feed_rows(a->st, a->d_x, len, a->d_rowptr[slot], counts.data(), sF))) { fail("channeliser"); return; }
       for (size_t i = 0; i < live.size(); ++i) fm[i] = counts[live[i]->st_chan];
+      {
+        // columns that are wanted as rows: a copy_out inspector's d_y, the d_lin of a slab inspector with a spectrum or an estimator on
+        std::vector<const suamd_complex *> src; std::vector<SUSCOUNT> stride, fixed; std::vector<suamd_complex *> dst; std::vector<uint32_t *> sink;
+        for (size_t i = 0; i < live.size(); ++i) {
+          Inspector &in = *live[i];
+          if (in.lane < 0 || fm[i] == 0) continue;
+          suamd_complex *to = nullptr;
+          if (in.copy_out) to = in.d_y;
+          else if (in.spectsrc_id || in.est_on[0] || in.est_on[1] || in.est_on[2]) {
+            if (!in.d_lin) {
+              for (Inspector::Slot &sl : in.slot) if (!sl.d_lin) sl.d_lin = static_cast<suamd_complex *>(a->rows.take(in.cap * 8));
+              in.d_lin = in.slot[slot].d_lin;
+            }
+            to = in.d_lin;
+          }
+          if (!to) continue;
+          src.push_back(sb.y + in.lane); stride.push_back(pitch); fixed.push_back(fm[i]); dst.push_back(to); sink.push_back(a->d_sink);
+        }
+        if (!src.empty() && !suamd_rows_deliver_strided(a->ctx, (unsigned)src.size(), src.data(), stride.data(), nullptr, fixed.data(), dst.data(), sink.data(), sF)) fail("channel rows");
+      }
     } else {
       for (Inspector *pi : live) { fb.push_back(pi->bank); fy.push_back(pi->d_y); }
       if (!suamd_chanbank_gang_feed(a->ctx, fb.data(), (unsigned)fb.size(), a->d_x, len, fy.data(), fm.data(), sF)) { fail("channeliser"); return; }
@@ -1001,7 +1124,8 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
       in.pend_m = fm[i];
       in.pend_src = in.d_y;
       in.stream = sF;                                         // spectra and estimators read the channel samples: beside the chain
-      if (in.spectsrc_id) enqueue_spectrum(a, in, fm[i]);
+      const suamd_complex *yrow = in.in_slab ? in.d_lin : in.d_y;   // the block's channel samples as a contiguous row (null: none was made)
+      if (in.spectsrc_id && yrow) enqueue_spectrum(a, in, fm[i]);
       in.spect_have_prev = true; in.last_slot = slot; in.last_fir_m = fm[i];   // for the next block's "sample before"
       for (int k = 0; k < Inspector::NEST; ++k) {             // enabled estimators look at the channel samples too
         if (!in.est_on[k]) continue;
@@ -1010,7 +1134,8 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
         if (fm[i] < want) continue;                           // fewer than 512 channel samples per block: no estimate
         if (in.est[k] && suamd_baud_estimator_size(in.est[k]) != want) { suamd_baud_estimator_destroy(in.est[k]); in.est[k] = nullptr; }
         if (!in.est[k]) in.est[k] = suamd_baud_estimator_new(a->ctx, k, want);   // (the estimator ids ARE the kinds: fac, nonlinear, carrier)
-        if (!in.est[k] || !suamd_baud_estimator_feed_to(in.est[k], in.d_y, fm[i], &in.pin->est[k], sF)) { fail("estimator"); continue; }
+        if (!yrow) continue;
+        if (!in.est[k] || !suamd_baud_estimator_feed_to(in.est[k], yrow, fm[i], &in.pin->est[k], sF)) { fail("estimator"); continue; }
         in.est_fed[k] = true;
       }
     }
@@ -1019,7 +1144,9 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
   // per inspector: the row every stage reads and the one it writes (ping-pong d_a / d_z, nothing runs in place)
   struct Route { const suamd_complex *agc_in, *car_in, *mf_in, *clk_in; suamd_complex *agc_out, *car_out, *mf_out; };
   std::vector<Route> rt(live.size());
+  // gain control of the inspectors that own rows (gb ...) and of those that live in the slabs (sgb ...)
   std::vector<suamd_agc_bank_t *> gb; std::vector<const suamd_complex *> gx; std::vector<suamd_complex *> gy; std::vector<SUSCOUNT> gl;
+  std::vector<suamd_agc_bank_t *> sgb; std::vector<const suamd_complex *> sgx; std::vector<suamd_complex *> sgy; std::vector<SUSCOUNT> sgl;
   for (size_t i = 0; i < live.size(); ++i) {
     Inspector &in = *live[i];
     Route &r = rt[i];
@@ -1033,26 +1160,35 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
     if (in.mf) { r.mf_out = other(cur); cur = r.mf_out; }
     r.clk_in = cur;
     in.pend_src = cur;
-    if (in.agc) { gb.push_back(in.agc); gx.push_back(r.agc_in); gy.push_back(r.agc_out); gl.push_back(in.pend_m); }
+    if (in.agc && in.in_slab) { sgb.push_back(in.agc); sgx.push_back(r.agc_in); sgy.push_back(r.agc_out); sgl.push_back(in.pend_m); }
+    else if (in.agc) { gb.push_back(in.agc); gx.push_back(r.agc_in); gy.push_back(r.agc_out); gl.push_back(in.pend_m); }
     if (in.clock) in.pend_symbols = true; else in.pend_samples = true;
   }
   if (!gb.empty() && !suamd_agc_gang_pre(a->ctx, gb.data(), (unsigned)gb.size(), gx.data(), gl.data(), sA)) fail("gain control");
+  // (a slab inspector's gain control always reads its column of y and writes its column of a)
+  if (!sgb.empty() && !suamd_agc_gang_pre_slab(a->ctx, sgb.data(), (unsigned)sgb.size(), sb.y, pitch, sgx.data(), sgl.data(), sb.work, a->slab_rows, sA)) fail("gain control");
   if (a->trace) (void)hipEventRecord(a->ev_tpre, sA);
   for (int j = 0; j < P; ++j) {
     // ---- gain control on sA ----
     {
-      std::vector<SUSCOUNT> m0, m1;
+      std::vector<SUSCOUNT> m0, m1, sm0, sm1;
       for (size_t i = 0; i < live.size(); ++i) {
         Inspector &in = *live[i];
-        if (in.agc) { m0.push_back(sub(in, j)); m1.push_back(sub(in, j + 1)); }
+        if (in.agc && in.in_slab) { sm0.push_back(sub(in, j)); sm1.push_back(sub(in, j + 1)); }
+        else if (in.agc) { m0.push_back(sub(in, j)); m1.push_back(sub(in, j + 1)); }
         else if (in.fixed_gain > 0 && sub(in, j + 1) > sub(in, j)) {
-          const suamd_view row = {(SUSCOUNT)in.cap, 1};
-          suamd_rows_scale(a->ctx, rt[i].agc_in + sub(in, j), row, rt[i].agc_out + sub(in, j), row, 1, sub(in, j + 1) - sub(in, j), in.fixed_gain, sA);
+          const suamd_view row = {(SUSCOUNT)in.cap, (SUSCOUNT)in.ts};
+          suamd_rows_scale(a->ctx, rt[i].agc_in + sub(in, j) * in.ts, row, rt[i].agc_out + sub(in, j) * in.ts, row, 1, sub(in, j + 1) - sub(in, j), in.fixed_gain, sA);
         }
       }
       if (!gb.empty()) {
         if (!suamd_agc_gang_level(a->ctx, gb.data(), (unsigned)gb.size(), gl.data(), m0.data(), m1.data(), sA) ||
             !suamd_agc_gang_apply(a->ctx, gb.data(), (unsigned)gb.size(), gx.data(), gy.data(), gl.data(), m0.data(), m1.data(), sA)) fail("gain control");
+      }
+      if (!sgb.empty()) {
+        if (!suamd_agc_gang_level_slab(a->ctx, sgb.data(), (unsigned)sgb.size(), sb.y, pitch, sgx.data(), sgl.data(), sm0.data(), sm1.data(), sb.work, a->slab_rows, sA) ||
+            !suamd_agc_gang_apply_slab(a->ctx, sgb.data(), (unsigned)sgb.size(), sb.y, pitch, sgx.data(), sb.a, pitch, sgy.data(), sgl.data(), sm0.data(), sm1.data(),
+                                       sb.work, a->slab_rows, sA)) fail("gain control");
       }
       (void)hipEventRecord(a->ev_stage[0][j], sA);
       if (a->trace) (void)hipEventRecord(a->ev_tstage[0][j], sA);
@@ -1060,50 +1196,58 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
     // ---- carrier control on sC ----
     {
       (void)hipStreamWaitEvent(sC, a->ev_stage[0][j], 0);
-      std::vector<suamd_costas_bank_t *> cb; std::vector<const suamd_complex *> cx; std::vector<suamd_complex *> cy; std::vector<SUSCOUNT> cl;
-      std::vector<suamd_pll_bank_t *> pb; std::vector<const suamd_complex *> px; std::vector<suamd_complex *> py; std::vector<SUSCOUNT> pl;
+      std::vector<suamd_costas_bank_t *> cb, scb; std::vector<const suamd_complex *> cx, scx; std::vector<suamd_complex *> cy, scy; std::vector<SUSCOUNT> cl, scl;
+      std::vector<suamd_pll_bank_t *> pb, spb; std::vector<const suamd_complex *> px, spx; std::vector<suamd_complex *> py, spy; std::vector<SUSCOUNT> pl, spl;
       for (size_t i = 0; i < live.size(); ++i) {
         Inspector &in = *live[i];
         const SUSCOUNT b0 = sub(in, j), n = sub(in, j + 1) - b0;
         if (!rt[i].car_out || n == 0) continue;
-        const suamd_view row = {(SUSCOUNT)in.cap, 1};
-        const suamd_complex *xi = rt[i].car_in + b0;
-        suamd_complex *yo = rt[i].car_out + b0;
-        if (in.costas) { cb.push_back(in.costas); cx.push_back(xi); cy.push_back(yo); cl.push_back(n); }
+        const suamd_view row = {(SUSCOUNT)in.cap, (SUSCOUNT)in.ts};
+        const suamd_complex *xi = rt[i].car_in + b0 * in.ts;
+        suamd_complex *yo = rt[i].car_out + b0 * in.ts;
+        if (in.costas && in.in_slab) { scb.push_back(in.costas); scx.push_back(xi); scy.push_back(yo); scl.push_back(n); }
+        else if (in.costas) { cb.push_back(in.costas); cx.push_back(xi); cy.push_back(yo); cl.push_back(n); }
+        else if (in.pll && in.in_slab) { spb.push_back(in.pll); spx.push_back(xi); spy.push_back(yo); spl.push_back(n); }
         else if (in.pll) { pb.push_back(in.pll); px.push_back(xi); py.push_back(yo); pl.push_back(n); }
         else if (in.nco) suamd_nco_bank_feed(in.nco, xi, row, yo, row, n, sC);
         else if (in.quad) {
           // the sample before a later sub-range is still in the row; only the block's first one needs the carry
-          suamd_quad_demod_batch(a->ctx, xi, row, yo, row, 1, n, b0 ? xi - 1 : in.d_prev, in.first ? SU_TRUE : SU_FALSE, nullptr, sC);
-          if (b0 + n == in.pend_m) (void)hipMemcpyAsync(in.d_prev, xi + n - 1, 8, hipMemcpyDeviceToDevice, sC);
+          suamd_quad_demod_batch(a->ctx, xi, row, yo, row, 1, n, b0 ? xi - in.ts : in.d_prev, in.first ? SU_TRUE : SU_FALSE, nullptr, sC);
+          if (b0 + n == in.pend_m) (void)hipMemcpyAsync(in.d_prev, xi + (n - 1) * in.ts, 8, hipMemcpyDeviceToDevice, sC);
           in.first = false;
         }
       }
       if (!cb.empty() && !suamd_costas_gang_feed(a->ctx, cb.data(), (unsigned)cb.size(), cx.data(), cy.data(), cl.data(), sC)) fail("carrier control");
       if (!pb.empty() && !suamd_pll_gang_feed(a->ctx, pb.data(), (unsigned)pb.size(), px.data(), py.data(), pl.data(), sC)) fail("carrier control");
+      // (the three complex slabs of a slot are one allocation: whichever of them an item reads and writes, a call's items are near each other)
+      if (!scb.empty() && !suamd_costas_gang_feed_slab(a->ctx, scb.data(), (unsigned)scb.size(), scx.data(), pitch, scy.data(), pitch, scl.data(), sC)) fail("carrier control");
+      if (!spb.empty() && !suamd_pll_gang_feed_slab(a->ctx, spb.data(), (unsigned)spb.size(), spx.data(), pitch, spy.data(), pitch, spl.data(), sC)) fail("carrier control");
       (void)hipEventRecord(a->ev_stage[1][j], sC);
       if (a->trace) (void)hipEventRecord(a->ev_tstage[1][j], sC);
     }
     // ---- matched filter, clock recovery on sK ----
     {
       (void)hipStreamWaitEvent(sK, a->ev_stage[1][j], 0);
-      std::vector<suamd_clock_bank_t *> kb; std::vector<const suamd_complex *> kx; std::vector<SUSCOUNT> kl;
-      std::vector<suamd_complex *> ks; std::vector<uint32_t *> kc;
+      std::vector<suamd_clock_bank_t *> kb, skb; std::vector<const suamd_complex *> kx, skx; std::vector<SUSCOUNT> kl, skl;
+      std::vector<suamd_complex *> ks, sks; std::vector<uint32_t *> kc, skc;
       for (size_t i = 0; i < live.size(); ++i) {
         Inspector &in = *live[i];
         const SUSCOUNT b0 = sub(in, j), n = sub(in, j + 1) - b0;
         if (n == 0) continue;
-        const suamd_view row = {(SUSCOUNT)in.cap, 1};
-        if (in.mf) suamd_fir_bank_feed(in.mf, rt[i].mf_in + b0, row, rt[i].mf_out + b0, row, n, sK);
-        if (in.clock) { kb.push_back(in.clock); kx.push_back(rt[i].clk_in + b0); kl.push_back(n); ks.push_back(in.d_sym); kc.push_back(in.d_count); }
+        const suamd_view row = {(SUSCOUNT)in.cap, (SUSCOUNT)in.ts};
+        if (in.mf) suamd_fir_bank_feed(in.mf, rt[i].mf_in + b0 * in.ts, row, rt[i].mf_out + b0 * in.ts, row, n, sK);
+        if (in.clock && in.in_slab) { skb.push_back(in.clock); skx.push_back(rt[i].clk_in + b0 * in.ts); skl.push_back(n); sks.push_back(in.d_sym); skc.push_back(in.d_count); }
+        else if (in.clock) { kb.push_back(in.clock); kx.push_back(rt[i].clk_in + b0); kl.push_back(n); ks.push_back(in.d_sym); kc.push_back(in.d_count); }
       }
       if (!kb.empty() && !suamd_clock_gang_feed(a->ctx, kb.data(), (unsigned)kb.size(), kx.data(), kl.data(), ks.data(), kc.data(), sK)) fail("clock recovery");
+      if (!skb.empty() && !suamd_clock_gang_feed_slab(a->ctx, skb.data(), (unsigned)skb.size(), skx.data(), pitch, skl.data(), sks.data(), skc.data(), sK)) fail("clock recovery");
       (void)hipEventRecord(a->ev_stage[2][j], sK);
       if (a->trace) (void)hipEventRecord(a->ev_tstage[2][j], sK);
     }
   }
   // ---- tails: AGC state carry on sA; equalizers and the symbol counts on sK ----
   if (!gb.empty() && !suamd_agc_gang_finish(a->ctx, gb.data(), (unsigned)gb.size(), gx.data(), gl.data(), sA)) fail("gain control");
+  if (!sgb.empty() && !suamd_agc_gang_finish_slab(a->ctx, sgb.data(), (unsigned)sgb.size(), sb.y, pitch, sgx.data(), sgl.data(), sb.work, a->slab_rows, sA)) fail("gain control");
   {
     std::vector<suamd_cma_bank_t *> eq; std::vector<const suamd_complex *> ex; std::vector<suamd_complex *> ey; std::vector<const uint32_t *> ec;
     for (Inspector *pi : live) {
@@ -1131,17 +1275,19 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
       in.pend_m = k;
     }
     // hand-off: every inspector's batch goes to its mapped landing zone in one launch (sK is downstream of all stages)
-    std::vector<const suamd_complex *> src; std::vector<uint32_t *> cnt; std::vector<SUSCOUNT> fixed;
+    std::vector<const suamd_complex *> src; std::vector<uint32_t *> cnt; std::vector<SUSCOUNT> fixed, stride;
     std::vector<suamd_complex *> dst; std::vector<uint32_t *> cout;
     for (Inspector *pi : live) {
       Inspector &in = *pi;
       src.push_back(in.pend_symbols ? in.d_sym : in.pend_src);
+      // (symbol rows, and what power / audio left in d_sym, are contiguous; a slab inspector's sample stream is its column)
+      stride.push_back(in.pend_symbols || in.pend_src == in.d_sym ? 1 : (SUSCOUNT)in.ts);
       cnt.push_back(in.pend_symbols ? in.d_count : nullptr);
       fixed.push_back(in.pend_symbols ? 0 : in.pend_m);
       dst.push_back(in.h_out);
       cout.push_back(&in.pin->count);
     }
-    if (!suamd_rows_deliver(a->ctx, (unsigned)live.size(), src.data(), cnt.data(), fixed.data(), dst.data(), cout.data(), sK)) fail("hand-off");
+    if (!suamd_rows_deliver_strided(a->ctx, (unsigned)live.size(), src.data(), stride.data(), cnt.data(), fixed.data(), dst.data(), cout.data(), sK)) fail("hand-off");
     if (a->trace) (void)hipEventRecord(a->ev_tdone, sK);
   }
 }
@@ -1542,6 +1688,14 @@ void free_device(suscan_analyzer *a)
     a->d_rowptr[p] = a->h_rowptr[p] = nullptr;
   }
   a->rowptr_cap = 0;
+  for (auto &sl : a->slab) {
+    if (sl.y) (void)hipFree(sl.y);                          // (a and z are parts of the same allocation)
+    if (sl.work) (void)hipFree(sl.work);
+    sl = suscan_analyzer::SlabSet();
+  }
+  a->slab_rows = a->slab_pitch = 0;
+  if (a->d_sink) (void)hipFree(a->d_sink);
+  a->d_sink = nullptr;
   if (a->psd) suamd_psd_destroy(a->psd);
   for (int p = 0; p < 2; ++p) {
     if (a->h_psd[p]) (void)hipHostFree(a->h_psd[p]);

@@ -207,6 +207,15 @@ hipError_t pll_gang(const PllGangItem *d_items, int n, void *tm, long long slab,
 hipError_t cma_gang(const CmaGangItem *d_items, int n, int ntaps, hipStream_t st);
 hipError_t costas_gang(const CostasGangItem *d_items, const GangGroup *d_groups, int ngroups, void *tm, long long slab, hipStream_t st);
 hipError_t clock_gang(const ClockGangItem *d_items, int n, void *tm, long long slab, hipStream_t st);
+// The same gangs on rows that ARE columns of a time-major slab already (the live analyzer's inspectors of the FFT filter
+// bank: sample m of an item sits `pitch` elements behind sample m - 1, items side by side in a row of the slab): no gather,
+// no scatter -- lane j streams its column in place, byte offset (item pointer - base) from a wave-uniform base.  `in` /
+// `out`: an address at or below every item's x / y with all of them less than 4 GiB above it.  The slabs must be readable
+// one tile (64 rows) beyond the longest item.
+struct GangSlab { const void *in; void *out; long long pitch_in, pitch_out; };
+hipError_t costas_gang_slab(const CostasGangItem *d_items, const GangGroup *d_groups, int ngroups, GangSlab io, hipStream_t st);
+hipError_t pll_gang_slab(const PllGangItem *d_items, int n, GangSlab io, hipStream_t st);
+hipError_t clock_gang_slab(const ClockGangItem *d_items, int n, GangSlab io, hipStream_t st);
 
 struct AgcParams {
   float knee, gain_slope;
@@ -239,13 +248,24 @@ hipError_t agc_state_update(const AgcParams &p, const AgcState &s, int nchan, co
 hipError_t agc_level_gang(const AgcGangItem *d_items, int n, void *tm, long long slab, hipStream_t st);
 // steps (1)+(2) and (5) of agc_feed for many 1-channel banks with contiguous rows: one launch each
 struct AgcPreItem { const void *x; const float *hist; float *db, *peak; long long len; int H; };
-struct AgcStateItem { float *delay_line, *hist; const void *x; const float *db; long long len; int delay, H; };
+struct AgcStateItem { float *delay_line, *hist; const void *x; const float *db; long long len; int delay, H;
+                      long long xs, dbs; };   // element strides of x and db (1: contiguous rows; a slab's pitch: columns)
 hipError_t agc_pre_items(const AgcPreItem *d_items, int n, long long max_len, hipStream_t st);
 hipError_t agc_state_items(const AgcStateItem *d_items, int n, hipStream_t st);
+// the same steps for items that are columns of a time-major slab (the live analyzer's inspectors of the FFT filter bank):
+// samples in column `lane` of x (pitch px), magnitudes / peaks / levels in column `lane` of two work slabs of pitch pw,
+// outputs [m0, m1) to column lane_y of y.  One launch each for all items; tiles of 64 items x 64 / 128 time steps.
+struct AgcSlabItem { AgcParams p; AgcState s; int lane, lane_y; long long len, m0, m1; };
+hipError_t agc_pre_slab(const AgcSlabItem *d_items, int n, const void *x, long long px, float *db, float *peak, long long pw,
+                        long long max_len, hipStream_t st);
+hipError_t agc_apply_slab(const AgcSlabItem *d_items, int n, const void *x, long long px, void *y, long long py, const float *lvl,
+                          long long pw, long long mlo, long long mhi, hipStream_t st);
+hipError_t agc_level_gang_slab(const AgcGangItem *d_items, int n, GangSlab io, hipStream_t st);
 
 // rows -> landing zones (host-mapped or device), grid.x = item: n = count ? *count : fixed samples of src go to dst,
 // n to *count_out; count (a device counter the producer accumulates into) is cleared for the next block
-struct DeliverItem { const void *src; void *dst; uint32_t *count; unsigned fixed; uint32_t *count_out; };
+struct DeliverItem { const void *src; void *dst; uint32_t *count; unsigned fixed; uint32_t *count_out;
+                     unsigned stride; };   // element stride of src (1: a contiguous row; a slab's pitch: a column)
 hipError_t rows_deliver(const DeliverItem *d_items, int n, hipStream_t st);
 
 // ---- specview.hip ----

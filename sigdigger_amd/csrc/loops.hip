@@ -603,8 +603,8 @@ __global__ __launch_bounds__(64) void agc_state_items_kernel(const sdk::AgcState
   const long long src = (long long)i + it.len;
   float2 d = {0.f, 0.f};
   float h = 0.f;
-  if (i < it.delay) d = src < it.delay ? float2{it.delay_line[src * 2 + 0], it.delay_line[src * 2 + 1]} : x[src - it.delay];
-  if (i < hl) h = src < hl ? it.hist[src] : it.db[src - hl];
+  if (i < it.delay) d = src < it.delay ? float2{it.delay_line[src * 2 + 0], it.delay_line[src * 2 + 1]} : x[(src - it.delay) * it.xs];
+  if (i < hl) h = src < hl ? it.hist[src] : it.db[(src - hl) * it.dbs];
   __syncthreads();                                        // every slot is read before any is overwritten
   if (i < it.delay) { it.delay_line[i * 2 + 0] = d.x; it.delay_line[i * 2 + 1] = d.y; }
   if (i < hl) it.hist[i] = h;
@@ -827,11 +827,11 @@ __device__ __forceinline__ long long uniform64(long long v)
   return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
+// (tm / tmo: where the lanes read and write -- the same packed slab for the gather / scatter form; lo / loo: the lane's byte
+// offset there.  The slab form of a 64-column pitch runs this loop too, on the producer's slab and with the items' own columns.)
 template <bool HAS_OUT, typename T, typename F>
-__device__ __forceinline__ void gang_stream_tm(T *tm_io, long long len, F step)
+__device__ __forceinline__ void gang_stream_tm(const T *tm, T *tmo, const uint32_t lo, const uint32_t loo, long long len, F step)
 {
-  T *tm = tm_io, *tmo = tm_io;
-  const uint32_t lo = threadIdx.x * (uint32_t)sizeof(T);
   const long long maxlen = uniform64(wave_max(len));
   if (maxlen <= 0) return;
   const long long minlen = uniform64(-wave_max(len > 0 ? -len : -(1ll << 62)));   // shortest non-empty row
@@ -845,7 +845,7 @@ __device__ __forceinline__ void gang_stream_tm(T *tm_io, long long len, F step)
       if (len > 0) {
 #pragma unroll
         for (int j = 0; j < CHUNK; ++j) {
-          if constexpr (HAS_OUT) st_elem(tmo, (i + j) * 64, lo, step(i + j, cur[j]));
+          if constexpr (HAS_OUT) st_elem(tmo, (i + j) * 64, loo, step(i + j, cur[j]));
           else step(i + j, cur[j]);
         }
       }
@@ -853,7 +853,7 @@ __device__ __forceinline__ void gang_stream_tm(T *tm_io, long long len, F step)
 #pragma unroll
       for (int j = 0; j < CHUNK; ++j) {
         if (i + j < len) {
-          if constexpr (HAS_OUT) st_elem(tmo, (i + j) * 64, lo, step(i + j, cur[j]));
+          if constexpr (HAS_OUT) st_elem(tmo, (i + j) * 64, loo, step(i + j, cur[j]));
           else step(i + j, cur[j]);
         }
       }
@@ -940,7 +940,7 @@ __device__ __forceinline__ void costas_gang_body(const sdk::CostasGangItem *__re
     r.yh[i] = c32{s.yh[(i - 1) * 2 + 0], s.yh[(i - 1) * 2 + 1]};
   }
   const long long len = live ? it.len : 0;
-  gang_stream_tm<true>(tm, len, [&](long long, float2 v) { return costas_step<KIND, ORDER, GAIN1>(p, r, v); });
+  gang_stream_tm<true>(tm, tm, j * 8u, j * 8u, len, [&](long long, float2 v) { return costas_step<KIND, ORDER, GAIN1>(p, r, v); });
   if (!live) return;
   s.phase[0] = r.phase;
   s.omega[0] = r.omega;
@@ -980,7 +980,8 @@ __global__ __launch_bounds__(64) void pll_gang_kernel(const sdk::PllGangItem *__
   uint32_t phase = it.s.phase[0];
   float omega = it.s.omega[0];
   const long long len = live ? it.len : 0;
-  gang_stream_tm<true>(tm + (size_t)blockIdx.x * slab, len, [&](long long, float2 v) { return pll_step(alpha, beta, phase, omega, v); });
+  float2 *my = tm + (size_t)blockIdx.x * slab;
+  gang_stream_tm<true>(my, my, threadIdx.x * 8u, threadIdx.x * 8u, len, [&](long long, float2 v) { return pll_step(alpha, beta, phase, omega, v); });
   if (!live) return;
   it.s.phase[0] = phase;
   it.s.omega[0] = omega;
@@ -1320,7 +1321,8 @@ __global__ __launch_bounds__(64) void agc_level_gang_kernel(const sdk::AgcGangIt
   const float knee = it.p.knee;
   const unsigned hang_max = it.p.hang_max;
   const long long len = live ? it.len : 0;
-  gang_stream_tm<true>(tm + (size_t)blockIdx.x * slab, len, [&](long long, float pk) {
+  float *my = tm + (size_t)blockIdx.x * slab;
+  gang_stream_tm<true>(my, my, threadIdx.x * 4u, threadIdx.x * 4u, len, [&](long long, float pk) {
     float d = pk - fast;
     const float fa = d > 0.0f ? far : faf;
     fast = sd::fma_(fa, d, fast);
@@ -1337,6 +1339,265 @@ __global__ __launch_bounds__(64) void agc_level_gang_kernel(const sdk::AgcGangIt
   });
   if (!live) return;
   s.hang_n[0] = hang_n; s.fast_level[0] = fast; s.slow_level[0] = slow;
+}
+
+// ---------------------------------------------------------------------------------------
+// Gangs whose rows are columns of a time-major slab already (kernels.hpp GangSlab): what rows_tm_gather would build is
+// what the producer -- the FFT filter bank writing channel c of every time step side by side -- left in memory.  The
+// recurrence streams it where it lies: a wave-uniform base, the lane's byte offset from it, a run-time pitch.  The byte
+// offsets of a chunk's CHUNK steps are loop invariants and stay in registers (a lone wavefront owns the register file), so
+// a load is still scalar base + vector offset and nothing is added per sample.  Per lane the steps are the packed form's.
+template <bool HAS_OUT, typename T, typename F>
+__device__ __forceinline__ void gang_stream_slab(const T *tin, T *tout, long long pin, long long pout, uint32_t lo_in, uint32_t lo_out,
+                                                 long long len, F step)
+{
+  const long long maxlen = uniform64(wave_max(len));
+  if (maxlen <= 0) return;
+  const long long minlen = uniform64(-wave_max(len > 0 ? -len : -(1ll << 62)));   // shortest non-empty row
+  uint32_t oin[CHUNK], oout[CHUNK];
+#pragma unroll
+  for (int j = 0; j < CHUNK; ++j) {
+    oin[j] = lo_in + (uint32_t)j * (uint32_t)pin * (uint32_t)sizeof(T);
+    oout[j] = lo_out + (uint32_t)j * (uint32_t)pout * (uint32_t)sizeof(T);
+  }
+  T cur[CHUNK], nxt[CHUNK];
+#pragma unroll
+  for (int j = 0; j < CHUNK; ++j) cur[j] = ld_elem(tin, 0, oin[j]);
+  for (long long i = 0; i < maxlen; i += CHUNK) {
+    const T *bn = tin + (i + CHUNK) * pin;
+    T *bo = tout + i * pout;
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) nxt[j] = ld_elem(bn, 0, oin[j]);
+    if (i + CHUNK <= minlen) {                               // inside every row: no per-step predication
+      if (len > 0) {
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j) {
+          if constexpr (HAS_OUT) st_elem(bo, 0, oout[j], step(i + j, cur[j]));
+          else step(i + j, cur[j]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CHUNK; ++j) {
+        if (i + j < len) {
+          if constexpr (HAS_OUT) st_elem(bo, 0, oout[j], step(i + j, cur[j]));
+          else step(i + j, cur[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) cur[j] = nxt[j];
+  }
+}
+
+__device__ __forceinline__ uint32_t slab_offset(const void *p, const void *base)
+{
+  return (uint32_t)(static_cast<const char *>(p) - static_cast<const char *>(base));
+}
+
+template <int KIND, int ORDER, bool GAIN1>
+__device__ __forceinline__ void costas_gang_slab_body(const sdk::CostasGangItem *__restrict__ items, int count, const sdk::GangSlab &io)
+{
+  const int j = threadIdx.x;
+  const bool live = j < count;
+  const sdk::CostasGangItem it = items[live ? j : 0];
+  const sdk::CostasParams p = it.p;
+  const sdk::CostasState s = it.s;
+  CostasRegs<ORDER> r;
+  r.phase = s.phase[0];
+  r.omega = s.omega[0];
+#pragma unroll
+  for (int i = 1; i <= ORDER; ++i) {
+    r.xh[i] = c32{s.xh[(i - 1) * 2 + 0], s.xh[(i - 1) * 2 + 1]};
+    r.yh[i] = c32{s.yh[(i - 1) * 2 + 0], s.yh[(i - 1) * 2 + 1]};
+  }
+  const long long len = live ? it.len : 0;
+  auto step = [&](long long, float2 v) { return costas_step<KIND, ORDER, GAIN1>(p, r, v); };
+  // a pitch of 64 columns (at most 64 narrow inspectors on the shard -- BASELINE configs[3]'s slice) is the packed slabs' own:
+  // the loop with immediate offsets
+  if (io.pitch_in == 64 && io.pitch_out == 64)
+    gang_stream_tm<true>(static_cast<const float2 *>(io.in), static_cast<float2 *>(io.out), slab_offset(it.x, io.in), slab_offset(it.y, io.out), len, step);
+  else
+    gang_stream_slab<true>(static_cast<const float2 *>(io.in), static_cast<float2 *>(io.out), io.pitch_in, io.pitch_out,
+                           slab_offset(it.x, io.in), slab_offset(it.y, io.out), len, step);
+  if (!live) return;
+  s.phase[0] = r.phase;
+  s.omega[0] = r.omega;
+#pragma unroll
+  for (int i2 = 1; i2 <= ORDER; ++i2) {
+    s.xh[(i2 - 1) * 2 + 0] = r.xh[i2].re; s.xh[(i2 - 1) * 2 + 1] = r.xh[i2].im;
+    s.yh[(i2 - 1) * 2 + 0] = r.yh[i2].re; s.yh[(i2 - 1) * 2 + 1] = r.yh[i2].im;
+  }
+}
+
+__global__ __launch_bounds__(64) void costas_gang_slab_kernel(const sdk::CostasGangItem *__restrict__ items,
+                                                              const sdk::GangGroup *__restrict__ groups, sdk::GangSlab io)
+{
+  const sdk::GangGroup gd = groups[blockIdx.x];
+  const sdk::CostasGangItem *mine = items + gd.first;
+  switch (gd.kind * 8 + gd.order) {
+#define SD_GANG_CASE(K, O) case (K) * 8 + (O): if (gd.gain1) costas_gang_slab_body<K, O, true>(mine, gd.count, io); \
+                                               else costas_gang_slab_body<K, O, false>(mine, gd.count, io); break;
+    SD_GANG_CASE(1, 0) SD_GANG_CASE(1, 1) SD_GANG_CASE(1, 2) SD_GANG_CASE(1, 3) SD_GANG_CASE(1, 4)
+    SD_GANG_CASE(2, 0) SD_GANG_CASE(2, 1) SD_GANG_CASE(2, 2) SD_GANG_CASE(2, 3) SD_GANG_CASE(2, 4)
+    SD_GANG_CASE(3, 0) SD_GANG_CASE(3, 1) SD_GANG_CASE(3, 2) SD_GANG_CASE(3, 3) SD_GANG_CASE(3, 4)
+#undef SD_GANG_CASE
+    default: break;
+  }
+}
+
+__global__ __launch_bounds__(64) void pll_gang_slab_kernel(const sdk::PllGangItem *__restrict__ items, int n, sdk::GangSlab io)
+{
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const bool live = j < n;
+  const sdk::PllGangItem it = items[live ? j : 0];
+  const float alpha = it.alpha, beta = it.beta;
+  uint32_t phase = it.s.phase[0];
+  float omega = it.s.omega[0];
+  const long long len = live ? it.len : 0;
+  auto step = [&](long long, float2 v) { return pll_step(alpha, beta, phase, omega, v); };
+  if (io.pitch_in == 64 && io.pitch_out == 64)
+    gang_stream_tm<true>(static_cast<const float2 *>(io.in), static_cast<float2 *>(io.out), slab_offset(it.x, io.in), slab_offset(it.y, io.out), len, step);
+  else
+    gang_stream_slab<true>(static_cast<const float2 *>(io.in), static_cast<float2 *>(io.out), io.pitch_in, io.pitch_out,
+                           slab_offset(it.x, io.in), slab_offset(it.y, io.out), len, step);
+  if (!live) return;
+  it.s.phase[0] = phase;
+  it.s.omega[0] = omega;
+}
+
+__global__ __launch_bounds__(64) void clock_gang_slab_kernel(const sdk::ClockGangItem *__restrict__ items, int n, sdk::GangSlab io)
+{
+  __shared__ float2 lds[RING * 64];
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const bool live = j < n;
+  const sdk::ClockGangItem it = items[live ? j : 0];
+  sdk::ClockParams p = it.p;
+  const int steps = __builtin_amdgcn_readfirstlane(it.steps);
+  if (__builtin_amdgcn_readfirstlane(it.uniform)) {
+    p.alpha = uniform_f(p.alpha); p.beta = uniform_f(p.beta); p.gain = uniform_f(p.gain); p.bmin = uniform_f(p.bmin); p.bmax = uniform_f(p.bmax);
+  }
+  const sdk::ClockState s = it.s;
+  ClockRegs r;
+  r.phi = s.phi[0]; r.bnor = s.bnor[0];
+  r.halfcycle = s.halfcycle[0];
+  r.prev = float2{s.prev[0], s.prev[1]};
+  r.x0 = float2{s.x0[0], s.x0[1]};
+  r.x1 = float2{s.x1[0], s.x1[1]};
+  r.x2 = float2{s.x2[0], s.x2[1]};
+  r.n = it.count[0];
+  const long long len = live ? it.len : 0;
+  float2 *out = reinterpret_cast<float2 *>(it.sym);
+  const float2 *base = static_cast<const float2 *>(io.in);
+  const uint32_t lo = slab_offset(it.x, io.in);
+  if (steps > 0) clock_ring(base, io.pitch_in, lo, len, live, steps, p, r, out, lds);
+  else clock_stream_tm<true>(base, io.pitch_in, lo, len, p, r, out, lds);
+  if (!live) return;
+  s.phi[0] = r.phi; s.bnor[0] = r.bnor; s.halfcycle[0] = r.halfcycle;
+  s.prev[0] = r.prev.x; s.prev[1] = r.prev.y;
+  s.x0[0] = r.x0.x; s.x0[1] = r.x0.y;
+  s.x1[0] = r.x1.x; s.x1[1] = r.x1.y;
+  s.x2[0] = r.x2.x; s.x2[1] = r.x2.y;
+  it.count[0] = r.n;
+}
+
+__global__ __launch_bounds__(64) void agc_level_gang_slab_kernel(const sdk::AgcGangItem *__restrict__ items, int n, sdk::GangSlab io)
+{
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const bool live = j < n;
+  const sdk::AgcGangItem it = items[live ? j : 0];
+  const sdk::AgcState s = it.s;
+  unsigned hang_n = s.hang_n[0];
+  float fast = s.fast_level[0], slow = s.slow_level[0];
+  const float far = it.p.fast_alpha_rise, faf = it.p.fast_alpha_fall, sar = it.p.slow_alpha_rise, saf = it.p.slow_alpha_fall;
+  const float knee = it.p.knee;
+  const unsigned hang_max = it.p.hang_max;
+  const long long len = live ? it.len : 0;
+  const uint32_t lo = slab_offset(it.peak, io.in);
+  auto step = [&](long long, float pk) {
+    float d = pk - fast;
+    const float fa = d > 0.0f ? far : faf;
+    fast = sd::fma_(fa, d, fast);
+    d = pk - slow;
+    const bool rise = d > 0.0f;
+    const bool fall = !rise && hang_n >= hang_max;
+    const float sa = rise ? sar : saf;
+    const float upd = sd::fma_(sa, d, slow);
+    slow = (rise || fall) ? upd : slow;
+    hang_n = rise ? 0u : (fall ? hang_n : hang_n + 1u);
+    float lvl = fast > slow ? fast : slow;
+    if (lvl < knee) lvl = knee;
+    return lvl;
+  };
+  if (io.pitch_in == 64 && io.pitch_out == 64) gang_stream_tm<true>(static_cast<const float *>(io.in), static_cast<float *>(io.out), lo, lo, len, step);
+  else gang_stream_slab<true>(static_cast<const float *>(io.in), static_cast<float *>(io.out), io.pitch_in, io.pitch_out, lo, lo, len, step);
+  if (!live) return;
+  s.hang_n[0] = hang_n; s.fast_level[0] = fast; s.slow_level[0] = slow;
+}
+
+// The AGC's feed-forward steps on a slab: item k of the table is lane k % 64 of workgroup row k / 64, its samples sit in
+// column it.lane of x, its magnitudes / peaks / levels in the same column of the work slabs (pitch `pw`).  A tile is 64
+// items x SLAB_TM time steps, every access a row of adjacent columns.  Per value the operations (and, for the sliding
+// maximum, the order of the comparisons: newest first) are agc_pre_items_kernel's / agc_apply_items_kernel's.
+constexpr int SLAB_TM = 128;
+__global__ __launch_bounds__(256) void agc_pre_slab_kernel(const sdk::AgcSlabItem *__restrict__ items, int n, const float2 *__restrict__ x,
+                                                           long long px, float *__restrict__ db, float *__restrict__ peak, long long pw)
+{
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ float tile[SLAB_TM + 63][64];
+  const int lane = threadIdx.x & 63, rowt = threadIdx.x >> 6;
+  const int k = blockIdx.y * 64 + lane;
+  const bool live = k < n;
+  const sdk::AgcSlabItem it = items[live ? k : 0];
+  const long long len = live ? it.len : 0;
+  const int hl = (int)it.p.mag_history_size - 1;
+  const long long col = it.lane;
+  const long long m0 = (long long)blockIdx.x * SLAB_TM;
+  for (int r = rowt; r < SLAB_TM + 63; r += 4) {
+    const long long m = m0 - 63 + r;
+    float v = 0.f;
+    if (m < len) {
+      if (m >= 0) {
+        const float2 s = x[m * px + col];
+        v = 3.01029995663981195f * sd::log2_(sd::fma_(s.x, s.x, s.y * s.y) + 1e-8f);
+        if (m >= m0) db[m * pw + col] = v;
+      } else if (m + hl >= 0) v = it.s.mag_history[m + hl];
+    }
+    tile[r][lane] = v;
+  }
+  __syncthreads();
+  for (int t = rowt; t < SLAB_TM; t += 4) {
+    const long long m = m0 + t;
+    if (m >= len) break;
+    float pk = tile[t + 63][lane];
+    for (int i = 1; i <= hl; ++i) {
+      const float v = tile[t + 63 - i][lane];
+      pk = pk > v ? pk : v;
+    }
+    peak[m * pw + col] = pk;
+  }
+}
+
+__global__ __launch_bounds__(256) void agc_apply_slab_kernel(const sdk::AgcSlabItem *__restrict__ items, int n, const float2 *__restrict__ x,
+                                                             long long px, float2 *__restrict__ y, long long py,
+                                                             const float *__restrict__ lvl, long long pw, long long mlo)
+{
+  __builtin_amdgcn_s_setprio(3);
+  const int lane = threadIdx.x & 63, rowt = threadIdx.x >> 6;
+  const int k = blockIdx.y * 64 + lane;
+  if (k >= n) return;
+  const sdk::AgcSlabItem it = items[k];
+  const long long delay = it.p.delay_line_size;
+  const float slope = it.p.gain_slope - 1.0f;
+  const long long mb = mlo + (long long)blockIdx.x * 64;
+  for (int r = rowt; r < 64; r += 4) {
+    const long long m = mb + r;
+    if (m < it.m0 || m >= it.m1) continue;
+    const float2 xd = m >= delay ? x[(m - delay) * px + it.lane] : float2{it.s.delay_line[m * 2 + 0], it.s.delay_line[m * 2 + 1]};
+    const float g_db = lvl[m * pw + it.lane] * slope;
+    const float g = sd::exp2_(g_db * 0.166096404744368117f) * 0.7f;
+    y[m * py + it.lane_y] = float2{xd.x * g, xd.y * g};
+  }
 }
 
 }  // namespace
@@ -1640,6 +1901,52 @@ hipError_t costas_gang(const CostasGangItem *d_items, const GangGroup *d_groups,
 {
   if (ngroups <= 0) return hipSuccess;
   hipLaunchKernelGGL(costas_gang_kernel, dim3((unsigned)ngroups), dim3(64), 0, st, d_items, d_groups, static_cast<float2 *>(tm), slab);
+  return hipGetLastError();
+}
+
+hipError_t costas_gang_slab(const CostasGangItem *d_items, const GangGroup *d_groups, int ngroups, GangSlab io, hipStream_t st)
+{
+  if (ngroups <= 0) return hipSuccess;
+  hipLaunchKernelGGL(costas_gang_slab_kernel, dim3((unsigned)ngroups), dim3(64), 0, st, d_items, d_groups, io);
+  return hipGetLastError();
+}
+
+hipError_t pll_gang_slab(const PllGangItem *d_items, int n, GangSlab io, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pll_gang_slab_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_items, n, io);
+  return hipGetLastError();
+}
+
+hipError_t clock_gang_slab(const ClockGangItem *d_items, int n, GangSlab io, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(clock_gang_slab_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_items, n, io);
+  return hipGetLastError();
+}
+
+hipError_t agc_level_gang_slab(const AgcGangItem *d_items, int n, GangSlab io, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(agc_level_gang_slab_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_items, n, io);
+  return hipGetLastError();
+}
+
+hipError_t agc_pre_slab(const AgcSlabItem *d_items, int n, const void *x, long long px, float *db, float *peak, long long pw,
+                        long long max_len, hipStream_t st)
+{
+  if (n <= 0 || max_len <= 0) return hipSuccess;
+  hipLaunchKernelGGL(agc_pre_slab_kernel, dim3((unsigned)((max_len + SLAB_TM - 1) / SLAB_TM), (unsigned)((n + 63) / 64)), dim3(256), 0, st,
+                     d_items, n, static_cast<const float2 *>(x), px, db, peak, pw);
+  return hipGetLastError();
+}
+
+hipError_t agc_apply_slab(const AgcSlabItem *d_items, int n, const void *x, long long px, void *y, long long py, const float *lvl,
+                          long long pw, long long mlo, long long mhi, hipStream_t st)
+{
+  if (n <= 0 || mhi <= mlo) return hipSuccess;
+  hipLaunchKernelGGL(agc_apply_slab_kernel, dim3((unsigned)((mhi - mlo + 63) / 64), (unsigned)((n + 63) / 64)), dim3(256), 0, st,
+                     d_items, n, static_cast<const float2 *>(x), px, static_cast<float2 *>(y), py, lvl, pw, mlo);
   return hipGetLastError();
 }
 

@@ -497,8 +497,10 @@ SUBOOL suamd_specttuner_set_run(suamd_specttuner_t *st, unsigned run)
   return SU_TRUE;
 }
 
+// (mix_y: channels of at most mix_max_size bins go through the view {mix_y, mix_view}, the others through d_y / d_rows)
 static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_y, suamd_view view,
-                      suamd_complex *const *d_rows, SUSCOUNT *counts, void *stream, size_t rows_span = 0);
+                      suamd_complex *const *d_rows, SUSCOUNT *counts, void *stream, size_t rows_span = 0,
+                      suamd_complex *mix_y = nullptr, suamd_view mix_view = suamd_view{0, 1}, unsigned mix_max_size = 0);
 
 SUBOOL suamd_specttuner_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_y, suamd_view view,
                              SUSCOUNT *counts, void *stream)
@@ -523,8 +525,19 @@ SUBOOL suamd_specttuner_feed_rows_near(suamd_specttuner_t *st, const suamd_compl
   return st_feed(st, d_x, len, static_cast<suamd_complex *>(const_cast<void *>(d_base)), suamd_view{0, 1}, d_rows, counts, stream, span_bytes);
 }
 
-static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_y, suamd_view view,
-                      suamd_complex *const *d_rows, SUSCOUNT *counts, void *stream, size_t rows_span)
+SUBOOL suamd_specttuner_feed_mixed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_y, suamd_view view,
+                                   unsigned view_max_size, suamd_complex *const *d_rows, const void *d_base, size_t span_bytes,
+                                   SUSCOUNT *counts, void *stream)
+{
+  if (!d_y || !d_rows) { suamd_set_error("null output"); return SU_FALSE; }
+  const bool near = d_base && span_bytes && span_bytes < ((size_t)1 << 31);
+  return st_feed(st, d_x, len, near ? static_cast<suamd_complex *>(const_cast<void *>(d_base)) : nullptr, suamd_view{0, 1}, d_rows, counts, stream,
+                 near ? span_bytes : 0, d_y, view, view_max_size);
+}
+
+static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT len, suamd_complex *d_y_all, suamd_view view_all,
+                      suamd_complex *const *d_rows_all, SUSCOUNT *counts, void *stream, size_t rows_span_all,
+                      suamd_complex *mix_y, suamd_view mix_view, unsigned mix_max_size)
 {
   if (!st || (len && !d_x)) { suamd_set_error("null argument"); return SU_FALSE; }
   if (len % st->H) { suamd_set_error("len must be a multiple of half a window (%u)", st->H); return SU_FALSE; }
@@ -543,6 +556,12 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
         if (!ok) { suamd_set_error("device allocation failed"); return SU_FALSE; }
       }
       if (g.members.empty()) continue;
+      // where this size group's samples go: the mixed feed's view for the narrow sizes, the caller's rows / view otherwise
+      const bool to_mix = mix_y && (1u << g.log2s) <= mix_max_size;
+      suamd_complex *d_y = to_mix ? mix_y : d_y_all;
+      const suamd_view view = to_mix ? mix_view : view_all;
+      suamd_complex *const *d_rows = to_mix ? nullptr : d_rows_all;
+      const size_t rows_span = to_mix ? 0 : rows_span_all;
       if (!d_y && !d_rows) { suamd_set_error("null output"); return SU_FALSE; }
       sdk::StArgs a{};
       a.x = d_x; a.hist = st->d_hist[st->hist_cur]; a.have_hist = st->have_hist ? 1 : 0;

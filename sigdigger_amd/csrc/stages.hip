@@ -447,7 +447,8 @@ __global__ __launch_bounds__(1024) void rows_deliver_kernel(const sdk::DeliverIt
   }
   const float2 *src = static_cast<const float2 *>(it.src);
   float2 *dst = static_cast<float2 *>(it.dst);
-  for (unsigned m = threadIdx.x; m < n; m += 1024) dst[m] = src[m];
+  if (it.stride == 1) { for (unsigned m = threadIdx.x; m < n; m += 1024) dst[m] = src[m]; }
+  else { for (unsigned m = threadIdx.x; m < n; m += 1024) dst[m] = src[(size_t)m * it.stride]; }
 }
 
 }  // namespace

@@ -46,6 +46,7 @@
   X(analyzer_poison_rows, "SUAMD_ANALYZER_POISON_ROWS", 0, 0, 1, "1: inspector rows start as NaNs (debug)") \
   X(analyzer_subranges, "SUAMD_ANALYZER_SUBRANGES", 0, 0, 8, "sub-ranges a block takes through the serial stages; 0: 4, or 2 beyond 128 inspectors") \
   X(analyzer_pipeline, "SUAMD_ANALYZER_PIPELINE", 1, 0, 1,   "0: one block in flight instead of two") \
+  X(analyzer_slab,   "SUAMD_ANALYZER_SLAB",   1, 0, 1,       "FFT filter bank: 0 gives every inspector rows of its own (rounds 1-5) instead of columns of one time-major slab for the narrow (<= 64-bin) channels") \
   X(analyzer_stage_priority, "SUAMD_ANALYZER_STAGE_PRIORITY", 99, -2, 99, "priority of the three recurrence streams (HIP: lower is higher); 99: the device's highest; -2 (env: off): default-priority streams")
 
 namespace sdk {

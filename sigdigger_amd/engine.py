@@ -590,6 +590,29 @@ class SpectTuner:
                   "suamd_specttuner_feed_rows")
         return [int(v) for v in counts]
 
+    def feed_mixed(self, x, slab, view_max_size, rows, near=True, stream=None):
+        """suamd_specttuner_feed_mixed: channels of at most view_max_size bins become columns of `slab` (2-D complex64
+        [time][pitch], column = channel index), wider ones go to rows[c] as in feed_rows.  Returns counts."""
+        _chk_c64(x, "x")
+        ptrs = [0 if r is None else int(r.data_ptr()) for r in rows]
+        table = getattr(self, "_row_table", None)
+        if table is None or table.numel() != len(ptrs) or table.device != x.device:
+            if table is not None:
+                torch.cuda.synchronize(table.device)
+            table = self._row_table = torch.empty(max(len(ptrs), 1), dtype=torch.int64, device=x.device)
+            self._row_table_host = None
+        if self._row_table_host != ptrs:
+            torch.cuda.synchronize(x.device)
+            if ptrs:
+                table[:len(ptrs)].copy_(torch.tensor(ptrs, dtype=torch.int64))
+            self._row_table_host = list(ptrs)
+        counts = (C.c_uint64 * max(self.capacity(), 1))()
+        live = [p for p in ptrs if p]
+        base, span = (min(live), max(live) - min(live) + 8) if (near and live) else (None, 0)
+        check(self.ctx.lib.suamd_specttuner_feed_mixed(self.h, _ptr(x), x.numel(), _ptr(slab), _l.View(1, slab.shape[1]), int(view_max_size),
+                                                       table.data_ptr(), base, span, counts, _stream(stream)), "suamd_specttuner_feed_mixed")
+        return [int(v) for v in counts]
+
 
 class _LoopBank:
     _destroy = None
@@ -834,6 +857,67 @@ def gang_clock(ctx, banks, xs, syms, counts, stream=None):
     check(ctx.lib.suamd_clock_gang_feed(ctx.h, _ptr_array([b.h for b in banks]), n, _ptr_array([_ptr(x) for x in xs]), lens,
                                         _ptr_array([_ptr(s) for s in syms]), _ptr_array([_ptr(c) for c in counts]),
                                         _stream(stream)), "suamd_clock_gang_feed")
+
+
+# ---- gangs on time-major slabs: slab = 2-D complex64 tensor [rows][pitch], item i = column cols[i], its first sample in
+# row r0[i] (default 0), lens[i] samples
+def _slab_cols(slab, cols, r0=None):
+    if slab.dim() != 2 or not slab.is_contiguous():
+        raise SigDiggerAmdError("a slab is a contiguous 2-D tensor [rows][pitch]")
+    pitch = slab.shape[1]
+    es = slab.element_size()
+    return _ptr_array([int(slab.data_ptr()) + (int(r0[i] if r0 is not None else 0) * pitch + int(c)) * es for i, c in enumerate(cols)])
+
+
+def gang_costas_slab(ctx, banks, xslab, xcols, yslab, ycols, lens, r0=None, stream=None):
+    n = len(banks)
+    check(ctx.lib.suamd_costas_gang_feed_slab(ctx.h, _ptr_array([b.h for b in banks]), n, _slab_cols(xslab, xcols, r0), xslab.shape[1],
+                                              _slab_cols(yslab, ycols, r0), yslab.shape[1], (C.c_uint64 * n)(*[int(v) for v in lens]), _stream(stream)),
+          "suamd_costas_gang_feed_slab")
+
+
+def gang_pll_slab(ctx, banks, xslab, xcols, yslab, ycols, lens, r0=None, stream=None):
+    n = len(banks)
+    check(ctx.lib.suamd_pll_gang_feed_slab(ctx.h, _ptr_array([b.h for b in banks]), n, _slab_cols(xslab, xcols, r0), xslab.shape[1],
+                                           _slab_cols(yslab, ycols, r0), yslab.shape[1], (C.c_uint64 * n)(*[int(v) for v in lens]), _stream(stream)),
+          "suamd_pll_gang_feed_slab")
+
+
+def gang_clock_slab(ctx, banks, xslab, xcols, lens, syms, counts, r0=None, stream=None):
+    n = len(banks)
+    check(ctx.lib.suamd_clock_gang_feed_slab(ctx.h, _ptr_array([b.h for b in banks]), n, _slab_cols(xslab, xcols, r0), xslab.shape[1],
+                                             (C.c_uint64 * n)(*[int(v) for v in lens]), _ptr_array([_ptr(s) for s in syms]),
+                                             _ptr_array([_ptr(c) for c in counts]), _stream(stream)), "suamd_clock_gang_feed_slab")
+
+
+def gang_agc_slab(ctx, banks, xslab, xcols, yslab, ycols, lens, work, parts=4, stream=None):
+    """The AGC's four steps on slabs (suamd_agc_gang_*_slab): work = float32 tensor of 2 * rows * pitch elements."""
+    n = len(banks)
+    lens_l = [int(v) for v in lens]
+    lens_c = (C.c_uint64 * n)(*lens_l)
+    b = _ptr_array([bk.h for bk in banks])
+    px, py = _slab_cols(xslab, xcols), _slab_cols(yslab, ycols)
+    pitch = xslab.shape[1]
+    rows = work.numel() // (2 * pitch)
+    st = _stream(stream)
+    check(ctx.lib.suamd_agc_gang_pre_slab(ctx.h, b, n, _ptr(xslab), pitch, px, lens_c, _ptr(work), rows, st), "suamd_agc_gang_pre_slab")
+    for j in range(parts):
+        m0 = (C.c_uint64 * n)(*[L * j // parts for L in lens_l])
+        m1 = (C.c_uint64 * n)(*[L * (j + 1) // parts for L in lens_l])
+        check(ctx.lib.suamd_agc_gang_level_slab(ctx.h, b, n, _ptr(xslab), pitch, px, lens_c, m0, m1, _ptr(work), rows, st), "suamd_agc_gang_level_slab")
+        check(ctx.lib.suamd_agc_gang_apply_slab(ctx.h, b, n, _ptr(xslab), pitch, px, _ptr(yslab), yslab.shape[1], py, lens_c, m0, m1,
+                                                _ptr(work), rows, st), "suamd_agc_gang_apply_slab")
+    check(ctx.lib.suamd_agc_gang_finish_slab(ctx.h, b, n, _ptr(xslab), pitch, px, lens_c, _ptr(work), rows, st), "suamd_agc_gang_finish_slab")
+
+
+def rows_deliver_strided(ctx, src_ptrs, strides, counts, dsts, count_outs, stream=None):
+    """suamd_rows_deliver_strided: src_ptrs[i] = address of the first sample, strides[i] = its element stride."""
+    n = len(src_ptrs)
+    dc = _ptr_array([None if isinstance(c, int) else _ptr(c) for c in counts])
+    fx = (C.c_uint64 * n)(*[c if isinstance(c, int) else 0 for c in counts])
+    check(ctx.lib.suamd_rows_deliver_strided(ctx.h, n, _ptr_array(list(src_ptrs)), (C.c_uint64 * n)(*strides), dc, fx,
+                                             _ptr_array([_ptr(d) for d in dsts]), _ptr_array([_ptr(c) for c in count_outs]),
+                                             _stream(stream)), "suamd_rows_deliver_strided")
 
 
 class SNREstimator(_LoopBank):

@@ -83,6 +83,7 @@ PROTOTYPES = {
     "suamd_specttuner_feed": (INT, [VP, VP, U64, VP, View, C.POINTER(U64), VP]),
     "suamd_specttuner_feed_rows": (INT, [VP, VP, U64, VP, C.POINTER(U64), VP]),
     "suamd_specttuner_feed_rows_near": (INT, [VP, VP, U64, VP, VP, C.c_size_t, C.POINTER(U64), VP]),
+    "suamd_specttuner_feed_mixed": (INT, [VP, VP, U64, VP, View, UINT, VP, VP, C.c_size_t, C.POINTER(U64), VP]),
     "suamd_specttuner_set_run": (INT, [VP, UINT]),
     "suamd_specttuner_set_slots": (INT, [VP, UINT]),
     "suamd_specttuner_channel_capacity": (UINT, [VP]),
@@ -148,6 +149,14 @@ PROTOTYPES = {
     "suamd_chanbank_gang_feed": (INT, [VP, VP, UINT, VP, U64, VP, VP, VP]),
     "suamd_rows_deliver": (INT, [VP, UINT, VP, VP, VP, VP, VP, VP]),
     "suamd_clock_gang_feed": (INT, [VP, VP, UINT, VP, VP, VP, VP, VP]),
+    "suamd_costas_gang_feed_slab": (INT, [VP, VP, UINT, VP, U64, VP, U64, VP, VP]),
+    "suamd_pll_gang_feed_slab": (INT, [VP, VP, UINT, VP, U64, VP, U64, VP, VP]),
+    "suamd_clock_gang_feed_slab": (INT, [VP, VP, UINT, VP, U64, VP, VP, VP, VP]),
+    "suamd_agc_gang_pre_slab": (INT, [VP, VP, UINT, VP, U64, VP, VP, VP, U64, VP]),
+    "suamd_agc_gang_level_slab": (INT, [VP, VP, UINT, VP, U64, VP, VP, VP, VP, VP, U64, VP]),
+    "suamd_agc_gang_apply_slab": (INT, [VP, VP, UINT, VP, U64, VP, VP, U64, VP, VP, VP, VP, VP, U64, VP]),
+    "suamd_agc_gang_finish_slab": (INT, [VP, VP, UINT, VP, U64, VP, VP, VP, U64, VP]),
+    "suamd_rows_deliver_strided": (INT, [VP, UINT, VP, VP, VP, VP, VP, VP, VP]),
     "suamd_rows_scale": (INT, [VP, VP, View, VP, View, UINT, U64, F32, VP]),
     "suamd_nco_bank_new": (VP, [VP, UINT, VP]),
     "suamd_nco_bank_destroy": (None, [VP]),

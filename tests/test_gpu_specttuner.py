@@ -503,3 +503,43 @@ def test_wide_channels_without_the_warm_up_window(ctx, tune, dec, nch):
                 assert n1 > 0, "SUAMD_ST_SEAM=1 never launched the seam kernel: the two runs took the same path"
             for a, b in zip(ref, got):
                 assert a.size == b.size > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (run, tm)
+
+
+def test_mixed_feed_narrow_channels_to_a_slab_wide_ones_to_rows(ctx):
+    """suamd_specttuner_feed_mixed (the live analyzer's feed): channels of <= 64 bins land as columns of a time-major slab,
+    wider ones in their own rows; the samples are the plain view feed's, bit for bit; a closed channel's column is left
+    alone; two feeds."""
+    x = cnoise(H * 64, 4242)
+    dx = torch.from_numpy(x).cuda()
+    decs = [64, 64, 16, 128, 64, 4, 512, 64, 64, 32, 64]
+    chans = [(0.1 + 0.5 * c, 2 * np.pi / d * 0.7, 1.0, bool(c % 4 == 0)) for c, d in enumerate(decs)]
+    ref = engine.SpectTuner(ctx, W)
+    mix = engine.SpectTuner(ctx, W)
+    for st in (ref, mix):
+        st.set_run(3)
+    ids = [ref.open_channel(*c) for c in chans]
+    assert ids == [mix.open_channel(*c) for c in chans]
+    ref.close_channel(ids[4]); mix.close_channel(ids[4])
+    pitch = 64
+    cap = x.size // min(decs) + 64
+    slab = torch.full((x.size // 64 + 64, pitch), 7.0 + 0j, dtype=torch.complex64, device="cuda")
+    arena = torch.zeros((len(ids), cap), dtype=torch.complex64, device="cuda")
+    got_r, got_m = [[] for _ in ids], [[] for _ in ids]
+    for lo, hi in ((0, H * 24), (H * 24, x.size)):
+        out, counts = ref.feed(dx[lo:hi])
+        rows = [None if (W // decs[c] <= 64 or c == ids[4]) else arena[c] for c in ids]
+        cm = mix.feed_mixed(dx[lo:hi], slab, 64, rows)
+        torch.cuda.synchronize()
+        assert list(cm) == list(counts)
+        for c in ids:
+            if c == ids[4]:
+                continue
+            got_r[c].append(out[c][:counts[c]].cpu().numpy())
+            got_m[c].append((slab[:cm[c], c] if W // decs[c] <= 64 else arena[c][:cm[c]]).cpu().numpy())
+    for c in ids:
+        if c == ids[4]:
+            continue
+        assert np.array_equal(np.concatenate(got_r[c]).view(np.uint32), np.concatenate(got_m[c]).view(np.uint32)), (c, decs[c])
+    assert bool((slab[:, ids[4]] == 7.0).all()), "a closed channel's column is not written"
+    assert bool((slab[:, len(ids):] == 7.0).all()), "columns beyond the channel table are not written"
+    ref.close(); mix.close()
