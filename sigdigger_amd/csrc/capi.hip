@@ -1981,10 +1981,11 @@ SUBOOL suamd_agc_gang_pre_slab(suamd_ctx_t *ctx, suamd_agc_bank_t *const *banks,
   for (size_t o = 0; o < items.size(); o += 512) {
     std::vector<sdk::AgcSlabItem> part(items.begin() + o, items.begin() + std::min(items.size(), o + 512));
     long long span = 0;
-    for (const sdk::AgcSlabItem &it : part) span = std::max(span, it.len);
+    int halo = 0;
+    for (const sdk::AgcSlabItem &it : part) { span = std::max(span, it.len); halo = std::max(halo, (int)it.p.mag_history_size - 1); }
     sdk::AgcSlabItem *d = gang_upload(ctx, part, st);
     if (!d) return SU_FALSE;
-    HIP_TRY(sdk::agc_pre_slab(d, (int)part.size(), d_x_slab, (long long)x_pitch, d_work, d_work + (size_t)work_rows * x_pitch, (long long)x_pitch, span, st), SU_FALSE);
+    HIP_TRY(sdk::agc_pre_slab(d, (int)part.size(), d_x_slab, (long long)x_pitch, d_work, d_work + (size_t)work_rows * x_pitch, (long long)x_pitch, span, halo, st), SU_FALSE);
   }
   return SU_TRUE;
 }

@@ -256,8 +256,9 @@ hipError_t agc_state_items(const AgcStateItem *d_items, int n, hipStream_t st);
 // samples in column `lane` of x (pitch px), magnitudes / peaks / levels in column `lane` of two work slabs of pitch pw,
 // outputs [m0, m1) to column lane_y of y.  One launch each for all items; tiles of 64 items x 64 / 128 time steps.
 struct AgcSlabItem { AgcParams p; AgcState s; int lane, lane_y; long long len, m0, m1; };
+// (halo: the longest magnitude history of the items, mag_history_size - 1)
 hipError_t agc_pre_slab(const AgcSlabItem *d_items, int n, const void *x, long long px, float *db, float *peak, long long pw,
-                        long long max_len, hipStream_t st);
+                        long long max_len, int halo, hipStream_t st);
 hipError_t agc_apply_slab(const AgcSlabItem *d_items, int n, const void *x, long long px, void *y, long long py, const float *lvl,
                           long long pw, long long mlo, long long mhi, hipStream_t st);
 hipError_t agc_level_gang_slab(const AgcGangItem *d_items, int n, GangSlab io, hipStream_t st);

@@ -829,38 +829,58 @@ __device__ __forceinline__ long long uniform64(long long v)
 
 // (tm / tmo: where the lanes read and write -- the same packed slab for the gather / scatter form; lo / loo: the lane's byte
 // offset there.  The slab form of a 64-column pitch runs this loop too, on the producer's slab and with the items' own columns.)
+// EVERY lane has work: a lane without an item, or with an empty row, is given a copy of another lane's item by its caller
+// (gang_lane) -- it computes and stores exactly what that lane does, and its state is not written back.  That keeps the
+// steady-state loop ONE straight path.  With the `if (len > 0)` it used to have around the steps, two paths with different
+// numbers of stores in flight met at the back edge, and the compiler's wait there was s_waitcnt vmcnt(0): every chunk waited
+// for its own last store to complete (the bank kernels, one path, get counted waits) -- 86 against 77 ns per Costas sample.
 template <bool HAS_OUT, typename T, typename F>
 __device__ __forceinline__ void gang_stream_tm(const T *tm, T *tmo, const uint32_t lo, const uint32_t loo, long long len, F step)
 {
   const long long maxlen = uniform64(wave_max(len));
   if (maxlen <= 0) return;
-  const long long minlen = uniform64(-wave_max(len > 0 ? -len : -(1ll << 62)));   // shortest non-empty row
+  const long long minlen = uniform64(-wave_max(-len));
   T cur[CHUNK], nxt[CHUNK];
 #pragma unroll
   for (int j = 0; j < CHUNK; ++j) cur[j] = ld_elem(tm, (long long)j * 64, lo);
-  for (long long i = 0; i < maxlen; i += CHUNK) {
+  long long i = 0;
+  for (; i + CHUNK <= minlen; i += CHUNK) {                  // inside every row
 #pragma unroll
     for (int j = 0; j < CHUNK; ++j) nxt[j] = ld_elem(tm, (i + CHUNK + j) * 64, lo);
-    if (i + CHUNK <= minlen) {                               // inside every row: no per-step predication
-      if (len > 0) {
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j) {
-          if constexpr (HAS_OUT) st_elem(tmo, (i + j) * 64, loo, step(i + j, cur[j]));
-          else step(i + j, cur[j]);
-        }
-      }
-    } else {
+    for (int j = 0; j < CHUNK; ++j) {
+      if constexpr (HAS_OUT) st_elem(tmo, (i + j) * 64, loo, step(i + j, cur[j]));
+      else step(i + j, cur[j]);
+    }
 #pragma unroll
-      for (int j = 0; j < CHUNK; ++j) {
-        if (i + j < len) {
-          if constexpr (HAS_OUT) st_elem(tmo, (i + j) * 64, loo, step(i + j, cur[j]));
-          else step(i + j, cur[j]);
-        }
+    for (int j = 0; j < CHUNK; ++j) cur[j] = nxt[j];
+  }
+  for (; i < maxlen; i += CHUNK) {                           // the rows' ends: step by step
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) nxt[j] = ld_elem(tm, (i + CHUNK + j) * 64, lo);
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) {
+      if (i + j < len) {
+        if constexpr (HAS_OUT) st_elem(tmo, (i + j) * 64, loo, step(i + j, cur[j]));
+        else step(i + j, cur[j]);
       }
     }
 #pragma unroll
     for (int j = 0; j < CHUNK; ++j) cur[j] = nxt[j];
   }
+}
+
+// Which item a lane of a gang works on: its own (lane < count, a row that is not empty), else a copy of the first lane that
+// has one.  false: nobody has work.  own: the lane's state goes back to its item.
+template <typename Item>
+__device__ __forceinline__ bool gang_lane(const Item *__restrict__ items, int count, int j, int *src, bool *own)
+{
+  const long long mylen = j < count ? items[j].len : 0;
+  const unsigned long long has = __ballot(mylen > 0);
+  if (has == 0) return false;
+  *own = mylen > 0;
+  *src = *own ? j : (int)__ffsll((long long)has) - 1;
+  return true;
 }
 
 // rows of a gang's items <-> slabs: item k of the table (item_bytes apart; its row pointer and length sit at off_ptr /
@@ -926,9 +946,9 @@ __device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__b
 template <int KIND, int ORDER, bool GAIN1>
 __device__ __forceinline__ void costas_gang_body(const sdk::CostasGangItem *__restrict__ items, int count, float2 *tm)
 {
-  const int j = threadIdx.x;
-  const bool live = j < count;
-  const sdk::CostasGangItem it = items[live ? j : 0];
+  int j; bool live;
+  if (!gang_lane(items, count, (int)threadIdx.x, &j, &live)) return;
+  const sdk::CostasGangItem it = items[j];
   const sdk::CostasParams p = it.p;                           // per lane: every item its own loop
   const sdk::CostasState s = it.s;
   CostasRegs<ORDER> r;
@@ -939,8 +959,7 @@ __device__ __forceinline__ void costas_gang_body(const sdk::CostasGangItem *__re
     r.xh[i] = c32{s.xh[(i - 1) * 2 + 0], s.xh[(i - 1) * 2 + 1]};
     r.yh[i] = c32{s.yh[(i - 1) * 2 + 0], s.yh[(i - 1) * 2 + 1]};
   }
-  const long long len = live ? it.len : 0;
-  gang_stream_tm<true>(tm, tm, j * 8u, j * 8u, len, [&](long long, float2 v) { return costas_step<KIND, ORDER, GAIN1>(p, r, v); });
+  gang_stream_tm<true>(tm, tm, j * 8u, j * 8u, it.len, [&](long long, float2 v) { return costas_step<KIND, ORDER, GAIN1>(p, r, v); });
   if (!live) return;
   s.phase[0] = r.phase;
   s.omega[0] = r.omega;
@@ -973,15 +992,15 @@ __global__ __launch_bounds__(64) void costas_gang_kernel(const sdk::CostasGangIt
 
 __global__ __launch_bounds__(64) void pll_gang_kernel(const sdk::PllGangItem *__restrict__ items, int n, float2 *tm, long long slab)
 {
-  const int j = blockIdx.x * 64 + threadIdx.x;
-  const bool live = j < n;
-  const sdk::PllGangItem it = items[live ? j : 0];
+  const sdk::PllGangItem *mine = items + (size_t)blockIdx.x * 64;
+  int j; bool live;
+  if (!gang_lane(mine, n - (int)blockIdx.x * 64, (int)threadIdx.x, &j, &live)) return;
+  const sdk::PllGangItem it = mine[j];
   const float alpha = it.alpha, beta = it.beta;
   uint32_t phase = it.s.phase[0];
   float omega = it.s.omega[0];
-  const long long len = live ? it.len : 0;
   float2 *my = tm + (size_t)blockIdx.x * slab;
-  gang_stream_tm<true>(my, my, threadIdx.x * 8u, threadIdx.x * 8u, len, [&](long long, float2 v) { return pll_step(alpha, beta, phase, omega, v); });
+  gang_stream_tm<true>(my, my, j * 8u, j * 8u, it.len, [&](long long, float2 v) { return pll_step(alpha, beta, phase, omega, v); });
   if (!live) return;
   it.s.phase[0] = phase;
   it.s.omega[0] = omega;
@@ -1311,18 +1330,19 @@ __global__ __launch_bounds__(64) void clock_gang_kernel(const sdk::ClockGangItem
 
 __global__ __launch_bounds__(64) void agc_level_gang_kernel(const sdk::AgcGangItem *__restrict__ items, int n, float *tm, long long slab)
 {
-  const int j = blockIdx.x * 64 + threadIdx.x;
-  const bool live = j < n;
-  const sdk::AgcGangItem it = items[live ? j : 0];
+  const sdk::AgcGangItem *mine = items + (size_t)blockIdx.x * 64;
+  int j; bool live;
+  if (!gang_lane(mine, n - (int)blockIdx.x * 64, (int)threadIdx.x, &j, &live)) return;
+  const sdk::AgcGangItem it = mine[j];
   const sdk::AgcState s = it.s;
   unsigned hang_n = s.hang_n[0];
   float fast = s.fast_level[0], slow = s.slow_level[0];
   const float far = it.p.fast_alpha_rise, faf = it.p.fast_alpha_fall, sar = it.p.slow_alpha_rise, saf = it.p.slow_alpha_fall;
   const float knee = it.p.knee;
   const unsigned hang_max = it.p.hang_max;
-  const long long len = live ? it.len : 0;
+  const long long len = it.len;
   float *my = tm + (size_t)blockIdx.x * slab;
-  gang_stream_tm<true>(my, my, threadIdx.x * 4u, threadIdx.x * 4u, len, [&](long long, float pk) {
+  gang_stream_tm<true>(my, my, j * 4u, j * 4u, len, [&](long long, float pk) {
     float d = pk - fast;
     const float fa = d > 0.0f ? far : faf;
     fast = sd::fma_(fa, d, fast);
@@ -1353,7 +1373,7 @@ __device__ __forceinline__ void gang_stream_slab(const T *tin, T *tout, long lon
 {
   const long long maxlen = uniform64(wave_max(len));
   if (maxlen <= 0) return;
-  const long long minlen = uniform64(-wave_max(len > 0 ? -len : -(1ll << 62)));   // shortest non-empty row
+  const long long minlen = uniform64(-wave_max(-len));       // (every lane has work: gang_lane)
   uint32_t oin[CHUNK], oout[CHUNK];
 #pragma unroll
   for (int j = 0; j < CHUNK; ++j) {
@@ -1363,26 +1383,30 @@ __device__ __forceinline__ void gang_stream_slab(const T *tin, T *tout, long lon
   T cur[CHUNK], nxt[CHUNK];
 #pragma unroll
   for (int j = 0; j < CHUNK; ++j) cur[j] = ld_elem(tin, 0, oin[j]);
-  for (long long i = 0; i < maxlen; i += CHUNK) {
+  long long i = 0;
+  for (; i + CHUNK <= minlen; i += CHUNK) {                  // inside every row: one straight path
     const T *bn = tin + (i + CHUNK) * pin;
     T *bo = tout + i * pout;
 #pragma unroll
     for (int j = 0; j < CHUNK; ++j) nxt[j] = ld_elem(bn, 0, oin[j]);
-    if (i + CHUNK <= minlen) {                               // inside every row: no per-step predication
-      if (len > 0) {
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j) {
-          if constexpr (HAS_OUT) st_elem(bo, 0, oout[j], step(i + j, cur[j]));
-          else step(i + j, cur[j]);
-        }
-      }
-    } else {
+    for (int j = 0; j < CHUNK; ++j) {
+      if constexpr (HAS_OUT) st_elem(bo, 0, oout[j], step(i + j, cur[j]));
+      else step(i + j, cur[j]);
+    }
 #pragma unroll
-      for (int j = 0; j < CHUNK; ++j) {
-        if (i + j < len) {
-          if constexpr (HAS_OUT) st_elem(bo, 0, oout[j], step(i + j, cur[j]));
-          else step(i + j, cur[j]);
-        }
+    for (int j = 0; j < CHUNK; ++j) cur[j] = nxt[j];
+  }
+  for (; i < maxlen; i += CHUNK) {
+    const T *bn = tin + (i + CHUNK) * pin;
+    T *bo = tout + i * pout;
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) nxt[j] = ld_elem(bn, 0, oin[j]);
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) {
+      if (i + j < len) {
+        if constexpr (HAS_OUT) st_elem(bo, 0, oout[j], step(i + j, cur[j]));
+        else step(i + j, cur[j]);
       }
     }
 #pragma unroll
@@ -1398,9 +1422,9 @@ __device__ __forceinline__ uint32_t slab_offset(const void *p, const void *base)
 template <int KIND, int ORDER, bool GAIN1>
 __device__ __forceinline__ void costas_gang_slab_body(const sdk::CostasGangItem *__restrict__ items, int count, const sdk::GangSlab &io)
 {
-  const int j = threadIdx.x;
-  const bool live = j < count;
-  const sdk::CostasGangItem it = items[live ? j : 0];
+  int j; bool live;
+  if (!gang_lane(items, count, (int)threadIdx.x, &j, &live)) return;
+  const sdk::CostasGangItem it = items[j];
   const sdk::CostasParams p = it.p;
   const sdk::CostasState s = it.s;
   CostasRegs<ORDER> r;
@@ -1411,7 +1435,7 @@ __device__ __forceinline__ void costas_gang_slab_body(const sdk::CostasGangItem 
     r.xh[i] = c32{s.xh[(i - 1) * 2 + 0], s.xh[(i - 1) * 2 + 1]};
     r.yh[i] = c32{s.yh[(i - 1) * 2 + 0], s.yh[(i - 1) * 2 + 1]};
   }
-  const long long len = live ? it.len : 0;
+  const long long len = it.len;
   auto step = [&](long long, float2 v) { return costas_step<KIND, ORDER, GAIN1>(p, r, v); };
   // a pitch of 64 columns (at most 64 narrow inspectors on the shard -- BASELINE configs[3]'s slice) is the packed slabs' own:
   // the loop with immediate offsets
@@ -1448,13 +1472,14 @@ __global__ __launch_bounds__(64) void costas_gang_slab_kernel(const sdk::CostasG
 
 __global__ __launch_bounds__(64) void pll_gang_slab_kernel(const sdk::PllGangItem *__restrict__ items, int n, sdk::GangSlab io)
 {
-  const int j = blockIdx.x * 64 + threadIdx.x;
-  const bool live = j < n;
-  const sdk::PllGangItem it = items[live ? j : 0];
+  const sdk::PllGangItem *mine = items + (size_t)blockIdx.x * 64;
+  int j; bool live;
+  if (!gang_lane(mine, n - (int)blockIdx.x * 64, (int)threadIdx.x, &j, &live)) return;
+  const sdk::PllGangItem it = mine[j];
   const float alpha = it.alpha, beta = it.beta;
   uint32_t phase = it.s.phase[0];
   float omega = it.s.omega[0];
-  const long long len = live ? it.len : 0;
+  const long long len = it.len;
   auto step = [&](long long, float2 v) { return pll_step(alpha, beta, phase, omega, v); };
   if (io.pitch_in == 64 && io.pitch_out == 64)
     gang_stream_tm<true>(static_cast<const float2 *>(io.in), static_cast<float2 *>(io.out), slab_offset(it.x, io.in), slab_offset(it.y, io.out), len, step);
@@ -1503,16 +1528,17 @@ __global__ __launch_bounds__(64) void clock_gang_slab_kernel(const sdk::ClockGan
 
 __global__ __launch_bounds__(64) void agc_level_gang_slab_kernel(const sdk::AgcGangItem *__restrict__ items, int n, sdk::GangSlab io)
 {
-  const int j = blockIdx.x * 64 + threadIdx.x;
-  const bool live = j < n;
-  const sdk::AgcGangItem it = items[live ? j : 0];
+  const sdk::AgcGangItem *mine = items + (size_t)blockIdx.x * 64;
+  int j; bool live;
+  if (!gang_lane(mine, n - (int)blockIdx.x * 64, (int)threadIdx.x, &j, &live)) return;
+  const sdk::AgcGangItem it = mine[j];
   const sdk::AgcState s = it.s;
   unsigned hang_n = s.hang_n[0];
   float fast = s.fast_level[0], slow = s.slow_level[0];
   const float far = it.p.fast_alpha_rise, faf = it.p.fast_alpha_fall, sar = it.p.slow_alpha_rise, saf = it.p.slow_alpha_fall;
   const float knee = it.p.knee;
   const unsigned hang_max = it.p.hang_max;
-  const long long len = live ? it.len : 0;
+  const long long len = it.len;
   const uint32_t lo = slab_offset(it.peak, io.in);
   auto step = [&](long long, float pk) {
     float d = pk - fast;
@@ -1539,9 +1565,12 @@ __global__ __launch_bounds__(64) void agc_level_gang_slab_kernel(const sdk::AgcG
 // column it.lane of x, its magnitudes / peaks / levels in the same column of the work slabs (pitch `pw`).  A tile is 64
 // items x SLAB_TM time steps, every access a row of adjacent columns.  Per value the operations (and, for the sliding
 // maximum, the order of the comparisons: newest first) are agc_pre_items_kernel's / agc_apply_items_kernel's.
-constexpr int SLAB_TM = 128;
+// (SLAB_TM = 32 time steps and a halo of the gang's longest history, not of the 63 steps the longest possible one takes: with
+// 128 + 63 rows per tile a 2 Mi-sample block was 256 workgroups of 48 KB of LDS and took 52 us -- three times the row form,
+// and the next block's channeliser, which wants the same LDS, ran beside it)
+constexpr int SLAB_TM = 32;
 __global__ __launch_bounds__(256) void agc_pre_slab_kernel(const sdk::AgcSlabItem *__restrict__ items, int n, const float2 *__restrict__ x,
-                                                           long long px, float *__restrict__ db, float *__restrict__ peak, long long pw)
+                                                           long long px, float *__restrict__ db, float *__restrict__ peak, long long pw, int halo)
 {
   __builtin_amdgcn_s_setprio(3);
   __shared__ float tile[SLAB_TM + 63][64];
@@ -1550,11 +1579,11 @@ __global__ __launch_bounds__(256) void agc_pre_slab_kernel(const sdk::AgcSlabIte
   const bool live = k < n;
   const sdk::AgcSlabItem it = items[live ? k : 0];
   const long long len = live ? it.len : 0;
-  const int hl = (int)it.p.mag_history_size - 1;
+  const int hl = (int)it.p.mag_history_size - 1;              // <= halo
   const long long col = it.lane;
   const long long m0 = (long long)blockIdx.x * SLAB_TM;
-  for (int r = rowt; r < SLAB_TM + 63; r += 4) {
-    const long long m = m0 - 63 + r;
+  for (int r = rowt; r < SLAB_TM + halo; r += 4) {            // tile row r <-> time m0 - halo + r
+    const long long m = m0 - halo + r;
     float v = 0.f;
     if (m < len) {
       if (m >= 0) {
@@ -1569,15 +1598,16 @@ __global__ __launch_bounds__(256) void agc_pre_slab_kernel(const sdk::AgcSlabIte
   for (int t = rowt; t < SLAB_TM; t += 4) {
     const long long m = m0 + t;
     if (m >= len) break;
-    float pk = tile[t + 63][lane];
+    float pk = tile[t + halo][lane];
     for (int i = 1; i <= hl; ++i) {
-      const float v = tile[t + 63 - i][lane];
+      const float v = tile[t + halo - i][lane];
       pk = pk > v ? pk : v;
     }
     peak[m * pw + col] = pk;
   }
 }
 
+constexpr int APPLY_TM = 16;     // time steps per workgroup (64: an 8192-step sub-range was 128 workgroups and took 11 us; the row form 5)
 __global__ __launch_bounds__(256) void agc_apply_slab_kernel(const sdk::AgcSlabItem *__restrict__ items, int n, const float2 *__restrict__ x,
                                                              long long px, float2 *__restrict__ y, long long py,
                                                              const float *__restrict__ lvl, long long pw, long long mlo)
@@ -1589,8 +1619,8 @@ __global__ __launch_bounds__(256) void agc_apply_slab_kernel(const sdk::AgcSlabI
   const sdk::AgcSlabItem it = items[k];
   const long long delay = it.p.delay_line_size;
   const float slope = it.p.gain_slope - 1.0f;
-  const long long mb = mlo + (long long)blockIdx.x * 64;
-  for (int r = rowt; r < 64; r += 4) {
+  const long long mb = mlo + (long long)blockIdx.x * APPLY_TM;
+  for (int r = rowt; r < APPLY_TM; r += 4) {
     const long long m = mb + r;
     if (m < it.m0 || m >= it.m1) continue;
     const float2 xd = m >= delay ? x[(m - delay) * px + it.lane] : float2{it.s.delay_line[m * 2 + 0], it.s.delay_line[m * 2 + 1]};
@@ -1933,11 +1963,12 @@ hipError_t agc_level_gang_slab(const AgcGangItem *d_items, int n, GangSlab io, h
 }
 
 hipError_t agc_pre_slab(const AgcSlabItem *d_items, int n, const void *x, long long px, float *db, float *peak, long long pw,
-                        long long max_len, hipStream_t st)
+                        long long max_len, int halo, hipStream_t st)
 {
   if (n <= 0 || max_len <= 0) return hipSuccess;
+  if (halo < 0 || halo > 63) return hipErrorInvalidValue;
   hipLaunchKernelGGL(agc_pre_slab_kernel, dim3((unsigned)((max_len + SLAB_TM - 1) / SLAB_TM), (unsigned)((n + 63) / 64)), dim3(256), 0, st,
-                     d_items, n, static_cast<const float2 *>(x), px, db, peak, pw);
+                     d_items, n, static_cast<const float2 *>(x), px, db, peak, pw, halo);
   return hipGetLastError();
 }
 
@@ -1945,7 +1976,7 @@ hipError_t agc_apply_slab(const AgcSlabItem *d_items, int n, const void *x, long
                           long long pw, long long mlo, long long mhi, hipStream_t st)
 {
   if (n <= 0 || mhi <= mlo) return hipSuccess;
-  hipLaunchKernelGGL(agc_apply_slab_kernel, dim3((unsigned)((mhi - mlo + 63) / 64), (unsigned)((n + 63) / 64)), dim3(256), 0, st,
+  hipLaunchKernelGGL(agc_apply_slab_kernel, dim3((unsigned)((mhi - mlo + APPLY_TM - 1) / APPLY_TM), (unsigned)((n + 63) / 64)), dim3(256), 0, st,
                      d_items, n, static_cast<const float2 *>(x), px, static_cast<float2 *>(y), py, lvl, pw, mlo);
   return hipGetLastError();
 }

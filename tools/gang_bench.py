@@ -37,3 +37,22 @@ def clk_gang():
     for c in cnts: c.zero_()
     engine.gang_clock(ctx, kg, xs, syms, cnts)
 print("clock gang   %.2f ms" % timeit(clk_gang))
+# the same items as columns of a time-major slab (round 6): no gather / scatter, the recurrence streams the slab
+Y = torch.zeros((M + 128, C_), dtype=torch.complex64, device="cuda"); Y[:M] = torch.from_numpy(np.ascontiguousarray(rows.T)).cuda()
+A = torch.zeros_like(Y); Z = torch.zeros_like(Y)
+cols = list(range(C_))
+cs = [engine.CostasBank(ctx, 1, 2, 0.0, 0.125, 3, 0.005) for _ in range(C_)]
+print("costas slab  %.2f ms" % timeit(lambda: engine.gang_costas_slab(ctx, cs, Y, cols, Z, cols, [M] * C_)))
+work = torch.zeros(2 * (M + 128) * C_, dtype=torch.float32, device="cuda")
+asl = [engine.AGCBank(ctx, 1, tau=16.0) for _ in range(C_)]
+print("agc slab     %.2f ms" % timeit(lambda: engine.gang_agc_slab(ctx, asl, Y, cols, A, cols, [M] * C_, work, parts=1)))
+ks = [engine.ClockBank(ctx, 1, 0.2, 1 / 16) for _ in range(C_)]
+def clk_slab():
+    for c in cnts: c.zero_()
+    engine.gang_clock_slab(ctx, ks, Y, cols, [M] * C_, syms, cnts)
+print("clock slab   %.2f ms" % timeit(clk_slab))
+Y2 = torch.zeros((M + 128, 2 * C_), dtype=torch.complex64, device="cuda"); Y2[:M, ::2] = Y[:M]
+Z2 = torch.zeros_like(Y2)
+cols2 = list(range(0, 2 * C_, 2))
+cs2 = [engine.CostasBank(ctx, 1, 2, 0.0, 0.125, 3, 0.005) for _ in range(C_)]
+print("costas slab, pitch 128 (run-time pitch loop)  %.2f ms" % timeit(lambda: engine.gang_costas_slab(ctx, cs2, Y2, cols2, Z2, cols2, [M] * C_)))
