@@ -369,6 +369,53 @@ def pmc_traffic_in_run(args, kernels):
     return res
 
 
+def live_kernel_trace_in_run(log2_blocks=(21, 22), nblocks=16):
+    """The channeliser's and the PSD kernels' OWN durations inside the C++ live analyzer: child runs of the live leg
+    (tools/live_c4.py = run_live_roofline at one block length) under `rocprofv3 --kernel-trace --stats`.  The analyzer's
+    worker keeps four streams busy, and a dispatch-bound event pair there starts at a marker IN FRONT of the kernel's packet:
+    it also counts the time the dispatch waits for compute units that other streams' workgroups hold (58 - 62 us read for a
+    kernel rocprofv3 times at 30 - 40 us).  The profiler reads the dispatch's own timestamps.  {} when rocprofv3 is not on
+    the box or a pass fails; keys as run_live_roofline's."""
+    import csv, glob, shutil, subprocess, tempfile
+    if os.environ.get("SUAMD_BENCH_CHILD") or not shutil.which("rocprofv3"):
+        return {}
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="suamd_live_", dir="/tmp")
+    try:
+        for lg in log2_blocks:
+            out = os.path.join(tmp, str(lg))
+            cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "-o", "t", "--", sys.executable,
+                   os.path.join(here, "tools", "live_c4.py")]
+            env = dict(os.environ, SUAMD_BENCH_CHILD="1", TMPDIR="/tmp", LIVE_LOG2=str(lg), LIVE_BLOCKS=str(nblocks), PYTHONPATH=here)
+            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=180)
+            files = glob.glob(os.path.join(out, "**", "*kernel_stats.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                continue
+            L = 1 << lg
+            chan, psd = None, 0.0
+            for row in csv.DictReader(open(files[0])):
+                k = row["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+                avg_us, calls = float(row["AverageNs"]) / 1e3, int(row["Calls"])
+                if k in CHANNELISER_KERNELS and (chan is None or avg_us * calls > chan[1] * chan[2]):
+                    chan = (k, avg_us, calls, float(row["MinNs"]) / 1e3, float(row["MaxNs"]) / 1e3)
+                if k in ("psd_kernel", "psd_reduce_kernel"):
+                    psd += avg_us
+            if chan:
+                nbytes = 8.0 * L + 8.0 * 64 * (L // 64)
+                e = {"kernel": chan[0], "kernel_us": round(chan[1], 2), "launches": chan[2], "min_max_us": [round(chan[3], 2), round(chan[4], 2)],
+                     "frac": round(nbytes / (chan[1] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                if psd:
+                    e["psd_kernel_us"] = round(psd, 2)
+                    e["psd_frac"] = round((8.0 * L + 4.0 * 8192) / (psd * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                res[f"{L >> 20}Mi"] = e
+    except Exception:
+        pass
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
 def channeliser_alone(ctx, dev, fn, D, T, channeliser, log2_block, slots=None, reps=10):
     """the channeliser kernel alone on a resident block (dispatch-bound event pairs): ms per launch and the kernel's name"""
     Lb = 1 << log2_block
@@ -1091,7 +1138,11 @@ def main():
         if world == 1 and not args.no_pmc:
             import threading
             box = {}
-            pmc_thread = threading.Thread(target=lambda: box.update(r=pmc_traffic_in_run(args, (kname, "psd_kernel", "psd_reduce_kernel"))))
+            def children():
+                box.update(r=pmc_traffic_in_run(args, (kname, "psd_kernel", "psd_reduce_kernel")))
+                if live:                                      # (the live leg's kernels by the profiler's clock: see live_kernel_trace_in_run)
+                    box.update(live=live_kernel_trace_in_run())
+            pmc_thread = threading.Thread(target=children)
             pmc_thread.start()
         cpu = None
         if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (rank 0's host cores)
@@ -1108,6 +1159,11 @@ def main():
         if pmc_thread is not None:
             pmc_thread.join()
             pmc = box.get("r") or {}
+            if live and box.get("live"):
+                detail["live_roofline_rocprofv3"] = box["live"]
+                for k, v in box["live"].items():
+                    if k in live and "error" not in live[k]:
+                        live[k]["rocprofv3"] = v
         detail["pmc_counters"] = pmc or None
         src_now = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (4 steps), 2 x FETCH + WRITE"
         roof = fir_stage_roofline(C, D, L, fir_ms, kname, args.workload, TIMING if chan_k else "stream events around the stage",
@@ -1126,8 +1182,23 @@ def main():
                          "traffic_over_algorithmic": round(psd_tr / psd_bytes, 4) if psd_tr else None}
         if live:
             # the same two kernels inside the C++ live analyzer (the drop-in boundary), at a GUI's block lengths
-            roof_c["live_analyzer"] = {k: ({kk: v.get(kk) for kk in ("kernel", "frac", "kernel_ms", "value_MSps")} | ({"psd_frac": v["psd"]["frac"]} if "psd" in v else {}))
-                                       if "error" not in v else {"error": v["error"][:80]} for k, v in live.items()}
+            # (frac / kernel_ms: rocprofv3's kernel-trace of a child run of the same leg when the box has the profiler -- `timing`
+            # says which --; frac_event_pairs: the dispatch-bound event pairs, which inside the analyzer's four busy streams also
+            # count the dispatch's wait for compute units)
+            def live_entry(v):
+                if "error" in v:
+                    return {"error": v["error"][:80]}
+                e = {kk: v.get(kk) for kk in ("kernel", "frac", "kernel_ms", "value_MSps")}
+                if "psd" in v:
+                    e["psd_frac"] = v["psd"]["frac"]
+                e["timing"] = "event pairs"
+                rp = v.get("rocprofv3")
+                if rp:
+                    e.update({"frac_event_pairs": e["frac"], "frac": rp["frac"], "kernel_ms": round(rp["kernel_us"] / 1e3, 5), "timing": "rocprofv3 child"})
+                    if "psd_frac" in rp:
+                        e["psd_frac"] = rp["psd_frac"]
+                return e
+            roof_c["live_analyzer"] = {k: live_entry(v) for k, v in live.items()}
         if not fft_bank and fir_ms:
             roof_c["fp32_vector"] = {"peak_tflops": FP32_PEAK_TFLOPS, "frac_as_built": round(fir_flops_built / (fir_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
                                      "frac_survey_8d": round(fir_flops_survey / (fir_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}

@@ -24,6 +24,7 @@ SOURCES = {
     "chan.hip":  ["-ffp-contract=off"],
     "chan_stream.hip": ["-ffp-contract=off"],
     "loops.hip": ["-ffp-contract=off"],
+    "gangs.hip": ["-ffp-contract=off"],
     "specview.hip": ["-ffp-contract=off"],
     "fft.hip": ["-ffp-contract=fast"],
     "psd_large.hip": ["-ffp-contract=fast"],
@@ -42,7 +43,7 @@ SOURCES = {
     "tuning.cpp": ["-ffp-contract=off"],
     "sigutils_host.cpp": ["-ffp-contract=off", "-Wno-return-type-c-linkage"],   # std::complex<float> == float _Complex in the x86-64 ABI
 }
-HEADERS = ["kernels.hpp", "sd_math.hpp", "design.hpp", "fft_core.hpp", "fft_reg.hpp", "tuning.hpp", os.path.join("..", "..", "include", "sigdigger_amd.h"),
+HEADERS = ["kernels.hpp", "sd_math.hpp", "loops_dev.hpp", "design.hpp", "fft_core.hpp", "fft_reg.hpp", "tuning.hpp", os.path.join("..", "..", "include", "sigdigger_amd.h"),
            os.path.join("..", "..", "include", "suscan_amd.h")]
 
 

@@ -182,7 +182,7 @@ struct ClockParams { float alpha, beta, gain, bmin, bmax; };
 hipError_t clock_feed(const ClockParams &p, const ClockState &s, int nchan, const void *x, View xv,
                       long long len, void *sym, long long sym_stride, uint32_t *count, hipStream_t st);
 
-// ---- gangs: many 1-channel banks with their OWN parameters, one lane each, in one launch -------------
+// ---- gangs.hip: many 1-channel banks with their OWN parameters, one lane each, in one launch -------------
 // (the live analyzer's inspectors differ in loop bandwidth, baud, decimation ... and cannot share a bank;
 // a gang runs their recurrences side by side like a bank does).  Rows are contiguous (unit time stride),
 // lengths may differ per item.  items: device array.
