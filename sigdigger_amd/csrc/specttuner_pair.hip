@@ -45,6 +45,9 @@ __device__ __forceinline__ cf xfade_p(float al, cf cur, float be, cf prv)
 }
 
 typedef __attribute__((address_space(1))) cf gcf;
+// the channel table as the compiler may treat it: written by the host before the launch, constant while it runs (loads from
+// the constant address space are not clobbered by the kernel's stores)
+typedef const __attribute__((address_space(4))) sdk::StChan *cchan;
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 constexpr int WAVE = 64;
 constexpr int PW_W = 4096, PW_H = 2048;
@@ -285,11 +288,28 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
     }
     if constexpr (!SEP) alias_barrier();                         // the next window's first swap lands where the staging was read
   };
+  // The residual NCO of a channel opened `precise` (the live analyzer's inspectors are): step and start phase, read ONCE per
+  // window (rot_load, at the head of the channel stage).  Round 6: they used to be read inside emit_one, from plain global
+  // memory -- the compiler, which must assume that an output store may have changed the channel table, re-read n_open before
+  // EVERY store and waited for it with s_waitcnt vmcnt(0): sixteen times per window a wavefront waited for its previous
+  // store to be acknowledged (and for the next window's prefetch).  Held across the whole window loop they would be spilled
+  // (the forward transform leaves no register), hence per window, behind a pointer the optimiser cannot see through.
+  struct RotZ { uint32_t dphase, phase0; bool precise; };
+  RotZ rz[NGW];
+  auto rot_load = [&]() {
+#pragma unroll
+    for (int gl = 0; gl < NGW; ++gl) {
+      const sdk::StChan *q = cdp[gl];
+      asm volatile("" : "+v"(q));
+      const cchan cc = (cchan)q;
+      rz[gl] = RotZ{cc->dphase, (uint32_t)(a.n0 - cc->n_open), cc->precise != 0};
+    }
+  };
   auto emit_one = [&](auto rot, int gl, long long wo, int i, cf o) {
     if constexpr (decltype(rot)::value) {
       const uint32_t m = (uint32_t)((unsigned long long)wo * HS + i);
-      const bool precise = cdp[gl]->precise != 0;
-      const uint32_t dphase = cdp[gl]->dphase, phase0 = (uint32_t)(a.n0 - cdp[gl]->n_open);
+      const bool precise = rz[gl].precise;
+      const uint32_t dphase = rz[gl].dphase, phase0 = rz[gl].phase0;
       float c, s;
       sd::phasor_u32((phase0 + m) * dphase, c, s);
       c = precise ? c : 1.0f;
@@ -426,6 +446,7 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
     TS(6);
     // ---- channel stage: lane = channel ----
     const bool seam = w == w_begin && w_begin > 0;
+    if (any_precise && !seam) rot_load();
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ho + slot * HO, 0, (int)HO * 8, 0x00020000);
     // slot o: this block's sample `cur` and the next block's partner `nx`
     auto slot_done = [&](auto seam_tag, auto rot, int o, cf cur, cf nx) {
@@ -553,6 +574,7 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
   } else if (!self_seam) {
     // the seam block: request register slot_q(o) holds the next run's unweighted sample of slot o
     if constexpr (ROWT) pair_barrier();                          // (the partner may still be reading the last block's staging)
+    if (any_precise) rot_load();
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
       const int i = slot_out(o);
