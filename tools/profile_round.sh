@@ -29,6 +29,17 @@ for lg in 21 22; do LIVE_LOG2=$lg python tools/live_c4.py 2>/dev/null | tail -1;
 for s in 0; do SUAMD_ST_ROW_STAGE=$s LIVE_LOG2=21 python tools/live_c4.py 2>/dev/null | tail -1; done >> $OUT/live_analyzer.txt
 (cd /tmp && LIVE_LOG2=21 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_live -o t -- python $REPO/tools/live_c4.py > /dev/null 2> $OUT/trace_live.err)
 f=$(find $OUT/trace_live -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/live_kernel_stats.csv
+# the same leg with the inspectors as slab columns (default) and as rows (SUAMD_ANALYZER_SLAB=0), 2 Mi and 4 Mi blocks: rate + rocprofv3's kernels
+: > $OUT/live_slab_ab.txt
+for v in 1 0; do for lg in 21 22; do
+  echo "SUAMD_ANALYZER_SLAB=$v block 2^$lg:" >> $OUT/live_slab_ab.txt
+  SUAMD_ANALYZER_SLAB=$v LIVE_LOG2=$lg python tools/live_c4.py 2>/dev/null | tail -1 >> $OUT/live_slab_ab.txt
+  (cd /tmp && SUAMD_ANALYZER_SLAB=$v LIVE_LOG2=$lg LIVE_BLOCKS=16 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_live_${v}_$lg -o t -- python $REPO/tools/live_c4.py > /dev/null 2>> $OUT/trace_live.err)
+  f=$(find $OUT/trace_live_${v}_$lg -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && grep -v "at::native\|rocclr" "$f" | head -30 > profiles/${TAG}_live_slab${v}_block${lg}_kernel_stats.csv
+done; done
+cp $OUT/live_slab_ab.txt profiles/${TAG}_live_slab_ab.txt
+python tools/gang_bench.py > profiles/${TAG}_gang_bench.txt 2>/dev/null
 python tools/st_bench.py > $OUT/kernel_microbench.txt 2>&1
 python tools/fir_bench.py >> $OUT/kernel_microbench.txt 2>&1
 python tools/fir_c1.py >> $OUT/kernel_microbench.txt 2>&1
