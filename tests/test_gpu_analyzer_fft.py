@@ -693,3 +693,79 @@ def test_main_spectrum_of_large_frames_through_the_analyzer(tmp_path, sdo, n):
     got = np.stack(frames)
     err = np.max(np.abs(got - ref), axis=1) / np.max(ref, axis=1)
     assert np.all(err < 1e-5), err
+
+
+def test_the_slab_grows_under_running_inspectors(tmp_path, sdo):
+    """Round 6: the narrow channels of the filter bank are columns of one time-major slab per shard, pitch = the tuner's
+    channel table rounded up to 64.  Sixty narrow raw inspectors (and two wide ones, which keep rows of their own) run
+    when ten more narrow ones are opened: the table passes 64 entries, the slabs are re-allocated at pitch 128 under the
+    running streams -- and every stream, old and new, is the oracle's from its first block to the end of the capture."""
+    nblocks = 12
+    rng = np.random.default_rng(77)
+    narrow_bw = [2.5e3, 5e3, 1.2e3]                                   # D = 128, 64, 256: channels of 32, 64, 16 bins
+    first = [((k - 30) * 15e3 + 1e3, narrow_bw[k % 3]) for k in range(60)] + [(200e3, 40e3), (-150e3, 150e3)]
+    late = [((k - 5) * 23e3 + 4e3, narrow_bw[k % 3]) for k in range(10)]
+    chans = first + late
+    x = synth.psk_carriers(L * nblocks, [0.11, -0.23, 0.37], sps=64, order=4, seed=9, snr_db=25)
+    x = (x + 0.05 * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))).astype(np.complex64)
+    path = tmp_path / "iq.raw"
+    x.tofile(path)
+    Lb, mq, an = _start(path, L)
+    Lb.suscan_analyzer_set_throttle_async(an, 2 * FS, 0)
+
+    def open_(k):
+        # (the late ones are not `precise`: a residual NCO counts from the window its channel was opened at, which this test
+        # does not track -- tests/test_gpu_analyzer_fuzz.py does)
+        fc, bw = chans[k]
+        ch = suscan.Channel(fc=fc, f_lo=fc - bw / 2, f_hi=fc + bw / 2, bw=bw, ft=433.92e6)
+        assert Lb.suscan_analyzer_open_ex_async(an, b"raw", C.byref(ch), int(k % 2 == 0 and k < len(first)), -1, 100 + k)
+
+    for k in range(len(first)):
+        open_(k)
+    st = {"psd": 0, "open_at": {}, "samples": {}, "late_posted": False, "status": []}
+
+    def on_msg(t, ptr):
+        if t == suscan.MSG_PSD:
+            st["psd"] += 1
+            if st["psd"] == 4 and not st["late_posted"]:
+                st["late_posted"] = True
+                for k in range(len(first), len(chans)):
+                    open_(k)
+        elif t in (suscan.MSG_INTERNAL, suscan.MSG_READ_ERROR) and ptr:
+            m = C.cast(ptr, C.POINTER(suscan.StatusMsg)).contents
+            st["status"].append((t, m.code, (m.err_msg or b"").decode("utf-8", "replace")))
+        elif t == suscan.MSG_INSPECTOR:
+            m = C.cast(ptr, C.POINTER(suscan.InspectorMsg)).contents
+            if m.kind == suscan.KIND_OPEN:
+                k = m.req_id - 100
+                st["open_at"][k] = st["psd"]
+                assert Lb.suscan_analyzer_set_inspector_id_async(an, m.handle, 500 + k, 0)
+        elif t == suscan.MSG_SAMPLES:
+            m = C.cast(ptr, C.POINTER(suscan.SampleBatchMsg)).contents
+            a = np.ctypeslib.as_array(m.samples, shape=(m.sample_count * 2,)).copy().view(np.complex64)
+            st["samples"].setdefault(m.inspector_id - 500, []).append(a)
+
+    _pump(Lb, an, on_msg)
+    Lb.suscan_analyzer_destroy(an)
+    Lb.suscan_mq_finalize(C.byref(mq))
+    assert not [s for s in st["status"] if s[0] == suscan.MSG_INTERNAL], st["status"]
+    assert len(st["open_at"]) == len(chans) and st["psd"] == nblocks, (len(st["open_at"]), st["psd"], st["status"])
+    assert min(st["open_at"][k] for k in range(len(first), len(chans))) >= 3, "the late ones were opened under running streams"
+    for k, (fc, bw) in enumerate(chans):
+        D, f0, bwa, guard = _chan_params(fc, bw)
+        assert k in st["samples"], (k, st["status"])
+        got = np.concatenate(st["samples"][k])
+        if k < len(first):
+            _check_raw_channel(sdo, x, got, k, D, f0, bwa, guard, nblocks, max(st["open_at"].values()))
+            continue
+        # a channel opened while the tuner runs starts on the window that straddles the block boundary, with a zero cross-fade
+        # partner: the oracle started half a window before that boundary (and, as above, the first batch or two may have gone
+        # out before the id hand-shake: the tails are compared for each reading of the count)
+        b = nblocks - (got.size // (W // D // 2)) * H // L
+        errs = []
+        for bb in range(min(b + 1, nblocks - 1), max(b - 4, 0), -1):
+            ref = sdo.specttuner_run(x[bb * L - H:], W, f0, bwa, guard, precise=False)
+            n = min(got.size, ref.size)
+            if n > 0.6 * ref.size:
+                errs.append(_relerr(got[-n:], ref[-n:]))
+        assert errs and min(errs) <= TOL, (k, b, got.size, errs)
