@@ -646,6 +646,7 @@ struct suscan_analyzer {
   static constexpr int NSUB = 16;             // at most this many sub-ranges of a block pipelined through those stages
   int nsub = 4;                               // sub-ranges of the block being enqueued (nsub_env, or chosen by the inspector count)
   int nsub_env = 0;                           // SUAMD_ANALYZER_SUBRANGES; 0: automatic
+  bool slab_on = true;                        // tuning().analyzer_slab as it was when the shard started: the narrow channels' layout is one decision per analyzer
   bool trace = false;                         // SUAMD_ANALYZER_TRACE: per-block host timeline on stderr
   double t_chains_done = 0;
   hipEvent_t ev_t0 = nullptr, ev_tfir = nullptr, ev_tpre = nullptr, ev_tdone = nullptr, ev_tstage[3][NSUB] = {};   // timed, trace only
@@ -733,7 +734,7 @@ bool build_chain(suscan_analyzer *a, Inspector &in, std::string &err)
   {
     // narrow channels of the filter bank are columns of the shard's slab (the feed sends every channel of <= 64 bins there);
     // classes whose stages want contiguous rows throughout copy their column out instead of living in it
-    const bool narrow = a->use_fft && sdk::tuning().analyzer_slab != 0 && suamd_specttuner_channel_size(a->st, in.st_chan) <= 64;
+    const bool narrow = a->use_fft && a->slab_on && suamd_specttuner_channel_size(a->st, in.st_chan) <= 64;
     const bool lives = narrow && in.cls != "audio" && in.cls != "power";
     if (lives != in.in_slab) in.free_rows();                 // (rows <-> columns: the other kind of buffers)
     in.in_slab = lives;
@@ -1752,6 +1753,7 @@ bool init_device(suscan_analyzer *a, std::string &err)
   if (ok && hipEventCreateWithFlags(&a->ev_input, hipEventDisableTiming) != hipSuccess) { ok = false; err = "hipEventCreate failed"; }
   a->trace = sdk::tuning().analyzer_trace != 0;
   if (const int v = (int)sdk::tuning().analyzer_subranges; v >= 1 && v <= suscan_analyzer::NSUB) a->nsub = a->nsub_env = v;   // 1 = whole block per stage
+  a->slab_on = sdk::tuning().analyzer_slab != 0;            // (every narrow channel of a tuner goes one way: not re-read while inspectors are open)
   for (int g = 0; ok && g < 3; ++g)
     for (int j = 0; ok && j < suscan_analyzer::NSUB; ++j)
       if (hipEventCreateWithFlags(&a->ev_stage[g][j], hipEventDisableTiming) != hipSuccess) { ok = false; err = "hipEventCreate failed"; }
