@@ -18,6 +18,7 @@
 #undef STW_TSTAMP
 #undef STP_UNSAFE_NO_EXCHANGE
 #undef STP_UNSAFE_NO_ALIAS_BARRIERS
+#undef STP_UNSAFE_NO_STORES
 #endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -321,6 +322,9 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
     } else if constexpr (Y32) {
       const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
           reinterpret_cast<cf *>(a.y) + (long long)((unsigned long long)wo * HS) * yms, 0, 0x7fffffff, 0x00020000);
+#ifdef STP_UNSAFE_NO_STORES
+      if (a.epoch == 0xffffffffu)                              // (never true: the stores stay in the code and move no data -- a timing experiment)
+#endif
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), ry, yvoff[gl], (unsigned)i * yms8, AUX_NT);
     } else if (kbase + group_of(gl) * WAVE < a.nchan) {
       *(gcf *)(ybase[gl] + ((long long)((unsigned long long)wo * HS) + i) * yms) = o;
