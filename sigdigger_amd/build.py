@@ -38,12 +38,14 @@ SOURCES = {
     "ingest.hip": ["-ffp-contract=off"],
     "stages.hip": ["-ffp-contract=off"],
     "capi.hip":  ["-ffp-contract=off"],
+    "capi_gangs.hip":  ["-ffp-contract=off"],
     "analyzer.cpp": ["-ffp-contract=off"],
+    "analyzer_config.cpp": ["-ffp-contract=off"],
     "export.cpp": ["-ffp-contract=off"],
     "tuning.cpp": ["-ffp-contract=off"],
     "sigutils_host.cpp": ["-ffp-contract=off", "-Wno-return-type-c-linkage"],   # std::complex<float> == float _Complex in the x86-64 ABI
 }
-HEADERS = ["kernels.hpp", "sd_math.hpp", "loops_dev.hpp", "design.hpp", "fft_core.hpp", "fft_reg.hpp", "tuning.hpp", os.path.join("..", "..", "include", "sigdigger_amd.h"),
+HEADERS = ["kernels.hpp", "sd_math.hpp", "loops_dev.hpp", "capi_internal.hpp", "analyzer_internal.hpp", "design.hpp", "fft_core.hpp", "fft_reg.hpp", "tuning.hpp", os.path.join("..", "..", "include", "sigdigger_amd.h"),
            os.path.join("..", "..", "include", "suscan_amd.h")]
 
 
