@@ -25,11 +25,17 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/suscan_amd.h"
 #include "analyzer_internal.hpp"
 #include "tuning.hpp"
+
+// a gang call's rows must lie within this many bytes of each other (32-bit lane offsets): one slot's three slabs do, up to here
+#ifndef SUAMD_SLAB_NEAR_BYTES
+#define SUAMD_SLAB_NEAR_BYTES ((size_t)1 << 32)
+#endif
 
 using suan::cfg_get;
 using suan::dupstr;
@@ -1097,9 +1103,27 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
       }
       if (!cb.empty() && !suamd_costas_gang_feed(a->ctx, cb.data(), (unsigned)cb.size(), cx.data(), cy.data(), cl.data(), sC)) fail("carrier control");
       if (!pb.empty() && !suamd_pll_gang_feed(a->ctx, pb.data(), (unsigned)pb.size(), px.data(), py.data(), pl.data(), sC)) fail("carrier control");
-      // (the three complex slabs of a slot are one allocation: whichever of them an item reads and writes, a call's items are near each other)
-      if (!scb.empty() && !suamd_costas_gang_feed_slab(a->ctx, scb.data(), (unsigned)scb.size(), scx.data(), pitch, scy.data(), pitch, scl.data(), sC)) fail("carrier control");
-      if (!spb.empty() && !suamd_pll_gang_feed_slab(a->ctx, spb.data(), (unsigned)spb.size(), spx.data(), pitch, spy.data(), pitch, spl.data(), sC)) fail("carrier control");
+      // (the three complex slabs of a slot are one allocation: whichever of them an item reads and writes, a call's items are
+      // near each other -- while one slab stays below 4 GiB / 3; beyond that the items go out slab pair by slab pair)
+      const size_t slab_bytes = a->slab_rows * a->slab_pitch * sizeof(suamd_complex);
+      const bool by_pair = 3 * slab_bytes >= SUAMD_SLAB_NEAR_BYTES;
+      auto which = [&](const suamd_complex *p) { return p >= sb.z ? 2 : (p >= sb.a ? 1 : 0); };
+      auto gangs_by_pair = [&](auto &banks, auto &xs, auto &ys, auto &ls, auto feed) {
+        if (banks.empty()) return true;
+        if (!by_pair) return feed(banks, xs, ys, ls);
+        bool ok = true;
+        for (int key = 0; key < 9; ++key) {
+          std::remove_reference_t<decltype(banks)> b2; std::remove_reference_t<decltype(xs)> x2; std::remove_reference_t<decltype(ys)> y2; std::remove_reference_t<decltype(ls)> l2;
+          for (size_t q = 0; q < banks.size(); ++q)
+            if (which(xs[q]) * 3 + which(ys[q]) == key) { b2.push_back(banks[q]); x2.push_back(xs[q]); y2.push_back(ys[q]); l2.push_back(ls[q]); }
+          if (!b2.empty()) ok = feed(b2, x2, y2, l2) && ok;
+        }
+        return ok;
+      };
+      if (!gangs_by_pair(scb, scx, scy, scl, [&](auto &b, auto &x, auto &y, auto &l) {
+            return suamd_costas_gang_feed_slab(a->ctx, b.data(), (unsigned)b.size(), x.data(), pitch, y.data(), pitch, l.data(), sC) != SU_FALSE; })) fail("carrier control");
+      if (!gangs_by_pair(spb, spx, spy, spl, [&](auto &b, auto &x, auto &y, auto &l) {
+            return suamd_pll_gang_feed_slab(a->ctx, b.data(), (unsigned)b.size(), x.data(), pitch, y.data(), pitch, l.data(), sC) != SU_FALSE; })) fail("carrier control");
       (void)hipEventRecord(a->ev_stage[1][j], sC);
       if (a->trace) (void)hipEventRecord(a->ev_tstage[1][j], sC);
     }
@@ -1118,7 +1142,16 @@ void enqueue_inspectors_slot(suscan_analyzer *a, size_t len, int slot)
         else if (in.clock) { kb.push_back(in.clock); kx.push_back(rt[i].clk_in + b0); kl.push_back(n); ks.push_back(in.d_sym); kc.push_back(in.d_count); }
       }
       if (!kb.empty() && !suamd_clock_gang_feed(a->ctx, kb.data(), (unsigned)kb.size(), kx.data(), kl.data(), ks.data(), kc.data(), sK)) fail("clock recovery");
-      if (!skb.empty() && !suamd_clock_gang_feed_slab(a->ctx, skb.data(), (unsigned)skb.size(), skx.data(), pitch, skl.data(), sks.data(), skc.data(), sK)) fail("clock recovery");
+      {
+        const size_t slab_bytes = a->slab_rows * a->slab_pitch * sizeof(suamd_complex);
+        const bool by_slab = 3 * slab_bytes >= SUAMD_SLAB_NEAR_BYTES;    // (as for the carrier gangs: inputs from one slab per call then)
+        for (int key = 0; key < (by_slab ? 3 : 1) && !skb.empty(); ++key) {
+          std::vector<suamd_clock_bank_t *> b2; std::vector<const suamd_complex *> x2; std::vector<SUSCOUNT> l2; std::vector<suamd_complex *> s2; std::vector<uint32_t *> c2;
+          for (size_t q = 0; q < skb.size(); ++q)
+            if (!by_slab || (skx[q] >= sb.z ? 2 : (skx[q] >= sb.a ? 1 : 0)) == key) { b2.push_back(skb[q]); x2.push_back(skx[q]); l2.push_back(skl[q]); s2.push_back(sks[q]); c2.push_back(skc[q]); }
+          if (!b2.empty() && !suamd_clock_gang_feed_slab(a->ctx, b2.data(), (unsigned)b2.size(), x2.data(), pitch, l2.data(), s2.data(), c2.data(), sK)) fail("clock recovery");
+        }
+      }
       (void)hipEventRecord(a->ev_stage[2][j], sK);
       if (a->trace) (void)hipEventRecord(a->ev_tstage[2][j], sK);
     }
