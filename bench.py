@@ -973,6 +973,37 @@ def _r(v, n=4):
     return round(v, n) if isinstance(v, float) else v
 
 
+LINE_LIMIT = 4096
+
+
+def compact_line(out, limit=LINE_LIMIT):
+    """The ONE line the driver parses (the last line that starts with "{"; round 5's 23 KB line was not parsed): under
+    `limit` bytes whatever the run added.  A line that would be longer loses its secondary objects one at a time, least
+    important first (they are all in the detail file) -- never the contract fields, `roofline`'s core or `cpu_baseline`."""
+    out = json.loads(json.dumps(out))                         # (a deep copy: the detail file keeps the long form)
+    drop = [("multi_gpu", "ranks"), ("other_workloads",), ("live_sharded_analyzer",), ("roofline", "live_analyzer"), ("roofline", "psd"),
+            ("multi_gpu",), ("roofline", "traffic_source"), ("roofline", "timing"), ("stage_ms",), ("cpu_baseline", "sample"),
+            ("config", "symbol_clocks"), ("config", "schedule"), ("roofline", "fp32_vector")]
+    line = json.dumps(out, separators=(",", ":"))
+    dropped = []
+    for path in drop:
+        if len(line) < limit:
+            break
+        o = out
+        for k in path[:-1]:
+            o = o.get(k) if isinstance(o, dict) else None
+        if isinstance(o, dict) and path[-1] in o:
+            del o[path[-1]]
+            dropped.append(".".join(path))
+            out["dropped_for_length"] = dropped
+            line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= limit:                                    # (cannot happen with the fields above gone: long strings cut as a last resort)
+        def cut(o):
+            return {k: cut(v) for k, v in o.items()} if isinstance(o, dict) else (o[:60] if isinstance(o, str) else o)
+        line = json.dumps(cut(out), separators=(",", ":"))
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1289,10 +1320,7 @@ def main():
             out["detail_file"] = None
             print(f"# bench.py: detail file not written: {e}", file=sys.stderr)
         assert out["n_gpus"] == args.gpus == world, (out["n_gpus"], args.gpus, world)
-        line = json.dumps(out, separators=(",", ":"))
-        # ONE compact line (the driver parses the last line that starts with "{"; round 5's 23 KB line was not parsed)
-        assert len(line) < 4096, len(line)
-        print(line, flush=True)
+        print(compact_line(out), flush=True)
 
     if dist is not None:
         dist.barrier()
