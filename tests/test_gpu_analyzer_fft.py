@@ -60,7 +60,7 @@ def _real_gpus():
     return torch.cuda.device_count()
 
 
-@pytest.mark.parametrize("devices", [None, "0,0", "0,0,0", "0,0,0:rccl-standin", "0,1:rccl"])
+@pytest.mark.parametrize("devices", [None, "0,0", "0,0,0", "0,0,0:rccl-standin", "0,0:rccl-real-refuses", "0,1:rccl"])
 def test_raw_inspectors_share_one_forward_fft_and_match_the_oracle(tmp_path, sdo, monkeypatch, devices):
     """devices: SUAMD_DEVICES.  "0,0" / "0,0,0" run two / three GPU shards (csrc/analyzer.cpp: BlockBus) on the one GPU of
     the test box: inspector handle h lives on shard h mod G, every shard gets every block from shard 0's pinned buffer
@@ -68,8 +68,17 @@ def test_raw_inspectors_share_one_forward_fft_and_match_the_oracle(tmp_path, sdo
     ":rccl-standin": the block reaches the shards through the analyzer's RCCL branch (SUAMD_ANALYZER_BCAST=rccl: one
     ncclBroadcast per block rooted at shard 0) served by tests/rccl_standin.cpp on the one device -- setup_rccl, the
     root's call and the shards' matching calls all execute; "0,1:rccl": the real librccl over two real GPUs (skipped
-    on a one-GPU box)."""
+    on a one-GPU box); "0,0:rccl-real-refuses": the REAL librccl is loaded and asked for two ranks on the one device, which it
+    refuses (ncclCommInitAll fails) -- the analyzer says so and the blocks travel as per-GPU host copies: the dlopen, the
+    symbol lookups and the refusal path run against the library the production box has."""
     standin = None
+    refuses = False
+    if devices and devices.endswith(":rccl-real-refuses"):
+        devices = devices.split(":")[0]
+        refuses = True
+        monkeypatch.delenv("SUAMD_RCCL_LIB", raising=False)
+        monkeypatch.setenv("SUAMD_RCCL_ALLOW_SAME_DEVICE", "1")
+        monkeypatch.setenv("SUAMD_ANALYZER_BCAST", "rccl")
     if devices and devices.endswith(":rccl-standin"):
         devices = devices.split(":")[0]
         so = _build_rccl_standin(tmp_path)
@@ -132,6 +141,8 @@ def test_raw_inspectors_share_one_forward_fft_and_match_the_oracle(tmp_path, sdo
     Lb.suscan_analyzer_destroy(an)
     Lb.suscan_mq_finalize(C.byref(mq))
     assert len(st["open_at"]) == len(chans) and st["psd"] == nblocks, (st["open_at"], st["psd"], st["status"])   # one PSD stream whatever the shard count
+    if refuses:
+        assert any("ncclCommInitAll failed" in m for _, _, m in st["status"]), st["status"]
     if standin is not None:
         # every block went out as ONE broadcast of the block's bytes, rooted at shard 0
         assert standin.standin_broadcasts() == nblocks and standin.standin_bytes() == nblocks * L * 8
