@@ -343,6 +343,50 @@ def test_blocks_that_are_not_whole_half_windows_fall_back_to_the_fir_channeliser
     assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+@pytest.mark.parametrize("n", [512, 1024, 4096, 16384])
+def test_channel_detector_noise_floor_is_the_exact_median_and_the_walk_equals_the_oracle(sdo, ctx, n):
+    """chandet.hip: the noise floor is the element of rank n / 2 -- a radix SELECT on the device, a sort in the oracle and in
+    numpy: the same element whatever the values look like (ties, one value only, few distinct values, forty decades of
+    dynamic range, negative numbers and zeros, which a power spectrum never has); and the channel walk, which reads the
+    spectrum from LDS, gives the oracle's records bit for bit at the smallest and the largest size"""
+    import torch
+    from sigdigger_amd import engine
+    rng = np.random.default_rng(n)
+    cases = {
+        "chi2": (rng.chisquare(8, n) / 8).astype(np.float32),
+        "ties": rng.integers(0, 4, n).astype(np.float32),
+        "one value": np.full(n, 0.25, np.float32),
+        "two values": np.where(np.arange(n) % 2 == 0, 1.0, 2.0).astype(np.float32),
+        "decades": (10.0 ** rng.uniform(-30, 30, n)).astype(np.float32),
+        "signed": np.concatenate([rng.standard_normal(n - 8), np.zeros(8)]).astype(np.float32),
+        "sorted": np.arange(n, dtype=np.float32),
+        "reversed": np.arange(n, 0, -1).astype(np.float32),
+    }
+    for name, P in cases.items():
+        det = engine.ChannelDetector(ctx, n, alpha=0.2, beta=0.0, gamma=0.5, snr=4.0)
+        det.feed(torch.from_numpy(P).cuda())
+        want = np.sort(P)[n // 2]
+        got = np.float32(det.noise_floor())
+        assert got.view(np.uint32) == want.view(np.uint32) or (got == want == 0), (name, got, want)
+    # several updates: the smoothed floor and the records against the oracle object
+    det = engine.ChannelDetector(ctx, n, alpha=0.2, beta=0.0, gamma=0.5, snr=4.0)
+    ora = sdo.ChannelDetector(n, 0.2, 0.5, 4.0)
+    base = np.full(n, 1e-3, np.float32)
+    for lo, hi, lvl in ((n // 16, n // 16 + n // 64, 0.05), (n // 4, n // 4 + 3, 0.2), (n // 2 - 5, n // 2 + 9, 0.01), (n - n // 8, n - n // 8 + 1, 1.0),
+                        (n - n // 16, n - 1, 0.004), (0, 6, 0.3)):
+        base[lo:hi] += lvl
+    for k in range(4):
+        P = np.roll((base * rng.chisquare(8, n).astype(np.float32) / 8).astype(np.float32), n // 2)
+        det.feed(torch.from_numpy(P).cuda())
+        ora.feed(P)
+        assert det.noise_floor() == np.float32(ora.N0), k
+    got, ref = det.channels(1e6), ora.find()
+    assert len(got) == len(ref) >= 4
+    df = 1e6 / n
+    for g, (first, last, width, peak, s_, ws) in zip(got, ref):
+        assert g["f_lo"] == (first - n / 2 - 0.5) * df and g["f_hi"] == (last - n / 2 + 0.5) * df and g["fc"] == (ws / s_ - n / 2) * df
+
+
 def test_channel_detector_bit_exact_and_channel_messages(tmp_path, sdo, ctx):
     """Row N1: su_channel_detector on the device -- (a) the object against the oracle on the same frames: smoothed spectrum,
     noise floor and every channel record bit for bit; (b) the analyzer's CHANNEL messages find the carriers of a capture."""
