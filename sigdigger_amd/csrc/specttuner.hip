@@ -332,6 +332,13 @@ hipError_t launch_st(const sdk::StArgs &a, hipStream_t st)
   if constexpr (LOG2S >= 7 && LOG2S <= 11) {
     if (sdk::st_two_turns(LOG2S, a.nchan)) return launch_st_v<LOG2W, LOG2S, 2, true, 2>(a, st);
   }
+  // Banks of ONE channel group of 256- or 2048-bin channels run without the next window's prefetch (same arithmetic, same
+  // bits): measured per size, same box, alternating (round 6; 4 Mi / 16 Mi samples): 1 x 256 bins 43.8 -> 40.4 / 131 -> 125 us
+  // (C2's FFT variant), 16 x 256 51.9 -> 47.8 / 143.6 -> 139.7, 1 x 2048 50.0 -> 45.8 / 145 -> 136; 128-, 512-, 1024- and
+  // 4096-bin channels keep it (1 x 128: 122.9 with, 127.1 without per 16 Mi).  Four workgroups per CU WITH the prefetch spills (59 us).
+  if constexpr (LOG2S == 8 || LOG2S == 11) {
+    if (a.nchan <= sdk::st_channels_per_group(LOG2S)) return launch_st_v<LOG2W, LOG2S, 3, false, 1>(a, st);
+  }
   return launch_st_v<LOG2W, LOG2S, 3, true, 1>(a, st);
 }
 
