@@ -62,11 +62,15 @@ constexpr int PW_MAXSEL = 12;                                  // 64-bin tables 
 constexpr int PW_EX = 1024;                                    // elements of one direction of a mid-DFT swap (16 x 64)
 constexpr int AUX_NT = 2;
 constexpr int AUX_SC1 = 16;
-// The first half of a window is the half the run's previous window requested as its second: its last use.  Marked
-// non-temporal, a hit does not renew the line -- the L2 (4 MiB per XCD, about what an XCD's 128 workgroups stream per
-// window) keeps the second halves, which ARE used again, one window longer.
+// The first half of a window is the half the run's previous window requested as its second: its last use.  Requested
+// non-temporal (-DSTP_FIRST_HALF_AUX=2: a hit does not renew the line, the L2 -- 4 MiB per XCD, about what an XCD's 128
+// workgroups stream per window -- keeps the second halves, which ARE used again, one window longer) the kernel moves the bytes
+// its run structure gives by construction: FETCH_SIZE 80.7 MiB per 16 Mi block against 100.1 with the default policy
+// (traffic 1.19 x against 1.34 x of the algorithmic bytes) -- and takes LONGER: 80.4 against 78.6 us (rocprofv3, same box,
+// alternating, twice; sc0 | nt: 80.4, sc0: 78.6).  HBM traffic is not what bounds this kernel, the non-temporal requests
+// cost more than the re-reads they save: the default policy is the default again (it was non-temporal for most of round 6).
 #ifndef STP_FIRST_HALF_AUX
-#define STP_FIRST_HALF_AUX AUX_NT
+#define STP_FIRST_HALF_AUX 0
 #endif
 
 #ifdef STW_TSTAMP
