@@ -126,6 +126,7 @@ struct StArgs {
   unsigned long long n0;        // outputs per channel emitted by earlier feeds (phase of the residual NCO)
   void *y; View yv;
   const void *const *rows;      // when set: channel `row`'s samples of this feed start at rows[row] (unit time stride), y / yv.cs unused
+  int any_precise;              // two-wavefront kernel: 0 promises that no channel of the launch is precise, 2 that all are (instantiations with one form of the channel stage only), 1: some
 };
 // channels one workgroup serves side by side for inverse transforms of 2^log2s points
 int st_channels_per_group(int log2s);

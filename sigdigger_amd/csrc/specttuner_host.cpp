@@ -157,6 +157,7 @@ struct SizeGroup {
   size_t seam_elems = 0;
   unsigned epoch = 0;                  // flag value of the next launch
   bool hk_uniform = false;             // one response for all members
+  bool any_precise = false, all_precise = false;   // some / every member was opened `precise` (residual NCO on its outputs)
   int nsel = 0;                        // distinct responses of the members (tables in d_hk)
   float *d_win = nullptr;
   c32 *d_prev[2] = {nullptr, nullptr};
@@ -308,6 +309,8 @@ bool rebuild_group(suamd_specttuner *st, SizeGroup &g, const std::vector<int> &o
   std::vector<c32> hk;
   for (unsigned hw : halfws) { std::vector<c32> h = design_response(st->W, S, hw); hk.insert(hk.end(), h.begin(), h.end()); }
   g.hk_uniform = halfws.size() == 1;
+  g.any_precise = false; g.all_precise = !tab.empty();
+  for (const sdk::StChan &c : tab) { g.any_precise |= c.precise != 0; g.all_precise &= c.precise != 0; }
   g.nsel = (int)halfws.size();
   if (g.d_chans) (void)hipFree(g.d_chans);
   if (g.d_hk) (void)hipFree(g.d_hk);
@@ -587,6 +590,7 @@ static SUBOOL st_feed(suamd_specttuner_t *st, const suamd_complex *d_x, SUSCOUNT
           if (g.hkt_blocks < (g.members.size() + cpw - 1) / cpw * (cpw / 64)) { suamd_set_error("internal: response table smaller than the launch"); return SU_FALSE; }
         }
         a.hk_uniform = g.hk_uniform ? 1 : 0;
+        a.any_precise = !g.any_precise ? 0 : g.all_precise ? 2 : 1;
         a.nsel = g.nsel;
         {
           // 32-bit buffer addressing of the outputs when the whole view of this feed lies below 2 GiB

@@ -160,7 +160,11 @@ __device__ __forceinline__ void dft64_pair(const cf *in, cf *out, cf *ex, int t,
 // inspector -- through a transposition in LDS.  Lane = channel means a store instruction touches 64 rows with 8 bytes each:
 // 118 us per 2 Mi-sample block in the 64-inspector analyzer (rocprofv3, round 6) against 17 for time-major output.  Staged,
 // a block's 64 x 32 outputs leave as 16-byte pieces, sixteen lanes covering 256 contiguous bytes of a row.
-template <int P, int LOG2S, bool Y32, bool SEP, bool ROWT>
+// ROTCAP: which channels of the launch are precise (residual NCO on the outputs) -- 0: none, 2: all, 1: some (each wavefront
+// looks at its own lanes).  0 and 2 leave the other form of the channel stage out of the kernel altogether: merely present --
+// never executed -- the residual-NCO code cost a bank without precise channels 1.8 us per 16 Mi block (78.6 -> 76.8 us,
+// same-box A / B, three times in turn, round 6: code size and register allocation of the common path).
+template <int P, int LOG2S, bool Y32, bool SEP, bool ROWT, int ROTCAP>
 __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const int t)
 {
   static_assert(!ROWT || (LOG2S == 6 && Y32), "row-transposed stores: 64-bin channels, 32-bit offsets");
@@ -258,7 +262,7 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
   int center[NGW];
   cf *ybase[NGW];
   unsigned yvoff[NGW];
-  bool any_precise = false;
+  bool any_precise = ROTCAP == 2;
 #pragma unroll
   for (int gl = 0; gl < NGW; ++gl) {
     const int kk = kbase + group_of(gl) * WAVE;
@@ -269,7 +273,7 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
     // (Y32 with a row table: the caller has promised every row within 2 GiB of a.y -- offsets from there)
     yvoff[gl] = kk >= a.nchan ? 0x80000000u : a.rows ? (unsigned)(reinterpret_cast<const char *>(a.rows[row]) - reinterpret_cast<const char *>(a.y))
                                                       : (unsigned)((long long)row * a.yv.cs * 8);
-    any_precise |= __builtin_amdgcn_ballot_w64(cdp[gl]->precise != 0) != 0;
+    if constexpr (ROTCAP == 1) any_precise |= __builtin_amdgcn_ballot_w64(cdp[gl]->precise != 0) != 0;
   }
   const long long yms = a.rows ? 1 : a.yv.ms;
   const unsigned yms8 = (unsigned)(yms * 8);
@@ -454,7 +458,7 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
     TS(6);
     // ---- channel stage: lane = channel ----
     const bool seam = w == w_begin && w_begin > 0;
-    if (any_precise && !seam) rot_load();
+    if constexpr (ROTCAP != 0) { if (any_precise && !seam) rot_load(); }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ho + slot * HO, 0, (int)HO * 8, 0x00020000);
     // slot o: this block's sample `cur` and the next block's partner `nx`
     auto slot_done = [&](auto seam_tag, auto rot, int o, cf cur, cf nx) {
@@ -513,7 +517,9 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
         }
       };
       if (seam) chan_out(std::true_type{}, std::false_type{});
-      else if (any_precise) chan_out(std::false_type{}, std::true_type{});
+      else if constexpr (ROTCAP == 2) chan_out(std::false_type{}, std::true_type{});
+      else if constexpr (ROTCAP == 0) chan_out(std::false_type{}, std::false_type{});
+      else if (any_precise) chan_out(std::false_type{}, std::bool_constant<ROTCAP != 0>{});
       else chan_out(std::false_type{}, std::false_type{});
       if constexpr (ROWT) { if (!seam) stage_flush(w); }
     } else {
@@ -552,7 +558,9 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
         }
       };
       if (seam) chan_out(std::true_type{}, std::false_type{});
-      else if (any_precise) chan_out(std::false_type{}, std::true_type{});
+      else if constexpr (ROTCAP == 2) chan_out(std::false_type{}, std::true_type{});
+      else if constexpr (ROTCAP == 0) chan_out(std::false_type{}, std::false_type{});
+      else if (any_precise) chan_out(std::false_type{}, std::bool_constant<ROTCAP != 0>{});
       else chan_out(std::false_type{}, std::false_type{});
       // both wavefronts are through with the spectrum before the next window's first swap lands in it
       if constexpr (!SEP) alias_barrier();
@@ -582,12 +590,14 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
   } else if (!self_seam) {
     // the seam block: request register slot_q(o) holds the next run's unweighted sample of slot o
     if constexpr (ROWT) pair_barrier();                          // (the partner may still be reading the last block's staging)
-    if (any_precise) rot_load();
+    if constexpr (ROTCAP != 0) { if (any_precise) rot_load(); }
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
       const int i = slot_out(o);
       const cf v = xfade_p(kWinP[i * WS], nxt[slot_q(o)], kWinP[(i + HS) * WS], prev[o]);
-      if (any_precise) emit_one(std::true_type{}, slot_group(o), w_end, i, v);
+      if constexpr (ROTCAP == 2) emit_one(std::true_type{}, slot_group(o), w_end, i, v);
+      else if constexpr (ROTCAP == 0) emit_one(std::false_type{}, slot_group(o), w_end, i, v);
+      else if (any_precise) emit_one(std::bool_constant<ROTCAP != 0>{}, slot_group(o), w_end, i, v);
       else emit_one(std::false_type{}, slot_group(o), w_end, i, v);
     }
     if constexpr (ROWT) stage_flush(w_end);
@@ -598,15 +608,15 @@ __device__ __forceinline__ void stp_body(const sdk::StArgs &a, cf *buf, const in
 #endif
 }
 
-template <int LOG2S, bool Y32, bool SEP, bool ROWT = false>
+template <int LOG2S, bool Y32, bool SEP, bool ROWT = false, int ROTCAP = 1>
 __global__ __launch_bounds__(2 * WAVE, 2) void stp_kernel(sdk::StArgs a)
 {
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf *buf = reinterpret_cast<cf *>(smem);
   const int t = threadIdx.x & (WAVE - 1);
-  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0) stp_body<0, LOG2S, Y32, SEP, ROWT>(a, buf, t);
-  else stp_body<1, LOG2S, Y32, SEP, ROWT>(a, buf, t);
+  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0) stp_body<0, LOG2S, Y32, SEP, ROWT, ROTCAP>(a, buf, t);
+  else stp_body<1, LOG2S, Y32, SEP, ROWT, ROTCAP>(a, buf, t);
 }
 
 template <int LOG2S>
@@ -632,7 +642,11 @@ hipError_t launch_stp(const sdk::StArgs &a, hipStream_t st)
   if constexpr (LOG2S == 6) {
     if (rowt) { if (sep) go(stp_kernel<LOG2S, true, true, true>); else go(stp_kernel<LOG2S, true, false, true>); return hipGetLastError(); }
   }
-  if (sep) { if (a.y32) go(stp_kernel<LOG2S, true, true>); else go(stp_kernel<LOG2S, false, true>); }
+  // (32-bit offsets -- every bank of the harness and of the analyzer's slabs -- come in the three forms of ROTCAP; the 64-bit
+  // form, a fallback for outputs beyond 2 GiB, and the per-channel rows only in the general one)
+  if (a.y32 && a.any_precise == 0) { if (sep) go(stp_kernel<LOG2S, true, true, false, 0>); else go(stp_kernel<LOG2S, true, false, false, 0>); }
+  else if (a.y32 && a.any_precise == 2) { if (sep) go(stp_kernel<LOG2S, true, true, false, 2>); else go(stp_kernel<LOG2S, true, false, false, 2>); }
+  else if (sep) { if (a.y32) go(stp_kernel<LOG2S, true, true>); else go(stp_kernel<LOG2S, false, true>); }
   else { if (a.y32) go(stp_kernel<LOG2S, true, false>); else go(stp_kernel<LOG2S, false, false>); }
   return hipGetLastError();
 }
