@@ -85,7 +85,10 @@ constexpr bool EARLY_LDS = STW_EARLY_LDS != 0;                 // transposition 
 constexpr int AUX_NT = 2;                                      // nt: the outputs are written once and not read back here (64 ch x 4 Mi: 36.1 -> 34.4 us)
 constexpr int AUX_SC1 = 16;                                    // cache-policy bit of the raw buffer builtins: sc1 (agent scope)
 
-template <int LOG2S, bool UNIFORM, bool Y32>
+// ROTCAP: which channels of the launch are precise -- 0 none, 2 all, 1 some (specttuner_pair.hip: the forms that carry ONE form of
+// the channel stage; here the whole stage -- bins, response, inverse transform, outputs -- is in each form, and the kernel with all
+// three is 76 - 86 KB of code for a 64 KB instruction cache)
+template <int LOG2S, bool UNIFORM, bool Y32, int ROTCAP>
 __global__ __launch_bounds__(WAVE * STW_WPB, 1) void stw_kernel(sdk::StArgs a)
 {
 #ifdef STW_TSTAMP
@@ -207,9 +210,11 @@ __global__ __launch_bounds__(WAVE * STW_WPB, 1) void stw_kernel(sdk::StArgs a)
   // store is a buffer store: wave-uniform descriptor (the block's first instant) + the lane's offset + a scalar i * stride
   // Y32: host-checked, every byte offset of the view fits 31 bits.  `rot`: some lane of this wavefront has a residual NCO
   // (then every lane rotates, the others by exactly 1 + 0j: no divergent branch per sample)
-  bool any_precise = false;
+  bool any_precise = ROTCAP == 2;
+  if constexpr (ROTCAP == 1) {
 #pragma unroll
-  for (int g = 0; g < NG; ++g) any_precise |= __builtin_amdgcn_ballot_w64(precise[g]) != 0;
+    for (int g = 0; g < NG; ++g) any_precise |= __builtin_amdgcn_ballot_w64(precise[g]) != 0;
+  }
   auto emit_one = [&](auto rot, int g, long long wo, int i, cf o) {
     if constexpr (decltype(rot)::value) {
       const uint32_t m = (uint32_t)((unsigned long long)wo * HS + i);
@@ -446,7 +451,9 @@ __global__ __launch_bounds__(WAVE * STW_WPB, 1) void stw_kernel(sdk::StArgs a)
     }
     };
     if (seam) chan(std::true_type{}, std::false_type{});
-    else if (any_precise) chan(std::false_type{}, std::true_type{});
+    else if constexpr (ROTCAP == 2) chan(std::false_type{}, std::true_type{});
+    else if constexpr (ROTCAP == 0) chan(std::false_type{}, std::false_type{});
+    else if (any_precise) chan(std::false_type{}, std::bool_constant<ROTCAP != 0>{});
     else chan(std::false_type{}, std::false_type{});
     if (seam) publish = true;                                  // the flag follows once the stores have drained (next window's top)
     if (single && !final_run && w + 1 == w_end) {
@@ -492,7 +499,9 @@ __global__ __launch_bounds__(WAVE * STW_WPB, 1) void stw_kernel(sdk::StArgs a)
       for (int i = 0; i < HS; ++i) {
         constexpr int ws = 64 / S;
         const cf o = xfade(kWin64[i * ws], nxt[g * HS + i], kWin64[(i + HS) * ws], prev[g][i]);
-        if (any_precise) emit_one(std::true_type{}, g, w_end, i, o);
+        if constexpr (ROTCAP == 2) emit_one(std::true_type{}, g, w_end, i, o);
+        else if constexpr (ROTCAP == 0) emit_one(std::false_type{}, g, w_end, i, o);
+        else if (any_precise) emit_one(std::bool_constant<ROTCAP != 0>{}, g, w_end, i, o);
         else emit_one(std::false_type{}, g, w_end, i, o);
       }
     }
@@ -503,11 +512,11 @@ __global__ __launch_bounds__(WAVE * STW_WPB, 1) void stw_kernel(sdk::StArgs a)
 #endif
 }
 
-template <int LOG2S, bool UNIFORM, bool Y32>
+template <int LOG2S, bool UNIFORM, bool Y32, int ROTCAP>
 hipError_t launch_stw_u(const sdk::StArgs &a, hipStream_t st)
 {
   constexpr int NG = WAVE >> LOG2S;
-  auto kern = stw_kernel<LOG2S, UNIFORM, Y32>;
+  auto kern = stw_kernel<LOG2S, UNIFORM, Y32, ROTCAP>;
   const unsigned nruns = (unsigned)((a.nwin + a.run - 1) / a.run);
   const unsigned ny = (unsigned)((a.nchan + NG * WAVE - 1) / (NG * WAVE));
   if constexpr (WV_LDS * STW_WPB > 65536) {
@@ -521,8 +530,11 @@ hipError_t launch_stw_u(const sdk::StArgs &a, hipStream_t st)
 template <int LOG2S>
 hipError_t launch_stw(const sdk::StArgs &a, hipStream_t st)
 {
-  if (a.y32) return a.hk_uniform ? launch_stw_u<LOG2S, true, true>(a, st) : launch_stw_u<LOG2S, false, true>(a, st);
-  return a.hk_uniform ? launch_stw_u<LOG2S, true, false>(a, st) : launch_stw_u<LOG2S, false, false>(a, st);
+  // (32-bit offsets come in the three forms of ROTCAP; the 64-bit fallback in the general one)
+  if (a.y32 && a.any_precise == 0) return a.hk_uniform ? launch_stw_u<LOG2S, true, true, 0>(a, st) : launch_stw_u<LOG2S, false, true, 0>(a, st);
+  if (a.y32 && a.any_precise == 2) return a.hk_uniform ? launch_stw_u<LOG2S, true, true, 2>(a, st) : launch_stw_u<LOG2S, false, true, 2>(a, st);
+  if (a.y32) return a.hk_uniform ? launch_stw_u<LOG2S, true, true, 1>(a, st) : launch_stw_u<LOG2S, false, true, 1>(a, st);
+  return a.hk_uniform ? launch_stw_u<LOG2S, true, false, 1>(a, st) : launch_stw_u<LOG2S, false, false, 1>(a, st);
 }
 
 }  // namespace
