@@ -99,6 +99,17 @@ __device__ __forceinline__ v2f_ mix_conj(v2f_ x, v2f_ cs)
   return m;
 }
 
+// x * ref, ref = (cos, sin):  re = fma(x.re, cos, -(x.im * sin)),  im = fma(x.re, sin, x.im * cos) -- the residual NCO of a
+// precise channel (SPEC.md C2) -- as two VOP3P instructions, one statement (no s_nop between them)
+__device__ __forceinline__ v2f_ mix_rot(v2f_ x, v2f_ cs)
+{
+  v2f_ t, m;
+  asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"                              // (x.im sin, x.im cos)
+      "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"            // (x.re cos - t.lo, x.re sin + t.hi)
+      : "=&v"(t), "=&v"(m) : "v"(x), "v"(cs));
+  return m;
+}
+
 // D2: atan2 (radians), Cephes atanf kernel on min/max.
 SD_HD float atan2_(float y, float x)
 {

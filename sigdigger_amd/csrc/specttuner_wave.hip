@@ -218,11 +218,9 @@ __global__ __launch_bounds__(WAVE * STW_WPB, 1) void stw_kernel(sdk::StArgs a)
   auto emit_one = [&](auto rot, int g, long long wo, int i, cf o) {
     if constexpr (decltype(rot)::value) {
       const uint32_t m = (uint32_t)((unsigned long long)wo * HS + i);
-      float c, s;
-      sd::phasor_u32((phase0[g] + m) * dphase[g], c, s);
-      c = precise[g] ? c : 1.0f;
-      s = precise[g] ? s : 0.0f;
-      o = cf{__builtin_fmaf(o.x, c, -(o.y * s)), __builtin_fmaf(o.x, s, o.y * c)};   // one rounding pattern at every call site
+      sd::v2f_ cs = sd::phasor_pk((phase0[g] + m) * dphase[g]);          // (packed: specttuner_pair.hip's emit_one)
+      if constexpr (ROTCAP != 2) { cs.x = precise[g] ? cs.x : 1.0f; cs.y = precise[g] ? cs.y : 0.0f; }
+      o = sd::mix_rot(o, cs);                                            // one rounding pattern at every call site
     }
     if constexpr (Y32) {
       const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
