@@ -277,6 +277,48 @@ def test_a_mixed_bank_equals_the_binary32_statement_bit_for_bit(ctx, sdo):
         assert np.array_equal(_bits(got[k]), _bits(ref[k])), k
 
 
+@pytest.mark.parametrize("kernel", ["pair", "wave"])
+def test_the_bank_changes_between_no_some_and_all_precise_channels(ctx, sdo, tune, kernel):
+    """The narrow-channel kernels come in three forms by which channels of a launch are precise (none / some / all: the host's
+    flag per size group, csrc/specttuner_pair.hip ROTCAP).  One tuner whose bank goes none -> some -> all -> none between feeds:
+    every channel's stream equals the oracle's for a channel opened where it was opened (a channel that opens mid-stream
+    sees the half window before its first feed as history: a fresh oracle started one half window earlier)."""
+    tune.setenv("st_kernel", 0 if kernel == "pair" else 1)
+    x = cnoise(H * 26, 77)
+    bw = 2 * np.pi / 64 * 0.8
+    dx = torch.from_numpy(x).cuda()
+    st = engine.SpectTuner(ctx, W)
+    cuts = [0, H * 6, H * 12, H * 19, H * 26]
+    got = {}
+
+    def feed(k, live):
+        out, cnt = st.feed(dx[cuts[k]:cuts[k + 1]])
+        torch.cuda.synchronize()
+        for name, idx in live.items():
+            got.setdefault(name, []).append(out[idx, :cnt[idx]].cpu().numpy())
+
+    a = st.open_channel(1.0, bw, precise=False)
+    a2 = st.open_channel(2.2, bw * 0.7, precise=False)
+    feed(0, {"a": a, "a2": a2})                                     # no precise channel
+    b = st.open_channel(3.0, bw, precise=True)
+    feed(1, {"a": a, "a2": a2, "b": b})                             # some
+    st.close_channel(a); st.close_channel(a2)
+    b2 = st.open_channel(4.1, bw * 0.6, precise=True)
+    feed(2, {"b": b, "b2": b2})                                     # all
+    st.close_channel(b); st.close_channel(b2)
+    c = st.open_channel(5.0, bw, precise=False)
+    feed(3, {"c": c})                                               # none again
+    st.close()
+    want = {"a": (0, cuts[2], 1.0, bw, False), "a2": (0, cuts[2], 2.2, bw * 0.7, False),
+            "b": (cuts[1] - H, cuts[3], 3.0, bw, True), "b2": (cuts[2] - H, cuts[3], 4.1, bw * 0.6, True),
+            "c": (cuts[3] - H, cuts[4], 5.0, bw, False)}
+    for name, (lo, hi, f0, w_, precise) in want.items():
+        ref = sdo.specttuner_run_f32(x[lo:hi], f0, w_, 1.0, precise)
+        g = np.concatenate(got[name])
+        assert g.size == ref.size, (name, g.size, ref.size)
+        assert np.array_equal(_bits(g), _bits(ref)), name
+
+
 def test_full_size_block_all_64_channels_equal_the_binary32_statement(ctx, sdo):
     """BASELINE's C4 slice as the bench builds it: 4 Mi samples, 64 channels of 64 bins on the 90 kHz raster, time-major
     rows -- ALL 64 rows against the oracle, bit for bit (the oracle transforms the 2047 windows on the host's cores)"""
